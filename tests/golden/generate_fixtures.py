@@ -1,0 +1,480 @@
+"""Golden-vector generator: runs the REAL reference (imported unmodified from
+``/root/reference``) on small seeded inputs and stores inputs + outputs as
+``.npz`` fixtures next to this file.
+
+Runs only in the build container (``/root/reference`` does not exist on the GPU
+box). The three third-party packages the reference imports but this image lacks
+(``tensordict``, ``torchrl``, ``mlflow``) are provided by ``_stubs/`` -- containers
+and no-op tracking only, no arithmetic (see ``_stubs/README.md``).
+
+Usage::
+
+    python tests/golden/generate_fixtures.py
+
+Every fixture is data (inputs and expected outputs); no reference source text is
+stored. Reference call sites are cited per fixture.
+
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+sys.path[:0] = [
+    os.path.join(HERE, "_stubs"),
+    REPO,
+    os.path.join(REFERENCE, "src"),
+    REFERENCE,
+]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
+
+from tensordict import TensorDict  # noqa: E402  (stub -> rl8_amd.tensordict)
+
+import rl8  # noqa: E402,F401
+from rl8 import AlgorithmConfig  # noqa: E402
+from rl8.data import DataKeys  # noqa: E402
+from rl8.distributions import Categorical, Normal, SquashedNormal  # noqa: E402
+from rl8.env import ContinuousDummyEnv, DiscreteDummyEnv  # noqa: E402
+from rl8.nn.functional import generalized_advantage_estimate, ppo_losses  # noqa: E402
+
+
+def save(name: str, **arrays) -> None:
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path)} bytes, {len(out)} arrays")
+
+
+# --------------------------------------------------------------------------- #
+# F1: generalized_advantage_estimate  (src/rl8/nn/functional.py:50-123)
+# --------------------------------------------------------------------------- #
+def gen_gae() -> None:
+    arrays = {}
+    cases = []
+    g = torch.Generator().manual_seed(1)
+    # (name, N, H, gamma, lambda, reward_scale, normalize)
+    specs = [
+        ("a", 64, 32, 0.95, 0.95, 1.0, False),
+        ("b", 64, 32, 0.95, 0.95, 1.0, True),
+        ("c", 64, 32, 0.95, 0.95, 271.828, True),
+        ("d", 70, 15, 0.99, 0.9, 3.5, True),  # ragged N, even H+1
+        ("e", 3, 1, 0.95, 0.95, 2.0, True),  # horizon 1
+        ("f", 257, 7, 1.0, 1.0, 1.0, False),
+        ("g", 33, 128, 0.95, 0.95, 17.0, True),  # CartPole-like horizon
+    ]
+    for name, n, h, gamma, lam, scale, norm in specs:
+        state = torch.empty(n, 1).uniform_(-100, 100, generator=g)
+        rewards = -(state + torch.randn(n, h + 1, generator=g).cumsum(1)).abs()
+        rewards = rewards.unsqueeze(-1).contiguous()
+        values = torch.randn(n, h + 1, 1, generator=g)
+        batch = TensorDict(
+            {DataKeys.REWARDS: rewards.clone(), DataKeys.VALUES: values.clone()},
+            batch_size=[n, h + 1],
+        )
+        out = generalized_advantage_estimate(
+            batch,
+            gae_lambda=lam,
+            gamma=gamma,
+            inplace=False,
+            normalize_advantages=norm,
+            return_returns=True,
+            reward_scale=scale,
+        )
+        arrays[f"{name}_rewards"] = rewards
+        arrays[f"{name}_values"] = values
+        arrays[f"{name}_scaled_rewards"] = batch[DataKeys.REWARDS]
+        arrays[f"{name}_advantages"] = out[DataKeys.ADVANTAGES]
+        arrays[f"{name}_returns"] = out[DataKeys.RETURNS]
+        arrays[f"{name}_params"] = np.array([gamma, lam, scale, float(norm)], np.float64)
+        cases.append(name)
+    # Reference known-answer test (tests/test_nn/test_functional.py:14-49).
+    n, h = 10, 5
+    batch = TensorDict(
+        {
+            DataKeys.REWARDS: torch.ones(n, h + 1, 1),
+            DataKeys.VALUES: torch.ones(n, h + 1, 1),
+        },
+        batch_size=[n, h + 1],
+    )
+    out = generalized_advantage_estimate(
+        batch, gae_lambda=1, gamma=1, inplace=False, normalize_advantages=False
+    )
+    undiscounted = torch.flip(torch.cumsum(torch.ones(n, h + 1, 1), dim=1), dims=(1,))
+    assert (out[DataKeys.ADVANTAGES] == undiscounted - 1).all()
+    assert (out[DataKeys.RETURNS] == undiscounted).all()
+    arrays["kat_advantages"] = out[DataKeys.ADVANTAGES]
+    arrays["kat_returns"] = out[DataKeys.RETURNS]
+    arrays["cases"] = np.array(cases)
+    save("gae.npz", **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# F2: ppo_losses + approximate KL + autograd grads
+#     (src/rl8/nn/functional.py:259-363, algorithms/_feedforward.py:552-559,
+#      distributions.py:113-170)
+# --------------------------------------------------------------------------- #
+def gen_ppo_losses() -> None:
+    arrays = {}
+    cases = []
+    g = torch.Generator().manual_seed(2)
+    m = 384
+
+    def common():
+        adv = torch.randn(m, 1, generator=g)
+        returns = torch.randn(m, 1, generator=g) * 3
+        values = (returns + torch.randn(m, 1, generator=g) * 2).requires_grad_(True)
+        return adv, returns, values
+
+    def finish(name, dist, actions, logp_old, adv, returns, values, feats, hp):
+        buffer_batch = TensorDict(
+            {
+                DataKeys.ACTIONS: actions,
+                DataKeys.LOGP: logp_old,
+                DataKeys.ADVANTAGES: adv,
+                DataKeys.RETURNS: returns,
+            },
+            batch_size=[m],
+        )
+        sample_batch = TensorDict({DataKeys.VALUES: values}, batch_size=[m])
+        losses = ppo_losses(buffer_batch, sample_batch, dist, **hp)
+        losses["total"].backward()
+        with torch.no_grad():
+            lr = dist.logp(actions) - logp_old
+            kl = torch.mean((torch.exp(lr) - 1) - lr)
+        arrays[f"{name}_actions"] = actions
+        arrays[f"{name}_logp_old"] = logp_old
+        arrays[f"{name}_advantages"] = adv
+        arrays[f"{name}_returns"] = returns
+        arrays[f"{name}_values"] = values
+        arrays[f"{name}_grad_values"] = values.grad
+        for k, f in feats.items():
+            arrays[f"{name}_feat_{k}"] = f
+            arrays[f"{name}_grad_{k}"] = f.grad
+        arrays[f"{name}_losses"] = np.array(
+            [
+                float(losses["entropy"].reshape(-1)[0]),
+                float(losses["policy"]),
+                float(losses["vf"]),
+                float(losses["total"].reshape(-1)[0]),
+                float(kl),
+            ],
+            np.float64,
+        )
+        arrays[f"{name}_hparams"] = np.array(
+            [
+                hp["clip_param"],
+                hp["dual_clip_param"] if hp["dual_clip_param"] else 0.0,
+                hp["entropy_coeff"],
+                hp["vf_clip_param"],
+                hp["vf_coeff"],
+            ],
+            np.float64,
+        )
+        cases.append(name)
+
+    hps = {
+        "p0": dict(clip_param=0.2, dual_clip_param=None, entropy_coeff=0.0, vf_clip_param=5.0, vf_coeff=1.0),
+        "p1": dict(clip_param=0.2, dual_clip_param=5.0, entropy_coeff=0.0, vf_clip_param=5.0, vf_coeff=1.0),
+        "p2": dict(clip_param=0.3, dual_clip_param=None, entropy_coeff=1e-2, vf_clip_param=1.0, vf_coeff=0.5),
+        "p3": dict(clip_param=0.1, dual_clip_param=3.0, entropy_coeff=1e-2, vf_clip_param=2.0, vf_coeff=2.0),
+    }
+    for ncls in (2, 3, 5):
+        for hname, hp in hps.items():
+            adv, returns, values = common()
+            logits = (torch.randn(m, 1, ncls, generator=g) * 1.5).requires_grad_(True)
+            actions = torch.randint(0, ncls, (m, 1), generator=g)
+            dist = Categorical(TensorDict({"logits": logits}, batch_size=[m]), None)
+            with torch.no_grad():
+                logp_old = dist.logp(actions) + torch.randn(m, 1, generator=g) * 0.4
+            finish(f"cat{ncls}_{hname}", dist, actions, logp_old, adv, returns, values, {"logits": logits}, hp)
+    for dname, dcls in (("normal", Normal), ("squashed", SquashedNormal)):
+        for hname, hp in hps.items():
+            if dname == "squashed" and hp["entropy_coeff"] != 0:
+                continue
+            for adim in (1, 2):
+                adv, returns, values = common()
+                mean = torch.randn(m, adim, generator=g).requires_grad_(True)
+                log_std = torch.tanh(torch.randn(m, adim, generator=g)).requires_grad_(True)
+                feats = TensorDict({"mean": mean, "log_std": log_std}, batch_size=[m])
+                dist = dcls(feats, None)
+                with torch.no_grad():
+                    actions = dcls(feats, None).sample()
+                    if dname == "squashed":
+                        # exercise the clamp branch too
+                        actions[:4] = torch.tensor([[1.0] * adim, [-1.0] * adim, [0.0] * adim, [0.9999999] * adim])
+                    logp_old = dist.logp(actions) + torch.randn(m, 1, generator=g) * 0.4
+                finish(
+                    f"{dname}{adim}_{hname}", dist, actions, logp_old, adv, returns,
+                    values, {"mean": mean, "log_std": log_std}, hp,
+                )
+    arrays["cases"] = np.array(cases)
+    save("ppo_losses.npz", **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# F3: env steps (src/rl8/env.py:224-230,253-259; examples/cartpole/env.py:12-64)
+# --------------------------------------------------------------------------- #
+def gen_env_steps() -> None:
+    arrays = {}
+    g = torch.Generator().manual_seed(3)
+    n, steps = 257, 6
+    # Discrete dummy.
+    env = DiscreteDummyEnv(n, 32)
+    env.state = torch.empty(n, 1).uniform_(-100, 100, generator=g)
+    arrays["disc_state0"] = env.state.clone()
+    acts, states, rewards = [], [], []
+    for _ in range(steps):
+        a = torch.randint(0, 2, (n, 1), generator=g)
+        out = env.step(a)
+        acts.append(a)
+        states.append(out[DataKeys.OBS].clone())
+        rewards.append(out[DataKeys.REWARDS].clone())
+    arrays["disc_actions"] = torch.stack(acts)
+    arrays["disc_states"] = torch.stack(states)
+    arrays["disc_rewards"] = torch.stack(rewards)
+    # Continuous dummy.
+    env = ContinuousDummyEnv(n, 32)
+    env.state = torch.empty(n, 1).uniform_(-100, 100, generator=g)
+    arrays["cont_state0"] = env.state.clone()
+    acts, states, rewards = [], [], []
+    for _ in range(steps):
+        a = torch.tanh(torch.randn(n, 1, generator=g))
+        out = env.step(a)
+        acts.append(a)
+        states.append(out[DataKeys.OBS].clone())
+        rewards.append(out[DataKeys.REWARDS].clone())
+    arrays["cont_actions"] = torch.stack(acts)
+    arrays["cont_states"] = torch.stack(states)
+    arrays["cont_rewards"] = torch.stack(rewards)
+
+    # CartPole, eager body of the compiled step (the function torch.compile wraps).
+    from examples.cartpole import env as cartpole_env
+
+    eager_step = cartpole_env.step
+    for attr in ("_torchdynamo_orig_callable", "__wrapped__"):
+        if hasattr(eager_step, attr):
+            eager_step = getattr(eager_step, attr)
+            break
+    from dataclasses import asdict
+
+    for integ in ("euler", "semi-implicit"):
+        cfg = cartpole_env.CartPoleConfig(kinematics_integrator=integ)
+        state = torch.normal(0, 0.5, size=(4, n), generator=g)
+        arrays[f"cp_{integ}_state0"] = state.clone()
+        acts, states, obss, rewards = [], [], [], []
+        for _ in range(steps):
+            a = torch.randint(0, 3, (n, 1), generator=g)
+            x, x_dot, theta, theta_dot = state
+            state, obs, reward = eager_step(x, x_dot, theta, theta_dot, a, **asdict(cfg))
+            acts.append(a)
+            states.append(state.clone())
+            obss.append(obs.contiguous().clone())
+            rewards.append(reward.clone())
+        arrays[f"cp_{integ}_actions"] = torch.stack(acts)
+        arrays[f"cp_{integ}_states"] = torch.stack(states)
+        arrays[f"cp_{integ}_obs"] = torch.stack(obss)
+        arrays[f"cp_{integ}_rewards"] = torch.stack(rewards)
+    # Non-default physics.
+    cfg = cartpole_env.CartPoleConfig(force_mag=7.5, gravity=3.7, length=0.8, pole_mass=0.25, cart_mass=2.0, tau=0.01)
+    state = torch.normal(0, 0.5, size=(4, n), generator=g)
+    a = torch.randint(0, 3, (n, 1), generator=g)
+    x, x_dot, theta, theta_dot = state
+    s2, obs, reward = eager_step(x, x_dot, theta, theta_dot, a, **asdict(cfg))
+    arrays["cp_custom_cfg"] = np.array(
+        [cfg.force_mag, cfg.gravity, cfg.length, cfg.pole_mass, cfg.pole_mass_length, cfg.total_mass, cfg.tau],
+        np.float64,
+    )
+    arrays["cp_custom_state0"] = state
+    arrays["cp_custom_actions"] = a
+    arrays["cp_custom_state1"] = s2
+    arrays["cp_custom_obs"] = obs.contiguous()
+    arrays["cp_custom_rewards"] = reward
+    save("env_steps.npz", **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# F4: samplers (src/rl8/distributions.py:113-170 -> torch.distributions)
+# --------------------------------------------------------------------------- #
+def draw_exponential_like(probs: torch.Tensor) -> torch.Tensor:
+    """The noise ``torch.multinomial`` will draw next (num_samples=1 path:
+    ``q = empty_like(p).exponential_(1)``, result ``argmax(p / q)``), read without
+    advancing the default generator."""
+    state = torch.get_rng_state()
+    q = torch.empty_like(probs).exponential_(1)
+    torch.set_rng_state(state)
+    return q
+
+
+def gen_samplers() -> None:
+    arrays = {}
+    torch.manual_seed(4)
+    m = 4096
+    for ncls in (2, 3, 5):
+        scale = 1e-3 if ncls == 2 else 2.0
+        logits = torch.randn(m, 1, ncls) * scale
+        dist = Categorical(TensorDict({"logits": logits}, batch_size=[m]), None)
+        q = draw_exponential_like(dist.dist.probs.reshape(-1, ncls))
+        actions = dist.sample()
+        check = torch.argmax(dist.dist.probs.reshape(-1, ncls) / q, dim=-1, keepdim=True)
+        assert (check == actions).all(), "multinomial != argmax(p/q): torch changed"
+        arrays[f"cat{ncls}_logits"] = logits
+        arrays[f"cat{ncls}_q"] = q.reshape(m, 1, ncls)
+        arrays[f"cat{ncls}_actions"] = actions
+        arrays[f"cat{ncls}_logp"] = dist.logp(actions)
+        arrays[f"cat{ncls}_entropy"] = dist.entropy()
+        arrays[f"cat{ncls}_mode"] = dist.deterministic_sample()
+    for adim in (1, 3):
+        mean = torch.randn(m, adim)
+        log_std = torch.tanh(torch.randn(m, adim))
+        feats = TensorDict({"mean": mean, "log_std": log_std}, batch_size=[m])
+        for dname, dcls in (("normal", Normal), ("squashed", SquashedNormal)):
+            dist = dcls(feats, None)
+            state = torch.get_rng_state()
+            eps = torch.randn(m, adim)
+            torch.set_rng_state(state)
+            actions = dist.sample()
+            ref = mean + torch.exp(log_std) * eps
+            if dname == "squashed":
+                ref = ref.tanh()
+            assert (ref == actions).all(), "Normal.sample != loc + scale*randn"
+            arrays[f"{dname}{adim}_mean"] = mean
+            arrays[f"{dname}{adim}_log_std"] = log_std
+            arrays[f"{dname}{adim}_eps"] = eps
+            arrays[f"{dname}{adim}_actions"] = actions
+            arrays[f"{dname}{adim}_logp"] = dist.logp(actions)
+            arrays[f"{dname}{adim}_mode"] = dist.deterministic_sample()
+            if dname == "normal":
+                arrays[f"{dname}{adim}_entropy"] = dist.entropy()
+    save("samplers.npz", **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# F5/F6: end-to-end traces of Algorithm.collect()/step()
+#        (src/rl8/algorithms/_feedforward.py:301-615)
+# --------------------------------------------------------------------------- #
+class Recorder:
+    """Records the noise torch draws inside the reference's collect()/step()
+    by wrapping torch entry points (never reference code)."""
+
+    def __init__(self) -> None:
+        self.cat_q: list[torch.Tensor] = []
+        self.normal_eps: list[torch.Tensor] = []
+        self.perms: list[torch.Tensor] = []
+        self.resets: list[torch.Tensor] = []
+
+    def __enter__(self):
+        rec = self
+        self._cat_sample = torch.distributions.Categorical.sample
+        self._normal_sample = torch.distributions.Normal.sample
+        self._randperm = torch.randperm
+
+        def cat_sample(dist, sample_shape=torch.Size()):
+            probs_2d = dist.probs.reshape(-1, dist._num_events)
+            rec.cat_q.append(draw_exponential_like(probs_2d).reshape(dist.probs.shape))
+            return rec._cat_sample(dist, sample_shape)
+
+        def normal_sample(dist, sample_shape=torch.Size()):
+            state = torch.get_rng_state()
+            rec.normal_eps.append(torch.randn(dist.loc.shape))
+            torch.set_rng_state(state)
+            out = rec._normal_sample(dist, sample_shape)
+            assert (out == dist.loc + dist.scale * rec.normal_eps[-1]).all()
+            return out
+
+        def randperm(*args, **kwargs):
+            out = rec._randperm(*args, **kwargs)
+            rec.perms.append(out.clone())
+            return out
+
+        torch.distributions.Categorical.sample = cat_sample
+        torch.distributions.Normal.sample = normal_sample
+        torch.randperm = randperm
+        return self
+
+    def __exit__(self, *exc):
+        torch.distributions.Categorical.sample = self._cat_sample
+        torch.distributions.Normal.sample = self._normal_sample
+        torch.randperm = self._randperm
+
+
+def snapshot_buffer(buffer, prefix, arrays):
+    for k, v in buffer.items():
+        arrays[f"{prefix}_{k}"] = v.clone()
+
+
+def gen_trace(name, env_cls, config_kwargs, iterations=2) -> None:
+    arrays = {}
+    torch.manual_seed(42)
+    algo = AlgorithmConfig(num_envs=64, horizon=32, device="cpu", **config_kwargs).build(env_cls)
+    for k, v in algo.policy.model.state_dict().items():
+        arrays[f"init_{k}"] = v.clone()
+    collect_keys = None
+    step_keys = None
+    for it in range(iterations):
+        with Recorder() as rec:
+            wrapped_reset = algo.env.reset
+
+            def reset(*, config=None, _r=wrapped_reset):
+                out = _r(config=config)
+                rec.resets.append(out.clone())
+                return out
+
+            algo.env.reset = reset
+            collect_stats = algo.collect()
+            algo.env.reset = wrapped_reset
+            snapshot_buffer(algo.buffer, f"it{it}_collect", arrays)
+            arrays[f"it{it}_reward_scale"] = np.float64(algo.state.reward_scale)
+            step_stats = algo.step()
+        if rec.resets:
+            arrays[f"it{it}_reset_state"] = rec.resets[0]
+        if rec.cat_q:
+            arrays[f"it{it}_cat_q"] = torch.stack(rec.cat_q)
+        if rec.normal_eps:
+            arrays[f"it{it}_normal_eps"] = torch.stack(rec.normal_eps)
+        arrays[f"it{it}_perms"] = torch.stack(rec.perms)
+        collect_keys = sorted(k for k in collect_stats if not k.startswith("profiling"))
+        step_keys = sorted(k for k in step_stats if not k.startswith("profiling"))
+        arrays[f"it{it}_collect_stats"] = np.array([collect_stats[k] for k in collect_keys], np.float64)
+        arrays[f"it{it}_step_stats"] = np.array([step_stats[k] for k in step_keys], np.float64)
+        for k, v in algo.policy.model.state_dict().items():
+            arrays[f"it{it}_final_{k}"] = v.clone()
+        arrays[f"it{it}_final_obs"] = algo.buffer[DataKeys.OBS][:, -1].clone()
+    arrays["collect_stat_keys"] = np.array(collect_keys)
+    arrays["step_stat_keys"] = np.array(step_keys)
+    arrays["config"] = np.array([f"{k}={v}" for k, v in config_kwargs.items()] or ["default"])
+    save(name, **arrays)
+
+
+def main() -> None:
+    gen_gae()
+    gen_ppo_losses()
+    gen_env_steps()
+    gen_samplers()
+    gen_trace("trace_ff_discrete.npz", DiscreteDummyEnv, {})
+    gen_trace(
+        "trace_ff_discrete_minibatch.npz",
+        DiscreteDummyEnv,
+        dict(sgd_minibatch_size=256, entropy_coeff=1e-2, dual_clip_param=5.0, horizons_per_env_reset=2),
+    )
+    gen_trace(
+        "trace_ff_continuous_squashed.npz",
+        ContinuousDummyEnv,
+        dict(distribution_cls=SquashedNormal),
+    )
+    gen_trace("trace_ff_continuous_normal.npz", ContinuousDummyEnv, dict(entropy_coeff=1e-2))
+
+
+if __name__ == "__main__":
+    main()
