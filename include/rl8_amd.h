@@ -1,0 +1,236 @@
+/*
+ * rl8_amd.h -- C ABI of the MI355X (gfx950) PPO hot path.
+ *
+ * One shared library, librl8_amd.so, built from rl8_amd/csrc with
+ * `hipcc --offload-arch=gfx950`. Plain pointers and sizes only; every pointer is
+ * a DEVICE pointer owned by the caller (PyTorch in the Python host, hipMalloc in
+ * a C host) unless it says "host". Nothing here allocates, frees or
+ * synchronises: each call enqueues kernels on `stream` (a hipStream_t passed as
+ * void*; NULL = the default stream) and returns.
+ *
+ * Return value: 0 on success; RL8_E* (negative) when an argument check fails
+ * (nothing was launched); a positive hipError_t if the launch itself failed.
+ *
+ * The reference (theOGognf/rl8) has no FFI on this path: its boundary is Python
+ * call signatures. Each entry point below cites the reference function whose
+ * arithmetic it replaces (paths relative to the reference checkout);
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Layouts.  N = num_envs, H = horizon, M = samples in a (mini)batch,
+ * A = action dims, K = classes per action dim.
+ *   "env-major"  buffer leaf: [N][H+1] contiguous  (the reference's [N, H+1, 1])
+ *   "time-major" buffer leaf: [H+1][N] contiguous  (rl8_amd's own rollout
+ *                buffer; exposed to Python as a transposed [N, H+1, 1] view)
+ */
+#ifndef RL8_AMD_H
+#define RL8_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RL8_OK 0
+#define RL8_ENULL (-1)   /* required pointer is NULL */
+#define RL8_ESIZE (-2)   /* size / shape argument out of range */
+#define RL8_EALIGN (-3)  /* pointer not aligned as required */
+#define RL8_ECONFIG (-4) /* unsupported combination of options */
+
+#define RL8_MAX_CLASSES 64 /* K upper bound for the categorical kernels */
+#define RL8_MAX_PARTIALS 2048 /* upper bound on per-launch partial rows */
+
+/* ABI / build identification: returns e.g. 100 for 1.0.0; `arch` (host
+ * pointer, may be NULL) receives "gfx950". */
+int rl8_abi_version(char *arch, int arch_len);
+
+/* Scratch the reductions need (bytes); the caller allocates it once
+ * (device memory, 16-byte aligned) and passes it to the calls that take
+ * `scratch`.  Contents need no initialisation. */
+int64_t rl8_scratch_bytes(void);
+
+/* ---------------------------------------------------------------------- *
+ * a-1  DummyEnv.step                  src/rl8/env.py:224-230, 253-259
+ * state [N] f32 updated in place; action [N] int64 (discrete: state += 2a-1)
+ * or f32 (continuous: state += a); reward_out [N] = -|state|.
+ * ---------------------------------------------------------------------- */
+int rl8_dummy_env_step_f32(float *state, const void *action, int is_discrete,
+                           float *reward_out, int64_t n, void *stream);
+
+/* DummyEnv.reset                      src/rl8/env.py:197-203
+ * state ~ U(-bounds, bounds) from the build's Philox stream (rl8_philox.h);
+ * env_offset = global index of this shard's first env. */
+int rl8_dummy_env_reset_f32(float *state, int64_t n, float bounds, uint64_t seed,
+                            uint64_t reset_count, int64_t env_offset, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * a-2  CartPole step                  examples/cartpole/env.py:12-64
+ * state SoA [4][N] (x, x_dot, theta, theta_dot) in place; action [N] int64 in
+ * {0,1,2}; obs_out [N][5] rows (x, x_dot, cos, sin, theta_dot) written with
+ * row stride obs_stride floats (5 for a dense [N,5]); reward_out [N].
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  float force_mag, gravity, length, pole_mass, pole_mass_length, total_mass, tau;
+  int32_t semi_implicit; /* 0: "euler" (:43-47), 1: semi-implicit (:48-52) */
+} rl8_cartpole_cfg;
+
+int rl8_cartpole_step_f32(float *state, const int64_t *action, const rl8_cartpole_cfg *cfg /*host*/,
+                          float *obs_out, int64_t obs_stride, float *reward_out, int64_t n,
+                          void *stream);
+
+/* CartPole.reset                      examples/cartpole/env.py:128-136
+ * state ~ N(0, std) [4][N]; obs_out as above (may be NULL). */
+int rl8_cartpole_reset_f32(float *state, int64_t n, float std, uint64_t seed,
+                           uint64_t reset_count, int64_t env_offset, float *obs_out,
+                           int64_t obs_stride, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * a-6  Distribution.sample / logp     src/rl8/distributions.py:113-170
+ * (-> torch.distributions.Categorical.sample == argmax(p / q), q ~ Exp(1))
+ * logits [M][A][K] f32; noise: injected q [M][A][K] (may be NULL -> Philox
+ * (seed, row_offset + row, step)); action_out [M][A] int64; logp_out [M] f32.
+ * deterministic != 0 -> mode.
+ * ---------------------------------------------------------------------- */
+int rl8_categorical_sample_logp_f32(const float *logits, const float *noise, int64_t *action_out,
+                                    float *logp_out, int64_t m, int a, int k, uint64_t seed,
+                                    uint64_t step, int64_t row_offset, int deterministic,
+                                    void *stream);
+
+/* Normal / SquashedNormal: mean, log_std [M][A]; noise: injected eps [M][A]
+ * (may be NULL -> Philox); action_out [M][A] f32; logp_out [M]. */
+int rl8_normal_sample_logp_f32(const float *mean, const float *log_std, const float *noise,
+                               float *action_out, float *logp_out, int64_t m, int a,
+                               int squashed, uint64_t seed, uint64_t step, int64_t row_offset,
+                               int deterministic, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * a-3  Rollout bookkeeping            src/rl8/algorithms/_feedforward.py:378-393
+ * One launch per timestep t for a generic Env: rdr[t+1] = gamma*rdr[t] + r and
+ * the five column writes.  All destinations are columns of TIME-MAJOR leaves,
+ * i.e. contiguous [N][d] slabs; sources are the policy / env outputs [N][d].
+ * rdr_t / rdr_t1 may be NULL (normalize_rewards = False).
+ * ---------------------------------------------------------------------- */
+int rl8_rollout_scatter_f32(const void *action, int64_t action_row_bytes, const float *logp,
+                            const float *value, const float *reward, const float *obs,
+                            int64_t obs_dim, void *action_col, float *logp_col, float *value_col,
+                            float *reward_col, float *obs_col_next, const float *rdr_t,
+                            float *rdr_t1, float gamma, int64_t n, void *stream);
+
+/* Fused per-timestep kernel for the built-in dummy envs: sampler (a-6) +
+ * env.step (a-1) + bookkeeping (a-3) in ONE launch.
+ *   discrete:   features = logits [N][1][2];  noise = q [N][1][2] or NULL
+ *   continuous: features = mean [N][1], features2 = log_std [N][1]; noise = eps
+ *               [N][1] or NULL; squashed selects SquashedNormal.
+ * state [N] in place (the env's state; also written to obs_col_next). */
+int rl8_rollout_step_dummy_f32(int is_discrete, int squashed, const float *features,
+                               const float *features2, const float *value, const float *noise,
+                               float *state, void *action_col, float *logp_col, float *value_col,
+                               float *reward_col, float *obs_col_next, const float *rdr_t,
+                               float *rdr_t1, float gamma, int64_t n, uint64_t seed, uint64_t step,
+                               int64_t env_offset, int deterministic, void *stream);
+
+/* Fused per-timestep kernel for CartPole (K = 3): sampler + physics +
+ * bookkeeping.  obs_col_next is a [N][5] slab. */
+int rl8_rollout_step_cartpole_f32(const float *logits, const float *value, const float *noise,
+                                  float *state, const rl8_cartpole_cfg *cfg /*host*/,
+                                  int64_t *action_col, float *logp_col, float *value_col,
+                                  float *reward_col, float *obs_col_next, const float *rdr_t,
+                                  float *rdr_t1, float gamma, int64_t n, uint64_t seed,
+                                  uint64_t step, int64_t env_offset, int deterministic,
+                                  void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * a-4  Collect statistics             src/rl8/algorithms/_feedforward.py:411-436
+ * rewards / rdr leaves with element strides (env_stride, time_stride) so both
+ * layouts are accepted; rdr may be NULL.  Writes 12 doubles to stats_out:
+ *   [0] n_envs  [1] sum(ret) [2] sum(ret^2) [3] min(ret) [4] max(ret)
+ *   [5] n*h     [6] sum(r)   [7] sum(r^2)   [8] min(r)   [9] max(r)
+ *   [10] sum(rdr[:,1:]) [11] sum(rdr[:,1:]^2)
+ * (raw moments, so that shards can be combined with one all-reduce each for
+ * SUM / MIN / MAX before the host forms mean and unbiased std).
+ * ---------------------------------------------------------------------- */
+int rl8_rollout_stats_f32(const float *rewards, const float *rdr, int64_t n, int64_t h,
+                          int64_t env_stride, int64_t time_stride, double *stats_out,
+                          void *scratch, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * a-5  generalized_advantage_estimate src/rl8/nn/functional.py:50-123
+ * Scan: rewards are divided by `reward_denominator` (= f32(reward_scale+1e-8),
+ * :106) on load -- and written back when write_scaled_rewards != 0, as the
+ * reference does -- then for t = H-1..0
+ *   delta = r[t] + (gamma*v[t+1] - v[t]);  adv[t] = delta + gamma_lambda*adv[t+1]
+ * adv[H] = 0, ret[t] = adv[t] + v[t] for all H+1 columns (:116-117).
+ * moments_out (3 doubles: count, sum, sum of squares of adv[:, :H]) feeds the
+ * normalisation; all-reduce it across env shards before normalising.
+ * layout: 0 = env-major (LDS-staged tiles), 1 = time-major (register scan).
+ * rewards and adv_out / values and ret_out may not alias each other.
+ * ---------------------------------------------------------------------- */
+int rl8_gae_scan_f32(float *rewards, const float *values, float *adv_out, float *ret_out,
+                     int64_t n, int64_t h, int layout, float gamma, float gamma_lambda,
+                     float reward_denominator, int write_scaled_rewards, double *moments_out,
+                     void *scratch, void *stream);
+
+/* adv[:, :H] = (adv - mean) / (std + 1e-8), mean / unbiased std formed from
+ * `moments` (device, 3 doubles) (:118-122). */
+int rl8_advantage_normalise_f32(float *adv, int64_t n, int64_t h, int layout,
+                                const double *moments, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * a-7  ppo_losses + approximate KL, forward AND backward
+ *      src/rl8/nn/functional.py:259-363, algorithms/_feedforward.py:545-559
+ * Per sample i: features, value[i], action[i], logp_old[i], adv[i], ret[i].
+ * Writes grad_* = d(total)/d(input) * grad_scale (grad_scale =
+ * 1 / (M_global * grad_accumulation_steps)), and loss_sums_out (device, 5
+ * doubles): sum over samples of entropy, policy, vf terms, the sample count,
+ * and the KL terms -- raw sums so that env shards combine with one all-reduce;
+ * the host divides.  grad pointers may be NULL (forward only).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  float clip_param;
+  float dual_clip_param; /* <= 0: disabled (reference: None) */
+  float entropy_coeff;
+  float vf_clip_param;
+  float vf_coeff;
+  float grad_scale;
+} rl8_ppo_hparams;
+
+int rl8_ppo_loss_categorical_fwd_bwd_f32(const float *logits, const float *value,
+                                         const int64_t *action, const float *logp_old,
+                                         const float *adv, const float *ret, int64_t m, int a,
+                                         int k, const rl8_ppo_hparams *hp /*host*/,
+                                         float *grad_logits, float *grad_value,
+                                         double *loss_sums_out, void *scratch, void *stream);
+
+int rl8_ppo_loss_normal_fwd_bwd_f32(const float *mean, const float *log_std, const float *value,
+                                    const float *action, const float *logp_old, const float *adv,
+                                    const float *ret, int64_t m, int a, int squashed,
+                                    const rl8_ppo_hparams *hp /*host*/, float *grad_mean,
+                                    float *grad_log_std, float *grad_value,
+                                    double *loss_sums_out, void *scratch, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * a-8  Batcher gather                 src/rl8/_utils.py:211-225
+ * index [M] int64 holds REFERENCE sample ids s = env*H + t (the flattening of
+ * _feedforward.py:481).  Each of the `n_fields` sources is a buffer leaf with
+ * element strides; the matching destination is a dense [M][row_elems] array.
+ * Elements are 4 or 8 bytes wide (f32 / int64).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const void *src;
+  void *dst;
+  int64_t env_stride;  /* in elements */
+  int64_t time_stride; /* in elements */
+  int32_t row_elems;   /* trailing elements per (env, t) cell */
+  int32_t elem_bytes;  /* 4 or 8 */
+} rl8_gather_field;
+
+#define RL8_MAX_GATHER_FIELDS 8
+
+int rl8_gather_minibatch(const int64_t *index, int64_t m, int64_t h,
+                         const rl8_gather_field *fields /*host*/, int n_fields, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RL8_AMD_H */

@@ -1,0 +1,392 @@
+// K4: fused PPO loss, forward and backward in one pass.
+// Restates src/rl8/nn/functional.py:316-363 (clipped / dual-clipped surrogate,
+// clamped Huber value loss, entropy bonus), the approximate-KL monitor of
+// src/rl8/algorithms/_feedforward.py:552-559, the distribution log-prob /
+// entropy of src/rl8/distributions.py:113-170, and what autograd would leave in
+// features.grad / values.grad after `total.backward()`.
+//
+// HBM-bound, no reuse: each sample is read once (features, value, action,
+// logp_old, advantage, return) and its two gradients written once -- 44 B per
+// sample for Categorical(K=2).  The ~50 eager launches + autograd graph of the
+// reference collapse into one launch; loss terms are accumulated per thread in
+// fp64, reduced with wave shuffles and written as per-block partials that a
+// one-block kernel sums in a fixed order (bitwise reproducible, no atomics).
+//
+// The gradient scale 1/(M_global * grad_accumulation_steps) is known before the
+// launch, so gradients do not wait for the reduced loss.
+#include "common.hip.h"
+#include "device_math.hip.h"
+
+namespace rl8 {
+
+constexpr int kLossCols = 4;  // entropy, policy, vf, kl
+
+// ---------------------------------------------------------------------------
+// Categorical, A == 1, compile-time K, SPT samples per thread with 16-byte
+// loads wherever SPT*K*4 and SPT*4 are multiples of 16.
+// ---------------------------------------------------------------------------
+template <int K, int SPT, bool HAS_GRAD>
+__global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
+    const float *__restrict__ logits, const float *__restrict__ value,
+    const int64_t *__restrict__ action, const float *__restrict__ logp_old,
+    const float *__restrict__ adv, const float *__restrict__ ret, int64_t m, rl8_ppo_hparams hp,
+    float *__restrict__ grad_logits, float *__restrict__ grad_value,
+    double *__restrict__ partials) {
+  __shared__ double smem[kLossCols * kWavesPerBlock];
+  double acc[kLossCols] = {0.0, 0.0, 0.0, 0.0};
+  const bool with_entropy = hp.entropy_coeff != 0.0f;
+  const int64_t groups = m / SPT;  // full groups; the tail is handled below
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+    const int64_t i0 = g * SPT;
+    float x[SPT * K], v[SPT], lo[SPT], ad[SPT], rt[SPT];
+    int64_t act[SPT];
+    if constexpr (SPT == 4) {
+      // SPT*K floats = K float4; the others one float4 / two 16-byte loads.
+      const float4 *xp = reinterpret_cast<const float4 *>(logits + i0 * K);
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const float4 t = xp[q];
+        x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+      }
+      const float4 tv = *reinterpret_cast<const float4 *>(value + i0);
+      const float4 tl = *reinterpret_cast<const float4 *>(logp_old + i0);
+      const float4 ta = *reinterpret_cast<const float4 *>(adv + i0);
+      const float4 tr = *reinterpret_cast<const float4 *>(ret + i0);
+      v[0] = tv.x; v[1] = tv.y; v[2] = tv.z; v[3] = tv.w;
+      lo[0] = tl.x; lo[1] = tl.y; lo[2] = tl.z; lo[3] = tl.w;
+      ad[0] = ta.x; ad[1] = ta.y; ad[2] = ta.z; ad[3] = ta.w;
+      rt[0] = tr.x; rt[1] = tr.y; rt[2] = tr.z; rt[3] = tr.w;
+      const longlong2 a0 = *reinterpret_cast<const longlong2 *>(action + i0);
+      const longlong2 a1 = *reinterpret_cast<const longlong2 *>(action + i0 + 2);
+      act[0] = a0.x; act[1] = a0.y; act[2] = a1.x; act[3] = a1.y;
+    } else {
+#pragma unroll
+      for (int s = 0; s < SPT; ++s) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) x[s * K + j] = logits[(i0 + s) * K + j];
+        v[s] = value[i0 + s]; lo[s] = logp_old[i0 + s]; ad[s] = adv[i0 + s];
+        rt[s] = ret[i0 + s]; act[s] = action[i0 + s];
+      }
+    }
+    float gx[SPT * K], gv[SPT];
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+      float xs[K], nl[K], p[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) xs[j] = x[s * K + j];
+      categorical_normalise<K, false>(xs, nl, p);
+      float logp = nl[0];
+#pragma unroll
+      for (int j = 1; j < K; ++j) logp = (act[s] == j) ? nl[j] : logp;
+      float ent = 0.0f;
+      if (with_entropy) {
+        float e = 0.0f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) e += nl[j] * p[j];
+        ent = -e;
+      }
+      const PolicyTerm pt = ppo_policy_term(logp, lo[s], ad[s], hp);
+      float dv;
+      const float vterm = ppo_vf_term(v[s], rt[s], hp, &dv);
+      acc[0] += (double)ent;
+      acc[1] += (double)pt.term;
+      acc[2] += (double)vterm;
+      acc[3] += (double)pt.kl;
+      if (HAS_GRAD) {
+        gv[s] = hp.grad_scale * hp.vf_coeff * dv;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float dlogp = (act[s] == j ? 1.0f : 0.0f) - p[j];
+          float gj = -pt.dterm_dlogp * dlogp;
+          if (with_entropy) gj -= hp.entropy_coeff * (-p[j] * (nl[j] + ent));
+          gx[s * K + j] = hp.grad_scale * gj;
+        }
+      }
+    }
+    if (HAS_GRAD) {
+      if constexpr (SPT == 4) {
+        float4 *gp = reinterpret_cast<float4 *>(grad_logits + i0 * K);
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+          gp[q] = make_float4(gx[4 * q + 0], gx[4 * q + 1], gx[4 * q + 2], gx[4 * q + 3]);
+        *reinterpret_cast<float4 *>(grad_value + i0) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+#pragma unroll
+          for (int j = 0; j < K; ++j) grad_logits[(i0 + s) * K + j] = gx[s * K + j];
+          grad_value[i0 + s] = gv[s];
+        }
+      }
+    }
+  }
+  block_reduce<kLossCols, SumOp>(acc, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < kLossCols; ++c)
+      partials[(int64_t)blockIdx.x * kPartialWidth + c] = acc[c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Categorical, any A and K <= RL8_MAX_CLASSES: one sample per thread, scalar
+// access.  Also mops up the (m % SPT) tail of the vector kernel via `first`.
+// ---------------------------------------------------------------------------
+template <bool HAS_GRAD>
+__global__ __launch_bounds__(kBlock) void ppo_loss_categorical_generic_kernel(
+    const float *__restrict__ logits, const float *__restrict__ value,
+    const int64_t *__restrict__ action, const float *__restrict__ logp_old,
+    const float *__restrict__ adv, const float *__restrict__ ret, int64_t first, int64_t m, int a,
+    int k, rl8_ppo_hparams hp, float *__restrict__ grad_logits, float *__restrict__ grad_value,
+    double *__restrict__ partials, int partial_row0) {
+  __shared__ double smem[kLossCols * kWavesPerBlock];
+  double acc[kLossCols] = {0.0, 0.0, 0.0, 0.0};
+  const bool with_entropy = hp.entropy_coeff != 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  float nl[RL8_MAX_CLASSES], p[RL8_MAX_CLASSES];
+  for (int64_t i = first + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) {
+    float logp = 0.0f, ent = 0.0f;
+    for (int d = 0; d < a; ++d) {
+      categorical_normalise_dyn<false>(logits + (i * a + d) * k, k, nl, p);
+      int64_t ai = action[i * a + d];
+      ai = ai < 0 ? 0 : (ai >= k ? k - 1 : ai);
+      const float l = nl[ai];
+      logp = d == 0 ? l : logp + l;
+      if (with_entropy) {
+        float e = 0.0f;
+        for (int j = 0; j < k; ++j) e += nl[j] * p[j];
+        ent = d == 0 ? -e : ent + (-e);
+      }
+    }
+    const PolicyTerm pt = ppo_policy_term(logp, logp_old[i], adv[i], hp);
+    float dv;
+    const float vterm = ppo_vf_term(value[i], ret[i], hp, &dv);
+    acc[0] += (double)ent;
+    acc[1] += (double)pt.term;
+    acc[2] += (double)vterm;
+    acc[3] += (double)pt.kl;
+    if (HAS_GRAD) {
+      grad_value[i] = hp.grad_scale * hp.vf_coeff * dv;
+      for (int d = 0; d < a; ++d) {
+        categorical_normalise_dyn<false>(logits + (i * a + d) * k, k, nl, p);
+        float hd = 0.0f;
+        if (with_entropy) {
+          for (int j = 0; j < k; ++j) hd += nl[j] * p[j];
+          hd = -hd;
+        }
+        const int64_t act = action[i * a + d];
+        for (int j = 0; j < k; ++j) {
+          const float dlogp = (j == act ? 1.0f : 0.0f) - p[j];
+          float gj = -pt.dterm_dlogp * dlogp;
+          if (with_entropy) gj -= hp.entropy_coeff * (-p[j] * (nl[j] + hd));
+          grad_logits[(i * a + d) * k + j] = hp.grad_scale * gj;
+        }
+      }
+    }
+  }
+  block_reduce<kLossCols, SumOp>(acc, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < kLossCols; ++c)
+      partials[(int64_t)(partial_row0 + blockIdx.x) * kPartialWidth + c] = acc[c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Normal / SquashedNormal, any A: one sample per thread.
+// ---------------------------------------------------------------------------
+template <bool HAS_GRAD>
+__global__ __launch_bounds__(kBlock) void ppo_loss_normal_kernel(
+    const float *__restrict__ mean, const float *__restrict__ log_std,
+    const float *__restrict__ value, const float *__restrict__ action,
+    const float *__restrict__ logp_old, const float *__restrict__ adv,
+    const float *__restrict__ ret, int64_t m, int a, int squashed, rl8_ppo_hparams hp,
+    float *__restrict__ grad_mean, float *__restrict__ grad_log_std,
+    float *__restrict__ grad_value, double *__restrict__ partials) {
+  __shared__ double smem[kLossCols * kWavesPerBlock];
+  double acc[kLossCols] = {0.0, 0.0, 0.0, 0.0};
+  const bool with_entropy = hp.entropy_coeff != 0.0f && !squashed;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) {
+    float logp = 0.0f, corr = 0.0f, ent = 0.0f;
+    for (int d = 0; d < a; ++d) {
+      const float mu = mean[i * a + d], sc = expf(log_std[i * a + d]);
+      const float act = action[i * a + d];
+      float l;
+      if (squashed) {
+        l = fminf(fmaxf(normal_log_prob(squashed_invert(act), mu, sc), -100.0f), 100.0f);
+        const float t = logf((1.0f - act * act) + kF32Eps);
+        corr = d == 0 ? t : corr + t;
+      } else {
+        l = normal_log_prob(act, mu, sc);
+        const float e = kNormalEntropyConst + logf(sc);
+        ent = d == 0 ? e : ent + e;
+      }
+      logp = d == 0 ? l : logp + l;
+    }
+    if (squashed) logp = logp - corr;
+    const PolicyTerm pt = ppo_policy_term(logp, logp_old[i], adv[i], hp);
+    float dv;
+    const float vterm = ppo_vf_term(value[i], ret[i], hp, &dv);
+    acc[0] += (double)(with_entropy ? ent : 0.0f);
+    acc[1] += (double)pt.term;
+    acc[2] += (double)vterm;
+    acc[3] += (double)pt.kl;
+    if (HAS_GRAD) {
+      grad_value[i] = hp.grad_scale * hp.vf_coeff * dv;
+      for (int d = 0; d < a; ++d) {
+        const float mu = mean[i * a + d], sc = expf(log_std[i * a + d]);
+        float x = action[i * a + d], pass = 1.0f;
+        if (squashed) {
+          x = squashed_invert(x);
+          const float l = normal_log_prob(x, mu, sc);
+          pass = (l >= -100.0f && l <= 100.0f) ? 1.0f : 0.0f;
+        }
+        const float z = (x - mu) / sc;
+        float gm = -pt.dterm_dlogp * (pass * (z / sc));
+        float gs = -pt.dterm_dlogp * (pass * (z * z - 1.0f));
+        if (with_entropy) gs -= hp.entropy_coeff;
+        grad_mean[i * a + d] = hp.grad_scale * gm;
+        grad_log_std[i * a + d] = hp.grad_scale * gs;
+      }
+    }
+  }
+  block_reduce<kLossCols, SumOp>(acc, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < kLossCols; ++c)
+      partials[(int64_t)blockIdx.x * kPartialWidth + c] = acc[c];
+  }
+}
+
+// out[0..4] = sum entropy, sum policy, sum vf, sample count, sum kl.
+__global__ void ppo_loss_sums_kernel(const double *__restrict__ partials, int rows, double count,
+                                     double *__restrict__ out) {
+  __shared__ double smem[kLossCols * kWavesPerBlock];
+  double acc[kLossCols] = {0.0, 0.0, 0.0, 0.0};
+  for (int r = threadIdx.x; r < rows; r += kBlock) {
+#pragma unroll
+    for (int c = 0; c < kLossCols; ++c) acc[c] += partials[(int64_t)r * kPartialWidth + c];
+  }
+  block_reduce<kLossCols, SumOp>(acc, smem);
+  if (threadIdx.x == 0) {
+    out[0] = acc[0];
+    out[1] = acc[1];
+    out[2] = acc[2];
+    out[3] = count;
+    out[4] = acc[3];
+  }
+}
+
+template <int K>
+static int launch_categorical_vec(const float *logits, const float *value, const int64_t *action,
+                                  const float *logp_old, const float *adv, const float *ret,
+                                  int64_t m, const rl8_ppo_hparams &hp, float *grad_logits,
+                                  float *grad_value, double *partials, int *rows, hipStream_t s) {
+  const int64_t groups = m / 4;
+  const int grid = grid_for(groups, kBlock);
+  if (grad_logits)
+    ppo_loss_categorical_kernel<K, 4, true><<<grid, kBlock, 0, s>>>(
+        logits, value, action, logp_old, adv, ret, m, hp, grad_logits, grad_value, partials);
+  else
+    ppo_loss_categorical_kernel<K, 4, false><<<grid, kBlock, 0, s>>>(
+        logits, value, action, logp_old, adv, ret, m, hp, nullptr, nullptr, partials);
+  *rows = grid;
+  return launch_status();
+}
+
+}  // namespace rl8
+
+using namespace rl8;
+
+static int check_hp(const rl8_ppo_hparams *hp) {
+  if (!hp) return RL8_ENULL;
+  if (!(hp->clip_param > 0.0f && hp->clip_param < 1.0f)) return RL8_ECONFIG;
+  if (!(hp->vf_clip_param > 0.0f)) return RL8_ECONFIG;
+  return RL8_OK;
+}
+
+RL8_API int rl8_ppo_loss_categorical_fwd_bwd_f32(
+    const float *logits, const float *value, const int64_t *action, const float *logp_old,
+    const float *adv, const float *ret, int64_t m, int a, int k, const rl8_ppo_hparams *hp,
+    float *grad_logits, float *grad_value, double *loss_sums_out, void *scratch, void *stream) {
+  if (!logits || !value || !action || !logp_old || !adv || !ret || !loss_sums_out || !scratch)
+    return RL8_ENULL;
+  if ((grad_logits == nullptr) != (grad_value == nullptr)) return RL8_ENULL;
+  if (m <= 0 || a <= 0 || k <= 1 || k > RL8_MAX_CLASSES) return RL8_ESIZE;
+  int st = check_hp(hp);
+  if (st != RL8_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  double *partials = (double *)scratch;
+  int rows = 0;
+  const bool vec_ok = a == 1 && (k == 2 || k == 3) && m >= 4 && aligned16(logits) &&
+                      aligned16(value) && aligned16(action) && aligned16(logp_old) &&
+                      aligned16(adv) && aligned16(ret) &&
+                      (!grad_logits || (aligned16(grad_logits) && aligned16(grad_value)));
+  if (vec_ok) {
+    st = (k == 2) ? launch_categorical_vec<2>(logits, value, action, logp_old, adv, ret, m, *hp,
+                                              grad_logits, grad_value, partials, &rows, s)
+                  : launch_categorical_vec<3>(logits, value, action, logp_old, adv, ret, m, *hp,
+                                              grad_logits, grad_value, partials, &rows, s);
+    if (st != RL8_OK) return st;
+    const int64_t first = (m / 4) * 4;
+    if (first < m) {  // at most 3 samples
+      if (grad_logits)
+        ppo_loss_categorical_generic_kernel<true><<<1, kBlock, 0, s>>>(
+            logits, value, action, logp_old, adv, ret, first, m, a, k, *hp, grad_logits,
+            grad_value, partials, rows);
+      else
+        ppo_loss_categorical_generic_kernel<false><<<1, kBlock, 0, s>>>(
+            logits, value, action, logp_old, adv, ret, first, m, a, k, *hp, nullptr, nullptr,
+            partials, rows);
+      rows += 1;
+    }
+  } else {
+    const int grid = grid_for(m, kBlock);
+    if (grad_logits)
+      ppo_loss_categorical_generic_kernel<true><<<grid, kBlock, 0, s>>>(
+          logits, value, action, logp_old, adv, ret, 0, m, a, k, *hp, grad_logits, grad_value,
+          partials, 0);
+    else
+      ppo_loss_categorical_generic_kernel<false><<<grid, kBlock, 0, s>>>(
+          logits, value, action, logp_old, adv, ret, 0, m, a, k, *hp, nullptr, nullptr, partials,
+          0);
+    rows = grid;
+  }
+  st = launch_status();
+  if (st != RL8_OK) return st;
+  ppo_loss_sums_kernel<<<1, kBlock, 0, s>>>(partials, rows, (double)m, loss_sums_out);
+  return launch_status();
+}
+
+RL8_API int rl8_ppo_loss_normal_fwd_bwd_f32(
+    const float *mean, const float *log_std, const float *value, const float *action,
+    const float *logp_old, const float *adv, const float *ret, int64_t m, int a, int squashed,
+    const rl8_ppo_hparams *hp, float *grad_mean, float *grad_log_std, float *grad_value,
+    double *loss_sums_out, void *scratch, void *stream) {
+  if (!mean || !log_std || !value || !action || !logp_old || !adv || !ret || !loss_sums_out ||
+      !scratch)
+    return RL8_ENULL;
+  const int ng = (grad_mean != nullptr) + (grad_log_std != nullptr) + (grad_value != nullptr);
+  if (ng != 0 && ng != 3) return RL8_ENULL;
+  if (m <= 0 || a <= 0) return RL8_ESIZE;
+  int st = check_hp(hp);
+  if (st != RL8_OK) return st;
+  if (squashed && hp->entropy_coeff != 0.0f) return RL8_ECONFIG;  // distributions.py:153-157
+  hipStream_t s = (hipStream_t)stream;
+  double *partials = (double *)scratch;
+  const int grid = grid_for(m, kBlock);
+  if (ng)
+    ppo_loss_normal_kernel<true><<<grid, kBlock, 0, s>>>(mean, log_std, value, action, logp_old,
+                                                         adv, ret, m, a, squashed, *hp, grad_mean,
+                                                         grad_log_std, grad_value, partials);
+  else
+    ppo_loss_normal_kernel<false><<<grid, kBlock, 0, s>>>(mean, log_std, value, action, logp_old,
+                                                          adv, ret, m, a, squashed, *hp, nullptr,
+                                                          nullptr, nullptr, partials);
+  st = launch_status();
+  if (st != RL8_OK) return st;
+  ppo_loss_sums_kernel<<<1, kBlock, 0, s>>>(partials, grid, (double)m, loss_sums_out);
+  return launch_status();
+}

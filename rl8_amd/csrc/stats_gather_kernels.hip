@@ -1,0 +1,170 @@
+// K6 rollout statistics, K5 minibatch gather, and the ABI housekeeping calls.
+//
+// K6 restates src/rl8/algorithms/_feedforward.py:411-436: per-env returns
+// (sum over the horizon), min / max / mean / unbiased std of returns and of
+// rewards, and std of the reversed discounted returns -- eight eager reductions
+// and nine host syncs in the reference, one pass over 8 B per transition here.
+// Raw fp64 moments are emitted (not means) so that env shards on several GPUs
+// combine with plain SUM / MIN / MAX all-reduces.
+//
+// K5 restates src/rl8/_utils.py:211-225 (Batcher): index-gather of every buffer
+// leaf for one minibatch, all leaves in one launch.
+#include "common.hip.h"
+
+namespace rl8 {
+
+constexpr int kStatCols = 10;
+// partial columns: 0 sum(ret) 1 sum(ret^2) 2 min(ret) 3 max(ret)
+//                  4 sum(r)   5 sum(r^2)   6 min(r)   7 max(r)
+//                  8 sum(rdr) 9 sum(rdr^2)
+
+__global__ __launch_bounds__(kBlock) void rollout_stats_kernel(
+    const float *__restrict__ rewards, const float *__restrict__ rdr, int64_t n, int64_t h,
+    int64_t env_stride, int64_t time_stride, double *__restrict__ partials) {
+  __shared__ double smem[4 * kWavesPerBlock];
+  double sums[6] = {0, 0, 0, 0, 0, 0};  // ret, ret^2, r, r^2, rdr, rdr^2
+  double mins[2] = {INFINITY, INFINITY}, maxs[2] = {-INFINITY, -INFINITY};
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+    const float *rrow = rewards + e * env_stride;
+    float ret = 0.0f;  // torch.sum(rewards[:, :-1], dim=1) accumulates in f32
+    for (int64_t t = 0; t < h; ++t) {
+      const float r = rrow[t * time_stride];
+      ret = ret + r;
+      sums[2] += (double)r;
+      sums[3] += (double)r * (double)r;
+      mins[1] = r < mins[1] ? (double)r : mins[1];
+      maxs[1] = r > maxs[1] ? (double)r : maxs[1];
+    }
+    sums[0] += (double)ret;
+    sums[1] += (double)ret * (double)ret;
+    mins[0] = ret < mins[0] ? (double)ret : mins[0];
+    maxs[0] = ret > maxs[0] ? (double)ret : maxs[0];
+    if (rdr) {
+      const float *drow = rdr + e * env_stride;
+      for (int64_t t = 1; t <= h; ++t) {
+        const double d = (double)drow[t * time_stride];
+        sums[4] += d;
+        sums[5] += d * d;
+      }
+    }
+  }
+  double a4[4] = {sums[0], sums[1], sums[2], sums[3]};
+  block_reduce<4, SumOp>(a4, smem);
+  double b2[2] = {sums[4], sums[5]};
+  block_reduce<2, SumOp>(b2, smem);
+  block_reduce<2, MinOp>(mins, smem);
+  block_reduce<2, MaxOp>(maxs, smem);
+  if (threadIdx.x == 0) {
+    double *row = partials + (int64_t)blockIdx.x * kPartialWidth;
+    row[0] = a4[0]; row[1] = a4[1]; row[2] = mins[0]; row[3] = maxs[0];
+    row[4] = a4[2]; row[5] = a4[3]; row[6] = mins[1]; row[7] = maxs[1];
+    row[8] = b2[0]; row[9] = b2[1];
+  }
+}
+
+__global__ void rollout_stats_finalize_kernel(const double *__restrict__ partials, int rows,
+                                              double n, double nh, double *__restrict__ out) {
+  __shared__ double smem[6 * kWavesPerBlock];
+  double sums[6] = {0, 0, 0, 0, 0, 0};
+  double mins[2] = {INFINITY, INFINITY}, maxs[2] = {-INFINITY, -INFINITY};
+  for (int r = threadIdx.x; r < rows; r += kBlock) {
+    const double *row = partials + (int64_t)r * kPartialWidth;
+    sums[0] += row[0]; sums[1] += row[1]; sums[2] += row[4];
+    sums[3] += row[5]; sums[4] += row[8]; sums[5] += row[9];
+    mins[0] = row[2] < mins[0] ? row[2] : mins[0];
+    maxs[0] = row[3] > maxs[0] ? row[3] : maxs[0];
+    mins[1] = row[6] < mins[1] ? row[6] : mins[1];
+    maxs[1] = row[7] > maxs[1] ? row[7] : maxs[1];
+  }
+  block_reduce<6, SumOp>(sums, smem);
+  block_reduce<2, MinOp>(mins, smem);
+  block_reduce<2, MaxOp>(maxs, smem);
+  if (threadIdx.x == 0) {
+    out[0] = n;   out[1] = sums[0]; out[2] = sums[1]; out[3] = mins[0]; out[4] = maxs[0];
+    out[5] = nh;  out[6] = sums[2]; out[7] = sums[3]; out[8] = mins[1]; out[9] = maxs[1];
+    out[10] = sums[4]; out[11] = sums[5];
+  }
+}
+
+struct GatherArgs {
+  rl8_gather_field f[RL8_MAX_GATHER_FIELDS];
+  int n_fields;
+};
+
+// One lane per (sample, field-element).  Reads are random 4/8-byte accesses
+// (this is a shuffle), writes are dense.
+__global__ __launch_bounds__(kBlock) void gather_minibatch_kernel(
+    const int64_t *__restrict__ index, int64_t m, int64_t h, GatherArgs args) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) {
+    const int64_t s = index[i];
+    const int64_t env = s / h, t = s - env * h;
+#pragma unroll 1
+    for (int f = 0; f < args.n_fields; ++f) {
+      const rl8_gather_field &fd = args.f[f];
+      const int64_t src0 = env * fd.env_stride + t * fd.time_stride;
+      if (fd.elem_bytes == 4) {
+        const uint32_t *src = static_cast<const uint32_t *>(fd.src) + src0;
+        uint32_t *dst = static_cast<uint32_t *>(fd.dst) + i * fd.row_elems;
+        for (int c = 0; c < fd.row_elems; ++c) dst[c] = src[c];
+      } else {
+        const uint64_t *src = static_cast<const uint64_t *>(fd.src) + src0;
+        uint64_t *dst = static_cast<uint64_t *>(fd.dst) + i * fd.row_elems;
+        for (int c = 0; c < fd.row_elems; ++c) dst[c] = src[c];
+      }
+    }
+  }
+}
+
+}  // namespace rl8
+
+using namespace rl8;
+
+RL8_API int rl8_abi_version(char *arch, int arch_len) {
+  if (arch && arch_len > 0) {
+    const char *a = "gfx950";
+    int i = 0;
+    for (; a[i] && i < arch_len - 1; ++i) arch[i] = a[i];
+    arch[i] = 0;
+  }
+  return 100;
+}
+
+RL8_API int64_t rl8_scratch_bytes(void) {
+  return (int64_t)(RL8_MAX_PARTIALS + 8) * kPartialWidth * (int64_t)sizeof(double);
+}
+
+RL8_API int rl8_rollout_stats_f32(const float *rewards, const float *rdr, int64_t n, int64_t h,
+                                  int64_t env_stride, int64_t time_stride, double *stats_out,
+                                  void *scratch, void *stream) {
+  if (!rewards || !stats_out || !scratch) return RL8_ENULL;
+  if (n <= 0 || h <= 0 || env_stride <= 0 || time_stride <= 0) return RL8_ESIZE;
+  hipStream_t s = (hipStream_t)stream;
+  double *partials = (double *)scratch;
+  const int grid = grid_for(n, kBlock);
+  rollout_stats_kernel<<<grid, kBlock, 0, s>>>(rewards, rdr, n, h, env_stride, time_stride,
+                                               partials);
+  int st = launch_status();
+  if (st != RL8_OK) return st;
+  rollout_stats_finalize_kernel<<<1, kBlock, 0, s>>>(partials, grid, (double)n,
+                                                     (double)n * (double)h, stats_out);
+  return launch_status();
+}
+
+RL8_API int rl8_gather_minibatch(const int64_t *index, int64_t m, int64_t h,
+                                 const rl8_gather_field *fields, int n_fields, void *stream) {
+  if (!index || !fields) return RL8_ENULL;
+  if (m <= 0 || h <= 0 || n_fields <= 0 || n_fields > RL8_MAX_GATHER_FIELDS) return RL8_ESIZE;
+  GatherArgs args;
+  args.n_fields = n_fields;
+  for (int f = 0; f < n_fields; ++f) {
+    if (!fields[f].src || !fields[f].dst) return RL8_ENULL;
+    if (fields[f].elem_bytes != 4 && fields[f].elem_bytes != 8) return RL8_ECONFIG;
+    if (fields[f].row_elems <= 0) return RL8_ESIZE;
+    args.f[f] = fields[f];
+  }
+  gather_minibatch_kernel<<<grid_for(m, kBlock), kBlock, 0, (hipStream_t)stream>>>(index, m, h,
+                                                                                 args);
+  return launch_status();
+}

@@ -1,0 +1,532 @@
+"""ctypes binding of ``librl8_amd.so`` (the gfx950 kernels behind
+``include/rl8_amd.h``) for PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: it owns device memory and the stream. Every wrapper
+passes ``tensor.data_ptr()`` and the current HIP stream to the C ABI, checks the
+integer status, and returns. Nothing synchronises.
+
+There is NO CPU fallback: if the shared library is missing, or a tensor is not
+on a HIP device, the call raises.
+
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any, Sequence
+
+import torch
+
+_LIB_NAME = "librl8_amd.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+_lib: None | C.CDLL = None
+
+_ERRORS = {
+    -1: "required pointer is NULL",
+    -2: "size / shape argument out of range",
+    -3: "pointer not aligned as required",
+    -4: "unsupported combination of options",
+}
+
+MAX_CLASSES = 64
+MAX_GATHER_FIELDS = 8
+LAYOUT_ENV_MAJOR = 0
+LAYOUT_TIME_MAJOR = 1
+
+
+class HipExtensionError(RuntimeError):
+    """The HIP extension is missing or a kernel launch failed."""
+
+
+class CartPoleCfg(C.Structure):
+    _fields_ = [
+        ("force_mag", C.c_float),
+        ("gravity", C.c_float),
+        ("length", C.c_float),
+        ("pole_mass", C.c_float),
+        ("pole_mass_length", C.c_float),
+        ("total_mass", C.c_float),
+        ("tau", C.c_float),
+        ("semi_implicit", C.c_int32),
+    ]
+
+
+class PPOHparams(C.Structure):
+    _fields_ = [
+        ("clip_param", C.c_float),
+        ("dual_clip_param", C.c_float),
+        ("entropy_coeff", C.c_float),
+        ("vf_clip_param", C.c_float),
+        ("vf_coeff", C.c_float),
+        ("grad_scale", C.c_float),
+    ]
+
+
+class GatherField(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p),
+        ("dst", C.c_void_p),
+        ("env_stride", C.c_int64),
+        ("time_stride", C.c_int64),
+        ("row_elems", C.c_int32),
+        ("elem_bytes", C.c_int32),
+    ]
+
+
+_vp, _i64, _u64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_float
+
+# name -> argtypes, mirroring include/rl8_amd.h one to one.
+SIGNATURES: dict[str, list[Any]] = {
+    "rl8_abi_version": [C.c_char_p, _i32],
+    "rl8_scratch_bytes": [],
+    "rl8_dummy_env_step_f32": [_vp, _vp, _i32, _vp, _i64, _vp],
+    "rl8_dummy_env_reset_f32": [_vp, _i64, _f32, _u64, _u64, _i64, _vp],
+    "rl8_cartpole_step_f32": [_vp, _vp, C.POINTER(CartPoleCfg), _vp, _i64, _vp, _i64, _vp],
+    "rl8_cartpole_reset_f32": [_vp, _i64, _f32, _u64, _u64, _i64, _vp, _i64, _vp],
+    "rl8_categorical_sample_logp_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _u64, _u64, _i64, _i32, _vp],
+    "rl8_normal_sample_logp_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _u64, _u64, _i64, _i32, _vp],
+    "rl8_rollout_scatter_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp],
+    "rl8_rollout_step_dummy_f32": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _u64, _u64, _i64, _i32, _vp],
+    "rl8_rollout_step_cartpole_f32": [_vp, _vp, _vp, _vp, C.POINTER(CartPoleCfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _u64, _u64, _i64, _i32, _vp],
+    "rl8_rollout_stats_f32": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
+    "rl8_gae_scan_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _f32, _f32, _i32, _vp, _vp, _vp],
+    "rl8_advantage_normalise_f32": [_vp, _i64, _i64, _i32, _vp, _vp],
+    "rl8_ppo_loss_categorical_fwd_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(PPOHparams), _vp, _vp, _vp, _vp, _vp],
+    "rl8_ppo_loss_normal_fwd_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(PPOHparams), _vp, _vp, _vp, _vp, _vp, _vp],
+    "rl8_gather_minibatch": [_vp, _i64, _i64, C.POINTER(GatherField), _i32, _vp],
+}
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the extension (after torch, so that the HIP runtime torch already
+    mapped -- soname ``libamdhip64.so.7`` -- is the one the kernels launch on)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise HipExtensionError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import"
+                " __graft_entry__ as g; g.build()'` (or `make -C rl8_amd/csrc`)."
+                " rl8_amd has no CPU fallback."
+            )
+        lib = C.CDLL(_LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int64 if name == "rl8_scratch_bytes" else C.c_int
+        _lib = lib
+    return _lib
+
+
+def _check(status: int, name: str) -> None:
+    if status == 0:
+        return
+    if status < 0:
+        raise ValueError(f"{name}: {_ERRORS.get(status, 'argument check failed')} ({status})")
+    raise HipExtensionError(f"{name}: HIP launch failed with hipError_t {status}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: None | torch.Tensor) -> None | int:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipExtensionError(
+            "rl8_amd kernels take HIP device tensors only (got a"
+            f" {t.device} tensor); there is no CPU fallback."
+        )
+    return t.data_ptr()
+
+
+def _dense(t: torch.Tensor, dtype: torch.dtype, what: str) -> torch.Tensor:
+    if t.dtype != dtype:
+        raise TypeError(f"{what} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{what} must be contiguous")
+    return t
+
+
+_scratch: dict[tuple[int, int], torch.Tensor] = {}
+
+
+def scratch(device: torch.device) -> torch.Tensor:
+    """Per (device, stream) reduction scratch, allocated once."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    buf = _scratch.get(key)
+    if buf is None:
+        nbytes = int(load().rl8_scratch_bytes())
+        buf = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def abi_version() -> tuple[int, str]:
+    buf = C.create_string_buffer(16)
+    v = load().rl8_abi_version(buf, 16)
+    return int(v), buf.value.decode()
+
+
+# --------------------------------------------------------------------------- #
+# Environments.
+# --------------------------------------------------------------------------- #
+def dummy_env_step(state: torch.Tensor, action: torch.Tensor, reward_out: torch.Tensor) -> None:
+    n = state.numel()
+    discrete = action.dtype == torch.int64
+    if not discrete and action.dtype != torch.float32:
+        raise TypeError(f"dummy env actions must be int64 or float32, got {action.dtype}")
+    _dense(state, torch.float32, "state")
+    _dense(reward_out, torch.float32, "reward_out")
+    if action.numel() != n or reward_out.numel() != n or not action.is_contiguous():
+        raise ValueError("state, action and reward_out must be dense with one element per env")
+    _check(
+        load().rl8_dummy_env_step_f32(_ptr(state), _ptr(action), int(discrete), _ptr(reward_out), n, _stream()),
+        "rl8_dummy_env_step_f32",
+    )
+
+
+def dummy_env_reset(state: torch.Tensor, bounds: float, seed: int, reset_count: int, env_offset: int = 0) -> None:
+    _dense(state, torch.float32, "state")
+    _check(
+        load().rl8_dummy_env_reset_f32(_ptr(state), state.numel(), bounds, seed, reset_count, env_offset, _stream()),
+        "rl8_dummy_env_reset_f32",
+    )
+
+
+def cartpole_step(state: torch.Tensor, action: torch.Tensor, cfg: CartPoleCfg, obs_out: torch.Tensor, reward_out: torch.Tensor) -> None:
+    _dense(state, torch.float32, "state")
+    _dense(action, torch.int64, "action")
+    _dense(obs_out, torch.float32, "obs_out")
+    _dense(reward_out, torch.float32, "reward_out")
+    n = state.shape[1]
+    if state.shape[0] != 4 or action.numel() != n or obs_out.numel() != 5 * n or reward_out.numel() != n:
+        raise ValueError("cartpole_step: state [4,N], action [N,1], obs_out [N,5], reward_out [N,1]")
+    _check(
+        load().rl8_cartpole_step_f32(_ptr(state), _ptr(action), C.byref(cfg), _ptr(obs_out), 5, _ptr(reward_out), n, _stream()),
+        "rl8_cartpole_step_f32",
+    )
+
+
+def cartpole_reset(state: torch.Tensor, std: float, seed: int, reset_count: int, env_offset: int, obs_out: None | torch.Tensor) -> None:
+    _dense(state, torch.float32, "state")
+    n = state.shape[1]
+    if obs_out is not None:
+        _dense(obs_out, torch.float32, "obs_out")
+        if obs_out.numel() != 5 * n:
+            raise ValueError("obs_out must be [N,5]")
+    _check(
+        load().rl8_cartpole_reset_f32(_ptr(state), n, std, seed, reset_count, env_offset, _ptr(obs_out), 5, _stream()),
+        "rl8_cartpole_reset_f32",
+    )
+
+
+# --------------------------------------------------------------------------- #
+# Samplers.
+# --------------------------------------------------------------------------- #
+def categorical_sample_logp(
+    logits: torch.Tensor,
+    noise: None | torch.Tensor,
+    *,
+    seed: int = 0,
+    step: int = 0,
+    row_offset: int = 0,
+    deterministic: bool = False,
+) -> tuple[torch.Tensor, torch.Tensor]:
+    """logits [M, A, K] -> (actions [M, A] int64, logp [M, 1])."""
+    logits = _dense(logits.detach(), torch.float32, "logits")
+    m, a, k = logits.shape
+    if noise is not None:
+        noise = _dense(noise, torch.float32, "noise")
+        if noise.shape != logits.shape:
+            raise ValueError("noise must have the shape of logits")
+    actions = torch.empty(m, a, dtype=torch.int64, device=logits.device)
+    logp = torch.empty(m, 1, dtype=torch.float32, device=logits.device)
+    _check(
+        load().rl8_categorical_sample_logp_f32(
+            _ptr(logits), _ptr(noise), _ptr(actions), _ptr(logp), m, a, k, seed, step, row_offset,
+            int(deterministic), _stream(),
+        ),
+        "rl8_categorical_sample_logp_f32",
+    )
+    return actions, logp
+
+
+def normal_sample_logp(
+    mean: torch.Tensor,
+    log_std: torch.Tensor,
+    noise: None | torch.Tensor,
+    *,
+    squashed: bool,
+    seed: int = 0,
+    step: int = 0,
+    row_offset: int = 0,
+    deterministic: bool = False,
+) -> tuple[torch.Tensor, torch.Tensor]:
+    mean = _dense(mean.detach(), torch.float32, "mean")
+    log_std = _dense(log_std.detach(), torch.float32, "log_std")
+    m, a = mean.shape
+    if log_std.shape != mean.shape:
+        raise ValueError("mean and log_std must have the same shape")
+    if noise is not None:
+        noise = _dense(noise, torch.float32, "noise")
+        if noise.shape != mean.shape:
+            raise ValueError("noise must have the shape of mean")
+    actions = torch.empty(m, a, dtype=torch.float32, device=mean.device)
+    logp = torch.empty(m, 1, dtype=torch.float32, device=mean.device)
+    _check(
+        load().rl8_normal_sample_logp_f32(
+            _ptr(mean), _ptr(log_std), _ptr(noise), _ptr(actions), _ptr(logp), m, a, int(squashed),
+            seed, step, row_offset, int(deterministic), _stream(),
+        ),
+        "rl8_normal_sample_logp_f32",
+    )
+    return actions, logp
+
+
+# --------------------------------------------------------------------------- #
+# Rollout bookkeeping.
+# --------------------------------------------------------------------------- #
+def rollout_scatter(
+    action: torch.Tensor, logp: torch.Tensor, value: torch.Tensor, reward: torch.Tensor, obs: torch.Tensor,
+    action_col: torch.Tensor, logp_col: torch.Tensor, value_col: torch.Tensor, reward_col: torch.Tensor,
+    obs_col_next: torch.Tensor, rdr_t: None | torch.Tensor, rdr_t1: None | torch.Tensor, gamma: float,
+) -> None:
+    n = logp.shape[0]
+    for name, t in (("action", action), ("logp", logp), ("value", value), ("reward", reward), ("obs", obs),
+                    ("action_col", action_col), ("logp_col", logp_col), ("value_col", value_col),
+                    ("reward_col", reward_col), ("obs_col_next", obs_col_next)):
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+    if action.dtype != action_col.dtype or action.numel() != action_col.numel():
+        raise ValueError("action and action_col must match")
+    if obs.numel() != obs_col_next.numel() or obs.dtype != torch.float32:
+        raise ValueError("obs and obs_col_next must match (float32)")
+    _check(
+        load().rl8_rollout_scatter_f32(
+            _ptr(action), action.element_size() * (action.numel() // n), _ptr(logp), _ptr(value), _ptr(reward),
+            _ptr(obs), obs.numel() // n, _ptr(action_col), _ptr(logp_col), _ptr(value_col), _ptr(reward_col),
+            _ptr(obs_col_next), _ptr(rdr_t), _ptr(rdr_t1), gamma, n, _stream(),
+        ),
+        "rl8_rollout_scatter_f32",
+    )
+
+
+def rollout_step_dummy(
+    *, discrete: bool, squashed: bool, features: torch.Tensor, features2: None | torch.Tensor, value: torch.Tensor,
+    noise: None | torch.Tensor, state: torch.Tensor, action_col: torch.Tensor, logp_col: torch.Tensor,
+    value_col: torch.Tensor, reward_col: torch.Tensor, obs_col_next: torch.Tensor, rdr_t: None | torch.Tensor,
+    rdr_t1: None | torch.Tensor, gamma: float, seed: int, step: int, env_offset: int, deterministic: bool,
+) -> None:
+    n = state.numel()
+    tensors = [features, value, state, action_col, logp_col, value_col, reward_col, obs_col_next]
+    tensors += [t for t in (features2, noise, rdr_t, rdr_t1) if t is not None]
+    for t in tensors:
+        if not t.is_contiguous():
+            raise ValueError("rollout_step_dummy: all tensors must be contiguous")
+    want_feat = 2 * n if discrete else n
+    if features.numel() != want_feat or value.numel() != n or action_col.numel() != n:
+        raise ValueError("rollout_step_dummy: shape mismatch")
+    if noise is not None and noise.numel() != want_feat:
+        raise ValueError("rollout_step_dummy: noise shape mismatch")
+    if action_col.dtype != (torch.int64 if discrete else torch.float32):
+        raise TypeError("rollout_step_dummy: action column dtype mismatch")
+    for t in (logp_col, value_col, reward_col, obs_col_next):
+        if t.numel() != n or t.dtype != torch.float32:
+            raise ValueError("rollout_step_dummy: column shape/dtype mismatch")
+    _check(
+        load().rl8_rollout_step_dummy_f32(
+            int(discrete), int(squashed), _ptr(features), _ptr(features2), _ptr(value), _ptr(noise), _ptr(state),
+            _ptr(action_col), _ptr(logp_col), _ptr(value_col), _ptr(reward_col), _ptr(obs_col_next),
+            _ptr(rdr_t), _ptr(rdr_t1), gamma, n, seed, step, env_offset, int(deterministic), _stream(),
+        ),
+        "rl8_rollout_step_dummy_f32",
+    )
+
+
+def rollout_step_cartpole(
+    *, logits: torch.Tensor, value: torch.Tensor, noise: None | torch.Tensor, state: torch.Tensor, cfg: CartPoleCfg,
+    action_col: torch.Tensor, logp_col: torch.Tensor, value_col: torch.Tensor, reward_col: torch.Tensor,
+    obs_col_next: torch.Tensor, rdr_t: None | torch.Tensor, rdr_t1: None | torch.Tensor, gamma: float, seed: int,
+    step: int, env_offset: int, deterministic: bool,
+) -> None:
+    n = state.shape[1]
+    tensors = [logits, value, state, action_col, logp_col, value_col, reward_col, obs_col_next]
+    tensors += [t for t in (noise, rdr_t, rdr_t1) if t is not None]
+    for t in tensors:
+        if not t.is_contiguous():
+            raise ValueError("rollout_step_cartpole: all tensors must be contiguous")
+    if logits.numel() != 3 * n or value.numel() != n or obs_col_next.numel() != 5 * n or action_col.numel() != n:
+        raise ValueError("rollout_step_cartpole: shape mismatch")
+    if noise is not None and noise.numel() != 3 * n:
+        raise ValueError("rollout_step_cartpole: noise shape mismatch")
+    _check(
+        load().rl8_rollout_step_cartpole_f32(
+            _ptr(logits), _ptr(value), _ptr(noise), _ptr(state), C.byref(cfg), _ptr(action_col), _ptr(logp_col),
+            _ptr(value_col), _ptr(reward_col), _ptr(obs_col_next), _ptr(rdr_t), _ptr(rdr_t1), gamma, n, seed,
+            step, env_offset, int(deterministic), _stream(),
+        ),
+        "rl8_rollout_step_cartpole_f32",
+    )
+
+
+def buffer_layout(leaf: torch.Tensor) -> tuple[int, int, int]:
+    """(layout, env_stride, time_stride) of a [N, T, 1] (or [N, T]) buffer leaf."""
+    n, t = leaf.shape[0], leaf.shape[1]
+    es, ts = leaf.stride(0), leaf.stride(1)
+    if leaf.ndim == 3 and leaf.shape[2] != 1:
+        raise ValueError("expected a [N, T, 1] leaf")
+    if (ts == 1 or t == 1) and (es == t or n == 1):
+        return LAYOUT_ENV_MAJOR, es, ts
+    if (es == 1 or n == 1) and (ts == n or t == 1):
+        return LAYOUT_TIME_MAJOR, es, ts
+    return -1, es, ts
+
+
+def rollout_stats(rewards: torch.Tensor, rdr: None | torch.Tensor) -> torch.Tensor:
+    """rewards / rdr [N, H+1, 1] in either layout -> 12 raw moments (fp64, device)."""
+    n, h1 = rewards.shape[0], rewards.shape[1]
+    _, es, ts = buffer_layout(rewards)
+    if rewards.dtype != torch.float32:
+        raise TypeError("rewards must be float32")
+    if rdr is not None and (rdr.stride() != rewards.stride() or rdr.shape != rewards.shape):
+        raise ValueError("rdr must share the layout of rewards")
+    out = torch.empty(12, dtype=torch.float64, device=rewards.device)
+    _check(
+        load().rl8_rollout_stats_f32(_ptr(rewards), _ptr(rdr), n, h1 - 1, es, ts, _ptr(out),
+                                     _ptr(scratch(rewards.device)), _stream()),
+        "rl8_rollout_stats_f32",
+    )
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# GAE.
+# --------------------------------------------------------------------------- #
+def gae_scan(
+    rewards: torch.Tensor, values: torch.Tensor, adv: torch.Tensor, ret: torch.Tensor, *, layout: int,
+    n: int, h: int, gamma: float, gamma_lambda: float, reward_denominator: float, write_scaled_rewards: bool,
+) -> torch.Tensor:
+    """Launches the scan; returns the device moments tensor (count, sum, sumsq)."""
+    moments = torch.empty(3, dtype=torch.float64, device=rewards.device)
+    _check(
+        load().rl8_gae_scan_f32(
+            _ptr(rewards), _ptr(values), _ptr(adv), _ptr(ret), n, h, layout, gamma, gamma_lambda,
+            reward_denominator, int(write_scaled_rewards), _ptr(moments), _ptr(scratch(rewards.device)), _stream(),
+        ),
+        "rl8_gae_scan_f32",
+    )
+    return moments
+
+
+def advantage_normalise(adv: torch.Tensor, *, layout: int, n: int, h: int, moments: torch.Tensor) -> None:
+    if moments.dtype != torch.float64 or moments.numel() < 3:
+        raise TypeError("moments must be 3 float64 values")
+    _check(
+        load().rl8_advantage_normalise_f32(_ptr(adv), n, h, layout, _ptr(moments), _stream()),
+        "rl8_advantage_normalise_f32",
+    )
+
+
+# --------------------------------------------------------------------------- #
+# PPO loss.
+# --------------------------------------------------------------------------- #
+def ppo_hparams(
+    *, clip_param: float, dual_clip_param: None | float, entropy_coeff: float, vf_clip_param: float,
+    vf_coeff: float, grad_scale: float,
+) -> PPOHparams:
+    return PPOHparams(clip_param, dual_clip_param if dual_clip_param else 0.0, entropy_coeff, vf_clip_param,
+                      vf_coeff, grad_scale)
+
+
+def _loss_inputs(m: int, *named: tuple[str, torch.Tensor, torch.dtype, int]) -> None:
+    for name, t, dtype, numel in named:
+        _dense(t, dtype, name)
+        if t.numel() != numel:
+            raise ValueError(f"{name} has {t.numel()} elements, expected {numel} for M={m}")
+
+
+def ppo_loss_categorical(
+    logits: torch.Tensor, value: torch.Tensor, action: torch.Tensor, logp_old: torch.Tensor, adv: torch.Tensor,
+    ret: torch.Tensor, hp: PPOHparams, *, with_grad: bool = True,
+) -> tuple[torch.Tensor, None | torch.Tensor, None | torch.Tensor]:
+    """Returns (loss_sums[5] fp64 device, grad_logits, grad_value)."""
+    m, a, k = logits.shape
+    _loss_inputs(m, ("logits", logits, torch.float32, m * a * k), ("value", value, torch.float32, m),
+                 ("action", action, torch.int64, m * a), ("logp_old", logp_old, torch.float32, m),
+                 ("adv", adv, torch.float32, m), ("ret", ret, torch.float32, m))
+    sums = torch.empty(5, dtype=torch.float64, device=logits.device)
+    g_logits = torch.empty_like(logits) if with_grad else None
+    g_value = torch.empty_like(value) if with_grad else None
+    _check(
+        load().rl8_ppo_loss_categorical_fwd_bwd_f32(
+            _ptr(logits), _ptr(value), _ptr(action), _ptr(logp_old), _ptr(adv), _ptr(ret), m, a, k, C.byref(hp),
+            _ptr(g_logits), _ptr(g_value), _ptr(sums), _ptr(scratch(logits.device)), _stream(),
+        ),
+        "rl8_ppo_loss_categorical_fwd_bwd_f32",
+    )
+    return sums, g_logits, g_value
+
+
+def ppo_loss_normal(
+    mean: torch.Tensor, log_std: torch.Tensor, value: torch.Tensor, action: torch.Tensor, logp_old: torch.Tensor,
+    adv: torch.Tensor, ret: torch.Tensor, hp: PPOHparams, *, squashed: bool, with_grad: bool = True,
+):
+    m, a = mean.shape
+    _loss_inputs(m, ("mean", mean, torch.float32, m * a), ("log_std", log_std, torch.float32, m * a),
+                 ("value", value, torch.float32, m), ("action", action, torch.float32, m * a),
+                 ("logp_old", logp_old, torch.float32, m), ("adv", adv, torch.float32, m),
+                 ("ret", ret, torch.float32, m))
+    sums = torch.empty(5, dtype=torch.float64, device=mean.device)
+    g_mean = torch.empty_like(mean) if with_grad else None
+    g_ls = torch.empty_like(log_std) if with_grad else None
+    g_value = torch.empty_like(value) if with_grad else None
+    _check(
+        load().rl8_ppo_loss_normal_fwd_bwd_f32(
+            _ptr(mean), _ptr(log_std), _ptr(value), _ptr(action), _ptr(logp_old), _ptr(adv), _ptr(ret), m, a,
+            int(squashed), C.byref(hp), _ptr(g_mean), _ptr(g_ls), _ptr(g_value), _ptr(sums),
+            _ptr(scratch(mean.device)), _stream(),
+        ),
+        "rl8_ppo_loss_normal_fwd_bwd_f32",
+    )
+    return sums, g_mean, g_ls, g_value
+
+
+# --------------------------------------------------------------------------- #
+# Minibatch gather.
+# --------------------------------------------------------------------------- #
+def gather_minibatch(index: torch.Tensor, h: int, leaves: Sequence[torch.Tensor]) -> list[torch.Tensor]:
+    """index [M] int64 of reference sample ids (env*H + t); leaves are [N, T, d]
+    buffer leaves (any stride over env/time, dense over d). Returns dense [M, d]
+    tensors."""
+    _dense(index, torch.int64, "index")
+    m = index.numel()
+    if len(leaves) > MAX_GATHER_FIELDS:
+        raise ValueError(f"at most {MAX_GATHER_FIELDS} leaves per gather")
+    fields = (GatherField * len(leaves))()
+    outs = []
+    for i, leaf in enumerate(leaves):
+        if leaf.ndim < 2:
+            raise ValueError("leaves must be [N, T, ...]")
+        trailing = leaf.shape[2:]
+        row = 1
+        for d in trailing:
+            row *= d
+        # trailing dims must be dense
+        expect = 1
+        for d, st in zip(reversed(trailing), reversed(leaf.stride()[2:])):
+            if d != 1 and st != expect:
+                raise ValueError("leaf trailing dims must be dense")
+            expect *= d
+        if leaf.element_size() not in (4, 8):
+            raise TypeError("leaf elements must be 4 or 8 bytes wide")
+        dst = torch.empty((m, *trailing), dtype=leaf.dtype, device=leaf.device)
+        fields[i] = GatherField(_ptr(leaf), _ptr(dst), leaf.stride(0), leaf.stride(1), row, leaf.element_size())
+        outs.append(dst)
+    _check(load().rl8_gather_minibatch(_ptr(index), m, h, fields, len(leaves), _stream()), "rl8_gather_minibatch")
+    return outs

@@ -1,0 +1,499 @@
+"""Parity of the gfx950 kernels (called through the C ABI via rl8_amd.hip)
+against the CPU oracle on identical seeded inputs, and against the reference's
+golden vectors.
+
+Bars: bit-exact for action indices, gathers, and add/mul/div-only arithmetic
+(dummy env, GAE scan and normalisation, RDR recurrence); 1e-6 absolute for
+CartPole physics (sin/cos differ by an ulp between libms; the reference's own
+compiled and eager steps differ by as much); 1e-5 relative for losses / 2e-5 for
+their gradients (north_star tolerance).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle  # noqa: E402  (checker only)
+
+from rl8_amd import hip  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def test_abi_loads_on_device():
+    version, arch = hip.abi_version()
+    assert version == 100 and arch == "gfx950"
+    assert torch.cuda.get_device_properties(0).gcnArchName.startswith("gfx950")
+
+
+# --------------------------------------------------------------------------- #
+# GAE
+# --------------------------------------------------------------------------- #
+def run_gae(rewards, values, *, layout, gamma, lam, scale, norm, write_back=True):
+    """rewards/values numpy env-major [N, H+1, 1]; returns numpy env-major outputs."""
+    n, h1 = rewards.shape[:2]
+    h = h1 - 1
+    if layout == hip.LAYOUT_TIME_MAJOR:
+        r = dev(rewards.reshape(n, h1).T.copy())
+        v = dev(values.reshape(n, h1).T.copy())
+    else:
+        r = dev(rewards.reshape(n, h1))
+        v = dev(values.reshape(n, h1))
+    adv = torch.full_like(r, 123.0)
+    ret = torch.full_like(r, 456.0)
+    denom = float(np.float32(scale + 1e-8))
+    moments = hip.gae_scan(
+        r, v, adv, ret, layout=layout, n=n, h=h, gamma=float(np.float32(gamma)),
+        gamma_lambda=float(np.float32(gamma * lam)), reward_denominator=denom, write_scaled_rewards=write_back,
+    )
+    if norm:
+        hip.advantage_normalise(adv, layout=layout, n=n, h=h, moments=moments)
+    torch.cuda.synchronize()
+
+    def back(t):
+        a = host(t)
+        if layout == hip.LAYOUT_TIME_MAJOR:
+            a = a.T
+        return a.reshape(n, h1, 1)
+
+    return back(r), back(adv), back(ret), host(moments)
+
+
+@pytest.mark.parametrize("layout", [hip.LAYOUT_ENV_MAJOR, hip.LAYOUT_TIME_MAJOR])
+def test_gae_matches_reference_golden_bit_exact(golden, layout):
+    g = golden("gae.npz")
+    for case in g["cases"]:
+        gamma, lam, scale, norm = g[f"{case}_params"]
+        r, adv, ret, _ = run_gae(g[f"{case}_rewards"], g[f"{case}_values"], layout=layout, gamma=gamma,
+                                 lam=lam, scale=scale, norm=bool(norm))
+        assert np.array_equal(r, g[f"{case}_scaled_rewards"]), case
+        assert np.array_equal(ret, g[f"{case}_returns"]), case
+        assert np.array_equal(adv, g[f"{case}_advantages"]), case
+
+
+@pytest.mark.parametrize("layout", [hip.LAYOUT_ENV_MAJOR, hip.LAYOUT_TIME_MAJOR])
+def test_gae_known_answer(layout):
+    # tests/test_nn/test_functional.py:14-49 of the reference
+    ones = np.ones((10, 6, 1), np.float32)
+    _, adv, ret, _ = run_gae(ones, ones, layout=layout, gamma=1.0, lam=1.0, scale=1.0, norm=False)
+    undiscounted = np.flip(np.cumsum(ones, axis=1), axis=1)
+    assert np.array_equal(adv, undiscounted - 1)
+    assert np.array_equal(ret, undiscounted)
+
+
+@pytest.mark.parametrize("layout", [hip.LAYOUT_ENV_MAJOR, hip.LAYOUT_TIME_MAJOR])
+@pytest.mark.parametrize("n,h", [(1, 1), (5, 3), (1000, 32), (4096, 32), (777, 128), (300, 400), (8192, 33)])
+def test_gae_vs_oracle_shapes(layout, n, h):
+    rng = np.random.default_rng(n * 1000 + h)
+    rewards = -np.abs(rng.uniform(-100, 100, (n, h + 1, 1))).astype(np.float32)
+    values = rng.standard_normal((n, h + 1, 1)).astype(np.float32)
+    want = oracle.gae(rewards, values, gamma=0.95, gae_lambda=0.9, reward_scale=41.5, normalize_advantages=n * h > 1)
+    r, adv, ret, moments = run_gae(rewards, values, layout=layout, gamma=0.95, lam=0.9, scale=41.5, norm=n * h > 1)
+    assert np.array_equal(r, want["scaled_rewards"])
+    assert np.array_equal(ret, want["returns"])
+    assert np.array_equal(adv, want["advantages"])
+    assert moments[0] == n * h
+
+
+def test_gae_without_write_back_leaves_rewards():
+    rng = np.random.default_rng(5)
+    rewards = rng.standard_normal((64, 9, 1)).astype(np.float32)
+    values = rng.standard_normal((64, 9, 1)).astype(np.float32)
+    want = oracle.gae(rewards, values, reward_scale=3.0, normalize_advantages=False)
+    for layout in (hip.LAYOUT_ENV_MAJOR, hip.LAYOUT_TIME_MAJOR):
+        r, adv, ret, _ = run_gae(rewards, values, layout=layout, gamma=0.95, lam=0.95, scale=3.0, norm=False,
+                                 write_back=False)
+        assert np.array_equal(r, rewards)
+        assert np.array_equal(adv, want["advantages"])
+        assert np.array_equal(ret, want["returns"])
+
+
+def test_gae_argument_checks():
+    t = torch.zeros(8, device=DEV)
+    with pytest.raises(ValueError):
+        hip.gae_scan(t, t, t, t, layout=1, n=0, h=1, gamma=1.0, gamma_lambda=1.0, reward_denominator=1.0,
+                     write_scaled_rewards=False)
+    with pytest.raises(ValueError):
+        hip.gae_scan(t, t, t, t, layout=7, n=2, h=3, gamma=1.0, gamma_lambda=1.0, reward_denominator=1.0,
+                     write_scaled_rewards=False)
+    with pytest.raises(hip.HipExtensionError):
+        hip.gae_scan(t.cpu(), t, t, t, layout=1, n=2, h=3, gamma=1.0, gamma_lambda=1.0, reward_denominator=1.0,
+                     write_scaled_rewards=False)
+
+
+# --------------------------------------------------------------------------- #
+# PPO loss
+# --------------------------------------------------------------------------- #
+def _hp_from(arr, m, gas=1):
+    clip, dual, ent, vfclip, vfc = (float(x) for x in arr)
+    return dict(clip_param=clip, dual_clip_param=dual or None, entropy_coeff=ent, vf_clip_param=vfclip, vf_coeff=vfc), \
+        1.0 / (m * gas)
+
+
+def _losses_from_sums(sums, kw, gas=1):
+    ent_s, pol_s, vf_s, cnt, kl_s = sums
+    ent = ent_s / cnt if kw["entropy_coeff"] != 0 else 0.0
+    pol, vf = pol_s / cnt, vf_s / cnt
+    total = kw["vf_coeff"] * vf - pol - (kw["entropy_coeff"] * ent if kw["entropy_coeff"] != 0 else 0.0)
+    return [ent / gas, pol / gas, vf / gas, total / gas, kl_s / cnt]
+
+
+def test_ppo_loss_matches_reference_autograd(golden):
+    g = golden("ppo_losses.npz")
+    for case in g["cases"]:
+        m = g[f"{case}_values"].shape[0]
+        kw, gscale = _hp_from(g[f"{case}_hparams"], m)
+        hp = hip.ppo_hparams(grad_scale=gscale, **kw)
+        common = [dev(g[f"{case}_values"])]
+        tail = [dev(g[f"{case}_logp_old"]), dev(g[f"{case}_advantages"]), dev(g[f"{case}_returns"])]
+        if case.startswith("cat"):
+            sums, g_logits, g_value = hip.ppo_loss_categorical(
+                dev(g[f"{case}_feat_logits"]), common[0], dev(g[f"{case}_actions"]), *tail, hp)
+            np.testing.assert_allclose(host(g_logits), g[f"{case}_grad_logits"], rtol=2e-5, atol=1e-8, err_msg=case)
+        else:
+            sums, g_mean, g_ls, g_value = hip.ppo_loss_normal(
+                dev(g[f"{case}_feat_mean"]), dev(g[f"{case}_feat_log_std"]), common[0], dev(g[f"{case}_actions"]),
+                *tail, hp, squashed=case.startswith("squashed"))
+            np.testing.assert_allclose(host(g_mean), g[f"{case}_grad_mean"], rtol=1e-4, atol=1e-7, err_msg=case)
+            np.testing.assert_allclose(host(g_ls), g[f"{case}_grad_log_std"], rtol=1e-4, atol=1e-7, err_msg=case)
+        np.testing.assert_allclose(host(g_value), g[f"{case}_grad_values"], rtol=2e-5, atol=1e-9, err_msg=case)
+        got = _losses_from_sums(host(sums), kw)
+        for i, name in enumerate(oracle.LOSS_KEYS):
+            assert got[i] == pytest.approx(g[f"{case}_losses"][i], rel=1e-5, abs=1e-7), (case, name)
+
+
+@pytest.mark.parametrize("m", [1, 3, 4, 7, 1025, 65536 + 3])
+@pytest.mark.parametrize("k", [2, 3, 6])
+def test_ppo_loss_categorical_vs_oracle(m, k):
+    rng = np.random.default_rng(m * 10 + k)
+    logits = (rng.standard_normal((m, 1, k)) * 1.5).astype(np.float32)
+    values = rng.standard_normal((m, 1)).astype(np.float32) * 3
+    returns = values + rng.standard_normal((m, 1)).astype(np.float32) * 2
+    actions = rng.integers(0, k, (m, 1))
+    logp_old = (np.log(1.0 / k) + rng.standard_normal((m, 1)) * 0.3).astype(np.float32)
+    adv = rng.standard_normal((m, 1)).astype(np.float32)
+    kw = dict(clip_param=0.2, dual_clip_param=5.0, entropy_coeff=1e-2, vf_clip_param=5.0, vf_coeff=0.7)
+    gas = 4
+    want, wg_logits, wg_values = oracle.ppo_loss_categorical(
+        logits, values, actions, logp_old, adv, returns, oracle.ppo_hparams(grad_accumulation_steps=gas, **kw))
+    hp = hip.ppo_hparams(grad_scale=1.0 / (m * gas), **kw)
+    sums, g_logits, g_value = hip.ppo_loss_categorical(
+        dev(logits), dev(values), dev(actions), dev(logp_old), dev(adv), dev(returns), hp)
+    got = _losses_from_sums(host(sums), kw, gas)
+    for i, name in enumerate(oracle.LOSS_KEYS):
+        assert got[i] == pytest.approx(want[name], rel=1e-5, abs=1e-7), name
+    np.testing.assert_allclose(host(g_logits), wg_logits, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(host(g_value), wg_values, rtol=2e-5, atol=1e-10)
+    # forward-only launch gives the same sums
+    sums2, none1, none2 = hip.ppo_loss_categorical(
+        dev(logits), dev(values), dev(actions), dev(logp_old), dev(adv), dev(returns), hp, with_grad=False)
+    assert none1 is None and none2 is None
+    assert np.array_equal(host(sums2), host(sums))
+
+
+def test_ppo_loss_multi_action_dims_vs_oracle():
+    rng = np.random.default_rng(9)
+    m, a, k = 513, 3, 4
+    logits = rng.standard_normal((m, a, k)).astype(np.float32)
+    values = rng.standard_normal((m, 1)).astype(np.float32)
+    returns = rng.standard_normal((m, 1)).astype(np.float32)
+    actions = rng.integers(0, k, (m, a))
+    logp_old = (a * np.log(1.0 / k) + rng.standard_normal((m, 1)) * 0.3).astype(np.float32)
+    adv = rng.standard_normal((m, 1)).astype(np.float32)
+    kw = dict(clip_param=0.2, dual_clip_param=None, entropy_coeff=1e-2, vf_clip_param=5.0, vf_coeff=1.0)
+    want, wg_logits, wg_values = oracle.ppo_loss_categorical(logits, values, actions, logp_old, adv, returns,
+                                                             oracle.ppo_hparams(**kw))
+    sums, g_logits, g_value = hip.ppo_loss_categorical(
+        dev(logits), dev(values), dev(actions), dev(logp_old), dev(adv), dev(returns),
+        hip.ppo_hparams(grad_scale=1.0 / m, **kw))
+    got = _losses_from_sums(host(sums), kw)
+    for i, name in enumerate(oracle.LOSS_KEYS):
+        assert got[i] == pytest.approx(want[name], rel=1e-5, abs=1e-7), name
+    np.testing.assert_allclose(host(g_logits), wg_logits, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(host(g_value), wg_values, rtol=2e-5, atol=1e-10)
+
+
+def test_ppo_loss_squashed_entropy_is_rejected():
+    m = 8
+    z = torch.zeros(m, 1, device=DEV)
+    hp = hip.ppo_hparams(clip_param=0.2, dual_clip_param=None, entropy_coeff=0.01, vf_clip_param=5.0, vf_coeff=1.0,
+                         grad_scale=1.0)
+    with pytest.raises(ValueError):
+        hip.ppo_loss_normal(z, z, z, z, z, z, z, hp, squashed=True)
+
+
+# --------------------------------------------------------------------------- #
+# Environments + samplers
+# --------------------------------------------------------------------------- #
+def test_dummy_env_steps_match_reference(golden):
+    g = golden("env_steps.npz")
+    for kind, dtype in (("disc", torch.int64), ("cont", torch.float32)):
+        state = dev(g[f"{kind}_state0"])
+        reward = torch.empty_like(state)
+        for t in range(g[f"{kind}_actions"].shape[0]):
+            hip.dummy_env_step(state, dev(g[f"{kind}_actions"][t], dtype), reward)
+            assert np.array_equal(host(state), g[f"{kind}_states"][t]), (kind, t)
+            assert np.array_equal(host(reward), g[f"{kind}_rewards"][t]), (kind, t)
+
+
+def test_cartpole_steps_match_reference(golden):
+    g = golden("env_steps.npz")
+    for integ in ("euler", "semi-implicit"):
+        cfg = hip.CartPoleCfg(5.0, 9.8, 0.5, 0.1, 0.05, 1.1, 0.02, 0 if integ == "euler" else 1)
+        for t in range(g[f"cp_{integ}_actions"].shape[0]):
+            prev = g[f"cp_{integ}_state0"] if t == 0 else g[f"cp_{integ}_states"][t - 1]
+            state = dev(prev)
+            n = state.shape[1]
+            obs = torch.empty(n, 5, device=DEV)
+            rew = torch.empty(n, 1, device=DEV)
+            hip.cartpole_step(state, dev(g[f"cp_{integ}_actions"][t]), cfg, obs, rew)
+            np.testing.assert_allclose(host(state), g[f"cp_{integ}_states"][t], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(host(obs), g[f"cp_{integ}_obs"][t], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(host(rew), g[f"cp_{integ}_rewards"][t], rtol=1e-6, atol=1e-6)
+
+
+def test_env_resets_match_oracle_noise():
+    n = 5000
+    state = torch.empty(n, 1, device=DEV)
+    hip.dummy_env_reset(state, 100.0, seed=1234, reset_count=3, env_offset=17)
+    want = oracle.dummy_env_reset(n, 100.0, 1234, 3, 17)
+    assert np.array_equal(host(state), want)
+    assert np.abs(want).max() <= 100.0 and abs(float(want.mean())) < 5.0
+    cp = torch.empty(4, n, device=DEV)
+    obs = torch.empty(n, 5, device=DEV)
+    hip.cartpole_reset(cp, 0.01, seed=99, reset_count=0, env_offset=0, obs_out=obs)
+    want = oracle.cartpole_reset(n, 0.01, 99, 0, 0)
+    assert np.array_equal(host(cp), want)
+    assert 0.008 < float(want.std()) < 0.012
+    np.testing.assert_allclose(host(obs)[:, 2], np.cos(want[2]), atol=1e-6)
+
+
+@pytest.mark.parametrize("ncls", [2, 3, 5])
+def test_categorical_sampler_matches_reference_actions(golden, ncls):
+    g = golden("samplers.npz")
+    actions, logp = hip.categorical_sample_logp(dev(g[f"cat{ncls}_logits"]), dev(g[f"cat{ncls}_q"]))
+    assert np.array_equal(host(actions), g[f"cat{ncls}_actions"])
+    np.testing.assert_allclose(host(logp), g[f"cat{ncls}_logp"], rtol=1e-5, atol=1e-6)
+    mode, _ = hip.categorical_sample_logp(dev(g[f"cat{ncls}_logits"]), None, deterministic=True)
+    assert np.array_equal(host(mode), g[f"cat{ncls}_mode"])
+
+
+def test_categorical_sampler_philox_bit_exact_vs_oracle():
+    rng = np.random.default_rng(0)
+    m = 200_000
+    logits = (rng.standard_normal((m, 1, 2)) * 1e-3).astype(np.float32)
+    want_a, want_lp = oracle.categorical_sample(logits, seed=42, step=7, row_offset=1000)
+    got_a, got_lp = hip.categorical_sample_logp(dev(logits), None, seed=42, step=7, row_offset=1000)
+    assert np.array_equal(host(got_a), want_a)
+    assert np.array_equal(host(got_lp), want_lp)
+    assert 0.49 < want_a.mean() < 0.51
+    logits3 = rng.standard_normal((4099, 2, 3)).astype(np.float32)
+    want_a, want_lp = oracle.categorical_sample(logits3, seed=5, step=0)
+    got_a, got_lp = hip.categorical_sample_logp(dev(logits3), None, seed=5, step=0)
+    assert np.array_equal(host(got_a), want_a)
+    np.testing.assert_allclose(host(got_lp), want_lp, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["normal", "squashed"])
+@pytest.mark.parametrize("adim", [1, 3])
+def test_normal_samplers_match_reference(golden, kind, adim):
+    g = golden("samplers.npz")
+    p = f"{kind}{adim}"
+    actions, logp = hip.normal_sample_logp(dev(g[f"{p}_mean"]), dev(g[f"{p}_log_std"]), dev(g[f"{p}_eps"]),
+                                           squashed=kind == "squashed")
+    np.testing.assert_allclose(host(actions), g[f"{p}_actions"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(host(logp), g[f"{p}_logp"], rtol=1e-4, atol=2e-4)
+    # Philox noise agrees with the oracle's
+    a2, lp2 = hip.normal_sample_logp(dev(g[f"{p}_mean"]), dev(g[f"{p}_log_std"]), None, squashed=kind == "squashed",
+                                     seed=3, step=11, row_offset=5)
+    wa, wlp = oracle.normal_sample(g[f"{p}_mean"], g[f"{p}_log_std"], squashed=kind == "squashed", seed=3, step=11,
+                                   row_offset=5)
+    np.testing.assert_allclose(host(a2), wa, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(host(lp2), wlp, rtol=1e-4, atol=2e-4)
+
+
+# --------------------------------------------------------------------------- #
+# Fused per-timestep kernels == composition of the standalone pieces
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n", [1, 63, 4096, 100_001])
+def test_fused_dummy_discrete_step_vs_oracle(n):
+    rng = np.random.default_rng(n)
+    logits = (rng.standard_normal((n, 1, 2)) * 0.5).astype(np.float32)
+    value = rng.standard_normal((n, 1)).astype(np.float32)
+    q = rng.exponential(1.0, (n, 1, 2)).astype(np.float32)
+    state0 = rng.uniform(-100, 100, (n, 1)).astype(np.float32)
+    rdr0 = rng.standard_normal((n, 1)).astype(np.float32)
+    for noise in (q, None):
+        want_a, want_lp = oracle.categorical_sample(logits, noise, seed=8, step=2, row_offset=3)
+        want_s, want_r = oracle.dummy_env_step(state0, want_a)
+        want_rdr = oracle.rdr_step(rdr0, want_r, 0.95)
+        state = dev(state0)
+        cols = {k: torch.empty(n, 1, device=DEV) for k in ("logp", "value", "reward", "obs", "rdr1")}
+        action_col = torch.empty(n, 1, dtype=torch.int64, device=DEV)
+        hip.rollout_step_dummy(
+            discrete=True, squashed=False, features=dev(logits), features2=None, value=dev(value),
+            noise=dev(noise) if noise is not None else None, state=state, action_col=action_col,
+            logp_col=cols["logp"], value_col=cols["value"], reward_col=cols["reward"], obs_col_next=cols["obs"],
+            rdr_t=dev(rdr0), rdr_t1=cols["rdr1"], gamma=float(np.float32(0.95)), seed=8, step=2, env_offset=3,
+            deterministic=False)
+        assert np.array_equal(host(action_col), want_a)
+        assert np.array_equal(host(cols["logp"]), want_lp)
+        assert np.array_equal(host(state), want_s)
+        assert np.array_equal(host(cols["obs"]), want_s)
+        assert np.array_equal(host(cols["reward"]), want_r)
+        assert np.array_equal(host(cols["value"]), value)
+        assert np.array_equal(host(cols["rdr1"]), want_rdr)
+
+
+@pytest.mark.parametrize("squashed", [False, True])
+def test_fused_dummy_continuous_step_vs_oracle(squashed):
+    rng = np.random.default_rng(1)
+    n = 10_000
+    mean = rng.standard_normal((n, 1)).astype(np.float32)
+    log_std = np.tanh(rng.standard_normal((n, 1))).astype(np.float32)
+    value = rng.standard_normal((n, 1)).astype(np.float32)
+    eps = rng.standard_normal((n, 1)).astype(np.float32)
+    state0 = rng.uniform(-100, 100, (n, 1)).astype(np.float32)
+    want_a, want_lp = oracle.normal_sample(mean, log_std, eps, squashed=squashed)
+    want_s, want_r = oracle.dummy_env_step(state0, want_a)
+    state = dev(state0)
+    cols = {k: torch.empty(n, 1, device=DEV) for k in ("action", "logp", "value", "reward", "obs")}
+    hip.rollout_step_dummy(
+        discrete=False, squashed=squashed, features=dev(mean), features2=dev(log_std), value=dev(value),
+        noise=dev(eps), state=state, action_col=cols["action"], logp_col=cols["logp"], value_col=cols["value"],
+        reward_col=cols["reward"], obs_col_next=cols["obs"], rdr_t=None, rdr_t1=None, gamma=0.95, seed=0, step=0,
+        env_offset=0, deterministic=False)
+    np.testing.assert_allclose(host(cols["action"]), want_a, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(host(cols["logp"]), want_lp, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(host(state), want_s, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(host(cols["reward"]), want_r, rtol=1e-6, atol=1e-5)
+
+
+def test_fused_cartpole_step_vs_oracle():
+    rng = np.random.default_rng(2)
+    n = 30_000
+    logits = rng.standard_normal((n, 1, 3)).astype(np.float32)
+    value = rng.standard_normal((n, 1)).astype(np.float32)
+    state0 = (rng.standard_normal((4, n)) * 0.5).astype(np.float32)
+    rdr0 = rng.standard_normal((n, 1)).astype(np.float32)
+    want_a, want_lp = oracle.categorical_sample(logits, seed=21, step=5)
+    cfg_o = oracle.cartpole_cfg()
+    want_s, want_obs, want_r = oracle.cartpole_step(state0, want_a, cfg_o)
+    state = dev(state0)
+    cfg = hip.CartPoleCfg(5.0, 9.8, 0.5, 0.1, 0.05, 1.1, 0.02, 0)
+    action_col = torch.empty(n, 1, dtype=torch.int64, device=DEV)
+    cols = {k: torch.empty(n, 1, device=DEV) for k in ("logp", "value", "reward", "rdr1")}
+    obs = torch.empty(n, 5, device=DEV)
+    hip.rollout_step_cartpole(
+        logits=dev(logits), value=dev(value), noise=None, state=state, cfg=cfg, action_col=action_col,
+        logp_col=cols["logp"], value_col=cols["value"], reward_col=cols["reward"], obs_col_next=obs,
+        rdr_t=dev(rdr0), rdr_t1=cols["rdr1"], gamma=float(np.float32(0.95)), seed=21, step=5, env_offset=0,
+        deterministic=False)
+    assert np.array_equal(host(action_col), want_a)
+    np.testing.assert_allclose(host(state), want_s, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(host(obs), want_obs, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(host(cols["reward"]), want_r, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(host(cols["rdr1"]), oracle.rdr_step(rdr0, want_r, 0.95), rtol=1e-6, atol=1e-6)
+
+
+def test_rollout_scatter_generic_env():
+    rng = np.random.default_rng(3)
+    n, od = 1000, 7
+    action = rng.integers(0, 5, (n, 2))
+    logp, value, reward = (rng.standard_normal((n, 1)).astype(np.float32) for _ in range(3))
+    obs = rng.standard_normal((n, od)).astype(np.float32)
+    rdr0 = rng.standard_normal((n, 1)).astype(np.float32)
+    cols = {k: torch.zeros(n, 1, device=DEV) for k in ("logp", "value", "reward", "rdr1")}
+    action_col = torch.zeros(n, 2, dtype=torch.int64, device=DEV)
+    obs_col = torch.zeros(n, od, device=DEV)
+    hip.rollout_scatter(dev(action), dev(logp), dev(value), dev(reward), dev(obs), action_col, cols["logp"],
+                        cols["value"], cols["reward"], obs_col, dev(rdr0), cols["rdr1"], float(np.float32(0.95)))
+    assert np.array_equal(host(action_col), action)
+    assert np.array_equal(host(cols["logp"]), logp)
+    assert np.array_equal(host(cols["value"]), value)
+    assert np.array_equal(host(cols["reward"]), reward)
+    assert np.array_equal(host(obs_col), obs)
+    assert np.array_equal(host(cols["rdr1"]), oracle.rdr_step(rdr0, reward, 0.95))
+
+
+# --------------------------------------------------------------------------- #
+# Stats + gather
+# --------------------------------------------------------------------------- #
+def _stats_dict(raw):
+    n, s1, s2, mn, mx, nh, r1, r2, rmn, rmx, d1, d2 = raw
+
+    def std(cnt, a, b):
+        return float(np.sqrt(max((b - a * a / cnt) / (cnt - 1), 0.0)))
+
+    return {
+        "returns/min": mn, "returns/max": mx, "returns/mean": s1 / n, "returns/std": std(n, s1, s2),
+        "rewards/min": rmn, "rewards/max": rmx, "rewards/mean": r1 / nh, "rewards/std": std(nh, r1, r2),
+        "reward_scale": std(nh, d1, d2),
+    }
+
+
+@pytest.mark.parametrize("time_major", [False, True])
+def test_rollout_stats_vs_oracle_and_trace(golden, time_major):
+    g = golden("trace_ff_discrete.npz")
+    rewards, rdr = g["it0_collect_rewards"], g["it0_collect_reversed_discounted_returns"]
+
+    def put(a):
+        t = dev(a)
+        if time_major:
+            t = t.transpose(0, 1).contiguous().transpose(0, 1)
+        return t
+
+    got = _stats_dict(host(hip.rollout_stats(put(rewards), put(rdr))))
+    want = oracle.rollout_stats(rewards, rdr)
+    for k in want:
+        assert got[k] == pytest.approx(want[k], rel=1e-6), k
+    ref = dict(zip(g["collect_stat_keys"], g["it0_collect_stats"]))
+    for k in ("returns/min", "returns/max", "returns/mean", "returns/std", "rewards/min", "rewards/max",
+              "rewards/mean", "rewards/std"):
+        assert got[k] == pytest.approx(ref[k], rel=2e-6), k
+    assert got["reward_scale"] == pytest.approx(float(g["it0_reward_scale"]), rel=2e-6)
+    rng = np.random.default_rng(4)
+    big = rng.standard_normal((5000, 17, 1)).astype(np.float32)
+    got = _stats_dict(host(hip.rollout_stats(put(big), None)))
+    want = oracle.rollout_stats(big, None)
+    for k in want:
+        if k != "reward_scale":
+            assert got[k] == pytest.approx(want[k], rel=1e-6, abs=1e-9), k
+
+
+@pytest.mark.parametrize("time_major", [False, True])
+def test_gather_minibatch_bit_exact(time_major):
+    rng = np.random.default_rng(6)
+    n, h = 300, 12
+    obs = rng.standard_normal((n, h + 1, 5)).astype(np.float32)
+    act = rng.integers(0, 9, (n, h + 1, 2))
+    adv = rng.standard_normal((n, h + 1, 1)).astype(np.float32)
+
+    def put(a):
+        t = dev(a)
+        if time_major:
+            t = t.transpose(0, 1).contiguous().transpose(0, 1)
+        return t
+
+    index = oracle.permutation(n * h, 11, 0)[:1000]
+    outs = hip.gather_minibatch(dev(index), h, [put(obs), put(act), put(adv)])
+    env, t = index // h, index % h
+    assert np.array_equal(host(outs[0]), obs[env, t])
+    assert np.array_equal(host(outs[1]), act[env, t])
+    assert np.array_equal(host(outs[2]), adv[env, t])
+    # same thing through the oracle's row gather on the flattened [N*H] view
+    flat = np.ascontiguousarray(obs[:, :h]).reshape(n * h, 5)
+    assert np.array_equal(host(outs[0]), oracle.gather_rows(index, flat))
