@@ -1,0 +1,247 @@
+"""End-to-end parity of ``Algorithm.collect()`` / ``.step()`` on the GPU against
+traces of the real reference (tests/golden/trace_*.npz: initial weights, reset
+state, the noise torch drew per timestep, the minibatch permutations -> buffer
+after collect, CollectStats, StepStats, final weights), plus the reference's own
+behavioural tests (tests/test_algorithms.py of the reference).
+
+Bars: action indices bit-exact; buffer floats and losses to 1e-5 relative
+(north_star). The policy network runs on rocBLAS here and on MKL in the
+reference, so logits differ in the last ulps; everything downstream is compared
+with tolerances that reflect fp32 GEMM reordering, not kernel error.
+"""
+
+import math
+from unittest.mock import patch
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from rl8_amd import AlgorithmConfig  # noqa: E402
+from rl8_amd.data import DataKeys  # noqa: E402
+from rl8_amd.distributions import SquashedNormal  # noqa: E402
+from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv  # noqa: E402
+
+NUM_ENVS = 64
+HORIZON = 32
+
+
+def build_from_trace(g, env_cls, **config):
+    algo = AlgorithmConfig(num_envs=NUM_ENVS, horizon=HORIZON, **config).build(env_cls)
+    state = {k[len("init_"):]: torch.from_numpy(g[k]) for k in g if k.startswith("init_")}
+    algo.policy.model.load_state_dict(state)
+    return algo
+
+
+def inject(algo, g, it):
+    """Make collect()/step() consume the reference's recorded randomness."""
+    dev = algo.policy.device
+    if f"it{it}_reset_state" in g:
+        reset_state = torch.from_numpy(g[f"it{it}_reset_state"]).to(dev)
+        real_reset = algo.env.reset
+
+        def reset(*, config=None):
+            real_reset(config=config)
+            algo.env.state.copy_(reset_state)
+            return algo.env.state
+
+        algo.env.reset = reset
+    key = f"it{it}_cat_q" if f"it{it}_cat_q" in g else f"it{it}_normal_eps"
+    noise = g[key]
+    # the reference draws once more per collect? no: H sampling calls per collect,
+    # the (H+1)-th forward takes no sample.  validate() drew the first recorded
+    # sample only in iteration 0 if build() ran inside the recorder (it did not).
+    assert noise.shape[0] == HORIZON
+    algo.injected_noise = torch.from_numpy(noise).to(dev)
+    algo.injected_permutations = [torch.from_numpy(p) for p in g[f"it{it}_perms"]]
+
+
+def compare_collect(algo, g, it, *, discrete):
+    buf = algo.buffer
+    want = {k[len(f"it{it}_collect_"):]: g[k] for k in g if k.startswith(f"it{it}_collect_") and not k.endswith("stats")}
+    got_actions = buf[DataKeys.ACTIONS][:, :HORIZON].cpu().numpy()
+    if discrete:
+        assert np.array_equal(got_actions, want["actions"][:, :HORIZON])
+    else:
+        np.testing.assert_allclose(got_actions, want["actions"][:, :HORIZON], rtol=1e-5, atol=1e-5)
+    for key in ("obs", "rewards", "reversed_discounted_returns"):
+        np.testing.assert_allclose(buf[key].cpu().numpy(), want[key], rtol=1e-5, atol=1e-4, err_msg=key)
+    np.testing.assert_allclose(buf[DataKeys.LOGP].cpu().numpy()[:, :HORIZON], want["logp"][:, :HORIZON],
+                               rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(buf[DataKeys.VALUES].cpu().numpy(), want["values"], rtol=1e-4, atol=2e-5)
+
+
+def compare_stats(got, keys, want, rel):
+    for k, w in zip(keys, want):
+        assert got[k] == pytest.approx(w, rel=rel, abs=1e-7), (k, got[k], w)
+
+
+def run_trace(golden, name, env_cls, *, discrete, step_rel, **config):
+    g = golden(name)
+    algo = build_from_trace(g, env_cls, **config)
+    for it in range(2):
+        inject(algo, g, it)
+        collect_stats = algo.collect()
+        compare_collect(algo, g, it, discrete=discrete)
+        compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5)
+        assert algo.state.reward_scale == pytest.approx(float(g[f"it{it}_reward_scale"]), rel=1e-5)
+        step_stats = algo.step()
+        compare_stats(step_stats, g["step_stat_keys"], g[f"it{it}_step_stats"], step_rel)
+        final_obs = algo.buffer[DataKeys.OBS][:, -1].cpu().numpy()
+        np.testing.assert_allclose(final_obs, g[f"it{it}_final_obs"], rtol=1e-5, atol=1e-4)
+        # the rest of the buffer was zeroed (reference re-allocates it, :603-609)
+        assert float(algo.buffer[DataKeys.REWARDS].abs().sum()) == 0.0
+        assert float(algo.buffer[DataKeys.OBS][:, :-1].abs().sum()) == 0.0
+        sd = algo.policy.model.state_dict()
+        for k, v in sd.items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f"it{it}_final_{k}"], rtol=2e-3, atol=2e-4,
+                                       err_msg=f"it{it} {k}")
+
+
+def test_trace_feedforward_discrete_full_batch(golden):
+    run_trace(golden, "trace_ff_discrete.npz", DiscreteDummyEnv, discrete=True, step_rel=1e-4)
+
+
+def test_trace_feedforward_discrete_minibatches(golden):
+    run_trace(golden, "trace_ff_discrete_minibatch.npz", DiscreteDummyEnv, discrete=True, step_rel=1e-4,
+              sgd_minibatch_size=256, entropy_coeff=1e-2, dual_clip_param=5.0, horizons_per_env_reset=2)
+
+
+def test_trace_feedforward_continuous_squashed(golden):
+    run_trace(golden, "trace_ff_continuous_squashed.npz", ContinuousDummyEnv, discrete=False, step_rel=1e-3,
+              distribution_cls=SquashedNormal)
+
+
+def test_trace_feedforward_continuous_normal_entropy(golden):
+    run_trace(golden, "trace_ff_continuous_normal.npz", ContinuousDummyEnv, discrete=False, step_rel=1e-3,
+              entropy_coeff=1e-2)
+
+
+def test_first_sgd_iteration_losses_match_reference_to_1e5(golden):
+    """Before any optimizer step the weights are the reference's, so the loss of
+    the first SGD iteration isolates kernel + GEMM error: 1e-5 relative."""
+    g = golden("trace_ff_discrete.npz")
+    algo = build_from_trace(g, DiscreteDummyEnv, num_sgd_iters=1)
+    inject(algo, g, 0)
+    algo.collect()
+    got = algo.step()
+    # reference: same config but 4 iterations -> recompute its first-iteration
+    # loss with the oracle from the recorded buffer
+    from oracle import oracle
+    from oracle.ppo_cpu import first_iteration_losses
+
+    want = first_iteration_losses(g, 0, oracle)
+    for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+        assert got[k] == pytest.approx(want[k], rel=1e-5, abs=1e-7), k
+
+
+# --- behaviour tests mirrored from the reference's tests/test_algorithms.py ---
+@pytest.mark.parametrize("env_cls", [ContinuousDummyEnv, DiscreteDummyEnv])
+def test_accumulated_gradients_match_full_batch(env_cls):
+    # reference tests/test_algorithms.py:16-68 (rel_tol 1e-5)
+    def run(**kw):
+        torch.manual_seed(42)
+        algo = AlgorithmConfig(num_envs=NUM_ENVS, horizon=HORIZON, entropy_coeff=1e-2, **kw).build(env_cls)
+        algo.collect()
+        return algo.step()
+
+    full = run()
+    accumulated = run(accumulate_grads=True, sgd_minibatch_size=NUM_ENVS)
+    for k in ("losses/entropy", "losses/policy", "losses/total", "losses/vf", "monitors/kl_div"):
+        assert math.isclose(full[k], accumulated[k], rel_tol=1e-5), k
+
+
+@pytest.mark.parametrize("env_cls", [ContinuousDummyEnv, DiscreteDummyEnv])
+def test_algorithm_validate(env_cls):
+    algo = AlgorithmConfig(horizon=HORIZON, num_envs=NUM_ENVS).build(env_cls)
+    algo.validate()
+
+
+def test_feedforward_algorithm_resets():
+    # reference tests/test_algorithms.py:85-100
+    algo = AlgorithmConfig(horizon=HORIZON, num_envs=NUM_ENVS, horizons_per_env_reset=2).build(DiscreteDummyEnv)
+    with patch.object(DiscreteDummyEnv, "reset", wraps=algo.env.reset) as reset:
+        algo.collect()
+        assert algo.state.horizons == 1 and reset.call_count == 1
+        algo.collect()
+        assert algo.state.horizons == 2 and reset.call_count == 1
+        algo.collect()
+        assert algo.state.horizons == 3 and reset.call_count == 2
+
+
+def test_step_requires_collect_and_hparam_errors():
+    algo = AlgorithmConfig(horizon=4, num_envs=8).build(DiscreteDummyEnv)
+    with pytest.raises(RuntimeError, match="is not buffered"):
+        algo.step()
+    algo.collect()
+    algo.step()
+    with pytest.raises(RuntimeError):
+        algo.step()
+    with pytest.raises(ValueError, match="sgd_minibatch_size"):
+        AlgorithmConfig(horizon=4, num_envs=8, sgd_minibatch_size=5).build(DiscreteDummyEnv)
+    with pytest.raises(ValueError, match="clip_param"):
+        AlgorithmConfig(horizon=4, num_envs=8, clip_param=1.5).build(DiscreteDummyEnv)
+
+
+def test_collect_stats_keys_and_types():
+    algo = AlgorithmConfig(horizon=8, num_envs=128).build(DiscreteDummyEnv)
+    stats = algo.collect()
+    assert set(stats) == {
+        "env/resets", "env/steps", "profiling/collect_ms", "returns/min", "returns/max", "returns/mean",
+        "returns/std", "rewards/min", "rewards/max", "rewards/mean", "rewards/std",
+    }
+    assert stats["env/steps"] == 128 * 8 and stats["env/resets"] == 128
+    step = algo.step()
+    assert set(step) == {
+        "coefficients/entropy", "coefficients/vf", "losses/entropy", "losses/policy", "losses/vf",
+        "losses/total", "monitors/kl_div", "profiling/step_ms",
+    }
+    assert all(isinstance(v, float) for v in step.values())
+
+
+def test_fused_and_generic_rollouts_agree():
+    """The one-launch-per-timestep path and the generic policy.sample -> env.step ->
+    scatter path must fill identical buffers from the same Philox stream."""
+    def run(force_generic):
+        torch.manual_seed(7)
+        algo = AlgorithmConfig(horizon=16, num_envs=512).build(DiscreteDummyEnv)
+        if force_generic:
+            algo._fusable = lambda: False
+        algo.collect()
+        return {k: v.clone() for k, v in algo.buffer.items()}
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_row_chunking_does_not_change_the_update():
+    def run(rows):
+        torch.manual_seed(3)
+        algo = AlgorithmConfig(horizon=16, num_envs=256).build(DiscreteDummyEnv)
+        algo.max_rows_per_pass = rows
+        algo.collect()
+        stats = algo.step()
+        return stats, [p.detach().clone() for p in algo.policy.model.parameters()]
+
+    s1, p1 = run(1 << 22)
+    s2, p2 = run(1000)
+    for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+        assert s1[k] == pytest.approx(s2[k], rel=1e-5), k
+    for a, b in zip(p1, p2):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-5)
+
+
+def test_early_stopping_on_kl():
+    torch.manual_seed(0)
+    algo = AlgorithmConfig(horizon=16, num_envs=256, target_kl_div=1e-9, num_sgd_iters=8).build(DiscreteDummyEnv)
+    algo.collect()
+    before = [p.detach().clone() for p in algo.policy.model.parameters()]
+    stats = algo.step()
+    # first minibatch: kl == 0 exactly (same weights) -> update happens; the
+    # second iteration's kl > 1.5e-9 stops the loop before its update.
+    assert stats["monitors/kl_div"] >= 0.0
+    after = [p.detach().clone() for p in algo.policy.model.parameters()]
+    assert any(not torch.equal(a, b) for a, b in zip(before, after))
