@@ -1,0 +1,218 @@
+"""Headline benchmark: env transitions/sec (+ policy updates/sec) of
+``collect(); step()`` on DiscreteDummyEnv, num_envs = 2^20 per GPU, horizon 32,
+all ``AlgorithmConfig`` defaults (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one ``collect()`` (32 timesteps of policy forward + fused sample /
+env.step / bookkeeping launch, bootstrap value, stats) + one ``step()`` (GAE,
+4 SGD iterations of policy forward, fused PPO loss fwd+bwd, policy backward,
+clip, Adam). Everything lives in HBM before the timed region starts.
+
+Weak scaling: every rank owns 2^20 environments (env-sharded, RCCL all-reduce of
+moments / loss sums / gradients only).
+
+Besides the contract's fields, the JSON line carries
+  roofline      the dominant hand-written kernel (fused PPO loss fwd+bwd, 44 B per
+                sample algorithmic) timed with HIP events inside the timed region;
+  kernels       the same for every hand kernel that ran;
+  cpu_baseline  the CPU restatement (oracle/, kind "port") of the same algorithm
+                on the host cores, on a bounded sample (rank 0, N=1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290
+HBM_COPY_CEILING_GBS = 6290.0
+
+# Algorithmic bytes per unit (DESIGN.md "Kernels").
+ALGORITHMIC_BYTES = {
+    "ppo_loss_categorical": 44.0,   # logits 8 + value 4 + action 8 + logp 4 + adv 4 + ret 4; grads 8 + 4
+    "ppo_loss_normal": 40.0,
+    "gae_scan": 16.0 + 8.0 / 32.0,  # r 4 + v 4 + adv 4 + ret 4 per transition, + 8 B/env for column H
+    "advantage_normalise": 8.0,
+    "rollout_step_dummy": 52.0,     # logits 8 value 4 state 4 rdr 4 | action 8 logp 4 value 4 reward 4 obs 4 state 4 rdr 4
+    "rollout_stats": 8.0,
+    "gather_minibatch": 56.0,
+}
+
+
+def parse_args() -> argparse.Namespace:
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--num-envs", type=int, default=1 << 20, help="environments PER GPU")
+    p.add_argument("--horizon", type=int, default=32)
+    p.add_argument("--env", default="discrete", choices=["discrete", "continuous", "cartpole"])
+    p.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(budget_s: float) -> dict:
+    """The CPU restatement of the same algorithm (oracle/ppo_cpu.py: C kernels +
+    torch-CPU MLP) on BASELINE config 1 (DiscreteDummyEnv, N=8192, H=32,
+    defaults), host cores of this box. Bounded: one warm-up iteration, then
+    whole iterations until ~budget_s seconds are spent."""
+    from oracle.ppo_cpu import OraclePPO
+
+    cores = torch.get_num_threads()
+    torch.manual_seed(0)
+    algo = OraclePPO("discrete", num_envs=8192, horizon=32)
+    algo.collect()
+    algo.step()
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        algo.collect()
+        algo.step()
+        iters += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed >= budget_s or iters >= 50:
+            break
+    return {
+        "value": 8192 * 32 * iters / elapsed,
+        "unit": "env transitions/sec",
+        "policy_updates_per_sec": iters / elapsed,
+        "cores": cores,
+        "host_cpus": os.cpu_count(),
+        "kind": "port",
+        "sample": f"{iters} x (collect+step), DiscreteDummyEnv num_envs=8192 horizon=32 defaults"
+                  f" (BASELINE configs[0]), {elapsed:.1f} s, oracle C kernels + torch-CPU MLP",
+    }
+
+
+def main() -> None:
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from rl8_amd import AlgorithmConfig, hip
+    from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv
+
+    if args.env == "cartpole":
+        from rl8_amd.envs.cartpole import CartPole as env_cls
+    else:
+        env_cls = DiscreteDummyEnv if args.env == "discrete" else ContinuousDummyEnv
+
+    torch.manual_seed(0)
+    global_envs = args.num_envs * world
+    algo = AlgorithmConfig(num_envs=global_envs, horizon=args.horizon).build(env_cls)
+    horizon = algo.hparams.horizon
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        algo.collect()
+        algo.step()
+
+    hip.timer.reset()
+    hip.timer.enabled = True
+    barrier()
+    t0 = time.perf_counter()
+    collect_ms = step_ms = 0.0
+    for _ in range(args.steps):
+        c = algo.collect()
+        s = algo.step()
+        collect_ms += c["profiling/collect_ms"]
+        step_ms += s["profiling/step_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hip.timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    kernels = {}
+    for name, rec in hip.timer.summary().items():
+        bytes_per_launch = ALGORITHMIC_BYTES.get(name, 0.0) * rec["units_per_launch"]
+        gbs = bytes_per_launch / (rec["avg_ms"] * 1e-3) / 1e9 if rec["avg_ms"] > 0 else 0.0
+        kernels[name] = {
+            "launches": rec["launches"],
+            "avg_ms": round(rec["avg_ms"], 5),
+            "total_ms": round(rec["total_ms"], 3),
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "achieved_GBps": round(gbs, 1),
+            "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
+        }
+
+    if rank == 0:
+        dominant = "ppo_loss_categorical" if "ppo_loss_categorical" in kernels else "ppo_loss_normal"
+        dom = kernels[dominant]
+        transitions = global_envs * horizon * args.steps
+        line = {
+            "metric": "env transitions/sec + policy updates/sec, DiscreteDummyEnv num_envs=2^20 h=32",
+            "value": transitions / elapsed,
+            "unit": "env transitions/sec",
+            "policy_updates_per_sec": args.steps / elapsed,
+            "optimizer_steps_per_sec": args.steps * algo.hparams.num_sgd_iters * algo.hparams.num_minibatches / elapsed,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "collect_ms_per_step": collect_ms / args.steps,
+            "update_ms_per_step": step_ms / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (Philox-reset DiscreteDummyEnv states, random-init default MLP)",
+            "config": {
+                "workload": f"{env_cls.__name__} collect()+step(), num_envs={args.num_envs} per GPU"
+                            f" ({global_envs} total), horizon={horizon}, AlgorithmConfig defaults"
+                            " (4 SGD iters, one full-buffer minibatch, Adam 1e-3)",
+                "num_envs_per_gpu": args.num_envs,
+                "horizon": horizon,
+                "parallelism": f"env-sharded x{world}",
+            },
+            "roofline": {
+                "kernel": f"rl8_{dominant}_fwd_bwd_f32",
+                "bound": "hbm",
+                "achieved": dom["achieved_GBps"],
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(dom["achieved_GBps"] / HBM_PEAK_GBS, 4),
+                "frac_of_measured_copy_ceiling": round(dom["achieved_GBps"] / HBM_COPY_CEILING_GBS, 4),
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                "avg_launch_ms": dom["avg_ms"],
+                "launches": dom["launches"],
+                "traffic": None,
+            },
+            "kernels": kernels,
+            "hand_kernel_ms_per_step": round(sum(k["total_ms"] for k in kernels.values()) / args.steps, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,55 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional HIP-event timing of launches, per ABI entry point. Events are
+    recorded on the stream the kernel is launched on (torch's current stream);
+    nothing synchronises until :meth:`summary` is called. Used by ``bench.py``
+    for the roofline figures; off by default."""
+
+    def __init__(self) -> None:
+        self.enabled = False
+        self.records: dict[str, list[tuple[torch.cuda.Event, torch.cuda.Event, float]]] = {}
+
+    def reset(self) -> None:
+        self.records = {}
+
+    def summary(self) -> dict[str, dict[str, float]]:
+        torch.cuda.synchronize()
+        out = {}
+        for name, events in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in events]
+            units = [u for _, _, u in events]
+            out[name] = {
+                "launches": len(ms),
+                "total_ms": sum(ms),
+                "avg_ms": sum(ms) / len(ms),
+                "units_per_launch": sum(units) / len(units),
+            }
+        return out
+
+
+timer = KernelTimer()
+
+
+class _timed:
+    __slots__ = ("name", "units", "start")
+
+    def __init__(self, name: str, units: float) -> None:
+        self.name, self.units = name, units
+
+    def __enter__(self) -> None:
+        if timer.enabled:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+
+    def __exit__(self, *exc: Any) -> None:
+        if timer.enabled:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            timer.records.setdefault(self.name, []).append((self.start, end, self.units))
+
+
 def _ptr(t: None | torch.Tensor) -> None | int:
     if t is None:
         return None
@@ -339,14 +388,16 @@ def rollout_step_dummy(
     for t in (logp_col, value_col, reward_col, obs_col_next):
         if t.numel() != n or t.dtype != torch.float32:
             raise ValueError("rollout_step_dummy: column shape/dtype mismatch")
-    _check(
-        load().rl8_rollout_step_dummy_f32(
-            int(discrete), int(squashed), _ptr(features), _ptr(features2), _ptr(value), _ptr(noise), _ptr(state),
-            _ptr(action_col), _ptr(logp_col), _ptr(value_col), _ptr(reward_col), _ptr(obs_col_next),
-            _ptr(rdr_t), _ptr(rdr_t1), gamma, n, seed, step, env_offset, int(deterministic), _stream(),
-        ),
-        "rl8_rollout_step_dummy_f32",
-    )
+    with _timed("rollout_step_dummy", n):
+        _check(
+            load().rl8_rollout_step_dummy_f32(
+                int(discrete), int(squashed), _ptr(features), _ptr(features2), _ptr(value), _ptr(noise),
+                _ptr(state), _ptr(action_col), _ptr(logp_col), _ptr(value_col), _ptr(reward_col),
+                _ptr(obs_col_next), _ptr(rdr_t), _ptr(rdr_t1), gamma, n, seed, step, env_offset,
+                int(deterministic), _stream(),
+            ),
+            "rl8_rollout_step_dummy_f32",
+        )
 
 
 def rollout_step_cartpole(
@@ -397,11 +448,12 @@ def rollout_stats(rewards: torch.Tensor, rdr: None | torch.Tensor) -> torch.Tens
     if rdr is not None and (rdr.stride() != rewards.stride() or rdr.shape != rewards.shape):
         raise ValueError("rdr must share the layout of rewards")
     out = torch.empty(12, dtype=torch.float64, device=rewards.device)
-    _check(
-        load().rl8_rollout_stats_f32(_ptr(rewards), _ptr(rdr), n, h1 - 1, es, ts, _ptr(out),
-                                     _ptr(scratch(rewards.device)), _stream()),
-        "rl8_rollout_stats_f32",
-    )
+    with _timed("rollout_stats", n * (h1 - 1)):
+        _check(
+            load().rl8_rollout_stats_f32(_ptr(rewards), _ptr(rdr), n, h1 - 1, es, ts, _ptr(out),
+                                         _ptr(scratch(rewards.device)), _stream()),
+            "rl8_rollout_stats_f32",
+        )
     return out
 
 
@@ -414,23 +466,26 @@ def gae_scan(
 ) -> torch.Tensor:
     """Launches the scan; returns the device moments tensor (count, sum, sumsq)."""
     moments = torch.empty(3, dtype=torch.float64, device=rewards.device)
-    _check(
-        load().rl8_gae_scan_f32(
-            _ptr(rewards), _ptr(values), _ptr(adv), _ptr(ret), n, h, layout, gamma, gamma_lambda,
-            reward_denominator, int(write_scaled_rewards), _ptr(moments), _ptr(scratch(rewards.device)), _stream(),
-        ),
-        "rl8_gae_scan_f32",
-    )
+    with _timed("gae_scan", n * h):
+        _check(
+            load().rl8_gae_scan_f32(
+                _ptr(rewards), _ptr(values), _ptr(adv), _ptr(ret), n, h, layout, gamma, gamma_lambda,
+                reward_denominator, int(write_scaled_rewards), _ptr(moments), _ptr(scratch(rewards.device)),
+                _stream(),
+            ),
+            "rl8_gae_scan_f32",
+        )
     return moments
 
 
 def advantage_normalise(adv: torch.Tensor, *, layout: int, n: int, h: int, moments: torch.Tensor) -> None:
     if moments.dtype != torch.float64 or moments.numel() < 3:
         raise TypeError("moments must be 3 float64 values")
-    _check(
-        load().rl8_advantage_normalise_f32(_ptr(adv), n, h, layout, _ptr(moments), _stream()),
-        "rl8_advantage_normalise_f32",
-    )
+    with _timed("advantage_normalise", n * h):
+        _check(
+            load().rl8_advantage_normalise_f32(_ptr(adv), n, h, layout, _ptr(moments), _stream()),
+            "rl8_advantage_normalise_f32",
+        )
 
 
 # --------------------------------------------------------------------------- #
@@ -463,13 +518,14 @@ def ppo_loss_categorical(
     sums = torch.empty(5, dtype=torch.float64, device=logits.device)
     g_logits = torch.empty_like(logits) if with_grad else None
     g_value = torch.empty_like(value) if with_grad else None
-    _check(
-        load().rl8_ppo_loss_categorical_fwd_bwd_f32(
-            _ptr(logits), _ptr(value), _ptr(action), _ptr(logp_old), _ptr(adv), _ptr(ret), m, a, k, C.byref(hp),
-            _ptr(g_logits), _ptr(g_value), _ptr(sums), _ptr(scratch(logits.device)), _stream(),
-        ),
-        "rl8_ppo_loss_categorical_fwd_bwd_f32",
-    )
+    with _timed("ppo_loss_categorical", m):
+        _check(
+            load().rl8_ppo_loss_categorical_fwd_bwd_f32(
+                _ptr(logits), _ptr(value), _ptr(action), _ptr(logp_old), _ptr(adv), _ptr(ret), m, a, k,
+                C.byref(hp), _ptr(g_logits), _ptr(g_value), _ptr(sums), _ptr(scratch(logits.device)), _stream(),
+            ),
+            "rl8_ppo_loss_categorical_fwd_bwd_f32",
+        )
     return sums, g_logits, g_value
 
 
@@ -486,14 +542,15 @@ def ppo_loss_normal(
     g_mean = torch.empty_like(mean) if with_grad else None
     g_ls = torch.empty_like(log_std) if with_grad else None
     g_value = torch.empty_like(value) if with_grad else None
-    _check(
-        load().rl8_ppo_loss_normal_fwd_bwd_f32(
-            _ptr(mean), _ptr(log_std), _ptr(value), _ptr(action), _ptr(logp_old), _ptr(adv), _ptr(ret), m, a,
-            int(squashed), C.byref(hp), _ptr(g_mean), _ptr(g_ls), _ptr(g_value), _ptr(sums),
-            _ptr(scratch(mean.device)), _stream(),
-        ),
-        "rl8_ppo_loss_normal_fwd_bwd_f32",
-    )
+    with _timed("ppo_loss_normal", m):
+        _check(
+            load().rl8_ppo_loss_normal_fwd_bwd_f32(
+                _ptr(mean), _ptr(log_std), _ptr(value), _ptr(action), _ptr(logp_old), _ptr(adv), _ptr(ret), m, a,
+                int(squashed), C.byref(hp), _ptr(g_mean), _ptr(g_ls), _ptr(g_value), _ptr(sums),
+                _ptr(scratch(mean.device)), _stream(),
+            ),
+            "rl8_ppo_loss_normal_fwd_bwd_f32",
+        )
     return sums, g_mean, g_ls, g_value
 
 
@@ -528,5 +585,7 @@ def gather_minibatch(index: torch.Tensor, h: int, leaves: Sequence[torch.Tensor]
         dst = torch.empty((m, *trailing), dtype=leaf.dtype, device=leaf.device)
         fields[i] = GatherField(_ptr(leaf), _ptr(dst), leaf.stride(0), leaf.stride(1), row, leaf.element_size())
         outs.append(dst)
-    _check(load().rl8_gather_minibatch(_ptr(index), m, h, fields, len(leaves), _stream()), "rl8_gather_minibatch")
+    with _timed("gather_minibatch", m):
+        _check(load().rl8_gather_minibatch(_ptr(index), m, h, fields, len(leaves), _stream()),
+               "rl8_gather_minibatch")
     return outs

@@ -70,8 +70,9 @@ class EnvShards:
         """12 raw stats of this shard -> 12 raw stats of the global rollout."""
         if not self.active:
             return raw
-        gathered = torch.empty(self.world_size, raw.numel(), dtype=raw.dtype, device=raw.device)
-        dist.all_gather_into_tensor(gathered, raw.contiguous(), group=self.group)
+        flat = torch.empty(self.world_size * raw.numel(), dtype=raw.dtype, device=raw.device)
+        dist.all_gather_into_tensor(flat, raw.contiguous().reshape(-1), group=self.group)
+        gathered = flat.view(self.world_size, raw.numel())
         out = torch.empty_like(raw)
         out[list(STAT_SUM)] = gathered[:, list(STAT_SUM)].sum(0)
         out[list(STAT_MIN)] = gathered[:, list(STAT_MIN)].min(0).values

@@ -1,0 +1,144 @@
+"""World-size-2 tests of the env-shard collectives (rl8_amd/parallel.py) on the
+CPU with the gloo backend: what two ranks combine must equal what one rank
+computes over all environments. Kernels are not involved; shard-local inputs
+come from the oracle (checker) so the test states the N>1 contract end to end:
+
+  stats(all envs)        == combine(stats(shard 0), stats(shard 1))
+  normalised advantages  == normalise(shard, SUM of shard moments)
+  loss / gradient        == SUM of shard loss sums / shard gradients scaled 1/M_global
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle
+from rl8_amd.algorithms._feedforward import _collect_stats_from_raw
+from rl8_amd.nn.functional import losses_from_sums
+from rl8_amd.parallel import EnvShards
+
+WORLD = 2
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def raw_stats(rewards: np.ndarray, rdr: np.ndarray) -> torch.Tensor:
+    """The 12 raw moments rl8_rollout_stats_f32 emits, from numpy."""
+    h = rewards.shape[1] - 1
+    r = rewards[:, :h, 0].astype(np.float64)
+    ret = rewards[:, :h, 0].sum(1, dtype=np.float32).astype(np.float64)
+    d = rdr[:, 1:, 0].astype(np.float64)
+    return torch.tensor([
+        len(ret), ret.sum(), (ret**2).sum(), ret.min(), ret.max(),
+        r.size, r.sum(), (r**2).sum(), r.min(), r.max(), d.sum(), (d**2).sum(),
+    ], dtype=torch.float64)
+
+
+def worker(rank: int, port: int, results) -> None:
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        shards = EnvShards()
+        assert shards.active and shards.world_size == WORLD and shards.rank == rank
+        n, h = 96, 12
+        rng = np.random.default_rng(123)  # same data on every rank; each takes its slice
+        rewards = -np.abs(rng.uniform(-50, 50, (n, h + 1, 1))).astype(np.float32)
+        rdr = rng.standard_normal((n, h + 1, 1)).astype(np.float32)
+        values = rng.standard_normal((n, h + 1, 1)).astype(np.float32)
+        local = slice(rank * n // WORLD, (rank + 1) * n // WORLD)
+        assert shards.env_offset(n // WORLD) == local.start
+
+        # 1. collect statistics
+        combined = shards.combine_rollout_stats(raw_stats(rewards[local], rdr[local]))
+        stats, scale = _collect_stats_from_raw(combined.tolist())
+        want = oracle.rollout_stats(rewards, rdr)
+        for k, v in stats.items():
+            assert v == pytest.approx(want[k], rel=1e-6), k
+        assert scale == pytest.approx(want["reward_scale"], rel=1e-6)
+
+        # 2. advantage moments -> identical normalisation on every shard
+        full = oracle.gae(rewards, values, reward_scale=scale, normalize_advantages=False)
+        adv_local = full["advantages"][local, :h].astype(np.float64)
+        moments = shards.sum_(torch.tensor([adv_local.size, adv_local.sum(), (adv_local**2).sum()], dtype=torch.float64))
+        cnt, s, sq = moments.tolist()
+        mean = s / cnt
+        std = np.sqrt((sq - s * mean) / (cnt - 1))
+        normalised = oracle.gae(rewards, values, reward_scale=scale, normalize_advantages=True)
+        assert np.float32(mean) == np.float32(normalised["mean"])
+        assert np.float32(std) == np.float32(normalised["std"])
+
+        # 3. loss sums and gradients: shard-local loss with grad_scale 1/M_global
+        m = n * h
+        flat = lambda a: np.ascontiguousarray(a[:, :h]).reshape(-1, a.shape[-1])  # noqa: E731
+        logits = rng.standard_normal((n, h + 1, 2)).astype(np.float32)
+        actions = rng.integers(0, 2, (n, h + 1, 1))
+        logp_old = (rng.standard_normal((n, h + 1, 1)) * 0.3 - 0.69).astype(np.float32)
+        hp = oracle.ppo_hparams(entropy_coeff=0.01)
+        want_losses, want_g, _ = oracle.ppo_loss_categorical(
+            flat(logits).reshape(m, 1, 2), flat(values), flat(actions), flat(logp_old),
+            flat(normalised["advantages"]), flat(normalised["returns"]), hp)
+        ml = m // WORLD
+        loc_losses, loc_g, _ = oracle.ppo_loss_categorical(
+            flat(logits[local]).reshape(ml, 1, 2), flat(values[local]), flat(actions[local]), flat(logp_old[local]),
+            flat(normalised["advantages"][local]), flat(normalised["returns"][local]), hp)
+        # oracle returns means over its ml samples -> back to raw sums
+        ent_coeff = 0.01
+        pol, vf, ent, kl = (loc_losses[k] * ml for k in ("policy", "vf", "entropy", "kl"))
+        sums = shards.sum_(torch.tensor([ent, pol, vf, float(ml), kl], dtype=torch.float64))
+        got = losses_from_sums(*sums.tolist(), entropy_coeff=ent_coeff, vf_coeff=1.0)
+        for k in ("entropy", "policy", "vf", "total", "kl"):
+            assert got[k] == pytest.approx(want_losses[k], rel=1e-9, abs=1e-12), k
+        # gradient: a linear "model" w so that dL/dw = sum_i g_i * x_i; shard grads are
+        # scaled by 1/M_global (oracle scaled them by 1/ml) and SUM-reduced.
+        w = torch.nn.Parameter(torch.zeros(2))
+        x = torch.from_numpy(flat(logits[local]).astype(np.float64))
+        w.grad = (torch.from_numpy(loc_g.reshape(ml, 2).astype(np.float64)) * (ml / m) * x).sum(0).float()
+        shards.sum_gradients_([w])
+        xw = torch.from_numpy(flat(logits).astype(np.float64))
+        want_grad = (torch.from_numpy(want_g.reshape(m, 2).astype(np.float64)) * xw).sum(0).float()
+        torch.testing.assert_close(w.grad, want_grad, rtol=1e-5, atol=1e-7)
+
+        # 4. parameter broadcast
+        lin = torch.nn.Linear(3, 2)
+        with torch.no_grad():
+            lin.weight.fill_(float(rank + 1))
+        shards.broadcast_parameters_(lin)
+        assert float(lin.weight.mean()) == 1.0
+        results.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        results.put((rank, traceback.format_exc() + str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_env_shard_collectives_world_size_2():
+    ctx = mp.get_context("spawn")
+    results = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, port, results)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    outcomes = [results.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, outcome in sorted(outcomes):
+        assert outcome == "ok", f"rank {rank}: {outcome}"
+
+
+def test_single_process_is_identity():
+    shards = EnvShards()
+    assert not shards.active and shards.world_size == 1 and shards.env_offset(100) == 0
+    t = torch.arange(12, dtype=torch.float64)
+    assert shards.combine_rollout_stats(t) is t and shards.sum_(t) is t
