@@ -52,6 +52,34 @@ ALGORITHMIC_BYTES = {
 }
 
 
+# HBM traffic from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# passes over tools/kernel_microbench.py at config-2 shapes; corrected as
+# MI355X_MICROARCH.md prescribes; summary committed under profiles/). Scaled by
+# units to the launch size bench.py uses.
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_traffic_microbench.json")
+PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in that profiled launch)
+    "ppo_loss_categorical": ("ppo_loss_categorical_kernel", 1 << 22),
+    "ppo_loss_normal": ("ppo_loss_normal_kernel", 1 << 22),
+    "gae_scan": ("gae_scan_time_major_kernel", (1 << 20) * 32),
+    "advantage_normalise": ("advantage_normalise_flat_kernel", (1 << 20) * 32),
+    "rollout_step_dummy": ("rollout_step_dummy_kernel", 1 << 20),
+    "rollout_stats": ("rollout_stats_kernel", (1 << 20) * 32),
+    "gather_minibatch": ("gather_minibatch_kernel", 1 << 22),
+}
+
+
+def pmc_traffic(name: str, units_per_launch: float):
+    try:
+        summary = json.load(open(PMC_SUMMARY))
+    except OSError:
+        return None
+    needle, units = PMC_KERNEL.get(name, (None, 1))
+    for kernel, rec in summary.items():
+        if needle and needle in kernel:
+            return rec["traffic_bytes_per_launch"] / units * units_per_launch
+    return None
+
+
 def parse_args() -> argparse.Namespace:
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -159,6 +187,7 @@ def main() -> None:
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "achieved_GBps": round(gbs, 1),
             "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
+            "pmc_traffic_bytes_per_launch": pmc_traffic(name, rec["units_per_launch"]),
         }
 
     if rank == 0:
@@ -201,7 +230,7 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                 "avg_launch_ms": dom["avg_ms"],
                 "launches": dom["launches"],
-                "traffic": None,
+                "traffic": dom["pmc_traffic_bytes_per_launch"],
             },
             "kernels": kernels,
             "hand_kernel_ms_per_step": round(sum(k["total_ms"] for k in kernels.values()) / args.steps, 3),

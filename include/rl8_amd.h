@@ -44,9 +44,11 @@ extern "C" {
  * pointer, may be NULL) receives "gfx950". */
 int rl8_abi_version(char *arch, int arch_len);
 
-/* Scratch the reductions need (bytes); the caller allocates it once
- * (device memory, 16-byte aligned) and passes it to the calls that take
- * `scratch`.  Contents need no initialisation. */
+/* Scratch the reductions need (bytes); the caller allocates it once per stream
+ * (device memory, 16-byte aligned), ZEROES it once, and passes it to the calls
+ * that take `scratch`.  It holds per-block partial rows and the arrival ticket
+ * of the single-launch reductions (re-zeroed by each call); two calls sharing
+ * one scratch must be ordered on one stream. */
 int64_t rl8_scratch_bytes(void);
 
 /* ---------------------------------------------------------------------- *

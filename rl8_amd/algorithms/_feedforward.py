@@ -59,7 +59,7 @@ from ..tensordict import TensorDict
 
 #: Rows pushed through the policy network per forward/backward pass inside one
 #: minibatch (activations: rows x 256 x 4 B per layer).
-DEFAULT_MAX_ROWS_PER_PASS = 1 << 22
+DEFAULT_MAX_ROWS_PER_PASS = 1 << 23
 
 
 @dataclass

@@ -93,6 +93,32 @@ __device__ __forceinline__ void categorical_normalise(const float (&x)[K], float
   for (int j = 0; j < K; ++j) p[j] = p[j] / s2;
 }
 
+// Loss-kernel variant (tolerance-checked, 1e-5): the hardware exp2 / log2 /
+// rcp units, and p_j = e_j / sum(e) from the first pass -- the reference's second
+// softmax over the already-normalised logits renormalises by 1 +- 1e-7, which is
+// dropped here.  ~4x fewer instructions per sample than the exact-order variant,
+// which keeps the fused loss kernel HBM-bound rather than ALU-bound.
+template <int K>
+__device__ __forceinline__ void categorical_normalise_fast(const float (&x)[K], float (&nl)[K],
+                                                           float (&p)[K]) {
+  float mx = x[0];
+#pragma unroll
+  for (int j = 1; j < K; ++j) mx = fmaxf(mx, x[j]);
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    p[j] = __expf(x[j] - mx);
+    s += p[j];
+  }
+  const float lse = mx + __logf(s);
+  const float inv = __builtin_amdgcn_rcpf(s);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    nl[j] = x[j] - lse;
+    p[j] = p[j] * inv;
+  }
+}
+
 // Runtime-K variant (K <= RL8_MAX_CLASSES) for the generic kernels.
 template <bool CR>
 __device__ __forceinline__ void categorical_normalise_dyn(const float *x, int k, float *nl,
@@ -191,7 +217,7 @@ struct PolicyTerm {
 __device__ __forceinline__ PolicyTerm ppo_policy_term(float logp_new, float logp_old, float adv,
                                                       const rl8_ppo_hparams &hp) {
   const float lr = logp_new - logp_old;
-  const float ratio = expf(lr);
+  const float ratio = __expf(lr);
   const float lo = 1.0f - hp.clip_param, hi = 1.0f + hp.clip_param;
   const float clamped = fminf(fmaxf(ratio, lo), hi);
   const float s1 = adv * ratio;

@@ -16,6 +16,8 @@
 //
 // Both variants also emit fp64 (count, sum, sum of squares) of adv[:, :H] as
 // per-block partials reduced in a fixed order (bitwise reproducible).
+#include <stdlib.h>
+
 #include "common.hip.h"
 
 namespace rl8 {
@@ -44,11 +46,34 @@ struct VecIO<1> {
   __device__ __forceinline__ static void store(float *p, const f4 &a) { *p = a.v[0]; }
 };
 
+// Publishes (sum, sum_sq) of this block; the last block to arrive adds the rows
+// in order and writes moments_out = (count, sum, sum_sq).
+__device__ __forceinline__ void publish_moments(double (&acc)[2], double *partials, double count,
+                                                double *moments_out, double *smem) {
+  if (threadIdx.x == 0) {
+    publish_partial(partials + (int64_t)blockIdx.x * kPartialWidth + 0, acc[0]);
+    publish_partial(partials + (int64_t)blockIdx.x * kPartialWidth + 1, acc[1]);
+  }
+  if (!last_block_arrives(ticket_word(partials))) return;
+  double tot[2] = {0.0, 0.0};
+  for (int r = threadIdx.x; r < (int)gridDim.x; r += blockDim.x) {
+    tot[0] += read_partial(partials + (int64_t)r * kPartialWidth + 0);
+    tot[1] += read_partial(partials + (int64_t)r * kPartialWidth + 1);
+  }
+  block_reduce<2, SumOp>(tot, smem);
+  if (threadIdx.x == 0) {
+    moments_out[0] = count;
+    moments_out[1] = tot[0];
+    moments_out[2] = tot[1];
+    *ticket_word(partials) = 0u;
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gae_scan_time_major_kernel(
     float *__restrict__ rewards, const float *__restrict__ values, float *__restrict__ adv,
     float *__restrict__ ret, int64_t n, int64_t h, float gamma, float gamma_lambda, float denom,
-    int write_back, double *__restrict__ partials) {
+    int write_back, double *__restrict__ partials, double *__restrict__ moments_out) {
   __shared__ double smem[2 * kWavesPerBlock];
   double acc[2] = {0.0, 0.0};
   const int64_t stride_e = (int64_t)gridDim.x * kBlock * VEC;
@@ -89,21 +114,30 @@ __global__ __launch_bounds__(kBlock) void gae_scan_time_major_kernel(
     }
   }
   block_reduce<2, SumOp>(acc, smem);
-  if (threadIdx.x == 0) {
-    partials[(int64_t)blockIdx.x * kPartialWidth + 0] = acc[0];
-    partials[(int64_t)blockIdx.x * kPartialWidth + 1] = acc[1];
-  }
+  publish_moments(acc, partials, (double)n * (double)h, moments_out, smem);
 }
 
-// Env-major, LDS-staged.  Dynamic LDS: two [E][S] float tiles (rewards->adv,
-// values->ret).  blockDim = kBlock; lanes [0, E) scan.
-__global__ __launch_bounds__(kBlock) void gae_scan_env_major_kernel(
+// Env-major, LDS-staged.  One lane per env: blockDim.x == envs_per_block.
+// Dynamic LDS: two [E][S] float tiles (rewards -> advantages, values -> returns).
+//
+// FLAT == true (whole rows in one chunk and S == H+1, i.e. H+1 odd): the tile's
+// global footprint is one contiguous run of E*(H+1) floats whose layout equals
+// the LDS layout, so staging is a straight 16-byte-per-lane copy with several
+// loads in flight per lane, and the odd row stride keeps the per-env column
+// walk conflict-free.  Otherwise rows are padded to an odd stride and copied
+// element-wise (time chunks of long horizons, even H+1).
+constexpr int kStageUnroll = 4;
+
+template <bool FLAT>
+__global__ void gae_scan_env_major_kernel(
     float *__restrict__ rewards, const float *__restrict__ values, float *__restrict__ adv,
     float *__restrict__ ret, int64_t n, int64_t h, float gamma, float gamma_lambda, float denom,
-    int write_back, int envs_per_block, int chunk, int lds_stride,
-    double *__restrict__ partials) {
+    int write_back, int chunk, int lds_stride, double *__restrict__ partials,
+    double *__restrict__ moments_out) {
   extern __shared__ float lds[];
   __shared__ double smem[2 * kWavesPerBlock];
+  const int envs_per_block = blockDim.x;
+  const int nthreads = blockDim.x;
   float *tile_r = lds;
   float *tile_v = lds + (int64_t)envs_per_block * lds_stride;
   const int64_t stride = h + 1;
@@ -111,74 +145,126 @@ __global__ __launch_bounds__(kBlock) void gae_scan_env_major_kernel(
   double acc[2] = {0.0, 0.0};
   const int64_t tiles = (n + envs_per_block - 1) / envs_per_block;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-  const int64_t e0 = tile * envs_per_block;
-  const int ne = (int)((n - e0) < envs_per_block ? (n - e0) : envs_per_block);
-  float prev = 0.0f, v_next = 0.0f;
-  // Walk the H+1 columns from the end in chunks of `chunk` steps.
-  for (int64_t t1 = stride; t1 > 0; t1 -= chunk) {
-    const int64_t t0 = t1 - chunk > 0 ? t1 - chunk : 0;
-    const int tc = (int)(t1 - t0);
-    const int count = ne * tc;
-    __syncthreads();  // previous chunk fully written out before the tile is reused
-    for (int idx = tid; idx < count; idx += kBlock) {
-      const int e = idx / tc, j = idx - e * tc;
-      const int64_t g = (e0 + e) * stride + t0 + j;
-      const float r = rewards[g] / denom;
-      if (write_back) rewards[g] = r;
-      tile_r[e * lds_stride + j] = r;
-      tile_v[e * lds_stride + j] = values[g];
-    }
-    __syncthreads();
-    if (tid < ne) {
-      float *row_r = tile_r + tid * lds_stride;
-      float *row_v = tile_v + tid * lds_stride;
-      for (int j = tc - 1; j >= 0; --j) {
-        const float v = row_v[j];
-        if (t0 + j == h) {  // column H: adv = 0, ret = values (:105, :117)
-          prev = 0.0f;
-          row_r[j] = 0.0f;
-          row_v[j] = 0.0f + v;
-        } else {
-          const float delta = row_r[j] + (gamma * v_next - v);
-          prev = delta + gamma_lambda * prev;
-          row_r[j] = prev;
-          row_v[j] = prev + v;
-          acc[0] += (double)prev;
-          acc[1] += (double)prev * (double)prev;
+    const int64_t e0 = tile * envs_per_block;
+    const int ne = (int)((n - e0) < envs_per_block ? (n - e0) : envs_per_block);
+    float prev = 0.0f, v_next = 0.0f;
+    // Walk the H+1 columns from the end in chunks of `chunk` steps.
+    for (int64_t t1 = stride; t1 > 0; t1 -= chunk) {
+      const int64_t t0 = t1 - chunk > 0 ? t1 - chunk : 0;
+      const int tc = (int)(t1 - t0);
+      const int count = ne * tc;
+      __syncthreads();  // previous tile / chunk fully written out before reuse
+      if (FLAT) {
+        const int64_t base = e0 * stride;
+        const int nvec = count >> 2;
+        const float4 *gr = reinterpret_cast<const float4 *>(rewards + base);
+        const float4 *gv = reinterpret_cast<const float4 *>(values + base);
+        float4 *lr = reinterpret_cast<float4 *>(tile_r);
+        float4 *lv = reinterpret_cast<float4 *>(tile_v);
+        for (int i0 = tid; i0 < nvec; i0 += nthreads * kStageUnroll) {
+          float4 r4[kStageUnroll], v4[kStageUnroll];
+#pragma unroll
+          for (int u = 0; u < kStageUnroll; ++u) {
+            const int i = i0 + u * nthreads;
+            if (i < nvec) {
+              r4[u] = gr[i];
+              v4[u] = gv[i];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kStageUnroll; ++u) {
+            const int i = i0 + u * nthreads;
+            if (i < nvec) {
+              r4[u].x = r4[u].x / denom; r4[u].y = r4[u].y / denom;
+              r4[u].z = r4[u].z / denom; r4[u].w = r4[u].w / denom;
+              lr[i] = r4[u];
+              lv[i] = v4[u];
+              if (write_back) reinterpret_cast<float4 *>(rewards + base)[i] = r4[u];
+            }
+          }
         }
-        v_next = v;
+        for (int i = (nvec << 2) + tid; i < count; i += nthreads) {  // < 4 leftovers
+          const float r = rewards[base + i] / denom;
+          if (write_back) rewards[base + i] = r;
+          tile_r[i] = r;
+          tile_v[i] = values[base + i];
+        }
+      } else {
+        for (int i0 = tid; i0 < count; i0 += nthreads * kStageUnroll) {
+          float r1[kStageUnroll], v1[kStageUnroll];
+#pragma unroll
+          for (int u = 0; u < kStageUnroll; ++u) {
+            const int idx = i0 + u * nthreads;
+            if (idx < count) {
+              const int e = idx / tc, j = idx - e * tc;
+              const int64_t g = (e0 + e) * stride + t0 + j;
+              r1[u] = rewards[g];
+              v1[u] = values[g];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kStageUnroll; ++u) {
+            const int idx = i0 + u * nthreads;
+            if (idx < count) {
+              const int e = idx / tc, j = idx - e * tc;
+              const float r = r1[u] / denom;
+              if (write_back) rewards[(e0 + e) * stride + t0 + j] = r;
+              tile_r[e * lds_stride + j] = r;
+              tile_v[e * lds_stride + j] = v1[u];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < ne) {
+        float *row_r = tile_r + tid * lds_stride;
+        float *row_v = tile_v + tid * lds_stride;
+#pragma unroll 4
+        for (int j = tc - 1; j >= 0; --j) {
+          const float v = row_v[j];
+          if (t0 + j == h) {  // column H: adv = 0, ret = values (:105, :117)
+            prev = 0.0f;
+            row_r[j] = 0.0f;
+            row_v[j] = 0.0f + v;
+          } else {
+            const float delta = row_r[j] + (gamma * v_next - v);
+            prev = delta + gamma_lambda * prev;
+            row_r[j] = prev;
+            row_v[j] = prev + v;
+            acc[0] += (double)prev;
+            acc[1] += (double)prev * (double)prev;
+          }
+          v_next = v;
+        }
+      }
+      __syncthreads();
+      if (FLAT) {
+        const int64_t base = e0 * stride;
+        const int nvec = count >> 2;
+        float4 *ga = reinterpret_cast<float4 *>(adv + base);
+        float4 *gq = reinterpret_cast<float4 *>(ret + base);
+        const float4 *lr = reinterpret_cast<const float4 *>(tile_r);
+        const float4 *lv = reinterpret_cast<const float4 *>(tile_v);
+        for (int i = tid; i < nvec; i += nthreads) {
+          ga[i] = lr[i];
+          gq[i] = lv[i];
+        }
+        for (int i = (nvec << 2) + tid; i < count; i += nthreads) {
+          adv[base + i] = tile_r[i];
+          ret[base + i] = tile_v[i];
+        }
+      } else {
+        for (int idx = tid; idx < count; idx += nthreads) {
+          const int e = idx / tc, j = idx - e * tc;
+          const int64_t g = (e0 + e) * stride + t0 + j;
+          adv[g] = tile_r[e * lds_stride + j];
+          ret[g] = tile_v[e * lds_stride + j];
+        }
       }
     }
-    __syncthreads();
-    for (int idx = tid; idx < count; idx += kBlock) {
-      const int e = idx / tc, j = idx - e * tc;
-      const int64_t g = (e0 + e) * stride + t0 + j;
-      adv[g] = tile_r[e * lds_stride + j];
-      ret[g] = tile_v[e * lds_stride + j];
-    }
-  }
   }
   block_reduce<2, SumOp>(acc, smem);
-  if (tid == 0) {
-    partials[(int64_t)blockIdx.x * kPartialWidth + 0] = acc[0];
-    partials[(int64_t)blockIdx.x * kPartialWidth + 1] = acc[1];
-  }
-}
-
-__global__ void gae_moments_kernel(const double *__restrict__ partials, int rows, double count,
-                                   double *__restrict__ out) {
-  __shared__ double smem[2 * kWavesPerBlock];
-  double acc[2] = {0.0, 0.0};
-  for (int r = threadIdx.x; r < rows; r += kBlock) {
-    acc[0] += partials[(int64_t)r * kPartialWidth + 0];
-    acc[1] += partials[(int64_t)r * kPartialWidth + 1];
-  }
-  block_reduce<2, SumOp>(acc, smem);
-  if (threadIdx.x == 0) {
-    out[0] = count;
-    out[1] = acc[0];
-    out[2] = acc[1];
-  }
+  publish_moments(acc, partials, (double)n * (double)h, moments_out, smem);
 }
 
 struct NormConsts {
@@ -243,27 +329,48 @@ RL8_API int rl8_gae_scan_f32(float *rewards, const float *values, float *adv_out
     if (vec)
       gae_scan_time_major_kernel<4><<<rows, kBlock, 0, s>>>(
           rewards, values, adv_out, ret_out, n, h, gamma, gamma_lambda, reward_denominator,
-          write_scaled_rewards, partials);
+          write_scaled_rewards, partials, moments_out);
     else
       gae_scan_time_major_kernel<1><<<rows, kBlock, 0, s>>>(
           rewards, values, adv_out, ret_out, n, h, gamma, gamma_lambda, reward_denominator,
-          write_scaled_rewards, partials);
+          write_scaled_rewards, partials, moments_out);
   } else {
     const int64_t cols = h + 1;
     const int chunk = (int)(cols < 127 ? cols : 127);
     const int lds_stride = chunk | 1;  // odd => conflict-free column walks
-    int e = (int)(65536 / ((int64_t)lds_stride * 8) / kWave) * kWave;
-    if (e > kBlock) e = kBlock;
+    // One lane per env; as many envs per block as ~72 KB of LDS allow (2 blocks
+    // per CU), in whole waves.  RL8_GAE_ENVS_PER_BLOCK overrides (tuning).
+    static int env_override = -1;
+    if (env_override < 0) {
+      const char *v = getenv("RL8_GAE_ENVS_PER_BLOCK");
+      env_override = v ? atoi(v) : 0;
+    }
+    int e = (int)(73728 / ((int64_t)lds_stride * 8) / kWave) * kWave;
+    if (e > 256) e = 256;
+    if (env_override >= kWave && env_override <= 256 && env_override % kWave == 0) e = env_override;
     if (e < kWave) e = kWave;
-    rows = grid_for(n, e);
     const size_t lds_bytes = (size_t)2 * e * lds_stride * sizeof(float);
-    gae_scan_env_major_kernel<<<rows, kBlock, lds_bytes, s>>>(
-        rewards, values, adv_out, ret_out, n, h, gamma, gamma_lambda, reward_denominator,
-        write_scaled_rewards, e, chunk, lds_stride, partials);
+    const bool flat = chunk == cols && lds_stride == cols && (e % 4 == 0) && aligned16(rewards) &&
+                      aligned16(values) && aligned16(adv_out) && aligned16(ret_out);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gae_scan_env_major_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gae_scan_env_major_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError();
+      attr_set = true;
+    }
+    rows = grid_for(n, e);
+    if (flat)
+      gae_scan_env_major_kernel<true><<<rows, e, lds_bytes, s>>>(
+          rewards, values, adv_out, ret_out, n, h, gamma, gamma_lambda, reward_denominator,
+          write_scaled_rewards, chunk, lds_stride, partials, moments_out);
+    else
+      gae_scan_env_major_kernel<false><<<rows, e, lds_bytes, s>>>(
+          rewards, values, adv_out, ret_out, n, h, gamma, gamma_lambda, reward_denominator,
+          write_scaled_rewards, chunk, lds_stride, partials, moments_out);
   }
-  int st = launch_status();
-  if (st != RL8_OK) return st;
-  gae_moments_kernel<<<1, kBlock, 0, s>>>(partials, rows, (double)n * (double)h, moments_out);
   return launch_status();
 }
 

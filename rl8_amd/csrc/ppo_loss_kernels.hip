@@ -21,6 +21,34 @@ namespace rl8 {
 
 constexpr int kLossCols = 4;  // entropy, policy, vf, kl
 
+// Publishes this block's row; the last block to arrive sums rows [0, rows) in
+// order and writes out[0..4] = sum entropy, policy, vf, sample count, sum kl.
+__device__ __forceinline__ void publish_loss_row(double (&acc)[kLossCols], double *partials,
+                                                 int row, int rows, double count, double *out,
+                                                 double *smem) {
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < kLossCols; ++c)
+      publish_partial(partials + (int64_t)row * kPartialWidth + c, acc[c]);
+  }
+  if (!last_block_arrives(ticket_word(partials))) return;
+  double tot[kLossCols] = {0.0, 0.0, 0.0, 0.0};
+  for (int r = threadIdx.x; r < rows; r += kBlock) {
+#pragma unroll
+    for (int c = 0; c < kLossCols; ++c)
+      tot[c] += read_partial(partials + (int64_t)r * kPartialWidth + c);
+  }
+  block_reduce<kLossCols, SumOp>(tot, smem);
+  if (threadIdx.x == 0) {
+    out[0] = tot[0];
+    out[1] = tot[1];
+    out[2] = tot[2];
+    out[3] = count;
+    out[4] = tot[3];
+    *ticket_word(partials) = 0u;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Categorical, A == 1, compile-time K, SPT samples per thread with 16-byte
 // loads wherever SPT*K*4 and SPT*4 are multiples of 16.
@@ -31,11 +59,11 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
     const int64_t *__restrict__ action, const float *__restrict__ logp_old,
     const float *__restrict__ adv, const float *__restrict__ ret, int64_t m, rl8_ppo_hparams hp,
     float *__restrict__ grad_logits, float *__restrict__ grad_value,
-    double *__restrict__ partials) {
+    double *__restrict__ partials, int extra_rows, double *__restrict__ sums_out) {
   __shared__ double smem[kLossCols * kWavesPerBlock];
   double acc[kLossCols] = {0.0, 0.0, 0.0, 0.0};
   const bool with_entropy = hp.entropy_coeff != 0.0f;
-  const int64_t groups = m / SPT;  // full groups; the tail is handled below
+  const int64_t groups = m / SPT;  // full groups; the tail went to a generic launch
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
     const int64_t i0 = g * SPT;
@@ -70,12 +98,13 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
       }
     }
     float gx[SPT * K], gv[SPT];
+    float part[kLossCols] = {0.0f, 0.0f, 0.0f, 0.0f};  // this group's terms, f32
 #pragma unroll
     for (int s = 0; s < SPT; ++s) {
       float xs[K], nl[K], p[K];
 #pragma unroll
       for (int j = 0; j < K; ++j) xs[j] = x[s * K + j];
-      categorical_normalise<K, false>(xs, nl, p);
+      categorical_normalise_fast<K>(xs, nl, p);
       float logp = nl[0];
 #pragma unroll
       for (int j = 1; j < K; ++j) logp = (act[s] == j) ? nl[j] : logp;
@@ -89,10 +118,10 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
       const PolicyTerm pt = ppo_policy_term(logp, lo[s], ad[s], hp);
       float dv;
       const float vterm = ppo_vf_term(v[s], rt[s], hp, &dv);
-      acc[0] += (double)ent;
-      acc[1] += (double)pt.term;
-      acc[2] += (double)vterm;
-      acc[3] += (double)pt.kl;
+      part[0] += ent;
+      part[1] += pt.term;
+      part[2] += vterm;
+      part[3] += pt.kl;
       if (HAS_GRAD) {
         gv[s] = hp.grad_scale * hp.vf_coeff * dv;
 #pragma unroll
@@ -104,6 +133,8 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
         }
       }
     }
+#pragma unroll
+    for (int c = 0; c < kLossCols; ++c) acc[c] += (double)part[c];
     if (HAS_GRAD) {
       if constexpr (SPT == 4) {
         float4 *gp = reinterpret_cast<float4 *>(grad_logits + i0 * K);
@@ -122,11 +153,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
     }
   }
   block_reduce<kLossCols, SumOp>(acc, smem);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int c = 0; c < kLossCols; ++c)
-      partials[(int64_t)blockIdx.x * kPartialWidth + c] = acc[c];
-  }
+  publish_loss_row(acc, partials, blockIdx.x, gridDim.x + extra_rows, (double)m, sums_out, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -139,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_generic_kernel(
     const int64_t *__restrict__ action, const float *__restrict__ logp_old,
     const float *__restrict__ adv, const float *__restrict__ ret, int64_t first, int64_t m, int a,
     int k, rl8_ppo_hparams hp, float *__restrict__ grad_logits, float *__restrict__ grad_value,
-    double *__restrict__ partials, int partial_row0) {
+    double *__restrict__ partials, int partial_row0, double *__restrict__ sums_out) {
   __shared__ double smem[kLossCols * kWavesPerBlock];
   double acc[kLossCols] = {0.0, 0.0, 0.0, 0.0};
   const bool with_entropy = hp.entropy_coeff != 0.0f;
@@ -186,7 +213,9 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_generic_kernel(
     }
   }
   block_reduce<kLossCols, SumOp>(acc, smem);
-  if (threadIdx.x == 0) {
+  if (sums_out) {  // sole launch: publish + finalise
+    publish_loss_row(acc, partials, blockIdx.x, gridDim.x, (double)m, sums_out, smem);
+  } else if (threadIdx.x == 0) {  // tail helper of the vector kernel: row only
 #pragma unroll
     for (int c = 0; c < kLossCols; ++c)
       partials[(int64_t)(partial_row0 + blockIdx.x) * kPartialWidth + c] = acc[c];
@@ -203,7 +232,8 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_normal_kernel(
     const float *__restrict__ logp_old, const float *__restrict__ adv,
     const float *__restrict__ ret, int64_t m, int a, int squashed, rl8_ppo_hparams hp,
     float *__restrict__ grad_mean, float *__restrict__ grad_log_std,
-    float *__restrict__ grad_value, double *__restrict__ partials) {
+    float *__restrict__ grad_value, double *__restrict__ partials,
+    double *__restrict__ sums_out) {
   __shared__ double smem[kLossCols * kWavesPerBlock];
   double acc[kLossCols] = {0.0, 0.0, 0.0, 0.0};
   const bool with_entropy = hp.entropy_coeff != 0.0f && !squashed;
@@ -253,46 +283,25 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_normal_kernel(
     }
   }
   block_reduce<kLossCols, SumOp>(acc, smem);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int c = 0; c < kLossCols; ++c)
-      partials[(int64_t)blockIdx.x * kPartialWidth + c] = acc[c];
-  }
-}
-
-// out[0..4] = sum entropy, sum policy, sum vf, sample count, sum kl.
-__global__ void ppo_loss_sums_kernel(const double *__restrict__ partials, int rows, double count,
-                                     double *__restrict__ out) {
-  __shared__ double smem[kLossCols * kWavesPerBlock];
-  double acc[kLossCols] = {0.0, 0.0, 0.0, 0.0};
-  for (int r = threadIdx.x; r < rows; r += kBlock) {
-#pragma unroll
-    for (int c = 0; c < kLossCols; ++c) acc[c] += partials[(int64_t)r * kPartialWidth + c];
-  }
-  block_reduce<kLossCols, SumOp>(acc, smem);
-  if (threadIdx.x == 0) {
-    out[0] = acc[0];
-    out[1] = acc[1];
-    out[2] = acc[2];
-    out[3] = count;
-    out[4] = acc[3];
-  }
+  publish_loss_row(acc, partials, blockIdx.x, gridDim.x, (double)m, sums_out, smem);
 }
 
 template <int K>
 static int launch_categorical_vec(const float *logits, const float *value, const int64_t *action,
                                   const float *logp_old, const float *adv, const float *ret,
                                   int64_t m, const rl8_ppo_hparams &hp, float *grad_logits,
-                                  float *grad_value, double *partials, int *rows, hipStream_t s) {
+                                  float *grad_value, double *partials, int extra_rows,
+                                  double *sums_out, hipStream_t s) {
   const int64_t groups = m / 4;
   const int grid = grid_for(groups, kBlock);
   if (grad_logits)
     ppo_loss_categorical_kernel<K, 4, true><<<grid, kBlock, 0, s>>>(
-        logits, value, action, logp_old, adv, ret, m, hp, grad_logits, grad_value, partials);
+        logits, value, action, logp_old, adv, ret, m, hp, grad_logits, grad_value, partials,
+        extra_rows, sums_out);
   else
     ppo_loss_categorical_kernel<K, 4, false><<<grid, kBlock, 0, s>>>(
-        logits, value, action, logp_old, adv, ret, m, hp, nullptr, nullptr, partials);
-  *rows = grid;
+        logits, value, action, logp_old, adv, ret, m, hp, nullptr, nullptr, partials, extra_rows,
+        sums_out);
   return launch_status();
 }
 
@@ -319,44 +328,44 @@ RL8_API int rl8_ppo_loss_categorical_fwd_bwd_f32(
   if (st != RL8_OK) return st;
   hipStream_t s = (hipStream_t)stream;
   double *partials = (double *)scratch;
-  int rows = 0;
   const bool vec_ok = a == 1 && (k == 2 || k == 3) && m >= 4 && aligned16(logits) &&
                       aligned16(value) && aligned16(action) && aligned16(logp_old) &&
                       aligned16(adv) && aligned16(ret) &&
                       (!grad_logits || (aligned16(grad_logits) && aligned16(grad_value)));
   if (vec_ok) {
-    st = (k == 2) ? launch_categorical_vec<2>(logits, value, action, logp_old, adv, ret, m, *hp,
-                                              grad_logits, grad_value, partials, &rows, s)
-                  : launch_categorical_vec<3>(logits, value, action, logp_old, adv, ret, m, *hp,
-                                              grad_logits, grad_value, partials, &rows, s);
-    if (st != RL8_OK) return st;
+    // Up to 3 tail samples go through the generic kernel first; it deposits its
+    // row after the vector kernel's rows and the vector kernel finalises both.
     const int64_t first = (m / 4) * 4;
-    if (first < m) {  // at most 3 samples
+    const int extra = first < m ? 1 : 0;
+    const int grid = grid_for(m / 4, kBlock);
+    if (extra) {
       if (grad_logits)
         ppo_loss_categorical_generic_kernel<true><<<1, kBlock, 0, s>>>(
             logits, value, action, logp_old, adv, ret, first, m, a, k, *hp, grad_logits,
-            grad_value, partials, rows);
+            grad_value, partials, grid, nullptr);
       else
         ppo_loss_categorical_generic_kernel<false><<<1, kBlock, 0, s>>>(
             logits, value, action, logp_old, adv, ret, first, m, a, k, *hp, nullptr, nullptr,
-            partials, rows);
-      rows += 1;
+            partials, grid, nullptr);
+      st = launch_status();
+      if (st != RL8_OK) return st;
     }
-  } else {
-    const int grid = grid_for(m, kBlock);
-    if (grad_logits)
-      ppo_loss_categorical_generic_kernel<true><<<grid, kBlock, 0, s>>>(
-          logits, value, action, logp_old, adv, ret, 0, m, a, k, *hp, grad_logits, grad_value,
-          partials, 0);
-    else
-      ppo_loss_categorical_generic_kernel<false><<<grid, kBlock, 0, s>>>(
-          logits, value, action, logp_old, adv, ret, 0, m, a, k, *hp, nullptr, nullptr, partials,
-          0);
-    rows = grid;
+    return (k == 2) ? launch_categorical_vec<2>(logits, value, action, logp_old, adv, ret, m, *hp,
+                                                grad_logits, grad_value, partials, extra,
+                                                loss_sums_out, s)
+                    : launch_categorical_vec<3>(logits, value, action, logp_old, adv, ret, m, *hp,
+                                                grad_logits, grad_value, partials, extra,
+                                                loss_sums_out, s);
   }
-  st = launch_status();
-  if (st != RL8_OK) return st;
-  ppo_loss_sums_kernel<<<1, kBlock, 0, s>>>(partials, rows, (double)m, loss_sums_out);
+  const int grid = grid_for(m, kBlock);
+  if (grad_logits)
+    ppo_loss_categorical_generic_kernel<true><<<grid, kBlock, 0, s>>>(
+        logits, value, action, logp_old, adv, ret, 0, m, a, k, *hp, grad_logits, grad_value,
+        partials, 0, loss_sums_out);
+  else
+    ppo_loss_categorical_generic_kernel<false><<<grid, kBlock, 0, s>>>(
+        logits, value, action, logp_old, adv, ret, 0, m, a, k, *hp, nullptr, nullptr, partials, 0,
+        loss_sums_out);
   return launch_status();
 }
 
@@ -378,15 +387,12 @@ RL8_API int rl8_ppo_loss_normal_fwd_bwd_f32(
   double *partials = (double *)scratch;
   const int grid = grid_for(m, kBlock);
   if (ng)
-    ppo_loss_normal_kernel<true><<<grid, kBlock, 0, s>>>(mean, log_std, value, action, logp_old,
-                                                         adv, ret, m, a, squashed, *hp, grad_mean,
-                                                         grad_log_std, grad_value, partials);
+    ppo_loss_normal_kernel<true><<<grid, kBlock, 0, s>>>(
+        mean, log_std, value, action, logp_old, adv, ret, m, a, squashed, *hp, grad_mean,
+        grad_log_std, grad_value, partials, loss_sums_out);
   else
-    ppo_loss_normal_kernel<false><<<grid, kBlock, 0, s>>>(mean, log_std, value, action, logp_old,
-                                                          adv, ret, m, a, squashed, *hp, nullptr,
-                                                          nullptr, nullptr, partials);
-  st = launch_status();
-  if (st != RL8_OK) return st;
-  ppo_loss_sums_kernel<<<1, kBlock, 0, s>>>(partials, grid, (double)m, loss_sums_out);
+    ppo_loss_normal_kernel<false><<<grid, kBlock, 0, s>>>(
+        mean, log_std, value, action, logp_old, adv, ret, m, a, squashed, *hp, nullptr, nullptr,
+        nullptr, partials, loss_sums_out);
   return launch_status();
 }

@@ -13,40 +13,66 @@
 
 namespace rl8 {
 
-constexpr int kStatCols = 10;
 // partial columns: 0 sum(ret) 1 sum(ret^2) 2 min(ret) 3 max(ret)
 //                  4 sum(r)   5 sum(r^2)   6 min(r)   7 max(r)
 //                  8 sum(rdr) 9 sum(rdr^2)
 
+// VEC == 4: time-major leaves (env_stride == 1): one lane walks 4 adjacent envs
+// with 16-byte loads per column.  VEC == 1: any strides, one env per lane.
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void rollout_stats_kernel(
     const float *__restrict__ rewards, const float *__restrict__ rdr, int64_t n, int64_t h,
-    int64_t env_stride, int64_t time_stride, double *__restrict__ partials) {
-  __shared__ double smem[4 * kWavesPerBlock];
+    int64_t env_stride, int64_t time_stride, double *__restrict__ partials,
+    double *__restrict__ out) {
+  __shared__ double smem[6 * kWavesPerBlock];
   double sums[6] = {0, 0, 0, 0, 0, 0};  // ret, ret^2, r, r^2, rdr, rdr^2
   double mins[2] = {INFINITY, INFINITY}, maxs[2] = {-INFINITY, -INFINITY};
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
-    const float *rrow = rewards + e * env_stride;
-    float ret = 0.0f;  // torch.sum(rewards[:, :-1], dim=1) accumulates in f32
+  const int64_t stride = (int64_t)gridDim.x * kBlock * VEC;
+  for (int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC; e < n; e += stride) {
+    float ret[VEC];  // torch.sum(rewards[:, :-1], dim=1) accumulates in f32
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ret[i] = 0.0f;
+    float rmin = INFINITY, rmax = -INFINITY;
+#pragma unroll 4
     for (int64_t t = 0; t < h; ++t) {
-      const float r = rrow[t * time_stride];
-      ret = ret + r;
-      sums[2] += (double)r;
-      sums[3] += (double)r * (double)r;
-      mins[1] = r < mins[1] ? (double)r : mins[1];
-      maxs[1] = r > maxs[1] ? (double)r : maxs[1];
-    }
-    sums[0] += (double)ret;
-    sums[1] += (double)ret * (double)ret;
-    mins[0] = ret < mins[0] ? (double)ret : mins[0];
-    maxs[0] = ret > maxs[0] ? (double)ret : maxs[0];
-    if (rdr) {
-      const float *drow = rdr + e * env_stride;
-      for (int64_t t = 1; t <= h; ++t) {
-        const double d = (double)drow[t * time_stride];
-        sums[4] += d;
-        sums[5] += d * d;
+      float r[VEC];
+      if constexpr (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(rewards + t * time_stride + e);
+        r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+      } else {
+        r[0] = rewards[e * env_stride + t * time_stride];
       }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        ret[i] = ret[i] + r[i];
+        sums[2] += (double)r[i];
+        sums[3] += (double)r[i] * (double)r[i];
+        rmin = fminf(rmin, r[i]);
+        rmax = fmaxf(rmax, r[i]);
+      }
+      if (rdr) {
+        float d[VEC];
+        if constexpr (VEC == 4) {
+          const float4 q = *reinterpret_cast<const float4 *>(rdr + (t + 1) * time_stride + e);
+          d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        } else {
+          d[0] = rdr[e * env_stride + (t + 1) * time_stride];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          sums[4] += (double)d[i];
+          sums[5] += (double)d[i] * (double)d[i];
+        }
+      }
+    }
+    mins[1] = (double)rmin < mins[1] ? (double)rmin : mins[1];
+    maxs[1] = (double)rmax > maxs[1] ? (double)rmax : maxs[1];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      sums[0] += (double)ret[i];
+      sums[1] += (double)ret[i] * (double)ret[i];
+      mins[0] = ret[i] < mins[0] ? (double)ret[i] : mins[0];
+      maxs[0] = ret[i] > maxs[0] ? (double)ret[i] : maxs[0];
     }
   }
   double a4[4] = {sums[0], sums[1], sums[2], sums[3]};
@@ -57,19 +83,22 @@ __global__ __launch_bounds__(kBlock) void rollout_stats_kernel(
   block_reduce<2, MaxOp>(maxs, smem);
   if (threadIdx.x == 0) {
     double *row = partials + (int64_t)blockIdx.x * kPartialWidth;
-    row[0] = a4[0]; row[1] = a4[1]; row[2] = mins[0]; row[3] = maxs[0];
-    row[4] = a4[2]; row[5] = a4[3]; row[6] = mins[1]; row[7] = maxs[1];
-    row[8] = b2[0]; row[9] = b2[1];
+    const double vals[10] = {a4[0], a4[1], mins[0], maxs[0], a4[2], a4[3], mins[1], maxs[1],
+                             b2[0], b2[1]};
+#pragma unroll
+    for (int c = 0; c < 10; ++c) publish_partial(row + c, vals[c]);
   }
-}
-
-__global__ void rollout_stats_finalize_kernel(const double *__restrict__ partials, int rows,
-                                              double n, double nh, double *__restrict__ out) {
-  __shared__ double smem[6 * kWavesPerBlock];
-  double sums[6] = {0, 0, 0, 0, 0, 0};
-  double mins[2] = {INFINITY, INFINITY}, maxs[2] = {-INFINITY, -INFINITY};
+  if (!last_block_arrives(ticket_word(partials))) return;
+  // Last block: combine every row in order (fixed order => reproducible).
+  for (int i = 0; i < 6; ++i) sums[i] = 0.0;
+  mins[0] = mins[1] = INFINITY;
+  maxs[0] = maxs[1] = -INFINITY;
+  const int rows = (int)gridDim.x;
+  const double nn = (double)n, nh = (double)n * (double)h;
   for (int r = threadIdx.x; r < rows; r += kBlock) {
-    const double *row = partials + (int64_t)r * kPartialWidth;
+    double row[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) row[c] = read_partial(partials + (int64_t)r * kPartialWidth + c);
     sums[0] += row[0]; sums[1] += row[1]; sums[2] += row[4];
     sums[3] += row[5]; sums[4] += row[8]; sums[5] += row[9];
     mins[0] = row[2] < mins[0] ? row[2] : mins[0];
@@ -81,9 +110,10 @@ __global__ void rollout_stats_finalize_kernel(const double *__restrict__ partial
   block_reduce<2, MinOp>(mins, smem);
   block_reduce<2, MaxOp>(maxs, smem);
   if (threadIdx.x == 0) {
-    out[0] = n;   out[1] = sums[0]; out[2] = sums[1]; out[3] = mins[0]; out[4] = maxs[0];
+    out[0] = nn;  out[1] = sums[0]; out[2] = sums[1]; out[3] = mins[0]; out[4] = maxs[0];
     out[5] = nh;  out[6] = sums[2]; out[7] = sums[3]; out[8] = mins[1]; out[9] = maxs[1];
     out[10] = sums[4]; out[11] = sums[5];
+    *ticket_word(partials) = 0u;
   }
 }
 
@@ -142,13 +172,14 @@ RL8_API int rl8_rollout_stats_f32(const float *rewards, const float *rdr, int64_
   if (n <= 0 || h <= 0 || env_stride <= 0 || time_stride <= 0) return RL8_ESIZE;
   hipStream_t s = (hipStream_t)stream;
   double *partials = (double *)scratch;
-  const int grid = grid_for(n, kBlock);
-  rollout_stats_kernel<<<grid, kBlock, 0, s>>>(rewards, rdr, n, h, env_stride, time_stride,
-                                               partials);
-  int st = launch_status();
-  if (st != RL8_OK) return st;
-  rollout_stats_finalize_kernel<<<1, kBlock, 0, s>>>(partials, grid, (double)n,
-                                                     (double)n * (double)h, stats_out);
+  const bool vec = env_stride == 1 && n % 4 == 0 && time_stride % 4 == 0 && aligned16(rewards) &&
+                   (!rdr || aligned16(rdr));
+  if (vec)
+    rollout_stats_kernel<4><<<grid_for(n, kBlock * 4), kBlock, 0, s>>>(
+        rewards, rdr, n, h, env_stride, time_stride, partials, stats_out);
+  else
+    rollout_stats_kernel<1><<<grid_for(n, kBlock), kBlock, 0, s>>>(
+        rewards, rdr, n, h, env_stride, time_stride, partials, stats_out);
   return launch_status();
 }
 

