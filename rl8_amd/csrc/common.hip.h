@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rl8_amd.h"
 
@@ -107,11 +108,17 @@ __device__ __forceinline__ unsigned *ticket_word(double *scratch) {
   return reinterpret_cast<unsigned *>(scratch + (int64_t)RL8_MAX_PARTIALS * 16);
 }
 
-inline int grid_for(int64_t work_items, int items_per_block) {
+inline int grid_for(int64_t work_items, int items_per_block, int cap = kMaxGrid) {
   int64_t g = (work_items + items_per_block - 1) / items_per_block;
   if (g < 1) g = 1;
-  if (g > kMaxGrid) g = kMaxGrid;
+  if (g > cap) g = cap;
   return (int)g;
+}
+
+// Tuning knob: integer environment variable read once (0 / unset = default).
+inline int env_int(const char *name) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : 0;
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -14,6 +14,8 @@
 //
 // The gradient scale 1/(M_global * grad_accumulation_steps) is known before the
 // launch, so gradients do not wait for the reduced loss.
+#include <stdlib.h>
+
 #include "common.hip.h"
 #include "device_math.hip.h"
 
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
   const bool with_entropy = hp.entropy_coeff != 0.0f;
   const int64_t groups = m / SPT;  // full groups; the tail went to a generic launch
   const int64_t stride = (int64_t)gridDim.x * kBlock;
+#pragma unroll 2
   for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
     const int64_t i0 = g * SPT;
     float x[SPT * K], v[SPT], lo[SPT], ad[SPT], rt[SPT];
@@ -286,14 +289,34 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_normal_kernel(
   publish_loss_row(acc, partials, blockIdx.x, gridDim.x, (double)m, sums_out, smem);
 }
 
+// Workgroups of the 4-samples-per-lane kernel (RL8_LOSS_GRID_CAP: tuning knob).
+static int vec_loss_grid(int64_t m) {
+  const int64_t groups = m / 4;
+  // One workgroup per CU, grid-striding: measured 5.1 TB/s vs 4.2 TB/s with 8
+  // workgroups per CU at 8M samples (fewer concurrent streams per HBM channel).
+  int grid = grid_for(groups, kBlock);
+  if (grid > kCUs) grid = kCUs;
+  static int cap = -1;
+  if (cap < 0) {
+    const char *v = getenv("RL8_LOSS_GRID_CAP");
+    cap = v ? atoi(v) : 0;
+  }
+  if (cap > 0) {
+    const int64_t gg = (groups + kBlock - 1) / kBlock;
+    grid = (int)(gg < cap ? gg : cap);
+    if (grid > RL8_MAX_PARTIALS) grid = RL8_MAX_PARTIALS;
+    if (grid < 1) grid = 1;
+  }
+  return grid;
+}
+
 template <int K>
 static int launch_categorical_vec(const float *logits, const float *value, const int64_t *action,
                                   const float *logp_old, const float *adv, const float *ret,
                                   int64_t m, const rl8_ppo_hparams &hp, float *grad_logits,
                                   float *grad_value, double *partials, int extra_rows,
                                   double *sums_out, hipStream_t s) {
-  const int64_t groups = m / 4;
-  const int grid = grid_for(groups, kBlock);
+  const int grid = vec_loss_grid(m);
   if (grad_logits)
     ppo_loss_categorical_kernel<K, 4, true><<<grid, kBlock, 0, s>>>(
         logits, value, action, logp_old, adv, ret, m, hp, grad_logits, grad_value, partials,
@@ -337,7 +360,7 @@ RL8_API int rl8_ppo_loss_categorical_fwd_bwd_f32(
     // row after the vector kernel's rows and the vector kernel finalises both.
     const int64_t first = (m / 4) * 4;
     const int extra = first < m ? 1 : 0;
-    const int grid = grid_for(m / 4, kBlock);
+    const int grid = vec_loss_grid(m);
     if (extra) {
       if (grad_logits)
         ppo_loss_categorical_generic_kernel<true><<<1, kBlock, 0, s>>>(

@@ -355,12 +355,14 @@ RL8_API int rl8_rollout_step_dummy_f32(int is_discrete, int squashed, const floa
                       (noise && (reinterpret_cast<uintptr_t>(noise) & 7u))))
     return RL8_EALIGN;
   hipStream_t s = (hipStream_t)stream;
+  static const int cap = env_int("RL8_STEP_GRID_CAP");
+  const int grid = grid_for(n, kBlock, cap > 0 ? cap : kMaxGrid);
   if (is_discrete)
-    rollout_step_dummy_kernel<true><<<grid_for(n, kBlock), kBlock, 0, s>>>(
+    rollout_step_dummy_kernel<true><<<grid, kBlock, 0, s>>>(
         squashed, features, features2, value, noise, state, action_col, logp_col, value_col,
         reward_col, obs_col_next, rdr_t, rdr_t1, gamma, n, seed, step, env_offset, deterministic);
   else
-    rollout_step_dummy_kernel<false><<<grid_for(n, kBlock), kBlock, 0, s>>>(
+    rollout_step_dummy_kernel<false><<<grid, kBlock, 0, s>>>(
         squashed, features, features2, value, noise, state, action_col, logp_col, value_col,
         reward_col, obs_col_next, rdr_t, rdr_t1, gamma, n, seed, step, env_offset, deterministic);
   return launch_status();

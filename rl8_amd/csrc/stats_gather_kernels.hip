@@ -174,8 +174,9 @@ RL8_API int rl8_rollout_stats_f32(const float *rewards, const float *rdr, int64_
   double *partials = (double *)scratch;
   const bool vec = env_stride == 1 && n % 4 == 0 && time_stride % 4 == 0 && aligned16(rewards) &&
                    (!rdr || aligned16(rdr));
+  static const int cap = env_int("RL8_STATS_GRID_CAP");
   if (vec)
-    rollout_stats_kernel<4><<<grid_for(n, kBlock * 4), kBlock, 0, s>>>(
+    rollout_stats_kernel<4><<<grid_for(n, kBlock * 4, cap > 0 ? cap : kMaxGrid), kBlock, 0, s>>>(
         rewards, rdr, n, h, env_stride, time_stride, partials, stats_out);
   else
     rollout_stats_kernel<1><<<grid_for(n, kBlock), kBlock, 0, s>>>(
