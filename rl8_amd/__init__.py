@@ -10,8 +10,19 @@ networks run on PyTorch-ROCm.
 Importing the package never needs a GPU; running anything does.
 """
 
-from .algorithms import Algorithm, AlgorithmConfig
+from .algorithms import (
+    Algorithm,
+    AlgorithmConfig,
+    RecurrentAlgorithm,
+    RecurrentAlgorithmConfig,
+)
 from .env import Env
 
-__all__ = ["Algorithm", "AlgorithmConfig", "Env"]
+__all__ = [
+    "Algorithm",
+    "AlgorithmConfig",
+    "Env",
+    "RecurrentAlgorithm",
+    "RecurrentAlgorithmConfig",
+]
 __version__ = "0.1.0"

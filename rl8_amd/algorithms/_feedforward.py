@@ -198,15 +198,7 @@ class Algorithm:
         self.env.env_offset = self.shards.env_offset(local_envs)
         assert_nd_spec(self.env.observation_spec)
         assert_nd_spec(self.env.action_spec)
-        self.policy = Policy(
-            self.env.observation_spec,
-            self.env.action_spec,
-            model=config.model,
-            model_cls=config.model_cls,
-            model_config=config.model_config,
-            distribution_cls=config.distribution_cls,
-            device=device,
-        )
+        self.policy = self._make_policy(config, device)
         self.shards.broadcast_parameters_(self.policy.model)
         self.noise = NoiseStream()
         self.noise.row_offset = self.env.env_offset
@@ -214,6 +206,7 @@ class Algorithm:
         self.buffer_spec = Composite(
             {
                 DataKeys.OBS: self.env.observation_spec,
+                **self._extra_buffer_specs(),
                 DataKeys.REWARDS: Unbounded(1, device=device),
                 DataKeys.ACTIONS: self.env.action_spec,
                 DataKeys.LOGP: Unbounded(1, device=device),
@@ -237,9 +230,11 @@ class Algorithm:
             kind=config.entropy_coeff_schedule_kind,
         )
         sgd_minibatch_size = (
-            config.sgd_minibatch_size if config.sgd_minibatch_size else num_envs * horizon
+            config.sgd_minibatch_size
+            if config.sgd_minibatch_size
+            else self._default_minibatch_size(config, num_envs, horizon)
         )
-        self.hparams = AlgorithmHparams(
+        self.hparams = self._make_hparams(
             accumulate_grads=config.accumulate_grads,
             clip_param=config.clip_param,
             device=device,
@@ -262,13 +257,39 @@ class Algorithm:
         ).validate()
         if self.shards.active and sgd_minibatch_size % self.shards.world_size:
             raise ValueError("`sgd_minibatch_size` must be divisible by the number of ranks.")
-        self.state = AlgorithmState()
+        self.state = self._make_state()
         self.optimizer = optimizer
         self.grad_scaler = GradScaler(device="cuda", enabled=config.enable_amp)
         self.max_rows_per_pass = DEFAULT_MAX_ROWS_PER_PASS
         #: Parity hooks: noise / permutations recorded from a reference run.
         self.injected_noise: None | torch.Tensor = None  # [H, N, ...]
         self.injected_permutations: None | list[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ #
+    # Construction hooks (overridden by the recurrent algorithm).
+    # ------------------------------------------------------------------ #
+    def _make_policy(self, config: Any, device: str) -> Any:
+        return Policy(
+            self.env.observation_spec,
+            self.env.action_spec,
+            model=config.model,
+            model_cls=config.model_cls,
+            model_config=config.model_config,
+            distribution_cls=config.distribution_cls,
+            device=device,
+        )
+
+    def _extra_buffer_specs(self) -> dict[str, Any]:
+        return {}
+
+    def _default_minibatch_size(self, config: Any, num_envs: int, horizon: int) -> int:
+        return num_envs * horizon
+
+    def _make_hparams(self, **common: Any) -> AlgorithmHparams:
+        return AlgorithmHparams(**common)
+
+    def _make_state(self) -> AlgorithmState:
+        return AlgorithmState()
 
     # ------------------------------------------------------------------ #
     # Buffer: time-major storage, env-major views.
@@ -280,32 +301,46 @@ class Algorithm:
                 "rl8_amd's rollout buffer holds tensor observation / action specs"
                 " (composite specs are outside the accelerated path)."
             )
+        #: key -> ``[H+1, N, ...]`` storage of the flat leaves.
         self._tm: dict[str, torch.Tensor] = {}
-        views = {}
+        #: recurrent-state leaves (``buffer["states"][k]``), same layout.
+        self._tm_states: dict[str, torch.Tensor] = {}
+
+        def slab(spec: Any) -> torch.Tensor:
+            return torch.zeros(horizon + 1, num_envs, *spec.shape, dtype=spec.dtype, device=spec.device)
+
+        views: dict[str, Any] = {}
+        device = None
         for key in self.buffer_spec:
             spec = self.buffer_spec[key]
-            storage = torch.zeros(
-                horizon + 1, num_envs, *spec.shape, dtype=spec.dtype, device=spec.device
-            )
-            self._tm[key] = storage
-            views[key] = storage.transpose(0, 1)
-        self.buffer = TensorDict(
-            views, batch_size=[num_envs, horizon + 1], device=self.hparams_device(views)
-        )
-
-    @staticmethod
-    def hparams_device(views: dict[str, torch.Tensor]) -> torch.device:
-        return next(iter(views.values())).device
+            if isinstance(spec, Composite):
+                if key != DataKeys.STATES:
+                    raise NotImplementedError(f"composite buffer leaf {key!r} is not supported")
+                nested = {}
+                for sub in spec:
+                    storage = slab(spec[sub])
+                    self._tm_states[sub] = storage
+                    nested[sub] = storage.transpose(0, 1)
+                views[key] = TensorDict(nested, batch_size=[num_envs, horizon + 1])
+            else:
+                storage = slab(spec)
+                self._tm[key] = storage
+                views[key] = storage.transpose(0, 1)
+                device = storage.device
+        self.buffer = TensorDict(views, batch_size=[num_envs, horizon + 1], device=device)
 
     def _reset_buffer(self) -> None:
-        """``buffer_spec.zero(...)`` then ``obs[:, -1] = final_obs`` of the
-        reference (:603-609), in place: storage is reused, not re-allocated."""
+        """``buffer_spec.zero(...)`` then ``obs[:, -1] = final_obs`` (and the final
+        recurrent states) of the reference (:603-609), in place: storage is
+        reused, not re-allocated."""
         h = self.hparams.horizon
         for key, storage in self._tm.items():
             if key == DataKeys.OBS:
                 storage[:h].zero_()
             else:
                 storage.zero_()
+        for storage in self._tm_states.values():
+            storage[:h].zero_()
 
     # ------------------------------------------------------------------ #
     # Small accessors shared with the reference's base class.
@@ -521,19 +556,9 @@ class Algorithm:
                 moment_reduce=self.shards.sum_ if self.shards.active else None,
             )
 
-            local_samples = self.local_num_envs * H
-            local_mb = hp.sgd_minibatch_size // world
             num_minibatches = hp.num_minibatches
             gas = num_minibatches if hp.accumulate_grads else 1
-            grad_scale = 1.0 / (hp.sgd_minibatch_size * gas)
-            train_keys = (DataKeys.OBS, DataKeys.ACTIONS, DataKeys.LOGP, DataKeys.ADVANTAGES,
-                          DataKeys.RETURNS)
-            flat_full = None
-            if num_minibatches == 1:
-                # Time-major storage: dropping the last column and flattening is
-                # the contiguous prefix -- no copy, no shuffle (a mean over the
-                # whole buffer does not depend on order).
-                flat_full = {k: tm[k][:H].reshape(local_samples, *tm[k].shape[2:]) for k in train_keys}
+            grad_scale = 1.0 / (self._samples_per_minibatch() * gas)
 
             stat_tracker = StatTracker(
                 ["coefficients/entropy", "coefficients/vf", "losses/entropy", "losses/policy",
@@ -560,29 +585,9 @@ class Algorithm:
                 )
 
             stop_early = False
-            perm_cursor = 0
-            for _ in range(hp.num_sgd_iters):
-                if flat_full is not None:
-                    index_chunks: list[None | torch.Tensor] = [None]
-                else:
-                    if hp.shuffle_minibatches:
-                        if self.injected_permutations is not None:
-                            perm = self.injected_permutations[perm_cursor].to(tm[DataKeys.LOGP].device)
-                            perm_cursor += 1
-                        else:
-                            perm = torch.randperm(local_samples, device=tm[DataKeys.LOGP].device)
-                    else:
-                        perm = torch.arange(local_samples, device=tm[DataKeys.LOGP].device)
-                    index_chunks = list(torch.split(perm, local_mb))
-                for i, index in enumerate(index_chunks):
+            for sgd_iter in range(hp.num_sgd_iters):
+                for i, batch in enumerate(self._iter_minibatches(sgd_iter)):
                     step_this_batch = (i + 1) % gas == 0
-                    if index is None:
-                        batch = flat_full
-                    else:
-                        gathered = hip.gather_minibatch(
-                            index.contiguous(), H, [self.buffer[k] for k in train_keys]
-                        )
-                        batch = dict(zip(train_keys, gathered))
                     sums = self._minibatch_forward_backward(batch, entropy_coeff, grad_scale)
                     self.shards.sum_(sums)
                     if sync_each:
@@ -624,9 +629,52 @@ class Algorithm:
             self._reset_buffer()
             self.state.buffered = False
             self.injected_permutations = None
+            self._flat_full = None
             step_stats = stat_tracker.items()
         step_stats["profiling/step_ms"] = step_timer()
         return step_stats  # type: ignore[return-value]
+
+    #: Leaves a training minibatch is made of.
+    TRAIN_KEYS = (DataKeys.OBS, DataKeys.ACTIONS, DataKeys.LOGP, DataKeys.ADVANTAGES, DataKeys.RETURNS)
+
+    def _samples_per_minibatch(self) -> int:
+        """Global number of samples the loss of one minibatch averages over."""
+        return self.hparams.sgd_minibatch_size
+
+    def _permutation(self, sgd_iter: int, size: int) -> torch.Tensor:
+        """Order in which this SGD iteration visits the local units (samples, or
+        sequences for the recurrent algorithm): a fresh permutation per iteration
+        as the reference's ``Batcher`` draws (``_utils.py:211-218``), an injected
+        one (parity runs), or ``arange`` without shuffling."""
+        device = self._tm[DataKeys.LOGP].device
+        if not self.hparams.shuffle_minibatches:
+            return torch.arange(size, device=device)
+        if self.injected_permutations is not None:
+            return self.injected_permutations[sgd_iter].to(device)
+        return torch.randperm(size, device=device)
+
+    def _iter_minibatches(self, sgd_iter: int):
+        """Yields the minibatches of one SGD iteration as dicts of dense tensors."""
+        hp = self.hparams
+        H, tm = hp.horizon, self._tm
+        local_samples = self.local_num_envs * H
+        if hp.num_minibatches == 1:
+            # Time-major storage: dropping the last column and flattening is the
+            # contiguous prefix -- no copy, no shuffle (a mean over the whole
+            # buffer does not depend on order).
+            if getattr(self, "_flat_full", None) is None:
+                self._flat_full = {
+                    k: tm[k][:H].reshape(local_samples, *tm[k].shape[2:]) for k in self.TRAIN_KEYS
+                }
+            yield self._flat_full
+            return
+        local_mb = hp.sgd_minibatch_size // self.shards.world_size
+        perm = self._permutation(sgd_iter, local_samples)
+        for index in torch.split(perm, local_mb):
+            gathered = hip.gather_minibatch(
+                index.contiguous(), H, [self.buffer[k] for k in self.TRAIN_KEYS]
+            )
+            yield dict(zip(self.TRAIN_KEYS, gathered))
 
     def _minibatch_forward_backward(
         self, batch: dict[str, torch.Tensor], entropy_coeff: float, grad_scale: float

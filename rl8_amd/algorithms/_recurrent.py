@@ -1,0 +1,354 @@
+"""Recurrent PPO: ``RecurrentAlgorithmConfig`` / ``RecurrentAlgorithm``.
+
+API follows the reference's ``src/rl8/algorithms/_recurrent.py``
+(``RecurrentAlgorithmConfig`` :29-192, ``collect`` :325-479, ``step`` :481-652):
+truncated BPTT over ``seq_len`` steps, recurrent states carried in the rollout
+buffer, re-initialised every ``seqs_per_state_reset`` sequences, sequences (not
+samples) shuffled into minibatches.
+
+Built on :class:`Algorithm`: same time-major buffer (the ``states`` leaves are
+``[H+1][N][layers][hidden]`` slabs, so the per-timestep state carry is a dense
+copy, not the reference's strided one), same fused per-timestep launch, same GAE
+and fused loss kernels. A minibatch of sequences is assembled by
+``rl8_gather_minibatch``: per-sample leaves through the narrow path, the initial
+states of each sequence (1 KiB rows) through the wave-per-row path.
+
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+import torch.amp as amp
+
+from .. import hip
+from .._utils import profile_ms
+from ..data import (
+    CollectStats,
+    DataKeys,
+    RecurrentAlgorithmHparams,
+    RecurrentAlgorithmState,
+)
+from ..env import EnvFactory
+from ..models_recurrent import RecurrentModel, RecurrentModelFactory
+from ..nn.functional import fused_ppo_loss, has_fused_loss
+from ..policies_recurrent import RecurrentPolicy
+from ..specs import Composite
+from ..tensordict import TensorDict
+from ._feedforward import Algorithm, AlgorithmConfig, _collect_stats_from_raw
+
+
+@dataclass
+class RecurrentAlgorithmConfig(AlgorithmConfig):
+    """Configuration of a recurrent PPO algorithm: :class:`AlgorithmConfig` plus
+    the truncated-BPTT settings."""
+
+    model: None | RecurrentModel = None  # type: ignore[assignment]
+    model_cls: None | RecurrentModelFactory = None  # type: ignore[assignment]
+    #: Truncated backpropagation-through-time sequence length (a factor of
+    #: ``horizon``).
+    seq_len: int = 4
+    #: Sequences collected between re-initialisations of the recurrent states
+    #: (negative: never after the first).
+    seqs_per_state_reset: int = 8
+
+    def build(self, env_cls: EnvFactory) -> "RecurrentAlgorithm":  # type: ignore[override]
+        algo = RecurrentAlgorithm(env_cls, config=self)
+        algo.validate()
+        return algo
+
+
+class RecurrentAlgorithm(Algorithm):
+    """Recurrent PPO (LSTM policies) with the usual stabilising tricks."""
+
+    hparams: RecurrentAlgorithmHparams
+    policy: RecurrentPolicy  # type: ignore[assignment]
+    state: RecurrentAlgorithmState  # type: ignore[assignment]
+
+    def __init__(self, env_cls: EnvFactory, /, config: None | RecurrentAlgorithmConfig = None) -> None:
+        config = config or RecurrentAlgorithmConfig()
+        self._recurrent_config = config
+        super().__init__(env_cls, config=config)
+
+    # -- construction hooks ---------------------------------------------------
+    def _make_policy(self, config: Any, device: str) -> RecurrentPolicy:
+        return RecurrentPolicy(
+            self.env.observation_spec,
+            self.env.action_spec,
+            model=config.model,
+            model_cls=config.model_cls,
+            model_config=config.model_config,
+            distribution_cls=config.distribution_cls,
+            device=device,
+        )
+
+    def _extra_buffer_specs(self) -> dict[str, Any]:
+        return {DataKeys.STATES: self.policy.state_spec}
+
+    def _default_minibatch_size(self, config: Any, num_envs: int, horizon: int) -> int:
+        return num_envs * (horizon // config.seq_len)
+
+    def _make_hparams(self, **common: Any) -> RecurrentAlgorithmHparams:
+        return RecurrentAlgorithmHparams(
+            seq_len=self._recurrent_config.seq_len,
+            seqs_per_state_reset=self._recurrent_config.seqs_per_state_reset,
+            **common,
+        )
+
+    def _make_state(self) -> RecurrentAlgorithmState:
+        return RecurrentAlgorithmState()
+
+    # -- helpers ----------------------------------------------------------------
+    def _state_slabs(self, t: int) -> TensorDict:
+        """States at column ``t`` as a ``[N, 1, layers, hidden]`` tensordict."""
+        n = self.local_num_envs
+        return TensorDict(
+            {k: v[t].unsqueeze(1) for k, v in self._tm_states.items()}, batch_size=[n, 1]
+        )
+
+    def _samples_per_minibatch(self) -> int:
+        return self.hparams.sgd_minibatch_size * self.hparams.seq_len
+
+    # -- collect ------------------------------------------------------------------
+    def collect(
+        self,
+        *,
+        env_config: None | dict[str, Any] = None,
+        deterministic: bool = False,
+    ) -> CollectStats:
+        """As :meth:`Algorithm.collect`, additionally carrying the recurrent
+        states from column to column and re-initialising them at sequence
+        boundaries according to ``seqs_per_state_reset``."""
+        hp = self.hparams
+        H, N = hp.horizon, self.local_num_envs
+        tm, stm = self._tm, self._tm_states
+        rdr = tm.get(DataKeys.REVERSED_DISCOUNTED_RETURNS)
+        with profile_ms() as collect_timer:
+            env_was_reset = False
+            carry = (self.state.horizons and hp.horizons_per_env_reset < 0) or (
+                self.state.horizons % hp.horizons_per_env_reset
+            )
+            if carry:
+                tm[DataKeys.OBS][0].copy_(tm[DataKeys.OBS][H])
+                if rdr is not None:
+                    rdr[0].copy_(rdr[H])
+            else:
+                tm[DataKeys.OBS][0].copy_(self.env.reset(config=env_config))
+                env_was_reset = True
+                if rdr is not None:
+                    rdr[0].zero_()
+            for v in stm.values():  # :380-382
+                v[0].copy_(v[H])
+
+            fused = self._fusable()
+            gamma = float(torch.tensor(hp.gamma, dtype=torch.float32))
+            for t in range(H):
+                if self.state.seqs and hp.seqs_per_state_reset < 0:
+                    pass
+                elif not (t % hp.seq_len) and not (self.state.seqs % hp.seqs_per_state_reset):
+                    init = self.policy.init_states(N)  # :385-392
+                    for k, v in stm.items():
+                        v[t].copy_(init[k])
+                noise_t = self.injected_noise[t] if self.injected_noise is not None else None
+                step_id = self.noise.next_step()
+                in_batch = TensorDict({DataKeys.OBS: tm[DataKeys.OBS][t].unsqueeze(1)}, batch_size=[N, 1])
+                if fused:
+                    sample, new_states = self.policy.sample(
+                        in_batch, self._state_slabs(t), deterministic=deterministic, inplace=False,
+                        requires_grad=False, return_actions=False, return_logp=False, return_values=True,
+                    )
+                    self._fused_step(sample[DataKeys.FEATURES], sample[DataKeys.VALUES], noise_t, t, gamma,
+                                     step_id, deterministic)
+                else:
+                    self.policy.injected_noise = noise_t
+                    self.noise.step = step_id
+                    sample, new_states = self.policy.sample(
+                        in_batch, self._state_slabs(t), deterministic=deterministic, inplace=False,
+                        requires_grad=False, return_actions=True, return_logp=True, return_values=True,
+                    )
+                    out = self.env.step(sample[DataKeys.ACTIONS])
+                    hip.rollout_scatter(
+                        sample[DataKeys.ACTIONS].contiguous(), sample[DataKeys.LOGP].contiguous(),
+                        sample[DataKeys.VALUES].contiguous(), out[DataKeys.REWARDS].contiguous(),
+                        out[DataKeys.OBS].contiguous(), tm[DataKeys.ACTIONS][t], tm[DataKeys.LOGP][t],
+                        tm[DataKeys.VALUES][t], tm[DataKeys.REWARDS][t], tm[DataKeys.OBS][t + 1],
+                        rdr[t] if rdr is not None else None, rdr[t + 1] if rdr is not None else None, gamma,
+                    )
+                for k, v in stm.items():  # :428
+                    v[t + 1].copy_(new_states[k])
+                if not ((t + 1) % hp.seq_len):
+                    self.state.seqs += 1
+
+            # Bootstrap value at the last observation and state (:433-446).
+            in_batch = TensorDict({DataKeys.OBS: tm[DataKeys.OBS][H].unsqueeze(1)}, batch_size=[N, 1])
+            sample, _ = self.policy.sample(
+                in_batch, self._state_slabs(H), deterministic=deterministic, inplace=False,
+                requires_grad=False, return_actions=False, return_logp=False, return_values=True,
+            )
+            tm[DataKeys.VALUES][H].copy_(sample[DataKeys.VALUES])
+
+            # Stats.  The reference's recurrent variant slices rewards [:, 1:-1]
+            # (:449), unlike the feed-forward [:, :-1]; reward_scale still uses
+            # rdr[:, 1:].  Two passes of the stats kernel reproduce both.
+            rewards = self.buffer[DataKeys.REWARDS]
+            if H >= 2:
+                raw = hip.rollout_stats(rewards[:, 1:], None)
+            else:
+                raw = torch.full((12,), float("nan"), dtype=torch.float64, device=rewards.device)
+            if rdr is not None:
+                raw_rdr = hip.rollout_stats(rewards, self.buffer[DataKeys.REVERSED_DISCOUNTED_RETURNS])
+                raw = torch.cat([raw[:10], raw_rdr[10:]])
+                rdr_count = float(N * H)
+            raw = self.shards.combine_rollout_stats(raw)
+            values = raw.tolist()
+            collect_stats, _ = _collect_stats_from_raw(values)
+            if rdr is not None:
+                world = self.shards.world_size
+                _, reward_scale = _collect_stats_from_raw(
+                    values[:5] + [rdr_count * world] + values[6:]
+                )
+            else:
+                reward_scale = 1.0
+            self.state.horizons += 1
+            self.state.buffered = True
+            self.state.reward_scale = reward_scale if hp.normalize_rewards else 1.0
+            self.injected_noise = None
+
+        collect_stats["env/resets"] = hp.num_envs * int(env_was_reset)
+        collect_stats["env/steps"] = hp.num_envs * hp.horizon
+        collect_stats["profiling/collect_ms"] = collect_timer()
+        return collect_stats
+
+    # -- step ---------------------------------------------------------------------
+    def _iter_minibatches(self, sgd_iter: int):
+        """Minibatches of SEQUENCES: per-sample leaves as ``[B*L, ...]`` in
+        (sequence, step) order, observations as ``[B, L, ...]``, and each
+        sequence's initial recurrent states ``[B, layers, hidden]``."""
+        hp = self.hparams
+        H, L = hp.horizon, hp.seq_len
+        local_seqs = self.local_num_envs * (H // L)
+        local_mb = hp.sgd_minibatch_size // self.shards.world_size
+        perm = self._permutation(sgd_iter, local_seqs)
+        steps = torch.arange(L, device=perm.device)
+        state_keys = list(self._tm_states)
+        for seq_index in torch.split(perm, local_mb):
+            # reference sequence id q = env * (H/L) + s  ->  sample ids q*L + j
+            sample_ids = (seq_index[:, None] * L + steps[None, :]).reshape(-1).contiguous()
+            gathered = hip.gather_minibatch(sample_ids, H, [self.buffer[k] for k in self.TRAIN_KEYS])
+            batch = dict(zip(self.TRAIN_KEYS, gathered))
+            first_ids = (seq_index * L).contiguous()
+            states = hip.gather_minibatch(
+                first_ids, H, [self.buffer[DataKeys.STATES][k] for k in state_keys]
+            )
+            batch["_states"] = dict(zip(state_keys, states))
+            batch["_num_seqs"] = seq_index.numel()
+            yield batch
+
+    def _minibatch_forward_backward(
+        self, batch: dict[str, Any], entropy_coeff: float, grad_scale: float
+    ) -> torch.Tensor:
+        hp = self.hparams
+        L = hp.seq_len
+        num_seqs = batch["_num_seqs"]
+        dist_cls = self.policy.distribution_cls
+        if not has_fused_loss(dist_cls):
+            raise NotImplementedError(
+                "RecurrentAlgorithm trains with the built-in distributions"
+                " (Categorical, Normal, SquashedNormal)."
+            )
+        seqs_per_pass = max(1, self.max_rows_per_pass // L)
+        total_sums: None | torch.Tensor = None
+        scale = None
+        if hp.enable_amp:
+            scale = self.grad_scaler.scale(torch.ones((), device=batch[DataKeys.LOGP].device))
+        for start in range(0, num_seqs, seqs_per_pass):
+            stop = min(num_seqs, start + seqs_per_pass)
+            b = stop - start
+            rows = slice(start * L, stop * L)
+            obs = batch[DataKeys.OBS][rows].reshape(b, L, *batch[DataKeys.OBS].shape[1:])
+            states = TensorDict(
+                {k: v[start:stop].unsqueeze(1) for k, v in batch["_states"].items()}, batch_size=[b, 1]
+            )
+            with amp.autocast("cuda", enabled=hp.enable_amp):
+                sample, _ = self.policy.sample(
+                    TensorDict({DataKeys.OBS: obs}, batch_size=[b, L]), states, deterministic=False,
+                    inplace=False, requires_grad=True, return_actions=False, return_logp=False,
+                    return_values=True,
+                )
+            sums, inputs, grads = fused_ppo_loss(
+                dist_cls, sample[DataKeys.FEATURES], sample[DataKeys.VALUES], batch[DataKeys.ACTIONS][rows],
+                batch[DataKeys.LOGP][rows], batch[DataKeys.ADVANTAGES][rows], batch[DataKeys.RETURNS][rows],
+                clip_param=hp.clip_param, dual_clip_param=hp.dual_clip_param, entropy_coeff=entropy_coeff,
+                vf_clip_param=hp.vf_clip_param, vf_coeff=hp.vf_coeff, grad_scale=grad_scale,
+            )
+            if scale is not None:
+                grads = [g * scale.to(g.dtype) for g in grads]
+            torch.autograd.backward(inputs, grads)
+            total_sums = sums if total_sums is None else total_sums + sums
+        assert total_sums is not None
+        return total_sums
+
+    # -- validate -------------------------------------------------------------------
+    def validate(self) -> None:
+        """Shape checks on one reset / sample / step round trip (:654-756)."""
+        n = self.local_num_envs
+        obs = self.env.reset()
+        self.env.observation_spec.assert_is_in(obs)
+        try:
+            self.buffer[DataKeys.OBS][:, 0, ...] = obs
+        except RuntimeError as e:
+            raise AssertionError(
+                f"The observation from {self.env.reset.__qualname__} doesn't match the"
+                " observation spec shape."
+            ) from e
+        states = self.policy.init_states(n)
+        try:
+            self.buffer[DataKeys.STATES][:, 0, ...] = states
+        except RuntimeError as e:
+            raise AssertionError(
+                "The recurrent states from the policy don't match the state spec."
+            ) from e
+        sample_batch, out_states = self.policy.sample(
+            self.buffer[:, :1, ...].select(DataKeys.OBS),
+            self.buffer[DataKeys.STATES][:, :1, ...],
+            deterministic=False, inplace=False, requires_grad=False, return_actions=True,
+            return_logp=True, return_values=True,
+        )
+        actions = sample_batch[DataKeys.ACTIONS]
+        assert actions.ndim >= 2, (
+            "Actions must be at least 2D and have shape ``[N, ...]`` (where ``N`` is"
+            " the number of independent elements or environment instances, and ``...``"
+            " is any number of additional dimensions)."
+        )
+        self.env.action_spec.assert_is_in(actions)
+        try:
+            self.buffer[DataKeys.ACTIONS][:, 0, ...] = actions
+            self.buffer[DataKeys.STATES][:, 1, ...] = out_states
+        except RuntimeError as e:
+            raise AssertionError(
+                "The action or states sampled from the policy don't match their specs."
+            ) from e
+        assert sample_batch[DataKeys.LOGP].shape == torch.Size([n, 1]), (
+            "Action log probabilities must be 2D and have shape ``[N, 1]`` (where ``N``"
+            " is the number of independent elements or environment instances)."
+        )
+        assert sample_batch[DataKeys.VALUES].shape == torch.Size([n, 1]), (
+            "Expected value estimates must be 2D and have shape ``[N, 1]`` (where ``N``"
+            " is the number of independent elements or environment instances)."
+        )
+        out_batch = self.env.step(actions)
+        self.env.observation_spec.assert_is_in(out_batch[DataKeys.OBS])
+        assert out_batch[DataKeys.REWARDS].shape == torch.Size([n, 1]), (
+            "Rewards must be 2D and have shape ``[N, 1]`` (where ``N`` is the number of"
+            " independent elements or environment instances)."
+        )
+        # validate() must not leave anything behind in the buffer
+        self._reset_buffer()
+        self._tm[DataKeys.OBS][self.hparams.horizon].zero_()
+        for v in self._tm_states.values():
+            v.zero_()
+
+
+__all__ = ["RecurrentAlgorithm", "RecurrentAlgorithmConfig", "Composite"]

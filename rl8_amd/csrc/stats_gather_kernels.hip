@@ -147,6 +147,25 @@ __global__ __launch_bounds__(kBlock) void gather_minibatch_kernel(
   }
 }
 
+// Wide rows (recurrent states: 1 KiB per layer): one wave per gathered row, 16 B
+// per lane, so each row moves as whole 1-KiB wave instructions.
+__global__ __launch_bounds__(kBlock) void gather_wide_rows_kernel(
+    const int64_t *__restrict__ index, int64_t m, int64_t h, rl8_gather_field fd) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kWave;
+  const int64_t waves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int vecs = (int)((int64_t)fd.row_elems * fd.elem_bytes / 16);
+  for (int64_t i = wave0; i < m; i += waves) {
+    const int64_t s = index[i];
+    const int64_t env = s / h, t = s - env * h;
+    const char *src = static_cast<const char *>(fd.src) +
+                      (env * fd.env_stride + t * fd.time_stride) * fd.elem_bytes;
+    char *dst = static_cast<char *>(fd.dst) + i * (int64_t)fd.row_elems * fd.elem_bytes;
+    for (int c = lane; c < vecs; c += kWave)
+      reinterpret_cast<float4 *>(dst)[c] = reinterpret_cast<const float4 *>(src)[c];
+  }
+}
+
 }  // namespace rl8
 
 using namespace rl8;
@@ -189,14 +208,26 @@ RL8_API int rl8_gather_minibatch(const int64_t *index, int64_t m, int64_t h,
   if (!index || !fields) return RL8_ENULL;
   if (m <= 0 || h <= 0 || n_fields <= 0 || n_fields > RL8_MAX_GATHER_FIELDS) return RL8_ESIZE;
   GatherArgs args;
-  args.n_fields = n_fields;
+  args.n_fields = 0;
+  hipStream_t s = (hipStream_t)stream;
   for (int f = 0; f < n_fields; ++f) {
-    if (!fields[f].src || !fields[f].dst) return RL8_ENULL;
-    if (fields[f].elem_bytes != 4 && fields[f].elem_bytes != 8) return RL8_ECONFIG;
-    if (fields[f].row_elems <= 0) return RL8_ESIZE;
-    args.f[f] = fields[f];
+    const rl8_gather_field &fd = fields[f];
+    if (!fd.src || !fd.dst) return RL8_ENULL;
+    if (fd.elem_bytes != 4 && fd.elem_bytes != 8) return RL8_ECONFIG;
+    if (fd.row_elems <= 0) return RL8_ESIZE;
+    const int64_t row_bytes = (int64_t)fd.row_elems * fd.elem_bytes;
+    const bool wide = row_bytes >= 256 && row_bytes % 16 == 0 && aligned16(fd.src) &&
+                      aligned16(fd.dst) && (fd.env_stride * fd.elem_bytes) % 16 == 0 &&
+                      (fd.time_stride * fd.elem_bytes) % 16 == 0;
+    if (wide) {
+      gather_wide_rows_kernel<<<grid_for(m, kWavesPerBlock), kBlock, 0, s>>>(index, m, h, fd);
+      const int st = launch_status();
+      if (st != RL8_OK) return st;
+    } else {
+      args.f[args.n_fields++] = fd;
+    }
   }
-  gather_minibatch_kernel<<<grid_for(m, kBlock), kBlock, 0, (hipStream_t)stream>>>(index, m, h,
-                                                                                 args);
+  if (args.n_fields > 0)
+    gather_minibatch_kernel<<<grid_for(m, kBlock), kBlock, 0, s>>>(index, m, h, args);
   return launch_status();
 }

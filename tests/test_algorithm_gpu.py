@@ -309,3 +309,104 @@ def test_cartpole_learns():
         last = algo.collect()["returns/mean"]
         algo.step()
     assert last > first + 0.2 * abs(first), (first, last)
+
+
+# --- recurrent algorithm (BASELINE config 5 shape, small) ----------------------
+def run_recurrent_trace(golden, name, env_cls, *, discrete, **config):
+    from rl8_amd import RecurrentAlgorithmConfig
+
+    g = golden(name)
+    algo = RecurrentAlgorithmConfig(num_envs=NUM_ENVS, horizon=HORIZON, **config).build(env_cls)
+    state = {k[len("init_"):]: torch.from_numpy(g[k]) for k in g if k.startswith("init_")}
+    algo.policy.model.load_state_dict(state)
+    for it in range(2):
+        inject(algo, g, it)
+        collect_stats = algo.collect()
+        loose = 1.0 if it == 0 else 25.0
+        buf = algo.buffer
+        got_actions = buf[DataKeys.ACTIONS][:, :HORIZON].cpu().numpy()
+        if discrete:
+            assert np.array_equal(got_actions, g[f"it{it}_collect_actions"][:, :HORIZON])
+        else:
+            np.testing.assert_allclose(got_actions, g[f"it{it}_collect_actions"][:, :HORIZON], rtol=1e-4, atol=1e-4 * loose)
+        for key in ("obs", "rewards", "reversed_discounted_returns"):
+            np.testing.assert_allclose(buf[key].cpu().numpy(), g[f"it{it}_collect_{key}"], rtol=1e-5, atol=2e-4 * loose, err_msg=key)
+        np.testing.assert_allclose(buf[DataKeys.VALUES].cpu().numpy(), g[f"it{it}_collect_values"], rtol=1e-4 * loose, atol=5e-5 * loose)
+        for sk in ("hidden_states", "cell_states"):
+            leaf = buf[DataKeys.STATES][sk].cpu().numpy()
+            np.testing.assert_allclose(leaf[:, -1], g[f"it{it}_collect_states_{sk}_last"], rtol=1e-4 * loose, atol=2e-5 * loose)
+            np.testing.assert_allclose(leaf[:, 6], g[f"it{it}_collect_states_{sk}_col6"], rtol=1e-4 * loose, atol=2e-5 * loose)
+        compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5 * loose, 1e-7)
+        assert algo.state.reward_scale == pytest.approx(float(g[f"it{it}_reward_scale"]), rel=1e-5 * loose)
+        step_stats = algo.step()
+        compare_stats(step_stats, g["step_stat_keys"], g[f"it{it}_step_stats"], 1e-3 * (1 if it == 0 else 10),
+                      2e-6 if it == 0 else 1e-4)
+        # final states survive the buffer reset (:645-646)
+        for sk in ("hidden_states", "cell_states"):
+            leaf = algo.buffer[DataKeys.STATES][sk]
+            assert float(leaf[:, :-1].abs().sum()) == 0.0
+            np.testing.assert_allclose(leaf[:, -1].cpu().numpy(), g[f"it{it}_collect_states_{sk}_last"],
+                                       rtol=1e-4 * loose, atol=2e-5 * loose)
+    assert algo.state.seqs == 2 * (HORIZON // algo.hparams.seq_len)
+
+
+def test_trace_recurrent_discrete(golden):
+    run_recurrent_trace(golden, "trace_rec_discrete.npz", DiscreteDummyEnv, discrete=True)
+
+
+def test_trace_recurrent_continuous_minibatches(golden):
+    run_recurrent_trace(golden, "trace_rec_continuous_minibatch.npz", ContinuousDummyEnv, discrete=False,
+                        sgd_minibatch_size=128, entropy_coeff=1e-2, seq_len=8, seqs_per_state_reset=2,
+                        horizons_per_env_reset=2)
+
+
+@pytest.mark.parametrize("env_cls", [ContinuousDummyEnv, DiscreteDummyEnv])
+def test_recurrent_accumulated_gradients_match_full_batch(env_cls):
+    from rl8_amd import RecurrentAlgorithmConfig
+
+    def run(**kw):
+        torch.manual_seed(42)
+        algo = RecurrentAlgorithmConfig(num_envs=NUM_ENVS, horizon=HORIZON, entropy_coeff=1e-2, **kw).build(env_cls)
+        algo.collect()
+        return algo.step()
+
+    full = run()
+    accumulated = run(accumulate_grads=True, sgd_minibatch_size=NUM_ENVS)
+    for k in ("losses/entropy", "losses/policy", "losses/total", "losses/vf", "monitors/kl_div"):
+        assert math.isclose(full[k], accumulated[k], rel_tol=1e-5), k
+
+
+def test_recurrent_algorithm_resets():
+    # reference tests/test_algorithms.py:103-125
+    from rl8_amd import RecurrentAlgorithmConfig
+    from rl8_amd.policies_recurrent import RecurrentPolicy
+
+    algo = RecurrentAlgorithmConfig(horizon=HORIZON, num_envs=NUM_ENVS, seq_len=4, seqs_per_state_reset=8).build(DiscreteDummyEnv)
+    with (
+        patch.object(DiscreteDummyEnv, "reset", wraps=algo.env.reset) as reset,
+        patch.object(RecurrentPolicy, "init_states", wraps=algo.policy.init_states) as init_states,
+    ):
+        algo.collect()
+        assert algo.state.horizons == 1 and reset.call_count == 1
+        assert algo.state.seqs == 8 and init_states.call_count == 1
+        algo.collect()
+        assert algo.state.horizons == 2 and reset.call_count == 2
+        assert algo.state.seqs == 16 and init_states.call_count == 2
+
+
+def test_recurrent_fused_and_generic_rollouts_agree():
+    from rl8_amd import RecurrentAlgorithmConfig
+
+    def run(force_generic):
+        torch.manual_seed(7)
+        algo = RecurrentAlgorithmConfig(horizon=16, num_envs=256).build(DiscreteDummyEnv)
+        if force_generic:
+            algo._fusable = lambda: False
+        algo.collect()
+        return {k: v.clone() for k, v in algo.buffer.items() if torch.is_tensor(v)}
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    with pytest.raises(ValueError, match="seq_len"):
+        RecurrentAlgorithmConfig(horizon=30, num_envs=8, seq_len=4).build(DiscreteDummyEnv)

@@ -543,3 +543,17 @@ def test_single_launch_reductions_are_complete_and_reproducible():
     np.testing.assert_allclose(stats[9], float(rewards[:h].max()), rtol=0)
     vf_terms = torch.clamp(torch.nn.functional.smooth_l1_loss(value, ret, reduction="none"), 0, 5.0)
     np.testing.assert_allclose(sums[2], float(vf_terms.double().sum()), rtol=1e-6)
+
+
+def test_gather_wide_rows_recurrent_states():
+    rng = np.random.default_rng(8)
+    n, h = 64, 16
+    hidden = rng.standard_normal((h + 1, n, 1, 256)).astype(np.float32)  # time-major storage
+    leaf = dev(hidden).transpose(0, 1)  # [N, H+1, 1, 256] view
+    small = dev(rng.standard_normal((h + 1, n, 1)).astype(np.float32)).transpose(0, 1)
+    seqs = oracle.permutation(n * h // 4, 3, 0)[:100]
+    first_ids = seqs * 4
+    wide, narrow = hip.gather_minibatch(dev(first_ids), h, [leaf, small])
+    env, t = first_ids // h, first_ids % h
+    assert np.array_equal(host(wide), hidden[t, env])
+    assert np.array_equal(host(narrow), host(small)[env, t])
