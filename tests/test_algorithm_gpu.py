@@ -399,7 +399,7 @@ def test_recurrent_fused_and_generic_rollouts_agree():
 
     def run(force_generic):
         torch.manual_seed(7)
-        algo = RecurrentAlgorithmConfig(horizon=16, num_envs=256).build(DiscreteDummyEnv)
+        algo = RecurrentAlgorithmConfig(horizon=16, num_envs=256, seqs_per_state_reset=4).build(DiscreteDummyEnv)
         if force_generic:
             algo._fusable = lambda: False
         algo.collect()
