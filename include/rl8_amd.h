@@ -231,6 +231,41 @@ typedef struct {
 int rl8_gather_minibatch(const int64_t *index, int64_t m, int64_t h,
                          const rl8_gather_field *fields /*host*/, int n_fields, void *stream);
 
+/* ---------------------------------------------------------------------- *
+ * N1  Default policy / value tower, fused
+ *      src/rl8/models/_feedforward.py:336-375 (DefaultDiscreteModel),
+ *      :263-310 (DefaultContinuousModel), src/rl8/nn/modules/mlp.py:12-52
+ * One tower = Linear(d_in, 256) ReLU Linear(256, 256) ReLU Linear(256, n_out),
+ * fp32 throughout (layer 2 on v_mfma_f32_32x32x2_f32), activations kept on
+ * chip.  d_in <= 16, n_out <= 8.  Weights in torch.nn.Linear layout
+ * ([out][in] row-major); the 256x256 matrix is passed in MFMA fragment order,
+ * produced by rl8_mlp_pack_w2_f32 (transposed = 0 for the forward pass and the
+ * weight-gradient pass, 1 for the data-gradient pass of the backward).
+ * ---------------------------------------------------------------------- */
+int rl8_mlp_pack_w2_f32(const float *w2 /*[256][256]*/, float *w2_packed /*[65536]*/,
+                        int transposed, void *stream);
+
+/* out [M][n_out] = tower(x [M][d_in]).  save_h1 / save_h2 ([M][256], may be
+ * NULL) receive the post-ReLU activations the backward pass needs. */
+int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *w1,
+                              const float *b1, const float *w2_packed, const float *b2,
+                              const float *w3, const float *b3, int n_out, float *out,
+                              float *save_h1, float *save_h2, void *stream);
+
+/* Backward of one tower ("dgrad" half): given dOut [M][n_out] and the saved
+ * activations, writes dZ2 [M][256] (the host forms dW2 = dZ2^T h1 with a library
+ * GEMM) and `*partial_rows_out` rows (<= rl8_mlp_backward_max_rows()) of
+ * rl8_mlp_backward_partial_floats(d_in, n_out) floats each into `partials`:
+ *   [dW1 (256*d_in) | db1 (256) | db2 (256) | dW3 (n_out*256) | db3 (n_out)]
+ * whose column sums are the parameter gradients.  w2t_packed is
+ * rl8_mlp_pack_w2_f32(..., transposed = 1).  partial_rows_out is a host pointer. */
+int64_t rl8_mlp_backward_partial_floats(int d_in, int n_out);
+int rl8_mlp_backward_max_rows(void);
+int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
+                               const float *dout, int64_t m, int d_in, const float *w2t_packed,
+                               const float *w3, int n_out, float *dz2_out, float *partials,
+                               int *partial_rows_out /*host*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

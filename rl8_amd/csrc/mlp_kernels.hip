@@ -1,0 +1,426 @@
+// N1: the default policy / value tower -- Linear(d_in,256) ReLU
+// Linear(256,256) ReLU Linear(256,n_out) (src/rl8/models/_feedforward.py:336-362,
+// src/rl8/nn/modules/mlp.py:12-52) -- as ONE fp32 kernel per direction that keeps
+// the 256-wide activations on chip.
+//
+// Why: once the memory-bound kernels are fused, >99.9 % of collect()+step() is
+// these towers.  Eager PyTorch runs them as GEMM + bias + ReLU launches whose
+// [rows x 256] fp32 activations make an HBM round trip each (2 KB per sample per
+// layer, forward and backward); at 2^20 x 32 samples that traffic costs as much
+// as the GEMMs.  Here a workgroup walks 64-row tiles: layer 1 on the VALU
+// (d_in is tiny: an outer product), layer 2 on the matrix cores with fp32
+// MFMA (v_mfma_f32_32x32x2_f32: exact fp32 fma chains, no precision change),
+// the head on the VALU, activations in LDS / accumulators throughout.  HBM sees
+// the observations, the outputs and -- for training only -- one store of h1 / h2.
+//
+// MFMA operand maps (gfx950, 32x32x2 f32): lane l holds A[i = l&31][k = l>>5],
+// B[k = l>>5][j = l&31]; D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31], r<16.
+// The k index is permuted so that each lane's four consecutive k-steps use four
+// consecutive floats: k = 8g + 4*(l>>5) + e, e = 0..3 (sums are order-free up to
+// fp32 rounding).  W2 is pre-packed in that fragment order (rl8_mlp_pack_w2_f32)
+// so a wave's B fragment for (N-tile, g) is one contiguous 1-KiB load.
+//
+// LDS: one [64][257] fp32 tile (h1, overwritten by h2); the odd row stride makes
+// both the row walks of the MFMA A operand and the column walks of the VALU
+// phases bank-conflict-free.
+#include "common.hip.h"
+
+namespace rl8 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kHidden = 256;
+constexpr int kTileRows = 64;         // samples per workgroup tile
+constexpr int kLdsStride = kHidden + 1;
+constexpr int kMaxIn = 16;
+constexpr int kMaxOut = 8;
+constexpr int kGroups = kHidden / 8;  // k-groups of 8
+
+// w2 [256 out][256 in] row-major -> fragment order:
+// packed[((n*32 + g)*64 + l)*4 + e] = w2[32n + (l&31)][8g + 4(l>>5) + e]
+__global__ __launch_bounds__(kBlock) void mlp_pack_w2_kernel(const float *__restrict__ w2,
+                                                             float *__restrict__ packed) {
+  const int idx = blockIdx.x * kBlock + threadIdx.x;  // one float4 each
+  if (idx >= kHidden * kHidden / 4) return;
+  const int l = idx & 63, g = (idx >> 6) & 31, n = idx >> 11;
+  const int j = 32 * n + (l & 31), k = 8 * g + 4 * (l >> 5);
+  const float4 v = *reinterpret_cast<const float4 *>(w2 + j * kHidden + k);
+  reinterpret_cast<float4 *>(packed)[idx] = v;
+}
+
+// Transposed packing for the backward data-gradient GEMM dH1 = dZ2 x W2:
+// B[k = j][n = i] = w2[j][i]:  packedT[((n*32 + g)*64 + l)*4 + e] = w2[8g + 4(l>>5) + e][32n + (l&31)]
+__global__ __launch_bounds__(kBlock) void mlp_pack_w2t_kernel(const float *__restrict__ w2,
+                                                              float *__restrict__ packed) {
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= kHidden * kHidden / 4) return;
+  const int l = idx & 63, g = (idx >> 6) & 31, n = idx >> 11;
+  const int i = 32 * n + (l & 31), j0 = 8 * g + 4 * (l >> 5);
+  float4 v;
+  v.x = w2[(j0 + 0) * kHidden + i];
+  v.y = w2[(j0 + 1) * kHidden + i];
+  v.z = w2[(j0 + 2) * kHidden + i];
+  v.w = w2[(j0 + 3) * kHidden + i];
+  reinterpret_cast<float4 *>(packed)[idx] = v;
+}
+
+// One 64-row x 256-col GEMM tile on the matrix cores:
+//   acc[m][n] (+)= A_tile[32m + i][k] * Bp[(N-tile 2*wave + n)][k]
+// A_tile: LDS [64][257]; Bp: fragment-packed [8][32][64] float4.  Wave `wave`
+// produces output columns [64*wave, 64*wave + 64).
+//
+// Software-pipelined by hand, two k-groups per trip with two named register
+// sets: the B fragments (L2) and A fragments (LDS) of group g+1 are issued
+// before the 16 MFMAs of group g, so every load has ~1000 cycles to land and the
+// compiler's counted waits leave the younger loads in flight.
+struct Frag {
+  float4 b0, b1;
+  float a0[4], a1[4];
+};
+
+__device__ __forceinline__ void load_frag(Frag &f, const float4 *__restrict__ b0p,
+                                          const float4 *__restrict__ b1p,
+                                          const float *__restrict__ a0p,
+                                          const float *__restrict__ a1p, int g) {
+  f.b0 = b0p[g * kWave];
+  f.b1 = b1p[g * kWave];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f.a0[e] = a0p[8 * g + e];
+    f.a1[e] = a1p[8 * g + e];
+  }
+}
+
+__device__ __forceinline__ void mma_frag(const Frag &f, f32x16 (&acc)[2][2]) {
+  const float c0e[4] = {f.b0.x, f.b0.y, f.b0.z, f.b0.w};
+  const float c1e[4] = {f.b1.x, f.b1.y, f.b1.z, f.b1.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], c0e[e], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], c1e[e], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[e], c0e[e], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[e], c1e[e], acc[1][1], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void tile_gemm_64x256x256(const float *__restrict__ a_tile,
+                                                     const float4 *__restrict__ bp, int wave,
+                                                     int lane, f32x16 (&acc)[2][2]) {
+  const int i = lane & 31, hh = lane >> 5;
+  const float4 *b0p = bp + ((2 * wave + 0) * kGroups) * kWave + lane;
+  const float4 *b1p = bp + ((2 * wave + 1) * kGroups) * kWave + lane;
+  const float *a0p = a_tile + (0 * 32 + i) * kLdsStride + 4 * hh;
+  const float *a1p = a_tile + (1 * 32 + i) * kLdsStride + 4 * hh;
+  Frag fa, fb;
+  load_frag(fa, b0p, b1p, a0p, a1p, 0);
+#pragma unroll 1
+  for (int g = 0; g < kGroups; g += 2) {
+    load_frag(fb, b0p, b1p, a0p, a1p, g + 1);
+    mma_frag(fa, acc);
+    if (g + 2 < kGroups) load_frag(fa, b0p, b1p, a0p, a1p, g + 2);
+    mma_frag(fb, acc);
+  }
+}
+
+// Forward of one tower over m rows.  save_h1 / save_h2 (may be NULL): [m][256].
+// LDS: ONE [64][257] tile (h1, then h2 in place once the MFMA loop has consumed
+// h1) + the observation tile + the head weights = 78 KB => two workgroups per
+// CU, so one workgroup's VALU phases overlap the other's matrix phase.
+__global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
+    const float *__restrict__ x, int64_t m, int d_in, const float *__restrict__ w1,
+    const float *__restrict__ b1, const float4 *__restrict__ w2p, const float *__restrict__ b2,
+    const float *__restrict__ w3, const float *__restrict__ b3, int n_out,
+    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2) {
+  extern __shared__ float lds[];
+  float *ht = lds;                                  // [64][257]: h1, later h2
+  float *xs = ht + kTileRows * kLdsStride;          // [64][kMaxIn]
+  float *w3s = xs + kTileRows * kMaxIn;             // [kMaxOut][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // Per-thread constants: column `tid` of layer 1, head weights to LDS.
+  float w1r[kMaxIn];
+#pragma unroll
+  for (int i = 0; i < kMaxIn; ++i) w1r[i] = i < d_in ? w1[tid * d_in + i] : 0.0f;
+  const float b1r = b1[tid];
+  for (int idx = tid; idx < n_out * kHidden; idx += kBlock) w3s[idx] = w3[idx];
+  float b2r[2];
+  b2r[0] = b2[64 * wave + (lane & 31)];
+  b2r[1] = b2[64 * wave + 32 + (lane & 31)];
+  float b3r[kMaxOut];
+#pragma unroll
+  for (int q = 0; q < kMaxOut; ++q) b3r[q] = q < n_out ? b3[q] : 0.0f;
+
+  const int64_t tiles = (m + kTileRows - 1) / kTileRows;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * kTileRows;
+    const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
+    __syncthreads();  // previous tile's readers of xs / ht are done
+    for (int idx = tid; idx < kTileRows * d_in; idx += kBlock) {
+      const int s = idx / d_in, i = idx - s * d_in;
+      xs[s * kMaxIn + i] = s < rows ? x[(r0 + s) * d_in + i] : 0.0f;
+    }
+    __syncthreads();
+    // Layer 1 (VALU): thread = output column, loop over the tile's rows.
+#pragma unroll 4
+    for (int s = 0; s < kTileRows; ++s) {
+      float v = b1r;
+      for (int i = 0; i < d_in; ++i) v += xs[s * kMaxIn + i] * w1r[i];
+      v = v > 0.0f ? v : 0.0f;
+      ht[s * kLdsStride + tid] = v;
+      if (save_h1 && s < rows) save_h1[(r0 + s) * kHidden + tid] = v;
+    }
+    __syncthreads();
+    // Layer 2 (MFMA).
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    tile_gemm_64x256x256(ht, w2p, wave, lane, acc);
+    __syncthreads();  // every wave has read all of h1: the tile may be overwritten
+    // bias + ReLU, accumulators -> h2 (in place of h1).
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int s = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int j = 64 * wave + 32 * nt + (lane & 31);
+          float v = acc[mt][nt][r] + b2r[nt];
+          v = v > 0.0f ? v : 0.0f;
+          ht[s * kLdsStride + j] = v;
+        }
+    __syncthreads();
+    if (save_h2) {
+      for (int idx = tid; idx < rows * kHidden; idx += kBlock) {
+        const int s = idx >> 8, j = idx & 255;
+        save_h2[(r0 + s) * kHidden + j] = ht[s * kLdsStride + j];
+      }
+    }
+    // Head (VALU): 4 lanes per row (a quarter of the 256 inputs each, rotated by
+    // 8 per quarter to spread LDS banks), combined with two lane shuffles.
+    {
+      const int s = 16 * wave + (lane >> 2), q4 = lane & 3;
+      float o[kMaxOut];
+#pragma unroll
+      for (int q = 0; q < kMaxOut; ++q) o[q] = 0.0f;
+      const float *row = ht + s * kLdsStride + 64 * q4;
+      const float *wq = w3s + 64 * q4;
+      for (int jj = 0; jj < 64; ++jj) {
+        const int j = (jj + 8 * q4) & 63;
+        const float hv = row[j];
+#pragma unroll
+        for (int q = 0; q < kMaxOut; ++q)
+          if (q < n_out) o[q] += hv * wq[q * kHidden + j];
+      }
+#pragma unroll
+      for (int q = 0; q < kMaxOut; ++q) {
+        if (q < n_out) {
+          float v = o[q];
+          v += __shfl_xor(v, 1, kWave);
+          v += __shfl_xor(v, 2, kWave);
+          if (q4 == 0 && s < rows) out[(r0 + s) * n_out + q] = v + b3r[q];
+        }
+      }
+    }
+  }
+}
+
+// Backward of one tower over m rows, data-gradient half ("dgrad"):
+//   dZ2 = (dOut x W3) * (h2 > 0)            VALU, lane = column
+//   dH1 = dZ2 x W2                          MFMA (W2 packed transposed)
+//   dZ1 = dH1 * (h1 > 0)                    accumulator epilogue
+// and every small parameter gradient on the way:
+//   dW3 = dOut^T h2, db3 = sum dOut, db2 = sum dZ2, dW1 = dZ1^T x, db1 = sum dZ1.
+// dZ2 is also stored ([m][256]) for the one remaining large product,
+// dW2 = dZ2^T h1, which the host issues as a plain library GEMM.
+// Small gradients leave as one row of per-workgroup partials,
+//   [dW1 (256*d_in) | db1 (256) | db2 (256) | dW3 (n_out*256) | db3 (n_out)],
+// summed on the host side in a fixed order (bitwise reproducible, no atomics).
+__global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
+    const float *__restrict__ x, const float *__restrict__ h1, const float *__restrict__ h2,
+    const float *__restrict__ dout, int64_t m, int d_in, const float4 *__restrict__ w2tp,
+    const float *__restrict__ w3, int n_out, float *__restrict__ dz2_out,
+    float *__restrict__ partials, int partial_stride) {
+  extern __shared__ float lds[];
+  float *zt = lds;                                  // [64][257]: h2 -> dZ2
+  float *xs = zt + kTileRows * kLdsStride;          // [64][kMaxIn]
+  float *ds = xs + kTileRows * kMaxIn;              // [64][kMaxOut] dOut tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5;
+
+  float w3r[kMaxOut];  // column `tid` of W3
+#pragma unroll
+  for (int q = 0; q < kMaxOut; ++q) w3r[q] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
+  // running sums owned by this thread
+  float dw3[kMaxOut], db3[kMaxOut], db2 = 0.0f;  // column tid (db3: replicated, thread 0 writes)
+#pragma unroll
+  for (int q = 0; q < kMaxOut; ++q) dw3[q] = db3[q] = 0.0f;
+  float dw1[2][kMaxIn], db1[2] = {0.0f, 0.0f};    // columns 64*wave + 32*nt + (lane&31), this lane-half's rows
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int c = 0; c < kMaxIn; ++c) dw1[nt][c] = 0.0f;
+
+  const int64_t tiles = (m + kTileRows - 1) / kTileRows;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * kTileRows;
+    const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
+    __syncthreads();
+    for (int idx = tid; idx < kTileRows * d_in; idx += kBlock) {
+      const int s = idx / d_in, c = idx - s * d_in;
+      xs[s * kMaxIn + c] = s < rows ? x[(r0 + s) * d_in + c] : 0.0f;
+    }
+    for (int idx = tid; idx < kTileRows * n_out; idx += kBlock) {
+      const int s = idx / n_out, q = idx - s * n_out;
+      ds[s * kMaxOut + q] = s < rows ? dout[(r0 + s) * n_out + q] : 0.0f;
+    }
+    __syncthreads();
+    // Phase 1 (VALU, thread = column j): dZ2 and the head gradients.
+#pragma unroll 4
+    for (int s = 0; s < kTileRows; ++s) {
+      const float hv = s < rows ? h2[(r0 + s) * kHidden + tid] : 0.0f;
+      float g = 0.0f;
+#pragma unroll
+      for (int q = 0; q < kMaxOut; ++q) {
+        if (q < n_out) {
+          const float d = ds[s * kMaxOut + q];
+          g += d * w3r[q];
+          dw3[q] += d * hv;
+          db3[q] += d;
+        }
+      }
+      const float dz = hv > 0.0f ? g : 0.0f;
+      db2 += dz;
+      zt[s * kLdsStride + tid] = dz;
+      if (s < rows) dz2_out[(r0 + s) * kHidden + tid] = dz;
+    }
+    __syncthreads();
+    // Phase 2 (MFMA): dH1 = dZ2 x W2.
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    tile_gemm_64x256x256(zt, w2tp, wave, lane, acc);
+    // Phase 3: dZ1 = dH1 * (h1 > 0); fold into dW1 / db1 running sums.
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int s = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (s < rows) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int i = 64 * wave + 32 * nt + (lane & 31);
+            const float hv = h1[(r0 + s) * kHidden + i];
+            const float dz = hv > 0.0f ? acc[mt][nt][r] : 0.0f;
+            db1[nt] += dz;
+            for (int c = 0; c < d_in; ++c) dw1[nt][c] += dz * xs[s * kMaxIn + c];
+          }
+        }
+      }
+  }
+  // Workgroup partial row.
+  float *row = partials + (int64_t)blockIdx.x * partial_stride;
+  const int off_db1 = kHidden * d_in, off_db2 = off_db1 + kHidden, off_dw3 = off_db2 + kHidden;
+  const int off_db3 = off_dw3 + n_out * kHidden;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int i = 64 * wave + 32 * nt + (lane & 31);
+    const float b = db1[nt] + __shfl_xor(db1[nt], 32, kWave);
+    if (hh == 0) row[off_db1 + i] = b;
+    for (int c = 0; c < d_in; ++c) {
+      const float w = dw1[nt][c] + __shfl_xor(dw1[nt][c], 32, kWave);
+      if (hh == 0) row[i * d_in + c] = w;
+    }
+  }
+  row[off_db2 + tid] = db2;
+  for (int q = 0; q < n_out; ++q) row[off_dw3 + q * kHidden + tid] = dw3[q];
+  if (tid == 0)
+    for (int q = 0; q < n_out; ++q) row[off_db3 + q] = db3[q];
+}
+
+inline size_t mlp_backward_lds_bytes() {
+  return sizeof(float) * (kTileRows * kLdsStride + kTileRows * kMaxIn + kTileRows * kMaxOut);
+}
+
+inline size_t mlp_forward_lds_bytes() {
+  return sizeof(float) * (kTileRows * kLdsStride + kTileRows * kMaxIn + kMaxOut * kHidden);
+}
+
+}  // namespace rl8
+
+using namespace rl8;
+
+RL8_API int rl8_mlp_pack_w2_f32(const float *w2, float *w2_packed, int transposed, void *stream) {
+  if (!w2 || !w2_packed) return RL8_ENULL;
+  if (!aligned16(w2) || !aligned16(w2_packed)) return RL8_EALIGN;
+  const int grid = kHidden * kHidden / 4 / kBlock;
+  if (transposed)
+    mlp_pack_w2t_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(w2, w2_packed);
+  else
+    mlp_pack_w2_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(w2, w2_packed);
+  return launch_status();
+}
+
+RL8_API int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *w1,
+                                      const float *b1, const float *w2_packed, const float *b2,
+                                      const float *w3, const float *b3, int n_out, float *out,
+                                      float *save_h1, float *save_h2, void *stream) {
+  if (!x || !w1 || !b1 || !w2_packed || !b2 || !w3 || !b3 || !out) return RL8_ENULL;
+  if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
+  if (!aligned16(w2_packed)) return RL8_EALIGN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_forward_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  const int64_t tiles = (m + kTileRows - 1) / kTileRows;
+  static const int cap = env_int("RL8_MLP_GRID_CAP");
+  const int max_grid = cap > 0 ? cap : 2 * kCUs;  // two resident workgroups per CU
+  const int grid = (int)(tiles < max_grid ? tiles : max_grid);
+  mlp_tower_forward_kernel<<<grid, kBlock, mlp_forward_lds_bytes(), (hipStream_t)stream>>>(
+      x, m, d_in, w1, b1, reinterpret_cast<const float4 *>(w2_packed), b2, w3, b3, n_out, out,
+      save_h1, save_h2);
+  return launch_status();
+}
+
+RL8_API int64_t rl8_mlp_backward_partial_floats(int d_in, int n_out) {
+  return (int64_t)kHidden * d_in + 2 * kHidden + (int64_t)n_out * kHidden + n_out;
+}
+
+RL8_API int rl8_mlp_backward_max_rows(void) { return 2 * kCUs; }
+
+RL8_API int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
+                                       const float *dout, int64_t m, int d_in,
+                                       const float *w2t_packed, const float *w3, int n_out,
+                                       float *dz2_out, float *partials, int *partial_rows_out,
+                                       void *stream) {
+  if (!x || !h1 || !h2 || !dout || !w2t_packed || !w3 || !dz2_out || !partials ||
+      !partial_rows_out)
+    return RL8_ENULL;
+  if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
+  if (!aligned16(w2t_packed)) return RL8_EALIGN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  const int64_t tiles = (m + kTileRows - 1) / kTileRows;
+  const int grid = (int)(tiles < 2 * kCUs ? tiles : 2 * kCUs);
+  *partial_rows_out = grid;
+  mlp_tower_backward_kernel<<<grid, kBlock, mlp_backward_lds_bytes(), (hipStream_t)stream>>>(
+      x, h1, h2, dout, m, d_in, reinterpret_cast<const float4 *>(w2t_packed), w3, n_out, dz2_out,
+      partials, (int)rl8_mlp_backward_partial_floats(d_in, n_out));
+  return launch_status();
+}

@@ -95,6 +95,11 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_ppo_loss_categorical_fwd_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(PPOHparams), _vp, _vp, _vp, _vp, _vp],
     "rl8_ppo_loss_normal_fwd_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(PPOHparams), _vp, _vp, _vp, _vp, _vp, _vp],
     "rl8_gather_minibatch": [_vp, _i64, _i64, C.POINTER(GatherField), _i32, _vp],
+    "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
+    "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "rl8_mlp_backward_partial_floats": [_i32, _i32],
+    "rl8_mlp_backward_max_rows": [],
+    "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
 }
 
 
@@ -117,7 +122,9 @@ def load() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
-            fn.restype = C.c_int64 if name == "rl8_scratch_bytes" else C.c_int
+            fn.restype = (
+                C.c_int64 if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats") else C.c_int
+            )
         _lib = lib
     return _lib
 
@@ -589,3 +596,91 @@ def gather_minibatch(index: torch.Tensor, h: int, leaves: Sequence[torch.Tensor]
         _check(load().rl8_gather_minibatch(_ptr(index), m, h, fields, len(leaves), _stream()),
                "rl8_gather_minibatch")
     return outs
+
+
+# --------------------------------------------------------------------------- #
+# Fused MLP tower (N1).
+# --------------------------------------------------------------------------- #
+MLP_HIDDEN = 256
+MLP_MAX_IN = 16
+MLP_MAX_OUT = 8
+
+
+def mlp_pack_w2(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
+    """[256, 256] nn.Linear weight -> MFMA fragment order (65536 floats)."""
+    w2 = _dense(w2.detach(), torch.float32, "w2")
+    if tuple(w2.shape) != (MLP_HIDDEN, MLP_HIDDEN):
+        raise ValueError("w2 must be [256, 256]")
+    packed = torch.empty(MLP_HIDDEN * MLP_HIDDEN, dtype=torch.float32, device=w2.device)
+    _check(load().rl8_mlp_pack_w2_f32(_ptr(w2), _ptr(packed), int(transposed), _stream()), "rl8_mlp_pack_w2_f32")
+    return packed
+
+
+def mlp_tower_forward(
+    x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2_packed: torch.Tensor, b2: torch.Tensor,
+    w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False,
+) -> tuple[torch.Tensor, None | torch.Tensor, None | torch.Tensor]:
+    """x [M, d_in] -> out [M, n_out] (and the saved activations when ``save``)."""
+    x = _dense(x.detach(), torch.float32, "x")
+    m, d_in = x.shape
+    n_out = w3.shape[0]
+    for name, t, shape in (("w1", w1, (MLP_HIDDEN, d_in)), ("b1", b1, (MLP_HIDDEN,)), ("b2", b2, (MLP_HIDDEN,)),
+                           ("w3", w3, (n_out, MLP_HIDDEN)), ("b3", b3, (n_out,))):
+        _dense(t.detach(), torch.float32, name)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+    if w2_packed.numel() != MLP_HIDDEN * MLP_HIDDEN:
+        raise ValueError("w2_packed must come from mlp_pack_w2")
+    out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
+    h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
+    h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
+    with _timed("mlp_tower_forward", m):
+        _check(
+            load().rl8_mlp_tower_forward_f32(
+                _ptr(x), m, d_in, _ptr(w1.detach()), _ptr(b1.detach()), _ptr(w2_packed), _ptr(b2.detach()),
+                _ptr(w3.detach()), _ptr(b3.detach()), n_out, _ptr(out), _ptr(h1), _ptr(h2), _stream(),
+            ),
+            "rl8_mlp_tower_forward_f32",
+        )
+    return out, h1, h2
+
+
+def mlp_tower_backward(
+    x: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor, dout: torch.Tensor, w2t_packed: torch.Tensor,
+    w3: torch.Tensor,
+) -> dict[str, torch.Tensor]:
+    """Gradients of one tower's parameters given ``dout`` [M, n_out] and the
+    activations saved by the forward pass. Returns ``w1, b1, w2, b2, w3, b3``."""
+    m, d_in = x.shape
+    n_out = w3.shape[0]
+    for name, t, numel in (("x", x, m * d_in), ("h1", h1, m * MLP_HIDDEN), ("h2", h2, m * MLP_HIDDEN),
+                           ("dout", dout, m * n_out)):
+        _dense(t, torch.float32, name)
+        if t.numel() != numel:
+            raise ValueError(f"{name} has the wrong number of elements")
+    lib = load()
+    width = int(lib.rl8_mlp_backward_partial_floats(d_in, n_out))
+    max_rows = int(lib.rl8_mlp_backward_max_rows())
+    partials = torch.empty(max_rows, width, dtype=torch.float32, device=x.device)
+    dz2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device)
+    rows = C.c_int(0)
+    with _timed("mlp_tower_backward", m):
+        _check(
+            lib.rl8_mlp_tower_backward_f32(
+                _ptr(x), _ptr(h1), _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
+                _ptr(dz2), _ptr(partials), C.byref(rows), _stream(),
+            ),
+            "rl8_mlp_tower_backward_f32",
+        )
+    small = partials[: rows.value].sum(0)
+    o1 = MLP_HIDDEN * d_in
+    grads = {
+        "w1": small[:o1].view(MLP_HIDDEN, d_in),
+        "b1": small[o1 : o1 + MLP_HIDDEN],
+        "b2": small[o1 + MLP_HIDDEN : o1 + 2 * MLP_HIDDEN],
+        "w3": small[o1 + 2 * MLP_HIDDEN : o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN].view(n_out, MLP_HIDDEN),
+        "b3": small[o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN :],
+        # the one large product left: dW2 = dZ2^T h1 (library GEMM)
+        "w2": dz2.t() @ h1,
+    }
+    return grads

@@ -200,11 +200,19 @@ class DefaultContinuousModel(Model):
         self._value: None | torch.Tensor = None
 
     def forward(self, batch: TensorDict, /) -> TensorDict:
+        from .nn import fused_mlp
+
         obs = batch[DataKeys.OBS]
-        latents = self.latent_model(obs)
-        action_mean = self.action_mean(latents)
-        action_log_std = self.action_log_std(latents)
-        self._value = self.vf_model(obs)
+        fused = fused_mlp.tower_forward(self.latent_model, [self.action_mean, self.action_log_std], obs)
+        if fused is not None:
+            a = self.action_mean.out_features
+            action_mean, action_log_std = fused[:, :a], fused[:, a:]
+        else:
+            latents = self.latent_model(obs)
+            action_mean = self.action_mean(latents)
+            action_log_std = self.action_log_std(latents)
+        value = fused_mlp.tower_forward(self.vf_model[:2], [self.vf_model[2]], obs)
+        self._value = value if value is not None else self.vf_model(obs)
         return TensorDict(
             {"mean": action_mean, "log_std": torch.tanh(action_log_std)},
             batch_size=batch.batch_size,
@@ -245,11 +253,15 @@ class DefaultDiscreteModel(Model):
         self._value: None | torch.Tensor = None
 
     def forward(self, batch: TensorDict, /) -> TensorDict:
+        from .nn import fused_mlp
+
         obs = batch[DataKeys.OBS]
-        logits = self.feature_model(obs).reshape(
-            -1, self.action_spec.shape[0], self.action_spec.space.n
-        )
-        self._value = self.vf_model(obs)
+        logits = fused_mlp.tower_forward(self.feature_model[:2], [self.feature_model[2]], obs)
+        if logits is None:
+            logits = self.feature_model(obs)
+        logits = logits.reshape(-1, self.action_spec.shape[0], self.action_spec.space.n)
+        value = fused_mlp.tower_forward(self.vf_model[:2], [self.vf_model[2]], obs)
+        self._value = value if value is not None else self.vf_model(obs)
         return TensorDict({"logits": logits}, batch_size=batch.batch_size, device=obs.device)
 
     def to(self, device: Device) -> "DefaultDiscreteModel":  # type: ignore[override]

@@ -1,0 +1,98 @@
+"""The default policy / value tower as fused gfx950 kernels.
+
+``Linear(d_in, 256) -> ReLU -> Linear(256, 256) -> ReLU -> Linear(256, n_out)``
+(``src/rl8/models/_feedforward.py:336-362`` of the reference) runs as one forward
+kernel and one backward kernel + one library GEMM, in fp32 on the matrix cores,
+instead of ~8 (forward) / ~20 (backward) eager launches whose 256-wide
+activations each make an HBM round trip. Parameters stay ordinary
+``torch.nn.Linear`` weights; this module only changes how the tower is evaluated.
+
+``tower_forward`` falls back to the module's own eager path whenever the tower
+is not exactly that shape (other widths, activations, norm layers, AMP autocast,
+non-HIP tensors), so custom models are unaffected.
+
+"""
+
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+
+#: Set to False to evaluate towers with eager PyTorch (A/B comparisons).
+ENABLED = True
+
+_pack_cache: dict[tuple[int, bool], tuple[int, torch.Tensor]] = {}
+
+
+def _packed(w2: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """MFMA-fragment-ordered copy of ``w2``, re-made only when the optimizer has
+    changed the weight (tracked by the tensor's version counter)."""
+    key = (w2.data_ptr(), transposed)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == w2._version:
+        return hit[1]
+    packed = hip.mlp_pack_w2(w2, transposed=transposed)
+    _pack_cache[key] = (w2._version, packed)
+    return packed
+
+
+class _FusedTower(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3):  # type: ignore[override]
+        need_grad = any(ctx.needs_input_grad[1:])
+        out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(w2, False), b2, w3, b3, save=need_grad)
+        if need_grad:
+            ctx.save_for_backward(x, h1, h2, w2, w3)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):  # type: ignore[override]
+        x, h1, h2, w2, w3 = ctx.saved_tensors
+        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(w2, True), w3)
+        return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"]
+
+
+def _match(trunk: nn.Module, heads: Sequence[nn.Linear]) -> None | tuple[nn.Linear, nn.Linear]:
+    """(layer1, layer2) if ``trunk`` is ``Sequential(MLP(Linear, ReLU, Linear), ReLU)``
+    (optionally followed by the single head) with 256-wide biased layers."""
+    if not isinstance(trunk, nn.Sequential) or len(trunk) < 2:
+        return None
+    mlp, act = trunk[0], trunk[1]
+    if not isinstance(mlp, nn.Sequential) or len(mlp) != 3 or not isinstance(act, nn.ReLU):
+        return None
+    l1, a1, l2 = mlp[0], mlp[1], mlp[2]
+    if not (isinstance(l1, nn.Linear) and isinstance(a1, nn.ReLU) and isinstance(l2, nn.Linear)):
+        return None
+    if l1.out_features != hip.MLP_HIDDEN or l2.out_features != hip.MLP_HIDDEN or l2.in_features != hip.MLP_HIDDEN:
+        return None
+    if l1.in_features > hip.MLP_MAX_IN or l1.bias is None or l2.bias is None:
+        return None
+    if sum(h.out_features for h in heads) > hip.MLP_MAX_OUT or any(h.bias is None for h in heads):
+        return None
+    if any(h.in_features != hip.MLP_HIDDEN for h in heads):
+        return None
+    return l1, l2
+
+
+def tower_forward(trunk: nn.Sequential, heads: Sequence[nn.Linear], x: torch.Tensor) -> None | torch.Tensor:
+    """``cat([head(trunk(x)) for head in heads], -1)`` through the fused kernels,
+    or ``None`` when this tower / input is not eligible (caller then runs the
+    modules eagerly)."""
+    if not ENABLED or not x.is_cuda or x.dtype != torch.float32 or x.ndim != 2:
+        return None
+    if torch.is_autocast_enabled():
+        return None
+    layers = _match(trunk, heads)
+    if layers is None or x.shape[1] != layers[0].in_features:
+        return None
+    l1, l2 = layers
+    if len(heads) == 1:
+        w3, b3 = heads[0].weight, heads[0].bias
+    else:
+        w3 = torch.cat([h.weight for h in heads], 0)
+        b3 = torch.cat([h.bias for h in heads], 0)
+    return _FusedTower.apply(x.contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3)

@@ -410,3 +410,35 @@ def test_recurrent_fused_and_generic_rollouts_agree():
         assert torch.equal(a[k], b[k]), k
     with pytest.raises(ValueError, match="seq_len"):
         RecurrentAlgorithmConfig(horizon=30, num_envs=8, seq_len=4).build(DiscreteDummyEnv)
+
+
+# --- fused MLP towers (N1) -------------------------------------------------------
+@pytest.mark.parametrize("env_cls", [ContinuousDummyEnv, DiscreteDummyEnv])
+def test_fused_towers_match_eager_towers(env_cls):
+    """Same seed, same Philox noise: a collect()+step() with the fused tower kernels
+    must agree with the eager-PyTorch towers (fp32 reduction order differs)."""
+    from rl8_amd.nn import fused_mlp
+
+    def run(enabled):
+        fused_mlp.ENABLED = enabled
+        try:
+            torch.manual_seed(5)
+            algo = AlgorithmConfig(num_envs=256, horizon=16, entropy_coeff=0.0).build(env_cls)
+            c = algo.collect()
+            buf = {k: v.clone() for k, v in algo.buffer.items()}
+            s = algo.step()
+            return c, buf, s, [p.detach().clone() for p in algo.policy.model.parameters()]
+        finally:
+            fused_mlp.ENABLED = True
+
+    c1, b1, s1, p1 = run(True)
+    c0, b0, s0, p0 = run(False)
+    if env_cls is DiscreteDummyEnv:
+        assert torch.equal(b1[DataKeys.ACTIONS], b0[DataKeys.ACTIONS])
+    torch.testing.assert_close(b1[DataKeys.VALUES], b0[DataKeys.VALUES], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(b1[DataKeys.LOGP], b0[DataKeys.LOGP], rtol=1e-4, atol=1e-5)
+    assert c1["returns/mean"] == pytest.approx(c0["returns/mean"], rel=1e-5)
+    for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+        assert s1[k] == pytest.approx(s0[k], rel=2e-4, abs=1e-6), k
+    for a, b in zip(p1, p0):
+        torch.testing.assert_close(a, b, rtol=5e-3, atol=2e-4)

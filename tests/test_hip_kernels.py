@@ -557,3 +557,64 @@ def test_gather_wide_rows_recurrent_states():
     env, t = first_ids // h, first_ids % h
     assert np.array_equal(host(wide), hidden[t, env])
     assert np.array_equal(host(narrow), host(small)[env, t])
+
+
+# --------------------------------------------------------------------------- #
+# N1: fused MLP tower vs a plain PyTorch fp32 reference of the same op
+# --------------------------------------------------------------------------- #
+def _torch_tower(x, w1, b1, w2, b2, w3, b3):
+    h1 = torch.relu(x @ w1.T + b1)
+    h2 = torch.relu(h1 @ w2.T + b2)
+    return h2 @ w3.T + b3, h1, h2
+
+
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (63, 1, 1), (64, 1, 2), (1000, 5, 3), (4097, 16, 8), (100_000, 1, 2)])
+def test_mlp_tower_forward_matches_torch(m, d_in, n_out):
+    g = torch.Generator(device=DEV).manual_seed(m + d_in)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 30
+    w1 = torch.randn(256, d_in, device=DEV, generator=g) * 0.5
+    b1 = torch.randn(256, device=DEV, generator=g) * 0.1
+    w2 = torch.randn(256, 256, device=DEV, generator=g) / 16
+    b2 = torch.randn(256, device=DEV, generator=g) * 0.1
+    w3 = torch.randn(n_out, 256, device=DEV, generator=g) / 16
+    b3 = torch.randn(n_out, device=DEV, generator=g)
+    want, h1w, h2w = _torch_tower(x.double(), w1.double(), b1.double(), w2.double(), b2.double(), w3.double(), b3.double())
+    packed = hip.mlp_pack_w2(w2)
+    out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, packed, b2, w3, b3, save=True)
+    scale = float(want.abs().max()) + 1e-6
+    assert float((out.double() - want).abs().max()) / scale < 2e-6
+    assert float((h1.double() - h1w).abs().max()) / (float(h1w.abs().max()) + 1e-6) < 1e-6
+    assert float((h2.double() - h2w).abs().max()) / (float(h2w.abs().max()) + 1e-6) < 2e-6
+    out2, none1, none2 = hip.mlp_tower_forward(x, w1, b1, packed, b2, w3, b3)
+    assert none1 is None and none2 is None and torch.equal(out, out2)
+    # as accurate as torch's own fp32 path
+    ref32, _, _ = _torch_tower(x, w1, b1, w2, b2, w3, b3)
+    err_ours = float((out.double() - want).abs().max())
+    err_torch = float((ref32.double() - want).abs().max())
+    assert err_ours <= 4 * err_torch + 1e-6 * scale
+
+
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (65, 1, 1), (1000, 5, 3), (40_000, 1, 2), (4097, 16, 8)])
+def test_mlp_tower_backward_matches_autograd(m, d_in, n_out):
+    g = torch.Generator(device=DEV).manual_seed(7 * m + d_in)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 3
+    params = {
+        "w1": torch.randn(256, d_in, device=DEV, generator=g) * 0.5,
+        "b1": torch.randn(256, device=DEV, generator=g) * 0.1,
+        "w2": torch.randn(256, 256, device=DEV, generator=g) / 16,
+        "b2": torch.randn(256, device=DEV, generator=g) * 0.1,
+        "w3": torch.randn(n_out, 256, device=DEV, generator=g) / 16,
+        "b3": torch.randn(n_out, device=DEV, generator=g),
+    }
+    dout = torch.randn(m, n_out, device=DEV, generator=g) / m
+    ref = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    out_ref, _, _ = _torch_tower(x.double(), *(ref[k] for k in ("w1", "b1", "w2", "b2", "w3", "b3")))
+    out_ref.backward(dout.double())
+    out, h1, h2 = hip.mlp_tower_forward(x, params["w1"], params["b1"], hip.mlp_pack_w2(params["w2"]), params["b2"],
+                                        params["w3"], params["b3"], save=True)
+    grads = hip.mlp_tower_backward(x, h1, h2, dout, hip.mlp_pack_w2(params["w2"], transposed=True), params["w3"])
+    for k in params:
+        want = ref[k].grad
+        scale = float(want.abs().max()) + 1e-12
+        err = float((grads[k].double() - want).abs().max()) / scale
+        assert err < 2e-5, (k, err)

@@ -85,7 +85,27 @@ def gae_em():
                         gamma_lambda=f32(0.9025), reward_denominator=f32(30.0), write_scaled_rewards=False)
 
 
+mlp_x = torch.randn(N, 1, device=dev, generator=g) * 30
+mlp_w1 = torch.randn(256, 1, device=dev, generator=g)
+mlp_b1 = torch.randn(256, device=dev, generator=g)
+mlp_w2 = torch.randn(256, 256, device=dev, generator=g) / 16
+mlp_b2 = torch.randn(256, device=dev, generator=g)
+mlp_w3 = torch.randn(2, 256, device=dev, generator=g) / 16
+mlp_b3 = torch.randn(2, device=dev, generator=g)
+mlp_w2p = hip.mlp_pack_w2(mlp_w2)
+MLP_FLOP = 2 * N * (256 * 1 + 256 * 256 + 256 * 2)
+
+
+def torch_tower():
+    h = torch.relu(torch.addmm(mlp_b1, mlp_x, mlp_w1.T))
+    h = torch.relu(torch.addmm(mlp_b2, h, mlp_w2.T))
+    return torch.addmm(mlp_b3, h, mlp_w3.T)
+
+
 KERNELS = {
+    # the two MLP entries report TFLOP/s in the GB/s column (algorithmic "bytes" = FLOP / 1000)
+    "mlp_tower_forward_fused": (lambda: hip.mlp_tower_forward(mlp_x, mlp_w1, mlp_b1, mlp_w2p, mlp_b2, mlp_w3, mlp_b3), MLP_FLOP / 1000),
+    "mlp_tower_forward_torch": (torch_tower, MLP_FLOP / 1000),
     # name: (callable, algorithmic bytes per launch)
     "gae_scan_time_major": (gae_tm, 16 * N * H + 8 * N),
     "gae_scan_env_major_lds": (gae_em, 16 * N * H + 8 * N),
