@@ -25,35 +25,35 @@ from .. import hip
 #: Set to False to evaluate towers with eager PyTorch (A/B comparisons).
 ENABLED = True
 
-_pack_cache: dict[tuple[int, bool], tuple[int, torch.Tensor]] = {}
-
-
-def _packed(w2: torch.Tensor, transposed: bool) -> torch.Tensor:
-    """MFMA-fragment-ordered copy of ``w2``, re-made only when the optimizer has
-    changed the weight (tracked by the tensor's version counter)."""
-    key = (w2.data_ptr(), transposed)
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == w2._version:
-        return hit[1]
+def _packed(layer: nn.Linear, transposed: bool) -> torch.Tensor:
+    """MFMA-fragment-ordered copy of ``layer.weight``, cached ON the layer and
+    re-made when the optimizer has changed the weight (version counter) or the
+    weight tensor has been replaced / moved."""
+    w2 = layer.weight
+    cache = layer.__dict__.setdefault("_rl8_w2_packs", {})
+    hit = cache.get(transposed)
+    if hit is not None and hit[0] == w2._version and hit[1] == w2.data_ptr():
+        return hit[2]
     packed = hip.mlp_pack_w2(w2, transposed=transposed)
-    _pack_cache[key] = (w2._version, packed)
+    cache[transposed] = (w2._version, w2.data_ptr(), packed)
     return packed
 
 
 class _FusedTower(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3):  # type: ignore[override]
-        need_grad = any(ctx.needs_input_grad[1:])
-        out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(w2, False), b2, w3, b3, save=need_grad)
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, layer2):  # type: ignore[override]
+        need_grad = any(ctx.needs_input_grad[1:7])
+        out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
         if need_grad:
-            ctx.save_for_backward(x, h1, h2, w2, w3)
+            ctx.layer2 = layer2
+            ctx.save_for_backward(x, h1, h2, w3)
         return out
 
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
-        x, h1, h2, w2, w3 = ctx.saved_tensors
-        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(w2, True), w3)
-        return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"]
+        x, h1, h2, w3 = ctx.saved_tensors
+        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True), w3)
+        return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None
 
 
 def _match(trunk: nn.Module, heads: Sequence[nn.Linear]) -> None | tuple[nn.Linear, nn.Linear]:
@@ -95,4 +95,4 @@ def tower_forward(trunk: nn.Sequential, heads: Sequence[nn.Linear], x: torch.Ten
     else:
         w3 = torch.cat([h.weight for h in heads], 0)
         b3 = torch.cat([h.bias for h in heads], 0)
-    return _FusedTower.apply(x.contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3)
+    return _FusedTower.apply(x.contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3, l2)
