@@ -130,7 +130,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
     const float *__restrict__ x, int64_t m, int d_in, const float *__restrict__ w1,
     const float *__restrict__ b1, const float4 *__restrict__ w2p, const float *__restrict__ b2,
     const float *__restrict__ w3, const float *__restrict__ b3, int n_out,
-    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2) {
+    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2,
+    uint32_t *__restrict__ save_m1) {
   extern __shared__ float lds[];
   float *ht = lds;                                  // [64][257]: h1, later h2
   float *xs = ht + kTileRows * kLdsStride;          // [64][kMaxIn]
@@ -167,7 +168,14 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
       for (int i = 0; i < d_in; ++i) v += xs[s * kMaxIn + i] * w1r[i];
       v = v > 0.0f ? v : 0.0f;
       ht[s * kLdsStride + tid] = v;
-      if (save_h1 && s < rows) save_h1[(r0 + s) * kHidden + tid] = v;
+      if (save_h1 && s < rows) {
+        save_h1[(r0 + s) * kHidden + tid] = v;
+        // ReLU mask of h1, one bit per unit: word (row, tid/32) -- what the
+        // backward epilogue needs instead of re-reading 1 KiB of h1 per row.
+        const unsigned long long ballot = __ballot(v > 0.0f);
+        if ((lane & 31) == 0)
+          save_m1[(r0 + s) * (kHidden / 32) + (tid >> 5)] = (uint32_t)(ballot >> (lane & 32));
+      }
     }
     __syncthreads();
     // Layer 2 (MFMA).
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
 //   [dW1 (256*d_in) | db1 (256) | db2 (256) | dW3 (n_out*256) | db3 (n_out)],
 // summed on the host side in a fixed order (bitwise reproducible, no atomics).
 __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
-    const float *__restrict__ x, const float *__restrict__ h1, const float *__restrict__ h2,
+    const float *__restrict__ x, const uint32_t *__restrict__ m1, const float *__restrict__ h2,
     const float *__restrict__ dout, int64_t m, int d_in, const float4 *__restrict__ w2tp,
     const float *__restrict__ w3, int n_out, float *__restrict__ dz2_out,
     float *__restrict__ partials, int partial_stride) {
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
   float *zt = lds;                                  // [64][257]: h2 -> dZ2
   float *xs = zt + kTileRows * kLdsStride;          // [64][kMaxIn]
   float *ds = xs + kTileRows * kMaxIn;              // [64][kMaxOut] dOut tile
+  uint32_t *ms = reinterpret_cast<uint32_t *>(ds + kTileRows * kMaxOut);  // [64][8] h1 mask
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5;
 
@@ -278,11 +287,34 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
       const int s = idx / n_out, q = idx - s * n_out;
       ds[s * kMaxOut + q] = s < rows ? dout[(r0 + s) * n_out + q] : 0.0f;
     }
+    for (int idx = tid; idx < kTileRows * (kHidden / 32); idx += kBlock)
+      ms[idx] = idx < rows * (kHidden / 32) ? m1[r0 * (kHidden / 32) + idx] : 0u;
+    {
+      // h2 tile: the tile's rows are one contiguous run of rows*256 floats in
+      // HBM -> 16-byte loads, four in flight per lane, scattered into the padded
+      // LDS tile.
+      const float4 *src = reinterpret_cast<const float4 *>(h2 + r0 * kHidden);
+      const int nvec = rows * (kHidden / 4);
+      for (int i0 = tid; i0 < kTileRows * (kHidden / 4); i0 += kBlock * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kBlock;
+          v[u] = i < nvec ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kBlock;
+          float *dst = zt + (i >> 6) * kLdsStride + ((i & 63) << 2);
+          dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+        }
+      }
+    }
     __syncthreads();
     // Phase 1 (VALU, thread = column j): dZ2 and the head gradients.
 #pragma unroll 4
     for (int s = 0; s < kTileRows; ++s) {
-      const float hv = s < rows ? h2[(r0 + s) * kHidden + tid] : 0.0f;
+      const float hv = zt[s * kLdsStride + tid];
       float g = 0.0f;
 #pragma unroll
       for (int q = 0; q < kMaxOut; ++q) {
@@ -317,9 +349,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
         if (s < rows) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
-            const int i = 64 * wave + 32 * nt + (lane & 31);
-            const float hv = h1[(r0 + s) * kHidden + i];
-            const float dz = hv > 0.0f ? acc[mt][nt][r] : 0.0f;
+            const uint32_t word = ms[s * (kHidden / 32) + 2 * wave + nt];
+            const float dz = ((word >> (lane & 31)) & 1u) ? acc[mt][nt][r] : 0.0f;
             db1[nt] += dz;
             for (int c = 0; c < d_in; ++c) dw1[nt][c] += dz * xs[s * kMaxIn + c];
           }
@@ -347,7 +378,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
 }
 
 inline size_t mlp_backward_lds_bytes() {
-  return sizeof(float) * (kTileRows * kLdsStride + kTileRows * kMaxIn + kTileRows * kMaxOut);
+  return sizeof(float) * (kTileRows * kLdsStride + kTileRows * kMaxIn + kTileRows * kMaxOut +
+                          kTileRows * (kHidden / 32));
 }
 
 inline size_t mlp_forward_lds_bytes() {
@@ -372,8 +404,10 @@ RL8_API int rl8_mlp_pack_w2_f32(const float *w2, float *w2_packed, int transpose
 RL8_API int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *w1,
                                       const float *b1, const float *w2_packed, const float *b2,
                                       const float *w3, const float *b3, int n_out, float *out,
-                                      float *save_h1, float *save_h2, void *stream) {
+                                      float *save_h1, float *save_h2, uint32_t *save_m1,
+                                      void *stream) {
   if (!x || !w1 || !b1 || !w2_packed || !b2 || !w3 || !b3 || !out) return RL8_ENULL;
+  if ((save_h1 == nullptr) != (save_m1 == nullptr)) return RL8_ENULL;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
   if (!aligned16(w2_packed)) return RL8_EALIGN;
   static bool attr_set = false;
@@ -389,7 +423,7 @@ RL8_API int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const
   const int grid = (int)(tiles < max_grid ? tiles : max_grid);
   mlp_tower_forward_kernel<<<grid, kBlock, mlp_forward_lds_bytes(), (hipStream_t)stream>>>(
       x, m, d_in, w1, b1, reinterpret_cast<const float4 *>(w2_packed), b2, w3, b3, n_out, out,
-      save_h1, save_h2);
+      save_h1, save_h2, save_m1);
   return launch_status();
 }
 
@@ -399,14 +433,15 @@ RL8_API int64_t rl8_mlp_backward_partial_floats(int d_in, int n_out) {
 
 RL8_API int rl8_mlp_backward_max_rows(void) { return 2 * kCUs; }
 
-RL8_API int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
+RL8_API int rl8_mlp_tower_backward_f32(const float *x, const uint32_t *m1, const float *h2,
                                        const float *dout, int64_t m, int d_in,
                                        const float *w2t_packed, const float *w3, int n_out,
                                        float *dz2_out, float *partials, int *partial_rows_out,
                                        void *stream) {
-  if (!x || !h1 || !h2 || !dout || !w2t_packed || !w3 || !dz2_out || !partials ||
+  if (!x || !m1 || !h2 || !dout || !w2t_packed || !w3 || !dz2_out || !partials ||
       !partial_rows_out)
     return RL8_ENULL;
+  if (!aligned16(h2)) return RL8_EALIGN;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
   if (!aligned16(w2t_packed)) return RL8_EALIGN;
   static bool attr_set = false;
@@ -420,7 +455,7 @@ RL8_API int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const fl
   const int grid = (int)(tiles < 2 * kCUs ? tiles : 2 * kCUs);
   *partial_rows_out = grid;
   mlp_tower_backward_kernel<<<grid, kBlock, mlp_backward_lds_bytes(), (hipStream_t)stream>>>(
-      x, h1, h2, dout, m, d_in, reinterpret_cast<const float4 *>(w2t_packed), w3, n_out, dz2_out,
+      x, m1, h2, dout, m, d_in, reinterpret_cast<const float4 *>(w2t_packed), w3, n_out, dz2_out,
       partials, (int)rl8_mlp_backward_partial_floats(d_in, n_out));
   return launch_status();
 }
