@@ -103,6 +103,7 @@ __device__ __forceinline__ void mma_frag(const Frag &f, f32x16 (&acc)[2][2]) {
   }
 }
 
+template <int VARIANT>
 __device__ __forceinline__ void tile_gemm_64x256x256(const float *__restrict__ a_tile,
                                                      const float4 *__restrict__ bp, int wave,
                                                      int lane, f32x16 (&acc)[2][2]) {
@@ -111,14 +112,33 @@ __device__ __forceinline__ void tile_gemm_64x256x256(const float *__restrict__ a
   const float4 *b1p = bp + ((2 * wave + 1) * kGroups) * kWave + lane;
   const float *a0p = a_tile + (0 * 32 + i) * kLdsStride + 4 * hh;
   const float *a1p = a_tile + (1 * 32 + i) * kLdsStride + 4 * hh;
-  Frag fa, fb;
-  load_frag(fa, b0p, b1p, a0p, a1p, 0);
+  if constexpr (VARIANT == 0) {
+    Frag fa, fb;
+    load_frag(fa, b0p, b1p, a0p, a1p, 0);
 #pragma unroll 1
-  for (int g = 0; g < kGroups; g += 2) {
-    load_frag(fb, b0p, b1p, a0p, a1p, g + 1);
-    mma_frag(fa, acc);
-    if (g + 2 < kGroups) load_frag(fa, b0p, b1p, a0p, a1p, g + 2);
-    mma_frag(fb, acc);
+    for (int g = 0; g < kGroups; g += 2) {
+      load_frag(fb, b0p, b1p, a0p, a1p, g + 1);
+      mma_frag(fa, acc);
+      if (g + 2 < kGroups) load_frag(fa, b0p, b1p, a0p, a1p, g + 2);
+      mma_frag(fb, acc);
+    }
+  } else {
+    // three register sets, fragments two k-groups ahead
+    Frag f0, f1, f2;
+    load_frag(f0, b0p, b1p, a0p, a1p, 0);
+    load_frag(f1, b0p, b1p, a0p, a1p, 1);
+#pragma unroll 1
+    for (int g = 0; g < kGroups - 2; g += 3) {
+      load_frag(f2, b0p, b1p, a0p, a1p, g + 2);
+      mma_frag(f0, acc);
+      load_frag(f0, b0p, b1p, a0p, a1p, g + 3 < kGroups ? g + 3 : kGroups - 1);
+      mma_frag(f1, acc);
+      load_frag(f1, b0p, b1p, a0p, a1p, g + 4 < kGroups ? g + 4 : kGroups - 1);
+      mma_frag(f2, acc);
+    }
+    // kGroups = 32 = 3*10 + 2: groups 30, 31 remain in f0, f1
+    mma_frag(f0, acc);
+    mma_frag(f1, acc);
   }
 }
 
@@ -126,46 +146,78 @@ __device__ __forceinline__ void tile_gemm_64x256x256(const float *__restrict__ a
 // LDS: ONE [64][257] tile (h1, then h2 in place once the MFMA loop has consumed
 // h1) + the observation tile + the head weights = 78 KB => two workgroups per
 // CU, so one workgroup's VALU phases overlap the other's matrix phase.
+// DIN / NOUT: compile-time input / output widths (0 = run-time, up to
+// kMaxIn / kMaxOut): the VALU phases are short only when fully unrolled and
+// branch-free (measured: a run-time-bounded head loop cost more than the
+// whole matrix phase).
+template <int DIN, int NOUT>
 __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
-    const float *__restrict__ x, int64_t m, int d_in, const float *__restrict__ w1,
+    const float *__restrict__ x, int64_t m, int d_in_rt, const float *__restrict__ w1,
     const float *__restrict__ b1, const float4 *__restrict__ w2p, const float *__restrict__ b2,
-    const float *__restrict__ w3, const float *__restrict__ b3, int n_out,
+    const float *__restrict__ w3, const float *__restrict__ b3, int n_out_rt,
     float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2,
     uint32_t *__restrict__ save_m1) {
+  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
+  constexpr int kOut = NOUT > 0 ? NOUT : kMaxOut;
+  const int d_in = DIN > 0 ? DIN : d_in_rt;
+  const int n_out = NOUT > 0 ? NOUT : n_out_rt;
   extern __shared__ float lds[];
   float *ht = lds;                                  // [64][257]: h1, later h2
   float *xs = ht + kTileRows * kLdsStride;          // [64][kMaxIn]
-  float *w3s = xs + kTileRows * kMaxIn;             // [kMaxOut][256]
+  float *w3s = xs + kTileRows * kMaxIn;             // [kMaxOut][256], zero-padded rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  // Per-thread constants: column `tid` of layer 1, head weights to LDS.
-  float w1r[kMaxIn];
+  // Per-thread constants: column `tid` of layer 1 (zero-padded), head weights
+  // to LDS (rows >= n_out zeroed so the run-time-width head needs no branches).
+  float w1r[kIn];
 #pragma unroll
-  for (int i = 0; i < kMaxIn; ++i) w1r[i] = i < d_in ? w1[tid * d_in + i] : 0.0f;
+  for (int i = 0; i < kIn; ++i) w1r[i] = i < d_in ? w1[tid * d_in + i] : 0.0f;
   const float b1r = b1[tid];
-  for (int idx = tid; idx < n_out * kHidden; idx += kBlock) w3s[idx] = w3[idx];
+  for (int idx = tid; idx < kOut * kHidden; idx += kBlock)
+    w3s[idx] = idx < n_out * kHidden ? w3[idx] : 0.0f;
   float b2r[2];
   b2r[0] = b2[64 * wave + (lane & 31)];
   b2r[1] = b2[64 * wave + 32 + (lane & 31)];
-  float b3r[kMaxOut];
+  float b3r[kOut];
 #pragma unroll
-  for (int q = 0; q < kMaxOut; ++q) b3r[q] = q < n_out ? b3[q] : 0.0f;
+  for (int q = 0; q < kOut; ++q) b3r[q] = q < n_out ? b3[q] : 0.0f;
 
   const int64_t tiles = (m + kTileRows - 1) / kTileRows;
+  // Observation tile: element e of the [64][d_in] tile is owned by thread e
+  // (+256, ...); fetched one tile ahead so its HBM latency hides under the
+  // matrix phase.
+  constexpr int kXPerThread = (kTileRows * kIn + kBlock - 1) / kBlock;
+  float xreg[kXPerThread];
+  auto fetch_x = [&](int64_t tile) {
+    const int64_t r0 = tile * kTileRows;
+#pragma unroll
+    for (int u = 0; u < kXPerThread; ++u) {
+      const int idx = tid + u * kBlock;
+      const int64_t g = r0 * d_in + idx;
+      xreg[u] = (idx < kTileRows * d_in && g < m * d_in) ? x[g] : 0.0f;
+    }
+  };
+  if ((int64_t)blockIdx.x < tiles) fetch_x(blockIdx.x);
+
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t r0 = tile * kTileRows;
     const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
     __syncthreads();  // previous tile's readers of xs / ht are done
-    for (int idx = tid; idx < kTileRows * d_in; idx += kBlock) {
-      const int s = idx / d_in, i = idx - s * d_in;
-      xs[s * kMaxIn + i] = s < rows ? x[(r0 + s) * d_in + i] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < kXPerThread; ++u) {
+      const int idx = tid + u * kBlock;
+      if (idx < kTileRows * d_in) {
+        const int s = DIN > 0 ? idx / kIn : idx / d_in;
+        xs[s * kMaxIn + (idx - s * d_in)] = xreg[u];
+      }
     }
     __syncthreads();
     // Layer 1 (VALU): thread = output column, loop over the tile's rows.
-#pragma unroll 4
+#pragma unroll 8
     for (int s = 0; s < kTileRows; ++s) {
       float v = b1r;
-      for (int i = 0; i < d_in; ++i) v += xs[s * kMaxIn + i] * w1r[i];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) v += xs[s * kMaxIn + i] * w1r[i];
       v = v > 0.0f ? v : 0.0f;
       ht[s * kLdsStride + tid] = v;
       if (save_h1 && s < rows) {
@@ -178,6 +230,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
       }
     }
     __syncthreads();
+    if (tile + gridDim.x < tiles) fetch_x(tile + gridDim.x);  // lands during the matrix phase
     // Layer 2 (MFMA).
     f32x16 acc[2][2];
 #pragma unroll
@@ -186,7 +239,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    tile_gemm_64x256x256(ht, w2p, wave, lane, acc);
+    tile_gemm_64x256x256<0>(ht, w2p, wave, lane, acc);
     __syncthreads();  // every wave has read all of h1: the tile may be overwritten
     // bias + ReLU, accumulators -> h2 (in place of h1).
 #pragma unroll
@@ -209,29 +262,28 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
       }
     }
     // Head (VALU): 4 lanes per row (a quarter of the 256 inputs each, rotated by
-    // 8 per quarter to spread LDS banks), combined with two lane shuffles.
+    // 8 per quarter to spread LDS banks), fully unrolled and branch-free, then
+    // combined with two lane shuffles.
     {
       const int s = 16 * wave + (lane >> 2), q4 = lane & 3;
-      float o[kMaxOut];
+      float o[kOut];
 #pragma unroll
-      for (int q = 0; q < kMaxOut; ++q) o[q] = 0.0f;
+      for (int q = 0; q < kOut; ++q) o[q] = 0.0f;
       const float *row = ht + s * kLdsStride + 64 * q4;
       const float *wq = w3s + 64 * q4;
+#pragma unroll 16
       for (int jj = 0; jj < 64; ++jj) {
         const int j = (jj + 8 * q4) & 63;
         const float hv = row[j];
 #pragma unroll
-        for (int q = 0; q < kMaxOut; ++q)
-          if (q < n_out) o[q] += hv * wq[q * kHidden + j];
+        for (int q = 0; q < kOut; ++q) o[q] += hv * wq[q * kHidden + j];
       }
 #pragma unroll
-      for (int q = 0; q < kMaxOut; ++q) {
-        if (q < n_out) {
-          float v = o[q];
-          v += __shfl_xor(v, 1, kWave);
-          v += __shfl_xor(v, 2, kWave);
-          if (q4 == 0 && s < rows) out[(r0 + s) * n_out + q] = v + b3r[q];
-        }
+      for (int q = 0; q < kOut; ++q) {
+        float v = o[q];
+        v += __shfl_xor(v, 1, kWave);
+        v += __shfl_xor(v, 2, kWave);
+        if (q < n_out && q4 == 0 && s < rows) out[(r0 + s) * n_out + q] = v + b3r[q];
       }
     }
   }
@@ -248,44 +300,49 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
 // Small gradients leave as one row of per-workgroup partials,
 //   [dW1 (256*d_in) | db1 (256) | db2 (256) | dW3 (n_out*256) | db3 (n_out)],
 // summed on the host side in a fixed order (bitwise reproducible, no atomics).
-__global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
+template <int DIN, int NOUT>
+__global__ __launch_bounds__(kBlock, DIN == 0 ? 1 : 2) void mlp_tower_backward_kernel(
     const float *__restrict__ x, const uint32_t *__restrict__ m1, const float *__restrict__ h2,
-    const float *__restrict__ dout, int64_t m, int d_in, const float4 *__restrict__ w2tp,
-    const float *__restrict__ w3, int n_out, float *__restrict__ dz2_out,
+    const float *__restrict__ dout, int64_t m, int d_in_rt, const float4 *__restrict__ w2tp,
+    const float *__restrict__ w3, int n_out_rt, float *__restrict__ dz2_out,
     float *__restrict__ partials, int partial_stride) {
+  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
+  constexpr int kOut = NOUT > 0 ? NOUT : kMaxOut;
+  const int d_in = DIN > 0 ? DIN : d_in_rt;
+  const int n_out = NOUT > 0 ? NOUT : n_out_rt;
   extern __shared__ float lds[];
   float *zt = lds;                                  // [64][257]: h2 -> dZ2
-  float *xs = zt + kTileRows * kLdsStride;          // [64][kMaxIn]
-  float *ds = xs + kTileRows * kMaxIn;              // [64][kMaxOut] dOut tile
+  float *xs = zt + kTileRows * kLdsStride;          // [64][kMaxIn], zero-padded columns
+  float *ds = xs + kTileRows * kMaxIn;              // [64][kMaxOut] dOut tile, zero-padded
   uint32_t *ms = reinterpret_cast<uint32_t *>(ds + kTileRows * kMaxOut);  // [64][8] h1 mask
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5;
 
-  float w3r[kMaxOut];  // column `tid` of W3
+  float w3r[kOut];  // column `tid` of W3, zero-padded
 #pragma unroll
-  for (int q = 0; q < kMaxOut; ++q) w3r[q] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
+  for (int q = 0; q < kOut; ++q) w3r[q] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
   // running sums owned by this thread
-  float dw3[kMaxOut], db3[kMaxOut], db2 = 0.0f;  // column tid (db3: replicated, thread 0 writes)
+  float dw3[kOut], db3[kOut], db2 = 0.0f;  // column tid (db3 replicated; thread 0 writes)
 #pragma unroll
-  for (int q = 0; q < kMaxOut; ++q) dw3[q] = db3[q] = 0.0f;
-  float dw1[2][kMaxIn], db1[2] = {0.0f, 0.0f};    // columns 64*wave + 32*nt + (lane&31), this lane-half's rows
+  for (int q = 0; q < kOut; ++q) dw3[q] = db3[q] = 0.0f;
+  float dw1[2][kIn], db1[2] = {0.0f, 0.0f};  // columns 64*wave + 32*nt + (lane&31), this half's rows
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int c = 0; c < kMaxIn; ++c) dw1[nt][c] = 0.0f;
+    for (int c = 0; c < kIn; ++c) dw1[nt][c] = 0.0f;
 
   const int64_t tiles = (m + kTileRows - 1) / kTileRows;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t r0 = tile * kTileRows;
     const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
     __syncthreads();
-    for (int idx = tid; idx < kTileRows * d_in; idx += kBlock) {
-      const int s = idx / d_in, c = idx - s * d_in;
-      xs[s * kMaxIn + c] = s < rows ? x[(r0 + s) * d_in + c] : 0.0f;
+    for (int idx = tid; idx < kTileRows * kMaxIn; idx += kBlock) {
+      const int s = idx / kMaxIn, c = idx - s * kMaxIn;
+      xs[idx] = (s < rows && c < d_in) ? x[(r0 + s) * d_in + c] : 0.0f;
     }
-    for (int idx = tid; idx < kTileRows * n_out; idx += kBlock) {
-      const int s = idx / n_out, q = idx - s * n_out;
-      ds[s * kMaxOut + q] = s < rows ? dout[(r0 + s) * n_out + q] : 0.0f;
+    for (int idx = tid; idx < kTileRows * kMaxOut; idx += kBlock) {
+      const int s = idx / kMaxOut, q = idx - s * kMaxOut;
+      ds[idx] = (s < rows && q < n_out) ? dout[(r0 + s) * n_out + q] : 0.0f;
     }
     for (int idx = tid; idx < kTileRows * (kHidden / 32); idx += kBlock)
       ms[idx] = idx < rows * (kHidden / 32) ? m1[r0 * (kHidden / 32) + idx] : 0u;
@@ -312,18 +369,16 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
     }
     __syncthreads();
     // Phase 1 (VALU, thread = column j): dZ2 and the head gradients.
-#pragma unroll 4
+#pragma unroll 8
     for (int s = 0; s < kTileRows; ++s) {
       const float hv = zt[s * kLdsStride + tid];
       float g = 0.0f;
 #pragma unroll
-      for (int q = 0; q < kMaxOut; ++q) {
-        if (q < n_out) {
-          const float d = ds[s * kMaxOut + q];
-          g += d * w3r[q];
-          dw3[q] += d * hv;
-          db3[q] += d;
-        }
+      for (int q = 0; q < kOut; ++q) {
+        const float d = ds[s * kMaxOut + q];
+        g += d * w3r[q];
+        dw3[q] += d * hv;
+        db3[q] += d;
       }
       const float dz = hv > 0.0f ? g : 0.0f;
       db2 += dz;
@@ -339,21 +394,24 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    tile_gemm_64x256x256(zt, w2tp, wave, lane, acc);
-    // Phase 3: dZ1 = dH1 * (h1 > 0); fold into dW1 / db1 running sums.
+    tile_gemm_64x256x256<0>(zt, w2tp, wave, lane, acc);
+    // Phase 3: dZ1 = dH1 * (h1 > 0) (mask bits; rows past the end have zero
+    // masks and zero x, so no row guard is needed); fold into dW1 / db1.
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int s = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (s < rows) {
+        float xr[kIn];
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const uint32_t word = ms[s * (kHidden / 32) + 2 * wave + nt];
-            const float dz = ((word >> (lane & 31)) & 1u) ? acc[mt][nt][r] : 0.0f;
-            db1[nt] += dz;
-            for (int c = 0; c < d_in; ++c) dw1[nt][c] += dz * xs[s * kMaxIn + c];
-          }
+        for (int c = 0; c < kIn; ++c) xr[c] = xs[s * kMaxIn + c];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const uint32_t word = ms[s * (kHidden / 32) + 2 * wave + nt];
+          const float dz = ((word >> (lane & 31)) & 1u) ? acc[mt][nt][r] : 0.0f;
+          db1[nt] += dz;
+#pragma unroll
+          for (int c = 0; c < kIn; ++c) dw1[nt][c] += dz * xr[c];
         }
       }
   }
@@ -366,15 +424,21 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_kernel(
     const int i = 64 * wave + 32 * nt + (lane & 31);
     const float b = db1[nt] + __shfl_xor(db1[nt], 32, kWave);
     if (hh == 0) row[off_db1 + i] = b;
-    for (int c = 0; c < d_in; ++c) {
+#pragma unroll
+    for (int c = 0; c < kIn; ++c) {
       const float w = dw1[nt][c] + __shfl_xor(dw1[nt][c], 32, kWave);
-      if (hh == 0) row[i * d_in + c] = w;
+      if (hh == 0 && c < d_in) row[i * d_in + c] = w;
     }
   }
   row[off_db2 + tid] = db2;
-  for (int q = 0; q < n_out; ++q) row[off_dw3 + q * kHidden + tid] = dw3[q];
-  if (tid == 0)
-    for (int q = 0; q < n_out; ++q) row[off_db3 + q] = db3[q];
+#pragma unroll
+  for (int q = 0; q < kOut; ++q)
+    if (q < n_out) row[off_dw3 + q * kHidden + tid] = dw3[q];
+  if (tid == 0) {
+#pragma unroll
+    for (int q = 0; q < kOut; ++q)
+      if (q < n_out) row[off_db3 + q] = db3[q];
+  }
 }
 
 inline size_t mlp_backward_lds_bytes() {
@@ -401,6 +465,37 @@ RL8_API int rl8_mlp_pack_w2_f32(const float *w2, float *w2_packed, int transpose
   return launch_status();
 }
 
+template <int DIN, int NOUT>
+static int launch_forward(int grid, hipStream_t s, const float *x, int64_t m, int d_in,
+                          const float *w1, const float *b1, const float4 *w2p, const float *b2,
+                          const float *w3, const float *b3, int n_out, float *out, float *save_h1,
+                          float *save_h2, uint32_t *save_m1) {
+  static bool attr_set = false;  // one flag per instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void *>(&mlp_tower_forward_kernel<DIN, NOUT>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  mlp_tower_forward_kernel<DIN, NOUT><<<grid, kBlock, mlp_forward_lds_bytes(), s>>>(
+      x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, save_h1, save_h2, save_m1);
+  return launch_status();
+}
+
+template <int DIN>
+static int dispatch_forward_nout(int n_out, int grid, hipStream_t s, const float *x, int64_t m,
+                                 int d_in, const float *w1, const float *b1, const float4 *w2p,
+                                 const float *b2, const float *w3, const float *b3, float *out,
+                                 float *h1, float *h2, uint32_t *m1) {
+  switch (n_out) {
+    case 1: return launch_forward<DIN, 1>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2, m1);
+    case 2: return launch_forward<DIN, 2>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2, m1);
+    case 3: return launch_forward<DIN, 3>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2, m1);
+    default: return launch_forward<DIN, 0>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2, m1);
+  }
+}
+
 RL8_API int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *w1,
                                       const float *b1, const float *w2_packed, const float *b2,
                                       const float *w3, const float *b3, int n_out, float *out,
@@ -410,21 +505,17 @@ RL8_API int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const
   if ((save_h1 == nullptr) != (save_m1 == nullptr)) return RL8_ENULL;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
   if (!aligned16(w2_packed)) return RL8_EALIGN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_forward_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
   const int64_t tiles = (m + kTileRows - 1) / kTileRows;
   static const int cap = env_int("RL8_MLP_GRID_CAP");
   const int max_grid = cap > 0 ? cap : 2 * kCUs;  // two resident workgroups per CU
   const int grid = (int)(tiles < max_grid ? tiles : max_grid);
-  mlp_tower_forward_kernel<<<grid, kBlock, mlp_forward_lds_bytes(), (hipStream_t)stream>>>(
-      x, m, d_in, w1, b1, reinterpret_cast<const float4 *>(w2_packed), b2, w3, b3, n_out, out,
-      save_h1, save_h2, save_m1);
-  return launch_status();
+  const float4 *w2p = reinterpret_cast<const float4 *>(w2_packed);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d_in) {  // common observation widths compiled in; anything else run-time
+    case 1: return dispatch_forward_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2, save_m1);
+    case 5: return dispatch_forward_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2, save_m1);
+    default: return dispatch_forward_nout<0>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2, save_m1);
+  }
 }
 
 RL8_API int64_t rl8_mlp_backward_partial_floats(int d_in, int n_out) {
@@ -432,6 +523,37 @@ RL8_API int64_t rl8_mlp_backward_partial_floats(int d_in, int n_out) {
 }
 
 RL8_API int rl8_mlp_backward_max_rows(void) { return 2 * kCUs; }
+
+template <int DIN, int NOUT>
+static int launch_backward(int grid, hipStream_t s, const float *x, const uint32_t *m1,
+                           const float *h2, const float *dout, int64_t m, int d_in,
+                           const float4 *w2tp, const float *w3, int n_out, float *dz2_out,
+                           float *partials, int stride) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void *>(&mlp_tower_backward_kernel<DIN, NOUT>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  mlp_tower_backward_kernel<DIN, NOUT><<<grid, kBlock, mlp_backward_lds_bytes(), s>>>(
+      x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+  return launch_status();
+}
+
+template <int DIN>
+static int dispatch_backward_nout(int n_out, int grid, hipStream_t s, const float *x,
+                                  const uint32_t *m1, const float *h2, const float *dout,
+                                  int64_t m, int d_in, const float4 *w2tp, const float *w3,
+                                  float *dz2_out, float *partials, int stride) {
+  switch (n_out) {
+    case 1: return launch_backward<DIN, 1>(grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+    case 2: return launch_backward<DIN, 2>(grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+    case 3: return launch_backward<DIN, 3>(grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+    default: return launch_backward<DIN, 0>(grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+  }
+}
 
 RL8_API int rl8_mlp_tower_backward_f32(const float *x, const uint32_t *m1, const float *h2,
                                        const float *dout, int64_t m, int d_in,
@@ -444,18 +566,15 @@ RL8_API int rl8_mlp_tower_backward_f32(const float *x, const uint32_t *m1, const
   if (!aligned16(h2)) return RL8_EALIGN;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
   if (!aligned16(w2t_packed)) return RL8_EALIGN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
   const int64_t tiles = (m + kTileRows - 1) / kTileRows;
   const int grid = (int)(tiles < 2 * kCUs ? tiles : 2 * kCUs);
   *partial_rows_out = grid;
-  mlp_tower_backward_kernel<<<grid, kBlock, mlp_backward_lds_bytes(), (hipStream_t)stream>>>(
-      x, m1, h2, dout, m, d_in, reinterpret_cast<const float4 *>(w2t_packed), w3, n_out, dz2_out,
-      partials, (int)rl8_mlp_backward_partial_floats(d_in, n_out));
-  return launch_status();
+  const float4 *w2tp = reinterpret_cast<const float4 *>(w2t_packed);
+  const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d_in) {
+    case 1: return dispatch_backward_nout<1>(n_out, grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
+    case 5: return dispatch_backward_nout<5>(n_out, grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
+    default: return dispatch_backward_nout<0>(n_out, grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
+  }
 }
