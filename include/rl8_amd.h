@@ -268,6 +268,13 @@ int rl8_mlp_tower_backward_f32(const float *x, const uint32_t *m1, const float *
                                const float *w3, int n_out, float *dz2_out, float *partials,
                                int *partial_rows_out /*host*/, void *stream);
 
+/* Weight gradient of the 256x256 layer: dw2_out [256][256] (+)= dZ2^T h1 over M
+ * rows (fp32 MFMA; per-workgroup partial slabs in `workspace`, summed in a fixed
+ * order).  workspace: rl8_mlp_wgrad_workspace_bytes() bytes, no initialisation. */
+int64_t rl8_mlp_wgrad_workspace_bytes(void);
+int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, float *workspace,
+                      float *dw2_out, int accumulate, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -524,6 +524,116 @@ RL8_API int64_t rl8_mlp_backward_partial_floats(int d_in, int n_out) {
 
 RL8_API int rl8_mlp_backward_max_rows(void) { return 2 * kCUs; }
 
+// Weight gradient of the 256x256 layer: dW2[j][i] = sum_s dZ2[s][j] * h1[s][i],
+// a [256 x M] x [M x 256] product with the reduction over SAMPLES.  Every
+// workgroup owns the whole 256x256 output (8 waves x 8 accumulator tiles) and a
+// slice of the rows; it stages 64-row tiles of dZ2 and h1 through LDS (both
+// tiles are contiguous 64 KiB runs in HBM; the next tile's loads are issued
+// into registers before the matrix loop of the current one), and leaves its
+// partial sum in a workspace slab that a second kernel adds up in slab order
+// (bitwise reproducible; no atomics).
+constexpr int kWgradThreads = 512;
+// 8 waves: wave = (pair of j-tiles, quad of i-tiles)
+constexpr int kStageVecs = kTileRows * kHidden / 4 / kWgradThreads;  // float4 per thread per tile
+
+__global__ __launch_bounds__(kWgradThreads, 2) void mlp_wgrad_kernel(
+    const float *__restrict__ dz2, const float *__restrict__ h1, int64_t m,
+    float *__restrict__ slabs) {
+  extern __shared__ float lds[];
+  float *zt = lds;                           // [64][257] dZ2 tile
+  float *ht = lds + kTileRows * kLdsStride;  // [64][257] h1 tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 31, kh = lane >> 5;
+  const int wj = wave >> 1, wi = wave & 1;   // j-tiles {2wj, 2wj+1}, i-tiles {4wi .. 4wi+3}
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int64_t tiles = (m + kTileRows - 1) / kTileRows;
+  float4 sz[kStageVecs], sh[kStageVecs];
+  auto fetch = [&](int64_t tile) {
+    const int64_t r0 = tile * kTileRows;
+    const int64_t nvec = ((m - r0) < kTileRows ? (m - r0) : kTileRows) * (kHidden / 4);
+    const float4 *pz = reinterpret_cast<const float4 *>(dz2 + r0 * kHidden);
+    const float4 *ph = reinterpret_cast<const float4 *>(h1 + r0 * kHidden);
+#pragma unroll
+    for (int u = 0; u < kStageVecs; ++u) {
+      const int i = tid + u * kWgradThreads;
+      const bool ok = i < nvec;  // rows past the end contribute zeros
+      sz[u] = ok ? pz[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      sh[u] = ok ? ph[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int u = 0; u < kStageVecs; ++u) {
+      const int i = tid + u * kWgradThreads;
+      const int off = (i >> 6) * kLdsStride + ((i & 63) << 2);
+      zt[off + 0] = sz[u].x; zt[off + 1] = sz[u].y; zt[off + 2] = sz[u].z; zt[off + 3] = sz[u].w;
+      ht[off + 0] = sh[u].x; ht[off + 1] = sh[u].y; ht[off + 2] = sh[u].z; ht[off + 3] = sh[u].w;
+    }
+  };
+  if ((int64_t)blockIdx.x < tiles) fetch(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    __syncthreads();  // every wave is done reading the previous tile
+    stage();
+    __syncthreads();
+    if (tile + gridDim.x < tiles) fetch(tile + gridDim.x);  // in flight during the matrix loop
+    const float *za = zt + 64 * wj + jl;        // + s*stride (+32 for the second j-tile)
+    const float *hb = ht + 128 * wi + jl;       // + s*stride (+32*b for i-tile b)
+#pragma unroll 2
+    for (int g = 0; g < kTileRows / 8; ++g) {
+      float a[2][4], b[4][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 8 * g + 4 * kh + e;
+        a[0][e] = za[s * kLdsStride];
+        a[1][e] = za[s * kLdsStride + 32];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t][e] = hb[s * kLdsStride + 32 * t];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ja = 0; ja < 2; ++ja)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[ja][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ja][e], b[t][e], acc[ja][t], 0, 0, 0);
+    }
+  }
+  // Partial slab of this workgroup: slab[j][i].
+  float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;
+#pragma unroll
+  for (int ja = 0; ja < 2; ++ja)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 64 * wj + 32 * ja + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int i = 128 * wi + 32 * t + jl;
+        slab[j * kHidden + i] = acc[ja][t][r];
+      }
+}
+
+// out[idx] (+)= sum over slabs, in slab order.
+__global__ __launch_bounds__(kBlock) void mlp_wgrad_reduce_kernel(const float *__restrict__ slabs,
+                                                                 int rows, float *__restrict__ out,
+                                                                 int accumulate) {
+  const int idx = blockIdx.x * kBlock + threadIdx.x;  // one float4 each
+  if (idx >= kHidden * kHidden / 4) return;
+  const float4 *p = reinterpret_cast<const float4 *>(slabs) + idx;
+  float4 sum = accumulate ? reinterpret_cast<float4 *>(out)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < rows; ++r) {
+    const float4 v = p[(int64_t)r * (kHidden * kHidden / 4)];
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  reinterpret_cast<float4 *>(out)[idx] = sum;
+}
+
 template <int DIN, int NOUT>
 static int launch_backward(int grid, hipStream_t s, const float *x, const uint32_t *m1,
                            const float *h2, const float *dout, int64_t m, int d_in,
@@ -577,4 +687,33 @@ RL8_API int rl8_mlp_tower_backward_f32(const float *x, const uint32_t *m1, const
     case 5: return dispatch_backward_nout<5>(n_out, grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
     default: return dispatch_backward_nout<0>(n_out, grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
   }
+}
+
+RL8_API int64_t rl8_mlp_wgrad_workspace_bytes(void) {
+  return (int64_t)kCUs * kHidden * kHidden * (int64_t)sizeof(float);
+}
+
+RL8_API int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, float *workspace,
+                              float *dw2_out, int accumulate, void *stream) {
+  if (!dz2 || !h1 || !workspace || !dw2_out) return RL8_ENULL;
+  if (m <= 0) return RL8_ESIZE;
+  if (!aligned16(dz2) || !aligned16(h1) || !aligned16(workspace) || !aligned16(dw2_out))
+    return RL8_EALIGN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  const int64_t tiles = (m + kTileRows - 1) / kTileRows;
+  const int grid = (int)(tiles < kCUs ? tiles : kCUs);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds_bytes = sizeof(float) * 2 * kTileRows * kLdsStride;
+  mlp_wgrad_kernel<<<grid, kWgradThreads, lds_bytes, s>>>(dz2, h1, m, workspace);
+  int st = launch_status();
+  if (st != RL8_OK) return st;
+  mlp_wgrad_reduce_kernel<<<kHidden * kHidden / 4 / kBlock, kBlock, 0, s>>>(workspace, grid,
+                                                                          dw2_out, accumulate);
+  return launch_status();
 }

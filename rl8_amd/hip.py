@@ -100,6 +100,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
     "rl8_mlp_backward_max_rows": [],
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_mlp_wgrad_workspace_bytes": [],
+    "rl8_mlp_wgrad_f32": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
 }
 
 
@@ -123,7 +125,9 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = (
-                C.c_int64 if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats") else C.c_int
+                C.c_int64
+                if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes")
+                else C.c_int
             )
         _lib = lib
     return _lib
@@ -682,7 +686,28 @@ def mlp_tower_backward(
         "b2": small[o1 + MLP_HIDDEN : o1 + 2 * MLP_HIDDEN],
         "w3": small[o1 + 2 * MLP_HIDDEN : o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN].view(n_out, MLP_HIDDEN),
         "b3": small[o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN :],
-        # the one large product left: dW2 = dZ2^T h1 (library GEMM)
-        "w2": dz2.t() @ h1,
+        "w2": mlp_wgrad(dz2, h1),
     }
     return grads
+
+
+_wgrad_ws: dict[tuple[int, int], torch.Tensor] = {}
+
+
+def mlp_wgrad(dz2: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
+    """dW2 [256, 256] = dz2^T @ h1 over the rows (fp32 MFMA, deterministic)."""
+    _dense(dz2, torch.float32, "dz2")
+    _dense(h1, torch.float32, "h1")
+    if dz2.shape != h1.shape or dz2.shape[1] != MLP_HIDDEN:
+        raise ValueError("dz2 and h1 must both be [M, 256]")
+    lib = load()
+    key = (dz2.device.index if dz2.device.index is not None else torch.cuda.current_device(), _stream())
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = torch.empty(int(lib.rl8_mlp_wgrad_workspace_bytes()) // 4, dtype=torch.float32, device=dz2.device)
+        _wgrad_ws[key] = ws
+    out = torch.empty(MLP_HIDDEN, MLP_HIDDEN, dtype=torch.float32, device=dz2.device)
+    with _timed("mlp_wgrad", dz2.shape[0]):
+        _check(lib.rl8_mlp_wgrad_f32(_ptr(dz2), _ptr(h1), dz2.shape[0], _ptr(ws), _ptr(out), 0, _stream()),
+               "rl8_mlp_wgrad_f32")
+    return out

@@ -620,3 +620,16 @@ def test_mlp_tower_backward_matches_autograd(m, d_in, n_out):
         scale = float(want.abs().max()) + 1e-12
         err = float((grads[k].double() - want).abs().max()) / scale
         assert err < 2e-5, (k, err)
+
+
+@pytest.mark.parametrize("m", [1, 63, 64, 1000, 16384 + 7, 300_000])
+def test_mlp_wgrad_matches_torch(m):
+    g = torch.Generator(device=DEV).manual_seed(m)
+    dz2 = torch.randn(m, 256, device=DEV, generator=g)
+    h1 = torch.relu(torch.randn(m, 256, device=DEV, generator=g))
+    want = dz2.double().t() @ h1.double()
+    got = hip.mlp_wgrad(dz2, h1)
+    scale = float(want.abs().max()) + 1e-9
+    assert float((got.double() - want).abs().max()) / scale < 5e-6
+    again = hip.mlp_wgrad(dz2, h1)
+    assert torch.equal(got, again)  # fixed summation order
