@@ -50,6 +50,14 @@ class EnvShards:
         active = dist.is_available() and dist.is_initialized()
         self.world_size = dist.get_world_size(group) if active else 1
         self.rank = dist.get_rank(group) if active else 0
+        #: gloo has no device-tensor collectives on ROCm builds: the (tiny)
+        #: messages are staged through the host. Production runs use nccl (RCCL).
+        self._via_host = active and dist.get_backend(group) == "gloo"
+
+    def _staged(self, t: torch.Tensor) -> tuple[torch.Tensor, bool]:
+        if self._via_host and t.is_cuda:
+            return t.cpu(), True
+        return t, False
 
     @property
     def active(self) -> bool:
@@ -63,16 +71,20 @@ class EnvShards:
     def sum_(self, t: torch.Tensor) -> torch.Tensor:
         """In-place SUM all-reduce (moments, loss sums)."""
         if self.active:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            buf, staged = self._staged(t)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            if staged:
+                t.copy_(buf)
         return t
 
     def combine_rollout_stats(self, raw: torch.Tensor) -> torch.Tensor:
         """12 raw stats of this shard -> 12 raw stats of the global rollout."""
         if not self.active:
             return raw
-        flat = torch.empty(self.world_size * raw.numel(), dtype=raw.dtype, device=raw.device)
-        dist.all_gather_into_tensor(flat, raw.contiguous().reshape(-1), group=self.group)
-        gathered = flat.view(self.world_size, raw.numel())
+        src, staged = self._staged(raw.contiguous().reshape(-1))
+        flat = torch.empty(self.world_size * raw.numel(), dtype=raw.dtype, device=src.device)
+        dist.all_gather_into_tensor(flat, src, group=self.group)
+        gathered = flat.view(self.world_size, raw.numel()).to(raw.device)
         out = torch.empty_like(raw)
         out[list(STAT_SUM)] = gathered[:, list(STAT_SUM)].sum(0)
         out[list(STAT_MIN)] = gathered[:, list(STAT_MIN)].min(0).values
@@ -87,7 +99,10 @@ class EnvShards:
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        buf, staged = self._staged(flat)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        if staged:
+            flat = buf.to(flat.device)
         offset = 0
         for g in grads:
             n = g.numel()
@@ -99,4 +114,7 @@ class EnvShards:
         if not self.active:
             return
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=self.group)
+            buf, staged = self._staged(t.data)
+            dist.broadcast(buf, src=src, group=self.group)
+            if staged:
+                t.data.copy_(buf)

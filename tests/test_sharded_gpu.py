@@ -1,0 +1,108 @@
+"""Two ranks sharing ONE MI355X (gloo rendezvous, collectives staged through the
+host) must reproduce the single-process run of the same global problem:
+environments are sharded across ranks, noise is keyed by GLOBAL env index, so the
+rollouts are the same numbers, and moments / loss sums / gradients are combined
+with the collectives of rl8_amd/parallel.py. This is the end-to-end check of the
+N>1 path that one GPU allows; production uses backend "nccl" (RCCL) with one
+rank per GPU."""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+GLOBAL_ENVS, HORIZON, ITERS = 512, 16, 2
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_algo(kind: str, **kw):
+    from rl8_amd import AlgorithmConfig, RecurrentAlgorithmConfig
+    from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv
+
+    torch.manual_seed(1234)
+    if kind == "recurrent":
+        algo = RecurrentAlgorithmConfig(num_envs=GLOBAL_ENVS, horizon=HORIZON, seqs_per_state_reset=4, **kw).build(DiscreteDummyEnv)
+    elif kind == "continuous":
+        algo = AlgorithmConfig(num_envs=GLOBAL_ENVS, horizon=HORIZON, **kw).build(ContinuousDummyEnv)
+    else:
+        algo = AlgorithmConfig(num_envs=GLOBAL_ENVS, horizon=HORIZON, **kw).build(DiscreteDummyEnv)
+    out = []
+    for _ in range(ITERS):
+        c = algo.collect()
+        s = algo.step()
+        out.append((c, s))
+    params = torch.cat([p.detach().reshape(-1) for p in algo.policy.model.parameters()]).cpu()
+    return out, params, algo.local_num_envs
+
+
+def worker(rank: int, world: int, port: int, kind: str, kw: dict, results) -> None:
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out, params, local_envs = run_algo(kind, **kw)
+        assert local_envs == GLOBAL_ENVS // world
+        results.put((rank, out, params))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        results.put((rank, traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def sharded(kind: str, **kw):
+    ctx = mp.get_context("spawn")
+    results = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, kind, kw, results)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [results.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    got.sort(key=lambda t: t[0])
+    for rank, out, _ in got:
+        assert not isinstance(out, str), f"rank {rank} failed:\n{out}"
+    return got
+
+
+@pytest.mark.parametrize("kind,kw", [
+    ("discrete", {}),
+    ("discrete", dict(sgd_minibatch_size=1024, shuffle_minibatches=False, entropy_coeff=1e-2)),
+    ("continuous", {}),
+    ("recurrent", {}),
+])
+def test_two_ranks_match_one_process(kind, kw):
+    single, single_params, _ = run_algo(kind, **kw)
+    got = sharded(kind, **kw)
+    (_, out0, params0), (_, out1, params1) = got
+    # both ranks agree with each other exactly (same reduced numbers, same update)
+    assert torch.equal(params0, params1)
+    for it in range(ITERS):
+        c_single, s_single = single[it]
+        c0, s0 = out0[it]
+        c1, s1 = out1[it]
+        for k in c_single:
+            if k.startswith("profiling"):
+                continue
+            assert c0[k] == c1[k], k
+            assert c0[k] == pytest.approx(c_single[k], rel=1e-6, abs=1e-9), (it, k)
+        for k in s_single:
+            if k.startswith("profiling"):
+                continue
+            assert s0[k] == s1[k], k
+            assert s0[k] == pytest.approx(s_single[k], rel=2e-4, abs=2e-6), (it, k)
+    torch.testing.assert_close(params0, single_params, rtol=2e-3, atol=2e-4)
