@@ -96,6 +96,8 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--num-envs", type=int, default=1 << 20, help="environments PER GPU")
     p.add_argument("--horizon", type=int, default=32)
     p.add_argument("--env", default="discrete", choices=["discrete", "continuous", "cartpole"])
+    p.add_argument("--distribution", default="default", choices=["default", "squashed"])
+    p.add_argument("--recurrent", action="store_true", help="RecurrentAlgorithmConfig (LSTM, seq_len 4)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
@@ -144,7 +146,8 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from rl8_amd import AlgorithmConfig, hip
+    from rl8_amd import AlgorithmConfig, RecurrentAlgorithmConfig, hip
+    from rl8_amd.distributions import SquashedNormal
     from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv
 
     if args.env == "cartpole":
@@ -154,7 +157,9 @@ def main() -> None:
 
     torch.manual_seed(0)
     global_envs = args.num_envs * world
-    algo = AlgorithmConfig(num_envs=global_envs, horizon=args.horizon).build(env_cls)
+    config_cls = RecurrentAlgorithmConfig if args.recurrent else AlgorithmConfig
+    extra = {"distribution_cls": SquashedNormal} if args.distribution == "squashed" else {}
+    algo = config_cls(num_envs=global_envs, horizon=args.horizon, **extra).build(env_cls)
     horizon = algo.hparams.horizon
 
     def barrier() -> None:
@@ -218,6 +223,7 @@ def main() -> None:
 
     if rank == 0:
         hbm_dominant = "ppo_loss_categorical" if "ppo_loss_categorical" in kernels else "ppo_loss_normal"
+        variant = ("Recurrent" if args.recurrent else "") + (" SquashedNormal" if args.distribution == "squashed" else "")
         dom = kernels[hbm_dominant]
         # The kernel the timed region spends most of its time in.
         dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
@@ -257,7 +263,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic (Philox-reset DiscreteDummyEnv states, random-init default MLP)",
             "config": {
-                "workload": f"{env_cls.__name__} collect()+step(), num_envs={args.num_envs} per GPU"
+                "workload": f"{env_cls.__name__}{variant} collect()+step(), num_envs={args.num_envs} per GPU"
                             f" ({global_envs} total), horizon={horizon}, AlgorithmConfig defaults"
                             " (4 SGD iters, one full-buffer minibatch, Adam 1e-3)",
                 "num_envs_per_gpu": args.num_envs,

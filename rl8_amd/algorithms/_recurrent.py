@@ -39,6 +39,12 @@ from ..specs import Composite
 from ..tensordict import TensorDict
 from ._feedforward import Algorithm, AlgorithmConfig, _collect_stats_from_raw
 
+#: Rows (sequences x seq_len) pushed through the LSTM per forward/backward pass.
+#: MIOpen's RNN workspace holds ~7 x hidden floats per (step, sequence) and is
+#: indexed with 32-bit offsets: 2^21 rows of a 256-wide LSTM faulted on gfx950,
+#: 2^18 rows keep it under 2^29 elements.
+RECURRENT_MAX_ROWS_PER_PASS = 1 << 18
+
 
 @dataclass
 class RecurrentAlgorithmConfig(AlgorithmConfig):
@@ -258,7 +264,7 @@ class RecurrentAlgorithm(Algorithm):
                 "RecurrentAlgorithm trains with the built-in distributions"
                 " (Categorical, Normal, SquashedNormal)."
             )
-        seqs_per_pass = max(1, self.max_rows_per_pass // L)
+        seqs_per_pass = max(1, min(self.max_rows_per_pass, RECURRENT_MAX_ROWS_PER_PASS) // L)
         total_sums: None | torch.Tensor = None
         scale = None
         if hp.enable_amp:
