@@ -246,24 +246,23 @@ int rl8_mlp_pack_w2_f32(const float *w2 /*[256][256]*/, float *w2_packed /*[6553
                         int transposed, void *stream);
 
 /* out [M][n_out] = tower(x [M][d_in]).  For training, save_h1 / save_h2
- * ([M][256]) receive the post-ReLU activations and save_m1 ([M][8] uint32) the
- * ReLU mask of h1, one bit per unit (bit i%32 of word i/32); all three NULL for
- * inference. */
+ * ([M][256] each, 16-byte aligned) receive the post-ReLU activations; both NULL
+ * for inference. */
 int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *w1,
                               const float *b1, const float *w2_packed, const float *b2,
                               const float *w3, const float *b3, int n_out, float *out,
-                              float *save_h1, float *save_h2, uint32_t *save_m1, void *stream);
+                              float *save_h1, float *save_h2, void *stream);
 
 /* Backward of one tower ("dgrad" half): given dOut [M][n_out] and the saved
- * activations (h2 and the h1 mask m1), writes dZ2 [M][256] (the host forms dW2 = dZ2^T h1 with a library
- * GEMM) and `*partial_rows_out` rows (<= rl8_mlp_backward_max_rows()) of
+ * activations h1 / h2, writes dZ2 [M][256] (input of rl8_mlp_wgrad_f32, which
+ * forms dW2 = dZ2^T h1) and `*partial_rows_out` rows (<= rl8_mlp_backward_max_rows()) of
  * rl8_mlp_backward_partial_floats(d_in, n_out) floats each into `partials`:
  *   [dW1 (256*d_in) | db1 (256) | db2 (256) | dW3 (n_out*256) | db3 (n_out)]
  * whose column sums are the parameter gradients.  w2t_packed is
  * rl8_mlp_pack_w2_f32(..., transposed = 1).  partial_rows_out is a host pointer. */
 int64_t rl8_mlp_backward_partial_floats(int d_in, int n_out);
 int rl8_mlp_backward_max_rows(void);
-int rl8_mlp_tower_backward_f32(const float *x, const uint32_t *m1, const float *h2,
+int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
                                const float *dout, int64_t m, int d_in, const float *w2t_packed,
                                const float *w3, int n_out, float *dz2_out, float *partials,
                                int *partial_rows_out /*host*/, void *stream);

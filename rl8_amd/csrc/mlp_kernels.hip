@@ -36,66 +36,106 @@ constexpr int kMaxIn = 16;
 constexpr int kMaxOut = 8;
 constexpr int kGroups = kHidden / 8;  // k-groups of 8
 
-// w2 [256 out][256 in] row-major -> fragment order:
-// packed[((n*32 + g)*64 + l)*4 + e] = w2[32n + (l&31)][8g + 4(l>>5) + e]
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptors (gfx9 dword3 = 32-bit data format): loads / stores
+// through them take their row offset from an SGPR, so the address arithmetic
+// runs on the scalar unit, and anything past `bytes` is dropped by the hardware
+// -- which is the row guard of a partial last tile.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_rsrc(const void *base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buffer_store_f32(float v, __amdgpu_buffer_rsrc_t r, int voffset,
+                                                 int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voffset, soffset, 0);
+}
+__device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 0));
+}
+// (Only the 32-bit forms: this toolchain lowers the b64 / b128 load builtins to
+// a single dword.)
+
+// w2 [256 out][256 in] row-major -> fragment order, one 256-byte run per
+// (N-tile n, k-group g, element e) so that a wave's B operand for one MFMA is a
+// single coalesced dword load:
+// packed[((n*32 + g)*4 + e)*64 + l] = w2[32n + (l&31)][8g + 4(l>>5) + e]
 __global__ __launch_bounds__(kBlock) void mlp_pack_w2_kernel(const float *__restrict__ w2,
                                                              float *__restrict__ packed) {
-  const int idx = blockIdx.x * kBlock + threadIdx.x;  // one float4 each
-  if (idx >= kHidden * kHidden / 4) return;
-  const int l = idx & 63, g = (idx >> 6) & 31, n = idx >> 11;
-  const int j = 32 * n + (l & 31), k = 8 * g + 4 * (l >> 5);
-  const float4 v = *reinterpret_cast<const float4 *>(w2 + j * kHidden + k);
-  reinterpret_cast<float4 *>(packed)[idx] = v;
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= kHidden * kHidden) return;
+  const int l = idx & 63, e = (idx >> 6) & 3, g = (idx >> 8) & 31, n = idx >> 13;
+  packed[idx] = w2[(32 * n + (l & 31)) * kHidden + 8 * g + 4 * (l >> 5) + e];
 }
 
 // Transposed packing for the backward data-gradient GEMM dH1 = dZ2 x W2:
-// B[k = j][n = i] = w2[j][i]:  packedT[((n*32 + g)*64 + l)*4 + e] = w2[8g + 4(l>>5) + e][32n + (l&31)]
+// B[k = j][n = i] = w2[j][i]:  packedT[((n*32 + g)*4 + e)*64 + l] = w2[8g + 4(l>>5) + e][32n + (l&31)]
 __global__ __launch_bounds__(kBlock) void mlp_pack_w2t_kernel(const float *__restrict__ w2,
                                                               float *__restrict__ packed) {
   const int idx = blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= kHidden * kHidden / 4) return;
-  const int l = idx & 63, g = (idx >> 6) & 31, n = idx >> 11;
-  const int i = 32 * n + (l & 31), j0 = 8 * g + 4 * (l >> 5);
-  float4 v;
-  v.x = w2[(j0 + 0) * kHidden + i];
-  v.y = w2[(j0 + 1) * kHidden + i];
-  v.z = w2[(j0 + 2) * kHidden + i];
-  v.w = w2[(j0 + 3) * kHidden + i];
-  reinterpret_cast<float4 *>(packed)[idx] = v;
+  if (idx >= kHidden * kHidden) return;
+  const int l = idx & 63, e = (idx >> 6) & 3, g = (idx >> 8) & 31, n = idx >> 13;
+  packed[idx] = w2[(8 * g + 4 * (l >> 5) + e) * kHidden + 32 * n + (l & 31)];
 }
 
-// One 64-row x 256-col GEMM tile on the matrix cores:
-//   acc[m][n] (+)= A_tile[32m + i][k] * Bp[(N-tile 2*wave + n)][k]
-// A_tile: LDS [64][257]; Bp: fragment-packed [8][32][64] float4.  Wave `wave`
-// produces output columns [64*wave, 64*wave + 64).
+// COST MODEL (measured, tools/probes/mfma_valu_probe.hip): on gfx950 an fp32 MFMA
+// and ordinary VALU instructions do NOT overlap -- not from the same wave and not
+// from another wave of the same SIMD.  A stream of v_mfma_f32_32x32x2_f32 runs at
+// 155 TFLOP/s (64 cycles each at 2.37 GHz); every VALU instruction in between
+// adds ~2.2 ns (~5 cycles) plus ~5 ns per MFMA->VALU->MFMA switch.  LDS and
+// memory instructions do overlap.  So a kernel's time is  MFMA + sum(VALU), and
+// these kernels are written to minimise the VALU instruction count per tile:
+// addresses come from SGPRs / immediates (buffer loads, fully unrolled LDS
+// offsets), pairs go through v_pk_fma_f32, and nothing is recomputed on the VALU
+// that a memory instruction can fetch.
 //
+// One 64-row x 256-col GEMM tile on the matrix cores:
+//   acc[m][n] = A_tile[32m + i][k] * Bp[(N-tile 2*wave + n)][k]
+// A_tile: LDS [64][257]; Bp: fragment-packed [8][32][4][64] floats behind a buffer
+// descriptor.  Wave `wave` produces output columns [64*wave, 64*wave + 64).
 // Software-pipelined by hand, two k-groups per trip with two named register
 // sets: the B fragments (L2) and A fragments (LDS) of group g+1 are issued
-// before the 16 MFMAs of group g, so every load has ~1000 cycles to land and the
-// compiler's counted waits leave the younger loads in flight.
+// before the 16 MFMAs of group g.
 struct Frag {
-  float4 b0, b1;
+  float b0[4], b1[4];
   float a0[4], a1[4];
 };
 
-__device__ __forceinline__ void load_frag(Frag &f, const float4 *__restrict__ b0p,
-                                          const float4 *__restrict__ b1p,
-                                          const float *__restrict__ a0p,
-                                          const float *__restrict__ a1p, int g) {
-  f.b0 = b0p[g * kWave];
-  f.b1 = b1p[g * kWave];
+__device__ __forceinline__ void load_frag(Frag &f, __amdgpu_buffer_rsrc_t bp, int bvoff,
+                                          const float *__restrict__ a0p, int g) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
+    f.b0[e] = buffer_load_f32(bp, bvoff + e * (kWave * 4), g * (kWave * 16));
+    f.b1[e] = buffer_load_f32(bp, bvoff + kGroups * kWave * 16 + e * (kWave * 4), g * (kWave * 16));
     f.a0[e] = a0p[8 * g + e];
-    f.a1[e] = a1p[8 * g + e];
+    f.a1[e] = a0p[32 * kLdsStride + 8 * g + e];
   }
 }
 
+// max(v, 0) as exactly one v_max_f32 (fmaxf() costs a second, canonicalising,
+// v_max on values the compiler cannot prove quiet; NaN -> 0 either way).
+__device__ __forceinline__ float relu1(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
+// FIRST: the accumulators start from the inline constant 0 (no v_mov per
+// accumulator register).
+template <bool FIRST>
 __device__ __forceinline__ void mma_frag(const Frag &f, f32x16 (&acc)[2][2]) {
-  const float c0e[4] = {f.b0.x, f.b0.y, f.b0.z, f.b0.w};
-  const float c1e[4] = {f.b1.x, f.b1.y, f.b1.z, f.b1.w};
+  const float(&c0e)[4] = f.b0;
+  const float(&c1e)[4] = f.b1;
+  if constexpr (FIRST) {
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[0], c0e[0], zero, 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[0], c1e[0], zero, 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[0], c0e[0], zero, 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[0], c1e[0], zero, 0, 0, 0);
+  }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = FIRST ? 1 : 0; e < 4; ++e) {
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], c0e[e], acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], c1e[e], acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[e], c0e[e], acc[1][0], 0, 0, 0);
@@ -103,84 +143,80 @@ __device__ __forceinline__ void mma_frag(const Frag &f, f32x16 (&acc)[2][2]) {
   }
 }
 
-template <int VARIANT>
 __device__ __forceinline__ void tile_gemm_64x256x256(const float *__restrict__ a_tile,
-                                                     const float4 *__restrict__ bp, int wave,
-                                                     int lane, f32x16 (&acc)[2][2]) {
+                                                     __amdgpu_buffer_rsrc_t bp, int wave, int lane,
+                                                     f32x16 (&acc)[2][2]) {
   const int i = lane & 31, hh = lane >> 5;
-  const float4 *b0p = bp + ((2 * wave + 0) * kGroups) * kWave + lane;
-  const float4 *b1p = bp + ((2 * wave + 1) * kGroups) * kWave + lane;
-  const float *a0p = a_tile + (0 * 32 + i) * kLdsStride + 4 * hh;
-  const float *a1p = a_tile + (1 * 32 + i) * kLdsStride + 4 * hh;
-  if constexpr (VARIANT == 0) {
-    Frag fa, fb;
-    load_frag(fa, b0p, b1p, a0p, a1p, 0);
+  const int bvoff = (2 * wave) * kGroups * kWave * 16 + lane * 4;
+  const float *a0p = a_tile + i * kLdsStride + 4 * hh;
+  Frag fa, fb;
+  load_frag(fa, bp, bvoff, a0p, 0);
+  load_frag(fb, bp, bvoff, a0p, 1);
+  mma_frag<true>(fa, acc);
+  load_frag(fa, bp, bvoff, a0p, 2);
+  mma_frag<false>(fb, acc);
 #pragma unroll 1
-    for (int g = 0; g < kGroups; g += 2) {
-      load_frag(fb, b0p, b1p, a0p, a1p, g + 1);
-      mma_frag(fa, acc);
-      if (g + 2 < kGroups) load_frag(fa, b0p, b1p, a0p, a1p, g + 2);
-      mma_frag(fb, acc);
-    }
-  } else {
-    // three register sets, fragments two k-groups ahead
-    Frag f0, f1, f2;
-    load_frag(f0, b0p, b1p, a0p, a1p, 0);
-    load_frag(f1, b0p, b1p, a0p, a1p, 1);
-#pragma unroll 1
-    for (int g = 0; g < kGroups - 2; g += 3) {
-      load_frag(f2, b0p, b1p, a0p, a1p, g + 2);
-      mma_frag(f0, acc);
-      load_frag(f0, b0p, b1p, a0p, a1p, g + 3 < kGroups ? g + 3 : kGroups - 1);
-      mma_frag(f1, acc);
-      load_frag(f1, b0p, b1p, a0p, a1p, g + 4 < kGroups ? g + 4 : kGroups - 1);
-      mma_frag(f2, acc);
-    }
-    // kGroups = 32 = 3*10 + 2: groups 30, 31 remain in f0, f1
-    mma_frag(f0, acc);
-    mma_frag(f1, acc);
+  for (int g = 2; g < kGroups; g += 2) {
+    load_frag(fb, bp, bvoff, a0p, g + 1);
+    mma_frag<false>(fa, acc);
+    if (g + 2 < kGroups) load_frag(fa, bp, bvoff, a0p, g + 2);
+    mma_frag<false>(fb, acc);
   }
 }
 
-// Forward of one tower over m rows.  save_h1 / save_h2 (may be NULL): [m][256].
-// LDS: ONE [64][257] tile (h1, then h2 in place once the MFMA loop has consumed
-// h1) + the observation tile + the head weights = 78 KB => two workgroups per
-// CU, so one workgroup's VALU phases overlap the other's matrix phase.
+constexpr int pad_out(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
+
+// Forward of one tower over m rows.  SAVE: also store h1 / h2 ([m][256] each) for
+// the backward kernels.  LDS: ONE [64][257] tile (h1, then h2 in place once the
+// matrix loop has consumed h1) + the observation tile + the head weights = 78 KB
+// => two workgroups per CU (the second hides the first's barrier / memory waits;
+// see the cost model above for what it cannot hide).
 // DIN / NOUT: compile-time input / output widths (0 = run-time, up to
-// kMaxIn / kMaxOut): the VALU phases are short only when fully unrolled and
-// branch-free (measured: a run-time-bounded head loop cost more than the
-// whole matrix phase).
-template <int DIN, int NOUT>
+// kMaxIn / kMaxOut, zero-padded so the loops stay branch-free).
+template <int DIN, int NOUT, bool SAVE>
 __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
     const float *__restrict__ x, int64_t m, int d_in_rt, const float *__restrict__ w1,
     const float *__restrict__ b1, const float4 *__restrict__ w2p, const float *__restrict__ b2,
     const float *__restrict__ w3, const float *__restrict__ b3, int n_out_rt,
-    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2,
-    uint32_t *__restrict__ save_m1) {
+    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2) {
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
-  constexpr int kOut = NOUT > 0 ? NOUT : kMaxOut;
+  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
+  typedef float outvec __attribute__((ext_vector_type(kOut)));
+  // Full unrolling turns every LDS offset into an immediate, but with wide
+  // inputs / heads it also hoists hundreds of LDS reads into registers.
+  constexpr int kLayer1Unroll = kIn <= 2 ? kTileRows : 8;
+  constexpr int kHeadUnroll = kOut <= 2 ? 64 : 8;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
   const int n_out = NOUT > 0 ? NOUT : n_out_rt;
   extern __shared__ float lds[];
-  float *ht = lds;                                  // [64][257]: h1, later h2
-  float *xs = ht + kTileRows * kLdsStride;          // [64][kMaxIn]
-  float *w3s = xs + kTileRows * kMaxIn;             // [kMaxOut][256], zero-padded rows
+  // Small arrays first: their (uniform) addresses then fit the 16-bit immediate
+  // offset of the LDS instructions and need no address register.
+  float *xs = lds;                                  // [64][kIn], zero-padded columns
+  float *w3s = xs + kTileRows * kMaxIn;             // [256][kOut]: head weights, unit-major
+  float *ht = w3s + kMaxOut * kHidden;              // [64][257]: h1, later h2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5;
 
-  // Per-thread constants: column `tid` of layer 1 (zero-padded), head weights
-  // to LDS (rows >= n_out zeroed so the run-time-width head needs no branches).
+  // Per-thread constants: column `tid` of layer 1 (zero-padded); head weights to
+  // LDS as [unit][output] so one wide LDS read feeds one packed fma.
   float w1r[kIn];
 #pragma unroll
   for (int i = 0; i < kIn; ++i) w1r[i] = i < d_in ? w1[tid * d_in + i] : 0.0f;
   const float b1r = b1[tid];
-  for (int idx = tid; idx < kOut * kHidden; idx += kBlock)
-    w3s[idx] = idx < n_out * kHidden ? w3[idx] : 0.0f;
+  for (int idx = tid; idx < kOut * kHidden; idx += kBlock) {
+    const int j = idx / kOut, q = idx - j * kOut;
+    w3s[idx] = q < n_out ? w3[q * kHidden + j] : 0.0f;
+  }
   float b2r[2];
   b2r[0] = b2[64 * wave + (lane & 31)];
   b2r[1] = b2[64 * wave + 32 + (lane & 31)];
-  float b3r[kOut];
+  outvec b3r;
 #pragma unroll
   for (int q = 0; q < kOut; ++q) b3r[q] = q < n_out ? b3[q] : 0.0f;
+  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2p, kHidden * kHidden * 4);
+  if constexpr (DIN == 0) {
+    for (int idx = tid; idx < kTileRows * kMaxIn; idx += kBlock) xs[idx] = 0.0f;
+  }
 
   const int64_t tiles = (m + kTileRows - 1) / kTileRows;
   // Observation tile: element e of the [64][d_in] tile is owned by thread e
@@ -202,81 +238,81 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t r0 = tile * kTileRows;
     const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
+    // Stores of this tile's h1 / h2 rows: descriptor based at the tile, sized to
+    // its valid rows (stores past the end of a partial tile are dropped).
+    const __amdgpu_buffer_rsrc_t h1rsrc = buffer_rsrc(SAVE ? save_h1 + r0 * kHidden : nullptr, rows * kHidden * 4);
+    const __amdgpu_buffer_rsrc_t h2rsrc = buffer_rsrc(SAVE ? save_h2 + r0 * kHidden : nullptr, rows * kHidden * 4);
     __syncthreads();  // previous tile's readers of xs / ht are done
 #pragma unroll
     for (int u = 0; u < kXPerThread; ++u) {
       const int idx = tid + u * kBlock;
       if (idx < kTileRows * d_in) {
         const int s = DIN > 0 ? idx / kIn : idx / d_in;
-        xs[s * kMaxIn + (idx - s * d_in)] = xreg[u];
+        xs[s * kIn + (idx - s * d_in)] = xreg[u];
       }
     }
     __syncthreads();
-    // Layer 1 (VALU): thread = output column, loop over the tile's rows.
-#pragma unroll 8
+    // Layer 1 (VALU): thread = output column; per row d_in fmas + one max, the
+    // observation from a broadcast LDS read, offsets all immediates (fully
+    // unrolled for the narrow inputs; wider ones would hoist 64 x d_in LDS reads
+    // into registers and spill).
+#pragma unroll kLayer1Unroll
     for (int s = 0; s < kTileRows; ++s) {
       float v = b1r;
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) v += xs[s * kMaxIn + i] * w1r[i];
-      v = v > 0.0f ? v : 0.0f;
+      for (int i = 0; i < kIn; ++i) v = __builtin_fmaf(xs[s * kIn + i], w1r[i], v);
+      v = relu1(v);
       ht[s * kLdsStride + tid] = v;
-      if (save_h1 && s < rows) {
-        save_h1[(r0 + s) * kHidden + tid] = v;
-        // ReLU mask of h1, one bit per unit: word (row, tid/32) -- what the
-        // backward epilogue needs instead of re-reading 1 KiB of h1 per row.
-        const unsigned long long ballot = __ballot(v > 0.0f);
-        if ((lane & 31) == 0)
-          save_m1[(r0 + s) * (kHidden / 32) + (tid >> 5)] = (uint32_t)(ballot >> (lane & 32));
-      }
+      if constexpr (SAVE) buffer_store_f32(v, h1rsrc, tid * 4, s * (kHidden * 4));
     }
     __syncthreads();
     if (tile + gridDim.x < tiles) fetch_x(tile + gridDim.x);  // lands during the matrix phase
     // Layer 2 (MFMA).
     f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    tile_gemm_64x256x256<0>(ht, w2p, wave, lane, acc);
+    tile_gemm_64x256x256(ht, w2rsrc, wave, lane, acc);
     __syncthreads();  // every wave has read all of h1: the tile may be overwritten
-    // bias + ReLU, accumulators -> h2 (in place of h1).
+    // bias (packed adds over register pairs) + ReLU, accumulators -> h2 (in place
+    // of h1) and, when saving, straight to HBM (each store covers two 128-byte
+    // row segments).
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int s = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        for (int r = 0; r < 16; r += 2) {
           const int j = 64 * wave + 32 * nt + (lane & 31);
-          float v = acc[mt][nt][r] + b2r[nt];
-          v = v > 0.0f ? v : 0.0f;
-          ht[s * kLdsStride + j] = v;
+          const f32x2 pre = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{b2r[nt], b2r[nt]};
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int sr = 32 * mt + ((r + u) & 3) + 8 * ((r + u) >> 2);  // + 4*hh
+            const float v = relu1(pre[u]);
+            ht[(sr + 4 * hh) * kLdsStride + j] = v;
+            if constexpr (SAVE)
+              buffer_store_f32(v, h2rsrc, (4 * hh * kHidden + j) * 4, sr * (kHidden * 4));
+          }
         }
     __syncthreads();
-    if (save_h2) {
-      for (int idx = tid; idx < rows * kHidden; idx += kBlock) {
-        const int s = idx >> 8, j = idx & 255;
-        save_h2[(r0 + s) * kHidden + j] = ht[s * kLdsStride + j];
-      }
-    }
-    // Head (VALU): 4 lanes per row (a quarter of the 256 inputs each, rotated by
-    // 8 per quarter to spread LDS banks), fully unrolled and branch-free, then
-    // combined with two lane shuffles.
+    // Head (VALU): 4 lanes per row; lane (a, q4) of wave w owns row 4a + w and the
+    // units j = q4 (mod 4) -- LDS bank 4a + q4 + const, so the 64 lanes hit 64
+    // different banks with immediate offsets only -- one packed fma per unit for
+    // a pair of outputs, then two lane shuffles.
     {
-      const int s = 16 * wave + (lane >> 2), q4 = lane & 3;
-      float o[kOut];
+      const int s = 4 * (lane >> 2) + wave, q4 = lane & 3;
+      outvec o;
 #pragma unroll
       for (int q = 0; q < kOut; ++q) o[q] = 0.0f;
-      const float *row = ht + s * kLdsStride + 64 * q4;
-      const float *wq = w3s + 64 * q4;
-#pragma unroll 16
+      const float *row = ht + s * kLdsStride + q4;
+      const outvec *wq = reinterpret_cast<const outvec *>(w3s) + q4;
+#pragma unroll kHeadUnroll
       for (int jj = 0; jj < 64; ++jj) {
-        const int j = (jj + 8 * q4) & 63;
-        const float hv = row[j];
+        const float hv = row[4 * jj];
+        outvec hvv;
 #pragma unroll
-        for (int q = 0; q < kOut; ++q) o[q] += hv * wq[q * kHidden + j];
+        for (int q = 0; q < kOut; ++q) hvv[q] = hv;
+        if constexpr (kOut == 1)
+          o[0] = __builtin_fmaf(hv, wq[4 * jj][0], o[0]);
+        else
+          o = __builtin_elementwise_fma(hvv, wq[4 * jj], o);
       }
 #pragma unroll
       for (int q = 0; q < kOut; ++q) {
@@ -290,62 +326,74 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
 }
 
 // Backward of one tower over m rows, data-gradient half ("dgrad"):
-//   dZ2 = (dOut x W3) * (h2 > 0)            VALU, lane = column
+//   dZ2 = (dOut x W3) * (h2 > 0)            VALU, thread = column, two rows per packed op
 //   dH1 = dZ2 x W2                          MFMA (W2 packed transposed)
 //   dZ1 = dH1 * (h1 > 0)                    accumulator epilogue
 // and every small parameter gradient on the way:
 //   dW3 = dOut^T h2, db3 = sum dOut, db2 = sum dZ2, dW1 = dZ1^T x, db1 = sum dZ1.
 // dZ2 is also stored ([m][256]) for the one remaining large product,
-// dW2 = dZ2^T h1, which the host issues as a plain library GEMM.
+// dW2 = dZ2^T h1 (rl8_mlp_wgrad_f32).  h1 arrives in accumulator layout by
+// buffer loads issued ahead of the matrix loop (its sign is the ReLU mask).
 // Small gradients leave as one row of per-workgroup partials,
 //   [dW1 (256*d_in) | db1 (256) | db2 (256) | dW3 (n_out*256) | db3 (n_out)],
 // summed on the host side in a fixed order (bitwise reproducible, no atomics).
 template <int DIN, int NOUT>
-__global__ __launch_bounds__(kBlock, DIN == 0 ? 1 : 2) void mlp_tower_backward_kernel(
-    const float *__restrict__ x, const uint32_t *__restrict__ m1, const float *__restrict__ h2,
+__global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_tower_backward_kernel(
+    const float *__restrict__ x, const float *__restrict__ h1, const float *__restrict__ h2,
     const float *__restrict__ dout, int64_t m, int d_in_rt, const float4 *__restrict__ w2tp,
     const float *__restrict__ w3, int n_out_rt, float *__restrict__ dz2_out,
     float *__restrict__ partials, int partial_stride) {
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
-  constexpr int kOut = NOUT > 0 ? NOUT : kMaxOut;
+  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
   const int n_out = NOUT > 0 ? NOUT : n_out_rt;
   extern __shared__ float lds[];
-  float *zt = lds;                                  // [64][257]: h2 -> dZ2
-  float *xs = zt + kTileRows * kLdsStride;          // [64][kMaxIn], zero-padded columns
-  float *ds = xs + kTileRows * kMaxIn;              // [64][kMaxOut] dOut tile, zero-padded
-  uint32_t *ms = reinterpret_cast<uint32_t *>(ds + kTileRows * kMaxOut);  // [64][8] h1 mask
+  // Small arrays first (uniform addresses within the 16-bit LDS immediate).
+  float *xs = lds;                                  // [64][kIn], zero-padded columns
+  float *ds = xs + kTileRows * kMaxIn;              // [kOut][64] dOut tile (output-major), zero-padded
+  float *zt = ds + kTileRows * kMaxOut;             // [64][257]: h2 -> dZ2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5;
 
   float w3r[kOut];  // column `tid` of W3, zero-padded
 #pragma unroll
   for (int q = 0; q < kOut; ++q) w3r[q] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
-  // running sums owned by this thread
-  float dw3[kOut], db3[kOut], db2 = 0.0f;  // column tid (db3 replicated; thread 0 writes)
+  // Running sums owned by this thread; pairs = (even rows, odd rows) or
+  // (column nt = 0, column nt = 1), folded once at the end.
+  f32x2 dw3[kOut], db2 = {0.0f, 0.0f};
 #pragma unroll
-  for (int q = 0; q < kOut; ++q) dw3[q] = db3[q] = 0.0f;
-  float dw1[2][kIn], db1[2] = {0.0f, 0.0f};  // columns 64*wave + 32*nt + (lane&31), this half's rows
+  for (int q = 0; q < kOut; ++q) dw3[q] = f32x2{0.0f, 0.0f};
+  f32x2 dw1[kIn], db1 = {0.0f, 0.0f};  // columns 64*wave + 32*nt + (lane&31), this half's rows
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int c = 0; c < kIn; ++c) dw1[nt][c] = 0.0f;
+  for (int c = 0; c < kIn; ++c) dw1[c] = f32x2{0.0f, 0.0f};
+  constexpr int kDoutPerThread = (kTileRows * kOut + kBlock - 1) / kBlock;
+  float db3 = 0.0f;  // output tid % kOut, this thread's share of the rows
+  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2tp, kHidden * kHidden * 4);
+  if constexpr (DIN == 0) {
+    for (int idx = tid; idx < kTileRows * kMaxIn; idx += kBlock) xs[idx] = 0.0f;
+  }
 
   const int64_t tiles = (m + kTileRows - 1) / kTileRows;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t r0 = tile * kTileRows;
     const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
+    const __amdgpu_buffer_rsrc_t h1rsrc = buffer_rsrc(h1 + r0 * kHidden, rows * kHidden * 4);
+    const __amdgpu_buffer_rsrc_t dzrsrc = buffer_rsrc(dz2_out + r0 * kHidden, rows * kHidden * 4);
     __syncthreads();
-    for (int idx = tid; idx < kTileRows * kMaxIn; idx += kBlock) {
-      const int s = idx / kMaxIn, c = idx - s * kMaxIn;
-      xs[idx] = (s < rows && c < d_in) ? x[(r0 + s) * d_in + c] : 0.0f;
+    for (int idx = tid; idx < kTileRows * d_in; idx += kBlock) {
+      const int s = idx / d_in, c = idx - s * d_in;
+      xs[s * kIn + c] = s < rows ? x[r0 * d_in + idx] : 0.0f;
     }
-    for (int idx = tid; idx < kTileRows * kMaxOut; idx += kBlock) {
-      const int s = idx / kMaxOut, q = idx - s * kMaxOut;
-      ds[idx] = (s < rows && q < n_out) ? dout[(r0 + s) * n_out + q] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < kDoutPerThread; ++u) {
+      const int idx = tid + u * kBlock;
+      if (idx < kTileRows * kOut) {
+        const int s = idx / kOut, q = idx - s * kOut;
+        const float d = (s < rows && q < n_out) ? dout[(r0 + s) * n_out + q] : 0.0f;
+        ds[q * kTileRows + s] = d;  // rows (s, s+1) adjacent: one 8-byte read per packed operand
+        db3 += d;
+      }
     }
-    for (int idx = tid; idx < kTileRows * (kHidden / 32); idx += kBlock)
-      ms[idx] = idx < rows * (kHidden / 32) ? m1[r0 * (kHidden / 32) + idx] : 0u;
     {
       // h2 tile: the tile's rows are one contiguous run of rows*256 floats in
       // HBM -> 16-byte loads, four in flight per lane, scattered into the padded
@@ -368,50 +416,60 @@ __global__ __launch_bounds__(kBlock, DIN == 0 ? 1 : 2) void mlp_tower_backward_k
       }
     }
     __syncthreads();
-    // Phase 1 (VALU, thread = column j): dZ2 and the head gradients.
-#pragma unroll 8
-    for (int s = 0; s < kTileRows; ++s) {
-      const float hv = zt[s * kLdsStride + tid];
-      float g = 0.0f;
+    // Phase 1 (VALU, thread = column j, two rows per step): dZ2 and the head
+    // gradients.
+#pragma unroll
+    for (int s = 0; s < kTileRows; s += 2) {
+      const f32x2 hv = {zt[s * kLdsStride + tid], zt[(s + 1) * kLdsStride + tid]};
+      f32x2 g = {0.0f, 0.0f};
 #pragma unroll
       for (int q = 0; q < kOut; ++q) {
-        const float d = ds[s * kMaxOut + q];
-        g += d * w3r[q];
-        dw3[q] += d * hv;
-        db3[q] += d;
+        const f32x2 d = *reinterpret_cast<const f32x2 *>(ds + q * kTileRows + s);
+        g = __builtin_elementwise_fma(d, f32x2{w3r[q], w3r[q]}, g);
+        dw3[q] = __builtin_elementwise_fma(d, hv, dw3[q]);
       }
-      const float dz = hv > 0.0f ? g : 0.0f;
+      const f32x2 dz = {hv.x > 0.0f ? g.x : 0.0f, hv.y > 0.0f ? g.y : 0.0f};
       db2 += dz;
-      zt[s * kLdsStride + tid] = dz;
-      if (s < rows) dz2_out[(r0 + s) * kHidden + tid] = dz;
+      zt[s * kLdsStride + tid] = dz.x;
+      zt[(s + 1) * kLdsStride + tid] = dz.y;
+      buffer_store_f32(dz.x, dzrsrc, tid * 4, s * (kHidden * 4));
+      buffer_store_f32(dz.y, dzrsrc, tid * 4, (s + 1) * (kHidden * 4));
     }
     __syncthreads();
+    // h1 in accumulator layout (its sign is the ReLU mask; rows past the end read
+    // as 0 => masked).  The upper 32 rows' half is in flight during the matrix
+    // loop, the lower half is fetched behind it while the upper half is folded
+    // (all 64 values live across the loop would not fit two waves per SIMD).
+    float h1a[2][2][16];
+    auto fetch_h1 = [&](int mt) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int sr = 32 * mt + (r & 3) + 8 * (r >> 2);
+          h1a[mt][nt][r] = buffer_load_f32(
+              h1rsrc, (4 * hh * kHidden + 64 * wave + 32 * nt + (lane & 31)) * 4, sr * (kHidden * 4));
+        }
+    };
+    fetch_h1(0);
     // Phase 2 (MFMA): dH1 = dZ2 x W2.
     f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    tile_gemm_64x256x256<0>(zt, w2tp, wave, lane, acc);
-    // Phase 3: dZ1 = dH1 * (h1 > 0) (mask bits; rows past the end have zero
-    // masks and zero x, so no row guard is needed); fold into dW1 / db1.
+    tile_gemm_64x256x256(zt, w2rsrc, wave, lane, acc);
+    fetch_h1(1);
+    // Phase 3: dZ1 = dH1 * (h1 > 0); fold into dW1 / db1, the two columns of a
+    // lane as one packed op.
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int s = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        float xr[kIn];
+        const f32x2 dz = {h1a[mt][0][r] > 0.0f ? acc[mt][0][r] : 0.0f,
+                          h1a[mt][1][r] > 0.0f ? acc[mt][1][r] : 0.0f};
+        db1 += dz;
 #pragma unroll
-        for (int c = 0; c < kIn; ++c) xr[c] = xs[s * kMaxIn + c];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const uint32_t word = ms[s * (kHidden / 32) + 2 * wave + nt];
-          const float dz = ((word >> (lane & 31)) & 1u) ? acc[mt][nt][r] : 0.0f;
-          db1[nt] += dz;
-#pragma unroll
-          for (int c = 0; c < kIn; ++c) dw1[nt][c] += dz * xr[c];
+        for (int c = 0; c < kIn; ++c) {
+          const float xv = xs[s * kIn + c];
+          dw1[c] = __builtin_elementwise_fma(dz, f32x2{xv, xv}, dw1[c]);
         }
       }
   }
@@ -426,24 +484,27 @@ __global__ __launch_bounds__(kBlock, DIN == 0 ? 1 : 2) void mlp_tower_backward_k
     if (hh == 0) row[off_db1 + i] = b;
 #pragma unroll
     for (int c = 0; c < kIn; ++c) {
-      const float w = dw1[nt][c] + __shfl_xor(dw1[nt][c], 32, kWave);
+      const float w = dw1[c][nt] + __shfl_xor(dw1[c][nt], 32, kWave);
       if (hh == 0 && c < d_in) row[i * d_in + c] = w;
     }
   }
-  row[off_db2 + tid] = db2;
+  row[off_db2 + tid] = db2.x + db2.y;
 #pragma unroll
   for (int q = 0; q < kOut; ++q)
-    if (q < n_out) row[off_dw3 + q * kHidden + tid] = dw3[q];
-  if (tid == 0) {
-#pragma unroll
-    for (int q = 0; q < kOut; ++q)
-      if (q < n_out) row[off_db3 + q] = db3[q];
+    if (q < n_out) row[off_dw3 + q * kHidden + tid] = dw3[q].x + dw3[q].y;
+  // db3: thread t holds a share of output t % kOut; fold through LDS.
+  __syncthreads();
+  ds[tid] = db3;
+  __syncthreads();
+  if (tid < n_out) {
+    float sum = 0.0f;
+    for (int t = tid; t < kBlock; t += kOut) sum += ds[t];
+    row[off_db3 + tid] = sum;
   }
 }
 
 inline size_t mlp_backward_lds_bytes() {
-  return sizeof(float) * (kTileRows * kLdsStride + kTileRows * kMaxIn + kTileRows * kMaxOut +
-                          kTileRows * (kHidden / 32));
+  return sizeof(float) * (kTileRows * kLdsStride + kTileRows * kMaxIn + kTileRows * kMaxOut);
 }
 
 inline size_t mlp_forward_lds_bytes() {
@@ -457,7 +518,7 @@ using namespace rl8;
 RL8_API int rl8_mlp_pack_w2_f32(const float *w2, float *w2_packed, int transposed, void *stream) {
   if (!w2 || !w2_packed) return RL8_ENULL;
   if (!aligned16(w2) || !aligned16(w2_packed)) return RL8_EALIGN;
-  const int grid = kHidden * kHidden / 4 / kBlock;
+  const int grid = kHidden * kHidden / kBlock;
   if (transposed)
     mlp_pack_w2t_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(w2, w2_packed);
   else
@@ -465,44 +526,52 @@ RL8_API int rl8_mlp_pack_w2_f32(const float *w2, float *w2_packed, int transpose
   return launch_status();
 }
 
-template <int DIN, int NOUT>
-static int launch_forward(int grid, hipStream_t s, const float *x, int64_t m, int d_in,
-                          const float *w1, const float *b1, const float4 *w2p, const float *b2,
-                          const float *w3, const float *b3, int n_out, float *out, float *save_h1,
-                          float *save_h2, uint32_t *save_m1) {
+template <int DIN, int NOUT, bool SAVE>
+static int launch_forward_save(int grid, hipStream_t s, const float *x, int64_t m, int d_in,
+                               const float *w1, const float *b1, const float4 *w2p,
+                               const float *b2, const float *w3, const float *b3, int n_out,
+                               float *out, float *save_h1, float *save_h2) {
   static bool attr_set = false;  // one flag per instantiation
   if (!attr_set) {
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void *>(&mlp_tower_forward_kernel<DIN, NOUT>),
+        reinterpret_cast<const void *>(&mlp_tower_forward_kernel<DIN, NOUT, SAVE>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_tower_forward_kernel<DIN, NOUT><<<grid, kBlock, mlp_forward_lds_bytes(), s>>>(
-      x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, save_h1, save_h2, save_m1);
+  mlp_tower_forward_kernel<DIN, NOUT, SAVE><<<grid, kBlock, mlp_forward_lds_bytes(), s>>>(
+      x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, save_h1, save_h2);
   return launch_status();
+}
+
+template <int DIN, int NOUT>
+static int launch_forward(int grid, hipStream_t s, const float *x, int64_t m, int d_in,
+                          const float *w1, const float *b1, const float4 *w2p, const float *b2,
+                          const float *w3, const float *b3, int n_out, float *out, float *h1,
+                          float *h2) {
+  return h1 ? launch_forward_save<DIN, NOUT, true>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2)
+            : launch_forward_save<DIN, NOUT, false>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2);
 }
 
 template <int DIN>
 static int dispatch_forward_nout(int n_out, int grid, hipStream_t s, const float *x, int64_t m,
                                  int d_in, const float *w1, const float *b1, const float4 *w2p,
                                  const float *b2, const float *w3, const float *b3, float *out,
-                                 float *h1, float *h2, uint32_t *m1) {
+                                 float *h1, float *h2) {
   switch (n_out) {
-    case 1: return launch_forward<DIN, 1>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2, m1);
-    case 2: return launch_forward<DIN, 2>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2, m1);
-    case 3: return launch_forward<DIN, 3>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2, m1);
-    default: return launch_forward<DIN, 0>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2, m1);
+    case 1: return launch_forward<DIN, 1>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2);
+    case 2: return launch_forward<DIN, 2>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2);
+    case 3: return launch_forward<DIN, 3>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2);
+    default: return launch_forward<DIN, 0>(grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, h1, h2);
   }
 }
 
 RL8_API int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *w1,
                                       const float *b1, const float *w2_packed, const float *b2,
                                       const float *w3, const float *b3, int n_out, float *out,
-                                      float *save_h1, float *save_h2, uint32_t *save_m1,
-                                      void *stream) {
+                                      float *save_h1, float *save_h2, void *stream) {
   if (!x || !w1 || !b1 || !w2_packed || !b2 || !w3 || !b3 || !out) return RL8_ENULL;
-  if ((save_h1 == nullptr) != (save_m1 == nullptr)) return RL8_ENULL;
+  if ((save_h1 == nullptr) != (save_h2 == nullptr)) return RL8_ENULL;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
   if (!aligned16(w2_packed)) return RL8_EALIGN;
   const int64_t tiles = (m + kTileRows - 1) / kTileRows;
@@ -512,9 +581,9 @@ RL8_API int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const
   const float4 *w2p = reinterpret_cast<const float4 *>(w2_packed);
   hipStream_t s = (hipStream_t)stream;
   switch (d_in) {  // common observation widths compiled in; anything else run-time
-    case 1: return dispatch_forward_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2, save_m1);
-    case 5: return dispatch_forward_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2, save_m1);
-    default: return dispatch_forward_nout<0>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2, save_m1);
+    case 1: return dispatch_forward_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2);
+    case 5: return dispatch_forward_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2);
+    default: return dispatch_forward_nout<0>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2);
   }
 }
 
@@ -635,7 +704,7 @@ __global__ __launch_bounds__(kBlock) void mlp_wgrad_reduce_kernel(const float *_
 }
 
 template <int DIN, int NOUT>
-static int launch_backward(int grid, hipStream_t s, const float *x, const uint32_t *m1,
+static int launch_backward(int grid, hipStream_t s, const float *x, const float *h1,
                            const float *h2, const float *dout, int64_t m, int d_in,
                            const float4 *w2tp, const float *w3, int n_out, float *dz2_out,
                            float *partials, int stride) {
@@ -648,32 +717,32 @@ static int launch_backward(int grid, hipStream_t s, const float *x, const uint32
     attr_set = true;
   }
   mlp_tower_backward_kernel<DIN, NOUT><<<grid, kBlock, mlp_backward_lds_bytes(), s>>>(
-      x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+      x, h1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
   return launch_status();
 }
 
 template <int DIN>
 static int dispatch_backward_nout(int n_out, int grid, hipStream_t s, const float *x,
-                                  const uint32_t *m1, const float *h2, const float *dout,
+                                  const float *h1, const float *h2, const float *dout,
                                   int64_t m, int d_in, const float4 *w2tp, const float *w3,
                                   float *dz2_out, float *partials, int stride) {
   switch (n_out) {
-    case 1: return launch_backward<DIN, 1>(grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
-    case 2: return launch_backward<DIN, 2>(grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
-    case 3: return launch_backward<DIN, 3>(grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
-    default: return launch_backward<DIN, 0>(grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+    case 1: return launch_backward<DIN, 1>(grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+    case 2: return launch_backward<DIN, 2>(grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+    case 3: return launch_backward<DIN, 3>(grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
+    default: return launch_backward<DIN, 0>(grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
   }
 }
 
-RL8_API int rl8_mlp_tower_backward_f32(const float *x, const uint32_t *m1, const float *h2,
+RL8_API int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
                                        const float *dout, int64_t m, int d_in,
                                        const float *w2t_packed, const float *w3, int n_out,
                                        float *dz2_out, float *partials, int *partial_rows_out,
                                        void *stream) {
-  if (!x || !m1 || !h2 || !dout || !w2t_packed || !w3 || !dz2_out || !partials ||
+  if (!x || !h1 || !h2 || !dout || !w2t_packed || !w3 || !dz2_out || !partials ||
       !partial_rows_out)
     return RL8_ENULL;
-  if (!aligned16(h2)) return RL8_EALIGN;
+  if (!aligned16(h2) || !aligned16(h1) || !aligned16(dz2_out)) return RL8_EALIGN;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
   if (!aligned16(w2t_packed)) return RL8_EALIGN;
   const int64_t tiles = (m + kTileRows - 1) / kTileRows;
@@ -683,9 +752,9 @@ RL8_API int rl8_mlp_tower_backward_f32(const float *x, const uint32_t *m1, const
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
   switch (d_in) {
-    case 1: return dispatch_backward_nout<1>(n_out, grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
-    case 5: return dispatch_backward_nout<5>(n_out, grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
-    default: return dispatch_backward_nout<0>(n_out, grid, s, x, m1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
+    case 1: return dispatch_backward_nout<1>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
+    case 5: return dispatch_backward_nout<5>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
+    default: return dispatch_backward_nout<0>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
   }
 }
 

@@ -20,6 +20,9 @@ import torch
 
 _LIB_NAME = "librl8_amd.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+# Kernel-tuning runs point this at an experimental build of the SAME ABI
+# (tools/diag_mlp.sh); there is still no fallback if the file is missing.
+_LIB_PATH = os.environ.get("RL8_AMD_LIBRARY", _LIB_PATH)
 _lib: None | C.CDLL = None
 
 _ERRORS = {
@@ -96,7 +99,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_ppo_loss_normal_fwd_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(PPOHparams), _vp, _vp, _vp, _vp, _vp, _vp],
     "rl8_gather_minibatch": [_vp, _i64, _i64, C.POINTER(GatherField), _i32, _vp],
     "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
-    "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
     "rl8_mlp_backward_max_rows": [],
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
@@ -623,9 +626,9 @@ def mlp_pack_w2(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
 def mlp_tower_forward(
     x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2_packed: torch.Tensor, b2: torch.Tensor,
     w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False,
-) -> tuple[torch.Tensor, None | torch.Tensor, None | torch.Tensor, None | torch.Tensor]:
-    """x [M, d_in] -> out [M, n_out]; with ``save`` also h1, h2 ([M, 256]) and the
-    bit-packed ReLU mask of h1 ([M, 8] int32) for the backward pass."""
+) -> tuple[torch.Tensor, None | torch.Tensor, None | torch.Tensor]:
+    """x [M, d_in] -> out [M, n_out]; with ``save`` also the post-ReLU activations
+    h1, h2 ([M, 256]) for the backward pass."""
     x = _dense(x.detach(), torch.float32, "x")
     m, d_in = x.shape
     n_out = w3.shape[0]
@@ -639,20 +642,19 @@ def mlp_tower_forward(
     out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
     h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
     h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
-    m1 = torch.empty(m, MLP_HIDDEN // 32, dtype=torch.int32, device=x.device) if save else None
     with _timed("mlp_tower_forward", m):
         _check(
             load().rl8_mlp_tower_forward_f32(
                 _ptr(x), m, d_in, _ptr(w1.detach()), _ptr(b1.detach()), _ptr(w2_packed), _ptr(b2.detach()),
-                _ptr(w3.detach()), _ptr(b3.detach()), n_out, _ptr(out), _ptr(h1), _ptr(h2), _ptr(m1), _stream(),
+                _ptr(w3.detach()), _ptr(b3.detach()), n_out, _ptr(out), _ptr(h1), _ptr(h2), _stream(),
             ),
             "rl8_mlp_tower_forward_f32",
         )
-    return out, h1, h2, m1
+    return out, h1, h2
 
 
 def mlp_tower_backward(
-    x: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor, m1: torch.Tensor, dout: torch.Tensor,
+    x: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor, dout: torch.Tensor,
     w2t_packed: torch.Tensor, w3: torch.Tensor,
 ) -> dict[str, torch.Tensor]:
     """Gradients of one tower's parameters given ``dout`` [M, n_out] and the
@@ -673,7 +675,7 @@ def mlp_tower_backward(
     with _timed("mlp_tower_backward", m):
         _check(
             lib.rl8_mlp_tower_backward_f32(
-                _ptr(x), _ptr(m1), _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
+                _ptr(x), _ptr(h1), _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
                 _ptr(dz2), _ptr(partials), C.byref(rows), _stream(),
             ),
             "rl8_mlp_tower_backward_f32",

@@ -43,16 +43,16 @@ class _FusedTower(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, layer2):  # type: ignore[override]
         need_grad = any(ctx.needs_input_grad[1:7])
-        out, h1, h2, m1 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
+        out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
         if need_grad:
             ctx.layer2 = layer2
-            ctx.save_for_backward(x, h1, h2, m1, w3)
+            ctx.save_for_backward(x, h1, h2, w3)
         return out
 
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
-        x, h1, h2, m1, w3 = ctx.saved_tensors
-        g = hip.mlp_tower_backward(x, h1, h2, m1, dout.contiguous().float(), _packed(ctx.layer2, True), w3)
+        x, h1, h2, w3 = ctx.saved_tensors
+        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True), w3)
         return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None
 
 

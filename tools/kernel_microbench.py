@@ -102,7 +102,7 @@ def torch_tower():
     return torch.addmm(mlp_b3, h, mlp_w3.T)
 
 
-_, mlp_h1, mlp_h2, mlp_m1 = hip.mlp_tower_forward(mlp_x, mlp_w1, mlp_b1, mlp_w2p, mlp_b2, mlp_w3, mlp_b3, save=True)
+_, mlp_h1, mlp_h2 = hip.mlp_tower_forward(mlp_x, mlp_w1, mlp_b1, mlp_w2p, mlp_b2, mlp_w3, mlp_b3, save=True)
 mlp_w2tp = hip.mlp_pack_w2(mlp_w2, transposed=True)
 mlp_dout = torch.randn(N, 2, device=dev, generator=g) / N
 
@@ -112,7 +112,7 @@ KERNELS = {
     "mlp_wgrad_fused": (lambda: hip.mlp_wgrad(mlp_dz2, mlp_h1), 2 * N * 65536 / 1000),
     "mlp_wgrad_torch": (lambda: mlp_dz2.t() @ mlp_h1, 2 * N * 65536 / 1000),
     "mlp_tower_forward_save": (lambda: hip.mlp_tower_forward(mlp_x, mlp_w1, mlp_b1, mlp_w2p, mlp_b2, mlp_w3, mlp_b3, save=True), MLP_FLOP / 1000),
-    "mlp_tower_backward_fused": (lambda: hip.mlp_tower_backward(mlp_x, mlp_h1, mlp_h2, mlp_m1, mlp_dout, mlp_w2tp, mlp_w3), 2 * MLP_FLOP / 1000),
+    "mlp_tower_backward_fused": (lambda: hip.mlp_tower_backward(mlp_x, mlp_h1, mlp_h2, mlp_dout, mlp_w2tp, mlp_w3), 2 * MLP_FLOP / 1000),
     # the two MLP entries report TFLOP/s in the GB/s column (algorithmic "bytes" = FLOP / 1000)
     "mlp_tower_forward_fused": (lambda: hip.mlp_tower_forward(mlp_x, mlp_w1, mlp_b1, mlp_w2p, mlp_b2, mlp_w3, mlp_b3), MLP_FLOP / 1000),
     "mlp_tower_forward_torch": (torch_tower, MLP_FLOP / 1000),

@@ -1,0 +1,130 @@
+// Hardware probe (kernel-tuning aid, not part of the library): how much VALU work
+// can ride under a stream of v_mfma_f32_32x32x2_f32 on a gfx950 SIMD --
+//   same   : K VALU fmas per MFMA issued by the SAME wave
+//   other  : a second wave on the same SIMD issues the VALU fmas
+// and what the sustained fp32 MFMA rate is (which pins the clock under load).
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_valu_probe mfma_valu_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int K>
+__device__ __forceinline__ void valu_block(float (&v)[8], float a, float b) {
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[k & 7]) : "v"(a), "v"(b));
+}
+
+// MODE 0: every wave does MFMA + K fmas per MFMA.  MODE 1: waves 0..3 MFMA only,
+// waves 4..7 (same SIMDs) K fmas per (the other wave's) MFMA.  MODE 2: LDS reads
+// (ds_read_b32) instead of fmas, same wave.
+template <int K, int MODE>
+__global__ __launch_bounds__(512) void probe(float *out, int iters, int flag) {
+  __shared__ float lds[4096];
+  const int wave = threadIdx.x >> 6;
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  float v[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+  float a = 1.0f + threadIdx.x * 1e-9f, b = 1e-9f;
+  lds[threadIdx.x] = a;
+  __syncthreads();
+  const bool mfma_wave = MODE != 1 || wave < 4;
+  const bool valu_wave = MODE != 1 || wave >= 4;
+  if (mfma_wave && valu_wave) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+        if (MODE == 2) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            float t;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"((threadIdx.x * 4 + k * 64) & 16383));
+            v[k & 7] = t;
+          }
+        } else {
+          valu_block<K>(v, a, b);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+  } else if (mfma_wave) {
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+  } else {
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) valu_block<K>(v, a, b);
+  }
+  if (flag) {
+    float s = 0;
+    for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 16; ++r) s += acc[i][r];
+    for (int k = 0; k < 8; ++k) s += v[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  }
+}
+
+template <int K, int MODE>
+void run(const char *name, int threads, float *out, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int grid = 256;
+  for (int w = 0; w < 3; ++w) probe<K, MODE><<<grid, threads>>>(out, iters, 0);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0);
+    probe<K, MODE><<<grid, threads>>>(out, iters, 0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const int mfma_waves = MODE == 1 ? 4 : threads / 64;
+  const double mfmas = (double)grid * mfma_waves * iters * 4;
+  const double tflops = mfmas * 4096.0 / (best * 1e-3) / 1e12;
+  // cycles per MFMA per SIMD if the clock were 2.4 GHz
+  const double mfma_per_simd = (double)iters * 4 * (MODE == 1 ? 1 : threads / 256);
+  printf("%-28s threads=%3d K=%2d  %8.3f ms  %7.1f TFLOP/s  %6.1f ns/MFMA/SIMD\n", name, threads, K, best,
+         tflops, best * 1e6 / mfma_per_simd);
+}
+
+int main() {
+  float *out;
+  hipMalloc(&out, 256 * 512 * sizeof(float));
+  const int iters = 20000;
+  // warm the clocks
+  for (int i = 0; i < 20; ++i) probe<0, 0><<<256, 256>>>(out, iters, 0);
+  hipDeviceSynchronize();
+  run<0, 0>("mfma only, 1 wave/SIMD", 256, out, iters);
+  run<0, 0>("mfma only, 2 waves/SIMD", 512, out, iters);
+  run<1, 0>("same wave", 256, out, iters);
+  run<2, 0>("same wave", 256, out, iters);
+  run<4, 0>("same wave", 256, out, iters);
+  run<8, 0>("same wave", 256, out, iters);
+  run<12, 0>("same wave", 256, out, iters);
+  run<16, 0>("same wave", 256, out, iters);
+  run<4, 0>("same wave, 2 waves/SIMD", 512, out, iters);
+  run<8, 0>("same wave, 2 waves/SIMD", 512, out, iters);
+  run<1, 1>("other wave", 512, out, iters);
+  run<2, 1>("other wave", 512, out, iters);
+  run<4, 1>("other wave", 512, out, iters);
+  run<8, 1>("other wave", 512, out, iters);
+  run<12, 1>("other wave", 512, out, iters);
+  run<16, 1>("other wave", 512, out, iters);
+  run<24, 1>("other wave", 512, out, iters);
+  run<1, 2>("same wave, LDS reads", 256, out, iters);
+  run<2, 2>("same wave, LDS reads", 256, out, iters);
+  run<4, 2>("same wave, LDS reads", 256, out, iters);
+  run<8, 2>("same wave, LDS reads", 256, out, iters);
+  hipFree(out);
+  return 0;
+}
