@@ -36,6 +36,15 @@ constexpr int kMaxIn = 16;
 constexpr int kMaxOut = 8;
 constexpr int kGroups = kHidden / 8;  // k-groups of 8
 
+// Kernel-tuning builds only (tools/diag_mlp.sh): -DRL8_DIAG_SKIP=<bits> drops
+// one memory stream of a tower kernel so its cost can be read off the microbench
+// (forward: 8 h2 store, 32 h1 store; backward: 64 h2 loads, 128 dZ2 stores,
+// 256 h1 loads).  The shipped library is built with 0.
+#ifndef RL8_DIAG_SKIP
+#define RL8_DIAG_SKIP 0
+#endif
+constexpr int kDiagSkip = RL8_DIAG_SKIP;
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
       for (int i = 0; i < kIn; ++i) v = __builtin_fmaf(xs[s * kIn + i], w1r[i], v);
       v = relu1(v);
       ht[s * kLdsStride + tid] = v;
-      if constexpr (SAVE) buffer_store_f32(v, h1rsrc, tid * 4, s * (kHidden * 4));
+      if constexpr (SAVE && !(kDiagSkip & 32)) buffer_store_f32(v, h1rsrc, tid * 4, s * (kHidden * 4));
     }
     __syncthreads();
     if (tile + gridDim.x < tiles) fetch_x(tile + gridDim.x);  // lands during the matrix phase
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
             const int sr = 32 * mt + ((r + u) & 3) + 8 * ((r + u) >> 2);  // + 4*hh
             const float v = relu1(pre[u]);
             ht[(sr + 4 * hh) * kLdsStride + j] = v;
-            if constexpr (SAVE)
+            if constexpr (SAVE && !(kDiagSkip & 8))
               buffer_store_f32(v, h2rsrc, (4 * hh * kHidden + j) * 4, sr * (kHidden * 4));
           }
         }
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int i = i0 + u * kBlock;
-          v[u] = i < nvec ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[u] = (!(kDiagSkip & 64) && i < nvec) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -432,8 +441,10 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       db2 += dz;
       zt[s * kLdsStride + tid] = dz.x;
       zt[(s + 1) * kLdsStride + tid] = dz.y;
-      buffer_store_f32(dz.x, dzrsrc, tid * 4, s * (kHidden * 4));
-      buffer_store_f32(dz.y, dzrsrc, tid * 4, (s + 1) * (kHidden * 4));
+      if constexpr (!(kDiagSkip & 128)) {
+        buffer_store_f32(dz.x, dzrsrc, tid * 4, s * (kHidden * 4));
+        buffer_store_f32(dz.y, dzrsrc, tid * 4, (s + 1) * (kHidden * 4));
+      }
     }
     __syncthreads();
     // h1 in accumulator layout (its sign is the ReLU mask; rows past the end read
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int sr = 32 * mt + (r & 3) + 8 * (r >> 2);
-          h1a[mt][nt][r] = buffer_load_f32(
+          h1a[mt][nt][r] = (kDiagSkip & 256) ? 1.0f : buffer_load_f32(
               h1rsrc, (4 * hh * kHidden + 64 * wave + 32 * nt + (lane & 31)) * 4, sr * (kHidden * 4));
         }
     };
@@ -596,22 +607,27 @@ RL8_API int rl8_mlp_backward_max_rows(void) { return 2 * kCUs; }
 // Weight gradient of the 256x256 layer: dW2[j][i] = sum_s dZ2[s][j] * h1[s][i],
 // a [256 x M] x [M x 256] product with the reduction over SAMPLES.  Every
 // workgroup owns the whole 256x256 output (8 waves x 8 accumulator tiles) and a
-// slice of the rows; it stages 64-row tiles of dZ2 and h1 through LDS (both
-// tiles are contiguous 64 KiB runs in HBM; the next tile's loads are issued
-// into registers before the matrix loop of the current one), and leaves its
-// partial sum in a workspace slab that a second kernel adds up in slab order
-// (bitwise reproducible; no atomics).
-constexpr int kWgradThreads = 512;
-// 8 waves: wave = (pair of j-tiles, quad of i-tiles)
-constexpr int kStageVecs = kTileRows * kHidden / 4 / kWgradThreads;  // float4 per thread per tile
+// slice of the rows.  32-row tiles of dZ2 and h1 go HBM -> LDS with the
+// direct-to-LDS buffer loads (one 1-KiB row per instruction: no registers, no
+// VALU, no ds_write), double-buffered so the next tile lands during the matrix
+// loop of the current one; the loop itself is MFMA + LDS reads with immediate
+// offsets only.  The partial sum is left in a workspace slab that a second
+// kernel adds up in slab order (bitwise reproducible; no atomics).
+constexpr int kWgradThreads = 512;  // 8 waves: wave = (pair of j-tiles, quad of i-tiles)
+constexpr int kWgradRows = 32;      // rows per staged tile
+// Row stride 256 + 32 floats: rows stay 16-byte aligned and the two half-waves of
+// an operand read (rows s and s+1) fall on disjoint banks.
+constexpr int kWgradStride = kHidden + 32;
+constexpr int kWgradTile = kWgradRows * kWgradStride;  // floats per array per buffer
 
-__global__ __launch_bounds__(kWgradThreads, 2) void mlp_wgrad_kernel(
+__device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0f70); }
+
+__global__ __launch_bounds__(kWgradThreads, 1) void mlp_wgrad_kernel(
     const float *__restrict__ dz2, const float *__restrict__ h1, int64_t m,
     float *__restrict__ slabs) {
-  extern __shared__ float lds[];
-  float *zt = lds;                           // [64][257] dZ2 tile
-  float *ht = lds + kTileRows * kLdsStride;  // [64][257] h1 tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ float lds[];  // [2 buffers][dZ2 tile | h1 tile][32][288]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int jl = lane & 31, kh = lane >> 5;
   const int wj = wave >> 1, wi = wave & 1;   // j-tiles {2wj, 2wj+1}, i-tiles {4wi .. 4wi+3}
   f32x16 acc[2][4];
@@ -622,48 +638,40 @@ __global__ __launch_bounds__(kWgradThreads, 2) void mlp_wgrad_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  const int64_t tiles = (m + kTileRows - 1) / kTileRows;
-  float4 sz[kStageVecs], sh[kStageVecs];
-  auto fetch = [&](int64_t tile) {
-    const int64_t r0 = tile * kTileRows;
-    const int64_t nvec = ((m - r0) < kTileRows ? (m - r0) : kTileRows) * (kHidden / 4);
-    const float4 *pz = reinterpret_cast<const float4 *>(dz2 + r0 * kHidden);
-    const float4 *ph = reinterpret_cast<const float4 *>(h1 + r0 * kHidden);
+  const int64_t tiles = (m + kWgradRows - 1) / kWgradRows;
+  // Wave w fetches rows w, w+8, w+16, w+24 of both arrays; rows past the end of
+  // the data are out of range of the descriptor and arrive as zeros.
+  auto fetch = [&](int64_t tile, int buffer) {
+    const int64_t r0 = tile * kWgradRows;
+    const int rows = (int)((m - r0) < kWgradRows ? (m - r0) : kWgradRows);
+    const __amdgpu_buffer_rsrc_t zr = buffer_rsrc(dz2 + r0 * kHidden, rows * kHidden * 4);
+    const __amdgpu_buffer_rsrc_t hr = buffer_rsrc(h1 + r0 * kHidden, rows * kHidden * 4);
+    float *zb = lds + buffer * 2 * kWgradTile, *hb = zb + kWgradTile;
 #pragma unroll
-    for (int u = 0; u < kStageVecs; ++u) {
-      const int i = tid + u * kWgradThreads;
-      const bool ok = i < nvec;  // rows past the end contribute zeros
-      sz[u] = ok ? pz[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      sh[u] = ok ? ph[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < kWgradRows / 8; ++u) {
+      const int row = wave + 8 * u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, zb + row * kWgradStride, 16, lane * 16, row * (kHidden * 4), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, hb + row * kWgradStride, 16, lane * 16, row * (kHidden * 4), 0, 0);
     }
   };
-  auto stage = [&]() {
+  int it = 0;
+  if ((int64_t)blockIdx.x < tiles) fetch(blockIdx.x, 0);
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, ++it) {
+    wait_vmcnt0();    // this wave's rows of the current tile have landed
+    __syncthreads();  // ... everyone's have, and everyone is done with the other buffer
+    if (tile + gridDim.x < tiles) fetch(tile + gridDim.x, (it + 1) & 1);
+    const float *za = lds + (it & 1) * 2 * kWgradTile + 4 * kh * kWgradStride + 64 * wj + jl;
+    const float *hb = za + kWgradTile - 64 * wj + 128 * wi;
 #pragma unroll
-    for (int u = 0; u < kStageVecs; ++u) {
-      const int i = tid + u * kWgradThreads;
-      const int off = (i >> 6) * kLdsStride + ((i & 63) << 2);
-      zt[off + 0] = sz[u].x; zt[off + 1] = sz[u].y; zt[off + 2] = sz[u].z; zt[off + 3] = sz[u].w;
-      ht[off + 0] = sh[u].x; ht[off + 1] = sh[u].y; ht[off + 2] = sh[u].z; ht[off + 3] = sh[u].w;
-    }
-  };
-  if ((int64_t)blockIdx.x < tiles) fetch(blockIdx.x);
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    __syncthreads();  // every wave is done reading the previous tile
-    stage();
-    __syncthreads();
-    if (tile + gridDim.x < tiles) fetch(tile + gridDim.x);  // in flight during the matrix loop
-    const float *za = zt + 64 * wj + jl;        // + s*stride (+32 for the second j-tile)
-    const float *hb = ht + 128 * wi + jl;       // + s*stride (+32*b for i-tile b)
-#pragma unroll 2
-    for (int g = 0; g < kTileRows / 8; ++g) {
+    for (int g = 0; g < kWgradRows / 8; ++g) {
       float a[2][4], b[4][4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int s = 8 * g + 4 * kh + e;
-        a[0][e] = za[s * kLdsStride];
-        a[1][e] = za[s * kLdsStride + 32];
+        const int s = 8 * g + e;  // + 4*kh (in the base)
+        a[0][e] = za[s * kWgradStride];
+        a[1][e] = za[s * kWgradStride + 32];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[t][e] = hb[s * kLdsStride + 32 * t];
+        for (int t = 0; t < 4; ++t) b[t][e] = hb[s * kWgradStride + 32 * t];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -775,10 +783,10 @@ RL8_API int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, floa
     (void)hipGetLastError();
     attr_set = true;
   }
-  const int64_t tiles = (m + kTileRows - 1) / kTileRows;
+  const int64_t tiles = (m + kWgradRows - 1) / kWgradRows;
   const int grid = (int)(tiles < kCUs ? tiles : kCUs);
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds_bytes = sizeof(float) * 2 * kTileRows * kLdsStride;
+  const size_t lds_bytes = sizeof(float) * 4 * kWgradTile;
   mlp_wgrad_kernel<<<grid, kWgradThreads, lds_bytes, s>>>(dz2, h1, m, workspace);
   int st = launch_status();
   if (st != RL8_OK) return st;
