@@ -615,17 +615,81 @@ RL8_API int rl8_mlp_backward_max_rows(void) { return 2 * kCUs; }
 // kernel adds up in slab order (bitwise reproducible; no atomics).
 constexpr int kWgradThreads = 512;  // 8 waves: wave = (pair of j-tiles, quad of i-tiles)
 constexpr int kWgradRows = 32;      // rows per staged tile
-// Row stride 256 + 32 floats: rows stay 16-byte aligned and the two half-waves of
-// an operand read (rows s and s+1) fall on disjoint banks.
-constexpr int kWgradStride = kHidden + 32;
+// LDS row stride 320 floats = 5 x 64 dwords, so the row offset fits the
+// immediates of ds_read2st64_b32 (units of 64 dwords) and the matrix loop needs
+// no address arithmetic; rows with bit 2 set -- the rows the upper half-wave reads
+// -- are shifted by 32 floats so the two half-waves fall on disjoint banks.
+constexpr int kWgradStride = 320;
 constexpr int kWgradTile = kWgradRows * kWgradStride;  // floats per array per buffer
+constexpr int wgrad_row_offset(int row) { return row * kWgradStride + ((row & 4) ? 32 : 0); }
 
 __device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0f70); }
+
+// Operands of one k-group (8 rows; this lane's four are 8g + 4*kh + e), read
+// with ds_read2st64_b32: two rows of one column per instruction, row offsets as
+// immediates.  Issued through inline asm because the compiler would rather pair
+// the columns (ds_read2_b32) and then has to add a new base per row -- one VALU
+// instruction between MFMAs per row, each costing an MFMA->VALU->MFMA switch.
+// Being invisible to the compiler's counters, the reads are fenced by
+// wgrad_wait<N>() (s_waitcnt lgkmcnt(N), with the operands as in/out so that
+// no use can be scheduled above it).
+typedef __attribute__((address_space(3))) float lds_float_t;
+__device__ __forceinline__ unsigned lds_address(const float *p) {
+  return (unsigned)(uintptr_t)(lds_float_t *)p;
+}
+
+struct WgradFrag {
+  f32x2 a[2][2], b[4][2];  // [column tile][row pair (e, e+1)]
+};
+
+template <int O0, int O1>
+__device__ __forceinline__ f32x2 lds_read2st64(unsigned addr) {
+  f32x2 v;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+  return v;
+}
+
+// addr[0..1]: dZ2 columns of the two j-tiles, addr[2..5]: h1 columns of the four i-tiles.
+template <int G>
+__device__ __forceinline__ void wgrad_load(WgradFrag &f, const unsigned (&addr)[6]) {
+  constexpr int R = 8 * G * (kWgradStride / 64);  // row offset in units of 64 dwords
+  constexpr int S = kWgradStride / 64;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    f.a[p][0] = lds_read2st64<R, R + S>(addr[p]);
+    f.a[p][1] = lds_read2st64<R + 2 * S, R + 3 * S>(addr[p]);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f.b[t][0] = lds_read2st64<R, R + S>(addr[2 + t]);
+    f.b[t][1] = lds_read2st64<R + 2 * S, R + 3 * S>(addr[2 + t]);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wgrad_wait(WgradFrag &f) {
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.b[0][0]),
+                 "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[2][0]), "+v"(f.b[2][1]),
+                 "+v"(f.b[3][0]), "+v"(f.b[3][1])
+               : "n"(N));
+}
+
+__device__ __forceinline__ void wgrad_mma(const WgradFrag &f, f32x16 (&acc)[2][4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int ja = 0; ja < 2; ++ja)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[ja][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[ja][e >> 1][e & 1], f.b[t][e >> 1][e & 1],
+                                                          acc[ja][t], 0, 0, 0);
+}
 
 __global__ __launch_bounds__(kWgradThreads, 1) void mlp_wgrad_kernel(
     const float *__restrict__ dz2, const float *__restrict__ h1, int64_t m,
     float *__restrict__ slabs) {
-  extern __shared__ float lds[];  // [2 buffers][dZ2 tile | h1 tile][32][288]
+  extern __shared__ float lds[];  // [2 buffers][dZ2 tile | h1 tile][32 rows x 320]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int jl = lane & 31, kh = lane >> 5;
@@ -649,38 +713,68 @@ __global__ __launch_bounds__(kWgradThreads, 1) void mlp_wgrad_kernel(
     float *zb = lds + buffer * 2 * kWgradTile, *hb = zb + kWgradTile;
 #pragma unroll
     for (int u = 0; u < kWgradRows / 8; ++u) {
-      const int row = wave + 8 * u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, zb + row * kWgradStride, 16, lane * 16, row * (kHidden * 4), 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, hb + row * kWgradStride, 16, lane * 16, row * (kHidden * 4), 0, 0);
+      const int row = wave + 8 * u;  // bit 2 of the row = bit 2 of the wave
+      const int off = row * kWgradStride + ((wave & 4) ? 32 : 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, zb + off, 16, lane * 16, row * (kHidden * 4), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, hb + off, 16, lane * 16, row * (kHidden * 4), 0, 0);
     }
   };
-  int it = 0;
-  if ((int64_t)blockIdx.x < tiles) fetch(blockIdx.x, 0);
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, ++it) {
-    wait_vmcnt0();    // this wave's rows of the current tile have landed
-    __syncthreads();  // ... everyone's have, and everyone is done with the other buffer
-    if (tile + gridDim.x < tiles) fetch(tile + gridDim.x, (it + 1) & 1);
-    const float *za = lds + (it & 1) * 2 * kWgradTile + 4 * kh * kWgradStride + 64 * wj + jl;
-    const float *hb = za + kWgradTile - 64 * wj + 128 * wi;
+  // Per-lane LDS addresses of the six operand columns, for either buffer.
+  auto columns = [&](int buffer, unsigned (&addr)[6]) {
+    const float *za = lds + buffer * 2 * kWgradTile + wgrad_row_offset(4) * kh + 64 * wj + jl;
+    addr[0] = lds_address(za);
+    addr[1] = addr[0] + 32 * 4;
 #pragma unroll
-    for (int g = 0; g < kWgradRows / 8; ++g) {
-      float a[2][4], b[4][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int s = 8 * g + e;  // + 4*kh (in the base)
-        a[0][e] = za[s * kWgradStride];
-        a[1][e] = za[s * kWgradStride + 32];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[t][e] = hb[s * kWgradStride + 32 * t];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int ja = 0; ja < 2; ++ja)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[ja][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ja][e], b[t][e], acc[ja][t], 0, 0, 0);
-    }
+    for (int t = 0; t < 4; ++t) addr[2 + t] = addr[0] + (kWgradTile - 64 * wj + 128 * wi + 32 * t) * 4;
+  };
+  // Pipeline.  The one barrier per tile sits BEFORE the tile's last k-group, when
+  // that group's operands are already in registers: behind it the buffer is
+  // free (the tile after next starts streaming into it) and the next tile has
+  // landed (its first operands are read while the last 32 MFMAs run).  A
+  // barrier at the tile boundary instead leaves all eight waves without
+  // operands at the same moment -- ~1000 idle cycles of the matrix pipes per
+  // tile, measured.
+  const int64_t t0 = blockIdx.x, stride = gridDim.x;
+  fetch(t0, 0);
+  if (t0 + stride < tiles) fetch(t0 + stride, 1);
+  if (t0 + stride < tiles)
+    __builtin_amdgcn_s_waitcnt(0x0f70 | 8);  // vmcnt(8): the first tile's 8 loads are done
+  else
+    wait_vmcnt0();
+  __syncthreads();
+  unsigned addr0[6], addr1[6];
+  WgradFrag fa, fb;
+  columns(0, addr0);
+  columns(1, addr1);
+  wgrad_load<0>(fa, addr0);
+  auto one_tile = [&](int64_t tile, int buffer, const unsigned (&addr)[6], const unsigned (&next_addr)[6]) {
+    wgrad_load<1>(fb, addr);
+    wgrad_wait<12>(fa);
+    __builtin_amdgcn_sched_barrier(0);
+    wgrad_mma(fa, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    wgrad_load<2>(fa, addr);
+    wgrad_wait<12>(fb);
+    __builtin_amdgcn_sched_barrier(0);
+    wgrad_mma(fb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    wgrad_load<3>(fb, addr);
+    wgrad_wait<12>(fa);
+    __builtin_amdgcn_sched_barrier(0);
+    wgrad_mma(fa, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    wgrad_wait<0>(fb);  // every read of this buffer is complete
+    wait_vmcnt0();      // this wave's rows of the next tile have landed
+    __syncthreads();
+    if (tile + 2 * stride < tiles) fetch(tile + 2 * stride, buffer);
+    if (tile + stride < tiles) wgrad_load<0>(fa, next_addr);
+    __builtin_amdgcn_sched_barrier(0);
+    wgrad_mma(fb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int64_t tile = t0; tile < tiles; tile += 2 * stride) {
+    one_tile(tile, 0, addr0, addr1);
+    if (tile + stride < tiles) one_tile(tile + stride, 1, addr1, addr0);
   }
   // Partial slab of this workgroup: slab[j][i].
   float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;

@@ -107,9 +107,12 @@ mlp_w2tp = hip.mlp_pack_w2(mlp_w2, transposed=True)
 mlp_dout = torch.randn(N, 2, device=dev, generator=g) / N
 
 mlp_dz2 = torch.randn(N, 256, device=dev, generator=g)
+mlp_zero = torch.zeros(N, 256, device=dev)
 
 KERNELS = {
     "mlp_wgrad_fused": (lambda: hip.mlp_wgrad(mlp_dz2, mlp_h1), 2 * N * 65536 / 1000),
+    # same launch on all-zero operands: the gap to the line above is clock / power, not the kernel
+    "mlp_wgrad_zeros": (lambda: hip.mlp_wgrad(mlp_zero, mlp_zero), 2 * N * 65536 / 1000),
     "mlp_wgrad_torch": (lambda: mlp_dz2.t() @ mlp_h1, 2 * N * 65536 / 1000),
     "mlp_tower_forward_save": (lambda: hip.mlp_tower_forward(mlp_x, mlp_w1, mlp_b1, mlp_w2p, mlp_b2, mlp_w3, mlp_b3, save=True), MLP_FLOP / 1000),
     "mlp_tower_backward_fused": (lambda: hip.mlp_tower_backward(mlp_x, mlp_h1, mlp_h2, mlp_dout, mlp_w2tp, mlp_w3), 2 * MLP_FLOP / 1000),

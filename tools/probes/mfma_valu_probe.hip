@@ -97,6 +97,57 @@ void run(const char *name, int threads, float *out, int iters) {
          tflops, best * 1e6 / mfma_per_simd);
 }
 
+// Power: the same MFMA stream on operands that change every instruction
+// (pseudo-random floats) -- what the matrix pipe sustains on real data.
+__global__ __launch_bounds__(256) void probe_random(float *out, int iters, int flag) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  float a[8], b[8];
+  unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  for (int k = 0; k < 8; ++k) {
+    h = h * 1664525u + 1013904223u;
+    a[k] = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    h = h * 1664525u + 1013904223u;
+    b[k] = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+  }
+  for (int it = 0; it < iters; it += 16) {  // 64 MFMAs per trip, every operand pair different
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[k & 3]) : "v"(a[k]), "v"(b[(k + j) & 7]));
+  }
+  if (flag) {
+    float s = 0;
+    for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  }
+}
+
+void run_random(float *out, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int w = 0; w < 10; ++w) probe_random<<<256, 256>>>(out, iters, 0);
+  hipDeviceSynchronize();
+  float best = 1e30f, sum = 0;
+  for (int rep = 0; rep < 10; ++rep) {
+    hipEventRecord(e0);
+    probe_random<<<256, 256>>>(out, iters, 0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+    sum += ms;
+  }
+  const double mfmas = 256.0 * 4 * iters * 4;
+  printf("%-28s threads=256       %8.3f ms best %8.3f ms mean  %7.1f / %7.1f TFLOP/s\n", "mfma only, random operands", best,
+         sum / 10, mfmas * 4096.0 / (best * 1e-3) / 1e12, mfmas * 4096.0 / (sum / 10 * 1e-3) / 1e12);
+}
+
 int main() {
   float *out;
   hipMalloc(&out, 256 * 512 * sizeof(float));
@@ -106,6 +157,8 @@ int main() {
   hipDeviceSynchronize();
   run<0, 0>("mfma only, 1 wave/SIMD", 256, out, iters);
   run<0, 0>("mfma only, 2 waves/SIMD", 512, out, iters);
+  run_random(out, iters);
+  run_random(out, iters * 10);
   run<1, 0>("same wave", 256, out, iters);
   run<2, 0>("same wave", 256, out, iters);
   run<4, 0>("same wave", 256, out, iters);
