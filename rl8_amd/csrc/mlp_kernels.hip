@@ -426,8 +426,9 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     }
     __syncthreads();
     // Phase 1 (VALU, thread = column j, two rows per step): dZ2 and the head
-    // gradients.
-#pragma unroll
+    // gradients.  (Unrolled by 8 steps, not fully: the scheduler otherwise hoists
+    // every LDS read of the phase into registers and spills.)
+#pragma unroll 8
     for (int s = 0; s < kTileRows; s += 2) {
       const f32x2 hv = {zt[s * kLdsStride + tid], zt[(s + 1) * kLdsStride + tid]};
       f32x2 g = {0.0f, 0.0f};
