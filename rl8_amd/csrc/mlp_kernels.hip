@@ -106,21 +106,32 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_w2t_kernel(const float *__res
 // Software-pipelined by hand, two k-groups per trip with two named register
 // sets: the B fragments (L2) and A fragments (LDS) of group g+1 are issued
 // before the 16 MFMAs of group g.
-struct Frag {
+// Operand fragments of one k-group: B (weights, through L2) and A (activations,
+// LDS) are prefetched at different distances, so they are separate sets.
+struct BFrag {
   float b0[4], b1[4];
+};
+struct AFrag {
   float a0[4], a1[4];
 };
 
-__device__ __forceinline__ void load_frag(Frag &f, __amdgpu_buffer_rsrc_t bp, int bvoff,
-                                          const float *__restrict__ a0p, int g) {
+__device__ __forceinline__ void load_b(BFrag &f, __amdgpu_buffer_rsrc_t bp, int bvoff, int g) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     f.b0[e] = buffer_load_f32(bp, bvoff + e * (kWave * 4), g * (kWave * 16));
     f.b1[e] = buffer_load_f32(bp, bvoff + kGroups * kWave * 16 + e * (kWave * 4), g * (kWave * 16));
+  }
+}
+
+__device__ __forceinline__ void load_a(AFrag &f, const float *__restrict__ a0p, int g) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
     f.a0[e] = a0p[8 * g + e];
     f.a1[e] = a0p[32 * kLdsStride + 8 * g + e];
   }
 }
+
+__device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 
 // max(v, 0) as exactly one v_max_f32 (fmaxf() costs a second, canonicalising,
 // v_max on values the compiler cannot prove quiet; NaN -> 0 either way).
@@ -133,45 +144,83 @@ __device__ __forceinline__ float relu1(float v) {
 // FIRST: the accumulators start from the inline constant 0 (no v_mov per
 // accumulator register).
 template <bool FIRST>
-__device__ __forceinline__ void mma_frag(const Frag &f, f32x16 (&acc)[2][2]) {
-  const float(&c0e)[4] = f.b0;
-  const float(&c1e)[4] = f.b1;
+__device__ __forceinline__ void mma_frag(const AFrag &fa, const BFrag &fb, f32x16 (&acc)[2][2]) {
   if constexpr (FIRST) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[0], c0e[0], zero, 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[0], c1e[0], zero, 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[0], c0e[0], zero, 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[0], c1e[0], zero, 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a0[0], fb.b0[0], zero, 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a0[0], fb.b1[0], zero, 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a1[0], fb.b0[0], zero, 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a1[0], fb.b1[0], zero, 0, 0, 0);
   }
 #pragma unroll
   for (int e = FIRST ? 1 : 0; e < 4; ++e) {
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], c0e[e], acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], c1e[e], acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[e], c0e[e], acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[e], c1e[e], acc[1][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a0[e], fb.b0[e], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a0[e], fb.b1[e], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a1[e], fb.b0[e], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a1[e], fb.b1[e], acc[1][1], 0, 0, 0);
   }
 }
 
-__device__ __forceinline__ void tile_gemm_64x256x256(const float *__restrict__ a_tile,
-                                                     __amdgpu_buffer_rsrc_t bp, int wave, int lane,
-                                                     f32x16 (&acc)[2][2]) {
-  const int i = lane & 31, hh = lane >> 5;
-  const int bvoff = (2 * wave) * kGroups * kWave * 16 + lane * 4;
-  const float *a0p = a_tile + i * kLdsStride + 4 * hh;
-  Frag fa, fb;
-  load_frag(fa, bp, bvoff, a0p, 0);
-  load_frag(fb, bp, bvoff, a0p, 1);
-  mma_frag<true>(fa, acc);
-  load_frag(fa, bp, bvoff, a0p, 2);
-  mma_frag<false>(fb, acc);
-#pragma unroll 1
-  for (int g = 2; g < kGroups; g += 2) {
-    load_frag(fb, bp, bvoff, a0p, g + 1);
-    mma_frag<false>(fa, acc);
-    if (g + 2 < kGroups) load_frag(fa, bp, bvoff, a0p, g + 2);
-    mma_frag<false>(fb, acc);
+// The 64x256x256 tile product, in two parts so that the first weight fragments
+// can be requested BEFORE the VALU phase that precedes the matrix loop:
+//   TileGemm gemm(w2 descriptor, wave, lane);
+//   gemm.prefetch();                 // B fragments of k-groups 0..2 -> registers
+//   ... VALU phase writing the A tile to LDS (and storing to HBM), barrier ...
+//   gemm.run(a_tile, acc);
+// Why: loads and stores retire through one in-order counter (vmcnt), so a
+// weight load issued after the phase's 64 stores cannot be waited for until
+// those stores have drained to L2 (~1 us); requested ahead of them it is ready
+// when the loop starts.  Inside the loop B fragments run three sets deep (two
+// groups = ~0.9 us ahead), A fragments (LDS) two sets.
+struct TileGemm {
+  __amdgpu_buffer_rsrc_t bp;
+  int bvoff, a_off;
+  BFrag b[3];
+
+  __device__ __forceinline__ TileGemm(__amdgpu_buffer_rsrc_t w, int wave, int lane)
+      : bp(w), bvoff((2 * wave) * kGroups * kWave * 16 + lane * 4),
+        a_off((lane & 31) * kLdsStride + 4 * (lane >> 5)) {}
+
+  __device__ __forceinline__ void prefetch() {
+    load_b(b[0], bp, bvoff, 0);
+    load_b(b[1], bp, bvoff, 1);
+    load_b(b[2], bp, bvoff, 2);
   }
-}
+
+  template <bool FIRST>
+  __device__ __forceinline__ void step(AFrag &fa, BFrag &fb, const float *a0p, int g,
+                                       f32x16 (&acc)[2][2]) {
+    mma_frag<FIRST>(fa, fb, acc);
+    load_a(fa, a0p, g + 2 < kGroups ? g + 2 : kGroups - 1);  // (the last reloads are unused)
+    load_b(fb, bp, bvoff, g + 3 < kGroups ? g + 3 : kGroups - 1);
+  }
+
+  __device__ __forceinline__ void run(const float *__restrict__ a_tile, f32x16 (&acc)[2][2]) {
+    const float *a0p = a_tile + a_off;
+    AFrag a[2];
+    load_a(a[0], a0p, 0);
+    load_a(a[1], a0p, 1);
+    // A set = g mod 2, B set = g mod 3: six groups per trip.
+    step<true>(a[0], b[0], a0p, 0, acc);
+    step<false>(a[1], b[1], a0p, 1, acc);
+    step<false>(a[0], b[2], a0p, 2, acc);
+    step<false>(a[1], b[0], a0p, 3, acc);
+    step<false>(a[0], b[1], a0p, 4, acc);
+    step<false>(a[1], b[2], a0p, 5, acc);
+#pragma unroll 1
+    for (int g = 6; g < kGroups - 2; g += 6) {
+      step<false>(a[0], b[0], a0p, g, acc);
+      step<false>(a[1], b[1], a0p, g + 1, acc);
+      step<false>(a[0], b[2], a0p, g + 2, acc);
+      step<false>(a[1], b[0], a0p, g + 3, acc);
+      step<false>(a[0], b[1], a0p, g + 4, acc);
+      step<false>(a[1], b[2], a0p, g + 5, acc);
+    }
+    // kGroups = 32 = 5 * 6 + 2
+    mma_frag<false>(a[0], b[0], acc);
+    mma_frag<false>(a[1], b[1], acc);
+  }
+};
 
 constexpr int pad_out(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
 
@@ -222,7 +271,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
   outvec b3r;
 #pragma unroll
   for (int q = 0; q < kOut; ++q) b3r[q] = q < n_out ? b3[q] : 0.0f;
-  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2p, kHidden * kHidden * 4);
+  TileGemm gemm(buffer_rsrc(w2p, kHidden * kHidden * 4), wave, lane);
   if constexpr (DIN == 0) {
     for (int idx = tid; idx < kTileRows * kMaxIn; idx += kBlock) xs[idx] = 0.0f;
   }
@@ -261,6 +310,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
       }
     }
     __syncthreads();
+    gemm.prefetch();  // first weight fragments, requested ahead of this tile's h1 stores
     // Layer 1 (VALU): thread = output column; per row d_in fmas + one max, the
     // observation from a broadcast LDS read, offsets all immediates (fully
     // unrolled for the narrow inputs; wider ones would hoist 64 x d_in LDS reads
@@ -278,7 +328,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
     if (tile + gridDim.x < tiles) fetch_x(tile + gridDim.x);  // lands during the matrix phase
     // Layer 2 (MFMA).
     f32x16 acc[2][2];
-    tile_gemm_64x256x256(ht, w2rsrc, wave, lane, acc);
+    gemm.run(ht, acc);
     __syncthreads();  // every wave has read all of h1: the tile may be overwritten
     // bias (packed adds over register pairs) + ReLU, accumulators -> h2 (in place
     // of h1) and, when saving, straight to HBM (each store covers two 128-byte
@@ -357,11 +407,14 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   const int d_in = DIN > 0 ? DIN : d_in_rt;
   const int n_out = NOUT > 0 ? NOUT : n_out_rt;
   extern __shared__ float lds[];
-  // Small arrays first (uniform addresses within the 16-bit LDS immediate).
-  float *xs = lds;                                  // [64][kIn], zero-padded columns
-  float *ds = xs + kTileRows * kMaxIn;              // [kOut][64] dOut tile (output-major), zero-padded
-  float *zt = ds + kTileRows * kMaxOut;             // [64][257]: h2 -> dZ2
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Small arrays first (uniform addresses within the 16-bit LDS immediate); the
+  // observation / dOut tiles are double-buffered (tile parity) so that the next
+  // tile can be staged while slower waves still fold the current one.
+  float *xs0 = lds;                                  // [2][64][kIn], zero-padded columns
+  float *ds0 = xs0 + 2 * kTileRows * kMaxIn;         // [2][kOut][64] dOut tile (output-major), zero-padded
+  float *zt = ds0 + 2 * kTileRows * kMaxOut;         // [64][257]: h2 -> dZ2
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5;
 
   float w3r[kOut];  // column `tid` of W3, zero-padded
@@ -375,56 +428,91 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   f32x2 dw1[kIn], db1 = {0.0f, 0.0f};  // columns 64*wave + 32*nt + (lane&31), this half's rows
 #pragma unroll
   for (int c = 0; c < kIn; ++c) dw1[c] = f32x2{0.0f, 0.0f};
+  constexpr int kXPerThread = (kTileRows * kIn + kBlock - 1) / kBlock;
   constexpr int kDoutPerThread = (kTileRows * kOut + kBlock - 1) / kBlock;
   float db3 = 0.0f;  // output tid % kOut, this thread's share of the rows
-  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2tp, kHidden * kHidden * 4);
+  TileGemm gemm(buffer_rsrc(w2tp, kHidden * kHidden * 4), wave, lane);
   if constexpr (DIN == 0) {
-    for (int idx = tid; idx < kTileRows * kMaxIn; idx += kBlock) xs[idx] = 0.0f;
+    for (int idx = tid; idx < 2 * kTileRows * kMaxIn; idx += kBlock) xs0[idx] = 0.0f;
+    __syncthreads();
   }
 
   const int64_t tiles = (m + kTileRows - 1) / kTileRows;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  // Everything a tile reads from HBM is requested one phase or more ahead:
+  //   h2 tile   -> LDS by direct-to-LDS loads (16 one-row loads per wave; rows past
+  //               the end arrive as zeros), issued as soon as the previous tile's
+  //               matrix loop has released the LDS tile;
+  //   x, dOut   -> registers at the same point, to LDS at the top of the tile;
+  //   h1        -> registers in accumulator layout (its sign is the ReLU mask):
+  //               upper half ahead of phase 1, lower half behind the matrix loop
+  //               (all 64 live across the loop would not fit two waves per SIMD);
+  //   W2 frags  -> TileGemm::prefetch ahead of phase 1's stores.
+  float xreg[kXPerThread], dreg[kDoutPerThread];
+  auto request_tile = [&](int64_t tile) {
+    const int64_t r0 = tile * kTileRows;
+    const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
+    if constexpr (!(kDiagSkip & 64)) {
+      const __amdgpu_buffer_rsrc_t h2rsrc = buffer_rsrc(h2 + r0 * kHidden, rows * kHidden * 4);
+#pragma unroll
+      for (int u = 0; u < kTileRows / 4; ++u) {
+        const int row = wave + 4 * u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(h2rsrc, zt + row * kLdsStride, 16, lane * 16,
+                                                 row * (kHidden * 4), 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kXPerThread; ++u) {
+      const int idx = tid + u * kBlock;
+      xreg[u] = (idx < kTileRows * d_in && idx < rows * d_in) ? x[r0 * d_in + idx] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kDoutPerThread; ++u) {
+      const int idx = tid + u * kBlock;
+      const int s = idx / kOut, q = idx - s * kOut;
+      dreg[u] = (idx < kTileRows * kOut && s < rows && q < n_out) ? dout[(r0 + s) * n_out + q] : 0.0f;
+    }
+  };
+  if ((int64_t)blockIdx.x < tiles) request_tile(blockIdx.x);
+  int parity = 0;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, parity ^= 1) {
     const int64_t r0 = tile * kTileRows;
     const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
     const __amdgpu_buffer_rsrc_t h1rsrc = buffer_rsrc(h1 + r0 * kHidden, rows * kHidden * 4);
     const __amdgpu_buffer_rsrc_t dzrsrc = buffer_rsrc(dz2_out + r0 * kHidden, rows * kHidden * 4);
-    __syncthreads();
-    for (int idx = tid; idx < kTileRows * d_in; idx += kBlock) {
-      const int s = idx / d_in, c = idx - s * d_in;
-      xs[s * kIn + c] = s < rows ? x[r0 * d_in + idx] : 0.0f;
+    float *xs = xs0 + parity * kTileRows * kMaxIn;
+    float *ds = ds0 + parity * kTileRows * kMaxOut;
+#pragma unroll
+    for (int u = 0; u < kXPerThread; ++u) {
+      const int idx = tid + u * kBlock;
+      if (idx < kTileRows * d_in) {
+        const int s = DIN > 0 ? idx / kIn : idx / d_in;
+        xs[s * kIn + (idx - s * d_in)] = xreg[u];
+      }
     }
 #pragma unroll
     for (int u = 0; u < kDoutPerThread; ++u) {
       const int idx = tid + u * kBlock;
       if (idx < kTileRows * kOut) {
         const int s = idx / kOut, q = idx - s * kOut;
-        const float d = (s < rows && q < n_out) ? dout[(r0 + s) * n_out + q] : 0.0f;
-        ds[q * kTileRows + s] = d;  // rows (s, s+1) adjacent: one 8-byte read per packed operand
-        db3 += d;
+        ds[q * kTileRows + s] = dreg[u];  // rows (s, s+1) adjacent: one 8-byte read per packed operand
+        db3 += dreg[u];
       }
     }
-    {
-      // h2 tile: the tile's rows are one contiguous run of rows*256 floats in
-      // HBM -> 16-byte loads, four in flight per lane, scattered into the padded
-      // LDS tile.
-      const float4 *src = reinterpret_cast<const float4 *>(h2 + r0 * kHidden);
-      const int nvec = rows * (kHidden / 4);
-      for (int i0 = tid; i0 < kTileRows * (kHidden / 4); i0 += kBlock * 4) {
-        float4 v[4];
+    wait_vmcnt0();    // this wave's h2 rows have landed
+    __syncthreads();  // ... everyone's have; xs / ds are written
+    float h1a[2][2][16];
+    auto fetch_h1 = [&](int mt) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * kBlock;
-          v[u] = (!(kDiagSkip & 64) && i < nvec) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * kBlock;
-          float *dst = zt + (i >> 6) * kLdsStride + ((i & 63) << 2);
-          dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+        for (int r = 0; r < 16; ++r) {
+          const int sr = 32 * mt + (r & 3) + 8 * (r >> 2);
+          h1a[mt][nt][r] = (kDiagSkip & 256) ? 1.0f : buffer_load_f32(
+              h1rsrc, (4 * hh * kHidden + 64 * wave + 32 * nt + (lane & 31)) * 4, sr * (kHidden * 4));
         }
-      }
-    }
-    __syncthreads();
+    };
+    gemm.prefetch();
+    fetch_h1(0);
     // Phase 1 (VALU, thread = column j, two rows per step): dZ2 and the head
     // gradients.  (Unrolled by 8 steps, not fully: the scheduler otherwise hoists
     // every LDS read of the phase into registers and spills.)
@@ -448,25 +536,11 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       }
     }
     __syncthreads();
-    // h1 in accumulator layout (its sign is the ReLU mask; rows past the end read
-    // as 0 => masked).  The upper 32 rows' half is in flight during the matrix
-    // loop, the lower half is fetched behind it while the upper half is folded
-    // (all 64 values live across the loop would not fit two waves per SIMD).
-    float h1a[2][2][16];
-    auto fetch_h1 = [&](int mt) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int sr = 32 * mt + (r & 3) + 8 * (r >> 2);
-          h1a[mt][nt][r] = (kDiagSkip & 256) ? 1.0f : buffer_load_f32(
-              h1rsrc, (4 * hh * kHidden + 64 * wave + 32 * nt + (lane & 31)) * 4, sr * (kHidden * 4));
-        }
-    };
-    fetch_h1(0);
     // Phase 2 (MFMA): dH1 = dZ2 x W2.
     f32x16 acc[2][2];
-    tile_gemm_64x256x256(zt, w2rsrc, wave, lane, acc);
+    gemm.run(zt, acc);
+    __syncthreads();  // every wave is done with the dZ2 tile: the next h2 tile may land
+    if (tile + gridDim.x < tiles) request_tile(tile + gridDim.x);
     fetch_h1(1);
     // Phase 3: dZ1 = dH1 * (h1 > 0); fold into dW1 / db1, the two columns of a
     // lane as one packed op.
@@ -506,17 +580,17 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     if (q < n_out) row[off_dw3 + q * kHidden + tid] = dw3[q].x + dw3[q].y;
   // db3: thread t holds a share of output t % kOut; fold through LDS.
   __syncthreads();
-  ds[tid] = db3;
+  ds0[tid] = db3;
   __syncthreads();
   if (tid < n_out) {
     float sum = 0.0f;
-    for (int t = tid; t < kBlock; t += kOut) sum += ds[t];
+    for (int t = tid; t < kBlock; t += kOut) sum += ds0[t];
     row[off_db3 + tid] = sum;
   }
 }
 
 inline size_t mlp_backward_lds_bytes() {
-  return sizeof(float) * (kTileRows * kLdsStride + kTileRows * kMaxIn + kTileRows * kMaxOut);
+  return sizeof(float) * (kTileRows * kLdsStride + 2 * kTileRows * kMaxIn + 2 * kTileRows * kMaxOut);
 }
 
 inline size_t mlp_forward_lds_bytes() {
@@ -623,8 +697,6 @@ constexpr int kWgradRows = 32;      // rows per staged tile
 constexpr int kWgradStride = 320;
 constexpr int kWgradTile = kWgradRows * kWgradStride;  // floats per array per buffer
 constexpr int wgrad_row_offset(int row) { return row * kWgradStride + ((row & 4) ? 32 : 0); }
-
-__device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 
 // Operands of one k-group (8 rows; this lane's four are 8g + 4*kh + e), read
 // with ds_read2st64_b32: two rows of one column per instruction, row offsets as
