@@ -95,7 +95,7 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--num-envs", type=int, default=1 << 20, help="environments PER GPU")
     p.add_argument("--horizon", type=int, default=32)
-    p.add_argument("--env", default="discrete", choices=["discrete", "continuous", "cartpole"])
+    p.add_argument("--env", default="discrete", choices=["discrete", "continuous", "cartpole", "mountain_car", "pendulum"])
     p.add_argument("--distribution", default="default", choices=["default", "squashed"])
     p.add_argument("--recurrent", action="store_true", help="RecurrentAlgorithmConfig (LSTM, seq_len 4)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
@@ -152,6 +152,10 @@ def main() -> None:
 
     if args.env == "cartpole":
         from rl8_amd.envs.cartpole import CartPole as env_cls
+    elif args.env == "mountain_car":
+        from rl8_amd.envs import MountainCar as env_cls
+    elif args.env == "pendulum":
+        from rl8_amd.envs import Pendulum as env_cls
     else:
         env_cls = DiscreteDummyEnv if args.env == "discrete" else ContinuousDummyEnv
 

@@ -142,6 +142,61 @@ int rl8_rollout_step_cartpole_f32(const float *logits, const float *value, const
                                   void *stream);
 
 /* ---------------------------------------------------------------------- *
+ * N2  The other example environments, same SoA-state template
+ *
+ * MountainCar                         examples/mountain_car/env.py:12-38, :96-104
+ * state SoA [2][N] (position, velocity) in place; action [N] int64 in {0,1,2};
+ * obs_out [N][2] rows (position, velocity) with row stride obs_stride floats;
+ * reward_out [N].  reset: position ~ N(-0.5, 0.05), velocity ~ N(0, 0.05) from the
+ * build's Philox stream; obs_out may be NULL.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  float force_mag, goal_position, goal_velocity, gravity, max_position, max_speed, min_position;
+} rl8_mountain_car_cfg;
+
+int rl8_mountain_car_step_f32(float *state, const int64_t *action,
+                              const rl8_mountain_car_cfg *cfg /*host*/, float *obs_out,
+                              int64_t obs_stride, float *reward_out, int64_t n, void *stream);
+int rl8_mountain_car_reset_f32(float *state, int64_t n, uint64_t seed, uint64_t reset_count,
+                               int64_t env_offset, float *obs_out, int64_t obs_stride,
+                               void *stream);
+/* Fused per-timestep kernel (K = 3 sampler + physics + bookkeeping), arguments as
+ * rl8_rollout_step_cartpole_f32; obs_col_next is a [N][2] slab. */
+int rl8_rollout_step_mountain_car_f32(const float *logits, const float *value, const float *noise,
+                                      float *state, const rl8_mountain_car_cfg *cfg /*host*/,
+                                      int64_t *action_col, float *logp_col, float *value_col,
+                                      float *reward_col, float *obs_col_next, const float *rdr_t,
+                                      float *rdr_t1, float gamma, int64_t n, uint64_t seed,
+                                      uint64_t step, int64_t env_offset, int deterministic,
+                                      void *stream);
+
+/* Pendulum                            examples/pendulum/env.py:12-39, :101-113
+ * state SoA [2][N] (th, thdot) in place; action [N] f32 (clipped to +-max_torque
+ * inside); obs_out [N][3] rows (cos th', sin th', thdot'); reward_out [N] = minus
+ * the cost of the state and torque BEFORE the step.  gravity_coeff = 3g/(2l) and
+ * torque_coeff = 3/(m l^2), formed in double by the caller as the reference does
+ * (:32).  reset: th ~ U(-pi, pi), thdot ~ U(-1, 1). */
+typedef struct {
+  float dt, gravity_coeff, torque_coeff, max_speed, max_torque;
+} rl8_pendulum_cfg;
+
+int rl8_pendulum_step_f32(float *state, const float *action, const rl8_pendulum_cfg *cfg /*host*/,
+                          float *obs_out, int64_t obs_stride, float *reward_out, int64_t n,
+                          void *stream);
+int rl8_pendulum_reset_f32(float *state, int64_t n, uint64_t seed, uint64_t reset_count,
+                           int64_t env_offset, float *obs_out, int64_t obs_stride, void *stream);
+/* Fused per-timestep kernel: Normal / SquashedNormal sampler (mean, log_std [N],
+ * noise: injected standard normals or NULL) + physics + bookkeeping;
+ * action_col [N] f32, obs_col_next [N][3]. */
+int rl8_rollout_step_pendulum_f32(int squashed, const float *mean, const float *log_std,
+                                  const float *value, const float *noise, float *state,
+                                  const rl8_pendulum_cfg *cfg /*host*/, float *action_col,
+                                  float *logp_col, float *value_col, float *reward_col,
+                                  float *obs_col_next, const float *rdr_t, float *rdr_t1,
+                                  float gamma, int64_t n, uint64_t seed, uint64_t step,
+                                  int64_t env_offset, int deterministic, void *stream);
+
+/* ---------------------------------------------------------------------- *
  * a-4  Collect statistics             src/rl8/algorithms/_feedforward.py:411-436
  * rewards / rdr leaves with element strides (env_stride, time_stride) so both
  * layouts are accepted; rdr may be NULL.  Writes 12 doubles to stats_out:

@@ -164,6 +164,59 @@ def cartpole_reset(n: int, std: float, seed: int, reset_count: int, env_offset: 
     return state
 
 
+class MountainCarCfg(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("force_mag", "goal_position", "goal_velocity", "gravity", "max_position",
+                                         "max_speed", "min_position")]
+
+
+def mountain_car_cfg(*, force_mag=0.001, goal_position=0.5, goal_velocity=0.0, gravity=0.0025, max_position=0.6,
+                     max_speed=0.07, min_position=-1.2) -> MountainCarCfg:
+    return MountainCarCfg(force_mag, goal_position, goal_velocity, gravity, max_position, max_speed, min_position)
+
+
+def mountain_car_step(state: np.ndarray, action: np.ndarray, cfg: MountainCarCfg):
+    """state [2, n] -> (state', obs [n, 2], reward [n, 1])  (examples/mountain_car/env.py:12-38)."""
+    state = _f32(state).copy()
+    n = state.shape[1]
+    obs = np.empty((n, 2), np.float32)
+    reward = np.empty((n, 1), np.float32)
+    lib().oracle_mountain_car_step(_p(state), _p(_i64(action)), C.byref(cfg), _p(obs), _p(reward), C.c_int64(n))
+    return state, obs, reward
+
+
+def mountain_car_reset(n: int, seed: int, reset_count: int, env_offset: int = 0) -> np.ndarray:
+    state = np.empty((2, n), np.float32)
+    lib().oracle_mountain_car_reset(_p(state), C.c_int64(n), C.c_uint64(seed), C.c_uint64(reset_count),
+                                    C.c_int64(env_offset))
+    return state
+
+
+class PendulumCfg(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("dt", "gravity_coeff", "torque_coeff", "max_speed", "max_torque")]
+
+
+def pendulum_cfg(*, dt=0.05, g=10.0, l=1.0, m=1.0, max_speed=8.0, max_torque=2.0) -> PendulumCfg:  # noqa: E741
+    return PendulumCfg(dt, 3 * g / (2 * l), 3.0 / (m * l**2), max_speed, max_torque)
+
+
+def pendulum_step(state: np.ndarray, action: np.ndarray, cfg: PendulumCfg):
+    """state [2, n], action [n, 1] -> (state', obs [n, 3], reward [n, 1])  (examples/pendulum/env.py:12-39)."""
+    state = _f32(state).copy()
+    n = state.shape[1]
+    obs = np.empty((n, 3), np.float32)
+    reward = np.empty((n, 1), np.float32)
+    lib().oracle_pendulum_step(_p(state), _p(_f32(action)), C.byref(cfg), _p(obs), _p(reward), C.c_int64(n))
+    return state, obs, reward
+
+
+def pendulum_reset(n: int, seed: int, reset_count: int, env_offset: int = 0) -> tuple[np.ndarray, np.ndarray]:
+    state = np.empty((2, n), np.float32)
+    obs = np.empty((n, 3), np.float32)
+    lib().oracle_pendulum_reset(_p(state), _p(obs), C.c_int64(n), C.c_uint64(seed), C.c_uint64(reset_count),
+                                C.c_int64(env_offset))
+    return state, obs
+
+
 # --------------------------------------------------------------------------- #
 # Rollout bookkeeping and stats.
 # --------------------------------------------------------------------------- #

@@ -148,6 +148,125 @@ ORACLE_API void oracle_cartpole_reset(float *state, int64_t n, float std, uint64
 }
 
 /* ------------------------------------------------------------------------ */
+/* N2  MountainCar step        examples/mountain_car/env.py:12-38             */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  float force_mag, goal_position, goal_velocity, gravity, max_position, max_speed, min_position;
+} oracle_mountain_car_cfg;
+
+/* state: SoA [2][n] rows position, velocity (updated in place); obs_out [n][2]
+ * (the reference returns state.T); reward_out [n]. */
+ORACLE_API void oracle_mountain_car_step(float *state, const int64_t *action,
+                                         const oracle_mountain_car_cfg *cfg, float *obs_out,
+                                         float *reward_out, int64_t n) {
+  float *ps = state, *vs = state + n;
+  for (int64_t i = 0; i < n; ++i) {
+    float p = ps[i], v = vs[i];
+    /* :29  velocity += (action - 1) * force_mag - gravity * cos(3 * position) */
+    const float push = (float)(action[i] - 1) * cfg->force_mag;
+    const float hill = cfg->gravity * cosf(3.0f * p);
+    v = v + (push - hill);
+    /* :30 */
+    v = v < -cfg->max_speed ? -cfg->max_speed : (v > cfg->max_speed ? cfg->max_speed : v);
+    /* :31-32 */
+    p = p + v;
+    p = p < cfg->min_position ? cfg->min_position : (p > cfg->max_position ? cfg->max_position : p);
+    /* :33 */
+    if (p == cfg->min_position && v < 0.0f) v = 0.0f;
+    /* :35-37 */
+    float r = fabsf(p - cfg->goal_position);
+    r = r * -1.0f;
+    if (p >= cfg->goal_position && v >= cfg->goal_velocity) r = 1.0f;
+    ps[i] = p;
+    vs[i] = v;
+    obs_out[2 * i + 0] = p;
+    obs_out[2 * i + 1] = v;
+    reward_out[i] = r;
+  }
+}
+
+/* MountainCar.reset  examples/mountain_car/env.py:96-104: position ~ N(-0.5, 0.05),
+ * velocity ~ N(0, 0.05); build-owned noise: one Box-Muller pair per env from
+ * counter (env, reset_count, STREAM_RESET, 0). */
+ORACLE_API void oracle_mountain_car_reset(float *state, int64_t n, uint64_t seed,
+                                          uint64_t reset_count, int64_t env_offset) {
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t r[4];
+    float z0, z1;
+    rl8_philox4x32_10(seed, (uint64_t)(i + env_offset), reset_count,
+                      rl8_stream_block(RL8_STREAM_RESET, 0), r);
+    rl8_box_muller(r[0], r[1], &z0, &z1);
+    state[i] = z0 * 0.05f + -0.5f;
+    state[n + i] = z1 * 0.05f + 0.0f;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* N2  Pendulum step           examples/pendulum/env.py:12-39                 */
+/* ------------------------------------------------------------------------ */
+/* gravity_coeff = 3g/(2l), torque_coeff = 3/(m l^2): the reference forms both in
+ * double on the host and multiplies the fp32 tensors by them (:32). */
+typedef struct {
+  float dt, gravity_coeff, torque_coeff, max_speed, max_torque;
+} oracle_pendulum_cfg;
+
+/* torch.remainder on floats: fmod, then shifted into the divisor's sign. */
+static float oracle_remainder(float a, float b) {
+  float mod = fmodf(a, b);
+  if (mod != 0.0f && ((b < 0.0f) != (mod < 0.0f))) mod += b;
+  return mod;
+}
+
+/* state: SoA [2][n] rows th, thdot (updated in place); action [n] float;
+ * obs_out [n][3] = cos th', sin th', thdot'; reward_out [n] = -costs(th, thdot, u). */
+ORACLE_API void oracle_pendulum_step(float *state, const float *action,
+                                     const oracle_pendulum_cfg *cfg, float *obs_out,
+                                     float *reward_out, int64_t n) {
+  const float pi = (float)3.141592653589793, two_pi = (float)(2 * 3.141592653589793);
+  float *ths = state, *tds = state + n;
+  for (int64_t i = 0; i < n; ++i) {
+    const float th = ths[i], thdot = tds[i];
+    /* :26 */
+    float u = action[i];
+    u = u < -cfg->max_torque ? -cfg->max_torque : (u > cfg->max_torque ? cfg->max_torque : u);
+    /* :27-31 */
+    const float ang = oracle_remainder(th + pi, two_pi) - pi;
+    const float costs = (ang * ang + 0.1f * (thdot * thdot)) + 0.001f * (u * u);
+    /* :33-35 */
+    float nd = thdot + (cfg->gravity_coeff * sinf(th) + cfg->torque_coeff * u) * cfg->dt;
+    nd = nd < -cfg->max_speed ? -cfg->max_speed : (nd > cfg->max_speed ? cfg->max_speed : nd);
+    const float nth = th + nd * cfg->dt;
+    ths[i] = nth;
+    tds[i] = nd;
+    obs_out[3 * i + 0] = cosf(nth);
+    obs_out[3 * i + 1] = sinf(nth);
+    obs_out[3 * i + 2] = nd;
+    reward_out[i] = -costs;
+  }
+}
+
+/* Pendulum.reset  examples/pendulum/env.py:101-113: th ~ U(-pi, pi), thdot ~ U(-1, 1)
+ * (torch's uniform_: u * (b - a) + a on a 24-bit u); obs = cos, sin, thdot. */
+ORACLE_API void oracle_pendulum_reset(float *state, float *obs_out, int64_t n, uint64_t seed,
+                                      uint64_t reset_count, int64_t env_offset) {
+  const float pi = (float)3.141592653589793;
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t r[4];
+    rl8_philox4x32_10(seed, (uint64_t)(i + env_offset), reset_count,
+                      rl8_stream_block(RL8_STREAM_RESET, 0), r);
+    const float th = rl8_u01_24(r[0]) * (pi - (-pi)) + (-pi);
+    const float td = rl8_u01_24(r[1]) * (1.0f - (-1.0f)) + (-1.0f);
+    state[i] = th;
+    state[n + i] = td;
+    if (obs_out) {
+      obs_out[3 * i + 0] = cosf(th);
+      obs_out[3 * i + 1] = sinf(th);
+      obs_out[3 * i + 2] = td;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
 /* a-3  Rollout bookkeeping    src/rl8/algorithms/_feedforward.py:378-393     */
 /* ------------------------------------------------------------------------ */
 /* rdr[:, t+1] = gamma * rdr[:, t] + r  (mul, then add: two roundings). */

@@ -26,6 +26,43 @@ __device__ __forceinline__ float dummy_step_continuous(float state, float action
 }
 
 // ---- CartPole physics (examples/cartpole/env.py:30-63) --------------------
+// MountainCar (examples/mountain_car/env.py:29-37), one env; returns the reward.
+__device__ __forceinline__ float mountain_car_advance(float &p, float &v, int64_t action,
+                                                      const rl8_mountain_car_cfg &c) {
+  const float push = (float)(action - 1) * c.force_mag;
+  const float hill = c.gravity * cosf(3.0f * p);
+  v = v + (push - hill);
+  v = v < -c.max_speed ? -c.max_speed : (v > c.max_speed ? c.max_speed : v);
+  p = p + v;
+  p = p < c.min_position ? c.min_position : (p > c.max_position ? c.max_position : p);
+  if (p == c.min_position && v < 0.0f) v = 0.0f;
+  float r = fabsf(p - c.goal_position) * -1.0f;
+  if (p >= c.goal_position && v >= c.goal_velocity) r = 1.0f;
+  return r;
+}
+
+// torch.remainder on floats: fmod, then shifted into the divisor's sign.
+__device__ __forceinline__ float torch_remainder(float a, float b) {
+  float mod = fmodf(a, b);
+  if (mod != 0.0f && ((b < 0.0f) != (mod < 0.0f))) mod += b;
+  return mod;
+}
+
+// Pendulum (examples/pendulum/env.py:26-39), one env; returns the reward (minus
+// the cost of the state and torque before the step).
+__device__ __forceinline__ float pendulum_advance(float &th, float &thdot, float action,
+                                                  const rl8_pendulum_cfg &c) {
+  const float pi = (float)3.141592653589793, two_pi = (float)(2 * 3.141592653589793);
+  const float u = action < -c.max_torque ? -c.max_torque : (action > c.max_torque ? c.max_torque : action);
+  const float ang = torch_remainder(th + pi, two_pi) - pi;
+  const float costs = (ang * ang + 0.1f * (thdot * thdot)) + 0.001f * (u * u);
+  float nd = thdot + (c.gravity_coeff * sinf(th) + c.torque_coeff * u) * c.dt;
+  nd = nd < -c.max_speed ? -c.max_speed : (nd > c.max_speed ? c.max_speed : nd);
+  th = th + nd * c.dt;
+  thdot = nd;
+  return -costs;
+}
+
 struct CartPoleState {
   float x, x_dot, theta, theta_dot;
 };

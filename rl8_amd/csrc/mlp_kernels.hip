@@ -666,8 +666,10 @@ RL8_API int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const
   const int grid = (int)(tiles < max_grid ? tiles : max_grid);
   const float4 *w2p = reinterpret_cast<const float4 *>(w2_packed);
   hipStream_t s = (hipStream_t)stream;
-  switch (d_in) {  // common observation widths compiled in; anything else run-time
+  switch (d_in) {  // the built-in environments' observation widths compiled in; anything else run-time
     case 1: return dispatch_forward_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2);
+    case 2: return dispatch_forward_nout<2>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2);
+    case 3: return dispatch_forward_nout<3>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2);
     case 5: return dispatch_forward_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2);
     default: return dispatch_forward_nout<0>(n_out, grid, s, x, m, d_in, w1, b1, w2p, b2, w3, b3, out, save_h1, save_h2);
   }
@@ -928,6 +930,8 @@ RL8_API int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const fl
   hipStream_t s = (hipStream_t)stream;
   switch (d_in) {
     case 1: return dispatch_backward_nout<1>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
+    case 2: return dispatch_backward_nout<2>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
+    case 3: return dispatch_backward_nout<3>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
     case 5: return dispatch_backward_nout<5>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
     default: return dispatch_backward_nout<0>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2tp, w3, dz2_out, partials, stride);
   }

@@ -55,6 +55,20 @@ class CartPoleCfg(C.Structure):
     ]
 
 
+class MountainCarCfg(C.Structure):
+    """``rl8_mountain_car_cfg`` (include/rl8_amd.h)."""
+
+    _fields_ = [(name, C.c_float) for name in ("force_mag", "goal_position", "goal_velocity", "gravity",
+                                               "max_position", "max_speed", "min_position")]
+
+
+class PendulumCfg(C.Structure):
+    """``rl8_pendulum_cfg`` (include/rl8_amd.h)."""
+
+    _fields_ = [(name, C.c_float) for name in ("dt", "gravity_coeff", "torque_coeff", "max_speed", "max_torque")]
+
+
+
 class PPOHparams(C.Structure):
     _fields_ = [
         ("clip_param", C.c_float),
@@ -91,6 +105,12 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_normal_sample_logp_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _u64, _u64, _i64, _i32, _vp],
     "rl8_rollout_scatter_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp],
     "rl8_rollout_step_dummy_f32": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _u64, _u64, _i64, _i32, _vp],
+    "rl8_mountain_car_step_f32": [_vp, _vp, C.POINTER(MountainCarCfg), _vp, _i64, _vp, _i64, _vp],
+    "rl8_mountain_car_reset_f32": [_vp, _i64, _u64, _u64, _i64, _vp, _i64, _vp],
+    "rl8_rollout_step_mountain_car_f32": [_vp, _vp, _vp, _vp, C.POINTER(MountainCarCfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _u64, _u64, _i64, _i32, _vp],
+    "rl8_pendulum_step_f32": [_vp, _vp, C.POINTER(PendulumCfg), _vp, _i64, _vp, _i64, _vp],
+    "rl8_pendulum_reset_f32": [_vp, _i64, _u64, _u64, _i64, _vp, _i64, _vp],
+    "rl8_rollout_step_pendulum_f32": [_i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(PendulumCfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _u64, _u64, _i64, _i32, _vp],
     "rl8_rollout_step_cartpole_f32": [_vp, _vp, _vp, _vp, C.POINTER(CartPoleCfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _u64, _u64, _i64, _i32, _vp],
     "rl8_rollout_stats_f32": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "rl8_gae_scan_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _f32, _f32, _i32, _vp, _vp, _vp],
@@ -289,6 +309,54 @@ def cartpole_reset(state: torch.Tensor, std: float, seed: int, reset_count: int,
     )
 
 
+def _classic_step(symbol: str, obs_dim: int, action_dtype: torch.dtype, state: torch.Tensor, action: torch.Tensor,
+                  cfg: C.Structure, obs_out: torch.Tensor, reward_out: torch.Tensor) -> None:
+    _dense(state, torch.float32, "state")
+    _dense(action, action_dtype, "action")
+    _dense(obs_out, torch.float32, "obs_out")
+    _dense(reward_out, torch.float32, "reward_out")
+    n = state.shape[1]
+    if state.shape[0] != 2 or action.numel() != n or obs_out.numel() != obs_dim * n or reward_out.numel() != n:
+        raise ValueError(f"{symbol}: state [2,N], action [N,1], obs_out [N,{obs_dim}], reward_out [N,1]")
+    _check(
+        getattr(load(), symbol)(_ptr(state), _ptr(action), C.byref(cfg), _ptr(obs_out), obs_dim, _ptr(reward_out), n, _stream()),
+        symbol,
+    )
+
+
+def _classic_reset(symbol: str, obs_dim: int, state: torch.Tensor, seed: int, reset_count: int, env_offset: int,
+                   obs_out: None | torch.Tensor) -> None:
+    _dense(state, torch.float32, "state")
+    n = state.shape[1]
+    if state.shape[0] != 2:
+        raise ValueError(f"{symbol}: state must be [2,N]")
+    if obs_out is not None:
+        _dense(obs_out, torch.float32, "obs_out")
+        if obs_out.numel() != obs_dim * n:
+            raise ValueError(f"obs_out must be [N,{obs_dim}]")
+    _check(getattr(load(), symbol)(_ptr(state), n, seed, reset_count, env_offset, _ptr(obs_out), obs_dim, _stream()), symbol)
+
+
+def mountain_car_step(state: torch.Tensor, action: torch.Tensor, cfg: MountainCarCfg, obs_out: torch.Tensor,
+                      reward_out: torch.Tensor) -> None:
+    """examples/mountain_car/env.py:12-38: state [2,N] in place, obs_out [N,2], reward_out [N,1]."""
+    _classic_step("rl8_mountain_car_step_f32", 2, torch.int64, state, action, cfg, obs_out, reward_out)
+
+
+def mountain_car_reset(state: torch.Tensor, seed: int, reset_count: int, env_offset: int, obs_out: None | torch.Tensor) -> None:
+    _classic_reset("rl8_mountain_car_reset_f32", 2, state, seed, reset_count, env_offset, obs_out)
+
+
+def pendulum_step(state: torch.Tensor, action: torch.Tensor, cfg: PendulumCfg, obs_out: torch.Tensor,
+                  reward_out: torch.Tensor) -> None:
+    """examples/pendulum/env.py:12-39: state [2,N] in place, obs_out [N,3], reward_out [N,1]."""
+    _classic_step("rl8_pendulum_step_f32", 3, torch.float32, state, action, cfg, obs_out, reward_out)
+
+
+def pendulum_reset(state: torch.Tensor, seed: int, reset_count: int, env_offset: int, obs_out: None | torch.Tensor) -> None:
+    _classic_reset("rl8_pendulum_reset_f32", 3, state, seed, reset_count, env_offset, obs_out)
+
+
 # --------------------------------------------------------------------------- #
 # Samplers.
 # --------------------------------------------------------------------------- #
@@ -437,6 +505,60 @@ def rollout_step_cartpole(
             step, env_offset, int(deterministic), _stream(),
         ),
         "rl8_rollout_step_cartpole_f32",
+    )
+
+
+def _check_step_tensors(name: str, tensors: list[None | torch.Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_contiguous():
+            raise ValueError(f"{name}: all tensors must be contiguous")
+
+
+def rollout_step_mountain_car(
+    *, logits: torch.Tensor, value: torch.Tensor, noise: None | torch.Tensor, state: torch.Tensor, cfg: MountainCarCfg,
+    action_col: torch.Tensor, logp_col: torch.Tensor, value_col: torch.Tensor, reward_col: torch.Tensor,
+    obs_col_next: torch.Tensor, rdr_t: None | torch.Tensor, rdr_t1: None | torch.Tensor, gamma: float, seed: int,
+    step: int, env_offset: int, deterministic: bool,
+) -> None:
+    n = state.shape[1]
+    _check_step_tensors("rollout_step_mountain_car", [logits, value, state, action_col, logp_col, value_col,
+                                                      reward_col, obs_col_next, noise, rdr_t, rdr_t1])
+    if logits.numel() != 3 * n or value.numel() != n or obs_col_next.numel() != 2 * n or action_col.numel() != n:
+        raise ValueError("rollout_step_mountain_car: shape mismatch")
+    if noise is not None and noise.numel() != 3 * n:
+        raise ValueError("rollout_step_mountain_car: noise shape mismatch")
+    _check(
+        load().rl8_rollout_step_mountain_car_f32(
+            _ptr(logits), _ptr(value), _ptr(noise), _ptr(state), C.byref(cfg), _ptr(action_col), _ptr(logp_col),
+            _ptr(value_col), _ptr(reward_col), _ptr(obs_col_next), _ptr(rdr_t), _ptr(rdr_t1), gamma, n, seed,
+            step, env_offset, int(deterministic), _stream(),
+        ),
+        "rl8_rollout_step_mountain_car_f32",
+    )
+
+
+def rollout_step_pendulum(
+    *, squashed: bool, mean: torch.Tensor, log_std: torch.Tensor, value: torch.Tensor, noise: None | torch.Tensor,
+    state: torch.Tensor, cfg: PendulumCfg, action_col: torch.Tensor, logp_col: torch.Tensor, value_col: torch.Tensor,
+    reward_col: torch.Tensor, obs_col_next: torch.Tensor, rdr_t: None | torch.Tensor, rdr_t1: None | torch.Tensor,
+    gamma: float, seed: int, step: int, env_offset: int, deterministic: bool,
+) -> None:
+    n = state.shape[1]
+    _check_step_tensors("rollout_step_pendulum", [mean, log_std, value, state, action_col, logp_col, value_col,
+                                                  reward_col, obs_col_next, noise, rdr_t, rdr_t1])
+    if mean.numel() != n or log_std.numel() != n or value.numel() != n or obs_col_next.numel() != 3 * n or action_col.numel() != n:
+        raise ValueError("rollout_step_pendulum: shape mismatch")
+    if action_col.dtype != torch.float32:
+        raise ValueError("rollout_step_pendulum: the action column must be float32")
+    if noise is not None and noise.numel() != n:
+        raise ValueError("rollout_step_pendulum: noise shape mismatch")
+    _check(
+        load().rl8_rollout_step_pendulum_f32(
+            int(squashed), _ptr(mean), _ptr(log_std), _ptr(value), _ptr(noise), _ptr(state), C.byref(cfg),
+            _ptr(action_col), _ptr(logp_col), _ptr(value_col), _ptr(reward_col), _ptr(obs_col_next), _ptr(rdr_t),
+            _ptr(rdr_t1), gamma, n, seed, step, env_offset, int(deterministic), _stream(),
+        ),
+        "rl8_rollout_step_pendulum_f32",
     )
 
 

@@ -305,6 +305,79 @@ def gen_env_steps() -> None:
 
 
 # --------------------------------------------------------------------------- #
+# F3b: the other example envs (N2): examples/mountain_car/env.py:12-38,
+#      examples/pendulum/env.py:12-39 -- eager bodies of the compiled steps
+# --------------------------------------------------------------------------- #
+def _eager(fn):
+    for attr in ("_torchdynamo_orig_callable", "__wrapped__"):
+        if hasattr(fn, attr):
+            return getattr(fn, attr)
+    return fn
+
+
+def gen_classic_env_steps() -> None:
+    from dataclasses import asdict
+
+    from examples.mountain_car import env as mc_env
+    from examples.pendulum import env as pd_env
+
+    arrays = {}
+    g = torch.Generator().manual_seed(5)
+    n, steps = 257, 8
+    mc_step, pd_step = _eager(mc_env.step), _eager(pd_env.step)
+    for tag, cfg in (
+        ("mc_default", mc_env.MountainCarConfig()),
+        ("mc_custom", mc_env.MountainCarConfig(force_mag=0.0015, goal_position=0.45, goal_velocity=0.01,
+                                               gravity=0.002, max_position=0.55, max_speed=0.06, min_position=-1.1)),
+    ):
+        # spread over the whole track so the wall, the clips and the goal all occur
+        position = torch.empty(n).uniform_(cfg.min_position - 0.02, cfg.max_position + 0.02, generator=g)
+        position = position.clip(cfg.min_position, cfg.max_position)
+        velocity = torch.empty(n).uniform_(-1.2 * cfg.max_speed, 1.2 * cfg.max_speed, generator=g)
+        state = torch.vstack((position, velocity))
+        arrays[f"{tag}_cfg"] = np.array(list(asdict(cfg).values()), np.float64)
+        arrays[f"{tag}_cfg_keys"] = np.array(list(asdict(cfg).keys()))
+        arrays[f"{tag}_state0"] = state.clone()
+        acts, states, obss, rewards = [], [], [], []
+        for _ in range(steps):
+            a = torch.randint(0, 3, (n, 1), generator=g)
+            p, v = state
+            state, obs, reward = mc_step(p, v, a, **asdict(cfg))
+            acts.append(a)
+            states.append(state.clone())
+            obss.append(obs.contiguous().clone())
+            rewards.append(reward.clone())
+        arrays[f"{tag}_actions"] = torch.stack(acts)
+        arrays[f"{tag}_states"] = torch.stack(states)
+        arrays[f"{tag}_obs"] = torch.stack(obss)
+        arrays[f"{tag}_rewards"] = torch.stack(rewards)
+    for tag, cfg in (
+        ("pd_default", pd_env.PendulumConfig()),
+        ("pd_custom", pd_env.PendulumConfig(dt=0.02, g=9.81, l=0.7, m=1.3, max_speed=6.0, max_torque=1.5)),
+    ):
+        th = torch.empty(n).uniform_(-3 * torch.pi, 3 * torch.pi, generator=g)
+        thdot = torch.empty(n).uniform_(-1.1 * cfg.max_speed, 1.1 * cfg.max_speed, generator=g)
+        state = torch.vstack((th, thdot))
+        arrays[f"{tag}_cfg"] = np.array(list(asdict(cfg).values()), np.float64)
+        arrays[f"{tag}_cfg_keys"] = np.array(list(asdict(cfg).keys()))
+        arrays[f"{tag}_state0"] = state.clone()
+        acts, states, obss, rewards = [], [], [], []
+        for _ in range(steps):
+            a = torch.randn(n, 1, generator=g) * 1.5  # beyond +-max_torque now and then
+            t, td = state
+            state, obs, reward = pd_step(t, td, a, **asdict(cfg))
+            acts.append(a)
+            states.append(state.clone())
+            obss.append(obs.contiguous().clone())
+            rewards.append(reward.clone())
+        arrays[f"{tag}_actions"] = torch.stack(acts)
+        arrays[f"{tag}_states"] = torch.stack(states)
+        arrays[f"{tag}_obs"] = torch.stack(obss)
+        arrays[f"{tag}_rewards"] = torch.stack(rewards)
+    save("classic_env_steps.npz", **arrays)
+
+
+# --------------------------------------------------------------------------- #
 # F4: samplers (src/rl8/distributions.py:113-170 -> torch.distributions)
 # --------------------------------------------------------------------------- #
 def draw_exponential_like(probs: torch.Tensor) -> torch.Tensor:
@@ -464,6 +537,9 @@ def gen_trace(name, env_cls, config_kwargs, iterations=2, recurrent=False) -> No
 
 
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "classic":
+        gen_classic_env_steps()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "recurrent":
         gen_trace("trace_rec_discrete.npz", DiscreteDummyEnv, {}, recurrent=True)
         gen_trace(
@@ -477,6 +553,7 @@ def main() -> None:
     gen_gae()
     gen_ppo_losses()
     gen_env_steps()
+    gen_classic_env_steps()
     gen_samplers()
     gen_trace("trace_ff_discrete.npz", DiscreteDummyEnv, {})
     gen_trace(

@@ -90,6 +90,56 @@ def test_cartpole_steps(golden):
     np.testing.assert_allclose(rew, g["cp_custom_rewards"], rtol=1e-6, atol=1e-6)
 
 
+def test_mountain_car_steps(golden):
+    g = golden("classic_env_steps.npz")
+    for tag in ("mc_default", "mc_custom"):
+        cfg = oracle.mountain_car_cfg(**dict(zip(g[f"{tag}_cfg_keys"].tolist(), g[f"{tag}_cfg"].tolist())))
+        state = g[f"{tag}_state0"]
+        walls = goals = 0
+        for t in range(g[f"{tag}_actions"].shape[0]):
+            prev = g[f"{tag}_state0"] if t == 0 else g[f"{tag}_states"][t - 1]
+            s, obs, rew = oracle.mountain_car_step(prev, g[f"{tag}_actions"][t], cfg)
+            # cos() is the only inexact op: last-ulp differences between libms
+            np.testing.assert_allclose(s, g[f"{tag}_states"][t], rtol=0, atol=2e-8)
+            np.testing.assert_allclose(obs, g[f"{tag}_obs"][t], rtol=0, atol=2e-8)
+            np.testing.assert_allclose(rew[:, 0], g[f"{tag}_rewards"][t], rtol=0, atol=1e-7)
+            walls += int((s[0] == np.float32(cfg.min_position)).sum())
+            goals += int((rew == 1.0).sum())
+            state, _, _ = oracle.mountain_car_step(state, g[f"{tag}_actions"][t], cfg)
+            np.testing.assert_allclose(state, g[f"{tag}_states"][t], rtol=0, atol=1e-6)
+        assert walls > 0 and goals > 0  # the fixture reaches the wall and the goal
+
+
+def test_pendulum_steps(golden):
+    g = golden("classic_env_steps.npz")
+    for tag in ("pd_default", "pd_custom"):
+        cfg = oracle.pendulum_cfg(**dict(zip(g[f"{tag}_cfg_keys"].tolist(), g[f"{tag}_cfg"].tolist())))
+        state = g[f"{tag}_state0"]
+        for t in range(g[f"{tag}_actions"].shape[0]):
+            prev = g[f"{tag}_state0"] if t == 0 else g[f"{tag}_states"][t - 1]
+            s, obs, rew = oracle.pendulum_step(prev, g[f"{tag}_actions"][t], cfg)
+            np.testing.assert_allclose(s, g[f"{tag}_states"][t], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(obs, g[f"{tag}_obs"][t], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(rew[:, 0], g[f"{tag}_rewards"][t], rtol=1e-6, atol=1e-6)
+            state, _, _ = oracle.pendulum_step(state, g[f"{tag}_actions"][t], cfg)
+            np.testing.assert_allclose(state, g[f"{tag}_states"][t], rtol=0, atol=2e-5)
+
+
+def test_classic_env_resets_are_in_range():
+    s = oracle.mountain_car_reset(4096, seed=7, reset_count=0)
+    assert abs(float(s[0].mean()) + 0.5) < 0.01 and abs(float(s[0].std()) - 0.05) < 0.005
+    assert abs(float(s[1].mean())) < 0.01 and abs(float(s[1].std()) - 0.05) < 0.005
+    s, obs = oracle.pendulum_reset(4096, seed=7, reset_count=0)
+    assert float(np.abs(s[0]).max()) <= np.float32(np.pi) and float(np.abs(s[1]).max()) <= 1.0
+    np.testing.assert_allclose(obs[:, 0], np.cos(s[0]), atol=1e-6)
+    np.testing.assert_allclose(obs[:, 2], s[1])
+    # a different reset counter / env offset gives different, reproducible draws
+    s2, _ = oracle.pendulum_reset(4096, seed=7, reset_count=1)
+    assert not np.array_equal(s, s2)
+    s3, _ = oracle.pendulum_reset(2048, seed=7, reset_count=0, env_offset=2048)
+    assert np.array_equal(s3, s[:, 2048:])
+
+
 @pytest.mark.parametrize("ncls", [2, 3, 5])
 def test_categorical_sampler_bit_exact_actions(golden, ncls):
     g = golden("samplers.npz")
