@@ -17,6 +17,7 @@ from .algorithms import (
     RecurrentAlgorithmConfig,
 )
 from .env import Env
+from .trainers import RecurrentTrainer, TrainConfig, Trainer
 
 __all__ = [
     "Algorithm",
@@ -24,5 +25,8 @@ __all__ = [
     "Env",
     "RecurrentAlgorithm",
     "RecurrentAlgorithmConfig",
+    "RecurrentTrainer",
+    "TrainConfig",
+    "Trainer",
 ]
 __version__ = "0.1.0"

@@ -226,16 +226,25 @@ class TrainStats(CollectStats, MemoryStats, StepStats, TrainerState):
     ...
 
 
+#: ``eval/``-prefixed collect statistics returned by ``Trainer.eval``.
+EvalCollectStats = dict[str, float]
+
+#: Any key of :class:`TrainStats` (what a stop condition monitors).
+TrainStatKey = str
+
+
 __all__ = [
     "AlgorithmHparams",
     "AlgorithmState",
     "CollectStats",
     "DataKeys",
     "Device",
+    "EvalCollectStats",
     "MemoryStats",
     "RecurrentAlgorithmHparams",
     "RecurrentAlgorithmState",
     "StepStats",
+    "TrainStatKey",
     "TrainStats",
     "TrainerState",
 ]
