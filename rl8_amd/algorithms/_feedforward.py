@@ -371,11 +371,18 @@ class Algorithm:
     def _fusable(self) -> bool:
         """One-launch-per-timestep path: a built-in env exposing
         ``fused_rollout_step`` with the distribution its kernel implements."""
-        if not hasattr(self.env, "fused_rollout_step"):
+        if not hasattr(self.env, "fused_rollout_step") or not self._identity_views():
             return False
         dist_cls = self.policy.distribution_cls
         supported = getattr(self.env, "fused_distributions", (Categorical, Normal, SquashedNormal))
         return dist_cls in supported and has_fused_loss(dist_cls)
+
+    def _identity_views(self) -> bool:
+        """The model reads ``obs`` as is (no rolling windows): observations can be
+        handed to it as ``[N, ...]`` slabs without going through the view
+        requirements."""
+        views = self.policy.model.view_requirements
+        return set(views) == {DataKeys.OBS} and all(v.is_identity for v in views.values())
 
     def _forward(self, obs: torch.Tensor, *, deterministic: bool) -> tuple[TensorDict, torch.Tensor]:
         """Policy network on a ``[N, obs...]`` slab -> (features, values)."""
@@ -439,7 +446,13 @@ class Algorithm:
                     self._generic_step(obs_t, noise_t, t, gamma, step_id, deterministic)
 
             # Bootstrap value at the last observation (:396-408).
-            _, values = self._forward(tm[DataKeys.OBS][H], deterministic=deterministic)
+            if self._identity_views():
+                _, values = self._forward(tm[DataKeys.OBS][H], deterministic=deterministic)
+            else:
+                values = self.policy.sample(
+                    self.buffer, kind="last", deterministic=deterministic, inplace=False, requires_grad=False,
+                    return_actions=False, return_logp=False, return_values=True, return_views=False,
+                )[DataKeys.VALUES]
             tm[DataKeys.VALUES][H].copy_(values)
 
             # One pass, one host sync (:411-436 takes 8 reductions and 9 syncs).
@@ -630,6 +643,7 @@ class Algorithm:
             self.state.buffered = False
             self.injected_permutations = None
             self._flat_full = None
+            self._views_all = None
             step_stats = stat_tracker.items()
         step_stats["profiling/step_ms"] = step_timer()
         return step_stats  # type: ignore[return-value]
@@ -658,6 +672,9 @@ class Algorithm:
         hp = self.hparams
         H, tm = hp.horizon, self._tm
         local_samples = self.local_num_envs * H
+        if not self._identity_views():
+            yield from self._iter_view_minibatches(sgd_iter)
+            return
         if hp.num_minibatches == 1:
             # Time-major storage: dropping the last column and flattening is the
             # contiguous prefix -- no copy, no shuffle (a mean over the whole
@@ -675,6 +692,34 @@ class Algorithm:
                 index.contiguous(), H, [self.buffer[k] for k in self.TRAIN_KEYS]
             )
             yield dict(zip(self.TRAIN_KEYS, gathered))
+
+    def _iter_view_minibatches(self, sgd_iter: int):
+        """Minibatches for models with rolling-window view requirements
+        (``src/rl8/algorithms/_feedforward.py:471-482``): the windows of the whole
+        buffer are built once per ``step()`` (env-major sample order, like the
+        flattened buffer) and indexed per minibatch."""
+        hp = self.hparams
+        H = hp.horizon
+        local_samples = self.local_num_envs * H
+        if getattr(self, "_views_all", None) is None:
+            views = self.policy.model.apply_view_requirements(self.buffer[:, :-1, ...], kind="all")
+            if views.batch_size[0] != local_samples:
+                raise ValueError(
+                    f"The model's view requirements keep {views.batch_size[0]} of {local_samples} samples;"
+                    " the buffer needs one window per sample (use `padded_rolling_window`)."
+                )
+            self._views_all = views
+        keys = [k for k in self.TRAIN_KEYS if k != DataKeys.OBS]
+        local_mb = hp.sgd_minibatch_size // self.shards.world_size
+        if hp.num_minibatches == 1:
+            perm = torch.arange(local_samples, device=self._tm[DataKeys.LOGP].device)
+        else:
+            perm = self._permutation(sgd_iter, local_samples)
+        for index in torch.split(perm, local_mb):
+            gathered = hip.gather_minibatch(index.contiguous(), H, [self.buffer[k] for k in keys])
+            batch: dict[str, Any] = dict(zip(keys, gathered))
+            batch[DataKeys.VIEWS] = self._views_all[index]
+            yield batch
 
     def _minibatch_forward_backward(
         self, batch: dict[str, torch.Tensor], entropy_coeff: float, grad_scale: float
@@ -695,11 +740,10 @@ class Algorithm:
             chunk = {k: v[start:stop] for k, v in batch.items()}
             n = stop - start
             with amp.autocast("cuda", enabled=hp.enable_amp):
+                views = chunk[DataKeys.VIEWS] if DataKeys.VIEWS in chunk else TensorDict(
+                    {DataKeys.OBS: chunk[DataKeys.OBS]}, batch_size=n)
                 sample = self.policy.sample(
-                    TensorDict(
-                        {DataKeys.VIEWS: TensorDict({DataKeys.OBS: chunk[DataKeys.OBS]}, batch_size=n)},
-                        batch_size=n,
-                    ),
+                    TensorDict({DataKeys.VIEWS: views}, batch_size=n),
                     kind="all",
                     deterministic=False,
                     inplace=False,

@@ -378,6 +378,66 @@ def gen_classic_env_steps() -> None:
 
 
 # --------------------------------------------------------------------------- #
+# F3c: view requirements (N4): src/rl8/views.py:54-453
+# --------------------------------------------------------------------------- #
+def _flatten_td(prefix, item, arrays):
+    if torch.is_tensor(item):
+        arrays[prefix] = item.contiguous().clone()
+        return
+    arrays[prefix + "__batch"] = np.array(list(item.batch_size), np.int64)
+    for k in item.keys():
+        _flatten_td(f"{prefix}__{k}", item[k], arrays)
+
+
+def gen_views() -> None:
+    from rl8.views import (PaddedRollingWindow, RollingWindow, ViewRequirement, pad_last_sequence,
+                           pad_whole_sequence, rolling_window)
+
+    arrays = {}
+    g = torch.Generator().manual_seed(9)
+    cases = {
+        "a": torch.randn(3, 7, 2, generator=g),
+        "b": torch.randn(2, 1, 4, generator=g),      # shorter than the window
+        "c": torch.randn(4, 5, generator=g),         # no feature dimension
+        "d": torch.randn(2, 6, 2, 3, generator=g),   # two feature dimensions
+    }
+    names = []
+    for name, x in cases.items():
+        arrays[f"{name}_x"] = x
+        for size in (1, 2, 3, 5):
+            tag = f"{name}_s{size}"
+            names.append(tag)
+            _flatten_td(f"{tag}_pad_last", pad_last_sequence(x, size), arrays)
+            _flatten_td(f"{tag}_pad_whole", pad_whole_sequence(x, size), arrays)
+            _flatten_td(f"{tag}_padded_all", PaddedRollingWindow.apply_all(x, size), arrays)
+            _flatten_td(f"{tag}_padded_last", PaddedRollingWindow.apply_last(x, size), arrays)
+            _flatten_td(f"{tag}_rolling_last", RollingWindow.apply_last(x, size), arrays)
+            if size <= x.shape[1]:
+                arrays[f"{tag}_window"] = rolling_window(x, size).contiguous()
+                arrays[f"{tag}_window_step2"] = rolling_window(x, size, step=2).contiguous()
+                arrays[f"{tag}_rolling_all"] = RollingWindow.apply_all(x, size).contiguous()
+    arrays["tensor_cases"] = np.array(names)
+    # nested tensordict through ViewRequirement (keys as a model would use them)
+    td = TensorDict(
+        {"obs": TensorDict({"prices": torch.randn(3, 6, 2, generator=g), "volume": torch.randn(3, 6, generator=g)},
+                           batch_size=[3, 6])},
+        batch_size=[3, 6],
+    )
+    arrays["td_prices"] = td["obs"]["prices"]
+    arrays["td_volume"] = td["obs"]["volume"]
+    for method in ("rolling_window", "padded_rolling_window"):
+        for shift in (0, 2):
+            vr = ViewRequirement(shift=shift, method=method)
+            tag = f"td_{method}_shift{shift}"
+            _flatten_td(f"{tag}_all", vr.apply_all("obs", td), arrays)
+            _flatten_td(f"{tag}_last", vr.apply_last("obs", td), arrays)
+            _flatten_td(f"{tag}_all_leaf", vr.apply_all(("obs", "prices"), td), arrays)
+            _flatten_td(f"{tag}_last_leaf", vr.apply_last(("obs", "prices"), td), arrays)
+            arrays[f"{tag}_drop_size"] = np.array(vr.drop_size)
+    save("views.npz", **arrays)
+
+
+# --------------------------------------------------------------------------- #
 # F4: samplers (src/rl8/distributions.py:113-170 -> torch.distributions)
 # --------------------------------------------------------------------------- #
 def draw_exponential_like(probs: torch.Tensor) -> torch.Tensor:
@@ -537,6 +597,9 @@ def gen_trace(name, env_cls, config_kwargs, iterations=2, recurrent=False) -> No
 
 
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "views":
+        gen_views()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "classic":
         gen_classic_env_steps()
         return
@@ -554,6 +617,7 @@ def main() -> None:
     gen_ppo_losses()
     gen_env_steps()
     gen_classic_env_steps()
+    gen_views()
     gen_samplers()
     gen_trace("trace_ff_discrete.npz", DiscreteDummyEnv, {})
     gen_trace(
