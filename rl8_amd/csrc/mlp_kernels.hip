@@ -133,6 +133,22 @@ __device__ __forceinline__ void load_a(AFrag &f, const float *__restrict__ a0p, 
 
 __device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 
+// Kernel-tuning builds only (-DRL8_PHASE_TRACE): shader-clock stamps at the phase
+// boundaries of the tower kernels, tile iterations 4..7 of every workgroup, read
+// back with rl8_debug_phase_trace().  Compiled out of the shipped library.
+#ifdef RL8_PHASE_TRACE
+constexpr int kTraceSlots = 12, kTraceTiles = 4;
+__device__ unsigned long long g_phase_trace[512 * 4 * kTraceTiles * kTraceSlots];
+__device__ __forceinline__ void trace_stamp(int iteration, int slot) {
+  if (iteration >= 4 && iteration < 4 + kTraceTiles && (threadIdx.x & 63) == 0)
+    g_phase_trace[((blockIdx.x * 4 + (threadIdx.x >> 6)) * kTraceTiles + (iteration - 4)) * kTraceSlots + slot] =
+        __builtin_amdgcn_s_memtime();
+}
+#define RL8_TRACE(iteration, slot) trace_stamp(iteration, slot)
+#else
+#define RL8_TRACE(iteration, slot)
+#endif
+
 // max(v, 0) as exactly one v_max_f32 (fmaxf() costs a second, canonicalising,
 // v_max on values the compiler cannot prove quiet; NaN -> 0 either way).
 __device__ __forceinline__ float relu1(float v) {
@@ -172,6 +188,8 @@ __device__ __forceinline__ void mma_frag(const AFrag &fa, const BFrag &fb, f32x1
 // those stores have drained to L2 (~1 us); requested ahead of them it is ready
 // when the loop starts.  Inside the loop B fragments run three sets deep (two
 // groups = ~0.9 us ahead), A fragments (LDS) two sets.
+constexpr int kValuPhasePriority = 2;
+
 struct TileGemm {
   __amdgpu_buffer_rsrc_t bp;
   int bvoff, a_off;
@@ -196,6 +214,14 @@ struct TileGemm {
   }
 
   __device__ __forceinline__ void run(const float *__restrict__ a_tile, f32x16 (&acc)[2][2]) {
+    // Wave priority: the matrix loop runs at the lowest priority and every VALU
+    // phase at a raised one.  Two workgroups share each SIMD; at equal priority
+    // the arbiter alternates one workgroup's VALU instructions with the other's
+    // MFMAs one for one, and each such switch costs ~17 cycles of the matrix pipe
+    // (measured with phase timestamps: a 140-instruction VALU phase took 9 000
+    // cycles).  Raised, the VALU phase issues as a burst (~5 cycles per
+    // instruction) and the matrix wave simply resumes behind it.
+    __builtin_amdgcn_s_setprio(0);
     const float *a0p = a_tile + a_off;
     AFrag a[2];
     load_a(a[0], a0p, 0);
@@ -219,6 +245,7 @@ struct TileGemm {
     // kGroups = 32 = 5 * 6 + 2
     mma_frag<false>(a[0], b[0], acc);
     mma_frag<false>(a[1], b[1], acc);
+    __builtin_amdgcn_s_setprio(kValuPhasePriority);
   }
 };
 
@@ -244,6 +271,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
   // inputs / heads it also hoists hundreds of LDS reads into registers.
   constexpr int kLayer1Unroll = kIn <= 2 ? kTileRows : 8;
   constexpr int kHeadUnroll = kOut <= 2 ? 64 : 8;
+  constexpr int kIlp = 8;  // independent rows per stage of a VALU phase
   const int d_in = DIN > 0 ? DIN : d_in_rt;
   const int n_out = NOUT > 0 ? NOUT : n_out_rt;
   extern __shared__ float lds[];
@@ -272,6 +300,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
 #pragma unroll
   for (int q = 0; q < kOut; ++q) b3r[q] = q < n_out ? b3[q] : 0.0f;
   TileGemm gemm(buffer_rsrc(w2p, kHidden * kHidden * 4), wave, lane);
+  __builtin_amdgcn_s_setprio(kValuPhasePriority);
   if constexpr (DIN == 0) {
     for (int idx = tid; idx < kTileRows * kMaxIn; idx += kBlock) xs[idx] = 0.0f;
   }
@@ -293,7 +322,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
   };
   if ((int64_t)blockIdx.x < tiles) fetch_x(blockIdx.x);
 
+  [[maybe_unused]] int iteration = -1;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    ++iteration;
+    RL8_TRACE(iteration, 0);
     const int64_t r0 = tile * kTileRows;
     const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
     // Stores of this tile's h1 / h2 rows: descriptor based at the tile, sized to
@@ -310,56 +342,88 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
       }
     }
     __syncthreads();
+    RL8_TRACE(iteration, 1);
     gemm.prefetch();  // first weight fragments, requested ahead of this tile's h1 stores
     // Layer 1 (VALU): thread = output column; per row d_in fmas + one max, the
-    // observation from a broadcast LDS read, offsets all immediates (fully
-    // unrolled for the narrow inputs; wider ones would hoist 64 x d_in LDS reads
-    // into registers and spill).
-#pragma unroll kLayer1Unroll
-    for (int s = 0; s < kTileRows; ++s) {
-      float v = b1r;
+    // observation from a broadcast LDS read, offsets all immediates.
+    // Blocks of kIlp rows, stage by stage: a wave issues in program order, and a
+    // dependent pair back to back leaves a gap in which the SIMD's other wave
+    // starts a 64-cycle MFMA -- measured, a chain-ordered VALU phase advanced one
+    // instruction per MFMA of its neighbour (~80 cycles each).  Independent
+    // instructions in a row issue as a burst instead.
+#pragma unroll kLayer1Unroll / kIlp
+    for (int s0 = 0; s0 < kTileRows; s0 += kIlp) {
+      float v[kIlp];
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) v = __builtin_fmaf(xs[s * kIn + i], w1r[i], v);
-      v = relu1(v);
-      ht[s * kLdsStride + tid] = v;
-      if constexpr (SAVE && !(kDiagSkip & 32)) buffer_store_f32(v, h1rsrc, tid * 4, s * (kHidden * 4));
+      for (int u = 0; u < kIlp; ++u) v[u] = b1r;
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) {
+        float xv[kIlp];
+#pragma unroll
+        for (int u = 0; u < kIlp; ++u) xv[u] = xs[(s0 + u) * kIn + i];
+#pragma unroll
+        for (int u = 0; u < kIlp; ++u) v[u] = __builtin_fmaf(xv[u], w1r[i], v[u]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kIlp; ++u) v[u] = relu1(v[u]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kIlp; ++u) {
+        ht[(s0 + u) * kLdsStride + tid] = v[u];
+        if constexpr (SAVE && !(kDiagSkip & 32)) buffer_store_f32(v[u], h1rsrc, tid * 4, (s0 + u) * (kHidden * 4));
+      }
     }
+    RL8_TRACE(iteration, 2);
     __syncthreads();
+    RL8_TRACE(iteration, 3);
     if (tile + gridDim.x < tiles) fetch_x(tile + gridDim.x);  // lands during the matrix phase
     // Layer 2 (MFMA).
     f32x16 acc[2][2];
     gemm.run(ht, acc);
+    RL8_TRACE(iteration, 4);
     __syncthreads();  // every wave has read all of h1: the tile may be overwritten
+    RL8_TRACE(iteration, 5);
     // bias (packed adds over register pairs) + ReLU, accumulators -> h2 (in place
     // of h1) and, when saving, straight to HBM (each store covers two 128-byte
-    // row segments).
+    // row segments).  Stage by stage over 16 values at a time (see layer 1).
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt) {
+        const int j = 64 * wave + 32 * nt + (lane & 31);
+        f32x2 pre[8];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int j = 64 * wave + 32 * nt + (lane & 31);
-          const f32x2 pre = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{b2r[nt], b2r[nt]};
+        for (int r = 0; r < 16; r += 2)
+          pre[r / 2] = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{b2r[nt], b2r[nt]};
+        __builtin_amdgcn_sched_barrier(0);
+        float v[16];
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int sr = 32 * mt + ((r + u) & 3) + 8 * ((r + u) >> 2);  // + 4*hh
-            const float v = relu1(pre[u]);
-            ht[(sr + 4 * hh) * kLdsStride + j] = v;
-            if constexpr (SAVE && !(kDiagSkip & 8))
-              buffer_store_f32(v, h2rsrc, (4 * hh * kHidden + j) * 4, sr * (kHidden * 4));
-          }
+        for (int r = 0; r < 16; ++r) v[r] = relu1(pre[r / 2][r & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int sr = 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
+          ht[(sr + 4 * hh) * kLdsStride + j] = v[r];
+          if constexpr (SAVE && !(kDiagSkip & 8))
+            buffer_store_f32(v[r], h2rsrc, (4 * hh * kHidden + j) * 4, sr * (kHidden * 4));
         }
+      }
+    RL8_TRACE(iteration, 6);
     __syncthreads();
+    RL8_TRACE(iteration, 7);
     // Head (VALU): 4 lanes per row; lane (a, q4) of wave w owns row 4a + w and the
     // units j = q4 (mod 4) -- LDS bank 4a + q4 + const, so the 64 lanes hit 64
     // different banks with immediate offsets only -- one packed fma per unit for
     // a pair of outputs, then two lane shuffles.
     {
       const int s = 4 * (lane >> 2) + wave, q4 = lane & 3;
-      outvec o;
+      // four accumulator sets so that consecutive fmas are independent
+      outvec oacc[4];
 #pragma unroll
-      for (int q = 0; q < kOut; ++q) o[q] = 0.0f;
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < kOut; ++q) oacc[c][q] = 0.0f;
       const float *row = ht + s * kLdsStride + q4;
       const outvec *wq = reinterpret_cast<const outvec *>(w3s) + q4;
 #pragma unroll kHeadUnroll
@@ -369,10 +433,11 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
 #pragma unroll
         for (int q = 0; q < kOut; ++q) hvv[q] = hv;
         if constexpr (kOut == 1)
-          o[0] = __builtin_fmaf(hv, wq[4 * jj][0], o[0]);
+          oacc[jj & 3][0] = __builtin_fmaf(hv, wq[4 * jj][0], oacc[jj & 3][0]);
         else
-          o = __builtin_elementwise_fma(hvv, wq[4 * jj], o);
+          oacc[jj & 3] = __builtin_elementwise_fma(hvv, wq[4 * jj], oacc[jj & 3]);
       }
+      const outvec o = (oacc[0] + oacc[1]) + (oacc[2] + oacc[3]);
 #pragma unroll
       for (int q = 0; q < kOut; ++q) {
         float v = o[q];
@@ -381,6 +446,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_forward_kernel(
         if (q < n_out && q4 == 0 && s < rows) out[(r0 + s) * n_out + q] = v + b3r[q];
       }
     }
+    RL8_TRACE(iteration, 8);
   }
 }
 
@@ -422,16 +488,27 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   for (int q = 0; q < kOut; ++q) w3r[q] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
   // Running sums owned by this thread; pairs = (even rows, odd rows) or
   // (column nt = 0, column nt = 1), folded once at the end.
-  f32x2 dw3[kOut], db2 = {0.0f, 0.0f};
+  constexpr int kPairs = kOut <= 2 ? 4 : 2;  // row pairs per block of phase 1 (one accumulator set each)
+  constexpr int kSets = 4;                   // accumulator sets of phase 3
+  f32x2 dw3[kOut][kPairs], db2[kPairs];
 #pragma unroll
-  for (int q = 0; q < kOut; ++q) dw3[q] = f32x2{0.0f, 0.0f};
-  f32x2 dw1[kIn], db1 = {0.0f, 0.0f};  // columns 64*wave + 32*nt + (lane&31), this half's rows
+  for (int u = 0; u < kPairs; ++u) {
+    db2[u] = f32x2{0.0f, 0.0f};
 #pragma unroll
-  for (int c = 0; c < kIn; ++c) dw1[c] = f32x2{0.0f, 0.0f};
+    for (int q = 0; q < kOut; ++q) dw3[q][u] = f32x2{0.0f, 0.0f};
+  }
+  f32x2 dw1[kIn][kSets], db1[kSets];  // columns 64*wave + 32*nt + (lane&31), this half's rows
+#pragma unroll
+  for (int c = 0; c < kSets; ++c) {
+    db1[c] = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < kIn; ++i) dw1[i][c] = f32x2{0.0f, 0.0f};
+  }
   constexpr int kXPerThread = (kTileRows * kIn + kBlock - 1) / kBlock;
   constexpr int kDoutPerThread = (kTileRows * kOut + kBlock - 1) / kBlock;
   float db3 = 0.0f;  // output tid % kOut, this thread's share of the rows
   TileGemm gemm(buffer_rsrc(w2tp, kHidden * kHidden * 4), wave, lane);
+  __builtin_amdgcn_s_setprio(kValuPhasePriority);
   if constexpr (DIN == 0) {
     for (int idx = tid; idx < 2 * kTileRows * kMaxIn; idx += kBlock) xs0[idx] = 0.0f;
     __syncthreads();
@@ -474,7 +551,10 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   };
   if ((int64_t)blockIdx.x < tiles) request_tile(blockIdx.x);
   int parity = 0;
+  [[maybe_unused]] int iteration = -1;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, parity ^= 1) {
+    ++iteration;
+    RL8_TRACE(iteration, 0);
     const int64_t r0 = tile * kTileRows;
     const int rows = (int)((m - r0) < kTileRows ? (m - r0) : kTileRows);
     const __amdgpu_buffer_rsrc_t h1rsrc = buffer_rsrc(h1 + r0 * kHidden, rows * kHidden * 4);
@@ -499,7 +579,9 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       }
     }
     wait_vmcnt0();    // this wave's h2 rows have landed
+    RL8_TRACE(iteration, 1);
     __syncthreads();  // ... everyone's have; xs / ds are written
+    RL8_TRACE(iteration, 2);
     float h1a[2][2][16];
     auto fetch_h1 = [&](int mt) {
 #pragma unroll
@@ -513,71 +595,120 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     };
     gemm.prefetch();
     fetch_h1(0);
-    // Phase 1 (VALU, thread = column j, two rows per step): dZ2 and the head
-    // gradients.  (Unrolled by 8 steps, not fully: the scheduler otherwise hoists
-    // every LDS read of the phase into registers and spills.)
-#pragma unroll 8
-    for (int s = 0; s < kTileRows; s += 2) {
-      const f32x2 hv = {zt[s * kLdsStride + tid], zt[(s + 1) * kLdsStride + tid]};
-      f32x2 g = {0.0f, 0.0f};
+    // Phase 1 (VALU, thread = column j, two rows per packed op): dZ2 and the head
+    // gradients.  Four row pairs per block, stage by stage, with one accumulator
+    // set per pair: consecutive instructions are independent, so the phase
+    // issues as a burst (see the forward kernel's layer 1).  (Blocks, not a full
+    // unroll: the scheduler would hoist every LDS read of the phase and spill.)
+#pragma unroll 2
+    for (int s0 = 0; s0 < kTileRows; s0 += 2 * kPairs) {
+      f32x2 hv[kPairs], d[kOut][kPairs], g[kPairs];
 #pragma unroll
-      for (int q = 0; q < kOut; ++q) {
-        const f32x2 d = *reinterpret_cast<const f32x2 *>(ds + q * kTileRows + s);
-        g = __builtin_elementwise_fma(d, f32x2{w3r[q], w3r[q]}, g);
-        dw3[q] = __builtin_elementwise_fma(d, hv, dw3[q]);
+      for (int u = 0; u < kPairs; ++u) {
+        const int s = s0 + 2 * u;
+        hv[u] = f32x2{zt[s * kLdsStride + tid], zt[(s + 1) * kLdsStride + tid]};
+#pragma unroll
+        for (int q = 0; q < kOut; ++q) d[q][u] = *reinterpret_cast<const f32x2 *>(ds + q * kTileRows + s);
       }
-      const f32x2 dz = {hv.x > 0.0f ? g.x : 0.0f, hv.y > 0.0f ? g.y : 0.0f};
-      db2 += dz;
-      zt[s * kLdsStride + tid] = dz.x;
-      zt[(s + 1) * kLdsStride + tid] = dz.y;
-      if constexpr (!(kDiagSkip & 128)) {
-        buffer_store_f32(dz.x, dzrsrc, tid * 4, s * (kHidden * 4));
-        buffer_store_f32(dz.y, dzrsrc, tid * 4, (s + 1) * (kHidden * 4));
+#pragma unroll
+      for (int u = 0; u < kPairs; ++u) g[u] = d[0][u] * f32x2{w3r[0], w3r[0]};
+#pragma unroll
+      for (int q = 1; q < kOut; ++q)
+#pragma unroll
+        for (int u = 0; u < kPairs; ++u) g[u] = __builtin_elementwise_fma(d[q][u], f32x2{w3r[q], w3r[q]}, g[u]);
+#pragma unroll
+      for (int q = 0; q < kOut; ++q)
+#pragma unroll
+        for (int u = 0; u < kPairs; ++u) dw3[q][u] = __builtin_elementwise_fma(d[q][u], hv[u], dw3[q][u]);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x2 dz[kPairs];
+#pragma unroll
+      for (int u = 0; u < kPairs; ++u)
+        dz[u] = f32x2{hv[u].x > 0.0f ? g[u].x : 0.0f, hv[u].y > 0.0f ? g[u].y : 0.0f};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kPairs; ++u) db2[u] += dz[u];
+#pragma unroll
+      for (int u = 0; u < kPairs; ++u) {
+        const int s = s0 + 2 * u;
+        zt[s * kLdsStride + tid] = dz[u].x;
+        zt[(s + 1) * kLdsStride + tid] = dz[u].y;
+        if constexpr (!(kDiagSkip & 128)) {
+          buffer_store_f32(dz[u].x, dzrsrc, tid * 4, s * (kHidden * 4));
+          buffer_store_f32(dz[u].y, dzrsrc, tid * 4, (s + 1) * (kHidden * 4));
+        }
       }
     }
+    RL8_TRACE(iteration, 3);
     __syncthreads();
+    RL8_TRACE(iteration, 4);
     // Phase 2 (MFMA): dH1 = dZ2 x W2.
     f32x16 acc[2][2];
     gemm.run(zt, acc);
+    RL8_TRACE(iteration, 5);
     __syncthreads();  // every wave is done with the dZ2 tile: the next h2 tile may land
+    RL8_TRACE(iteration, 6);
     if (tile + gridDim.x < tiles) request_tile(tile + gridDim.x);
     fetch_h1(1);
+    RL8_TRACE(iteration, 7);
     // Phase 3: dZ1 = dH1 * (h1 > 0); fold into dW1 / db1, the two columns of a
-    // lane as one packed op.
+    // lane as one packed op; four values per stage, one accumulator set each.
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int s = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const f32x2 dz = {h1a[mt][0][r] > 0.0f ? acc[mt][0][r] : 0.0f,
-                          h1a[mt][1][r] > 0.0f ? acc[mt][1][r] : 0.0f};
-        db1 += dz;
+      for (int r0 = 0; r0 < 16; r0 += kSets) {
+        f32x2 dz[kSets];
 #pragma unroll
-        for (int c = 0; c < kIn; ++c) {
-          const float xv = xs[s * kIn + c];
-          dw1[c] = __builtin_elementwise_fma(dz, f32x2{xv, xv}, dw1[c]);
-        }
+        for (int u = 0; u < kSets; ++u)
+          dz[u] = f32x2{h1a[mt][0][r0 + u] > 0.0f ? acc[mt][0][r0 + u] : 0.0f,
+                        h1a[mt][1][r0 + u] > 0.0f ? acc[mt][1][r0 + u] : 0.0f};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kSets; ++u) db1[u] += dz[u];
+#pragma unroll
+        for (int c = 0; c < kIn; ++c)
+#pragma unroll
+          for (int u = 0; u < kSets; ++u) {
+            const int r = r0 + u;
+            const int s = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float xv = xs[s * kIn + c];
+            dw1[c][u] = __builtin_elementwise_fma(dz[u], f32x2{xv, xv}, dw1[c][u]);
+          }
       }
+    RL8_TRACE(iteration, 8);
   }
   // Workgroup partial row.
   float *row = partials + (int64_t)blockIdx.x * partial_stride;
   const int off_db1 = kHidden * d_in, off_db2 = off_db1 + kHidden, off_dw3 = off_db2 + kHidden;
   const int off_db3 = off_dw3 + n_out * kHidden;
+  // fold the accumulator sets (fixed order)
+  f32x2 db1s = db1[0], db2s = db2[0];
+#pragma unroll
+  for (int c = 1; c < kSets; ++c) db1s += db1[c];
+#pragma unroll
+  for (int u = 1; u < kPairs; ++u) db2s += db2[u];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int i = 64 * wave + 32 * nt + (lane & 31);
-    const float b = db1[nt] + __shfl_xor(db1[nt], 32, kWave);
+    const float b = db1s[nt] + __shfl_xor(db1s[nt], 32, kWave);
     if (hh == 0) row[off_db1 + i] = b;
 #pragma unroll
     for (int c = 0; c < kIn; ++c) {
-      const float w = dw1[c][nt] + __shfl_xor(dw1[c][nt], 32, kWave);
+      f32x2 ws = dw1[c][0];
+#pragma unroll
+      for (int u = 1; u < kSets; ++u) ws += dw1[c][u];
+      const float w = ws[nt] + __shfl_xor(ws[nt], 32, kWave);
       if (hh == 0 && c < d_in) row[i * d_in + c] = w;
     }
   }
-  row[off_db2 + tid] = db2.x + db2.y;
+  row[off_db2 + tid] = db2s.x + db2s.y;
 #pragma unroll
-  for (int q = 0; q < kOut; ++q)
-    if (q < n_out) row[off_dw3 + q * kHidden + tid] = dw3[q].x + dw3[q].y;
+  for (int q = 0; q < kOut; ++q) {
+    f32x2 ws = dw3[q][0];
+#pragma unroll
+    for (int u = 1; u < kPairs; ++u) ws += dw3[q][u];
+    if (q < n_out) row[off_dw3 + q * kHidden + tid] = ws.x + ws.y;
+  }
   // db3: thread t holds a share of output t % kOut; fold through LDS.
   __syncthreads();
   ds0[tid] = db3;
@@ -600,6 +731,12 @@ inline size_t mlp_forward_lds_bytes() {
 }  // namespace rl8
 
 using namespace rl8;
+
+#ifdef RL8_PHASE_TRACE
+RL8_API int rl8_debug_phase_trace(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_phase_trace), sizeof(g_phase_trace));
+}
+#endif
 
 RL8_API int rl8_mlp_pack_w2_f32(const float *w2, float *w2_packed, int transposed, void *stream) {
   if (!w2 || !w2_packed) return RL8_ENULL;
