@@ -381,7 +381,9 @@ class Algorithm:
         """The model reads ``obs`` as is (no rolling windows): observations can be
         handed to it as ``[N, ...]`` slabs without going through the view
         requirements."""
-        views = self.policy.model.view_requirements
+        views = getattr(self.policy.model, "view_requirements", None)
+        if views is None:  # recurrent models take observations as they are
+            return True
         return set(views) == {DataKeys.OBS} and all(v.is_identity for v in views.values())
 
     def _forward(self, obs: torch.Tensor, *, deterministic: bool) -> tuple[TensorDict, torch.Tensor]:
