@@ -73,6 +73,11 @@ PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in
     "rollout_step_dummy": ("rollout_step_dummy_kernel", 1 << 20),
     "rollout_stats": ("rollout_stats_kernel", (1 << 20) * 32),
     "gather_minibatch": ("gather_minibatch_kernel", 1 << 22),
+    # the towers, profiled at 2^20 rows (policy tower of the discrete dummy env)
+    "mlp_tower_forward": ("mlp_tower_forward_kernel<1, 2, false>", 1 << 20),
+    "mlp_tower_forward_save": ("mlp_tower_forward_kernel<1, 2, true>", 1 << 20),
+    "mlp_tower_backward": ("mlp_tower_backward_kernel<1, 2>", 1 << 20),
+    "mlp_wgrad": ("mlp_wgrad_kernel", 1 << 20),
 }
 
 
@@ -210,6 +215,7 @@ def main() -> None:
                 "algorithmic_flop_per_launch": flops_per_launch,
                 "achieved_TFLOPs": round(tflops, 2),
                 "frac_of_f32_mfma_peak": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                "pmc_traffic_bytes_per_launch": pmc_traffic(name, rec["units_per_launch"]),
             }
             continue
         bytes_per_launch = ALGORITHMIC_BYTES.get(name, 0.0) * rec["units_per_launch"]
@@ -244,7 +250,7 @@ def main() -> None:
                 "avg_launch_ms": top["avg_ms"],
                 "launches": top["launches"],
                 "share_of_step_ms": round(top["total_ms"] / args.steps, 2),
-                "traffic": None,
+                "traffic": top["pmc_traffic_bytes_per_launch"],
             }
         else:
             roofline = None

@@ -764,7 +764,7 @@ def mlp_tower_forward(
     out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
     h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
     h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
-    with _timed("mlp_tower_forward", m):
+    with _timed("mlp_tower_forward_save" if save else "mlp_tower_forward", m):
         _check(
             load().rl8_mlp_tower_forward_f32(
                 _ptr(x), m, d_in, _ptr(w1.detach()), _ptr(b1.detach()), _ptr(w2_packed), _ptr(b2.detach()),

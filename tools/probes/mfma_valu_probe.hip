@@ -97,6 +97,70 @@ void run(const char *name, int threads, float *out, int iters) {
          tflops, best * 1e6 / mfma_per_simd);
 }
 
+// K buffer loads (dword, or dwordx4 with MODE4 = true) per MFMA from the same
+// wave, out of a 64-KiB L2-resident buffer: what a vector-memory instruction
+// costs the matrix pipe.
+template <int K, bool X4>
+__global__ __launch_bounds__(256) void probe_vmem(const float *src, float *out, int iters, int flag) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  float a = 1.0f + threadIdx.x * 1e-9f, b = 1e-9f;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 65536, 0x00020000);
+  const int voff = (threadIdx.x & 63) * (X4 ? 16 : 4);
+  float sink = 0.0f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if constexpr (X4) {
+          typedef float f4 __attribute__((ext_vector_type(4)));
+          f4 t;
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(t) : "v"(voff), "s"(rs), "n"(k * 1024));
+          asm volatile("" ::"v"(t));
+        } else {
+          float t;
+          asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(t) : "v"(voff), "s"(rs), "n"(k * 256));
+          asm volatile("" ::"v"(t));
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(8)");
+  }
+  asm volatile("s_waitcnt vmcnt(0)");
+  if (flag) {
+    float s = sink;
+    for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  }
+}
+
+template <int K, bool X4>
+void run_vmem(const float *src, float *out, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) probe_vmem<K, X4><<<256, 256>>>(src, out, iters, 0);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0);
+    probe_vmem<K, X4><<<256, 256>>>(src, out, iters, 0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double mfmas = 256.0 * 4 * iters * 4;
+  printf("%-28s threads=256 K=%2d  %8.3f ms  %7.1f TFLOP/s  %6.1f ns/MFMA/SIMD\n",
+         X4 ? "same wave, buffer dwordx4" : "same wave, buffer dword", K, best, mfmas * 4096.0 / (best * 1e-3) / 1e12,
+         best * 1e6 / (iters * 4.0));
+}
+
 // Power: the same MFMA stream on operands that change every instruction
 // (pseudo-random floats) -- what the matrix pipe sustains on real data.
 __global__ __launch_bounds__(256) void probe_random(float *out, int iters, int flag) {
@@ -178,6 +242,15 @@ int main() {
   run<2, 2>("same wave, LDS reads", 256, out, iters);
   run<4, 2>("same wave, LDS reads", 256, out, iters);
   run<8, 2>("same wave, LDS reads", 256, out, iters);
+  float *src;
+  hipMalloc(&src, 65536);
+  hipMemset(src, 0, 65536);
+  run_vmem<1, false>(src, out, iters);
+  run_vmem<2, false>(src, out, iters);
+  run_vmem<4, false>(src, out, iters);
+  run_vmem<1, true>(src, out, iters);
+  run_vmem<2, true>(src, out, iters);
+  hipFree(src);
   hipFree(out);
   return 0;
 }

@@ -27,7 +27,7 @@ def short(name: str) -> str:
 def stats(src: str, dst: str, keep: int = 25) -> None:
     rows = list(csv.DictReader(open(src)))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
-    picked = rows[:keep] + [r for r in rows[keep:] if "rl8::" in r["Name"]]
+    picked = rows[:keep] + [r for r in rows[keep:] if "rl8::" in r["Name"] or "mlp_" in r["Name"]]
     with open(dst, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "avg_us", "total_ms", "percent_of_kernel_time"])
@@ -48,7 +48,7 @@ def pmc(fetch_csv: str, write_csv: str, dst: str) -> None:
         agg = collections.defaultdict(list)
         grid = {}
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == counter and "rl8::" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and ("rl8::" in r["Kernel_Name"] or "mlp_" in r["Kernel_Name"]):
                 k = short(r["Kernel_Name"])
                 agg[k].append(float(r["Counter_Value"]))
                 grid[k] = int(r["Grid_Size"])
