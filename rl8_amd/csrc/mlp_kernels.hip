@@ -149,6 +149,23 @@ __device__ __forceinline__ void trace_stamp(int iteration, int slot) {
 #define RL8_TRACE(iteration, slot)
 #endif
 
+// ReLU gates of the backward pass, `gate > 0 ? value : 0`, as a compare into its
+// OWN SGPR pair and a select on it.  The compiler funnels every compare through
+// vcc, which chains compare -> (2 wait states) -> select -> compare ...; each
+// link of such a chain is a gap in which the SIMD's other wave starts an MFMA.
+// Callers issue a batch of compares, then the batch of selects (>= 2
+// instructions apart, the gfx940-family VALU-SGPR read hazard).
+__device__ __forceinline__ unsigned long long positive_mask(float gate) {
+  unsigned long long m;
+  asm("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(gate));
+  return m;
+}
+__device__ __forceinline__ float select_or_zero(unsigned long long mask, float value) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(value), "s"(mask));
+  return r;
+}
+
 // max(v, 0) as exactly one v_max_f32 (fmaxf() costs a second, canonicalising,
 // v_max on values the compiler cannot prove quiet; NaN -> 0 either way).
 __device__ __forceinline__ float relu1(float v) {
@@ -622,9 +639,18 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
         for (int u = 0; u < kPairs; ++u) dw3[q][u] = __builtin_elementwise_fma(d[q][u], hv[u], dw3[q][u]);
       __builtin_amdgcn_sched_barrier(0);
       f32x2 dz[kPairs];
+      {
+        unsigned long long gate[kPairs][2];
 #pragma unroll
-      for (int u = 0; u < kPairs; ++u)
-        dz[u] = f32x2{hv[u].x > 0.0f ? g[u].x : 0.0f, hv[u].y > 0.0f ? g[u].y : 0.0f};
+        for (int u = 0; u < kPairs; ++u) {
+          gate[u][0] = positive_mask(hv[u].x);
+          gate[u][1] = positive_mask(hv[u].y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kPairs; ++u)
+          dz[u] = f32x2{select_or_zero(gate[u][0], g[u].x), select_or_zero(gate[u][1], g[u].y)};
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < kPairs; ++u) db2[u] += dz[u];
@@ -658,10 +684,19 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
       for (int r0 = 0; r0 < 16; r0 += kSets) {
         f32x2 dz[kSets];
+        {
+          unsigned long long gate[kSets][2];
 #pragma unroll
-        for (int u = 0; u < kSets; ++u)
-          dz[u] = f32x2{h1a[mt][0][r0 + u] > 0.0f ? acc[mt][0][r0 + u] : 0.0f,
-                        h1a[mt][1][r0 + u] > 0.0f ? acc[mt][1][r0 + u] : 0.0f};
+          for (int u = 0; u < kSets; ++u) {
+            gate[u][0] = positive_mask(h1a[mt][0][r0 + u]);
+            gate[u][1] = positive_mask(h1a[mt][1][r0 + u]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < kSets; ++u)
+            dz[u] = f32x2{select_or_zero(gate[u][0], acc[mt][0][r0 + u]),
+                          select_or_zero(gate[u][1], acc[mt][1][r0 + u])};
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < kSets; ++u) db1[u] += dz[u];
