@@ -41,8 +41,12 @@ def _packed(layer: nn.Linear, transposed: bool) -> torch.Tensor:
 
 class _FusedTower(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, layer2):  # type: ignore[override]
-        need_grad = any(ctx.needs_input_grad[1:7])
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, layer2, grad_mode):  # type: ignore[override]
+        # needs_input_grad reflects the parameters' requires_grad even when the
+        # caller runs under no_grad (rollouts), and inside forward() grad mode is
+        # always off: the caller's grad mode comes in as an argument, so that
+        # activations are kept only when a backward can follow.
+        need_grad = grad_mode and any(ctx.needs_input_grad[1:7])
         out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
         if need_grad:
             ctx.layer2 = layer2
@@ -53,7 +57,7 @@ class _FusedTower(torch.autograd.Function):
     def backward(ctx, dout):  # type: ignore[override]
         x, h1, h2, w3 = ctx.saved_tensors
         g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True), w3)
-        return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None
+        return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None
 
 
 def _match(trunk: nn.Module, heads: Sequence[nn.Linear]) -> None | tuple[nn.Linear, nn.Linear]:
@@ -95,4 +99,5 @@ def tower_forward(trunk: nn.Sequential, heads: Sequence[nn.Linear], x: torch.Ten
     else:
         w3 = torch.cat([h.weight for h in heads], 0)
         b3 = torch.cat([h.bias for h in heads], 0)
-    return _FusedTower.apply(x.contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3, l2)
+    return _FusedTower.apply(x.contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3, l2,
+                             torch.is_grad_enabled())
