@@ -18,7 +18,7 @@
 // The k index is permuted so that each lane's four consecutive k-steps use four
 // consecutive floats: k = 8g + 4*(l>>5) + e, e = 0..3 (sums are order-free up to
 // fp32 rounding).  W2 is pre-packed in that fragment order (rl8_mlp_pack_w2_f32)
-// so a wave's B fragment for (N-tile, g) is one contiguous 1-KiB load.
+// so a wave's B operand for one MFMA is one coalesced 256-byte load.
 //
 // LDS: one [64][257] fp32 tile (h1, overwritten by h2); the odd row stride makes
 // both the row walks of the MFMA A operand and the column walks of the VALU
@@ -103,9 +103,8 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_w2t_kernel(const float *__res
 //   acc[m][n] = A_tile[32m + i][k] * Bp[(N-tile 2*wave + n)][k]
 // A_tile: LDS [64][257]; Bp: fragment-packed [8][32][4][64] floats behind a buffer
 // descriptor.  Wave `wave` produces output columns [64*wave, 64*wave + 64).
-// Software-pipelined by hand, two k-groups per trip with two named register
-// sets: the B fragments (L2) and A fragments (LDS) of group g+1 are issued
-// before the 16 MFMAs of group g.
+// Software-pipelined by hand (struct TileGemm below).
+//
 // Operand fragments of one k-group: B (weights, through L2) and A (activations,
 // LDS) are prefetched at different distances, so they are separate sets.
 struct BFrag {

@@ -1,12 +1,18 @@
 #!/bin/bash
-# Kernel-tuning aid: builds variants of librl8_amd.so with one phase of the tower
-# forward kernel compiled out (RL8_DIAG_SKIP bits, see mlp_kernels.hip) into
-# build_diag/, to be timed with
-#   RL8_AMD_LIBRARY=build_diag/librl8_amd_skip<bits>.so python tools/kernel_microbench.py --only mlp_tower_forward
+# Kernel-tuning aid: experimental builds of librl8_amd.so (same ABI) into build_diag/.
+#   tools/diag_mlp.sh 64 128 256   one memory stream of a tower kernel compiled out
+#                                  (RL8_DIAG_SKIP bits, see mlp_kernels.hip), timed with
+#       RL8_AMD_LIBRARY=build_diag/librl8_amd_skip<bits>.so python tools/kernel_microbench.py --only mlp_tower_backward_fused
+#   tools/diag_mlp.sh trace        phase timestamps compiled in, read with tools/phase_trace.py
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_diag
-for bits in "$@"; do
-  make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/obj$bits" OUT="$PWD/build_diag/librl8_amd_skip$bits.so" \
-       FLAGS_EXTRA="-DRL8_DIAG_SKIP=$bits"
+for what in "$@"; do
+  if [ "$what" = trace ]; then
+    make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/objtrace" OUT="$PWD/build_diag/librl8_amd_trace.so" \
+         FLAGS_EXTRA="-DRL8_PHASE_TRACE"
+  else
+    make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/obj$what" OUT="$PWD/build_diag/librl8_amd_skip$what.so" \
+         FLAGS_EXTRA="-DRL8_DIAG_SKIP=$what"
+  fi
 done
