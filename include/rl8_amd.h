@@ -286,6 +286,19 @@ typedef struct {
 int rl8_gather_minibatch(const int64_t *index, int64_t m, int64_t h,
                          const rl8_gather_field *fields /*host*/, int n_fields, void *stream);
 
+/* The same gather for a buffer that is shuffled many times per step()
+ * (num_sgd_iters x num_minibatches): rl8_pack_samples lays the fields of every
+ * sample side by side once -- packed[s][...] for the reference's sample id
+ * s = env*H + t, t < h, row_words 4-byte words per sample (a multiple of 4, at most
+ * 32, at least the sum of the fields' row words, fields in the order given; `dst` of the
+ * fields is ignored) -- and rl8_gather_packed then reads one row per sample
+ * (`src`, `env_stride`, `time_stride` ignored): one random sector per sample
+ * instead of one per field. */
+int rl8_pack_samples(const rl8_gather_field *fields /*host*/, int n_fields, int64_t n, int64_t h,
+                     void *packed, int row_words, void *stream);
+int rl8_gather_packed(const int64_t *index, int64_t m, const void *packed, int row_words,
+                      const rl8_gather_field *fields /*host*/, int n_fields, void *stream);
+
 /* ---------------------------------------------------------------------- *
  * N1  Default policy / value tower, fused
  *      src/rl8/models/_feedforward.py:336-375 (DefaultDiscreteModel),

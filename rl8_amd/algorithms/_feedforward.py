@@ -646,6 +646,7 @@ class Algorithm:
             self.injected_permutations = None
             self._flat_full = None
             self._views_all = None
+            self._packed = None
             step_stats = stat_tracker.items()
         step_stats["profiling/step_ms"] = step_timer()
         return step_stats  # type: ignore[return-value]
@@ -689,11 +690,12 @@ class Algorithm:
             return
         local_mb = hp.sgd_minibatch_size // self.shards.world_size
         perm = self._permutation(sgd_iter, local_samples)
+        if getattr(self, "_packed", None) is None:
+            # the buffer is shuffled num_sgd_iters x num_minibatches times: lay each
+            # sample's fields side by side once, then every gather reads one row
+            self._packed = hip.PackedSamples(H, [self.buffer[k] for k in self.TRAIN_KEYS])
         for index in torch.split(perm, local_mb):
-            gathered = hip.gather_minibatch(
-                index.contiguous(), H, [self.buffer[k] for k in self.TRAIN_KEYS]
-            )
-            yield dict(zip(self.TRAIN_KEYS, gathered))
+            yield dict(zip(self.TRAIN_KEYS, self._packed.gather(index.contiguous())))
 
     def _iter_view_minibatches(self, sgd_iter: int):
         """Minibatches for models with rolling-window view requirements

@@ -147,6 +147,106 @@ __global__ __launch_bounds__(kBlock) void gather_minibatch_kernel(
   }
 }
 
+// K5b: packed sample rows.  A shuffled minibatch reads every field of a sample
+// from a different random address: five 4/8-byte reads, five 32/64-byte sectors,
+// ~12x the algorithmic bytes (PMC).  When a buffer is going to be shuffled
+// several times (num_sgd_iters x num_minibatches gathers per step()), the fields
+// of every sample are first laid side by side, once, in the reference's sample
+// order s = env*H + t; a minibatch then reads ONE 16-byte-aligned row per
+// sample.  pack: reads follow storage order (lanes along envs), each lane writes
+// its own row.  gather: each lane reads its row word by word (one sector, served
+// from L1 after the first touch) and writes the dense outputs.
+struct PackedArgs {
+  rl8_gather_field f[RL8_MAX_GATHER_FIELDS];
+  int n_fields;
+  int row_words;
+};
+
+// Both kernels move a row as 16-byte vectors (a random access costs the
+// texture-address unit one slot per lane and instruction, whatever its width:
+// word-by-word rows were address-bound, not HBM-bound) and stage it in a
+// thread-private LDS slot, which -- unlike registers -- can be indexed by the
+// run-time field offsets.  VECS = row_words / 4.
+template <int VECS>
+__global__ __launch_bounds__(kBlock) void pack_samples_kernel(int64_t n, int64_t h,
+                                                              uint32_t *__restrict__ packed,
+                                                              PackedArgs args) {
+  __shared__ float4 stage[kBlock * VECS];
+  float4 *mine = stage + threadIdx.x * VECS;
+  uint32_t *words_of_mine = reinterpret_cast<uint32_t *>(mine);
+  const int64_t total = n * h, stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+    const int64_t t = i / n, env = i - t * n;  // lanes along envs: storage order of a time-major buffer
+    int off = 0;
+#pragma unroll 1
+    for (int f = 0; f < args.n_fields; ++f) {
+      const rl8_gather_field &fd = args.f[f];
+      const int words = fd.row_elems * (fd.elem_bytes / 4);
+      const uint32_t *src = static_cast<const uint32_t *>(fd.src) +
+                            (env * fd.env_stride + t * fd.time_stride) * (fd.elem_bytes / 4);
+      for (int c = 0; c < words; ++c) words_of_mine[off + c] = src[c];
+      off += words;
+    }
+    float4 *row = reinterpret_cast<float4 *>(packed + (env * h + t) * args.row_words);
+#pragma unroll
+    for (int v = 0; v < VECS; ++v) row[v] = mine[v];
+  }
+}
+
+template <int VECS>
+__global__ __launch_bounds__(kBlock) void gather_packed_kernel(const int64_t *__restrict__ index,
+                                                               int64_t m,
+                                                               const uint32_t *__restrict__ packed,
+                                                               PackedArgs args) {
+  __shared__ float4 stage[kBlock * VECS];
+  float4 *mine = stage + threadIdx.x * VECS;
+  const uint32_t *words_of_mine = reinterpret_cast<const uint32_t *>(mine);
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) {
+    const float4 *row = reinterpret_cast<const float4 *>(packed + index[i] * args.row_words);
+#pragma unroll
+    for (int v = 0; v < VECS; ++v) mine[v] = row[v];
+    int off = 0;
+#pragma unroll 1
+    for (int f = 0; f < args.n_fields; ++f) {
+      const rl8_gather_field &fd = args.f[f];
+      const int words = fd.row_elems * (fd.elem_bytes / 4);
+      uint32_t *dst = static_cast<uint32_t *>(fd.dst) + i * words;
+      for (int c = 0; c < words; ++c) dst[c] = words_of_mine[off + c];
+      off += words;
+    }
+  }
+}
+
+constexpr int kMaxPackedVecs = 8;  // rows of up to 128 bytes
+
+template <int VECS>
+static void launch_packed(bool pack, int grid, hipStream_t s, int64_t n, int64_t h,
+                          const int64_t *index, int64_t m, uint32_t *packed,
+                          const PackedArgs &args) {
+  if (pack)
+    pack_samples_kernel<VECS><<<grid, kBlock, 0, s>>>(n, h, packed, args);
+  else
+    gather_packed_kernel<VECS><<<grid, kBlock, 0, s>>>(index, m, packed, args);
+}
+
+static int dispatch_packed(bool pack, int grid, hipStream_t s, int64_t n, int64_t h,
+                           const int64_t *index, int64_t m, uint32_t *packed,
+                           const PackedArgs &args) {
+  switch (args.row_words / 4) {
+    case 1: launch_packed<1>(pack, grid, s, n, h, index, m, packed, args); break;
+    case 2: launch_packed<2>(pack, grid, s, n, h, index, m, packed, args); break;
+    case 3: launch_packed<3>(pack, grid, s, n, h, index, m, packed, args); break;
+    case 4: launch_packed<4>(pack, grid, s, n, h, index, m, packed, args); break;
+    case 5: launch_packed<5>(pack, grid, s, n, h, index, m, packed, args); break;
+    case 6: launch_packed<6>(pack, grid, s, n, h, index, m, packed, args); break;
+    case 7: launch_packed<7>(pack, grid, s, n, h, index, m, packed, args); break;
+    case 8: launch_packed<8>(pack, grid, s, n, h, index, m, packed, args); break;
+    default: return RL8_ESIZE;
+  }
+  return launch_status();
+}
+
 // Wide rows (recurrent states: 1 KiB per layer): one wave per gathered row, 16 B
 // per lane, so each row moves as whole 1-KiB wave instructions.
 __global__ __launch_bounds__(kBlock) void gather_wide_rows_kernel(
@@ -230,4 +330,47 @@ RL8_API int rl8_gather_minibatch(const int64_t *index, int64_t m, int64_t h,
   if (args.n_fields > 0)
     gather_minibatch_kernel<<<grid_for(m, kBlock), kBlock, 0, s>>>(index, m, h, args);
   return launch_status();
+}
+
+static int packed_args(const rl8_gather_field *fields, int n_fields, int row_words, bool need_src,
+                       bool need_dst, PackedArgs *args) {
+  if (!fields) return RL8_ENULL;
+  if (n_fields <= 0 || n_fields > RL8_MAX_GATHER_FIELDS) return RL8_ESIZE;
+  int words = 0;
+  for (int f = 0; f < n_fields; ++f) {
+    const rl8_gather_field &fd = fields[f];
+    if ((need_src && !fd.src) || (need_dst && !fd.dst)) return RL8_ENULL;
+    if (fd.elem_bytes != 4 && fd.elem_bytes != 8) return RL8_ECONFIG;
+    if (fd.row_elems <= 0) return RL8_ESIZE;
+    words += fd.row_elems * (fd.elem_bytes / 4);
+    args->f[f] = fd;
+  }
+  if (row_words < words || row_words % 4 || row_words > 4 * kMaxPackedVecs) return RL8_ESIZE;
+  args->n_fields = n_fields;
+  args->row_words = row_words;
+  return RL8_OK;
+}
+
+RL8_API int rl8_pack_samples(const rl8_gather_field *fields, int n_fields, int64_t n, int64_t h,
+                             void *packed, int row_words, void *stream) {
+  if (!packed) return RL8_ENULL;
+  if (n <= 0 || h <= 0) return RL8_ESIZE;
+  if (!aligned16(packed)) return RL8_EALIGN;
+  PackedArgs args;
+  const int st = packed_args(fields, n_fields, row_words, true, false, &args);
+  if (st != RL8_OK) return st;
+  return dispatch_packed(true, grid_for(n * h, kBlock), (hipStream_t)stream, n, h, nullptr, 0,
+                         static_cast<uint32_t *>(packed), args);
+}
+
+RL8_API int rl8_gather_packed(const int64_t *index, int64_t m, const void *packed, int row_words,
+                              const rl8_gather_field *fields, int n_fields, void *stream) {
+  if (!index || !packed) return RL8_ENULL;
+  if (m <= 0) return RL8_ESIZE;
+  PackedArgs args;
+  const int st = packed_args(fields, n_fields, row_words, false, true, &args);
+  if (st != RL8_OK) return st;
+  if (!aligned16(packed)) return RL8_EALIGN;
+  return dispatch_packed(false, grid_for(m, kBlock), (hipStream_t)stream, 0, 0, index, m,
+                         const_cast<uint32_t *>(static_cast<const uint32_t *>(packed)), args);
 }

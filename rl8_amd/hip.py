@@ -118,6 +118,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_ppo_loss_categorical_fwd_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(PPOHparams), _vp, _vp, _vp, _vp, _vp],
     "rl8_ppo_loss_normal_fwd_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(PPOHparams), _vp, _vp, _vp, _vp, _vp, _vp],
     "rl8_gather_minibatch": [_vp, _i64, _i64, C.POINTER(GatherField), _i32, _vp],
+    "rl8_pack_samples": [_vp, _i32, _i64, _i64, _vp, _i32, _vp],
+    "rl8_gather_packed": [_vp, _i64, _vp, _i32, _vp, _i32, _vp],
     "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
     "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
@@ -725,6 +727,54 @@ def gather_minibatch(index: torch.Tensor, h: int, leaves: Sequence[torch.Tensor]
         _check(load().rl8_gather_minibatch(_ptr(index), m, h, fields, len(leaves), _stream()),
                "rl8_gather_minibatch")
     return outs
+
+
+class PackedSamples:
+    """The training fields of every sample of a rollout buffer, side by side in
+    the reference's sample order (``rl8_pack_samples``); ``gather(index)`` returns
+    the dense minibatch tensors, one per field."""
+
+    def __init__(self, h: int, leaves: Sequence[torch.Tensor]) -> None:
+        if not leaves or len(leaves) > MAX_GATHER_FIELDS:
+            raise ValueError(f"between 1 and {MAX_GATHER_FIELDS} leaves per pack")
+        n = leaves[0].shape[0]
+        self.fields = (GatherField * len(leaves))()
+        self.meta: list[tuple[tuple[int, ...], torch.dtype]] = []
+        words = 0
+        for i, leaf in enumerate(leaves):
+            if leaf.ndim < 2 or leaf.shape[0] != n or leaf.shape[1] < h:
+                raise ValueError("leaves must be [N, >= H, ...] views of one buffer")
+            if leaf.element_size() not in (4, 8):
+                raise TypeError("leaf elements must be 4 or 8 bytes wide")
+            trailing = tuple(leaf.shape[2:])
+            row = 1
+            for d in trailing:
+                row *= d
+            if leaf[0, 0].numel() and not leaf[0, 0].is_contiguous():
+                raise ValueError("leaf trailing dims must be dense")
+            self.fields[i] = GatherField(_ptr(leaf), None, leaf.stride(0), leaf.stride(1), row, leaf.element_size())
+            self.meta.append((trailing, leaf.dtype))
+            words += row * (leaf.element_size() // 4)
+        self.row_words = (words + 3) // 4 * 4
+        self.samples = n * h
+        self.device = leaves[0].device
+        self.packed = torch.empty(self.samples * self.row_words, dtype=torch.int32, device=self.device)
+        with _timed("pack_samples", self.samples):
+            _check(load().rl8_pack_samples(self.fields, len(leaves), n, h, _ptr(self.packed), self.row_words, _stream()),
+                   "rl8_pack_samples")
+
+    def gather(self, index: torch.Tensor) -> list[torch.Tensor]:
+        _dense(index, torch.int64, "index")
+        m = index.numel()
+        outs = []
+        for i, (trailing, dtype) in enumerate(self.meta):
+            dst = torch.empty((m, *trailing), dtype=dtype, device=self.device)
+            self.fields[i].dst = _ptr(dst)
+            outs.append(dst)
+        with _timed("gather_packed", m):
+            _check(load().rl8_gather_packed(_ptr(index), m, _ptr(self.packed), self.row_words, self.fields,
+                                            len(self.meta), _stream()), "rl8_gather_packed")
+        return outs
 
 
 # --------------------------------------------------------------------------- #

@@ -497,6 +497,18 @@ def test_gather_minibatch_bit_exact(time_major):
     # same thing through the oracle's row gather on the flattened [N*H] view
     flat = np.ascontiguousarray(obs[:, :h]).reshape(n * h, 5)
     assert np.array_equal(host(outs[0]), oracle.gather_rows(index, flat))
+    # and through the packed rows (pack once, gather many): 5 + 2*2 + 1 = 10 -> 12 words per row
+    packed = hip.PackedSamples(h, [put(obs), put(act), put(adv)])
+    assert packed.row_words == 12 and packed.samples == n * h
+    for seed in (0, 1):
+        index = oracle.permutation(n * h, 11, seed)[: 1000 + seed]
+        outs = packed.gather(dev(index))
+        env, t = index // h, index % h
+        assert np.array_equal(host(outs[0]), obs[env, t])
+        assert np.array_equal(host(outs[1]), act[env, t]) and outs[1].dtype == torch.int64
+        assert np.array_equal(host(outs[2]), adv[env, t])
+    whole = packed.gather(dev(np.arange(n * h)))
+    assert np.array_equal(host(whole[0]), flat)
 
 
 # --------------------------------------------------------------------------- #

@@ -73,6 +73,7 @@ obs_leaf = torch.randn(H + 1, N, 1, device=dev, generator=g).transpose(0, 1)
 act_leaf = torch.randint(0, 2, (H + 1, N, 1), device=dev, generator=g).transpose(0, 1)
 f_leaf = [torch.randn(H + 1, N, 1, device=dev, generator=g).transpose(0, 1) for _ in range(3)]
 moments = torch.tensor([float(N * H), 0.0, float(N * H)], dtype=torch.float64, device=dev)
+packed_rows = hip.PackedSamples(H, [obs_leaf, act_leaf, *f_leaf])
 
 
 def gae_tm():
@@ -136,6 +137,9 @@ KERNELS = {
         rdr_t1=cols["rdr1"], gamma=f32(0.95), seed=1, step=0, env_offset=0, deterministic=False), 88 * N),
     "rollout_stats": (lambda: hip.rollout_stats(rewards.T.unsqueeze(-1), rdr.T.unsqueeze(-1)), 8 * N * H),
     "gather_minibatch": (lambda: hip.gather_minibatch(perm, H, [obs_leaf, act_leaf, *f_leaf]), 56 * M),
+    # the same minibatch out of rows packed once per step (24 B read + 32 B written per sample of the buffer)
+    "gather_packed": (lambda: packed_rows.gather(perm), 56 * M),
+    "pack_samples": (lambda: hip.PackedSamples(H, [obs_leaf, act_leaf, *f_leaf]), 56 * N * H),
 }
 only = [s for s in args.only.split(",") if s]
 names = [k for k in KERNELS if not only or k in only]
