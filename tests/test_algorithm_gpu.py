@@ -517,3 +517,28 @@ def test_windowed_model_that_drops_samples_is_rejected():
     algo.collect()
     with pytest.raises(ValueError, match="one window per sample"):
         algo.step()
+
+
+def test_enable_amp_keeps_the_fused_fp32_towers():
+    """`enable_amp=True` (what the reference's example scripts pass on a GPU) must
+    not fall off the fused path: same kernels, same numbers as fp32 up to the
+    grad-scaler's power-of-two scaling."""
+    from rl8_amd import hip
+
+    def run(amp):
+        torch.manual_seed(3)
+        algo = AlgorithmConfig(num_envs=512, horizon=16, enable_amp=amp).build(DiscreteDummyEnv)
+        hip.timer.reset()
+        hip.timer.enabled = True
+        collect = algo.collect()
+        step = algo.step()
+        hip.timer.enabled = False
+        return collect, step, set(hip.timer.summary()), torch.cat([p.detach().flatten() for p in algo.policy.model.parameters()])
+
+    c0, s0, k0, p0 = run(False)
+    c1, s1, k1, p1 = run(True)
+    assert {"mlp_tower_forward", "mlp_tower_forward_save", "mlp_tower_backward", "mlp_wgrad"} <= k1 and k0 == k1
+    assert c0["returns/mean"] == c1["returns/mean"]
+    for k in ("losses/policy", "losses/vf", "losses/total"):
+        assert s0[k] == pytest.approx(s1[k], rel=1e-5, abs=1e-8), k
+    torch.testing.assert_close(p0, p1, rtol=1e-4, atol=1e-6)

@@ -127,3 +127,19 @@ def test_two_ranks_match_one_process(kind, kw):
     diff = (params0 - single_params).abs()
     assert float((diff > 2e-4 + 2e-3 * single_params.abs()).float().mean()) < 1e-4
     assert float(diff.max()) < 4e-3
+
+
+def test_collectives_through_rccl_with_one_rank():
+    """The production backend: every collective EnvShards issues (fp64 all-gather of
+    the rollout moments, fp64 all-reduces of advantage moments and loss sums, the
+    flattened-gradient all-reduce, the parameter broadcast) driven through real
+    RCCL -- with the one rank a single-GPU box allows and the collectives forced
+    on. (Two ranks need two GPUs; their arithmetic is covered above with gloo.)"""
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_single_rank.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "rccl single-rank collectives ok" in out.stdout
