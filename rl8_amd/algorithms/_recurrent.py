@@ -40,10 +40,10 @@ from ..tensordict import TensorDict
 from ._feedforward import Algorithm, AlgorithmConfig, _collect_stats_from_raw
 
 #: Rows (sequences x seq_len) pushed through the LSTM per forward/backward pass.
-#: MIOpen's RNN workspace holds ~7 x hidden floats per (step, sequence) and is
-#: indexed with 32-bit offsets: 2^21 rows of a 256-wide LSTM faulted on gfx950,
-#: 2^18 rows keep it under 2^29 elements.
-RECURRENT_MAX_ROWS_PER_PASS = 1 << 18
+#: Rows (sequences x steps) of one forward / backward pass through the LSTM;
+#: larger minibatches accumulate over several passes. 2^21 rows of the default
+#: 256-wide LSTM keep the pass's activations around 20 GB.
+RECURRENT_MAX_ROWS_PER_PASS = 1 << 21
 
 
 @dataclass
