@@ -23,18 +23,9 @@
 // LDS: one [64][257] fp32 tile (h1, overwritten by h2); the odd row stride makes
 // both the row walks of the MFMA A operand and the column walks of the VALU
 // phases bank-conflict-free.
-#include "common.hip.h"
+#include "mfma_tile.hip.h"
 
 namespace rl8 {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kHidden = 256;
-constexpr int kTileRows = 64;         // samples per workgroup tile
-constexpr int kLdsStride = kHidden + 1;
-constexpr int kMaxIn = 16;
-constexpr int kMaxOut = 8;
-constexpr int kGroups = kHidden / 8;  // k-groups of 8
 
 // Kernel-tuning builds only (tools/diag_mlp.sh): -DRL8_DIAG_SKIP=<bits> drops
 // one memory stream of a tower kernel so its cost can be read off the microbench
@@ -44,27 +35,6 @@ constexpr int kGroups = kHidden / 8;  // k-groups of 8
 #define RL8_DIAG_SKIP 0
 #endif
 constexpr int kDiagSkip = RL8_DIAG_SKIP;
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// Raw buffer descriptors (gfx9 dword3 = 32-bit data format): loads / stores
-// through them take their row offset from an SGPR, so the address arithmetic
-// runs on the scalar unit, and anything past `bytes` is dropped by the hardware
-// -- which is the row guard of a partial last tile.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_rsrc(const void *base, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ void buffer_store_f32(float v, __amdgpu_buffer_rsrc_t r, int voffset,
-                                                 int soffset) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voffset, soffset, 0);
-}
-__device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 0));
-}
-// (Only the 32-bit forms: this toolchain lowers the b64 / b128 load builtins to
-// a single dword.)
 
 // w2 [256 out][256 in] row-major -> fragment order, one 256-byte run per
 // (N-tile n, k-group g, element e) so that a wave's B operand for one MFMA is a
@@ -88,50 +58,6 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_w2t_kernel(const float *__res
   packed[idx] = w2[(8 * g + 4 * (l >> 5) + e) * kHidden + 32 * n + (l & 31)];
 }
 
-// COST MODEL (measured, tools/probes/mfma_valu_probe.hip): on gfx950 an fp32 MFMA
-// and ordinary VALU instructions do NOT overlap -- not from the same wave and not
-// from another wave of the same SIMD.  A stream of v_mfma_f32_32x32x2_f32 runs at
-// 155 TFLOP/s (64 cycles each at 2.37 GHz); every VALU instruction in between
-// adds ~2.2 ns (~5 cycles) plus ~5 ns per MFMA->VALU->MFMA switch.  LDS and
-// memory instructions do overlap.  So a kernel's time is  MFMA + sum(VALU), and
-// these kernels are written to minimise the VALU instruction count per tile:
-// addresses come from SGPRs / immediates (buffer loads, fully unrolled LDS
-// offsets), pairs go through v_pk_fma_f32, and nothing is recomputed on the VALU
-// that a memory instruction can fetch.
-//
-// One 64-row x 256-col GEMM tile on the matrix cores:
-//   acc[m][n] = A_tile[32m + i][k] * Bp[(N-tile 2*wave + n)][k]
-// A_tile: LDS [64][257]; Bp: fragment-packed [8][32][4][64] floats behind a buffer
-// descriptor.  Wave `wave` produces output columns [64*wave, 64*wave + 64).
-// Software-pipelined by hand (struct TileGemm below).
-//
-// Operand fragments of one k-group: B (weights, through L2) and A (activations,
-// LDS) are prefetched at different distances, so they are separate sets.
-struct BFrag {
-  float b0[4], b1[4];
-};
-struct AFrag {
-  float a0[4], a1[4];
-};
-
-__device__ __forceinline__ void load_b(BFrag &f, __amdgpu_buffer_rsrc_t bp, int bvoff, int g) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    f.b0[e] = buffer_load_f32(bp, bvoff + e * (kWave * 4), g * (kWave * 16));
-    f.b1[e] = buffer_load_f32(bp, bvoff + kGroups * kWave * 16 + e * (kWave * 4), g * (kWave * 16));
-  }
-}
-
-__device__ __forceinline__ void load_a(AFrag &f, const float *__restrict__ a0p, int g) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    f.a0[e] = a0p[8 * g + e];
-    f.a1[e] = a0p[32 * kLdsStride + 8 * g + e];
-  }
-}
-
-__device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0f70); }
-
 // Kernel-tuning builds only (-DRL8_PHASE_TRACE): shader-clock stamps at the phase
 // boundaries of the tower kernels, tile iterations 4..7 of every workgroup, read
 // back with rl8_debug_phase_trace().  Compiled out of the shipped library.
@@ -147,125 +73,6 @@ __device__ __forceinline__ void trace_stamp(int iteration, int slot) {
 #else
 #define RL8_TRACE(iteration, slot)
 #endif
-
-// ReLU gates of the backward pass, `gate > 0 ? value : 0`, as a compare into its
-// OWN SGPR pair and a select on it.  The compiler funnels every compare through
-// vcc, which chains compare -> (2 wait states) -> select -> compare ...; each
-// link of such a chain is a gap in which the SIMD's other wave starts an MFMA.
-// Callers issue a batch of compares, then the batch of selects (>= 2
-// instructions apart, the gfx940-family VALU-SGPR read hazard).
-__device__ __forceinline__ unsigned long long positive_mask(float gate) {
-  unsigned long long m;
-  asm("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(gate));
-  return m;
-}
-__device__ __forceinline__ float select_or_zero(unsigned long long mask, float value) {
-  float r;
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(value), "s"(mask));
-  return r;
-}
-
-// max(v, 0) as exactly one v_max_f32 (fmaxf() costs a second, canonicalising,
-// v_max on values the compiler cannot prove quiet; NaN -> 0 either way).
-__device__ __forceinline__ float relu1(float v) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-  return r;
-}
-
-// FIRST: the accumulators start from the inline constant 0 (no v_mov per
-// accumulator register).
-template <bool FIRST>
-__device__ __forceinline__ void mma_frag(const AFrag &fa, const BFrag &fb, f32x16 (&acc)[2][2]) {
-  if constexpr (FIRST) {
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a0[0], fb.b0[0], zero, 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a0[0], fb.b1[0], zero, 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a1[0], fb.b0[0], zero, 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a1[0], fb.b1[0], zero, 0, 0, 0);
-  }
-#pragma unroll
-  for (int e = FIRST ? 1 : 0; e < 4; ++e) {
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a0[e], fb.b0[e], acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a0[e], fb.b1[e], acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a1[e], fb.b0[e], acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a1[e], fb.b1[e], acc[1][1], 0, 0, 0);
-  }
-}
-
-// The 64x256x256 tile product, in two parts so that the first weight fragments
-// can be requested BEFORE the VALU phase that precedes the matrix loop:
-//   TileGemm gemm(w2 descriptor, wave, lane);
-//   gemm.prefetch();                 // B fragments of k-groups 0..2 -> registers
-//   ... VALU phase writing the A tile to LDS (and storing to HBM), barrier ...
-//   gemm.run(a_tile, acc);
-// Why: loads and stores retire through one in-order counter (vmcnt), so a
-// weight load issued after the phase's 64 stores cannot be waited for until
-// those stores have drained to L2 (~1 us); requested ahead of them it is ready
-// when the loop starts.  Inside the loop B fragments run three sets deep (two
-// groups = ~0.9 us ahead), A fragments (LDS) two sets.
-constexpr int kValuPhasePriority = 2;
-
-struct TileGemm {
-  __amdgpu_buffer_rsrc_t bp;
-  int bvoff, a_off;
-  BFrag b[3];
-
-  __device__ __forceinline__ TileGemm(__amdgpu_buffer_rsrc_t w, int wave, int lane)
-      : bp(w), bvoff((2 * wave) * kGroups * kWave * 16 + lane * 4),
-        a_off((lane & 31) * kLdsStride + 4 * (lane >> 5)) {}
-
-  __device__ __forceinline__ void prefetch() {
-    load_b(b[0], bp, bvoff, 0);
-    load_b(b[1], bp, bvoff, 1);
-    load_b(b[2], bp, bvoff, 2);
-  }
-
-  template <bool FIRST>
-  __device__ __forceinline__ void step(AFrag &fa, BFrag &fb, const float *a0p, int g,
-                                       f32x16 (&acc)[2][2]) {
-    mma_frag<FIRST>(fa, fb, acc);
-    load_a(fa, a0p, g + 2 < kGroups ? g + 2 : kGroups - 1);  // (the last reloads are unused)
-    load_b(fb, bp, bvoff, g + 3 < kGroups ? g + 3 : kGroups - 1);
-  }
-
-  __device__ __forceinline__ void run(const float *__restrict__ a_tile, f32x16 (&acc)[2][2]) {
-    // Wave priority: the matrix loop runs at the lowest priority and every VALU
-    // phase at a raised one.  Two workgroups share each SIMD; at equal priority
-    // the arbiter alternates one workgroup's VALU instructions with the other's
-    // MFMAs one for one, and each such switch costs ~17 cycles of the matrix pipe
-    // (measured with phase timestamps: a 140-instruction VALU phase took 9 000
-    // cycles).  Raised, the VALU phase issues as a burst (~5 cycles per
-    // instruction) and the matrix wave simply resumes behind it.
-    __builtin_amdgcn_s_setprio(0);
-    const float *a0p = a_tile + a_off;
-    AFrag a[2];
-    load_a(a[0], a0p, 0);
-    load_a(a[1], a0p, 1);
-    // A set = g mod 2, B set = g mod 3: six groups per trip.
-    step<true>(a[0], b[0], a0p, 0, acc);
-    step<false>(a[1], b[1], a0p, 1, acc);
-    step<false>(a[0], b[2], a0p, 2, acc);
-    step<false>(a[1], b[0], a0p, 3, acc);
-    step<false>(a[0], b[1], a0p, 4, acc);
-    step<false>(a[1], b[2], a0p, 5, acc);
-#pragma unroll 1
-    for (int g = 6; g < kGroups - 2; g += 6) {
-      step<false>(a[0], b[0], a0p, g, acc);
-      step<false>(a[1], b[1], a0p, g + 1, acc);
-      step<false>(a[0], b[2], a0p, g + 2, acc);
-      step<false>(a[1], b[0], a0p, g + 3, acc);
-      step<false>(a[0], b[1], a0p, g + 4, acc);
-      step<false>(a[1], b[2], a0p, g + 5, acc);
-    }
-    // kGroups = 32 = 5 * 6 + 2
-    mma_frag<false>(a[0], b[0], acc);
-    mma_frag<false>(a[1], b[1], acc);
-    __builtin_amdgcn_s_setprio(kValuPhasePriority);
-  }
-};
-
-constexpr int pad_out(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
 
 // Forward of one tower over m rows.  SAVE: also store h1 / h2 ([m][256] each) for
 // the backward kernels.  LDS: ONE [64][257] tile (h1, then h2 in place once the
