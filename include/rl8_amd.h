@@ -342,6 +342,30 @@ int64_t rl8_mlp_wgrad_workspace_bytes(void);
 int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, float *workspace,
                       float *dw2_out, int accumulate, void *stream);
 
+/* ---------------------------------------------------------------------- *
+ * a-9  Default recurrent models' LSTM, fused
+ *      src/rl8/models/_recurrent.py:201-321 (torch.nn.LSTM(d_in, 256, num_layers=1,
+ *      batch_first=True) inside DefaultContinuous/DiscreteRecurrentModel)
+ * One layer, hidden 256, fp32 (matrix products on v_mfma_f32_32x32x2_f32), gate
+ * order i, f, g, o as in torch, 1 <= d_in <= 7 (rl8_lstm_supports).
+ *
+ * rl8_lstm_pack_f32: torch-layout parameters (w_ih [1024][d_in], w_hh [1024][256],
+ * b_ih, b_hh [1024]) -> `packed` (rl8_lstm_pack_floats() floats): per gate, the
+ * 256 x (256 + 8) matrix [w_hh | w_ih | b_ih + b_hh | 0] in MFMA fragment order.
+ *
+ * rl8_lstm_forward_f32: x [B][L][d_in] dense; h0, c0 [B][256] -> hs [B][L][256]
+ * (every h_t), hn, cn [B][256].  For training, save_gates [B][L][4][256]
+ * (post-activation i, f, g, o) and save_c [B][L][256] receive what
+ * rl8_lstm_backward_f32 needs; both NULL for rollouts.
+ * ---------------------------------------------------------------------- */
+int rl8_lstm_supports(int d_in);
+int64_t rl8_lstm_pack_floats(void);
+int rl8_lstm_pack_f32(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                      int d_in, float *packed, void *stream);
+int rl8_lstm_forward_f32(const float *x, int64_t b, int l, int d_in, const float *h0, const float *c0,
+                         const float *w_packed, float *hs, float *hn, float *cn, float *save_gates,
+                         float *save_c, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,241 @@
+// a-9 (recurrent PPO): the default recurrent models' one-layer,
+// 256-wide LSTM (src/rl8/models/_recurrent.py:201-321 -> torch.nn.LSTM, batch_first)
+// as fused fp32 kernels on the matrix cores, on the machinery of the towers
+// (mfma_tile.hip.h): per timestep the recurrent product h_{t-1} x W_hh^T is four
+// 256x256 tile products (one per gate, each against its own fragment-packed
+// weight block), the input projection (d_in is tiny) and every gate non-linearity
+// and cell update happen on the accumulators, and the time loop runs inside the
+// kernel with h_t handed to the next step through LDS.  PyTorch's own path is a
+// GEMM per operand and timestep (64 TFLOP/s here) plus a pointwise kernel per
+// timestep that round-trips the 4 KiB of gates per row through HBM.
+//
+// Layout: a workgroup owns 32 sequences (one 32-row M-tile) at a time; wave w owns
+// hidden units [64w, 64w + 64) of all four gates, so a lane holds i, f, g, o, c of
+// the same (row, unit) in the same accumulator slot: row (r&3) + 8(r>>2) + 4(l>>5),
+// unit 64w + 32nt + (l&31).  Gate order in the weights is torch's: i, f, g, o.
+// Gates are evaluated i, g, f, o so that at most one gate's activations, the
+// product i*g and the cell state are live next to the accumulators.
+#include "mfma_tile.hip.h"
+
+namespace rl8 {
+
+constexpr int kLstmRows = 32;  // sequences per tile
+constexpr int kLstmGroups = kGroups + 1;              // K = 256 hidden + 8 (inputs, bias column, zero padding)
+constexpr int kLstmStride = kHidden + 9;              // LDS row pitch of the [h | x | 1 | 0..] tile, odd
+constexpr int kLstmMaxIn = 7;                         // inputs + the bias column fit the extra k-group
+constexpr int kLstmPackFloats = 4 * 8 * kLstmGroups * 4 * kWave;  // per direction
+constexpr int kGateOrder[4] = {0, 2, 1, 3};
+
+// Gate non-linearities on the hardware exp2 / rcp (1 ulp each; the reference's
+// tolerance is 1e-5): sigmoid(x) = 1 / (1 + e^-x), tanh(x) = 1 - 2 / (e^2x + 1).
+__device__ __forceinline__ float sigmoid_f(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float tanh_f(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+}
+
+// Forward weights in fragment order, the input projection and the biases folded
+// into the recurrent product as eight extra k: with the operand row
+// [h_{t-1} (256) | x_t (d) | 1 | 0 ...] and
+//   Wcat[j][k] = w_hh[j][k] (k < 256), w_ih[j][k - 256] (k < 256 + d),
+//                b_ih[j] + b_hh[j] (k = 256 + d), 0 beyond,
+// a gate's pre-activation is one tile product -- no VALU work and no registers
+// for inputs or biases.  packed[(((q*8 + n)*33 + g)*4 + e)*64 + l] =
+//   Wcat[256q + 32n + (l&31)][8g + 4(l>>5) + e]   (cf. rl8_mlp_pack_w2_f32).
+__global__ __launch_bounds__(kBlock) void lstm_pack_kernel(const float *__restrict__ w_ih,
+                                                           const float *__restrict__ w_hh,
+                                                           const float *__restrict__ b_ih,
+                                                           const float *__restrict__ b_hh, int d_in,
+                                                           float *__restrict__ packed) {
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= kLstmPackFloats) return;
+  const int l = idx & 63, e = (idx >> 6) & 3, gn = idx >> 8;
+  const int g = gn % kLstmGroups, qn = gn / kLstmGroups;  // qn = q*8 + n
+  const int j = 32 * qn + (l & 31), k = 8 * g + 4 * (l >> 5) + e;
+  float v = 0.0f;
+  if (k < kHidden)
+    v = w_hh[j * kHidden + k];
+  else if (k < kHidden + d_in)
+    v = w_ih[j * d_in + (k - kHidden)];
+  else if (k == kHidden + d_in)
+    v = b_ih[j] + b_hh[j];
+  packed[idx] = v;
+}
+
+// Forward over b sequences of l steps.  SAVE: also store the post-activation gates
+// ([b][l][4][256], order i, f, g, o) and the cell states ([b][l][256]) for the
+// backward kernel.  LDS: one [32][265] tile: h_{t-1} (then h_t), x_t, the ones
+// column = 34 KB.
+template <bool SAVE>
+__global__ __launch_bounds__(kBlock, 2) void lstm_forward_kernel(
+    const float *__restrict__ x, int64_t b, int l, int d_in, const float *__restrict__ h0,
+    const float *__restrict__ c0, const float *__restrict__ w_packed, float *__restrict__ hs,
+    float *__restrict__ hn, float *__restrict__ cn, float *__restrict__ save_gates,
+    float *__restrict__ save_c) {
+  extern __shared__ float lds[];
+  float *ht = lds;  // [32][265]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, l31 = lane & 31;
+
+  __amdgpu_buffer_rsrc_t wrsrc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    wrsrc[q] = buffer_rsrc(w_packed + q * (kLstmPackFloats / 4), kLstmPackFloats);  // bytes of one gate
+  TileGemmT<1, kLstmGroups, kLstmStride> gemm(wrsrc[0], wave, lane);
+  __builtin_amdgcn_s_setprio(kValuPhasePriority);
+  // Accumulator slot (nt, r) of this lane is row (r&3) + 8(r>>2) + 4*hh, unit
+  // 64*wave + 32*nt + l31.  Byte offsets: the lane part (4*hh rows + unit) goes in
+  // the VGPR offset, the (r) row part in the scalar offset; the row pitch depends
+  // on the array.
+  const int unit4 = (64 * wave + l31) * 4;
+  const int v_state = 4 * hh * kHidden * 4 + unit4;          // [rows][256]: c0, hn, cn
+  const int v_seq = 4 * hh * l * kHidden * 4 + unit4;        // [rows][l][256]: hs, cs
+  const int v_gates = 4 * hh * l * 4 * kHidden * 4 + unit4;  // [rows][l][4][256]
+  // columns 256.. of the tile: zeros, then the ones column; x_t is written per step
+  for (int i = tid; i < kLstmRows * 9; i += kBlock) {
+    const int row = i / 9, c = i - row * 9;
+    ht[row * kLstmStride + kHidden + c] = c == d_in ? 1.0f : 0.0f;
+  }
+  // this thread's element of the [32][d] observation tile (threads beyond 32*d idle)
+  const int x_row = tid / d_in, x_col = tid - x_row * d_in;
+  const bool x_owner = tid < kLstmRows * d_in;
+
+  const int64_t tiles = (b + kLstmRows - 1) / kLstmRows;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t b0 = tile * kLstmRows;
+    const int rows = (int)((b - b0) < kLstmRows ? (b - b0) : kLstmRows);
+    const __amdgpu_buffer_rsrc_t h0rsrc = buffer_rsrc(h0 + b0 * kHidden, rows * kHidden * 4);
+    const __amdgpu_buffer_rsrc_t c0rsrc = buffer_rsrc(c0 + b0 * kHidden, rows * kHidden * 4);
+    const float *xt = x + (b0 + x_row) * l * d_in + x_col;  // + t*d_in
+    const bool x_valid = x_owner && x_row < rows;
+    __syncthreads();  // the previous tile's last readers of ht are done
+    // h0 tile -> LDS (one 1-KiB row per direct-to-LDS load; rows past the end = 0)
+#pragma unroll
+    for (int u = 0; u < kLstmRows / 4; ++u) {
+      const int row = wave + 4 * u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(h0rsrc, ht + row * kLstmStride, 16, lane * 16, row * (kHidden * 4), 0, 0);
+    }
+    if (x_owner) ht[x_row * kLstmStride + kHidden + x_col] = x_valid ? xt[0] : 0.0f;
+    float c[2][16], h[2][16];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        c[nt][r] = buffer_load_f32(c0rsrc, v_state + nt * 128, ((r & 3) + 8 * (r >> 2)) * (kHidden * 4));
+    gemm.bp = wrsrc[kGateOrder[0]];
+    gemm.prefetch();
+    wait_vmcnt0();
+    __syncthreads();
+
+    for (int t = 0; t < l; ++t) {
+      const float x_next = (x_valid && t + 1 < l) ? xt[(t + 1) * d_in] : 0.0f;  // lands during the products
+      const int64_t row_step0 = b0 * l + t;  // tile row 0 at this step (row pitch l)
+      const __amdgpu_buffer_rsrc_t hsrsrc =
+          buffer_rsrc(hs + row_step0 * kHidden, ((rows - 1) * l + 1) * kHidden * 4);
+      const __amdgpu_buffer_rsrc_t csrsrc =
+          buffer_rsrc(SAVE ? save_c + row_step0 * kHidden : nullptr, ((rows - 1) * l + 1) * kHidden * 4);
+      const __amdgpu_buffer_rsrc_t gsrsrc = buffer_rsrc(
+          SAVE ? save_gates + row_step0 * 4 * kHidden : nullptr, ((rows - 1) * l + 1) * 4 * kHidden * 4);
+      float p[2][16];
+#pragma unroll
+      for (int step = 0; step < 4; ++step) {
+        const int q = kGateOrder[step];
+        f32x16 acc[1][2];
+        gemm.run(ht, acc);
+        if (step < 3) {
+          gemm.bp = wrsrc[kGateOrder[step + 1]];
+          gemm.prefetch();
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float a = q == 2 ? tanh_f(acc[0][nt][r]) : sigmoid_f(acc[0][nt][r]);
+            if constexpr (SAVE)
+              buffer_store_f32(a, gsrsrc, v_gates + nt * 128 + q * (kHidden * 4),
+                               ((r & 3) + 8 * (r >> 2)) * l * (4 * kHidden * 4));
+            if (q == 0) {
+              p[nt][r] = a;
+            } else if (q == 2) {
+              p[nt][r] *= a;
+            } else if (q == 1) {
+              c[nt][r] = __builtin_fmaf(a, c[nt][r], p[nt][r]);
+            } else {
+              h[nt][r] = a * tanh_f(c[nt][r]);
+            }
+          }
+      }
+      __syncthreads();  // every wave has read the tile for all four gates
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int sr = (r & 3) + 8 * (r >> 2);
+          ht[(sr + 4 * hh) * kLstmStride + 64 * wave + 32 * nt + l31] = h[nt][r];
+          buffer_store_f32(h[nt][r], hsrsrc, v_seq + nt * 128, sr * l * (kHidden * 4));
+          if constexpr (SAVE) buffer_store_f32(c[nt][r], csrsrc, v_seq + nt * 128, sr * l * (kHidden * 4));
+        }
+      if (x_owner) ht[x_row * kLstmStride + kHidden + x_col] = x_next;
+      if (t + 1 < l) {
+        gemm.bp = wrsrc[kGateOrder[0]];
+        gemm.prefetch();
+      }
+      __syncthreads();
+    }
+    // final states
+    const __amdgpu_buffer_rsrc_t hnrsrc = buffer_rsrc(hn + b0 * kHidden, rows * kHidden * 4);
+    const __amdgpu_buffer_rsrc_t cnrsrc = buffer_rsrc(cn + b0 * kHidden, rows * kHidden * 4);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int sr = (r & 3) + 8 * (r >> 2);
+        buffer_store_f32(h[nt][r], hnrsrc, v_state + nt * 128, sr * (kHidden * 4));
+        buffer_store_f32(c[nt][r], cnrsrc, v_state + nt * 128, sr * (kHidden * 4));
+      }
+  }
+}
+
+inline size_t lstm_lds_bytes() { return sizeof(float) * kLstmRows * kLstmStride; }
+
+}  // namespace rl8
+
+using namespace rl8;
+
+RL8_API int rl8_lstm_supports(int d_in) { return d_in >= 1 && d_in <= kLstmMaxIn; }
+
+RL8_API int64_t rl8_lstm_pack_floats(void) { return kLstmPackFloats; }
+
+RL8_API int rl8_lstm_pack_f32(const float *w_ih, const float *w_hh, const float *b_ih,
+                              const float *b_hh, int d_in, float *packed, void *stream) {
+  if (!w_ih || !w_hh || !b_ih || !b_hh || !packed) return RL8_ENULL;
+  if (!rl8_lstm_supports(d_in)) return RL8_ESIZE;
+  if (!aligned16(packed)) return RL8_EALIGN;
+  lstm_pack_kernel<<<(kLstmPackFloats + kBlock - 1) / kBlock, kBlock, 0, (hipStream_t)stream>>>(
+      w_ih, w_hh, b_ih, b_hh, d_in, packed);
+  return launch_status();
+}
+
+RL8_API int rl8_lstm_forward_f32(const float *x, int64_t b, int l, int d_in, const float *h0,
+                                 const float *c0, const float *w_packed, float *hs, float *hn,
+                                 float *cn, float *save_gates, float *save_c, void *stream) {
+  if (!x || !h0 || !c0 || !w_packed || !hs || !hn || !cn) return RL8_ENULL;
+  if ((save_gates == nullptr) != (save_c == nullptr)) return RL8_ENULL;
+  if (b <= 0 || l <= 0) return RL8_ESIZE;
+  if (!rl8_lstm_supports(d_in)) return RL8_ESIZE;
+  // buffer descriptors address one tile's rows with 32-bit offsets
+  if ((int64_t)kLstmRows * l * 4 * kHidden * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
+  if (!aligned16(w_packed) || !aligned16(h0)) return RL8_EALIGN;
+  const int64_t tiles = (b + kLstmRows - 1) / kLstmRows;
+  const int grid = (int)(tiles < 2 * kCUs ? tiles : 2 * kCUs);
+  hipStream_t s = (hipStream_t)stream;
+  if (save_gates)
+    lstm_forward_kernel<true><<<grid, kBlock, lstm_lds_bytes(), s>>>(x, b, l, d_in, h0, c0, w_packed, hs, hn, cn,
+                                                                   save_gates, save_c);
+  else
+    lstm_forward_kernel<false><<<grid, kBlock, lstm_lds_bytes(), s>>>(x, b, l, d_in, h0, c0, w_packed, hs, hn, cn,
+                                                                    save_gates, save_c);
+  return launch_status();
+}

@@ -60,11 +60,12 @@ __device__ __forceinline__ float buffer_load_f32(__amdgpu_buffer_rsrc_t r, int v
 struct BFrag {
   float b0[4], b1[4];
 };
+template <int KG>  // k-groups per N-tile in the packed weights
 __device__ __forceinline__ void load_b(BFrag &f, __amdgpu_buffer_rsrc_t bp, int bvoff, int g) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     f.b0[e] = buffer_load_f32(bp, bvoff + e * (kWave * 4), g * (kWave * 16));
-    f.b1[e] = buffer_load_f32(bp, bvoff + kGroups * kWave * 16 + e * (kWave * 4), g * (kWave * 16));
+    f.b1[e] = buffer_load_f32(bp, bvoff + KG * kWave * 16 + e * (kWave * 4), g * (kWave * 16));
   }
 }
 
@@ -73,12 +74,12 @@ struct AFragT {
   float a[MT][4];
 };
 
-template <int MT>
+template <int MT, int STRIDE>
 __device__ __forceinline__ void load_a(AFragT<MT> &f, const float *__restrict__ a0p, int g) {
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) f.a[m][e] = a0p[32 * m * kLdsStride + 8 * g + e];
+    for (int m = 0; m < MT; ++m) f.a[m][e] = a0p[32 * m * STRIDE + 8 * g + e];
 }
 
 __device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0f70); }
@@ -143,28 +144,31 @@ __device__ __forceinline__ void mma_frag(const AFragT<MT> &fa, const BFrag &fb, 
 // groups = ~0.9 us ahead), A fragments (LDS) two sets.
 constexpr int kValuPhasePriority = 2;
 
-template <int MT>
+// MT: 32-row M-tiles; KG: k-groups of 8 (K = 8*KG; 33 = the LSTM's 256 hidden +
+// up to 7 inputs + the bias column); STRIDE: row pitch of the LDS tile in floats.
+template <int MT, int KG = kGroups, int STRIDE = kLdsStride>
 struct TileGemmT {
+  static_assert(KG == 32 || KG == 33, "the tail of run() is written out for these depths");
   __amdgpu_buffer_rsrc_t bp;
   int bvoff, a_off;
   BFrag b[3];
 
   __device__ __forceinline__ TileGemmT(__amdgpu_buffer_rsrc_t w, int wave, int lane)
-      : bp(w), bvoff((2 * wave) * kGroups * kWave * 16 + lane * 4),
-        a_off((lane & 31) * kLdsStride + 4 * (lane >> 5)) {}
+      : bp(w), bvoff((2 * wave) * KG * kWave * 16 + lane * 4),
+        a_off((lane & 31) * STRIDE + 4 * (lane >> 5)) {}
 
   __device__ __forceinline__ void prefetch() {
-    load_b(b[0], bp, bvoff, 0);
-    load_b(b[1], bp, bvoff, 1);
-    load_b(b[2], bp, bvoff, 2);
+    load_b<KG>(b[0], bp, bvoff, 0);
+    load_b<KG>(b[1], bp, bvoff, 1);
+    load_b<KG>(b[2], bp, bvoff, 2);
   }
 
   template <bool FIRST>
   __device__ __forceinline__ void step(AFragT<MT> &fa, BFrag &fb, const float *a0p, int g,
                                        f32x16 (&acc)[MT][2]) {
     mma_frag<FIRST, MT>(fa, fb, acc);
-    load_a(fa, a0p, g + 2 < kGroups ? g + 2 : kGroups - 1);  // (the last reloads are unused)
-    load_b(fb, bp, bvoff, g + 3 < kGroups ? g + 3 : kGroups - 1);
+    load_a<MT, STRIDE>(fa, a0p, g + 2 < KG ? g + 2 : KG - 1);  // (the last reloads are unused)
+    load_b<KG>(fb, bp, bvoff, g + 3 < KG ? g + 3 : KG - 1);
   }
 
   // ACCUMULATE: add to what `acc` already holds instead of starting from zero.
@@ -180,8 +184,8 @@ struct TileGemmT {
     __builtin_amdgcn_s_setprio(0);
     const float *a0p = a_tile + a_off;
     AFragT<MT> a[2];
-    load_a(a[0], a0p, 0);
-    load_a(a[1], a0p, 1);
+    load_a<MT, STRIDE>(a[0], a0p, 0);
+    load_a<MT, STRIDE>(a[1], a0p, 1);
     // A set = g mod 2, B set = g mod 3: six groups per trip.
     step<!ACCUMULATE>(a[0], b[0], a0p, 0, acc);
     step<false>(a[1], b[1], a0p, 1, acc);
@@ -190,7 +194,7 @@ struct TileGemmT {
     step<false>(a[0], b[1], a0p, 4, acc);
     step<false>(a[1], b[2], a0p, 5, acc);
 #pragma unroll 1
-    for (int g = 6; g < kGroups - 2; g += 6) {
+    for (int g = 6; g < 30; g += 6) {
       step<false>(a[0], b[0], a0p, g, acc);
       step<false>(a[1], b[1], a0p, g + 1, acc);
       step<false>(a[0], b[2], a0p, g + 2, acc);
@@ -198,9 +202,15 @@ struct TileGemmT {
       step<false>(a[0], b[1], a0p, g + 4, acc);
       step<false>(a[1], b[2], a0p, g + 5, acc);
     }
-    // kGroups = 32 = 5 * 6 + 2
-    mma_frag<false, MT>(a[0], b[0], acc);
-    mma_frag<false, MT>(a[1], b[1], acc);
+    // groups 30.. : A sets hold 30, 31; B sets hold 30, 31, 32
+    if constexpr (KG == 32) {
+      mma_frag<false, MT>(a[0], b[0], acc);
+      mma_frag<false, MT>(a[1], b[1], acc);
+    } else {
+      step<false>(a[0], b[0], a0p, 30, acc);  // also fetches A of group 32
+      mma_frag<false, MT>(a[1], b[1], acc);
+      mma_frag<false, MT>(a[0], b[2], acc);
+    }
     __builtin_amdgcn_s_setprio(kValuPhasePriority);
   }
 };

@@ -120,6 +120,10 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_gather_minibatch": [_vp, _i64, _i64, C.POINTER(GatherField), _i32, _vp],
     "rl8_pack_samples": [_vp, _i32, _i64, _i64, _vp, _i32, _vp],
     "rl8_gather_packed": [_vp, _i64, _vp, _i32, _vp, _i32, _vp],
+    "rl8_lstm_supports": [_i32],
+    "rl8_lstm_pack_floats": [],
+    "rl8_lstm_pack_f32": [_vp, _vp, _vp, _vp, _i32, _vp, _vp],
+    "rl8_lstm_forward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
     "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
@@ -151,7 +155,8 @@ def load() -> C.CDLL:
             fn.argtypes = argtypes
             fn.restype = (
                 C.c_int64
-                if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes")
+                if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes",
+                            "rl8_lstm_pack_floats")
                 else C.c_int
             )
         _lib = lib
@@ -885,3 +890,51 @@ def mlp_wgrad(dz2: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
         _check(lib.rl8_mlp_wgrad_f32(_ptr(dz2), _ptr(h1), dz2.shape[0], _ptr(ws), _ptr(out), 0, _stream()),
                "rl8_mlp_wgrad_f32")
     return out
+
+
+# --------------------------------------------------------------------------- #
+# Fused LSTM (a-9): one layer, hidden 256, batch_first.
+# --------------------------------------------------------------------------- #
+LSTM_HIDDEN = 256
+
+
+def lstm_supports(d_in: int) -> bool:
+    return bool(load().rl8_lstm_supports(int(d_in)))
+
+
+def lstm_pack(w_ih: torch.Tensor, w_hh: torch.Tensor, b_ih: torch.Tensor, b_hh: torch.Tensor) -> torch.Tensor:
+    """torch.nn.LSTM parameters (``weight_ih_l0`` [1024, d], ``weight_hh_l0``
+    [1024, 256], ``bias_ih_l0``, ``bias_hh_l0`` [1024]) -> forward weights in MFMA
+    fragment order with the input projection and biases folded in."""
+    d_in = w_ih.shape[1]
+    for name, t, shape in (("w_ih", w_ih, (4 * LSTM_HIDDEN, d_in)), ("w_hh", w_hh, (4 * LSTM_HIDDEN, LSTM_HIDDEN)),
+                           ("b_ih", b_ih, (4 * LSTM_HIDDEN,)), ("b_hh", b_hh, (4 * LSTM_HIDDEN,))):
+        _dense(t.detach(), torch.float32, name)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+    lib = load()
+    packed = torch.empty(int(lib.rl8_lstm_pack_floats()), dtype=torch.float32, device=w_hh.device)
+    _check(lib.rl8_lstm_pack_f32(_ptr(w_ih.detach()), _ptr(w_hh.detach()), _ptr(b_ih.detach()), _ptr(b_hh.detach()),
+                                 d_in, _ptr(packed), _stream()), "rl8_lstm_pack_f32")
+    return packed
+
+
+def lstm_forward(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, w_packed: torch.Tensor, *, save: bool = False):
+    """x [B, L, d], h0 / c0 [B, 256] -> (hs [B, L, 256], hn, cn [B, 256], gates, cs);
+    ``gates`` [B, L, 4, 256] and ``cs`` [B, L, 256] only with ``save``."""
+    x = _dense(x.detach(), torch.float32, "x")
+    b, l, d_in = x.shape
+    for name, t in (("h0", h0), ("c0", c0)):
+        _dense(t, torch.float32, name)
+        if tuple(t.shape) != (b, LSTM_HIDDEN):
+            raise ValueError(f"{name} must be [{b}, {LSTM_HIDDEN}], got {tuple(t.shape)}")
+    dev = x.device
+    hs = torch.empty(b, l, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    hn = torch.empty(b, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    cn = torch.empty(b, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    gates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev) if save else None
+    cs = torch.empty(b, l, LSTM_HIDDEN, dtype=torch.float32, device=dev) if save else None
+    with _timed("lstm_forward_save" if save else "lstm_forward", b * l):
+        _check(load().rl8_lstm_forward_f32(_ptr(x), b, l, d_in, _ptr(h0), _ptr(c0), _ptr(w_packed), _ptr(hs), _ptr(hn),
+                                           _ptr(cn), _ptr(gates), _ptr(cs), _stream()), "rl8_lstm_forward_f32")
+    return hs, hn, cn, gates, cs
