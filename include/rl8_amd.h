@@ -341,6 +341,11 @@ int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
 int64_t rl8_mlp_wgrad_workspace_bytes(void);
 int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, float *workspace,
                       float *dw2_out, int accumulate, void *stream);
+/* The same product over rows that sit `pitch` floats apart (multiples of 4,
+ * >= 256): e.g. one gate of an LSTM's [M][4][256] gate gradients, pitch 1024. */
+int rl8_mlp_wgrad_strided_f32(const float *dz2, int64_t dz2_pitch, const float *h1, int64_t h1_pitch,
+                              int64_t m, float *workspace, float *dw2_out, int accumulate,
+                              void *stream);
 
 /* ---------------------------------------------------------------------- *
  * a-9  Default recurrent models' LSTM, fused
@@ -365,6 +370,23 @@ int rl8_lstm_pack_f32(const float *w_ih, const float *w_hh, const float *b_ih, c
 int rl8_lstm_forward_f32(const float *x, int64_t b, int l, int d_in, const float *h0, const float *c0,
                          const float *w_packed, float *hs, float *hn, float *cn, float *save_gates,
                          float *save_c, void *stream);
+
+/* Backward through time ("dgrad" half): given dhs [B][L][256] (gradient of every
+ * h_t output) and what the forward saved, writes the pre-activation gate
+ * gradients dgates [B][L][4][256] and `*partial_rows_out` rows
+ * (<= rl8_lstm_backward_max_rows()) of rl8_lstm_backward_partial_floats(d_in)
+ * floats into `partials`: [dW_ih (1024 * d_in) | db (1024)], whose column sums are
+ * the gradients of w_ih and of each bias vector.  whht_packed [4][65536]: block q =
+ * rl8_mlp_pack_w2_f32(w_hh[256q : 256q + 256], transposed = 1).  The recurrent
+ * weight gradient is dW_hh[256q : 256q + 256] = rl8_mlp_wgrad_strided_f32(dgates +
+ * 256q, 1024, h_prev, 256, B*L, ...) with h_prev[b][t] = h_{t-1} (h0 at t = 0).
+ * No gradient is produced for x, h0, c0 or the final states. */
+int64_t rl8_lstm_backward_partial_floats(int d_in);
+int rl8_lstm_backward_max_rows(void);
+int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, const float *c0,
+                          const float *gates, const float *cs, const float *dhs,
+                          const float *whht_packed, float *dgates, float *partials,
+                          int *partial_rows_out /*host*/, void *stream);
 
 #ifdef __cplusplus
 }

@@ -198,6 +198,175 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_forward_kernel(
   }
 }
 
+// Backward through time over b sequences of l steps ("dgrad" half):
+// per step, from dL/dh_t (the heads' gradient plus what flows back from t+1) and
+// the carried dL/dc_t,
+//   do = dh * tanh(c_t) * o(1-o)            dc  = dh * o * (1 - tanh^2 c_t) + dc_carry
+//   di = dc * g * i(1-i)     dg = dc * i * (1 - g^2)     df = dc * c_{t-1} * f(1-f)
+//   dc_carry = dc * f        dh_carry = sum_q dgate_q x W_hh[q]      (four MFMA tile products)
+// The pre-activation gate gradients dG ([b][l][4][256]) are stored: the weight
+// gradients are products of dG with [h_{t-1} | x_t | 1] over all rows
+// (rl8_mlp_wgrad_strided_f32 per gate for W_hh, lstm_input_grad_kernel for W_ih and
+// the biases).  Gradients with respect to x, h0 and c0 are not produced: in PPO the
+// observations and the initial states come out of the rollout buffer.
+// LDS: two [32][257] tiles (gate q+1's gradients are written while slower waves
+// still multiply gate q's): 66 KB.
+struct LstmBackwardStep {
+  __amdgpu_buffer_rsrc_t dg;  // this step's dG rows
+  int v_gates, l;
+};
+
+template <int SLOT, bool FIRST>
+__device__ __forceinline__ void lstm_emit_gate(int q, const float (&dgq)[2][16], const LstmBackwardStep &st,
+                                               TileGemmT<1> &gemm, const __amdgpu_buffer_rsrc_t (&wrsrc)[4],
+                                               float *lds, int wave, int hh, int l31, f32x16 (&acc)[1][2]) {
+  float *tile = lds + SLOT * kLstmRows * kLdsStride;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int sr = (r & 3) + 8 * (r >> 2);
+      buffer_store_f32(dgq[nt][r], st.dg, st.v_gates + nt * 128 + q * (kHidden * 4), sr * st.l * (4 * kHidden * 4));
+      tile[(sr + 4 * hh) * kLdsStride + 64 * wave + 32 * nt + l31] = dgq[nt][r];
+    }
+  gemm.bp = wrsrc[q];
+  gemm.prefetch();
+  __syncthreads();  // the tile is complete (its previous readers passed the last barrier before writing here)
+  gemm.run<!FIRST>(tile, acc);
+}
+
+__global__ __launch_bounds__(kBlock, 2) void lstm_backward_kernel(
+    int64_t b, int l, const float *__restrict__ c0, const float *__restrict__ gates,
+    const float *__restrict__ cs, const float *__restrict__ dhs,
+    const float *__restrict__ whht_packed, float *__restrict__ dgates) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, l31 = lane & 31;
+
+  __amdgpu_buffer_rsrc_t wrsrc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wrsrc[q] = buffer_rsrc(whht_packed + q * kHidden * kHidden, kHidden * kHidden * 4);
+  TileGemmT<1> gemm(wrsrc[0], wave, lane);
+  __builtin_amdgcn_s_setprio(kValuPhasePriority);
+  const int unit4 = (64 * wave + l31) * 4;
+  const int v_state = 4 * hh * kHidden * 4 + unit4;
+  const int v_seq = 4 * hh * l * kHidden * 4 + unit4;
+  const int v_gates = 4 * hh * l * 4 * kHidden * 4 + unit4;
+
+  const int64_t tiles = (b + kLstmRows - 1) / kLstmRows;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t b0 = tile * kLstmRows;
+    const int rows = (int)((b - b0) < kLstmRows ? (b - b0) : kLstmRows);
+    const __amdgpu_buffer_rsrc_t c0rsrc = buffer_rsrc(c0 + b0 * kHidden, rows * kHidden * 4);
+    float dh_carry[2][16], dc_carry[2][16];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh_carry[nt][r] = dc_carry[nt][r] = 0.0f;
+
+    for (int t = l - 1; t >= 0; --t) {
+      const int64_t row_step0 = b0 * l + t;
+      const uint32_t seq_bytes = (uint32_t)(((rows - 1) * l + 1) * kHidden * 4);
+      const __amdgpu_buffer_rsrc_t dhrsrc = buffer_rsrc(dhs + row_step0 * kHidden, seq_bytes);
+      const __amdgpu_buffer_rsrc_t csrsrc = buffer_rsrc(cs + row_step0 * kHidden, seq_bytes);
+      // c_{t-1}: the previous step's saved cell state, or c0
+      const __amdgpu_buffer_rsrc_t cprsrc = t > 0 ? buffer_rsrc(cs + (row_step0 - 1) * kHidden, seq_bytes) : c0rsrc;
+      const int v_cprev = t > 0 ? v_seq : v_state;
+      const int cprev_pitch = t > 0 ? l * kHidden * 4 : kHidden * 4;
+      const __amdgpu_buffer_rsrc_t gsrsrc = buffer_rsrc(gates + row_step0 * 4 * kHidden, seq_bytes * 4);
+      const LstmBackwardStep st = {buffer_rsrc(dgates + row_step0 * 4 * kHidden, seq_bytes * 4), v_gates, l};
+      auto load_gate = [&](int q, float (&dst)[2][16]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dst[nt][r] = buffer_load_f32(gsrsrc, v_gates + nt * 128 + q * (kHidden * 4),
+                                         ((r & 3) + 8 * (r >> 2)) * l * (4 * kHidden * 4));
+      };
+
+      f32x16 acc[1][2];  // dL/dh_{t-1} through the recurrent weights
+      float dc[2][16];
+      {
+        float o[2][16], dgo[2][16];
+        load_gate(3, o);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int so = ((r & 3) + 8 * (r >> 2)) * l * (kHidden * 4);
+            const float dh = buffer_load_f32(dhrsrc, v_seq + nt * 128, so) + dh_carry[nt][r];
+            const float tc = tanh_f(buffer_load_f32(csrsrc, v_seq + nt * 128, so));
+            dgo[nt][r] = dh * tc * (o[nt][r] * (1.0f - o[nt][r]));
+            dc[nt][r] = __builtin_fmaf(dh * o[nt][r], 1.0f - tc * tc, dc_carry[nt][r]);
+          }
+        lstm_emit_gate<0, true>(3, dgo, st, gemm, wrsrc, lds, wave, hh, l31, acc);
+      }
+      {
+        float gi[2][16], gg[2][16], dgi[2][16];
+        load_gate(0, gi);
+        load_gate(2, gg);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dgi[nt][r] = dc[nt][r] * gg[nt][r] * (gi[nt][r] * (1.0f - gi[nt][r]));
+        lstm_emit_gate<1, false>(0, dgi, st, gemm, wrsrc, lds, wave, hh, l31, acc);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dgi[nt][r] = dc[nt][r] * gi[nt][r] * (1.0f - gg[nt][r] * gg[nt][r]);
+        lstm_emit_gate<0, false>(2, dgi, st, gemm, wrsrc, lds, wave, hh, l31, acc);
+      }
+      {
+        float f[2][16], dgf[2][16];
+        load_gate(1, f);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float cp = buffer_load_f32(cprsrc, v_cprev + nt * 128, ((r & 3) + 8 * (r >> 2)) * cprev_pitch);
+            dgf[nt][r] = dc[nt][r] * cp * (f[nt][r] * (1.0f - f[nt][r]));
+            dc_carry[nt][r] = dc[nt][r] * f[nt][r];
+          }
+        lstm_emit_gate<1, false>(1, dgf, st, gemm, wrsrc, lds, wave, hh, l31, acc);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh_carry[nt][r] = acc[0][nt][r];
+    }
+  }
+}
+
+// Gradients of the input weights and the biases: column sums over all M = B*L
+// rows of dG[row][j] * x[row][c] and of dG[row][j] (j < 1024).  Memory-bound (one
+// more read of dG); thread = column, a workgroup walks a slice of the rows, and
+// leaves one partial row [dW_ih (1024*d) | db (1024)] summed by the host side in
+// workgroup order.
+template <int DIN>
+__global__ __launch_bounds__(kBlock) void lstm_input_grad_kernel(const float *__restrict__ x,
+                                                                 const float *__restrict__ dgates,
+                                                                 int64_t m, float *__restrict__ partials) {
+  const int j = blockIdx.y * kBlock + threadIdx.x;  // column of dG (gridDim.y = 4)
+  float db = 0.0f, dw[DIN];
+#pragma unroll
+  for (int c = 0; c < DIN; ++c) dw[c] = 0.0f;
+  const int64_t rows_per_block = (m + gridDim.x - 1) / gridDim.x;
+  const int64_t r_begin = blockIdx.x * rows_per_block;
+  const int64_t r_end = r_begin + rows_per_block < m ? r_begin + rows_per_block : m;
+#pragma unroll 4
+  for (int64_t r = r_begin; r < r_end; ++r) {
+    const float g = dgates[r * (4 * kHidden) + j];
+    db += g;
+#pragma unroll
+    for (int c = 0; c < DIN; ++c) dw[c] = __builtin_fmaf(g, x[r * DIN + c], dw[c]);
+  }
+  float *row = partials + (int64_t)blockIdx.x * (4 * kHidden * (DIN + 1));
+  row[4 * kHidden * DIN + j] = db;
+#pragma unroll
+  for (int c = 0; c < DIN; ++c) row[j * DIN + c] = dw[c];
+}
+
 inline size_t lstm_lds_bytes() { return sizeof(float) * kLstmRows * kLstmStride; }
 
 }  // namespace rl8
@@ -238,4 +407,46 @@ RL8_API int rl8_lstm_forward_f32(const float *x, int64_t b, int l, int d_in, con
     lstm_forward_kernel<false><<<grid, kBlock, lstm_lds_bytes(), s>>>(x, b, l, d_in, h0, c0, w_packed, hs, hn, cn,
                                                                     save_gates, save_c);
   return launch_status();
+}
+
+RL8_API int64_t rl8_lstm_backward_partial_floats(int d_in) { return (int64_t)4 * kHidden * (d_in + 1); }
+
+RL8_API int rl8_lstm_backward_max_rows(void) { return 4 * kCUs; }
+
+template <int DIN>
+static int launch_lstm_input_grad(int rows, hipStream_t s, const float *x, const float *dgates,
+                                  int64_t m, float *partials) {
+  lstm_input_grad_kernel<DIN><<<dim3(rows, 4), kBlock, 0, s>>>(x, dgates, m, partials);
+  return launch_status();
+}
+
+RL8_API int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, const float *c0,
+                                  const float *gates, const float *cs, const float *dhs,
+                                  const float *whht_packed, float *dgates, float *partials,
+                                  int *partial_rows_out, void *stream) {
+  if (!x || !c0 || !gates || !cs || !dhs || !whht_packed || !dgates || !partials || !partial_rows_out)
+    return RL8_ENULL;
+  if (b <= 0 || l <= 0) return RL8_ESIZE;
+  if (!rl8_lstm_supports(d_in)) return RL8_ESIZE;
+  if ((int64_t)kLstmRows * l * 4 * kHidden * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
+  if (!aligned16(whht_packed)) return RL8_EALIGN;
+  const int64_t tiles = (b + kLstmRows - 1) / kLstmRows;
+  const int grid = (int)(tiles < 2 * kCUs ? tiles : 2 * kCUs);
+  hipStream_t s = (hipStream_t)stream;
+  lstm_backward_kernel<<<grid, kBlock, 2 * sizeof(float) * kLstmRows * kLdsStride, s>>>(
+      b, l, c0, gates, cs, dhs, whht_packed, dgates);
+  int st = launch_status();
+  if (st != RL8_OK) return st;
+  const int64_t m = b * l;
+  const int rows = (int)(m < 4 * kCUs ? m : 4 * kCUs);
+  *partial_rows_out = rows;
+  switch (d_in) {
+    case 1: return launch_lstm_input_grad<1>(rows, s, x, dgates, m, partials);
+    case 2: return launch_lstm_input_grad<2>(rows, s, x, dgates, m, partials);
+    case 3: return launch_lstm_input_grad<3>(rows, s, x, dgates, m, partials);
+    case 4: return launch_lstm_input_grad<4>(rows, s, x, dgates, m, partials);
+    case 5: return launch_lstm_input_grad<5>(rows, s, x, dgates, m, partials);
+    case 6: return launch_lstm_input_grad<6>(rows, s, x, dgates, m, partials);
+    default: return launch_lstm_input_grad<7>(rows, s, x, dgates, m, partials);
+  }
 }

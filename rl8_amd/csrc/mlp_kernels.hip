@@ -740,8 +740,8 @@ __device__ __forceinline__ void wgrad_mma(const WgradFrag &f, f32x16 (&acc)[2][4
 }
 
 __global__ __launch_bounds__(kWgradThreads, 1) void mlp_wgrad_kernel(
-    const float *__restrict__ dz2, const float *__restrict__ h1, int64_t m,
-    float *__restrict__ slabs) {
+    const float *__restrict__ dz2, int64_t z_pitch, const float *__restrict__ h1, int64_t h_pitch,
+    int64_t m, float *__restrict__ slabs) {
   extern __shared__ float lds[];  // [2 buffers][dZ2 tile | h1 tile][32 rows x 320]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -761,15 +761,16 @@ __global__ __launch_bounds__(kWgradThreads, 1) void mlp_wgrad_kernel(
   auto fetch = [&](int64_t tile, int buffer) {
     const int64_t r0 = tile * kWgradRows;
     const int rows = (int)((m - r0) < kWgradRows ? (m - r0) : kWgradRows);
-    const __amdgpu_buffer_rsrc_t zr = buffer_rsrc(dz2 + r0 * kHidden, rows * kHidden * 4);
-    const __amdgpu_buffer_rsrc_t hr = buffer_rsrc(h1 + r0 * kHidden, rows * kHidden * 4);
+    // row pitches in floats (256 for dense operands; 1024 for one gate of an LSTM's [rows][4][256] gradients)
+    const __amdgpu_buffer_rsrc_t zr = buffer_rsrc(dz2 + r0 * z_pitch, (uint32_t)(((rows - 1) * z_pitch + kHidden) * 4));
+    const __amdgpu_buffer_rsrc_t hr = buffer_rsrc(h1 + r0 * h_pitch, (uint32_t)(((rows - 1) * h_pitch + kHidden) * 4));
     float *zb = lds + buffer * 2 * kWgradTile, *hb = zb + kWgradTile;
 #pragma unroll
     for (int u = 0; u < kWgradRows / 8; ++u) {
       const int row = wave + 8 * u;  // bit 2 of the row = bit 2 of the wave
       const int off = row * kWgradStride + ((wave & 4) ? 32 : 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, zb + off, 16, lane * 16, row * (kHidden * 4), 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, hb + off, 16, lane * 16, row * (kHidden * 4), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, zb + off, 16, lane * 16, row * (int)z_pitch * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, hb + off, 16, lane * 16, row * (int)h_pitch * 4, 0, 0);
     }
   };
   // Per-lane LDS addresses of the six operand columns, for either buffer.
@@ -919,10 +920,13 @@ RL8_API int64_t rl8_mlp_wgrad_workspace_bytes(void) {
   return (int64_t)kCUs * kHidden * kHidden * (int64_t)sizeof(float);
 }
 
-RL8_API int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, float *workspace,
-                              float *dw2_out, int accumulate, void *stream) {
+RL8_API int rl8_mlp_wgrad_strided_f32(const float *dz2, int64_t dz2_pitch, const float *h1,
+                                      int64_t h1_pitch, int64_t m, float *workspace, float *dw2_out,
+                                      int accumulate, void *stream) {
   if (!dz2 || !h1 || !workspace || !dw2_out) return RL8_ENULL;
-  if (m <= 0) return RL8_ESIZE;
+  if (m <= 0 || dz2_pitch < kHidden || h1_pitch < kHidden || dz2_pitch > 65536 || h1_pitch > 65536 ||
+      dz2_pitch % 4 || h1_pitch % 4)
+    return RL8_ESIZE;
   if (!aligned16(dz2) || !aligned16(h1) || !aligned16(workspace) || !aligned16(dw2_out))
     return RL8_EALIGN;
   static bool attr_set = false;
@@ -936,10 +940,15 @@ RL8_API int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, floa
   const int grid = (int)(tiles < kCUs ? tiles : kCUs);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds_bytes = sizeof(float) * 4 * kWgradTile;
-  mlp_wgrad_kernel<<<grid, kWgradThreads, lds_bytes, s>>>(dz2, h1, m, workspace);
+  mlp_wgrad_kernel<<<grid, kWgradThreads, lds_bytes, s>>>(dz2, dz2_pitch, h1, h1_pitch, m, workspace);
   int st = launch_status();
   if (st != RL8_OK) return st;
   mlp_wgrad_reduce_kernel<<<kHidden * kHidden / 4 / kBlock, kBlock, 0, s>>>(workspace, grid,
                                                                           dw2_out, accumulate);
   return launch_status();
+}
+
+RL8_API int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, float *workspace,
+                              float *dw2_out, int accumulate, void *stream) {
+  return rl8_mlp_wgrad_strided_f32(dz2, kHidden, h1, kHidden, m, workspace, dw2_out, accumulate, stream);
 }

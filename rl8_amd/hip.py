@@ -124,6 +124,10 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_pack_floats": [],
     "rl8_lstm_pack_f32": [_vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "rl8_lstm_forward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rl8_lstm_backward_partial_floats": [_i32],
+    "rl8_lstm_backward_max_rows": [],
+    "rl8_lstm_backward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_mlp_wgrad_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp],
     "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
     "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
@@ -156,7 +160,7 @@ def load() -> C.CDLL:
             fn.restype = (
                 C.c_int64
                 if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes",
-                            "rl8_lstm_pack_floats")
+                            "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats")
                 else C.c_int
             )
         _lib = lib
@@ -938,3 +942,56 @@ def lstm_forward(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, w_packed: 
         _check(load().rl8_lstm_forward_f32(_ptr(x), b, l, d_in, _ptr(h0), _ptr(c0), _ptr(w_packed), _ptr(hs), _ptr(hn),
                                            _ptr(cn), _ptr(gates), _ptr(cs), _stream()), "rl8_lstm_forward_f32")
     return hs, hn, cn, gates, cs
+
+
+def lstm_pack_transposed(w_hh: torch.Tensor) -> torch.Tensor:
+    """``weight_hh_l0`` [1024, 256] -> the four gate blocks packed for the backward
+    data-gradient product (``rl8_mlp_pack_w2_f32(..., transposed=1)`` per gate)."""
+    w_hh = _dense(w_hh.detach(), torch.float32, "w_hh")
+    if tuple(w_hh.shape) != (4 * LSTM_HIDDEN, LSTM_HIDDEN):
+        raise ValueError("w_hh must be [1024, 256]")
+    return torch.cat([mlp_pack_w2(w_hh[LSTM_HIDDEN * q : LSTM_HIDDEN * (q + 1)], transposed=True) for q in range(4)])
+
+
+def lstm_backward(
+    x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, hs: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor,
+    dhs: torch.Tensor, whht_packed: torch.Tensor,
+) -> dict[str, torch.Tensor]:
+    """Parameter gradients of the LSTM given ``dhs`` [B, L, 256] (gradient of every
+    ``h_t``) and what ``lstm_forward(..., save=True)`` returned. Returns ``w_ih``,
+    ``w_hh``, ``b`` (the gradient of each of the two bias vectors)."""
+    x = _dense(x.detach(), torch.float32, "x")
+    b, l, d_in = x.shape
+    for name, t, shape in (("h0", h0, (b, LSTM_HIDDEN)), ("c0", c0, (b, LSTM_HIDDEN)), ("hs", hs, (b, l, LSTM_HIDDEN)),
+                           ("gates", gates, (b, l, 4, LSTM_HIDDEN)), ("cs", cs, (b, l, LSTM_HIDDEN)),
+                           ("dhs", dhs, (b, l, LSTM_HIDDEN))):
+        _dense(t, torch.float32, name)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+    lib = load()
+    dev = x.device
+    width = int(lib.rl8_lstm_backward_partial_floats(d_in))
+    partials = torch.empty(int(lib.rl8_lstm_backward_max_rows()), width, dtype=torch.float32, device=dev)
+    dgates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    rows = C.c_int(0)
+    with _timed("lstm_backward", b * l):
+        _check(lib.rl8_lstm_backward_f32(_ptr(x), b, l, d_in, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dhs),
+                                         _ptr(whht_packed), _ptr(dgates), _ptr(partials), C.byref(rows), _stream()),
+               "rl8_lstm_backward_f32")
+    small = partials[: rows.value].sum(0)
+    # h_{t-1} for every row: h0, then the outputs shifted by one step
+    h_prev = torch.cat([h0.unsqueeze(1), hs[:, :-1]], dim=1).contiguous()
+    m = b * l
+    key = (dev.index or 0, _stream() or 0)
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = _wgrad_ws[key] = torch.empty(int(lib.rl8_mlp_wgrad_workspace_bytes()) // 4, dtype=torch.float32, device=dev)
+    dw_hh = torch.empty(4 * LSTM_HIDDEN, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    flat = dgates.view(m, 4 * LSTM_HIDDEN)
+    with _timed("lstm_wgrad", m):
+        for q in range(4):
+            _check(lib.rl8_mlp_wgrad_strided_f32(_ptr(flat) + 4 * LSTM_HIDDEN * q, 4 * LSTM_HIDDEN, _ptr(h_prev),
+                                                 LSTM_HIDDEN, m, _ptr(ws), _ptr(dw_hh) + 4 * LSTM_HIDDEN * LSTM_HIDDEN * q,
+                                                 0, _stream()), "rl8_mlp_wgrad_strided_f32")
+    return {"w_ih": small[: 4 * LSTM_HIDDEN * d_in].view(4 * LSTM_HIDDEN, d_in), "w_hh": dw_hh,
+            "b": small[4 * LSTM_HIDDEN * d_in :]}

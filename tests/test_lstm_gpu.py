@@ -56,3 +56,27 @@ def test_lstm_argument_checks():
         hip.lstm_forward(x, torch.zeros(4, 128, device=DEV), torch.zeros(4, 256, device=DEV), packed)
     with pytest.raises(ValueError):
         hip.lstm_pack(lstm.weight_ih_l0, lstm.weight_hh_l0[:, :128], lstm.bias_ih_l0, lstm.bias_hh_l0)
+
+
+@pytest.mark.parametrize("b,l,d_in", [(1, 1, 1), (33, 3, 1), (64, 4, 2), (300, 5, 5), (2000, 8, 1), (4097, 2, 7)])
+def test_lstm_backward_matches_autograd(b, l, d_in):
+    lstm = reference_lstm(d_in, b + 7 * l)
+    g = torch.Generator(device=DEV).manual_seed(b + 1)
+    x = torch.randn(b, l, d_in, device=DEV, generator=g) * 3
+    h0 = torch.randn(b, 256, device=DEV, generator=g) * 0.5
+    c0 = torch.randn(b, 256, device=DEV, generator=g)
+    dhs = torch.randn(b, l, 256, device=DEV, generator=g) / (b * l)
+    with torch.backends.cudnn.flags(enabled=False):
+        out, _ = lstm(x, (h0.unsqueeze(0), c0.unsqueeze(0)))
+    out.backward(dhs)
+    hs, hn, cn, gates, cs = hip.lstm_forward(x, h0, c0, pack(lstm), save=True)
+    grads = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, hip.lstm_pack_transposed(lstm.weight_hh_l0))
+
+    def close(got, want, name):
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got - want).abs().max()) / scale < 2e-5, (name, float((got - want).abs().max()), scale)
+
+    close(grads["w_hh"], lstm.weight_hh_l0.grad, "w_hh")
+    close(grads["w_ih"], lstm.weight_ih_l0.grad, "w_ih")
+    close(grads["b"], lstm.bias_ih_l0.grad, "b_ih")
+    close(grads["b"], lstm.bias_hh_l0.grad, "b_hh")
