@@ -101,14 +101,22 @@ def _small_head(in_dim: int, out_dim: int) -> nn.Linear:
 
 
 def _run_lstm(lstm: nn.LSTM, obs: torch.Tensor, states: TensorDict) -> tuple[torch.Tensor, TensorDict, int]:
-    h_0 = states[DataKeys.HIDDEN_STATES][:, 0, ...].permute(1, 0, 2).contiguous()
-    c_0 = states[DataKeys.CELL_STATES][:, 0, ...].permute(1, 0, 2).contiguous()
-    # PyTorch's own fused LSTM cell (GEMM + one pointwise kernel per step), not the
-    # MIOpen RNN: on gfx950 the latter is 2x slower at these shapes (update 670 vs
-    # 329 ms on BASELINE config 5's per-GPU share) and its 32-bit-indexed workspace
-    # faults beyond 2^18 rows per call.
-    with torch.backends.cudnn.flags(enabled=False):
-        latents, (h_n, c_n) = lstm(obs, (h_0, c_0))
+    from .nn import fused_lstm
+
+    h_first = states[DataKeys.HIDDEN_STATES][:, 0, ...]  # [B, layers, hidden]
+    c_first = states[DataKeys.CELL_STATES][:, 0, ...]
+    fused = fused_lstm.lstm_forward(lstm, obs, h_first[:, 0], c_first[:, 0]) if lstm.num_layers == 1 else None
+    if fused is not None:
+        latents, h_last, c_last = fused
+        h_n, c_n = h_last.unsqueeze(0), c_last.unsqueeze(0)
+    else:
+        h_0 = h_first.permute(1, 0, 2).contiguous()
+        c_0 = c_first.permute(1, 0, 2).contiguous()
+        # PyTorch's own fused LSTM cell (GEMM + one pointwise kernel per step), not the
+        # MIOpen RNN: on gfx950 the latter is 2x slower at these shapes and its
+        # 32-bit-indexed workspace faults beyond 2^18 rows per call.
+        with torch.backends.cudnn.flags(enabled=False):
+            latents, (h_n, c_n) = lstm(obs, (h_0, c_0))
     new_states = TensorDict(
         {DataKeys.HIDDEN_STATES: h_n.permute(1, 0, 2), DataKeys.CELL_STATES: c_n.permute(1, 0, 2)},
         batch_size=obs.size(0),

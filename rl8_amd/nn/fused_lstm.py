@@ -1,0 +1,93 @@
+"""The default recurrent models' LSTM as fused gfx950 kernels.
+
+``torch.nn.LSTM(d_in, 256, num_layers=1, batch_first=True)`` -- what
+``DefaultContinuousRecurrentModel`` / ``DefaultDiscreteRecurrentModel`` are built
+around (``src/rl8/models/_recurrent.py:201-321`` of the reference) -- runs as one
+forward kernel (time loop inside, gates never leave the chip) and, for training,
+one backward-through-time kernel plus the weight-gradient kernels, instead of two
+GEMMs and a pointwise kernel per timestep. Parameters stay the module's own;
+``lstm_forward`` returns ``None`` for any other LSTM (more layers, other widths,
+projections, bidirectional, non-HIP / non-fp32 inputs) and the caller runs the
+module itself.
+
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+
+#: Set to False to evaluate LSTMs with PyTorch (A/B comparisons).
+ENABLED = True
+
+
+def _eligible(lstm: nn.LSTM, x: torch.Tensor) -> bool:
+    return (
+        ENABLED
+        and x.is_cuda
+        and x.dtype == torch.float32
+        and x.ndim == 3
+        and lstm.num_layers == 1
+        and lstm.hidden_size == hip.LSTM_HIDDEN
+        and lstm.batch_first
+        and lstm.bias
+        and not lstm.bidirectional
+        and lstm.proj_size == 0
+        and x.shape[2] == lstm.input_size
+        and hip.lstm_supports(lstm.input_size)
+    )
+
+
+def _packs(lstm: nn.LSTM, transposed: bool) -> torch.Tensor:
+    """Fragment-ordered copies of the weights, cached ON the module and re-made
+    when the optimizer has changed a parameter (version counters) or a parameter
+    tensor has been replaced / moved."""
+    params = (lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
+    stamp = tuple((p._version, p.data_ptr()) for p in params)
+    cache = lstm.__dict__.setdefault("_rl8_lstm_packs", {})
+    hit = cache.get(transposed)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    packed = hip.lstm_pack_transposed(params[1]) if transposed else hip.lstm_pack(*params)
+    cache[transposed] = (stamp, packed)
+    return packed
+
+
+class _FusedLSTM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, lstm, grad_mode):  # type: ignore[override]
+        need_grad = grad_mode and any(ctx.needs_input_grad[3:7])
+        hs, hn, cn, gates, cs = hip.lstm_forward(x, h0, c0, _packs(lstm, False), save=need_grad)
+        ctx.set_materialize_grads(False)
+        if need_grad:
+            ctx.lstm = lstm
+            ctx.save_for_backward(x, h0, c0, hs, gates, cs)
+        ctx.mark_non_differentiable(cn)
+        return hs, hn, cn
+
+    @staticmethod
+    def backward(ctx, dhs, dhn, dcn):  # type: ignore[override]
+        x, h0, c0, hs, gates, cs = ctx.saved_tensors
+        if dhs is None:
+            dhs = torch.zeros_like(hs)
+        dhs = dhs.contiguous().float()
+        if dhn is not None:  # h_n is h_{L-1}
+            dhs = dhs.clone()
+            dhs[:, -1] += dhn
+        g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, _packs(ctx.lstm, True))
+        return None, None, None, g["w_ih"], g["w_hh"], g["b"], g["b"], None, None
+
+
+def lstm_forward(lstm: nn.LSTM, x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor):
+    """``lstm(x, (h0[None], c0[None]))`` for ``x`` [B, L, d], ``h0`` / ``c0`` [B, 256]
+    through the fused kernels: ``(hs [B, L, 256], h_n [B, 256], c_n [B, 256])``, or
+    ``None`` when this LSTM / input is not eligible. No gradient flows to ``x``,
+    ``h0``, ``c0`` (rollout-buffer data) nor out of ``c_n``."""
+    if not _eligible(lstm, x):
+        return None
+    return _FusedLSTM.apply(
+        x.contiguous(), h0.contiguous().float(), c0.contiguous().float(), lstm.weight_ih_l0, lstm.weight_hh_l0,
+        lstm.bias_ih_l0, lstm.bias_hh_l0, lstm, torch.is_grad_enabled(),
+    )
