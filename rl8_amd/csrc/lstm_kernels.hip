@@ -259,77 +259,93 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_backward_kernel(
     const int64_t b0 = tile * kLstmRows;
     const int rows = (int)((b - b0) < kLstmRows ? (b - b0) : kLstmRows);
     const __amdgpu_buffer_rsrc_t c0rsrc = buffer_rsrc(c0 + b0 * kHidden, rows * kHidden * 4);
-    float dh_carry[2][16], dc_carry[2][16];
+    // Software pipeline over the steps: every group of loads is issued ahead of a
+    // tile product and consumed behind it -- {i, g} before gate o's product, {f,
+    // c_{t-1}} before gate g's, the next step's {o, dh} before gate f's; c_{t-1}
+    // becomes the next step's c_t without a reload.
+    float dh_carry[2][16], dc_carry[2][16], o[2][16], dh_out[2][16], c_t[2][16];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh_carry[nt][r] = dc_carry[nt][r] = 0.0f;
+    auto seq_rsrc = [&](const float *base, int t, int per_row) {
+      return buffer_rsrc(base + (b0 * l + t) * (int64_t)per_row, (uint32_t)(((rows - 1) * l + 1) * per_row * 4));
+    };
+    auto load_gate = [&](const __amdgpu_buffer_rsrc_t &gs, int q, float (&dst)[2][16]) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dst[nt][r] = buffer_load_f32(gs, v_gates + nt * 128 + q * (kHidden * 4),
+                                       ((r & 3) + 8 * (r >> 2)) * l * (4 * kHidden * 4));
+    };
+    auto load_seq = [&](const __amdgpu_buffer_rsrc_t &rs, float (&dst)[2][16]) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dst[nt][r] = buffer_load_f32(rs, v_seq + nt * 128, ((r & 3) + 8 * (r >> 2)) * l * (kHidden * 4));
+    };
+    {
+      const int t = l - 1;
+      load_gate(seq_rsrc(gates, t, 4 * kHidden), 3, o);
+      load_seq(seq_rsrc(dhs, t, kHidden), dh_out);
+      load_seq(seq_rsrc(cs, t, kHidden), c_t);
+    }
 
     for (int t = l - 1; t >= 0; --t) {
-      const int64_t row_step0 = b0 * l + t;
-      const uint32_t seq_bytes = (uint32_t)(((rows - 1) * l + 1) * kHidden * 4);
-      const __amdgpu_buffer_rsrc_t dhrsrc = buffer_rsrc(dhs + row_step0 * kHidden, seq_bytes);
-      const __amdgpu_buffer_rsrc_t csrsrc = buffer_rsrc(cs + row_step0 * kHidden, seq_bytes);
-      // c_{t-1}: the previous step's saved cell state, or c0
-      const __amdgpu_buffer_rsrc_t cprsrc = t > 0 ? buffer_rsrc(cs + (row_step0 - 1) * kHidden, seq_bytes) : c0rsrc;
-      const int v_cprev = t > 0 ? v_seq : v_state;
-      const int cprev_pitch = t > 0 ? l * kHidden * 4 : kHidden * 4;
-      const __amdgpu_buffer_rsrc_t gsrsrc = buffer_rsrc(gates + row_step0 * 4 * kHidden, seq_bytes * 4);
-      const LstmBackwardStep st = {buffer_rsrc(dgates + row_step0 * 4 * kHidden, seq_bytes * 4), v_gates, l};
-      auto load_gate = [&](int q, float (&dst)[2][16]) {
+      const __amdgpu_buffer_rsrc_t gsrsrc = seq_rsrc(gates, t, 4 * kHidden);
+      const LstmBackwardStep st = {seq_rsrc(dgates, t, 4 * kHidden), v_gates, l};
+      f32x16 acc[1][2];  // dL/dh_{t-1} through the recurrent weights
+      float dc[2][16], gi[2][16], gg[2][16], dgq[2][16];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dh = dh_out[nt][r] + dh_carry[nt][r];
+          const float tc = tanh_f(c_t[nt][r]);
+          dgq[nt][r] = dh * tc * (o[nt][r] * (1.0f - o[nt][r]));
+          dc[nt][r] = __builtin_fmaf(dh * o[nt][r], 1.0f - tc * tc, dc_carry[nt][r]);
+        }
+      load_gate(gsrsrc, 0, gi);
+      load_gate(gsrsrc, 2, gg);
+      lstm_emit_gate<0, true>(3, dgq, st, gemm, wrsrc, lds, wave, hh, l31, acc);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dgq[nt][r] = dc[nt][r] * gg[nt][r] * (gi[nt][r] * (1.0f - gi[nt][r]));
+      lstm_emit_gate<1, false>(0, dgq, st, gemm, wrsrc, lds, wave, hh, l31, acc);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dgq[nt][r] = dc[nt][r] * gi[nt][r] * (1.0f - gg[nt][r] * gg[nt][r]);
+      // f and c_{t-1} (the previous step's saved cell state, or c0) into the registers i, g just left
+      float (&f)[2][16] = gi;
+      float (&cp)[2][16] = gg;
+      load_gate(gsrsrc, 1, f);
+      if (t > 0) {
+        load_seq(seq_rsrc(cs, t - 1, kHidden), cp);
+      } else {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            dst[nt][r] = buffer_load_f32(gsrsrc, v_gates + nt * 128 + q * (kHidden * 4),
-                                         ((r & 3) + 8 * (r >> 2)) * l * (4 * kHidden * 4));
-      };
-
-      f32x16 acc[1][2];  // dL/dh_{t-1} through the recurrent weights
-      float dc[2][16];
-      {
-        float o[2][16], dgo[2][16];
-        load_gate(3, o);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int so = ((r & 3) + 8 * (r >> 2)) * l * (kHidden * 4);
-            const float dh = buffer_load_f32(dhrsrc, v_seq + nt * 128, so) + dh_carry[nt][r];
-            const float tc = tanh_f(buffer_load_f32(csrsrc, v_seq + nt * 128, so));
-            dgo[nt][r] = dh * tc * (o[nt][r] * (1.0f - o[nt][r]));
-            dc[nt][r] = __builtin_fmaf(dh * o[nt][r], 1.0f - tc * tc, dc_carry[nt][r]);
-          }
-        lstm_emit_gate<0, true>(3, dgo, st, gemm, wrsrc, lds, wave, hh, l31, acc);
+            cp[nt][r] = buffer_load_f32(c0rsrc, v_state + nt * 128, ((r & 3) + 8 * (r >> 2)) * (kHidden * 4));
       }
-      {
-        float gi[2][16], gg[2][16], dgi[2][16];
-        load_gate(0, gi);
-        load_gate(2, gg);
+      lstm_emit_gate<0, false>(2, dgq, st, gemm, wrsrc, lds, wave, hh, l31, acc);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dgi[nt][r] = dc[nt][r] * gg[nt][r] * (gi[nt][r] * (1.0f - gi[nt][r]));
-        lstm_emit_gate<1, false>(0, dgi, st, gemm, wrsrc, lds, wave, hh, l31, acc);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dgi[nt][r] = dc[nt][r] * gi[nt][r] * (1.0f - gg[nt][r] * gg[nt][r]);
-        lstm_emit_gate<0, false>(2, dgi, st, gemm, wrsrc, lds, wave, hh, l31, acc);
+        for (int r = 0; r < 16; ++r) {
+          dgq[nt][r] = dc[nt][r] * cp[nt][r] * (f[nt][r] * (1.0f - f[nt][r]));
+          dc_carry[nt][r] = dc[nt][r] * f[nt][r];
+          c_t[nt][r] = cp[nt][r];  // the next (earlier) step's c_t
+        }
+      if (t > 0) {
+        load_gate(seq_rsrc(gates, t - 1, 4 * kHidden), 3, o);
+        load_seq(seq_rsrc(dhs, t - 1, kHidden), dh_out);
       }
-      {
-        float f[2][16], dgf[2][16];
-        load_gate(1, f);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float cp = buffer_load_f32(cprsrc, v_cprev + nt * 128, ((r & 3) + 8 * (r >> 2)) * cprev_pitch);
-            dgf[nt][r] = dc[nt][r] * cp * (f[nt][r] * (1.0f - f[nt][r]));
-            dc_carry[nt][r] = dc[nt][r] * f[nt][r];
-          }
-        lstm_emit_gate<1, false>(1, dgf, st, gemm, wrsrc, lds, wave, hh, l31, acc);
-      }
+      lstm_emit_gate<1, false>(1, dgq, st, gemm, wrsrc, lds, wave, hh, l31, acc);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
