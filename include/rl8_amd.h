@@ -388,6 +388,18 @@ int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, const floa
                           const float *whht_packed, float *dgates, float *partials,
                           int *partial_rows_out /*host*/, void *stream);
 
+/* The recurrent models' output heads (src/rl8/models/_recurrent.py:230-236, 287-292),
+ * all of them at once: out [M][n] = h [M][256] x w^T + b, w [n][256] (the heads'
+ * nn.Linear weights stacked), n <= 8.  Backward: dh_out [M][256] = dout x w and
+ * `*partial_rows_out` rows (<= rl8_linear_heads_max_rows()) of [dW (n*256) | db (n)]
+ * whose column sums are the parameter gradients. */
+int rl8_linear_heads_max_rows(void);
+int rl8_linear_heads_forward_f32(const float *h, int64_t m, const float *w, const float *b, int n_out,
+                                 float *out, void *stream);
+int rl8_linear_heads_backward_f32(const float *h, const float *dout, int64_t m, const float *w,
+                                  int n_out, float *dh_out, float *partials,
+                                  int *partial_rows_out /*host*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -466,3 +466,143 @@ RL8_API int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, co
     default: return launch_lstm_input_grad<7>(rows, s, x, dgates, m, partials);
   }
 }
+
+// ---------------------------------------------------------------------------
+// The recurrent models' output heads: a few Linear(256, n) layers on the LSTM's
+// outputs (src/rl8/models/_recurrent.py:230-236, 287-292), evaluated together:
+// out [M][n] = h [M][256] x W^T + b with n <= 8.  A library GEMM with N = 1..3 runs
+// at a small fraction of HBM speed here (3.5 ms per head and direction at M = 2^21);
+// these are single passes over h.  Memory-bound: 1 KiB read per row forward,
+// 1 KiB read + 1 KiB written backward.
+// ---------------------------------------------------------------------------
+namespace rl8 {
+
+constexpr int kHeadsMaxOut = 8;
+
+// Forward: 4 lanes per row (a quarter of the 256 inputs each, 16-byte loads), the
+// weights broadcast from LDS, two shuffles.
+template <int NOUT>
+__global__ __launch_bounds__(kBlock) void linear_heads_forward_kernel(const float4 *__restrict__ h,
+                                                                      int64_t m,
+                                                                      const float *__restrict__ w,
+                                                                      const float *__restrict__ bias,
+                                                                      float *__restrict__ out) {
+  __shared__ float4 ws[NOUT * kHidden / 4];
+  for (int i = threadIdx.x; i < NOUT * kHidden / 4; i += kBlock) ws[i] = reinterpret_cast<const float4 *>(w)[i];
+  __syncthreads();
+  const int q4 = threadIdx.x & 3;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / 4);
+  for (int64_t row = (int64_t)blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2); row < m; row += stride) {
+    float o[NOUT];
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) o[q] = 0.0f;
+    const float4 *hr = h + row * (kHidden / 4) + q4 * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 v = hr[i];
+#pragma unroll
+      for (int q = 0; q < NOUT; ++q) {
+        const float4 wv = ws[q * (kHidden / 4) + q4 * 16 + i];
+        o[q] = __builtin_fmaf(v.x, wv.x, o[q]);
+        o[q] = __builtin_fmaf(v.y, wv.y, o[q]);
+        o[q] = __builtin_fmaf(v.z, wv.z, o[q]);
+        o[q] = __builtin_fmaf(v.w, wv.w, o[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) {
+      float v = o[q];
+      v += __shfl_xor(v, 1, kWave);
+      v += __shfl_xor(v, 2, kWave);
+      if (q4 == 0) out[row * NOUT + q] = v + bias[q];
+    }
+  }
+}
+
+// Backward: thread = input unit j; a workgroup walks a contiguous slice of the rows:
+// dh[s][j] = sum_q dout[s][q] w[q][j]; dW[q][j] += dout[s][q] h[s][j]; db[q] += dout[s][q].
+// One partial row per workgroup: [dW (n*256) | db (n)], summed by the host side in
+// workgroup order.
+template <int NOUT>
+__global__ __launch_bounds__(kBlock) void linear_heads_backward_kernel(const float *__restrict__ h,
+                                                                       const float *__restrict__ dout,
+                                                                       int64_t m,
+                                                                       const float *__restrict__ w,
+                                                                       float *__restrict__ dh,
+                                                                       float *__restrict__ partials) {
+  const int j = threadIdx.x;
+  float wr[NOUT], dw[NOUT], db[NOUT];
+#pragma unroll
+  for (int q = 0; q < NOUT; ++q) {
+    wr[q] = w[q * kHidden + j];
+    dw[q] = db[q] = 0.0f;
+  }
+  const int64_t per_block = (m + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = blockIdx.x * per_block;
+  const int64_t r1 = r0 + per_block < m ? r0 + per_block : m;
+#pragma unroll 4
+  for (int64_t s = r0; s < r1; ++s) {
+    const float hv = h[s * kHidden + j];
+    float g = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) {
+      const float d = dout[s * NOUT + q];
+      g = __builtin_fmaf(d, wr[q], g);
+      dw[q] = __builtin_fmaf(d, hv, dw[q]);
+      db[q] += d;
+    }
+    dh[s * kHidden + j] = g;
+  }
+  float *row = partials + (int64_t)blockIdx.x * (NOUT * kHidden + NOUT);
+#pragma unroll
+  for (int q = 0; q < NOUT; ++q) {
+    row[q * kHidden + j] = dw[q];
+    if (j == 0) row[NOUT * kHidden + q] = db[q];
+  }
+}
+
+}  // namespace rl8
+
+RL8_API int rl8_linear_heads_max_rows(void) { return kMaxGrid; }
+
+RL8_API int rl8_linear_heads_forward_f32(const float *h, int64_t m, const float *w, const float *b,
+                                         int n_out, float *out, void *stream) {
+  if (!h || !w || !b || !out) return RL8_ENULL;
+  if (m <= 0 || n_out <= 0 || n_out > kHeadsMaxOut) return RL8_ESIZE;
+  if (!aligned16(h) || !aligned16(w)) return RL8_EALIGN;
+  const int grid = grid_for(m, kBlock / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const float4 *h4 = reinterpret_cast<const float4 *>(h);
+  switch (n_out) {
+    case 1: linear_heads_forward_kernel<1><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
+    case 2: linear_heads_forward_kernel<2><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
+    case 3: linear_heads_forward_kernel<3><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
+    case 4: linear_heads_forward_kernel<4><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
+    case 5: linear_heads_forward_kernel<5><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
+    case 6: linear_heads_forward_kernel<6><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
+    case 7: linear_heads_forward_kernel<7><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
+    default: linear_heads_forward_kernel<8><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
+  }
+  return launch_status();
+}
+
+RL8_API int rl8_linear_heads_backward_f32(const float *h, const float *dout, int64_t m,
+                                          const float *w, int n_out, float *dh_out, float *partials,
+                                          int *partial_rows_out, void *stream) {
+  if (!h || !dout || !w || !dh_out || !partials || !partial_rows_out) return RL8_ENULL;
+  if (m <= 0 || n_out <= 0 || n_out > kHeadsMaxOut) return RL8_ESIZE;
+  const int grid = (int)(m < kMaxGrid ? m : kMaxGrid);
+  *partial_rows_out = grid;
+  hipStream_t s = (hipStream_t)stream;
+  switch (n_out) {
+    case 1: linear_heads_backward_kernel<1><<<grid, kBlock, 0, s>>>(h, dout, m, w, dh_out, partials); break;
+    case 2: linear_heads_backward_kernel<2><<<grid, kBlock, 0, s>>>(h, dout, m, w, dh_out, partials); break;
+    case 3: linear_heads_backward_kernel<3><<<grid, kBlock, 0, s>>>(h, dout, m, w, dh_out, partials); break;
+    case 4: linear_heads_backward_kernel<4><<<grid, kBlock, 0, s>>>(h, dout, m, w, dh_out, partials); break;
+    case 5: linear_heads_backward_kernel<5><<<grid, kBlock, 0, s>>>(h, dout, m, w, dh_out, partials); break;
+    case 6: linear_heads_backward_kernel<6><<<grid, kBlock, 0, s>>>(h, dout, m, w, dh_out, partials); break;
+    case 7: linear_heads_backward_kernel<7><<<grid, kBlock, 0, s>>>(h, dout, m, w, dh_out, partials); break;
+    default: linear_heads_backward_kernel<8><<<grid, kBlock, 0, s>>>(h, dout, m, w, dh_out, partials); break;
+  }
+  return launch_status();
+}

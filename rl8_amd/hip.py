@@ -127,6 +127,9 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_backward_partial_floats": [_i32],
     "rl8_lstm_backward_max_rows": [],
     "rl8_lstm_backward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_linear_heads_max_rows": [],
+    "rl8_linear_heads_forward_f32": [_vp, _i64, _vp, _vp, _i32, _vp, _vp],
+    "rl8_linear_heads_backward_f32": [_vp, _vp, _i64, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_wgrad_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp],
     "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
     "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
@@ -995,3 +998,37 @@ def lstm_backward(
                                                  0, _stream()), "rl8_mlp_wgrad_strided_f32")
     return {"w_ih": small[: 4 * LSTM_HIDDEN * d_in].view(4 * LSTM_HIDDEN, d_in), "w_hh": dw_hh,
             "b": small[4 * LSTM_HIDDEN * d_in :]}
+
+
+def linear_heads_forward(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """h [M, 256] x w [n, 256]^T + b [n] -> [M, n] (n <= 8)."""
+    h = _dense(h.detach(), torch.float32, "h")
+    w = _dense(w.detach(), torch.float32, "w")
+    b = _dense(b.detach(), torch.float32, "b")
+    m, n = h.shape[0], w.shape[0]
+    if h.shape[1] != LSTM_HIDDEN or w.shape[1] != LSTM_HIDDEN or b.numel() != n:
+        raise ValueError("linear_heads_forward: h [M, 256], w [n, 256], b [n]")
+    out = torch.empty(m, n, dtype=torch.float32, device=h.device)
+    with _timed("linear_heads_forward", m):
+        _check(load().rl8_linear_heads_forward_f32(_ptr(h), m, _ptr(w), _ptr(b), n, _ptr(out), _stream()),
+               "rl8_linear_heads_forward_f32")
+    return out
+
+
+def linear_heads_backward(h: torch.Tensor, dout: torch.Tensor, w: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (dh [M, 256], dw [n, 256], db [n])."""
+    h = _dense(h.detach(), torch.float32, "h")
+    dout = _dense(dout, torch.float32, "dout")
+    w = _dense(w.detach(), torch.float32, "w")
+    m, n = h.shape[0], w.shape[0]
+    if tuple(dout.shape) != (m, n):
+        raise ValueError("linear_heads_backward: dout must be [M, n]")
+    lib = load()
+    dh = torch.empty(m, LSTM_HIDDEN, dtype=torch.float32, device=h.device)
+    partials = torch.empty(int(lib.rl8_linear_heads_max_rows()), n * LSTM_HIDDEN + n, dtype=torch.float32, device=h.device)
+    rows = C.c_int(0)
+    with _timed("linear_heads_backward", m):
+        _check(lib.rl8_linear_heads_backward_f32(_ptr(h), _ptr(dout), m, _ptr(w), n, _ptr(dh), _ptr(partials),
+                                                 C.byref(rows), _stream()), "rl8_linear_heads_backward_f32")
+    small = partials[: rows.value].sum(0)
+    return dh, small[: n * LSTM_HIDDEN].view(n, LSTM_HIDDEN), small[n * LSTM_HIDDEN :]

@@ -148,9 +148,14 @@ class DefaultContinuousRecurrentModel(RecurrentModel):
     def forward(self, batch: TensorDict, states: TensorDict, /) -> tuple[TensorDict, TensorDict]:
         obs = batch[DataKeys.OBS]
         latents, new_states, _ = _run_lstm(self.lstm, obs, states)
-        action_mean = self.action_mean(latents).reshape(-1, self.action_spec.shape[0])
-        action_log_std = self.action_log_std(latents).reshape(-1, self.action_spec.shape[0])
-        self._value = self.vf_model(latents).reshape(-1, 1)
+        from .nn import fused_lstm
+
+        outs = fused_lstm.heads_forward([self.action_mean, self.action_log_std, self.vf_model], latents)
+        if outs is None:
+            outs = [self.action_mean(latents), self.action_log_std(latents), self.vf_model(latents)]
+        action_mean = outs[0].reshape(-1, self.action_spec.shape[0])
+        action_log_std = outs[1].reshape(-1, self.action_spec.shape[0])
+        self._value = outs[2].reshape(-1, 1)
         return (
             TensorDict(
                 {"mean": action_mean, "log_std": torch.tanh(action_log_std)},
@@ -192,8 +197,13 @@ class DefaultDiscreteRecurrentModel(RecurrentModel):
     def forward(self, batch: TensorDict, states: TensorDict, /) -> tuple[TensorDict, TensorDict]:
         obs = batch[DataKeys.OBS]
         latents, new_states, _ = _run_lstm(self.lstm, obs, states)
-        logits = self.feature_head(latents).reshape(-1, self.action_spec.shape[0], self.action_spec.space.n)
-        self._value = self.vf_head(latents).reshape(-1, 1)
+        from .nn import fused_lstm
+
+        outs = fused_lstm.heads_forward([self.feature_head, self.vf_head], latents)
+        if outs is None:
+            outs = [self.feature_head(latents), self.vf_head(latents)]
+        logits = outs[0].reshape(-1, self.action_spec.shape[0], self.action_spec.space.n)
+        self._value = outs[1].reshape(-1, 1)
         return TensorDict({"logits": logits}, batch_size=logits.size(0), device=obs.device), new_states
 
     def to(self, device: Device) -> "DefaultDiscreteRecurrentModel":  # type: ignore[override]

@@ -91,3 +91,35 @@ def lstm_forward(lstm: nn.LSTM, x: torch.Tensor, h0: torch.Tensor, c0: torch.Ten
         x.contiguous(), h0.contiguous().float(), c0.contiguous().float(), lstm.weight_ih_l0, lstm.weight_hh_l0,
         lstm.bias_ih_l0, lstm.bias_hh_l0, lstm, torch.is_grad_enabled(),
     )
+
+
+class _FusedHeads(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, w, b):  # type: ignore[override]
+        out = hip.linear_heads_forward(h, w, b)
+        ctx.save_for_backward(h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):  # type: ignore[override]
+        h, w = ctx.saved_tensors
+        dh, dw, db = hip.linear_heads_backward(h, dout.contiguous().float(), w)
+        return dh, dw, db
+
+
+def heads_forward(heads: list[nn.Linear], latents: torch.Tensor) -> None | list[torch.Tensor]:
+    """``[head(latents) for head in heads]`` for ``Linear(256, n_i)`` heads on
+    ``latents`` [..., 256] in one pass over ``latents`` (and one for the backward),
+    or ``None`` when not eligible."""
+    if not ENABLED or not latents.is_cuda or latents.dtype != torch.float32 or latents.shape[-1] != hip.LSTM_HIDDEN:
+        return None
+    if any(h.in_features != hip.LSTM_HIDDEN or h.bias is None for h in heads):
+        return None
+    widths = [h.out_features for h in heads]
+    if sum(widths) > 8:
+        return None
+    w = torch.cat([h.weight for h in heads], 0) if len(heads) > 1 else heads[0].weight
+    b = torch.cat([h.bias for h in heads], 0) if len(heads) > 1 else heads[0].bias
+    flat = latents.reshape(-1, hip.LSTM_HIDDEN)
+    out = _FusedHeads.apply(flat.contiguous(), w, b)
+    return list(out.split(widths, dim=1))

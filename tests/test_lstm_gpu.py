@@ -80,3 +80,62 @@ def test_lstm_backward_matches_autograd(b, l, d_in):
     close(grads["w_ih"], lstm.weight_ih_l0.grad, "w_ih")
     close(grads["b"], lstm.bias_ih_l0.grad, "b_ih")
     close(grads["b"], lstm.bias_hh_l0.grad, "b_hh")
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (67, 3), (5000, 2), (100_001, 8)])
+def test_linear_heads_match_torch(m, n):
+    g = torch.Generator(device=DEV).manual_seed(m)
+    h = torch.randn(m, 256, device=DEV, generator=g)
+    w = (torch.randn(n, 256, device=DEV, generator=g) / 16).requires_grad_(True)
+    b = torch.randn(n, device=DEV, generator=g).requires_grad_(True)
+    dout = torch.randn(m, n, device=DEV, generator=g) / m
+    hr = h.clone().requires_grad_(True)
+    want = torch.nn.functional.linear(hr.double(), w.double(), b.double())
+    want.backward(dout.double())
+    out = hip.linear_heads_forward(h, w, b)
+    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=1e-5)
+    dh, dw, db = hip.linear_heads_backward(h, dout, w)
+    torch.testing.assert_close(dh.double(), hr.grad.double(), rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(dw.double(), w.grad.double(), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(db.double(), b.grad.double(), rtol=1e-4, atol=1e-7)
+
+
+def test_fused_recurrent_model_matches_the_eager_modules():
+    """The default recurrent model through the fused LSTM + heads must give the
+    outputs and parameter gradients of the same modules run by PyTorch."""
+    from rl8_amd.data import DataKeys
+    from rl8_amd.env import DiscreteDummyEnv
+    from rl8_amd.models_recurrent import DefaultDiscreteRecurrentModel
+    from rl8_amd.nn import fused_lstm
+    from rl8_amd.tensordict import TensorDict
+
+    env = DiscreteDummyEnv(4, 8, device=DEV)
+    torch.manual_seed(2)
+    model = DefaultDiscreteRecurrentModel(env.observation_spec, env.action_spec).to(DEV)
+    b, l = 300, 4
+    g = torch.Generator(device=DEV).manual_seed(0)
+    obs = torch.randn(b, l, 1, device=DEV, generator=g) * 10
+    states = TensorDict(
+        {DataKeys.HIDDEN_STATES: torch.randn(b, l, 1, 256, device=DEV, generator=g) * 0.3,
+         DataKeys.CELL_STATES: torch.randn(b, l, 1, 256, device=DEV, generator=g)}, batch_size=[b, l])
+    w_logits = torch.randn(b * l, 1, 2, device=DEV, generator=g)
+    w_value = torch.randn(b * l, 1, device=DEV, generator=g)
+
+    def run(enabled):
+        fused_lstm.ENABLED = enabled
+        try:
+            model.zero_grad()
+            feats, new_states = model(TensorDict({DataKeys.OBS: obs}, batch_size=[b, l]), states)
+            ((feats["logits"] * w_logits).sum() + (model.value_function() * w_value).sum()).backward()
+            return (feats["logits"].detach().clone(), model.value_function().detach().clone(),
+                    new_states[DataKeys.HIDDEN_STATES].detach().clone(), new_states[DataKeys.CELL_STATES].detach().clone(),
+                    {k: p.grad.clone() for k, p in model.named_parameters()})
+        finally:
+            fused_lstm.ENABLED = True
+
+    fused, eager = run(True), run(False)
+    for a, e in zip(fused[:4], eager[:4]):
+        torch.testing.assert_close(a, e, rtol=1e-5, atol=2e-6)
+    for k in eager[4]:
+        scale = float(eager[4][k].abs().max()) + 1e-12
+        assert float((fused[4][k] - eager[4][k]).abs().max()) / scale < 5e-5, k
