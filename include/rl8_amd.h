@@ -321,6 +321,22 @@ int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *
                               const float *w3, const float *b3, int n_out, float *out,
                               float *save_h1, float *save_h2, void *stream);
 
+/* The same forward with the 256x256 product on the bf16 matrix pipe at fp32
+ * accuracy: both operands are split exactly into three bf16 planes
+ * (x = hi + mid + lo) and six of the nine plane products are accumulated in fp32
+ * (the three dropped ones are below one fp32 ulp of the product) -- 6 MFMAs of
+ * 16x the fp32 MFMA rate per 16 k instead of 8.  Inputs, outputs and saved
+ * activations are fp32 exactly as above; h1 is bit-identical, out / h2 agree
+ * with rl8_mlp_tower_forward_f32 to fp32 rounding.  w2_split
+ * (rl8_mlp_split_packed_bytes() bytes, 16-byte aligned) comes from
+ * rl8_mlp_pack_w2_split (transposed as for rl8_mlp_pack_w2_f32). */
+int64_t rl8_mlp_split_packed_bytes(void);
+int rl8_mlp_pack_w2_split(const float *w2 /*[256][256]*/, int transposed, void *w2_split, void *stream);
+int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const float *w1,
+                                    const float *b1, const void *w2_split, const float *b2,
+                                    const float *w3, const float *b3, int n_out, float *out,
+                                    float *save_h1, float *save_h2, void *stream);
+
 /* Backward of one tower ("dgrad" half): given dOut [M][n_out] and the saved
  * activations h1 / h2, writes dZ2 [M][256] (input of rl8_mlp_wgrad_f32, which
  * forms dW2 = dZ2^T h1) and `*partial_rows_out` rows (<= rl8_mlp_backward_max_rows()) of

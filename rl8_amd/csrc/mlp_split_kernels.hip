@@ -1,0 +1,463 @@
+// N1, second generation of the tower forward: the 256x256 layer as an
+// fp32-ACCURATE product on the bf16 matrix pipe.
+//
+// Why.  gfx950 runs fp32 MFMAs and the VALU on the same multipliers: 155 TFLOP/s,
+// and nothing overlaps with them (tools/probes/mfma_valu_probe.hip).  The bf16
+// matrix pipe sustains 1.75 PFLOP/s on changing operands and VALU work DOES run
+// beside it (tools/probes/bf16_split_probe.hip).  An fp32 value is exactly the sum
+// of three bf16 values (8 + 8 + 8 significand bits, by truncation:
+// hi = top16(x), mid = top16(x - hi), lo = x - hi - mid), bf16 x bf16 products
+// are exact in fp32 and the MFMA accumulates in fp32, so
+//   a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh) + O(2^-24 |a*b|)
+// -- six bf16 MFMAs per 16 k instead of eight fp32 MFMAs of 1/16 the rate.  The
+// dropped terms (am*bl, al*bm, al*bl) are below one fp32 ulp of the product; the
+// measured error of a K=256 dot product against fp64 is the same as that of an
+// fp32 fma chain.  This is NOT a bf16 tower: inputs,
+// outputs, saved activations and accumulation are fp32.
+//
+// Shape.  Both operands go through LDS, K-chunked, because at this rate the
+// weights can no longer stream from L2 per wave: a workgroup (4 waves) owns a
+// 128-row x 256-column macro tile, 128 accumulator registers per wave (wave =
+// 64 rows x 128 columns), and walks K in 16 steps of 16:
+//   B chunk (W2, three planes, fragment-ordered by rl8_mlp_pack_w2_split) comes
+//     HBM/L2 -> LDS by direct-to-LDS buffer loads: no registers, no VALU;
+//   A chunk (h1 = relu(x W1^T + b1), 128 rows x 16 k) is COMPUTED on the VALU for
+//     the next step while the matrix pipe works on the current one, split into
+//     the three planes and written to LDS as ready-made 16-byte fragments.
+// Two chunk buffers; one barrier per step.  Every LDS access of the loop is inline
+// asm with hand-placed s_waitcnt: the compiler serialises compiler-visible LDS
+// accesses behind outstanding direct-to-LDS loads (vmcnt(0) before each).
+#include <type_traits>
+
+#include "mfma_tile.hip.h"
+
+namespace rl8 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kSplitRows = 128;                 // rows per macro tile
+constexpr int kSplitSteps = kHidden / 16;       // k-steps of 16
+constexpr int kSplitABytes = 3 * 2 * kSplitRows * 16;      // [plane][k-half][row] x 16 B
+constexpr int kSplitBBytes = 3 * 8 * 1024;                 // [column tile][plane] x 1 KiB
+constexpr int kSplitStageBytes = kSplitABytes + kSplitBBytes;
+constexpr int kSplitPackedBytes = kSplitSteps * kSplitBBytes;  // 393 216
+
+// w2 [256][256] row-major fp32 -> three bf16 planes in fragment order:
+// 16-byte unit ((s*8 + ct)*3 + p)*64 + l holds, for plane p, the eight values
+//   B(col = 32 ct + (l & 31), k = 16 s + 8 (l >> 5) + e), e = 0..7,
+// B(col, k) = w2[col][k] (forward) or w2[k][col] (transposed: the data-gradient
+// product dH1 = dZ2 x W2).  One k-step of all eight column tiles is 24 KiB
+// contiguous: the direct-to-LDS copy of a step is 24 one-KiB loads.
+__global__ __launch_bounds__(kBlock) void mlp_pack_w2_split_kernel(const float *__restrict__ w2, int transposed,
+                                                                   uint32_t *__restrict__ packed) {
+  const int unit = blockIdx.x * kBlock + threadIdx.x;  // (s, ct, l): one 16-byte unit of each plane
+  if (unit >= kSplitSteps * 8 * 64) return;
+  const int l = unit & 63, ct = (unit >> 6) & 7, s = unit >> 9;
+  const int col = 32 * ct + (l & 31), k0 = 16 * s + 8 * (l >> 5);
+  uint32_t plane[3][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = transposed ? w2[(k0 + e) * kHidden + col] : w2[col * kHidden + k0 + e];
+    const uint32_t hi = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(hi);
+    const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;
+    const uint32_t parts[3] = {hi, mid, lo};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      if (e & 1)
+        plane[p][e >> 1] |= parts[p];
+      else
+        plane[p][e >> 1] = parts[p] >> 16;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    uint32_t *dst = packed + ((((s * 8 + ct) * 3 + p) * 64 + l) << 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = plane[p][q];
+  }
+}
+
+// ---- LDS access, invisible to the compiler's wait-count insertion -------------
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+__device__ __forceinline__ unsigned lds_offset(const void *p) {
+  return (unsigned)(uintptr_t)(lds_byte_t *)p;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_write_b32(unsigned addr, float v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ float lds_read_b32(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+// The operand registers of one k-step.  `m` first holds the mid planes and is
+// re-loaded with the lo planes once the mid terms have been issued.
+struct SplitFrags {
+  u32x4 ah[2], bh[4], am[2], bm[4];
+};
+__device__ __forceinline__ void wait_lds_all(SplitFrags &f) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.ah[0]), "+v"(f.ah[1]), "+v"(f.bh[0]), "+v"(f.bh[1]), "+v"(f.bh[2]), "+v"(f.bh[3]),
+                 "+v"(f.am[0]), "+v"(f.am[1]), "+v"(f.bm[0]), "+v"(f.bm[1]), "+v"(f.bm[2]), "+v"(f.bm[3]));
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void split_mma(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      if constexpr (FIRST) {
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mt]),
+                                                              __builtin_bit_cast(bf16x8, b[nt]), zero, 0, 0, 0);
+      } else {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mt]),
+                                                              __builtin_bit_cast(bf16x8, b[nt]), acc[mt][nt], 0, 0, 0);
+      }
+    }
+}
+
+// v (fp32 pair) -> the three packed bf16 pairs (element 0 in the low half).
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+  const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+  const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+  const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+  const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+  hi = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+  mid = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
+// Sum over the 32 lanes of each half-wave, valid in lanes 16..31 / 48..63.
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+  return v;
+}
+
+constexpr int split_forward_lds_bytes(int k_out) { return 2 * kSplitStageBytes + kSplitRows * k_out * 2 * 4; }
+
+template <int DIN, int NOUT, bool SAVE>
+__global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_tower_forward_split_kernel(
+    const float *__restrict__ x, int64_t m, int d_in_rt, const float *__restrict__ w1,
+    const float *__restrict__ b1, const void *__restrict__ w2s, const float *__restrict__ b2,
+    const float *__restrict__ w3, const float *__restrict__ b3, int n_out_rt,
+    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2) {
+  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
+  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
+  const int d_in = DIN > 0 ? DIN : d_in_rt;
+  const int n_out = NOUT > 0 ? NOUT : n_out_rt;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [stage 0: A | B][stage 1: A | B][head partials: [2 column halves][128 rows][kOut]]
+  const unsigned lds0 = lds_offset(smem);
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;  // rows [64 wr, +64), columns [128 wc, +128)
+  // Producer role: row `prow` of the macro tile, k-half `pkh` (wave-uniform) of every step.
+  const int prow = tid & 127, pkh = wave >> 1;
+
+  // Per-lane LDS addresses (stage 0; stage 1 = + kSplitStageBytes).
+  const unsigned a_read = lds0 + (hh * kSplitRows + 64 * wr + l32) * 16;
+  const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
+  const unsigned a_write = lds0 + (pkh * kSplitRows + prow) * 16;
+  const unsigned outp = lds0 + 2 * kSplitStageBytes;
+  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2s, kSplitPackedBytes);
+
+  // Epilogue constants: this lane's four output columns.
+  float b2r[4], w3r[4][kOut];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int j = 128 * wc + 32 * nt + l32;
+    b2r[nt] = b2[j];
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) w3r[nt][q] = q < n_out ? w3[q * kHidden + j] : 0.0f;
+  }
+
+  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
+  const int64_t stride = gridDim.x;
+
+  // Producer state: the tile whose h1 chunks are being produced (runs one step
+  // ahead of the consumer, so it moves to the next tile before step 15).
+  float px[kIn], xn[kIn];
+  int64_t p_r0 = (int64_t)blockIdx.x * kSplitRows;
+  auto load_x = [&](float (&dst)[kIn], int64_t r0) {
+    const int64_t row = r0 + prow;
+#pragma unroll
+    for (int i = 0; i < kIn; ++i) dst[i] = (row < m && i < d_in) ? x[row * d_in + i] : 0.0f;
+  };
+  load_x(px, p_r0);
+  load_x(xn, p_r0 + stride * kSplitRows);
+
+  // Chunk `ks` of the producer's tile -> stage `stage`.
+  auto request_b = [&](int ks, int stage) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int block = wave * 6 + u;  // 24 one-KiB blocks per step, six per wave
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, smem + stage * kSplitStageBytes + kSplitABytes + block * 1024,
+                                               16, lane * 16, (ks * 24 + block) * 1024, 0, 0);
+    }
+  };
+  auto produce_a = [&](int ks, u32x4 (&planes)[3]) {
+    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);
+    float h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = b1[kb + e];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i)
+        if (DIN > 0 || i < d_in) v = __builtin_fmaf(px[i], w1[(kb + e) * d_in + i], v);
+      h[e] = relu1(v);
+    }
+    if constexpr (SAVE) {
+      const int64_t row = p_r0 + prow;
+      if (row < m) {
+        float4 *dst = reinterpret_cast<float4 *>(save_h1 + row * kHidden + kb);
+        dst[0] = make_float4(h[0], h[1], h[2], h[3]);
+        dst[1] = make_float4(h[4], h[5], h[6], h[7]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t hi, mid, lo;
+      split_pair(h[e], h[e + 1], hi, mid, lo);
+      planes[0][e >> 1] = hi;
+      planes[1][e >> 1] = mid;
+      planes[2][e >> 1] = lo;
+    }
+  };
+  auto write_a = [&](int stage, const u32x4 (&planes)[3]) {
+    const unsigned addr = a_write + stage * kSplitStageBytes;
+    lds_write_b128<0>(addr, planes[0]);
+    lds_write_b128<2 * kSplitRows * 16>(addr, planes[1]);
+    lds_write_b128<4 * kSplitRows * 16>(addr, planes[2]);
+  };
+  auto step_barrier = [&]() {
+    // LDS writes of the next chunk, the direct-to-LDS weight loads and (all
+    // issued at least a matrix group ago) this step's h1 stores.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  f32x16 acc[2][4];
+  int64_t r0 = p_r0;  // consumer's tile
+
+  // One k-step: consume stage P (chunk s) while producing chunk s+1 -- of the
+  // next tile when s = 15 -- into the other stage.
+  auto do_step = [&](auto first_tag, auto parity_tag, int s) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int P = decltype(parity_tag)::value;
+    const int ks = (s + 1) & (kSplitSteps - 1);
+    request_b(ks, P ^ 1);
+    const unsigned ar = a_read + P * kSplitStageBytes, br = b_read + P * kSplitStageBytes;
+    SplitFrags f;
+    f.ah[0] = lds_read_b128<0>(ar);
+    f.ah[1] = lds_read_b128<512>(ar);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) f.bh[nt] = nt == 0   ? lds_read_b128<0>(br)
+                                              : nt == 1 ? lds_read_b128<3 * 1024>(br)
+                                              : nt == 2 ? lds_read_b128<6 * 1024>(br)
+                                                        : lds_read_b128<9 * 1024>(br);
+    f.am[0] = lds_read_b128<2 * kSplitRows * 16>(ar);
+    f.am[1] = lds_read_b128<2 * kSplitRows * 16 + 512>(ar);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<1024>(br)
+                                              : nt == 1 ? lds_read_b128<4 * 1024>(br)
+                                              : nt == 2 ? lds_read_b128<7 * 1024>(br)
+                                                        : lds_read_b128<10 * 1024>(br);
+    if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) px[i] = xn[i];
+      p_r0 += stride * kSplitRows;
+      load_x(xn, p_r0 + stride * kSplitRows);
+    }
+    u32x4 planes[3];
+    produce_a(ks, planes);
+    wait_lds_all(f);
+    split_mma<FIRST>(f.am, f.bm, acc);
+    split_mma<false>(f.ah, f.bm, acc);
+    split_mma<false>(f.am, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    write_a(P ^ 1, planes);
+    // lo planes into the registers of the mid planes
+    f.am[0] = lds_read_b128<4 * kSplitRows * 16>(ar);
+    f.am[1] = lds_read_b128<4 * kSplitRows * 16 + 512>(ar);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<2 * 1024>(br)
+                                              : nt == 1 ? lds_read_b128<5 * 1024>(br)
+                                              : nt == 2 ? lds_read_b128<8 * 1024>(br)
+                                                        : lds_read_b128<11 * 1024>(br);
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma<false>(f.ah, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lds_all(f);
+    split_mma<false>(f.ah, f.bm, acc);
+    split_mma<false>(f.am, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    step_barrier();
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  // Prologue: chunk 0 of the first tile.
+  if ((int64_t)blockIdx.x < tiles) {
+    request_b(0, 0);
+    u32x4 planes[3];
+    produce_a(0, planes);
+    write_a(0, planes);
+    step_barrier();
+  }
+
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
+    r0 = tile * kSplitRows;
+    const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
+    do_step(T{}, P0{}, 0);
+    do_step(F{}, P1{}, 1);
+#pragma unroll 1
+    for (int s = 2; s < kSplitSteps - 2; s += 2) {
+      do_step(F{}, P0{}, s);
+      do_step(F{}, P1{}, s + 1);
+    }
+    do_step(F{}, P0{}, kSplitSteps - 2);
+    do_step(F{}, P1{}, kSplitSteps - 1);
+
+    // Epilogue: bias + ReLU on the accumulators; h2 to HBM when saving (each
+    // store = two 128-byte row segments); head = per-lane partial over this
+    // lane's four columns, summed across the half-wave with DPP adds, the two
+    // column halves of the workgroup meeting in LDS.
+    const __amdgpu_buffer_rsrc_t h2rsrc = buffer_rsrc(SAVE ? save_h2 + r0 * kHidden : nullptr, rows * kHidden * 4);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int j = 128 * wc + 32 * nt + l32;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 pre = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{b2r[nt], b2r[nt]};
+          acc[mt][nt][r] = relu1(pre[0]);
+          acc[mt][nt][r + 1] = relu1(pre[1]);
+        }
+        if constexpr (SAVE) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
+            buffer_store_f32(acc[mt][nt][r], h2rsrc, (4 * hh * kHidden + j) * 4, sr * (kHidden * 4));
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < kOut; ++q) {
+          if (q < n_out) {
+            float p = acc[mt][0][r] * w3r[0][q];
+#pragma unroll
+            for (int nt = 1; nt < 4; ++nt) p = __builtin_fmaf(acc[mt][nt][r], w3r[nt][q], p);
+            p = half_wave_sum(p);
+            if (l32 == 31) lds_write_b32(outp + ((wc * kSplitRows + row) * kOut + q) * 4, p);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int idx = tid; idx < kSplitRows * n_out; idx += kBlock) {
+      const int row = idx / n_out, q = idx - row * n_out;
+      const float v = lds_read_b32(outp + (row * kOut + q) * 4) + lds_read_b32(outp + ((kSplitRows + row) * kOut + q) * 4);
+      if (row < rows) out[(r0 + row) * n_out + q] = v + b3[q];
+    }
+    // (the next tile's first head partials are written a full tile later, behind
+    // sixteen barriers: no extra barrier needed here)
+  }
+}
+
+template <int DIN, int NOUT, bool SAVE>
+static int launch_forward_split(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
+                                const float *b1, const void *w2s, const float *b2, const float *w3,
+                                const float *b3, int n_out, float *out, float *h1, float *h2) {
+  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_forward_split_kernel<DIN, NOUT, SAVE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  mlp_tower_forward_split_kernel<DIN, NOUT, SAVE><<<grid, kBlock, split_forward_lds_bytes(kOut), s>>>(
+      x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+  return launch_status();
+}
+
+template <int DIN, int NOUT>
+static int launch_forward_split_save(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
+                                     const float *b1, const void *w2s, const float *b2, const float *w3,
+                                     const float *b3, int n_out, float *out, float *h1, float *h2) {
+  return h1 ? launch_forward_split<DIN, NOUT, true>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2)
+            : launch_forward_split<DIN, NOUT, false>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+}
+
+template <int DIN>
+static int dispatch_forward_split_nout(int n_out, int grid, hipStream_t s, const float *x, int64_t m, int d_in,
+                                       const float *w1, const float *b1, const void *w2s, const float *b2,
+                                       const float *w3, const float *b3, float *out, float *h1, float *h2) {
+  switch (n_out) {
+    case 1: return launch_forward_split_save<DIN, 1>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+    case 2: return launch_forward_split_save<DIN, 2>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+    case 3: return launch_forward_split_save<DIN, 3>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+    default: return launch_forward_split_save<DIN, 0>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+  }
+}
+
+}  // namespace rl8
+
+using namespace rl8;
+
+RL8_API int64_t rl8_mlp_split_packed_bytes(void) { return kSplitPackedBytes; }
+
+RL8_API int rl8_mlp_pack_w2_split(const float *w2, int transposed, void *packed, void *stream) {
+  if (!w2 || !packed) return RL8_ENULL;
+  if (((uintptr_t)packed & 15) != 0) return RL8_EALIGN;
+  mlp_pack_w2_split_kernel<<<(kSplitSteps * 8 * 64 + kBlock - 1) / kBlock, kBlock, 0, (hipStream_t)stream>>>(
+      w2, transposed, reinterpret_cast<uint32_t *>(packed));
+  return launch_status();
+}
+
+RL8_API int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const float *w1,
+                                            const float *b1, const void *w2_split, const float *b2,
+                                            const float *w3, const float *b3, int n_out, float *out,
+                                            float *save_h1, float *save_h2, void *stream) {
+  if (!x || !w1 || !b1 || !w2_split || !b2 || !w3 || !b3 || !out) return RL8_ENULL;
+  if ((save_h1 == nullptr) != (save_h2 == nullptr)) return RL8_ENULL;
+  if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
+  if (((uintptr_t)w2_split & 15) != 0 || (save_h1 && ((uintptr_t)save_h1 & 15) != 0)) return RL8_EALIGN;
+  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
+  static const int cap = env_int("RL8_MLP_GRID_CAP");
+  const int max_grid = cap > 0 ? cap : 2 * kCUs;
+  const int grid = (int)(tiles < max_grid ? tiles : max_grid);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d_in) {
+    case 1: return dispatch_forward_split_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
+    case 2: return dispatch_forward_split_nout<2>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
+    case 3: return dispatch_forward_split_nout<3>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
+    case 5: return dispatch_forward_split_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
+    default: return dispatch_forward_split_nout<0>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
+  }
+}

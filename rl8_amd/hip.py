@@ -133,6 +133,9 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_wgrad_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp],
     "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
     "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "rl8_mlp_split_packed_bytes": [],
+    "rl8_mlp_pack_w2_split": [_vp, _i32, _vp, _vp],
+    "rl8_mlp_tower_forward_split_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
     "rl8_mlp_backward_max_rows": [],
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
@@ -163,7 +166,7 @@ def load() -> C.CDLL:
             fn.restype = (
                 C.c_int64
                 if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes",
-                            "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats")
+                            "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats", "rl8_mlp_split_packed_bytes")
                 else C.c_int
             )
         _lib = lib
@@ -833,6 +836,48 @@ def mlp_tower_forward(
                 _ptr(w3.detach()), _ptr(b3.detach()), n_out, _ptr(out), _ptr(h1), _ptr(h2), _stream(),
             ),
             "rl8_mlp_tower_forward_f32",
+        )
+    return out, h1, h2
+
+
+def mlp_pack_w2_split(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
+    """[256, 256] nn.Linear weight -> three bf16 planes (w = hi + mid + lo exactly)
+    in the fragment order of the split-product kernels (393216 bytes, uint8)."""
+    w2 = _dense(w2.detach(), torch.float32, "w2")
+    if tuple(w2.shape) != (MLP_HIDDEN, MLP_HIDDEN):
+        raise ValueError("w2 must be [256, 256]")
+    lib = load()
+    packed = torch.empty(int(lib.rl8_mlp_split_packed_bytes()), dtype=torch.uint8, device=w2.device)
+    _check(lib.rl8_mlp_pack_w2_split(_ptr(w2), int(transposed), _ptr(packed), _stream()), "rl8_mlp_pack_w2_split")
+    return packed
+
+
+def mlp_tower_forward_split(
+    x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2_split: torch.Tensor, b2: torch.Tensor,
+    w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False,
+) -> tuple[torch.Tensor, None | torch.Tensor, None | torch.Tensor]:
+    """``mlp_tower_forward`` with the 256x256 product as six bf16-plane MFMAs per
+    16 k (fp32 accuracy, fp32 in / out / accumulate)."""
+    x = _dense(x.detach(), torch.float32, "x")
+    m, d_in = x.shape
+    n_out = w3.shape[0]
+    for name, t, shape in (("w1", w1, (MLP_HIDDEN, d_in)), ("b1", b1, (MLP_HIDDEN,)), ("b2", b2, (MLP_HIDDEN,)),
+                           ("w3", w3, (n_out, MLP_HIDDEN)), ("b3", b3, (n_out,))):
+        _dense(t.detach(), torch.float32, name)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+    if w2_split.dtype != torch.uint8 or w2_split.numel() != int(load().rl8_mlp_split_packed_bytes()):
+        raise ValueError("w2_split must come from mlp_pack_w2_split")
+    out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
+    h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
+    h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
+    with _timed("mlp_tower_forward_save" if save else "mlp_tower_forward", m):
+        _check(
+            load().rl8_mlp_tower_forward_split_f32(
+                _ptr(x), m, d_in, _ptr(w1.detach()), _ptr(b1.detach()), _ptr(w2_split), _ptr(b2.detach()),
+                _ptr(w3.detach()), _ptr(b3.detach()), n_out, _ptr(out), _ptr(h1), _ptr(h2), _stream(),
+            ),
+            "rl8_mlp_tower_forward_split_f32",
         )
     return out, h1, h2
 

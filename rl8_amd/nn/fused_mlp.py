@@ -20,6 +20,7 @@ config), whose casts and elementwise launches dominate at this width.
 
 from __future__ import annotations
 
+import os
 from typing import Sequence
 
 import torch
@@ -30,17 +31,25 @@ from .. import hip
 #: Set to False to evaluate towers with eager PyTorch (A/B comparisons).
 ENABLED = True
 
-def _packed(layer: nn.Linear, transposed: bool) -> torch.Tensor:
+#: How the 256x256 product of the forward kernel is formed: "split" = exact 3-way
+#: bf16 split of both fp32 operands, six plane products per 16 k on the bf16
+#: matrix pipe, fp32 accumulate (fp32 accuracy, ~1.8x the fp32-MFMA kernel);
+#: "f32" = v_mfma_f32_32x32x2_f32.  ``RL8_AMD_TOWER_GEMM`` overrides.
+FORWARD_GEMM = os.environ.get("RL8_AMD_TOWER_GEMM", "split")
+
+
+def _packed(layer: nn.Linear, transposed: bool, split: bool = False) -> torch.Tensor:
     """MFMA-fragment-ordered copy of ``layer.weight``, cached ON the layer and
     re-made when the optimizer has changed the weight (version counter) or the
     weight tensor has been replaced / moved."""
     w2 = layer.weight
     cache = layer.__dict__.setdefault("_rl8_w2_packs", {})
-    hit = cache.get(transposed)
+    hit = cache.get((transposed, split))
     if hit is not None and hit[0] == w2._version and hit[1] == w2.data_ptr():
         return hit[2]
-    packed = hip.mlp_pack_w2(w2, transposed=transposed)
-    cache[transposed] = (w2._version, w2.data_ptr(), packed)
+    pack = hip.mlp_pack_w2_split if split else hip.mlp_pack_w2
+    packed = pack(w2, transposed=transposed)
+    cache[(transposed, split)] = (w2._version, w2.data_ptr(), packed)
     return packed
 
 
@@ -52,7 +61,11 @@ class _FusedTower(torch.autograd.Function):
         # always off: the caller's grad mode comes in as an argument, so that
         # activations are kept only when a backward can follow.
         need_grad = grad_mode and any(ctx.needs_input_grad[1:7])
-        out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
+        if FORWARD_GEMM == "split":
+            out, h1, h2 = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, True), b2, w3, b3,
+                                                      save=need_grad)
+        else:
+            out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
         if need_grad:
             ctx.layer2 = layer2
             ctx.save_for_backward(x, h1, h2, w3)

@@ -92,7 +92,9 @@ def run_trace(golden, name, env_cls, *, discrete, step_rel, **config):
         inject(algo, g, it)
         collect_stats = algo.collect()
         compare_collect(algo, g, it, discrete=discrete)
-        compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5)
+        # absolute band: rewards/max is -min|state| of states that are O(100) sums of
+        # actions, so one fp32 ulp of a state (7.6e-6) is the floor for it.
+        compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5, abs_tol=1e-5)
         assert algo.state.reward_scale == pytest.approx(float(g[f"it{it}_reward_scale"]), rel=1e-5)
         step_stats = algo.step()
         # it >= 1: weights have drifted (see compare_collect); the policy loss is a
