@@ -351,6 +351,18 @@ int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
                                const float *w3, int n_out, float *dz2_out, float *partials,
                                int *partial_rows_out /*host*/, void *stream);
 
+/* The data-gradient half of the backward pass with dH1 = dZ2 x W2 as bf16-plane
+ * products (see rl8_mlp_tower_forward_split_f32); same arguments, outputs and
+ * partial-row layout as rl8_mlp_tower_backward_f32, except that w2t_split comes from
+ * rl8_mlp_pack_w2_split(..., transposed = 1).  Two launches: the matrix kernel
+ * (dZ2, dW1, db1) and an HBM-streaming kernel for the head gradients (db2, dW3,
+ * db3), which are column sums over rows. */
+int rl8_mlp_backward_split_supports(int d_in, int n_out); /* compiled-in observation widths: 1, 2, 3, 5 */
+int rl8_mlp_tower_backward_split_f32(const float *x, const float *h1, const float *h2,
+                                     const float *dout, int64_t m, int d_in, const void *w2t_split,
+                                     const float *w3, int n_out, float *dz2_out, float *partials,
+                                     int *partial_rows_out /*host*/, void *stream);
+
 /* Weight gradient of the 256x256 layer: dw2_out [256][256] (+)= dZ2^T h1 over M
  * rows (fp32 MFMA; per-workgroup partial slabs in `workspace`, summed in a fixed
  * order).  workspace: rl8_mlp_wgrad_workspace_bytes() bytes, no initialisation. */

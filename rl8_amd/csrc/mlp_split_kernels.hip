@@ -426,6 +426,366 @@ static int dispatch_forward_split_nout(int n_out, int grid, hipStream_t s, const
   }
 }
 
+
+// ---- backward ("dgrad" half) on the same scheme --------------------------------
+//   dZ2 = (dOut x W3) * (h2 > 0)   computed per k-chunk on the VALU (thread = row,
+//                                  eight columns), stored for the weight-gradient
+//                                  product and split into the A planes;
+//   dH1 = dZ2 x W2                 bf16-plane MFMAs (B = W2 packed transposed);
+//   dZ1 = dH1 * (h1 > 0)           accumulator epilogue, folded into dW1 / db1
+//                                  (lane = column: per-lane running sums).
+// The head gradients (db2, dW3, db3) are column sums over rows of quantities that
+// this kernel holds row-per-thread; they are formed by mlp_head_grads_kernel, an
+// HBM-streaming kernel with thread = column, into the same partial rows.
+template <int DIN, int NOUT>
+__global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_tower_backward_split_kernel(
+    const float *__restrict__ x, const float *__restrict__ h1, const float *__restrict__ h2,
+    const float *__restrict__ dout, int64_t m, int d_in_rt, const void *__restrict__ w2ts,
+    const float *__restrict__ w3, int n_out_rt, float *__restrict__ dz2_out,
+    float *__restrict__ partials, int partial_stride) {
+  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
+  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
+  const int d_in = DIN > 0 ? DIN : d_in_rt;
+  const int n_out = NOUT > 0 ? NOUT : n_out_rt;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = lds_offset(smem);
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int prow = tid & 127, pkh = wave >> 1;
+  const unsigned a_read = lds0 + (hh * kSplitRows + 64 * wr + l32) * 16;
+  const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
+  const unsigned a_write = lds0 + (pkh * kSplitRows + prow) * 16;
+  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2ts, kSplitPackedBytes);
+
+  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
+  const int64_t stride = gridDim.x;
+
+  // Producer state (one step ahead of the consumer; moves to the next tile before step 15).
+  int64_t p_tile = blockIdx.x;
+  float dr[kOut], dn[kOut];
+  auto load_dout = [&](float (&dst)[kOut], int64_t tile) {
+    const int64_t row = tile * kSplitRows + prow;
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) dst[q] = (row < m && q < n_out) ? dout[row * n_out + q] : 0.0f;
+  };
+  load_dout(dr, p_tile);
+  load_dout(dn, p_tile + stride);
+  float4 hq[2][2];  // h2 of the two chunks in flight (this thread's row, eight columns each)
+  auto load_h2 = [&](float4 (&dst)[2], int64_t tile, int ks) {
+    const int64_t row = tile * kSplitRows + prow;
+    dst[0] = dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < m) {
+      const float4 *src = reinterpret_cast<const float4 *>(h2 + row * kHidden + 16 * ks + 8 * pkh);
+      dst[0] = src[0];
+      dst[1] = src[1];
+    }
+  };
+  auto request_b = [&](int ks, int stage) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int block = wave * 6 + u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, smem + stage * kSplitStageBytes + kSplitABytes + block * 1024,
+                                               16, lane * 16, (ks * 24 + block) * 1024, 0, 0);
+    }
+  };
+  auto produce_a = [&](const float4 (&hv)[2], int64_t tile, int ks, u32x4 (&planes)[3]) {
+    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);
+    const float hval[8] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w};
+    float dz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float g = dr[0] * w3[kb + e];
+#pragma unroll
+      for (int q = 1; q < kOut; ++q)
+        if (NOUT > 0 ? q < NOUT : q < n_out) g = __builtin_fmaf(dr[q], w3[q * kHidden + kb + e], g);
+      dz[e] = hval[e] > 0.0f ? g : 0.0f;
+    }
+    const int64_t row = tile * kSplitRows + prow;
+    if (row < m) {
+      float4 *dst = reinterpret_cast<float4 *>(dz2_out + row * kHidden + kb);
+      dst[0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      dst[1] = make_float4(dz[4], dz[5], dz[6], dz[7]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t hi, mid, lo;
+      split_pair(dz[e], dz[e + 1], hi, mid, lo);
+      planes[0][e >> 1] = hi;
+      planes[1][e >> 1] = mid;
+      planes[2][e >> 1] = lo;
+    }
+  };
+  auto write_a = [&](int stage, const u32x4 (&planes)[3]) {
+    const unsigned addr = a_write + stage * kSplitStageBytes;
+    lds_write_b128<0>(addr, planes[0]);
+    lds_write_b128<2 * kSplitRows * 16>(addr, planes[1]);
+    lds_write_b128<4 * kSplitRows * 16>(addr, planes[2]);
+  };
+  auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  f32x16 acc[2][4];
+  float db1[4], dw1[4][kIn];  // this lane's four columns, its half of the rows
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    db1[nt] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kIn; ++i) dw1[nt][i] = 0.0f;
+  }
+
+  auto do_step = [&](auto first_tag, auto parity_tag, int s) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int P = decltype(parity_tag)::value;
+    const int ks = (s + 1) & (kSplitSteps - 1);
+    request_b(ks, P ^ 1);
+    const unsigned ar = a_read + P * kSplitStageBytes, br = b_read + P * kSplitStageBytes;
+    SplitFrags f;
+    f.ah[0] = lds_read_b128<0>(ar);
+    f.ah[1] = lds_read_b128<512>(ar);
+    f.bh[0] = lds_read_b128<0>(br);
+    f.bh[1] = lds_read_b128<3 * 1024>(br);
+    f.bh[2] = lds_read_b128<6 * 1024>(br);
+    f.bh[3] = lds_read_b128<9 * 1024>(br);
+    f.am[0] = lds_read_b128<2 * kSplitRows * 16>(ar);
+    f.am[1] = lds_read_b128<2 * kSplitRows * 16 + 512>(ar);
+    f.bm[0] = lds_read_b128<1024>(br);
+    f.bm[1] = lds_read_b128<4 * 1024>(br);
+    f.bm[2] = lds_read_b128<7 * 1024>(br);
+    f.bm[3] = lds_read_b128<10 * 1024>(br);
+    if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
+#pragma unroll
+      for (int q = 0; q < kOut; ++q) dr[q] = dn[q];
+      p_tile += stride;
+      load_dout(dn, p_tile + stride);
+    }
+    u32x4 planes[3];
+    produce_a(hq[P ^ 1], p_tile, ks, planes);
+    // h2 of the chunk after next (two steps ahead of its use)
+    load_h2(hq[P], s == kSplitSteps - 2 ? p_tile + stride : p_tile, (s + 2) & (kSplitSteps - 1));
+    wait_lds_all(f);
+    split_mma<FIRST>(f.am, f.bm, acc);
+    split_mma<false>(f.ah, f.bm, acc);
+    split_mma<false>(f.am, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    write_a(P ^ 1, planes);
+    f.am[0] = lds_read_b128<4 * kSplitRows * 16>(ar);
+    f.am[1] = lds_read_b128<4 * kSplitRows * 16 + 512>(ar);
+    f.bm[0] = lds_read_b128<2 * 1024>(br);
+    f.bm[1] = lds_read_b128<5 * 1024>(br);
+    f.bm[2] = lds_read_b128<8 * 1024>(br);
+    f.bm[3] = lds_read_b128<11 * 1024>(br);
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma<false>(f.ah, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lds_all(f);
+    split_mma<false>(f.ah, f.bm, acc);
+    split_mma<false>(f.am, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    step_barrier();
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  if ((int64_t)blockIdx.x < tiles) {
+    load_h2(hq[0], p_tile, 0);
+    load_h2(hq[1], p_tile, 1);
+    request_b(0, 0);
+    u32x4 planes[3];
+    produce_a(hq[0], p_tile, 0, planes);
+    write_a(0, planes);
+    step_barrier();
+  }
+
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
+    const int64_t r0 = tile * kSplitRows;
+    const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
+    do_step(T{}, P0{}, 0);
+    do_step(F{}, P1{}, 1);
+#pragma unroll 1
+    for (int s = 2; s < kSplitSteps - 2; s += 2) {
+      do_step(F{}, P0{}, s);
+      do_step(F{}, P1{}, s + 1);
+    }
+    do_step(F{}, P0{}, kSplitSteps - 2);
+    do_step(F{}, P1{}, kSplitSteps - 1);
+
+    // Epilogue: dZ1 = dH1 * (h1 > 0) folded into db1 / dW1.  h1 and the
+    // observations arrive through tile-sized descriptors (rows past the end of a
+    // partial tile read as zero: gate closed).
+    const __amdgpu_buffer_rsrc_t h1rsrc = buffer_rsrc(h1 + r0 * kHidden, rows * kHidden * 4);
+    const __amdgpu_buffer_rsrc_t xrsrc = buffer_rsrc(x + r0 * d_in, rows * d_in * 4);
+    // (wide observations: the x values of a batch of four rows are loaded inside
+    // the batch -- sixteen rows' worth of them would not fit beside the accumulators)
+    constexpr bool kHoistX = kIn <= 2;
+    auto load_x_rows = [&](float (&xv)[16][kIn], int mt, int r_begin, int r_end) {
+#pragma unroll
+      for (int r = r_begin; r < r_end; ++r) {
+        const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
+#pragma unroll
+        for (int i = 0; i < kIn; ++i)
+          xv[r][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(xrsrc, (4 * hh * d_in + i) * 4, sr * d_in * 4) : 0.0f;
+      }
+    };
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float xv[16][kIn];
+      if constexpr (kHoistX) load_x_rows(xv, mt, 0, 16);
+#pragma unroll
+      for (int np = 0; np < 4; np += 2) {
+        float hv[2][16];
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);
+            hv[n2][r] = buffer_load_f32(h1rsrc, (4 * hh * kHidden + 128 * wc + 32 * (np + n2) + l32) * 4,
+                                        sr * (kHidden * 4));
+          }
+#pragma unroll
+        for (int rb = 0; rb < 16; rb += 4) {
+          if constexpr (!kHoistX) load_x_rows(xv, mt, rb, rb + 4);
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) {
+            unsigned long long gate[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gate[u] = positive_mask(hv[n2][rb + u]);
+            __builtin_amdgcn_sched_barrier(0);
+            float dz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dz[u] = select_or_zero(gate[u], acc[mt][np + n2][rb + u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              db1[np + n2] += dz[u];
+#pragma unroll
+              for (int i = 0; i < kIn; ++i) dw1[np + n2][i] = __builtin_fmaf(dz[u], xv[rb + u][i], dw1[np + n2][i]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // Workgroup partial row: [dW1 (256*d_in) | db1 (256) | ... head gradients (mlp_head_grads_kernel)].
+  // Fold the two row halves of a lane pair (hh), then the two row-halves of the
+  // workgroup (wr) through LDS, in a fixed order.
+  float *row = partials + (int64_t)blockIdx.x * partial_stride;
+  float *red = reinterpret_cast<float *>(smem);  // [256 columns][1 + kIn]
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = 128 * wc + 32 * nt + l32;
+    db1[nt] += __shfl_xor(db1[nt], 32, kWave);
+#pragma unroll
+    for (int i = 0; i < kIn; ++i) dw1[nt][i] += __shfl_xor(dw1[nt][i], 32, kWave);
+    if (wr == 1 && hh == 0) {
+      red[col * (1 + kIn)] = db1[nt];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) red[col * (1 + kIn) + 1 + i] = dw1[nt][i];
+    }
+  }
+  __syncthreads();
+  if (wr == 0 && hh == 0) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col = 128 * wc + 32 * nt + l32;
+      row[kHidden * d_in + col] = db1[nt] + red[col * (1 + kIn)];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i)
+        if (DIN > 0 || i < d_in) row[col * d_in + i] = dw1[nt][i] + red[col * (1 + kIn) + 1 + i];
+    }
+  }
+}
+
+// db2 = sum_rows dZ2, dW3 = dOut^T h2, db3 = sum_rows dOut: thread = column, rows
+// streamed from HBM (h2: 1 KiB per row; dOut through the scalar cache).  Workgroup
+// b covers the same 128-row tiles as workgroup b of the kernel above and writes
+// the remaining segments of the same partial row.
+template <int NOUT>
+__global__ __launch_bounds__(kBlock) void mlp_head_grads_kernel(
+    const float *__restrict__ h2, const float *__restrict__ dout, int64_t m, const float *__restrict__ w3,
+    int n_out_rt, int d_in, float *__restrict__ partials, int partial_stride) {
+  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
+  const int n_out = NOUT > 0 ? NOUT : n_out_rt;
+  const int tid = threadIdx.x;
+  float w3r[kOut];
+#pragma unroll
+  for (int q = 0; q < kOut; ++q) w3r[q] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
+  float db2[2] = {0.0f, 0.0f}, dw3[kOut][2], db3[kOut];
+#pragma unroll
+  for (int q = 0; q < kOut; ++q) dw3[q][0] = dw3[q][1] = db3[q] = 0.0f;
+  constexpr int kBatch = 16;
+  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * kSplitRows;
+    const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
+    const __amdgpu_buffer_rsrc_t h2rsrc = buffer_rsrc(h2 + r0 * kHidden, rows * kHidden * 4);
+    for (int s0 = 0; s0 < rows; s0 += kBatch) {
+      float hv[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) hv[u] = buffer_load_f32(h2rsrc, tid * 4, (s0 + u) * (kHidden * 4));
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int s = s0 + u;
+        const bool valid = s < rows;
+        const int64_t srow = r0 + (valid ? s : rows - 1);
+        float g = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kOut; ++q) {
+          if (NOUT > 0 ? q < NOUT : q < n_out) {
+            const float d = valid ? dout[srow * n_out + q] : 0.0f;
+            g = __builtin_fmaf(d, w3r[q], g);
+            dw3[q][u & 1] = __builtin_fmaf(d, hv[u], dw3[q][u & 1]);
+            db3[q] += d;
+          }
+        }
+        db2[u & 1] += hv[u] > 0.0f ? g : 0.0f;
+      }
+    }
+  }
+  float *row = partials + (int64_t)blockIdx.x * partial_stride;
+  const int off_db2 = kHidden * d_in + kHidden, off_dw3 = off_db2 + kHidden, off_db3 = off_dw3 + n_out * kHidden;
+  row[off_db2 + tid] = db2[0] + db2[1];
+#pragma unroll
+  for (int q = 0; q < kOut; ++q)
+    if (q < n_out) {
+      row[off_dw3 + q * kHidden + tid] = dw3[q][0] + dw3[q][1];
+      if (tid == q) row[off_db3 + q] = db3[q];
+    }
+}
+
+template <int DIN, int NOUT>
+static int launch_backward_split(int grid, hipStream_t s, const float *x, const float *h1, const float *h2,
+                                 const float *dout, int64_t m, int d_in, const void *w2ts, const float *w3,
+                                 int n_out, float *dz2_out, float *partials, int stride) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_split_kernel<DIN, NOUT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  mlp_tower_backward_split_kernel<DIN, NOUT><<<grid, kBlock, 2 * kSplitStageBytes, s>>>(
+      x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+  const int status = launch_status();
+  if (status != 0) return status;
+  mlp_head_grads_kernel<NOUT><<<grid, kBlock, 0, s>>>(h2, dout, m, w3, n_out, d_in, partials, stride);
+  return launch_status();
+}
+
+template <int DIN>
+static int dispatch_backward_split_nout(int n_out, int grid, hipStream_t s, const float *x, const float *h1,
+                                        const float *h2, const float *dout, int64_t m, int d_in, const void *w2ts,
+                                        const float *w3, float *dz2_out, float *partials, int stride) {
+  switch (n_out) {
+    case 1: return launch_backward_split<DIN, 1>(grid, s, x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+    case 2: return launch_backward_split<DIN, 2>(grid, s, x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+    case 3: return launch_backward_split<DIN, 3>(grid, s, x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+    default: return launch_backward_split<DIN, 0>(grid, s, x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+  }
+}
+
 }  // namespace rl8
 
 using namespace rl8;
@@ -460,4 +820,33 @@ RL8_API int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in,
     case 5: return dispatch_forward_split_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
     default: return dispatch_forward_split_nout<0>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
   }
+}
+
+RL8_API int rl8_mlp_tower_backward_split_f32(const float *x, const float *h1, const float *h2,
+                                             const float *dout, int64_t m, int d_in,
+                                             const void *w2t_split, const float *w3, int n_out,
+                                             float *dz2_out, float *partials, int *partial_rows_out,
+                                             void *stream) {
+  if (!x || !h1 || !h2 || !dout || !w2t_split || !w3 || !dz2_out || !partials || !partial_rows_out)
+    return RL8_ENULL;
+  if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
+  if (((uintptr_t)w2t_split & 15) != 0 || !aligned16(h2) || !aligned16(dz2_out)) return RL8_EALIGN;
+  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
+  static const int cap = env_int("RL8_MLP_GRID_CAP");
+  const int max_grid = cap > 0 ? cap : 2 * kCUs;
+  const int grid = (int)(tiles < max_grid ? tiles : max_grid);
+  *partial_rows_out = grid;
+  const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d_in) {
+    case 1: return dispatch_backward_split_nout<1>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
+    case 2: return dispatch_backward_split_nout<2>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
+    case 3: return dispatch_backward_split_nout<3>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
+    case 5: return dispatch_backward_split_nout<5>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
+    default: return RL8_ESIZE;  // rl8_mlp_backward_split_supports(): other widths use rl8_mlp_tower_backward_f32
+  }
+}
+
+RL8_API int rl8_mlp_backward_split_supports(int d_in, int n_out) {
+  return (d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5) && n_out >= 1 && n_out <= kMaxOut;
 }

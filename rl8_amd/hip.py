@@ -139,6 +139,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
     "rl8_mlp_backward_max_rows": [],
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_mlp_backward_split_supports": [_i32, _i32],
+    "rl8_mlp_tower_backward_split_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_wgrad_workspace_bytes": [],
     "rl8_mlp_wgrad_f32": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
 }
@@ -840,6 +842,10 @@ def mlp_tower_forward(
     return out, h1, h2
 
 
+def mlp_backward_split_supports(d_in: int, n_out: int) -> bool:
+    return bool(load().rl8_mlp_backward_split_supports(int(d_in), int(n_out)))
+
+
 def mlp_pack_w2_split(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
     """[256, 256] nn.Linear weight -> three bf16 planes (w = hi + mid + lo exactly)
     in the fragment order of the split-product kernels (393216 bytes, uint8)."""
@@ -886,6 +892,8 @@ def mlp_tower_backward(
     x: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor, dout: torch.Tensor,
     w2t_packed: torch.Tensor, w3: torch.Tensor,
 ) -> dict[str, torch.Tensor]:
+    """``w2t_packed`` from ``mlp_pack_w2(..., transposed=True)`` (fp32 MFMA kernel)
+    or ``mlp_pack_w2_split(..., transposed=True)`` (uint8: bf16-plane kernel)."""
     """Gradients of one tower's parameters given ``dout`` [M, n_out] and the
     activations saved by the forward pass. Returns ``w1, b1, w2, b2, w3, b3``."""
     m, d_in = x.shape
@@ -901,13 +909,13 @@ def mlp_tower_backward(
     partials = torch.empty(max_rows, width, dtype=torch.float32, device=x.device)
     dz2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device)
     rows = C.c_int(0)
+    split = w2t_packed.dtype == torch.uint8
+    fn = lib.rl8_mlp_tower_backward_split_f32 if split else lib.rl8_mlp_tower_backward_f32
     with _timed("mlp_tower_backward", m):
         _check(
-            lib.rl8_mlp_tower_backward_f32(
-                _ptr(x), _ptr(h1), _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
-                _ptr(dz2), _ptr(partials), C.byref(rows), _stream(),
-            ),
-            "rl8_mlp_tower_backward_f32",
+            fn(_ptr(x), _ptr(h1), _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
+               _ptr(dz2), _ptr(partials), C.byref(rows), _stream()),
+            "rl8_mlp_tower_backward_split_f32" if split else "rl8_mlp_tower_backward_f32",
         )
     small = partials[: rows.value].sum(0)
     o1 = MLP_HIDDEN * d_in

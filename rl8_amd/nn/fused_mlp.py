@@ -36,6 +36,8 @@ ENABLED = True
 #: matrix pipe, fp32 accumulate (fp32 accuracy, ~1.8x the fp32-MFMA kernel);
 #: "f32" = v_mfma_f32_32x32x2_f32.  ``RL8_AMD_TOWER_GEMM`` overrides.
 FORWARD_GEMM = os.environ.get("RL8_AMD_TOWER_GEMM", "split")
+#: Same choice for the data-gradient product of the backward pass.
+BACKWARD_GEMM = os.environ.get("RL8_AMD_TOWER_GEMM", "split")
 
 
 def _packed(layer: nn.Linear, transposed: bool, split: bool = False) -> torch.Tensor:
@@ -74,7 +76,8 @@ class _FusedTower(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
         x, h1, h2, w3 = ctx.saved_tensors
-        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True), w3)
+        split = BACKWARD_GEMM == "split" and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0])
+        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True, split), w3)
         return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None
 
 
