@@ -331,6 +331,7 @@ int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *
  * (rl8_mlp_split_packed_bytes() bytes, 16-byte aligned) comes from
  * rl8_mlp_pack_w2_split (transposed as for rl8_mlp_pack_w2_f32). */
 int64_t rl8_mlp_split_packed_bytes(void);
+int rl8_mlp_forward_split_supports(int d_in, int n_out); /* d_in 1, 2 x n_out 1..3; else RL8_ESIZE */
 int rl8_mlp_pack_w2_split(const float *w2 /*[256][256]*/, int transposed, void *w2_split, void *stream);
 int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const float *w1,
                                     const float *b1, const void *w2_split, const float *b2,
@@ -352,16 +353,25 @@ int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
                                int *partial_rows_out /*host*/, void *stream);
 
 /* The data-gradient half of the backward pass with dH1 = dZ2 x W2 as bf16-plane
- * products (see rl8_mlp_tower_forward_split_f32); same arguments, outputs and
- * partial-row layout as rl8_mlp_tower_backward_f32, except that w2t_split comes from
- * rl8_mlp_pack_w2_split(..., transposed = 1).  Two launches: the matrix kernel
- * (dZ2, dW1, db1) and an HBM-streaming kernel for the head gradients (db2, dW3,
- * db3), which are column sums over rows. */
-int rl8_mlp_backward_split_supports(int d_in, int n_out); /* compiled-in observation widths: 1, 2, 3, 5 */
-int rl8_mlp_tower_backward_split_f32(const float *x, const float *h1, const float *h2,
+ * products (see rl8_mlp_tower_forward_split_f32).  Same outputs and partial-row
+ * layout as rl8_mlp_tower_backward_f32; differences in the arguments: w2t_split
+ * comes from rl8_mlp_pack_w2_split(..., transposed = 1), and instead of the saved
+ * h1 the kernel takes layer 1 itself (w1, b1) and recomputes the ReLU gate
+ * h1 > 0 <=> b1 + x . w1 > 0 with the forward pass's own fma chain (1 KiB per row
+ * less HBM traffic).  Two launches: the matrix kernel (dZ2, dW1, db1) and an
+ * HBM-streaming kernel for the head gradients (db2, dW3, db3), which are column
+ * sums over rows. */
+int rl8_mlp_backward_split_supports(int d_in, int n_out); /* d_in 1 x n_out 1, 2; else RL8_ESIZE */
+int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, const float *b1, const float *h2,
                                      const float *dout, int64_t m, int d_in, const void *w2t_split,
                                      const float *w3, int n_out, float *dz2_out, float *partials,
                                      int *partial_rows_out /*host*/, void *stream);
+
+/* dW2 (+)= dZ2^T h1 on bf16 planes, with h1 = relu(x W1^T + b1) recomputed from the
+ * observations instead of read back (workspace: rl8_mlp_wgrad_workspace_bytes()). */
+int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const float *w1, const float *b1,
+                            int64_t m, int d_in, float *workspace, float *dw2_out, int accumulate,
+                            void *stream);
 
 /* Weight gradient of the 256x256 layer: dw2_out [256][256] (+)= dZ2^T h1 over M
  * rows (fp32 MFMA; per-workgroup partial slabs in `workspace`, summed in a fixed

@@ -35,9 +35,23 @@ namespace rl8 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Kernel-tuning builds only (tools/diag_mlp.sh): -DRL8_DIAG_SKIP=<bits> drops one
+// memory stream (forward: 8 h2 store, 32 h1 store; backward: 64 h2 loads, 128 dZ2
+// stores, 256 h1 / x loads of the epilogue).  The shipped library is built with 0.
+#ifndef RL8_DIAG_SKIP
+#define RL8_DIAG_SKIP 0
+#endif
+constexpr int kSplitDiagSkip = RL8_DIAG_SKIP;
+
 constexpr int kSplitRows = 128;                 // rows per macro tile
 constexpr int kSplitSteps = kHidden / 16;       // k-steps of 16
-constexpr int kSplitABytes = 3 * 2 * kSplitRows * 16;      // [plane][k-half][row] x 16 B
+// A chunk in LDS: [plane][k-half][row] x 16 B (one MFMA operand fragment per row
+// and k-half).  The k-half stride is padded by 64 B so that the producers' 8-byte
+// writes (lanes 4i..4i+3 = the four quarter-fragments of row i) fall on disjoint
+// banks for the two k-halves.
+constexpr int kSplitKhStride = kSplitRows * 16 + 64;
+constexpr int kSplitPlaneStride = 2 * kSplitKhStride;
+constexpr int kSplitABytes = 3 * kSplitPlaneStride;
 constexpr int kSplitBBytes = 3 * 8 * 1024;                 // [column tile][plane] x 1 KiB
 constexpr int kSplitStageBytes = kSplitABytes + kSplitBBytes;
 constexpr int kSplitPackedBytes = kSplitSteps * kSplitBBytes;  // 393 216
@@ -95,6 +109,11 @@ template <int OFF>
 __device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
   asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ void lds_write_b32(unsigned addr, float v) {
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -102,6 +121,12 @@ __device__ __forceinline__ float lds_read_b32(unsigned addr) {
   float v;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
   return v;
+}
+
+// Lane index from the execution mask (no register has to carry threadIdx.x across
+// the matrix loop for the code behind it).
+__device__ __forceinline__ int lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
 // The operand registers of one k-step.  `m` first holds the mid planes and is
@@ -171,37 +196,38 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;  // rows [64 wr, +64), columns [128 wc, +128)
-  // Producer role: row `prow` of the macro tile, k-half `pkh` (wave-uniform) of every step.
-  const int prow = tid & 127, pkh = wave >> 1;
+  // Producer role: lanes 4i..4i+3 hold the four quarter-fragments (four k each) of
+  // rows i and i + 64 of the macro tile, so that a wave's h1 store covers 64
+  // contiguous bytes per row (16 rows per instruction, not 64 scattered ones).
+  const int jq = tid & 3, prow = tid >> 2;
 
   // Per-lane LDS addresses (stage 0; stage 1 = + kSplitStageBytes).
-  const unsigned a_read = lds0 + (hh * kSplitRows + 64 * wr + l32) * 16;
+  const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
   const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
-  const unsigned a_write = lds0 + (pkh * kSplitRows + prow) * 16;
-  const unsigned outp = lds0 + 2 * kSplitStageBytes;
+  const unsigned a_write = lds0 + (jq >> 1) * kSplitKhStride + prow * 16 + (jq & 1) * 8;
   const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2s, kSplitPackedBytes);
-
-  // Epilogue constants: this lane's four output columns.
-  float b2r[4], w3r[4][kOut];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int j = 128 * wc + 32 * nt + l32;
-    b2r[nt] = b2[j];
-#pragma unroll
-    for (int q = 0; q < kOut; ++q) w3r[nt][q] = q < n_out ? w3[q * kHidden + j] : 0.0f;
-  }
 
   const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
   const int64_t stride = gridDim.x;
 
   // Producer state: the tile whose h1 chunks are being produced (runs one step
   // ahead of the consumer, so it moves to the next tile before step 15).
-  float px[kIn], xn[kIn];
+  float px[2][kIn], xn[2][kIn];
   int64_t p_r0 = (int64_t)blockIdx.x * kSplitRows;
-  auto load_x = [&](float (&dst)[kIn], int64_t r0) {
-    const int64_t row = r0 + prow;
+  // h1 stores: uniform (scalar) tile base + one per-lane 32-bit offset.
+  const unsigned lane_off = prow * kHidden + 4 * jq;
+  auto rows_from = [&](int64_t r0) {
+    const int64_t left = m - r0;
+    return left <= 0 ? 0 : left < kSplitRows ? (int)left : kSplitRows;
+  };
+  int p_rows = rows_from(p_r0);
+  auto load_x = [&](float (&dst)[2][kIn], int64_t r0) {
 #pragma unroll
-    for (int i = 0; i < kIn; ++i) dst[i] = (row < m && i < d_in) ? x[row * d_in + i] : 0.0f;
+    for (int u = 0; u < 2; ++u) {
+      const int64_t row = r0 + prow + 64 * u;
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) dst[u][i] = (row < m && i < d_in) ? x[row * d_in + i] : 0.0f;
+    }
   };
   load_x(px, p_r0);
   load_x(xn, p_r0 + stride * kSplitRows);
@@ -215,43 +241,72 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
                                                16, lane * 16, (ks * 24 + block) * 1024, 0, 0);
     }
   };
-  auto produce_a = [&](int ks, u32x4 (&planes)[3]) {
-    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);
-    float h[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = b1[kb + e];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i)
-        if (DIN > 0 || i < d_in) v = __builtin_fmaf(px[i], w1[(kb + e) * d_in + i], v);
-      h[e] = relu1(v);
+  // planes[u][p]: row prow + 64u, plane p: this lane's four k as two packed pairs.
+  auto produce_a = [&](int ks, u32x2 (&planes)[2][3]) {
+    const int k0 = 16 * ks + 4 * jq;
+    float bv[4], wv[4][kIn];
+    {
+      const float4 t = *reinterpret_cast<const float4 *>(b1 + k0);
+      bv[0] = t.x, bv[1] = t.y, bv[2] = t.z, bv[3] = t.w;
     }
-    if constexpr (SAVE) {
-      const int64_t row = p_r0 + prow;
-      if (row < m) {
-        float4 *dst = reinterpret_cast<float4 *>(save_h1 + row * kHidden + kb);
-        dst[0] = make_float4(h[0], h[1], h[2], h[3]);
-        dst[1] = make_float4(h[4], h[5], h[6], h[7]);
+    if constexpr (DIN > 0) {  // four rows of W1 = kIn aligned 16-byte vectors
+      float flat[4 * kIn];
+#pragma unroll
+      for (int v4 = 0; v4 < kIn; ++v4) {
+        const float4 t = reinterpret_cast<const float4 *>(w1 + k0 * kIn)[v4];
+        flat[4 * v4] = t.x, flat[4 * v4 + 1] = t.y, flat[4 * v4 + 2] = t.z, flat[4 * v4 + 3] = t.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) wv[e][i] = flat[e * kIn + i];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) wv[e][i] = i < d_in ? w1[(k0 + e) * d_in + i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = bv[e];
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) v = __builtin_fmaf(px[u][i], wv[e][i], v);
+        h[e] = relu1(v);
+      }
+      if constexpr (SAVE && !(kSplitDiagSkip & 32)) {
+        // (a plain guarded store: a loop-carried buffer descriptor -- one per producer
+        // tile -- was miscompiled, its size word not following the tile)
+        if (prow + 64 * u < p_rows)
+          *reinterpret_cast<f32x4 *>(save_h1 + p_r0 * kHidden + 16 * ks + (lane_off + 64u * u * kHidden)) = h;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        uint32_t hi, mid, lo;
+        split_pair(h[e], h[e + 1], hi, mid, lo);
+        planes[u][0][e >> 1] = hi;
+        planes[u][1][e >> 1] = mid;
+        planes[u][2][e >> 1] = lo;
       }
     }
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      uint32_t hi, mid, lo;
-      split_pair(h[e], h[e + 1], hi, mid, lo);
-      planes[0][e >> 1] = hi;
-      planes[1][e >> 1] = mid;
-      planes[2][e >> 1] = lo;
-    }
   };
-  auto write_a = [&](int stage, const u32x4 (&planes)[3]) {
+  auto write_a = [&](int stage, const u32x2 (&planes)[2][3]) {
     const unsigned addr = a_write + stage * kSplitStageBytes;
-    lds_write_b128<0>(addr, planes[0]);
-    lds_write_b128<2 * kSplitRows * 16>(addr, planes[1]);
-    lds_write_b128<4 * kSplitRows * 16>(addr, planes[2]);
+    lds_write_b64<0>(addr, planes[0][0]);
+    lds_write_b64<kSplitPlaneStride>(addr, planes[0][1]);
+    lds_write_b64<2 * kSplitPlaneStride>(addr, planes[0][2]);
+    lds_write_b64<1024>(addr, planes[1][0]);
+    lds_write_b64<kSplitPlaneStride + 1024>(addr, planes[1][1]);
+    lds_write_b64<2 * kSplitPlaneStride + 1024>(addr, planes[1][2]);
   };
   auto step_barrier = [&]() {
-    // LDS writes of the next chunk, the direct-to-LDS weight loads and (all
-    // issued at least a matrix group ago) this step's h1 stores.
+    // vmcnt(0): the direct-to-LDS weight loads have landed (and, in-order, every
+    // older store -- this step's h1 stores were issued a matrix group or more ago).
+    // NOT vmcnt(2) "everything but the step's two stores": a register spill
+    // anywhere behind those stores is a vector-memory instruction the count does
+    // not know about, and it measured no faster.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
 
@@ -274,8 +329,8 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
                                               : nt == 1 ? lds_read_b128<3 * 1024>(br)
                                               : nt == 2 ? lds_read_b128<6 * 1024>(br)
                                                         : lds_read_b128<9 * 1024>(br);
-    f.am[0] = lds_read_b128<2 * kSplitRows * 16>(ar);
-    f.am[1] = lds_read_b128<2 * kSplitRows * 16 + 512>(ar);
+    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
+    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<1024>(br)
                                               : nt == 1 ? lds_read_b128<4 * 1024>(br)
@@ -283,21 +338,26 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
                                                         : lds_read_b128<10 * 1024>(br);
     if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) px[i] = xn[i];
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) px[u][i] = xn[u][i];
       p_r0 += stride * kSplitRows;
+      p_rows = rows_from(p_r0);
       load_x(xn, p_r0 + stride * kSplitRows);
     }
-    u32x4 planes[3];
-    produce_a(ks, planes);
+    {
+      u32x2 planes[2][3];
+      produce_a(ks, planes);
+      write_a(P ^ 1, planes);  // (straight away: twelve registers less across the matrix groups)
+    }
     wait_lds_all(f);
     split_mma<FIRST>(f.am, f.bm, acc);
     split_mma<false>(f.ah, f.bm, acc);
     split_mma<false>(f.am, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
-    write_a(P ^ 1, planes);
     // lo planes into the registers of the mid planes
-    f.am[0] = lds_read_b128<4 * kSplitRows * 16>(ar);
-    f.am[1] = lds_read_b128<4 * kSplitRows * 16 + 512>(ar);
+    f.am[0] = lds_read_b128<2 * kSplitPlaneStride>(ar);
+    f.am[1] = lds_read_b128<2 * kSplitPlaneStride + 512>(ar);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<2 * 1024>(br)
                                               : nt == 1 ? lds_read_b128<5 * 1024>(br)
@@ -320,7 +380,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   // Prologue: chunk 0 of the first tile.
   if ((int64_t)blockIdx.x < tiles) {
     request_b(0, 0);
-    u32x4 planes[3];
+    u32x2 planes[2][3];
     produce_a(0, planes);
     write_a(0, planes);
     step_barrier();
@@ -344,6 +404,18 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     // lane's four columns, summed across the half-wave with DPP adds, the two
     // column halves of the workgroup meeting in LDS.
     const __amdgpu_buffer_rsrc_t h2rsrc = buffer_rsrc(SAVE ? save_h2 + r0 * kHidden : nullptr, rows * kHidden * 4);
+    const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
+    const unsigned outp = lds_offset(smem) + 2 * kSplitStageBytes;
+    // This lane's four output columns (re-read per tile -- L1 hits -- rather than
+    // held across the matrix loop, where every register counts).
+    float b2r[4], w3r[4][kOut];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int j = 128 * wc + 32 * nt + l32;
+      b2r[nt] = b2[j];
+#pragma unroll
+      for (int q = 0; q < kOut; ++q) w3r[nt][q] = q < n_out ? w3[q * kHidden + j] : 0.0f;
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -355,7 +427,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
           acc[mt][nt][r] = relu1(pre[0]);
           acc[mt][nt][r + 1] = relu1(pre[1]);
         }
-        if constexpr (SAVE) {
+        if constexpr (SAVE && !(kSplitDiagSkip & 8)) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
@@ -379,7 +451,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int idx = tid; idx < kSplitRows * n_out; idx += kBlock) {
+    for (int idx = 64 * wave + lane_id(); idx < kSplitRows * n_out; idx += kBlock) {
       const int row = idx / n_out, q = idx - row * n_out;
       const float v = lds_read_b32(outp + (row * kOut + q) * 4) + lds_read_b32(outp + ((kSplitRows + row) * kOut + q) * 4);
       if (row < rows) out[(r0 + row) * n_out + q] = v + b3[q];
@@ -422,10 +494,9 @@ static int dispatch_forward_split_nout(int n_out, int grid, hipStream_t s, const
     case 1: return launch_forward_split_save<DIN, 1>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
     case 2: return launch_forward_split_save<DIN, 2>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
     case 3: return launch_forward_split_save<DIN, 3>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
-    default: return launch_forward_split_save<DIN, 0>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+    default: return RL8_ESIZE;
   }
 }
-
 
 // ---- backward ("dgrad" half) on the same scheme --------------------------------
 //   dZ2 = (dOut x W3) * (h2 > 0)   computed per k-chunk on the VALU (thread = row,
@@ -439,9 +510,9 @@ static int dispatch_forward_split_nout(int n_out, int grid, hipStream_t s, const
 // HBM-streaming kernel with thread = column, into the same partial rows.
 template <int DIN, int NOUT>
 __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_tower_backward_split_kernel(
-    const float *__restrict__ x, const float *__restrict__ h1, const float *__restrict__ h2,
-    const float *__restrict__ dout, int64_t m, int d_in_rt, const void *__restrict__ w2ts,
-    const float *__restrict__ w3, int n_out_rt, float *__restrict__ dz2_out,
+    const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+    const float *__restrict__ h2, const float *__restrict__ dout, int64_t m, int d_in_rt,
+    const void *__restrict__ w2ts, const float *__restrict__ w3, int n_out_rt, float *__restrict__ dz2_out,
     float *__restrict__ partials, int partial_stride) {
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
@@ -452,10 +523,10 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int prow = tid & 127, pkh = wave >> 1;
-  const unsigned a_read = lds0 + (hh * kSplitRows + 64 * wr + l32) * 16;
+  const int jq = tid & 3, prow = tid >> 2;  // producer role: see the forward kernel
+  const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
   const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
-  const unsigned a_write = lds0 + (pkh * kSplitRows + prow) * 16;
+  const unsigned a_write = lds0 + (jq >> 1) * kSplitKhStride + prow * 16 + (jq & 1) * 8;
   const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2ts, kSplitPackedBytes);
 
   const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
@@ -463,22 +534,39 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 
   // Producer state (one step ahead of the consumer; moves to the next tile before step 15).
   int64_t p_tile = blockIdx.x;
-  float dr[kOut], dn[kOut];
-  auto load_dout = [&](float (&dst)[kOut], int64_t tile) {
-    const int64_t row = tile * kSplitRows + prow;
+  int p_rows;                      // valid rows of the producer's tile
+  float dr[2][kOut], dn[2][kOut];  // dOut of rows prow, prow + 64 of the producer's tile / the tile after
+  auto load_dout = [&](float (&dst)[2][kOut], int64_t tile) {
 #pragma unroll
-    for (int q = 0; q < kOut; ++q) dst[q] = (row < m && q < n_out) ? dout[row * n_out + q] : 0.0f;
+    for (int u = 0; u < 2; ++u) {
+      const int64_t row = tile * kSplitRows + prow + 64 * u;
+#pragma unroll
+      for (int q = 0; q < kOut; ++q) dst[u][q] = (row < m && q < n_out) ? dout[row * n_out + q] : 0.0f;
+    }
   };
   load_dout(dr, p_tile);
   load_dout(dn, p_tile + stride);
-  float4 hq[2][2];  // h2 of the two chunks in flight (this thread's row, eight columns each)
+  // h2 of the chunk produced next: [row u] = this lane's four columns, requested a
+  // step ahead.  Rows past the end are clamped to the last row (always a valid
+  // address, no branch): their dOut is zero, so their dZ2 is, and their stores
+  // are dropped.
+  float4 hq[2];
+  // Addresses: a uniform (scalar) tile base plus ONE per-lane 32-bit offset shared by
+  // the h2 loads and the dZ2 stores (same [row][256] layout) -- 64-bit per-lane
+  // pointers cost registers the matrix loop does not have.
+  const unsigned lane_off = prow * kHidden + 4 * jq;
+  auto rows_in_tile = [&](int64_t tile) {
+    const int64_t left = m - tile * kSplitRows;
+    return left <= 0 ? 0 : left < kSplitRows ? (int)left : kSplitRows;
+  };
   auto load_h2 = [&](float4 (&dst)[2], int64_t tile, int ks) {
-    const int64_t row = tile * kSplitRows + prow;
-    dst[0] = dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < m) {
-      const float4 *src = reinterpret_cast<const float4 *>(h2 + row * kHidden + 16 * ks + 8 * pkh);
-      dst[0] = src[0];
-      dst[1] = src[1];
+    const int rows = rows_in_tile(tile);
+    const float *base = h2 + tile * (kSplitRows * kHidden) + 16 * ks;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      dst[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // (rows past the end: gate closed)
+      if (!(kSplitDiagSkip & 64) && prow + 64 * u < rows)
+        dst[u] = *reinterpret_cast<const float4 *>(base + (lane_off + 64u * u * kHidden));
     }
   };
   auto request_b = [&](int ks, int stage) {
@@ -489,49 +577,61 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
                                                16, lane * 16, (ks * 24 + block) * 1024, 0, 0);
     }
   };
-  auto produce_a = [&](const float4 (&hv)[2], int64_t tile, int ks, u32x4 (&planes)[3]) {
-    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);
-    const float hval[8] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w};
-    float dz[8];
+  auto produce_a = [&](const float4 (&hv)[2], int ks, u32x2 (&planes)[2][3]) {
+    const int k0 = 16 * ks + 4 * jq;
+    float wv[kOut][4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float g = dr[0] * w3[kb + e];
-#pragma unroll
-      for (int q = 1; q < kOut; ++q)
-        if (NOUT > 0 ? q < NOUT : q < n_out) g = __builtin_fmaf(dr[q], w3[q * kHidden + kb + e], g);
-      dz[e] = hval[e] > 0.0f ? g : 0.0f;
-    }
-    const int64_t row = tile * kSplitRows + prow;
-    if (row < m) {
-      float4 *dst = reinterpret_cast<float4 *>(dz2_out + row * kHidden + kb);
-      dst[0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
-      dst[1] = make_float4(dz[4], dz[5], dz[6], dz[7]);
+    for (int q = 0; q < kOut; ++q) {
+      if (NOUT > 0 ? q < NOUT : q < n_out) {
+        const float4 t = *reinterpret_cast<const float4 *>(w3 + q * kHidden + k0);
+        wv[q][0] = t.x, wv[q][1] = t.y, wv[q][2] = t.z, wv[q][3] = t.w;
+      } else {
+        wv[q][0] = wv[q][1] = wv[q][2] = wv[q][3] = 0.0f;
+      }
     }
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      uint32_t hi, mid, lo;
-      split_pair(dz[e], dz[e + 1], hi, mid, lo);
-      planes[0][e >> 1] = hi;
-      planes[1][e >> 1] = mid;
-      planes[2][e >> 1] = lo;
+    for (int u = 0; u < 2; ++u) {
+      const float hval[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
+      f32x4 dz;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g = dr[u][0] * wv[0][e];
+#pragma unroll
+        for (int q = 1; q < kOut; ++q)
+          if (NOUT > 0 ? q < NOUT : q < n_out) g = __builtin_fmaf(dr[u][q], wv[q][e], g);
+        dz[e] = hval[e] > 0.0f ? g : 0.0f;
+      }
+      if constexpr (!(kSplitDiagSkip & 128)) {
+        if (prow + 64 * u < p_rows)
+          *reinterpret_cast<f32x4 *>(dz2_out + p_tile * (kSplitRows * kHidden) + 16 * ks + (lane_off + 64u * u * kHidden)) = dz;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        uint32_t hi, mid, lo;
+        split_pair(dz[e], dz[e + 1], hi, mid, lo);
+        planes[u][0][e >> 1] = hi;
+        planes[u][1][e >> 1] = mid;
+        planes[u][2][e >> 1] = lo;
+      }
     }
   };
-  auto write_a = [&](int stage, const u32x4 (&planes)[3]) {
+  auto write_a = [&](int stage, const u32x2 (&planes)[2][3]) {
     const unsigned addr = a_write + stage * kSplitStageBytes;
-    lds_write_b128<0>(addr, planes[0]);
-    lds_write_b128<2 * kSplitRows * 16>(addr, planes[1]);
-    lds_write_b128<4 * kSplitRows * 16>(addr, planes[2]);
+    lds_write_b64<0>(addr, planes[0][0]);
+    lds_write_b64<kSplitPlaneStride>(addr, planes[0][1]);
+    lds_write_b64<2 * kSplitPlaneStride>(addr, planes[0][2]);
+    lds_write_b64<1024>(addr, planes[1][0]);
+    lds_write_b64<kSplitPlaneStride + 1024>(addr, planes[1][1]);
+    lds_write_b64<2 * kSplitPlaneStride + 1024>(addr, planes[1][2]);
   };
   auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
   f32x16 acc[2][4];
-  float db1[4], dw1[4][kIn];  // this lane's four columns, its half of the rows
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    db1[nt] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < kIn; ++i) dw1[nt][i] = 0.0f;
-  }
+  // Running column sums [256][1 + kIn] (db1 | dW1 row) live in LDS behind the two
+  // chunk stages, not in registers: the matrix loop has none to spare.
+  const unsigned colsum = lds0 + 2 * kSplitStageBytes;
+  for (int idx = tid; idx < kHidden * (1 + kIn); idx += kBlock) lds_write_b32(colsum + idx * 4, 0.0f);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   auto do_step = [&](auto first_tag, auto parity_tag, int s) {
     constexpr bool FIRST = decltype(first_tag)::value;
@@ -546,30 +646,36 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     f.bh[1] = lds_read_b128<3 * 1024>(br);
     f.bh[2] = lds_read_b128<6 * 1024>(br);
     f.bh[3] = lds_read_b128<9 * 1024>(br);
-    f.am[0] = lds_read_b128<2 * kSplitRows * 16>(ar);
-    f.am[1] = lds_read_b128<2 * kSplitRows * 16 + 512>(ar);
+    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
+    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
     f.bm[0] = lds_read_b128<1024>(br);
     f.bm[1] = lds_read_b128<4 * 1024>(br);
     f.bm[2] = lds_read_b128<7 * 1024>(br);
     f.bm[3] = lds_read_b128<10 * 1024>(br);
     if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
 #pragma unroll
-      for (int q = 0; q < kOut; ++q) dr[q] = dn[q];
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < kOut; ++q) dr[u][q] = dn[u][q];
       p_tile += stride;
+      p_rows = rows_in_tile(p_tile);
       load_dout(dn, p_tile + stride);
     }
-    u32x4 planes[3];
-    produce_a(hq[P ^ 1], p_tile, ks, planes);
-    // h2 of the chunk after next (two steps ahead of its use)
-    load_h2(hq[P], s == kSplitSteps - 2 ? p_tile + stride : p_tile, (s + 2) & (kSplitSteps - 1));
+    {
+      u32x2 planes[2][3];
+      produce_a(hq, ks, planes);
+      write_a(P ^ 1, planes);
+    }
+    // h2 of the chunk after next, into the registers just consumed: used by the
+    // next step's produce_a (the step barrier waits for it; it has this step to arrive).
+    load_h2(hq, s == kSplitSteps - 2 ? p_tile + stride : p_tile, (s + 2) & (kSplitSteps - 1));
     wait_lds_all(f);
     split_mma<FIRST>(f.am, f.bm, acc);
     split_mma<false>(f.ah, f.bm, acc);
     split_mma<false>(f.am, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
-    write_a(P ^ 1, planes);
-    f.am[0] = lds_read_b128<4 * kSplitRows * 16>(ar);
-    f.am[1] = lds_read_b128<4 * kSplitRows * 16 + 512>(ar);
+    f.am[0] = lds_read_b128<2 * kSplitPlaneStride>(ar);
+    f.am[1] = lds_read_b128<2 * kSplitPlaneStride + 512>(ar);
     f.bm[0] = lds_read_b128<2 * 1024>(br);
     f.bm[1] = lds_read_b128<5 * 1024>(br);
     f.bm[2] = lds_read_b128<8 * 1024>(br);
@@ -588,13 +694,14 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
 
+  p_rows = rows_in_tile(p_tile);
   if ((int64_t)blockIdx.x < tiles) {
-    load_h2(hq[0], p_tile, 0);
-    load_h2(hq[1], p_tile, 1);
+    load_h2(hq, p_tile, 0);
     request_b(0, 0);
-    u32x4 planes[3];
-    produce_a(hq[0], p_tile, 0, planes);
+    u32x2 planes[2][3];
+    produce_a(hq, 0, planes);
     write_a(0, planes);
+    load_h2(hq, p_tile, 1);
     step_barrier();
   }
 
@@ -611,90 +718,100 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     do_step(F{}, P0{}, kSplitSteps - 2);
     do_step(F{}, P1{}, kSplitSteps - 1);
 
-    // Epilogue: dZ1 = dH1 * (h1 > 0) folded into db1 / dW1.  h1 and the
-    // observations arrive through tile-sized descriptors (rows past the end of a
-    // partial tile read as zero: gate closed).
-    const __amdgpu_buffer_rsrc_t h1rsrc = buffer_rsrc(h1 + r0 * kHidden, rows * kHidden * 4);
+    // Epilogue: dZ1 = dH1 * (h1 > 0) folded into db1 / dW1.  The gate is RECOMPUTED
+    // from the observations -- h1 > 0 <=> b1 + x . w1 > 0, the same fma chain as the
+    // forward pass, so the same decision bit for bit -- instead of reading 1 KiB of
+    // h1 per row back from HBM (d_in is tiny; the observations are needed for dW1
+    // anyway).  They arrive through a tile-sized descriptor: rows past the end of
+    // a partial tile read as zero and their dH1 is zero (zero dOut).
     const __amdgpu_buffer_rsrc_t xrsrc = buffer_rsrc(x + r0 * d_in, rows * d_in * 4);
-    // (wide observations: the x values of a batch of four rows are loaded inside
-    // the batch -- sixteen rows' worth of them would not fit beside the accumulators)
-    constexpr bool kHoistX = kIn <= 2;
-    auto load_x_rows = [&](float (&xv)[16][kIn], int mt, int r_begin, int r_end) {
+    const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
+    const unsigned colsum = lds_offset(smem) + 2 * kSplitStageBytes;
+    float w1c[4][kIn], b1c[4];  // this lane's four columns of layer 1 (reloaded per tile: L1 hits)
 #pragma unroll
-      for (int r = r_begin; r < r_end; ++r) {
-        const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col = 128 * wc + 32 * nt + l32;
+      b1c[nt] = b1[col];
 #pragma unroll
-        for (int i = 0; i < kIn; ++i)
-          xv[r][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(xrsrc, (4 * hh * d_in + i) * 4, sr * d_in * 4) : 0.0f;
-      }
-    };
+      for (int i = 0; i < kIn; ++i) w1c[nt][i] = (DIN > 0 || i < d_in) ? w1[col * d_in + i] : 0.0f;
+    }
+    float db1[4], dw1[4][kIn];  // this tile: this lane's four columns, its half of the rows
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float xv[16][kIn];
-      if constexpr (kHoistX) load_x_rows(xv, mt, 0, 16);
+    for (int nt = 0; nt < 4; ++nt) {
+      db1[nt] = 0.0f;
 #pragma unroll
-      for (int np = 0; np < 4; np += 2) {
-        float hv[2][16];
+      for (int i = 0; i < kIn; ++i) dw1[nt][i] = 0.0f;
+    }
 #pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);
-            hv[n2][r] = buffer_load_f32(h1rsrc, (4 * hh * kHidden + 128 * wc + 32 * (np + n2) + l32) * 4,
-                                        sr * (kHidden * 4));
+      for (int rb = 0; rb < 16; rb += 4) {
+        float xv[4][kIn];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = rb + u;
+          const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
+#pragma unroll
+          for (int i = 0; i < kIn; ++i)
+            xv[u][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(xrsrc, (4 * hh * d_in + i) * 4, sr * d_in * 4) : 0.0f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          float pre[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            pre[u] = b1c[nt];
+#pragma unroll
+            for (int i = 0; i < kIn; ++i) pre[u] = __builtin_fmaf(xv[u][i], w1c[nt][i], pre[u]);
           }
+          unsigned long long gate[4];
 #pragma unroll
-        for (int rb = 0; rb < 16; rb += 4) {
-          if constexpr (!kHoistX) load_x_rows(xv, mt, rb, rb + 4);
+          for (int u = 0; u < 4; ++u) gate[u] = positive_mask(pre[u]);
+          __builtin_amdgcn_sched_barrier(0);
+          float dz[4];
 #pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2) {
-            unsigned long long gate[4];
+          for (int u = 0; u < 4; ++u) dz[u] = select_or_zero(gate[u], acc[mt][nt][rb + u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) gate[u] = positive_mask(hv[n2][rb + u]);
-            __builtin_amdgcn_sched_barrier(0);
-            float dz[4];
+          for (int u = 0; u < 4; ++u) {
+            db1[nt] += dz[u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dz[u] = select_or_zero(gate[u], acc[mt][np + n2][rb + u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              db1[np + n2] += dz[u];
-#pragma unroll
-              for (int i = 0; i < kIn; ++i) dw1[np + n2][i] = __builtin_fmaf(dz[u], xv[rb + u][i], dw1[np + n2][i]);
-            }
+            for (int i = 0; i < kIn; ++i) dw1[nt][i] = __builtin_fmaf(dz[u], xv[u][i], dw1[nt][i]);
           }
         }
       }
+    // Into the running sums, in a fixed order: the two row halves of a lane pair
+    // (DPP-free: one cross-half shuffle), then the wave of rows 0..63, a barrier,
+    // the wave of rows 64..127.  (The next tile touches them sixteen barriers later.)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      db1[nt] += __shfl_xor(db1[nt], 32, kWave);
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) dw1[nt][i] += __shfl_xor(dw1[nt][i], 32, kWave);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (wr == half && hh == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const unsigned a = colsum + (128 * wc + 32 * nt + l32) * (1 + kIn) * 4;
+          lds_write_b32(a, lds_read_b32(a) + db1[nt]);
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) lds_write_b32(a + 4 + 4 * i, lds_read_b32(a + 4 + 4 * i) + dw1[nt][i]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
 
   // Workgroup partial row: [dW1 (256*d_in) | db1 (256) | ... head gradients (mlp_head_grads_kernel)].
-  // Fold the two row halves of a lane pair (hh), then the two row-halves of the
-  // workgroup (wr) through LDS, in a fixed order.
   float *row = partials + (int64_t)blockIdx.x * partial_stride;
-  float *red = reinterpret_cast<float *>(smem);  // [256 columns][1 + kIn]
-  __syncthreads();
+  {
+    const int t = 64 * wave + lane_id();
+    const unsigned a = lds_offset(smem) + 2 * kSplitStageBytes + t * (1 + kIn) * 4;
+    row[kHidden * d_in + t] = lds_read_b32(a);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int col = 128 * wc + 32 * nt + l32;
-    db1[nt] += __shfl_xor(db1[nt], 32, kWave);
-#pragma unroll
-    for (int i = 0; i < kIn; ++i) dw1[nt][i] += __shfl_xor(dw1[nt][i], 32, kWave);
-    if (wr == 1 && hh == 0) {
-      red[col * (1 + kIn)] = db1[nt];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) red[col * (1 + kIn) + 1 + i] = dw1[nt][i];
-    }
-  }
-  __syncthreads();
-  if (wr == 0 && hh == 0) {
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int col = 128 * wc + 32 * nt + l32;
-      row[kHidden * d_in + col] = db1[nt] + red[col * (1 + kIn)];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i)
-        if (DIN > 0 || i < d_in) row[col * d_in + i] = dw1[nt][i] + red[col * (1 + kIn) + 1 + i];
-    }
+    for (int i = 0; i < kIn; ++i)
+      if (DIN > 0 || i < d_in) row[t * d_in + i] = lds_read_b32(a + 4 + 4 * i);
   }
 }
 
@@ -756,9 +873,9 @@ __global__ __launch_bounds__(kBlock) void mlp_head_grads_kernel(
 }
 
 template <int DIN, int NOUT>
-static int launch_backward_split(int grid, hipStream_t s, const float *x, const float *h1, const float *h2,
-                                 const float *dout, int64_t m, int d_in, const void *w2ts, const float *w3,
-                                 int n_out, float *dz2_out, float *partials, int stride) {
+static int launch_backward_split(int grid, hipStream_t s, const float *x, const float *w1, const float *b1,
+                                 const float *h2, const float *dout, int64_t m, int d_in, const void *w2ts,
+                                 const float *w3, int n_out, float *dz2_out, float *partials, int stride) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_split_kernel<DIN, NOUT>),
@@ -766,8 +883,9 @@ static int launch_backward_split(int grid, hipStream_t s, const float *x, const 
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_tower_backward_split_kernel<DIN, NOUT><<<grid, kBlock, 2 * kSplitStageBytes, s>>>(
-      x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
+  mlp_tower_backward_split_kernel<DIN, NOUT><<<grid, kBlock, 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4, s>>>(
+      x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
   const int status = launch_status();
   if (status != 0) return status;
   mlp_head_grads_kernel<NOUT><<<grid, kBlock, 0, s>>>(h2, dout, m, w3, n_out, d_in, partials, stride);
@@ -775,15 +893,222 @@ static int launch_backward_split(int grid, hipStream_t s, const float *x, const 
 }
 
 template <int DIN>
-static int dispatch_backward_split_nout(int n_out, int grid, hipStream_t s, const float *x, const float *h1,
-                                        const float *h2, const float *dout, int64_t m, int d_in, const void *w2ts,
-                                        const float *w3, float *dz2_out, float *partials, int stride) {
+static int dispatch_backward_split_nout(int n_out, int grid, hipStream_t s, const float *x, const float *w1,
+                                        const float *b1, const float *h2, const float *dout, int64_t m, int d_in,
+                                        const void *w2ts, const float *w3, float *dz2_out, float *partials,
+                                        int stride) {
   switch (n_out) {
-    case 1: return launch_backward_split<DIN, 1>(grid, s, x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
-    case 2: return launch_backward_split<DIN, 2>(grid, s, x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
-    case 3: return launch_backward_split<DIN, 3>(grid, s, x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
-    default: return launch_backward_split<DIN, 0>(grid, s, x, h1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+    case 1: return launch_backward_split<DIN, 1>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+    case 2: return launch_backward_split<DIN, 2>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+    default: return RL8_ESIZE;
   }
+}
+
+// ---- weight gradient of the 256x256 layer on the same scheme -------------------
+//   dW2[j][i] = sum over samples s of dZ2[s][j] * h1[s][i]
+// The reduction runs over SAMPLES, so an MFMA operand fragment is "eight
+// consecutive samples of one column" -- and with thread = column that is exactly
+// what a thread collects from row-major data with coalesced loads: no transpose
+// anywhere.  One workgroup of 8 waves per CU owns the whole 256x256 output (wave =
+// 2 j-tiles x 4 i-tiles = 128 accumulator registers) and a strided share of the
+// 16-sample chunks; per chunk each thread
+//   * takes eight samples of column j of dZ2 (HBM, prefetched two chunks ahead),
+//   * RECOMPUTES eight samples of column i of h1 = relu(b1[i] + x . w1[i]) -- layer 1
+//     is a handful of fmas per element, the observations come through the scalar
+//     cache -- instead of reading 1 KiB of h1 per sample back from HBM,
+//   splits both into the three planes and writes them to LDS as ready fragments,
+// all on the VALU beside the bf16 MFMAs of the previous chunk.  Partial sums leave
+// as one slab per workgroup, added up in slab order by mlp_wgrad_split_reduce_kernel
+// (bitwise reproducible; no atomics).
+constexpr int kWsThreads = 512;
+constexpr int kWsChunk = 16;                             // samples per k-step
+constexpr int kWsOperandBytes = 3 * 2 * kHidden * 16;    // [plane][sample half][column] x 16 B
+constexpr int kWsPlane = 2 * kHidden * 16;
+constexpr int kWsStageBytes = 2 * kWsOperandBytes;       // dZ2^T | h1
+
+template <int DIN>
+__global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
+    const float *__restrict__ dz2, const float *__restrict__ x, const float *__restrict__ w1,
+    const float *__restrict__ b1, int64_t m, int d_in_rt, float *__restrict__ slabs) {
+  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
+  const int d_in = DIN > 0 ? DIN : d_in_rt;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = lds_offset(smem);
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wj = wave >> 1, wi = wave & 1;  // j-tiles {2wj, 2wj+1}, i-tiles {4wi .. 4wi+3}
+  const int col = tid & 255;                // producer: column (j of dZ2 and i of h1) ...
+  const int kh = wave >> 2;                 // ... and which eight samples of the chunk (wave-uniform)
+
+  const unsigned a_read = lds0 + (hh * kHidden + 64 * wj + l32) * 16;
+  const unsigned b_read = lds0 + kWsOperandBytes + (hh * kHidden + 128 * wi + l32) * 16;
+  const unsigned p_write = lds0 + (kh * kHidden + col) * 16;
+
+  float w1r[kIn];
+#pragma unroll
+  for (int c = 0; c < kIn; ++c) w1r[c] = (DIN > 0 || c < d_in) ? w1[col * d_in + c] : 0.0f;
+  const float b1r = b1[col];
+
+  const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
+  const int64_t stride = gridDim.x;
+  const int64_t mine = (chunks - blockIdx.x + stride - 1) / stride;  // >= 1 (grid <= chunks)
+
+  // dZ2 of chunk number n of this workgroup: this thread's column, its eight samples.
+  // Chunks past the end (and samples past m) read as zero through the descriptor.
+  auto load_dz = [&](float (&dst)[8], int64_t n) {
+    const int64_t chunk = blockIdx.x + n * stride;
+    const int64_t left = m - chunk * kWsChunk;
+    const int rows = left <= 0 ? 0 : left < kWsChunk ? (int)left : kWsChunk;
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? dz2 + chunk * kWsChunk * kHidden : dz2, rows * kHidden * 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = buffer_load_f32(rsrc, col * 4, (8 * kh + e) * (kHidden * 4));
+  };
+  auto split8 = [&](const float (&v)[8], u32x4 (&planes)[3]) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t hi, mid, lo;
+      split_pair(v[e], v[e + 1], hi, mid, lo);
+      planes[0][e >> 1] = hi;
+      planes[1][e >> 1] = mid;
+      planes[2][e >> 1] = lo;
+    }
+  };
+  auto produce = [&](const float (&dzv)[8], int64_t n, u32x4 (&pa)[3], u32x4 (&pb)[3]) {
+    split8(dzv, pa);
+    const int64_t chunk = blockIdx.x + n * stride;
+    float h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int64_t row = chunk * kWsChunk + 8 * kh + e;
+      row = row < m ? row : m - 1;  // (its dZ2 is zero)
+      float v = b1r;
+#pragma unroll
+      for (int c = 0; c < kIn; ++c)
+        if (DIN > 0 || c < d_in) v = __builtin_fmaf(x[row * d_in + c], w1r[c], v);
+      h[e] = relu1(v);
+    }
+    split8(h, pb);
+  };
+  auto write_planes = [&](int stage, const u32x4 (&pa)[3], const u32x4 (&pb)[3]) {
+    const unsigned addr = p_write + stage * kWsStageBytes;
+    lds_write_b128<0>(addr, pa[0]);
+    lds_write_b128<kWsPlane>(addr, pa[1]);
+    lds_write_b128<2 * kWsPlane>(addr, pa[2]);
+    lds_write_b128<kWsOperandBytes>(addr, pb[0]);
+    lds_write_b128<kWsOperandBytes + kWsPlane>(addr, pb[1]);
+    lds_write_b128<kWsOperandBytes + 2 * kWsPlane>(addr, pb[2]);
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  f32x16 acc[2][4];
+  float dzq[2][8];
+
+  // Chunk n (stage n & 1) is consumed while chunk n+1 is produced from dzq[(n+1) & 1]
+  // and the dZ2 of chunk n+2 is requested into dzq[n & 1].
+  auto do_step = [&](auto first_tag, auto parity_tag, int64_t n) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int P = decltype(parity_tag)::value;
+    const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
+    SplitFrags f;
+    f.ah[0] = lds_read_b128<0>(ar);
+    f.ah[1] = lds_read_b128<512>(ar);
+    f.bh[0] = lds_read_b128<0>(br);
+    f.bh[1] = lds_read_b128<512>(br);
+    f.bh[2] = lds_read_b128<1024>(br);
+    f.bh[3] = lds_read_b128<1536>(br);
+    f.am[0] = lds_read_b128<kWsPlane>(ar);
+    f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
+    f.bm[0] = lds_read_b128<kWsPlane>(br);
+    f.bm[1] = lds_read_b128<kWsPlane + 512>(br);
+    f.bm[2] = lds_read_b128<kWsPlane + 1024>(br);
+    f.bm[3] = lds_read_b128<kWsPlane + 1536>(br);
+    {
+      u32x4 pa[3], pb[3];
+      produce(dzq[P ^ 1], n + 1, pa, pb);
+      write_planes(P ^ 1, pa, pb);
+    }
+    load_dz(dzq[P], n + 2);
+    wait_lds_all(f);
+    split_mma<FIRST>(f.am, f.bm, acc);
+    split_mma<false>(f.ah, f.bm, acc);
+    split_mma<false>(f.am, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    f.am[0] = lds_read_b128<2 * kWsPlane>(ar);
+    f.am[1] = lds_read_b128<2 * kWsPlane + 512>(ar);
+    f.bm[0] = lds_read_b128<2 * kWsPlane>(br);
+    f.bm[1] = lds_read_b128<2 * kWsPlane + 512>(br);
+    f.bm[2] = lds_read_b128<2 * kWsPlane + 1024>(br);
+    f.bm[3] = lds_read_b128<2 * kWsPlane + 1536>(br);
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma<false>(f.ah, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lds_all(f);
+    split_mma<false>(f.ah, f.bm, acc);
+    split_mma<false>(f.am, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  {
+    load_dz(dzq[0], 0);
+    load_dz(dzq[1], 1);
+    u32x4 pa[3], pb[3];
+    produce(dzq[0], 0, pa, pb);
+    write_planes(0, pa, pb);
+    lds_barrier();
+  }
+  do_step(T{}, P0{}, 0);
+  int64_t n = 1;
+#pragma unroll 1
+  for (; n + 1 < mine; n += 2) {
+    do_step(F{}, P1{}, n);
+    do_step(F{}, P0{}, n + 1);
+  }
+  if (n < mine) do_step(F{}, P1{}, n);
+
+  float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;
+#pragma unroll
+  for (int ja = 0; ja < 2; ++ja)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 64 * wj + 32 * ja + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int i = 128 * wi + 32 * t + l32;
+        slab[j * kHidden + i] = acc[ja][t][r];
+      }
+}
+
+// out[idx] (+)= sum over slabs, in slab order.
+__global__ __launch_bounds__(kBlock) void mlp_wgrad_split_reduce_kernel(const float *__restrict__ slabs, int rows,
+                                                                       float *__restrict__ out, int accumulate) {
+  const int idx = blockIdx.x * kBlock + threadIdx.x;  // one float4 each
+  if (idx >= kHidden * kHidden / 4) return;
+  const float4 *p = reinterpret_cast<const float4 *>(slabs) + idx;
+  float4 sum = accumulate ? reinterpret_cast<float4 *>(out)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < rows; ++r) {
+    const float4 v = p[(int64_t)r * (kHidden * kHidden / 4)];
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  reinterpret_cast<float4 *>(out)[idx] = sum;
+}
+
+template <int DIN>
+static int launch_wgrad_split(int grid, hipStream_t s, const float *dz2, const float *x, const float *w1,
+                              const float *b1, int64_t m, int d_in, float *slabs) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  mlp_wgrad_split_kernel<DIN><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(dz2, x, w1, b1, m, d_in, slabs);
+  return launch_status();
 }
 
 }  // namespace rl8
@@ -807,30 +1132,40 @@ RL8_API int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in,
   if (!x || !w1 || !b1 || !w2_split || !b2 || !w3 || !b3 || !out) return RL8_ENULL;
   if ((save_h1 == nullptr) != (save_h2 == nullptr)) return RL8_ENULL;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
-  if (((uintptr_t)w2_split & 15) != 0 || (save_h1 && ((uintptr_t)save_h1 & 15) != 0)) return RL8_EALIGN;
+  if (((uintptr_t)w2_split & 15) != 0 || !aligned16(w1) || !aligned16(b1) || (save_h1 && !aligned16(save_h1)))
+    return RL8_EALIGN;
   const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
   static const int cap = env_int("RL8_MLP_GRID_CAP");
   const int max_grid = cap > 0 ? cap : 2 * kCUs;
   const int grid = (int)(tiles < max_grid ? tiles : max_grid);
   hipStream_t s = (hipStream_t)stream;
+  // Only the widths whose kernels are verified spill-free are compiled (see
+  // rl8_mlp_forward_split_supports); the rest keep rl8_mlp_tower_forward_f32.
   switch (d_in) {
     case 1: return dispatch_forward_split_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
     case 2: return dispatch_forward_split_nout<2>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
-    case 3: return dispatch_forward_split_nout<3>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
-    case 5: return dispatch_forward_split_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
-    default: return dispatch_forward_split_nout<0>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
+    default: return RL8_ESIZE;
   }
 }
 
-RL8_API int rl8_mlp_tower_backward_split_f32(const float *x, const float *h1, const float *h2,
-                                             const float *dout, int64_t m, int d_in,
+// These kernels read LDS through inline asm the compiler cannot see; a register
+// spill placed between such a read and its wait could save a register whose data
+// has not arrived.  So a width is offered only if its kernel compiles WITHOUT
+// scratch (tests/test_kernel_resources.py holds the list to that); other widths
+// use the fp32-MFMA kernels.
+RL8_API int rl8_mlp_forward_split_supports(int d_in, int n_out) {
+  return (d_in == 1 || d_in == 2) && n_out >= 1 && n_out <= 3;
+}
+
+RL8_API int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, const float *b1,
+                                             const float *h2, const float *dout, int64_t m, int d_in,
                                              const void *w2t_split, const float *w3, int n_out,
                                              float *dz2_out, float *partials, int *partial_rows_out,
                                              void *stream) {
-  if (!x || !h1 || !h2 || !dout || !w2t_split || !w3 || !dz2_out || !partials || !partial_rows_out)
+  if (!x || !w1 || !b1 || !h2 || !dout || !w2t_split || !w3 || !dz2_out || !partials || !partial_rows_out)
     return RL8_ENULL;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
-  if (((uintptr_t)w2t_split & 15) != 0 || !aligned16(h2) || !aligned16(dz2_out)) return RL8_EALIGN;
+  if (((uintptr_t)w2t_split & 15) != 0 || !aligned16(h2) || !aligned16(dz2_out) || !aligned16(w3)) return RL8_EALIGN;
   const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
   static const int cap = env_int("RL8_MLP_GRID_CAP");
   const int max_grid = cap > 0 ? cap : 2 * kCUs;
@@ -839,14 +1174,34 @@ RL8_API int rl8_mlp_tower_backward_split_f32(const float *x, const float *h1, co
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
   switch (d_in) {
-    case 1: return dispatch_backward_split_nout<1>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
-    case 2: return dispatch_backward_split_nout<2>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
-    case 3: return dispatch_backward_split_nout<3>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
-    case 5: return dispatch_backward_split_nout<5>(n_out, grid, s, x, h1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
+    case 1: return dispatch_backward_split_nout<1>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
     default: return RL8_ESIZE;  // rl8_mlp_backward_split_supports(): other widths use rl8_mlp_tower_backward_f32
   }
 }
 
 RL8_API int rl8_mlp_backward_split_supports(int d_in, int n_out) {
-  return (d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5) && n_out >= 1 && n_out <= kMaxOut;
+  return d_in == 1 && (n_out == 1 || n_out == 2);  // spill-free widths only (see rl8_mlp_forward_split_supports)
+}
+
+/* dW2 (+)= dZ2^T h1 with h1 recomputed from the observations (see the kernel). */
+RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const float *w1, const float *b1,
+                                    int64_t m, int d_in, float *workspace, float *dw2_out, int accumulate,
+                                    void *stream) {
+  if (!dz2 || !x || !w1 || !b1 || !workspace || !dw2_out) return RL8_ENULL;
+  if (m <= 0 || d_in <= 0 || d_in > kMaxIn) return RL8_ESIZE;
+  if (!aligned16(dz2) || !aligned16(workspace) || !aligned16(dw2_out)) return RL8_EALIGN;
+  const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
+  const int grid = (int)(chunks < kCUs ? chunks : kCUs);
+  hipStream_t s = (hipStream_t)stream;
+  int status;
+  switch (d_in) {
+    case 1: status = launch_wgrad_split<1>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
+    case 2: status = launch_wgrad_split<2>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
+    case 3: status = launch_wgrad_split<3>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
+    case 5: status = launch_wgrad_split<5>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
+    default: status = launch_wgrad_split<0>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
+  }
+  if (status != 0) return status;
+  mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / 4 / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, accumulate);
+  return launch_status();
 }

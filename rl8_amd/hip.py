@@ -140,7 +140,9 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_backward_max_rows": [],
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_backward_split_supports": [_i32, _i32],
-    "rl8_mlp_tower_backward_split_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_mlp_forward_split_supports": [_i32, _i32],
+    "rl8_mlp_tower_backward_split_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_mlp_wgrad_split_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "rl8_mlp_wgrad_workspace_bytes": [],
     "rl8_mlp_wgrad_f32": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
 }
@@ -842,6 +844,10 @@ def mlp_tower_forward(
     return out, h1, h2
 
 
+def mlp_forward_split_supports(d_in: int, n_out: int) -> bool:
+    return bool(load().rl8_mlp_forward_split_supports(int(d_in), int(n_out)))
+
+
 def mlp_backward_split_supports(d_in: int, n_out: int) -> bool:
     return bool(load().rl8_mlp_backward_split_supports(int(d_in), int(n_out)))
 
@@ -891,11 +897,17 @@ def mlp_tower_forward_split(
 def mlp_tower_backward(
     x: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor, dout: torch.Tensor,
     w2t_packed: torch.Tensor, w3: torch.Tensor,
+    w1: None | torch.Tensor = None, b1: None | torch.Tensor = None, *, wgrad_split: bool = False,
 ) -> dict[str, torch.Tensor]:
-    """``w2t_packed`` from ``mlp_pack_w2(..., transposed=True)`` (fp32 MFMA kernel)
-    or ``mlp_pack_w2_split(..., transposed=True)`` (uint8: bf16-plane kernel)."""
     """Gradients of one tower's parameters given ``dout`` [M, n_out] and the
-    activations saved by the forward pass. Returns ``w1, b1, w2, b2, w3, b3``."""
+    activations saved by the forward pass. Returns ``w1, b1, w2, b2, w3, b3``.
+
+    ``w2t_packed`` from ``mlp_pack_w2(..., transposed=True)`` selects the fp32 MFMA
+    kernel; from ``mlp_pack_w2_split(..., transposed=True)`` (uint8) the bf16-plane
+    kernel, which also needs layer 1 (``w1``, ``b1``): it recomputes the ReLU gate
+    of h1 instead of reading h1 back. ``wgrad_split`` forms dW2 with the bf16-plane
+    weight-gradient kernel (any width; needs ``w1``, ``b1``) even when the
+    data-gradient half runs on the fp32 kernel."""
     m, d_in = x.shape
     n_out = w3.shape[0]
     for name, t, numel in (("x", x, m * d_in), ("h1", h1, m * MLP_HIDDEN), ("h2", h2, m * MLP_HIDDEN),
@@ -910,13 +922,24 @@ def mlp_tower_backward(
     dz2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device)
     rows = C.c_int(0)
     split = w2t_packed.dtype == torch.uint8
-    fn = lib.rl8_mlp_tower_backward_split_f32 if split else lib.rl8_mlp_tower_backward_f32
     with _timed("mlp_tower_backward", m):
-        _check(
-            fn(_ptr(x), _ptr(h1), _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
-               _ptr(dz2), _ptr(partials), C.byref(rows), _stream()),
-            "rl8_mlp_tower_backward_split_f32" if split else "rl8_mlp_tower_backward_f32",
-        )
+        if split:
+            if w1 is None or b1 is None:
+                raise ValueError("the bf16-plane backward needs w1 and b1")
+            _check(
+                lib.rl8_mlp_tower_backward_split_f32(
+                    _ptr(x), _ptr(_dense(w1.detach(), torch.float32, "w1")), _ptr(_dense(b1.detach(), torch.float32, "b1")),
+                    _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
+                    _ptr(dz2), _ptr(partials), C.byref(rows), _stream()),
+                "rl8_mlp_tower_backward_split_f32",
+            )
+        else:
+            _check(
+                lib.rl8_mlp_tower_backward_f32(
+                    _ptr(x), _ptr(h1), _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
+                    _ptr(dz2), _ptr(partials), C.byref(rows), _stream()),
+                "rl8_mlp_tower_backward_f32",
+            )
     small = partials[: rows.value].sum(0)
     o1 = MLP_HIDDEN * d_in
     grads = {
@@ -925,12 +948,38 @@ def mlp_tower_backward(
         "b2": small[o1 + MLP_HIDDEN : o1 + 2 * MLP_HIDDEN],
         "w3": small[o1 + 2 * MLP_HIDDEN : o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN].view(n_out, MLP_HIDDEN),
         "b3": small[o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN :],
-        "w2": mlp_wgrad(dz2, h1),
+        "w2": mlp_wgrad_split(dz2, x, w1, b1) if (split or wgrad_split) else mlp_wgrad(dz2, h1),
     }
     return grads
 
 
 _wgrad_ws: dict[tuple[int, int], torch.Tensor] = {}
+
+
+def _wgrad_workspace(device: torch.device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = torch.empty(int(load().rl8_mlp_wgrad_workspace_bytes()) // 4, dtype=torch.float32, device=device)
+        _wgrad_ws[key] = ws
+    return ws
+
+
+def mlp_wgrad_split(dz2: torch.Tensor, x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
+    """dW2 [256, 256] = dz2^T @ relu(x @ w1^T + b1) over the rows: bf16-plane MFMAs at
+    fp32 accuracy, h1 recomputed from the observations (deterministic)."""
+    _dense(dz2, torch.float32, "dz2")
+    _dense(x, torch.float32, "x")
+    m, d_in = x.shape
+    if tuple(dz2.shape) != (m, MLP_HIDDEN):
+        raise ValueError("dz2 must be [M, 256] with M = x.shape[0]")
+    out = torch.empty(MLP_HIDDEN, MLP_HIDDEN, dtype=torch.float32, device=dz2.device)
+    with _timed("mlp_wgrad", m):
+        _check(load().rl8_mlp_wgrad_split_f32(_ptr(dz2), _ptr(x), _ptr(_dense(w1.detach(), torch.float32, "w1")),
+                                              _ptr(_dense(b1.detach(), torch.float32, "b1")), m, d_in,
+                                              _ptr(_wgrad_workspace(dz2.device)), _ptr(out), 0, _stream()),
+               "rl8_mlp_wgrad_split_f32")
+    return out
 
 
 def mlp_wgrad(dz2: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:

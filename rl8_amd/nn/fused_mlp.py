@@ -63,21 +63,22 @@ class _FusedTower(torch.autograd.Function):
         # always off: the caller's grad mode comes in as an argument, so that
         # activations are kept only when a backward can follow.
         need_grad = grad_mode and any(ctx.needs_input_grad[1:7])
-        if FORWARD_GEMM == "split":
+        if FORWARD_GEMM == "split" and hip.mlp_forward_split_supports(x.shape[1], w3.shape[0]):
             out, h1, h2 = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, True), b2, w3, b3,
                                                       save=need_grad)
         else:
             out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
         if need_grad:
             ctx.layer2 = layer2
-            ctx.save_for_backward(x, h1, h2, w3)
+            ctx.save_for_backward(x, h1, h2, w3, w1, b1)
         return out
 
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
-        x, h1, h2, w3 = ctx.saved_tensors
+        x, h1, h2, w3, w1, b1 = ctx.saved_tensors
         split = BACKWARD_GEMM == "split" and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0])
-        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True, split), w3)
+        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True, split), w3,
+                                   w1, b1, wgrad_split=BACKWARD_GEMM == "split")
         return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None
 
 

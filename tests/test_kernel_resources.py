@@ -42,3 +42,33 @@ def test_compiled_tower_kernels_do_not_use_scratch(tmp_path):
         else:
             assert scratch == 0, (name, scratch)  # run-time widths get one workgroup per CU instead
     assert checked >= 36 + 1
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_compiled_split_kernels_resources(tmp_path):
+    """The bf16-plane tower kernels: every variant that is compiled (and so can be
+    dispatched: rl8_mlp_*_split_supports) must be free of scratch and fit two
+    workgroups per CU."""
+    csrc = os.path.join(ROOT, "rl8_amd", "csrc")
+    asm = tmp_path / "split.s"
+    subprocess.run(
+        [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/include", f"-I{csrc}",
+         "-S", "--cuda-device-only", "-o", str(asm), os.path.join(csrc, "mlp_split_kernels.hip")],
+        check=True, capture_output=True, timeout=900,
+    )
+    text = asm.read_text()
+    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)\n\ts_barrier", text)
+    assert len(waits) >= 14 * 6 and set(waits) == {"0"}  # the hand-written step barriers
+    kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
+    checked = 0
+    for name, body in kernels:
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        if re.search(r"mlp_tower_(forward|backward)_split_kernel|mlp_wgrad_split_kernel", name):
+            # every compiled (= dispatched) variant: no scratch at all -- these kernels read
+            # LDS through inline asm, so a spill between a read and its wait is a hazard,
+            # not just a slowdown -- and two workgroups per CU
+            assert scratch == 0, (name, scratch)
+            assert vgprs <= 256, (name, vgprs)
+            checked += 1
+    assert checked >= 12 + 2 + 5

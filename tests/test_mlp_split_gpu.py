@@ -1,0 +1,195 @@
+"""N1, second generation: the tower kernels whose 256x256 products run as bf16-plane
+MFMAs (exact 3-way split of both fp32 operands, six of nine plane products, fp32
+accumulate: rl8_amd/csrc/mlp_split_kernels.hip). The claim under test is "fp32
+accuracy": every result is compared with an fp64 evaluation of the same op AND
+with torch's own fp32 path / the fp32-MFMA kernels at the same inputs, and must
+be as close to fp64 as those are. Run-to-run bit equality is checked for every
+kernel (fixed summation orders; it is also what exposes a synchronisation bug).
+"""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from rl8_amd import hip  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _params(g, d_in, n_out):
+    return {
+        "w1": torch.randn(256, d_in, device=DEV, generator=g) * 0.5,
+        "b1": torch.randn(256, device=DEV, generator=g) * 0.1,
+        "w2": torch.randn(256, 256, device=DEV, generator=g) / 16,
+        "b2": torch.randn(256, device=DEV, generator=g) * 0.1,
+        "w3": torch.randn(n_out, 256, device=DEV, generator=g) / 16,
+        "b3": torch.randn(n_out, device=DEV, generator=g),
+    }
+
+
+def _tower(x, p):
+    h1 = torch.relu(x @ p["w1"].T + p["b1"])
+    h2 = torch.relu(h1 @ p["w2"].T + p["b2"])
+    return h2 @ p["w3"].T + p["b3"], h1, h2
+
+
+def _rel(got, want):
+    return float((got.double() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+
+
+def test_split_planes_reconstruct_the_weights_exactly():
+    """hi + mid + lo == w bit for bit (truncation splits an fp32 significand 8+8+8)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    w = torch.randn(256, 256, device=DEV, generator=g) * torch.logspace(-12, 6, 256, device=DEV)[:, None]
+    for transposed in (False, True):
+        packed = hip.mlp_pack_w2_split(w, transposed=transposed)
+        words = packed.view(torch.int16).view(16, 8, 3, 64, 8).to(torch.int32)  # [step][col tile][plane][lane][e]
+        planes = (words << 16).view(torch.float32).double().sum(2)              # [step][col tile][lane][e]
+        lane = torch.arange(64, device=DEV)
+        col = (32 * torch.arange(8, device=DEV)[None, :, None, None] + (lane & 31)[None, None, :, None]).expand(16, 8, 64, 8)
+        k = (16 * torch.arange(16, device=DEV)[:, None, None, None] + 8 * (lane >> 5)[None, None, :, None]
+             + torch.arange(8, device=DEV)[None, None, None, :]).expand(16, 8, 64, 8)
+        want = (w[k, col] if transposed else w[col, k]).double()
+        assert torch.equal(planes, want)
+
+
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (127, 1, 1), (128, 1, 2), (129, 2, 3), (1000, 2, 1), (4097, 1, 3),
+                                          (5000, 2, 2), (70_001, 1, 2)])
+def test_forward_split_is_fp32_accurate(m, d_in, n_out):
+    assert hip.mlp_forward_split_supports(d_in, n_out)
+    g = torch.Generator(device=DEV).manual_seed(m + d_in)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 30
+    p = _params(g, d_in, n_out)
+    want, h1w, h2w = _tower(x.double(), {k: v.double() for k, v in p.items()})
+    packed = hip.mlp_pack_w2_split(p["w2"])
+    out, h1, h2 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"], save=True)
+    assert _rel(out, want) < 4e-6 and _rel(h2, h2w) < 2e-6 and _rel(h1, h1w) < 1e-6
+    # the same layer-1 fma chain as the fp32-MFMA kernel: h1 bit for bit
+    out32, h1_32, h2_32 = hip.mlp_tower_forward(x, p["w1"], p["b1"], hip.mlp_pack_w2(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                                save=True)
+    assert torch.equal(h1, h1_32)
+    # as close to fp64 as the fp32-MFMA kernel and as torch's fp32 path
+    ref32, _, h2_t = _tower(x, p)
+    scale = float(want.abs().max()) + 1e-6
+    err = float((out.double() - want).abs().max())
+    assert err <= 3 * float((out32.double() - want).abs().max()) + 1e-6 * scale
+    assert err <= 4 * float((ref32.double() - want).abs().max()) + 1e-6 * scale
+    assert float((h2.double() - h2w).abs().max()) <= 3 * float((h2_32.double() - h2w).abs().max()) + 1e-6 * float(h2w.abs().max())
+    # inference variant and run-to-run bit equality
+    out2, n1, n2 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"])
+    assert n1 is None and n2 is None and torch.equal(out, out2)
+    out3, h1b, h2b = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"], save=True)
+    assert torch.equal(out, out3) and torch.equal(h1, h1b) and torch.equal(h2, h2b)
+
+
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 1, 2), (4097, 1, 1), (40_000, 1, 2), (9000, 1, 1),
+                                          (33_000, 1, 2)])
+def test_backward_split_matches_fp64(m, d_in, n_out):
+    """Against an fp64 evaluation of the backward formulas on the SAVED activations
+    (the ReLU gates are part of the input of a backward pass: an autograd run in
+    fp64 flips the gates of pre-activations within fp32 rounding of zero, which
+    says nothing about these kernels)."""
+    assert hip.mlp_backward_split_supports(d_in, n_out)
+    g = torch.Generator(device=DEV).manual_seed(7 * m + d_in)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 3
+    p = _params(g, d_in, n_out)
+    dout = torch.randn(m, n_out, device=DEV, generator=g) / m
+    out, h1, h2 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_split(p["w2"]), p["b2"], p["w3"],
+                                              p["b3"], save=True)
+    d, a1, a2 = dout.double(), h1.double(), h2.double()
+    dz2 = (d @ p["w3"].double()) * (a2 > 0)
+    dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
+    want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0), "w2": dz2.T @ a1, "b2": dz2.sum(0), "w3": d.T @ a2, "b3": d.sum(0)}
+    w2t = hip.mlp_pack_w2_split(p["w2"], transposed=True)
+    grads = hip.mlp_tower_backward(x, h1, h2, dout, w2t, p["w3"], p["w1"], p["b1"])
+    grads32 = hip.mlp_tower_backward(x, h1, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
+    for k in p:
+        err, err32 = _rel(grads[k], want[k]), _rel(grads32[k], want[k])
+        assert err < 2e-5, (k, err)
+        assert err <= 8 * err32 + 2e-6, (k, err, err32)  # as accurate as the fp32-MFMA kernels
+    again = hip.mlp_tower_backward(x, h1, h2, dout, w2t, p["w3"], p["w1"], p["b1"])
+    for k in p:
+        assert torch.equal(grads[k], again[k]), k  # fixed summation order, no race
+
+
+def test_unsupported_widths_are_refused_not_miscomputed():
+    """Only widths whose kernels compile without scratch are offered
+    (tests/test_kernel_resources.py); anything else must fail loudly."""
+    assert not hip.mlp_backward_split_supports(5, 3) and not hip.mlp_forward_split_supports(5, 3)
+    x = torch.zeros(256, 5, device=DEV)
+    h = torch.zeros(256, 256, device=DEV)
+    w5, b = torch.zeros(256, 5, device=DEV), torch.zeros(256, device=DEV)
+    w3, b3 = torch.zeros(3, 256, device=DEV), torch.zeros(3, device=DEV)
+    w2 = torch.zeros(256, 256, device=DEV)
+    with pytest.raises(ValueError):
+        hip.mlp_tower_backward(x, h, h, torch.zeros(256, 3, device=DEV), hip.mlp_pack_w2_split(w2, transposed=True), w3, w5, b)
+    with pytest.raises(ValueError):
+        hip.mlp_tower_forward_split(x, w5, b, hip.mlp_pack_w2_split(w2), b, w3, b3)
+
+
+def test_wider_towers_mix_fp32_and_split_kernels():
+    """CartPole's tower (5 -> 256 -> 256 -> 3): forward and data-gradient on the
+    fp32-MFMA kernels, weight gradient on the bf16-plane kernel; must match eager."""
+    from rl8_amd.nn import fused_mlp
+
+    torch.manual_seed(6)
+    mlp = torch.nn.Sequential(torch.nn.Linear(5, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
+    trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
+    head = torch.nn.Linear(256, 3).to(DEV)
+    x = torch.randn(3000, 5, device=DEV)
+    wts = torch.linspace(-1, 1, 3, device=DEV)
+    ((fused_mlp.tower_forward(trunk, [head], x) * wts).sum() / 3000).backward()
+    got = {n: p.grad.clone() for n, p in list(trunk.named_parameters()) + list(head.named_parameters())}
+    for p in list(trunk.parameters()) + list(head.parameters()):
+        p.grad = None
+    ((head(trunk(x)) * wts).sum() / 3000).backward()
+    for (n, p) in list(trunk.named_parameters()) + list(head.named_parameters()):
+        assert _rel(got[n], p.grad.double()) < 2e-5, n
+
+
+@pytest.mark.parametrize("m,d_in", [(1, 1), (15, 1), (16, 2), (17, 5), (1000, 3), (16384 + 7, 1), (300_000, 1), (5000, 9)])
+def test_wgrad_split_matches_torch(m, d_in):
+    g = torch.Generator(device=DEV).manual_seed(m)
+    dz2 = torch.randn(m, 256, device=DEV, generator=g)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 3
+    w1 = torch.randn(256, d_in, device=DEV, generator=g) * 0.5
+    b1 = torch.randn(256, device=DEV, generator=g) * 0.1
+    # h1 exactly as the forward kernels form it (fma chain in input order)
+    _, h1, _ = hip.mlp_tower_forward(x, w1, b1, hip.mlp_pack_w2(torch.zeros(256, 256, device=DEV)),
+                                     torch.zeros(256, device=DEV), torch.zeros(1, 256, device=DEV),
+                                     torch.zeros(1, device=DEV), save=True)
+    want = dz2.double().t() @ h1.double()
+    got = hip.mlp_wgrad_split(dz2, x, w1, b1)
+    scale = float(want.abs().max()) + 1e-9
+    err = float((got.double() - want).abs().max()) / scale
+    err32 = float((hip.mlp_wgrad(dz2, h1).double() - want).abs().max()) / scale
+    assert err < 5e-6 and err <= 4 * err32 + 1e-6
+    assert torch.equal(got, hip.mlp_wgrad_split(dz2, x, w1, b1))  # fixed summation order
+
+
+def test_fused_tower_autograd_uses_the_split_kernels_and_matches_eager():
+    from rl8_amd.nn import fused_mlp
+
+    assert fused_mlp.FORWARD_GEMM == "split" and fused_mlp.BACKWARD_GEMM == "split"
+    torch.manual_seed(5)
+    mlp = torch.nn.Sequential(torch.nn.Linear(1, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
+    trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
+    head = torch.nn.Linear(256, 2).to(DEV)
+    x = torch.randn(3000, 1, device=DEV)
+    hip.timer.reset()
+    hip.timer.enabled = True
+    try:
+        out = fused_mlp.tower_forward(trunk, [head], x)
+        loss = (out * torch.linspace(-1, 1, 2, device=DEV)).sum() / 3000
+        loss.backward()
+        launched = set(hip.timer.summary())
+    finally:
+        hip.timer.enabled = False
+    assert {"mlp_tower_forward_save", "mlp_tower_backward", "mlp_wgrad"} <= launched
+    got = {n: p.grad.clone() for n, p in list(trunk.named_parameters()) + list(head.named_parameters())}
+    for p in list(trunk.parameters()) + list(head.parameters()):
+        p.grad = None
+    ((head(trunk(x)) * torch.linspace(-1, 1, 2, device=DEV)).sum() / 3000).backward()
+    for (n, p) in list(trunk.named_parameters()) + list(head.named_parameters()):
+        assert _rel(got[n], p.grad.double()) < 2e-5, n
