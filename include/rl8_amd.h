@@ -327,7 +327,9 @@ int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *
  * (the three dropped ones are below one fp32 ulp of the product) -- 6 MFMAs of
  * 16x the fp32 MFMA rate per 16 k instead of 8.  Inputs, outputs and saved
  * activations are fp32 exactly as above; h1 is bit-identical, out / h2 agree
- * with rl8_mlp_tower_forward_f32 to fp32 rounding.  w2_split
+ * with rl8_mlp_tower_forward_f32 to fp32 rounding.  save_h1 may be NULL while
+ * save_h2 is given: the bf16-plane backward kernels recompute h1 from the
+ * observations and never read it.  w2_split
  * (rl8_mlp_split_packed_bytes() bytes, 16-byte aligned) comes from
  * rl8_mlp_pack_w2_split (transposed as for rl8_mlp_pack_w2_f32). */
 int64_t rl8_mlp_split_packed_bytes(void);

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       if constexpr (SAVE && !(kSplitDiagSkip & 32)) {
         // (a plain guarded store: a loop-carried buffer descriptor -- one per producer
         // tile -- was miscompiled, its size word not following the tile)
-        if (prow + 64 * u < p_rows)
+        if (save_h1 != nullptr && prow + 64 * u < p_rows)  // (h1 is optional: the bf16-plane backward recomputes it)
           *reinterpret_cast<f32x4 *>(save_h1 + p_r0 * kHidden + 16 * ks + (lane_off + 64u * u * kHidden)) = h;
       }
 #pragma unroll
@@ -482,7 +482,7 @@ template <int DIN, int NOUT>
 static int launch_forward_split_save(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
                                      const float *b1, const void *w2s, const float *b2, const float *w3,
                                      const float *b3, int n_out, float *out, float *h1, float *h2) {
-  return h1 ? launch_forward_split<DIN, NOUT, true>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2)
+  return h2 ? launch_forward_split<DIN, NOUT, true>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2)
             : launch_forward_split<DIN, NOUT, false>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
 }
 
@@ -1130,9 +1130,10 @@ RL8_API int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in,
                                             const float *w3, const float *b3, int n_out, float *out,
                                             float *save_h1, float *save_h2, void *stream) {
   if (!x || !w1 || !b1 || !w2_split || !b2 || !w3 || !b3 || !out) return RL8_ENULL;
-  if ((save_h1 == nullptr) != (save_h2 == nullptr)) return RL8_ENULL;
+  if (save_h1 != nullptr && save_h2 == nullptr) return RL8_ENULL;  // h2 alone is allowed: see the header
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
-  if (((uintptr_t)w2_split & 15) != 0 || !aligned16(w1) || !aligned16(b1) || (save_h1 && !aligned16(save_h1)))
+  if (((uintptr_t)w2_split & 15) != 0 || !aligned16(w1) || !aligned16(b1) || (save_h1 && !aligned16(save_h1)) ||
+      (save_h2 && !aligned16(save_h2)))
     return RL8_EALIGN;
   const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
   static const int cap = env_int("RL8_MLP_GRID_CAP");

@@ -866,10 +866,11 @@ def mlp_pack_w2_split(w2: torch.Tensor, *, transposed: bool = False) -> torch.Te
 
 def mlp_tower_forward_split(
     x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2_split: torch.Tensor, b2: torch.Tensor,
-    w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False,
+    w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False, save_h1: bool = True,
 ) -> tuple[torch.Tensor, None | torch.Tensor, None | torch.Tensor]:
     """``mlp_tower_forward`` with the 256x256 product as six bf16-plane MFMAs per
-    16 k (fp32 accuracy, fp32 in / out / accumulate)."""
+    16 k (fp32 accuracy, fp32 in / out / accumulate). ``save_h1=False`` keeps only
+    h2 (the bf16-plane backward kernels recompute h1)."""
     x = _dense(x.detach(), torch.float32, "x")
     m, d_in = x.shape
     n_out = w3.shape[0]
@@ -881,7 +882,7 @@ def mlp_tower_forward_split(
     if w2_split.dtype != torch.uint8 or w2_split.numel() != int(load().rl8_mlp_split_packed_bytes()):
         raise ValueError("w2_split must come from mlp_pack_w2_split")
     out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
-    h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
+    h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save and save_h1 else None
     h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
     with _timed("mlp_tower_forward_save" if save else "mlp_tower_forward", m):
         _check(
@@ -895,7 +896,7 @@ def mlp_tower_forward_split(
 
 
 def mlp_tower_backward(
-    x: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor, dout: torch.Tensor,
+    x: torch.Tensor, h1: None | torch.Tensor, h2: torch.Tensor, dout: torch.Tensor,
     w2t_packed: torch.Tensor, w3: torch.Tensor,
     w1: None | torch.Tensor = None, b1: None | torch.Tensor = None, *, wgrad_split: bool = False,
 ) -> dict[str, torch.Tensor]:
@@ -910,8 +911,13 @@ def mlp_tower_backward(
     data-gradient half runs on the fp32 kernel."""
     m, d_in = x.shape
     n_out = w3.shape[0]
+    split = w2t_packed.dtype == torch.uint8
+    if h1 is None and not split:
+        raise ValueError("h1 may be omitted only on the bf16-plane path")
     for name, t, numel in (("x", x, m * d_in), ("h1", h1, m * MLP_HIDDEN), ("h2", h2, m * MLP_HIDDEN),
                            ("dout", dout, m * n_out)):
+        if t is None:
+            continue
         _dense(t, torch.float32, name)
         if t.numel() != numel:
             raise ValueError(f"{name} has the wrong number of elements")
@@ -921,7 +927,6 @@ def mlp_tower_backward(
     partials = torch.empty(max_rows, width, dtype=torch.float32, device=x.device)
     dz2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device)
     rows = C.c_int(0)
-    split = w2t_packed.dtype == torch.uint8
     with _timed("mlp_tower_backward", m):
         if split:
             if w1 is None or b1 is None:

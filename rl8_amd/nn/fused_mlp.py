@@ -64,8 +64,10 @@ class _FusedTower(torch.autograd.Function):
         # activations are kept only when a backward can follow.
         need_grad = grad_mode and any(ctx.needs_input_grad[1:7])
         if FORWARD_GEMM == "split" and hip.mlp_forward_split_supports(x.shape[1], w3.shape[0]):
+            # h1 is stored only if a backward kernel will read it (the bf16-plane ones recompute it)
+            keep_h1 = not (BACKWARD_GEMM == "split" and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0]))
             out, h1, h2 = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, True), b2, w3, b3,
-                                                      save=need_grad)
+                                                      save=need_grad, save_h1=keep_h1)
         else:
             out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
         if need_grad:

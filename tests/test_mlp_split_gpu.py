@@ -81,6 +81,10 @@ def test_forward_split_is_fp32_accurate(m, d_in, n_out):
     assert n1 is None and n2 is None and torch.equal(out, out2)
     out3, h1b, h2b = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"], save=True)
     assert torch.equal(out, out3) and torch.equal(h1, h1b) and torch.equal(h2, h2b)
+    # h1 is optional (the bf16-plane backward recomputes it)
+    out4, h1c, h2c = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"], save=True,
+                                                 save_h1=False)
+    assert h1c is None and torch.equal(out, out4) and torch.equal(h2, h2c)
 
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 1, 2), (4097, 1, 1), (40_000, 1, 2), (9000, 1, 1),
@@ -108,9 +112,11 @@ def test_backward_split_matches_fp64(m, d_in, n_out):
         err, err32 = _rel(grads[k], want[k]), _rel(grads32[k], want[k])
         assert err < 2e-5, (k, err)
         assert err <= 8 * err32 + 2e-6, (k, err, err32)  # as accurate as the fp32-MFMA kernels
-    again = hip.mlp_tower_backward(x, h1, h2, dout, w2t, p["w3"], p["w1"], p["b1"])
+    again = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"])  # h1 is not read
     for k in p:
         assert torch.equal(grads[k], again[k]), k  # fixed summation order, no race
+    with pytest.raises(ValueError):
+        hip.mlp_tower_backward(x, None, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
 
 
 def test_unsupported_widths_are_refused_not_miscomputed():
