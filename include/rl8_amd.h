@@ -362,7 +362,8 @@ int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
  * h1 > 0 <=> b1 + x . w1 > 0 with the forward pass's own fma chain (1 KiB per row
  * less HBM traffic).  Two launches: the matrix kernel (dZ2, dW1, db1) and an
  * HBM-streaming kernel for the head gradients (db2, dW3, db3), which are column
- * sums over rows. */
+ * sums over rows.  dz2_out = NULL selects the first half of the fused backward
+ * (see rl8_mlp_wgrad_fused_split_f32). */
 int rl8_mlp_backward_split_supports(int d_in, int n_out); /* d_in 1 x n_out 1, 2; else RL8_ESIZE */
 int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, const float *b1, const float *h2,
                                      const float *dout, int64_t m, int d_in, const void *w2t_split,
@@ -374,6 +375,16 @@ int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, const floa
 int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const float *w1, const float *b1,
                             int64_t m, int d_in, float *workspace, float *dw2_out, int accumulate,
                             void *stream);
+
+/* The fused backward: rl8_mlp_tower_backward_split_f32 with dz2_out = NULL (no dZ2
+ * store, no head-gradient launch) followed by this call, whose weight-gradient
+ * kernel re-forms dZ2 = (dOut x W3) * (h2 > 0) and h1 itself (thread = column) and
+ * accumulates the head gradients on the way.  dw2_out [256][256] receives dW2; the
+ * head segments [db2 | dW3 | db3] of `partials` (the same buffer and row count the
+ * first call reported) are filled.  Widths: rl8_mlp_backward_split_supports. */
+int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, const float *x, const float *w1,
+                                  const float *b1, const float *w3, int64_t m, int d_in, int n_out,
+                                  float *workspace, float *dw2_out, float *partials, void *stream);
 
 /* Weight gradient of the 256x256 layer: dw2_out [256][256] (+)= dZ2^T h1 over M
  * rows (fp32 MFMA; per-workgroup partial slabs in `workspace`, summed in a fixed

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ h2, const float *__restrict__ dout, int64_t m, int d_in_rt,
     const void *__restrict__ w2ts, const float *__restrict__ w3, int n_out_rt, float *__restrict__ dz2_out,
-    float *__restrict__ partials, int partial_stride) {
+    float *__restrict__ partials, int partial_stride, int head_rows) {
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
         dz[e] = hval[e] > 0.0f ? g : 0.0f;
       }
       if constexpr (!(kSplitDiagSkip & 128)) {
-        if (prow + 64 * u < p_rows)
+        if (dz2_out != nullptr && prow + 64 * u < p_rows)  // (optional: the fused weight-gradient kernel re-forms dZ2)
           *reinterpret_cast<f32x4 *>(dz2_out + p_tile * (kSplitRows * kHidden) + 16 * ks + (lane_off + 64u * u * kHidden)) = dz;
       }
 #pragma unroll
@@ -812,6 +812,10 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
     for (int i = 0; i < kIn; ++i)
       if (DIN > 0 || i < d_in) row[t * d_in + i] = lds_read_b32(a + 4 + 4 * i);
+    // head_rows >= 0: the head-gradient segments of the first head_rows rows belong
+    // to the fused weight-gradient kernel; rows beyond them are zero.
+    if (head_rows >= 0 && (int)blockIdx.x >= head_rows)
+      for (int idx = kHidden * d_in + kHidden + t; idx < partial_stride; idx += kBlock) row[idx] = 0.0f;
   }
 }
 
@@ -875,7 +879,8 @@ __global__ __launch_bounds__(kBlock) void mlp_head_grads_kernel(
 template <int DIN, int NOUT>
 static int launch_backward_split(int grid, hipStream_t s, const float *x, const float *w1, const float *b1,
                                  const float *h2, const float *dout, int64_t m, int d_in, const void *w2ts,
-                                 const float *w3, int n_out, float *dz2_out, float *partials, int stride) {
+                                 const float *w3, int n_out, float *dz2_out, float *partials, int stride,
+                                 int head_rows = -1) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_split_kernel<DIN, NOUT>),
@@ -885,9 +890,9 @@ static int launch_backward_split(int grid, hipStream_t s, const float *x, const 
   }
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   mlp_tower_backward_split_kernel<DIN, NOUT><<<grid, kBlock, 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4, s>>>(
-      x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+      x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows);
   const int status = launch_status();
-  if (status != 0) return status;
+  if (status != 0 || head_rows >= 0) return status;  // (fused: the weight-gradient kernel forms the head gradients)
   mlp_head_grads_kernel<NOUT><<<grid, kBlock, 0, s>>>(h2, dout, m, w3, n_out, d_in, partials, stride);
   return launch_status();
 }
@@ -896,10 +901,10 @@ template <int DIN>
 static int dispatch_backward_split_nout(int n_out, int grid, hipStream_t s, const float *x, const float *w1,
                                         const float *b1, const float *h2, const float *dout, int64_t m, int d_in,
                                         const void *w2ts, const float *w3, float *dz2_out, float *partials,
-                                        int stride) {
+                                        int stride, int head_rows) {
   switch (n_out) {
-    case 1: return launch_backward_split<DIN, 1>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
-    case 2: return launch_backward_split<DIN, 2>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride);
+    case 1: return launch_backward_split<DIN, 1>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows);
+    case 2: return launch_backward_split<DIN, 2>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows);
     default: return RL8_ESIZE;
   }
 }
@@ -926,11 +931,26 @@ constexpr int kWsOperandBytes = 3 * 2 * kHidden * 16;    // [plane][sample half]
 constexpr int kWsPlane = 2 * kHidden * 16;
 constexpr int kWsStageBytes = 2 * kWsOperandBytes;       // dZ2^T | h1
 
-template <int DIN>
+// FUSED (= n_out) > 0: the first operand is not read but formed on the spot,
+//   dZ2 = (dOut x W3) * (h2 > 0)  from h2 (`dz2` then points at h2), dOut and W3 --
+// thread = column, so W3's column is per-thread constants and dOut comes through
+// the scalar cache -- and, since h2, dOut and dZ2 are all in hand column-wise, the
+// head gradients db2 = sum dZ2, dW3 = dOut^T h2, db3 = sum dOut are accumulated
+// too (per thread; one partial row per workgroup).  The data-gradient kernel then
+// neither stores dZ2 nor needs a separate head-gradient pass.
+struct WgradFusedArgs {
+  const float *dout, *w3;
+  float *partials;     // rows of `partial_stride` floats: [dW1 | db1 | db2 | dW3 | db3]
+  int partial_stride;
+  int other_rows;      // rows whose [dW1 | db1] segment the data-gradient kernel fills
+};
+
+template <int DIN, int FUSED = 0>
 __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     const float *__restrict__ dz2, const float *__restrict__ x, const float *__restrict__ w1,
-    const float *__restrict__ b1, int64_t m, int d_in_rt, float *__restrict__ slabs) {
+    const float *__restrict__ b1, int64_t m, int d_in_rt, float *__restrict__ slabs, WgradFusedArgs fused) {
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
+  constexpr int kOut = FUSED > 0 ? FUSED : 1;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = lds_offset(smem);
@@ -948,6 +968,14 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 #pragma unroll
   for (int c = 0; c < kIn; ++c) w1r[c] = (DIN > 0 || c < d_in) ? w1[col * d_in + c] : 0.0f;
   const float b1r = b1[col];
+  [[maybe_unused]] float w3r[kOut], db2a = 0.0f, dw3a[kOut], db3a[kOut];
+  if constexpr (FUSED > 0) {
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) {
+      w3r[q] = fused.w3[q * kHidden + col];
+      dw3a[q] = db3a[q] = 0.0f;
+    }
+  }
 
   const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
   const int64_t stride = gridDim.x;
@@ -974,8 +1002,29 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     }
   };
   auto produce = [&](const float (&dzv)[8], int64_t n, u32x4 (&pa)[3], u32x4 (&pb)[3]) {
-    split8(dzv, pa);
     const int64_t chunk = blockIdx.x + n * stride;
+    if constexpr (FUSED > 0) {
+      float dz[8];  // dzv holds h2
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int64_t row = chunk * kWsChunk + 8 * kh + e;
+        const bool valid = row < m;
+        row = valid ? row : m - 1;  // (its h2 reads as zero)
+        float g = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kOut; ++q) {
+          const float d = fused.dout[row * kOut + q];
+          g = __builtin_fmaf(d, w3r[q], g);
+          dw3a[q] = __builtin_fmaf(d, dzv[e], dw3a[q]);
+          db3a[q] += valid ? d : 0.0f;
+        }
+        dz[e] = dzv[e] > 0.0f ? g : 0.0f;
+        db2a += dz[e];
+      }
+      split8(dz, pa);
+    } else {
+      split8(dzv, pa);
+    }
     float h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1081,6 +1130,37 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
         const int i = 128 * wi + 32 * t + l32;
         slab[j * kHidden + i] = acc[ja][t][r];
       }
+
+  if constexpr (FUSED > 0) {
+    // Head gradients: fold the two sample halves (kh) of a column through LDS in a
+    // fixed order and write this workgroup's partial row; zero the other kernel's
+    // segment where it has no row of its own.
+    float *red = reinterpret_cast<float *>(smem);  // [256][1 + kOut] + [kOut]
+    __syncthreads();
+    if (kh == 1) {
+      red[col * (1 + kOut)] = db2a;
+#pragma unroll
+      for (int q = 0; q < kOut; ++q) red[col * (1 + kOut) + 1 + q] = dw3a[q];
+      if (col == 0) {
+#pragma unroll
+        for (int q = 0; q < kOut; ++q) red[kHidden * (1 + kOut) + q] = db3a[q];
+      }
+    }
+    __syncthreads();
+    float *row = fused.partials + (int64_t)blockIdx.x * fused.partial_stride;
+    const int off_db2 = kHidden * d_in + kHidden, off_dw3 = off_db2 + kHidden, off_db3 = off_dw3 + kOut * kHidden;
+    if (kh == 0) {
+      row[off_db2 + col] = db2a + red[col * (1 + kOut)];
+#pragma unroll
+      for (int q = 0; q < kOut; ++q) row[off_dw3 + q * kHidden + col] = dw3a[q] + red[col * (1 + kOut) + 1 + q];
+      if (col == 0) {
+#pragma unroll
+        for (int q = 0; q < kOut; ++q) row[off_db3 + q] = db3a[q] + red[kHidden * (1 + kOut) + q];
+      }
+    }
+    if ((int)blockIdx.x >= fused.other_rows)
+      for (int idx = tid; idx < kHidden * d_in + kHidden; idx += kWsThreads) row[idx] = 0.0f;
+  }
 }
 
 // out[idx] (+)= sum over slabs, in slab order.
@@ -1107,7 +1187,21 @@ static int launch_wgrad_split(int grid, hipStream_t s, const float *dz2, const f
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_wgrad_split_kernel<DIN><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(dz2, x, w1, b1, m, d_in, slabs);
+  mlp_wgrad_split_kernel<DIN><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(dz2, x, w1, b1, m, d_in, slabs, WgradFusedArgs{});
+  return launch_status();
+}
+
+template <int DIN, int NOUT>
+static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
+                              const float *b1, int64_t m, int d_in, float *slabs, WgradFusedArgs fused) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, NOUT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  mlp_wgrad_split_kernel<DIN, NOUT><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(h2, x, w1, b1, m, d_in, slabs, fused);
   return launch_status();
 }
 
@@ -1158,24 +1252,27 @@ RL8_API int rl8_mlp_forward_split_supports(int d_in, int n_out) {
   return (d_in == 1 || d_in == 2) && n_out >= 1 && n_out <= 3;
 }
 
+static void fused_backward_grids(int64_t m, int *g1, int *g2);
+
 RL8_API int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, const float *b1,
                                              const float *h2, const float *dout, int64_t m, int d_in,
                                              const void *w2t_split, const float *w3, int n_out,
                                              float *dz2_out, float *partials, int *partial_rows_out,
                                              void *stream) {
-  if (!x || !w1 || !b1 || !h2 || !dout || !w2t_split || !w3 || !dz2_out || !partials || !partial_rows_out)
+  if (!x || !w1 || !b1 || !h2 || !dout || !w2t_split || !w3 || !partials || !partial_rows_out)
     return RL8_ENULL;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
   if (((uintptr_t)w2t_split & 15) != 0 || !aligned16(h2) || !aligned16(dz2_out) || !aligned16(w3)) return RL8_EALIGN;
-  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
-  static const int cap = env_int("RL8_MLP_GRID_CAP");
-  const int max_grid = cap > 0 ? cap : 2 * kCUs;
-  const int grid = (int)(tiles < max_grid ? tiles : max_grid);
-  *partial_rows_out = grid;
+  int grid, g2;
+  fused_backward_grids(m, &grid, &g2);
+  // dz2_out == NULL: first half of the fused backward -- no dZ2 store, no head-gradient
+  // launch; rl8_mlp_wgrad_fused_split_f32 fills the head segments of rows < g2.
+  const int head_rows = dz2_out ? -1 : g2;
+  *partial_rows_out = dz2_out ? grid : (grid > g2 ? grid : g2);
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
   switch (d_in) {
-    case 1: return dispatch_backward_split_nout<1>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride);
+    case 1: return dispatch_backward_split_nout<1>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows);
     default: return RL8_ESIZE;  // rl8_mlp_backward_split_supports(): other widths use rl8_mlp_tower_backward_f32
   }
 }
@@ -1204,5 +1301,34 @@ RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const floa
   }
   if (status != 0) return status;
   mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / 4 / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, accumulate);
+  return launch_status();
+}
+
+// Grids of the two halves of the fused backward (both derive them from m alone,
+// so that each can zero the partial-row segments the other does not cover).
+static void fused_backward_grids(int64_t m, int *g1, int *g2) {
+  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
+  const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
+  static const int cap = env_int("RL8_MLP_GRID_CAP");
+  const int max_grid = cap > 0 ? cap : 2 * kCUs;
+  *g1 = (int)(tiles < max_grid ? tiles : max_grid);
+  *g2 = (int)(chunks < kCUs ? chunks : kCUs);
+}
+
+RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, const float *x, const float *w1,
+                                          const float *b1, const float *w3, int64_t m, int d_in, int n_out,
+                                          float *workspace, float *dw2_out, float *partials, void *stream) {
+  if (!h2 || !dout || !x || !w1 || !b1 || !w3 || !workspace || !dw2_out || !partials) return RL8_ENULL;
+  if (m <= 0 || !rl8_mlp_backward_split_supports(d_in, n_out)) return RL8_ESIZE;
+  if (!aligned16(h2) || !aligned16(workspace) || !aligned16(dw2_out)) return RL8_EALIGN;
+  int g1, g2;
+  fused_backward_grids(m, &g1, &g2);
+  const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
+  hipStream_t s = (hipStream_t)stream;
+  const WgradFusedArgs fused{dout, w3, partials, stride, g1};
+  const int status = n_out == 1 ? launch_wgrad_fused<1, 1>(g2, s, h2, x, w1, b1, m, d_in, workspace, fused)
+                                : launch_wgrad_fused<1, 2>(g2, s, h2, x, w1, b1, m, d_in, workspace, fused);
+  if (status != 0) return status;
+  mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / 4 / kBlock, kBlock, 0, s>>>(workspace, g2, dw2_out, 0);
   return launch_status();
 }

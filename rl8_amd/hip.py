@@ -143,6 +143,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_forward_split_supports": [_i32, _i32],
     "rl8_mlp_tower_backward_split_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_wgrad_split_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
+    "rl8_mlp_wgrad_fused_split_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_wgrad_workspace_bytes": [],
     "rl8_mlp_wgrad_f32": [_vp, _vp, _i64, _vp, _vp, _i32, _vp],
 }
@@ -925,20 +926,32 @@ def mlp_tower_backward(
     width = int(lib.rl8_mlp_backward_partial_floats(d_in, n_out))
     max_rows = int(lib.rl8_mlp_backward_max_rows())
     partials = torch.empty(max_rows, width, dtype=torch.float32, device=x.device)
-    dz2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device)
     rows = C.c_int(0)
-    with _timed("mlp_tower_backward", m):
-        if split:
-            if w1 is None or b1 is None:
-                raise ValueError("the bf16-plane backward needs w1 and b1")
+    dw2 = None
+    if split:
+        # fused: the data-gradient kernel stores no dZ2; the weight-gradient kernel
+        # re-forms it (and h1) and accumulates the head gradients
+        if w1 is None or b1 is None:
+            raise ValueError("the bf16-plane backward needs w1 and b1")
+        w1p, b1p = _ptr(_dense(w1.detach(), torch.float32, "w1")), _ptr(_dense(b1.detach(), torch.float32, "b1"))
+        with _timed("mlp_tower_backward", m):
             _check(
                 lib.rl8_mlp_tower_backward_split_f32(
-                    _ptr(x), _ptr(_dense(w1.detach(), torch.float32, "w1")), _ptr(_dense(b1.detach(), torch.float32, "b1")),
-                    _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
-                    _ptr(dz2), _ptr(partials), C.byref(rows), _stream()),
+                    _ptr(x), w1p, b1p, _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
+                    None, _ptr(partials), C.byref(rows), _stream()),
                 "rl8_mlp_tower_backward_split_f32",
             )
-        else:
+        dw2 = torch.empty(MLP_HIDDEN, MLP_HIDDEN, dtype=torch.float32, device=x.device)
+        with _timed("mlp_wgrad", m):
+            _check(
+                lib.rl8_mlp_wgrad_fused_split_f32(
+                    _ptr(h2), _ptr(dout), _ptr(x), w1p, b1p, _ptr(w3.detach()), m, d_in, n_out,
+                    _ptr(_wgrad_workspace(x.device)), _ptr(dw2), _ptr(partials), _stream()),
+                "rl8_mlp_wgrad_fused_split_f32",
+            )
+    else:
+        dz2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device)
+        with _timed("mlp_tower_backward", m):
             _check(
                 lib.rl8_mlp_tower_backward_f32(
                     _ptr(x), _ptr(h1), _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
@@ -953,7 +966,7 @@ def mlp_tower_backward(
         "b2": small[o1 + MLP_HIDDEN : o1 + 2 * MLP_HIDDEN],
         "w3": small[o1 + 2 * MLP_HIDDEN : o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN].view(n_out, MLP_HIDDEN),
         "b3": small[o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN :],
-        "w2": mlp_wgrad_split(dz2, x, w1, b1) if (split or wgrad_split) else mlp_wgrad(dz2, h1),
+        "w2": dw2 if split else (mlp_wgrad_split(dz2, x, w1, b1) if wgrad_split else mlp_wgrad(dz2, h1)),
     }
     return grads
 
