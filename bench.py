@@ -40,6 +40,8 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290
 HBM_COPY_CEILING_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (= fp32 vector) peak, MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (spec), MI355X_MICROARCH.md; 1750 sustained on changing operands
+SPLIT_PRODUCTS = 6              # bf16 plane products per fp32 product in the bf16-plane kernels
 
 # MFMA-bound kernels: algorithmic FLOP per unit (row) for the default towers,
 # 2 * (256*d_in + 256*256 + 256*n_out); the backward kernel does the data-gradient
@@ -200,6 +202,26 @@ def main() -> None:
 
     kernels = {}
     obs_dim = int(algo.env.observation_spec.shape[0])
+    model = algo.policy.model
+    if hasattr(model, "feature_model"):      # default discrete model: logits tower + value tower
+        tower_heads = [model.feature_model[2].out_features, 1]
+    elif hasattr(model, "action_mean"):      # default continuous model: (mean | log_std) tower + value tower
+        tower_heads = [model.action_mean.out_features + model.action_log_std.out_features, 1]
+    else:
+        tower_heads = []
+    from rl8_amd.nn import fused_mlp
+
+    def tower_gemm(name: str) -> str:
+        """Which matrix pipe this tower kernel ran its 256x256 product on."""
+        if not tower_heads:
+            return "f32"
+        widths = [(obs_dim, n) for n in tower_heads]
+        if name in ("mlp_tower_forward", "mlp_tower_forward_save"):
+            ok = fused_mlp.FORWARD_GEMM == "split" and all(hip.mlp_forward_split_supports(d, n) for d, n in widths)
+        else:
+            ok = fused_mlp.BACKWARD_GEMM == "split" and all(hip.mlp_backward_split_supports(d, n) for d, n in widths)
+        return "bf16x3-split" if ok else "f32"
+
     for name, rec in hip.timer.summary().items():
         if name.startswith("mlp_"):
             # n_out differs per tower (policy 2-3, value 1); price both at the mean.
@@ -207,16 +229,27 @@ def main() -> None:
             per_row = 2.0 * 256 * 256 if name == "mlp_wgrad" else tower_flops_per_row(obs_dim, 1.5)
             flops_per_launch = per_row * rec["units_per_launch"]
             tflops = flops_per_launch / (rec["avg_ms"] * 1e-3) / 1e12
+            gemm = tower_gemm(name)
             kernels[name] = {
                 "bound": "mfma",
+                "gemm": gemm,
                 "launches": rec["launches"],
                 "avg_ms": round(rec["avg_ms"], 5),
                 "total_ms": round(rec["total_ms"], 3),
                 "algorithmic_flop_per_launch": flops_per_launch,
-                "achieved_TFLOPs": round(tflops, 2),
+                "achieved_TFLOPs": round(tflops, 2),            # fp32-equivalent: algorithmic flops / time
                 "frac_of_f32_mfma_peak": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
                 "pmc_traffic_bytes_per_launch": pmc_traffic(name, rec["units_per_launch"]),
             }
+            if gemm != "f32":
+                # every fp32 multiply-add of the 256x256 product is SPLIT_PRODUCTS bf16 ones on the matrix pipe
+                executed = SPLIT_PRODUCTS * 2.0 * 256 * 256 * rec["units_per_launch"]
+                bf16_tflops = executed / (rec["avg_ms"] * 1e-3) / 1e12
+                kernels[name].update({
+                    "executed_bf16_flop_per_launch": executed,
+                    "executed_bf16_TFLOPs": round(bf16_tflops, 1),
+                    "frac_of_bf16_mfma_peak": round(bf16_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                })
             continue
         bytes_per_launch = ALGORITHMIC_BYTES.get(name, 0.0) * rec["units_per_launch"]
         gbs = bytes_per_launch / (rec["avg_ms"] * 1e-3) / 1e9 if rec["avg_ms"] > 0 else 0.0
@@ -238,7 +271,28 @@ def main() -> None:
         # The kernel the timed region spends most of its time in.
         dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
         top = kernels[dominant]
-        if top["bound"] == "mfma":
+        if top["bound"] == "mfma" and top["gemm"] != "f32":
+            # bf16-plane kernel: priced in the bf16 multiply-adds the matrix pipe executes
+            # (6 per fp32 multiply-add of the algorithm) against the dense bf16 peak
+            roofline = {
+                "kernel": f"rl8_{dominant}_split_f32",
+                "bound": "mfma",
+                "achieved": top["executed_bf16_TFLOPs"],
+                "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": top["frac_of_bf16_mfma_peak"],
+                "flop_per_launch": top["executed_bf16_flop_per_launch"],
+                "flop_definition": "6 bf16 plane products x 2*256*256 per row (fp32 operands split exactly into"
+                                   " 3 bf16 planes, fp32 accumulate)",
+                "f32_equivalent_TFLOPs": top["achieved_TFLOPs"],
+                "f32_mfma_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+                "algorithmic_flop_per_launch": top["algorithmic_flop_per_launch"],
+                "avg_launch_ms": top["avg_ms"],
+                "launches": top["launches"],
+                "share_of_step_ms": round(top["total_ms"] / args.steps, 2),
+                "traffic": top["pmc_traffic_bytes_per_launch"],
+            }
+        elif top["bound"] == "mfma":
             roofline = {
                 "kernel": f"rl8_{dominant}_f32",
                 "bound": "mfma",
@@ -271,6 +325,7 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "gemm": sorted({k["gemm"] for k in kernels.values() if k["bound"] == "mfma"}),
             "data": "synthetic (Philox-reset DiscreteDummyEnv states, random-init default MLP)",
             "config": {
                 "workload": f"{env_cls.__name__}{variant} collect()+step(), num_envs={args.num_envs} per GPU"
