@@ -329,7 +329,10 @@ int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *
  * activations are fp32 exactly as above; h1 is bit-identical, out / h2 agree
  * with rl8_mlp_tower_forward_f32 to fp32 rounding.  save_h1 may be NULL while
  * save_h2 is given: the bf16-plane backward kernels recompute h1 from the
- * observations and never read it.  w2_split
+ * observations and never read it.  save_gate2 (optional, with save_h2) [M][8]
+ * words receives the ReLU gate of layer 2, bit j of row s = (h2[s][j] > 0): the
+ * data-gradient kernel needs only that bit of h2 (32 B per row instead of 1 KiB).
+ * w2_split
  * (rl8_mlp_split_packed_bytes() bytes, 16-byte aligned) comes from
  * rl8_mlp_pack_w2_split (transposed as for rl8_mlp_pack_w2_f32). */
 int64_t rl8_mlp_split_packed_bytes(void);
@@ -338,7 +341,7 @@ int rl8_mlp_pack_w2_split(const float *w2 /*[256][256]*/, int transposed, void *
 int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const float *w1,
                                     const float *b1, const void *w2_split, const float *b2,
                                     const float *w3, const float *b3, int n_out, float *out,
-                                    float *save_h1, float *save_h2, void *stream);
+                                    float *save_h1, float *save_h2, uint32_t *save_gate2, void *stream);
 
 /* Backward of one tower ("dgrad" half): given dOut [M][n_out] and the saved
  * activations h1 / h2, writes dZ2 [M][256] (input of rl8_mlp_wgrad_f32, which
@@ -363,12 +366,15 @@ int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
  * less HBM traffic).  Two launches: the matrix kernel (dZ2, dW1, db1) and an
  * HBM-streaming kernel for the head gradients (db2, dW3, db3), which are column
  * sums over rows.  dz2_out = NULL selects the first half of the fused backward
- * (see rl8_mlp_wgrad_fused_split_f32). */
+ * (see rl8_mlp_wgrad_fused_split_f32).  gate2 (the forward's save_gate2) replaces the
+ * h2 reads of the matrix kernel by 32 B of gate bits per row; h2 may then be NULL
+ * in the fused mode. */
 int rl8_mlp_backward_split_supports(int d_in, int n_out); /* d_in 1 x n_out 1, 2; else RL8_ESIZE */
 int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, const float *b1, const float *h2,
                                      const float *dout, int64_t m, int d_in, const void *w2t_split,
                                      const float *w3, int n_out, float *dz2_out, float *partials,
-                                     int *partial_rows_out /*host*/, void *stream);
+                                     int *partial_rows_out /*host*/, const uint32_t *gate2 /*or NULL*/,
+                                     void *stream);
 
 /* dW2 (+)= dZ2^T h1 on bf16 planes, with h1 = relu(x W1^T + b1) recomputed from the
  * observations instead of read back (workspace: rl8_mlp_wgrad_workspace_bytes()). */

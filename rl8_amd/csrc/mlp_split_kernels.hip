@@ -129,6 +129,16 @@ __device__ __forceinline__ int lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// vgpr[lane LANE] = scalar value (this toolchain has no builtin for v_writelane_b32).
+template <int LANE>
+__device__ __forceinline__ int write_lane(int vgpr, uint32_t value) {
+  // (s_nop: the scalar usually comes straight from a VALU compare, and the hazard
+  // recognizer does not look inside inline asm -- gfx940-family VALU-writes-SGPR ->
+  // VALU-reads-it wait states)
+  asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(vgpr) : "s"(value), "n"(LANE));
+  return vgpr;
+}
+
 // The operand registers of one k-step.  `m` first holds the mid planes and is
 // re-loaded with the lo planes once the mid terms have been issued.
 struct SplitFrags {
@@ -142,6 +152,18 @@ __device__ __forceinline__ void wait_lds_all(SplitFrags &f) {
 
 template <bool FIRST>
 __device__ __forceinline__ void split_mma(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
+  if constexpr ((kSplitDiagSkip & 2048) != 0) {  // tuning builds: no matrix work (one MFMA per group keeps the data flow)
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]),
+                                                        FIRST ? f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[0][0], 0, 0, 0);
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (mt + nt) acc[mt][nt] = acc[0][0];
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -185,7 +207,8 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     const float *__restrict__ x, int64_t m, int d_in_rt, const float *__restrict__ w1,
     const float *__restrict__ b1, const void *__restrict__ w2s, const float *__restrict__ b2,
     const float *__restrict__ w3, const float *__restrict__ b3, int n_out_rt,
-    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2) {
+    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2,
+    uint32_t *__restrict__ save_gate2) {
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
@@ -418,6 +441,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+      [[maybe_unused]] int gate_words[2] = {0, 0};
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int j = 128 * wc + 32 * nt + l32;
@@ -432,6 +456,44 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
           for (int r = 0; r < 16; ++r) {
             const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
             buffer_store_f32(acc[mt][nt][r], h2rsrc, (4 * hh * kHidden + j) * 4, sr * (kHidden * 4));
+          }
+        }
+        if constexpr (SAVE) {
+          // ReLU gate of h2, one bit per element, [row][8 words]: a compare of an
+          // accumulator register IS two finished words (32 columns of the hh = 0
+          // row, 32 of the hh = 1 row); they are parked in lane (row mod 32) + 32
+          // (nt odd) of collector nt / 2 and leave as four stores per wave and tile.
+          if (save_gate2 != nullptr) {
+            auto park = [&](auto r_tag) {
+              constexpr int r = decltype(r_tag)::value;
+              constexpr int rl = (r & 3) + 8 * (r >> 2);
+              const unsigned long long bits = __builtin_amdgcn_ballot_w64(acc[mt][nt][r] > 0.0f);
+              if (nt & 1) {
+                gate_words[nt >> 1] = write_lane<rl + 32>(gate_words[nt >> 1], (uint32_t)bits);
+                gate_words[nt >> 1] = write_lane<rl + 36>(gate_words[nt >> 1], (uint32_t)(bits >> 32));
+              } else {
+                gate_words[nt >> 1] = write_lane<rl>(gate_words[nt >> 1], (uint32_t)bits);
+                gate_words[nt >> 1] = write_lane<rl + 4>(gate_words[nt >> 1], (uint32_t)(bits >> 32));
+              }
+            };
+            park(std::integral_constant<int, 0>{}), park(std::integral_constant<int, 1>{});
+            park(std::integral_constant<int, 2>{}), park(std::integral_constant<int, 3>{});
+            park(std::integral_constant<int, 4>{}), park(std::integral_constant<int, 5>{});
+            park(std::integral_constant<int, 6>{}), park(std::integral_constant<int, 7>{});
+            park(std::integral_constant<int, 8>{}), park(std::integral_constant<int, 9>{});
+            park(std::integral_constant<int, 10>{}), park(std::integral_constant<int, 11>{});
+            park(std::integral_constant<int, 12>{}), park(std::integral_constant<int, 13>{});
+            park(std::integral_constant<int, 14>{}), park(std::integral_constant<int, 15>{});
+          }
+        }
+      }
+      if constexpr (SAVE) {
+        if (save_gate2 != nullptr) {
+          const int row = 64 * wr + 32 * mt + l32;
+          if (row < rows) {
+            uint32_t *dst = save_gate2 + (r0 + row) * 8 + 4 * wc + hh;
+            dst[0] = (uint32_t)gate_words[0];
+            dst[2] = (uint32_t)gate_words[1];
           }
         }
       }
@@ -464,7 +526,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 template <int DIN, int NOUT, bool SAVE>
 static int launch_forward_split(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
                                 const float *b1, const void *w2s, const float *b2, const float *w3,
-                                const float *b3, int n_out, float *out, float *h1, float *h2) {
+                                const float *b3, int n_out, float *out, float *h1, float *h2, uint32_t *gate) {
   constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
   static bool attr_set = false;
   if (!attr_set) {
@@ -474,26 +536,27 @@ static int launch_forward_split(int grid, hipStream_t s, const float *x, int64_t
     attr_set = true;
   }
   mlp_tower_forward_split_kernel<DIN, NOUT, SAVE><<<grid, kBlock, split_forward_lds_bytes(kOut), s>>>(
-      x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+      x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
   return launch_status();
 }
 
 template <int DIN, int NOUT>
 static int launch_forward_split_save(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
                                      const float *b1, const void *w2s, const float *b2, const float *w3,
-                                     const float *b3, int n_out, float *out, float *h1, float *h2) {
-  return h2 ? launch_forward_split<DIN, NOUT, true>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2)
-            : launch_forward_split<DIN, NOUT, false>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+                                     const float *b3, int n_out, float *out, float *h1, float *h2, uint32_t *gate) {
+  return h2 ? launch_forward_split<DIN, NOUT, true>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate)
+            : launch_forward_split<DIN, NOUT, false>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
 }
 
 template <int DIN>
 static int dispatch_forward_split_nout(int n_out, int grid, hipStream_t s, const float *x, int64_t m, int d_in,
                                        const float *w1, const float *b1, const void *w2s, const float *b2,
-                                       const float *w3, const float *b3, float *out, float *h1, float *h2) {
+                                       const float *w3, const float *b3, float *out, float *h1, float *h2,
+                                       uint32_t *gate) {
   switch (n_out) {
-    case 1: return launch_forward_split_save<DIN, 1>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
-    case 2: return launch_forward_split_save<DIN, 2>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
-    case 3: return launch_forward_split_save<DIN, 3>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2);
+    case 1: return launch_forward_split_save<DIN, 1>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
+    case 2: return launch_forward_split_save<DIN, 2>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
+    case 3: return launch_forward_split_save<DIN, 3>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
     default: return RL8_ESIZE;
   }
 }
@@ -513,7 +576,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ h2, const float *__restrict__ dout, int64_t m, int d_in_rt,
     const void *__restrict__ w2ts, const float *__restrict__ w3, int n_out_rt, float *__restrict__ dz2_out,
-    float *__restrict__ partials, int partial_stride, int head_rows) {
+    float *__restrict__ partials, int partial_stride, int head_rows, const uint32_t *__restrict__ gate2) {
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
@@ -524,6 +587,13 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int jq = tid & 3, prow = tid >> 2;  // producer role: see the forward kernel
+  // gate2 given: the ReLU gate of h2 comes as bits (the forward kernel's save_gate2),
+  // one 4-KiB block per tile copied to LDS by direct-to-LDS loads, instead of 1 KiB
+  // of h2 per row through registers a step ahead -- that HBM latency, forced to
+  // fit one k-step by the step barrier's vmcnt(0), was 40 % of this kernel.
+  const bool use_bits = gate2 != nullptr;
+  const unsigned gate_lds = lds0 + 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4;  // [128 rows][8 words]
+  uint32_t g0[2] = {0u, 0u};  // word 0 of rows prow, prow + 64 of the NEXT tile (its chunk 0 is produced before the block lands)
   const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
   const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
   const unsigned a_write = lds0 + (jq >> 1) * kSplitKhStride + prow * 16 + (jq & 1) * 8;
@@ -550,7 +620,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   // step ahead.  Rows past the end are clamped to the last row (always a valid
   // address, no branch): their dOut is zero, so their dZ2 is, and their stores
   // are dropped.
-  float4 hq[2];
+  float4 hq[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   // Addresses: a uniform (scalar) tile base plus ONE per-lane 32-bit offset shared by
   // the h2 loads and the dZ2 stores (same [row][256] layout) -- 64-bit per-lane
   // pointers cost registers the matrix loop does not have.
@@ -577,7 +647,22 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
                                                16, lane * 16, (ks * 24 + block) * 1024, 0, 0);
     }
   };
-  auto produce_a = [&](const float4 (&hv)[2], int ks, u32x2 (&planes)[2][3]) {
+  // Gate block of `tile` -> LDS: wave w copies rows 32w .. 32w+31 (1 KiB, contiguous);
+  // rows past the end of the data arrive as zeros (gate closed).
+  auto request_gate = [&](int64_t tile) {
+    const int rows = rows_in_tile(tile);
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? gate2 + tile * (kSplitRows * 8) : gate2, rows * 32);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, smem + 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4 + wave * 1024, 16,
+                                             lane * 16, wave * 1024, 0, 0);
+  };
+  auto load_g0 = [&](int64_t tile) {
+    const int rows = rows_in_tile(tile);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) g0[u] = prow + 64 * u < rows ? gate2[(tile * kSplitRows + prow + 64 * u) * 8] : 0u;
+  };
+  // hv: h2 values (use_bits false) -- or unused; from_regs: chunk 0 of a tile whose
+  // gate block has not landed yet takes its bits from g0.
+  auto produce_a = [&](const float4 (&hv)[2], int ks, u32x2 (&planes)[2][3], bool from_regs = false) {
     const int k0 = 16 * ks + 4 * jq;
     float wv[kOut][4];
 #pragma unroll
@@ -592,6 +677,11 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const float hval[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
+      uint32_t nibble = 0;
+      if (use_bits) {
+        const uint32_t word = from_regs ? g0[u] : __float_as_uint(lds_read_b32(gate_lds + ((prow + 64 * u) * 8 + (ks >> 1)) * 4));
+        nibble = word >> (16 * (ks & 1) + 4 * jq);
+      }
       f32x4 dz;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -599,7 +689,8 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
         for (int q = 1; q < kOut; ++q)
           if (NOUT > 0 ? q < NOUT : q < n_out) g = __builtin_fmaf(dr[u][q], wv[q][e], g);
-        dz[e] = hval[e] > 0.0f ? g : 0.0f;
+        const bool open = use_bits ? ((nibble >> e) & 1u) != 0 : hval[e] > 0.0f;
+        dz[e] = open ? g : 0.0f;
       }
       if constexpr (!(kSplitDiagSkip & 128)) {
         if (dz2_out != nullptr && prow + 64 * u < p_rows)  // (optional: the fused weight-gradient kernel re-forms dZ2)
@@ -660,15 +751,22 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       p_tile += stride;
       p_rows = rows_in_tile(p_tile);
       load_dout(dn, p_tile + stride);
+      // every wave is past barrier(14): nobody reads the old gate block any more;
+      // the new one lands by this step's barrier, chunk 0 uses g0 meanwhile
+      if (use_bits) request_gate(p_tile);
     }
     {
       u32x2 planes[2][3];
-      produce_a(hq, ks, planes);
+      produce_a(hq, ks, planes, s == kSplitSteps - 1);
       write_a(P ^ 1, planes);
     }
-    // h2 of the chunk after next, into the registers just consumed: used by the
-    // next step's produce_a (the step barrier waits for it; it has this step to arrive).
-    load_h2(hq, s == kSplitSteps - 2 ? p_tile + stride : p_tile, (s + 2) & (kSplitSteps - 1));
+    if (use_bits) {
+      if (s == kSplitSteps - 3) load_g0(p_tile + stride);  // two steps ahead of its use
+    } else {
+      // h2 of the chunk after next, into the registers just consumed: used by the
+      // next step's produce_a (the step barrier waits for it; it has this step to arrive).
+      load_h2(hq, s == kSplitSteps - 2 ? p_tile + stride : p_tile, (s + 2) & (kSplitSteps - 1));
+    }
     wait_lds_all(f);
     split_mma<FIRST>(f.am, f.bm, acc);
     split_mma<false>(f.ah, f.bm, acc);
@@ -696,12 +794,17 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 
   p_rows = rows_in_tile(p_tile);
   if ((int64_t)blockIdx.x < tiles) {
-    load_h2(hq, p_tile, 0);
+    if (use_bits) {
+      request_gate(p_tile);
+      step_barrier();  // (once per kernel: the first gate block has landed)
+    } else {
+      load_h2(hq, p_tile, 0);
+    }
     request_b(0, 0);
     u32x2 planes[2][3];
     produce_a(hq, 0, planes);
     write_a(0, planes);
-    load_h2(hq, p_tile, 1);
+    if (!use_bits) load_h2(hq, p_tile, 1);
     step_barrier();
   }
 
@@ -880,7 +983,7 @@ template <int DIN, int NOUT>
 static int launch_backward_split(int grid, hipStream_t s, const float *x, const float *w1, const float *b1,
                                  const float *h2, const float *dout, int64_t m, int d_in, const void *w2ts,
                                  const float *w3, int n_out, float *dz2_out, float *partials, int stride,
-                                 int head_rows = -1) {
+                                 int head_rows = -1, const uint32_t *gate2 = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_split_kernel<DIN, NOUT>),
@@ -889,8 +992,8 @@ static int launch_backward_split(int grid, hipStream_t s, const float *x, const 
     attr_set = true;
   }
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
-  mlp_tower_backward_split_kernel<DIN, NOUT><<<grid, kBlock, 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4, s>>>(
-      x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows);
+  mlp_tower_backward_split_kernel<DIN, NOUT><<<grid, kBlock, 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4 + kSplitRows * 32, s>>>(
+      x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
   const int status = launch_status();
   if (status != 0 || head_rows >= 0) return status;  // (fused: the weight-gradient kernel forms the head gradients)
   mlp_head_grads_kernel<NOUT><<<grid, kBlock, 0, s>>>(h2, dout, m, w3, n_out, d_in, partials, stride);
@@ -901,10 +1004,10 @@ template <int DIN>
 static int dispatch_backward_split_nout(int n_out, int grid, hipStream_t s, const float *x, const float *w1,
                                         const float *b1, const float *h2, const float *dout, int64_t m, int d_in,
                                         const void *w2ts, const float *w3, float *dz2_out, float *partials,
-                                        int stride, int head_rows) {
+                                        int stride, int head_rows, const uint32_t *gate2) {
   switch (n_out) {
-    case 1: return launch_backward_split<DIN, 1>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows);
-    case 2: return launch_backward_split<DIN, 2>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows);
+    case 1: return launch_backward_split<DIN, 1>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
+    case 2: return launch_backward_split<DIN, 2>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
     default: return RL8_ESIZE;
   }
 }
@@ -1222,9 +1325,9 @@ RL8_API int rl8_mlp_pack_w2_split(const float *w2, int transposed, void *packed,
 RL8_API int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const float *w1,
                                             const float *b1, const void *w2_split, const float *b2,
                                             const float *w3, const float *b3, int n_out, float *out,
-                                            float *save_h1, float *save_h2, void *stream) {
+                                            float *save_h1, float *save_h2, uint32_t *save_gate2, void *stream) {
   if (!x || !w1 || !b1 || !w2_split || !b2 || !w3 || !b3 || !out) return RL8_ENULL;
-  if (save_h1 != nullptr && save_h2 == nullptr) return RL8_ENULL;  // h2 alone is allowed: see the header
+  if ((save_h1 != nullptr || save_gate2 != nullptr) && save_h2 == nullptr) return RL8_ENULL;  // h2 alone is allowed
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
   if (((uintptr_t)w2_split & 15) != 0 || !aligned16(w1) || !aligned16(b1) || (save_h1 && !aligned16(save_h1)) ||
       (save_h2 && !aligned16(save_h2)))
@@ -1237,8 +1340,8 @@ RL8_API int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in,
   // Only the widths whose kernels are verified spill-free are compiled (see
   // rl8_mlp_forward_split_supports); the rest keep rl8_mlp_tower_forward_f32.
   switch (d_in) {
-    case 1: return dispatch_forward_split_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
-    case 2: return dispatch_forward_split_nout<2>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2);
+    case 1: return dispatch_forward_split_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
+    case 2: return dispatch_forward_split_nout<2>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
     default: return RL8_ESIZE;
   }
 }
@@ -1258,8 +1361,8 @@ RL8_API int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, co
                                              const float *h2, const float *dout, int64_t m, int d_in,
                                              const void *w2t_split, const float *w3, int n_out,
                                              float *dz2_out, float *partials, int *partial_rows_out,
-                                             void *stream) {
-  if (!x || !w1 || !b1 || !h2 || !dout || !w2t_split || !w3 || !partials || !partial_rows_out)
+                                             const uint32_t *gate2, void *stream) {
+  if (!x || !w1 || !b1 || (!h2 && (!gate2 || dz2_out)) || !dout || !w2t_split || !w3 || !partials || !partial_rows_out)
     return RL8_ENULL;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
   if (((uintptr_t)w2t_split & 15) != 0 || !aligned16(h2) || !aligned16(dz2_out) || !aligned16(w3)) return RL8_EALIGN;
@@ -1272,7 +1375,7 @@ RL8_API int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, co
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
   switch (d_in) {
-    case 1: return dispatch_backward_split_nout<1>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows);
+    case 1: return dispatch_backward_split_nout<1>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows, gate2);
     default: return RL8_ESIZE;  // rl8_mlp_backward_split_supports(): other widths use rl8_mlp_tower_backward_f32
   }
 }

@@ -135,13 +135,13 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_split_packed_bytes": [],
     "rl8_mlp_pack_w2_split": [_vp, _i32, _vp, _vp],
-    "rl8_mlp_tower_forward_split_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "rl8_mlp_tower_forward_split_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
     "rl8_mlp_backward_max_rows": [],
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_backward_split_supports": [_i32, _i32],
     "rl8_mlp_forward_split_supports": [_i32, _i32],
-    "rl8_mlp_tower_backward_split_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_mlp_tower_backward_split_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp, _vp],
     "rl8_mlp_wgrad_split_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "rl8_mlp_wgrad_fused_split_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_wgrad_workspace_bytes": [],
@@ -867,11 +867,13 @@ def mlp_pack_w2_split(w2: torch.Tensor, *, transposed: bool = False) -> torch.Te
 
 def mlp_tower_forward_split(
     x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2_split: torch.Tensor, b2: torch.Tensor,
-    w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False, save_h1: bool = True,
-) -> tuple[torch.Tensor, None | torch.Tensor, None | torch.Tensor]:
+    w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False, save_h1: bool = True, save_gate: bool = False,
+) -> tuple[torch.Tensor, ...]:
     """``mlp_tower_forward`` with the 256x256 product as six bf16-plane MFMAs per
     16 k (fp32 accuracy, fp32 in / out / accumulate). ``save_h1=False`` keeps only
-    h2 (the bf16-plane backward kernels recompute h1)."""
+    h2 (the bf16-plane backward kernels recompute h1). ``save_gate=True`` (with
+    ``save``) appends a fourth result, the ReLU gate of h2 as bits ([M, 8] int32:
+    bit j of row s = h2[s, j] > 0), which the data-gradient kernel reads instead of h2."""
     x = _dense(x.detach(), torch.float32, "x")
     m, d_in = x.shape
     n_out = w3.shape[0]
@@ -885,21 +887,23 @@ def mlp_tower_forward_split(
     out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
     h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save and save_h1 else None
     h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
+    gate = torch.empty(m, 8, dtype=torch.int32, device=x.device) if save and save_gate else None
     with _timed("mlp_tower_forward_save" if save else "mlp_tower_forward", m):
         _check(
             load().rl8_mlp_tower_forward_split_f32(
                 _ptr(x), m, d_in, _ptr(w1.detach()), _ptr(b1.detach()), _ptr(w2_split), _ptr(b2.detach()),
-                _ptr(w3.detach()), _ptr(b3.detach()), n_out, _ptr(out), _ptr(h1), _ptr(h2), _stream(),
+                _ptr(w3.detach()), _ptr(b3.detach()), n_out, _ptr(out), _ptr(h1), _ptr(h2), _ptr(gate), _stream(),
             ),
             "rl8_mlp_tower_forward_split_f32",
         )
-    return out, h1, h2
+    return (out, h1, h2, gate) if save_gate else (out, h1, h2)
 
 
 def mlp_tower_backward(
     x: torch.Tensor, h1: None | torch.Tensor, h2: torch.Tensor, dout: torch.Tensor,
     w2t_packed: torch.Tensor, w3: torch.Tensor,
     w1: None | torch.Tensor = None, b1: None | torch.Tensor = None, *, wgrad_split: bool = False,
+    gate2: None | torch.Tensor = None,
 ) -> dict[str, torch.Tensor]:
     """Gradients of one tower's parameters given ``dout`` [M, n_out] and the
     activations saved by the forward pass. Returns ``w1, b1, w2, b2, w3, b3``.
@@ -909,7 +913,8 @@ def mlp_tower_backward(
     kernel, which also needs layer 1 (``w1``, ``b1``): it recomputes the ReLU gate
     of h1 instead of reading h1 back. ``wgrad_split`` forms dW2 with the bf16-plane
     weight-gradient kernel (any width; needs ``w1``, ``b1``) even when the
-    data-gradient half runs on the fp32 kernel."""
+    data-gradient half runs on the fp32 kernel. ``gate2`` (``save_gate`` of the
+    bf16-plane forward): gate bits of h2 for the data-gradient kernel."""
     m, d_in = x.shape
     n_out = w3.shape[0]
     split = w2t_packed.dtype == torch.uint8
@@ -922,6 +927,8 @@ def mlp_tower_backward(
         _dense(t, torch.float32, name)
         if t.numel() != numel:
             raise ValueError(f"{name} has the wrong number of elements")
+    if gate2 is not None and (gate2.dtype != torch.int32 or tuple(gate2.shape) != (m, 8) or not gate2.is_contiguous()):
+        raise ValueError("gate2 must be the [M, 8] int32 gate of mlp_tower_forward_split(save_gate=True)")
     lib = load()
     width = int(lib.rl8_mlp_backward_partial_floats(d_in, n_out))
     max_rows = int(lib.rl8_mlp_backward_max_rows())
@@ -938,7 +945,7 @@ def mlp_tower_backward(
             _check(
                 lib.rl8_mlp_tower_backward_split_f32(
                     _ptr(x), w1p, b1p, _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
-                    None, _ptr(partials), C.byref(rows), _stream()),
+                    None, _ptr(partials), C.byref(rows), _ptr(gate2), _stream()),
                 "rl8_mlp_tower_backward_split_f32",
             )
         dw2 = torch.empty(MLP_HIDDEN, MLP_HIDDEN, dtype=torch.float32, device=x.device)

@@ -66,21 +66,22 @@ class _FusedTower(torch.autograd.Function):
         if FORWARD_GEMM == "split" and hip.mlp_forward_split_supports(x.shape[1], w3.shape[0]):
             # h1 is stored only if a backward kernel will read it (the bf16-plane ones recompute it)
             keep_h1 = not (BACKWARD_GEMM == "split" and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0]))
-            out, h1, h2 = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, True), b2, w3, b3,
-                                                      save=need_grad, save_h1=keep_h1)
+            out, h1, h2, gate = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, True), b2, w3, b3,
+                                                            save=need_grad, save_h1=keep_h1, save_gate=True)
         else:
             out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
+            gate = None
         if need_grad:
             ctx.layer2 = layer2
-            ctx.save_for_backward(x, h1, h2, w3, w1, b1)
+            ctx.save_for_backward(x, h1, h2, w3, w1, b1, gate)
         return out
 
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
-        x, h1, h2, w3, w1, b1 = ctx.saved_tensors
+        x, h1, h2, w3, w1, b1, gate = ctx.saved_tensors
         split = BACKWARD_GEMM == "split" and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0])
         g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True, split), w3,
-                                   w1, b1, wgrad_split=BACKWARD_GEMM == "split")
+                                   w1, b1, wgrad_split=BACKWARD_GEMM == "split", gate2=gate if split else None)
         return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None
 
 

@@ -85,6 +85,12 @@ def test_forward_split_is_fp32_accurate(m, d_in, n_out):
     out4, h1c, h2c = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"], save=True,
                                                  save_h1=False)
     assert h1c is None and torch.equal(out, out4) and torch.equal(h2, h2c)
+    # the ReLU gate of h2 as bits: bit j of row s = h2[s, j] > 0
+    out5, _, h2d, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"], save=True,
+                                                     save_gate=True)
+    want_bits = (h2d > 0).view(m, 8, 32).to(torch.int64)
+    want_words = (want_bits << torch.arange(32, device=DEV)).sum(-1)
+    assert torch.equal(out, out5) and torch.equal(gate.to(torch.int64) & 0xFFFFFFFF, want_words)
 
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 1, 2), (4097, 1, 1), (40_000, 1, 2), (9000, 1, 1),
@@ -99,8 +105,8 @@ def test_backward_split_matches_fp64(m, d_in, n_out):
     x = torch.randn(m, d_in, device=DEV, generator=g) * 3
     p = _params(g, d_in, n_out)
     dout = torch.randn(m, n_out, device=DEV, generator=g) / m
-    out, h1, h2 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_split(p["w2"]), p["b2"], p["w3"],
-                                              p["b3"], save=True)
+    out, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_split(p["w2"]), p["b2"], p["w3"],
+                                                    p["b3"], save=True, save_gate=True)
     d, a1, a2 = dout.double(), h1.double(), h2.double()
     dz2 = (d @ p["w3"].double()) * (a2 > 0)
     dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
@@ -119,6 +125,10 @@ def test_backward_split_matches_fp64(m, d_in, n_out):
     again = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"])  # h1 is not read
     for k in p:
         assert torch.equal(grads[k], again[k]), k  # fixed summation order, no race
+    # gate bits instead of h2 reads in the data-gradient kernel: the same decisions, so the same bits out
+    bits = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate)
+    for k in p:
+        assert torch.equal(grads[k], bits[k]), k
     with pytest.raises(ValueError):
         hip.mlp_tower_backward(x, None, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
 
