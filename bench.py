@@ -81,14 +81,20 @@ PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in
     "mlp_tower_backward": ("mlp_tower_backward_kernel<1, 2>", 1 << 20),
     "mlp_wgrad": ("mlp_wgrad_kernel", 1 << 20),
 }
+PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
+    "mlp_tower_forward": ("mlp_tower_forward_split_kernel<1, 2, false>", 1 << 20),
+    "mlp_tower_forward_save": ("mlp_tower_forward_split_kernel<1, 2, true>", 1 << 20),
+    "mlp_tower_backward": ("mlp_tower_backward_split_kernel<1, 2>", 1 << 20),
+    "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2>", 1 << 20),
+}
 
 
-def pmc_traffic(name: str, units_per_launch: float):
+def pmc_traffic(name: str, units_per_launch: float, split: bool = False):
     try:
         summary = json.load(open(PMC_SUMMARY))
     except OSError:
         return None
-    needle, units = PMC_KERNEL.get(name, (None, 1))
+    needle, units = (PMC_KERNEL_SPLIT if split else PMC_KERNEL).get(name, (None, 1))
     for kernel, rec in summary.items():
         if needle and needle in kernel:
             return rec["traffic_bytes_per_launch"] / units * units_per_launch
@@ -239,7 +245,7 @@ def main() -> None:
                 "algorithmic_flop_per_launch": flops_per_launch,
                 "achieved_TFLOPs": round(tflops, 2),            # fp32-equivalent: algorithmic flops / time
                 "frac_of_f32_mfma_peak": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                "pmc_traffic_bytes_per_launch": pmc_traffic(name, rec["units_per_launch"]),
+                "pmc_traffic_bytes_per_launch": pmc_traffic(name, rec["units_per_launch"], gemm != "f32"),
             }
             if gemm != "f32":
                 # every fp32 multiply-add of the 256x256 product is SPLIT_PRODUCTS bf16 ones on the matrix pipe
