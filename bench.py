@@ -224,6 +224,8 @@ def main() -> None:
         widths = [(obs_dim, n) for n in tower_heads]
         if name in ("mlp_tower_forward", "mlp_tower_forward_save"):
             ok = fused_mlp.FORWARD_GEMM == "split" and all(hip.mlp_forward_split_supports(d, n) for d, n in widths)
+        elif name == "mlp_wgrad":  # the bf16-plane weight-gradient kernel takes any width
+            ok = fused_mlp.BACKWARD_GEMM == "split"
         else:
             ok = fused_mlp.BACKWARD_GEMM == "split" and all(hip.mlp_backward_split_supports(d, n) for d, n in widths)
         return "bf16x3-split" if ok else "f32"
