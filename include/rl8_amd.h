@@ -386,8 +386,9 @@ int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const float *w1, c
  * store, no head-gradient launch) followed by this call, whose weight-gradient
  * kernel re-forms dZ2 = (dOut x W3) * (h2 > 0) and h1 itself (thread = column) and
  * accumulates the head gradients on the way.  dw2_out [256][256] receives dW2; the
- * head segments [db2 | dW3 | db3] of `partials` (the same buffer and row count the
- * first call reported) are filled.  Widths: rl8_mlp_backward_split_supports. */
+ * head segments [db2 | dW3] of `partials` (the same buffer and row count the first
+ * call reported) are filled and the db3 segment is zeroed: db3 = the column sums of
+ * dOut, which the caller forms itself.  Widths: rl8_mlp_backward_split_supports. */
 int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, const float *x, const float *w1,
                                   const float *b1, const float *w3, int64_t m, int d_in, int n_out,
                                   float *workspace, float *dw2_out, float *partials, void *stream);

@@ -179,15 +179,18 @@ __device__ __forceinline__ void split_mma(const u32x4 (&a)[2], const u32x4 (&b)[
     }
 }
 
-// v (fp32 pair) -> the three packed bf16 pairs (element 0 in the low half).
+// v (fp32 pair) -> the three packed bf16 pairs (element 0 in the low half).  The
+// two exact subtractions of a pair are packed (v_pk_add_f32): 9 VALU instructions
+// per pair.
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
-  const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
-  const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
-  const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-  const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+  const f32x2 x = {x0, x1};
+  const f32x2 h = {__uint_as_float(__float_as_uint(x0) & 0xffff0000u), __uint_as_float(__float_as_uint(x1) & 0xffff0000u)};
+  const f32x2 r = x - h;
+  const f32x2 mm = {__uint_as_float(__float_as_uint(r[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(r[1]) & 0xffff0000u)};
+  const f32x2 q = r - mm;
   hi = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-  mid = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-  lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+  mid = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x07060302u);
 }
 
 // Sum over the 32 lanes of each half-wave, valid in lanes 16..31 / 48..63.
@@ -368,16 +371,17 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       p_rows = rows_from(p_r0);
       load_x(xn, p_r0 + stride * kSplitRows);
     }
-    {
-      u32x2 planes[2][3];
-      produce_a(ks, planes);
-      write_a(P ^ 1, planes);  // (straight away: twelve registers less across the matrix groups)
-    }
+    // The next chunk's arithmetic is left to the scheduler to interleave with the
+    // first matrix group (VALU instructions issue beside bf16 MFMAs for free);
+    // its fragments go to LDS behind that group.
+    u32x2 planes[2][3];
+    produce_a(ks, planes);
     wait_lds_all(f);
     split_mma<FIRST>(f.am, f.bm, acc);
     split_mma<false>(f.ah, f.bm, acc);
     split_mma<false>(f.am, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
+    write_a(P ^ 1, planes);
     // lo planes into the registers of the mid planes
     f.am[0] = lds_read_b128<2 * kSplitPlaneStride>(ar);
     f.am[1] = lds_read_b128<2 * kSplitPlaneStride + 512>(ar);
@@ -616,10 +620,8 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   };
   load_dout(dr, p_tile);
   load_dout(dn, p_tile + stride);
-  // h2 of the chunk produced next: [row u] = this lane's four columns, requested a
-  // step ahead.  Rows past the end are clamped to the last row (always a valid
-  // address, no branch): their dOut is zero, so their dZ2 is, and their stores
-  // are dropped.
+  // h2 of the chunk produced next (only without gate bits): [row u] = this lane's
+  // four columns, requested a step ahead; rows past the end read as zero (gate closed).
   float4 hq[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   // Addresses: a uniform (scalar) tile base plus ONE per-lane 32-bit offset shared by
   // the h2 loads and the dZ2 stores (same [row][256] layout) -- 64-bit per-lane
@@ -755,11 +757,8 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       // the new one lands by this step's barrier, chunk 0 uses g0 meanwhile
       if (use_bits) request_gate(p_tile);
     }
-    {
-      u32x2 planes[2][3];
-      produce_a(hq, ks, planes, s == kSplitSteps - 1);
-      write_a(P ^ 1, planes);
-    }
+    u32x2 planes[2][3];
+    produce_a(hq, ks, planes, s == kSplitSteps - 1);
     if (use_bits) {
       if (s == kSplitSteps - 3) load_g0(p_tile + stride);  // two steps ahead of its use
     } else {
@@ -772,6 +771,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     split_mma<false>(f.ah, f.bm, acc);
     split_mma<false>(f.am, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
+    write_a(P ^ 1, planes);
     f.am[0] = lds_read_b128<2 * kSplitPlaneStride>(ar);
     f.am[1] = lds_read_b128<2 * kSplitPlaneStride + 512>(ar);
     f.bm[0] = lds_read_b128<2 * 1024>(br);
@@ -1038,8 +1038,9 @@ constexpr int kWsStageBytes = 2 * kWsOperandBytes;       // dZ2^T | h1
 //   dZ2 = (dOut x W3) * (h2 > 0)  from h2 (`dz2` then points at h2), dOut and W3 --
 // thread = column, so W3's column is per-thread constants and dOut comes through
 // the scalar cache -- and, since h2, dOut and dZ2 are all in hand column-wise, the
-// head gradients db2 = sum dZ2, dW3 = dOut^T h2, db3 = sum dOut are accumulated
-// too (per thread; one partial row per workgroup).  The data-gradient kernel then
+// head gradients db2 = sum dZ2 and dW3 = dOut^T h2 are accumulated too (per thread;
+// one partial row per workgroup; db3 = sum dOut is left to the caller: it is a
+// column sum of a [M][n_out] array and would cost this kernel 4 VALU per sample).  The data-gradient kernel then
 // neither stores dZ2 nor needs a separate head-gradient pass.
 struct WgradFusedArgs {
   const float *dout, *w3;
@@ -1071,12 +1072,12 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 #pragma unroll
   for (int c = 0; c < kIn; ++c) w1r[c] = (DIN > 0 || c < d_in) ? w1[col * d_in + c] : 0.0f;
   const float b1r = b1[col];
-  [[maybe_unused]] float w3r[kOut], db2a = 0.0f, dw3a[kOut], db3a[kOut];
+  [[maybe_unused]] float w3r[kOut], db2a = 0.0f, dw3a[kOut];
   if constexpr (FUSED > 0) {
 #pragma unroll
     for (int q = 0; q < kOut; ++q) {
       w3r[q] = fused.w3[q * kHidden + col];
-      dw3a[q] = db3a[q] = 0.0f;
+      dw3a[q] = 0.0f;
     }
   }
 
@@ -1106,20 +1107,25 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   };
   auto produce = [&](const float (&dzv)[8], int64_t n, u32x4 (&pa)[3], u32x4 (&pb)[3]) {
     const int64_t chunk = blockIdx.x + n * stride;
+    // Samples past the end are clamped to the last row: their h2 / dZ2 read as zero
+    // through the descriptor, so whatever they contribute is multiplied by zero.
+    // (A variant that kept these row indices on the scalar unit -- dOut then comes
+    // through the scalar cache -- was 10 % slower here.)
+    auto row_of = [&](int e) {
+      const int64_t row = chunk * kWsChunk + 8 * kh + e;
+      return row < m ? row : m - 1;
+    };
     if constexpr (FUSED > 0) {
       float dz[8];  // dzv holds h2
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        int64_t row = chunk * kWsChunk + 8 * kh + e;
-        const bool valid = row < m;
-        row = valid ? row : m - 1;  // (its h2 reads as zero)
+        const int64_t row = row_of(e);
         float g = 0.0f;
 #pragma unroll
         for (int q = 0; q < kOut; ++q) {
           const float d = fused.dout[row * kOut + q];
           g = __builtin_fmaf(d, w3r[q], g);
           dw3a[q] = __builtin_fmaf(d, dzv[e], dw3a[q]);
-          db3a[q] += valid ? d : 0.0f;
         }
         dz[e] = dzv[e] > 0.0f ? g : 0.0f;
         db2a += dz[e];
@@ -1131,8 +1137,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     float h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      int64_t row = chunk * kWsChunk + 8 * kh + e;
-      row = row < m ? row : m - 1;  // (its dZ2 is zero)
+      const int64_t row = row_of(e);
       float v = b1r;
 #pragma unroll
       for (int c = 0; c < kIn; ++c)
@@ -1174,17 +1179,15 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     f.bm[1] = lds_read_b128<kWsPlane + 512>(br);
     f.bm[2] = lds_read_b128<kWsPlane + 1024>(br);
     f.bm[3] = lds_read_b128<kWsPlane + 1536>(br);
-    {
-      u32x4 pa[3], pb[3];
-      produce(dzq[P ^ 1], n + 1, pa, pb);
-      write_planes(P ^ 1, pa, pb);
-    }
+    u32x4 pa[3], pb[3];
+    produce(dzq[P ^ 1], n + 1, pa, pb);
     load_dz(dzq[P], n + 2);
     wait_lds_all(f);
     split_mma<FIRST>(f.am, f.bm, acc);
     split_mma<false>(f.ah, f.bm, acc);
     split_mma<false>(f.am, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
+    write_planes(P ^ 1, pa, pb);
     f.am[0] = lds_read_b128<2 * kWsPlane>(ar);
     f.am[1] = lds_read_b128<2 * kWsPlane + 512>(ar);
     f.bm[0] = lds_read_b128<2 * kWsPlane>(br);
@@ -1244,10 +1247,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       red[col * (1 + kOut)] = db2a;
 #pragma unroll
       for (int q = 0; q < kOut; ++q) red[col * (1 + kOut) + 1 + q] = dw3a[q];
-      if (col == 0) {
-#pragma unroll
-        for (int q = 0; q < kOut; ++q) red[kHidden * (1 + kOut) + q] = db3a[q];
-      }
     }
     __syncthreads();
     float *row = fused.partials + (int64_t)blockIdx.x * fused.partial_stride;
@@ -1256,10 +1255,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       row[off_db2 + col] = db2a + red[col * (1 + kOut)];
 #pragma unroll
       for (int q = 0; q < kOut; ++q) row[off_dw3 + q * kHidden + col] = dw3a[q] + red[col * (1 + kOut) + 1 + q];
-      if (col == 0) {
-#pragma unroll
-        for (int q = 0; q < kOut; ++q) row[off_db3 + q] = db3a[q] + red[kHidden * (1 + kOut) + q];
-      }
+      // db3 = sum of dOut needs no matrix kernel: the caller forms it (the segment is zeroed)
+      if (col < kOut) row[off_db3 + col] = 0.0f;
     }
     if ((int)blockIdx.x >= fused.other_rows)
       for (int idx = tid; idx < kHidden * d_in + kHidden; idx += kWsThreads) row[idx] = 0.0f;

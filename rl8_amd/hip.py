@@ -972,7 +972,8 @@ def mlp_tower_backward(
         "b1": small[o1 : o1 + MLP_HIDDEN],
         "b2": small[o1 + MLP_HIDDEN : o1 + 2 * MLP_HIDDEN],
         "w3": small[o1 + 2 * MLP_HIDDEN : o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN].view(n_out, MLP_HIDDEN),
-        "b3": small[o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN :],
+        # (the fused bf16-plane backward leaves db3 -- a column sum of dout -- to the caller)
+        "b3": dout.sum(0) if split else small[o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN :],
         "w2": dw2 if split else (mlp_wgrad_split(dz2, x, w1, b1) if wgrad_split else mlp_wgrad(dz2, h1)),
     }
     return grads
