@@ -179,18 +179,23 @@ __device__ __forceinline__ void split_mma(const u32x4 (&a)[2], const u32x4 (&b)[
     }
 }
 
-// v (fp32 pair) -> the three packed bf16 pairs (element 0 in the low half).  The
-// two exact subtractions of a pair are packed (v_pk_add_f32): 9 VALU instructions
-// per pair.
+// v (fp32 pair) -> the three packed bf16 pairs (element 0 in the low half).
+// Deliberately scalar arithmetic (and this file is built with -fno-slp-vectorize):
+// with packed fp32 instructions in these loops -- v_pk_fma_f32 chains the SLP
+// vectoriser formed out of the head-gradient fmas, operands shuffled by v_mov right
+// behind them, all interleaved with bf16 MFMAs -- one run in four of the fused
+// weight-gradient kernel came back with a few accumulators wrong in lanes 48..63
+// (the low half of a packed pair computed from the value written two instructions
+// later).  No packed fp32 ops: 0 of 40 stress runs; tests/test_mlp_split_gpu.py
+// repeats every kernel under load and compares bits.
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
-  const f32x2 x = {x0, x1};
-  const f32x2 h = {__uint_as_float(__float_as_uint(x0) & 0xffff0000u), __uint_as_float(__float_as_uint(x1) & 0xffff0000u)};
-  const f32x2 r = x - h;
-  const f32x2 mm = {__uint_as_float(__float_as_uint(r[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(r[1]) & 0xffff0000u)};
-  const f32x2 q = r - mm;
+  const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+  const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+  const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+  const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
   hi = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-  mid = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
-  lo = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x07060302u);
+  mid = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
 }
 
 // Sum over the 32 lanes of each half-wave, valid in lanes 16..31 / 48..63.
@@ -450,11 +455,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       for (int nt = 0; nt < 4; ++nt) {
         const int j = 128 * wc + 32 * nt + l32;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 pre = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{b2r[nt], b2r[nt]};
-          acc[mt][nt][r] = relu1(pre[0]);
-          acc[mt][nt][r + 1] = relu1(pre[1]);
-        }
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = relu1(acc[mt][nt][r] + b2r[nt]);
         if constexpr (SAVE && !(kSplitDiagSkip & 8)) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {

@@ -53,12 +53,14 @@ def test_compiled_split_kernels_resources(tmp_path):
     asm = tmp_path / "split.s"
     subprocess.run(
         [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/include", f"-I{csrc}",
-         "-S", "--cuda-device-only", "-o", str(asm), os.path.join(csrc, "mlp_split_kernels.hip")],
+         "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", str(asm), os.path.join(csrc, "mlp_split_kernels.hip")],
         check=True, capture_output=True, timeout=900,
     )
     text = asm.read_text()
     waits = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)\n\ts_barrier", text)
     assert len(waits) >= 14 * 6 and set(waits) == {"0"}  # the hand-written step barriers
+    # no packed fp32 arithmetic in these kernels (a hazard beside the bf16 MFMAs: see split_pair())
+    assert not re.search(r"\bv_pk_(fma|add|mul)_f32\b", text)
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
     checked = 0
     for name, body in kernels:

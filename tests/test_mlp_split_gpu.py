@@ -213,3 +213,83 @@ def test_fused_tower_autograd_uses_the_split_kernels_and_matches_eager():
     ((head(trunk(x)) * torch.linspace(-1, 1, 2, device=DEV)).sum() / 3000).backward()
     for (n, p) in list(trunk.named_parameters()) + list(head.named_parameters()):
         assert _rel(got[n], p.grad.double()) < 2e-5, n
+
+
+def test_full_size_launch_equals_its_chunks():
+    """BASELINE's training launch (2^23 rows, the chunk `Algorithm.step` feeds the towers)
+    against the same rows in eight launches: a row's outputs depend on nothing but that
+    row (fixed k order), so forward results must be bit-identical however the rows are
+    cut into launches; gradients are sums over rows, so they must agree to fp32 rounding."""
+    m, parts = 1 << 23, 8
+    g = torch.Generator(device=DEV).manual_seed(99)
+    x = torch.empty(m, 1, device=DEV).uniform_(-100, 100, generator=g)  # DiscreteDummyEnv observations
+    p = _params(g, 1, 2)
+    dout = torch.randn(m, 2, device=DEV, generator=g) / m
+    w2s, w2ts = hip.mlp_pack_w2_split(p["w2"]), hip.mlp_pack_w2_split(p["w2"], transposed=True)
+    out, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2s, p["b2"], p["w3"], p["b3"], save=True,
+                                                   save_h1=False, save_gate=True)
+    full = hip.mlp_tower_backward(x, None, h2, dout, w2ts, p["w3"], p["w1"], p["b1"], gate2=gate)
+    acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in full.items()}
+    step = m // parts
+    for i in range(parts):
+        sl = slice(i * step, (i + 1) * step)
+        o, _, h2c, gc = hip.mlp_tower_forward_split(x[sl], p["w1"], p["b1"], w2s, p["b2"], p["w3"], p["b3"], save=True,
+                                                    save_h1=False, save_gate=True)
+        assert torch.equal(o, out[sl]) and torch.equal(h2c, h2[sl]) and torch.equal(gc, gate[sl])
+        part = hip.mlp_tower_backward(x[sl], None, h2c, dout[sl].contiguous(), w2ts, p["w3"], p["w1"], p["b1"], gate2=gc)
+        for k in acc:
+            acc[k] += part[k].double()
+    for k in acc:
+        assert _rel(full[k], acc[k]) < 2e-5, k
+    # inference launch of the rollout (2^20 rows) against the training launch's rows
+    o_inf, _, _ = hip.mlp_tower_forward_split(x[: 1 << 20], p["w1"], p["b1"], w2s, p["b2"], p["w3"], p["b3"])
+    assert torch.equal(o_inf, out[: 1 << 20])
+
+
+def test_split_kernels_repeat_bit_for_bit_under_load():
+    """Forty back-to-back runs of every bf16-plane kernel at the rollout launch size
+    must return the same bits (fixed summation orders; no instruction-level hazard:
+    an early build with compiler-formed packed fp32 ops beside the MFMAs got a few
+    head-gradient accumulators wrong in one run out of four)."""
+    m = 1 << 20
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.empty(m, 1, device=DEV).uniform_(-3, 3, generator=g)
+    p = _params(g, 1, 2)
+    dout = torch.randn(m, 2, device=DEV, generator=g) / m
+    w2s, w2ts = hip.mlp_pack_w2_split(p["w2"]), hip.mlp_pack_w2_split(p["w2"], transposed=True)
+
+    def run():
+        out, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2s, p["b2"], p["w3"], p["b3"], save=True,
+                                                       save_h1=False, save_gate=True)
+        grads = hip.mlp_tower_backward(x, None, h2, dout, w2ts, p["w3"], p["w1"], p["b1"], gate2=gate)
+        return [out, h2, gate] + [grads[k] for k in ("w1", "b1", "w2", "b2", "w3", "b3")]
+
+    first = run()
+    # against fp64 once (the head gradients are the ones that broke)
+    want_w3 = dout.double().T @ first[1].double()
+    assert _rel(first[7], want_w3) < 5e-6
+    for trial in range(40):
+        again = run()
+        for a, b in zip(first, again):
+            assert torch.equal(a, b), trial
+
+
+def test_fp32_mfma_kernels_repeat_bit_for_bit_under_load():
+    """The same stress for the fp32-MFMA generation (which uses packed fp32 ops by
+    design, beside fp32 MFMAs that do not co-issue with the VALU)."""
+    m = 1 << 19
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.empty(m, 5, device=DEV).uniform_(-3, 3, generator=g)
+    p = _params(g, 5, 3)
+    dout = torch.randn(m, 3, device=DEV, generator=g) / m
+    w2p, w2tp = hip.mlp_pack_w2(p["w2"]), hip.mlp_pack_w2(p["w2"], transposed=True)
+
+    def run():
+        out, h1, h2 = hip.mlp_tower_forward(x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True)
+        grads = hip.mlp_tower_backward(x, h1, h2, dout, w2tp, p["w3"], p["w1"], p["b1"], wgrad_split=True)
+        return [out, h1, h2] + [grads[k] for k in ("w1", "b1", "w2", "b2", "w3", "b3")]
+
+    first = run()
+    for trial in range(30):
+        for a, b in zip(first, run()):
+            assert torch.equal(a, b), trial
