@@ -336,7 +336,7 @@ int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *
  * (rl8_mlp_split_packed_bytes() bytes, 16-byte aligned) comes from
  * rl8_mlp_pack_w2_split (transposed as for rl8_mlp_pack_w2_f32). */
 int64_t rl8_mlp_split_packed_bytes(void);
-int rl8_mlp_forward_split_supports(int d_in, int n_out); /* d_in 1, 2 x n_out 1..3; else RL8_ESIZE */
+int rl8_mlp_forward_split_supports(int d_in, int n_out); /* d_in 1, 2, 3, 5 x n_out 1..3; else RL8_ESIZE */
 int rl8_mlp_pack_w2_split(const float *w2 /*[256][256]*/, int transposed, void *w2_split, void *stream);
 int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const float *w1,
                                     const float *b1, const void *w2_split, const float *b2,
@@ -369,7 +369,7 @@ int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
  * (see rl8_mlp_wgrad_fused_split_f32).  gate2 (the forward's save_gate2) replaces the
  * h2 reads of the matrix kernel by 32 B of gate bits per row; h2 may then be NULL
  * in the fused mode. */
-int rl8_mlp_backward_split_supports(int d_in, int n_out); /* d_in 1 x n_out 1, 2; else RL8_ESIZE */
+int rl8_mlp_backward_split_supports(int d_in, int n_out); /* the same widths */
 int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, const float *b1, const float *h2,
                                      const float *dout, int64_t m, int d_in, const void *w2t_split,
                                      const float *w3, int n_out, float *dz2_out, float *partials,

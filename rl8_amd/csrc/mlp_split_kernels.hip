@@ -243,25 +243,32 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 
   // Producer state: the tile whose h1 chunks are being produced (runs one step
   // ahead of the consumer, so it moves to the next tile before step 15).
-  float px[2][kIn], xn[2][kIn];
+  float px[2][kIn];
+  [[maybe_unused]] float xn[2][kIn];
   int64_t p_r0 = (int64_t)blockIdx.x * kSplitRows;
-  // h1 stores: uniform (scalar) tile base + one per-lane 32-bit offset.
+  // Addresses: uniform (scalar) tile base + one per-lane 32-bit offset -- 64-bit
+  // per-lane pointers cost registers the matrix loop does not have.
   const unsigned lane_off = prow * kHidden + 4 * jq;
   auto rows_from = [&](int64_t r0) {
     const int64_t left = m - r0;
     return left <= 0 ? 0 : left < kSplitRows ? (int)left : kSplitRows;
   };
   int p_rows = rows_from(p_r0);
-  auto load_x = [&](float (&dst)[2][kIn], int64_t r0) {
+  auto load_x = [&](float (&dst)[2][kIn], int64_t r0) {  // (uniform base + 32-bit lane offsets: see lane_off)
+    const int rows = rows_from(r0);
+    const float *base = x + r0 * d_in;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int64_t row = r0 + prow + 64 * u;
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) dst[u][i] = (row < m && i < d_in) ? x[row * d_in + i] : 0.0f;
+      for (int i = 0; i < kIn; ++i)
+        dst[u][i] = (prow + 64 * u < rows && i < d_in) ? base[(unsigned)((prow + 64 * u) * d_in + i)] : 0.0f;
     }
   };
+  // (wide observations: the next tile's rows are loaded at the tile switch instead of
+  // a tile ahead -- the prefetch registers are what spilled)
+  constexpr bool kPrefetchX = kIn <= 2;
   load_x(px, p_r0);
-  load_x(xn, p_r0 + stride * kSplitRows);
+  if constexpr (kPrefetchX) load_x(xn, p_r0 + stride * kSplitRows);
 
   // Chunk `ks` of the producer's tile -> stage `stage`.
   auto request_b = [&](int ks, int stage) {
@@ -273,40 +280,37 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     }
   };
   // planes[u][p]: row prow + 64u, plane p: this lane's four k as two packed pairs.
+  const __amdgpu_buffer_rsrc_t w1rsrc = buffer_rsrc(w1, kHidden * d_in * 4), b1rsrc = buffer_rsrc(b1, kHidden * 4);
   auto produce_a = [&](int ks, u32x2 (&planes)[2][3]) {
-    const int k0 = 16 * ks + 4 * jq;
-    float bv[4], wv[4][kIn];
-    {
-      const float4 t = *reinterpret_cast<const float4 *>(b1 + k0);
-      bv[0] = t.x, bv[1] = t.y, bv[2] = t.z, bv[3] = t.w;
-    }
-    if constexpr (DIN > 0) {  // four rows of W1 = kIn aligned 16-byte vectors
-      float flat[4 * kIn];
+    // Layer 1 for this lane's four k of its two rows, two k at a time (so that only
+    // two rows of W1 are in registers at once: wide observations have none to spare).
+    f32x4 hrow[2];
 #pragma unroll
-      for (int v4 = 0; v4 < kIn; ++v4) {
-        const float4 t = reinterpret_cast<const float4 *>(w1 + k0 * kIn)[v4];
-        flat[4 * v4] = t.x, flat[4 * v4 + 1] = t.y, flat[4 * v4 + 2] = t.z, flat[4 * v4 + 3] = t.w;
+    for (int ep = 0; ep < 4; ep += 2) {
+      float bv[2], wv[2][kIn];
+      // (through descriptors: the per-lane part of the address is one constant register,
+      // the step-dependent part a scalar -- a strength-reduced 64-bit per-lane pointer
+      // per array was what spilled for wide observations)
+#pragma unroll
+      for (int ee = 0; ee < 2; ++ee) {
+        bv[ee] = buffer_load_f32(b1rsrc, 4 * jq * 4, (16 * ks + ep + ee) * 4);
+#pragma unroll
+        for (int i = 0; i < kIn; ++i)
+          wv[ee][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(w1rsrc, 4 * jq * d_in * 4, ((16 * ks + ep + ee) * d_in + i) * 4) : 0.0f;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int i = 0; i < kIn; ++i) wv[e][i] = flat[e * kIn + i];
-    } else {
+        for (int ee = 0; ee < 2; ++ee) {
+          float v = bv[ee];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < kIn; ++i) wv[e][i] = i < d_in ? w1[(k0 + e) * d_in + i] : 0.0f;
+          for (int i = 0; i < kIn; ++i) v = __builtin_fmaf(px[u][i], wv[ee][i], v);
+          hrow[u][ep + ee] = relu1(v);
+        }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      f32x4 h;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = bv[e];
-#pragma unroll
-        for (int i = 0; i < kIn; ++i) v = __builtin_fmaf(px[u][i], wv[e][i], v);
-        h[e] = relu1(v);
-      }
+      const f32x4 h = hrow[u];
       if constexpr (SAVE && !(kSplitDiagSkip & 32)) {
         // (a plain guarded store: a loop-carried buffer descriptor -- one per producer
         // tile -- was miscompiled, its size word not following the tile)
@@ -368,13 +372,17 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
                                               : nt == 2 ? lds_read_b128<7 * 1024>(br)
                                                         : lds_read_b128<10 * 1024>(br);
     if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < kIn; ++i) px[u][i] = xn[u][i];
       p_r0 += stride * kSplitRows;
       p_rows = rows_from(p_r0);
-      load_x(xn, p_r0 + stride * kSplitRows);
+      if constexpr (kPrefetchX) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) px[u][i] = xn[u][i];
+        load_x(xn, p_r0 + stride * kSplitRows);
+      } else {
+        load_x(px, p_r0);
+      }
     }
     // The next chunk's arithmetic is left to the scheduler to interleave with the
     // first matrix group (VALU instructions issue beside bf16 MFMAs for free);
@@ -496,9 +504,9 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
         if (save_gate2 != nullptr) {
           const int row = 64 * wr + 32 * mt + l32;
           if (row < rows) {
-            uint32_t *dst = save_gate2 + (r0 + row) * 8 + 4 * wc + hh;
-            dst[0] = (uint32_t)gate_words[0];
-            dst[2] = (uint32_t)gate_words[1];
+            uint32_t *dst = save_gate2 + r0 * 8;  // uniform base, 32-bit lane offset
+            dst[(unsigned)(row * 8 + 4 * wc + hh)] = (uint32_t)gate_words[0];
+            dst[(unsigned)(row * 8 + 4 * wc + hh + 2)] = (uint32_t)gate_words[1];
           }
         }
       }
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     for (int idx = 64 * wave + lane_id(); idx < kSplitRows * n_out; idx += kBlock) {
       const int row = idx / n_out, q = idx - row * n_out;
       const float v = lds_read_b32(outp + (row * kOut + q) * 4) + lds_read_b32(outp + ((kSplitRows + row) * kOut + q) * 4);
-      if (row < rows) out[(r0 + row) * n_out + q] = v + b3[q];
+      if (row < rows) (out + r0 * n_out)[(unsigned)idx] = v + b3[q];
     }
     // (the next tile's first head partials are written a full tile later, behind
     // sixteen barriers: no extra barrier needed here)
@@ -665,18 +673,14 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   };
   // hv: h2 values (use_bits false) -- or unused; from_regs: chunk 0 of a tile whose
   // gate block has not landed yet takes its bits from g0.
+  const __amdgpu_buffer_rsrc_t w3rsrc = buffer_rsrc(w3, n_out * kHidden * 4);
   auto produce_a = [&](const float4 (&hv)[2], int ks, u32x2 (&planes)[2][3], bool from_regs = false) {
-    const int k0 = 16 * ks + 4 * jq;
-    float wv[kOut][4];
+    float wv[kOut][4];  // W3[q][16 ks + 4 jq + e], through a descriptor (see the forward kernel's producer)
 #pragma unroll
-    for (int q = 0; q < kOut; ++q) {
-      if (NOUT > 0 ? q < NOUT : q < n_out) {
-        const float4 t = *reinterpret_cast<const float4 *>(w3 + q * kHidden + k0);
-        wv[q][0] = t.x, wv[q][1] = t.y, wv[q][2] = t.z, wv[q][3] = t.w;
-      } else {
-        wv[q][0] = wv[q][1] = wv[q][2] = wv[q][3] = 0.0f;
-      }
-    }
+    for (int q = 0; q < kOut; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        wv[q][e] = (NOUT > 0 ? q < NOUT : q < n_out) ? buffer_load_f32(w3rsrc, 4 * jq * 4, (q * kHidden + 16 * ks + e) * 4) : 0.0f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const float hval[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
@@ -1009,6 +1013,7 @@ static int dispatch_backward_split_nout(int n_out, int grid, hipStream_t s, cons
   switch (n_out) {
     case 1: return launch_backward_split<DIN, 1>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
     case 2: return launch_backward_split<DIN, 2>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
+    case 3: return launch_backward_split<DIN, 3>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
     default: return RL8_ESIZE;
   }
 }
@@ -1340,6 +1345,8 @@ RL8_API int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in,
   switch (d_in) {
     case 1: return dispatch_forward_split_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
     case 2: return dispatch_forward_split_nout<2>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
+    case 3: return dispatch_forward_split_nout<3>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
+    case 5: return dispatch_forward_split_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
     default: return RL8_ESIZE;
   }
 }
@@ -1350,7 +1357,7 @@ RL8_API int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in,
 // scratch (tests/test_kernel_resources.py holds the list to that); other widths
 // use the fp32-MFMA kernels.
 RL8_API int rl8_mlp_forward_split_supports(int d_in, int n_out) {
-  return (d_in == 1 || d_in == 2) && n_out >= 1 && n_out <= 3;
+  return (d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5) && n_out >= 1 && n_out <= 3;
 }
 
 static void fused_backward_grids(int64_t m, int *g1, int *g2);
@@ -1374,12 +1381,15 @@ RL8_API int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, co
   hipStream_t s = (hipStream_t)stream;
   switch (d_in) {
     case 1: return dispatch_backward_split_nout<1>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows, gate2);
+    case 2: return dispatch_backward_split_nout<2>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows, gate2);
+    case 3: return dispatch_backward_split_nout<3>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows, gate2);
+    case 5: return dispatch_backward_split_nout<5>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows, gate2);
     default: return RL8_ESIZE;  // rl8_mlp_backward_split_supports(): other widths use rl8_mlp_tower_backward_f32
   }
 }
 
 RL8_API int rl8_mlp_backward_split_supports(int d_in, int n_out) {
-  return d_in == 1 && (n_out == 1 || n_out == 2);  // spill-free widths only (see rl8_mlp_forward_split_supports)
+  return rl8_mlp_forward_split_supports(d_in, n_out);  // spill-free widths only
 }
 
 /* dW2 (+)= dZ2^T h1 with h1 recomputed from the observations (see the kernel). */
@@ -1427,8 +1437,14 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
   const WgradFusedArgs fused{dout, w3, partials, stride, g1};
-  const int status = n_out == 1 ? launch_wgrad_fused<1, 1>(g2, s, h2, x, w1, b1, m, d_in, workspace, fused)
-                                : launch_wgrad_fused<1, 2>(g2, s, h2, x, w1, b1, m, d_in, workspace, fused);
+  int status = RL8_ESIZE;
+#define RL8_WGRAD_FUSED(D, N) \
+  if (d_in == D && n_out == N) status = launch_wgrad_fused<D, N>(g2, s, h2, x, w1, b1, m, d_in, workspace, fused);
+  RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3)
+  RL8_WGRAD_FUSED(2, 1) RL8_WGRAD_FUSED(2, 2) RL8_WGRAD_FUSED(2, 3)
+  RL8_WGRAD_FUSED(3, 1) RL8_WGRAD_FUSED(3, 2) RL8_WGRAD_FUSED(3, 3)
+  RL8_WGRAD_FUSED(5, 1) RL8_WGRAD_FUSED(5, 2) RL8_WGRAD_FUSED(5, 3)
+#undef RL8_WGRAD_FUSED
   if (status != 0) return status;
   mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / 4 / kBlock, kBlock, 0, s>>>(workspace, g2, dw2_out, 0);
   return launch_status();

@@ -73,4 +73,4 @@ def test_compiled_split_kernels_resources(tmp_path):
             assert scratch == 0, (name, scratch)
             assert vgprs <= 256, (name, vgprs)
             checked += 1
-    assert checked >= 12 + 2 + 5
+    assert checked >= 24 + 12 + 5 + 12

@@ -54,8 +54,8 @@ def test_split_planes_reconstruct_the_weights_exactly():
         assert torch.equal(planes, want)
 
 
-@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (127, 1, 1), (128, 1, 2), (129, 2, 3), (1000, 2, 1), (4097, 1, 3),
-                                          (5000, 2, 2), (70_001, 1, 2)])
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (127, 1, 1), (128, 1, 2), (129, 2, 3), (1000, 5, 3), (4097, 1, 3),
+                                          (5000, 3, 2), (70_001, 1, 2), (33_333, 5, 1), (20_000, 2, 2)])
 def test_forward_split_is_fp32_accurate(m, d_in, n_out):
     assert hip.mlp_forward_split_supports(d_in, n_out)
     g = torch.Generator(device=DEV).manual_seed(m + d_in)
@@ -93,8 +93,8 @@ def test_forward_split_is_fp32_accurate(m, d_in, n_out):
     assert torch.equal(out, out5) and torch.equal(gate.to(torch.int64) & 0xFFFFFFFF, want_words)
 
 
-@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 1, 2), (4097, 1, 1), (40_000, 1, 2), (9000, 1, 1),
-                                          (33_000, 1, 2)])
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 5, 3), (4097, 3, 2), (40_000, 1, 2), (9000, 2, 1),
+                                          (33_000, 1, 2), (33_000, 5, 3), (20_000, 3, 1), (16_500, 2, 3)])
 def test_backward_split_matches_fp64(m, d_in, n_out):
     """Against an fp64 evaluation of the backward formulas on the SAVED activations
     (the ReLU gates are part of the input of a backward pass: an autograd run in
@@ -136,36 +136,39 @@ def test_backward_split_matches_fp64(m, d_in, n_out):
 def test_unsupported_widths_are_refused_not_miscomputed():
     """Only widths whose kernels compile without scratch are offered
     (tests/test_kernel_resources.py); anything else must fail loudly."""
-    assert not hip.mlp_backward_split_supports(5, 3) and not hip.mlp_forward_split_supports(5, 3)
-    x = torch.zeros(256, 5, device=DEV)
+    assert not hip.mlp_backward_split_supports(7, 2) and not hip.mlp_forward_split_supports(4, 1)
+    assert not hip.mlp_forward_split_supports(1, 4)
+    x = torch.zeros(256, 7, device=DEV)
     h = torch.zeros(256, 256, device=DEV)
-    w5, b = torch.zeros(256, 5, device=DEV), torch.zeros(256, device=DEV)
+    w7, b = torch.zeros(256, 7, device=DEV), torch.zeros(256, device=DEV)
     w3, b3 = torch.zeros(3, 256, device=DEV), torch.zeros(3, device=DEV)
     w2 = torch.zeros(256, 256, device=DEV)
     with pytest.raises(ValueError):
-        hip.mlp_tower_backward(x, h, h, torch.zeros(256, 3, device=DEV), hip.mlp_pack_w2_split(w2, transposed=True), w3, w5, b)
+        hip.mlp_tower_backward(x, h, h, torch.zeros(256, 3, device=DEV), hip.mlp_pack_w2_split(w2, transposed=True), w3, w7, b)
     with pytest.raises(ValueError):
-        hip.mlp_tower_forward_split(x, w5, b, hip.mlp_pack_w2_split(w2), b, w3, b3)
+        hip.mlp_tower_forward_split(x, w7, b, hip.mlp_pack_w2_split(w2), b, w3, b3)
 
 
 def test_wider_towers_mix_fp32_and_split_kernels():
-    """CartPole's tower (5 -> 256 -> 256 -> 3): forward and data-gradient on the
-    fp32-MFMA kernels, weight gradient on the bf16-plane kernel; must match eager."""
+    """CartPole's tower (5 -> 256 -> 256 -> 3) through the fused autograd function --
+    and an unlisted width (7 -> 256 -> 256 -> 2: fp32-MFMA forward / data gradient,
+    bf16-plane weight gradient); both must match eager."""
     from rl8_amd.nn import fused_mlp
 
     torch.manual_seed(6)
-    mlp = torch.nn.Sequential(torch.nn.Linear(5, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
-    trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
-    head = torch.nn.Linear(256, 3).to(DEV)
-    x = torch.randn(3000, 5, device=DEV)
-    wts = torch.linspace(-1, 1, 3, device=DEV)
-    ((fused_mlp.tower_forward(trunk, [head], x) * wts).sum() / 3000).backward()
-    got = {n: p.grad.clone() for n, p in list(trunk.named_parameters()) + list(head.named_parameters())}
-    for p in list(trunk.parameters()) + list(head.parameters()):
-        p.grad = None
-    ((head(trunk(x)) * wts).sum() / 3000).backward()
-    for (n, p) in list(trunk.named_parameters()) + list(head.named_parameters()):
-        assert _rel(got[n], p.grad.double()) < 2e-5, n
+    for d_in, n_out in ((5, 3), (7, 2)):
+        mlp = torch.nn.Sequential(torch.nn.Linear(d_in, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
+        trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
+        head = torch.nn.Linear(256, n_out).to(DEV)
+        x = torch.randn(3000, d_in, device=DEV)
+        wts = torch.linspace(-1, 1, n_out, device=DEV)
+        ((fused_mlp.tower_forward(trunk, [head], x) * wts).sum() / 3000).backward()
+        got = {n: p.grad.clone() for n, p in list(trunk.named_parameters()) + list(head.named_parameters())}
+        for p in list(trunk.parameters()) + list(head.parameters()):
+            p.grad = None
+        ((head(trunk(x)) * wts).sum() / 3000).backward()
+        for (n, p) in list(trunk.named_parameters()) + list(head.named_parameters()):
+            assert _rel(got[n], p.grad.double()) < 2e-5, (d_in, n)
 
 
 @pytest.mark.parametrize("m,d_in", [(1, 1), (15, 1), (16, 2), (17, 5), (1000, 3), (16384 + 7, 1), (300_000, 1), (5000, 9)])
