@@ -12,7 +12,7 @@
 // -- six bf16 MFMAs per 16 k instead of eight fp32 MFMAs of 1/16 the rate.  The
 // dropped terms (am*bl, al*bm, al*bl) are below one fp32 ulp of the product; the
 // measured error of a K=256 dot product against fp64 is the same as that of an
-// fp32 fma chain (DESIGN.md section 3.8).  This is NOT a bf16 tower: inputs,
+// fp32 fma chain (DESIGN.md section 3.1).  This is NOT a bf16 tower: inputs,
 // outputs, saved activations and accumulation are fp32.
 //
 // Shape.  Both operands go through LDS, K-chunked, because at this rate the
@@ -681,14 +681,19 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         wv[q][e] = (NOUT > 0 ? q < NOUT : q < n_out) ? buffer_load_f32(w3rsrc, 4 * jq * 4, (q * kHidden + 16 * ks + e) * 4) : 0.0f;
+    // gate words of both rows: the two LDS reads back to back, one wait
+    uint32_t gword[2] = {g0[0], g0[1]};
+    if (use_bits && !from_regs) {
+      const unsigned ga = gate_lds + (prow * 8 + (ks >> 1)) * 4;
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(gword[0]), "=&v"(gword[1])
+                   : "v"(ga)
+                   : "memory");
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const float hval[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
-      uint32_t nibble = 0;
-      if (use_bits) {
-        const uint32_t word = from_regs ? g0[u] : __float_as_uint(lds_read_b32(gate_lds + ((prow + 64 * u) * 8 + (ks >> 1)) * 4));
-        nibble = word >> (16 * (ks & 1) + 4 * jq);
-      }
+      const uint32_t nibble = gword[u] >> (16 * (ks & 1) + 4 * jq);
       f32x4 dz;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
