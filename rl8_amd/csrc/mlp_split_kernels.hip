@@ -285,28 +285,51 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     // Layer 1 for this lane's four k of its two rows, two k at a time (so that only
     // two rows of W1 are in registers at once: wide observations have none to spare).
     f32x4 hrow[2];
+    if constexpr (DIN == 1 || DIN == 2) {
+      // narrow observations: the lane's four rows of W1 and b1 are 1 + kIn aligned 16-byte
+      // vectors (uniform base + 32-bit index: no per-lane 64-bit pointer)
+      const unsigned v = 4 * ks + jq;
+      const float4 bt = reinterpret_cast<const float4 *>(b1)[v];
+      const float bv[4] = {bt.x, bt.y, bt.z, bt.w};
+      float wflat[4 * kIn];
 #pragma unroll
-    for (int ep = 0; ep < 4; ep += 2) {
-      float bv[2], wv[2][kIn];
-      // (through descriptors: the per-lane part of the address is one constant register,
-      // the step-dependent part a scalar -- a strength-reduced 64-bit per-lane pointer
-      // per array was what spilled for wide observations)
-#pragma unroll
-      for (int ee = 0; ee < 2; ++ee) {
-        bv[ee] = buffer_load_f32(b1rsrc, 4 * jq * 4, (16 * ks + ep + ee) * 4);
-#pragma unroll
-        for (int i = 0; i < kIn; ++i)
-          wv[ee][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(w1rsrc, 4 * jq * d_in * 4, ((16 * ks + ep + ee) * d_in + i) * 4) : 0.0f;
+      for (int v4 = 0; v4 < kIn; ++v4) {
+        const float4 t = reinterpret_cast<const float4 *>(w1)[v * kIn + v4];
+        wflat[4 * v4] = t.x, wflat[4 * v4 + 1] = t.y, wflat[4 * v4 + 2] = t.z, wflat[4 * v4 + 3] = t.w;
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int ee = 0; ee < 2; ++ee) {
-          float v = bv[ee];
+        for (int e = 0; e < 4; ++e) {
+          float acc1 = bv[e];
 #pragma unroll
-          for (int i = 0; i < kIn; ++i) v = __builtin_fmaf(px[u][i], wv[ee][i], v);
-          hrow[u][ep + ee] = relu1(v);
+          for (int i = 0; i < kIn; ++i) acc1 = __builtin_fmaf(px[u][i], wflat[e * kIn + i], acc1);
+          hrow[u][e] = relu1(acc1);
         }
+    } else {
+#pragma unroll
+      for (int ep = 0; ep < 4; ep += 2) {
+        float bv[2], wv[2][kIn];
+        // (through descriptors: the per-lane part of the address is one constant register,
+        // the step-dependent part a scalar -- a strength-reduced 64-bit per-lane pointer
+        // per array was what spilled for wide observations)
+#pragma unroll
+        for (int ee = 0; ee < 2; ++ee) {
+          bv[ee] = buffer_load_f32(b1rsrc, 4 * jq * 4, (16 * ks + ep + ee) * 4);
+#pragma unroll
+          for (int i = 0; i < kIn; ++i)
+            wv[ee][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(w1rsrc, 4 * jq * d_in * 4, ((16 * ks + ep + ee) * d_in + i) * 4) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int ee = 0; ee < 2; ++ee) {
+            float v = bv[ee];
+#pragma unroll
+            for (int i = 0; i < kIn; ++i) v = __builtin_fmaf(px[u][i], wv[ee][i], v);
+            hrow[u][ep + ee] = relu1(v);
+          }
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -673,14 +696,17 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   };
   // hv: h2 values (use_bits false) -- or unused; from_regs: chunk 0 of a tile whose
   // gate block has not landed yet takes its bits from g0.
-  const __amdgpu_buffer_rsrc_t w3rsrc = buffer_rsrc(w3, n_out * kHidden * 4);
   auto produce_a = [&](const float4 (&hv)[2], int ks, u32x2 (&planes)[2][3], bool from_regs = false) {
-    float wv[kOut][4];  // W3[q][16 ks + 4 jq + e], through a descriptor (see the forward kernel's producer)
+    float wv[kOut][4];  // W3[q][16 ks + 4 jq + e]: one aligned 16-byte vector per output (uniform base + 32-bit index)
 #pragma unroll
-    for (int q = 0; q < kOut; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        wv[q][e] = (NOUT > 0 ? q < NOUT : q < n_out) ? buffer_load_f32(w3rsrc, 4 * jq * 4, (q * kHidden + 16 * ks + e) * 4) : 0.0f;
+    for (int q = 0; q < kOut; ++q) {
+      if (NOUT > 0 ? q < NOUT : q < n_out) {
+        const float4 t = reinterpret_cast<const float4 *>(w3)[(unsigned)(q * (kHidden / 4) + 4 * ks + jq)];
+        wv[q][0] = t.x, wv[q][1] = t.y, wv[q][2] = t.z, wv[q][3] = t.w;
+      } else {
+        wv[q][0] = wv[q][1] = wv[q][2] = wv[q][3] = 0.0f;
+      }
+    }
     // gate words of both rows: the two LDS reads back to back, one wait
     uint32_t gword[2] = {g0[0], g0[1]};
     if (use_bits && !from_regs) {
