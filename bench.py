@@ -292,8 +292,11 @@ def main() -> None:
                 "flop_per_launch": top["executed_bf16_flop_per_launch"],
                 "flop_definition": "6 bf16 plane products x 2*256*256 per row (fp32 operands split exactly into"
                                    " 3 bf16 planes, fp32 accumulate)",
-                "f32_equivalent_TFLOPs": top["achieved_TFLOPs"],
+                "f32_equivalent_TFLOPs": top["achieved_TFLOPs"],   # the algorithm's fp32 FLOP / time
                 "f32_mfma_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+                "f32_equivalent_frac_of_f32_mfma_peak": top["frac_of_f32_mfma_peak"],  # > 1: beyond the fp32 matrix roofline
+                "bf16_sustained_TFLOPs_measured": 1750.0,          # tools/probes/bf16_split_probe.hip, changing operands
+                "frac_of_sustained": round(top["executed_bf16_TFLOPs"] / 1750.0, 4),
                 "algorithmic_flop_per_launch": top["algorithmic_flop_per_launch"],
                 "avg_launch_ms": top["avg_ms"],
                 "launches": top["launches"],
