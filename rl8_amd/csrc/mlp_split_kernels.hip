@@ -466,7 +466,9 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     // store = two 128-byte row segments); head = per-lane partial over this
     // lane's four columns, summed across the half-wave with DPP adds, the two
     // column halves of the workgroup meeting in LDS.
-    const __amdgpu_buffer_rsrc_t h2rsrc = buffer_rsrc(SAVE ? save_h2 + r0 * kHidden : nullptr, rows * kHidden * 4);
+    // (tuning builds, bit 4096: every tile's h2 lands on the first tile's lines -- the stores are issued but stay in L2)
+    const __amdgpu_buffer_rsrc_t h2rsrc =
+        buffer_rsrc(SAVE ? save_h2 + ((kSplitDiagSkip & 4096) ? (r0 & 0x1ffff) : r0) * kHidden : nullptr, rows * kHidden * 4);
     const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
     const unsigned outp = lds_offset(smem) + 2 * kSplitStageBytes;
     // This lane's four output columns (re-read per tile -- L1 hits -- rather than

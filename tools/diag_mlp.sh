@@ -2,7 +2,7 @@
 # Kernel-tuning aid: experimental builds of librl8_amd.so (same ABI) into build_diag/.
 #   tools/diag_mlp.sh 64 128 256   one memory stream of a tower kernel compiled out
 #                                  (RL8_DIAG_SKIP bits, see mlp_kernels.hip; mlp_split_kernels.hip: 8 h2 stores,
-#                                  32 h1 stores, 64 h2 loads, 128 dZ2 stores, 2048 no matrix work), timed with
+#                                  32 h1 stores, 64 h2 loads, 128 dZ2 stores, 2048 no matrix work, 4096 h2 stores kept in L2), timed with
 #       RL8_AMD_LIBRARY=build_diag/librl8_amd_skip<bits>.so python tools/kernel_microbench.py --only mlp_tower_backward_fused
 #   tools/diag_mlp.sh trace        phase timestamps compiled in, read with tools/phase_trace.py
 set -e
