@@ -227,15 +227,17 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;  // rows [64 wr, +64), columns [128 wc, +128)
-  // Producer role: lanes 4i..4i+3 hold the four quarter-fragments (four k each) of
-  // rows i and i + 64 of the macro tile, so that a wave's h1 store covers 64
-  // contiguous bytes per row (16 rows per instruction, not 64 scattered ones).
-  const int jq = tid & 3, prow = tid >> 2;
+  // Producer role: row `prow` of the macro tile and k-half `pkh` of every step; the
+  // k-half is wave-uniform, so the eight rows of W1 / b1 a step needs come through
+  // the scalar cache (no vector loads, no registers) and are used as scalar operands.
+  // (Lanes 4i..4i+3 = one row -- 64 contiguous bytes per row for the h1 stores -- was
+  // tried while h1 was still stored; it measured no faster and needs per-lane weights.)
+  const int prow = tid & 127, pkh = wave >> 1;
 
   // Per-lane LDS addresses (stage 0; stage 1 = + kSplitStageBytes).
   const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
   const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
-  const unsigned a_write = lds0 + (jq >> 1) * kSplitKhStride + prow * 16 + (jq & 1) * 8;
+  const unsigned a_write = lds0 + pkh * kSplitKhStride + prow * 16;
   const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2s, kSplitPackedBytes);
 
   const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
@@ -243,29 +245,23 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 
   // Producer state: the tile whose h1 chunks are being produced (runs one step
   // ahead of the consumer, so it moves to the next tile before step 15).
-  float px[2][kIn];
-  [[maybe_unused]] float xn[2][kIn];
+  float px[kIn];
+  [[maybe_unused]] float xn[kIn];
   int64_t p_r0 = (int64_t)blockIdx.x * kSplitRows;
-  // Addresses: uniform (scalar) tile base + one per-lane 32-bit offset -- 64-bit
-  // per-lane pointers cost registers the matrix loop does not have.
-  const unsigned lane_off = prow * kHidden + 4 * jq;
   auto rows_from = [&](int64_t r0) {
     const int64_t left = m - r0;
     return left <= 0 ? 0 : left < kSplitRows ? (int)left : kSplitRows;
   };
   int p_rows = rows_from(p_r0);
-  auto load_x = [&](float (&dst)[2][kIn], int64_t r0) {  // (uniform base + 32-bit lane offsets: see lane_off)
+  // (addresses: uniform tile base + 32-bit lane offset -- 64-bit per-lane pointers cost
+  // registers the matrix loop does not have)
+  auto load_x = [&](float (&dst)[kIn], int64_t r0) {
     const int rows = rows_from(r0);
     const float *base = x + r0 * d_in;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-#pragma unroll
-      for (int i = 0; i < kIn; ++i)
-        dst[u][i] = (prow + 64 * u < rows && i < d_in) ? base[(unsigned)((prow + 64 * u) * d_in + i)] : 0.0f;
-    }
+    for (int i = 0; i < kIn; ++i) dst[i] = (prow < rows && i < d_in) ? base[(unsigned)(prow * d_in + i)] : 0.0f;
   };
-  // (wide observations: the next tile's rows are loaded at the tile switch instead of
-  // a tile ahead -- the prefetch registers are what spilled)
+  // (wide observations: the next tile's row is loaded at the tile switch instead of a tile ahead)
   constexpr bool kPrefetchX = kIn <= 2;
   load_x(px, p_r0);
   if constexpr (kPrefetchX) load_x(xn, p_r0 + stride * kSplitRows);
@@ -279,85 +275,39 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
                                                16, lane * 16, (ks * 24 + block) * 1024, 0, 0);
     }
   };
-  // planes[u][p]: row prow + 64u, plane p: this lane's four k as two packed pairs.
-  const __amdgpu_buffer_rsrc_t w1rsrc = buffer_rsrc(w1, kHidden * d_in * 4), b1rsrc = buffer_rsrc(b1, kHidden * 4);
-  auto produce_a = [&](int ks, u32x2 (&planes)[2][3]) {
-    // Layer 1 for this lane's four k of its two rows, two k at a time (so that only
-    // two rows of W1 are in registers at once: wide observations have none to spare).
-    f32x4 hrow[2];
-    if constexpr (DIN == 1 || DIN == 2) {
-      // narrow observations: the lane's four rows of W1 and b1 are 1 + kIn aligned 16-byte
-      // vectors (uniform base + 32-bit index: no per-lane 64-bit pointer)
-      const unsigned v = 4 * ks + jq;
-      const float4 bt = reinterpret_cast<const float4 *>(b1)[v];
-      const float bv[4] = {bt.x, bt.y, bt.z, bt.w};
-      float wflat[4 * kIn];
+  // planes[p]: this thread's fragment (row prow, eight k) of plane p.
+  auto produce_a = [&](int ks, u32x4 (&planes)[3]) {
+    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);
+    float h[8];
 #pragma unroll
-      for (int v4 = 0; v4 < kIn; ++v4) {
-        const float4 t = reinterpret_cast<const float4 *>(w1)[v * kIn + v4];
-        wflat[4 * v4] = t.x, wflat[4 * v4 + 1] = t.y, wflat[4 * v4 + 2] = t.z, wflat[4 * v4 + 3] = t.w;
-      }
+    for (int e = 0; e < 8; ++e) {
+      float v = b1[kb + e];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float acc1 = bv[e];
-#pragma unroll
-          for (int i = 0; i < kIn; ++i) acc1 = __builtin_fmaf(px[u][i], wflat[e * kIn + i], acc1);
-          hrow[u][e] = relu1(acc1);
-        }
-    } else {
-#pragma unroll
-      for (int ep = 0; ep < 4; ep += 2) {
-        float bv[2], wv[2][kIn];
-        // (through descriptors: the per-lane part of the address is one constant register,
-        // the step-dependent part a scalar -- a strength-reduced 64-bit per-lane pointer
-        // per array was what spilled for wide observations)
-#pragma unroll
-        for (int ee = 0; ee < 2; ++ee) {
-          bv[ee] = buffer_load_f32(b1rsrc, 4 * jq * 4, (16 * ks + ep + ee) * 4);
-#pragma unroll
-          for (int i = 0; i < kIn; ++i)
-            wv[ee][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(w1rsrc, 4 * jq * d_in * 4, ((16 * ks + ep + ee) * d_in + i) * 4) : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int ee = 0; ee < 2; ++ee) {
-            float v = bv[ee];
-#pragma unroll
-            for (int i = 0; i < kIn; ++i) v = __builtin_fmaf(px[u][i], wv[ee][i], v);
-            hrow[u][ep + ee] = relu1(v);
-          }
+      for (int i = 0; i < kIn; ++i)
+        if (DIN > 0 || i < d_in) v = __builtin_fmaf(px[i], w1[(kb + e) * d_in + i], v);
+      h[e] = relu1(v);
+    }
+    if constexpr (SAVE && !(kSplitDiagSkip & 32)) {
+      if (save_h1 != nullptr && prow < p_rows) {  // (h1 is optional: the bf16-plane backward recomputes it)
+        f32x4 *dst = reinterpret_cast<f32x4 *>(save_h1 + p_r0 * kHidden + kb + (unsigned)(prow * kHidden));
+        dst[0] = f32x4{h[0], h[1], h[2], h[3]};
+        dst[1] = f32x4{h[4], h[5], h[6], h[7]};
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const f32x4 h = hrow[u];
-      if constexpr (SAVE && !(kSplitDiagSkip & 32)) {
-        // (a plain guarded store: a loop-carried buffer descriptor -- one per producer
-        // tile -- was miscompiled, its size word not following the tile)
-        if (save_h1 != nullptr && prow + 64 * u < p_rows)  // (h1 is optional: the bf16-plane backward recomputes it)
-          *reinterpret_cast<f32x4 *>(save_h1 + p_r0 * kHidden + 16 * ks + (lane_off + 64u * u * kHidden)) = h;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        uint32_t hi, mid, lo;
-        split_pair(h[e], h[e + 1], hi, mid, lo);
-        planes[u][0][e >> 1] = hi;
-        planes[u][1][e >> 1] = mid;
-        planes[u][2][e >> 1] = lo;
-      }
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t hi, mid, lo;
+      split_pair(h[e], h[e + 1], hi, mid, lo);
+      planes[0][e >> 1] = hi;
+      planes[1][e >> 1] = mid;
+      planes[2][e >> 1] = lo;
     }
   };
-  auto write_a = [&](int stage, const u32x2 (&planes)[2][3]) {
+  auto write_a = [&](int stage, const u32x4 (&planes)[3]) {
     const unsigned addr = a_write + stage * kSplitStageBytes;
-    lds_write_b64<0>(addr, planes[0][0]);
-    lds_write_b64<kSplitPlaneStride>(addr, planes[0][1]);
-    lds_write_b64<2 * kSplitPlaneStride>(addr, planes[0][2]);
-    lds_write_b64<1024>(addr, planes[1][0]);
-    lds_write_b64<kSplitPlaneStride + 1024>(addr, planes[1][1]);
-    lds_write_b64<2 * kSplitPlaneStride + 1024>(addr, planes[1][2]);
+    lds_write_b128<0>(addr, planes[0]);
+    lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
+    lds_write_b128<2 * kSplitPlaneStride>(addr, planes[2]);
   };
   auto step_barrier = [&]() {
     // vmcnt(0): the direct-to-LDS weight loads have landed (and, in-order, every
@@ -399,9 +349,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       p_rows = rows_from(p_r0);
       if constexpr (kPrefetchX) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int i = 0; i < kIn; ++i) px[u][i] = xn[u][i];
+        for (int i = 0; i < kIn; ++i) px[i] = xn[i];
         load_x(xn, p_r0 + stride * kSplitRows);
       } else {
         load_x(px, p_r0);
@@ -410,7 +358,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     // The next chunk's arithmetic is left to the scheduler to interleave with the
     // first matrix group (VALU instructions issue beside bf16 MFMAs for free);
     // its fragments go to LDS behind that group.
-    u32x2 planes[2][3];
+    u32x4 planes[3];
     produce_a(ks, planes);
     wait_lds_all(f);
     split_mma<FIRST>(f.am, f.bm, acc);
@@ -443,7 +391,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   // Prologue: chunk 0 of the first tile.
   if ((int64_t)blockIdx.x < tiles) {
     request_b(0, 0);
-    u32x2 planes[2][3];
+    u32x4 planes[3];
     produce_a(0, planes);
     write_a(0, planes);
     step_barrier();
@@ -624,17 +572,17 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int jq = tid & 3, prow = tid >> 2;  // producer role: see the forward kernel
+  const int prow = tid & 127, pkh = wave >> 1;  // producer role: row, wave-uniform k-half (see the forward kernel)
   // gate2 given: the ReLU gate of h2 comes as bits (the forward kernel's save_gate2),
   // one 4-KiB block per tile copied to LDS by direct-to-LDS loads, instead of 1 KiB
   // of h2 per row through registers a step ahead -- that HBM latency, forced to
   // fit one k-step by the step barrier's vmcnt(0), was 40 % of this kernel.
   const bool use_bits = gate2 != nullptr;
   const unsigned gate_lds = lds0 + 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4;  // [128 rows][8 words]
-  uint32_t g0[2] = {0u, 0u};  // word 0 of rows prow, prow + 64 of the NEXT tile (its chunk 0 is produced before the block lands)
+  uint32_t g0 = 0u;  // word 0 of row prow of the NEXT tile (its chunk 0 is produced before the block lands)
   const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
   const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
-  const unsigned a_write = lds0 + (jq >> 1) * kSplitKhStride + prow * 16 + (jq & 1) * 8;
+  const unsigned a_write = lds0 + pkh * kSplitKhStride + prow * 16;
   const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2ts, kSplitPackedBytes);
 
   const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
@@ -642,37 +590,33 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 
   // Producer state (one step ahead of the consumer; moves to the next tile before step 15).
   int64_t p_tile = blockIdx.x;
-  int p_rows;                      // valid rows of the producer's tile
-  float dr[2][kOut], dn[2][kOut];  // dOut of rows prow, prow + 64 of the producer's tile / the tile after
-  auto load_dout = [&](float (&dst)[2][kOut], int64_t tile) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int64_t row = tile * kSplitRows + prow + 64 * u;
-#pragma unroll
-      for (int q = 0; q < kOut; ++q) dst[u][q] = (row < m && q < n_out) ? dout[row * n_out + q] : 0.0f;
-    }
-  };
-  load_dout(dr, p_tile);
-  load_dout(dn, p_tile + stride);
-  // h2 of the chunk produced next (only without gate bits): [row u] = this lane's
-  // four columns, requested a step ahead; rows past the end read as zero (gate closed).
-  float4 hq[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-  // Addresses: a uniform (scalar) tile base plus ONE per-lane 32-bit offset shared by
-  // the h2 loads and the dZ2 stores (same [row][256] layout) -- 64-bit per-lane
-  // pointers cost registers the matrix loop does not have.
-  const unsigned lane_off = prow * kHidden + 4 * jq;
+  int p_rows;                // valid rows of the producer's tile
+  float dr[kOut], dn[kOut];  // dOut of row prow of the producer's tile / of the tile after
   auto rows_in_tile = [&](int64_t tile) {
     const int64_t left = m - tile * kSplitRows;
     return left <= 0 ? 0 : left < kSplitRows ? (int)left : kSplitRows;
   };
+  // (addresses: uniform tile base + 32-bit lane offset -- 64-bit per-lane pointers cost
+  // registers the matrix loop does not have)
+  auto load_dout = [&](float (&dst)[kOut], int64_t tile) {
+    const int rows = rows_in_tile(tile);
+    const float *base = dout + tile * kSplitRows * n_out;
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) dst[q] = (prow < rows && q < n_out) ? base[(unsigned)(prow * n_out + q)] : 0.0f;
+  };
+  load_dout(dr, p_tile);
+  load_dout(dn, p_tile + stride);
+  // h2 of the chunk produced next (only without gate bits): this thread's eight columns,
+  // requested a step ahead; rows past the end read as zero (gate closed).
+  float4 hq[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  const unsigned lane_off = prow * kHidden + 8 * pkh;
   auto load_h2 = [&](float4 (&dst)[2], int64_t tile, int ks) {
     const int rows = rows_in_tile(tile);
     const float *base = h2 + tile * (kSplitRows * kHidden) + 16 * ks;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      dst[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // (rows past the end: gate closed)
-      if (!(kSplitDiagSkip & 64) && prow + 64 * u < rows)
-        dst[u] = *reinterpret_cast<const float4 *>(base + (lane_off + 64u * u * kHidden));
+    dst[0] = dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);  // (rows past the end: gate closed)
+    if (!(kSplitDiagSkip & 64) && prow < rows) {
+      dst[0] = *reinterpret_cast<const float4 *>(base + lane_off);
+      dst[1] = *reinterpret_cast<const float4 *>(base + lane_off + 4);
     }
   };
   auto request_b = [&](int ks, int stage) {
@@ -693,67 +637,47 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   };
   auto load_g0 = [&](int64_t tile) {
     const int rows = rows_in_tile(tile);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) g0[u] = prow + 64 * u < rows ? gate2[(tile * kSplitRows + prow + 64 * u) * 8] : 0u;
+    g0 = prow < rows ? (gate2 + tile * (kSplitRows * 8))[(unsigned)(prow * 8)] : 0u;
   };
   // hv: h2 values (use_bits false) -- or unused; from_regs: chunk 0 of a tile whose
   // gate block has not landed yet takes its bits from g0.
-  auto produce_a = [&](const float4 (&hv)[2], int ks, u32x2 (&planes)[2][3], bool from_regs = false) {
-    float wv[kOut][4];  // W3[q][16 ks + 4 jq + e]: one aligned 16-byte vector per output (uniform base + 32-bit index)
+  auto produce_a = [&](const float4 (&hv)[2], int ks, u32x4 (&planes)[3], bool from_regs = false) {
+    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);  // W3[q][kb + e]: uniform, through the scalar cache
+    uint32_t gword = g0;
+    if (use_bits && !from_regs) gword = __float_as_uint(lds_read_b32(gate_lds + (prow * 8 + (ks >> 1)) * 4));
+    const uint32_t byte = gword >> (16 * (ks & 1) + 8 * pkh);
+    const float hval[8] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w};
+    float dz[8];
 #pragma unroll
-    for (int q = 0; q < kOut; ++q) {
-      if (NOUT > 0 ? q < NOUT : q < n_out) {
-        const float4 t = reinterpret_cast<const float4 *>(w3)[(unsigned)(q * (kHidden / 4) + 4 * ks + jq)];
-        wv[q][0] = t.x, wv[q][1] = t.y, wv[q][2] = t.z, wv[q][3] = t.w;
-      } else {
-        wv[q][0] = wv[q][1] = wv[q][2] = wv[q][3] = 0.0f;
+    for (int e = 0; e < 8; ++e) {
+      float g = dr[0] * w3[kb + e];
+#pragma unroll
+      for (int q = 1; q < kOut; ++q)
+        if (NOUT > 0 ? q < NOUT : q < n_out) g = __builtin_fmaf(dr[q], w3[q * kHidden + kb + e], g);
+      const bool open = use_bits ? ((byte >> e) & 1u) != 0 : hval[e] > 0.0f;
+      dz[e] = open ? g : 0.0f;
+    }
+    if constexpr (!(kSplitDiagSkip & 128)) {
+      if (dz2_out != nullptr && prow < p_rows) {  // (optional: the fused weight-gradient kernel re-forms dZ2)
+        f32x4 *dst = reinterpret_cast<f32x4 *>(dz2_out + p_tile * (kSplitRows * kHidden) + 16 * ks + lane_off);
+        dst[0] = f32x4{dz[0], dz[1], dz[2], dz[3]};
+        dst[1] = f32x4{dz[4], dz[5], dz[6], dz[7]};
       }
     }
-    // gate words of both rows: the two LDS reads back to back, one wait
-    uint32_t gword[2] = {g0[0], g0[1]};
-    if (use_bits && !from_regs) {
-      const unsigned ga = gate_lds + (prow * 8 + (ks >> 1)) * 4;
-      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(gword[0]), "=&v"(gword[1])
-                   : "v"(ga)
-                   : "memory");
-    }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const float hval[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
-      const uint32_t nibble = gword[u] >> (16 * (ks & 1) + 4 * jq);
-      f32x4 dz;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float g = dr[u][0] * wv[0][e];
-#pragma unroll
-        for (int q = 1; q < kOut; ++q)
-          if (NOUT > 0 ? q < NOUT : q < n_out) g = __builtin_fmaf(dr[u][q], wv[q][e], g);
-        const bool open = use_bits ? ((nibble >> e) & 1u) != 0 : hval[e] > 0.0f;
-        dz[e] = open ? g : 0.0f;
-      }
-      if constexpr (!(kSplitDiagSkip & 128)) {
-        if (dz2_out != nullptr && prow + 64 * u < p_rows)  // (optional: the fused weight-gradient kernel re-forms dZ2)
-          *reinterpret_cast<f32x4 *>(dz2_out + p_tile * (kSplitRows * kHidden) + 16 * ks + (lane_off + 64u * u * kHidden)) = dz;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        uint32_t hi, mid, lo;
-        split_pair(dz[e], dz[e + 1], hi, mid, lo);
-        planes[u][0][e >> 1] = hi;
-        planes[u][1][e >> 1] = mid;
-        planes[u][2][e >> 1] = lo;
-      }
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t hi, mid, lo;
+      split_pair(dz[e], dz[e + 1], hi, mid, lo);
+      planes[0][e >> 1] = hi;
+      planes[1][e >> 1] = mid;
+      planes[2][e >> 1] = lo;
     }
   };
-  auto write_a = [&](int stage, const u32x2 (&planes)[2][3]) {
+  auto write_a = [&](int stage, const u32x4 (&planes)[3]) {
     const unsigned addr = a_write + stage * kSplitStageBytes;
-    lds_write_b64<0>(addr, planes[0][0]);
-    lds_write_b64<kSplitPlaneStride>(addr, planes[0][1]);
-    lds_write_b64<2 * kSplitPlaneStride>(addr, planes[0][2]);
-    lds_write_b64<1024>(addr, planes[1][0]);
-    lds_write_b64<kSplitPlaneStride + 1024>(addr, planes[1][1]);
-    lds_write_b64<2 * kSplitPlaneStride + 1024>(addr, planes[1][2]);
+    lds_write_b128<0>(addr, planes[0]);
+    lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
+    lds_write_b128<2 * kSplitPlaneStride>(addr, planes[2]);
   };
   auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
@@ -785,9 +709,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     f.bm[3] = lds_read_b128<10 * 1024>(br);
     if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int q = 0; q < kOut; ++q) dr[u][q] = dn[u][q];
+      for (int q = 0; q < kOut; ++q) dr[q] = dn[q];
       p_tile += stride;
       p_rows = rows_in_tile(p_tile);
       load_dout(dn, p_tile + stride);
@@ -795,7 +717,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       // the new one lands by this step's barrier, chunk 0 uses g0 meanwhile
       if (use_bits) request_gate(p_tile);
     }
-    u32x2 planes[2][3];
+    u32x4 planes[3];
     produce_a(hq, ks, planes, s == kSplitSteps - 1);
     if (use_bits) {
       if (s == kSplitSteps - 3) load_g0(p_tile + stride);  // two steps ahead of its use
@@ -839,7 +761,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       load_h2(hq, p_tile, 0);
     }
     request_b(0, 0);
-    u32x2 planes[2][3];
+    u32x4 planes[3];
     produce_a(hq, 0, planes);
     write_a(0, planes);
     if (!use_bits) load_h2(hq, p_tile, 1);
