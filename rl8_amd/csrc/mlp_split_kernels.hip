@@ -94,6 +94,20 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_w2_split_kernel(const float *
   }
 }
 
+// Kernel-tuning builds only (-DRL8_SPLIT_TRACE): shader-clock stamps of the forward
+// kernel's k-steps (tile iteration 3 of every workgroup, every wave), read back with
+// rl8_debug_split_trace().  Compiled out of the shipped library.
+#ifdef RL8_SPLIT_TRACE
+__device__ unsigned long long g_split_trace[512 * 4 * 16 * 4];
+__device__ __forceinline__ void split_stamp(int iteration, int wave, int step, int slot) {
+  if (iteration == 3 && (threadIdx.x & 63) == 0)
+    g_split_trace[((blockIdx.x * 4 + wave) * 16 + step) * 4 + slot] = __builtin_amdgcn_s_memtime();
+}
+#define RL8_SPLIT_STAMP(it, w, s, slot) split_stamp(it, w, s, slot)
+#else
+#define RL8_SPLIT_STAMP(it, w, s, slot)
+#endif
+
 // ---- LDS access, invisible to the compiler's wait-count insertion -------------
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 __device__ __forceinline__ unsigned lds_offset(const void *p) {
@@ -319,6 +333,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   };
 
   f32x16 acc[2][4];
+  [[maybe_unused]] int trace_it = -1;  // (tuning builds: tile iteration, see RL8_SPLIT_STAMP)
   int64_t r0 = p_r0;  // consumer's tile
 
   // One k-step: consume stage P (chunk s) while producing chunk s+1 -- of the
@@ -327,6 +342,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     constexpr bool FIRST = decltype(first_tag)::value;
     constexpr int P = decltype(parity_tag)::value;
     const int ks = (s + 1) & (kSplitSteps - 1);
+    RL8_SPLIT_STAMP(trace_it, wave, s, 0);
     request_b(ks, P ^ 1);
     const unsigned ar = a_read + P * kSplitStageBytes, br = b_read + P * kSplitStageBytes;
     SplitFrags f;
@@ -361,6 +377,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     u32x4 planes[3];
     produce_a(ks, planes);
     wait_lds_all(f);
+    RL8_SPLIT_STAMP(trace_it, wave, s, 1);
     split_mma<FIRST>(f.am, f.bm, acc);
     split_mma<false>(f.ah, f.bm, acc);
     split_mma<false>(f.am, f.bh, acc);
@@ -381,7 +398,9 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     split_mma<false>(f.ah, f.bm, acc);
     split_mma<false>(f.am, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
+    RL8_SPLIT_STAMP(trace_it, wave, s, 2);
     step_barrier();
+    RL8_SPLIT_STAMP(trace_it, wave, s, 3);
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -398,6 +417,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   }
 
   for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
+    ++trace_it;
     r0 = tile * kSplitRows;
     const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
     do_step(T{}, P0{}, 0);
@@ -1269,6 +1289,12 @@ static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const fl
 }  // namespace rl8
 
 using namespace rl8;
+
+#ifdef RL8_SPLIT_TRACE
+RL8_API int rl8_debug_split_trace(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_split_trace), sizeof(g_split_trace));
+}
+#endif
 
 RL8_API int64_t rl8_mlp_split_packed_bytes(void) { return kSplitPackedBytes; }
 
