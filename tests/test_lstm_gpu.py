@@ -139,3 +139,28 @@ def test_fused_recurrent_model_matches_the_eager_modules():
     for k in eager[4]:
         scale = float(eager[4][k].abs().max()) + 1e-12
         assert float((fused[4][k] - eager[4][k]).abs().max()) / scale < 5e-5, k
+
+
+def test_lstm_kernels_repeat_bit_for_bit_under_load():
+    """Thirty back-to-back forward + backward runs at a config-5-like shape must
+    return the same bits (fixed summation orders; these kernels use packed fp32
+    ops beside fp32 MFMAs -- the combination that, beside bf16 MFMAs, once
+    produced wrong lanes in the tower kernels)."""
+    b, l, d_in = 8192, 4, 1
+    lstm = reference_lstm(d_in, 3)
+    g = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.randn(b, l, d_in, device=DEV, generator=g) * 3
+    h0 = torch.randn(b, 256, device=DEV, generator=g) * 0.5
+    c0 = torch.randn(b, 256, device=DEV, generator=g)
+    dhs = torch.randn(b, l, 256, device=DEV, generator=g) / (b * l)
+    packed, packed_t = pack(lstm), hip.lstm_pack_transposed(lstm.weight_hh_l0)
+
+    def run():
+        hs, hn, cn, gates, cs = hip.lstm_forward(x, h0, c0, packed, save=True)
+        grads = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, packed_t)
+        return [hs, hn, cn, gates, cs, grads["w_hh"], grads["w_ih"], grads["b"]]
+
+    first = run()
+    for trial in range(30):
+        for a, c in zip(first, run()):
+            assert torch.equal(a, c), trial
