@@ -103,9 +103,15 @@ __device__ __forceinline__ void split_stamp(int iteration, int wave, int step, i
   if (iteration == 3 && (threadIdx.x & 63) == 0)
     g_split_trace[((blockIdx.x * 4 + wave) * 16 + step) * 4 + slot] = __builtin_amdgcn_s_memtime();
 }
+__device__ unsigned long long g_split_trace_epilogue[512 * 4 * 4];
+__device__ __forceinline__ void split_stamp_epilogue(int iteration, int wave, int slot) {
+  if (iteration == 3 && (threadIdx.x & 63) == 0) g_split_trace_epilogue[(blockIdx.x * 4 + wave) * 4 + slot] = __builtin_amdgcn_s_memtime();
+}
 #define RL8_SPLIT_STAMP(it, w, s, slot) split_stamp(it, w, s, slot)
+#define RL8_SPLIT_STAMP_E(it, w, slot) split_stamp_epilogue(it, w, slot)
 #else
 #define RL8_SPLIT_STAMP(it, w, s, slot)
+#define RL8_SPLIT_STAMP_E(it, w, slot)
 #endif
 
 // ---- LDS access, invisible to the compiler's wait-count insertion -------------
@@ -212,14 +218,20 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &hi, uin
   lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
 }
 
-// Sum over the 32 lanes of each half-wave, valid in lanes 16..31 / 48..63.
-__device__ __forceinline__ float half_wave_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
-  return v;
+// One level of the sum over the 32 lanes of each half-wave (after levels 0..4 the
+// total is valid in lanes 16..31 / 48..63).  Callers run a level over a BATCH of
+// independent values: a value's five levels are a dependent chain, and one chain
+// at a time (with its LDS write behind it) cost the forward epilogue 3x its
+// instruction count in cycles.
+template <int LEVEL>
+__device__ __forceinline__ float half_wave_sum_level(float v) {
+  constexpr int ctrl = LEVEL == 0 ? 0xb1     // quad_perm [1,0,3,2]
+                       : LEVEL == 1 ? 0x4e   // quad_perm [2,3,0,1]
+                       : LEVEL == 2 ? 0x141  // row_half_mirror
+                       : LEVEL == 3 ? 0x140  // row_mirror
+                                    : 0x142; // row_bcast:15 -> rows 1, 3
+  constexpr int row_mask = LEVEL == 4 ? 0xa : 0xf;
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false));
 }
 
 constexpr int split_forward_lds_bytes(int k_out) { return 2 * kSplitStageBytes + kSplitRows * k_out * 2 * 4; }
@@ -435,6 +447,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     // lane's four columns, summed across the half-wave with DPP adds, the two
     // column halves of the workgroup meeting in LDS.
     // (tuning builds, bit 4096: every tile's h2 lands on the first tile's lines -- the stores are issued but stay in L2)
+    RL8_SPLIT_STAMP_E(trace_it, wave, 0);
     const __amdgpu_buffer_rsrc_t h2rsrc =
         buffer_rsrc(SAVE ? save_h2 + ((kSplitDiagSkip & 4096) ? (r0 & 0x1ffff) : r0) * kHidden : nullptr, rows * kHidden * 4);
     const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
@@ -454,14 +467,14 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       [[maybe_unused]] int gate_words[2] = {0, 0};
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const int j = 128 * wc + 32 * nt + l32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = relu1(acc[mt][nt][r] + b2r[nt]);
         if constexpr (SAVE && !(kSplitDiagSkip & 8)) {
+          // (spreading these stores behind the head batches below measured no faster)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
-            buffer_store_f32(acc[mt][nt][r], h2rsrc, (4 * hh * kHidden + j) * 4, sr * (kHidden * 4));
+            buffer_store_f32(acc[mt][nt][r], h2rsrc, (4 * hh * kHidden + 128 * wc + 32 * nt + l32) * 4, sr * (kHidden * 4));
           }
         }
         if constexpr (SAVE) {
@@ -503,22 +516,42 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
           }
         }
       }
+      if (mt == 1) RL8_SPLIT_STAMP_E(trace_it, wave, 1);
+      // head: eight rows at a time -- all partial products, then the five reduction
+      // levels each over the whole batch, then the LDS writes
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      for (int rb = 0; rb < 16; rb += 8) {
+        float part[8][kOut];
 #pragma unroll
-        for (int q = 0; q < kOut; ++q) {
-          if (q < n_out) {
-            float p = acc[mt][0][r] * w3r[0][q];
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int nt = 1; nt < 4; ++nt) p = __builtin_fmaf(acc[mt][nt][r], w3r[nt][q], p);
-            p = half_wave_sum(p);
-            if (l32 == 31) lds_write_b32(outp + ((wc * kSplitRows + row) * kOut + q) * 4, p);
+          for (int q = 0; q < kOut; ++q) {
+            float p = acc[mt][0][rb + u] * w3r[0][q];
+#pragma unroll
+            for (int nt = 1; nt < 4; ++nt) p = __builtin_fmaf(acc[mt][nt][rb + u], w3r[nt][q], p);
+            part[u][q] = p;
+          }
+#define RL8_HEAD_LEVEL(L)                                                  \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u)                            \
+      _Pragma("unroll") for (int q = 0; q < kOut; ++q)                     \
+          if (q < n_out) part[u][q] = half_wave_sum_level<L>(part[u][q]);
+        RL8_HEAD_LEVEL(0) RL8_HEAD_LEVEL(1) RL8_HEAD_LEVEL(2) RL8_HEAD_LEVEL(3) RL8_HEAD_LEVEL(4)
+#undef RL8_HEAD_LEVEL
+        if (l32 == 31) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int r = rb + u;
+            const int row = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < kOut; ++q)
+              if (q < n_out) lds_write_b32(outp + ((wc * kSplitRows + row) * kOut + q) * 4, part[u][q]);
           }
         }
       }
     }
+    RL8_SPLIT_STAMP_E(trace_it, wave, 2);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    RL8_SPLIT_STAMP_E(trace_it, wave, 3);
     for (int idx = 64 * wave + lane_id(); idx < kSplitRows * n_out; idx += kBlock) {
       const int row = idx / n_out, q = idx - row * n_out;
       const float v = lds_read_b32(outp + (row * kOut + q) * 4) + lds_read_b32(outp + ((kSplitRows + row) * kOut + q) * 4);
@@ -825,42 +858,47 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
       for (int i = 0; i < kIn; ++i) dw1[nt][i] = 0.0f;
     }
+    // (narrow observations: the sixteen rows a row tile needs are requested together, up
+    // front -- per batch of four, their L1 round trip sat in front of every batch)
+    constexpr int kXRows = kIn <= 2 ? 16 : 4;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int rb = 0; rb < 16; rb += 4) {
-        float xv[4][kIn];
+      for (int rx = 0; rx < 16; rx += kXRows) {
+        float xv[kXRows][kIn];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int r = rb + u;
+        for (int u = 0; u < kXRows; ++u) {
+          const int r = rx + u;
           const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
 #pragma unroll
           for (int i = 0; i < kIn; ++i)
             xv[u][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(xrsrc, (4 * hh * d_in + i) * 4, sr * d_in * 4) : 0.0f;
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          float pre[4];
+        for (int rb = 0; rb < kXRows; rb += 4)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            pre[u] = b1c[nt];
+          for (int nt = 0; nt < 4; ++nt) {
+            float pre[4];
 #pragma unroll
-            for (int i = 0; i < kIn; ++i) pre[u] = __builtin_fmaf(xv[u][i], w1c[nt][i], pre[u]);
+            for (int u = 0; u < 4; ++u) {
+              pre[u] = b1c[nt];
+#pragma unroll
+              for (int i = 0; i < kIn; ++i) pre[u] = __builtin_fmaf(xv[rb + u][i], w1c[nt][i], pre[u]);
+            }
+            unsigned long long gate[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gate[u] = positive_mask(pre[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            float dz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dz[u] = select_or_zero(gate[u], acc[mt][nt][rx + rb + u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              db1[nt] += dz[u];
+#pragma unroll
+              for (int i = 0; i < kIn; ++i) dw1[nt][i] = __builtin_fmaf(dz[u], xv[rb + u][i], dw1[nt][i]);
+            }
           }
-          unsigned long long gate[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) gate[u] = positive_mask(pre[u]);
-          __builtin_amdgcn_sched_barrier(0);
-          float dz[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) dz[u] = select_or_zero(gate[u], acc[mt][nt][rb + u]);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            db1[nt] += dz[u];
-#pragma unroll
-            for (int i = 0; i < kIn; ++i) dw1[nt][i] = __builtin_fmaf(dz[u], xv[u][i], dw1[nt][i]);
-          }
-        }
       }
     // Into the running sums, in a fixed order: the two row halves of a lane pair
     // (DPP-free: one cross-half shuffle), then the wave of rows 0..63, a barrier,
@@ -874,12 +912,26 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       if (wr == half && hh == 0) {
+        // all reads, one wait, all writes (one read-modify-write at a time is a chain of LDS round trips)
+        float cur[4][1 + kIn];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int i = 0; i < 1 + kIn; ++i)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(cur[nt][i]) : "v"(colsum + ((128 * wc + 32 * nt + l32) * (1 + kIn) + i) * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const unsigned a = colsum + (128 * wc + 32 * nt + l32) * (1 + kIn) * 4;
-          lds_write_b32(a, lds_read_b32(a) + db1[nt]);
+          float v0 = cur[nt][0];
+          asm volatile("" : "+v"(v0));  // (use behind the wait)
+          lds_write_b32(a, v0 + db1[nt]);
 #pragma unroll
-          for (int i = 0; i < kIn; ++i) lds_write_b32(a + 4 + 4 * i, lds_read_b32(a + 4 + 4 * i) + dw1[nt][i]);
+          for (int i = 0; i < kIn; ++i) {
+            float vi = cur[nt][1 + i];
+            asm volatile("" : "+v"(vi));
+            lds_write_b32(a + 4 + 4 * i, vi + dw1[nt][i]);
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1293,6 +1345,9 @@ using namespace rl8;
 #ifdef RL8_SPLIT_TRACE
 RL8_API int rl8_debug_split_trace(unsigned long long *host_dst) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_split_trace), sizeof(g_split_trace));
+}
+RL8_API int rl8_debug_split_trace_epilogue(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_split_trace_epilogue), sizeof(g_split_trace_epilogue));
 }
 #endif
 

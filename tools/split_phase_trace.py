@@ -36,3 +36,10 @@ for save in (False, True):
     print("   per-step medians (step 0..15): wait", [int(np.median(lds_wait[:, :, s])) for s in range(16)])
     print("   barrier:", [int(np.median(barrier[:, :, s])) for s in range(16)])
     print("   issue:", [int(np.median(issue[:, :, s])) for s in range(16)])
+    ebuf = (C.c_ulonglong * (512 * 4 * 4))()
+    lib.rl8_debug_split_trace_epilogue.argtypes = [C.c_void_p]
+    assert lib.rl8_debug_split_trace_epilogue(ebuf) == 0
+    e = np.frombuffer(ebuf, dtype=np.uint64).reshape(512, 4, 4).astype(np.int64)
+    end15 = t[:, :, 15, 3]
+    print("   epilogue (cycles): barrier(15) -> start", int(np.median(e[..., 0] - end15)), "| bias/ReLU/h2 stores/gate + head of the first row tile",
+          int(np.median(e[..., 1] - e[..., 0])), "| second row tile's head", int(np.median(e[..., 2] - e[..., 1])), "| barrier", int(np.median(e[..., 3] - e[..., 2])))
