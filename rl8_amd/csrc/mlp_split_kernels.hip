@@ -170,6 +170,43 @@ __device__ __forceinline__ void wait_lds_all(SplitFrags &f) {
                  "+v"(f.am[0]), "+v"(f.am[1]), "+v"(f.bm[0]), "+v"(f.bm[1]), "+v"(f.bm[2]), "+v"(f.bm[3]));
 }
 
+// lgkmcnt <= N, ordering the named fragments behind it.  LDS returns in order, so with
+// ONLY ds_reads outstanding "all but the last N" have landed; a scalar-cache load in
+// flight would break that count (it returns out of order) -- kernels using this keep
+// their s_loads in front of the step's barrier (tests/test_kernel_resources.py checks
+// the instruction stream for it).
+template <int N>
+__device__ __forceinline__ void wait_lds(u32x4 &a) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wait_lds(u32x4 &a, u32x4 &b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wait_lds(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wait_lds(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+}
+
+// Eight consecutive floats at a wave-uniform address into scalar registers; NO wait:
+// the caller's next barrier (lgkmcnt(0)) is the wait, see scalar_tie().
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+template <int OFF>
+__device__ __forceinline__ f32x8 scalar_load_x8(const float *p) {
+  f32x8 v;
+  asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(p), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void scalar_tie(f32x8 &v) { asm volatile("" : "+s"(v)); }
+// a value every lane holds alike, moved to the scalar file
+__device__ __forceinline__ float uniform_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
 template <bool FIRST>
 __device__ __forceinline__ void split_mma(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
   if constexpr ((kSplitDiagSkip & 2048) != 0) {  // tuning builds: no matrix work (one MFMA per group keeps the data flow)
@@ -197,6 +234,16 @@ __device__ __forceinline__ void split_mma(const u32x4 (&a)[2], const u32x4 (&b)[
                                                               __builtin_bit_cast(bf16x8, b[nt]), acc[mt][nt], 0, 0, 0);
       }
     }
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void split_mma_row(const u32x4 &a, const u32x4 (&b)[4], f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[nt]),
+                                                      FIRST ? zero : acc[nt], 0, 0, 0);
+  }
 }
 
 // v (fp32 pair) -> the three packed bf16 pairs (element 0 in the low half).
@@ -1138,25 +1185,78 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       planes[2][e >> 1] = lo;
     }
   };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // Observations and dOut of the eight samples a wave produces are wave-uniform: with
+  // DIN known they sit in scalar registers, fetched (kIn + kOut loads of eight floats)
+  // in front of the PREVIOUS step's barrier, so that inside a step nothing but
+  // ds_reads is in flight on lgkmcnt and the first MFMAs can go as soon as THEIR
+  // fragments are in (wait_lds<N>), not after all twelve.
+  // (the widest variants would spill with up to 64 more live scalars: they keep per-row loads)
+  constexpr bool kScalars = DIN > 0 && (FUSED == 0 || kIn + kOut <= 5);
+  constexpr int kXq = kScalars ? kIn : 1, kDq = (kScalars && FUSED > 0) ? kOut : 1;
+  [[maybe_unused]] f32x8 xq[kXq], dq[kDq];
+  auto row0_of = [&](int64_t n) { return (blockIdx.x + n * stride) * kWsChunk + 8 * kh; };
+  // ... for chunk n of this workgroup, then the step barrier.  A chunk that is not
+  // whole (the last one; the one past the end the final step "produces") takes the
+  // per-row clamped loads instead.
+  auto scalars_then_barrier = [&](int64_t n) {
+    if constexpr (kScalars) {
+      const int64_t row0 = row0_of(n);
+      if (row0 + 8 <= m) {
+        const float *px = x + row0 * kIn;
+        xq[0] = scalar_load_x8<0>(px);
+        if constexpr (kIn > 1) xq[1] = scalar_load_x8<32>(px);
+        if constexpr (kIn > 2) xq[2] = scalar_load_x8<64>(px);
+        if constexpr (kIn > 3) xq[3] = scalar_load_x8<96>(px);
+        if constexpr (kIn > 4) xq[4] = scalar_load_x8<128>(px);
+        if constexpr (FUSED > 0) {
+          const float *pd = fused.dout + row0 * kOut;
+          dq[0] = scalar_load_x8<0>(pd);
+          if constexpr (kOut > 1) dq[1] = scalar_load_x8<32>(pd);
+          if constexpr (kOut > 2) dq[2] = scalar_load_x8<64>(pd);
+        }
+        lds_barrier();
+      } else {
+        // Samples past the end are clamped to the last row: their h2 / dZ2 read as zero
+        // through the descriptor, so whatever they contribute is multiplied by zero.
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int64_t row = row0 + e < m ? row0 + e : m - 1;
+#pragma unroll
+          for (int c = 0; c < kIn; ++c) xq[(e * kIn + c) >> 3][(e * kIn + c) & 7] = uniform_f32(x[row * kIn + c]);
+          if constexpr (FUSED > 0) {
+#pragma unroll
+            for (int q = 0; q < kOut; ++q) dq[(e * kOut + q) >> 3][(e * kOut + q) & 7] = uniform_f32(fused.dout[row * kOut + q]);
+          }
+        }
+        lds_barrier();
+      }
+#pragma unroll
+      for (int i = 0; i < kXq; ++i) scalar_tie(xq[i]);
+      if constexpr (FUSED > 0) {
+#pragma unroll
+        for (int i = 0; i < kDq; ++i) scalar_tie(dq[i]);
+      }
+    } else {
+      lds_barrier();
+    }
+  };
   auto produce = [&](const float (&dzv)[8], int64_t n, u32x4 (&pa)[3], u32x4 (&pb)[3]) {
-    const int64_t chunk = blockIdx.x + n * stride;
-    // Samples past the end are clamped to the last row: their h2 / dZ2 read as zero
-    // through the descriptor, so whatever they contribute is multiplied by zero.
-    // (A variant that kept these row indices on the scalar unit -- dOut then comes
-    // through the scalar cache -- was 10 % slower here.)
+    // (runtime d_in only: per-row loads, rows past the end clamped as above)
     auto row_of = [&](int e) {
-      const int64_t row = chunk * kWsChunk + 8 * kh + e;
+      const int64_t row = row0_of(n) + e;
       return row < m ? row : m - 1;
     };
     if constexpr (FUSED > 0) {
       float dz[8];  // dzv holds h2
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int64_t row = row_of(e);
         float g = 0.0f;
 #pragma unroll
         for (int q = 0; q < kOut; ++q) {
-          const float d = fused.dout[row * kOut + q];
+          float d;
+          if constexpr (kScalars) d = dq[(e * kOut + q) >> 3][(e * kOut + q) & 7];
+          else d = fused.dout[row_of(e) * kOut + q];
           g = __builtin_fmaf(d, w3r[q], g);
           dw3a[q] = __builtin_fmaf(d, dzv[e], dw3a[q]);
         }
@@ -1170,11 +1270,12 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     float h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int64_t row = row_of(e);
       float v = b1r;
 #pragma unroll
-      for (int c = 0; c < kIn; ++c)
-        if (DIN > 0 || c < d_in) v = __builtin_fmaf(x[row * d_in + c], w1r[c], v);
+      for (int c = 0; c < kIn; ++c) {
+        if constexpr (kScalars) v = __builtin_fmaf(xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], w1r[c], v);
+        else if (c < d_in) v = __builtin_fmaf(x[row_of(e) * d_in + c], w1r[c], v);
+      }
       h[e] = relu1(v);
     }
     split8(h, pb);
@@ -1188,7 +1289,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     lds_write_b128<kWsOperandBytes + kWsPlane>(addr, pb[1]);
     lds_write_b128<kWsOperandBytes + 2 * kWsPlane>(addr, pb[2]);
   };
-  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
   f32x16 acc[2][4];
   float dzq[2][8];
@@ -1200,25 +1300,45 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     constexpr int P = decltype(parity_tag)::value;
     const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
     SplitFrags f;
+    // issue order = the order the first products need them
+    f.am[0] = lds_read_b128<kWsPlane>(ar);
+    f.bm[0] = lds_read_b128<kWsPlane>(br);
+    f.bm[1] = lds_read_b128<kWsPlane + 512>(br);
+    f.bm[2] = lds_read_b128<kWsPlane + 1024>(br);
+    f.bm[3] = lds_read_b128<kWsPlane + 1536>(br);
+    f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
     f.ah[0] = lds_read_b128<0>(ar);
     f.ah[1] = lds_read_b128<512>(ar);
     f.bh[0] = lds_read_b128<0>(br);
     f.bh[1] = lds_read_b128<512>(br);
     f.bh[2] = lds_read_b128<1024>(br);
     f.bh[3] = lds_read_b128<1536>(br);
-    f.am[0] = lds_read_b128<kWsPlane>(ar);
-    f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
-    f.bm[0] = lds_read_b128<kWsPlane>(br);
-    f.bm[1] = lds_read_b128<kWsPlane + 512>(br);
-    f.bm[2] = lds_read_b128<kWsPlane + 1024>(br);
-    f.bm[3] = lds_read_b128<kWsPlane + 1536>(br);
     u32x4 pa[3], pb[3];
-    produce(dzq[P ^ 1], n + 1, pa, pb);
-    load_dz(dzq[P], n + 2);
-    wait_lds_all(f);
-    split_mma<FIRST>(f.am, f.bm, acc);
-    split_mma<false>(f.ah, f.bm, acc);
-    split_mma<false>(f.am, f.bh, acc);
+    if constexpr (kScalars) {
+      // The first two groups of products go out as their own fragments land; the
+      // producer arithmetic is fenced behind them (it has the other forty products
+      // to hide beside) so that the compiler cannot pull all the waits to the front.
+      load_dz(dzq[P], n + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lds<7>(f.am[0], f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
+      split_mma_row<FIRST>(f.am[0], f.bm, acc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lds<6>(f.am[1]);
+      split_mma_row<FIRST>(f.am[1], f.bm, acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      produce(dzq[P ^ 1], n + 1, pa, pb);
+      wait_lds<4>(f.ah[0], f.ah[1]);
+      split_mma<false>(f.ah, f.bm, acc);
+      wait_lds<0>(f.bh[0], f.bh[1], f.bh[2], f.bh[3]);
+      split_mma<false>(f.am, f.bh, acc);
+    } else {
+      produce(dzq[P ^ 1], n + 1, pa, pb);
+      load_dz(dzq[P], n + 2);
+      wait_lds_all(f);
+      split_mma<FIRST>(f.am, f.bm, acc);
+      split_mma<false>(f.ah, f.bm, acc);
+      split_mma<false>(f.am, f.bh, acc);
+    }
     __builtin_amdgcn_sched_barrier(0);
     write_planes(P ^ 1, pa, pb);
     f.am[0] = lds_read_b128<2 * kWsPlane>(ar);
@@ -1234,7 +1354,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     split_mma<false>(f.ah, f.bm, acc);
     split_mma<false>(f.am, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
-    lds_barrier();
+    scalars_then_barrier(n + 2);
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -1244,10 +1364,11 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   {
     load_dz(dzq[0], 0);
     load_dz(dzq[1], 1);
+    scalars_then_barrier(0);
     u32x4 pa[3], pb[3];
     produce(dzq[0], 0, pa, pb);
     write_planes(0, pa, pb);
-    lds_barrier();
+    scalars_then_barrier(1);
   }
   do_step(T{}, P0{}, 0);
   int64_t n = 1;
