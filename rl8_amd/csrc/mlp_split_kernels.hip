@@ -461,12 +461,12 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     step_barrier();
     RL8_SPLIT_STAMP(trace_it, wave, s, 3);
   };
+  // Prologue: chunk 0 of the first tile.
   using T = std::true_type;
   using F = std::false_type;
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
 
-  // Prologue: chunk 0 of the first tile.
   if ((int64_t)blockIdx.x < tiles) {
     request_b(0, 0);
     u32x4 planes[3];
@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   // ds_reads is in flight on lgkmcnt and the first MFMAs can go as soon as THEIR
   // fragments are in (wait_lds<N>), not after all twelve.
   // (the widest variants would spill with up to 64 more live scalars: they keep per-row loads)
-  constexpr bool kScalars = DIN > 0 && (FUSED == 0 || kIn + kOut <= 5);
+  constexpr bool kScalars = DIN > 0 && (FUSED == 0 || kIn + kOut <= 4);
   constexpr int kXq = kScalars ? kIn : 1, kDq = (kScalars && FUSED > 0) ? kOut : 1;
   [[maybe_unused]] f32x8 xq[kXq], dq[kDq];
   auto row0_of = [&](int64_t n) { return (blockIdx.x + n * stride) * kWsChunk + 8 * kh; };
@@ -1295,72 +1295,90 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 
   // Chunk n (stage n & 1) is consumed while chunk n+1 is produced from dzq[(n+1) & 1]
   // and the dZ2 of chunk n+2 is requested into dzq[n & 1].
-  auto do_step = [&](auto first_tag, auto parity_tag, int64_t n) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    constexpr int P = decltype(parity_tag)::value;
-    const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
-    SplitFrags f;
-    // issue order = the order the first products need them
-    f.am[0] = lds_read_b128<kWsPlane>(ar);
-    f.bm[0] = lds_read_b128<kWsPlane>(br);
-    f.bm[1] = lds_read_b128<kWsPlane + 512>(br);
-    f.bm[2] = lds_read_b128<kWsPlane + 1024>(br);
-    f.bm[3] = lds_read_b128<kWsPlane + 1536>(br);
-    f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
-    f.ah[0] = lds_read_b128<0>(ar);
-    f.ah[1] = lds_read_b128<512>(ar);
-    f.bh[0] = lds_read_b128<0>(br);
-    f.bh[1] = lds_read_b128<512>(br);
-    f.bh[2] = lds_read_b128<1024>(br);
-    f.bh[3] = lds_read_b128<1536>(br);
-    u32x4 pa[3], pb[3];
-    if constexpr (kScalars) {
-      // The first two groups of products go out as their own fragments land; the
-      // producer arithmetic is fenced behind them (it has the other forty products
-      // to hide beside) so that the compiler cannot pull all the waits to the front.
-      load_dz(dzq[P], n + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_lds<7>(f.am[0], f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
-      split_mma_row<FIRST>(f.am[0], f.bm, acc[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_lds<6>(f.am[1]);
-      split_mma_row<FIRST>(f.am[1], f.bm, acc[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      produce(dzq[P ^ 1], n + 1, pa, pb);
-      wait_lds<4>(f.ah[0], f.ah[1]);
-      split_mma<false>(f.ah, f.bm, acc);
-      wait_lds<0>(f.bh[0], f.bh[1], f.bh[2], f.bh[3]);
-      split_mma<false>(f.am, f.bh, acc);
-    } else {
-      produce(dzq[P ^ 1], n + 1, pa, pb);
-      load_dz(dzq[P], n + 2);
-      wait_lds_all(f);
-      split_mma<FIRST>(f.am, f.bm, acc);
-      split_mma<false>(f.ah, f.bm, acc);
-      split_mma<false>(f.am, f.bh, acc);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    write_planes(P ^ 1, pa, pb);
-    f.am[0] = lds_read_b128<2 * kWsPlane>(ar);
-    f.am[1] = lds_read_b128<2 * kWsPlane + 512>(ar);
-    f.bm[0] = lds_read_b128<2 * kWsPlane>(br);
-    f.bm[1] = lds_read_b128<2 * kWsPlane + 512>(br);
-    f.bm[2] = lds_read_b128<2 * kWsPlane + 1024>(br);
-    f.bm[3] = lds_read_b128<2 * kWsPlane + 1536>(br);
-    __builtin_amdgcn_sched_barrier(0);
-    split_mma<false>(f.ah, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_lds_all(f);
-    split_mma<false>(f.ah, f.bm, acc);
-    split_mma<false>(f.am, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    scalars_then_barrier(n + 2);
-  };
   using T = std::true_type;
   using F = std::false_type;
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
 
+  // One barrier per step, placed in FRONT of the step's last group of products: behind
+  // it the first fragments of the next chunk (one A, four B: the mid planes) are
+  // fetched into the registers the second-to-last group has just released, and land
+  // while the last group runs -- so a step opens with products, not with an LDS
+  // round trip.  The B registers trade roles each step for that: BM (mid, then lo
+  // planes) is f.bm in even steps and f.bh in odd ones, BH (hi planes) the other.
+  SplitFrags f;
+  auto first_reads = [&](auto parity_tag) {  // ... of the chunk in stage P, into am[0] and that step's BM
+    constexpr int P = decltype(parity_tag)::value;
+    const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
+    u32x4(&BM)[4] = *(P == 0 ? &f.bm : &f.bh);
+    f.am[0] = lds_read_b128<kWsPlane>(ar);
+    BM[0] = lds_read_b128<kWsPlane>(br);
+    BM[1] = lds_read_b128<kWsPlane + 512>(br);
+    BM[2] = lds_read_b128<kWsPlane + 1024>(br);
+    BM[3] = lds_read_b128<kWsPlane + 1536>(br);
+  };
+  auto do_step = [&](auto first_tag, auto parity_tag, int64_t n) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int P = decltype(parity_tag)::value;
+    const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
+    u32x4(&BM)[4] = *(P == 0 ? &f.bm : &f.bh);
+    u32x4(&BH)[4] = *(P == 0 ? &f.bh : &f.bm);
+    // am[0] and BM[0..3] are in (previous step / prologue); the other seven:
+    f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
+    f.ah[0] = lds_read_b128<0>(ar);
+    f.ah[1] = lds_read_b128<512>(ar);
+    BH[0] = lds_read_b128<0>(br);
+    BH[1] = lds_read_b128<512>(br);
+    BH[2] = lds_read_b128<1024>(br);
+    BH[3] = lds_read_b128<1536>(br);
+    u32x4 pa[3], pb[3];
+    if constexpr (kScalars) {
+      // The first two groups of products go out at once / as their own fragment lands;
+      // the producer arithmetic is fenced behind them (it has the other forty products
+      // to hide beside) so that the compiler cannot pull all the waits to the front.
+      load_dz(dzq[P], n + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      split_mma_row<FIRST>(f.am[0], BM, acc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lds<6>(f.am[1]);
+      split_mma_row<FIRST>(f.am[1], BM, acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      produce(dzq[P ^ 1], n + 1, pa, pb);
+      wait_lds<4>(f.ah[0], f.ah[1]);
+      split_mma<false>(f.ah, BM, acc);
+      wait_lds<0>(BH[0], BH[1], BH[2], BH[3]);
+      split_mma<false>(f.am, BH, acc);
+    } else {
+      produce(dzq[P ^ 1], n + 1, pa, pb);
+      load_dz(dzq[P], n + 2);
+      wait_lds_all(f);
+      split_mma<FIRST>(f.am, BM, acc);
+      split_mma<false>(f.ah, BM, acc);
+      split_mma<false>(f.am, BH, acc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    write_planes(P ^ 1, pa, pb);
+    f.am[0] = lds_read_b128<2 * kWsPlane>(ar);
+    f.am[1] = lds_read_b128<2 * kWsPlane + 512>(ar);
+    BM[0] = lds_read_b128<2 * kWsPlane>(br);
+    BM[1] = lds_read_b128<2 * kWsPlane + 512>(br);
+    BM[2] = lds_read_b128<2 * kWsPlane + 1024>(br);
+    BM[3] = lds_read_b128<2 * kWsPlane + 1536>(br);
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma<false>(f.ah, BH, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lds_all(f);
+    split_mma<false>(f.am, BH, acc);  // last use of am and BH in this step
+    __builtin_amdgcn_sched_barrier(0);
+    scalars_then_barrier(n + 2);
+    if constexpr (P == 0) first_reads(std::integral_constant<int, 1>{});
+    else first_reads(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma<false>(f.ah, BM, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    // landed before anything can copy or carry these registers (loop back-edge)
+    wait_lds<0>(f.am[0], BH[0], BH[1], BH[2], BH[3]);
+  };
   {
     load_dz(dzq[0], 0);
     load_dz(dzq[1], 1);
@@ -1369,6 +1387,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     produce(dzq[0], 0, pa, pb);
     write_planes(0, pa, pb);
     scalars_then_barrier(1);
+    first_reads(P0{});
+    wait_lds<0>(f.am[0], f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
   }
   do_step(T{}, P0{}, 0);
   int64_t n = 1;
