@@ -188,23 +188,26 @@ __device__ __forceinline__ void wait_lds(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d)
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 template <int N>
-__device__ __forceinline__ void wait_lds(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
-  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+__device__ __forceinline__ void wait_lds(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e, u32x4 &g) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(g) : "n"(N));
 }
 
-// Eight consecutive floats at a wave-uniform address into scalar registers; NO wait:
-// the caller's next barrier (lgkmcnt(0)) is the wait, see scalar_tie().
+// Scalar-register operands fetched by hand (s_buffer_load, NO wait: the caller's next
+// barrier with lgkmcnt(0) is the wait, scalar_tie() behind it the compiler's fence).
 typedef float f32x8 __attribute__((ext_vector_type(8)));
-template <int OFF>
-__device__ __forceinline__ f32x8 scalar_load_x8(const float *p) {
-  f32x8 v;
-  asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(p), "n"(OFF));
-  return v;
-}
 __device__ __forceinline__ void scalar_tie(f32x8 &v) { asm volatile("" : "+s"(v)); }
-// a value every lane holds alike, moved to the scalar file
-__device__ __forceinline__ float uniform_f32(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+// Raw buffer descriptor over [p, p + bytes) in scalar registers, and eight floats at
+// byte OFF of it (floats past `bytes` read as zero).
+__device__ __forceinline__ u32x4 scalar_rsrc(const float *p, int bytes) {
+  const uint64_t a = (uint64_t)(uintptr_t)p;
+  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)bytes, 0x00020000u};
+}
+template <int OFF>
+__device__ __forceinline__ f32x8 scalar_buffer_load_x8(u32x4 rsrc) {
+  f32x8 v;
+  // (early clobber: a later load through the same descriptor must still find it intact)
+  asm volatile("s_buffer_load_dwordx8 %0, %1, %2" : "=&s"(v) : "s"(rsrc), "n"(OFF));
+  return v;
 }
 
 template <bool FIRST>
@@ -1191,54 +1194,41 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   // in front of the PREVIOUS step's barrier, so that inside a step nothing but
   // ds_reads is in flight on lgkmcnt and the first MFMAs can go as soon as THEIR
   // fragments are in (wait_lds<N>), not after all twelve.
-  // (the widest variants would spill with up to 64 more live scalars: they keep per-row loads)
-  constexpr bool kScalars = DIN > 0 && (FUSED == 0 || kIn + kOut <= 4);
+  constexpr bool kScalars = DIN > 0;
   constexpr int kXq = kScalars ? kIn : 1, kDq = (kScalars && FUSED > 0) ? kOut : 1;
   [[maybe_unused]] f32x8 xq[kXq], dq[kDq];
   auto row0_of = [&](int64_t n) { return (blockIdx.x + n * stride) * kWsChunk + 8 * kh; };
-  // ... for chunk n of this workgroup, then the step barrier.  A chunk that is not
-  // whole (the last one; the one past the end the final step "produces") takes the
-  // per-row clamped loads instead.
-  auto scalars_then_barrier = [&](int64_t n) {
+  // ... of chunk n of this workgroup: requested through buffer descriptors that end at
+  // sample m, so samples past the end read as zero (as their h2 / dZ2 do: whatever
+  // they contribute is multiplied by zero) and no step needs a slow path.  No wait
+  // here: the step barrier's lgkmcnt(0) is the wait, scalars_landed() the fence.
+  auto request_scalars = [&](int64_t n) {
     if constexpr (kScalars) {
       const int64_t row0 = row0_of(n);
-      if (row0 + 8 <= m) {
-        const float *px = x + row0 * kIn;
-        xq[0] = scalar_load_x8<0>(px);
-        if constexpr (kIn > 1) xq[1] = scalar_load_x8<32>(px);
-        if constexpr (kIn > 2) xq[2] = scalar_load_x8<64>(px);
-        if constexpr (kIn > 3) xq[3] = scalar_load_x8<96>(px);
-        if constexpr (kIn > 4) xq[4] = scalar_load_x8<128>(px);
-        if constexpr (FUSED > 0) {
-          const float *pd = fused.dout + row0 * kOut;
-          dq[0] = scalar_load_x8<0>(pd);
-          if constexpr (kOut > 1) dq[1] = scalar_load_x8<32>(pd);
-          if constexpr (kOut > 2) dq[2] = scalar_load_x8<64>(pd);
-        }
-        lds_barrier();
-      } else {
-        // Samples past the end are clamped to the last row: their h2 / dZ2 read as zero
-        // through the descriptor, so whatever they contribute is multiplied by zero.
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int64_t row = row0 + e < m ? row0 + e : m - 1;
-#pragma unroll
-          for (int c = 0; c < kIn; ++c) xq[(e * kIn + c) >> 3][(e * kIn + c) & 7] = uniform_f32(x[row * kIn + c]);
-          if constexpr (FUSED > 0) {
-#pragma unroll
-            for (int q = 0; q < kOut; ++q) dq[(e * kOut + q) >> 3][(e * kOut + q) & 7] = uniform_f32(fused.dout[row * kOut + q]);
-          }
-        }
-        lds_barrier();
+      const int64_t left = m - row0;
+      const int rows = left <= 0 ? 0 : left < 8 ? (int)left : 8;
+      const u32x4 rx = scalar_rsrc(x + row0 * kIn, rows * kIn * 4);
+      xq[0] = scalar_buffer_load_x8<0>(rx);
+      if constexpr (kIn > 1) xq[1] = scalar_buffer_load_x8<32>(rx);
+      if constexpr (kIn > 2) xq[2] = scalar_buffer_load_x8<64>(rx);
+      if constexpr (kIn > 3) xq[3] = scalar_buffer_load_x8<96>(rx);
+      if constexpr (kIn > 4) xq[4] = scalar_buffer_load_x8<128>(rx);
+      if constexpr (FUSED > 0) {
+        const u32x4 rd = scalar_rsrc(fused.dout + row0 * kOut, rows * kOut * 4);
+        dq[0] = scalar_buffer_load_x8<0>(rd);
+        if constexpr (kOut > 1) dq[1] = scalar_buffer_load_x8<32>(rd);
+        if constexpr (kOut > 2) dq[2] = scalar_buffer_load_x8<64>(rd);
       }
+    }
+  };
+  auto scalars_landed = [&]() {  // directly behind a barrier / lgkmcnt(0)
+    if constexpr (kScalars) {
 #pragma unroll
       for (int i = 0; i < kXq; ++i) scalar_tie(xq[i]);
       if constexpr (FUSED > 0) {
 #pragma unroll
         for (int i = 0; i < kDq; ++i) scalar_tie(dq[i]);
       }
-    } else {
-      lds_barrier();
     }
   };
   auto produce = [&](const float (&dzv)[8], int64_t n, u32x4 (&pa)[3], u32x4 (&pb)[3]) {
@@ -1301,13 +1291,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   using P1 = std::integral_constant<int, 1>;
 
   // One barrier per step, placed in FRONT of the step's last group of products: behind
-  // it the first fragments of the next chunk (one A, four B: the mid planes) are
-  // fetched into the registers the second-to-last group has just released, and land
-  // while the last group runs -- so a step opens with products, not with an LDS
-  // round trip.  The B registers trade roles each step for that: BM (mid, then lo
-  // planes) is f.bm in even steps and f.bh in odd ones, BH (hi planes) the other.
+  // it the fragments the next step opens with (both A and four B of the mid planes)
+  // are fetched into the registers the second-to-last group has just released, and
+  // land while the last group runs -- a step opens with eight products, not with an
+  // LDS round trip.  The B registers trade roles each step for that: BM (mid, then
+  // lo planes) is f.bm in even steps and f.bh in odd ones, BH (hi planes) the other.
   SplitFrags f;
-  auto first_reads = [&](auto parity_tag) {  // ... of the chunk in stage P, into am[0] and that step's BM
+  auto first_reads = [&](auto parity_tag) {  // ... of the chunk in stage P, into am and that step's BM
     constexpr int P = decltype(parity_tag)::value;
     const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
     u32x4(&BM)[4] = *(P == 0 ? &f.bm : &f.bh);
@@ -1316,6 +1306,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     BM[1] = lds_read_b128<kWsPlane + 512>(br);
     BM[2] = lds_read_b128<kWsPlane + 1024>(br);
     BM[3] = lds_read_b128<kWsPlane + 1536>(br);
+    f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
   };
   auto do_step = [&](auto first_tag, auto parity_tag, int64_t n) {
     constexpr bool FIRST = decltype(first_tag)::value;
@@ -1323,39 +1314,29 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
     u32x4(&BM)[4] = *(P == 0 ? &f.bm : &f.bh);
     u32x4(&BH)[4] = *(P == 0 ? &f.bh : &f.bm);
-    // am[0] and BM[0..3] are in (previous step / prologue); the other seven:
-    f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
+    // am and BM are in (previous step / prologue); the hi planes:
     f.ah[0] = lds_read_b128<0>(ar);
     f.ah[1] = lds_read_b128<512>(ar);
     BH[0] = lds_read_b128<0>(br);
     BH[1] = lds_read_b128<512>(br);
     BH[2] = lds_read_b128<1024>(br);
     BH[3] = lds_read_b128<1536>(br);
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma_row<FIRST>(f.am[0], BM, acc[0]);  // at once: nothing in front of the first products
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma_row<FIRST>(f.am[1], BM, acc[1]);
     u32x4 pa[3], pb[3];
+    load_dz(dzq[P], n + 2);
+    produce(dzq[P ^ 1], n + 1, pa, pb);
     if constexpr (kScalars) {
-      // The first two groups of products go out at once / as their own fragment lands;
-      // the producer arithmetic is fenced behind them (it has the other forty products
-      // to hide beside) so that the compiler cannot pull all the waits to the front.
-      load_dz(dzq[P], n + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      split_mma_row<FIRST>(f.am[0], BM, acc[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_lds<6>(f.am[1]);
-      split_mma_row<FIRST>(f.am[1], BM, acc[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      produce(dzq[P ^ 1], n + 1, pa, pb);
-      wait_lds<4>(f.ah[0], f.ah[1]);
+      wait_lds<4>(f.ah[0], f.ah[1]);  // only ds_reads are in flight: in-order count
       split_mma<false>(f.ah, BM, acc);
       wait_lds<0>(BH[0], BH[1], BH[2], BH[3]);
-      split_mma<false>(f.am, BH, acc);
     } else {
-      produce(dzq[P ^ 1], n + 1, pa, pb);
-      load_dz(dzq[P], n + 2);
       wait_lds_all(f);
-      split_mma<FIRST>(f.am, BM, acc);
       split_mma<false>(f.ah, BM, acc);
-      split_mma<false>(f.am, BH, acc);
     }
+    split_mma<false>(f.am, BH, acc);
     __builtin_amdgcn_sched_barrier(0);
     write_planes(P ^ 1, pa, pb);
     f.am[0] = lds_read_b128<2 * kWsPlane>(ar);
@@ -1364,31 +1345,38 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     BM[1] = lds_read_b128<2 * kWsPlane + 512>(br);
     BM[2] = lds_read_b128<2 * kWsPlane + 1024>(br);
     BM[3] = lds_read_b128<2 * kWsPlane + 1536>(br);
+    request_scalars(n + 2);  // for the chunk the NEXT step produces
     __builtin_amdgcn_sched_barrier(0);
     split_mma<false>(f.ah, BH, acc);
     __builtin_amdgcn_sched_barrier(0);
     wait_lds_all(f);
     split_mma<false>(f.am, BH, acc);  // last use of am and BH in this step
     __builtin_amdgcn_sched_barrier(0);
-    scalars_then_barrier(n + 2);
-    if constexpr (P == 0) first_reads(std::integral_constant<int, 1>{});
-    else first_reads(std::integral_constant<int, 0>{});
+    lds_barrier();
+    scalars_landed();
+    if constexpr (P == 0) first_reads(P1{});
+    else first_reads(P0{});
     __builtin_amdgcn_sched_barrier(0);
     split_mma<false>(f.ah, BM, acc);
     __builtin_amdgcn_sched_barrier(0);
     // landed before anything can copy or carry these registers (loop back-edge)
-    wait_lds<0>(f.am[0], BH[0], BH[1], BH[2], BH[3]);
+    wait_lds<0>(f.am[0], f.am[1], BH[0], BH[1], BH[2], BH[3]);
   };
+
   {
     load_dz(dzq[0], 0);
     load_dz(dzq[1], 1);
-    scalars_then_barrier(0);
+    request_scalars(0);
+    lds_barrier();
+    scalars_landed();
     u32x4 pa[3], pb[3];
     produce(dzq[0], 0, pa, pb);
     write_planes(0, pa, pb);
-    scalars_then_barrier(1);
+    request_scalars(1);
+    lds_barrier();
+    scalars_landed();
     first_reads(P0{});
-    wait_lds<0>(f.am[0], f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
+    wait_lds<0>(f.am[0], f.am[1], f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
   }
   do_step(T{}, P0{}, 0);
   int64_t n = 1;

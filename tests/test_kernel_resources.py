@@ -74,3 +74,55 @@ def test_compiled_split_kernels_resources(tmp_path):
             assert vgprs <= 256, (name, vgprs)
             checked += 1
     assert checked >= 24 + 12 + 5 + 12
+    _check_wgrad_scalar_windows(text)
+
+
+def _sgprs(operand: str) -> set[int]:
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", operand)
+    return {int(m.group(1))} if m else set()
+
+
+def _check_wgrad_scalar_windows(text: str) -> None:
+    """The weight-gradient kernel issues s_buffer_load by hand, without a wait of its
+    own, and counts ds_reads in order (s_waitcnt lgkmcnt(N > 0)).  Both lean on the
+    instruction stream, so check it:
+      * from each hand-issued scalar load to the next `lgkmcnt(0)` + s_barrier nothing may
+        touch its destination registers (a copy or spill there would save stale data);
+      * no scalar-cache load may be in flight at a counted wait (it returns out of order).
+    """
+    bodies = re.findall(r"\n(_ZN3rl822mlp_wgrad_split_kernel\S+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S)
+    assert len(bodies) >= 17
+    loads = counted = 0
+    for name, body in bodies:
+        lines = [ln.strip() for ln in body.split("\n")]
+        lines = [ln for ln in lines if ln and not ln.startswith((";", "."))]
+        pending: set[int] = set()   # destinations of hand-issued loads not yet behind a barrier
+        smem_in_flight = False
+        for i, ln in enumerate(lines):
+            op, _, rest = ln.partition(" ")
+            operands = [o.strip() for o in rest.split(";")[0].split(",")]
+            if op.startswith("s_buffer_load"):
+                pending |= _sgprs(operands[0])
+                assert not any(pending & _sgprs(o) for o in operands[1:]), (name, ln)  # incl. its own descriptor
+                smem_in_flight = True
+                loads += 1
+                continue
+            if op.startswith("s_load"):
+                smem_in_flight = True
+            if op == "s_waitcnt":
+                m = re.search(r"lgkmcnt\((\d+)\)", rest)
+                if m and int(m.group(1)) == 0:
+                    smem_in_flight = False
+                    if i + 1 < len(lines) and lines[i + 1].startswith("s_barrier"):
+                        pending = set()
+                elif m:
+                    counted += 1
+                    assert not smem_in_flight, (name, i, ln)
+                continue
+            for o in operands:
+                assert not (pending & _sgprs(o)), (name, i, ln)
+    assert loads >= 16 * 2 * 2 and counted >= 16 * 2
+
