@@ -1108,7 +1108,11 @@ static int dispatch_backward_split_nout(int n_out, int grid, hipStream_t s, cons
 //     is a handful of fmas per element, the observations come through the scalar
 //     cache -- instead of reading 1 KiB of h1 per sample back from HBM,
 //   splits both into the three planes and writes them to LDS as ready fragments,
-// all on the VALU beside the bf16 MFMAs of the previous chunk.  Partial sums leave
+// all on the VALU beside the bf16 MFMAs of the previous chunk.  The workgroup has the CU
+// to itself, so nothing else fills its gaps and the step is ordered to have none: the
+// wave-uniform operands (observations, dOut) arrive in scalar registers a step ahead,
+// the one barrier per step sits in front of the step's LAST group of products and the
+// next step's first fragments are fetched right behind it (see do_step).  Partial sums leave
 // as one slab per workgroup, added up in slab order by mlp_wgrad_split_reduce_kernel
 // (bitwise reproducible; no atomics).
 constexpr int kWsThreads = 512;
