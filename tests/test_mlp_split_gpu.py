@@ -133,6 +133,40 @@ def test_backward_split_matches_fp64(m, d_in, n_out):
         hip.mlp_tower_backward(x, None, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
 
 
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (13, 1, 1), (4099, 2, 3), (20_003, 5, 3), (33_001, 3, 2), (9, 5, 1)])
+def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out):
+    """The kernels fetch whole windows of rows (eight samples of x / dOut through scalar
+    buffer descriptors, 16-sample chunks of h2, 128-row tiles) and rely on descriptors
+    that end at row m for the ragged tail.  Here every input is a view of a larger
+    allocation whose rows past m hold NaN: one such row read and used -- even
+    multiplied by zero -- would poison the gradients."""
+    g = torch.Generator(device=DEV).manual_seed(11 * m + n_out)
+    pad = 160
+
+    def view_of(t):
+        big = torch.full((m + pad, t.shape[1]), float("nan"), device=DEV)
+        big[:m] = t
+        return big[:m]
+
+    x = torch.randn(m, d_in, device=DEV, generator=g)
+    p = _params(g, d_in, n_out)
+    dout = torch.randn(m, n_out, device=DEV, generator=g) / m
+    w2p, w2t = hip.mlp_pack_w2_split(p["w2"]), hip.mlp_pack_w2_split(p["w2"], transposed=True)
+    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True, save_gate=True)
+    want = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate)
+    xv, h2v, dv = view_of(x), view_of(h2), view_of(dout)
+    outv, _, h2_again, gate_again = hip.mlp_tower_forward_split(xv, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True,
+                                                               save_gate=True)
+    assert torch.equal(h2_again, h2) and torch.equal(gate_again, gate) and bool(torch.isfinite(outv).all())
+    for gate2 in (None, gate):
+        got = hip.mlp_tower_backward(xv, None, h2v, dv, w2t, p["w3"], p["w1"], p["b1"], gate2=gate2)
+        for k in p:
+            assert bool(torch.isfinite(got[k]).all()), k
+            assert torch.equal(got[k], want[k]), k
+    dz2 = ((dout @ p["w3"]) * (h2 > 0)).contiguous()
+    assert torch.equal(hip.mlp_wgrad_split(view_of(dz2), xv, p["w1"], p["b1"]), hip.mlp_wgrad_split(dz2, x, p["w1"], p["b1"]))
+
+
 def test_unsupported_widths_are_refused_not_miscomputed():
     """Only widths whose kernels compile without scratch are offered
     (tests/test_kernel_resources.py); anything else must fail loudly."""
