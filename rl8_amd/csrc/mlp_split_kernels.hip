@@ -1432,15 +1432,21 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 // out[idx] (+)= sum over slabs, in slab order.
 __global__ __launch_bounds__(kBlock) void mlp_wgrad_split_reduce_kernel(const float *__restrict__ slabs, int rows,
                                                                        float *__restrict__ out, int accumulate) {
-  const int idx = blockIdx.x * kBlock + threadIdx.x;  // one float4 each
-  if (idx >= kHidden * kHidden / 4) return;
-  const float4 *p = reinterpret_cast<const float4 *>(slabs) + idx;
-  float4 sum = accumulate ? reinterpret_cast<float4 *>(out)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int r = 0; r < rows; ++r) {
-    const float4 v = p[(int64_t)r * (kHidden * kHidden / 4)];
-    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  // One float per thread (a workgroup per CU), slabs added in slab order; the loads of
+  // sixteen slabs are in flight together, only the additions are sequential.
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  const float *p = slabs + idx;
+  float sum = accumulate ? out[idx] : 0.0f;
+  int r = 0;
+  for (; r + 16 <= rows; r += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(r + u) * (kHidden * kHidden)];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sum += v[u];
   }
-  reinterpret_cast<float4 *>(out)[idx] = sum;
+  for (; r < rows; ++r) sum += p[(int64_t)r * (kHidden * kHidden)];
+  out[idx] = sum;
 }
 
 template <int DIN>
@@ -1580,7 +1586,7 @@ RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const floa
     default: status = launch_wgrad_split<0>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
   }
   if (status != 0) return status;
-  mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / 4 / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, accumulate);
+  mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, accumulate);
   return launch_status();
 }
 
@@ -1615,6 +1621,6 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
   RL8_WGRAD_FUSED(5, 1) RL8_WGRAD_FUSED(5, 2) RL8_WGRAD_FUSED(5, 3)
 #undef RL8_WGRAD_FUSED
   if (status != 0) return status;
-  mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / 4 / kBlock, kBlock, 0, s>>>(workspace, g2, dw2_out, 0);
+  mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, g2, dw2_out, 0);
   return launch_status();
 }
