@@ -524,7 +524,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
-            buffer_store_f32(acc[mt][nt][r], h2rsrc, (4 * hh * kHidden + 128 * wc + 32 * nt + l32) * 4, sr * (kHidden * 4));
+            buffer_store_f32_streaming(acc[mt][nt][r], h2rsrc, (4 * hh * kHidden + 128 * wc + 32 * nt + l32) * 4, sr * (kHidden * 4));
           }
         }
         if constexpr (SAVE) {
