@@ -58,8 +58,11 @@ from ..specs import Composite, Unbounded
 from ..tensordict import TensorDict
 
 #: Rows pushed through the policy network per forward/backward pass inside one
-#: minibatch (activations: rows x 256 x 4 B per layer).
-DEFAULT_MAX_ROWS_PER_PASS = 1 << 23
+#: minibatch.  The bf16-plane towers keep 1 KiB (h2) + 32 B (gate bits) per row and
+#: tower between forward and backward: 2^25 rows -- BASELINE's whole 33.5 M-sample
+#: batch in one pass -- peak at 68 GiB of the 288 GB, and fewer, larger launches
+#: measured 2.4 % faster than 2^23-row passes (1.2 % at 2^24).
+DEFAULT_MAX_ROWS_PER_PASS = 1 << 25
 
 
 @dataclass

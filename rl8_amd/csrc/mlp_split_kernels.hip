@@ -1115,6 +1115,13 @@ static int dispatch_backward_split_nout(int n_out, int grid, hipStream_t s, cons
 // next step's first fragments are fetched right behind it (see do_step).  Partial sums leave
 // as one slab per workgroup, added up in slab order by mlp_wgrad_split_reduce_kernel
 // (bitwise reproducible; no atomics).
+// A launch covers at most this many samples; longer inputs are summed segment by segment
+// (dW2 through the slab reduction's accumulate mode, the head-gradient partial rows in
+// place).  Every accumulator is an fp32 chain over its workgroup's share of the samples:
+// at 2^25 rows in one launch dW2 was 7e-5 (of its largest entry) off an fp64 evaluation,
+// at 2^23 per launch 4e-5 -- the length the parity tests were validated at, kept
+// whatever the caller's pass size.
+constexpr int64_t kWgradSegmentRows = (int64_t)1 << 23;
 constexpr int kWsThreads = 512;
 constexpr int kWsChunk = 16;                             // samples per k-step
 constexpr int kWsOperandBytes = 3 * 2 * kHidden * 16;    // [plane][sample half][column] x 16 B
@@ -1134,6 +1141,7 @@ struct WgradFusedArgs {
   float *partials;     // rows of `partial_stride` floats: [dW1 | db1 | db2 | dW3 | db3]
   int partial_stride;
   int other_rows;      // rows whose [dW1 | db1] segment the data-gradient kernel fills
+  int accumulate;      // a later segment of the same rows-of-samples sum: add to the partial rows
 };
 
 template <int DIN, int FUSED = 0>
@@ -1417,14 +1425,19 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     __syncthreads();
     float *row = fused.partials + (int64_t)blockIdx.x * fused.partial_stride;
     const int off_db2 = kHidden * d_in + kHidden, off_dw3 = off_db2 + kHidden, off_db3 = off_dw3 + kOut * kHidden;
+    const bool more = fused.accumulate != 0;  // (a later segment: the first one wrote / zeroed the row)
     if (kh == 0) {
-      row[off_db2 + col] = db2a + red[col * (1 + kOut)];
+      const float sum_b2 = db2a + red[col * (1 + kOut)];
+      row[off_db2 + col] = more ? row[off_db2 + col] + sum_b2 : sum_b2;
 #pragma unroll
-      for (int q = 0; q < kOut; ++q) row[off_dw3 + q * kHidden + col] = dw3a[q] + red[col * (1 + kOut) + 1 + q];
+      for (int q = 0; q < kOut; ++q) {
+        const float sum_w3 = dw3a[q] + red[col * (1 + kOut) + 1 + q];
+        row[off_dw3 + q * kHidden + col] = more ? row[off_dw3 + q * kHidden + col] + sum_w3 : sum_w3;
+      }
       // db3 = sum of dOut needs no matrix kernel: the caller forms it (the segment is zeroed)
-      if (col < kOut) row[off_db3 + col] = 0.0f;
+      if (col < kOut && !more) row[off_db3 + col] = 0.0f;
     }
-    if ((int)blockIdx.x >= fused.other_rows)
+    if (!more && (int)blockIdx.x >= fused.other_rows)
       for (int idx = tid; idx < kHidden * d_in + kHidden; idx += kWsThreads) row[idx] = 0.0f;
   }
 }
@@ -1574,19 +1587,25 @@ RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const floa
   if (!dz2 || !x || !w1 || !b1 || !workspace || !dw2_out) return RL8_ENULL;
   if (m <= 0 || d_in <= 0 || d_in > kMaxIn) return RL8_ESIZE;
   if (!aligned16(dz2) || !aligned16(workspace) || !aligned16(dw2_out)) return RL8_EALIGN;
-  const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
-  const int grid = (int)(chunks < kCUs ? chunks : kCUs);
   hipStream_t s = (hipStream_t)stream;
-  int status;
-  switch (d_in) {
-    case 1: status = launch_wgrad_split<1>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
-    case 2: status = launch_wgrad_split<2>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
-    case 3: status = launch_wgrad_split<3>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
-    case 5: status = launch_wgrad_split<5>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
-    default: status = launch_wgrad_split<0>(grid, s, dz2, x, w1, b1, m, d_in, workspace); break;
+  // Segments of kWgradSegmentRows samples, summed in order (see there).
+  for (int64_t at = 0; at < m; at += kWgradSegmentRows) {
+    const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
+    const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
+    const int grid = (int)(chunks < kCUs ? chunks : kCUs);
+    const float *dz = dz2 + at * kHidden, *xs = x + at * d_in;
+    int status;
+    switch (d_in) {
+      case 1: status = launch_wgrad_split<1>(grid, s, dz, xs, w1, b1, rows, d_in, workspace); break;
+      case 2: status = launch_wgrad_split<2>(grid, s, dz, xs, w1, b1, rows, d_in, workspace); break;
+      case 3: status = launch_wgrad_split<3>(grid, s, dz, xs, w1, b1, rows, d_in, workspace); break;
+      case 5: status = launch_wgrad_split<5>(grid, s, dz, xs, w1, b1, rows, d_in, workspace); break;
+      default: status = launch_wgrad_split<0>(grid, s, dz, xs, w1, b1, rows, d_in, workspace); break;
+    }
+    if (status != 0) return status;
+    mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out,
+                                                                                 accumulate || at > 0);
   }
-  if (status != 0) return status;
-  mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, accumulate);
   return launch_status();
 }
 
@@ -1611,16 +1630,25 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
   fused_backward_grids(m, &g1, &g2);
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
-  const WgradFusedArgs fused{dout, w3, partials, stride, g1};
-  int status = RL8_ESIZE;
+  // Segments of kWgradSegmentRows samples, summed in order (see there).  The first one
+  // runs the grid the data-gradient kernel counted on (g2 rows of partials written, the
+  // rest zeroed); later ones add to as many of those rows as they have workgroups.
+  for (int64_t at = 0; at < m; at += kWgradSegmentRows) {
+    const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
+    const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
+    const int grid = at == 0 ? g2 : (int)(chunks < g2 ? chunks : g2);
+    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0};
+    const float *h2s = h2 + at * kHidden, *xs = x + at * d_in;
+    int status = RL8_ESIZE;
 #define RL8_WGRAD_FUSED(D, N) \
-  if (d_in == D && n_out == N) status = launch_wgrad_fused<D, N>(g2, s, h2, x, w1, b1, m, d_in, workspace, fused);
-  RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3)
-  RL8_WGRAD_FUSED(2, 1) RL8_WGRAD_FUSED(2, 2) RL8_WGRAD_FUSED(2, 3)
-  RL8_WGRAD_FUSED(3, 1) RL8_WGRAD_FUSED(3, 2) RL8_WGRAD_FUSED(3, 3)
-  RL8_WGRAD_FUSED(5, 1) RL8_WGRAD_FUSED(5, 2) RL8_WGRAD_FUSED(5, 3)
+  if (d_in == D && n_out == N) status = launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused);
+    RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3)
+    RL8_WGRAD_FUSED(2, 1) RL8_WGRAD_FUSED(2, 2) RL8_WGRAD_FUSED(2, 3)
+    RL8_WGRAD_FUSED(3, 1) RL8_WGRAD_FUSED(3, 2) RL8_WGRAD_FUSED(3, 3)
+    RL8_WGRAD_FUSED(5, 1) RL8_WGRAD_FUSED(5, 2) RL8_WGRAD_FUSED(5, 3)
 #undef RL8_WGRAD_FUSED
-  if (status != 0) return status;
-  mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, g2, dw2_out, 0);
+    if (status != 0) return status;
+    mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0);
+  }
   return launch_status();
 }
