@@ -388,7 +388,9 @@ int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const float *w1, c
  * accumulates the head gradients on the way.  dw2_out [256][256] receives dW2; the
  * head segments [db2 | dW3] of `partials` (the same buffer and row count the first
  * call reported) are filled and the db3 segment is zeroed: db3 = the column sums of
- * dOut, which the caller forms itself.  Widths: rl8_mlp_backward_split_supports. */
+ * dOut, which the caller forms itself.  Widths: rl8_mlp_backward_split_supports.
+ * Inputs longer than 2^23 rows are summed in 2^23-row segments, in order (this call and
+ * rl8_mlp_wgrad_split_f32): the fp32 accumulation chains do not grow with m. */
 int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, const float *x, const float *w1,
                                   const float *b1, const float *w3, int64_t m, int d_in, int n_out,
                                   float *workspace, float *dw2_out, float *partials, void *stream);
