@@ -3,6 +3,7 @@
 all ``AlgorithmConfig`` defaults (BASELINE.json configs[1]).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8                      # starts its own 8 ranks (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -11,15 +12,30 @@ env.step / bookkeeping launch, bootstrap value, stats) + one ``step()`` (GAE,
 4 SGD iterations of policy forward, fused PPO loss fwd+bwd, policy backward,
 clip, Adam). Everything lives in HBM before the timed region starts.
 
-Weak scaling: every rank owns 2^20 environments (env-sharded, RCCL all-reduce of
-moments / loss sums / gradients only).
+Ranks. One process per GPU. Under ``torchrun`` the ranks exist already
+(``WORLD_SIZE`` in the environment). Called plainly with ``--gpus N > 1`` this
+process touches no GPU: it starts N children of this same script with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, waits,
+and prints rank 0's JSON line (``launch_ranks``).
+
+Scaling. ``--scaling weak`` (default): every rank owns ``--num-envs``
+environments. ``--scaling strong``: ``--num-envs`` is the GLOBAL count, split
+over the ranks (BASELINE configs[3]: ``--env continuous --distribution squashed
+--num-envs 1048576``; configs[4]: ``--recurrent --num-envs 65536 --horizon 256``).
+Either way the environments are sharded and the only traffic between ranks is
+the RCCL all-reduce of moments and of [gradient | loss sums] per optimizer step.
 
 Besides the contract's fields, the JSON line carries
-  roofline      the dominant hand-written kernel (fused PPO loss fwd+bwd, 44 B per
-                sample algorithmic) timed with HIP events inside the timed region;
+  roofline      the kernel the timed region spends most time in (the training
+                forward of the default towers: MFMA-bound, priced in executed bf16
+                FLOP against the 2.5 PF dense peak), timed with HIP events inside
+                the timed region; ``roofline_hbm`` the same for the largest
+                HBM-bound hand kernel (fused PPO loss fwd+bwd, 44 B per sample);
   kernels       the same for every hand kernel that ran;
   cpu_baseline  the CPU restatement (oracle/, kind "port") of the same algorithm
-                on the host cores, on a bounded sample (rank 0, N=1 only).
+                on the host cores, best of a thread-count sweep, on a bounded
+                sample (rank 0, N=1 only);
+  world_size / backend   as ``torch.distributed`` reports them.
 """
 
 from __future__ import annotations
@@ -27,6 +43,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,8 +52,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# torch is imported inside run(): the launcher parent (launch_ranks) never needs it
+# and must not initialise a GPU.
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290
 HBM_COPY_CEILING_GBS = 6290.0
@@ -101,63 +119,201 @@ def pmc_traffic(name: str, units_per_launch: float, split: bool = False):
     return None
 
 
-def parse_args() -> argparse.Namespace:
+def parse_args(argv: None | list[str] = None) -> argparse.Namespace:
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--num-envs", type=int, default=1 << 20, help="environments PER GPU")
+    p.add_argument("--num-envs", type=int, default=1 << 20,
+                   help="environments PER GPU (--scaling weak) or in TOTAL (--scaling strong)")
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     p.add_argument("--horizon", type=int, default=32)
     p.add_argument("--env", default="discrete", choices=["discrete", "continuous", "cartpole", "mountain_car", "pendulum"])
     p.add_argument("--distribution", default="default", choices=["default", "squashed"])
     p.add_argument("--recurrent", action="store_true", help="RecurrentAlgorithmConfig (LSTM, seq_len 4)")
-    p.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="nccl = RCCL over xGMI (production); gloo stages the tiny messages through the host"
+                        " (rehearsals: CPU rendezvous tests, several ranks on one GPU)")
+    p.add_argument("--single-device", action="store_true",
+                   help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL wants one device per rank)")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=30.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    return p.parse_args()
+    return p.parse_args(argv)
+
+
+# --------------------------------------------------------------------------- #
+# Self-launch: `python bench.py --gpus N` with no WORLD_SIZE in the environment
+# --------------------------------------------------------------------------- #
+def free_port() -> int:
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def rank_environment(rank: int, world: int, port: int, base: None | dict = None) -> dict:
+    """What torchrun would export for local rank ``rank`` of a one-node job."""
+    env = dict(os.environ if base is None else base)
+    env.update({
+        "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+        "GROUP_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+    })
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on these hosts
+    return env
+
+
+def launch_ranks(world: int, argv: list[str], *, script: str = os.path.abspath(__file__),
+                 timeout: None | float = None) -> tuple[int, str]:
+    """Start ``world`` fresh child processes of ``script`` (one per GPU), wait for
+    them, return (exit code, rank 0's stdout). The caller has not touched a GPU
+    and does not here: children are spawned (never exec'ed over this process) and
+    each initialises its own device. If a rank fails the others are stopped by
+    PID; the first non-zero exit code is returned (124 on timeout)."""
+    import tempfile
+
+    port = free_port()
+    deadline = None if timeout is None else time.monotonic() + timeout
+    with tempfile.TemporaryFile("w+") as rank0_out:
+        procs = [
+            subprocess.Popen([sys.executable, script, *argv], env=rank_environment(rank, world, port),
+                             stdout=rank0_out if rank == 0 else subprocess.DEVNULL)
+            for rank in range(world)
+        ]
+        rc, pending = 0, set(range(world))
+        try:
+            while pending and rc == 0:
+                for rank in sorted(pending):
+                    code = procs[rank].poll()
+                    if code is None:
+                        continue
+                    pending.discard(rank)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print(f"bench.py: rank {rank} exited with {code}; stopping the other ranks", file=sys.stderr)
+                if pending and rc == 0:
+                    if deadline is not None and time.monotonic() > deadline:
+                        rc = 124
+                        print("bench.py: ranks timed out", file=sys.stderr)
+                    else:
+                        time.sleep(0.05)
+        finally:
+            for rank in pending:
+                procs[rank].terminate()
+            for rank in pending:
+                try:
+                    procs[rank].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[rank].kill()
+        rank0_out.seek(0)
+        return rc, rank0_out.read()
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            return next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except (OSError, StopIteration):
+        return "unknown"
 
 
 def cpu_baseline(budget_s: float) -> dict:
     """The CPU restatement of the same algorithm (oracle/ppo_cpu.py: C kernels +
-    torch-CPU MLP) on BASELINE config 1 (DiscreteDummyEnv, N=8192, H=32,
-    defaults), host cores of this box. Bounded: one warm-up iteration, then
-    whole iterations until ~budget_s seconds are spent."""
+    torch-CPU MLP) on BASELINE configs[0] (DiscreteDummyEnv, N=8192, H=32,
+    defaults), on the host cores of this box -- the best the host does, not one
+    arbitrary setting: the 262 144 x 256 GEMMs of that config stop scaling (and
+    then lose) well below the core count of a GPU host, so the torch thread count
+    is swept (one timed collect()+step() each, after one warm-up iteration) and
+    the rest of the budget is spent at the fastest. ``sweep`` keeps every point."""
+    import torch
+
     from oracle.ppo_cpu import OraclePPO
 
-    cores = torch.get_num_threads()
+    host_cpus = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus
+    candidates = sorted({t for t in (8, 16, 32, 64, 128) if t <= usable} | {min(usable, 8)})
+    n = 8192 * 32
     torch.manual_seed(0)
     algo = OraclePPO("discrete", num_envs=8192, horizon=32)
-    algo.collect()
-    algo.step()
-    iters, t0 = 0, time.perf_counter()
-    while True:
+
+    def iteration() -> float:
+        t0 = time.perf_counter()
         algo.collect()
         algo.step()
-        iters += 1
-        elapsed = time.perf_counter() - t0
-        if elapsed >= budget_s or iters >= 50:
+        return time.perf_counter() - t0
+
+    t_start = time.perf_counter()
+    sweep: dict[int, float] = {}
+    # middle of the range first: if the budget runs out early the likeliest optimum was seen
+    order = sorted(candidates, key=lambda t: abs(t - 32))
+    torch.set_num_threads(order[0])
+    iteration()  # warm-up: thread pools, allocator, first-touch
+    for threads in order:
+        if sweep and time.perf_counter() - t_start > 0.6 * budget_s:
             break
+        torch.set_num_threads(threads)
+        sweep[threads] = iteration()
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = [sweep[best]]
+    while time.perf_counter() - t_start < budget_s and len(times) < 50:
+        times.append(iteration())
+    elapsed = sum(times)
     return {
-        "value": 8192 * 32 * iters / elapsed,
+        "value": n * len(times) / elapsed,
         "unit": "env transitions/sec",
-        "policy_updates_per_sec": iters / elapsed,
-        "cores": cores,
-        "host_cpus": os.cpu_count(),
+        "policy_updates_per_sec": len(times) / elapsed,
+        "cores": best,
+        "threads": best,
+        "host_cpus": host_cpus,
+        "usable_cpus": usable,
+        "cpu_model": cpu_model(),
+        "sweep_transitions_per_sec": {str(t): round(n / v, 1) for t, v in sorted(sweep.items())},
         "kind": "port",
-        "sample": f"{iters} x (collect+step), DiscreteDummyEnv num_envs=8192 horizon=32 defaults"
-                  f" (BASELINE configs[0]), {elapsed:.1f} s, oracle C kernels + torch-CPU MLP",
+        "sample": f"{len(times)} x (collect+step) at {best} torch threads (best of sweep {sorted(sweep)}),"
+                  f" DiscreteDummyEnv num_envs=8192 horizon=32 defaults (BASELINE configs[0]), {elapsed:.1f} s,"
+                  " oracle C kernels + torch-CPU MLP",
     }
 
 
 def main() -> None:
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process starts the ranks and stays off the GPU
+        rc, out = launch_ranks(args.gpus, sys.argv[1:])
+        # stdout carries the ONE JSON line; anything else rank 0 wrote there (gloo's
+        # connection banner) goes to stderr
+        for text in out.splitlines():
+            is_line = text.startswith("{") and text.rstrip().endswith("}")
+            print(text, file=sys.stdout if is_line else sys.stderr, flush=True)
+        sys.exit(rc)
+    run(args)
+
+
+def run(args: argparse.Namespace) -> None:
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.single_device and args.backend != "gloo":
+        raise SystemExit("bench.py: --single-device needs --backend gloo")
+    device_index = 0 if args.single_device else local_rank
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if args.backend == "nccl":
+            torch.cuda.set_device(device_index)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device_index}"))
+        else:
+            dist.init_process_group("gloo")
+        backend = dist.get_backend()
+        world = dist.get_world_size()
+        print(f"bench.py: rank {dist.get_rank()}/{world} up, backend {backend}", file=sys.stderr, flush=True)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(device_index)
+    # no HIP device / no librl8_amd.so: AlgorithmConfig.build() raises HipExtensionError below
 
     from rl8_amd import AlgorithmConfig, RecurrentAlgorithmConfig, hip
     from rl8_amd.distributions import SquashedNormal
@@ -173,7 +329,13 @@ def main() -> None:
         env_cls = DiscreteDummyEnv if args.env == "discrete" else ContinuousDummyEnv
 
     torch.manual_seed(0)
-    global_envs = args.num_envs * world
+    if args.scaling == "strong":
+        if args.num_envs % world:
+            raise SystemExit(f"bench.py: --scaling strong: --num-envs {args.num_envs} is not divisible by {world} ranks")
+        global_envs = args.num_envs
+    else:
+        global_envs = args.num_envs * world
+    envs_per_gpu = global_envs // world
     config_cls = RecurrentAlgorithmConfig if args.recurrent else AlgorithmConfig
     extra = {"distribution_cls": SquashedNormal} if args.distribution == "squashed" else {}
     algo = config_cls(num_envs=global_envs, horizon=args.horizon, **extra).build(env_cls)
@@ -202,7 +364,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     hip.timer.enabled = False
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
@@ -333,16 +495,20 @@ def main() -> None:
             "collect_ms_per_step": collect_ms / args.steps,
             "update_ms_per_step": step_ms / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
+            "world_size": world,
+            "backend": backend,
+            "collectives_per_step": algo.shards.collectives / max(args.steps + args.warmup, 1),
             "vs_baseline": None,
             "dtype": "f32",
             "gemm": sorted({k["gemm"] for k in kernels.values() if k["bound"] == "mfma"}),
             "data": "synthetic (Philox-reset DiscreteDummyEnv states, random-init default MLP)",
             "config": {
-                "workload": f"{env_cls.__name__}{variant} collect()+step(), num_envs={args.num_envs} per GPU"
+                "workload": f"{env_cls.__name__}{variant} collect()+step(), num_envs={envs_per_gpu} per GPU"
                             f" ({global_envs} total), horizon={horizon}, AlgorithmConfig defaults"
                             " (4 SGD iters, one full-buffer minibatch, Adam 1e-3)",
-                "num_envs_per_gpu": args.num_envs,
+                "num_envs_per_gpu": envs_per_gpu,
+                "num_envs_global": global_envs,
                 "horizon": horizon,
                 "parallelism": f"env-sharded x{world}",
             },

@@ -603,11 +603,19 @@ class Algorithm:
                 )
 
             stop_early = False
+            window: list[torch.Tensor] = []   # loss sums of the open accumulation window
             for sgd_iter in range(hp.num_sgd_iters):
                 for i, batch in enumerate(self._iter_minibatches(sgd_iter)):
                     step_this_batch = (i + 1) % gas == 0
                     sums = self._minibatch_forward_backward(batch, entropy_coeff, grad_scale)
-                    self.shards.sum_(sums)
+                    window.append(sums)
+                    if not sync_each:
+                        pending.append((sums, step_this_batch))
+                    if not step_this_batch:
+                        continue
+                    # shards: gradient + this window's loss sums in one all-reduce
+                    self.shards.sum_gradients_(self.policy.model.parameters(), window)
+                    window = []
                     if sync_each:
                         loss_values = losses_from_sums(
                             *sums.tolist(), entropy_coeff=entropy_coeff, vf_coeff=hp.vf_coeff,
@@ -615,20 +623,21 @@ class Algorithm:
                         )
                         record(loss_values, step_this_batch)
                         if loss_values["kl"] > 1.5 * hp.target_kl_div:
-                            # The reference breaks before backward(); dropping
-                            # this minibatch's gradients is the same thing.
+                            # The reference breaks before backward() (:577-582); the
+                            # fused loss has already run it, so its gradients are
+                            # dropped. `target_kl_div` excludes `accumulate_grads`
+                            # (AlgorithmHparams, reference data.py:227-231), hence
+                            # gas == 1 here and `.grad` held nothing else: both end
+                            # with every `.grad` None (tests/golden/early_stop.npz).
+                            assert gas == 1
                             self.optimizer.zero_grad()
                             stop_early = True
                             break
-                    else:
-                        pending.append((sums, step_this_batch))
-                    if step_this_batch:
-                        self.shards.sum_gradients_(self.policy.model.parameters())
-                        self.grad_scaler.unscale_(self.optimizer)
-                        nn.utils.clip_grad_norm_(self.policy.model.parameters(), hp.max_grad_norm)
-                        self.grad_scaler.step(self.optimizer)
-                        self.grad_scaler.update()
-                        self.optimizer.zero_grad()
+                    self.grad_scaler.unscale_(self.optimizer)
+                    nn.utils.clip_grad_norm_(self.policy.model.parameters(), hp.max_grad_norm)
+                    self.grad_scaler.step(self.optimizer)
+                    self.grad_scaler.update()
+                    self.optimizer.zero_grad()
                 if stop_early:
                     break
 

@@ -13,11 +13,11 @@ are four tiny reductions and the gradient, all carried by RCCL over xGMI
    SUM / MIN / MAX) -> global stats and ``reward_scale``;
 2. after the GAE scan: ``(count, sum, sum_sq)`` of the advantages (SUM) ->
    global mean / unbiased std, then a local normalise;
-3. per minibatch: the five loss sums (SUM) so stats and the early-stop decision
-   agree on every rank;
-4. per optimizer step: the flattened gradient (SUM; the loss kernel already
-   scaled per-sample gradients by 1 / global minibatch size), before clipping
-   so the clip norm is global.
+3. per optimizer step, in ONE buffer: the flattened gradient (SUM; the loss
+   kernel already scaled per-sample gradients by 1 / global minibatch size),
+   before clipping so the clip norm is global, together with the five loss sums
+   of each minibatch that fed it, so stats and the early-stop decision agree on
+   every rank.
 
 Messages are a few dozen bytes to ~0.5 MB: latency-bound on xGMI, never
 per-link-bandwidth-bound, so they are kept few and flat rather than bucketed.
@@ -26,7 +26,7 @@ per-link-bandwidth-bound, so they are kept few and flat rather than bucketed.
 
 from __future__ import annotations
 
-from typing import Iterable
+from typing import Iterable, Sequence
 
 import torch
 import torch.distributed as dist
@@ -53,6 +53,8 @@ class EnvShards:
         #: gloo has no device-tensor collectives on ROCm builds: the (tiny)
         #: messages are staged through the host. Production runs use nccl (RCCL).
         self._via_host = active and dist.get_backend(group) == "gloo"
+        #: collectives issued so far (tests and bench.py report it)
+        self.collectives = 0
 
     def _staged(self, t: torch.Tensor) -> tuple[torch.Tensor, bool]:
         if self._via_host and t.is_cuda:
@@ -73,6 +75,7 @@ class EnvShards:
         if self.active:
             buf, staged = self._staged(t)
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self.collectives += 1
             if staged:
                 t.copy_(buf)
         return t
@@ -84,6 +87,7 @@ class EnvShards:
         src, staged = self._staged(raw.contiguous().reshape(-1))
         flat = torch.empty(self.world_size * raw.numel(), dtype=raw.dtype, device=src.device)
         dist.all_gather_into_tensor(flat, src, group=self.group)
+        self.collectives += 1
         gathered = flat.view(self.world_size, raw.numel()).to(raw.device)
         out = torch.empty_like(raw)
         out[list(STAT_SUM)] = gathered[:, list(STAT_SUM)].sum(0)
@@ -91,30 +95,49 @@ class EnvShards:
         out[list(STAT_MAX)] = gathered[:, list(STAT_MAX)].max(0).values
         return out
 
-    def sum_gradients_(self, params: Iterable[torch.nn.Parameter]) -> None:
-        """One SUM all-reduce over the flattened gradient of ``params``."""
+    def sum_gradients_(self, params: Iterable[torch.nn.Parameter], sums: Sequence[torch.Tensor] = ()) -> None:
+        """ONE SUM all-reduce per optimizer step: the flattened gradient of ``params``
+        and, riding in the same buffer, the fp64 loss sums of the minibatches that
+        fed it (collectives (3)+(4) as one call). Everything in place.
+
+        The buffer is fp64: the loss sums need it, and ~0.5 MB more on a
+        latency-bound message costs nothing on xGMI. The shard gradients are thus
+        added to fp64 accuracy and rounded to fp32 once, so the order the ring adds
+        them in does not show in the result."""
         if not self.active:
             return
         grads = [p.grad for p in params if p.grad is not None]
-        if not grads:
+        pieces = [g.reshape(-1).double() for g in grads] + [t.reshape(-1).double() for t in sums]
+        if not pieces:
             return
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        flat = torch.cat(pieces)
         buf, staged = self._staged(flat)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        self.collectives += 1
         if staged:
             flat = buf.to(flat.device)
         offset = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[offset : offset + n].view_as(g))
+        for t in list(grads) + list(sums):
+            n = t.numel()
+            t.copy_(flat[offset : offset + n].view_as(t))
             offset += n
 
     def broadcast_parameters_(self, module: torch.nn.Module, src: int = 0) -> None:
-        """Make every replica start from rank ``src``'s weights."""
+        """Make every replica start from rank ``src``'s weights: one broadcast per
+        dtype present (one in all for the default models)."""
         if not self.active:
             return
-        for t in list(module.parameters()) + list(module.buffers()):
-            buf, staged = self._staged(t.data)
+        tensors = [t.data for t in list(module.parameters()) + list(module.buffers())]
+        for dtype in sorted({t.dtype for t in tensors}, key=str):
+            group = [t for t in tensors if t.dtype == dtype]
+            flat = torch.cat([t.reshape(-1) for t in group])
+            buf, staged = self._staged(flat)
             dist.broadcast(buf, src=src, group=self.group)
+            self.collectives += 1
             if staged:
-                t.data.copy_(buf)
+                flat = buf.to(flat.device)
+            offset = 0
+            for t in group:
+                n = t.numel()
+                t.copy_(flat[offset : offset + n].view_as(t))
+                offset += n

@@ -596,7 +596,185 @@ def gen_trace(name, env_cls, config_kwargs, iterations=2, recurrent=False) -> No
     save(name, **arrays)
 
 
+# --------------------------------------------------------------------------- #
+# F7: first-update pins of the assembled path (reference-held numbers for the
+#     1e-5 end-to-end bar): per-minibatch StatTracker updates of the traced
+#     configs (src/rl8/algorithms/_feedforward.py:562-574, _recurrent.py twin)
+#     and a num_sgd_iters=1 / one-minibatch run of every traced variant with the
+#     gradient the reference hands to its first optimizer step (:585-590).
+# --------------------------------------------------------------------------- #
+STAT_KEYS = (
+    "coefficients/entropy", "coefficients/vf", "losses/entropy", "losses/policy",
+    "losses/vf", "losses/total", "monitors/kl_div",
+)
+
+
+class UpdateRecorder:
+    """Records every ``StatTracker.update`` call (data + reduce flag) and the
+    gradients present at the first ``optimizer.step`` by wrapping the methods at
+    run time (the reference source stays untouched)."""
+
+    def __init__(self, algo) -> None:
+        self.algo = algo
+        self.updates: list[list[float]] = []
+        self.first_grads: None | dict[str, torch.Tensor] = None
+
+    def __enter__(self):
+        import rl8._utils as ref_utils
+
+        rec = self
+        self._cls = ref_utils.StatTracker
+        self._update = ref_utils.StatTracker.update
+        self._opt_step = self.algo.optimizer.step
+
+        def update(tracker, data, /, *, reduce=False):
+            rec.updates.append([float(data[k]) for k in STAT_KEYS] + [float(reduce)])
+            return rec._update(tracker, data, reduce=reduce)
+
+        def opt_step(*args, **kwargs):
+            if rec.first_grads is None:
+                rec.first_grads = {
+                    k: p.grad.detach().clone() for k, p in rec.algo.policy.model.named_parameters()
+                    if p.grad is not None
+                }
+            return rec._opt_step(*args, **kwargs)
+
+        ref_utils.StatTracker.update = update
+        self.algo.optimizer.step = opt_step
+        return self
+
+    def __exit__(self, *exc):
+        self._cls.update = self._update
+        self.algo.optimizer.step = self._opt_step
+
+
+def gen_first_update(name, trace_name, env_cls, config_kwargs, recurrent=False) -> None:
+    trace = dict(np.load(os.path.join(HERE, trace_name)))
+    cfg_cls = RecurrentAlgorithmConfig if recurrent else AlgorithmConfig
+    arrays = {}
+
+    def build(**overrides):
+        torch.manual_seed(42)
+        kwargs = {**config_kwargs, **overrides}
+        algo = cfg_cls(num_envs=64, horizon=32, device="cpu", **kwargs).build(env_cls)
+        for k, v in algo.policy.model.state_dict().items():
+            assert np.array_equal(v.numpy(), trace[f"init_{k}"]), f"init weights differ from {trace_name}: {k}"
+        return algo
+
+    def check_collect(algo):
+        # the rollout must be the one the committed trace holds: same inputs for the tests
+        for k, v in algo.buffer.items():
+            if torch.is_tensor(v):
+                assert np.array_equal(v.numpy(), trace[f"it0_collect_{k}"]), f"collect differs from {trace_name}: {k}"
+
+    # (a) the traced config itself: every per-minibatch update of iteration 0
+    algo = build()
+    algo.collect()
+    check_collect(algo)
+    with UpdateRecorder(algo) as rec:
+        step_stats = algo.step()
+    keys = [str(k) for k in trace["step_stat_keys"]]
+    for k, w in zip(keys, trace["it0_step_stats"]):
+        assert step_stats[k] == w, f"{trace_name}: re-run differs at {k}: {step_stats[k]} vs {w}"
+    arrays["traced_updates"] = np.array(rec.updates, np.float64)
+
+    # (b) one SGD iteration over one full-buffer minibatch
+    algo = build(num_sgd_iters=1, sgd_minibatch_size=None)
+    algo.collect()
+    check_collect(algo)
+    with UpdateRecorder(algo) as rec:
+        step_stats = algo.step()
+    assert len(rec.updates) == 1
+    arrays["sgd1_updates"] = np.array(rec.updates, np.float64)
+    arrays["sgd1_step_stats"] = np.array([step_stats[k] for k in keys], np.float64)
+    total_sq = 0.0
+    for k, gval in rec.first_grads.items():
+        arrays[f"sgd1_grad_{k}"] = gval
+        total_sq += float((gval.double() ** 2).sum())
+    arrays["sgd1_clipped_grad_norm"] = np.float64(total_sq ** 0.5)
+    for k, v in algo.policy.model.state_dict().items():
+        arrays[f"sgd1_final_{k}"] = v.clone()
+    arrays["stat_keys"] = np.array(STAT_KEYS + ("reduce",))
+    arrays["step_stat_keys"] = np.array(keys)
+    save(name, **arrays)
+
+
+TRACED_VARIANTS = [
+    # (first-update fixture, trace it extends, env, config, recurrent)
+    ("first_update_ff_discrete.npz", "trace_ff_discrete.npz", "discrete", {}, False),
+    ("first_update_ff_discrete_minibatch.npz", "trace_ff_discrete_minibatch.npz", "discrete",
+     dict(sgd_minibatch_size=256, entropy_coeff=1e-2, dual_clip_param=5.0, horizons_per_env_reset=2), False),
+    ("first_update_ff_continuous_squashed.npz", "trace_ff_continuous_squashed.npz", "continuous",
+     dict(distribution_cls=SquashedNormal), False),
+    ("first_update_ff_continuous_normal.npz", "trace_ff_continuous_normal.npz", "continuous",
+     dict(entropy_coeff=1e-2), False),
+    ("first_update_rec_discrete.npz", "trace_rec_discrete.npz", "discrete", {}, True),
+    ("first_update_rec_continuous_minibatch.npz", "trace_rec_continuous_minibatch.npz", "continuous",
+     dict(sgd_minibatch_size=128, entropy_coeff=1e-2, seq_len=8, seqs_per_state_reset=2, horizons_per_env_reset=2),
+     True),
+]
+
+
+def gen_first_updates() -> None:
+    envs = {"discrete": DiscreteDummyEnv, "continuous": ContinuousDummyEnv}
+    for name, trace_name, env, cfg, recurrent in TRACED_VARIANTS:
+        gen_first_update(name, trace_name, envs[env], cfg, recurrent=recurrent)
+
+
+def gen_early_stop() -> None:
+    """KL early stop (src/rl8/algorithms/_feedforward.py:577-582) on the rollout of
+    trace_ff_discrete.npz with four minibatches per SGD iteration. The reference
+    rejects ``target_kl_div`` together with ``accumulate_grads``
+    (src/rl8/data.py:227-231), so a stop always finds ``.grad`` freshly cleared."""
+    trace = dict(np.load(os.path.join(HERE, "trace_ff_discrete.npz")))
+    try:
+        AlgorithmConfig(num_envs=64, horizon=32, device="cpu", accumulate_grads=True, sgd_minibatch_size=512,
+                        target_kl_div=0.1).build(DiscreteDummyEnv)
+        raise AssertionError("reference accepted target_kl_div with accumulate_grads")
+    except ValueError as e:
+        assert "not compatible with gradient" in str(e)
+
+    def run(**kw):
+        torch.manual_seed(42)
+        algo = AlgorithmConfig(num_envs=64, horizon=32, device="cpu", sgd_minibatch_size=512, **kw).build(
+            DiscreteDummyEnv)
+        with Recorder() as noise:
+            algo.collect()
+            for k, v in algo.buffer.items():
+                assert np.array_equal(v.numpy(), trace[f"it0_collect_{k}"]), k
+            with UpdateRecorder(algo) as rec:
+                stats = algo.step()
+        return algo, rec, stats, noise
+
+    _, rec, _, _ = run()
+    kls = np.array(rec.updates)[:, STAT_KEYS.index("monitors/kl_div")]
+    # update 0 sees the rollout's own weights (kl == 0); one Adam step later the kl is
+    # far above any later one: stop there, with a target well clear of both
+    j, target = 1, 0.1
+    assert kls[0] == 0.0 and kls[1] > 3 * 1.5 * target, kls
+    algo, rec, stats, noise = run(target_kl_div=target)
+    assert len(rec.updates) == j + 1, len(rec.updates)
+    arrays = {
+        "target_kl_div": np.float64(target),
+        "stopped_at_update": np.int64(j),
+        "kl_without_stop": kls,
+        "updates": np.array(rec.updates, np.float64),
+        "stat_keys": np.array(STAT_KEYS + ("reduce",)),
+        "perms": torch.stack(noise.perms),
+        "step_stat_keys": np.array(sorted(k for k in stats if not k.startswith("profiling"))),
+    }
+    arrays["step_stats"] = np.array([stats[k] for k in arrays["step_stat_keys"]], np.float64)
+    arrays["grads_are_none_after_stop"] = np.array(all(p_.grad is None for p_ in algo.policy.model.parameters()))
+    for k, p_ in algo.policy.model.named_parameters():
+        arrays[f"final_{k}"] = p_.detach().clone()
+    save("early_stop.npz", **arrays)
+
+
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "first_updates":
+        gen_first_updates()
+        gen_early_stop()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "views":
         gen_views()
         return
@@ -638,6 +816,8 @@ def main() -> None:
         dict(sgd_minibatch_size=128, entropy_coeff=1e-2, seq_len=8, seqs_per_state_reset=2, horizons_per_env_reset=2),
         recurrent=True,
     )
+    gen_first_updates()
+    gen_early_stop()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,184 @@
+"""The assembled path against numbers the REFERENCE itself produced, at
+north_star's 1e-5 bar (tests/golden/first_update_*.npz, early_stop.npz; written by
+tests/golden/generate_fixtures.py from the unmodified reference).
+
+Before the first optimizer step the weights are bit-identical to the
+reference's, so the first ``StatTracker.update`` of a ``step()``
+(``src/rl8/algorithms/_feedforward.py:562-574``; recurrent twin
+``_recurrent.py``) and the gradient handed to the first ``optimizer.step()``
+(``:585-590``) isolate this build's kernels -- rollout, GAE, gather, towers /
+LSTM forward and backward, fused loss -- from optimizer drift. All six traced
+variants are held to that: feed-forward discrete (full batch / minibatched +
+entropy + dual clip), feed-forward Normal + entropy, feed-forward
+SquashedNormal, recurrent discrete, recurrent continuous minibatched.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from rl8_amd import AlgorithmConfig, RecurrentAlgorithmConfig  # noqa: E402
+from rl8_amd import _utils as host_utils  # noqa: E402
+from rl8_amd.distributions import SquashedNormal  # noqa: E402
+from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv  # noqa: E402
+
+from .test_algorithm_gpu import inject  # noqa: E402
+
+NUM_ENVS, HORIZON = 64, 32
+
+#: (first-update fixture, trace with the inputs, env, traced config, recurrent)
+VARIANTS = {
+    "ff_discrete": ("trace_ff_discrete.npz", DiscreteDummyEnv, {}, False),
+    "ff_discrete_minibatch": (
+        "trace_ff_discrete_minibatch.npz", DiscreteDummyEnv,
+        dict(sgd_minibatch_size=256, entropy_coeff=1e-2, dual_clip_param=5.0, horizons_per_env_reset=2), False),
+    "ff_continuous_squashed": (
+        "trace_ff_continuous_squashed.npz", ContinuousDummyEnv, dict(distribution_cls=SquashedNormal), False),
+    "ff_continuous_normal": ("trace_ff_continuous_normal.npz", ContinuousDummyEnv, dict(entropy_coeff=1e-2), False),
+    "rec_discrete": ("trace_rec_discrete.npz", DiscreteDummyEnv, {}, True),
+    "rec_continuous_minibatch": (
+        "trace_rec_continuous_minibatch.npz", ContinuousDummyEnv,
+        dict(sgd_minibatch_size=128, entropy_coeff=1e-2, seq_len=8, seqs_per_state_reset=2,
+             horizons_per_env_reset=2), True),
+}
+
+STAT_KEYS = ("coefficients/entropy", "coefficients/vf", "losses/entropy", "losses/policy", "losses/vf",
+             "losses/total", "monitors/kl_div")
+
+#: north_star: fp32 losses within 1e-5 (relative). Absolute floors only where the
+#: reference's own number is rounding noise: with normalised advantages and
+#: ratio == 1 the full-batch policy loss is -mean(adv) ~ 1e-8 (a sum of 2048 O(1)
+#: fp32 terms that cancel), and the first KL is exactly 0 in the reference because
+#: it evaluates the same module twice.
+REL = 1e-5
+ABS = {"losses/policy": 1e-6, "losses/total": 1e-6, "monitors/kl_div": 1e-7}
+
+
+class Recorder:
+    """Every ``StatTracker.update`` of a ``step()`` and the gradient at its first
+    ``optimizer.step()`` (the reference-side recorder of the fixtures, mirrored)."""
+
+    def __init__(self, algo):
+        self.algo, self.updates, self.first_grads = algo, [], None
+
+    def __enter__(self):
+        rec = self
+        self._update, self._opt_step = host_utils.StatTracker.update, self.algo.optimizer.step
+
+        def update(tracker, data, /, *, reduce=False):
+            rec.updates.append([float(data[k]) for k in STAT_KEYS] + [float(reduce)])
+            return rec._update(tracker, data, reduce=reduce)
+
+        def opt_step(*args, **kwargs):
+            if rec.first_grads is None:
+                rec.first_grads = {k: p.grad.detach().clone() for k, p in rec.algo.policy.model.named_parameters()
+                                   if p.grad is not None}
+            return rec._opt_step(*args, **kwargs)
+
+        host_utils.StatTracker.update = update
+        self.algo.optimizer.step = opt_step
+        return self
+
+    def __exit__(self, *exc):
+        host_utils.StatTracker.update = self._update
+        self.algo.optimizer.step = self._opt_step
+
+
+def build(golden, variant, **overrides):
+    trace_name, env_cls, config, recurrent = VARIANTS[variant]
+    trace = golden(trace_name)
+    cfg_cls = RecurrentAlgorithmConfig if recurrent else AlgorithmConfig
+    algo = cfg_cls(num_envs=NUM_ENVS, horizon=HORIZON, **{**config, **overrides}).build(env_cls)
+    algo.policy.model.load_state_dict(
+        {k[len("init_"):]: torch.from_numpy(trace[k]) for k in trace if k.startswith("init_")})
+    inject(algo, trace, 0)
+    return algo, trace
+
+
+def assert_update(got, want, label):
+    for i, k in enumerate(STAT_KEYS):
+        assert got[i] == pytest.approx(want[i], rel=REL, abs=ABS.get(k, 1e-9)), (label, k, got[i], want[i])
+    assert got[-1] == want[-1], (label, "reduce flag")
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_one_sgd_iteration_matches_reference_to_1e5(golden, variant):
+    """``num_sgd_iters=1`` over one full-buffer minibatch: StepStats, the clipped
+    gradient of the optimizer step and the weights after it."""
+    g = golden(f"first_update_{variant}.npz")
+    algo, _ = build(golden, variant, num_sgd_iters=1, sgd_minibatch_size=None)
+    algo.collect()
+    with Recorder(algo) as rec:
+        stats = algo.step()
+    assert len(rec.updates) == 1
+    assert_update(rec.updates[0], g["sgd1_updates"][0], variant)
+    for k, w in zip(g["step_stat_keys"], g["sgd1_step_stats"]):
+        assert stats[str(k)] == pytest.approx(w, rel=REL, abs=ABS.get(str(k), 1e-9)), (variant, k)
+    # Gradient of the whole model as the optimizer saw it (after clipping to
+    # max_grad_norm): error relative to the gradient's norm, and per tensor
+    # relative to that tensor's largest entry.
+    want = {k[len("sgd1_grad_"):]: g[k] for k in g if k.startswith("sgd1_grad_")}
+    assert set(want) == set(rec.first_grads)
+    err_sq = ref_sq = 0.0
+    for k, w in want.items():
+        got = rec.first_grads[k].double().cpu().numpy()
+        err_sq += float(((got - w) ** 2).sum())
+        ref_sq += float((w.astype(np.float64) ** 2).sum())
+        np.testing.assert_allclose(got, w, rtol=0, atol=2e-5 * float(np.abs(w).max()) + 1e-9, err_msg=f"{variant} {k}")
+    assert (err_sq / ref_sq) ** 0.5 < 1e-5, (variant, (err_sq / ref_sq) ** 0.5)
+    assert ref_sq ** 0.5 == pytest.approx(float(g["sgd1_clipped_grad_norm"]), rel=1e-6)
+    # One Adam step moves a weight by lr * g / (|g| + eps'): ~ +-1e-3 whatever the
+    # gradient's size, so only entries whose gradient is not itself rounding noise
+    # are comparable, and those must land on the reference's weights.
+    lr = 1e-3
+    for k, p in algo.policy.model.named_parameters():
+        w, gw = g[f"sgd1_final_{k}"], want[k]
+        solid = np.abs(gw) > 1e-3 * np.abs(gw).max()
+        np.testing.assert_allclose(p.detach().cpu().numpy()[solid], w[solid], rtol=0, atol=0.02 * lr,
+                                   err_msg=f"{variant} weights {k}")
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_first_minibatch_of_traced_config_matches_reference_to_1e5(golden, variant):
+    """The traced configs themselves (4 SGD iterations, minibatched where the
+    trace is): the first per-minibatch update at 1e-5; the later ones, taken after
+    1..31 Adam steps on differently-ordered GEMMs, within the drift band of
+    test_algorithm_gpu.run_trace."""
+    g = golden(f"first_update_{variant}.npz")
+    algo, _ = build(golden, variant)
+    algo.collect()
+    with Recorder(algo) as rec:
+        algo.step()
+    want = g["traced_updates"]
+    assert len(rec.updates) == len(want)
+    assert_update(rec.updates[0], want[0], variant)
+    got = np.array(rec.updates)
+    assert np.array_equal(got[:, -1], want[:, -1])
+    np.testing.assert_allclose(got[1:, :-1], want[1:, :-1], rtol=2e-2, atol=2e-3)
+
+
+def test_kl_early_stop_matches_reference(golden):
+    """``target_kl_div`` (reference ``_feedforward.py:577-582``): same number of
+    updates, same stats, every ``.grad`` None afterwards, same weights as the
+    reference's run on the same rollout and permutations."""
+    g = golden("early_stop.npz")
+    with pytest.raises(ValueError, match="not compatible with gradient"):
+        AlgorithmConfig(num_envs=NUM_ENVS, horizon=HORIZON, accumulate_grads=True, sgd_minibatch_size=512,
+                        target_kl_div=0.1).build(DiscreteDummyEnv)
+    algo, _ = build(golden, "ff_discrete", sgd_minibatch_size=512, target_kl_div=float(g["target_kl_div"]))
+    algo.collect()
+    algo.injected_permutations = [torch.from_numpy(p) for p in g["perms"]]
+    with Recorder(algo) as rec:
+        stats = algo.step()
+    want = g["updates"]
+    assert len(rec.updates) == len(want) == int(g["stopped_at_update"]) + 1
+    assert_update(rec.updates[0], want[0], "early stop")
+    np.testing.assert_allclose(np.array(rec.updates)[1:, :-1], want[1:, :-1], rtol=2e-3, atol=1e-5)
+    for k, w in zip(g["step_stat_keys"], g["step_stats"]):
+        assert stats[str(k)] == pytest.approx(w, rel=2e-3, abs=1e-5), k
+    assert bool(g["grads_are_none_after_stop"])
+    assert all(p.grad is None for p in algo.policy.model.parameters())
+    for k, p in algo.policy.model.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"final_{k}"], rtol=0, atol=2e-4, err_msg=k)

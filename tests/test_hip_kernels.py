@@ -167,8 +167,13 @@ def test_ppo_loss_matches_reference_autograd(golden):
             sums, g_mean, g_ls, g_value = hip.ppo_loss_normal(
                 dev(g[f"{case}_feat_mean"]), dev(g[f"{case}_feat_log_std"]), common[0], dev(g[f"{case}_actions"]),
                 *tail, hp, squashed=case.startswith("squashed"))
-            np.testing.assert_allclose(host(g_mean), g[f"{case}_grad_mean"], rtol=1e-4, atol=1e-7, err_msg=case)
-            np.testing.assert_allclose(host(g_ls), g[f"{case}_grad_log_std"], rtol=1e-4, atol=1e-7, err_msg=case)
+            # 2e-5 relative like the categorical gradients; the absolute floor (1e-6 of the
+            # largest entry) covers entries that are themselves cancellation residue
+            # (measured: <= 9e-7 of max|g| over all 28 cases, profiles/r02_normal_tolerances.txt)
+            for got, name in ((g_mean, "grad_mean"), (g_ls, "grad_log_std")):
+                want = g[f"{case}_{name}"]
+                np.testing.assert_allclose(host(got), want, rtol=2e-5, atol=1e-6 * float(np.abs(want).max()),
+                                           err_msg=f"{case} {name}")
         np.testing.assert_allclose(host(g_value), g[f"{case}_grad_values"], rtol=2e-5, atol=1e-9, err_msg=case)
         got = _losses_from_sums(host(sums), kw)
         for i, name in enumerate(oracle.LOSS_KEYS):
@@ -307,6 +312,30 @@ def test_categorical_sampler_philox_bit_exact_vs_oracle():
     np.testing.assert_allclose(host(got_lp), want_lp, rtol=1e-6, atol=1e-6)
 
 
+def assert_logp_close(got, want, actions, *, squashed):
+    """Sampler log-probs at 2e-5 (north_star's 1e-5 bar, one ulp of slack on either
+    side). ``Normal``: plain ``|d| <= 2e-5 * (1 + |want|)``.
+
+    ``SquashedNormal`` adds the one term that cannot be held to that in fp32 BY
+    EITHER SIDE: ``log(1 - s^2 + eps)`` (reference ``distributions.py:163-168``) is
+    evaluated from the fp32 action ``s = tanh(u)``; near saturation one ulp of ``s``
+    moves it by ``2|s| ulp(s) / (1 - s^2 + eps)`` -- up to 0.5 at ``|s| = 1 - 2^-24``.
+    ``tanh`` on the device and in torch's CPU vector library differ by an ulp on
+    ~10 % of draws, and the reference's own fp32 value is up to 1.3e-4 away from an
+    fp64 evaluation of its formula on its own action
+    (profiles/r02_normal_tolerances.txt). So each sample's band is widened by the
+    movement of that term under 2 ulps of its action -- nothing else is loosened."""
+    got, want = got.astype(np.float64), want.astype(np.float64)
+    band = 2e-5 * (1.0 + np.abs(want))
+    if squashed:
+        s = actions.astype(np.float64)
+        eps = float(np.finfo(np.float32).eps)
+        moved = (2.0 * np.abs(s) / (1.0 - s * s + eps)) * np.spacing(np.abs(actions).astype(np.float32))
+        band = band + 2.0 * moved.reshape(moved.shape[0], -1).sum(-1, keepdims=True).reshape(want.shape)
+    bad = np.abs(got - want) > band
+    assert not bad.any(), (int(bad.sum()), float(np.abs(got - want)[bad].max()))
+
+
 @pytest.mark.parametrize("kind", ["normal", "squashed"])
 @pytest.mark.parametrize("adim", [1, 3])
 def test_normal_samplers_match_reference(golden, kind, adim):
@@ -315,14 +344,14 @@ def test_normal_samplers_match_reference(golden, kind, adim):
     actions, logp = hip.normal_sample_logp(dev(g[f"{p}_mean"]), dev(g[f"{p}_log_std"]), dev(g[f"{p}_eps"]),
                                            squashed=kind == "squashed")
     np.testing.assert_allclose(host(actions), g[f"{p}_actions"], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(host(logp), g[f"{p}_logp"], rtol=1e-4, atol=2e-4)
+    assert_logp_close(host(logp), g[f"{p}_logp"], host(actions), squashed=kind == "squashed")
     # Philox noise agrees with the oracle's
     a2, lp2 = hip.normal_sample_logp(dev(g[f"{p}_mean"]), dev(g[f"{p}_log_std"]), None, squashed=kind == "squashed",
                                      seed=3, step=11, row_offset=5)
     wa, wlp = oracle.normal_sample(g[f"{p}_mean"], g[f"{p}_log_std"], squashed=kind == "squashed", seed=3, step=11,
                                    row_offset=5)
     np.testing.assert_allclose(host(a2), wa, rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(host(lp2), wlp, rtol=1e-4, atol=2e-4)
+    assert_logp_close(host(lp2), wlp, host(a2), squashed=kind == "squashed")
 
 
 # --------------------------------------------------------------------------- #
@@ -377,7 +406,7 @@ def test_fused_dummy_continuous_step_vs_oracle(squashed):
         reward_col=cols["reward"], obs_col_next=cols["obs"], rdr_t=None, rdr_t1=None, gamma=0.95, seed=0, step=0,
         env_offset=0, deterministic=False)
     np.testing.assert_allclose(host(cols["action"]), want_a, rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(host(cols["logp"]), want_lp, rtol=1e-4, atol=2e-4)
+    assert_logp_close(host(cols["logp"]), want_lp, host(cols["action"]), squashed=squashed)
     np.testing.assert_allclose(host(state), want_s, rtol=1e-6, atol=1e-5)
     np.testing.assert_allclose(host(cols["reward"]), want_r, rtol=1e-6, atol=1e-5)
 

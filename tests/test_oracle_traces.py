@@ -46,3 +46,35 @@ def test_oracle_driver_reproduces_reference_trace(golden, name, kw):
         np.testing.assert_allclose(algo.buf["obs"][:, -1], g[f"it{it}_final_obs"], rtol=1e-5, atol=1e-5)
         for k, v in algo.model.state_dict().items():
             np.testing.assert_allclose(v.numpy(), g[f"it{it}_final_{k}"], rtol=2e-3, atol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+def test_oracle_first_update_matches_reference_to_1e5(golden, name, kw):
+    """One SGD iteration over one full-buffer minibatch from the reference's
+    initial weights: the reference's own StepStats and the gradient it handed to
+    ``optimizer.step()`` (tests/golden/first_update_*.npz) at north_star's 1e-5."""
+    torch.set_num_threads(8)
+    g = golden(name)
+    first = golden(name.replace("trace_", "first_update_"))
+    algo = OraclePPO(num_envs=64, horizon=32, **{**kw, "num_sgd_iters": 1, "sgd_minibatch_size": None})
+    load_reference_weights(algo.model, g)
+    discrete = kw["env"] == "discrete"
+    algo.collect(noise=g["it0_cat_q"] if discrete else g["it0_normal_eps"], reset_state=g.get("it0_reset_state"))
+    grads = {}
+    real_step = algo.optimizer.step
+
+    def recording_step(*a, **k):
+        grads.update({n: p.grad.detach().clone().numpy() for n, p in algo.model.named_parameters()})
+        return real_step(*a, **k)
+
+    algo.optimizer.step = recording_step
+    step = algo.step(perms=None)
+    floors = {"losses/policy": 1e-6, "losses/total": 1e-6, "monitors/kl_div": 1e-7}
+    for k, w in zip(first["step_stat_keys"], first["sgd1_step_stats"]):
+        assert step[str(k)] == pytest.approx(w, rel=1e-5, abs=floors.get(str(k), 1e-9)), (k, step[str(k)], w)
+    err_sq = ref_sq = 0.0
+    for k, got in grads.items():
+        w = first[f"sgd1_grad_{k}"].astype(np.float64)
+        err_sq += float(((got - w) ** 2).sum())
+        ref_sq += float((w ** 2).sum())
+    assert (err_sq / ref_sq) ** 0.5 < 1e-5

@@ -94,16 +94,19 @@ def worker(rank: int, port: int, results) -> None:
         # oracle returns means over its ml samples -> back to raw sums
         ent_coeff = 0.01
         pol, vf, ent, kl = (loc_losses[k] * ml for k in ("policy", "vf", "entropy", "kl"))
-        sums = shards.sum_(torch.tensor([ent, pol, vf, float(ml), kl], dtype=torch.float64))
-        got = losses_from_sums(*sums.tolist(), entropy_coeff=ent_coeff, vf_coeff=1.0)
-        for k in ("entropy", "policy", "vf", "total", "kl"):
-            assert got[k] == pytest.approx(want_losses[k], rel=1e-9, abs=1e-12), k
+        sums = torch.tensor([ent, pol, vf, float(ml), kl], dtype=torch.float64)
         # gradient: a linear "model" w so that dL/dw = sum_i g_i * x_i; shard grads are
-        # scaled by 1/M_global (oracle scaled them by 1/ml) and SUM-reduced.
+        # scaled by 1/M_global (oracle scaled them by 1/ml) and SUM-reduced -- in the
+        # same all-reduce as the loss sums (one collective per optimizer step).
         w = torch.nn.Parameter(torch.zeros(2))
         x = torch.from_numpy(flat(logits[local]).astype(np.float64))
         w.grad = (torch.from_numpy(loc_g.reshape(ml, 2).astype(np.float64)) * (ml / m) * x).sum(0).float()
-        shards.sum_gradients_([w])
+        before = shards.collectives
+        shards.sum_gradients_([w], [sums])
+        assert shards.collectives == before + 1
+        got = losses_from_sums(*sums.tolist(), entropy_coeff=ent_coeff, vf_coeff=1.0)
+        for k in ("entropy", "policy", "vf", "total", "kl"):
+            assert got[k] == pytest.approx(want_losses[k], rel=1e-9, abs=1e-12), k
         xw = torch.from_numpy(flat(logits).astype(np.float64))
         want_grad = (torch.from_numpy(want_g.reshape(m, 2).astype(np.float64)) * xw).sum(0).float()
         torch.testing.assert_close(w.grad, want_grad, rtol=1e-5, atol=1e-7)
@@ -112,8 +115,14 @@ def worker(rank: int, port: int, results) -> None:
         lin = torch.nn.Linear(3, 2)
         with torch.no_grad():
             lin.weight.fill_(float(rank + 1))
+        bias0 = lin.bias.detach().clone()
+        gathered = [torch.empty_like(bias0) for _ in range(WORLD)]
+        dist.all_gather(gathered, bias0)
+        before = shards.collectives
         shards.broadcast_parameters_(lin)
+        assert shards.collectives == before + 1  # one flat buffer, not one call per tensor
         assert float(lin.weight.mean()) == 1.0
+        assert torch.equal(lin.bias.detach(), gathered[0])
         results.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
