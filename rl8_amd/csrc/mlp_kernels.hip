@@ -830,6 +830,12 @@ __global__ __launch_bounds__(kWgradThreads, 1) void mlp_wgrad_kernel(
     one_tile(tile, 0, addr0, addr1);
     if (tile + stride < tiles) one_tile(tile + stride, 1, addr1, addr0);
   }
+  // No hand-issued LDS read is in flight here (a tile prefetches fragments only when
+  // a next tile follows), but that is a fact about correlated branches; this wait
+  // (once per kernel) makes it a fact about the instruction stream, which is what
+  // tools/check_inflight_regs.py verifies before the epilogue reuses the registers.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // (the epilogue's address arithmetic stays behind the wait)
   // Partial slab of this workgroup: slab[j][i].
   float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;
 #pragma unroll

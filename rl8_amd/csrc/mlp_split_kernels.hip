@@ -250,14 +250,32 @@ __device__ __forceinline__ void split_mma_row(const u32x4 &a, const u32x4 (&b)[4
 }
 
 // v (fp32 pair) -> the three packed bf16 pairs (element 0 in the low half).
-// Deliberately scalar arithmetic (and this file is built with -fno-slp-vectorize):
-// with packed fp32 instructions in these loops -- v_pk_fma_f32 chains the SLP
-// vectoriser formed out of the head-gradient fmas, operands shuffled by v_mov right
-// behind them, all interleaved with bf16 MFMAs -- one run in four of the fused
-// weight-gradient kernel came back with a few accumulators wrong in lanes 48..63
-// (the low half of a packed pair computed from the value written two instructions
-// later).  No packed fp32 ops: 0 of 40 stress runs; tests/test_mlp_split_gpu.py
-// repeats every kernel under load and compares bits.
+// Deliberately scalar arithmetic, and this file is built with -fno-slp-vectorize:
+// NO PACKED FP32 ARITHMETIC (v_pk_{fma,add,mul}_f32) IN KERNELS THAT INTERLEAVE
+// VALU WORK WITH bf16 MFMAs.  What happened (round 1, fused weight-gradient kernel,
+// one run in four: a few dW3 accumulators wrong in lanes 48..63, always the low half
+// of a pair, off by one fma evaluated on "the value written two instructions
+// later"), read off the failing build's listing (commit 7f18347, recompiled to
+// ISA; tools/check_inflight_regs.py::packed_war finds 53 such windows in it):
+//     v_pk_fma_f32 v[196:197], v[224:225], v[194:195], v[196:197]   ; reads v224 (low half)
+//     v_pk_fma_f32 v[226:227], v[226:227], v[206:207], 0
+//     v_mov_b32    v224, v225        ; pair-alignment shuffle for the NEXT packed op
+// i.e. a packed op's SOURCE register overwritten one or two VALU slots later.  A
+// write-after-read in program order is architecturally safe, and for single-pass
+// VALU ops it is safe here too (these kernels are full of it, also directly behind
+// MFMAs that read the register).  A packed fp32 op issues as two passes; beside
+// bf16 MFMAs -- where VALU instructions are slotted between matrix passes instead of
+// owning the pipe -- the second pass's operand fetch for the last quarter-wave came
+// after the younger v_mov had written v224.  The fp32-MFMA kernels (mlp_kernels.hip)
+// contain the same packed ops at the same distance and never failed: fp32 MFMAs do
+// not co-issue with the VALU.  LLVM's gfx950 hazard recognizer has no rule for it, so
+// the rule lives here: no packed ops (flag above, scalar code below), enforced on the
+// shipped ISA by tests/test_kernel_resources.py (regex + packed_war scan).
+// The other suspect was ruled out on the same listing: the CFG walk of
+// tools/check_inflight_regs.py finds no instruction touching the destination of a
+// hand-issued load (ds_read_b128 / s_buffer_load_dwordx8 with the wait in a later
+// asm statement) before a covering s_waitcnt -- neither in the failing build nor in
+// the shipped one, where the same test now asserts it for every kernel.
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
   const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
   const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);

@@ -7,11 +7,61 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_inflight_regs as inflight  # noqa: E402
+
+
+def assert_no_inflight_register_access(text: str, pattern: str = "", min_hand_loads: int = 0) -> int:
+    """No kernel of this listing touches the destination of a hand-issued (inline asm)
+    load before a wait that covers it (tools/check_inflight_regs.py)."""
+    hand = 0
+    for name, body in inflight.kernels_of(text):
+        if pattern and not re.search(pattern, name):
+            continue
+        violations, stats = inflight.check_kernel(name, body)
+        assert not violations, (name, [(v.index, v.line, v.load) for v in violations[:3]])
+        hand += stats.get("hand_loads", 0)
+    assert hand >= min_hand_loads, hand
+    return hand
+
+
+def test_inflight_checker_flags_what_it_should():
+    """Positive controls: the walker must see a copy between an asm load and its wait,
+    honour counted waits and branch arms, and find the packed-fp32 WAR window."""
+    def kernel(lines):
+        return "\n".join("\t" + ln for ln in lines)
+
+    bad = kernel([";;#ASMSTART", "ds_read_b128 v[4:7], v1 offset:0", ";;#ASMEND", "v_mov_b32_e32 v9, v5",
+                  ";;#ASMSTART", "s_waitcnt lgkmcnt(0)", ";;#ASMEND", "s_endpgm"])
+    violations, stats = inflight.check_kernel("k", bad)
+    assert len(violations) == 1 and violations[0].line.startswith("v_mov_b32") and stats["hand_loads"] == 1
+    good = kernel([";;#ASMSTART", "ds_read_b128 v[4:7], v1 offset:0", ";;#ASMEND",
+                   ";;#ASMSTART", "ds_read_b128 v[8:11], v1 offset:16", ";;#ASMEND",
+                   ";;#ASMSTART", "s_waitcnt lgkmcnt(1)", ";;#ASMEND", "v_mov_b32_e32 v20, v5", "s_waitcnt lgkmcnt(0)",
+                   "v_mov_b32_e32 v21, v9", "s_endpgm"])
+    assert inflight.check_kernel("k", good)[0] == []
+    # a scalar-cache load in flight returns out of order: a counted wait retires nothing
+    smem = kernel([";;#ASMSTART", "ds_read_b128 v[4:7], v1 offset:0", ";;#ASMEND", "s_load_dword s4, s[0:1], 0x0",
+                   "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v20, v5", "s_endpgm"])
+    assert len(inflight.check_kernel("k", smem)[0]) == 1
+    # the wait sits on one arm of a branch only
+    arm = kernel([";;#ASMSTART", "ds_read_b128 v[4:7], v1 offset:0", ";;#ASMEND", "s_cbranch_scc1 .LBB0_2",
+                  "s_waitcnt lgkmcnt(0)", ".LBB0_2:", "v_mov_b32_e32 v20, v5", "s_endpgm"])
+    assert len(inflight.check_kernel("k", arm)[0]) == 1
+    # compiler-visible loads are the compiler's business (no false alarm on its schedules)
+    visible = kernel(["ds_read_b128 v[4:7], v1 offset:0", "v_mov_b32_e32 v9, v5", "s_endpgm"])
+    assert inflight.check_kernel("k", visible)[0] == []
+    war = kernel(["v_pk_fma_f32 v[196:197], v[224:225], v[194:195], v[196:197] op_sel_hi:[1,0,1]",
+                  "v_pk_fma_f32 v[226:227], v[226:227], v[206:207], 0 op_sel_hi:[1,1,0]",
+                  "v_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]", "v_mov_b32_e32 v224, v225"])
+    hits = inflight.packed_war(war)
+    assert len(hits) == 1 and hits[0][2] == 3 and hits[0][4] == [("v", 224)]
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
@@ -42,6 +92,8 @@ def test_compiled_tower_kernels_do_not_use_scratch(tmp_path):
         else:
             assert scratch == 0, (name, scratch)  # run-time widths get one workgroup per CU instead
     assert checked >= 36 + 1
+    # the fp32 weight-gradient kernel issues its LDS fragment reads by hand
+    assert_no_inflight_register_access(text, min_hand_loads=100)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
@@ -75,6 +127,13 @@ def test_compiled_split_kernels_resources(tmp_path):
             checked += 1
     assert checked >= 24 + 12 + 5 + 12
     _check_wgrad_scalar_windows(text)
+    # Every hand-issued load (ds_read_b128, s_buffer_load_dwordx8, ...) of every kernel: nothing
+    # reads or overwrites its destination before a wait that covers it, on any path.
+    assert_no_inflight_register_access(text, min_hand_loads=50 * 100)
+    # and the round-1 event's instruction pair cannot form: no packed fp32 op has a source
+    # overwritten within the next two VALU slots (there are no packed fp32 ops at all)
+    for name, body in inflight.kernels_of(text):
+        assert inflight.packed_war(body) == [], name
 
 
 def _sgprs(operand: str) -> set[int]:
