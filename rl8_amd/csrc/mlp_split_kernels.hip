@@ -42,6 +42,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define RL8_DIAG_SKIP 0
 #endif
 constexpr int kSplitDiagSkip = RL8_DIAG_SKIP;
+#ifndef RL8_H2_STORE_AUX
+#define RL8_H2_STORE_AUX (16 | 2)  // cache policy of the training forward's h2 stores: sc1 | nt (streaming)
+#endif
 
 constexpr int kSplitRows = 128;                 // rows per macro tile
 constexpr int kSplitSteps = kHidden / 16;       // k-steps of 16
@@ -239,6 +242,26 @@ __device__ __forceinline__ void split_mma(const u32x4 (&a)[2], const u32x4 (&b)[
     }
 }
 
+// The same products with the operand roles exchanged: the 32x32 block comes out
+// TRANSPOSED in the accumulator -- lane = sample row, registers = output columns
+// (r -> column (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  A- and B-fragments have the
+// same register layout (lane = index mod 32, k-half = lane / 32), so this costs
+// nothing, every dot product is the same sum, and four consecutive registers are four
+// consecutive columns of one row: the forward kernel's h2 leaves as 16-byte stores
+// and its head needs no cross-lane reduction tree (see the epilogue there).
+template <bool FIRST>
+__device__ __forceinline__ void split_mma_t(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[nt]),
+                                                            __builtin_bit_cast(bf16x8, a[mt]),
+                                                            FIRST ? zero : acc[mt][nt], 0, 0, 0);
+    }
+}
+
 template <bool FIRST>
 __device__ __forceinline__ void split_mma_row(const u32x4 &a, const u32x4 (&b)[4], f32x16 (&acc)[4]) {
 #pragma unroll
@@ -302,7 +325,11 @@ __device__ __forceinline__ float half_wave_sum_level(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false));
 }
 
-constexpr int split_forward_lds_bytes(int k_out) { return 2 * kSplitStageBytes + kSplitRows * k_out * 2 * 4; }
+// [stage 0][stage 1][head partials of the upper column half: [128 rows][k_out]][b2 | w3: (1 + k_out) x 1 KiB]
+constexpr int split_forward_lds_bytes(int k_out) {
+  return 2 * kSplitStageBytes + kSplitRows * k_out * 4 + (1 + k_out) * kHidden * 4;
+}
+static_assert(split_forward_lds_bytes(4) <= 80 * 1024, "two workgroups per CU");
 
 template <int DIN, int NOUT, bool SAVE>
 __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_tower_forward_split_kernel(
@@ -412,6 +439,17 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
 
+  // Epilogue constants, per register rather than per lane in the transposed
+  // accumulator layout: b2 and the rows of W3 (zero rows up to kOut) live in LDS and
+  // are fetched as 16-byte quads of four consecutive columns.
+  {
+    float *consts = reinterpret_cast<float *>(smem + 2 * kSplitStageBytes + kSplitRows * kOut * 4);
+    consts[tid] = b2[tid];
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) consts[(1 + q) * kHidden + tid] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
+    // (visible to every wave behind the prologue's step barrier below)
+  }
+
   f32x16 acc[2][4];
   [[maybe_unused]] int trace_it = -1;  // (tuning builds: tile iteration, see RL8_SPLIT_STAMP)
   int64_t r0 = p_r0;  // consumer's tile
@@ -458,9 +496,9 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     produce_a(ks, planes);
     wait_lds_all(f);
     RL8_SPLIT_STAMP(trace_it, wave, s, 1);
-    split_mma<FIRST>(f.am, f.bm, acc);
-    split_mma<false>(f.ah, f.bm, acc);
-    split_mma<false>(f.am, f.bh, acc);
+    split_mma_t<FIRST>(f.am, f.bm, acc);
+    split_mma_t<false>(f.ah, f.bm, acc);
+    split_mma_t<false>(f.am, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
     write_a(P ^ 1, planes);
     // lo planes into the registers of the mid planes
@@ -472,11 +510,11 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
                                               : nt == 2 ? lds_read_b128<8 * 1024>(br)
                                                         : lds_read_b128<11 * 1024>(br);
     __builtin_amdgcn_sched_barrier(0);
-    split_mma<false>(f.ah, f.bh, acc);
+    split_mma_t<false>(f.ah, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
     wait_lds_all(f);
-    split_mma<false>(f.ah, f.bm, acc);
-    split_mma<false>(f.am, f.bh, acc);
+    split_mma_t<false>(f.ah, f.bm, acc);
+    split_mma_t<false>(f.am, f.bh, acc);
     __builtin_amdgcn_sched_barrier(0);
     RL8_SPLIT_STAMP(trace_it, wave, s, 2);
     step_barrier();
@@ -510,123 +548,201 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     do_step(F{}, P0{}, kSplitSteps - 2);
     do_step(F{}, P1{}, kSplitSteps - 1);
 
-    // Epilogue: bias + ReLU on the accumulators; h2 to HBM when saving (each
-    // store = two 128-byte row segments); head = per-lane partial over this
-    // lane's four columns, summed across the half-wave with DPP adds, the two
-    // column halves of the workgroup meeting in LDS.
+    // Epilogue on the TRANSPOSED accumulators (split_mma_t): this lane holds sample
+    // row 64 wr + 32 mt + l32 and, of column block 128 wc + 32 nt, the sixteen columns
+    // 8 g + 4 hh + e (register r = 4 g + e).  So
+    //   * h2 leaves as 16-byte stores (four consecutive columns per lane, the two
+    //     half-waves side by side: 32 contiguous bytes per row and instruction, a full
+    //     128-byte line per row over g = 0..3) -- 32 stores per wave and tile instead
+    //     of 128 dword stores, the largest item of the old epilogue;
+    //   * the ReLU gate bits of a row are built in that row's own lane (add + funnel
+    //     shift per element) instead of 128 ballots and 256 v_writelane;
+    //   * the head is a dot product down the lane's registers against W3 quads from
+    //     LDS plus ONE half-wave exchange, instead of a five-level DPP reduction per
+    //     eight rows.
+    // b2 / W3 come from the constants block in LDS (hand-issued reads, explicit waits).
     // (tuning builds, bit 4096: every tile's h2 lands on the first tile's lines -- the stores are issued but stay in L2)
     RL8_SPLIT_STAMP_E(trace_it, wave, 0);
     const __amdgpu_buffer_rsrc_t h2rsrc =
         buffer_rsrc(SAVE ? save_h2 + ((kSplitDiagSkip & 4096) ? (r0 & 0x1ffff) : r0) * kHidden : nullptr, rows * kHidden * 4);
     const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
     const unsigned outp = lds_offset(smem) + 2 * kSplitStageBytes;
-    // This lane's four output columns (re-read per tile -- L1 hits -- rather than
-    // held across the matrix loop, where every register counts).
-    float b2r[4], w3r[4][kOut];
+    const unsigned constp = outp + kSplitRows * kOut * 4 + (128 * wc + 4 * hh) * 4;
+    constexpr int kChains = kOut <= 2 ? 4 : 2;  // (registers: three outputs x four chains spilled)
+    float part[2][kOut][kChains];
+    [[maybe_unused]] uint32_t gate_words[2][4];
+    // h2 goes to HBM through a per-wave transpose in LDS (stage 1 is dead between the
+    // barrier of step 15 and the barrier of this epilogue, for every wave): written as
+    // the accumulators hold it (lane = row), read back eight lanes per row, so a store
+    // instruction is eight full 128-byte lines instead of thirty-two 32-byte pieces
+    // (scattered 32-byte pieces measured 712 us per 2^20 rows at best, 1 185 us with
+    // the streaming policy, against 588 us with the stores compiled out).
+    constexpr int kH2Pitch = 128 + 16;
+    static_assert(4 * 64 * kH2Pitch <= kSplitStageBytes, "transpose scratch fits in stage 1");
+    [[maybe_unused]] const unsigned t_base = lds_offset(smem) + kSplitStageBytes + wave * (64 * kH2Pitch);
+    [[maybe_unused]] const unsigned t_write = t_base + l32 * kH2Pitch + 16 * hh;
+    [[maybe_unused]] const unsigned t_read = t_base + (lane_id() >> 3) * kH2Pitch + (lane_id() & 7) * 16;
+    [[maybe_unused]] const int h2_voff = ((64 * wr + (lane_id() >> 3)) * kHidden + 128 * wc + 4 * (lane_id() & 7)) * 4;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const int j = 128 * wc + 32 * nt + l32;
-      b2r[nt] = b2[j];
+      // The column block in groups of kGroup quads (g = eight columns): b2 and the
+      // kOut rows of W3 for the group from LDS, then bias + ReLU, the h2 quads into
+      // the transpose scratch, gate nibbles and head products.  (Wide heads take two
+      // quads at a time: sixteen W3 quads plus the block read back would not fit.)
+      constexpr int kGroup = kOut >= 4 ? 2 : 4;
+      [[maybe_unused]] u32x4 t_rows[8];
+      constexpr bool kStore = SAVE && !(kSplitDiagSkip & 8);
+      auto read_block = [&]() {  // the block back, eight lanes per row (in order behind the writes: same wave)
+        t_rows[0] = lds_read_b128<0 * 8 * kH2Pitch>(t_read);
+        t_rows[1] = lds_read_b128<1 * 8 * kH2Pitch>(t_read);
+        t_rows[2] = lds_read_b128<2 * 8 * kH2Pitch>(t_read);
+        t_rows[3] = lds_read_b128<3 * 8 * kH2Pitch>(t_read);
+        t_rows[4] = lds_read_b128<4 * 8 * kH2Pitch>(t_read);
+        t_rows[5] = lds_read_b128<5 * 8 * kH2Pitch>(t_read);
+        t_rows[6] = lds_read_b128<6 * 8 * kH2Pitch>(t_read);
+        t_rows[7] = lds_read_b128<7 * 8 * kH2Pitch>(t_read);
+      };
 #pragma unroll
-      for (int q = 0; q < kOut; ++q) w3r[nt][q] = q < n_out ? w3[q * kHidden + j] : 0.0f;
-    }
+      for (int g0 = 0; g0 < 4; g0 += kGroup) {
+        u32x4 bq[kGroup], wq[kOut][kGroup];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      [[maybe_unused]] int gate_words[2] = {0, 0};
+        for (int gi = 0; gi < kGroup; ++gi) {
+          const unsigned a = constp + (32 * nt + 8 * (g0 + gi)) * 4;
+          bq[gi] = lds_read_b128<0>(a);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = relu1(acc[mt][nt][r] + b2r[nt]);
-        if constexpr (SAVE && !(kSplitDiagSkip & 8)) {
-          // (spreading these stores behind the head batches below measured no faster)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
-            buffer_store_f32_streaming(acc[mt][nt][r], h2rsrc, (4 * hh * kHidden + 128 * wc + 32 * nt + l32) * 4, sr * (kHidden * 4));
-          }
+          for (int q = 0; q < kOut; ++q)
+            wq[q][gi] = q == 0   ? lds_read_b128<1 * kHidden * 4>(a)
+                        : q == 1 ? lds_read_b128<2 * kHidden * 4>(a)
+                        : q == 2 ? lds_read_b128<3 * kHidden * 4>(a)
+                        : q == 3 ? lds_read_b128<4 * kHidden * 4>(a)
+                        : q == 4 ? lds_read_b128<5 * kHidden * 4>(a)
+                        : q == 5 ? lds_read_b128<6 * kHidden * 4>(a)
+                        : q == 6 ? lds_read_b128<7 * kHidden * 4>(a)
+                                 : lds_read_b128<8 * kHidden * 4>(a);
         }
-        if constexpr (SAVE) {
-          // ReLU gate of h2, one bit per element, [row][8 words]: a compare of an
-          // accumulator register IS two finished words (32 columns of the hh = 0
-          // row, 32 of the hh = 1 row); they are parked in lane (row mod 32) + 32
-          // (nt odd) of collector nt / 2 and leave as four stores per wave and tile.
-          if (save_gate2 != nullptr) {
-            auto park = [&](auto r_tag) {
-              constexpr int r = decltype(r_tag)::value;
-              constexpr int rl = (r & 3) + 8 * (r >> 2);
-              const unsigned long long bits = __builtin_amdgcn_ballot_w64(acc[mt][nt][r] > 0.0f);
-              if (nt & 1) {
-                gate_words[nt >> 1] = write_lane<rl + 32>(gate_words[nt >> 1], (uint32_t)bits);
-                gate_words[nt >> 1] = write_lane<rl + 36>(gate_words[nt >> 1], (uint32_t)(bits >> 32));
+#pragma unroll
+        for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(bq[gi]);
+#pragma unroll
+        for (int q = 0; q < kOut; ++q)
+#pragma unroll
+          for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(wq[q][gi]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+          for (int gi = 0; gi < kGroup; ++gi) {
+            const int g = g0 + gi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)  // (not __builtin_bit_cast on a vector-element lvalue: it reads element 0)
+              acc[mt][nt][4 * g + e] = relu1(acc[mt][nt][4 * g + e] + __uint_as_float(bq[gi][e]));
+            if constexpr (kStore) {
+              // h2 block [64 rows][32 columns] of this wave -> its transpose scratch (row
+              // pitch 144 B: the eight lanes of a b128 phase hit eight distinct 16-byte
+              // slots, writing as well as reading)
+              const f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+              const u32x4 u = __builtin_bit_cast(u32x4, v);
+              if (mt == 0) {
+                g == 0 ? lds_write_b128<0>(t_write, u) : g == 1 ? lds_write_b128<32>(t_write, u)
+                : g == 2 ? lds_write_b128<64>(t_write, u) : lds_write_b128<96>(t_write, u);
               } else {
-                gate_words[nt >> 1] = write_lane<rl>(gate_words[nt >> 1], (uint32_t)bits);
-                gate_words[nt >> 1] = write_lane<rl + 4>(gate_words[nt >> 1], (uint32_t)(bits >> 32));
+                g == 0 ? lds_write_b128<32 * kH2Pitch>(t_write, u) : g == 1 ? lds_write_b128<32 * kH2Pitch + 32>(t_write, u)
+                : g == 2 ? lds_write_b128<32 * kH2Pitch + 64>(t_write, u) : lds_write_b128<32 * kH2Pitch + 96>(t_write, u);
               }
-            };
-            park(std::integral_constant<int, 0>{}), park(std::integral_constant<int, 1>{});
-            park(std::integral_constant<int, 2>{}), park(std::integral_constant<int, 3>{});
-            park(std::integral_constant<int, 4>{}), park(std::integral_constant<int, 5>{});
-            park(std::integral_constant<int, 6>{}), park(std::integral_constant<int, 7>{});
-            park(std::integral_constant<int, 8>{}), park(std::integral_constant<int, 9>{});
-            park(std::integral_constant<int, 10>{}), park(std::integral_constant<int, 11>{});
-            park(std::integral_constant<int, 12>{}), park(std::integral_constant<int, 13>{});
-            park(std::integral_constant<int, 14>{}), park(std::integral_constant<int, 15>{});
+            }
+          }
+        }
+        // (narrow heads: the block is read back here, ahead of the gate bits and head
+        // products that hide the round trip)
+        if constexpr (kStore && kGroup == 4) read_block();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+          for (int gi = 0; gi < kGroup; ++gi) {
+            const int g = g0 + gi;
+            if constexpr (SAVE) {
+              // gate of h2, bit c of word [row][4 wc + nt] <=> column 32 (4 wc + nt) + c > 0.
+              // h2 >= +0 here, so "h2 > 0" is bit 31 of (bits(h2) + 0x7fffffff); four of
+              // them are funnel-shifted into a nibble (element 0 lowest), the nibble goes
+              // to bit 8 g + 4 hh.  The other half-wave holds the interleaved nibbles.
+              uint32_t nib = 0;
+#pragma unroll
+              for (int e = 3; e >= 0; --e)
+                nib = __builtin_amdgcn_alignbit(nib, __float_as_uint(acc[mt][nt][4 * g + e]) + 0x7fffffffu, 31);
+              gate_words[mt][nt] = (g == 0 ? 0u : gate_words[mt][nt]) | (nib << (8 * g + 4 * hh));
+            }
+            // head partials of this row: four (two for wide heads) independent chains per
+            // output, 16 (32) terms each over the tile, so the sum is not one 64-term
+            // chain and the fmas do not wait on each other
+#pragma unroll
+            for (int q = 0; q < kOut; ++q) {
+              float p = (nt == 0 && g < kChains) ? 0.0f : part[mt][q][g % kChains];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) p = __builtin_fmaf(acc[mt][nt][4 * g + e], __uint_as_float(wq[q][gi][e]), p);
+              part[mt][q][g % kChains] = p;
+            }
           }
         }
       }
-      if constexpr (SAVE) {
-        if (save_gate2 != nullptr) {
-          const int row = 64 * wr + 32 * mt + l32;
-          if (row < rows) {
-            uint32_t *dst = save_gate2 + r0 * 8;  // uniform base, 32-bit lane offset
-            dst[(unsigned)(row * 8 + 4 * wc + hh)] = (uint32_t)gate_words[0];
-            dst[(unsigned)(row * 8 + 4 * wc + hh + 2)] = (uint32_t)gate_words[1];
-          }
+      if constexpr (kStore) {
+        if constexpr (kGroup != 4) read_block();
+        wait_lds<0>(t_rows[0], t_rows[1], t_rows[2], t_rows[3]);
+        wait_lds<0>(t_rows[4], t_rows[5], t_rows[6], t_rows[7]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)  // rows 8 i + (lane >> 3), columns 32 nt + 4 (lane & 7) .. + 3
+          __builtin_amdgcn_raw_buffer_store_b128(t_rows[i], h2rsrc, h2_voff + (8 * i * kHidden + 32 * nt) * 4, 0, RL8_H2_STORE_AUX);
+        if constexpr ((kSplitDiagSkip & 16384) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tuning builds: expose the store latency
+      }
+    }
+    RL8_SPLIT_STAMP_E(trace_it, wave, 1);
+    // Half-wave exchange: lane (l32, hh) ends with the total of row 64 wr + 32 hh + l32
+    // over this wave's 128 columns (v_permlane32_swap: [A_lo, B_lo] and [A_hi, B_hi]).
+    float total[kOut];
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) {
+      float p0 = part[0][q][0] + part[0][q][1], p1 = part[1][q][0] + part[1][q][1];
+      if constexpr (kChains == 4) {
+        p0 += part[0][q][2] + part[0][q][3];
+        p1 += part[1][q][2] + part[1][q][3];
+      }
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+      total[q] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const int my_row = 64 * wr + lane_id();
+    if constexpr (SAVE) {
+      if (save_gate2 != nullptr) {
+        // full words = own nibbles | the other half-wave's; lane (l32, hh) keeps row
+        // 64 wr + 32 hh + l32's four words and stores them as one 16-byte piece
+        u32x4 words;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const auto s0 = __builtin_amdgcn_permlane32_swap(gate_words[0][nt], gate_words[0][nt], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(gate_words[1][nt], gate_words[1][nt], false, false);
+          const uint32_t w0 = s0[0] | s0[1], w1 = s1[0] | s1[1];
+          words[nt] = hh ? w1 : w0;
+        }
+        if (my_row < rows) {
+          uint32_t *dst = save_gate2 + r0 * 8;  // uniform base, 32-bit lane offset
+          *reinterpret_cast<u32x4 *>(dst + (unsigned)(my_row * 8 + 4 * wc)) = words;
         }
       }
-      if (mt == 1) RL8_SPLIT_STAMP_E(trace_it, wave, 1);
-      // head: eight rows at a time -- all partial products, then the five reduction
-      // levels each over the whole batch, then the LDS writes
+    }
+    // The two column halves of the workgroup meet in LDS: the upper half (wc = 1)
+    // parks its totals, the lower half adds its own and stores the outputs.
+    if (wc == 1) {
 #pragma unroll
-      for (int rb = 0; rb < 16; rb += 8) {
-        float part[8][kOut];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int q = 0; q < kOut; ++q) {
-            float p = acc[mt][0][rb + u] * w3r[0][q];
-#pragma unroll
-            for (int nt = 1; nt < 4; ++nt) p = __builtin_fmaf(acc[mt][nt][rb + u], w3r[nt][q], p);
-            part[u][q] = p;
-          }
-#define RL8_HEAD_LEVEL(L)                                                  \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u)                            \
-      _Pragma("unroll") for (int q = 0; q < kOut; ++q)                     \
-          if (q < n_out) part[u][q] = half_wave_sum_level<L>(part[u][q]);
-        RL8_HEAD_LEVEL(0) RL8_HEAD_LEVEL(1) RL8_HEAD_LEVEL(2) RL8_HEAD_LEVEL(3) RL8_HEAD_LEVEL(4)
-#undef RL8_HEAD_LEVEL
-        if (l32 == 31) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int r = rb + u;
-            const int row = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-#pragma unroll
-            for (int q = 0; q < kOut; ++q)
-              if (q < n_out) lds_write_b32(outp + ((wc * kSplitRows + row) * kOut + q) * 4, part[u][q]);
-          }
-        }
-      }
+      for (int q = 0; q < kOut; ++q)
+        if (q < n_out) lds_write_b32(outp + (my_row * kOut + q) * 4, total[q]);
     }
     RL8_SPLIT_STAMP_E(trace_it, wave, 2);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     RL8_SPLIT_STAMP_E(trace_it, wave, 3);
-    for (int idx = 64 * wave + lane_id(); idx < kSplitRows * n_out; idx += kBlock) {
-      const int row = idx / n_out, q = idx - row * n_out;
-      const float v = lds_read_b32(outp + (row * kOut + q) * 4) + lds_read_b32(outp + ((kSplitRows + row) * kOut + q) * 4);
-      if (row < rows) (out + r0 * n_out)[(unsigned)idx] = v + b3[q];
+    if (wc == 0 && my_row < rows) {
+#pragma unroll
+      for (int q = 0; q < kOut; ++q)
+        if (q < n_out)
+          (out + r0 * n_out)[(unsigned)(my_row * n_out + q)] = total[q] + lds_read_b32(outp + (my_row * kOut + q) * 4) + b3[q];
     }
-    // (the next tile's first head partials are written a full tile later, behind
-    // sixteen barriers: no extra barrier needed here)
+    // (the next tile's head partials are parked a full tile later, behind sixteen
+    // barriers: no extra barrier needed here)
   }
 }
 

@@ -97,10 +97,18 @@ def run_trace(golden, name, env_cls, *, discrete, step_rel, **config):
         compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5, abs_tol=1e-5)
         assert algo.state.reward_scale == pytest.approx(float(g[f"it{it}_reward_scale"]), rel=1e-5)
         step_stats = algo.step()
-        # it >= 1: weights have drifted (see compare_collect); the policy loss is a
-        # mean of O(1) terms that nearly cancel, so it also gets an absolute band.
+        # The 1e-5 bar against the reference's own numbers is held where weights are
+        # still bit-identical: tests/test_first_update_gpu.py (first StatTracker update
+        # and first gradient of all six traced variants). These averages are taken over
+        # 4-32 Adam steps; Adam's first steps move every weight by ~lr * sign(g), so
+        # rounding-level differences in near-zero gradient entries become 1e-3 weight
+        # differences. it >= 1 adds a second rollout on drifted weights; the policy loss
+        # is a mean of O(1) terms that nearly cancel, so it also gets an absolute band.
+        # (The reference alone, re-run with 1/2/4/8 MKL threads, moves its own
+        # iteration-1 KL by 7e-4 relative on the minibatched config:
+        # profiles/r02_reference_drift.json.)
         compare_stats(step_stats, g["step_stat_keys"], g[f"it{it}_step_stats"], step_rel * (1 if it == 0 else 10),
-                      1e-7 if it == 0 else 1e-4)
+                      1e-7 if it == 0 else 2e-4)
         final_obs = algo.buffer[DataKeys.OBS][:, -1].cpu().numpy()
         np.testing.assert_allclose(final_obs, g[f"it{it}_final_obs"], rtol=1e-5, atol=1e-4)
         # the rest of the buffer was zeroed (reference re-allocates it, :603-609)
