@@ -31,6 +31,7 @@ from ..data import (
     RecurrentAlgorithmHparams,
     RecurrentAlgorithmState,
 )
+from ..distributions import Categorical
 from ..env import EnvFactory
 from ..models_recurrent import RecurrentModel, RecurrentModelFactory
 from ..nn.functional import fused_ppo_loss, has_fused_loss
@@ -44,6 +45,105 @@ from ._feedforward import Algorithm, AlgorithmConfig, _collect_stats_from_raw
 #: larger minibatches accumulate over several passes. 2^21 rows of the default
 #: 256-wide LSTM keep the pass's activations around 20 GB.
 RECURRENT_MAX_ROWS_PER_PASS = 1 << 21
+
+
+class _LeanRollout:
+    """The per-timestep launches of ``collect()`` for the default discrete recurrent
+    model on a dummy env, issued straight through the C ABI with addresses computed
+    once: LSTM step (new states written into the buffer's next column -- no copies),
+    the logits head, the value head, and the fused sampler + ``env.step`` +
+    bookkeeping kernel. Same kernels, same arguments, same order as
+    ``policy.sample()`` + ``_fused_step`` (tests/test_algorithm_gpu.py:
+    ``test_recurrent_lean_and_plumbed_rollouts_agree``); what goes is ~150 us of
+    tensordict / autograd-function / ``torch.cat`` host work per timestep, which at
+    8192 environments per GPU (BASELINE configs[4]) was twice the kernels' time."""
+
+    TIMER_EVERY = 16  # with hip.timer enabled, only every 16th timestep is bracketed by events
+
+    def __init__(self, algo: "RecurrentAlgorithm", deterministic: bool) -> None:
+        from ..nn import fused_lstm
+
+        self.lib = hip.load()
+        model = algo.policy.model
+        tm, stm = algo._tm, algo._tm_states
+        self.n = n = algo.local_num_envs
+        self.d_in = int(tm[DataKeys.OBS].shape[-1])
+        self.k = int(model.feature_head.out_features)
+        dev = tm[DataKeys.OBS].device
+        self.packed = fused_lstm._packs(model.lstm, False)
+        # parameters are leaf tensors: .detach() shares storage (kept alive on self)
+        self.params = [p.detach().contiguous() for p in (model.feature_head.weight, model.feature_head.bias,
+                                                         model.vf_head.weight, model.vf_head.bias)]
+        cache = algo.__dict__.setdefault("_lean_scratch", {})
+        key = (n, self.k, str(dev))
+        if cache.get("key") != key:
+            cache.update(key=key, hs=torch.empty(n, hip.LSTM_HIDDEN, device=dev),
+                         logits=torch.empty(n, self.k, device=dev), value=torch.empty(n, 1, device=dev))
+        self.hs, self.logits, self.value = cache["hs"], cache["logits"], cache["value"]
+        rdr = tm.get(DataKeys.REVERSED_DISCOUNTED_RETURNS)
+
+        def column(t: torch.Tensor) -> tuple[int, int]:
+            return t.data_ptr(), t.stride(0) * t.element_size()
+
+        self.obs, self.act, self.logp = column(tm[DataKeys.OBS]), column(tm[DataKeys.ACTIONS]), column(tm[DataKeys.LOGP])
+        self.val, self.rew = column(tm[DataKeys.VALUES]), column(tm[DataKeys.REWARDS])
+        self.rdr = column(rdr) if rdr is not None else None
+        self.h, self.c = column(stm[DataKeys.HIDDEN_STATES]), column(stm[DataKeys.CELL_STATES])
+        self.state_ptr = algo.env.state.data_ptr()
+        self.gamma = float(torch.tensor(algo.hparams.gamma, dtype=torch.float32))
+        self.seed, self.env_offset = algo.noise.seed, algo.env.env_offset
+        self.deterministic = int(deterministic)
+        self.ptrs = [t.data_ptr() for t in (self.packed, self.hs, self.logits, self.value, *self.params)]
+
+    @staticmethod
+    def available(algo: "RecurrentAlgorithm") -> bool:
+        from ..env import DummyEnv
+        from ..models_recurrent import DefaultDiscreteRecurrentModel
+        from ..nn import fused_lstm
+
+        model = algo.policy.model
+        if type(model) is not DefaultDiscreteRecurrentModel or not isinstance(algo.env, DummyEnv):
+            return False
+        if algo.policy.distribution_cls is not Categorical or model.action_spec.shape[0] != 1:
+            return False
+        lstm = model.lstm
+        obs = algo._tm[DataKeys.OBS]
+        return (fused_lstm.ENABLED and lstm.num_layers == 1 and lstm.hidden_size == hip.LSTM_HIDDEN and lstm.bias
+                and lstm.proj_size == 0 and not lstm.bidirectional and hip.lstm_supports(lstm.input_size)
+                and obs.dtype == torch.float32 and model.vf_head.bias is not None
+                and all(p.dtype == torch.float32 for p in model.parameters()))
+
+    def step(self, t: int, noise: None | torch.Tensor, step_id: int) -> None:
+        lib, n, stream = self.lib, self.n, hip._stream()
+        packed, hs, logits, value, w_pol, b_pol, w_vf, b_vf = self.ptrs
+        at = lambda col, i: col[0] + i * col[1]  # noqa: E731
+        timed = hip.timer.enabled and t % self.TIMER_EVERY == 0
+        with hip._timed("lstm_forward", n) if timed else _NO_TIMER:
+            hip._check(lib.rl8_lstm_forward_f32(at(self.obs, t), n, 1, self.d_in, at(self.h, t), at(self.c, t), packed, hs,
+                                                at(self.h, t + 1), at(self.c, t + 1), None, None, stream),
+                       "rl8_lstm_forward_f32")
+        with hip._timed("linear_heads_forward", n) if timed else _NO_TIMER:
+            hip._check(lib.rl8_linear_heads_forward_f32(hs, n, w_pol, b_pol, self.k, logits, stream),
+                       "rl8_linear_heads_forward_f32")
+            hip._check(lib.rl8_linear_heads_forward_f32(hs, n, w_vf, b_vf, 1, value, stream),
+                       "rl8_linear_heads_forward_f32")
+        with hip._timed("rollout_step_dummy", n) if timed else _NO_TIMER:
+            hip._check(lib.rl8_rollout_step_dummy_f32(
+                1, 0, logits, None, value, noise.data_ptr() if noise is not None else None, self.state_ptr,
+                at(self.act, t), at(self.logp, t), at(self.val, t), at(self.rew, t), at(self.obs, t + 1),
+                at(self.rdr, t) if self.rdr else None, at(self.rdr, t + 1) if self.rdr else None, self.gamma, n,
+                self.seed, step_id, self.env_offset, self.deterministic, stream), "rl8_rollout_step_dummy_f32")
+
+
+class _NoTimer:
+    def __enter__(self) -> None:
+        return None
+
+    def __exit__(self, *exc: Any) -> None:
+        return None
+
+
+_NO_TIMER = _NoTimer()
 
 
 @dataclass
@@ -72,6 +172,9 @@ class RecurrentAlgorithm(Algorithm):
     hparams: RecurrentAlgorithmHparams
     policy: RecurrentPolicy  # type: ignore[assignment]
     state: RecurrentAlgorithmState  # type: ignore[assignment]
+    #: Issue the rollout's per-timestep launches through :class:`_LeanRollout` when the
+    #: model / env pair allows it (False: always through ``policy.sample()``).
+    lean_rollout: bool = True
 
     def __init__(self, env_cls: EnvFactory, /, config: None | RecurrentAlgorithmConfig = None) -> None:
         config = config or RecurrentAlgorithmConfig()
@@ -149,6 +252,9 @@ class RecurrentAlgorithm(Algorithm):
                 v[0].copy_(v[H])
 
             fused = self._fusable()
+            lean = None
+            if fused and self.lean_rollout and _LeanRollout.available(self):
+                lean = _LeanRollout(self, deterministic)
             gamma = float(torch.tensor(hp.gamma, dtype=torch.float32))
             for t in range(H):
                 if self.state.seqs and hp.seqs_per_state_reset < 0:
@@ -159,6 +265,11 @@ class RecurrentAlgorithm(Algorithm):
                         v[t].copy_(init[k])
                 noise_t = self.injected_noise[t] if self.injected_noise is not None else None
                 step_id = self.noise.next_step()
+                if lean is not None:
+                    lean.step(t, noise_t.contiguous() if noise_t is not None else None, step_id)
+                    if not ((t + 1) % hp.seq_len):
+                        self.state.seqs += 1
+                    continue
                 in_batch = TensorDict({DataKeys.OBS: tm[DataKeys.OBS][t].unsqueeze(1)}, batch_size=[N, 1])
                 if fused:
                     sample, new_states = self.policy.sample(

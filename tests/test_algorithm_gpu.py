@@ -423,6 +423,42 @@ def test_recurrent_fused_and_generic_rollouts_agree():
         RecurrentAlgorithmConfig(horizon=30, num_envs=8, seq_len=4).build(DiscreteDummyEnv)
 
 
+def test_recurrent_lean_and_plumbed_rollouts_agree():
+    """The lean per-timestep launch path of RecurrentAlgorithm.collect() (straight C-ABI
+    calls, states written into the next buffer column) against the same rollout through
+    policy.sample() + tensordicts: identical buffers, states and statistics, and the
+    update that follows lands on identical losses."""
+    from rl8_amd import RecurrentAlgorithmConfig
+    from rl8_amd.algorithms._recurrent import _LeanRollout
+
+    def run(lean):
+        torch.manual_seed(9)
+        algo = RecurrentAlgorithmConfig(horizon=32, num_envs=300, seq_len=4, seqs_per_state_reset=4,
+                                        horizons_per_env_reset=2).build(DiscreteDummyEnv)
+        assert _LeanRollout.available(algo)
+        algo.lean_rollout = lean
+        out = []
+        for _ in range(2):
+            stats = algo.collect()
+            buf = {k: v.clone() for k, v in algo.buffer.items() if torch.is_tensor(v)}
+            states = {k: v.clone() for k, v in algo.buffer[DataKeys.STATES].items()}
+            out.append((stats, buf, states, algo.step()))
+        return out, algo.state.seqs
+
+    (a, seqs_a), (b, seqs_b) = run(True), run(False)
+    assert seqs_a == seqs_b
+    for (s0, b0, st0, u0), (s1, b1, st1, u1) in zip(a, b):
+        for k in b0:
+            assert torch.equal(b0[k], b1[k]), k
+        for k in st0:
+            assert torch.equal(st0[k], st1[k]), k
+        for k in s0:
+            if not k.startswith("profiling"):
+                assert s0[k] == s1[k], k
+        for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+            assert u0[k] == u1[k], k
+
+
 # --- fused MLP towers (N1) -------------------------------------------------------
 @pytest.mark.parametrize("env_cls", [ContinuousDummyEnv, DiscreteDummyEnv])
 def test_fused_towers_match_eager_towers(env_cls):
