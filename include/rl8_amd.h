@@ -408,6 +408,36 @@ int rl8_mlp_wgrad_strided_f32(const float *dz2, int64_t dz2_pitch, const float *
                               void *stream);
 
 /* ---------------------------------------------------------------------- *
+ * a-9, second generation: ONE LSTM timestep with the recurrent product as an
+ *      fp32-accurate product on the bf16 matrix pipe (the towers' bf16-plane scheme)
+ *      src/rl8/models/_recurrent.py:312-333 (the nn.LSTM call of the default recurrent
+ *      models), algorithms/_recurrent.py:385-431 (its per-timestep use in collect())
+ * The time loop is the caller's: one launch per timestep, states exchanged through HBM.
+ *
+ * rl8_lstm_pack_split: torch-layout parameters -> `packed` (rl8_lstm_split_packed_bytes()
+ *   bytes: W_hh as three bf16 planes in the kernel's fragment order) and `wb`
+ *   (rl8_lstm_split_wb_floats() floats: [1024][8] = [w_ih row | 0.. | b_ih + b_hh]).
+ * rl8_lstm_split_state: h [B][pitch] fp32 -> `planes` (rl8_lstm_split_state_bytes(B) bytes),
+ *   the step kernel's A operand.
+ * rl8_lstm_step_split_f32: x row r at x + r * x_pitch (d_in floats); h_planes of h_{t-1};
+ *   c_prev row r at c_prev + r * c_prev_pitch; writes h_t, c_t rows at the given pitches
+ *   (floats) and, when `gates` is not NULL, the post-activation gates i, f, g, o as
+ *   [4][256] per row at gates + r * gates_pitch (what rl8_lstm_backward_f32 reads).
+ *   d_in in {1, 2, 3, 5} (rl8_lstm_split_supports); other widths keep rl8_lstm_forward_f32.
+ * ---------------------------------------------------------------------- */
+int rl8_lstm_split_supports(int d_in);
+int64_t rl8_lstm_split_packed_bytes(void);
+int64_t rl8_lstm_split_wb_floats(void);
+int64_t rl8_lstm_split_state_bytes(int64_t b);
+int rl8_lstm_pack_split(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                        int d_in, void *packed, float *wb, void *stream);
+int rl8_lstm_split_state(const float *h, int64_t pitch, int64_t b, void *planes, void *stream);
+int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, const void *h_planes,
+                            const float *c_prev, int64_t c_prev_pitch, const void *w_planes,
+                            const float *wb, int64_t b, float *h_out, int64_t h_out_pitch, float *c_out,
+                            int64_t c_out_pitch, float *gates, int64_t gates_pitch, void *stream);
+
+/* ---------------------------------------------------------------------- *
  * a-9  Default recurrent models' LSTM, fused
  *      src/rl8/models/_recurrent.py:201-321 (torch.nn.LSTM(d_in, 256, num_layers=1,
  *      batch_first=True) inside DefaultContinuous/DiscreteRecurrentModel)

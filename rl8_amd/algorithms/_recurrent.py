@@ -70,7 +70,11 @@ class _LeanRollout:
         self.d_in = int(tm[DataKeys.OBS].shape[-1])
         self.k = int(model.feature_head.out_features)
         dev = tm[DataKeys.OBS].device
-        self.packed = fused_lstm._packs(model.lstm, False)
+        self.split = fused_lstm.use_split(model.lstm)
+        if self.split:  # bf16-plane step kernel: W_hh planes, [w_ih | bias] rows, planes of h_{t-1}
+            self.packed, self.wb = fused_lstm._packs(model.lstm, "split")
+        else:
+            self.packed, self.wb = fused_lstm._packs(model.lstm, False), None
         # parameters are leaf tensors: .detach() shares storage (kept alive on self)
         self.params = [p.detach().contiguous() for p in (model.feature_head.weight, model.feature_head.bias,
                                                          model.vf_head.weight, model.vf_head.bias)]
@@ -78,8 +82,9 @@ class _LeanRollout:
         key = (n, self.k, str(dev))
         if cache.get("key") != key:
             cache.update(key=key, hs=torch.empty(n, hip.LSTM_HIDDEN, device=dev),
-                         logits=torch.empty(n, self.k, device=dev), value=torch.empty(n, 1, device=dev))
-        self.hs, self.logits, self.value = cache["hs"], cache["logits"], cache["value"]
+                         logits=torch.empty(n, self.k, device=dev), value=torch.empty(n, 1, device=dev),
+                         planes=hip.lstm_state_planes(n, dev))
+        self.hs, self.logits, self.value, self.planes = cache["hs"], cache["logits"], cache["value"], cache["planes"]
         rdr = tm.get(DataKeys.REVERSED_DISCOUNTED_RETURNS)
 
         def column(t: torch.Tensor) -> tuple[int, int]:
@@ -94,6 +99,7 @@ class _LeanRollout:
         self.seed, self.env_offset = algo.noise.seed, algo.env.env_offset
         self.deterministic = int(deterministic)
         self.ptrs = [t.data_ptr() for t in (self.packed, self.hs, self.logits, self.value, *self.params)]
+        self.split_ptrs = (self.planes.data_ptr(), self.wb.data_ptr() if self.wb is not None else None)
 
     @staticmethod
     def available(algo: "RecurrentAlgorithm") -> bool:
@@ -118,10 +124,20 @@ class _LeanRollout:
         packed, hs, logits, value, w_pol, b_pol, w_vf, b_vf = self.ptrs
         at = lambda col, i: col[0] + i * col[1]  # noqa: E731
         timed = hip.timer.enabled and t % self.TIMER_EVERY == 0
-        with hip._timed("lstm_forward", n) if timed else _NO_TIMER:
-            hip._check(lib.rl8_lstm_forward_f32(at(self.obs, t), n, 1, self.d_in, at(self.h, t), at(self.c, t), packed, hs,
-                                                at(self.h, t + 1), at(self.c, t + 1), None, None, stream),
-                       "rl8_lstm_forward_f32")
+        if self.split:
+            planes, wb = self.split_ptrs
+            H = hip.LSTM_HIDDEN
+            hip._check(lib.rl8_lstm_split_state(at(self.h, t), H, n, planes, stream), "rl8_lstm_split_state")
+            with hip._timed("lstm_step", n) if timed else _NO_TIMER:
+                hip._check(lib.rl8_lstm_step_split_f32(at(self.obs, t), self.d_in, self.d_in, planes, at(self.c, t), H,
+                                                       packed, wb, n, at(self.h, t + 1), H, at(self.c, t + 1), H, None,
+                                                       0, stream), "rl8_lstm_step_split_f32")
+            hs = at(self.h, t + 1)  # the heads read h_t where the buffer keeps it
+        else:
+            with hip._timed("lstm_forward", n) if timed else _NO_TIMER:
+                hip._check(lib.rl8_lstm_forward_f32(at(self.obs, t), n, 1, self.d_in, at(self.h, t), at(self.c, t), packed,
+                                                    hs, at(self.h, t + 1), at(self.c, t + 1), None, None, stream),
+                           "rl8_lstm_forward_f32")
         with hip._timed("linear_heads_forward", n) if timed else _NO_TIMER:
             hip._check(lib.rl8_linear_heads_forward_f32(hs, n, w_pol, b_pol, self.k, logits, stream),
                        "rl8_linear_heads_forward_f32")

@@ -1,0 +1,398 @@
+// a-9 (recurrent PPO), second generation: one LSTM timestep of the default
+// recurrent models (src/rl8/models/_recurrent.py:201-321 -> torch.nn.LSTM(d, 256,
+// batch_first)) with the recurrent product h_{t-1} x W_hh^T as an fp32-ACCURATE product
+// on the bf16 matrix pipe -- the scheme of mlp_split_kernels.hip (an fp32 value is the
+// exact sum of three bf16 planes; six plane products per fp32 product; fp32 accumulate).
+// lstm_kernels.hip runs the same step on fp32 MFMAs (64 cycles per 32x32x2 block; 108-129
+// TFLOP/s); this one runs 2.7x fewer matrix-pipe cycles per product.
+//
+// Shape.  The time loop is OUTSIDE the kernel (one launch per timestep): with both
+// operands as bf16 planes in LDS there is no room to keep a tile's h_t on chip between
+// steps, and a launch over 2^19 sequences is long enough that it does not matter.
+//   rl8_lstm_split_state      h_{t-1} [B][256] fp32 -> three bf16 planes in fragment order
+//                             (1.5 KiB per row; HBM-bound, 2.5 KiB of traffic per row);
+//   rl8_lstm_step_split_f32   per 128-row tile and block of 64 hidden units: gate
+//                             pre-activations = h planes x W_hh planes, BOTH operands
+//                             HBM/L2 -> LDS by direct-to-LDS loads (no registers, no VALU
+//                             in the matrix loop); the input projection (d_in <= 7), the
+//                             biases, the gate non-linearities and the cell update on the
+//                             accumulators.
+// A workgroup's 256 accumulator columns are [i | f | g | o] x 32 units per wave column
+// half, so a lane holds all four gates of its (row, unit) pairs in the same register slot
+// -- the cell update needs no exchange -- and, lane = unit, every h / c / gate store is two
+// full 128-byte row segments.
+#include "split_tile.hip.h"
+
+namespace rl8 {
+
+constexpr int kLsUnits = 64;                      // hidden units per workgroup pass
+constexpr int kLsBlocks = kHidden / kLsUnits;     // unit blocks (grid dimension)
+constexpr int kLsPackedBytes = kLsBlocks * kSplitPackedBytes;  // W_hh planes: 1.5 MiB
+constexpr int kLsAChunkBytes = 12 * 1024;         // one k-step of a 128-row tile: [plane][k-half][row half] x 1 KiB
+constexpr int kLsATileBytes = kSplitSteps * kLsAChunkBytes;
+constexpr int kLsInCols = 8;                      // [w_ih (d_in <= 7) ... | b_ih + b_hh] per gate row
+constexpr int kLsXBytes = 7 * kSplitRows * 4;     // x tile in LDS, [input][row]
+
+// Gate non-linearities as in lstm_kernels.hip (hardware exp2 / rcp).
+__device__ __forceinline__ float ls_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ls_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+
+__device__ __forceinline__ void ls_planes(const float (&v)[8], u32x4 (&planes)[3]) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    uint32_t hi, mid, lo;
+    split_pair(v[e], v[e + 1], hi, mid, lo);
+    planes[0][e >> 1] = hi;
+    planes[1][e >> 1] = mid;
+    planes[2][e >> 1] = lo;
+  }
+}
+
+// W_hh [1024][256] (torch gate order i, f, g, o) -> planes: 16-byte unit
+// ((((ub*16 + s)*8 + ct)*3 + p)*64 + l) holds, for plane p, the eight values
+//   W_hh[256 q + 64 ub + 32 wc + (l & 31)][16 s + 8 (l >> 5) + e],   ct = 4 wc + q,
+// i.e. per unit block and k-step the 24 KiB the step's direct-to-LDS copy fetches, with
+// column tile ct = (wave column half, gate).  wb [1024][8] = [w_ih row | 0.. | b_ih + b_hh].
+__global__ __launch_bounds__(kBlock) void lstm_pack_split_kernel(const float *__restrict__ w_ih,
+                                                                 const float *__restrict__ w_hh,
+                                                                 const float *__restrict__ b_ih,
+                                                                 const float *__restrict__ b_hh, int d_in,
+                                                                 uint32_t *__restrict__ packed,
+                                                                 float *__restrict__ wb) {
+  const int unit = blockIdx.x * kBlock + threadIdx.x;  // (ub, s, ct, l)
+  if (unit < 4 * kHidden * kLsInCols) {
+    const int j = unit / kLsInCols, c = unit - j * kLsInCols;
+    wb[unit] = c < d_in ? w_ih[j * d_in + c] : c == kLsInCols - 1 ? b_ih[j] + b_hh[j] : 0.0f;
+  }
+  if (unit >= kLsBlocks * kSplitSteps * 8 * 64) return;
+  const int l = unit & 63, ct = (unit >> 6) & 7, s = (unit >> 9) & 15, ub = unit >> 13;
+  const int j = kHidden * (ct & 3) + kLsUnits * ub + 32 * (ct >> 2) + (l & 31), k0 = 16 * s + 8 * (l >> 5);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = w_hh[j * kHidden + k0 + e];
+  u32x4 planes[3];
+  ls_planes(v, planes);
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    reinterpret_cast<u32x4 *>(packed)[(((ub * kSplitSteps + s) * 8 + ct) * 3 + p) * 64 + l] = planes[p];
+}
+
+// h [B][pitch] fp32 -> planes [tile][k-step][plane][k-half][row] x 16 B (rows past B are
+// zero): the A operand of rl8_lstm_step_split_f32, one contiguous 12 KiB per tile and
+// k-step.  Thread = (row, k-half); sixteen fragments each.
+__global__ __launch_bounds__(kBlock) void lstm_split_state_kernel(const float *__restrict__ h, int64_t pitch,
+                                                                  int64_t b, uint32_t *__restrict__ planes_out) {
+  const int rr = threadIdx.x & 127, kh = threadIdx.x >> 7;
+  const int64_t tiles = (b + kSplitRows - 1) / kSplitRows;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t row = tile * kSplitRows + rr;
+    const float *src = h + row * pitch + 8 * kh;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(planes_out) + tile * (kLsATileBytes / 16) + kh * 128 + rr;
+#pragma unroll 4
+    for (int s = 0; s < kSplitSteps; ++s) {
+      float v[8];
+      if (row < b) {
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(src + 16 * s), hi = *reinterpret_cast<const f32x4 *>(src + 16 * s + 4);
+        v[0] = lo[0], v[1] = lo[1], v[2] = lo[2], v[3] = lo[3], v[4] = hi[0], v[5] = hi[1], v[6] = hi[2], v[7] = hi[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+      }
+      u32x4 planes[3];
+      ls_planes(v, planes);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[s * (kLsAChunkBytes / 16) + p * 256] = planes[p];
+    }
+  }
+}
+
+struct LstmStepArgs {
+  const float *x;       // [B][x_pitch]: this step's observations
+  const float *c_prev;  // [B][c_prev_pitch]
+  float *h_out, *c_out; // [B][*_pitch]
+  float *gates;         // [B][gates_pitch] -> [4][256] post-activation i, f, g, o; or null
+  int64_t x_pitch, c_prev_pitch, h_out_pitch, c_out_pitch, gates_pitch;
+};
+
+constexpr int lstm_step_lds_bytes() { return 2 * kSplitStageBytes + kLsXBytes; }
+static_assert(lstm_step_lds_bytes() <= 80 * 1024, "two workgroups per CU");
+
+// One timestep for rows [0, b): work item = (128-row tile, unit block ub); a workgroup
+// keeps its unit block (gridDim.x is a multiple of 4), so W_hh's planes for it stay in L2
+// and its gate rows of [w_ih | bias] are loaded once.
+template <int DIN, bool SAVE>
+__global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
+    const void *__restrict__ a_planes, const void *__restrict__ w_planes, const float *__restrict__ wb, int64_t b,
+    LstmStepArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = lds_offset(smem);
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ub = blockIdx.x & (kLsBlocks - 1);
+  const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
+  const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      buffer_rsrc(static_cast<const unsigned char *>(w_planes) + ub * kSplitPackedBytes, kSplitPackedBytes);
+  const int64_t tiles = (b + kSplitRows - 1) / kSplitRows;
+  const int64_t tile_stride = gridDim.x / kLsBlocks;
+
+  // this lane's unit: gate rows of [w_ih | bias]
+  const int unit = kLsUnits * ub + 32 * wc + l32;
+  float w_in[4][DIN], bias[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float *row = wb + (kHidden * q + unit) * kLsInCols;
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) w_in[q][i] = row[i];
+    bias[q] = row[kLsInCols - 1];
+  }
+
+  auto a_rsrc = [&](int64_t tile) {
+    return buffer_rsrc(static_cast<const unsigned char *>(a_planes) + tile * kLsATileBytes, kLsATileBytes);
+  };
+  // chunk ks of `tile` -> stage: 24 one-KiB blocks of W planes, 12 of h planes
+  auto request = [&](const __amdgpu_buffer_rsrc_t &arsrc, int ks, int stage) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int block = wave * 6 + u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, smem + stage * kSplitStageBytes + kSplitABytes + block * 1024, 16,
+                                               lane * 16, (ks * 24 + block) * 1024, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int c = wave * 3 + u;  // ((plane*2 + kh)*2 + half)
+      const int lds_at = (c >> 2) * kSplitPlaneStride + ((c >> 1) & 1) * kSplitKhStride + (c & 1) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, smem + stage * kSplitStageBytes + lds_at, 16, lane * 16,
+                                               (ks * 12 + c) * 1024, 0, 0);
+    }
+  };
+  auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  f32x16 acc[2][4];
+  auto do_step = [&](auto first_tag, auto parity_tag, const __amdgpu_buffer_rsrc_t &next_rsrc, int next_ks) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int P = decltype(parity_tag)::value;
+    request(next_rsrc, next_ks, P ^ 1);
+    const unsigned ar = a_read + P * kSplitStageBytes, br = b_read + P * kSplitStageBytes;
+    SplitFrags f;
+    f.ah[0] = lds_read_b128<0>(ar);
+    f.ah[1] = lds_read_b128<512>(ar);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) f.bh[nt] = nt == 0   ? lds_read_b128<0>(br)
+                                              : nt == 1 ? lds_read_b128<3 * 1024>(br)
+                                              : nt == 2 ? lds_read_b128<6 * 1024>(br)
+                                                        : lds_read_b128<9 * 1024>(br);
+    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
+    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<1024>(br)
+                                              : nt == 1 ? lds_read_b128<4 * 1024>(br)
+                                              : nt == 2 ? lds_read_b128<7 * 1024>(br)
+                                                        : lds_read_b128<10 * 1024>(br);
+    wait_lds_all(f);
+    split_mma<FIRST>(f.am, f.bm, acc);
+    split_mma<false>(f.ah, f.bm, acc);
+    split_mma<false>(f.am, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    f.am[0] = lds_read_b128<2 * kSplitPlaneStride>(ar);
+    f.am[1] = lds_read_b128<2 * kSplitPlaneStride + 512>(ar);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<2 * 1024>(br)
+                                              : nt == 1 ? lds_read_b128<5 * 1024>(br)
+                                              : nt == 2 ? lds_read_b128<8 * 1024>(br)
+                                                        : lds_read_b128<11 * 1024>(br);
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma<false>(f.ah, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lds_all(f);
+    split_mma<false>(f.ah, f.bm, acc);
+    split_mma<false>(f.am, f.bh, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    step_barrier();
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  int64_t tile = blockIdx.x / kLsBlocks;
+  if (tile < tiles) {
+    request(a_rsrc(tile), 0, 0);
+    step_barrier();
+  }
+  for (; tile < tiles; tile += tile_stride) {
+    const int64_t r0 = tile * kSplitRows;
+    const int rows = (int)((b - r0) < kSplitRows ? (b - r0) : kSplitRows);
+    // this row's observation (threads 0..127), parked in LDS behind the matrix loop
+    float xr[DIN];
+    {
+      const int row = tid & 127;
+      const float *xp = args.x + (r0 + row) * args.x_pitch;
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) xr[i] = (tid < kSplitRows && row < rows) ? xp[i] : 0.0f;
+    }
+    const __amdgpu_buffer_rsrc_t arsrc = a_rsrc(tile);
+    const int64_t next = tile + tile_stride < tiles ? tile + tile_stride : tile;  // (last item: a harmless re-fetch)
+    const __amdgpu_buffer_rsrc_t nrsrc = a_rsrc(next);
+    do_step(T{}, P0{}, arsrc, 1);
+    do_step(F{}, P1{}, arsrc, 2);
+#pragma unroll 1
+    for (int s = 2; s < kSplitSteps - 2; s += 2) {
+      do_step(F{}, P0{}, arsrc, s + 1);
+      do_step(F{}, P1{}, arsrc, s + 2);
+    }
+    do_step(F{}, P0{}, arsrc, kSplitSteps - 1);
+    do_step(F{}, P1{}, nrsrc, 0);  // the next item's chunk 0 lands during the epilogue
+
+    // ---- epilogue: pre-activations -> gates -> cell update ------------------------
+    const unsigned xs = lds0 + 2 * kSplitStageBytes;
+    if (tid < kSplitRows) {
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) lds_write_b32(xs + (i * kSplitRows + tid) * 4, xr[i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int lane_now = lane_id();
+    const int l32e = lane_now & 31, hhe = lane_now >> 5;
+    const int col4 = (kLsUnits * ub + 32 * wc + l32e) * 4;  // byte offset of this lane's unit in a [..][256] row
+    const __amdgpu_buffer_rsrc_t crsrc =
+        buffer_rsrc(args.c_prev + r0 * args.c_prev_pitch, (uint32_t)(((rows - 1) * args.c_prev_pitch + kHidden) * 4));
+    const __amdgpu_buffer_rsrc_t hrsrc =
+        buffer_rsrc(args.h_out + r0 * args.h_out_pitch, (uint32_t)(((rows - 1) * args.h_out_pitch + kHidden) * 4));
+    const __amdgpu_buffer_rsrc_t cors =
+        buffer_rsrc(args.c_out + r0 * args.c_out_pitch, (uint32_t)(((rows - 1) * args.c_out_pitch + kHidden) * 4));
+    const __amdgpu_buffer_rsrc_t grsrc = buffer_rsrc(
+        SAVE ? args.gates + r0 * args.gates_pitch : nullptr, (uint32_t)(((rows - 1) * args.gates_pitch + 4 * kHidden) * 4));
+    // row pitches in bytes (scalar); per array the lane part (unit column + this lane's
+    // 64 wr + 4 hh rows) is ONE vector offset, the rest of the row index is scalar
+    const int cp4 = (int)args.c_prev_pitch * 4, hp4 = (int)args.h_out_pitch * 4, co4 = (int)args.c_out_pitch * 4,
+              gp4 = (int)args.gates_pitch * 4;
+    const int lane_rows = 64 * wr + 4 * hhe;
+    const int v_cp = col4 + lane_rows * cp4, v_h = col4 + lane_rows * hp4, v_co = col4 + lane_rows * co4,
+              v_g = col4 + lane_rows * gp4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {  // four rows at a time: r = 4 rg + e, row = 8 rg + e + 4 hh
+        const int row0 = 64 * wr + 32 * mt + 8 * rg + 4 * hhe;
+        // the rows' observations: one 16-byte read per input
+        u32x4 xq[DIN];
+#pragma unroll
+        for (int i = 0; i < DIN; ++i)
+          xq[i] = i == 0   ? lds_read_b128<0 * kSplitRows * 4>(xs + row0 * 4)
+                  : i == 1 ? lds_read_b128<1 * kSplitRows * 4>(xs + row0 * 4)
+                  : i == 2 ? lds_read_b128<2 * kSplitRows * 4>(xs + row0 * 4)
+                  : i == 3 ? lds_read_b128<3 * kSplitRows * 4>(xs + row0 * 4)
+                  : i == 4 ? lds_read_b128<4 * kSplitRows * 4>(xs + row0 * 4)
+                  : i == 5 ? lds_read_b128<5 * kSplitRows * 4>(xs + row0 * 4)
+                           : lds_read_b128<6 * kSplitRows * 4>(xs + row0 * 4);
+        float cp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cp[e] = buffer_load_f32(crsrc, v_cp, (32 * mt + 8 * rg + e) * cp4);
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) wait_lds<0>(xq[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rg + e;
+          float pre[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = acc[mt][q][r] + bias[q];
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) v = __builtin_fmaf(__uint_as_float(xq[i][e]), w_in[q][i], v);
+            pre[q] = v;
+          }
+          const float gi = ls_sigmoid(pre[0]), gf = ls_sigmoid(pre[1]), gg = ls_tanh(pre[2]), go = ls_sigmoid(pre[3]);
+          const float c = __builtin_fmaf(gf, cp[e], gi * gg);
+          const float h = go * ls_tanh(c);
+          const int srow = 32 * mt + 8 * rg + e;  // scalar part of the row index
+          buffer_store_f32(h, hrsrc, v_h, srow * hp4);
+          buffer_store_f32(c, cors, v_co, srow * co4);
+          if constexpr (SAVE) {
+            buffer_store_f32(gi, grsrc, v_g, srow * gp4);
+            buffer_store_f32(gf, grsrc, v_g + kHidden * 4, srow * gp4);
+            buffer_store_f32(gg, grsrc, v_g + 2 * kHidden * 4, srow * gp4);
+            buffer_store_f32(go, grsrc, v_g + 3 * kHidden * 4, srow * gp4);
+          }
+        }
+      }
+    }
+    // (the next item's x is parked behind its own sixteen step barriers: no barrier here)
+  }
+}
+
+}  // namespace rl8
+
+using namespace rl8;
+
+RL8_API int rl8_lstm_split_supports(int d_in) { return d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5; }
+RL8_API int64_t rl8_lstm_split_packed_bytes(void) { return kLsPackedBytes; }
+RL8_API int64_t rl8_lstm_split_wb_floats(void) { return 4 * kHidden * kLsInCols; }
+// bytes of the state planes for b rows (whole 128-row tiles)
+RL8_API int64_t rl8_lstm_split_state_bytes(int64_t b) { return ((b + kSplitRows - 1) / kSplitRows) * (int64_t)kLsATileBytes; }
+
+RL8_API int rl8_lstm_pack_split(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int d_in,
+                                void *packed, float *wb, void *stream) {
+  if (!w_ih || !w_hh || !b_ih || !b_hh || !packed || !wb) return RL8_ENULL;
+  if (d_in < 1 || d_in > kLsInCols - 1) return RL8_ESIZE;
+  if (!aligned16(packed)) return RL8_EALIGN;
+  const int units = kLsBlocks * kSplitSteps * 8 * 64;  // 32 768 >= 1024 * 8
+  lstm_pack_split_kernel<<<(units + kBlock - 1) / kBlock, kBlock, 0, (hipStream_t)stream>>>(
+      w_ih, w_hh, b_ih, b_hh, d_in, static_cast<uint32_t *>(packed), wb);
+  return launch_status();
+}
+
+RL8_API int rl8_lstm_split_state(const float *h, int64_t pitch, int64_t b, void *planes, void *stream) {
+  if (!h || !planes) return RL8_ENULL;
+  if (b <= 0 || pitch < kHidden) return RL8_ESIZE;
+  if (!aligned16(h) || !aligned16(planes) || (pitch & 3)) return RL8_EALIGN;
+  const int64_t tiles = (b + kSplitRows - 1) / kSplitRows;
+  const int grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+  lstm_split_state_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(h, pitch, b, static_cast<uint32_t *>(planes));
+  return launch_status();
+}
+
+template <int DIN>
+static int launch_lstm_step(int grid, hipStream_t s, const void *a_planes, const void *w_planes, const float *wb, int64_t b,
+                            const LstmStepArgs &args) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_step_split_kernel<DIN, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_step_split_kernel<DIN, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  if (args.gates)
+    lstm_step_split_kernel<DIN, true><<<grid, kBlock, lstm_step_lds_bytes(), s>>>(a_planes, w_planes, wb, b, args);
+  else
+    lstm_step_split_kernel<DIN, false><<<grid, kBlock, lstm_step_lds_bytes(), s>>>(a_planes, w_planes, wb, b, args);
+  return launch_status();
+}
+
+RL8_API int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, const void *h_planes,
+                                    const float *c_prev, int64_t c_prev_pitch, const void *w_planes,
+                                    const float *wb, int64_t b, float *h_out, int64_t h_out_pitch, float *c_out,
+                                    int64_t c_out_pitch, float *gates, int64_t gates_pitch, void *stream) {
+  if (!x || !h_planes || !c_prev || !w_planes || !wb || !h_out || !c_out) return RL8_ENULL;
+  if (b <= 0 || !rl8_lstm_split_supports(d_in)) return RL8_ESIZE;
+  if (x_pitch < d_in || c_prev_pitch < kHidden || h_out_pitch < kHidden || c_out_pitch < kHidden ||
+      (gates && gates_pitch < 4 * kHidden))
+    return RL8_ESIZE;
+  // a tile's rows are addressed with 32-bit byte offsets
+  const int64_t widest = gates ? gates_pitch : (h_out_pitch > c_prev_pitch ? h_out_pitch : c_prev_pitch);
+  if ((int64_t)kSplitRows * widest * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
+  if (!aligned16(h_planes) || !aligned16(w_planes)) return RL8_EALIGN;
+  const int64_t tiles = (b + kSplitRows - 1) / kSplitRows;
+  const int64_t items = tiles * kLsBlocks;
+  const int grid = (int)(items < 2 * kCUs ? items : 2 * kCUs);  // both multiples of 4
+  const LstmStepArgs args = {x, c_prev, h_out, c_out, gates, x_pitch, c_prev_pitch, h_out_pitch, c_out_pitch, gates_pitch};
+  hipStream_t s = (hipStream_t)stream;
+  switch (d_in) {
+    case 1: return launch_lstm_step<1>(grid, s, h_planes, w_planes, wb, b, args);
+    case 2: return launch_lstm_step<2>(grid, s, h_planes, w_planes, wb, b, args);
+    case 3: return launch_lstm_step<3>(grid, s, h_planes, w_planes, wb, b, args);
+    default: return launch_lstm_step<5>(grid, s, h_planes, w_planes, wb, b, args);
+  }
+}

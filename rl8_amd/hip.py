@@ -124,6 +124,13 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_pack_floats": [],
     "rl8_lstm_pack_f32": [_vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "rl8_lstm_forward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rl8_lstm_split_supports": [_i32],
+    "rl8_lstm_split_packed_bytes": [],
+    "rl8_lstm_split_wb_floats": [],
+    "rl8_lstm_split_state_bytes": [_i64],
+    "rl8_lstm_pack_split": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "rl8_lstm_split_state": [_vp, _i64, _i64, _vp, _vp],
+    "rl8_lstm_step_split_f32": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
     "rl8_lstm_backward_partial_floats": [_i32],
     "rl8_lstm_backward_max_rows": [],
     "rl8_lstm_backward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp],
@@ -171,7 +178,8 @@ def load() -> C.CDLL:
             fn.restype = (
                 C.c_int64
                 if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes",
-                            "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats", "rl8_mlp_split_packed_bytes")
+                            "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats", "rl8_mlp_split_packed_bytes",
+                            "rl8_lstm_split_packed_bytes", "rl8_lstm_split_wb_floats", "rl8_lstm_split_state_bytes")
                 else C.c_int
             )
         _lib = lib
@@ -1073,6 +1081,64 @@ def lstm_forward(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, w_packed: 
         _check(load().rl8_lstm_forward_f32(_ptr(x), b, l, d_in, _ptr(h0), _ptr(c0), _ptr(w_packed), _ptr(hs), _ptr(hn),
                                            _ptr(cn), _ptr(gates), _ptr(cs), _stream()), "rl8_lstm_forward_f32")
     return hs, hn, cn, gates, cs
+
+
+def lstm_split_supports(d_in: int) -> bool:
+    return bool(load().rl8_lstm_split_supports(int(d_in)))
+
+
+def lstm_pack_split(w_ih: torch.Tensor, w_hh: torch.Tensor, b_ih: torch.Tensor, b_hh: torch.Tensor):
+    """torch.nn.LSTM parameters -> (W_hh as bf16 planes in the step kernel's fragment order,
+    ``wb`` [1024, 8] = [w_ih | 0.. | b_ih + b_hh])."""
+    d_in = w_ih.shape[1]
+    for name, t, shape in (("w_ih", w_ih, (4 * LSTM_HIDDEN, d_in)), ("w_hh", w_hh, (4 * LSTM_HIDDEN, LSTM_HIDDEN)),
+                           ("b_ih", b_ih, (4 * LSTM_HIDDEN,)), ("b_hh", b_hh, (4 * LSTM_HIDDEN,))):
+        _dense(t.detach(), torch.float32, name)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+    lib = load()
+    packed = torch.empty(int(lib.rl8_lstm_split_packed_bytes()), dtype=torch.uint8, device=w_hh.device)
+    wb = torch.empty(int(lib.rl8_lstm_split_wb_floats()), dtype=torch.float32, device=w_hh.device)
+    _check(lib.rl8_lstm_pack_split(_ptr(w_ih.detach()), _ptr(w_hh.detach()), _ptr(b_ih.detach()), _ptr(b_hh.detach()),
+                                   d_in, _ptr(packed), _ptr(wb), _stream()), "rl8_lstm_pack_split")
+    return packed, wb
+
+
+def lstm_state_planes(rows: int, device: torch.device | str) -> torch.Tensor:
+    """Buffer for the bf16 planes of ``rows`` rows of hidden state."""
+    return torch.empty(int(load().rl8_lstm_split_state_bytes(int(rows))), dtype=torch.uint8, device=device)
+
+
+def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, packed: torch.Tensor, wb: torch.Tensor,
+                       *, save: bool = False, planes: None | torch.Tensor = None):
+    """As :func:`lstm_forward` on the bf16-plane step kernel: one state split + one step
+    launch per timestep. Same outputs and saved layouts (``gates`` [B, L, 4, 256], ``cs``)."""
+    x = _dense(x.detach(), torch.float32, "x")
+    b, l, d_in = x.shape
+    for name, t in (("h0", h0), ("c0", c0)):
+        _dense(t, torch.float32, name)
+        if tuple(t.shape) != (b, LSTM_HIDDEN):
+            raise ValueError(f"{name} must be [{b}, {LSTM_HIDDEN}], got {tuple(t.shape)}")
+    dev = x.device
+    lib = load()
+    hs = torch.empty(b, l, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    cs = torch.empty(b, l, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    gates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev) if save else None
+    if planes is None:
+        planes = lstm_state_planes(b, dev)
+    H, stream = LSTM_HIDDEN, _stream()
+    xp, hsp, csp, gp = _ptr(x), _ptr(hs), _ptr(cs), _ptr(gates)
+    for t in range(l):
+        h_prev, h_pitch = (_ptr(h0), H) if t == 0 else (hsp + (t - 1) * H * 4, l * H)
+        c_prev, c_pitch = (_ptr(c0), H) if t == 0 else (csp + (t - 1) * H * 4, l * H)
+        _check(lib.rl8_lstm_split_state(h_prev, h_pitch, b, _ptr(planes), stream), "rl8_lstm_split_state")
+        with _timed("lstm_step_save" if save else "lstm_step", b):
+            _check(lib.rl8_lstm_step_split_f32(
+                xp + t * d_in * 4, l * d_in, d_in, _ptr(planes), c_prev, c_pitch, _ptr(packed), _ptr(wb), b,
+                hsp + t * H * 4, l * H, csp + t * H * 4, l * H, (gp + t * 4 * H * 4) if save else None, l * 4 * H,
+                stream), "rl8_lstm_step_split_f32")
+    hn, cn = hs[:, l - 1], cs[:, l - 1]
+    return hs, hn, cn, gates, (cs if save else None)
 
 
 def lstm_pack_transposed(w_hh: torch.Tensor) -> torch.Tensor:

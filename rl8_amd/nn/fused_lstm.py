@@ -14,6 +14,8 @@ module itself.
 
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -21,6 +23,10 @@ from .. import hip
 
 #: Set to False to evaluate LSTMs with PyTorch (A/B comparisons).
 ENABLED = True
+#: "split": the forward step on the bf16 matrix pipe (fp32-accurate bf16-plane products,
+#: lstm_split_kernels.hip) where the input width has a compiled variant; "f32": the
+#: fp32-MFMA kernel with the time loop inside (lstm_kernels.hip).
+FORWARD_GEMM = os.environ.get("RL8_AMD_LSTM_GEMM", "split")
 
 
 def _eligible(lstm: nn.LSTM, x: torch.Tensor) -> bool:
@@ -50,16 +56,28 @@ def _packs(lstm: nn.LSTM, transposed: bool) -> torch.Tensor:
     hit = cache.get(transposed)
     if hit is not None and hit[0] == stamp:
         return hit[1]
-    packed = hip.lstm_pack_transposed(params[1]) if transposed else hip.lstm_pack(*params)
+    if transposed == "split":
+        packed = hip.lstm_pack_split(*params)
+    else:
+        packed = hip.lstm_pack_transposed(params[1]) if transposed else hip.lstm_pack(*params)
     cache[transposed] = (stamp, packed)
     return packed
+
+
+def use_split(lstm: nn.LSTM) -> bool:
+    return FORWARD_GEMM == "split" and hip.lstm_split_supports(lstm.input_size)
 
 
 class _FusedLSTM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, lstm, grad_mode):  # type: ignore[override]
         need_grad = grad_mode and any(ctx.needs_input_grad[3:7])
-        hs, hn, cn, gates, cs = hip.lstm_forward(x, h0, c0, _packs(lstm, False), save=need_grad)
+        if use_split(lstm):
+            packed, wb = _packs(lstm, "split")
+            hs, hn, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=need_grad)
+            hn, cn = hn.contiguous(), cn.contiguous()
+        else:
+            hs, hn, cn, gates, cs = hip.lstm_forward(x, h0, c0, _packs(lstm, False), save=need_grad)
         ctx.set_materialize_grads(False)
         if need_grad:
             ctx.lstm = lstm

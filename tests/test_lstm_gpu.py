@@ -164,3 +164,39 @@ def test_lstm_kernels_repeat_bit_for_bit_under_load():
     for trial in range(30):
         for a, c in zip(first, run()):
             assert torch.equal(a, c), trial
+
+
+@pytest.mark.parametrize("b,l,d", [(1, 1, 1), (127, 4, 1), (129, 3, 2), (1000, 4, 5), (4097, 2, 3), (640, 7, 1)])
+def test_lstm_split_step_matches_the_fp32_kernel_and_fp64(b, l, d):
+    """The bf16-plane step kernel (one launch per timestep, h_{t-1} through bf16 planes)
+    against the fp32-MFMA kernel on the same inputs -- outputs, final states, saved gates
+    and cell states -- and both against an fp64 LSTM: the split kernel must be as close to
+    fp64 as the fp32 kernel is (fp32-accurate products, same gate arithmetic)."""
+    assert hip.lstm_split_supports(d)
+    g = torch.Generator(device=DEV).manual_seed(100 * b + 10 * l + d)
+    lstm = torch.nn.LSTM(d, 256, batch_first=True).to(DEV)
+    with torch.no_grad():
+        for p in lstm.parameters():
+            p.copy_(torch.randn(p.shape, device=DEV, generator=g) * 0.2)
+    x = torch.randn(b, l, d, device=DEV, generator=g) * 2
+    h0 = torch.randn(b, 256, device=DEV, generator=g) * 0.5
+    c0 = torch.randn(b, 256, device=DEV, generator=g)
+    params = (lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
+    ref = hip.lstm_forward(x, h0, c0, hip.lstm_pack(*params), save=True)
+    packed, wb = hip.lstm_pack_split(*params)
+    got = hip.lstm_forward_split(x, h0, c0, packed, wb, save=True)
+    lstm64 = torch.nn.LSTM(d, 256, batch_first=True).double().to(DEV)
+    lstm64.load_state_dict({k: v.double() for k, v in lstm.state_dict().items()})
+    with torch.no_grad(), torch.backends.cudnn.flags(enabled=False):
+        hs64, (hn64, cn64) = lstm64(x.double(), (h0.double()[None], c0.double()[None]))
+    names = ("hs", "hn", "cn", "gates", "cs")
+    for name, a, r in zip(names, got, ref):
+        # (two fp32 evaluations of pre-activations of size ~3: a few 1e-6 apart)
+        torch.testing.assert_close(a, r, rtol=2e-5, atol=6e-6, msg=name)
+    for name, a, r, want in (("hs", got[0], ref[0], hs64), ("hn", got[1], ref[1], hn64[0]), ("cn", got[2], ref[2], cn64[0])):
+        err_split = float((a.double() - want).abs().max())
+        err_f32 = float((r.double() - want).abs().max())
+        assert err_split <= max(2.0 * err_f32, 2e-6), (name, err_split, err_f32)
+    # inference launch (no saved gates) returns the same states
+    again = hip.lstm_forward_split(x, h0, c0, packed, wb, save=False)
+    assert torch.equal(again[0], got[0]) and again[3] is None
