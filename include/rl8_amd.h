@@ -406,6 +406,12 @@ int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, float *works
 int rl8_mlp_wgrad_strided_f32(const float *dz2, int64_t dz2_pitch, const float *h1, int64_t h1_pitch,
                               int64_t m, float *workspace, float *dw2_out, int accumulate,
                               void *stream);
+/* The same product on the bf16 matrix pipe (fp32-accurate bf16-plane products, both
+ * operands prefetched from memory): the LSTM's dW_hh[q] = dG_q^T h_{t-1}
+ * (autograd of src/rl8/models/_recurrent.py:312-333). */
+int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const float *h, int64_t h_pitch,
+                                    int64_t m, float *workspace, float *dw_out, int accumulate,
+                                    void *stream);
 
 /* ---------------------------------------------------------------------- *
  * a-9, second generation: ONE LSTM timestep with the recurrent product as an

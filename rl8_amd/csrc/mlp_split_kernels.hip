@@ -1043,10 +1043,22 @@ struct WgradFusedArgs {
   int accumulate;      // a later segment of the same rows-of-samples sum: add to the partial rows
 };
 
-template <int DIN, int FUSED = 0>
+// LOADH: both operands come from memory -- dZ rows at pitch `ops.dz_pitch`, h1 rows at
+// ops.h + row * ops.h_pitch -- instead of h1 being recomputed from the observations:
+// the recurrent weight gradient of the LSTM, dW_hh[q] = dG_q^T h_{t-1}, with dG_q one gate
+// of [M][4][256] rows (pitch 1024) and h_{t-1} [M][256].  Same loop; the producer splits a
+// second prefetched register set instead of running layer 1.
+struct WgradOperands {
+  const float *h;
+  int dz_pitch, h_pitch;  // floats
+};
+
+template <int DIN, int FUSED = 0, bool LOADH = false>
 __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     const float *__restrict__ dz2, const float *__restrict__ x, const float *__restrict__ w1,
-    const float *__restrict__ b1, int64_t m, int d_in_rt, float *__restrict__ slabs, WgradFusedArgs fused) {
+    const float *__restrict__ b1, int64_t m, int d_in_rt, float *__restrict__ slabs, WgradFusedArgs fused,
+    WgradOperands ops) {
+  static_assert(!LOADH || (DIN == 1 && FUSED == 0), "the two-operand mode is instantiated once");
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = FUSED > 0 ? FUSED : 1;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
@@ -1064,8 +1076,9 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 
   float w1r[kIn];
 #pragma unroll
-  for (int c = 0; c < kIn; ++c) w1r[c] = (DIN > 0 || c < d_in) ? w1[col * d_in + c] : 0.0f;
-  const float b1r = b1[col];
+  for (int c = 0; c < kIn; ++c) w1r[c] = LOADH ? 0.0f : (DIN > 0 || c < d_in) ? w1[col * d_in + c] : 0.0f;
+  const float b1r = LOADH ? 0.0f : b1[col];
+  const int dz_pitch = LOADH ? ops.dz_pitch : kHidden;
   [[maybe_unused]] float w3r[kOut], db2a = 0.0f, dw3a[kOut];
   if constexpr (FUSED > 0) {
 #pragma unroll
@@ -1085,9 +1098,19 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     const int64_t chunk = blockIdx.x + n * stride;
     const int64_t left = m - chunk * kWsChunk;
     const int rows = left <= 0 ? 0 : left < kWsChunk ? (int)left : kWsChunk;
-    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? dz2 + chunk * kWsChunk * kHidden : dz2, rows * kHidden * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? dz2 + chunk * kWsChunk * dz_pitch : dz2,
+                                                    rows > 0 ? ((rows - 1) * dz_pitch + kHidden) * 4 : 0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dst[e] = buffer_load_f32(rsrc, col * 4, (8 * kh + e) * (kHidden * 4));
+    for (int e = 0; e < 8; ++e) dst[e] = buffer_load_f32(rsrc, col * 4, (8 * kh + e) * (dz_pitch * 4));
+  };
+  [[maybe_unused]] auto load_h = [&](float (&dst)[8], int64_t n) {  // LOADH: the same for the h1 operand
+    const int64_t chunk = blockIdx.x + n * stride;
+    const int64_t left = m - chunk * kWsChunk;
+    const int rows = left <= 0 ? 0 : left < kWsChunk ? (int)left : kWsChunk;
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? ops.h + chunk * kWsChunk * ops.h_pitch : ops.h,
+                                                    rows > 0 ? ((rows - 1) * ops.h_pitch + kHidden) * 4 : 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = buffer_load_f32(rsrc, col * 4, (8 * kh + e) * (ops.h_pitch * 4));
   };
   auto split8 = [&](const float (&v)[8], u32x4 (&planes)[3]) {
 #pragma unroll
@@ -1105,7 +1128,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   // in front of the PREVIOUS step's barrier, so that inside a step nothing but
   // ds_reads is in flight on lgkmcnt and the first MFMAs can go as soon as THEIR
   // fragments are in (wait_lds<N>), not after all twelve.
-  constexpr bool kScalars = DIN > 0;
+  constexpr bool kScalars = DIN > 0 && !LOADH;
   constexpr int kXq = kScalars ? kIn : 1, kDq = (kScalars && FUSED > 0) ? kOut : 1;
   [[maybe_unused]] f32x8 xq[kXq], dq[kDq];
   auto row0_of = [&](int64_t n) { return (blockIdx.x + n * stride) * kWsChunk + 8 * kh; };
@@ -1142,7 +1165,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       }
     }
   };
-  auto produce = [&](const float (&dzv)[8], int64_t n, u32x4 (&pa)[3], u32x4 (&pb)[3]) {
+  auto produce = [&](const float (&dzv)[8], [[maybe_unused]] const float (&hv)[8], int64_t n, u32x4 (&pa)[3],
+                     u32x4 (&pb)[3]) {
+    if constexpr (LOADH) {
+      split8(dzv, pa);
+      split8(hv, pb);
+      return;
+    }
     // (runtime d_in only: per-row loads, rows past the end clamped as above)
     auto row_of = [&](int e) {
       const int64_t row = row0_of(n) + e;
@@ -1193,6 +1222,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 
   f32x16 acc[2][4];
   float dzq[2][8];
+  [[maybe_unused]] float hq[1][8];
 
   // Chunk n (stage n & 1) is consumed while chunk n+1 is produced from dzq[(n+1) & 1]
   // and the dZ2 of chunk n+2 is requested into dzq[n & 1].
@@ -1237,8 +1267,27 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     __builtin_amdgcn_sched_barrier(0);
     split_mma_row<FIRST>(f.am[1], BM, acc[1]);
     u32x4 pa[3], pb[3];
-    load_dz(dzq[P], n + 2);
-    produce(dzq[P ^ 1], n + 1, pa, pb);
+    if constexpr (LOADH) {
+      // One register set per operand and one set of planes: the chunk requested a step
+      // ago is split and written operand by operand (the other stage's last readers
+      // passed the previous step's barrier), then the set is re-requested for the chunk
+      // after it.  (Two sets each, planes of both operands held to the usual place
+      // behind the second product group: 576 B of scratch -- whole accumulator tuples.)
+      const unsigned addr = p_write + (P ^ 1) * kWsStageBytes;
+      split8(dzq[0], pa);
+      lds_write_b128<0>(addr, pa[0]);
+      lds_write_b128<kWsPlane>(addr, pa[1]);
+      lds_write_b128<2 * kWsPlane>(addr, pa[2]);
+      load_dz(dzq[0], n + 2);
+      split8(hq[0], pa);
+      lds_write_b128<kWsOperandBytes>(addr, pa[0]);
+      lds_write_b128<kWsOperandBytes + kWsPlane>(addr, pa[1]);
+      lds_write_b128<kWsOperandBytes + 2 * kWsPlane>(addr, pa[2]);
+      load_h(hq[0], n + 2);
+    } else {
+      load_dz(dzq[P], n + 2);
+      produce(dzq[P ^ 1], dzq[P ^ 1], n + 1, pa, pb);
+    }
     if constexpr (kScalars) {
       wait_lds<4>(f.ah[0], f.ah[1]);  // only ds_reads are in flight: in-order count
       split_mma<false>(f.ah, BM, acc);
@@ -1249,7 +1298,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     }
     split_mma<false>(f.am, BH, acc);
     __builtin_amdgcn_sched_barrier(0);
-    write_planes(P ^ 1, pa, pb);
+    if constexpr (!LOADH) write_planes(P ^ 1, pa, pb);
     f.am[0] = lds_read_b128<2 * kWsPlane>(ar);
     f.am[1] = lds_read_b128<2 * kWsPlane + 512>(ar);
     BM[0] = lds_read_b128<2 * kWsPlane>(br);
@@ -1276,12 +1325,17 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 
   {
     load_dz(dzq[0], 0);
-    load_dz(dzq[1], 1);
+    if constexpr (LOADH) load_h(hq[0], 0);
+    else load_dz(dzq[1], 1);
     request_scalars(0);
     lds_barrier();
     scalars_landed();
     u32x4 pa[3], pb[3];
-    produce(dzq[0], 0, pa, pb);
+    produce(dzq[0], hq[0], 0, pa, pb);
+    if constexpr (LOADH) {
+      load_dz(dzq[0], 1);
+      load_h(hq[0], 1);
+    }
     write_planes(0, pa, pb);
     request_scalars(1);
     lds_barrier();
@@ -1291,12 +1345,24 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   }
   do_step(T{}, P0{}, 0);
   int64_t n = 1;
+  if constexpr (LOADH) {
+    // an odd number of steps, the last one on an all-zero chunk past the end if need be
+    // (descriptors of size 0): with a remainder step behind the loop the optimizer merged
+    // it into the loop body, and the accumulators went through copies (524 B of scratch)
+    const int64_t steps = mine | 1;
 #pragma unroll 1
-  for (; n + 1 < mine; n += 2) {
-    do_step(F{}, P1{}, n);
-    do_step(F{}, P0{}, n + 1);
+    for (; n < steps; n += 2) {
+      do_step(F{}, P1{}, n);
+      do_step(F{}, P0{}, n + 1);
+    }
+  } else {
+#pragma unroll 1
+    for (; n + 1 < mine; n += 2) {
+      do_step(F{}, P1{}, n);
+      do_step(F{}, P0{}, n + 1);
+    }
+    if (n < mine) do_step(F{}, P1{}, n);
   }
-  if (n < mine) do_step(F{}, P1{}, n);
 
   float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;
 #pragma unroll
@@ -1371,7 +1437,8 @@ static int launch_wgrad_split(int grid, hipStream_t s, const float *dz2, const f
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_wgrad_split_kernel<DIN><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(dz2, x, w1, b1, m, d_in, slabs, WgradFusedArgs{});
+  mlp_wgrad_split_kernel<DIN><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(dz2, x, w1, b1, m, d_in, slabs, WgradFusedArgs{},
+                                                                           WgradOperands{});
   return launch_status();
 }
 
@@ -1385,7 +1452,8 @@ static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const fl
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_wgrad_split_kernel<DIN, NOUT><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(h2, x, w1, b1, m, d_in, slabs, fused);
+  mlp_wgrad_split_kernel<DIN, NOUT><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(h2, x, w1, b1, m, d_in, slabs, fused,
+                                                                                 WgradOperands{});
   return launch_status();
 }
 
@@ -1503,6 +1571,38 @@ RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const floa
     }
     if (status != 0) return status;
     mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out,
+                                                                                 accumulate || at > 0);
+  }
+  return launch_status();
+}
+
+/* dW (+)= dZ^T h with BOTH operands strided in memory (dZ rows at dz_pitch, h rows at
+ * h_pitch floats, 256 columns each): the LSTM's recurrent weight gradient per gate. */
+RL8_API int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const float *h, int64_t h_pitch,
+                                            int64_t m, float *workspace, float *dw_out, int accumulate,
+                                            void *stream) {
+  if (!dz || !h || !workspace || !dw_out) return RL8_ENULL;
+  if (m <= 0 || dz_pitch < kHidden || h_pitch < kHidden) return RL8_ESIZE;
+  if ((int64_t)kWsChunk * (dz_pitch > h_pitch ? dz_pitch : h_pitch) * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
+  if (!aligned16(workspace) || !aligned16(dw_out)) return RL8_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<1, 0, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  for (int64_t at = 0; at < m; at += kWgradSegmentRows) {  // segments summed in order, as above
+    const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
+    const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
+    const int grid = (int)(chunks < kCUs ? chunks : kCUs);
+    const WgradOperands ops{h + at * h_pitch, (int)dz_pitch, (int)h_pitch};
+    mlp_wgrad_split_kernel<1, 0, true><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(
+        dz + at * dz_pitch, nullptr, nullptr, nullptr, rows, 1, workspace, WgradFusedArgs{}, ops);
+    const int status = launch_status();
+    if (status != 0) return status;
+    mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw_out,
                                                                                  accumulate || at > 0);
   }
   return launch_status();

@@ -138,6 +138,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_linear_heads_forward_f32": [_vp, _i64, _vp, _vp, _i32, _vp, _vp],
     "rl8_linear_heads_backward_f32": [_vp, _vp, _i64, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_wgrad_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp],
+    "rl8_mlp_wgrad_split_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp],
     "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
     "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_split_packed_bytes": [],
@@ -1185,11 +1186,15 @@ def lstm_backward(
         ws = _wgrad_ws[key] = torch.empty(int(lib.rl8_mlp_wgrad_workspace_bytes()) // 4, dtype=torch.float32, device=dev)
     dw_hh = torch.empty(4 * LSTM_HIDDEN, LSTM_HIDDEN, dtype=torch.float32, device=dev)
     flat = dgates.view(m, 4 * LSTM_HIDDEN)
+    # per gate dW_hh[q] = dG_q^T h_{t-1}: the bf16-plane weight-gradient kernel in its
+    # two-operands-from-memory mode (RL8_AMD_LSTM_GEMM=f32: the fp32-MFMA kernel)
+    split = os.environ.get("RL8_AMD_LSTM_GEMM", "split") == "split"
+    fn, name = ((lib.rl8_mlp_wgrad_split_strided_f32, "rl8_mlp_wgrad_split_strided_f32") if split
+                else (lib.rl8_mlp_wgrad_strided_f32, "rl8_mlp_wgrad_strided_f32"))
     with _timed("lstm_wgrad", m):
         for q in range(4):
-            _check(lib.rl8_mlp_wgrad_strided_f32(_ptr(flat) + 4 * LSTM_HIDDEN * q, 4 * LSTM_HIDDEN, _ptr(h_prev),
-                                                 LSTM_HIDDEN, m, _ptr(ws), _ptr(dw_hh) + 4 * LSTM_HIDDEN * LSTM_HIDDEN * q,
-                                                 0, _stream()), "rl8_mlp_wgrad_strided_f32")
+            _check(fn(_ptr(flat) + 4 * LSTM_HIDDEN * q, 4 * LSTM_HIDDEN, _ptr(h_prev), LSTM_HIDDEN, m, _ptr(ws),
+                      _ptr(dw_hh) + 4 * LSTM_HIDDEN * LSTM_HIDDEN * q, 0, _stream()), name)
     return {"w_ih": small[: 4 * LSTM_HIDDEN * d_in].view(4 * LSTM_HIDDEN, d_in), "w_hh": dw_hh,
             "b": small[4 * LSTM_HIDDEN * d_in :]}
 
