@@ -1177,24 +1177,27 @@ def lstm_backward(
                                          _ptr(whht_packed), _ptr(dgates), _ptr(partials), C.byref(rows), _stream()),
                "rl8_lstm_backward_f32")
     small = partials[: rows.value].sum(0)
-    # h_{t-1} for every row: h0, then the outputs shifted by one step
-    h_prev = torch.cat([h0.unsqueeze(1), hs[:, :-1]], dim=1).contiguous()
     m = b * l
     key = (dev.index or 0, _stream() or 0)
     ws = _wgrad_ws.get(key)
     if ws is None:
         ws = _wgrad_ws[key] = torch.empty(int(lib.rl8_mlp_wgrad_workspace_bytes()) // 4, dtype=torch.float32, device=dev)
     dw_hh = torch.empty(4 * LSTM_HIDDEN, LSTM_HIDDEN, dtype=torch.float32, device=dev)
-    flat = dgates.view(m, 4 * LSTM_HIDDEN)
     # per gate dW_hh[q] = dG_q^T h_{t-1}: the bf16-plane weight-gradient kernel in its
-    # two-operands-from-memory mode (RL8_AMD_LSTM_GEMM=f32: the fp32-MFMA kernel)
+    # two-operands-from-memory mode (RL8_AMD_LSTM_GEMM=f32: the fp32-MFMA kernel), one
+    # launch per gate and timestep over the B rows of that step -- h_{t-1} is h0 for
+    # t = 0 and hs[:, t-1] (row pitch L*256) after, so no shifted copy of hs is made
     split = os.environ.get("RL8_AMD_LSTM_GEMM", "split") == "split"
     fn, name = ((lib.rl8_mlp_wgrad_split_strided_f32, "rl8_mlp_wgrad_split_strided_f32") if split
                 else (lib.rl8_mlp_wgrad_strided_f32, "rl8_mlp_wgrad_strided_f32"))
+    H = LSTM_HIDDEN
+    dgp, hsp, h0p, wsp, dwp, stream = _ptr(dgates), _ptr(hs), _ptr(h0), _ptr(ws), _ptr(dw_hh), _stream()
     with _timed("lstm_wgrad", m):
         for q in range(4):
-            _check(fn(_ptr(flat) + 4 * LSTM_HIDDEN * q, 4 * LSTM_HIDDEN, _ptr(h_prev), LSTM_HIDDEN, m, _ptr(ws),
-                      _ptr(dw_hh) + 4 * LSTM_HIDDEN * LSTM_HIDDEN * q, 0, _stream()), name)
+            for t in range(l):
+                h_prev, h_pitch = (h0p, H) if t == 0 else (hsp + (t - 1) * H * 4, l * H)
+                _check(fn(dgp + (t * 4 * H + q * H) * 4, l * 4 * H, h_prev, h_pitch, b, wsp, dwp + 4 * H * H * q,
+                          int(t > 0), stream), name)
     return {"w_ih": small[: 4 * LSTM_HIDDEN * d_in].view(4 * LSTM_HIDDEN, d_in), "w_hh": dw_hh,
             "b": small[4 * LSTM_HIDDEN * d_in :]}
 
