@@ -582,6 +582,14 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   const bool use_bits = gate2 != nullptr;
   const unsigned gate_lds = lds0 + 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4;  // [128 rows][8 words]
   uint32_t g0 = 0u;  // word 0 of row prow of the NEXT tile (its chunk 0 is produced before the block lands)
+  // Wide observations (d_in >= 3): the running column sums [256][1 + d_in] and the 4-KiB
+  // gate block do not both fit beside the two chunk stages in 80 KB, and at one workgroup
+  // per CU this kernel lost a third of its speed (CartPole: 29 ms per 2^25 rows against 19
+  // for d_in = 1).  There the gate word of (row, two k-steps) is fetched into a register two
+  // steps ahead instead (4 bytes per thread and pair of steps, L2 hits after a row's first
+  // word): `g0` is the word in use, `gnext` the one on its way.  No gate block in LDS.
+  constexpr bool kRegGate = kIn >= 3 && DIN > 0;
+  [[maybe_unused]] uint32_t gnext = 0u;
   const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
   const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
   const unsigned a_write = lds0 + pkh * kSplitKhStride + prow * 16;
@@ -605,6 +613,10 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     const float *base = dout + tile * kSplitRows * n_out;
 #pragma unroll
     for (int q = 0; q < kOut; ++q) dst[q] = (prow < rows && q < n_out) ? base[(unsigned)(prow * n_out + q)] : 0.0f;
+  };
+  [[maybe_unused]] auto load_gate_word = [&](int64_t tile, int word) {
+    const int rows = rows_in_tile(tile);
+    gnext = prow < rows ? (gate2 + tile * (kSplitRows * 8))[(unsigned)(prow * 8 + word)] : 0u;
   };
   load_dout(dr, p_tile);
   load_dout(dn, p_tile + stride);
@@ -646,7 +658,9 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   auto produce_a = [&](const float4 (&hv)[2], int ks, u32x4 (&planes)[3], bool from_regs = false) {
     const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);  // W3[q][kb + e]: uniform, through the scalar cache
     uint32_t gword = g0;
-    if (use_bits && !from_regs) gword = __float_as_uint(lds_read_b32(gate_lds + (prow * 8 + (ks >> 1)) * 4));
+    if constexpr (!kRegGate) {
+      if (use_bits && !from_regs) gword = __float_as_uint(lds_read_b32(gate_lds + (prow * 8 + (ks >> 1)) * 4));
+    }
     const uint32_t byte = gword >> (16 * (ks & 1) + 8 * pkh);
     const float hval[8] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w};
     float dz[8];
@@ -717,12 +731,24 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       load_dout(dn, p_tile + stride);
       // every wave is past barrier(14): nobody reads the old gate block any more;
       // the new one lands by this step's barrier, chunk 0 uses g0 meanwhile
-      if (use_bits) request_gate(p_tile);
+      if constexpr (!kRegGate) {
+        if (use_bits) request_gate(p_tile);
+      }
+    }
+    if constexpr (kRegGate) {
+      // chunk ks opens word ks / 2 when ks is even: take the prefetched word, request the
+      // next one (ks = 14: word 0 of the producer's next tile; ks = 0: p_tile has moved on)
+      if (use_bits && !(ks & 1)) {
+        g0 = gnext;
+        load_gate_word(ks == kSplitSteps - 2 ? p_tile + stride : p_tile, ((ks >> 1) + 1) & 7);
+      }
     }
     u32x4 planes[3];
     produce_a(hq, ks, planes, s == kSplitSteps - 1);
     if (use_bits) {
-      if (s == kSplitSteps - 3) load_g0(p_tile + stride);  // two steps ahead of its use
+      if constexpr (!kRegGate) {
+        if (s == kSplitSteps - 3) load_g0(p_tile + stride);  // two steps ahead of its use
+      }
     } else {
       // h2 of the chunk after next, into the registers just consumed: used by the
       // next step's produce_a (the step barrier waits for it; it has this step to arrive).
@@ -757,8 +783,14 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   p_rows = rows_in_tile(p_tile);
   if ((int64_t)blockIdx.x < tiles) {
     if (use_bits) {
-      request_gate(p_tile);
-      step_barrier();  // (once per kernel: the first gate block has landed)
+      if constexpr (kRegGate) {
+        load_gate_word(p_tile, 0);
+        g0 = gnext;
+        load_gate_word(p_tile, 1);  // opened by chunk 2, i.e. in step 1
+      } else {
+        request_gate(p_tile);
+        step_barrier();  // (once per kernel: the first gate block has landed)
+      }
     } else {
       load_h2(hq, p_tile, 0);
     }
@@ -973,7 +1005,10 @@ static int launch_backward_split(int grid, hipStream_t s, const float *x, const 
     attr_set = true;
   }
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
-  mlp_tower_backward_split_kernel<DIN, NOUT><<<grid, kBlock, 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4 + kSplitRows * 32, s>>>(
+  constexpr int kGateBlock = (kIn >= 3 && DIN > 0) ? 0 : kSplitRows * 32;  // (wide inputs: gate words through registers)
+  static_assert(DIN == 0 || NOUT == 0 || 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4 + kGateBlock <= 80 * 1024,
+                "two workgroups per CU");
+  mlp_tower_backward_split_kernel<DIN, NOUT><<<grid, kBlock, 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4 + kGateBlock, s>>>(
       x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
   const int status = launch_status();
   if (status != 0 || head_rows >= 0) return status;  // (fused: the weight-gradient kernel forms the head gradients)
