@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     for (int i = 0; i < kIn; ++i) dst[i] = (prow < rows && i < d_in) ? base[(unsigned)(prow * d_in + i)] : 0.0f;
   };
   // (wide observations: the next tile's row is loaded at the tile switch instead of a tile ahead)
-  constexpr bool kPrefetchX = kIn <= 2;
+  constexpr bool kPrefetchX = DIN > 0;  // (compiled widths: a tile ahead; run-time widths: at the tile switch)
   load_x(px, p_r0);
   if constexpr (kPrefetchX) load_x(xn, p_r0 + stride * kSplitRows);
 
@@ -842,45 +842,53 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     // (narrow observations: the sixteen rows a row tile needs are requested together, up
     // front -- per batch of four, their L1 round trip sat in front of every batch)
     constexpr int kXRows = kIn <= 2 ? 16 : 4;
+    constexpr int kBatches = 2 * 16 / kXRows;  // batches of kXRows rows over both row tiles
+    auto load_rows = [&](float (&dst)[kXRows][kIn], int batch) {
+      const int mt = batch / (16 / kXRows), rx = (batch % (16 / kXRows)) * kXRows;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int u = 0; u < kXRows; ++u) {
+        const int r = rx + u;
+        const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
 #pragma unroll
-      for (int rx = 0; rx < 16; rx += kXRows) {
-        float xv[kXRows][kIn];
-#pragma unroll
-        for (int u = 0; u < kXRows; ++u) {
-          const int r = rx + u;
-          const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
-#pragma unroll
-          for (int i = 0; i < kIn; ++i)
-            xv[u][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(xrsrc, (4 * hh * d_in + i) * 4, sr * d_in * 4) : 0.0f;
-        }
-#pragma unroll
-        for (int rb = 0; rb < kXRows; rb += 4)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            float pre[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              pre[u] = b1c[nt];
-#pragma unroll
-              for (int i = 0; i < kIn; ++i) pre[u] = __builtin_fmaf(xv[rb + u][i], w1c[nt][i], pre[u]);
-            }
-            unsigned long long gate[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) gate[u] = positive_mask(pre[u]);
-            __builtin_amdgcn_sched_barrier(0);
-            float dz[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) dz[u] = select_or_zero(gate[u], acc[mt][nt][rx + rb + u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              db1[nt] += dz[u];
-#pragma unroll
-              for (int i = 0; i < kIn; ++i) dw1[nt][i] = __builtin_fmaf(dz[u], xv[rb + u][i], dw1[nt][i]);
-            }
-          }
+        for (int i = 0; i < kIn; ++i)
+          dst[u][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(xrsrc, (4 * hh * d_in + i) * 4, sr * d_in * 4) : 0.0f;
       }
+    };
+    // (wide observations: batches of four rows, the NEXT batch's rows requested before the
+    // current batch is folded -- eight L1 round trips per tile sat in front of the batches)
+    float xbuf[2][kXRows][kIn];
+    load_rows(xbuf[0], 0);
+#pragma unroll
+    for (int batch = 0; batch < kBatches; ++batch) {
+      const int mt = batch / (16 / kXRows), rx = (batch % (16 / kXRows)) * kXRows;
+      if (batch + 1 < kBatches) load_rows(xbuf[(batch + 1) & 1], batch + 1);
+      float (&xv)[kXRows][kIn] = xbuf[batch & 1];
+#pragma unroll
+      for (int rb = 0; rb < kXRows; rb += 4)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          float pre[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            pre[u] = b1c[nt];
+#pragma unroll
+            for (int i = 0; i < kIn; ++i) pre[u] = __builtin_fmaf(xv[rb + u][i], w1c[nt][i], pre[u]);
+          }
+          unsigned long long gate[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) gate[u] = positive_mask(pre[u]);
+          __builtin_amdgcn_sched_barrier(0);
+          float dz[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dz[u] = select_or_zero(gate[u], acc[mt][nt][rx + rb + u]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            db1[nt] += dz[u];
+#pragma unroll
+            for (int i = 0; i < kIn; ++i) dw1[nt][i] = __builtin_fmaf(dz[u], xv[rb + u][i], dw1[nt][i]);
+          }
+        }
+    }
     // Into the running sums, in a fixed order: the two row halves of a lane pair
     // (DPP-free: one cross-half shuffle), then the wave of rows 0..63, a barrier,
     // the wave of rows 64..127.  (The next tile touches them sixteen barriers later.)
