@@ -84,7 +84,8 @@ ALGORITHMIC_BYTES = {
 # passes over tools/kernel_microbench.py at config-2 shapes; corrected as
 # MI355X_MICROARCH.md prescribes; summary committed under profiles/). Scaled by
 # units to the launch size bench.py uses.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_traffic_microbench.json")
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_microbench.json") for r in (2, 1))
+                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r02_pmc_traffic_microbench.json"))
 PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in that profiled launch)
     "ppo_loss_categorical": ("ppo_loss_categorical_kernel", 1 << 22),
     "ppo_loss_normal": ("ppo_loss_normal_kernel", 1 << 22),
@@ -392,7 +393,31 @@ def run(args: argparse.Namespace) -> None:
             ok = fused_mlp.BACKWARD_GEMM == "split" and all(hip.mlp_backward_split_supports(d, n) for d, n in widths)
         return "bf16x3-split" if ok else "f32"
 
+    lstm_gemm = {  # the recurrent models' LSTM (config 5): FLOP per row-step, matrix pipe
+        "lstm_step": (2.0 * 256 * 1024, "bf16x3-split"), "lstm_step_save": (2.0 * 256 * 1024, "bf16x3-split"),
+        "lstm_forward": (2.0 * 264 * 1024, "f32"), "lstm_forward_save": (2.0 * 264 * 1024, "f32"),
+        "lstm_backward": (2.0 * 1024 * 256, "f32"),
+        "lstm_wgrad": (2.0 * 1024 * 256, "bf16x3-split" if os.environ.get("RL8_AMD_LSTM_GEMM", "split") == "split" else "f32"),
+    }
     for name, rec in hip.timer.summary().items():
+        if name in lstm_gemm:
+            per_row, gemm = lstm_gemm[name]
+            flops_per_launch = per_row * rec["units_per_launch"]
+            tflops = flops_per_launch / (rec["avg_ms"] * 1e-3) / 1e12
+            kernels[name] = {
+                "bound": "mfma", "gemm": gemm, "launches": rec["launches"], "avg_ms": round(rec["avg_ms"], 5),
+                "total_ms": round(rec["total_ms"], 3), "algorithmic_flop_per_launch": flops_per_launch,
+                "achieved_TFLOPs": round(tflops, 2), "frac_of_f32_mfma_peak": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                "pmc_traffic_bytes_per_launch": None,
+            }
+            if gemm != "f32":
+                executed = SPLIT_PRODUCTS * flops_per_launch
+                kernels[name].update({
+                    "executed_bf16_flop_per_launch": executed,
+                    "executed_bf16_TFLOPs": round(executed / (rec["avg_ms"] * 1e-3) / 1e12, 1),
+                    "frac_of_bf16_mfma_peak": round(executed / (rec["avg_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                })
+            continue
         if name.startswith("mlp_"):
             # n_out differs per tower (policy 2-3, value 1); price both at the mean.
             # mlp_wgrad is the 256x256 weight-gradient product alone.
@@ -538,6 +563,8 @@ def run(args: argparse.Namespace) -> None:
                 "traffic": dom["pmc_traffic_bytes_per_launch"],
             },
             "kernels": kernels,
+            "kernels_note": "HIP-event times of ABI calls inside the timed region; the recurrent rollout's per-timestep"
+                            " launches are sampled (every 16th timestep), so their `launches` / `total_ms` are of the sample",
             "hand_kernel_ms_per_step": round(sum(k["total_ms"] for k in kernels.values()) / args.steps, 3),
             "fused_towers": True,
         }

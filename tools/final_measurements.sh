@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round measurements on the GPU box (run through gpurun): GPU tests, kernel microbench,
+# rocprofv3 kernel stats of the bench command, the two PMC passes (FETCH_SIZE / WRITE_SIZE,
+# separate runs, kernel-trace only) over the microbench, then the bench lines of every
+# BASELINE config's single-GPU share.  Summaries land in gpurun_out/ (scratch); the ones to
+# be judged are copied into profiles/ by hand afterwards.
+#   gpurun --timeout 1200 -- 'tools/final_measurements.sh r02'
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-r02}
+cd "$R"
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gputests.log 2>&1; tail -2 gpurun_out/${TAG}_gputests.log
+timeout -k 10 400 python tools/kernel_microbench.py --rounds 20 > gpurun_out/${TAG}_kernel_microbench.txt 2>&1 || { echo microbench failed; tail -5 gpurun_out/${TAG}_kernel_microbench.txt; exit 1; }
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_${TAG}" -o bench --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof_bench.log" 2>&1 || { echo "rocprof stats failed"; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$R/gpurun_out/pmc_fetch" -o mb --output-format csv -- python3 "$R/tools/kernel_microbench.py" --rounds 1 > "$R/gpurun_out/pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$R/gpurun_out/pmc_write" -o mb --output-format csv -- python3 "$R/tools/kernel_microbench.py" --rounds 1 > "$R/gpurun_out/pmc_write.log" 2>&1 || { echo "pmc write failed"; exit 1; }
+cd "$R"
+python tools/summarize_profiles.py stats "$(find gpurun_out/prof_${TAG} -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_bench_kernel_stats.csv || exit 1
+python tools/summarize_profiles.py pmc "$(find gpurun_out/pmc_fetch -name '*counter_collection.csv' | head -1)" "$(find gpurun_out/pmc_write -name '*counter_collection.csv' | head -1)" gpurun_out/${TAG}_pmc_traffic_microbench.json || exit 1
+cp gpurun_out/${TAG}_pmc_traffic_microbench.json profiles/${TAG}_pmc_traffic_microbench.json   # the bench lines below carry this build's traffic
+timeout -k 10 500 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err || { echo bench failed; tail -5 gpurun_out/${TAG}_bench_n1.err; exit 1; }
+timeout -k 10 300 python bench.py --env cartpole --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg3.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --env continuous --distribution squashed --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg4.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --recurrent --num-envs 8192 --horizon 256 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg5.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --env mountain_car --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_mountain_car.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --env pendulum --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_pendulum.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --gpus 2 --backend gloo --single-device --num-envs 262144 --steps 3 --warmup 1 > gpurun_out/${TAG}_b_2rank_rehearsal.json 2>/dev/null || exit 1
+for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_mountain_car b_pendulum b_2rank_rehearsal; do python -c "
+import json; d=json.loads(open('gpurun_out/${TAG}_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value']), round(d['ms_per_step'],1), round(d['collect_ms_per_step'],1), round(d['update_ms_per_step'],1))"; done
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+echo done
