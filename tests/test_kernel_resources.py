@@ -125,7 +125,7 @@ def test_compiled_split_kernels_resources(tmp_path):
             assert scratch == 0, (name, scratch)
             assert vgprs <= 256, (name, vgprs)
             checked += 1
-    assert checked >= 24 + 12 + 5 + 12
+    assert checked >= 24 + 12 + 5 + 12 + 1  # (+ the two-operand weight-gradient mode)
     _check_wgrad_scalar_windows(text)
     # Every hand-issued load (ds_read_b128, s_buffer_load_dwordx8, ...) of every kernel: nothing
     # reads or overwrites its destination before a wait that covers it, on any path.
@@ -185,3 +185,32 @@ def _check_wgrad_scalar_windows(text: str) -> None:
                 assert not (pending & _sgprs(o)), (name, i, ln)
     assert loads >= 16 * 2 * 2 and counted >= 16 * 2
 
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_compiled_lstm_split_kernels_resources(tmp_path):
+    """The bf16-plane LSTM step kernel (lstm_split_kernels.hip): every compiled input width
+    free of scratch, two workgroups per CU, no packed fp32 arithmetic beside the bf16 MFMAs,
+    and no hand-issued load's destination touched before its wait."""
+    csrc = os.path.join(ROOT, "rl8_amd", "csrc")
+    asm = tmp_path / "lstm_split.s"
+    subprocess.run(
+        [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/include", f"-I{csrc}",
+         "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", str(asm), os.path.join(csrc, "lstm_split_kernels.hip")],
+        check=True, capture_output=True, timeout=900,
+    )
+    text = asm.read_text()
+    assert not re.search(r"\bv_pk_(fma|add|mul)_f32\b", text)
+    kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
+    checked = 0
+    for name, body in kernels:
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        assert scratch == 0, (name, scratch)
+        if "lstm_step_split_kernel" in name:
+            assert vgprs <= 256, (name, vgprs)
+            checked += 1
+    assert checked == 8  # d_in in {1, 2, 3, 5} x {rollout, training}
+    assert_no_inflight_register_access(text, "lstm_step_split_kernel", min_hand_loads=8 * 100)
+    for name, body in inflight.kernels_of(text):
+        assert inflight.packed_war(body) == [], name
