@@ -348,113 +348,149 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     [[maybe_unused]] const unsigned t_write = t_base + l32 * kH2Pitch + 16 * hh;
     [[maybe_unused]] const unsigned t_read = t_base + (lane_id() >> 3) * kH2Pitch + (lane_id() & 7) * 16;
     [[maybe_unused]] const int h2_voff = ((64 * wr + (lane_id() >> 3)) * kHidden + 128 * wc + 4 * (lane_id() & 7)) * 4;
+    // The column blocks in groups of kGroup quads (g = eight columns): b2 and the kOut
+    // rows of W3 for the group from LDS, then bias + ReLU, the h2 quads into the transpose
+    // scratch, gate nibbles and head products.  (Wide heads take two quads at a time:
+    // sixteen W3 quads plus the block read back would not fit.)
+    // Software-pipelined over the groups: the LDS is busy with the CU's other workgroup's
+    // operand reads, so every lgkmcnt(0) in here cost 500+ cycles (twelve of them per tile
+    // measured 13 500 cycles for ~800 VALU instructions).  The next group's b2 quads are
+    // requested as soon as bias + ReLU has consumed this group's, its W3 quads as soon as
+    // the head products have, and the transposed block is waited for by COUNT (in-order
+    // LDS returns; no scalar load is in flight here), behind the gate and head arithmetic.
+    constexpr int kGroup = kOut >= 4 ? 1 : kOut >= 2 ? 2 : 4;  // (registers: more W3 quads in flight beside the block spilled)
+    constexpr int kStages = 4 * (4 / kGroup);  // (nt, g0) pairs
+    constexpr bool kStore = SAVE && !(kSplitDiagSkip & 8);
+    u32x4 bq[kGroup], wq[kOut][kGroup];
+    auto request_b2 = [&](int stage) {
+      const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      // The column block in groups of kGroup quads (g = eight columns): b2 and the
-      // kOut rows of W3 for the group from LDS, then bias + ReLU, the h2 quads into
-      // the transpose scratch, gate nibbles and head products.  (Wide heads take two
-      // quads at a time: sixteen W3 quads plus the block read back would not fit.)
-      constexpr int kGroup = kOut >= 4 ? 2 : 4;
-      [[maybe_unused]] u32x4 t_rows[8];
-      constexpr bool kStore = SAVE && !(kSplitDiagSkip & 8);
-      auto read_block = [&]() {  // the block back, eight lanes per row (in order behind the writes: same wave)
-        t_rows[0] = lds_read_b128<0 * 8 * kH2Pitch>(t_read);
-        t_rows[1] = lds_read_b128<1 * 8 * kH2Pitch>(t_read);
-        t_rows[2] = lds_read_b128<2 * 8 * kH2Pitch>(t_read);
-        t_rows[3] = lds_read_b128<3 * 8 * kH2Pitch>(t_read);
-        t_rows[4] = lds_read_b128<4 * 8 * kH2Pitch>(t_read);
-        t_rows[5] = lds_read_b128<5 * 8 * kH2Pitch>(t_read);
-        t_rows[6] = lds_read_b128<6 * 8 * kH2Pitch>(t_read);
-        t_rows[7] = lds_read_b128<7 * 8 * kH2Pitch>(t_read);
-      };
+      for (int gi = 0; gi < kGroup; ++gi) bq[gi] = lds_read_b128<0>(constp + (32 * nt + 8 * (g0 + gi)) * 4);
+    };
+    auto request_w3 = [&](int stage) {
+      const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
 #pragma unroll
-      for (int g0 = 0; g0 < 4; g0 += kGroup) {
-        u32x4 bq[kGroup], wq[kOut][kGroup];
-#pragma unroll
-        for (int gi = 0; gi < kGroup; ++gi) {
-          const unsigned a = constp + (32 * nt + 8 * (g0 + gi)) * 4;
-          bq[gi] = lds_read_b128<0>(a);
-#pragma unroll
-          for (int q = 0; q < kOut; ++q)
-            wq[q][gi] = q == 0   ? lds_read_b128<1 * kHidden * 4>(a)
-                        : q == 1 ? lds_read_b128<2 * kHidden * 4>(a)
-                        : q == 2 ? lds_read_b128<3 * kHidden * 4>(a)
-                        : q == 3 ? lds_read_b128<4 * kHidden * 4>(a)
-                        : q == 4 ? lds_read_b128<5 * kHidden * 4>(a)
-                        : q == 5 ? lds_read_b128<6 * kHidden * 4>(a)
-                        : q == 6 ? lds_read_b128<7 * kHidden * 4>(a)
-                                 : lds_read_b128<8 * kHidden * 4>(a);
-        }
-#pragma unroll
-        for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(bq[gi]);
+      for (int gi = 0; gi < kGroup; ++gi) {
+        const unsigned a = constp + (32 * nt + 8 * (g0 + gi)) * 4;
 #pragma unroll
         for (int q = 0; q < kOut; ++q)
+          wq[q][gi] = q == 0   ? lds_read_b128<1 * kHidden * 4>(a)
+                      : q == 1 ? lds_read_b128<2 * kHidden * 4>(a)
+                      : q == 2 ? lds_read_b128<3 * kHidden * 4>(a)
+                      : q == 3 ? lds_read_b128<4 * kHidden * 4>(a)
+                      : q == 4 ? lds_read_b128<5 * kHidden * 4>(a)
+                      : q == 5 ? lds_read_b128<6 * kHidden * 4>(a)
+                      : q == 6 ? lds_read_b128<7 * kHidden * 4>(a)
+                               : lds_read_b128<8 * kHidden * 4>(a);
+      }
+    };
+    request_b2(0);
+    request_w3(0);
+    [[maybe_unused]] u32x4 t_rows[8];
+    auto read_block = [&]() {  // the block back, eight lanes per row (in order behind the writes: same wave)
+      t_rows[0] = lds_read_b128<0 * 8 * kH2Pitch>(t_read);
+      t_rows[1] = lds_read_b128<1 * 8 * kH2Pitch>(t_read);
+      t_rows[2] = lds_read_b128<2 * 8 * kH2Pitch>(t_read);
+      t_rows[3] = lds_read_b128<3 * 8 * kH2Pitch>(t_read);
+      t_rows[4] = lds_read_b128<4 * 8 * kH2Pitch>(t_read);
+      t_rows[5] = lds_read_b128<5 * 8 * kH2Pitch>(t_read);
+      t_rows[6] = lds_read_b128<6 * 8 * kH2Pitch>(t_read);
+      t_rows[7] = lds_read_b128<7 * 8 * kH2Pitch>(t_read);
+    };
 #pragma unroll
-          for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(wq[q][gi]);
+    for (int stage = 0; stage < kStages; ++stage) {
+      const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
+      const bool last_of_block = g0 + kGroup == 4;
+      // this group's quads (requested a stage ago; everything older has landed too)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+      for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(bq[gi]);
+#pragma unroll
+      for (int q = 0; q < kOut; ++q)
+#pragma unroll
+        for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(wq[q][gi]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int gi = 0; gi < kGroup; ++gi) {
+          const int g = g0 + gi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)  // (not __builtin_bit_cast on a vector-element lvalue: it reads element 0)
+            acc[mt][nt][4 * g + e] = relu1(acc[mt][nt][4 * g + e] + __uint_as_float(bq[gi][e]));
+        }
+      if (stage + 1 < kStages) request_b2(stage + 1);
+      if constexpr (kStore) {
+        // h2 block [64 rows][32 columns] of this wave -> its transpose scratch (row pitch
+        // 144 B: the eight lanes of a b128 phase hit eight distinct 16-byte slots, writing
+        // as well as reading)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int gi = 0; gi < kGroup; ++gi) {
             const int g = g0 + gi;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)  // (not __builtin_bit_cast on a vector-element lvalue: it reads element 0)
-              acc[mt][nt][4 * g + e] = relu1(acc[mt][nt][4 * g + e] + __uint_as_float(bq[gi][e]));
-            if constexpr (kStore) {
-              // h2 block [64 rows][32 columns] of this wave -> its transpose scratch (row
-              // pitch 144 B: the eight lanes of a b128 phase hit eight distinct 16-byte
-              // slots, writing as well as reading)
-              const f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
-              const u32x4 u = __builtin_bit_cast(u32x4, v);
-              if (mt == 0) {
-                g == 0 ? lds_write_b128<0>(t_write, u) : g == 1 ? lds_write_b128<32>(t_write, u)
-                : g == 2 ? lds_write_b128<64>(t_write, u) : lds_write_b128<96>(t_write, u);
-              } else {
-                g == 0 ? lds_write_b128<32 * kH2Pitch>(t_write, u) : g == 1 ? lds_write_b128<32 * kH2Pitch + 32>(t_write, u)
-                : g == 2 ? lds_write_b128<32 * kH2Pitch + 64>(t_write, u) : lds_write_b128<32 * kH2Pitch + 96>(t_write, u);
-              }
+            const f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+            const u32x4 u = __builtin_bit_cast(u32x4, v);
+            if (mt == 0) {
+              g == 0 ? lds_write_b128<0>(t_write, u) : g == 1 ? lds_write_b128<32>(t_write, u)
+              : g == 2 ? lds_write_b128<64>(t_write, u) : lds_write_b128<96>(t_write, u);
+            } else {
+              g == 0 ? lds_write_b128<32 * kH2Pitch>(t_write, u) : g == 1 ? lds_write_b128<32 * kH2Pitch + 32>(t_write, u)
+              : g == 2 ? lds_write_b128<32 * kH2Pitch + 64>(t_write, u) : lds_write_b128<32 * kH2Pitch + 96>(t_write, u);
             }
           }
-        }
-        // (narrow heads: the block is read back here, ahead of the gate bits and head
-        // products that hide the round trip)
-        if constexpr (kStore && kGroup == 4) read_block();
+        if (last_of_block) read_block();
+      }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-          for (int gi = 0; gi < kGroup; ++gi) {
-            const int g = g0 + gi;
-            if constexpr (SAVE) {
-              // gate of h2, bit c of word [row][4 wc + nt] <=> column 32 (4 wc + nt) + c > 0.
-              // h2 >= +0 here, so "h2 > 0" is bit 31 of (bits(h2) + 0x7fffffff); four of
-              // them are funnel-shifted into a nibble (element 0 lowest), the nibble goes
-              // to bit 8 g + 4 hh.  The other half-wave holds the interleaved nibbles.
-              uint32_t nib = 0;
+        for (int gi = 0; gi < kGroup; ++gi) {
+          const int g = g0 + gi;
+          if constexpr (SAVE && !(kSplitDiagSkip & 65536)) {  // (tuning builds, bit 65536: no gate bits)
+            // gate of h2, bit c of word [row][4 wc + nt] <=> column 32 (4 wc + nt) + c > 0.
+            // h2 >= +0 here, so "h2 > 0" is bit 31 of (bits(h2) + 0x7fffffff); four of
+            // them are funnel-shifted into a nibble (element 0 lowest), the nibble goes
+            // to bit 8 g + 4 hh.  The other half-wave holds the interleaved nibbles.
+            uint32_t nib = 0;
 #pragma unroll
-              for (int e = 3; e >= 0; --e)
-                nib = __builtin_amdgcn_alignbit(nib, __float_as_uint(acc[mt][nt][4 * g + e]) + 0x7fffffffu, 31);
-              gate_words[mt][nt] = (g == 0 ? 0u : gate_words[mt][nt]) | (nib << (8 * g + 4 * hh));
-            }
-            // head partials of this row: four (two for wide heads) independent chains per
-            // output, 16 (32) terms each over the tile, so the sum is not one 64-term
-            // chain and the fmas do not wait on each other
+            for (int e = 3; e >= 0; --e)
+              nib = __builtin_amdgcn_alignbit(nib, __float_as_uint(acc[mt][nt][4 * g + e]) + 0x7fffffffu, 31);
+            gate_words[mt][nt] = (g == 0 ? 0u : gate_words[mt][nt]) | (nib << (8 * g + 4 * hh));
+          }
+          // head partials of this row: four (two for wide heads) independent chains per
+          // output, 16 (32) terms each over the tile, so the sum is not one 64-term
+          // chain and the fmas do not wait on each other
 #pragma unroll
-            for (int q = 0; q < kOut; ++q) {
-              float p = (nt == 0 && g < kChains) ? 0.0f : part[mt][q][g % kChains];
+          for (int q = 0; q < kOut; ++q) {
+            float p = (nt == 0 && g < kChains) ? 0.0f : part[mt][q][g % kChains];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) p = __builtin_fmaf(acc[mt][nt][4 * g + e], __uint_as_float(wq[q][gi][e]), p);
-              part[mt][q][g % kChains] = p;
-            }
+            for (int e = 0; e < 4; ++e) p = __builtin_fmaf(acc[mt][nt][4 * g + e], __uint_as_float(wq[q][gi][e]), p);
+            part[mt][q][g % kChains] = p;
           }
         }
       }
+      if (stage + 1 < kStages) request_w3(stage + 1);
       if constexpr (kStore) {
-        if constexpr (kGroup != 4) read_block();
-        wait_lds<0>(t_rows[0], t_rows[1], t_rows[2], t_rows[3]);
-        wait_lds<0>(t_rows[4], t_rows[5], t_rows[6], t_rows[7]);
+        if (last_of_block) {
+          // the block's eight reads are older than the next stage's W3 quads just requested
+          // (its b2 quads went out ahead of the block): wait for "all but those" (in-order
+          // returns; tools/check_inflight_regs.py caught the first version counting both)
+          constexpr int kNewer = kGroup * kOut;
+          if (stage + 1 < kStages) {
+            wait_lds<kNewer>(t_rows[0], t_rows[1], t_rows[2], t_rows[3]);
+            wait_lds<kNewer>(t_rows[4], t_rows[5], t_rows[6], t_rows[7]);
+          } else {
+            wait_lds<0>(t_rows[0], t_rows[1], t_rows[2], t_rows[3]);
+            wait_lds<0>(t_rows[4], t_rows[5], t_rows[6], t_rows[7]);
+          }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)  // rows 8 i + (lane >> 3), columns 32 nt + 4 (lane & 7) .. + 3
-          __builtin_amdgcn_raw_buffer_store_b128(t_rows[i], h2rsrc, h2_voff + (8 * i * kHidden + 32 * nt) * 4, 0, RL8_H2_STORE_AUX);
-        if constexpr ((kSplitDiagSkip & 16384) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tuning builds: expose the store latency
+          for (int i = 0; i < 8; ++i) {  // rows 8 i + (lane >> 3), columns 32 nt + 4 (lane & 7) .. + 3
+            if constexpr ((kSplitDiagSkip & 32768) != 0) {  // tuning builds: transposes without the global stores
+              asm volatile("" ::"v"(t_rows[i]));
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(t_rows[i], h2rsrc, h2_voff + (8 * i * kHidden + 32 * nt) * 4, 0, RL8_H2_STORE_AUX);
+            }
+          }
+          if constexpr ((kSplitDiagSkip & 16384) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tuning builds: expose the store latency
+        }
       }
     }
     RL8_SPLIT_STAMP_E(trace_it, wave, 1);
@@ -472,7 +508,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       total[q] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     const int my_row = 64 * wr + lane_id();
-    if constexpr (SAVE) {
+    if constexpr (SAVE && !(kSplitDiagSkip & 65536)) {
       if (save_gate2 != nullptr) {
         // full words = own nibbles | the other half-wave's; lane (l32, hh) keeps row
         // 64 wr + 32 hh + l32's four words and stores them as one 16-byte piece
