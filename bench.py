@@ -137,7 +137,7 @@ def parse_args(argv: None | list[str] = None) -> argparse.Namespace:
                         " (rehearsals: CPU rendezvous tests, several ranks on one GPU)")
     p.add_argument("--single-device", action="store_true",
                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL wants one device per rank)")
-    p.add_argument("--cpu-baseline-seconds", type=float, default=30.0)
+    p.add_argument("--cpu-baseline-seconds", type=float, default=45.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args(argv)
 
@@ -243,8 +243,8 @@ def cpu_baseline(budget_s: float) -> dict:
 
     t_start = time.perf_counter()
     sweep: dict[int, float] = {}
-    # middle of the range first: if the budget runs out early the likeliest optimum was seen
-    order = sorted(candidates, key=lambda t: abs(t - 32))
+    # likeliest optimum first: if the budget runs out early it has been seen
+    order = [t for t in (32, 64, 16, 8, 128) if t in candidates] + [t for t in candidates if t not in (32, 64, 16, 8, 128)]
     torch.set_num_threads(order[0])
     iteration()  # warm-up: thread pools, allocator, first-touch
     for threads in order:
