@@ -32,6 +32,10 @@ constexpr int kLsAChunkBytes = 12 * 1024;         // one k-step of a 128-row til
 constexpr int kLsATileBytes = kSplitSteps * kLsAChunkBytes;
 constexpr int kLsInCols = 8;                      // [w_ih (d_in <= 7) ... | b_ih + b_hh] per gate row
 constexpr int kLsXBytes = 7 * kSplitRows * 4;     // x tile in LDS, [input][row]
+#ifndef RL8_LS_DIAG
+#define RL8_LS_DIAG 0   // tuning builds: 1 no h/c/gate stores (one checksum store per lane), 2 no transcendentals
+#endif
+constexpr int kLsDiag = RL8_LS_DIAG;
 
 // Gate non-linearities as in lstm_kernels.hip (hardware exp2 / rcp).
 __device__ __forceinline__ float ls_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -270,6 +274,15 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
     const int lane_rows = 64 * wr + 4 * hhe;
     const int v_cp = col4 + lane_rows * cp4, v_h = col4 + lane_rows * hp4, v_co = col4 + lane_rows * co4,
               v_g = col4 + lane_rows * gp4;
+    // c_{t-1} of all thirty-two (row, unit) pairs of this lane, requested up front: fetched
+    // per group of four rows, their HBM round trip sat in front of every group (eight per
+    // item, ~1.5 us each of a 50 us item)
+    [[maybe_unused]] float diag_sum = 0.0f;
+    float cprev[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cprev[mt][r] = buffer_load_f32(crsrc, v_cp, (32 * mt + 8 * (r >> 2) + (r & 3)) * cp4);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
                            : lds_read_b128<6 * kSplitRows * 4>(xs + row0 * 4);
         float cp[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cp[e] = buffer_load_f32(crsrc, v_cp, (32 * mt + 8 * rg + e) * cp4);
+        for (int e = 0; e < 4; ++e) cp[e] = cprev[mt][4 * rg + e];
 #pragma unroll
         for (int i = 0; i < DIN; ++i) wait_lds<0>(xq[i]);
 #pragma unroll
@@ -302,10 +315,19 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
             for (int i = 0; i < DIN; ++i) v = __builtin_fmaf(__uint_as_float(xq[i][e]), w_in[q][i], v);
             pre[q] = v;
           }
-          const float gi = ls_sigmoid(pre[0]), gf = ls_sigmoid(pre[1]), gg = ls_tanh(pre[2]), go = ls_sigmoid(pre[3]);
+          float gi, gf, gg, go;
+          if constexpr ((kLsDiag & 2) != 0) {
+            gi = pre[0], gf = pre[1], gg = pre[2], go = pre[3];
+          } else {
+            gi = ls_sigmoid(pre[0]), gf = ls_sigmoid(pre[1]), gg = ls_tanh(pre[2]), go = ls_sigmoid(pre[3]);
+          }
           const float c = __builtin_fmaf(gf, cp[e], gi * gg);
-          const float h = go * ls_tanh(c);
+          const float h = (kLsDiag & 2) ? go * c : go * ls_tanh(c);
           const int srow = 32 * mt + 8 * rg + e;  // scalar part of the row index
+          if constexpr ((kLsDiag & 1) != 0) {
+            diag_sum += h + c + gi + gf + gg + go;
+            continue;
+          }
           buffer_store_f32(h, hrsrc, v_h, srow * hp4);
           buffer_store_f32(c, cors, v_co, srow * co4);
           if constexpr (SAVE) {
@@ -317,6 +339,7 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
         }
       }
     }
+    if constexpr ((kLsDiag & 1) != 0) buffer_store_f32(diag_sum, hrsrc, v_h, 0);
     // (the next item's x is parked behind its own sixteen step barriers: no barrier here)
   }
 }

