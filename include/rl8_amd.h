@@ -408,10 +408,15 @@ int rl8_mlp_wgrad_strided_f32(const float *dz2, int64_t dz2_pitch, const float *
                               void *stream);
 /* The same product on the bf16 matrix pipe (fp32-accurate bf16-plane products, both
  * operands prefetched from memory): the LSTM's dW_hh[q] = dG_q^T h_{t-1}
- * (autograd of src/rl8/models/_recurrent.py:312-333). */
+ * (autograd of src/rl8/models/_recurrent.py:312-333).  With x / colsums it also leaves, per
+ * workgroup, the column sums  sum_rows dZ[row][col] * x[row][i]  and  sum_rows dZ[row][col]:
+ * the same gate's dW_ih and bias gradients, from the dZ values its producers hold anyway
+ * (d_in in {1, 2, 3, 5}; the caller adds the *colsum_rows_out rows in order). */
 int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const float *h, int64_t h_pitch,
                                     int64_t m, float *workspace, float *dw_out, int accumulate,
-                                    void *stream);
+                                    const float *x /* [m][d_in] dense, or NULL */, int d_in,
+                                    float *colsums /* [<= 256 rows][256 * (d_in + 1)], or NULL */,
+                                    int *colsum_rows_out, void *stream);
 
 /* ---------------------------------------------------------------------- *
  * a-9, second generation: ONE LSTM timestep with the recurrent product as an
@@ -476,7 +481,9 @@ int rl8_lstm_forward_f32(const float *x, int64_t b, int l, int d_in, const float
  * rl8_mlp_pack_w2_f32(w_hh[256q : 256q + 256], transposed = 1).  The recurrent
  * weight gradient is dW_hh[256q : 256q + 256] = rl8_mlp_wgrad_strided_f32(dgates +
  * 256q, 1024, h_prev, 256, B*L, ...) with h_prev[b][t] = h_{t-1} (h0 at t = 0).
- * No gradient is produced for x, h0, c0 or the final states. */
+ * No gradient is produced for x, h0, c0 or the final states.  * partials == NULL: the data-gradient kernel only (dG out); the input-weight and bias
+ * gradients then come from rl8_mlp_wgrad_split_strided_f32's column sums.
+ */
 int64_t rl8_lstm_backward_partial_floats(int d_in);
 int rl8_lstm_backward_max_rows(void);
 int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, const float *c0,

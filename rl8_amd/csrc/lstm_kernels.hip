@@ -440,7 +440,9 @@ RL8_API int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, co
                                   const float *gates, const float *cs, const float *dhs,
                                   const float *whht_packed, float *dgates, float *partials,
                                   int *partial_rows_out, void *stream) {
-  if (!x || !c0 || !gates || !cs || !dhs || !whht_packed || !dgates || !partials || !partial_rows_out)
+  // partials == NULL: the data-gradient half only -- the caller forms dW_ih / db elsewhere
+  // (rl8_mlp_wgrad_split_strided_f32 leaves them as column sums of the dG it reads anyway)
+  if (!x || !c0 || !gates || !cs || !dhs || !whht_packed || !dgates || (partials && !partial_rows_out))
     return RL8_ENULL;
   if (b <= 0 || l <= 0) return RL8_ESIZE;
   if (!rl8_lstm_supports(d_in)) return RL8_ESIZE;
@@ -452,7 +454,7 @@ RL8_API int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, co
   lstm_backward_kernel<<<grid, kBlock, 2 * sizeof(float) * kLstmRows * kLdsStride, s>>>(
       b, l, c0, gates, cs, dhs, whht_packed, dgates);
   int st = launch_status();
-  if (st != RL8_OK) return st;
+  if (st != RL8_OK || !partials) return st;
   const int64_t m = b * l;
   const int rows = (int)(m < 4 * kCUs ? m : 4 * kCUs);
   *partial_rows_out = rows;

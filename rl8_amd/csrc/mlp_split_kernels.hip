@@ -1130,6 +1130,12 @@ struct WgradFusedArgs {
 struct WgradOperands {
   const float *h;
   int dz_pitch, h_pitch;  // floats
+  // Optional column sums over the rows of this launch (the LSTM's input-weight and bias
+  // gradients, from the dZ values the producers hold anyway): one partial row per
+  // workgroup, [256 x DIN (sum of dZ[row][col] * x[row][i]) | 256 (sum of dZ[row][col])],
+  // x dense [m][DIN] in the kernel's `x` argument.  NULL: none.
+  float *colsums;
+  int colsum_accumulate;  // a later segment: add to the rows the first one wrote
 };
 
 template <int DIN, int FUSED = 0, bool LOADH = false>
@@ -1137,7 +1143,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     const float *__restrict__ dz2, const float *__restrict__ x, const float *__restrict__ w1,
     const float *__restrict__ b1, int64_t m, int d_in_rt, float *__restrict__ slabs, WgradFusedArgs fused,
     WgradOperands ops) {
-  static_assert(!LOADH || (DIN == 1 && FUSED == 0), "the two-operand mode is instantiated once");
+  static_assert(!LOADH || (DIN > 0 && FUSED == 0), "the two-operand mode: compiled input widths, no head fusion");
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = FUSED > 0 ? FUSED : 1;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
@@ -1207,7 +1213,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   // in front of the PREVIOUS step's barrier, so that inside a step nothing but
   // ds_reads is in flight on lgkmcnt and the first MFMAs can go as soon as THEIR
   // fragments are in (wait_lds<N>), not after all twelve.
-  constexpr bool kScalars = DIN > 0 && !LOADH;
+  constexpr bool kScalars = DIN > 0;  // (two-operand mode: the observations feed the column sums only)
   constexpr int kXq = kScalars ? kIn : 1, kDq = (kScalars && FUSED > 0) ? kOut : 1;
   [[maybe_unused]] f32x8 xq[kXq], dq[kDq];
   auto row0_of = [&](int64_t n) { return (blockIdx.x + n * stride) * kWsChunk + 8 * kh; };
@@ -1219,8 +1225,9 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     if constexpr (kScalars) {
       const int64_t row0 = row0_of(n);
       const int64_t left = m - row0;
-      const int rows = left <= 0 ? 0 : left < 8 ? (int)left : 8;
-      const u32x4 rx = scalar_rsrc(x + row0 * kIn, rows * kIn * 4);
+      // (two-operand mode without column sums passes no observations: descriptors of size 0)
+      const int rows = (left <= 0 || x == nullptr) ? 0 : left < 8 ? (int)left : 8;
+      const u32x4 rx = scalar_rsrc(x != nullptr ? x + row0 * kIn : reinterpret_cast<const float *>(slabs), rows * kIn * 4);
       xq[0] = scalar_buffer_load_x8<0>(rx);
       if constexpr (kIn > 1) xq[1] = scalar_buffer_load_x8<32>(rx);
       if constexpr (kIn > 2) xq[2] = scalar_buffer_load_x8<64>(rx);
@@ -1302,6 +1309,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   f32x16 acc[2][4];
   float dzq[2][8];
   [[maybe_unused]] float hq[1][8];
+  [[maybe_unused]] float cs_b = 0.0f, cs_w[kIn];  // LOADH column sums of this thread's column and sample half
+#pragma unroll
+  for (int c = 0; c < kIn; ++c) cs_w[c] = 0.0f;
+  const bool want_colsums = LOADH && ops.colsums != nullptr;
 
   // Chunk n (stage n & 1) is consumed while chunk n+1 is produced from dzq[(n+1) & 1]
   // and the dZ2 of chunk n+2 is requested into dzq[n & 1].
@@ -1353,6 +1364,14 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       // after it.  (Two sets each, planes of both operands held to the usual place
       // behind the second product group: 576 B of scratch -- whole accumulator tuples.)
       const unsigned addr = p_write + (P ^ 1) * kWsStageBytes;
+      if (want_colsums) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          cs_b += dzq[0][e];
+#pragma unroll
+          for (int c = 0; c < kIn; ++c) cs_w[c] = __builtin_fmaf(dzq[0][e], xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], cs_w[c]);
+        }
+      }
       split8(dzq[0], pa);
       lds_write_b128<0>(addr, pa[0]);
       lds_write_b128<kWsPlane>(addr, pa[1]);
@@ -1410,6 +1429,16 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     lds_barrier();
     scalars_landed();
     u32x4 pa[3], pb[3];
+    if constexpr (LOADH) {
+      if (want_colsums) {  // chunk 0 (its observations were requested above)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          cs_b += dzq[0][e];
+#pragma unroll
+          for (int c = 0; c < kIn; ++c) cs_w[c] = __builtin_fmaf(dzq[0][e], xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], cs_w[c]);
+        }
+      }
+    }
     produce(dzq[0], hq[0], 0, pa, pb);
     if constexpr (LOADH) {
       load_dz(dzq[0], 1);
@@ -1455,6 +1484,29 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
         slab[j * kHidden + i] = acc[ja][t][r];
       }
 
+  if constexpr (LOADH) {
+    if (want_colsums) {  // fold the two sample halves of a column through LDS, fixed order
+      float *red = reinterpret_cast<float *>(smem);  // [256][1 + kIn]
+      __syncthreads();
+      if (kh == 1) {
+        red[col * (1 + kIn)] = cs_b;
+#pragma unroll
+        for (int c = 0; c < kIn; ++c) red[col * (1 + kIn) + 1 + c] = cs_w[c];
+      }
+      __syncthreads();
+      if (kh == 0) {
+        float *row = ops.colsums + (int64_t)blockIdx.x * (kHidden * (kIn + 1));
+        const bool more = ops.colsum_accumulate != 0;
+        const float b = cs_b + red[col * (1 + kIn)];
+        row[kHidden * kIn + col] = more ? row[kHidden * kIn + col] + b : b;
+#pragma unroll
+        for (int c = 0; c < kIn; ++c) {
+          const float w = cs_w[c] + red[col * (1 + kIn) + 1 + c];
+          row[col * kIn + c] = more ? row[col * kIn + c] + w : w;
+        }
+      }
+    }
+  }
   if constexpr (FUSED > 0) {
     // Head gradients: fold the two sample halves (kh) of a column through LDS in a
     // fixed order and write this workgroup's partial row; zero the other kernel's
@@ -1655,35 +1707,62 @@ RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const floa
   return launch_status();
 }
 
+template <int DIN>
+static int launch_wgrad_loadh(int grid, hipStream_t s, const float *dz, const float *x, int64_t rows, float *workspace,
+                              const WgradOperands &ops) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, 0, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  mlp_wgrad_split_kernel<DIN, 0, true><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(dz, x, nullptr, nullptr, rows, DIN,
+                                                                                 workspace, WgradFusedArgs{}, ops);
+  return launch_status();
+}
+
 /* dW (+)= dZ^T h with BOTH operands strided in memory (dZ rows at dz_pitch, h rows at
- * h_pitch floats, 256 columns each): the LSTM's recurrent weight gradient per gate. */
+ * h_pitch floats, 256 columns each): the LSTM's recurrent weight gradient per gate.
+ * x / d_in / colsums (all optional together): also the column sums
+ *   colsums[wg][col * d_in + i] = sum_rows dZ[row][col] * x[row][i],  colsums[wg][256 * d_in + col] = sum_rows dZ[row][col]
+ * per workgroup (rows of 256 * (d_in + 1) floats, *colsum_rows_out of them; the caller adds them
+ * up in row order) -- the LSTM's dW_ih and bias gradients of that gate; x dense [m][d_in],
+ * d_in in {1, 2, 3, 5}. */
 RL8_API int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const float *h, int64_t h_pitch,
                                             int64_t m, float *workspace, float *dw_out, int accumulate,
+                                            const float *x, int d_in, float *colsums, int *colsum_rows_out,
                                             void *stream) {
   if (!dz || !h || !workspace || !dw_out) return RL8_ENULL;
   if (m <= 0 || dz_pitch < kHidden || h_pitch < kHidden) return RL8_ESIZE;
   if ((int64_t)kWsChunk * (dz_pitch > h_pitch ? dz_pitch : h_pitch) * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
   if (!aligned16(workspace) || !aligned16(dw_out)) return RL8_EALIGN;
-  hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<1, 0, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
+  if (colsums) {
+    if (!x || !colsum_rows_out) return RL8_ENULL;
+    if (!(d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5)) return RL8_ESIZE;
   }
+  hipStream_t s = (hipStream_t)stream;
+  int first_grid = 0;
   for (int64_t at = 0; at < m; at += kWgradSegmentRows) {  // segments summed in order, as above
     const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
     const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
-    const int grid = (int)(chunks < kCUs ? chunks : kCUs);
-    const WgradOperands ops{h + at * h_pitch, (int)dz_pitch, (int)h_pitch};
-    mlp_wgrad_split_kernel<1, 0, true><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(
-        dz + at * dz_pitch, nullptr, nullptr, nullptr, rows, 1, workspace, WgradFusedArgs{}, ops);
-    const int status = launch_status();
+    int grid = (int)(chunks < kCUs ? chunks : kCUs);
+    if (at == 0) first_grid = grid;
+    if (grid > first_grid) grid = first_grid;  // (later segments add to the first one's rows)
+    const WgradOperands ops{h + at * h_pitch, (int)dz_pitch, (int)h_pitch, colsums, at > 0};
+    const float *xs = colsums ? x + at * d_in : nullptr;
+    int status;
+    switch (colsums ? d_in : 1) {
+      case 1: status = launch_wgrad_loadh<1>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+      case 2: status = launch_wgrad_loadh<2>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+      case 3: status = launch_wgrad_loadh<3>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+      default: status = launch_wgrad_loadh<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+    }
     if (status != 0) return status;
     mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw_out,
                                                                                  accumulate || at > 0);
   }
+  if (colsum_rows_out) *colsum_rows_out = first_grid;
   return launch_status();
 }
 

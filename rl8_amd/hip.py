@@ -138,7 +138,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_linear_heads_forward_f32": [_vp, _i64, _vp, _vp, _i32, _vp, _vp],
     "rl8_linear_heads_backward_f32": [_vp, _vp, _i64, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_wgrad_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp],
-    "rl8_mlp_wgrad_split_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp],
+    "rl8_mlp_wgrad_split_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
     "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_split_packed_bytes": [],
@@ -1168,36 +1168,56 @@ def lstm_backward(
             raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
     lib = load()
     dev = x.device
-    width = int(lib.rl8_lstm_backward_partial_floats(d_in))
-    partials = torch.empty(int(lib.rl8_lstm_backward_max_rows()), width, dtype=torch.float32, device=dev)
-    dgates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    H = LSTM_HIDDEN
+    split = os.environ.get("RL8_AMD_LSTM_GEMM", "split") == "split"
+    # With the bf16-plane weight-gradient kernel and a compiled input width, dW_ih and the
+    # bias gradient come out of that kernel as column sums of the dG it reads anyway; else
+    # the backward call makes one more pass over dG for them.
+    fused_colsums = split and lstm_split_supports(d_in)
+    dgates = torch.empty(b, l, 4, H, dtype=torch.float32, device=dev)
     rows = C.c_int(0)
+    partials = None
+    if not fused_colsums:
+        width = int(lib.rl8_lstm_backward_partial_floats(d_in))
+        partials = torch.empty(int(lib.rl8_lstm_backward_max_rows()), width, dtype=torch.float32, device=dev)
     with _timed("lstm_backward", b * l):
         _check(lib.rl8_lstm_backward_f32(_ptr(x), b, l, d_in, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dhs),
                                          _ptr(whht_packed), _ptr(dgates), _ptr(partials), C.byref(rows), _stream()),
                "rl8_lstm_backward_f32")
-    small = partials[: rows.value].sum(0)
     m = b * l
     key = (dev.index or 0, _stream() or 0)
     ws = _wgrad_ws.get(key)
     if ws is None:
         ws = _wgrad_ws[key] = torch.empty(int(lib.rl8_mlp_wgrad_workspace_bytes()) // 4, dtype=torch.float32, device=dev)
-    dw_hh = torch.empty(4 * LSTM_HIDDEN, LSTM_HIDDEN, dtype=torch.float32, device=dev)
-    # per gate dW_hh[q] = dG_q^T h_{t-1}: the bf16-plane weight-gradient kernel in its
-    # two-operands-from-memory mode (RL8_AMD_LSTM_GEMM=f32: the fp32-MFMA kernel), one
-    # launch per gate and timestep over the B rows of that step -- h_{t-1} is h0 for
-    # t = 0 and hs[:, t-1] (row pitch L*256) after, so no shifted copy of hs is made
-    split = os.environ.get("RL8_AMD_LSTM_GEMM", "split") == "split"
+    dw_hh = torch.empty(4 * H, H, dtype=torch.float32, device=dev)
+    # per gate and timestep dW_hh[q] += dG_q^T h_{t-1} over the B rows of that step: h_{t-1} is
+    # h0 for t = 0 and hs[:, t-1] (row pitch L*256) after, so no shifted copy of hs is made
+    dgp, hsp, h0p, wsp, dwp, stream = _ptr(dgates), _ptr(hs), _ptr(h0), _ptr(ws), _ptr(dw_hh), _stream()
+    if fused_colsums:
+        xt = [x[:, t].contiguous() for t in range(l)]            # dense [B][d] per step (the kernel's scalar loads)
+        cols = torch.empty(4, l, 256, H * (d_in + 1), dtype=torch.float32, device=dev)   # [gate][step][workgroup][...]
+        crow = C.c_int(0)
+        with _timed("lstm_wgrad", m):
+            for q in range(4):
+                for t in range(l):
+                    h_prev, h_pitch = (h0p, H) if t == 0 else (hsp + (t - 1) * H * 4, l * H)
+                    _check(lib.rl8_mlp_wgrad_split_strided_f32(
+                        dgp + (t * 4 * H + q * H) * 4, l * 4 * H, h_prev, h_pitch, b, wsp, dwp + 4 * H * H * q, int(t > 0),
+                        _ptr(xt[t]), d_in, _ptr(cols[q, t]), C.byref(crow), stream), "rl8_mlp_wgrad_split_strided_f32")
+        sums = cols[:, :, : crow.value].sum(dim=(1, 2))          # [4][256*(d+1)], steps then workgroups in order
+        dw_ih = sums[:, : H * d_in].reshape(4 * H, d_in)
+        db = sums[:, H * d_in :].reshape(4 * H)
+        return {"w_ih": dw_ih, "w_hh": dw_hh, "b": db}
+    small = partials[: rows.value].sum(0)
     fn, name = ((lib.rl8_mlp_wgrad_split_strided_f32, "rl8_mlp_wgrad_split_strided_f32") if split
                 else (lib.rl8_mlp_wgrad_strided_f32, "rl8_mlp_wgrad_strided_f32"))
-    H = LSTM_HIDDEN
-    dgp, hsp, h0p, wsp, dwp, stream = _ptr(dgates), _ptr(hs), _ptr(h0), _ptr(ws), _ptr(dw_hh), _stream()
+    extra = (None, 0, None, None) if split else ()
     with _timed("lstm_wgrad", m):
         for q in range(4):
             for t in range(l):
                 h_prev, h_pitch = (h0p, H) if t == 0 else (hsp + (t - 1) * H * 4, l * H)
                 _check(fn(dgp + (t * 4 * H + q * H) * 4, l * 4 * H, h_prev, h_pitch, b, wsp, dwp + 4 * H * H * q,
-                          int(t > 0), stream), name)
+                          int(t > 0), *extra, stream), name)
     return {"w_ih": small[: 4 * LSTM_HIDDEN * d_in].view(4 * LSTM_HIDDEN, d_in), "w_hh": dw_hh,
             "b": small[4 * LSTM_HIDDEN * d_in :]}
 
