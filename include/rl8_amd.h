@@ -433,7 +433,9 @@ int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const flo
  * rl8_lstm_step_split_f32: x row r at x + r * x_pitch (d_in floats); h_planes of h_{t-1};
  *   c_prev row r at c_prev + r * c_prev_pitch; writes h_t, c_t rows at the given pitches
  *   (floats) and, when `gates` is not NULL, the post-activation gates i, f, g, o as
- *   [4][256] per row at gates + r * gates_pitch (what rl8_lstm_backward_f32 reads).
+ *   [4][256] per row at gates + r * gates_pitch (what rl8_lstm_backward_f32 reads); when
+ *   `planes_out` is not NULL, h_t also as bf16 planes (rl8_lstm_split_state's layout) for the
+ *   next timestep's call, so that only the first step of a sequence needs rl8_lstm_split_state.
  *   d_in in {1, 2, 3, 5} (rl8_lstm_split_supports); other widths keep rl8_lstm_forward_f32.
  * ---------------------------------------------------------------------- */
 int rl8_lstm_split_supports(int d_in);
@@ -446,7 +448,9 @@ int rl8_lstm_split_state(const float *h, int64_t pitch, int64_t b, void *planes,
 int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, const void *h_planes,
                             const float *c_prev, int64_t c_prev_pitch, const void *w_planes,
                             const float *wb, int64_t b, float *h_out, int64_t h_out_pitch, float *c_out,
-                            int64_t c_out_pitch, float *gates, int64_t gates_pitch, void *stream);
+                            int64_t c_out_pitch, float *gates, int64_t gates_pitch,
+                            void *planes_out /* h_t as planes for the next step (another buffer than h_planes), or NULL */,
+                            void *stream);
 
 /* ---------------------------------------------------------------------- *
  * a-9  Default recurrent models' LSTM, fused

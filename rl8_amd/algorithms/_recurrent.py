@@ -83,7 +83,7 @@ class _LeanRollout:
         if cache.get("key") != key:
             cache.update(key=key, hs=torch.empty(n, hip.LSTM_HIDDEN, device=dev),
                          logits=torch.empty(n, self.k, device=dev), value=torch.empty(n, 1, device=dev),
-                         planes=hip.lstm_state_planes(n, dev))
+                         planes=hip.lstm_state_planes(n, dev, copies=2))
         self.hs, self.logits, self.value, self.planes = cache["hs"], cache["logits"], cache["value"], cache["planes"]
         rdr = tm.get(DataKeys.REVERSED_DISCOUNTED_RETURNS)
 
@@ -100,6 +100,8 @@ class _LeanRollout:
         self.deterministic = int(deterministic)
         self.ptrs = [t.data_ptr() for t in (self.packed, self.hs, self.logits, self.value, *self.params)]
         self.split_ptrs = (self.planes.data_ptr(), self.wb.data_ptr() if self.wb is not None else None)
+        self.planes_half = self.planes.numel() // 2
+        self.planes_of = -1   # timestep whose hidden state the planes buffer (t & 1) holds (-1: none)
 
     @staticmethod
     def available(algo: "RecurrentAlgorithm") -> bool:
@@ -127,11 +129,16 @@ class _LeanRollout:
         if self.split:
             planes, wb = self.split_ptrs
             H = hip.LSTM_HIDDEN
-            hip._check(lib.rl8_lstm_split_state(at(self.h, t), H, n, planes, stream), "rl8_lstm_split_state")
+            p_in, p_out = planes + (t & 1) * self.planes_half, planes + ((t + 1) & 1) * self.planes_half
+            if self.planes_of != t:
+                # the first timestep, or one whose states were just re-initialised: planes of h_t
+                # from the buffer; otherwise the previous step's kernel has left them
+                hip._check(lib.rl8_lstm_split_state(at(self.h, t), H, n, p_in, stream), "rl8_lstm_split_state")
             with hip._timed("lstm_step", n) if timed else _NO_TIMER:
-                hip._check(lib.rl8_lstm_step_split_f32(at(self.obs, t), self.d_in, self.d_in, planes, at(self.c, t), H,
+                hip._check(lib.rl8_lstm_step_split_f32(at(self.obs, t), self.d_in, self.d_in, p_in, at(self.c, t), H,
                                                        packed, wb, n, at(self.h, t + 1), H, at(self.c, t + 1), H, None,
-                                                       0, stream), "rl8_lstm_step_split_f32")
+                                                       0, p_out, stream), "rl8_lstm_step_split_f32")
+            self.planes_of = t + 1
             hs = at(self.h, t + 1)  # the heads read h_t where the buffer keeps it
         else:
             with hip._timed("lstm_forward", n) if timed else _NO_TIMER:
@@ -279,6 +286,8 @@ class RecurrentAlgorithm(Algorithm):
                     init = self.policy.init_states(N)  # :385-392
                     for k, v in stm.items():
                         v[t].copy_(init[k])
+                    if lean is not None:
+                        lean.planes_of = -1  # h_t was replaced: its planes must be re-made
                 noise_t = self.injected_noise[t] if self.injected_noise is not None else None
                 step_id = self.noise.next_step()
                 if lean is not None:

@@ -115,6 +115,7 @@ struct LstmStepArgs {
   const float *c_prev;  // [B][c_prev_pitch]
   float *h_out, *c_out; // [B][*_pitch]
   float *gates;         // [B][gates_pitch] -> [4][256] post-activation i, f, g, o; or null
+  void *planes_out;     // h_t as bf16 planes for the NEXT step (rl8_lstm_split_state's layout); or null
   int64_t x_pitch, c_prev_pitch, h_out_pitch, c_out_pitch, gates_pitch;
 };
 
@@ -278,6 +279,15 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
     // per group of four rows, their HBM round trip sat in front of every group (eight per
     // item, ~1.5 us each of a 50 us item)
     [[maybe_unused]] float diag_sum = 0.0f;
+    // h_t of this wave's [64 rows][32 units] block also goes through LDS (chunk stage 1 is
+    // dead from the barrier of step 15 to the barrier that ends this epilogue; row pitch 144 B)
+    // when the caller wants it as bf16 planes for the next timestep: written as the
+    // accumulators hold it (lane = unit), read back lane = row, eight units = one fragment.
+    constexpr int kHPitch = 32 * 4 + 16;
+    static_assert(4 * 64 * kHPitch <= kSplitStageBytes, "h scratch fits in stage 1");
+    const bool want_planes = args.planes_out != nullptr;
+    const unsigned h_scr = lds0 + kSplitStageBytes + wave * (64 * kHPitch);
+    const unsigned h_scr_w = h_scr + 4 * hhe * kHPitch + l32e * 4;
     float cprev[2][16];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -328,6 +338,7 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
             diag_sum += h + c + gi + gf + gg + go;
             continue;
           }
+          if (want_planes) lds_write_b32(h_scr_w + srow * kHPitch, h);
           buffer_store_f32(h, hrsrc, v_h, srow * hp4);
           buffer_store_f32(c, cors, v_co, srow * co4);
           if constexpr (SAVE) {
@@ -340,7 +351,34 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
       }
     }
     if constexpr ((kLsDiag & 1) != 0) buffer_store_f32(diag_sum, hrsrc, v_h, 0);
-    // (the next item's x is parked behind its own sixteen step barriers: no barrier here)
+    if (want_planes) {
+      // lane = row 64 wr + lane; fragment column j = units 8 j .. 8 j + 7 of this wave's 32:
+      // k-step s = (8 ub + 4 wc + j) / 2, k-half (j & 1) [4 wc is even], row half wr
+      unsigned char *dst = static_cast<unsigned char *>(args.planes_out) + tile * (int64_t)kLsATileBytes;
+      const unsigned rd = h_scr + lane_now * kHPitch;
+      u32x4 lo[4], hi[4];
+      lo[0] = lds_read_b128<0>(rd), hi[0] = lds_read_b128<16>(rd);
+      lo[1] = lds_read_b128<32>(rd), hi[1] = lds_read_b128<48>(rd);
+      lo[2] = lds_read_b128<64>(rd), hi[2] = lds_read_b128<80>(rd);
+      lo[3] = lds_read_b128<96>(rd), hi[3] = lds_read_b128<112>(rd);
+      wait_lds<0>(lo[0], lo[1], lo[2], lo[3]);
+      wait_lds<0>(hi[0], hi[1], hi[2], hi[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v[8] = {__uint_as_float(lo[j][0]), __uint_as_float(lo[j][1]), __uint_as_float(lo[j][2]), __uint_as_float(lo[j][3]),
+                            __uint_as_float(hi[j][0]), __uint_as_float(hi[j][1]), __uint_as_float(hi[j][2]), __uint_as_float(hi[j][3])};
+        u32x4 planes[3];
+        ls_planes(v, planes);
+        const int u8 = 8 * ub + 4 * wc + j;
+        const int step = u8 >> 1, khj = u8 & 1;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<u32x4 *>(dst + (step * 12 + (p * 2 + khj) * 2 + wr) * 1024 + lane_now * 16) = planes[p];
+      }
+      // every wave is done with the scratch before any wave's next step 0 writes stage 1
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // (the next item's x is parked behind its own sixteen step barriers: no barrier needed for it)
   }
 }
 
@@ -397,7 +435,8 @@ static int launch_lstm_step(int grid, hipStream_t s, const void *a_planes, const
 RL8_API int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, const void *h_planes,
                                     const float *c_prev, int64_t c_prev_pitch, const void *w_planes,
                                     const float *wb, int64_t b, float *h_out, int64_t h_out_pitch, float *c_out,
-                                    int64_t c_out_pitch, float *gates, int64_t gates_pitch, void *stream) {
+                                    int64_t c_out_pitch, float *gates, int64_t gates_pitch, void *planes_out,
+                                    void *stream) {
   if (!x || !h_planes || !c_prev || !w_planes || !wb || !h_out || !c_out) return RL8_ENULL;
   if (b <= 0 || !rl8_lstm_split_supports(d_in)) return RL8_ESIZE;
   if (x_pitch < d_in || c_prev_pitch < kHidden || h_out_pitch < kHidden || c_out_pitch < kHidden ||
@@ -410,7 +449,9 @@ RL8_API int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, c
   const int64_t tiles = (b + kSplitRows - 1) / kSplitRows;
   const int64_t items = tiles * kLsBlocks;
   const int grid = (int)(items < 2 * kCUs ? items : 2 * kCUs);  // both multiples of 4
-  const LstmStepArgs args = {x, c_prev, h_out, c_out, gates, x_pitch, c_prev_pitch, h_out_pitch, c_out_pitch, gates_pitch};
+  if (planes_out && (!aligned16(planes_out) || planes_out == h_planes)) return RL8_EALIGN;
+  const LstmStepArgs args = {x, c_prev, h_out, c_out, gates, planes_out, x_pitch, c_prev_pitch, h_out_pitch, c_out_pitch,
+                             gates_pitch};
   hipStream_t s = (hipStream_t)stream;
   switch (d_in) {
     case 1: return launch_lstm_step<1>(grid, s, h_planes, w_planes, wb, b, args);

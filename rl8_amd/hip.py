@@ -130,7 +130,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_split_state_bytes": [_i64],
     "rl8_lstm_pack_split": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "rl8_lstm_split_state": [_vp, _i64, _i64, _vp, _vp],
-    "rl8_lstm_step_split_f32": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
+    "rl8_lstm_step_split_f32": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
     "rl8_lstm_backward_partial_floats": [_i32],
     "rl8_lstm_backward_max_rows": [],
     "rl8_lstm_backward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp],
@@ -1105,9 +1105,10 @@ def lstm_pack_split(w_ih: torch.Tensor, w_hh: torch.Tensor, b_ih: torch.Tensor, 
     return packed, wb
 
 
-def lstm_state_planes(rows: int, device: torch.device | str) -> torch.Tensor:
-    """Buffer for the bf16 planes of ``rows`` rows of hidden state."""
-    return torch.empty(int(load().rl8_lstm_split_state_bytes(int(rows))), dtype=torch.uint8, device=device)
+def lstm_state_planes(rows: int, device: torch.device | str, copies: int = 1) -> torch.Tensor:
+    """``copies`` buffers (whole 128-row tiles each) for the bf16 planes of ``rows`` rows of
+    hidden state; a multi-step forward ping-pongs between two."""
+    return torch.empty(copies * int(load().rl8_lstm_split_state_bytes(int(rows))), dtype=torch.uint8, device=device)
 
 
 def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, packed: torch.Tensor, wb: torch.Tensor,
@@ -1126,18 +1127,22 @@ def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, pack
     cs = torch.empty(b, l, LSTM_HIDDEN, dtype=torch.float32, device=dev)
     gates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev) if save else None
     if planes is None:
-        planes = lstm_state_planes(b, dev)
+        planes = lstm_state_planes(b, dev, copies=2 if l > 1 else 1)
+    # two plane buffers: a step reads h_{t-1}'s planes from one and leaves h_t's in the other
+    half = planes.numel() // 2 if l > 1 else 0
+    if l > 1 and half < int(lib.rl8_lstm_split_state_bytes(b)):
+        raise ValueError("lstm_forward_split: `planes` must hold two state-plane buffers for L > 1")
     H, stream = LSTM_HIDDEN, _stream()
-    xp, hsp, csp, gp = _ptr(x), _ptr(hs), _ptr(cs), _ptr(gates)
+    xp, hsp, csp, gp, pp = _ptr(x), _ptr(hs), _ptr(cs), _ptr(gates), _ptr(planes)
+    _check(lib.rl8_lstm_split_state(_ptr(h0), H, b, pp, stream), "rl8_lstm_split_state")
     for t in range(l):
-        h_prev, h_pitch = (_ptr(h0), H) if t == 0 else (hsp + (t - 1) * H * 4, l * H)
         c_prev, c_pitch = (_ptr(c0), H) if t == 0 else (csp + (t - 1) * H * 4, l * H)
-        _check(lib.rl8_lstm_split_state(h_prev, h_pitch, b, _ptr(planes), stream), "rl8_lstm_split_state")
+        p_in, p_out = pp + (t & 1) * half, (pp + ((t + 1) & 1) * half) if t + 1 < l else None
         with _timed("lstm_step_save" if save else "lstm_step", b):
             _check(lib.rl8_lstm_step_split_f32(
-                xp + t * d_in * 4, l * d_in, d_in, _ptr(planes), c_prev, c_pitch, _ptr(packed), _ptr(wb), b,
+                xp + t * d_in * 4, l * d_in, d_in, p_in, c_prev, c_pitch, _ptr(packed), _ptr(wb), b,
                 hsp + t * H * 4, l * H, csp + t * H * 4, l * H, (gp + t * 4 * H * 4) if save else None, l * 4 * H,
-                stream), "rl8_lstm_step_split_f32")
+                p_out, stream), "rl8_lstm_step_split_f32")
     hn, cn = hs[:, l - 1], cs[:, l - 1]
     return hs, hn, cn, gates, (cs if save else None)
 

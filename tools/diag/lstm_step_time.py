@@ -7,7 +7,7 @@ g = torch.Generator(device=DEV).manual_seed(0)
 lstm = torch.nn.LSTM(d, 256, batch_first=True).to(DEV)
 x = torch.randn(b, l, d, device=DEV, generator=g); h0 = torch.randn(b, 256, device=DEV, generator=g) * .5; c0 = torch.randn(b, 256, device=DEV, generator=g)
 packed, wb = hip.lstm_pack_split(lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
-planes = hip.lstm_state_planes(b, DEV)
+planes = hip.lstm_state_planes(b, DEV, copies=2)
 for save in (False, True):
     for _ in range(2): hip.lstm_forward_split(x, h0, c0, packed, wb, save=save, planes=planes)
     torch.cuda.synchronize()
