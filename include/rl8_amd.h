@@ -343,6 +343,25 @@ int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const f
                                     const float *w3, const float *b3, int n_out, float *out,
                                     float *save_h1, float *save_h2, uint32_t *save_gate2, void *stream);
 
+/* The same forward with the 256x256 product as THREE fp16 MFMAs per 16 k: each
+ * activation row of h1 is scaled by a power of two chosen from a bound on its
+ * magnitude (max|b1| + sum_i |x_i| max|w1[:, i]|, placed at 2^14) and W2 by one
+ * power of two for the matrix, so both operands sit in the upper fp16 exponent
+ * range; each is then split into hi = fp16(v), lo = fp16(v - hi) (22 significand
+ * bits) and lo.hi + hi.lo + hi.hi is accumulated in fp32; the epilogue multiplies
+ * by the inverse powers of two (exact).  Same arguments, outputs and save options
+ * as rl8_mlp_tower_forward_split_f32; w2_f16 (rl8_mlp_f16_packed_bytes() bytes:
+ * two fp16 planes in fragment order + {scale, 1/scale}) comes from
+ * rl8_mlp_pack_w2_f16.  Replaces the same reference call sites
+ * (rl8/models/_feedforward.py:115-132 forward of the 256-256 towers). */
+int64_t rl8_mlp_f16_packed_bytes(void);
+int rl8_mlp_forward_f16_supports(int d_in, int n_out); /* as rl8_mlp_forward_split_supports */
+int rl8_mlp_pack_w2_f16(const float *w2 /*[256][256]*/, int transposed, void *w2_f16, void *stream);
+int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, const float *w1,
+                                  const float *b1, const void *w2_f16, const float *b2,
+                                  const float *w3, const float *b3, int n_out, float *out,
+                                  float *save_h1, float *save_h2, uint32_t *save_gate2, void *stream);
+
 /* Backward of one tower ("dgrad" half): given dOut [M][n_out] and the saved
  * activations h1 / h2, writes dZ2 [M][256] (input of rl8_mlp_wgrad_f32, which
  * forms dW2 = dZ2^T h1) and `*partial_rows_out` rows (<= rl8_mlp_backward_max_rows()) of

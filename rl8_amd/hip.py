@@ -147,6 +147,10 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
     "rl8_mlp_backward_max_rows": [],
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_mlp_f16_packed_bytes": [],
+    "rl8_mlp_forward_f16_supports": [_i32, _i32],
+    "rl8_mlp_pack_w2_f16": [_vp, _i32, _vp, _vp],
+    "rl8_mlp_tower_forward_f16_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "rl8_mlp_backward_split_supports": [_i32, _i32],
     "rl8_mlp_forward_split_supports": [_i32, _i32],
     "rl8_mlp_tower_backward_split_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp, _vp],
@@ -180,7 +184,8 @@ def load() -> C.CDLL:
                 C.c_int64
                 if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes",
                             "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats", "rl8_mlp_split_packed_bytes",
-                            "rl8_lstm_split_packed_bytes", "rl8_lstm_split_wb_floats", "rl8_lstm_split_state_bytes")
+                            "rl8_lstm_split_packed_bytes", "rl8_lstm_split_wb_floats", "rl8_lstm_split_state_bytes",
+                            "rl8_mlp_f16_packed_bytes")
                 else C.c_int
             )
         _lib = lib
@@ -862,6 +867,22 @@ def mlp_backward_split_supports(d_in: int, n_out: int) -> bool:
     return bool(load().rl8_mlp_backward_split_supports(int(d_in), int(n_out)))
 
 
+def mlp_forward_f16_supports(d_in: int, n_out: int) -> bool:
+    return bool(load().rl8_mlp_forward_f16_supports(int(d_in), int(n_out)))
+
+
+def mlp_pack_w2_f16(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
+    """[256, 256] nn.Linear weight -> two fp16 planes of 2^e * w (hi = fp16(v),
+    lo = fp16(v - hi)) in fragment order, followed by {2^e, 2^-e} (uint8)."""
+    w2 = _dense(w2.detach(), torch.float32, "w2")
+    if tuple(w2.shape) != (MLP_HIDDEN, MLP_HIDDEN):
+        raise ValueError("w2 must be [256, 256]")
+    lib = load()
+    packed = torch.empty(int(lib.rl8_mlp_f16_packed_bytes()), dtype=torch.uint8, device=w2.device)
+    _check(lib.rl8_mlp_pack_w2_f16(_ptr(w2), int(transposed), _ptr(packed), _stream()), "rl8_mlp_pack_w2_f16")
+    return packed
+
+
 def mlp_pack_w2_split(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
     """[256, 256] nn.Linear weight -> three bf16 planes (w = hi + mid + lo exactly)
     in the fragment order of the split-product kernels (393216 bytes, uint8)."""
@@ -891,19 +912,24 @@ def mlp_tower_forward_split(
         _dense(t.detach(), torch.float32, name)
         if tuple(t.shape) != shape:
             raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
-    if w2_split.dtype != torch.uint8 or w2_split.numel() != int(load().rl8_mlp_split_packed_bytes()):
-        raise ValueError("w2_split must come from mlp_pack_w2_split")
+    lib = load()
+    if w2_split.dtype == torch.uint8 and w2_split.numel() == int(lib.rl8_mlp_f16_packed_bytes()):
+        fn, fn_name = lib.rl8_mlp_tower_forward_f16_f32, "rl8_mlp_tower_forward_f16_f32"  # fp16 two-plane pack
+    elif w2_split.dtype == torch.uint8 and w2_split.numel() == int(lib.rl8_mlp_split_packed_bytes()):
+        fn, fn_name = lib.rl8_mlp_tower_forward_split_f32, "rl8_mlp_tower_forward_split_f32"
+    else:
+        raise ValueError("w2_split must come from mlp_pack_w2_split or mlp_pack_w2_f16")
     out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
     h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save and save_h1 else None
     h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
     gate = torch.empty(m, 8, dtype=torch.int32, device=x.device) if save and save_gate else None
     with _timed("mlp_tower_forward_save" if save else "mlp_tower_forward", m):
         _check(
-            load().rl8_mlp_tower_forward_split_f32(
+            fn(
                 _ptr(x), m, d_in, _ptr(w1.detach()), _ptr(b1.detach()), _ptr(w2_split), _ptr(b2.detach()),
                 _ptr(w3.detach()), _ptr(b3.detach()), n_out, _ptr(out), _ptr(h1), _ptr(h2), _ptr(gate), _stream(),
             ),
-            "rl8_mlp_tower_forward_split_f32",
+            fn_name,
         )
     return (out, h1, h2, gate) if save_gate else (out, h1, h2)
 

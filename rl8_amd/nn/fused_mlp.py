@@ -34,13 +34,15 @@ ENABLED = True
 #: How the 256x256 product of the forward kernel is formed: "split" = exact 3-way
 #: bf16 split of both fp32 operands, six plane products per 16 k on the bf16
 #: matrix pipe, fp32 accumulate (fp32 accuracy, ~1.8x the fp32-MFMA kernel);
-#: "f32" = v_mfma_f32_32x32x2_f32.  ``RL8_AMD_TOWER_GEMM`` overrides.
-FORWARD_GEMM = os.environ.get("RL8_AMD_TOWER_GEMM", "split")
+#: "f32" = v_mfma_f32_32x32x2_f32; "f16" = scaled two-plane fp16 split, three
+#: plane products per 16 k (forward only).  ``RL8_AMD_TOWER_GEMM`` /
+#: ``RL8_AMD_TOWER_FORWARD_GEMM`` override.
+FORWARD_GEMM = os.environ.get("RL8_AMD_TOWER_FORWARD_GEMM", os.environ.get("RL8_AMD_TOWER_GEMM", "split"))
 #: Same choice for the data-gradient product of the backward pass.
 BACKWARD_GEMM = os.environ.get("RL8_AMD_TOWER_GEMM", "split")
 
 
-def _packed(layer: nn.Linear, transposed: bool, split: bool = False) -> torch.Tensor:
+def _packed(layer: nn.Linear, transposed: bool, split: bool | str = False) -> torch.Tensor:
     """MFMA-fragment-ordered copy of ``layer.weight``, cached ON the layer and
     re-made when the optimizer has changed the weight (version counter) or the
     weight tensor has been replaced / moved."""
@@ -49,7 +51,7 @@ def _packed(layer: nn.Linear, transposed: bool, split: bool = False) -> torch.Te
     hit = cache.get((transposed, split))
     if hit is not None and hit[0] == w2._version and hit[1] == w2.data_ptr():
         return hit[2]
-    pack = hip.mlp_pack_w2_split if split else hip.mlp_pack_w2
+    pack = hip.mlp_pack_w2_f16 if split == "f16" else hip.mlp_pack_w2_split if split else hip.mlp_pack_w2
     packed = pack(w2, transposed=transposed)
     cache[(transposed, split)] = (w2._version, w2.data_ptr(), packed)
     return packed
@@ -63,10 +65,12 @@ class _FusedTower(torch.autograd.Function):
         # always off: the caller's grad mode comes in as an argument, so that
         # activations are kept only when a backward can follow.
         need_grad = grad_mode and any(ctx.needs_input_grad[1:7])
-        if FORWARD_GEMM == "split" and hip.mlp_forward_split_supports(x.shape[1], w3.shape[0]):
+        if FORWARD_GEMM in ("split", "f16") and hip.mlp_forward_split_supports(x.shape[1], w3.shape[0]):
             # h1 is stored only if a backward kernel will read it (the bf16-plane ones recompute it)
             keep_h1 = not (BACKWARD_GEMM == "split" and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0]))
-            out, h1, h2, gate = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, True), b2, w3, b3,
+            f16 = FORWARD_GEMM == "f16" and hip.mlp_forward_f16_supports(x.shape[1], w3.shape[0])
+            out, h1, h2, gate = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16" if f16 else True),
+                                                            b2, w3, b3,
                                                             save=need_grad, save_h1=keep_h1, save_gate=True)
         else:
             out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)

@@ -56,13 +56,16 @@ def test_split_planes_reconstruct_the_weights_exactly():
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (127, 1, 1), (128, 1, 2), (129, 2, 3), (1000, 5, 3), (4097, 1, 3),
                                           (5000, 3, 2), (70_001, 1, 2), (33_333, 5, 1), (20_000, 2, 2)])
-def test_forward_split_is_fp32_accurate(m, d_in, n_out):
-    assert hip.mlp_forward_split_supports(d_in, n_out)
+@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+def test_forward_split_is_fp32_accurate(m, d_in, n_out, scheme):
+    """Both generations of the plane-product forward against the SAME bars: six
+    bf16 plane products per 16 k ("bf16x3") and three scaled fp16 ones ("f16x2")."""
+    assert hip.mlp_forward_split_supports(d_in, n_out) and hip.mlp_forward_f16_supports(d_in, n_out)
     g = torch.Generator(device=DEV).manual_seed(m + d_in)
     x = torch.randn(m, d_in, device=DEV, generator=g) * 30
     p = _params(g, d_in, n_out)
     want, h1w, h2w = _tower(x.double(), {k: v.double() for k, v in p.items()})
-    packed = hip.mlp_pack_w2_split(p["w2"])
+    packed = (hip.mlp_pack_w2_f16 if scheme == "f16x2" else hip.mlp_pack_w2_split)(p["w2"])
     out, h1, h2 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"], save=True)
     assert _rel(out, want) < 4e-6 and _rel(h2, h2w) < 2e-6 and _rel(h1, h1w) < 1e-6
     # the same layer-1 fma chain as the fp32-MFMA kernel: h1 bit for bit
@@ -91,6 +94,64 @@ def test_forward_split_is_fp32_accurate(m, d_in, n_out):
     want_bits = (h2d > 0).view(m, 8, 32).to(torch.int64)
     want_words = (want_bits << torch.arange(32, device=DEV)).sum(-1)
     assert torch.equal(out, out5) and torch.equal(gate.to(torch.int64) & 0xFFFFFFFF, want_words)
+
+
+def test_f16_planes_reconstruct_the_scaled_weights_to_22_bits():
+    g = torch.Generator(device=DEV).manual_seed(5)
+    w = torch.randn(256, 256, device=DEV, generator=g) / 16
+    w[3, 7] = 0.0
+    for transposed in (False, True):
+        packed = hip.mlp_pack_w2_f16(w, transposed=transposed)
+        scale, inv = packed[-16:].view(torch.float32)[:2].tolist()
+        top = float(w.abs().max()) * scale
+        assert scale * inv == 1.0 and 2.0**13 <= top < 2.0**14   # a power of two placing max |w| below 2^14
+        planes = packed[:-16].view(torch.float16).view(16, 8, 2, 64, 8).double().sum(2)  # [step][col tile][lane][e]
+        lane = torch.arange(64, device=DEV)
+        col = (32 * torch.arange(8, device=DEV)[None, :, None, None] + (lane & 31)[None, None, :, None]).expand(16, 8, 64, 8)
+        k = (16 * torch.arange(16, device=DEV)[:, None, None, None] + 8 * (lane >> 5)[None, None, :, None]
+             + torch.arange(8, device=DEV)[None, None, None, :]).expand(16, 8, 64, 8)
+        want = (w[k, col] if transposed else w[col, k]).double() * scale
+        # hi = fp16(v), lo = fp16(v - hi): 22 significand bits, or the fp16 subnormal quantum
+        assert bool(((planes - want).abs() <= want.abs() * 2.0**-22 + 2.0**-25).all())
+
+
+@pytest.mark.parametrize("case", ["rows_of_mixed_magnitude", "outlier_weights", "zero_rows", "tiny_everything", "huge_inputs"])
+def test_forward_f16_scaling_holds_over_the_dynamic_range(case):
+    """The per-row / per-matrix powers of two are what keeps the fp16 planes in
+    range: rows 10^6 apart in one tile, a W2 with a few entries 1000x the rest,
+    all-zero rows and weights, and everything near the fp16 underflow / overflow."""
+    m, d_in, n_out = 3000, 3, 2
+    g = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.randn(m, d_in, device=DEV, generator=g)
+    p = _params(g, d_in, n_out)
+    if case == "rows_of_mixed_magnitude":
+        x *= 10.0 ** torch.randint(-3, 4, (m, 1), device=DEV, generator=g).float()
+    elif case == "outlier_weights":
+        p["w2"][torch.randint(0, 256, (20,), device=DEV, generator=g), torch.randint(0, 256, (20,), device=DEV, generator=g)] = 60.0
+    elif case == "zero_rows":
+        x[::3] = 0.0
+        p["b1"].zero_()
+        p["w2"][:, ::2] = 0.0
+    elif case == "tiny_everything":
+        x *= 1e-12
+        p["b1"] *= 1e-12
+        p["w2"] *= 1e-9
+    elif case == "huge_inputs":
+        x *= 1e12
+        p["w2"] *= 1e6
+    want, h1w, h2w = _tower(x.double(), {k: v.double() for k, v in p.items()})
+    out, _, h2 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                             save=True)
+    out6, _, h2_6 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_split(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                                save=True)
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(h2).all())
+    # per ROW against that row's own magnitude (a global relative error would hide the small rows)
+    row = h2w.abs().amax(1, keepdim=True) + p["b2"].abs().max().double()
+    err, err6 = ((h2.double() - h2w).abs() / row).max(), ((h2_6.double() - h2w).abs() / row).max()
+    assert float(err) <= 2e-6 and float(err) <= 3 * float(err6) + 1e-7, (float(err), float(err6))
+    orow = want.abs().amax(1, keepdim=True) + (h2w.abs() @ p["w3"].double().abs().T).amax(1, keepdim=True) + 1e-30
+    oerr, oerr6 = ((out.double() - want).abs() / orow).max(), ((out6.double() - want).abs() / orow).max()
+    assert float(oerr) <= 2e-6 and float(oerr) <= 3 * float(oerr6) + 1e-7, (float(oerr), float(oerr6))
 
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 5, 3), (4097, 3, 2), (40_000, 1, 2), (9000, 2, 1),

@@ -117,6 +117,7 @@ mlp_w2s = hip.mlp_pack_w2_split(mlp_w2)
 mlp_gate = hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2s, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False,
                                        save_gate=True)[3]
 mlp_w2ts = hip.mlp_pack_w2_split(mlp_w2, transposed=True)
+mlp_w2h = hip.mlp_pack_w2_f16(mlp_w2)  # scaled fp16 two-plane pack (3 plane products per 16 k)
 _lib = hip.load()
 _partials = torch.empty(int(_lib.rl8_mlp_backward_max_rows()), int(_lib.rl8_mlp_backward_partial_floats(1, 2)), device=dev)
 _dw2 = torch.empty(256, 256, device=dev)
@@ -139,6 +140,8 @@ KERNELS = {
     # bf16-plane kernels: "GB/s" column = fp32-equivalent TFLOP/s (algorithmic FLOP / 1000 as bytes)
     "mlp_tower_forward_split": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2s, mlp_b2, mlp_w3, mlp_b3), MLP_FLOP / 1000),
     "mlp_tower_forward_save_split": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2s, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False, save_gate=True), MLP_FLOP / 1000),
+    "mlp_tower_forward_f16": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h, mlp_b2, mlp_w3, mlp_b3), MLP_FLOP / 1000),
+    "mlp_tower_forward_save_f16": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False, save_gate=True), MLP_FLOP / 1000),
     "mlp_tower_backward_split": (split_dgrad, MLP_FLOP / 1000),
     "mlp_wgrad_fused_split": (split_wgrad_fused, 2 * N * 65536 / 1000),
     "mlp_wgrad_split": (lambda: hip.mlp_wgrad_split(mlp_dz2, mlp_x, mlp_w1, mlp_b1), 2 * N * 65536 / 1000),
