@@ -60,6 +60,8 @@ HBM_COPY_CEILING_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (= fp32 vector) peak, MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (spec), MI355X_MICROARCH.md; 1750 sustained on changing operands
 SPLIT_PRODUCTS = 6              # bf16 plane products per fp32 product in the bf16-plane kernels
+PLANE_PRODUCTS = {"bf16x3-split": 6, "f16x2-split": 3}  # 16-bit MFMA products per fp32 product, by scheme
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak = the bf16 one (same instruction shape and rate)
 
 # MFMA-bound kernels: algorithmic FLOP per unit (row) for the default towers,
 # 2 * (256*d_in + 256*256 + 256*n_out); the backward kernel does the data-gradient
@@ -100,6 +102,11 @@ PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in
     "mlp_tower_backward": ("mlp_tower_backward_kernel<1, 2>", 1 << 20),
     "mlp_wgrad": ("mlp_wgrad_kernel", 1 << 20),
 }
+PMC_KERNEL_F16 = {  # the fp16-plane kernels (forward, data gradient), same profiled shapes
+    "mlp_tower_forward": ("mlp_tower_forward_f16_kernel<1, 2, false>", 1 << 20),
+    "mlp_tower_forward_save": ("mlp_tower_forward_f16_kernel<1, 2, true>", 1 << 20),
+    "mlp_tower_backward": ("mlp_tower_backward_f16_kernel<1, 2>", 1 << 20),
+}
 PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
     "mlp_tower_forward": ("mlp_tower_forward_split_kernel<1, 2, false>", 1 << 20),
     "mlp_tower_forward_save": ("mlp_tower_forward_split_kernel<1, 2, true>", 1 << 20),
@@ -108,12 +115,13 @@ PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
 }
 
 
-def pmc_traffic(name: str, units_per_launch: float, split: bool = False):
+def pmc_traffic(name: str, units_per_launch: float, gemm: str = "f32"):
     try:
         summary = json.load(open(PMC_SUMMARY))
     except OSError:
         return None
-    needle, units = (PMC_KERNEL_SPLIT if split else PMC_KERNEL).get(name, (None, 1))
+    table = {"f16x2-split": PMC_KERNEL_F16, "bf16x3-split": PMC_KERNEL_SPLIT}.get(gemm, PMC_KERNEL)
+    needle, units = table.get(name, (None, 1))
     for kernel, rec in summary.items():
         if needle and needle in kernel:
             return rec["traffic_bytes_per_launch"] / units * units_per_launch
@@ -385,13 +393,16 @@ def run(args: argparse.Namespace) -> None:
         if not tower_heads:
             return "f32"
         widths = [(obs_dim, n) for n in tower_heads]
+        planes = ("split", "f16")
         if name in ("mlp_tower_forward", "mlp_tower_forward_save"):
-            ok = fused_mlp.FORWARD_GEMM == "split" and all(hip.mlp_forward_split_supports(d, n) for d, n in widths)
-        elif name == "mlp_wgrad":  # the bf16-plane weight-gradient kernel takes any width
-            ok = fused_mlp.BACKWARD_GEMM == "split"
+            ok = fused_mlp.FORWARD_GEMM in planes and all(hip.mlp_forward_split_supports(d, n) for d, n in widths)
+            f16 = ok and fused_mlp.FORWARD_GEMM == "f16" and all(hip.mlp_forward_f16_supports(d, n) for d, n in widths)
+        elif name == "mlp_wgrad":  # the bf16-plane weight-gradient kernel takes any width (and stays on bf16 planes)
+            ok, f16 = fused_mlp.BACKWARD_GEMM in planes, False
         else:
-            ok = fused_mlp.BACKWARD_GEMM == "split" and all(hip.mlp_backward_split_supports(d, n) for d, n in widths)
-        return "bf16x3-split" if ok else "f32"
+            ok = fused_mlp.BACKWARD_GEMM in planes and all(hip.mlp_backward_split_supports(d, n) for d, n in widths)
+            f16 = ok and fused_mlp.BACKWARD_GEMM == "f16" and all(hip.mlp_backward_f16_supports(d, n) for d, n in widths)
+        return "f16x2-split" if f16 else "bf16x3-split" if ok else "f32"
 
     lstm_gemm = {  # the recurrent models' LSTM (config 5): FLOP per row-step, matrix pipe
         "lstm_step": (2.0 * 256 * 1024, "bf16x3-split"), "lstm_step_save": (2.0 * 256 * 1024, "bf16x3-split"),
@@ -434,14 +445,15 @@ def run(args: argparse.Namespace) -> None:
                 "algorithmic_flop_per_launch": flops_per_launch,
                 "achieved_TFLOPs": round(tflops, 2),            # fp32-equivalent: algorithmic flops / time
                 "frac_of_f32_mfma_peak": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                "pmc_traffic_bytes_per_launch": pmc_traffic(name, rec["units_per_launch"], gemm != "f32"),
+                "pmc_traffic_bytes_per_launch": pmc_traffic(name, rec["units_per_launch"], gemm),
             }
             if gemm != "f32":
-                # every fp32 multiply-add of the 256x256 product is SPLIT_PRODUCTS bf16 ones on the matrix pipe
-                executed = SPLIT_PRODUCTS * 2.0 * 256 * 256 * rec["units_per_launch"]
+                # every fp32 multiply-add of the 256x256 product is 6 bf16 (3 fp16) ones on the matrix pipe
+                executed = PLANE_PRODUCTS[gemm] * 2.0 * 256 * 256 * rec["units_per_launch"]
                 bf16_tflops = executed / (rec["avg_ms"] * 1e-3) / 1e12
                 kernels[name].update({
-                    "executed_bf16_flop_per_launch": executed,
+                    "plane_products": PLANE_PRODUCTS[gemm],
+                    "executed_bf16_flop_per_launch": executed,   # (16-bit MFMA flop: bf16 or fp16 planes, same peak)
                     "executed_bf16_TFLOPs": round(bf16_tflops, 1),
                     "frac_of_bf16_mfma_peak": round(bf16_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
                 })
@@ -470,15 +482,18 @@ def run(args: argparse.Namespace) -> None:
             # bf16-plane kernel: priced in the bf16 multiply-adds the matrix pipe executes
             # (6 per fp32 multiply-add of the algorithm) against the dense bf16 peak
             roofline = {
-                "kernel": f"rl8_{dominant}_split_f32",
+                "kernel": {"mlp_wgrad": "rl8_mlp_wgrad_fused_split_f32"}.get(
+                    dominant, f"rl8_{dominant}_{'f16' if top['gemm'] == 'f16x2-split' else 'split'}_f32"),
                 "bound": "mfma",
                 "achieved": top["executed_bf16_TFLOPs"],
                 "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": top["frac_of_bf16_mfma_peak"],
                 "flop_per_launch": top["executed_bf16_flop_per_launch"],
-                "flop_definition": "6 bf16 plane products x 2*256*256 per row (fp32 operands split exactly into"
-                                   " 3 bf16 planes, fp32 accumulate)",
+                "flop_definition": ("3 fp16 plane products x 2*256*256 per row (fp32 operands scaled by powers of two and"
+                                    " split into 2 fp16 planes, fp32 accumulate)" if top["gemm"] == "f16x2-split" else
+                                    "6 bf16 plane products x 2*256*256 per row (fp32 operands split exactly into"
+                                    " 3 bf16 planes, fp32 accumulate)"),
                 "f32_equivalent_TFLOPs": top["achieved_TFLOPs"],   # the algorithm's fp32 FLOP / time
                 "f32_mfma_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
                 "f32_equivalent_frac_of_f32_mfma_peak": top["frac_of_f32_mfma_peak"],  # > 1: beyond the fp32 matrix roofline

@@ -362,6 +362,22 @@ int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, const flo
                                   const float *w3, const float *b3, int n_out, float *out,
                                   float *save_h1, float *save_h2, uint32_t *save_gate2, void *stream);
 
+/* The data-gradient half of the fused backward pass on the same fp16 planes (three MFMAs
+ * per 16 k): the fused mode of rl8_mlp_tower_backward_split_f32 (no dZ2 store; gate2 -- the
+ * forward's save_gate2 -- is required; w2t_f16 from rl8_mlp_pack_w2_f16(..., transposed = 1)).
+ * dZ2 rows are scaled by a power of two from the row bound sum_q |dOut_q| max|W3_q|, W2^T
+ * by the pack's, both undone on the accumulators.  Fills [dW1 | db1] of `*partial_rows_out`
+ * partial rows (same layout and row count as the bf16-plane kernel); the caller follows with
+ * rl8_mlp_wgrad_fused_split_f32 for dW2 and the head segments -- the weight gradient sums
+ * over samples, where no per-row power of two can be taken out of the sum, and stays on
+ * bf16 planes.  Replaces the autograd backward of the 256-256 towers
+ * (rl8/algorithms/_feedforward.py:374-386 loss.backward()). */
+int rl8_mlp_backward_f16_supports(int d_in, int n_out);
+int rl8_mlp_tower_backward_f16_f32(const float *x, const float *w1, const float *b1, const float *dout,
+                                   int64_t m, int d_in, const void *w2t_f16, const float *w3, int n_out,
+                                   float *partials, int *partial_rows_out /*host*/, const uint32_t *gate2,
+                                   void *stream);
+
 /* Backward of one tower ("dgrad" half): given dOut [M][n_out] and the saved
  * activations h1 / h2, writes dZ2 [M][256] (input of rl8_mlp_wgrad_f32, which
  * forms dW2 = dZ2^T h1) and `*partial_rows_out` rows (<= rl8_mlp_backward_max_rows()) of

@@ -40,6 +40,13 @@ __device__ __forceinline__ void f16_pair(float x0, float x1, uint32_t &hi, uint3
   lo = __builtin_bit_cast(uint32_t, lp);
 }
 
+// bound < 2^e for the power of two that scales an operand (2^(14 - e)); bounds below 2^-80
+// (and zero) keep a finite factor: such operands are far below fp16's top anyway.
+__device__ __forceinline__ int f16_bound_exponent(float bound) {
+  const int e = __builtin_amdgcn_frexp_expf(bound);
+  return e < -80 ? -80 : e;
+}
+
 // One plane product of the wave's 64 x 128 tile, operand roles exchanged (transposed
 // accumulators: lane = row; see split_mma_t).
 template <bool FIRST>
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(1024) void mlp_pack_w2_f16_kernel(const float *__re
     if (tid < half) red[tid] = __builtin_fmaxf(red[tid], red[tid + half]);
     __syncthreads();
   }
-  const int e = __builtin_amdgcn_frexp_expf(red[0]);  // max < 2^e
+  const int e = f16_bound_exponent(red[0]);  // max < 2^e
   const float scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
   if (tid == 0) {
     float *tail = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(packed) + kF16PackedBytes);
@@ -194,9 +201,9 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     float bound = b1max;
 #pragma unroll
     for (int i = 0; i < kIn; ++i) bound = __builtin_fmaf(__builtin_fabsf(px[i]), w1max[i], bound);
-    const int e = __builtin_amdgcn_frexp_expf(bound);        // bound < 2^e
-    p_scale = __builtin_amdgcn_ldexpf(1.0f, 14 - e);
-    if (tid < kSplitRows) lds_write_b32(scale_lds + (p_parity * kSplitRows + prow) * 4, __builtin_amdgcn_ldexpf(inv_w2_scale, e - 14));
+    const int e = f16_bound_exponent(bound);  // bound < 2^e
+    p_scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
+    if (tid < kSplitRows) lds_write_b32(scale_lds + (p_parity * kSplitRows + prow) * 4, __builtin_amdgcn_ldexpf(inv_w2_scale, e - kF16Top));
   };
 
   // Chunk `ks` of the producer's tile -> stage `stage`.
@@ -614,6 +621,379 @@ static int dispatch_forward_f16_nout(int n_out, int grid, hipStream_t s, const f
   }
 }
 
+// ---- backward ("dgrad" half) on the same scheme ----------------------------------
+//   dZ2 = (dOut x W3) * gate2      per k-chunk on the VALU (thread = row, eight columns),
+//                                  scaled by the row's power of two and split into the A planes;
+//   dH1 = dZ2 x W2                 three fp16 plane products (B = W2 packed transposed);
+//   dZ1 = dH1 * (h1 > 0)           accumulator epilogue (scaling undone), folded into dW1 / db1.
+// Structure of mlp_tower_backward_split_kernel (mlp_split_kernels.hip), fused mode only:
+// the ReLU gate of h2 comes as bits (the forward kernel's save_gate2), dZ2 is not stored and
+// the head gradients are left to the weight-gradient kernel (rl8_mlp_wgrad_fused_split_f32,
+// which stays on bf16 planes: its reduction runs over SAMPLES, so a per-sample power of two
+// cannot be taken out of the sum, and with one power of two per launch the entries of dW2
+// whose terms all lie far below the launch's largest lose relative accuracy -- measured
+// 6e-5 of an entry's own sum of |terms| with rows 10^6 apart, against 7e-7 for bf16 planes;
+// tools/diag/f16_wgrad_mixed_rows.py -- while the kernel, VALU- and latency-bound on its
+// operand production, was no faster than the six-product one).
+// The row bound that places the planes in fp16's range is
+//   |dZ2[row][k]| <= sum_q |dOut[row][q]| * max_k |W3[q][k]|,
+// a function of the row's dOut alone, so the producer thread has it in registers.
+constexpr int f16_backward_lds_bytes(int k_in) {
+  return 2 * kF16StageBytes + kHidden * (1 + k_in) * 4 + kSplitRows * 32 + 2 * kSplitRows * 4;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void f16_mma(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[mt]), __builtin_bit_cast(half8, b[nt]),
+                                                           FIRST ? zero : acc[mt][nt], 0, 0, 0);
+    }
+}
+
+template <int DIN, int NOUT>
+__global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
+    const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+    const float *__restrict__ dout, int64_t m, const void *__restrict__ w2ts, const float *__restrict__ w3,
+    float *__restrict__ partials, int partial_stride, int head_rows, const uint32_t *__restrict__ gate2) {
+  static_assert(DIN > 0 && NOUT > 0, "compiled widths only");
+  constexpr int kIn = DIN, d_in = DIN, n_out = NOUT;
+  constexpr int kOut = pad_out(NOUT);
+  static_assert(f16_backward_lds_bytes(kIn) <= 80 * 1024, "two workgroups per CU");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [stage 0: A | B][stage 1][column sums [256][1 + kIn]][gate block [128 rows][8 words]][row factors [2][128]]
+  const unsigned lds0 = lds_offset(smem);
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int prow = tid & 127, pkh = wave >> 1;  // producer role: row, wave-uniform k-half (see the forward kernel)
+  constexpr int kColsumOff = 2 * kF16StageBytes;
+  constexpr int kGateOff = kColsumOff + kHidden * (1 + kIn) * 4;
+  constexpr int kScaleOff = kGateOff + kSplitRows * 32;
+  const unsigned gate_lds = lds0 + kGateOff;
+  const unsigned scale_lds = lds0 + kScaleOff;
+  uint32_t g0 = 0u;  // word 0 of row prow of the NEXT tile (its chunk 0 is produced before the block lands)
+  const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
+  const unsigned b_read = lds0 + kF16ABytes + (4 * wc * 2) * 1024 + lane * 16;
+  const unsigned a_write = lds0 + pkh * kSplitKhStride + prow * 16;
+  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2ts, kF16PackedBytes);
+  const float inv_w2_scale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(w2ts) + kF16PackedBytes)[1];
+
+  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
+  const int64_t stride = gridDim.x;
+
+  // max_k |W3[q][k]| (uniform: scalar registers), before any stage is in use
+  float w3max[kOut];
+  {
+    float *red = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) {
+      __syncthreads();
+      red[tid] = q < n_out ? __builtin_fabsf(w3[q * kHidden + tid]) : 0.0f;
+      __syncthreads();
+      float mx = 0.0f;
+      for (int i = 0; i < kHidden; ++i) mx = __builtin_fmaxf(mx, red[i]);
+      w3max[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+    }
+    __syncthreads();
+  }
+
+  // Producer state (one step ahead of the consumer; moves to the next tile before step 15).
+  int64_t p_tile = blockIdx.x;
+  float dr[kOut], dn[kOut];  // dOut of row prow of the producer's tile / of the tile after
+  auto rows_in_tile = [&](int64_t tile) {
+    const int64_t left = m - tile * kSplitRows;
+    return left <= 0 ? 0 : left < kSplitRows ? (int)left : kSplitRows;
+  };
+  auto load_dout = [&](float (&dst)[kOut], int64_t tile) {
+    const int rows = rows_in_tile(tile);
+    const float *base = dout + tile * kSplitRows * n_out;
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) dst[q] = (prow < rows && q < n_out) ? base[(unsigned)(prow * n_out + q)] : 0.0f;
+  };
+  load_dout(dr, p_tile);
+  load_dout(dn, p_tile + stride);
+  float p_scale = 1.0f;  // of row prow of the producer's tile
+  int p_parity = 0, c_parity = 0;
+  auto set_row_scale = [&]() {
+    float bound = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) bound = __builtin_fmaf(__builtin_fabsf(dr[q]), w3max[q], bound);
+    const int e = f16_bound_exponent(bound);  // bound < 2^e
+    p_scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
+    if (tid < kSplitRows) lds_write_b32(scale_lds + (p_parity * kSplitRows + prow) * 4, __builtin_amdgcn_ldexpf(inv_w2_scale, e - kF16Top));
+  };
+  auto request_b = [&](int ks, int stage) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int block = wave * 4 + u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, smem + stage * kF16StageBytes + kF16ABytes + block * 1024,
+                                               16, lane * 16, (ks * 16 + block) * 1024, 0, 0);
+    }
+  };
+  // Gate block of `tile` -> LDS: wave w copies rows 32w .. 32w+31 (1 KiB, contiguous);
+  // rows past the end of the data arrive as zeros (gate closed).
+  auto request_gate = [&](int64_t tile) {
+    const int rows = rows_in_tile(tile);
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? gate2 + tile * (kSplitRows * 8) : gate2, rows * 32);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, smem + kGateOff + wave * 1024, 16, lane * 16, wave * 1024, 0, 0);
+  };
+  auto load_g0 = [&](int64_t tile) {
+    const int rows = rows_in_tile(tile);
+    g0 = prow < rows ? (gate2 + tile * (kSplitRows * 8))[(unsigned)(prow * 8)] : 0u;
+  };
+  // from_regs: chunk 0 of a tile whose gate block has not landed yet takes its bits from g0.
+  auto produce_a = [&](int ks, u32x4 (&planes)[2], bool from_regs = false) {
+    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);  // W3[q][kb + e]: uniform, through the scalar cache
+    uint32_t gword = g0;
+    if (!from_regs) gword = __float_as_uint(lds_read_b32(gate_lds + (prow * 8 + (ks >> 1)) * 4));
+    const uint32_t byte = gword >> (16 * (ks & 1) + 8 * pkh);
+    float dz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float g = dr[0] * w3[kb + e];
+#pragma unroll
+      for (int q = 1; q < kOut; ++q)
+        if (q < n_out) g = __builtin_fmaf(dr[q], w3[q * kHidden + kb + e], g);
+      dz[e] = ((byte >> e) & 1u) != 0 ? g * p_scale : 0.0f;  // (the power of two: exact)
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t hi, lo;
+      f16_pair(dz[e], dz[e + 1], hi, lo);
+      planes[0][e >> 1] = hi;
+      planes[1][e >> 1] = lo;
+    }
+  };
+  auto write_a = [&](int stage, const u32x4 (&planes)[2]) {
+    const unsigned addr = a_write + stage * kF16StageBytes;
+    lds_write_b128<0>(addr, planes[0]);
+    lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
+  };
+  auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  f32x16 acc[2][4];
+  // Running column sums [256][1 + kIn] (db1 | dW1 row) live in LDS behind the two
+  // chunk stages, not in registers: the matrix loop has none to spare.
+  for (int idx = tid; idx < kHidden * (1 + kIn); idx += kBlock) lds_write_b32(lds0 + kColsumOff + idx * 4, 0.0f);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  auto do_step = [&](auto first_tag, auto parity_tag, int s) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int P = decltype(parity_tag)::value;
+    const int ks = (s + 1) & (kSplitSteps - 1);
+    request_b(ks, P ^ 1);
+    const unsigned ar = a_read + P * kF16StageBytes, br = b_read + P * kF16StageBytes;
+    SplitFrags f;  // ah / bh: hi planes, am / bm: lo planes
+    f.ah[0] = lds_read_b128<0>(ar);
+    f.ah[1] = lds_read_b128<512>(ar);
+    f.bh[0] = lds_read_b128<0>(br);
+    f.bh[1] = lds_read_b128<2 * 1024>(br);
+    f.bh[2] = lds_read_b128<4 * 1024>(br);
+    f.bh[3] = lds_read_b128<6 * 1024>(br);
+    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
+    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
+    f.bm[0] = lds_read_b128<1024>(br);
+    f.bm[1] = lds_read_b128<3 * 1024>(br);
+    f.bm[2] = lds_read_b128<5 * 1024>(br);
+    f.bm[3] = lds_read_b128<7 * 1024>(br);
+    if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
+#pragma unroll
+      for (int q = 0; q < kOut; ++q) dr[q] = dn[q];
+      p_tile += stride;
+      load_dout(dn, p_tile + stride);
+      p_parity ^= 1;
+      set_row_scale();
+      // every wave is past barrier(14): nobody reads the old gate block any more;
+      // the new one lands by this step's barrier, chunk 0 uses g0 meanwhile
+      request_gate(p_tile);
+    }
+    u32x4 planes[2];
+    produce_a(ks, planes, s == kSplitSteps - 1);
+    if (s == kSplitSteps - 3) load_g0(p_tile + stride);  // two steps ahead of its use
+    wait_lds_all(f);
+    f16_mma<FIRST>(f.am, f.bh, acc);  // lo x hi
+    f16_mma<false>(f.ah, f.bm, acc);  // hi x lo
+    __builtin_amdgcn_sched_barrier(0);
+    write_a(P ^ 1, planes);
+    __builtin_amdgcn_sched_barrier(0);
+    f16_mma<false>(f.ah, f.bh, acc);  // hi x hi
+    __builtin_amdgcn_sched_barrier(0);
+    step_barrier();
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  if ((int64_t)blockIdx.x < tiles) {
+    set_row_scale();
+    request_gate(p_tile);
+    step_barrier();  // (once per kernel: the first gate block has landed)
+    request_b(0, 0);
+    u32x4 planes[2];
+    produce_a(0, planes);
+    write_a(0, planes);
+    step_barrier();
+  }
+
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
+    const int64_t r0 = tile * kSplitRows;
+    const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
+    do_step(T{}, P0{}, 0);
+    do_step(F{}, P1{}, 1);
+#pragma unroll 1
+    for (int s = 2; s < kSplitSteps - 2; s += 2) {
+      do_step(F{}, P0{}, s);
+      do_step(F{}, P1{}, s + 1);
+    }
+    do_step(F{}, P0{}, kSplitSteps - 2);
+    do_step(F{}, P1{}, kSplitSteps - 1);
+
+    // Epilogue: dZ1 = dH1 * (h1 > 0) folded into db1 / dW1, the gate RECOMPUTED from the
+    // observations (h1 > 0 <=> b1 + x . w1 > 0, the forward pass's own fma chain) -- see
+    // the bf16-plane kernel.  Here the accumulators still carry the operand scaling: each
+    // row's factor (its own power of two and W2's, inverted) comes from LDS, four rows a read.
+    const __amdgpu_buffer_rsrc_t xrsrc = buffer_rsrc(x + r0 * d_in, rows * d_in * 4);
+    const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
+    const unsigned colsum = lds_offset(smem) + kColsumOff;
+    const unsigned factors = lds_offset(smem) + kScaleOff + (c_parity * kSplitRows + 64 * wr + 4 * hh) * 4;
+    c_parity ^= 1;
+    float w1c[4][kIn], b1c[4];  // this lane's four columns of layer 1 (reloaded per tile: L1 hits)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col = 128 * wc + 32 * nt + l32;
+      b1c[nt] = b1[col];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) w1c[nt][i] = w1[col * d_in + i];
+    }
+    float db1[4], dw1[4][kIn];  // this tile: this lane's four columns, its half of the rows
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      db1[nt] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) dw1[nt][i] = 0.0f;
+    }
+    constexpr int kXRows = kIn <= 2 ? 16 : 4;
+    constexpr int kBatches = 2 * 16 / kXRows;  // batches of kXRows rows over both row tiles
+    auto load_rows = [&](float (&dst)[kXRows][kIn], int batch) {
+      const int mt = batch / (16 / kXRows), rx = (batch % (16 / kXRows)) * kXRows;
+#pragma unroll
+      for (int u = 0; u < kXRows; ++u) {
+        const int r = rx + u;
+        const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) dst[u][i] = buffer_load_f32(xrsrc, (4 * hh * d_in + i) * 4, sr * d_in * 4);
+      }
+    };
+    float xbuf[2][kXRows][kIn];
+    load_rows(xbuf[0], 0);
+#pragma unroll
+    for (int batch = 0; batch < kBatches; ++batch) {
+      const int mt = batch / (16 / kXRows), rx = (batch % (16 / kXRows)) * kXRows;
+      if (batch + 1 < kBatches) load_rows(xbuf[(batch + 1) & 1], batch + 1);
+      float (&xv)[kXRows][kIn] = xbuf[batch & 1];
+#pragma unroll
+      for (int rb = 0; rb < kXRows; rb += 4) {
+        // rows 64 wr + 32 mt + 8 ((rx + rb) / 4) + 4 hh + u, u = 0..3: their four factors
+        u32x4 fq = (mt == 0 ? lds_read_b128<0>(factors + 8 * ((rx + rb) >> 2) * 4)
+                            : lds_read_b128<32 * 4>(factors + 8 * ((rx + rb) >> 2) * 4));
+        wait_lds<0>(fq);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          float pre[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            pre[u] = b1c[nt];
+#pragma unroll
+            for (int i = 0; i < kIn; ++i) pre[u] = __builtin_fmaf(xv[rb + u][i], w1c[nt][i], pre[u]);
+          }
+          unsigned long long gate[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) gate[u] = positive_mask(pre[u]);
+          __builtin_amdgcn_sched_barrier(0);
+          float dz[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dz[u] = select_or_zero(gate[u], acc[mt][nt][rx + rb + u]) * __uint_as_float(fq[u]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            db1[nt] += dz[u];
+#pragma unroll
+            for (int i = 0; i < kIn; ++i) dw1[nt][i] = __builtin_fmaf(dz[u], xv[rb + u][i], dw1[nt][i]);
+          }
+        }
+      }
+    }
+    // Into the running sums, in a fixed order: the two row halves of a lane pair, then the
+    // wave of rows 0..63, a barrier, the wave of rows 64..127.
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      db1[nt] += __shfl_xor(db1[nt], 32, kWave);
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) dw1[nt][i] += __shfl_xor(dw1[nt][i], 32, kWave);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (wr == half && hh == 0) {
+        float cur[4][1 + kIn];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int i = 0; i < 1 + kIn; ++i)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(cur[nt][i]) : "v"(colsum + ((128 * wc + 32 * nt + l32) * (1 + kIn) + i) * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const unsigned a = colsum + (128 * wc + 32 * nt + l32) * (1 + kIn) * 4;
+          float v0 = cur[nt][0];
+          asm volatile("" : "+v"(v0));  // (use behind the wait)
+          lds_write_b32(a, v0 + db1[nt]);
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) {
+            float vi = cur[nt][1 + i];
+            asm volatile("" : "+v"(vi));
+            lds_write_b32(a + 4 + 4 * i, vi + dw1[nt][i]);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  }
+
+  // Workgroup partial row: [dW1 (256*d_in) | db1 (256) | head gradients (the weight-gradient kernel's)].
+  float *row = partials + (int64_t)blockIdx.x * partial_stride;
+  {
+    const int t = 64 * wave + lane_id();
+    const unsigned a = lds_offset(smem) + kColsumOff + t * (1 + kIn) * 4;
+    row[kHidden * d_in + t] = lds_read_b32(a);
+#pragma unroll
+    for (int i = 0; i < kIn; ++i) row[t * d_in + i] = lds_read_b32(a + 4 + 4 * i);
+    // the head-gradient segments of the first head_rows rows belong to the fused
+    // weight-gradient kernel; rows beyond them are zero.
+    if ((int)blockIdx.x >= head_rows)
+      for (int idx = kHidden * d_in + kHidden + t; idx < partial_stride; idx += kBlock) row[idx] = 0.0f;
+  }
+}
+
+template <int DIN, int NOUT>
+static int launch_backward_f16(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
+                               int64_t m, const void *w2ts, const float *w3, float *partials, int stride, int head_rows,
+                               const uint32_t *gate2) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_f16_kernel<DIN, NOUT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  mlp_tower_backward_f16_kernel<DIN, NOUT><<<grid, kBlock, f16_backward_lds_bytes(DIN), s>>>(
+      x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2);
+  return launch_status();
+}
+
 }  // namespace rl8
 
 using namespace rl8;
@@ -651,4 +1031,40 @@ RL8_API int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, c
     case 3: return dispatch_forward_f16_nout<3>(n_out, grid, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, out, save_h1, save_h2, save_gate2);
     default: return dispatch_forward_f16_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, out, save_h1, save_h2, save_gate2);
   }
+}
+
+RL8_API int rl8_mlp_backward_f16_supports(int d_in, int n_out) { return rl8_mlp_forward_f16_supports(d_in, n_out); }
+
+// Grids of the two halves of the fused backward (as in mlp_split_kernels.hip: both derive
+// them from m alone, so that each can zero the partial-row segments the other does not cover).
+static void f16_backward_grids(int64_t m, int *g1, int *g2) {
+  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
+  const int64_t chunks = (m + 16 - 1) / 16;  // (16-sample chunks of the weight-gradient kernel)
+  static const int cap = env_int("RL8_MLP_GRID_CAP");
+  const int max_grid = cap > 0 ? cap : 2 * kCUs;
+  *g1 = (int)(tiles < max_grid ? tiles : max_grid);
+  *g2 = (int)(chunks < kCUs ? chunks : kCUs);
+}
+
+RL8_API int rl8_mlp_tower_backward_f16_f32(const float *x, const float *w1, const float *b1, const float *dout,
+                                           int64_t m, int d_in, const void *w2t_f16, const float *w3, int n_out,
+                                           float *partials, int *partial_rows_out, const uint32_t *gate2,
+                                           void *stream) {
+  if (!x || !w1 || !b1 || !dout || !w2t_f16 || !w3 || !partials || !partial_rows_out || !gate2) return RL8_ENULL;
+  if (m <= 0 || !rl8_mlp_backward_f16_supports(d_in, n_out)) return RL8_ESIZE;
+  if (((uintptr_t)w2t_f16 & 15) != 0 || !aligned16(gate2) || !aligned16(w3)) return RL8_EALIGN;
+  int grid, g2;
+  f16_backward_grids(m, &grid, &g2);
+  *partial_rows_out = grid > g2 ? grid : g2;
+  const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
+  hipStream_t s = (hipStream_t)stream;
+  int status = RL8_ESIZE;
+#define RL8_BACKWARD_F16(D, N) \
+  if (d_in == D && n_out == N) status = launch_backward_f16<D, N>(grid, s, x, w1, b1, dout, m, w2t_f16, w3, partials, stride, g2, gate2);
+  RL8_BACKWARD_F16(1, 1) RL8_BACKWARD_F16(1, 2) RL8_BACKWARD_F16(1, 3)
+  RL8_BACKWARD_F16(2, 1) RL8_BACKWARD_F16(2, 2) RL8_BACKWARD_F16(2, 3)
+  RL8_BACKWARD_F16(3, 1) RL8_BACKWARD_F16(3, 2) RL8_BACKWARD_F16(3, 3)
+  RL8_BACKWARD_F16(5, 1) RL8_BACKWARD_F16(5, 2) RL8_BACKWARD_F16(5, 3)
+#undef RL8_BACKWARD_F16
+  return status;
 }

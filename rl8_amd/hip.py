@@ -147,6 +147,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
     "rl8_mlp_backward_max_rows": [],
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_mlp_backward_f16_supports": [_i32, _i32],
+    "rl8_mlp_tower_backward_f16_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, C.POINTER(C.c_int), _vp, _vp],
     "rl8_mlp_f16_packed_bytes": [],
     "rl8_mlp_forward_f16_supports": [_i32, _i32],
     "rl8_mlp_pack_w2_f16": [_vp, _i32, _vp, _vp],
@@ -871,6 +873,10 @@ def mlp_forward_f16_supports(d_in: int, n_out: int) -> bool:
     return bool(load().rl8_mlp_forward_f16_supports(int(d_in), int(n_out)))
 
 
+def mlp_backward_f16_supports(d_in: int, n_out: int) -> bool:
+    return bool(load().rl8_mlp_backward_f16_supports(int(d_in), int(n_out)))
+
+
 def mlp_pack_w2_f16(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
     """[256, 256] nn.Linear weight -> two fp16 planes of 2^e * w (hi = fp16(v),
     lo = fp16(v - hi)) in fragment order, followed by {2^e, 2^-e} (uint8)."""
@@ -953,6 +959,9 @@ def mlp_tower_backward(
     m, d_in = x.shape
     n_out = w3.shape[0]
     split = w2t_packed.dtype == torch.uint8
+    f16 = split and w2t_packed.numel() == int(load().rl8_mlp_f16_packed_bytes())
+    if f16 and gate2 is None:
+        raise ValueError("the fp16-plane backward needs gate2 (mlp_tower_forward_split(save_gate=True))")
     if h1 is None and not split:
         raise ValueError("h1 may be omitted only on the bf16-plane path")
     for name, t, numel in (("x", x, m * d_in), ("h1", h1, m * MLP_HIDDEN), ("h2", h2, m * MLP_HIDDEN),
@@ -977,14 +986,22 @@ def mlp_tower_backward(
             raise ValueError("the bf16-plane backward needs w1 and b1")
         w1p, b1p = _ptr(_dense(w1.detach(), torch.float32, "w1")), _ptr(_dense(b1.detach(), torch.float32, "b1"))
         with _timed("mlp_tower_backward", m):
-            _check(
-                lib.rl8_mlp_tower_backward_split_f32(
-                    _ptr(x), w1p, b1p, _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
-                    None, _ptr(partials), C.byref(rows), _ptr(gate2), _stream()),
-                "rl8_mlp_tower_backward_split_f32",
-            )
+            if f16:
+                _check(
+                    lib.rl8_mlp_tower_backward_f16_f32(
+                        _ptr(x), w1p, b1p, _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
+                        _ptr(partials), C.byref(rows), _ptr(gate2), _stream()),
+                    "rl8_mlp_tower_backward_f16_f32",
+                )
+            else:
+                _check(
+                    lib.rl8_mlp_tower_backward_split_f32(
+                        _ptr(x), w1p, b1p, _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
+                        None, _ptr(partials), C.byref(rows), _ptr(gate2), _stream()),
+                    "rl8_mlp_tower_backward_split_f32",
+                )
         dw2 = torch.empty(MLP_HIDDEN, MLP_HIDDEN, dtype=torch.float32, device=x.device)
-        with _timed("mlp_wgrad", m):
+        with _timed("mlp_wgrad", m):  # (bf16 planes for both generations: see rl8_mlp_tower_backward_f16_f32)
             _check(
                 lib.rl8_mlp_wgrad_fused_split_f32(
                     _ptr(h2), _ptr(dout), _ptr(x), w1p, b1p, _ptr(w3.detach()), m, d_in, n_out,

@@ -31,15 +31,18 @@ from .. import hip
 #: Set to False to evaluate towers with eager PyTorch (A/B comparisons).
 ENABLED = True
 
-#: How the 256x256 product of the forward kernel is formed: "split" = exact 3-way
-#: bf16 split of both fp32 operands, six plane products per 16 k on the bf16
-#: matrix pipe, fp32 accumulate (fp32 accuracy, ~1.8x the fp32-MFMA kernel);
-#: "f32" = v_mfma_f32_32x32x2_f32; "f16" = scaled two-plane fp16 split, three
-#: plane products per 16 k (forward only).  ``RL8_AMD_TOWER_GEMM`` /
-#: ``RL8_AMD_TOWER_FORWARD_GEMM`` override.
-FORWARD_GEMM = os.environ.get("RL8_AMD_TOWER_FORWARD_GEMM", os.environ.get("RL8_AMD_TOWER_GEMM", "split"))
-#: Same choice for the data-gradient product of the backward pass.
-BACKWARD_GEMM = os.environ.get("RL8_AMD_TOWER_GEMM", "split")
+#: How the 256x256 product of the forward kernel is formed: "f16" = both fp32
+#: operands scaled by powers of two (per activation row / per weight matrix) and
+#: split into two fp16 planes, three plane products per 16 k on the fp16 matrix
+#: pipe, fp32 accumulate (fp32 accuracy: same fp64 bars as the others);
+#: "split" = exact 3-way bf16 split, six plane products per 16 k (1.5x slower);
+#: "f32" = v_mfma_f32_32x32x2_f32 (2.7x slower).  ``RL8_AMD_TOWER_GEMM`` /
+#: ``RL8_AMD_TOWER_FORWARD_GEMM`` / ``RL8_AMD_TOWER_BACKWARD_GEMM`` override.
+FORWARD_GEMM = os.environ.get("RL8_AMD_TOWER_FORWARD_GEMM", os.environ.get("RL8_AMD_TOWER_GEMM", "f16"))
+#: Same choice for the data-gradient product of the backward pass (the weight
+#: gradient dW2 stays on bf16 planes under "f16": it sums over samples, where a
+#: per-row power of two cannot be taken out of the sum).
+BACKWARD_GEMM = os.environ.get("RL8_AMD_TOWER_BACKWARD_GEMM", os.environ.get("RL8_AMD_TOWER_GEMM", "f16"))
 
 
 def _packed(layer: nn.Linear, transposed: bool, split: bool | str = False) -> torch.Tensor:
@@ -67,7 +70,7 @@ class _FusedTower(torch.autograd.Function):
         need_grad = grad_mode and any(ctx.needs_input_grad[1:7])
         if FORWARD_GEMM in ("split", "f16") and hip.mlp_forward_split_supports(x.shape[1], w3.shape[0]):
             # h1 is stored only if a backward kernel will read it (the bf16-plane ones recompute it)
-            keep_h1 = not (BACKWARD_GEMM == "split" and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0]))
+            keep_h1 = not (BACKWARD_GEMM in ("split", "f16") and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0]))
             f16 = FORWARD_GEMM == "f16" and hip.mlp_forward_f16_supports(x.shape[1], w3.shape[0])
             out, h1, h2, gate = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16" if f16 else True),
                                                             b2, w3, b3,
@@ -83,9 +86,11 @@ class _FusedTower(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
         x, h1, h2, w3, w1, b1, gate = ctx.saved_tensors
-        split = BACKWARD_GEMM == "split" and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0])
+        split: bool | str = BACKWARD_GEMM in ("split", "f16") and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0])
+        if split and BACKWARD_GEMM == "f16" and gate is not None and hip.mlp_backward_f16_supports(x.shape[1], w3.shape[0]):
+            split = "f16"
         g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True, split), w3,
-                                   w1, b1, wgrad_split=BACKWARD_GEMM == "split", gate2=gate if split else None)
+                                   w1, b1, wgrad_split=BACKWARD_GEMM in ("split", "f16"), gate2=gate if split else None)
         return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None
 
 

@@ -156,12 +156,13 @@ def test_forward_f16_scaling_holds_over_the_dynamic_range(case):
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 5, 3), (4097, 3, 2), (40_000, 1, 2), (9000, 2, 1),
                                           (33_000, 1, 2), (33_000, 5, 3), (20_000, 3, 1), (16_500, 2, 3)])
-def test_backward_split_matches_fp64(m, d_in, n_out):
+@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+def test_backward_split_matches_fp64(m, d_in, n_out, scheme):
     """Against an fp64 evaluation of the backward formulas on the SAVED activations
     (the ReLU gates are part of the input of a backward pass: an autograd run in
     fp64 flips the gates of pre-activations within fp32 rounding of zero, which
-    says nothing about these kernels)."""
-    assert hip.mlp_backward_split_supports(d_in, n_out)
+    says nothing about these kernels).  Both plane schemes against the same bars."""
+    assert hip.mlp_backward_split_supports(d_in, n_out) and hip.mlp_backward_f16_supports(d_in, n_out)
     g = torch.Generator(device=DEV).manual_seed(7 * m + d_in)
     x = torch.randn(m, d_in, device=DEV, generator=g) * 3
     p = _params(g, d_in, n_out)
@@ -172,8 +173,9 @@ def test_backward_split_matches_fp64(m, d_in, n_out):
     dz2 = (d @ p["w3"].double()) * (a2 > 0)
     dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
     want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0), "w2": dz2.T @ a1, "b2": dz2.sum(0), "w3": d.T @ a2, "b3": d.sum(0)}
-    w2t = hip.mlp_pack_w2_split(p["w2"], transposed=True)
-    grads = hip.mlp_tower_backward(x, h1, h2, dout, w2t, p["w3"], p["w1"], p["b1"])
+    f16 = scheme == "f16x2"
+    w2t = (hip.mlp_pack_w2_f16 if f16 else hip.mlp_pack_w2_split)(p["w2"], transposed=True)
+    grads = hip.mlp_tower_backward(x, h1, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate if f16 else None)
     grads32 = hip.mlp_tower_backward(x, h1, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
     for k in p:
         err, err32 = _rel(grads[k], want[k]), _rel(grads32[k], want[k])
@@ -183,9 +185,13 @@ def test_backward_split_matches_fp64(m, d_in, n_out):
             continue
         assert err < 2e-5, (k, err)
         assert err <= 8 * err32 + 2e-6, (k, err, err32)  # as accurate as the fp32-MFMA kernels
-    again = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"])  # h1 is not read
+    again = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate if f16 else None)  # h1 is not read
     for k in p:
         assert torch.equal(grads[k], again[k]), k  # fixed summation order, no race
+    if f16:  # (fused mode only: the gate bits are required)
+        with pytest.raises(ValueError):
+            hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"])
+        return
     # gate bits instead of h2 reads in the data-gradient kernel: the same decisions, so the same bits out
     bits = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate)
     for k in p:
@@ -194,8 +200,55 @@ def test_backward_split_matches_fp64(m, d_in, n_out):
         hip.mlp_tower_backward(x, None, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
 
 
+@pytest.mark.parametrize("case", ["rows_of_mixed_magnitude", "one_outlier_row", "clipped_rows", "tiny_gradients",
+                                  "outlier_weights"])
+def test_backward_f16_scaling_holds_over_the_dynamic_range(case):
+    """dOut as PPO produces it is heavy-tailed (clipped samples contribute exactly zero, a few
+    samples carry most of the gradient): the data-gradient kernel scales per ROW, the
+    weight-gradient kernel per LAUNCH.  Every gradient against fp64 on the saved activations
+    and against the six-product bf16 kernels' own error."""
+    m, d_in, n_out = 20_000, 3, 2
+    g = torch.Generator(device=DEV).manual_seed(23)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 3
+    p = _params(g, d_in, n_out)
+    dout = torch.randn(m, n_out, device=DEV, generator=g) / m
+    if case == "rows_of_mixed_magnitude":
+        dout *= 10.0 ** torch.randint(-4, 3, (m, 1), device=DEV, generator=g).float()
+        x *= 10.0 ** torch.randint(-2, 2, (m, 1), device=DEV, generator=g).float()
+    elif case == "one_outlier_row":
+        dout[777] *= 1e6
+    elif case == "clipped_rows":
+        dout[torch.rand(m, device=DEV, generator=g) < 0.7] = 0.0
+    elif case == "tiny_gradients":
+        dout *= 1e-20
+    elif case == "outlier_weights":
+        p["w2"][torch.randint(0, 256, (20,), device=DEV, generator=g), torch.randint(0, 256, (20,), device=DEV, generator=g)] = 40.0
+        p["w3"][0, 5] = 30.0
+    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_split(p["w2"]), p["b2"], p["w3"],
+                                                  p["b3"], save=True, save_gate=True)
+    d, a1, a2 = dout.double(), h1.double(), h2.double()
+    dz2 = (d @ p["w3"].double()) * (a2 > 0)
+    dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
+    want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0), "w2": dz2.T @ a1, "b2": dz2.sum(0), "w3": d.T @ a2}
+    # the scale of a gradient entry: the sum of the magnitudes of its terms (what an fp32 sum is accurate against)
+    size = {"w1": dz1.abs().T @ x.double().abs(), "b1": dz1.abs().sum(0), "w2": dz2.abs().T @ a1, "b2": dz2.abs().sum(0),
+            "w3": d.abs().T @ a2}
+    got = hip.mlp_tower_backward(x, None, h2, dout, hip.mlp_pack_w2_f16(p["w2"], transposed=True), p["w3"], p["w1"], p["b1"],
+                                 gate2=gate)
+    got6 = hip.mlp_tower_backward(x, None, h2, dout, hip.mlp_pack_w2_split(p["w2"], transposed=True), p["w3"], p["w1"],
+                                  p["b1"], gate2=gate)
+    for k in want:
+        assert bool(torch.isfinite(got[k]).all()), k
+        floor = size[k].max() * 1e-30 + 1e-300
+        err = float(((got[k].double() - want[k]).abs() / (size[k] + floor)).max())
+        err6 = float(((got6[k].double() - want[k]).abs() / (size[k] + floor)).max())
+        # (the absolute bar is the fp32 accumulators' own: with one row 10^6 above the rest both schemes sit at 5e-6)
+        assert err < 2e-5 and err <= 3 * err6 + 2e-7, (k, err, err6)
+
+
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (13, 1, 1), (4099, 2, 3), (20_003, 5, 3), (33_001, 3, 2), (9, 5, 1)])
-def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out):
+@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out, scheme):
     """The kernels fetch whole windows of rows (eight samples of x / dOut through scalar
     buffer descriptors, 16-sample chunks of h2, 128-row tiles) and rely on descriptors
     that end at row m for the ragged tail.  Here every input is a view of a larger
@@ -212,14 +265,15 @@ def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out):
     x = torch.randn(m, d_in, device=DEV, generator=g)
     p = _params(g, d_in, n_out)
     dout = torch.randn(m, n_out, device=DEV, generator=g) / m
-    w2p, w2t = hip.mlp_pack_w2_split(p["w2"]), hip.mlp_pack_w2_split(p["w2"], transposed=True)
+    pack = hip.mlp_pack_w2_f16 if scheme == "f16x2" else hip.mlp_pack_w2_split
+    w2p, w2t = pack(p["w2"]), pack(p["w2"], transposed=True)
     _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True, save_gate=True)
     want = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate)
     xv, h2v, dv = view_of(x), view_of(h2), view_of(dout)
     outv, _, h2_again, gate_again = hip.mlp_tower_forward_split(xv, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True,
                                                                save_gate=True)
     assert torch.equal(h2_again, h2) and torch.equal(gate_again, gate) and bool(torch.isfinite(outv).all())
-    for gate2 in (None, gate):
+    for gate2 in ((gate,) if scheme == "f16x2" else (None, gate)):
         got = hip.mlp_tower_backward(xv, None, h2v, dv, w2t, p["w3"], p["w1"], p["b1"], gate2=gate2)
         for k in p:
             assert bool(torch.isfinite(got[k]).all()), k
@@ -289,7 +343,7 @@ def test_wgrad_split_matches_torch(m, d_in):
 def test_fused_tower_autograd_uses_the_split_kernels_and_matches_eager():
     from rl8_amd.nn import fused_mlp
 
-    assert fused_mlp.FORWARD_GEMM == "split" and fused_mlp.BACKWARD_GEMM == "split"
+    assert fused_mlp.FORWARD_GEMM == "f16" and fused_mlp.BACKWARD_GEMM == "f16"  # the shipped defaults
     torch.manual_seed(5)
     mlp = torch.nn.Sequential(torch.nn.Linear(1, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
     trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
@@ -313,8 +367,9 @@ def test_fused_tower_autograd_uses_the_split_kernels_and_matches_eager():
         assert _rel(got[n], p.grad.double()) < 2e-5, n
 
 
+@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("m,parts", [(1 << 23, 8), (1 << 25, 4)])
-def test_full_size_launch_equals_its_chunks(m, parts):
+def test_full_size_launch_equals_its_chunks(m, parts, scheme):
     """BASELINE's training launch (2^25 rows: `Algorithm.step` feeds the towers the whole
     33.5 M-sample batch in one pass; 32 GiB of h2, offsets past 2^32 bytes) and a 2^23-row one
     against the same rows in several launches: a row's outputs depend on nothing but that
@@ -324,7 +379,8 @@ def test_full_size_launch_equals_its_chunks(m, parts):
     x = torch.empty(m, 1, device=DEV).uniform_(-100, 100, generator=g)  # DiscreteDummyEnv observations
     p = _params(g, 1, 2)
     dout = torch.randn(m, 2, device=DEV, generator=g) / m
-    w2s, w2ts = hip.mlp_pack_w2_split(p["w2"]), hip.mlp_pack_w2_split(p["w2"], transposed=True)
+    pack = hip.mlp_pack_w2_f16 if scheme == "f16x2" else hip.mlp_pack_w2_split
+    w2s, w2ts = pack(p["w2"]), pack(p["w2"], transposed=True)
     out, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2s, p["b2"], p["w3"], p["b3"], save=True,
                                                    save_h1=False, save_gate=True)
     full = hip.mlp_tower_backward(x, None, h2, dout, w2ts, p["w3"], p["w1"], p["b1"], gate2=gate)
@@ -348,8 +404,9 @@ def test_full_size_launch_equals_its_chunks(m, parts):
     assert torch.equal(o_inf, out[: 1 << 20])
 
 
-def test_split_kernels_are_deterministic_and_head_gradients_exact():
-    """Run-to-run determinism of every bf16-plane kernel at the rollout launch size (a
+@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+def test_split_kernels_are_deterministic_and_head_gradients_exact(scheme):
+    """Run-to-run determinism of every bf16- / fp16-plane kernel at the rollout launch size (a
     property the fixed summation orders promise), and the head gradients against fp64.
 
     Not a hazard hunt: the round-1 wrong-dW3 event is closed from its instruction
@@ -362,7 +419,8 @@ def test_split_kernels_are_deterministic_and_head_gradients_exact():
     x = torch.empty(m, 1, device=DEV).uniform_(-3, 3, generator=g)
     p = _params(g, 1, 2)
     dout = torch.randn(m, 2, device=DEV, generator=g) / m
-    w2s, w2ts = hip.mlp_pack_w2_split(p["w2"]), hip.mlp_pack_w2_split(p["w2"], transposed=True)
+    pack = hip.mlp_pack_w2_f16 if scheme == "f16x2" else hip.mlp_pack_w2_split
+    w2s, w2ts = pack(p["w2"]), pack(p["w2"], transposed=True)
 
     def run():
         out, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2s, p["b2"], p["w3"], p["b3"], save=True,
@@ -400,9 +458,10 @@ def test_fp32_mfma_kernels_are_deterministic():
             assert torch.equal(a, b), trial
 
 
-def test_algorithm_agrees_between_the_two_tower_generations():
-    """collect() + step() with the bf16-plane towers against the same seeded run on
-    the fp32-MFMA towers: same actions, same statistics, losses to 1e-5 (the
+@pytest.mark.parametrize("planes", ["split", "f16"])
+def test_algorithm_agrees_between_the_tower_generations(planes):
+    """collect() + step() with the bf16-plane / fp16-plane towers against the same seeded
+    run on the fp32-MFMA towers: same actions, same statistics, losses to 1e-5 (the
     tolerance north_star sets against the reference's CPU path)."""
     from rl8_amd import AlgorithmConfig
     from rl8_amd.env import DiscreteDummyEnv
@@ -421,7 +480,7 @@ def test_algorithm_agrees_between_the_two_tower_generations():
         finally:
             fused_mlp.FORWARD_GEMM, fused_mlp.BACKWARD_GEMM = old
 
-    c_split, a_split, s_split = run("split")
+    c_split, a_split, s_split = run(planes)
     c_f32, a_f32, s_f32 = run("f32")
     assert torch.equal(a_split, a_f32)  # bit-exact action indices
     for k in c_f32:

@@ -131,6 +131,14 @@ def split_dgrad():  # data-gradient kernel alone (first half of the fused backwa
                                           _p(mlp_w3), 2, None, _p(_partials), C.byref(_rows), _p(mlp_gate), hip._stream())
 
 
+mlp_w2th = hip.mlp_pack_w2_f16(mlp_w2, transposed=True)
+
+
+def f16_dgrad():  # fp16-plane data-gradient kernel (fused mode)
+    _lib.rl8_mlp_tower_backward_f16_f32(_p(mlp_x), _p(mlp_w1), _p(mlp_b1), _p(mlp_dout), N, 1, _p(mlp_w2th), _p(mlp_w3), 2,
+                                        _p(_partials), C.byref(_rows), _p(mlp_gate), hip._stream())
+
+
 def split_wgrad_fused():  # weight-gradient kernel: re-forms dZ2 and h1, accumulates the head gradients
     _lib.rl8_mlp_wgrad_fused_split_f32(_p(mlp_h2), _p(mlp_dout), _p(mlp_x), _p(mlp_w1), _p(mlp_b1), _p(mlp_w3), N, 1, 2,
                                        _p(_ws), _p(_dw2), _p(_partials), hip._stream())
@@ -142,6 +150,7 @@ KERNELS = {
     "mlp_tower_forward_save_split": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2s, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False, save_gate=True), MLP_FLOP / 1000),
     "mlp_tower_forward_f16": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h, mlp_b2, mlp_w3, mlp_b3), MLP_FLOP / 1000),
     "mlp_tower_forward_save_f16": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False, save_gate=True), MLP_FLOP / 1000),
+    "mlp_tower_backward_f16": (f16_dgrad, MLP_FLOP / 1000),
     "mlp_tower_backward_split": (split_dgrad, MLP_FLOP / 1000),
     "mlp_wgrad_fused_split": (split_wgrad_fused, 2 * N * 65536 / 1000),
     "mlp_wgrad_split": (lambda: hip.mlp_wgrad_split(mlp_dz2, mlp_x, mlp_w1, mlp_b1), 2 * N * 65536 / 1000),
