@@ -369,8 +369,9 @@ int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, const flo
  * by the pack's, both undone on the accumulators.  Fills [dW1 | db1] of `*partial_rows_out`
  * partial rows (same layout and row count as the bf16-plane kernel); the caller follows with
  * rl8_mlp_wgrad_fused_split_f32 for dW2 and the head segments -- the weight gradient sums
- * over samples, where no per-row power of two can be taken out of the sum, and stays on
- * bf16 planes.  Replaces the autograd backward of the 256-256 towers
+ * over samples, where fp16's range cannot be recovered by a power of two per row, and stays
+ * on bf16 planes (two fp16 versions measured slower and less accurate: mlp_f16_kernels.hip).
+ * Replaces the autograd backward of the 256-256 towers
  * (rl8/algorithms/_feedforward.py:374-386 loss.backward()). */
 int rl8_mlp_backward_f16_supports(int d_in, int n_out);
 int rl8_mlp_tower_backward_f16_f32(const float *x, const float *w1, const float *b1, const float *dout,

@@ -628,13 +628,21 @@ static int dispatch_forward_f16_nout(int n_out, int grid, hipStream_t s, const f
 //   dZ1 = dH1 * (h1 > 0)           accumulator epilogue (scaling undone), folded into dW1 / db1.
 // Structure of mlp_tower_backward_split_kernel (mlp_split_kernels.hip), fused mode only:
 // the ReLU gate of h2 comes as bits (the forward kernel's save_gate2), dZ2 is not stored and
-// the head gradients are left to the weight-gradient kernel (rl8_mlp_wgrad_fused_split_f32,
-// which stays on bf16 planes: its reduction runs over SAMPLES, so a per-sample power of two
-// cannot be taken out of the sum, and with one power of two per launch the entries of dW2
-// whose terms all lie far below the launch's largest lose relative accuracy -- measured
-// 6e-5 of an entry's own sum of |terms| with rows 10^6 apart, against 7e-7 for bf16 planes;
-// tools/diag/f16_wgrad_mixed_rows.py -- while the kernel, VALU- and latency-bound on its
-// operand production, was no faster than the six-product one).
+// the head gradients are left to the weight-gradient kernel, rl8_mlp_wgrad_fused_split_f32 --
+// which stays on bf16 planes.  Two fp16 versions of it were built and measured (round 2):
+// its reduction runs over SAMPLES, so a power of two per sample can be taken out of the sum
+// only if the two operands' factors multiply to the same constant for every sample.
+//   * one power of two per operand and launch: 600 us per 2^20 rows against 586 for the
+//     six-product kernel, and entries of dW2 made only of small rows lose relative accuracy
+//     (6e-5 of the entry's own sum of |terms| with rows 10^6 apart; bf16 planes 7e-7);
+//   * per-sample factors 2^a(s), 2^b(s) with a(s) + b(s) constant, each operand placed half
+//     the sample's deficit below fp16's top (exponents from a streaming pre-pass, factors
+//     built by scalar integer arithmetic): 764 us, worst entry 4e-5 in the host model
+//     (tools/diag/f16_wgrad_mixed_rows.py; nearly dead units whose only terms are small).
+// Both operands of that kernel are produced on the VALU every step, so halving the MFMAs
+// leaves it bound by operand production (the fp16 split is three conversion instructions
+// per element and plane pair), while its accuracy depends on single elements, not on dot
+// products along a scaled row as here and in the forward kernel.
 // The row bound that places the planes in fp16's range is
 //   |dZ2[row][k]| <= sum_q |dOut[row][q]| * max_k |W3[q][k]|,
 // a function of the row's dOut alone, so the producer thread has it in registers.

@@ -955,7 +955,9 @@ def mlp_tower_backward(
     of h1 instead of reading h1 back. ``wgrad_split`` forms dW2 with the bf16-plane
     weight-gradient kernel (any width; needs ``w1``, ``b1``) even when the
     data-gradient half runs on the fp32 kernel. ``gate2`` (``save_gate`` of the
-    bf16-plane forward): gate bits of h2 for the data-gradient kernel."""
+    bf16-plane forward): gate bits of h2 for the data-gradient kernel. A pack from
+    ``mlp_pack_w2_f16(..., transposed=True)`` selects the fp16-plane data-gradient kernel
+    (fused mode: ``gate2`` required; the weight gradient stays on bf16 planes)."""
     m, d_in = x.shape
     n_out = w3.shape[0]
     split = w2t_packed.dtype == torch.uint8

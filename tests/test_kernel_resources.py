@@ -217,10 +217,10 @@ def test_compiled_lstm_split_kernels_resources(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_compiled_f16_forward_kernels_resources(tmp_path):
-    """The fp16 two-plane forward (mlp_f16_kernels.hip): no scratch, two workgroups per CU,
-    three v_mfma_f32_32x32x16_f16 per k-step and column block, no packed fp32 arithmetic and
-    no hand-issued load's destination touched before its wait."""
+def test_compiled_f16_kernels_resources(tmp_path):
+    """The fp16 two-plane forward and data-gradient kernels (mlp_f16_kernels.hip): no scratch,
+    two workgroups per CU, fp16 MFMAs only, no packed fp32 arithmetic and no hand-issued
+    load's destination touched before its wait."""
     csrc = os.path.join(ROOT, "rl8_amd", "csrc")
     asm = tmp_path / "mlp_f16.s"
     subprocess.run(
@@ -238,10 +238,10 @@ def test_compiled_f16_forward_kernels_resources(tmp_path):
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
         assert scratch == 0, (name, scratch)
-        if "mlp_tower_forward_f16_kernel" in name:
+        if "mlp_tower_forward_f16_kernel" in name or "mlp_tower_backward_f16_kernel" in name:
             assert vgprs <= 256 and lds <= 80 * 1024, (name, vgprs, lds)
             checked += 1
-    assert checked == 24  # d_in in {1, 2, 3, 5} x n_out in {1, 2, 3} x {inference, training}
-    assert_no_inflight_register_access(text, "mlp_tower_forward_f16_kernel", min_hand_loads=24 * 50)
+    assert checked == 24 + 12  # d_in in {1, 2, 3, 5} x n_out in {1, 2, 3} x {inference, training, data gradient}
+    assert_no_inflight_register_access(text, "mlp_tower_(forward|backward)_f16_kernel", min_hand_loads=36 * 50)
     for name, body in inflight.kernels_of(text):
         assert inflight.packed_war(body) == [], name
