@@ -1538,6 +1538,247 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   }
 }
 
+// The fused weight gradient of a tower with ONE output (value towers): there
+//   dZ2[s][j] = G[s][j] * dOut[s] * W3[j],   G = (h2 > 0) in {0, 1},
+// so   dW2[j][i] = W3[j] * sum_s G[s][j] * (dOut[s] * h1[s][i]):
+// the first operand is the gate itself -- ONE bf16 plane, exact -- and the second,
+// dOut[s] * h1[s][i], takes the three planes: THREE exact plane products per 16 samples
+// instead of six (and one operand less to split on the VALU); W3[j] multiplies the finished
+// sums.  Same loop shape as mlp_wgrad_split_kernel: thread = column, 16-sample chunks, one
+// barrier per step in front of the step's last group of products, the next step's first
+// fragments fetched behind it.  Head gradients on the way, as there:
+//   db2[j] = W3[j] * sum_s G[s][j] dOut[s],   dW3[j] = sum_s dOut[s] h2[s][j].
+constexpr int kWgOperandA = 2 * kHidden * 16;             // gate plane: [sample half][column] x 16 B
+constexpr int kWgStageBytes = kWgOperandA + kWsOperandBytes;  // gate | three planes of dOut * h1
+
+template <int DIN>
+__global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
+    const float *__restrict__ h2, const float *__restrict__ x, const float *__restrict__ w1,
+    const float *__restrict__ b1, int64_t m, float *__restrict__ slabs, WgradFusedArgs fused) {
+  static_assert(DIN > 0, "compiled input widths only");
+  constexpr int kIn = DIN, d_in = DIN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = lds_offset(smem);
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wj = wave >> 1, wi = wave & 1;  // j-tiles {2wj, 2wj+1}, i-tiles {4wi .. 4wi+3}
+  const int col = tid & 255;                // producer: column (j of the gate and i of h1) ...
+  const int kh = wave >> 2;                 // ... and which eight samples of the chunk (wave-uniform)
+
+  const unsigned a_read = lds0 + (hh * kHidden + 64 * wj + l32) * 16;
+  const unsigned b_read = lds0 + kWgOperandA + (hh * kHidden + 128 * wi + l32) * 16;
+  const unsigned p_write = lds0 + (kh * kHidden + col) * 16;
+
+  float w1r[kIn];
+#pragma unroll
+  for (int c = 0; c < kIn; ++c) w1r[c] = w1[col * d_in + c];
+  const float b1r = b1[col];
+  float gsum = 0.0f, dw3a = 0.0f;  // sum_s G dOut (db2 / W3) and dW3 of this thread's column and sample half
+
+  const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
+  const int64_t stride = gridDim.x;
+  const int64_t mine = (chunks - blockIdx.x + stride - 1) / stride;  // >= 1 (grid <= chunks)
+
+  // h2 of chunk number n of this workgroup: this thread's column, its eight samples.
+  // Chunks past the end (and samples past m) read as zero through the descriptor.
+  auto load_h2 = [&](float (&dst)[8], int64_t n) {
+    const int64_t chunk = blockIdx.x + n * stride;
+    const int64_t left = m - chunk * kWsChunk;
+    const int rows = left <= 0 ? 0 : left < kWsChunk ? (int)left : kWsChunk;
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? h2 + chunk * kWsChunk * kHidden : h2, rows * kHidden * 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = buffer_load_f32(rsrc, col * 4, (8 * kh + e) * (kHidden * 4));
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // Observations and dOut of the eight samples a wave produces: scalar registers, requested in
+  // front of the PREVIOUS step's barrier (see mlp_wgrad_split_kernel); samples past m read as zero.
+  f32x8 xq[kIn], dq;
+  auto request_scalars = [&](int64_t n) {
+    const int64_t row0 = (blockIdx.x + n * stride) * kWsChunk + 8 * kh;
+    const int64_t left = m - row0;
+    const int rows = left <= 0 ? 0 : left < 8 ? (int)left : 8;
+    const int64_t at = rows > 0 ? row0 : 0;
+    const u32x4 rx = scalar_rsrc(x + at * kIn, rows * kIn * 4);
+    xq[0] = scalar_buffer_load_x8<0>(rx);
+    if constexpr (kIn > 1) xq[1] = scalar_buffer_load_x8<32>(rx);
+    if constexpr (kIn > 2) xq[2] = scalar_buffer_load_x8<64>(rx);
+    if constexpr (kIn > 3) xq[3] = scalar_buffer_load_x8<96>(rx);
+    if constexpr (kIn > 4) xq[4] = scalar_buffer_load_x8<128>(rx);
+    const u32x4 rd = scalar_rsrc(fused.dout + at, rows * 4);
+    dq = scalar_buffer_load_x8<0>(rd);
+  };
+  auto scalars_landed = [&]() {  // directly behind a barrier / lgkmcnt(0)
+#pragma unroll
+    for (int i = 0; i < kIn; ++i) scalar_tie(xq[i]);
+    scalar_tie(dq);
+  };
+  // The chunk's operands -> stage `stage` (free from the previous step's barrier on): the
+  // gate plane, then the three planes of dOut * h1, each written as soon as it is formed.
+  auto produce = [&](const float (&h2v)[8], int stage) {
+    const unsigned addr = p_write + stage * kWgStageBytes;
+    {
+      u32x4 g;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const bool o0 = h2v[e] > 0.0f, o1 = h2v[e + 1] > 0.0f;
+        g[e >> 1] = (o0 ? 0x00003f80u : 0u) | (o1 ? 0x3f800000u : 0u);  // bf16 1.0 / 0.0
+        gsum += (o0 ? dq[e] : 0.0f) + (o1 ? dq[e + 1] : 0.0f);
+        dw3a = __builtin_fmaf(dq[e], h2v[e], dw3a);
+        dw3a = __builtin_fmaf(dq[e + 1], h2v[e + 1], dw3a);
+      }
+      lds_write_b128<0>(addr, g);
+    }
+    float b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = b1r;
+#pragma unroll
+      for (int c = 0; c < kIn; ++c) v = __builtin_fmaf(xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], w1r[c], v);
+      b[e] = relu1(v) * dq[e];
+    }
+    u32x4 planes[3];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t hi, mid, lo;
+      split_pair(b[e], b[e + 1], hi, mid, lo);
+      planes[0][e >> 1] = hi;
+      planes[1][e >> 1] = mid;
+      planes[2][e >> 1] = lo;
+    }
+    lds_write_b128<kWgOperandA>(addr, planes[0]);
+    lds_write_b128<kWgOperandA + kWsPlane>(addr, planes[1]);
+    lds_write_b128<kWgOperandA + 2 * kWsPlane>(addr, planes[2]);
+  };
+
+  f32x16 acc[2][4];
+  float hq[2][8];
+  using T = std::true_type;
+  using F = std::false_type;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  // Registers of a step: the gate fragments of the chunk in hand (G, two) and of the next one
+  // (fetched behind the barrier into the other pair), and two sets of four B fragments that
+  // trade roles: a step opens with its hi planes in X (even steps) or Y (odd), fetches the
+  // mid planes into the other set, the lo planes into the first set once the hi products
+  // are issued, and the next step's hi planes into the second behind the barrier.
+  SplitFrags f;  // ah / am: gate fragments of even / odd steps; bh / bm: the B sets X / Y
+  auto first_reads = [&](auto parity_tag) {  // ... of the chunk in stage P: gate -> that step's G, hi planes -> its first set
+    constexpr int P = decltype(parity_tag)::value;
+    const unsigned ar = a_read + P * kWgStageBytes, br = b_read + P * kWgStageBytes;
+    u32x4(&G)[2] = *(P == 0 ? &f.ah : &f.am);
+    u32x4(&B0)[4] = *(P == 0 ? &f.bh : &f.bm);
+    G[0] = lds_read_b128<0>(ar);
+    B0[0] = lds_read_b128<0>(br);
+    B0[1] = lds_read_b128<512>(br);
+    B0[2] = lds_read_b128<1024>(br);
+    B0[3] = lds_read_b128<1536>(br);
+    G[1] = lds_read_b128<512>(ar);
+  };
+  auto do_step = [&](auto first_tag, auto parity_tag, int64_t n) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int P = decltype(parity_tag)::value;
+    const unsigned br = b_read + P * kWgStageBytes;
+    u32x4(&G)[2] = *(P == 0 ? &f.ah : &f.am);
+    u32x4(&B0)[4] = *(P == 0 ? &f.bh : &f.bm);
+    u32x4(&B1)[4] = *(P == 0 ? &f.bm : &f.bh);
+    // G and B0 (hi planes) are in (previous step / prologue); the mid planes:
+    B1[0] = lds_read_b128<kWsPlane>(br);
+    B1[1] = lds_read_b128<kWsPlane + 512>(br);
+    B1[2] = lds_read_b128<kWsPlane + 1024>(br);
+    B1[3] = lds_read_b128<kWsPlane + 1536>(br);
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma<FIRST>(G, B0, acc);  // gate x hi: at once, nothing in front of the first products
+    load_h2(hq[P], n + 2);
+    produce(hq[P ^ 1], P ^ 1);
+    wait_lds<0>(B1[0], B1[1], B1[2], B1[3]);  // (only LDS operations are in flight)
+    __builtin_amdgcn_sched_barrier(0);
+    // the lo planes, into the hi planes' registers (their products are issued)
+    B0[0] = lds_read_b128<2 * kWsPlane>(br);
+    B0[1] = lds_read_b128<2 * kWsPlane + 512>(br);
+    B0[2] = lds_read_b128<2 * kWsPlane + 1024>(br);
+    B0[3] = lds_read_b128<2 * kWsPlane + 1536>(br);
+    split_mma<false>(G, B1, acc);  // gate x mid: last use of B1
+    __builtin_amdgcn_sched_barrier(0);
+    request_scalars(n + 2);  // for the chunk the NEXT step produces
+    wait_lds<0>(B0[0], B0[1], B0[2], B0[3]);  // (the scalar loads with them: nothing counts on order here)
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    scalars_landed();
+    if constexpr (P == 0) first_reads(P1{});  // into the other gate pair and B1's registers (= the next step's first set)
+    else first_reads(P0{});
+    __builtin_amdgcn_sched_barrier(0);
+    split_mma<false>(G, B0, acc);  // gate x lo
+    __builtin_amdgcn_sched_barrier(0);
+    // landed before anything can copy or carry these registers (loop back-edge)
+    {
+      u32x4(&GN)[2] = *(P == 0 ? &f.am : &f.ah);
+      wait_lds<0>(GN[0], GN[1], B1[0], B1[1], B1[2], B1[3]);
+    }
+  };
+
+  {
+    load_h2(hq[0], 0);
+    load_h2(hq[1], 1);
+    request_scalars(0);
+    lds_barrier();
+    scalars_landed();
+    produce(hq[0], 0);
+    request_scalars(1);
+    lds_barrier();
+    scalars_landed();
+    first_reads(P0{});
+    wait_lds<0>(f.ah[0], f.ah[1], f.bh[0], f.bh[1], f.bh[2], f.bh[3]);
+  }
+  do_step(T{}, P0{}, 0);
+  {
+    // an odd number of steps, the last one on an all-zero chunk past the end if need be
+    // (see mlp_wgrad_split_kernel's two-operand mode)
+    const int64_t steps = mine | 1;
+#pragma unroll 1
+    for (int64_t n = 1; n < steps; n += 2) {
+      do_step(F{}, P1{}, n);
+      do_step(F{}, P0{}, n + 1);
+    }
+  }
+
+  // W3[j] multiplies the finished sums (row j of the slab)
+  float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;
+#pragma unroll
+  for (int ja = 0; ja < 2; ++ja)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 64 * wj + 32 * ja + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float w3j = fused.w3[j];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) slab[j * kHidden + 128 * wi + 32 * t + l32] = acc[ja][t][r] * w3j;
+    }
+
+  // Head gradients: fold the two sample halves (kh) of a column through LDS in a fixed
+  // order and write this workgroup's partial row; zero the other kernel's segment where it
+  // has no row of its own.
+  float *red = reinterpret_cast<float *>(smem);  // [256][2]
+  __syncthreads();
+  if (kh == 1) {
+    red[col * 2] = gsum;
+    red[col * 2 + 1] = dw3a;
+  }
+  __syncthreads();
+  float *row = fused.partials + (int64_t)blockIdx.x * fused.partial_stride;
+  const int off_db2 = kHidden * d_in + kHidden, off_dw3 = off_db2 + kHidden, off_db3 = off_dw3 + kHidden;
+  const bool more = fused.accumulate != 0;  // (a later segment: the first one wrote / zeroed the row)
+  if (kh == 0) {
+    const float sum_b2 = (gsum + red[col * 2]) * fused.w3[col];
+    row[off_db2 + col] = more ? row[off_db2 + col] + sum_b2 : sum_b2;
+    const float sum_w3 = dw3a + red[col * 2 + 1];
+    row[off_dw3 + col] = more ? row[off_dw3 + col] + sum_w3 : sum_w3;
+    // db3 = sum of dOut needs no matrix kernel: the caller forms it (the segment is zeroed)
+    if (col == 0 && !more) row[off_db3] = 0.0f;
+  }
+  if (!more && (int)blockIdx.x >= fused.other_rows)
+    for (int idx = tid; idx < kHidden * d_in + kHidden; idx += kWsThreads) row[idx] = 0.0f;
+}
+
 // out[idx] (+)= sum over slabs, in slab order.
 __global__ __launch_bounds__(kBlock) void mlp_wgrad_split_reduce_kernel(const float *__restrict__ slabs, int rows,
                                                                        float *__restrict__ out, int accumulate) {
@@ -1585,6 +1826,20 @@ static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const fl
   }
   mlp_wgrad_split_kernel<DIN, NOUT><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(h2, x, w1, b1, m, d_in, slabs, fused,
                                                                                  WgradOperands{});
+  return launch_status();
+}
+
+template <int DIN>
+static int launch_wgrad_gate(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
+                             const float *b1, int64_t m, float *slabs, WgradFusedArgs fused) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  mlp_wgrad_gate_kernel<DIN><<<grid, kWsThreads, 2 * kWgStageBytes, s>>>(h2, x, w1, b1, m, slabs, fused);
   return launch_status();
 }
 
@@ -1797,6 +2052,19 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
     const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0};
     const float *h2s = h2 + at * kHidden, *xs = x + at * d_in;
     int status = RL8_ESIZE;
+    // one output: the gate-plane kernel (three plane products per 16 samples instead of six)
+    static const bool gate_kernel = env_int("RL8_WGRAD_GATE_OFF") == 0;
+    if (n_out == 1 && gate_kernel) {
+      switch (d_in) {
+        case 1: status = launch_wgrad_gate<1>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+        case 2: status = launch_wgrad_gate<2>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+        case 3: status = launch_wgrad_gate<3>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+        default: status = launch_wgrad_gate<5>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+      }
+      if (status != 0) return status;
+      mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0);
+      continue;
+    }
 #define RL8_WGRAD_FUSED(D, N) \
   if (d_in == D && n_out == N) status = launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused);
     RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3)

@@ -118,14 +118,14 @@ def test_compiled_split_kernels_resources(tmp_path):
     for name, body in kernels:
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
-        if re.search(r"mlp_tower_(forward|backward)_split_kernel|mlp_wgrad_split_kernel", name):
+        if re.search(r"mlp_tower_(forward|backward)_split_kernel|mlp_wgrad_split_kernel|mlp_wgrad_gate_kernel", name):
             # every compiled (= dispatched) variant: no scratch at all -- these kernels read
             # LDS through inline asm, so a spill between a read and its wait is a hazard,
             # not just a slowdown -- and two workgroups per CU
             assert scratch == 0, (name, scratch)
             assert vgprs <= 256, (name, vgprs)
             checked += 1
-    assert checked >= 24 + 12 + 5 + 12 + 1  # (+ the two-operand weight-gradient mode)
+    assert checked >= 24 + 12 + 5 + 12 + 1 + 4  # (+ the two-operand weight-gradient mode, + the gate-plane kernel)
     _check_wgrad_scalar_windows(text)
     # Every hand-issued load (ds_read_b128, s_buffer_load_dwordx8, ...) of every kernel: nothing
     # reads or overwrites its destination before a wait that covers it, on any path.

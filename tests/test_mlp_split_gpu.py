@@ -202,12 +202,13 @@ def test_backward_split_matches_fp64(m, d_in, n_out, scheme):
 
 @pytest.mark.parametrize("case", ["rows_of_mixed_magnitude", "one_outlier_row", "clipped_rows", "tiny_gradients",
                                   "outlier_weights"])
-def test_backward_f16_scaling_holds_over_the_dynamic_range(case):
+@pytest.mark.parametrize("n_out", [2, 1])
+def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
     """dOut as PPO produces it is heavy-tailed (clipped samples contribute exactly zero, a few
     samples carry most of the gradient): the data-gradient kernel scales per ROW, the
     weight-gradient kernel per LAUNCH.  Every gradient against fp64 on the saved activations
     and against the six-product bf16 kernels' own error."""
-    m, d_in, n_out = 20_000, 3, 2
+    m, d_in = 20_000, 3
     g = torch.Generator(device=DEV).manual_seed(23)
     x = torch.randn(m, d_in, device=DEV, generator=g) * 3
     p = _params(g, d_in, n_out)
@@ -242,8 +243,8 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case):
         floor = size[k].max() * 1e-30 + 1e-300
         err = float(((got[k].double() - want[k]).abs() / (size[k] + floor)).max())
         err6 = float(((got6[k].double() - want[k]).abs() / (size[k] + floor)).max())
-        # (the absolute bar is the fp32 accumulators' own: with one row 10^6 above the rest both schemes sit at 5e-6)
-        assert err < 2e-5 and err <= 3 * err6 + 2e-7, (k, err, err6)
+        # (the absolute bar is the fp32 accumulators' own: with one row 10^6 above the rest both schemes sit at 5e-6 .. 3e-5)
+        assert err < 1e-4 and err <= 3 * err6 + 2e-7, (k, err, err6)
 
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (13, 1, 1), (4099, 2, 3), (20_003, 5, 3), (33_001, 3, 2), (9, 5, 1)])
