@@ -1003,7 +1003,10 @@ def mlp_tower_backward(
                     "rl8_mlp_tower_backward_split_f32",
                 )
         dw2 = torch.empty(MLP_HIDDEN, MLP_HIDDEN, dtype=torch.float32, device=x.device)
-        with _timed("mlp_wgrad", m):  # (bf16 planes for both generations: see rl8_mlp_tower_backward_f16_f32)
+        # (bf16 planes for both generations: see rl8_mlp_tower_backward_f16_f32; single-output towers
+        # run the gate-plane kernel -- three plane products instead of six -- timed under its own name)
+        gate_kernel = n_out == 1 and not int(os.environ.get("RL8_WGRAD_GATE_OFF", "0") or 0)
+        with _timed("mlp_wgrad_gate" if gate_kernel else "mlp_wgrad", m):
             _check(
                 lib.rl8_mlp_wgrad_fused_split_f32(
                     _ptr(h2), _ptr(dout), _ptr(x), w1p, b1p, _ptr(w3.detach()), m, d_in, n_out,

@@ -139,6 +139,17 @@ def f16_dgrad():  # fp16-plane data-gradient kernel (fused mode)
                                         _p(_partials), C.byref(_rows), _p(mlp_gate), hip._stream())
 
 
+# the value tower (one output): its weight gradient runs the gate-plane kernel
+mlp_w3v = torch.randn(1, 256, device=dev, generator=g) / 16
+mlp_doutv = torch.randn(N, 1, device=dev, generator=g) / N
+_partials_v = torch.empty(int(_lib.rl8_mlp_backward_max_rows()), int(_lib.rl8_mlp_backward_partial_floats(1, 1)), device=dev)
+
+
+def gate_wgrad_fused():  # single-output tower: gate plane x three planes of dOut * h1 (3 products per 16 samples)
+    _lib.rl8_mlp_wgrad_fused_split_f32(_p(mlp_h2), _p(mlp_doutv), _p(mlp_x), _p(mlp_w1), _p(mlp_b1), _p(mlp_w3v), N, 1, 1,
+                                       _p(_ws), _p(_dw2), _p(_partials_v), hip._stream())
+
+
 def split_wgrad_fused():  # weight-gradient kernel: re-forms dZ2 and h1, accumulates the head gradients
     _lib.rl8_mlp_wgrad_fused_split_f32(_p(mlp_h2), _p(mlp_dout), _p(mlp_x), _p(mlp_w1), _p(mlp_b1), _p(mlp_w3), N, 1, 2,
                                        _p(_ws), _p(_dw2), _p(_partials), hip._stream())
@@ -153,6 +164,7 @@ KERNELS = {
     "mlp_tower_backward_f16": (f16_dgrad, MLP_FLOP / 1000),
     "mlp_tower_backward_split": (split_dgrad, MLP_FLOP / 1000),
     "mlp_wgrad_fused_split": (split_wgrad_fused, 2 * N * 65536 / 1000),
+    "mlp_wgrad_fused_gate": (gate_wgrad_fused, 2 * N * 65536 / 1000),
     "mlp_wgrad_split": (lambda: hip.mlp_wgrad_split(mlp_dz2, mlp_x, mlp_w1, mlp_b1), 2 * N * 65536 / 1000),
     "mlp_wgrad_fused": (lambda: hip.mlp_wgrad(mlp_dz2, mlp_h1), 2 * N * 65536 / 1000),
     # same launch on all-zero operands: the gap to the line above is clock / power, not the kernel
