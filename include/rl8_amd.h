@@ -362,6 +362,18 @@ int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, const flo
                                   const float *w3, const float *b3, int n_out, float *out,
                                   float *save_h1, float *save_h2, uint32_t *save_gate2, void *stream);
 
+/* A head of TWO outputs whose gradients are exact negatives of each other (a two-way categorical:
+ * rl8_ppo_loss_categorical_fwd_bwd_f32 emits them so) has dZ2 = gate * dOut[.][0] * (W3[0] - W3[1]):
+ * the weight gradient then needs one binary operand and three plane products per 16 samples
+ * instead of six (as for single-output towers, which rl8_mlp_wgrad_fused_split_f32 handles by
+ * itself).  rl8_mlp_dout_pair_check leaves 0 in *flag_out (device int) iff dout [m][2] has
+ * dout[s][1] == -dout[s][0] bit for bit in every row; only then may rl8_mlp_wgrad_fused_pair_f32
+ * replace rl8_mlp_wgrad_fused_split_f32(..., n_out = 2, ...): same arguments, same outputs. */
+int rl8_mlp_dout_pair_check(const float *dout /*[m][2]*/, int64_t m, int *flag_out /*device*/, void *stream);
+int rl8_mlp_wgrad_fused_pair_f32(const float *h2, const float *dout, const float *x, const float *w1,
+                                 const float *b1, const float *w3, int64_t m, int d_in,
+                                 float *workspace, float *dw2_out, float *partials, void *stream);
+
 /* The data-gradient half of the fused backward pass on the same fp16 planes (three MFMAs
  * per 16 k): the fused mode of rl8_mlp_tower_backward_split_f32 (no dZ2 store; gate2 -- the
  * forward's save_gate2 -- is required; w2t_f16 from rl8_mlp_pack_w2_f16(..., transposed = 1)).

@@ -51,6 +51,19 @@ __device__ __forceinline__ int f16_bound_exponent(float bound) {
 // accumulators: lane = row; see split_mma_t).
 template <bool FIRST>
 __device__ __forceinline__ void f16_mma_t(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
+  if constexpr ((kSplitDiagSkip & 2048) != 0) {  // tuning builds: no matrix work (one MFMA per group keeps the data flow)
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, b[0]), __builtin_bit_cast(half8, a[0]),
+                                                       FIRST ? zero : acc[0][0], 0, 0, 0);
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (mt + nt) acc[mt][nt] = acc[0][0];
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -207,7 +220,12 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   };
 
   // Chunk `ks` of the producer's tile -> stage `stage`.
+  [[maybe_unused]] int diag_b_loads = 0;  // (tuning builds, bit 2^20: only the first two chunks are loaded -- no L2 latency in the steps)
   auto request_b = [&](int ks, int stage) {
+    if constexpr ((kSplitDiagSkip & (1 << 20)) != 0) {
+      if (diag_b_loads >= 2) return;
+      ++diag_b_loads;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int block = wave * 4 + u;  // 16 one-KiB blocks per step, four per wave
@@ -233,6 +251,14 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
         dst[0] = f32x4{h[0], h[1], h[2], h[3]};
         dst[1] = f32x4{h[4], h[5], h[6], h[7]};
       }
+    }
+    if constexpr ((kSplitDiagSkip & (1 << 21)) != 0) {  // tuning builds: no split arithmetic
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        planes[0][e >> 1] = __float_as_uint(h[e]);
+        planes[1][e >> 1] = __float_as_uint(h[e + 1]);
+      }
+      return;
     }
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {  // scaled by this row's power of two (exact), then hi + lo in fp16
@@ -734,7 +760,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
     p_scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
     if (tid < kSplitRows) lds_write_b32(scale_lds + (p_parity * kSplitRows + prow) * 4, __builtin_amdgcn_ldexpf(inv_w2_scale, e - kF16Top));
   };
+  [[maybe_unused]] int diag_b_loads = 0;  // (tuning builds, bit 2^20: only the first two chunks are loaded)
   auto request_b = [&](int ks, int stage) {
+    if constexpr ((kSplitDiagSkip & (1 << 20)) != 0) {
+      if (diag_b_loads >= 2) return;
+      ++diag_b_loads;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int block = wave * 4 + u;

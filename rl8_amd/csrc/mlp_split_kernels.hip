@@ -1548,10 +1548,14 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 // barrier per step in front of the step's last group of products, the next step's first
 // fragments fetched behind it.  Head gradients on the way, as there:
 //   db2[j] = W3[j] * sum_s G[s][j] dOut[s],   dW3[j] = sum_s dOut[s] h2[s][j].
+// PAIR: the same for a head of TWO outputs whose gradients are exact negatives of each other,
+// dOut[s][1] == -dOut[s][0] (a two-way categorical: the loss kernel makes it exact; the host
+// checks it on the data before choosing this kernel): dZ2 = G * dOut[s][0] * (W3[0] - W3[1]),
+// and dW3[1] = -dW3[0].  dOut is then [m][2] and column 0 is taken.
 constexpr int kWgOperandA = 2 * kHidden * 16;             // gate plane: [sample half][column] x 16 B
 constexpr int kWgStageBytes = kWgOperandA + kWsOperandBytes;  // gate | three planes of dOut * h1
 
-template <int DIN>
+template <int DIN, bool PAIR = false>
 __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     const float *__restrict__ h2, const float *__restrict__ x, const float *__restrict__ w1,
     const float *__restrict__ b1, int64_t m, float *__restrict__ slabs, WgradFusedArgs fused) {
@@ -1593,6 +1597,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   // Observations and dOut of the eight samples a wave produces: scalar registers, requested in
   // front of the PREVIOUS step's barrier (see mlp_wgrad_split_kernel); samples past m read as zero.
   f32x8 xq[kIn], dq;
+  [[maybe_unused]] f32x8 dq_hi;  // PAIR: the samples' (g0, g1) pairs, sixteen dwords
+  auto dout_of = [&](int e) { return PAIR ? (e < 4 ? dq[2 * e] : dq_hi[2 * e - 8]) : dq[e]; };
   auto request_scalars = [&](int64_t n) {
     const int64_t row0 = (blockIdx.x + n * stride) * kWsChunk + 8 * kh;
     const int64_t left = m - row0;
@@ -1604,13 +1610,15 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     if constexpr (kIn > 2) xq[2] = scalar_buffer_load_x8<64>(rx);
     if constexpr (kIn > 3) xq[3] = scalar_buffer_load_x8<96>(rx);
     if constexpr (kIn > 4) xq[4] = scalar_buffer_load_x8<128>(rx);
-    const u32x4 rd = scalar_rsrc(fused.dout + at, rows * 4);
+    const u32x4 rd = scalar_rsrc(fused.dout + at * (PAIR ? 2 : 1), rows * (PAIR ? 8 : 4));
     dq = scalar_buffer_load_x8<0>(rd);
+    if constexpr (PAIR) dq_hi = scalar_buffer_load_x8<32>(rd);
   };
   auto scalars_landed = [&]() {  // directly behind a barrier / lgkmcnt(0)
 #pragma unroll
     for (int i = 0; i < kIn; ++i) scalar_tie(xq[i]);
     scalar_tie(dq);
+    if constexpr (PAIR) scalar_tie(dq_hi);
   };
   // The chunk's operands -> stage `stage` (free from the previous step's barrier on): the
   // gate plane, then the three planes of dOut * h1, each written as soon as it is formed.
@@ -1622,9 +1630,9 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
       for (int e = 0; e < 8; e += 2) {
         const bool o0 = h2v[e] > 0.0f, o1 = h2v[e + 1] > 0.0f;
         g[e >> 1] = (o0 ? 0x00003f80u : 0u) | (o1 ? 0x3f800000u : 0u);  // bf16 1.0 / 0.0
-        gsum += (o0 ? dq[e] : 0.0f) + (o1 ? dq[e + 1] : 0.0f);
-        dw3a = __builtin_fmaf(dq[e], h2v[e], dw3a);
-        dw3a = __builtin_fmaf(dq[e + 1], h2v[e + 1], dw3a);
+        gsum += (o0 ? dout_of(e) : 0.0f) + (o1 ? dout_of(e + 1) : 0.0f);
+        dw3a = __builtin_fmaf(dout_of(e), h2v[e], dw3a);
+        dw3a = __builtin_fmaf(dout_of(e + 1), h2v[e + 1], dw3a);
       }
       lds_write_b128<0>(addr, g);
     }
@@ -1634,7 +1642,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
       float v = b1r;
 #pragma unroll
       for (int c = 0; c < kIn; ++c) v = __builtin_fmaf(xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], w1r[c], v);
-      b[e] = relu1(v) * dq[e];
+      b[e] = relu1(v) * dout_of(e);
     }
     u32x4 planes[3];
 #pragma unroll
@@ -1742,14 +1750,15 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     }
   }
 
-  // W3[j] multiplies the finished sums (row j of the slab)
+  // W3[j] (PAIR: W3[0][j] - W3[1][j]) multiplies the finished sums (row j of the slab)
+  auto w3_of = [&](int j) { return PAIR ? fused.w3[j] - fused.w3[kHidden + j] : fused.w3[j]; };
   float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;
 #pragma unroll
   for (int ja = 0; ja < 2; ++ja)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = 64 * wj + 32 * ja + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      const float w3j = fused.w3[j];
+      const float w3j = w3_of(j);
 #pragma unroll
       for (int t = 0; t < 4; ++t) slab[j * kHidden + 128 * wi + 32 * t + l32] = acc[ja][t][r] * w3j;
     }
@@ -1765,15 +1774,17 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   }
   __syncthreads();
   float *row = fused.partials + (int64_t)blockIdx.x * fused.partial_stride;
-  const int off_db2 = kHidden * d_in + kHidden, off_dw3 = off_db2 + kHidden, off_db3 = off_dw3 + kHidden;
+  constexpr int kOut = PAIR ? 2 : 1;
+  const int off_db2 = kHidden * d_in + kHidden, off_dw3 = off_db2 + kHidden, off_db3 = off_dw3 + kOut * kHidden;
   const bool more = fused.accumulate != 0;  // (a later segment: the first one wrote / zeroed the row)
   if (kh == 0) {
-    const float sum_b2 = (gsum + red[col * 2]) * fused.w3[col];
+    const float sum_b2 = (gsum + red[col * 2]) * w3_of(col);
     row[off_db2 + col] = more ? row[off_db2 + col] + sum_b2 : sum_b2;
     const float sum_w3 = dw3a + red[col * 2 + 1];
     row[off_dw3 + col] = more ? row[off_dw3 + col] + sum_w3 : sum_w3;
+    if constexpr (PAIR) row[off_dw3 + kHidden + col] = more ? row[off_dw3 + kHidden + col] - sum_w3 : -sum_w3;
     // db3 = sum of dOut needs no matrix kernel: the caller forms it (the segment is zeroed)
-    if (col == 0 && !more) row[off_db3] = 0.0f;
+    if (col < kOut && !more) row[off_db3 + col] = 0.0f;
   }
   if (!more && (int)blockIdx.x >= fused.other_rows)
     for (int idx = tid; idx < kHidden * d_in + kHidden; idx += kWsThreads) row[idx] = 0.0f;
@@ -1829,18 +1840,30 @@ static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const fl
   return launch_status();
 }
 
-template <int DIN>
+template <int DIN, bool PAIR = false>
 static int launch_wgrad_gate(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
                              const float *b1, int64_t m, float *slabs, WgradFusedArgs fused) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN, PAIR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_wgrad_gate_kernel<DIN><<<grid, kWsThreads, 2 * kWgStageBytes, s>>>(h2, x, w1, b1, m, slabs, fused);
+  mlp_wgrad_gate_kernel<DIN, PAIR><<<grid, kWsThreads, 2 * kWgStageBytes, s>>>(h2, x, w1, b1, m, slabs, fused);
   return launch_status();
+}
+
+// flag[0] |= 1 if any row has dout[s][0] + dout[s][1] != 0 (bit patterns: g1 must be exactly -g0).
+__global__ __launch_bounds__(kBlock) void dout_pair_check_kernel(const uint32_t *__restrict__ dout, int64_t m,
+                                                               int *__restrict__ flag) {
+  bool bad = false;
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (int64_t)gridDim.x * kBlock) {
+    const uint2 v = reinterpret_cast<const uint2 *>(dout)[r];
+    // exact negatives: equal magnitudes, opposite signs -- or both zeros of any sign
+    bad |= !(((v.x ^ v.y) == 0x80000000u) || (((v.x | v.y) & 0x7fffffffu) == 0u));
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 }  // namespace rl8
@@ -2072,6 +2095,52 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
     RL8_WGRAD_FUSED(3, 1) RL8_WGRAD_FUSED(3, 2) RL8_WGRAD_FUSED(3, 3)
     RL8_WGRAD_FUSED(5, 1) RL8_WGRAD_FUSED(5, 2) RL8_WGRAD_FUSED(5, 3)
 #undef RL8_WGRAD_FUSED
+    if (status != 0) return status;
+    mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0);
+  }
+  return launch_status();
+}
+
+/* dout [m][2]: *flag_out (device int, zeroed here) becomes 1 unless dout[s][1] == -dout[s][0] bit for bit in every row. */
+RL8_API int rl8_mlp_dout_pair_check(const float *dout, int64_t m, int *flag_out, void *stream) {
+  if (!dout || !flag_out) return RL8_ENULL;
+  if (m <= 0) return RL8_ESIZE;
+  if (((uintptr_t)dout & 7) != 0) return RL8_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const hipError_t err = hipMemsetAsync(flag_out, 0, sizeof(int), s);
+  if (err != hipSuccess) return (int)err;
+  const int64_t blocks = (m + kBlock - 1) / kBlock;
+  dout_pair_check_kernel<<<(int)(blocks < 8 * kCUs ? blocks : 8 * kCUs), kBlock, 0, s>>>(
+      reinterpret_cast<const uint32_t *>(dout), m, flag_out);
+  return launch_status();
+}
+
+/* rl8_mlp_wgrad_fused_split_f32 for a head of two outputs whose gradients are exact negatives
+ * (dout[s][1] == -dout[s][0]: rl8_mlp_dout_pair_check): the gate-plane kernel, three plane
+ * products per 16 samples instead of six. */
+RL8_API int rl8_mlp_wgrad_fused_pair_f32(const float *h2, const float *dout, const float *x, const float *w1,
+                                         const float *b1, const float *w3, int64_t m, int d_in,
+                                         float *workspace, float *dw2_out, float *partials, void *stream) {
+  if (!h2 || !dout || !x || !w1 || !b1 || !w3 || !workspace || !dw2_out || !partials) return RL8_ENULL;
+  if (m <= 0 || !rl8_mlp_backward_split_supports(d_in, 2)) return RL8_ESIZE;
+  if (!aligned16(h2) || !aligned16(workspace) || !aligned16(dw2_out) || ((uintptr_t)dout & 7) != 0) return RL8_EALIGN;
+  int g1, g2;
+  fused_backward_grids(m, &g1, &g2);
+  const int stride = (int)rl8_mlp_backward_partial_floats(d_in, 2);
+  hipStream_t s = (hipStream_t)stream;
+  for (int64_t at = 0; at < m; at += kWgradSegmentRows) {  // segments summed in order, as rl8_mlp_wgrad_fused_split_f32
+    const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
+    const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
+    const int grid = at == 0 ? g2 : (int)(chunks < g2 ? chunks : g2);
+    const WgradFusedArgs fused{dout + at * 2, w3, partials, stride, g1, at > 0};
+    const float *h2s = h2 + at * kHidden, *xs = x + at * d_in;
+    int status;
+    switch (d_in) {
+      case 1: status = launch_wgrad_gate<1, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+      case 2: status = launch_wgrad_gate<2, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+      case 3: status = launch_wgrad_gate<3, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+      default: status = launch_wgrad_gate<5, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+    }
     if (status != 0) return status;
     mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0);
   }

@@ -134,6 +134,16 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
           if (with_entropy) gj -= hp.entropy_coeff * (-p[j] * (nl[j] + ent));
           gx[s * K + j] = hp.grad_scale * gj;
         }
+        if constexpr (K == 2) {
+          // A two-way categorical depends on the logit DIFFERENCE only, so its two gradients are
+          // exact negatives in real arithmetic; the two fp32 evaluations above differ in their last
+          // bits.  Their antisymmetric mean is as close to either and makes the property exact,
+          // which the weight-gradient kernel of a two-output head relies on (rl8_mlp_wgrad_fused_pair_f32:
+          // dZ2 = gate * g0 * (W3[0] - W3[1]), one binary operand instead of a dense one).
+          const float g = 0.5f * (gx[s * K] - gx[s * K + 1]);
+          gx[s * K] = g;
+          gx[s * K + 1] = -g;
+        }
       }
     }
 #pragma unroll
@@ -211,6 +221,12 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_generic_kernel(
           float gj = -pt.dterm_dlogp * dlogp;
           if (with_entropy) gj -= hp.entropy_coeff * (-p[j] * (nl[j] + hd));
           grad_logits[(i * a + d) * k + j] = hp.grad_scale * gj;
+        }
+        if (k == 2) {  // exact antisymmetry of a two-way categorical's gradients (see the K = 2 kernel above)
+          float *gp = grad_logits + (i * a + d) * 2;
+          const float g = 0.5f * (gp[0] - gp[1]);
+          gp[0] = g;
+          gp[1] = -g;
         }
       }
     }

@@ -149,6 +149,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_backward_f16_supports": [_i32, _i32],
     "rl8_mlp_tower_backward_f16_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, C.POINTER(C.c_int), _vp, _vp],
+    "rl8_mlp_dout_pair_check": [_vp, _i64, _vp, _vp],
+    "rl8_mlp_wgrad_fused_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_f16_packed_bytes": [],
     "rl8_mlp_forward_f16_supports": [_i32, _i32],
     "rl8_mlp_pack_w2_f16": [_vp, _i32, _vp, _vp],
@@ -987,6 +989,13 @@ def mlp_tower_backward(
         if w1 is None or b1 is None:
             raise ValueError("the bf16-plane backward needs w1 and b1")
         w1p, b1p = _ptr(_dense(w1.detach(), torch.float32, "w1")), _ptr(_dense(b1.detach(), torch.float32, "b1"))
+        # two outputs with exactly opposite gradients (a two-way categorical head): the weight
+        # gradient can take the gate-plane kernel; checked on the data, the answer read back
+        # behind the data-gradient launch so that the GPU has work while the host waits
+        pair_flag = None
+        if n_out == 2 and not int(os.environ.get("RL8_WGRAD_GATE_OFF", "0") or 0):
+            pair_flag = _pair_flag(x.device)
+            _check(lib.rl8_mlp_dout_pair_check(_ptr(dout), m, _ptr(pair_flag), _stream()), "rl8_mlp_dout_pair_check")
         with _timed("mlp_tower_backward", m):
             if f16:
                 _check(
@@ -1006,13 +1015,22 @@ def mlp_tower_backward(
         # (bf16 planes for both generations: see rl8_mlp_tower_backward_f16_f32; single-output towers
         # run the gate-plane kernel -- three plane products instead of six -- timed under its own name)
         gate_kernel = n_out == 1 and not int(os.environ.get("RL8_WGRAD_GATE_OFF", "0") or 0)
-        with _timed("mlp_wgrad_gate" if gate_kernel else "mlp_wgrad", m):
-            _check(
-                lib.rl8_mlp_wgrad_fused_split_f32(
-                    _ptr(h2), _ptr(dout), _ptr(x), w1p, b1p, _ptr(w3.detach()), m, d_in, n_out,
-                    _ptr(_wgrad_workspace(x.device)), _ptr(dw2), _ptr(partials), _stream()),
-                "rl8_mlp_wgrad_fused_split_f32",
-            )
+        pair = pair_flag is not None and int(pair_flag[0].item()) == 0
+        with _timed("mlp_wgrad_gate" if gate_kernel or pair else "mlp_wgrad", m):
+            if pair:
+                _check(
+                    lib.rl8_mlp_wgrad_fused_pair_f32(
+                        _ptr(h2), _ptr(dout), _ptr(x), w1p, b1p, _ptr(w3.detach()), m, d_in,
+                        _ptr(_wgrad_workspace(x.device)), _ptr(dw2), _ptr(partials), _stream()),
+                    "rl8_mlp_wgrad_fused_pair_f32",
+                )
+            else:
+                _check(
+                    lib.rl8_mlp_wgrad_fused_split_f32(
+                        _ptr(h2), _ptr(dout), _ptr(x), w1p, b1p, _ptr(w3.detach()), m, d_in, n_out,
+                        _ptr(_wgrad_workspace(x.device)), _ptr(dw2), _ptr(partials), _stream()),
+                    "rl8_mlp_wgrad_fused_split_f32",
+                )
     else:
         dz2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device)
         with _timed("mlp_tower_backward", m):
@@ -1034,6 +1052,17 @@ def mlp_tower_backward(
         "w2": dw2 if split else (mlp_wgrad_split(dz2, x, w1, b1) if wgrad_split else mlp_wgrad(dz2, h1)),
     }
     return grads
+
+
+_pair_flags: dict[tuple[int, int], torch.Tensor] = {}
+
+
+def _pair_flag(device: torch.device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    flag = _pair_flags.get(key)
+    if flag is None:
+        flag = _pair_flags[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return flag
 
 
 _wgrad_ws: dict[tuple[int, int], torch.Tensor] = {}

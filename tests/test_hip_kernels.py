@@ -202,6 +202,9 @@ def test_ppo_loss_categorical_vs_oracle(m, k):
         assert got[i] == pytest.approx(want[name], rel=1e-5, abs=1e-7), name
     np.testing.assert_allclose(host(g_logits), wg_logits, rtol=2e-5, atol=1e-9)
     np.testing.assert_allclose(host(g_value), wg_values, rtol=2e-5, atol=1e-10)
+    if k == 2:  # a two-way categorical's gradients are exact negatives (what the pair weight-gradient kernel needs)
+        gl = host(g_logits).reshape(m, 2)
+        assert np.array_equal(gl[:, 0], -gl[:, 1])
     # forward-only launch gives the same sums
     sums2, none1, none2 = hip.ppo_loss_categorical(
         dev(logits), dev(values), dev(actions), dev(logp_old), dev(adv), dev(returns), hp, with_grad=False)

@@ -125,7 +125,7 @@ def test_compiled_split_kernels_resources(tmp_path):
             assert scratch == 0, (name, scratch)
             assert vgprs <= 256, (name, vgprs)
             checked += 1
-    assert checked >= 24 + 12 + 5 + 12 + 1 + 4  # (+ the two-operand weight-gradient mode, + the gate-plane kernel)
+    assert checked >= 24 + 12 + 5 + 12 + 1 + 8  # (+ the two-operand weight-gradient mode, + the gate-plane kernels)
     _check_wgrad_scalar_windows(text)
     # Every hand-issued load (ds_read_b128, s_buffer_load_dwordx8, ...) of every kernel: nothing
     # reads or overwrites its destination before a wait that covers it, on any path.

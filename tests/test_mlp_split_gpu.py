@@ -247,6 +247,56 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
         assert err < 1e-4 and err <= 3 * err6 + 2e-7, (k, err, err6)
 
 
+@pytest.mark.parametrize("m,d_in", [(1, 1), (129, 1), (1000, 5), (4097, 3), (40_000, 1), (9000, 2)])
+def test_pair_weight_gradient_of_a_two_way_head(m, d_in, monkeypatch):
+    """dOut[s][1] == -dOut[s][0] exactly (what the categorical loss kernel emits for two actions):
+    dZ2 = gate * dOut[s][0] * (W3[0] - W3[1]), so the weight gradient runs with the gate as its
+    (binary, exact) first operand.  Chosen on the DATA (rl8_mlp_dout_pair_check); against fp64, against
+    the six-product kernel on the same inputs, and not chosen when one row breaks the property."""
+    g = torch.Generator(device=DEV).manual_seed(31 * m + d_in)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 3
+    p = _params(g, d_in, 2)
+    g0 = torch.randn(m, device=DEV, generator=g) / m
+    g0[torch.rand(m, device=DEV, generator=g) < 0.3] = 0.0   # clipped samples: exact zeros (of either sign below)
+    dout = torch.stack([g0, -g0], 1).contiguous()
+    _, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                                 save=True, save_h1=False, save_gate=True)
+    h1 = torch.relu(x @ p["w1"].T + p["b1"])
+    d, a1, a2 = dout.double(), h1.double(), h2.double()
+    dz2 = (d @ p["w3"].double()) * (a2 > 0)
+    dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
+    want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0), "w2": dz2.T @ a1, "b2": dz2.sum(0), "w3": d.T @ a2}
+    w2t = hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+
+    def run(data):
+        hip.timer.reset()
+        hip.timer.enabled = True
+        try:
+            grads = hip.mlp_tower_backward(x, None, h2, data, w2t, p["w3"], p["w1"], p["b1"], gate2=gate)
+            return grads, set(hip.timer.summary())
+        finally:
+            hip.timer.enabled = False
+
+    got, launched = run(dout)
+    assert "mlp_wgrad_gate" in launched and "mlp_wgrad" not in launched
+    monkeypatch.setenv("RL8_WGRAD_GATE_OFF", "1")
+    ref6, launched6 = run(dout)
+    monkeypatch.delenv("RL8_WGRAD_GATE_OFF")
+    assert "mlp_wgrad" in launched6 and "mlp_wgrad_gate" not in launched6
+    for k in want:
+        err, err6 = _rel(got[k], want[k]), _rel(ref6[k], want[k])
+        assert err < 2e-5 and err <= 3 * err6 + 2e-6, (k, err, err6)
+    assert torch.equal(got["w3"][1], -got["w3"][0])
+    again, _ = run(dout)
+    for k in got:
+        assert torch.equal(got[k], again[k]), k  # fixed summation order
+    # one row off by an ulp: the property no longer holds, the general kernel runs
+    broken = dout.clone()
+    broken[m // 2, 1] = torch.nextafter(broken[m // 2, 1] + 1e-30, torch.tensor(1.0, device=DEV))
+    _, launched_b = run(broken)
+    assert "mlp_wgrad" in launched_b and "mlp_wgrad_gate" not in launched_b
+
+
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (13, 1, 1), (4099, 2, 3), (20_003, 5, 3), (33_001, 3, 2), (9, 5, 1)])
 @pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
 def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out, scheme):
@@ -359,7 +409,8 @@ def test_fused_tower_autograd_uses_the_split_kernels_and_matches_eager():
         launched = set(hip.timer.summary())
     finally:
         hip.timer.enabled = False
-    assert {"mlp_tower_forward_save", "mlp_tower_backward", "mlp_wgrad"} <= launched
+    # (this loss gives the two outputs exactly opposite gradients: the pair weight-gradient kernel runs)
+    assert {"mlp_tower_forward_save", "mlp_tower_backward", "mlp_wgrad_gate"} <= launched
     got = {n: p.grad.clone() for n, p in list(trunk.named_parameters()) + list(head.named_parameters())}
     for p in list(trunk.parameters()) + list(head.parameters()):
         p.grad = None
