@@ -60,7 +60,7 @@ HBM_COPY_CEILING_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (= fp32 vector) peak, MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (spec), MI355X_MICROARCH.md; 1750 sustained on changing operands
 SPLIT_PRODUCTS = 6              # bf16 plane products per fp32 product in the bf16-plane kernels
-PLANE_PRODUCTS = {"bf16x3-split": 6, "f16x2-split": 3, "bf16-gate-x3": 3}  # 16-bit MFMA products per fp32 product, by scheme
+PLANE_PRODUCTS = {"bf16x3-split": 6, "f16x2-split": 3, "bf16-gate-x3": 3, "f16-gate-x2": 2}  # 16-bit MFMA products per fp32 product, by scheme
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak = the bf16 one (same instruction shape and rate)
 
 # MFMA-bound kernels: algorithmic FLOP per unit (row) for the default towers,
@@ -113,7 +113,10 @@ PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
     "mlp_tower_backward": ("mlp_tower_backward_split_kernel<1, 2>", 1 << 20),
     "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2>", 1 << 20),
 }
-PMC_KERNEL_GATE = {"mlp_wgrad_gate": ("mlp_wgrad_gate_kernel<1>", 1 << 20)}  # weight gradient of single-output towers
+PMC_KERNEL_GATE = {  # gate-mode kernels (heads whose dZ2 is gate * d * w3e)
+    "mlp_wgrad_gate": ("mlp_wgrad_gate_kernel<1, false>", 1 << 20),
+    "mlp_tower_backward_gate": ("mlp_tower_backward_f16_kernel<1, 1, true>", 1 << 20),
+}
 
 
 def pmc_traffic(name: str, units_per_launch: float, gemm: str = "f32"):
@@ -121,7 +124,8 @@ def pmc_traffic(name: str, units_per_launch: float, gemm: str = "f32"):
         summary = json.load(open(PMC_SUMMARY))
     except OSError:
         return None
-    table = {"f16x2-split": PMC_KERNEL_F16, "bf16x3-split": PMC_KERNEL_SPLIT, "bf16-gate-x3": PMC_KERNEL_GATE}.get(gemm, PMC_KERNEL)
+    table = {"f16x2-split": PMC_KERNEL_F16, "bf16x3-split": PMC_KERNEL_SPLIT, "bf16-gate-x3": PMC_KERNEL_GATE,
+             "f16-gate-x2": PMC_KERNEL_GATE}.get(gemm, PMC_KERNEL)
     needle, units = table.get(name, (None, 1))
     for kernel, rec in summary.items():
         if needle and needle in kernel:
@@ -398,8 +402,10 @@ def run(args: argparse.Namespace) -> None:
         if name in ("mlp_tower_forward", "mlp_tower_forward_save"):
             ok = fused_mlp.FORWARD_GEMM in planes and all(hip.mlp_forward_split_supports(d, n) for d, n in widths)
             f16 = ok and fused_mlp.FORWARD_GEMM == "f16" and all(hip.mlp_forward_f16_supports(d, n) for d, n in widths)
-        elif name == "mlp_wgrad_gate":  # single-output towers: gate plane x three planes of dOut * h1
+        elif name == "mlp_wgrad_gate":  # rank-one heads: gate plane x three planes of dOut * h1
             return "bf16-gate-x3"
+        elif name == "mlp_tower_backward_gate":  # rank-one heads: gate plane x two planes of w3e * W2
+            return "f16-gate-x2"
         elif name == "mlp_wgrad":  # the bf16-plane weight-gradient kernel takes any width (and stays on bf16 planes)
             ok, f16 = fused_mlp.BACKWARD_GEMM in planes, False
         else:
@@ -485,7 +491,8 @@ def run(args: argparse.Namespace) -> None:
             # bf16-plane kernel: priced in the bf16 multiply-adds the matrix pipe executes
             # (6 per fp32 multiply-add of the algorithm) against the dense bf16 peak
             roofline = {
-                "kernel": {"mlp_wgrad": "rl8_mlp_wgrad_fused_split_f32", "mlp_wgrad_gate": "rl8_mlp_wgrad_fused_split_f32 (n_out = 1)"}.get(
+                "kernel": {"mlp_wgrad": "rl8_mlp_wgrad_fused_split_f32", "mlp_wgrad_gate": "rl8_mlp_wgrad_fused_split_f32 (n_out = 1) / rl8_mlp_wgrad_fused_pair_f32",
+                           "mlp_tower_backward_gate": "rl8_mlp_tower_backward_gate_f16_f32"}.get(
                     dominant, f"rl8_{dominant}_{'f16' if top['gemm'] == 'f16x2-split' else 'split'}_f32"),
                 "bound": "mfma",
                 "achieved": top["executed_bf16_TFLOPs"],
@@ -495,6 +502,8 @@ def run(args: argparse.Namespace) -> None:
                 "flop_per_launch": top["executed_bf16_flop_per_launch"],
                 "flop_definition": ("3 bf16 plane products x 2*256*256 per row (ReLU gate as one exact bf16 plane x the three"
                                     " planes of dOut*h1, fp32 accumulate)" if top["gemm"] == "bf16-gate-x3" else
+                                    "2 fp16 plane products x 2*256*256 per row (ReLU gate as one exact fp16 plane x the two"
+                                    " planes of w3e*W2, fp32 accumulate)" if top["gemm"] == "f16-gate-x2" else
                                     "3 fp16 plane products x 2*256*256 per row (fp32 operands scaled by powers of two and"
                                     " split into 2 fp16 planes, fp32 accumulate)" if top["gemm"] == "f16x2-split" else
                                     "6 bf16 plane products x 2*256*256 per row (fp32 operands split exactly into"

@@ -391,6 +391,20 @@ int rl8_mlp_tower_backward_f16_f32(const float *x, const float *w1, const float 
                                    float *partials, int *partial_rows_out /*host*/, const uint32_t *gate2,
                                    void *stream);
 
+/* Gate mode of the fp16 data-gradient kernel, for heads whose dZ2 is gate * d[s] * w3e[k] -- n_out = 1
+ * (w3e = W3[0]), or n_out = 2 with dout[s][1] == -dout[s][0] in every row (rl8_mlp_dout_pair_check;
+ * w3e = W3[0] - W3[1], d = dout[.][0]):  dH1[s][i] = d[s] * sum_k gate[s][k] * (w3e[k] W2[k][i]).
+ * The gate is the A operand (one fp16 plane of zeros and ones straight from the gate bits), B the two
+ * planes of w3e[k] W2[k][i] from rl8_mlp_pack_w2_f16_gate (rl8_mlp_f16_packed_bytes() bytes; re-made
+ * when W2 or W3 change): two plane products per 16 k instead of three.  Other arguments, partial rows
+ * and the follow-up weight-gradient call as rl8_mlp_tower_backward_f16_f32. */
+int rl8_mlp_pack_w2_f16_gate(const float *w2 /*[256][256]*/, const float *w3 /*[n_out][256]*/, int n_out,
+                             void *w2t_gate, void *stream);
+int rl8_mlp_tower_backward_gate_f16_f32(const float *x, const float *w1, const float *b1, const float *dout,
+                                        int64_t m, int d_in, const void *w2t_gate, int n_out,
+                                        float *partials, int *partial_rows_out /*host*/,
+                                        const uint32_t *gate2, void *stream);
+
 /* Backward of one tower ("dgrad" half): given dOut [M][n_out] and the saved
  * activations h1 / h2, writes dZ2 [M][256] (input of rl8_mlp_wgrad_f32, which
  * forms dW2 = dZ2^T h1) and `*partial_rows_out` rows (<= rl8_mlp_backward_max_rows()) of

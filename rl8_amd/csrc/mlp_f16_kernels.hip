@@ -78,12 +78,21 @@ __device__ __forceinline__ void f16_mma_t(const u32x4 (&a)[2], const u32x4 (&b)[
 // max |w2| * 2^k < 2^14: 16-byte unit ((s*8 + ct)*2 + p)*64 + l holds, for plane p,
 //   B(col = 32 ct + (l & 31), k = 16 s + 8 (l >> 5) + e), e = 0..7  (B as in mlp_pack_w2_split),
 // and behind the planes two floats: 2^k and 2^-k.  One workgroup: the maximum first.
+// w3 != NULL (with transposed): the planes are those of W2[k][col] * w3e[k], w3e = W3[0] (n_w3 = 1) or
+// W3[0] - W3[1] (n_w3 = 2) -- the B operand of the data-gradient kernel's gate mode, where the ReLU gate is
+// the A operand and dZ2's dense factors moved into B.
 __global__ __launch_bounds__(1024) void mlp_pack_w2_f16_kernel(const float *__restrict__ w2, int transposed,
-                                                               uint32_t *__restrict__ packed) {
+                                                               uint32_t *__restrict__ packed,
+                                                               const float *__restrict__ w3 = nullptr, int n_w3 = 0) {
   __shared__ float red[1024];
+  __shared__ float w3e[kHidden];
   const int tid = threadIdx.x;
+  if (tid < kHidden) w3e[tid] = w3 == nullptr ? 1.0f : n_w3 == 2 ? w3[tid] - w3[kHidden + tid] : w3[tid];
+  __syncthreads();
   float mx = 0.0f;
-  for (int i = tid; i < kHidden * kHidden; i += 1024) mx = __builtin_fmaxf(mx, __builtin_fabsf(w2[i]));
+  // (row k of w2 is w2[k][.]: the factor belongs to the REDUCTION index of the transposed product)
+#pragma clang loop vectorize(disable) interleave(disable)  // (no packed fp32 ops anywhere in this file: the ISA test's rule)
+  for (int i = tid; i < kHidden * kHidden; i += 1024) mx = __builtin_fmaxf(mx, __builtin_fabsf(w2[i] * w3e[i >> 8]));
   red[tid] = mx;
   __syncthreads();
   for (int half = 512; half > 0; half >>= 1) {
@@ -104,8 +113,8 @@ __global__ __launch_bounds__(1024) void mlp_pack_w2_f16_kernel(const float *__re
     u32x4 hi, lo;
 #pragma unroll
     for (int e2 = 0; e2 < 8; e2 += 2) {
-      const float v0 = (transposed ? w2[(k0 + e2) * kHidden + col] : w2[col * kHidden + k0 + e2]) * scale;
-      const float v1 = (transposed ? w2[(k0 + e2 + 1) * kHidden + col] : w2[col * kHidden + k0 + e2 + 1]) * scale;
+      const float v0 = (transposed ? w2[(k0 + e2) * kHidden + col] * w3e[k0 + e2] : w2[col * kHidden + k0 + e2]) * scale;
+      const float v1 = (transposed ? w2[(k0 + e2 + 1) * kHidden + col] * w3e[k0 + e2 + 1] : w2[col * kHidden + k0 + e2 + 1]) * scale;
       uint32_t h, lw;
       f16_pair(v0, v1, h, lw);
       hi[e2 >> 1] = h;
@@ -688,7 +697,13 @@ __device__ __forceinline__ void f16_mma(const u32x4 (&a)[2], const u32x4 (&b)[4]
     }
 }
 
-template <int DIN, int NOUT>
+// GATE: heads whose dZ2 is rank one in (sample, unit) -- one output, or two outputs with exactly opposite
+// gradients (a two-way categorical): dZ2[s][k] = G[s][k] * d[s] * w3e[k], so
+//   dH1[s][i] = d[s] * sum_k G[s][k] * (w3e[k] W2[k][i]):
+// the A operand is the gate itself, ONE fp16 plane of zeros and ones made from the gate bits without any
+// arithmetic, B the two planes of w3e[k] W2[k][i] (rl8_mlp_pack_w2_f16_gate): TWO products per 16 k instead
+// of three, no split on the VALU, and d[s] joins the row factor applied to the accumulators.
+template <int DIN, int NOUT, bool GATE = false>
 __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
     const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ dout, int64_t m, const void *__restrict__ w2ts, const float *__restrict__ w3,
@@ -721,7 +736,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
 
   // max_k |W3[q][k]| (uniform: scalar registers), before any stage is in use
   float w3max[kOut];
-  {
+  if constexpr (GATE) {
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) w3max[q] = 0.0f;
+  } else {
     float *red = reinterpret_cast<float *>(smem);
 #pragma unroll
     for (int q = 0; q < kOut; ++q) {
@@ -753,6 +771,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
   float p_scale = 1.0f;  // of row prow of the producer's tile
   int p_parity = 0, c_parity = 0;
   auto set_row_scale = [&]() {
+    if constexpr (GATE) {  // the row's factor is its dOut times W2's power of two (no row scaling: the operand is the gate)
+      if (tid < kSplitRows) lds_write_b32(scale_lds + (p_parity * kSplitRows + prow) * 4, dr[0] * inv_w2_scale);
+      return;
+    }
     float bound = 0.0f;
 #pragma unroll
     for (int q = 0; q < kOut; ++q) bound = __builtin_fmaf(__builtin_fabsf(dr[q]), w3max[q], bound);
@@ -790,6 +812,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
     uint32_t gword = g0;
     if (!from_regs) gword = __float_as_uint(lds_read_b32(gate_lds + (prow * 8 + (ks >> 1)) * 4));
     const uint32_t byte = gword >> (16 * (ks & 1) + 8 * pkh);
+    if constexpr (GATE) {  // bit -> fp16 1.0 / 0.0
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)
+        planes[0][e >> 1] = (((byte >> e) & 1u) ? 0x00003c00u : 0u) | (((byte >> (e + 1)) & 1u) ? 0x3c000000u : 0u);
+      return;
+    }
     float dz[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -810,7 +838,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
   auto write_a = [&](int stage, const u32x4 (&planes)[2]) {
     const unsigned addr = a_write + stage * kF16StageBytes;
     lds_write_b128<0>(addr, planes[0]);
-    lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
+    if constexpr (!GATE) lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
   };
   auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
@@ -833,8 +861,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
     f.bh[1] = lds_read_b128<2 * 1024>(br);
     f.bh[2] = lds_read_b128<4 * 1024>(br);
     f.bh[3] = lds_read_b128<6 * 1024>(br);
-    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
-    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
+    if constexpr (GATE) {
+      f.am[0] = f.ah[0];  // (one A plane; the pair keeps wait_lds_all's operand list whole)
+      f.am[1] = f.ah[1];
+    } else {
+      f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
+      f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
+    }
     f.bm[0] = lds_read_b128<1024>(br);
     f.bm[1] = lds_read_b128<3 * 1024>(br);
     f.bm[2] = lds_read_b128<5 * 1024>(br);
@@ -853,6 +886,18 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
     u32x4 planes[2];
     produce_a(ks, planes, s == kSplitSteps - 1);
     if (s == kSplitSteps - 3) load_g0(p_tile + stride);  // two steps ahead of its use
+    if constexpr (GATE) {
+      wait_lds<0>(f.ah[0], f.ah[1], f.bh[0], f.bh[1], f.bh[2], f.bh[3]);
+      wait_lds<0>(f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
+      f16_mma<FIRST>(f.ah, f.bm, acc);  // gate x lo
+      __builtin_amdgcn_sched_barrier(0);
+      write_a(P ^ 1, planes);
+      __builtin_amdgcn_sched_barrier(0);
+      f16_mma<false>(f.ah, f.bh, acc);  // gate x hi
+      __builtin_amdgcn_sched_barrier(0);
+      step_barrier();
+      return;
+    }
     wait_lds_all(f);
     f16_mma<FIRST>(f.am, f.bh, acc);  // lo x hi
     f16_mma<false>(f.ah, f.bm, acc);  // hi x lo
@@ -1017,18 +1062,18 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
   }
 }
 
-template <int DIN, int NOUT>
+template <int DIN, int NOUT, bool GATE = false>
 static int launch_backward_f16(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                int64_t m, const void *w2ts, const float *w3, float *partials, int stride, int head_rows,
                                const uint32_t *gate2) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_f16_kernel<DIN, NOUT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_f16_kernel<DIN, NOUT, GATE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_tower_backward_f16_kernel<DIN, NOUT><<<grid, kBlock, f16_backward_lds_bytes(DIN), s>>>(
+  mlp_tower_backward_f16_kernel<DIN, NOUT, GATE><<<grid, kBlock, f16_backward_lds_bytes(DIN), s>>>(
       x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2);
   return launch_status();
 }
@@ -1105,5 +1150,41 @@ RL8_API int rl8_mlp_tower_backward_f16_f32(const float *x, const float *w1, cons
   RL8_BACKWARD_F16(3, 1) RL8_BACKWARD_F16(3, 2) RL8_BACKWARD_F16(3, 3)
   RL8_BACKWARD_F16(5, 1) RL8_BACKWARD_F16(5, 2) RL8_BACKWARD_F16(5, 3)
 #undef RL8_BACKWARD_F16
+  return status;
+}
+
+/* The B operand of rl8_mlp_tower_backward_gate_f16_f32: planes of W2[k][i] * w3e[k] (w3e = W3[0] for one output,
+ * W3[0] - W3[1] for a pair of exactly opposite gradients), layout and size of rl8_mlp_pack_w2_f16(..., transposed = 1). */
+RL8_API int rl8_mlp_pack_w2_f16_gate(const float *w2, const float *w3, int n_out, void *packed, void *stream) {
+  if (!w2 || !w3 || !packed) return RL8_ENULL;
+  if (n_out != 1 && n_out != 2) return RL8_ESIZE;
+  if (((uintptr_t)packed & 15) != 0) return RL8_EALIGN;
+  mlp_pack_w2_f16_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(w2, 1, reinterpret_cast<uint32_t *>(packed), w3, n_out);
+  return launch_status();
+}
+
+/* rl8_mlp_tower_backward_f16_f32 for heads whose dZ2 is gate * d[s] * w3e[k]: n_out = 1, or n_out = 2 with
+ * dout[s][1] == -dout[s][0] in every row (rl8_mlp_dout_pair_check; column 0 is used).  The gate is the A
+ * operand (one plane, no arithmetic), two plane products per 16 k; w2t_gate from rl8_mlp_pack_w2_f16_gate
+ * with the same W3.  Same partial rows as the general kernel. */
+RL8_API int rl8_mlp_tower_backward_gate_f16_f32(const float *x, const float *w1, const float *b1, const float *dout,
+                                                int64_t m, int d_in, const void *w2t_gate, int n_out,
+                                                float *partials, int *partial_rows_out, const uint32_t *gate2,
+                                                void *stream) {
+  if (!x || !w1 || !b1 || !dout || !w2t_gate || !partials || !partial_rows_out || !gate2) return RL8_ENULL;
+  if (m <= 0 || (n_out != 1 && n_out != 2) || !rl8_mlp_backward_f16_supports(d_in, n_out)) return RL8_ESIZE;
+  if (((uintptr_t)w2t_gate & 15) != 0 || !aligned16(gate2)) return RL8_EALIGN;
+  int grid, g2;
+  f16_backward_grids(m, &grid, &g2);
+  *partial_rows_out = grid > g2 ? grid : g2;
+  const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
+  hipStream_t s = (hipStream_t)stream;
+  int status = RL8_ESIZE;
+#define RL8_BACKWARD_GATE(D, N) \
+  if (d_in == D && n_out == N) \
+    status = launch_backward_f16<D, N, true>(grid, s, x, w1, b1, dout, m, w2t_gate, nullptr, partials, stride, g2, gate2);
+  RL8_BACKWARD_GATE(1, 1) RL8_BACKWARD_GATE(1, 2) RL8_BACKWARD_GATE(2, 1) RL8_BACKWARD_GATE(2, 2)
+  RL8_BACKWARD_GATE(3, 1) RL8_BACKWARD_GATE(3, 2) RL8_BACKWARD_GATE(5, 1) RL8_BACKWARD_GATE(5, 2)
+#undef RL8_BACKWARD_GATE
   return status;
 }

@@ -151,6 +151,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_tower_backward_f16_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, C.POINTER(C.c_int), _vp, _vp],
     "rl8_mlp_dout_pair_check": [_vp, _i64, _vp, _vp],
     "rl8_mlp_wgrad_fused_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp],
+    "rl8_mlp_pack_w2_f16_gate": [_vp, _vp, _i32, _vp, _vp],
+    "rl8_mlp_tower_backward_gate_f16_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp, _vp],
     "rl8_mlp_f16_packed_bytes": [],
     "rl8_mlp_forward_f16_supports": [_i32, _i32],
     "rl8_mlp_pack_w2_f16": [_vp, _i32, _vp, _vp],
@@ -891,6 +893,20 @@ def mlp_pack_w2_f16(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tens
     return packed
 
 
+def mlp_pack_w2_f16_gate(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    """B operand of the data-gradient kernel's gate mode: fp16 planes of ``w2[k][i] * w3e[k]`` with
+    ``w3e = w3[0]`` (one output) or ``w3[0] - w3[1]`` (two outputs with opposite gradients)."""
+    w2 = _dense(w2.detach(), torch.float32, "w2")
+    w3 = _dense(w3.detach(), torch.float32, "w3")
+    if tuple(w2.shape) != (MLP_HIDDEN, MLP_HIDDEN) or w3.ndim != 2 or w3.shape[1] != MLP_HIDDEN or w3.shape[0] not in (1, 2):
+        raise ValueError("w2 must be [256, 256] and w3 [1 or 2, 256]")
+    lib = load()
+    packed = torch.empty(int(lib.rl8_mlp_f16_packed_bytes()), dtype=torch.uint8, device=w2.device)
+    _check(lib.rl8_mlp_pack_w2_f16_gate(_ptr(w2), _ptr(w3), int(w3.shape[0]), _ptr(packed), _stream()),
+           "rl8_mlp_pack_w2_f16_gate")
+    return packed
+
+
 def mlp_pack_w2_split(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
     """[256, 256] nn.Linear weight -> three bf16 planes (w = hi + mid + lo exactly)
     in the fragment order of the split-product kernels (393216 bytes, uint8)."""
@@ -946,7 +962,7 @@ def mlp_tower_backward(
     x: torch.Tensor, h1: None | torch.Tensor, h2: torch.Tensor, dout: torch.Tensor,
     w2t_packed: torch.Tensor, w3: torch.Tensor,
     w1: None | torch.Tensor = None, b1: None | torch.Tensor = None, *, wgrad_split: bool = False,
-    gate2: None | torch.Tensor = None,
+    gate2: None | torch.Tensor = None, gate_pack=None,
 ) -> dict[str, torch.Tensor]:
     """Gradients of one tower's parameters given ``dout`` [M, n_out] and the
     activations saved by the forward pass. Returns ``w1, b1, w2, b2, w3, b3``.
@@ -959,7 +975,9 @@ def mlp_tower_backward(
     data-gradient half runs on the fp32 kernel. ``gate2`` (``save_gate`` of the
     bf16-plane forward): gate bits of h2 for the data-gradient kernel. A pack from
     ``mlp_pack_w2_f16(..., transposed=True)`` selects the fp16-plane data-gradient kernel
-    (fused mode: ``gate2`` required; the weight gradient stays on bf16 planes)."""
+    (fused mode: ``gate2`` required; the weight gradient stays on bf16 planes). ``gate_pack``: a
+    callable returning ``mlp_pack_w2_f16_gate(w2, w3)`` -- with it, single-output heads and two-output
+    heads whose gradients are exact negatives (checked on ``dout``) run the data gradient in gate mode."""
     m, d_in = x.shape
     n_out = w3.shape[0]
     split = w2t_packed.dtype == torch.uint8
@@ -992,12 +1010,24 @@ def mlp_tower_backward(
         # two outputs with exactly opposite gradients (a two-way categorical head): the weight
         # gradient can take the gate-plane kernel; checked on the data, the answer read back
         # behind the data-gradient launch so that the GPU has work while the host waits
-        pair_flag = None
-        if n_out == 2 and not int(os.environ.get("RL8_WGRAD_GATE_OFF", "0") or 0):
+        gates_on = not int(os.environ.get("RL8_WGRAD_GATE_OFF", "0") or 0)
+        pair_flag, pair = None, False
+        if n_out == 2 and gates_on:
             pair_flag = _pair_flag(x.device)
             _check(lib.rl8_mlp_dout_pair_check(_ptr(dout), m, _ptr(pair_flag), _stream()), "rl8_mlp_dout_pair_check")
-        with _timed("mlp_tower_backward", m):
-            if f16:
+            if f16 and gate_pack is not None:  # the data gradient needs the answer too: read it now (a short bubble)
+                pair = int(pair_flag[0].item()) == 0
+                pair_flag = None
+        gate_dgrad = f16 and gate_pack is not None and gates_on and (n_out == 1 or pair)
+        with _timed("mlp_tower_backward_gate" if gate_dgrad else "mlp_tower_backward", m):
+            if gate_dgrad:
+                _check(
+                    lib.rl8_mlp_tower_backward_gate_f16_f32(
+                        _ptr(x), w1p, b1p, _ptr(dout), m, d_in, _ptr(gate_pack()), n_out,
+                        _ptr(partials), C.byref(rows), _ptr(gate2), _stream()),
+                    "rl8_mlp_tower_backward_gate_f16_f32",
+                )
+            elif f16:
                 _check(
                     lib.rl8_mlp_tower_backward_f16_f32(
                         _ptr(x), w1p, b1p, _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
@@ -1014,8 +1044,8 @@ def mlp_tower_backward(
         dw2 = torch.empty(MLP_HIDDEN, MLP_HIDDEN, dtype=torch.float32, device=x.device)
         # (bf16 planes for both generations: see rl8_mlp_tower_backward_f16_f32; single-output towers
         # run the gate-plane kernel -- three plane products instead of six -- timed under its own name)
-        gate_kernel = n_out == 1 and not int(os.environ.get("RL8_WGRAD_GATE_OFF", "0") or 0)
-        pair = pair_flag is not None and int(pair_flag[0].item()) == 0
+        gate_kernel = n_out == 1 and gates_on
+        pair = pair or (pair_flag is not None and int(pair_flag[0].item()) == 0)
         with _timed("mlp_wgrad_gate" if gate_kernel or pair else "mlp_wgrad", m):
             if pair:
                 _check(

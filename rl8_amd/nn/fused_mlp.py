@@ -60,6 +60,20 @@ def _packed(layer: nn.Linear, transposed: bool, split: bool | str = False) -> to
     return packed
 
 
+def _packed_gate(layer: nn.Linear, w3: torch.Tensor) -> torch.Tensor:
+    """``hip.mlp_pack_w2_f16_gate(layer.weight, w3)``, cached on the layer like ``_packed`` and re-made when
+    either weight has changed."""
+    w2 = layer.weight
+    cache = layer.__dict__.setdefault("_rl8_w2_packs", {})
+    hit = cache.get("gate")
+    key = (w2._version, w2.data_ptr(), w3._version, w3.data_ptr(), tuple(w3.shape))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    packed = hip.mlp_pack_w2_f16_gate(w2, w3)
+    cache["gate"] = (key, packed)
+    return packed
+
+
 class _FusedTower(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, layer2, grad_mode):  # type: ignore[override]
@@ -89,8 +103,11 @@ class _FusedTower(torch.autograd.Function):
         split: bool | str = BACKWARD_GEMM in ("split", "f16") and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0])
         if split and BACKWARD_GEMM == "f16" and gate is not None and hip.mlp_backward_f16_supports(x.shape[1], w3.shape[0]):
             split = "f16"
+        # (w3 as saved is the parameter itself for a single head: its version counter tracks the optimizer)
+        gate_pack = (lambda: _packed_gate(ctx.layer2, w3)) if split == "f16" and w3.shape[0] <= 2 else None
         g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True, split), w3,
-                                   w1, b1, wgrad_split=BACKWARD_GEMM in ("split", "f16"), gate2=gate if split else None)
+                                   w1, b1, wgrad_split=BACKWARD_GEMM in ("split", "f16"), gate2=gate if split else None,
+                                   gate_pack=gate_pack)
         return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None
 
 

@@ -591,7 +591,7 @@ def test_enable_amp_keeps_the_fused_fp32_towers():
     c0, s0, k0, p0 = run(False)
     c1, s1, k1, p1 = run(True)
     # (two actions: policy and value tower both take the gate-plane weight-gradient kernel)
-    assert {"mlp_tower_forward", "mlp_tower_forward_save", "mlp_tower_backward", "mlp_wgrad_gate"} <= k1 and k0 == k1
+    assert {"mlp_tower_forward", "mlp_tower_forward_save", "mlp_tower_backward_gate", "mlp_wgrad_gate"} <= k1 and k0 == k1
     assert c0["returns/mean"] == c1["returns/mean"]
     for k in ("losses/policy", "losses/vf", "losses/total"):
         assert s0[k] == pytest.approx(s1[k], rel=1e-5, abs=1e-8), k

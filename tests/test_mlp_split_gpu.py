@@ -247,6 +247,70 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
         assert err < 1e-4 and err <= 3 * err6 + 2e-7, (k, err, err6)
 
 
+@pytest.mark.parametrize("case", ["plain", "rows_of_mixed_magnitude", "one_outlier_row", "clipped_rows", "outlier_weights"])
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 1), (129, 1, 2), (1000, 5, 1), (4097, 3, 2), (40_000, 1, 1), (9000, 2, 2),
+                                          (20_000, 3, 1), (33_000, 5, 2)])
+def test_gate_mode_data_gradient(m, d_in, n_out, case):
+    """Heads whose dZ2 is gate * d[s] * w3e[k] (one output; two outputs with exactly opposite gradients):
+    the data-gradient kernel takes the ReLU gate itself as its A operand and the planes of w3e[k] W2[k][i] as B.
+    dW1 / db1 (what that kernel produces) against fp64 on the saved activations and against the general
+    fp16-plane kernel's own error, over the dynamic-range cases of the general kernel's test."""
+    g = torch.Generator(device=DEV).manual_seed(13 * m + d_in + n_out)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 3
+    p = _params(g, d_in, n_out)
+    g0 = torch.randn(m, device=DEV, generator=g) / m
+    if case == "rows_of_mixed_magnitude":
+        g0 *= 10.0 ** torch.randint(-4, 3, (m,), device=DEV, generator=g).float()
+        x *= 10.0 ** torch.randint(-2, 2, (m, 1), device=DEV, generator=g).float()
+    elif case == "one_outlier_row":
+        g0[m // 3] *= 1e6
+    elif case == "clipped_rows":
+        g0[torch.rand(m, device=DEV, generator=g) < 0.7] = 0.0
+    elif case == "outlier_weights":
+        p["w2"][torch.randint(0, 256, (20,), device=DEV, generator=g), torch.randint(0, 256, (20,), device=DEV, generator=g)] = 40.0
+        p["w3"][0, 5] = 30.0
+    dout = (torch.stack([g0, -g0], 1) if n_out == 2 else g0[:, None]).contiguous()
+    _, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                                 save=True, save_h1=False, save_gate=True)
+    h1 = torch.relu(x @ p["w1"].T + p["b1"])
+    d, a1, a2 = dout.double(), h1.double(), h2.double()
+    dz2 = (d @ p["w3"].double()) * (a2 > 0)
+    dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
+    want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0), "w2": dz2.T @ a1, "b2": dz2.sum(0), "w3": d.T @ a2}
+    # the yardstick of dW1 / db1: the sum of the magnitudes of ALL terms, those of the inner products
+    # dH1[s][i] = sum_k dZ2[s][k] W2[k][i] included (an inner product that cancels is not the kernel's error;
+    # tools/diag/gate_dgrad_inner_error.py measures the three kernels on it: 1.3e-7 gate, 2.4e-7 general, 3.4e-7 bf16)
+    inner = (dz2.abs() @ p["w2"].double().abs()) * (a1 > 0)
+    size = {"w1": inner.T @ x.double().abs(), "b1": inner.sum(0)}
+    w2t = hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+
+    def run(gate_pack):
+        hip.timer.reset()
+        hip.timer.enabled = True
+        try:
+            grads = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack)
+            return grads, set(hip.timer.summary())
+        finally:
+            hip.timer.enabled = False
+
+    got, launched = run(lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"]))
+    ref, launched_ref = run(None)
+    assert "mlp_tower_backward_gate" in launched and "mlp_tower_backward" in launched_ref
+    for k in want:
+        assert bool(torch.isfinite(got[k]).all()), k
+        assert _rel(got[k], want[k]) < 2e-5, k
+        if k not in ("w1", "b1"):  # (the weight-gradient kernel's outputs: the same kernel in both runs)
+            assert torch.equal(got[k], ref[k]), k
+            continue
+        floor = size[k].max() * 1e-30 + 1e-300
+        err = float(((got[k].double() - want[k]).abs() / (size[k] + floor)).max())
+        err3 = float(((ref[k].double() - want[k]).abs() / (size[k] + floor)).max())
+        assert err < 2e-6 and err <= 3 * err3 + 2e-7, (k, err, err3)
+    again, _ = run(lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"]))
+    for k in got:
+        assert torch.equal(got[k], again[k]), k
+
+
 @pytest.mark.parametrize("m,d_in", [(1, 1), (129, 1), (1000, 5), (4097, 3), (40_000, 1), (9000, 2)])
 def test_pair_weight_gradient_of_a_two_way_head(m, d_in, monkeypatch):
     """dOut[s][1] == -dOut[s][0] exactly (what the categorical loss kernel emits for two actions):
@@ -409,8 +473,8 @@ def test_fused_tower_autograd_uses_the_split_kernels_and_matches_eager():
         launched = set(hip.timer.summary())
     finally:
         hip.timer.enabled = False
-    # (this loss gives the two outputs exactly opposite gradients: the pair weight-gradient kernel runs)
-    assert {"mlp_tower_forward_save", "mlp_tower_backward", "mlp_wgrad_gate"} <= launched
+    # (this loss gives the two outputs exactly opposite gradients: the gate-mode backward kernels run)
+    assert {"mlp_tower_forward_save", "mlp_tower_backward_gate", "mlp_wgrad_gate"} <= launched
     got = {n: p.grad.clone() for n, p in list(trunk.named_parameters()) + list(head.named_parameters())}
     for p in list(trunk.parameters()) + list(head.parameters()):
         p.grad = None

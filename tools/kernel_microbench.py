@@ -150,6 +150,14 @@ def gate_wgrad_fused():  # single-output tower: gate plane x three planes of dOu
                                        _p(_ws), _p(_dw2), _p(_partials_v), hip._stream())
 
 
+mlp_w2tg = hip.mlp_pack_w2_f16_gate(mlp_w2, mlp_w3v)  # B of the gate-mode data gradient (value tower)
+
+
+def f16_dgrad_gate():  # single-output tower: gate plane x two planes of w3 * W2 (2 products per 16 k)
+    _lib.rl8_mlp_tower_backward_gate_f16_f32(_p(mlp_x), _p(mlp_w1), _p(mlp_b1), _p(mlp_doutv), N, 1, _p(mlp_w2tg), 1,
+                                             _p(_partials_v), C.byref(_rows), _p(mlp_gate), hip._stream())
+
+
 def split_wgrad_fused():  # weight-gradient kernel: re-forms dZ2 and h1, accumulates the head gradients
     _lib.rl8_mlp_wgrad_fused_split_f32(_p(mlp_h2), _p(mlp_dout), _p(mlp_x), _p(mlp_w1), _p(mlp_b1), _p(mlp_w3), N, 1, 2,
                                        _p(_ws), _p(_dw2), _p(_partials), hip._stream())
@@ -165,6 +173,7 @@ KERNELS = {
     "mlp_tower_backward_split": (split_dgrad, MLP_FLOP / 1000),
     "mlp_wgrad_fused_split": (split_wgrad_fused, 2 * N * 65536 / 1000),
     "mlp_wgrad_fused_gate": (gate_wgrad_fused, 2 * N * 65536 / 1000),
+    "mlp_tower_backward_gate_f16": (f16_dgrad_gate, MLP_FLOP / 1000),
     "mlp_wgrad_split": (lambda: hip.mlp_wgrad_split(mlp_dz2, mlp_x, mlp_w1, mlp_b1), 2 * N * 65536 / 1000),
     "mlp_wgrad_fused": (lambda: hip.mlp_wgrad(mlp_dz2, mlp_h1), 2 * N * 65536 / 1000),
     # same launch on all-zero operands: the gap to the line above is clock / power, not the kernel
