@@ -687,6 +687,19 @@ constexpr int f16_backward_lds_bytes(int k_in) {
 
 template <bool FIRST>
 __device__ __forceinline__ void f16_mma(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
+  if constexpr ((kSplitDiagSkip & 2048) != 0) {  // tuning builds: no matrix work (one MFMA per group keeps the data flow)
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[0]), __builtin_bit_cast(half8, b[0]),
+                                                       FIRST ? zero : acc[0][0], 0, 0, 0);
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (mt + nt) acc[mt][nt] = acc[0][0];
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
