@@ -414,7 +414,7 @@ def run(args: argparse.Namespace) -> None:
         return "f16x2-split" if f16 else "bf16x3-split" if ok else "f32"
 
     lstm_gemm = {  # the recurrent models' LSTM (config 5): FLOP per row-step, matrix pipe
-        "lstm_step": (2.0 * 256 * 1024, "bf16x3-split"), "lstm_step_save": (2.0 * 256 * 1024, "bf16x3-split"),
+        "lstm_step": (2.0 * 256 * 1024, "f16x2-split"), "lstm_step_save": (2.0 * 256 * 1024, "f16x2-split"),
         "lstm_forward": (2.0 * 264 * 1024, "f32"), "lstm_forward_save": (2.0 * 264 * 1024, "f32"),
         "lstm_backward": (2.0 * 1024 * 256, "f32"),
         "lstm_wgrad": (2.0 * 1024 * 256, "bf16x3-split" if os.environ.get("RL8_AMD_LSTM_GEMM", "split") == "split" else "f32"),
@@ -431,8 +431,9 @@ def run(args: argparse.Namespace) -> None:
                 "pmc_traffic_bytes_per_launch": None,
             }
             if gemm != "f32":
-                executed = SPLIT_PRODUCTS * flops_per_launch
+                executed = PLANE_PRODUCTS[gemm] * flops_per_launch
                 kernels[name].update({
+                    "plane_products": PLANE_PRODUCTS[gemm],
                     "executed_bf16_flop_per_launch": executed,
                     "executed_bf16_TFLOPs": round(executed / (rec["avg_ms"] * 1e-3) / 1e12, 1),
                     "frac_of_bf16_mfma_peak": round(executed / (rec["avg_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -482,13 +482,14 @@ int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const flo
 
 /* ---------------------------------------------------------------------- *
  * a-9, second generation: ONE LSTM timestep with the recurrent product as an
- *      fp32-accurate product on the bf16 matrix pipe (the towers' bf16-plane scheme)
+ *      fp32-accurate product on the fp16 matrix pipe (the towers' two-plane scheme: |h| < 1, so
+ *      the state's planes are those of h * 2^14; W_hh carries one power of two for the matrix)
  *      src/rl8/models/_recurrent.py:312-333 (the nn.LSTM call of the default recurrent
  *      models), algorithms/_recurrent.py:385-431 (its per-timestep use in collect())
  * The time loop is the caller's: one launch per timestep, states exchanged through HBM.
  *
  * rl8_lstm_pack_split: torch-layout parameters -> `packed` (rl8_lstm_split_packed_bytes()
- *   bytes: W_hh as three bf16 planes in the kernel's fragment order) and `wb`
+ *   bytes: W_hh as two fp16 planes in the kernel's fragment order + its power of two) and `wb`
  *   (rl8_lstm_split_wb_floats() floats: [1024][8] = [w_ih row | 0.. | b_ih + b_hh]).
  * rl8_lstm_split_state: h [B][pitch] fp32 -> `planes` (rl8_lstm_split_state_bytes(B) bytes),
  *   the step kernel's A operand.
@@ -496,7 +497,7 @@ int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const flo
  *   c_prev row r at c_prev + r * c_prev_pitch; writes h_t, c_t rows at the given pitches
  *   (floats) and, when `gates` is not NULL, the post-activation gates i, f, g, o as
  *   [4][256] per row at gates + r * gates_pitch (what rl8_lstm_backward_f32 reads); when
- *   `planes_out` is not NULL, h_t also as bf16 planes (rl8_lstm_split_state's layout) for the
+ *   `planes_out` is not NULL, h_t also as fp16 planes (rl8_lstm_split_state's layout) for the
  *   next timestep's call, so that only the first step of a sequence needs rl8_lstm_split_state.
  *   d_in in {1, 2, 3, 5} (rl8_lstm_split_supports); other widths keep rl8_lstm_forward_f32.
  * ---------------------------------------------------------------------- */

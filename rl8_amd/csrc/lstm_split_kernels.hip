@@ -1,16 +1,20 @@
 // a-9 (recurrent PPO), second generation: one LSTM timestep of the default
 // recurrent models (src/rl8/models/_recurrent.py:201-321 -> torch.nn.LSTM(d, 256,
 // batch_first)) with the recurrent product h_{t-1} x W_hh^T as an fp32-ACCURATE product
-// on the bf16 matrix pipe -- the scheme of mlp_split_kernels.hip (an fp32 value is the
-// exact sum of three bf16 planes; six plane products per fp32 product; fp32 accumulate).
+// on the 16-bit matrix pipe.  First on bf16 planes (three per operand, six plane products,
+// the scheme of mlp_split_kernels.hip); now on fp16 planes (two per operand, THREE plane
+// products: mlp_f16_kernels.hip), which costs nothing here: |h| < 1 by construction
+// (h = o * tanh(c)), so the state's planes are those of h * 2^14 with no per-row factor, and
+// W_hh gets one power of two for the matrix (behind the planes, like the towers' W2); the
+// inverse of both meets the accumulators in the epilogue's first fma.
 // lstm_kernels.hip runs the same step on fp32 MFMAs (64 cycles per 32x32x2 block; 108-129
-// TFLOP/s); this one runs 2.7x fewer matrix-pipe cycles per product.
+// TFLOP/s); this one runs 5.3x fewer matrix-pipe cycles per product.
 //
 // Shape.  The time loop is OUTSIDE the kernel (one launch per timestep): with both
 // operands as bf16 planes in LDS there is no room to keep a tile's h_t on chip between
 // steps, and a launch over 2^19 sequences is long enough that it does not matter.
-//   rl8_lstm_split_state      h_{t-1} [B][256] fp32 -> three bf16 planes in fragment order
-//                             (1.5 KiB per row; HBM-bound, 2.5 KiB of traffic per row);
+//   rl8_lstm_split_state      h_{t-1} [B][256] fp32 -> two fp16 planes in fragment order
+//                             (1 KiB per row; HBM-bound, 2 KiB of traffic per row);
 //   rl8_lstm_step_split_f32   per 128-row tile and block of 64 hidden units: gate
 //                             pre-activations = h planes x W_hh planes, BOTH operands
 //                             HBM/L2 -> LDS by direct-to-LDS loads (no registers, no VALU
@@ -27,8 +31,12 @@ namespace rl8 {
 
 constexpr int kLsUnits = 64;                      // hidden units per workgroup pass
 constexpr int kLsBlocks = kHidden / kLsUnits;     // unit blocks (grid dimension)
-constexpr int kLsPackedBytes = kLsBlocks * kSplitPackedBytes;  // W_hh planes: 1.5 MiB
-constexpr int kLsAChunkBytes = 12 * 1024;         // one k-step of a 128-row tile: [plane][k-half][row half] x 1 KiB
+constexpr int kLsABytes = 2 * kSplitPlaneStride;  // LDS: [plane][k-half][row] x 16 B
+constexpr int kLsBBytes = 2 * 8 * 1024;           // LDS: [column tile][plane] x 1 KiB
+constexpr int kLsStageBytes = kLsABytes + kLsBBytes;
+constexpr int kLsWBlockBytes = kSplitSteps * kLsBBytes;           // W_hh planes of one unit block: 256 KiB
+constexpr int kLsPackedBytes = kLsBlocks * kLsWBlockBytes;        // 1 MiB (+ 16 bytes: scale, 1 / scale)
+constexpr int kLsAChunkBytes = 8 * 1024;          // one k-step of a 128-row tile: [plane][k-half][row half] x 1 KiB
 constexpr int kLsATileBytes = kSplitSteps * kLsAChunkBytes;
 constexpr int kLsInCols = 8;                      // [w_ih (d_in <= 7) ... | b_ih + b_hh] per gate row
 constexpr int kLsXBytes = 7 * kSplitRows * 4;     // x tile in LDS, [input][row]
@@ -41,21 +49,42 @@ constexpr int kLsDiag = RL8_LS_DIAG;
 __device__ __forceinline__ float ls_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ls_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
-__device__ __forceinline__ void ls_planes(const float (&v)[8], u32x4 (&planes)[3]) {
+// eight values times `scale` (a power of two) -> hi / lo fp16 planes
+__device__ __forceinline__ void ls_planes(const float (&v)[8], float scale, u32x4 (&planes)[2]) {
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
-    uint32_t hi, mid, lo;
-    split_pair(v[e], v[e + 1], hi, mid, lo);
+    uint32_t hi, lo;
+    f16_pair(v[e] * scale, v[e + 1] * scale, hi, lo);
     planes[0][e >> 1] = hi;
-    planes[1][e >> 1] = mid;
-    planes[2][e >> 1] = lo;
+    planes[1][e >> 1] = lo;
+  }
+}
+constexpr float kLsStateScale = 16384.0f;  // 2^14: |h| < 1
+
+// max |W_hh| -> {2^k, 2^-k} with max * 2^k < 2^14, behind the planes (one workgroup).
+__global__ __launch_bounds__(1024) void lstm_whh_scale_kernel(const float *__restrict__ w_hh, float *__restrict__ tail) {
+  __shared__ float red[1024];
+  const int tid = threadIdx.x;
+  float mx = 0.0f;
+  for (int i = tid; i < 4 * kHidden * kHidden; i += 1024) mx = __builtin_fmaxf(mx, __builtin_fabsf(w_hh[i]));
+  red[tid] = mx;
+  __syncthreads();
+  for (int half = 512; half > 0; half >>= 1) {
+    if (tid < half) red[tid] = __builtin_fmaxf(red[tid], red[tid + half]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int e = f16_bound_exponent(red[0]);
+    tail[0] = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
+    tail[1] = __builtin_amdgcn_ldexpf(1.0f, e - kF16Top);
+    tail[2] = tail[3] = 0.0f;
   }
 }
 
-// W_hh [1024][256] (torch gate order i, f, g, o) -> planes: 16-byte unit
-// ((((ub*16 + s)*8 + ct)*3 + p)*64 + l) holds, for plane p, the eight values
+// W_hh [1024][256] (torch gate order i, f, g, o), times the matrix's power of two -> planes: 16-byte unit
+// ((((ub*16 + s)*8 + ct)*2 + p)*64 + l) holds, for plane p, the eight values
 //   W_hh[256 q + 64 ub + 32 wc + (l & 31)][16 s + 8 (l >> 5) + e],   ct = 4 wc + q,
-// i.e. per unit block and k-step the 24 KiB the step's direct-to-LDS copy fetches, with
+// i.e. per unit block and k-step the 16 KiB the step's direct-to-LDS copy fetches, with
 // column tile ct = (wave column half, gate).  wb [1024][8] = [w_ih row | 0.. | b_ih + b_hh].
 __global__ __launch_bounds__(kBlock) void lstm_pack_split_kernel(const float *__restrict__ w_ih,
                                                                  const float *__restrict__ w_hh,
@@ -74,15 +103,16 @@ __global__ __launch_bounds__(kBlock) void lstm_pack_split_kernel(const float *__
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = w_hh[j * kHidden + k0 + e];
-  u32x4 planes[3];
-  ls_planes(v, planes);
+  const float scale = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(packed) + kLsPackedBytes)[0];
+  u32x4 planes[2];
+  ls_planes(v, scale, planes);
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
-    reinterpret_cast<u32x4 *>(packed)[(((ub * kSplitSteps + s) * 8 + ct) * 3 + p) * 64 + l] = planes[p];
+  for (int p = 0; p < 2; ++p)
+    reinterpret_cast<u32x4 *>(packed)[(((ub * kSplitSteps + s) * 8 + ct) * 2 + p) * 64 + l] = planes[p];
 }
 
 // h [B][pitch] fp32 -> planes [tile][k-step][plane][k-half][row] x 16 B (rows past B are
-// zero): the A operand of rl8_lstm_step_split_f32, one contiguous 12 KiB per tile and
+// zero): the A operand of rl8_lstm_step_split_f32, one contiguous 8 KiB per tile and
 // k-step.  Thread = (row, k-half); sixteen fragments each.
 __global__ __launch_bounds__(kBlock) void lstm_split_state_kernel(const float *__restrict__ h, int64_t pitch,
                                                                   int64_t b, uint32_t *__restrict__ planes_out) {
@@ -102,10 +132,10 @@ __global__ __launch_bounds__(kBlock) void lstm_split_state_kernel(const float *_
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.0f;
       }
-      u32x4 planes[3];
-      ls_planes(v, planes);
+      u32x4 planes[2];
+      ls_planes(v, kLsStateScale, planes);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) dst[s * (kLsAChunkBytes / 16) + p * 256] = planes[p];
+      for (int p = 0; p < 2; ++p) dst[s * (kLsAChunkBytes / 16) + p * 256] = planes[p];
     }
   }
 }
@@ -115,11 +145,13 @@ struct LstmStepArgs {
   const float *c_prev;  // [B][c_prev_pitch]
   float *h_out, *c_out; // [B][*_pitch]
   float *gates;         // [B][gates_pitch] -> [4][256] post-activation i, f, g, o; or null
-  void *planes_out;     // h_t as bf16 planes for the NEXT step (rl8_lstm_split_state's layout); or null
+  void *planes_out;     // h_t as fp16 planes for the NEXT step (rl8_lstm_split_state's layout); or null
   int64_t x_pitch, c_prev_pitch, h_out_pitch, c_out_pitch, gates_pitch;
 };
 
-constexpr int lstm_step_lds_bytes() { return 2 * kSplitStageBytes + kLsXBytes; }
+constexpr int kLsHPitch = 32 * 4 + 16;                                  // h scratch of the plane emission: [64 rows][144 B] per wave
+constexpr int kLsScratchTail = 4 * 64 * kLsHPitch - kLsStageBytes;      // ... = chunk stage 1 + this tail
+constexpr int lstm_step_lds_bytes() { return 2 * kLsStageBytes + kLsScratchTail + kLsXBytes; }
 static_assert(lstm_step_lds_bytes() <= 80 * 1024, "two workgroups per CU");
 
 // One timestep for rows [0, b): work item = (128-row tile, unit block ub); a workgroup
@@ -136,9 +168,12 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
   const int wr = wave >> 1, wc = wave & 1;
   const int ub = blockIdx.x & (kLsBlocks - 1);
   const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
-  const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
+  const unsigned b_read = lds0 + kLsABytes + (4 * wc * 2) * 1024 + lane * 16;
   const __amdgpu_buffer_rsrc_t wrsrc =
-      buffer_rsrc(static_cast<const unsigned char *>(w_planes) + ub * kSplitPackedBytes, kSplitPackedBytes);
+      buffer_rsrc(static_cast<const unsigned char *>(w_planes) + ub * kLsWBlockBytes, kLsWBlockBytes);
+  // undoes the operand scaling: 2^-14 of the state planes times W_hh's inverse power of two
+  const float unscale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(w_planes) + kLsPackedBytes)[1] *
+                        (1.0f / kLsStateScale);
   const int64_t tiles = (b + kSplitRows - 1) / kSplitRows;
   const int64_t tile_stride = gridDim.x / kLsBlocks;
 
@@ -156,20 +191,20 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
   auto a_rsrc = [&](int64_t tile) {
     return buffer_rsrc(static_cast<const unsigned char *>(a_planes) + tile * kLsATileBytes, kLsATileBytes);
   };
-  // chunk ks of `tile` -> stage: 24 one-KiB blocks of W planes, 12 of h planes
+  // chunk ks of `tile` -> stage: 16 one-KiB blocks of W planes, 8 of h planes
   auto request = [&](const __amdgpu_buffer_rsrc_t &arsrc, int ks, int stage) {
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int block = wave * 6 + u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, smem + stage * kSplitStageBytes + kSplitABytes + block * 1024, 16,
-                                               lane * 16, (ks * 24 + block) * 1024, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      const int block = wave * 4 + u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, smem + stage * kLsStageBytes + kLsABytes + block * 1024, 16,
+                                               lane * 16, (ks * 16 + block) * 1024, 0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int c = wave * 3 + u;  // ((plane*2 + kh)*2 + half)
+    for (int u = 0; u < 2; ++u) {
+      const int c = wave * 2 + u;  // ((plane*2 + kh)*2 + half)
       const int lds_at = (c >> 2) * kSplitPlaneStride + ((c >> 1) & 1) * kSplitKhStride + (c & 1) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, smem + stage * kSplitStageBytes + lds_at, 16, lane * 16,
-                                               (ks * 12 + c) * 1024, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, smem + stage * kLsStageBytes + lds_at, 16, lane * 16,
+                                               (ks * 8 + c) * 1024, 0, 0);
     }
   };
   auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -179,40 +214,24 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
     constexpr bool FIRST = decltype(first_tag)::value;
     constexpr int P = decltype(parity_tag)::value;
     request(next_rsrc, next_ks, P ^ 1);
-    const unsigned ar = a_read + P * kSplitStageBytes, br = b_read + P * kSplitStageBytes;
-    SplitFrags f;
+    const unsigned ar = a_read + P * kLsStageBytes, br = b_read + P * kLsStageBytes;
+    SplitFrags f;  // ah / bh: hi planes, am / bm: lo planes -- all twelve fragments of the step at once
     f.ah[0] = lds_read_b128<0>(ar);
     f.ah[1] = lds_read_b128<512>(ar);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) f.bh[nt] = nt == 0   ? lds_read_b128<0>(br)
-                                              : nt == 1 ? lds_read_b128<3 * 1024>(br)
-                                              : nt == 2 ? lds_read_b128<6 * 1024>(br)
-                                                        : lds_read_b128<9 * 1024>(br);
+    f.bh[0] = lds_read_b128<0>(br);
+    f.bh[1] = lds_read_b128<2 * 1024>(br);
+    f.bh[2] = lds_read_b128<4 * 1024>(br);
+    f.bh[3] = lds_read_b128<6 * 1024>(br);
     f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
     f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<1024>(br)
-                                              : nt == 1 ? lds_read_b128<4 * 1024>(br)
-                                              : nt == 2 ? lds_read_b128<7 * 1024>(br)
-                                                        : lds_read_b128<10 * 1024>(br);
+    f.bm[0] = lds_read_b128<1024>(br);
+    f.bm[1] = lds_read_b128<3 * 1024>(br);
+    f.bm[2] = lds_read_b128<5 * 1024>(br);
+    f.bm[3] = lds_read_b128<7 * 1024>(br);
     wait_lds_all(f);
-    split_mma<FIRST>(f.am, f.bm, acc);
-    split_mma<false>(f.ah, f.bm, acc);
-    split_mma<false>(f.am, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    f.am[0] = lds_read_b128<2 * kSplitPlaneStride>(ar);
-    f.am[1] = lds_read_b128<2 * kSplitPlaneStride + 512>(ar);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<2 * 1024>(br)
-                                              : nt == 1 ? lds_read_b128<5 * 1024>(br)
-                                              : nt == 2 ? lds_read_b128<8 * 1024>(br)
-                                                        : lds_read_b128<11 * 1024>(br);
-    __builtin_amdgcn_sched_barrier(0);
-    split_mma<false>(f.ah, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_lds_all(f);
-    split_mma<false>(f.ah, f.bm, acc);
-    split_mma<false>(f.am, f.bh, acc);
+    f16_mma<FIRST>(f.am, f.bh, acc);  // lo x hi
+    f16_mma<false>(f.ah, f.bm, acc);  // hi x lo
+    f16_mma<false>(f.ah, f.bh, acc);  // hi x hi
     __builtin_amdgcn_sched_barrier(0);
     step_barrier();
   };
@@ -251,7 +270,7 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
     do_step(F{}, P1{}, nrsrc, 0);  // the next item's chunk 0 lands during the epilogue
 
     // ---- epilogue: pre-activations -> gates -> cell update ------------------------
-    const unsigned xs = lds0 + 2 * kSplitStageBytes;
+    const unsigned xs = lds0 + 2 * kLsStageBytes + kLsScratchTail;
     if (tid < kSplitRows) {
 #pragma unroll
       for (int i = 0; i < DIN; ++i) lds_write_b32(xs + (i * kSplitRows + tid) * 4, xr[i]);
@@ -281,12 +300,12 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
     [[maybe_unused]] float diag_sum = 0.0f;
     // h_t of this wave's [64 rows][32 units] block also goes through LDS (chunk stage 1 is
     // dead from the barrier of step 15 to the barrier that ends this epilogue; row pitch 144 B)
-    // when the caller wants it as bf16 planes for the next timestep: written as the
+    // (+ the tail behind it) when the caller wants it as fp16 planes for the next timestep: written as the
     // accumulators hold it (lane = unit), read back lane = row, eight units = one fragment.
-    constexpr int kHPitch = 32 * 4 + 16;
-    static_assert(4 * 64 * kHPitch <= kSplitStageBytes, "h scratch fits in stage 1");
+    constexpr int kHPitch = kLsHPitch;
+    static_assert(4 * 64 * kHPitch <= kLsStageBytes + kLsScratchTail, "h scratch = stage 1 + the tail");
     const bool want_planes = args.planes_out != nullptr;
-    const unsigned h_scr = lds0 + kSplitStageBytes + wave * (64 * kHPitch);
+    const unsigned h_scr = lds0 + kLsStageBytes + wave * (64 * kHPitch);
     const unsigned h_scr_w = h_scr + 4 * hhe * kHPitch + l32e * 4;
     float cprev[2][16];
 #pragma unroll
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
           float pre[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float v = acc[mt][q][r] + bias[q];
+            float v = __builtin_fmaf(acc[mt][q][r], unscale, bias[q]);
 #pragma unroll
             for (int i = 0; i < DIN; ++i) v = __builtin_fmaf(__uint_as_float(xq[i][e]), w_in[q][i], v);
             pre[q] = v;
@@ -367,13 +386,13 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
       for (int j = 0; j < 4; ++j) {
         const float v[8] = {__uint_as_float(lo[j][0]), __uint_as_float(lo[j][1]), __uint_as_float(lo[j][2]), __uint_as_float(lo[j][3]),
                             __uint_as_float(hi[j][0]), __uint_as_float(hi[j][1]), __uint_as_float(hi[j][2]), __uint_as_float(hi[j][3])};
-        u32x4 planes[3];
-        ls_planes(v, planes);
+        u32x4 planes[2];
+        ls_planes(v, kLsStateScale, planes);
         const int u8 = 8 * ub + 4 * wc + j;
         const int step = u8 >> 1, khj = u8 & 1;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          *reinterpret_cast<u32x4 *>(dst + (step * 12 + (p * 2 + khj) * 2 + wr) * 1024 + lane_now * 16) = planes[p];
+        for (int p = 0; p < 2; ++p)
+          *reinterpret_cast<u32x4 *>(dst + (step * 8 + (p * 2 + khj) * 2 + wr) * 1024 + lane_now * 16) = planes[p];
       }
       // every wave is done with the scratch before any wave's next step 0 writes stage 1
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -387,7 +406,7 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
 using namespace rl8;
 
 RL8_API int rl8_lstm_split_supports(int d_in) { return d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5; }
-RL8_API int64_t rl8_lstm_split_packed_bytes(void) { return kLsPackedBytes; }
+RL8_API int64_t rl8_lstm_split_packed_bytes(void) { return kLsPackedBytes + 16; }
 RL8_API int64_t rl8_lstm_split_wb_floats(void) { return 4 * kHidden * kLsInCols; }
 // bytes of the state planes for b rows (whole 128-row tiles)
 RL8_API int64_t rl8_lstm_split_state_bytes(int64_t b) { return ((b + kSplitRows - 1) / kSplitRows) * (int64_t)kLsATileBytes; }
@@ -398,6 +417,8 @@ RL8_API int rl8_lstm_pack_split(const float *w_ih, const float *w_hh, const floa
   if (d_in < 1 || d_in > kLsInCols - 1) return RL8_ESIZE;
   if (!aligned16(packed)) return RL8_EALIGN;
   const int units = kLsBlocks * kSplitSteps * 8 * 64;  // 32 768 >= 1024 * 8
+  lstm_whh_scale_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(
+      w_hh, reinterpret_cast<float *>(static_cast<unsigned char *>(packed) + kLsPackedBytes));
   lstm_pack_split_kernel<<<(units + kBlock - 1) / kBlock, kBlock, 0, (hipStream_t)stream>>>(
       w_ih, w_hh, b_ih, b_hh, d_in, static_cast<uint32_t *>(packed), wb);
   return launch_status();

@@ -20,59 +20,11 @@
 
 namespace rl8 {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-
 constexpr int kF16ABytes = 2 * kSplitPlaneStride;          // [plane][k-half][row] x 16 B
 constexpr int kF16BBytes = 2 * 8 * 1024;                   // [column tile][plane] x 1 KiB
 constexpr int kF16StageBytes = kF16ABytes + kF16BBytes;    // 24 832
 constexpr int kF16PackedBytes = kSplitSteps * kF16BBytes;  // 262 144 (+ 16 bytes: scale, 1 / scale)
 constexpr int kF16ScratchTail = 4 * 64 * (128 + 16) - kF16StageBytes;  // the h2 transpose scratch beyond stage 1
-constexpr int kF16Top = 14;                                // scaled operands stay below 2^14 (fp16 max 65504)
-
-// (x0, x1) -> packed fp16 pairs hi, lo (element 0 in the low half); scalar arithmetic, as
-// split_pair(): no packed fp32 ops beside the MFMAs.
-__device__ __forceinline__ void f16_pair(float x0, float x1, uint32_t &hi, uint32_t &lo) {
-  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-  const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
-  const half2v hp = {h0, h1}, lp = {(_Float16)r0, (_Float16)r1};
-  hi = __builtin_bit_cast(uint32_t, hp);
-  lo = __builtin_bit_cast(uint32_t, lp);
-}
-
-// bound < 2^e for the power of two that scales an operand (2^(14 - e)); bounds below 2^-80
-// (and zero) keep a finite factor: such operands are far below fp16's top anyway.
-__device__ __forceinline__ int f16_bound_exponent(float bound) {
-  const int e = __builtin_amdgcn_frexp_expf(bound);
-  return e < -80 ? -80 : e;
-}
-
-// One plane product of the wave's 64 x 128 tile, operand roles exchanged (transposed
-// accumulators: lane = row; see split_mma_t).
-template <bool FIRST>
-__device__ __forceinline__ void f16_mma_t(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
-  if constexpr ((kSplitDiagSkip & 2048) != 0) {  // tuning builds: no matrix work (one MFMA per group keeps the data flow)
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, b[0]), __builtin_bit_cast(half8, a[0]),
-                                                       FIRST ? zero : acc[0][0], 0, 0, 0);
-    if constexpr (FIRST) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          if (mt + nt) acc[mt][nt] = acc[0][0];
-    }
-    return;
-  }
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, b[nt]), __builtin_bit_cast(half8, a[mt]),
-                                                           FIRST ? zero : acc[mt][nt], 0, 0, 0);
-    }
-}
 
 // w2 [256][256] fp32 -> two fp16 planes of w2 * 2^k in fragment order, k chosen so that
 // max |w2| * 2^k < 2^14: 16-byte unit ((s*8 + ct)*2 + p)*64 + l holds, for plane p,
@@ -683,31 +635,6 @@ static int dispatch_forward_f16_nout(int n_out, int grid, hipStream_t s, const f
 // a function of the row's dOut alone, so the producer thread has it in registers.
 constexpr int f16_backward_lds_bytes(int k_in) {
   return 2 * kF16StageBytes + kHidden * (1 + k_in) * 4 + kSplitRows * 32 + 2 * kSplitRows * 4;
-}
-
-template <bool FIRST>
-__device__ __forceinline__ void f16_mma(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
-  if constexpr ((kSplitDiagSkip & 2048) != 0) {  // tuning builds: no matrix work (one MFMA per group keeps the data flow)
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[0]), __builtin_bit_cast(half8, b[0]),
-                                                       FIRST ? zero : acc[0][0], 0, 0, 0);
-    if constexpr (FIRST) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          if (mt + nt) acc[mt][nt] = acc[0][0];
-    }
-    return;
-  }
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[mt]), __builtin_bit_cast(half8, b[nt]),
-                                                           FIRST ? zero : acc[mt][nt], 0, 0, 0);
-    }
 }
 
 // GATE: heads whose dZ2 is rank one in (sample, unit) -- one output, or two outputs with exactly opposite

@@ -243,4 +243,83 @@ __device__ __forceinline__ float half_wave_sum_level(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false));
 }
 
+// ---- fp16 two-plane scheme (mlp_f16_kernels.hip, lstm_split_kernels.hip) ----------------
+// An operand scaled by a power of two into fp16's range is carried as hi = fp16_rn(v),
+// lo = fp16_rn(v - hi) (22 significand bits); a*b = ah*bh + ah*bl + al*bh + O(2^-22 |a*b|):
+// three v_mfma_f32_32x32x16_f16 per 16 k, products exact, fp32 accumulate.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+constexpr int kF16Top = 14;                                // scaled operands stay below 2^14 (fp16 max 65504)
+
+// (x0, x1) -> packed fp16 pairs hi, lo (element 0 in the low half); scalar arithmetic, as
+// split_pair(): no packed fp32 ops beside the MFMAs.
+__device__ __forceinline__ void f16_pair(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
+  const half2v hp = {h0, h1}, lp = {(_Float16)r0, (_Float16)r1};
+  hi = __builtin_bit_cast(uint32_t, hp);
+  lo = __builtin_bit_cast(uint32_t, lp);
+}
+
+// bound < 2^e for the power of two that scales an operand (2^(14 - e)); bounds below 2^-80
+// (and zero) keep a finite factor: such operands are far below fp16's top anyway.
+__device__ __forceinline__ int f16_bound_exponent(float bound) {
+  const int e = __builtin_amdgcn_frexp_expf(bound);
+  return e < -80 ? -80 : e;
+}
+
+// One plane product of the wave's 64 x 128 tile, operand roles exchanged (transposed
+// accumulators: lane = row; see split_mma_t).
+template <bool FIRST>
+__device__ __forceinline__ void f16_mma_t(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
+  if constexpr ((kSplitDiagSkip & 2048) != 0) {  // tuning builds: no matrix work (one MFMA per group keeps the data flow)
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, b[0]), __builtin_bit_cast(half8, a[0]),
+                                                       FIRST ? zero : acc[0][0], 0, 0, 0);
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (mt + nt) acc[mt][nt] = acc[0][0];
+    }
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, b[nt]), __builtin_bit_cast(half8, a[mt]),
+                                                           FIRST ? zero : acc[mt][nt], 0, 0, 0);
+    }
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void f16_mma(const u32x4 (&a)[2], const u32x4 (&b)[4], f32x16 (&acc)[2][4]) {
+  if constexpr ((kSplitDiagSkip & 2048) != 0) {  // tuning builds: no matrix work (one MFMA per group keeps the data flow)
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[0]), __builtin_bit_cast(half8, b[0]),
+                                                       FIRST ? zero : acc[0][0], 0, 0, 0);
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          if (mt + nt) acc[mt][nt] = acc[0][0];
+    }
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[mt]), __builtin_bit_cast(half8, b[nt]),
+                                                           FIRST ? zero : acc[mt][nt], 0, 0, 0);
+    }
+}
+
+
 }  // namespace rl8

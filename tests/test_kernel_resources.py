@@ -189,8 +189,8 @@ def _check_wgrad_scalar_windows(text: str) -> None:
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_compiled_lstm_split_kernels_resources(tmp_path):
-    """The bf16-plane LSTM step kernel (lstm_split_kernels.hip): every compiled input width
-    free of scratch, two workgroups per CU, no packed fp32 arithmetic beside the bf16 MFMAs,
+    """The fp16-plane LSTM step kernel (lstm_split_kernels.hip): every compiled input width
+    free of scratch, two workgroups per CU, no packed fp32 arithmetic beside the MFMAs,
     and no hand-issued load's destination touched before its wait."""
     csrc = os.path.join(ROOT, "rl8_amd", "csrc")
     asm = tmp_path / "lstm_split.s"
