@@ -483,7 +483,7 @@ def test_fused_tower_autograd_uses_the_split_kernels_and_matches_eager():
         assert _rel(got[n], p.grad.double()) < 2e-5, n
 
 
-@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2", "f16x2-gate"])
 @pytest.mark.parametrize("m,parts", [(1 << 23, 8), (1 << 25, 4)])
 def test_full_size_launch_equals_its_chunks(m, parts, scheme):
     """BASELINE's training launch (2^25 rows: `Algorithm.step` feeds the towers the whole
@@ -495,11 +495,22 @@ def test_full_size_launch_equals_its_chunks(m, parts, scheme):
     x = torch.empty(m, 1, device=DEV).uniform_(-100, 100, generator=g)  # DiscreteDummyEnv observations
     p = _params(g, 1, 2)
     dout = torch.randn(m, 2, device=DEV, generator=g) / m
-    pack = hip.mlp_pack_w2_f16 if scheme == "f16x2" else hip.mlp_pack_w2_split
+    gate_pack = None
+    if scheme == "f16x2-gate":  # the headline's own kernels: a two-way categorical's gradients, gate-mode backward
+        dout[:, 1] = -dout[:, 0]
+        gate_pack = lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])  # noqa: E731
+    pack = hip.mlp_pack_w2_split if scheme == "bf16x3" else hip.mlp_pack_w2_f16
     w2s, w2ts = pack(p["w2"]), pack(p["w2"], transposed=True)
     out, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2s, p["b2"], p["w3"], p["b3"], save=True,
                                                    save_h1=False, save_gate=True)
-    full = hip.mlp_tower_backward(x, None, h2, dout, w2ts, p["w3"], p["w1"], p["b1"], gate2=gate)
+    hip.timer.reset()
+    hip.timer.enabled = True
+    try:
+        full = hip.mlp_tower_backward(x, None, h2, dout, w2ts, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack)
+        launched = set(hip.timer.summary())
+    finally:
+        hip.timer.enabled = False
+    assert ("mlp_tower_backward_gate" in launched and "mlp_wgrad_gate" in launched) == (scheme == "f16x2-gate")
     acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in full.items()}
     step = m // parts
     for i in range(parts):
@@ -507,7 +518,8 @@ def test_full_size_launch_equals_its_chunks(m, parts, scheme):
         o, _, h2c, gc = hip.mlp_tower_forward_split(x[sl], p["w1"], p["b1"], w2s, p["b2"], p["w3"], p["b3"], save=True,
                                                     save_h1=False, save_gate=True)
         assert torch.equal(o, out[sl]) and torch.equal(h2c, h2[sl]) and torch.equal(gc, gate[sl])
-        part = hip.mlp_tower_backward(x[sl], None, h2c, dout[sl].contiguous(), w2ts, p["w3"], p["w1"], p["b1"], gate2=gc)
+        part = hip.mlp_tower_backward(x[sl], None, h2c, dout[sl].contiguous(), w2ts, p["w3"], p["w1"], p["b1"], gate2=gc,
+                                      gate_pack=gate_pack)
         for k in acc:
             acc[k] += part[k].double()
         del o, h2c, gc, part
