@@ -257,29 +257,49 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   f32x16 acc[2][4];
   int64_t r0 = p_r0;  // consumer's tile
 
-  // One k-step: consume stage P (chunk s) while producing chunk s+1 -- of the
-  // next tile when s = 15 -- into the other stage.
-  auto do_step = [&](auto first_tag, auto parity_tag, int s) {
+  // One k-step: consume stage P (chunk s) while producing chunk s+1 -- of the next tile when
+  // s = 15 -- into the other stage.  The step barrier sits in FRONT of the step's last group of
+  // products (hi x hi, whose operands are in registers by then): behind it the chunk in the other
+  // stage is complete, so the fragments the next step opens with (A lo planes, B hi planes) are
+  // fetched into the registers the first two groups have released, and the W2 chunk after next is
+  // requested into the stage just read -- a step opens with eight products instead of an LDS round
+  // trip.  The B registers trade roles each step for that (hi planes in f.bh in even steps, in
+  // f.bm in odd ones).  KIND 0: first step of a tile (nothing fetched ahead: the epilogue of the
+  // previous tile lies in between and has the registers); KIND 2: last step (fetches nothing).
+  SplitFrags f;
+  auto open_reads = [&](auto parity_tag) {  // of the chunk in stage P: A lo planes -> am, B hi planes -> that step's first B set
+    constexpr int P = decltype(parity_tag)::value;
+    const unsigned ar = a_read + P * kF16StageBytes, br = b_read + P * kF16StageBytes;
+    u32x4(&BH)[4] = *(P == 0 ? &f.bh : &f.bm);
+    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
+    BH[0] = lds_read_b128<0>(br);
+    BH[1] = lds_read_b128<2 * 1024>(br);
+    BH[2] = lds_read_b128<4 * 1024>(br);
+    BH[3] = lds_read_b128<6 * 1024>(br);
+    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
+  };
+  auto do_step = [&](auto first_tag, auto parity_tag, auto kind_tag, int s) {
     constexpr bool FIRST = decltype(first_tag)::value;
     constexpr int P = decltype(parity_tag)::value;
+    constexpr int KIND = decltype(kind_tag)::value;
     const int ks = (s + 1) & (kSplitSteps - 1);
-    request_b(ks, P ^ 1);
     const unsigned ar = a_read + P * kF16StageBytes, br = b_read + P * kF16StageBytes;
-    SplitFrags f;  // ah / bh: hi planes, am / bm: lo planes -- all twelve fragments of the step at once
+    u32x4(&BH)[4] = *(P == 0 ? &f.bh : &f.bm);
+    u32x4(&BL)[4] = *(P == 0 ? &f.bm : &f.bh);
+    if constexpr (KIND == 0) {
+      request_b(1, 1);  // (late by one group: once per tile)
+      open_reads(parity_tag);
+    }
+    // am and BH are in (or on their way, KIND 0); the other two planes:
     f.ah[0] = lds_read_b128<0>(ar);
     f.ah[1] = lds_read_b128<512>(ar);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) f.bh[nt] = nt == 0   ? lds_read_b128<0>(br)
-                                              : nt == 1 ? lds_read_b128<2 * 1024>(br)
-                                              : nt == 2 ? lds_read_b128<4 * 1024>(br)
-                                                        : lds_read_b128<6 * 1024>(br);
-    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
-    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<1024>(br)
-                                              : nt == 1 ? lds_read_b128<3 * 1024>(br)
-                                              : nt == 2 ? lds_read_b128<5 * 1024>(br)
-                                                        : lds_read_b128<7 * 1024>(br);
+    BL[0] = lds_read_b128<1024>(br);
+    BL[1] = lds_read_b128<3 * 1024>(br);
+    BL[2] = lds_read_b128<5 * 1024>(br);
+    BL[3] = lds_read_b128<7 * 1024>(br);
+    if constexpr (KIND == 0) wait_lds_all(f);
+    __builtin_amdgcn_sched_barrier(0);
+    f16_mma_t<FIRST>(f.am, BH, acc);   // lo x hi: at once
     if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
       p_r0 += stride * kSplitRows;
       p_rows = rows_from(p_r0);
@@ -294,19 +314,25 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       set_row_scale();
     }
     // The next chunk's arithmetic is left to the scheduler to interleave with the
-    // first matrix group (VALU instructions issue beside the MFMAs for free);
-    // its fragments go to LDS behind that group.
+    // first matrix group (VALU instructions issue beside the MFMAs for free).
     u32x4 planes[2];
     produce_a(ks, planes);
-    wait_lds_all(f);
-    f16_mma_t<FIRST>(f.am, f.bh, acc);   // lo x hi
-    f16_mma_t<false>(f.ah, f.bm, acc);   // hi x lo
+    if constexpr (KIND != 0) wait_lds<0>(f.ah[0], f.ah[1], BL[0], BL[1], BL[2], BL[3]);
+    f16_mma_t<false>(f.ah, BL, acc);   // hi x lo: last use of BL
     __builtin_amdgcn_sched_barrier(0);
     write_a(P ^ 1, planes);
     __builtin_amdgcn_sched_barrier(0);
-    f16_mma_t<false>(f.ah, f.bh, acc);   // hi x hi
-    __builtin_amdgcn_sched_barrier(0);
     step_barrier();
+    if constexpr (KIND != 2) {
+      request_b((s + 2) & (kSplitSteps - 1), P);  // (s = 14: chunk 0 of the next tile)
+      if constexpr (P == 0) open_reads(std::integral_constant<int, 1>{});
+      else open_reads(std::integral_constant<int, 0>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f16_mma_t<false>(f.ah, BH, acc);   // hi x hi
+    __builtin_amdgcn_sched_barrier(0);
+    // landed before anything can copy or carry these registers (loop back-edge)
+    if constexpr (KIND != 2) wait_lds<0>(f.am[0], f.am[1], BL[0], BL[1], BL[2], BL[3]);
   };
   // Prologue: chunk 0 of the first tile.
   using T = std::true_type;
@@ -326,15 +352,18 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
     r0 = tile * kSplitRows;
     const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
-    do_step(T{}, P0{}, 0);
-    do_step(F{}, P1{}, 1);
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    do_step(T{}, P0{}, K0{}, 0);
+    do_step(F{}, P1{}, K1{}, 1);
 #pragma unroll 1
     for (int s = 2; s < kSplitSteps - 2; s += 2) {
-      do_step(F{}, P0{}, s);
-      do_step(F{}, P1{}, s + 1);
+      do_step(F{}, P0{}, K1{}, s);
+      do_step(F{}, P1{}, K1{}, s + 1);
     }
-    do_step(F{}, P0{}, kSplitSteps - 2);
-    do_step(F{}, P1{}, kSplitSteps - 1);
+    do_step(F{}, P0{}, K1{}, kSplitSteps - 2);
+    do_step(F{}, P1{}, K2{}, kSplitSteps - 1);
 
     // Epilogue on the TRANSPOSED accumulators (split_mma_t): this lane holds sample
     // row 64 wr + 32 mt + l32 and, of column block 128 wc + 32 nt, the sixteen columns
