@@ -350,7 +350,8 @@ int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const f
  * range; each is then split into hi = fp16(v), lo = fp16(v - hi) (22 significand
  * bits) and lo.hi + hi.lo + hi.hi is accumulated in fp32; the epilogue multiplies
  * by the inverse powers of two (exact).  Same arguments, outputs and save options
- * as rl8_mlp_tower_forward_split_f32; w2_f16 (rl8_mlp_f16_packed_bytes() bytes:
+ * as rl8_mlp_tower_forward_split_f32 (and save_gate2 may be given WITHOUT save_h2: see rl8_mlp_wgrad_gate_bits_f32);
+ * w2_f16 (rl8_mlp_f16_packed_bytes() bytes:
  * two fp16 planes in fragment order + {scale, 1/scale}) comes from
  * rl8_mlp_pack_w2_f16.  Replaces the same reference call sites
  * (rl8/models/_feedforward.py:115-132 forward of the 256-256 towers). */
@@ -373,6 +374,20 @@ int rl8_mlp_dout_pair_check(const float *dout /*[m][2]*/, int64_t m, int *flag_o
 int rl8_mlp_wgrad_fused_pair_f32(const float *h2, const float *dout, const float *x, const float *w1,
                                  const float *b1, const float *w3, int64_t m, int d_in,
                                  float *workspace, float *dw2_out, float *partials, void *stream);
+
+/* Rank-one heads without h2.  rl8_mlp_tower_forward_f16_f32 with save_h2 = NULL and save_gate2 given stores the
+ * gate bits alone (32 bytes per row instead of 1 KiB, none of the h2 store path); the data gradient's gate mode
+ * never needed h2; and the weight gradient's only other use of it, dW3 = dOut^T h2, follows from the sums M the
+ * gate-plane kernel forms anyway (dW2[j][i] = W3[j] M[j][i]):  with h2 = gate * (h1 W2^T + b2),
+ *   dW3[j] = sum_i W2[j][i] M[j][i] + b2[j] * sum_s gate[s][j] dOut[s].
+ * rl8_mlp_wgrad_gate_bits_f32: outputs of rl8_mlp_wgrad_fused_split_f32 (n_out = 1) / _pair_f32 (n_out = 2, after
+ * a clean rl8_mlp_dout_pair_check) from gate2 [m][8] instead of h2; w2 [256][256] and b2 [256] are the layer's
+ * own parameters.  In fp32 the result differs from the direct sum by the rounding the forward's own 256-term dot
+ * products put into h2 -- what another fp32 evaluation of h2 (the reference's) differs from this one by. */
+int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout, const float *x, const float *w1,
+                                const float *b1, const float *w2, const float *b2, const float *w3,
+                                int64_t m, int d_in, int n_out, float *workspace, float *dw2_out,
+                                float *partials, void *stream);
 
 /* The data-gradient half of the fused backward pass on the same fp16 planes (three MFMAs
  * per 16 k): the fused mode of rl8_mlp_tower_backward_split_f32 (no dZ2 store; gate2 -- the

@@ -83,7 +83,11 @@ constexpr int kF16Fixed = 2 * kF16StageBytes + kF16ScratchTail + 2 * kSplitRows 
 constexpr int f16_forward_lds_bytes(int k_out) { return kF16Fixed + kSplitRows * k_out * 4 + (1 + k_out) * kHidden * 4; }
 static_assert(f16_forward_lds_bytes(4) <= 80 * 1024, "two workgroups per CU");
 
-template <int DIN, int NOUT, bool SAVE>
+// SAVE: 0 inference; 1 training with h2 (and, on request, h1 and the gate bits of h2) stored; 2 training with
+// the gate bits ALONE -- what the backward pass of a rank-one head needs (gate-mode data gradient, gate-plane
+// weight gradient with dW3 taken from the weight-gradient sums: rl8_mlp_wgrad_gate_bits_f32): 32 bytes per row
+// instead of 1 KiB, and none of the h2 store path.
+template <int DIN, int NOUT, int SAVE>
 __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_tower_forward_f16_kernel(
     const float *__restrict__ x, int64_t m, int d_in_rt, const float *__restrict__ w1,
     const float *__restrict__ b1, const void *__restrict__ w2s, const float *__restrict__ b2,
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
         if (DIN > 0 || i < d_in) v = __builtin_fmaf(px[i], w1[(kb + e) * d_in + i], v);
       h[e] = relu1(v);
     }
-    if constexpr (SAVE && !(kSplitDiagSkip & 32)) {
+    if constexpr (SAVE == 1 && !(kSplitDiagSkip & 32)) {
       if (save_h1 != nullptr && prow < p_rows) {  // (h1 is optional: the bf16-plane backward recomputes it)
         f32x4 *dst = reinterpret_cast<f32x4 *>(save_h1 + p_r0 * kHidden + kb + (unsigned)(prow * kHidden));
         dst[0] = f32x4{h[0], h[1], h[2], h[3]};
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     // b2 / W3 come from the constants block in LDS (hand-issued reads, explicit waits).
     // (tuning builds, bit 4096: every tile's h2 lands on the first tile's lines -- the stores are issued but stay in L2)
         const __amdgpu_buffer_rsrc_t h2rsrc =
-        buffer_rsrc(SAVE ? save_h2 + ((kSplitDiagSkip & 4096) ? (r0 & 0x1ffff) : r0) * kHidden : nullptr, rows * kHidden * 4);
+        buffer_rsrc(SAVE == 1 ? save_h2 + ((kSplitDiagSkip & 4096) ? (r0 & 0x1ffff) : r0) * kHidden : nullptr, rows * kHidden * 4);
     const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
     const unsigned outp = lds_offset(smem) + kF16Fixed;
     const unsigned constp = outp + kSplitRows * kOut * 4 + (128 * wc + 4 * hh) * 4;
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
     // LDS returns; no scalar load is in flight here), behind the gate and head arithmetic.
     constexpr int kGroup = kOut >= 4 ? 1 : kOut >= 2 ? 2 : 4;  // (registers: more W3 quads in flight beside the block spilled)
     constexpr int kStages = 4 * (4 / kGroup);  // (nt, g0) pairs
-    constexpr bool kStore = SAVE && !(kSplitDiagSkip & 8);
+    constexpr bool kStore = SAVE == 1 && !(kSplitDiagSkip & 8);
     u32x4 bq[kGroup], wq[kOut][kGroup];
     auto request_b2 = [&](int stage) {
       const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
 #pragma unroll
         for (int gi = 0; gi < kGroup; ++gi) {
           const int g = g0 + gi;
-          if constexpr (SAVE && !(kSplitDiagSkip & 65536)) {  // (tuning builds, bit 65536: no gate bits)
+          if constexpr (SAVE != 0 && !(kSplitDiagSkip & 65536)) {  // (tuning builds, bit 65536: no gate bits)
             // gate of h2, bit c of word [row][4 wc + nt] <=> column 32 (4 wc + nt) + c > 0.
             // h2 >= +0 here, so "h2 > 0" is bit 31 of (bits(h2) + 0x7fffffff); four of
             // them are funnel-shifted into a nibble (element 0 lowest), the nibble goes
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
       total[q] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     const int my_row = 64 * wr + lane_id();
-    if constexpr (SAVE && !(kSplitDiagSkip & 65536)) {
+    if constexpr (SAVE != 0 && !(kSplitDiagSkip & 65536)) {
       if (save_gate2 != nullptr) {
         // full words = own nibbles | the other half-wave's; lane (l32, hh) keeps row
         // 64 wr + 32 hh + l32's four words and stores them as one 16-byte piece
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_t
   }
 }
 
-template <int DIN, int NOUT, bool SAVE>
+template <int DIN, int NOUT, int SAVE>
 static int launch_forward_f16(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
                                 const float *b1, const void *w2s, const float *b2, const float *w3,
                                 const float *b3, int n_out, float *out, float *h1, float *h2, uint32_t *gate) {
@@ -620,8 +624,9 @@ template <int DIN, int NOUT>
 static int launch_forward_f16_save(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
                                      const float *b1, const void *w2s, const float *b2, const float *w3,
                                      const float *b3, int n_out, float *out, float *h1, float *h2, uint32_t *gate) {
-  return h2 ? launch_forward_f16<DIN, NOUT, true>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate)
-            : launch_forward_f16<DIN, NOUT, false>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
+  return h2     ? launch_forward_f16<DIN, NOUT, 1>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate)
+         : gate ? launch_forward_f16<DIN, NOUT, 2>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate)
+                : launch_forward_f16<DIN, NOUT, 0>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
 }
 
 template <int DIN>
@@ -1070,7 +1075,7 @@ RL8_API int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, c
                                           float *save_h1, float *save_h2, uint32_t *save_gate2, void *stream) {
   if (!x || !w1 || !b1 || !w2_f16 || !b2 || !w3 || !b3 || !out) return RL8_ENULL;
   if (m <= 0 || !rl8_mlp_forward_f16_supports(d_in, n_out)) return RL8_ESIZE;
-  if ((save_h1 || save_gate2) && !save_h2) return RL8_ENULL;
+  if (save_h1 && !save_h2) return RL8_ENULL;  // (the gate bits alone are allowed: SAVE mode 2)
   if (((uintptr_t)w2_f16 & 15) != 0 || !aligned16(save_h1) || !aligned16(save_h2) || !aligned16(save_gate2))
     return RL8_EALIGN;
   const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;

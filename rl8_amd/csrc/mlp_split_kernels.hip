@@ -1120,6 +1120,9 @@ struct WgradFusedArgs {
   int partial_stride;
   int other_rows;      // rows whose [dW1 | db1] segment the data-gradient kernel fills
   int accumulate;      // a later segment of the same rows-of-samples sum: add to the partial rows
+  // gate-plane kernel in BITS mode only: the gate bits of h2 ([m][8] words) instead of h2 itself, and b2
+  const uint32_t *gate2 = nullptr;
+  const float *b2 = nullptr;
 };
 
 // LOADH: both operands come from memory -- dZ rows at pitch `ops.dz_pitch`, h1 rows at
@@ -1552,10 +1555,18 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 // dOut[s][1] == -dOut[s][0] (a two-way categorical: the loss kernel makes it exact; the host
 // checks it on the data before choosing this kernel): dZ2 = G * dOut[s][0] * (W3[0] - W3[1]),
 // and dW3[1] = -dW3[0].  dOut is then [m][2] and column 0 is taken.
+// BITS: the gate comes as the forward's gate BITS (32 bytes per row) and h2 is not read at all -- nor was it
+// stored: the only other use of h2 here, dW3[j] = sum_s dOut[s] h2[s][j], follows from the sums this kernel
+// forms anyway.  With h2 = G * (h1 W2^T + b2):
+//   dW3[j] = sum_i W2[j][i] * M[j][i] + b2[j] * sum_s G[s][j] dOut[s],   M[j][i] = sum_s G[s][j] dOut[s] h1[s][i]
+// and M is the accumulator (dW2[j][i] = W3[j] M[j][i]).  The slabs then hold M; mlp_wgrad_gate_reduce_kernel
+// applies W3 and forms the row dots.  In exact arithmetic the same number; in fp32 it differs from the direct
+// sum by the rounding of h2 itself (the forward's 256-term dot products), which is what the reference's own h2
+// differs from ours by.
 constexpr int kWgOperandA = 2 * kHidden * 16;             // gate plane: [sample half][column] x 16 B
 constexpr int kWgStageBytes = kWgOperandA + kWsOperandBytes;  // gate | three planes of dOut * h1
 
-template <int DIN, bool PAIR = false>
+template <int DIN, bool PAIR = false, bool BITS = false>
 __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     const float *__restrict__ h2, const float *__restrict__ x, const float *__restrict__ w1,
     const float *__restrict__ b1, int64_t m, float *__restrict__ slabs, WgradFusedArgs fused) {
@@ -1589,10 +1600,18 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     const int64_t chunk = blockIdx.x + n * stride;
     const int64_t left = m - chunk * kWsChunk;
     const int rows = left <= 0 ? 0 : left < kWsChunk ? (int)left : kWsChunk;
+    if constexpr (BITS) {  // this column's gate word of each of the eight rows (two distinct words per wave and row)
+      const uint32_t *g = fused.gate2;
+      const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? g + chunk * kWsChunk * 8 : g, rows * 32);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = buffer_load_f32(rsrc, (col >> 5) * 4, (8 * kh + e) * 32);
+      return;
+    }
     const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? h2 + chunk * kWsChunk * kHidden : h2, rows * kHidden * 4);
 #pragma unroll
     for (int e = 0; e < 8; ++e) dst[e] = buffer_load_f32(rsrc, col * 4, (8 * kh + e) * (kHidden * 4));
   };
+  auto open_of = [&](float v) { return BITS ? ((__float_as_uint(v) >> (col & 31)) & 1u) != 0 : v > 0.0f; };
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   // Observations and dOut of the eight samples a wave produces: scalar registers, requested in
   // front of the PREVIOUS step's barrier (see mlp_wgrad_split_kernel); samples past m read as zero.
@@ -1628,11 +1647,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
       u32x4 g;
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
-        const bool o0 = h2v[e] > 0.0f, o1 = h2v[e + 1] > 0.0f;
+        const bool o0 = open_of(h2v[e]), o1 = open_of(h2v[e + 1]);
         g[e >> 1] = (o0 ? 0x00003f80u : 0u) | (o1 ? 0x3f800000u : 0u);  // bf16 1.0 / 0.0
         gsum += (o0 ? dout_of(e) : 0.0f) + (o1 ? dout_of(e + 1) : 0.0f);
-        dw3a = __builtin_fmaf(dout_of(e), h2v[e], dw3a);
-        dw3a = __builtin_fmaf(dout_of(e + 1), h2v[e + 1], dw3a);
+        if constexpr (!BITS) {
+          dw3a = __builtin_fmaf(dout_of(e), h2v[e], dw3a);
+          dw3a = __builtin_fmaf(dout_of(e + 1), h2v[e + 1], dw3a);
+        }
       }
       lds_write_b128<0>(addr, g);
     }
@@ -1758,7 +1779,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = 64 * wj + 32 * ja + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      const float w3j = w3_of(j);
+      const float w3j = BITS ? 1.0f : w3_of(j);  // (BITS: the slabs hold M; the reduction applies W3)
 #pragma unroll
       for (int t = 0; t < 4; ++t) slab[j * kHidden + 128 * wi + 32 * t + l32] = acc[ja][t][r] * w3j;
     }
@@ -1780,7 +1801,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   if (kh == 0) {
     const float sum_b2 = (gsum + red[col * 2]) * w3_of(col);
     row[off_db2 + col] = more ? row[off_db2 + col] + sum_b2 : sum_b2;
-    const float sum_w3 = dw3a + red[col * 2 + 1];
+    // (BITS: the b2 part of dW3 = sum_i W2 M + b2 sum_s G dOut; the reduction adds the row dots to row 0)
+    const float sum_w3 = BITS ? (gsum + red[col * 2]) * fused.b2[col] : dw3a + red[col * 2 + 1];
     row[off_dw3 + col] = more ? row[off_dw3 + col] + sum_w3 : sum_w3;
     if constexpr (PAIR) row[off_dw3 + kHidden + col] = more ? row[off_dw3 + kHidden + col] - sum_w3 : -sum_w3;
     // db3 = sum of dOut needs no matrix kernel: the caller forms it (the segment is zeroed)
@@ -1788,6 +1810,42 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   }
   if (!more && (int)blockIdx.x >= fused.other_rows)
     for (int idx = tid; idx < kHidden * d_in + kHidden; idx += kWsThreads) row[idx] = 0.0f;
+}
+
+// BITS mode of the gate-plane kernel: M = sum over slabs (slab order); dW2[j][i] (+)= w3e[j] M[j][i]; and the row
+// dots sum_i W2[j][i] M[j][i] join dW3 in partial row 0 (PAIR: with opposite signs in the two rows of dW3).
+// Workgroup = row j of the 256 x 256 output.
+template <bool PAIR>
+__global__ __launch_bounds__(kBlock) void mlp_wgrad_gate_reduce_kernel(const float *__restrict__ slabs, int rows,
+                                                                      float *__restrict__ out, int accumulate,
+                                                                      const float *__restrict__ w2,
+                                                                      const float *__restrict__ w3,
+                                                                      float *__restrict__ dw3_row0) {
+  __shared__ float red[kBlock];
+  const int j = blockIdx.x, i = threadIdx.x, idx = j * kBlock + i;
+  const float *p = slabs + idx;
+  float sum = 0.0f;
+  int r = 0;
+  for (; r + 16 <= rows; r += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(r + u) * (kHidden * kHidden)];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sum += v[u];
+  }
+  for (; r < rows; ++r) sum += p[(int64_t)r * (kHidden * kHidden)];
+  const float w3e = PAIR ? w3[j] - w3[kHidden + j] : w3[j];
+  out[idx] = (accumulate ? out[idx] : 0.0f) + w3e * sum;
+  red[i] = w2[idx] * sum;
+  __syncthreads();
+  for (int half = kBlock / 2; half > 0; half >>= 1) {  // fixed order
+    if (i < half) red[i] += red[i + half];
+    __syncthreads();
+  }
+  if (i == 0) {
+    dw3_row0[j] += red[0];
+    if constexpr (PAIR) dw3_row0[kHidden + j] -= red[0];
+  }
 }
 
 // out[idx] (+)= sum over slabs, in slab order.
@@ -1840,17 +1898,17 @@ static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const fl
   return launch_status();
 }
 
-template <int DIN, bool PAIR = false>
+template <int DIN, bool PAIR = false, bool BITS = false>
 static int launch_wgrad_gate(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
                              const float *b1, int64_t m, float *slabs, WgradFusedArgs fused) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN, PAIR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN, PAIR, BITS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_wgrad_gate_kernel<DIN, PAIR><<<grid, kWsThreads, 2 * kWgStageBytes, s>>>(h2, x, w1, b1, m, slabs, fused);
+  mlp_wgrad_gate_kernel<DIN, PAIR, BITS><<<grid, kWsThreads, 2 * kWgStageBytes, s>>>(h2, x, w1, b1, m, slabs, fused);
   return launch_status();
 }
 
@@ -2143,6 +2201,46 @@ RL8_API int rl8_mlp_wgrad_fused_pair_f32(const float *h2, const float *dout, con
     }
     if (status != 0) return status;
     mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0);
+  }
+  return launch_status();
+}
+
+/* The weight gradient of a rank-one head from the gate BITS alone (no h2): n_out = 1, or n_out = 2 with
+ * dout[s][1] == -dout[s][0] in every row (rl8_mlp_dout_pair_check).  Same outputs as
+ * rl8_mlp_wgrad_fused_split_f32 / _pair_f32 -- dW2, and the head segments [db2 | dW3] of the partial rows --
+ * with dW3 = sum_i W2[.][i] M[.][i] + b2 * sum_s gate * dOut taken from the sums M the kernel forms anyway
+ * (dW2 = W3 M), so that neither this call nor the forward pass (rl8_mlp_tower_forward_f16_f32 with save_h2 =
+ * NULL, save_gate2 given) touches the 1 KiB per row of h2.  w2: the layer's [256][256] weight, b2 its bias. */
+RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout, const float *x, const float *w1,
+                                        const float *b1, const float *w2, const float *b2, const float *w3,
+                                        int64_t m, int d_in, int n_out, float *workspace, float *dw2_out,
+                                        float *partials, void *stream) {
+  if (!gate2 || !dout || !x || !w1 || !b1 || !w2 || !b2 || !w3 || !workspace || !dw2_out || !partials) return RL8_ENULL;
+  if (m <= 0 || (n_out != 1 && n_out != 2) || !rl8_mlp_backward_split_supports(d_in, n_out)) return RL8_ESIZE;
+  if (!aligned16(gate2) || !aligned16(workspace) || !aligned16(dw2_out) || ((uintptr_t)dout & 7) != 0) return RL8_EALIGN;
+  int g1, g2;
+  fused_backward_grids(m, &g1, &g2);
+  const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
+  const int off_dw3 = kHidden * d_in + 2 * kHidden;
+  hipStream_t s = (hipStream_t)stream;
+  for (int64_t at = 0; at < m; at += kWgradSegmentRows) {  // segments summed in order, as rl8_mlp_wgrad_fused_split_f32
+    const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
+    const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
+    const int grid = at == 0 ? g2 : (int)(chunks < g2 ? chunks : g2);
+    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0, gate2 + at * 8, b2};
+    const float *xs = x + at * d_in;
+    int status = RL8_ESIZE;
+#define RL8_WGRAD_BITS(D) \
+  if (d_in == D) \
+    status = n_out == 2 ? launch_wgrad_gate<D, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
+                        : launch_wgrad_gate<D, false, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused);
+    RL8_WGRAD_BITS(1) RL8_WGRAD_BITS(2) RL8_WGRAD_BITS(3) RL8_WGRAD_BITS(5)
+#undef RL8_WGRAD_BITS
+    if (status != 0) return status;
+    if (n_out == 2)
+      mlp_wgrad_gate_reduce_kernel<true><<<kHidden, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0, w2, w3, partials + off_dw3);
+    else
+      mlp_wgrad_gate_reduce_kernel<false><<<kHidden, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0, w2, w3, partials + off_dw3);
   }
   return launch_status();
 }

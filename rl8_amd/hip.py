@@ -153,6 +153,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_wgrad_fused_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_pack_w2_f16_gate": [_vp, _vp, _i32, _vp, _vp],
     "rl8_mlp_tower_backward_gate_f16_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp, _vp],
+    "rl8_mlp_wgrad_gate_bits_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_f16_packed_bytes": [],
     "rl8_mlp_forward_f16_supports": [_i32, _i32],
     "rl8_mlp_pack_w2_f16": [_vp, _i32, _vp, _vp],
@@ -922,12 +923,15 @@ def mlp_pack_w2_split(w2: torch.Tensor, *, transposed: bool = False) -> torch.Te
 def mlp_tower_forward_split(
     x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2_split: torch.Tensor, b2: torch.Tensor,
     w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False, save_h1: bool = True, save_gate: bool = False,
+    save_h2: bool = True,
 ) -> tuple[torch.Tensor, ...]:
     """``mlp_tower_forward`` with the 256x256 product as six bf16-plane MFMAs per
     16 k (fp32 accuracy, fp32 in / out / accumulate). ``save_h1=False`` keeps only
     h2 (the bf16-plane backward kernels recompute h1). ``save_gate=True`` (with
     ``save``) appends a fourth result, the ReLU gate of h2 as bits ([M, 8] int32:
-    bit j of row s = h2[s, j] > 0), which the data-gradient kernel reads instead of h2."""
+    bit j of row s = h2[s, j] > 0), which the data-gradient kernel reads instead of h2.
+    ``save_h2=False`` (fp16-plane pack, with ``save_gate``): the gate bits ALONE are kept -- all the
+    backward pass of a rank-one head needs (``mlp_tower_backward(..., h2=None, w2=..., b2=...)``)."""
     x = _dense(x.detach(), torch.float32, "x")
     m, d_in = x.shape
     n_out = w3.shape[0]
@@ -944,8 +948,12 @@ def mlp_tower_forward_split(
     else:
         raise ValueError("w2_split must come from mlp_pack_w2_split or mlp_pack_w2_f16")
     out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
+    if save and not save_h2:
+        if fn_name != "rl8_mlp_tower_forward_f16_f32" or not save_gate:
+            raise ValueError("save_h2=False needs the fp16-plane pack and save_gate=True")
+        save_h1 = False
     h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save and save_h1 else None
-    h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save else None
+    h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save and save_h2 else None
     gate = torch.empty(m, 8, dtype=torch.int32, device=x.device) if save and save_gate else None
     with _timed("mlp_tower_forward_save" if save else "mlp_tower_forward", m):
         _check(
@@ -959,10 +967,11 @@ def mlp_tower_forward_split(
 
 
 def mlp_tower_backward(
-    x: torch.Tensor, h1: None | torch.Tensor, h2: torch.Tensor, dout: torch.Tensor,
+    x: torch.Tensor, h1: None | torch.Tensor, h2: None | torch.Tensor, dout: torch.Tensor,
     w2t_packed: torch.Tensor, w3: torch.Tensor,
     w1: None | torch.Tensor = None, b1: None | torch.Tensor = None, *, wgrad_split: bool = False,
-    gate2: None | torch.Tensor = None, gate_pack=None,
+    gate2: None | torch.Tensor = None, gate_pack=None, w2: None | torch.Tensor = None, b2: None | torch.Tensor = None,
+    h2_fn=None, info: None | dict = None,
 ) -> dict[str, torch.Tensor]:
     """Gradients of one tower's parameters given ``dout`` [M, n_out] and the
     activations saved by the forward pass. Returns ``w1, b1, w2, b2, w3, b3``.
@@ -977,7 +986,11 @@ def mlp_tower_backward(
     ``mlp_pack_w2_f16(..., transposed=True)`` selects the fp16-plane data-gradient kernel
     (fused mode: ``gate2`` required; the weight gradient stays on bf16 planes). ``gate_pack``: a
     callable returning ``mlp_pack_w2_f16_gate(w2, w3)`` -- with it, single-output heads and two-output
-    heads whose gradients are exact negatives (checked on ``dout``) run the data gradient in gate mode."""
+    heads whose gradients are exact negatives (checked on ``dout``) run the data gradient in gate mode.
+    ``h2=None`` (a forward with ``save_h2=False``: gate bits only) with the layer's own ``w2`` [256, 256] and
+    ``b2``: such rank-one heads then take dW3 from the weight-gradient sums (``rl8_mlp_wgrad_gate_bits_f32``) and
+    h2 is never touched; if the head turns out not to be rank-one, ``h2_fn()`` must supply h2 (a forward re-run).
+    ``info`` (a dict) receives ``rank_one``: whether the gate kernels ran."""
     m, d_in = x.shape
     n_out = w3.shape[0]
     split = w2t_packed.dtype == torch.uint8
@@ -1015,9 +1028,13 @@ def mlp_tower_backward(
         if n_out == 2 and gates_on:
             pair_flag = _pair_flag(x.device)
             _check(lib.rl8_mlp_dout_pair_check(_ptr(dout), m, _ptr(pair_flag), _stream()), "rl8_mlp_dout_pair_check")
-            if f16 and gate_pack is not None:  # the data gradient needs the answer too: read it now (a short bubble)
+            if f16 and (gate_pack is not None or h2 is None):  # needed before the data gradient: read it now (a short bubble)
                 pair = int(pair_flag[0].item()) == 0
                 pair_flag = None
+        if h2 is None and not (f16 and gates_on and (n_out == 1 or pair) and w2 is not None and b2 is not None):
+            if h2_fn is None:
+                raise ValueError("h2=None needs a rank-one head on the fp16-plane path (with w2, b2) or h2_fn")
+            h2 = h2_fn()  # not a rank-one head after all: the forward is re-run for h2
         gate_dgrad = f16 and gate_pack is not None and gates_on and (n_out == 1 or pair)
         with _timed("mlp_tower_backward_gate" if gate_dgrad else "mlp_tower_backward", m):
             if gate_dgrad:
@@ -1046,8 +1063,18 @@ def mlp_tower_backward(
         # run the gate-plane kernel -- three plane products instead of six -- timed under its own name)
         gate_kernel = n_out == 1 and gates_on
         pair = pair or (pair_flag is not None and int(pair_flag[0].item()) == 0)
+        if info is not None:
+            info["rank_one"] = bool(gate_kernel or pair)
         with _timed("mlp_wgrad_gate" if gate_kernel or pair else "mlp_wgrad", m):
-            if pair:
+            if h2 is None:  # rank-one head, gate bits only: dW3 from the weight-gradient sums
+                _check(
+                    lib.rl8_mlp_wgrad_gate_bits_f32(
+                        _ptr(gate2), _ptr(dout), _ptr(x), w1p, b1p, _ptr(_dense(w2.detach(), torch.float32, "w2")),
+                        _ptr(_dense(b2.detach(), torch.float32, "b2")), _ptr(w3.detach()), m, d_in, n_out,
+                        _ptr(_wgrad_workspace(x.device)), _ptr(dw2), _ptr(partials), _stream()),
+                    "rl8_mlp_wgrad_gate_bits_f32",
+                )
+            elif pair:
                 _check(
                     lib.rl8_mlp_wgrad_fused_pair_f32(
                         _ptr(h2), _ptr(dout), _ptr(x), w1p, b1p, _ptr(w3.detach()), m, d_in,

@@ -74,6 +74,10 @@ def _packed_gate(layer: nn.Linear, w3: torch.Tensor) -> torch.Tensor:
     return packed
 
 
+def _gates_off() -> bool:
+    return bool(int(os.environ.get("RL8_WGRAD_GATE_OFF", "0") or 0))
+
+
 class _FusedTower(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, layer2, grad_mode):  # type: ignore[override]
@@ -86,28 +90,44 @@ class _FusedTower(torch.autograd.Function):
             # h1 is stored only if a backward kernel will read it (the bf16-plane ones recompute it)
             keep_h1 = not (BACKWARD_GEMM in ("split", "f16") and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0]))
             f16 = FORWARD_GEMM == "f16" and hip.mlp_forward_f16_supports(x.shape[1], w3.shape[0])
+            # Rank-one heads (one output; two outputs with exactly opposite gradients, as the last backward of
+            # this tower found them) need only the gate bits of h2 in the backward pass: no h2 store, no h2
+            # read.  Should a two-output head stop being rank-one, its backward re-runs this forward for h2.
+            n_out = w3.shape[0]
+            gate_only = (need_grad and f16 and not keep_h1 and BACKWARD_GEMM == "f16"
+                         and hip.mlp_backward_f16_supports(x.shape[1], n_out) and not _gates_off()
+                         and (n_out == 1 or (n_out == 2 and layer2.__dict__.get("_rl8_rank_one", False))))
             out, h1, h2, gate = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16" if f16 else True),
-                                                            b2, w3, b3,
-                                                            save=need_grad, save_h1=keep_h1, save_gate=True)
+                                                            b2, w3, b3, save=need_grad, save_h1=keep_h1, save_gate=True,
+                                                            save_h2=not gate_only)
         else:
             out, h1, h2 = hip.mlp_tower_forward(x, w1, b1, _packed(layer2, False), b2, w3, b3, save=need_grad)
             gate = None
         if need_grad:
             ctx.layer2 = layer2
-            ctx.save_for_backward(x, h1, h2, w3, w1, b1, gate)
+            ctx.save_for_backward(x, h1, h2, w3, w1, b1, gate, b2, b3)
         return out
 
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
-        x, h1, h2, w3, w1, b1, gate = ctx.saved_tensors
+        x, h1, h2, w3, w1, b1, gate, b2, b3 = ctx.saved_tensors
         split: bool | str = BACKWARD_GEMM in ("split", "f16") and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0])
         if split and BACKWARD_GEMM == "f16" and gate is not None and hip.mlp_backward_f16_supports(x.shape[1], w3.shape[0]):
             split = "f16"
         # (w3 as saved is the parameter itself for a single head: its version counter tracks the optimizer)
         gate_pack = (lambda: _packed_gate(ctx.layer2, w3)) if split == "f16" and w3.shape[0] <= 2 else None
-        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(ctx.layer2, True, split), w3,
+        layer2 = ctx.layer2
+
+        def h2_again():  # (a two-output head that is not rank-one after all: the forward once more, with h2)
+            return hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16"), b2, w3, b3, save=True,
+                                               save_h1=False, save_gate=True)[2]
+
+        info: dict = {}
+        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(layer2, True, split), w3,
                                    w1, b1, wgrad_split=BACKWARD_GEMM in ("split", "f16"), gate2=gate if split else None,
-                                   gate_pack=gate_pack)
+                                   gate_pack=gate_pack, w2=layer2.weight, b2=b2, h2_fn=h2_again, info=info)
+        if w3.shape[0] == 2:
+            layer2.__dict__["_rl8_rank_one"] = bool(info.get("rank_one", False))
         return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None
 
 

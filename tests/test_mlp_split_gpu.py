@@ -311,6 +311,68 @@ def test_gate_mode_data_gradient(m, d_in, n_out, case):
         assert torch.equal(got[k], again[k]), k
 
 
+@pytest.mark.parametrize("x_scale", [3.0, 100.0])
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 1), (129, 1, 2), (1000, 5, 1), (4097, 3, 2), (40_000, 1, 2), (9000, 2, 1),
+                                          (100_000, 1, 1)])
+def test_rank_one_backward_from_the_gate_bits_alone(m, d_in, n_out, x_scale):
+    """A forward that keeps ONLY the gate bits of h2 (32 bytes per row) and a backward that never sees h2: the gate
+    modes of the data and weight gradients, with dW3 = sum_i W2[.][i] M[.][i] + b2 sum_s G dOut taken from the sums M
+    the weight-gradient kernel forms anyway.  Every gradient against fp64 on the activations a full forward saves,
+    and against the h2-reading kernels on the same inputs; dW3 -- the reformulated one -- differs from the direct sum
+    by the rounding the forward's own dot products put into h2 (bar: the direct kernel's error x 10 + 2e-6 of the
+    largest entry; observations up to +-300 as the dummy envs produce them)."""
+    g = torch.Generator(device=DEV).manual_seed(17 * m + d_in + n_out)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * x_scale
+    p = _params(g, d_in, n_out)
+    g0 = torch.randn(m, device=DEV, generator=g) / m
+    g0[torch.rand(m, device=DEV, generator=g) < 0.3] = 0.0
+    dout = (torch.stack([g0, -g0], 1) if n_out == 2 else g0[:, None]).contiguous()
+    w2p, w2t = hip.mlp_pack_w2_f16(p["w2"]), hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+    args = (x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"])
+    out, _, h2, gate = hip.mlp_tower_forward_split(*args, save=True, save_h1=False, save_gate=True)
+    out_b, h1_b, h2_b, gate_b = hip.mlp_tower_forward_split(*args, save=True, save_gate=True, save_h2=False)
+    assert h1_b is None and h2_b is None and torch.equal(out_b, out) and torch.equal(gate_b, gate)
+    h1 = torch.relu(x @ p["w1"].T + p["b1"])
+    d, a1, a2 = dout.double(), h1.double(), h2.double()
+    dz2 = (d @ p["w3"].double()) * (a2 > 0)
+    dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
+    want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0), "w2": dz2.T @ a1, "b2": dz2.sum(0), "w3": d.T @ a2, "b3": d.sum(0)}
+    gate_pack = lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])  # noqa: E731
+    info = {}
+    got = hip.mlp_tower_backward(x, None, None, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack,
+                                 w2=p["w2"], b2=p["b2"], info=info)
+    ref = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack)
+    assert info["rank_one"]
+    for k in want:
+        if k == "b3":
+            continue
+        err, err_ref = _rel(got[k], want[k]), _rel(ref[k], want[k])
+        assert err < 2e-5, (k, err)
+        if k == "w3":
+            assert err <= 10 * err_ref + 2e-6, (k, err, err_ref)
+        else:  # the same kernels on the same operands (dW2: same sums, W3 applied behind the slab reduction instead of per slab)
+            assert err <= 3 * err_ref + 2e-6, (k, err, err_ref)
+    if n_out == 2:
+        assert torch.equal(got["w3"][1], -got["w3"][0])
+    again = hip.mlp_tower_backward(x, None, None, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack,
+                                   w2=p["w2"], b2=p["b2"])
+    for k in got:
+        assert torch.equal(got[k], again[k]), k
+    if n_out == 2:  # not a pair after all: h2 has to be supplied, and the general kernels run
+        broken = dout.clone()
+        broken[m // 2, 1] += 1e-3 / m
+        with pytest.raises(ValueError):
+            hip.mlp_tower_backward(x, None, None, broken, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack,
+                                   w2=p["w2"], b2=p["b2"])
+        calls = []
+        late = hip.mlp_tower_backward(x, None, None, broken, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack,
+                                      w2=p["w2"], b2=p["b2"], h2_fn=lambda: calls.append(1) or h2, info=info)
+        general = hip.mlp_tower_backward(x, None, h2, broken, w2t, p["w3"], p["w1"], p["b1"], gate2=gate)
+        assert calls == [1] and not info["rank_one"]
+        for k in late:
+            assert torch.equal(late[k], general[k]), k
+
+
 @pytest.mark.parametrize("m,d_in", [(1, 1), (129, 1), (1000, 5), (4097, 3), (40_000, 1), (9000, 2)])
 def test_pair_weight_gradient_of_a_two_way_head(m, d_in, monkeypatch):
     """dOut[s][1] == -dOut[s][0] exactly (what the categorical loss kernel emits for two actions):
@@ -475,6 +537,7 @@ def test_fused_tower_autograd_uses_the_split_kernels_and_matches_eager():
         hip.timer.enabled = False
     # (this loss gives the two outputs exactly opposite gradients: the gate-mode backward kernels run)
     assert {"mlp_tower_forward_save", "mlp_tower_backward_gate", "mlp_wgrad_gate"} <= launched
+    assert mlp[2].__dict__["_rl8_rank_one"] is True  # found on the data: the next forward keeps the gate bits only
     got = {n: p.grad.clone() for n, p in list(trunk.named_parameters()) + list(head.named_parameters())}
     for p in list(trunk.parameters()) + list(head.parameters()):
         p.grad = None

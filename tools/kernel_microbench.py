@@ -158,6 +158,15 @@ def f16_dgrad_gate():  # single-output tower: gate plane x two planes of w3 * W2
                                              _p(_partials_v), C.byref(_rows), _p(mlp_gate), hip._stream())
 
 
+def f16_forward_gate_only():  # training forward of a rank-one head: gate bits only, no h2
+    hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h, mlp_b2, mlp_w3, mlp_b3, save=True, save_gate=True, save_h2=False)
+
+
+def gate_bits_wgrad():  # weight gradient of a single-output head from the gate bits alone (dW3 from the sums)
+    _lib.rl8_mlp_wgrad_gate_bits_f32(_p(mlp_gate), _p(mlp_doutv), _p(mlp_x), _p(mlp_w1), _p(mlp_b1), _p(mlp_w2), _p(mlp_b2),
+                                     _p(mlp_w3v), N, 1, 1, _p(_ws), _p(_dw2), _p(_partials_v), hip._stream())
+
+
 def split_wgrad_fused():  # weight-gradient kernel: re-forms dZ2 and h1, accumulates the head gradients
     _lib.rl8_mlp_wgrad_fused_split_f32(_p(mlp_h2), _p(mlp_dout), _p(mlp_x), _p(mlp_w1), _p(mlp_b1), _p(mlp_w3), N, 1, 2,
                                        _p(_ws), _p(_dw2), _p(_partials), hip._stream())
@@ -173,6 +182,8 @@ KERNELS = {
     "mlp_tower_backward_split": (split_dgrad, MLP_FLOP / 1000),
     "mlp_wgrad_fused_split": (split_wgrad_fused, 2 * N * 65536 / 1000),
     "mlp_wgrad_fused_gate": (gate_wgrad_fused, 2 * N * 65536 / 1000),
+    "mlp_wgrad_gate_bits": (gate_bits_wgrad, 2 * N * 65536 / 1000),
+    "mlp_tower_forward_gate_only_f16": (f16_forward_gate_only, MLP_FLOP / 1000),
     "mlp_tower_backward_gate_f16": (f16_dgrad_gate, MLP_FLOP / 1000),
     "mlp_wgrad_split": (lambda: hip.mlp_wgrad_split(mlp_dz2, mlp_x, mlp_w1, mlp_b1), 2 * N * 65536 / 1000),
     "mlp_wgrad_fused": (lambda: hip.mlp_wgrad(mlp_dz2, mlp_h1), 2 * N * 65536 / 1000),
