@@ -103,9 +103,10 @@ PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in
     "mlp_wgrad": ("mlp_wgrad_kernel", 1 << 20),
 }
 PMC_KERNEL_F16 = {  # the fp16-plane kernels (forward, data gradient), same profiled shapes
-    "mlp_tower_forward": ("mlp_tower_forward_f16_kernel<1, 2, false>", 1 << 20),
-    "mlp_tower_forward_save": ("mlp_tower_forward_f16_kernel<1, 2, true>", 1 << 20),
-    "mlp_tower_backward": ("mlp_tower_backward_f16_kernel<1, 2>", 1 << 20),
+    "mlp_tower_forward": ("mlp_tower_forward_f16_kernel<1, 2, 0>", 1 << 20),
+    # (training forward of a rank-one head keeps the gate bits only: SAVE mode 2; mode 1 stores h2 as well)
+    "mlp_tower_forward_save": ("mlp_tower_forward_f16_kernel<1, 2, 2>", 1 << 20),
+    "mlp_tower_backward": ("mlp_tower_backward_f16_kernel<1, 2, false>", 1 << 20),
 }
 PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
     "mlp_tower_forward": ("mlp_tower_forward_split_kernel<1, 2, false>", 1 << 20),
@@ -114,7 +115,7 @@ PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
     "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2>", 1 << 20),
 }
 PMC_KERNEL_GATE = {  # gate-mode kernels (heads whose dZ2 is gate * d * w3e)
-    "mlp_wgrad_gate": ("mlp_wgrad_gate_kernel<1, false>", 1 << 20),
+    "mlp_wgrad_gate": ("mlp_wgrad_gate_kernel<1, false, true>", 1 << 20),
     "mlp_tower_backward_gate": ("mlp_tower_backward_f16_kernel<1, 1, true>", 1 << 20),
 }
 
