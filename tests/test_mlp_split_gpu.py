@@ -546,6 +546,59 @@ def test_fused_tower_autograd_uses_the_split_kernels_and_matches_eager():
         assert _rel(got[n], p.grad.double()) < 2e-5, n
 
 
+def test_fused_tower_keeps_only_gate_bits_for_rank_one_heads_and_recovers_when_wrong():
+    """The autograd wrapper's bookkeeping: a single-output tower never stores h2; a two-output tower stores it until a
+    backward has found its gradients to be exact negatives, then keeps the gate bits only; and when a later backward
+    finds a gradient that is NOT a pair the forward is re-run for h2 and the general kernels produce the same
+    gradients as eager PyTorch."""
+    from rl8_amd.nn import fused_mlp
+
+    torch.manual_seed(11)
+    def tower(n_out):
+        mlp = torch.nn.Sequential(torch.nn.Linear(2, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
+        return torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV), torch.nn.Linear(256, n_out).to(DEV)
+
+    x = torch.randn(5000, 2, device=DEV)
+    saved = []
+    real = hip.mlp_tower_forward_split
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        if k.get("save"):
+            saved.append(out[2] is not None)  # was h2 stored?
+        return out
+
+    def check(trunk, head, weights):
+        params = list(trunk.parameters()) + list(head.parameters())
+        for q in params:
+            q.grad = None
+        (fused_mlp.tower_forward(trunk, [head], x) * weights).sum().backward()
+        got = [q.grad.clone() for q in params]
+        for q in params:
+            q.grad = None
+        ((head(trunk(x))) * weights).sum().backward()
+        for a, q in zip(got, params):
+            assert _rel(a, q.grad.double()) < 2e-5
+
+    hip.mlp_tower_forward_split = spy
+    fused_mlp.hip.mlp_tower_forward_split = spy
+    try:
+        trunk1, head1 = tower(1)
+        check(trunk1, head1, torch.tensor([0.7], device=DEV) / 5000)
+        assert saved == [False]                       # one output: gate bits only from the start
+        saved.clear()
+        trunk2, head2 = tower(2)
+        pair = torch.tensor([1.0, -1.0], device=DEV) / 5000
+        check(trunk2, head2, pair)                    # h2 stored; the backward finds a pair
+        check(trunk2, head2, pair)                    # gate bits only
+        check(trunk2, head2, torch.tensor([1.0, 0.5], device=DEV) / 5000)   # not a pair: forward re-run inside backward
+        check(trunk2, head2, pair)                    # (the flag was dropped: h2 stored again)
+        assert saved == [True, False, False, True, True], saved  # third entry: the gate-only forward; fourth: its re-run for h2
+    finally:
+        hip.mlp_tower_forward_split = real
+        fused_mlp.hip.mlp_tower_forward_split = real
+
+
 @pytest.mark.parametrize("scheme", ["bf16x3", "f16x2", "f16x2-gate"])
 @pytest.mark.parametrize("m,parts", [(1 << 23, 8), (1 << 25, 4)])
 def test_full_size_launch_equals_its_chunks(m, parts, scheme):
