@@ -26,16 +26,23 @@ Either way the environments are sharded and the only traffic between ranks is
 the RCCL all-reduce of moments and of [gradient | loss sums] per optimizer step.
 
 Besides the contract's fields, the JSON line carries
-  roofline      the kernel the timed region spends most time in (the training
-                forward of the default towers: MFMA-bound, priced in executed bf16
-                FLOP against the 2.5 PF dense peak), timed with HIP events inside
-                the timed region; ``roofline_hbm`` the same for the largest
+  roofline      the kernel the timed region spends most time in (whichever it is
+                in this run -- with the defaults one of the three tower kernels:
+                MFMA-bound, priced in the 16-bit multiply-adds the matrix pipe
+                executes against the 2.5 PF dense peak), timed with HIP events
+                inside the timed region; ``roofline_hbm`` the same for the largest
                 HBM-bound hand kernel (fused PPO loss fwd+bwd, 44 B per sample);
   kernels       the same for every hand kernel that ran;
   cpu_baseline  the CPU restatement (oracle/, kind "port") of the same algorithm
                 on the host cores, best of a thread-count sweep, on a bounded
                 sample (rank 0, N=1 only);
-  world_size / backend   as ``torch.distributed`` reports them.
+  world_size / backend / collectives_per_step   as ``torch.distributed`` saw them;
+  rank_ms_per_step       every rank's own time per step (min / max / list): a
+                         straggler shows here, ``ms_per_step`` is the max.
+
+Self-launched ranks run in their own sessions with a parent-death signal; the
+parent forwards SIGTERM / SIGINT to them, stops everything at ``--launch-timeout``
+and, when a rank fails, prints the tail of that rank's (and rank 0's) stderr.
 """
 
 from __future__ import annotations
@@ -43,6 +50,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -59,9 +67,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy 
 HBM_COPY_CEILING_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (= fp32 vector) peak, MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (spec), MI355X_MICROARCH.md; 1750 sustained on changing operands
-SPLIT_PRODUCTS = 6              # bf16 plane products per fp32 product in the bf16-plane kernels
 PLANE_PRODUCTS = {"bf16x3-split": 6, "f16x2-split": 3, "bf16-gate-x3": 3, "f16-gate-x2": 2}  # 16-bit MFMA products per fp32 product, by scheme
-MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak = the bf16 one (same instruction shape and rate)
 
 # MFMA-bound kernels: algorithmic FLOP per unit (row) for the default towers,
 # 2 * (256*d_in + 256*256 + 256*n_out); the backward kernel does the data-gradient
@@ -151,6 +157,9 @@ def parse_args(argv: None | list[str] = None) -> argparse.Namespace:
                         " (rehearsals: CPU rendezvous tests, several ranks on one GPU)")
     p.add_argument("--single-device", action="store_true",
                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL wants one device per rank)")
+    p.add_argument("--launch-timeout", type=float, default=None,
+                   help="self-launched ranks (--gpus N without torchrun): seconds before the parent stops them all"
+                        " (default: 900 + 120 per step and warm-up step)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=45.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args(argv)
@@ -176,25 +185,90 @@ def rank_environment(rank: int, world: int, port: int, base: None | dict = None)
     return env
 
 
+def default_launch_timeout(steps: int, warmup: int) -> float:
+    """Finite by default: a rank hung in init_process_group or its first all-reduce must not hold N GPUs until an
+    outer driver kills the parent. Generous against the slowest config (first import + build + RCCL bring-up, then
+    <= 1 s per step on the headline config, ~10 s on CPU-rehearsal configs)."""
+    return 900.0 + 120.0 * (steps + warmup)
+
+
+def _die_with_parent() -> None:  # preexec_fn of a rank: new session + SIGTERM when the launcher dies (Linux)
+    os.setsid()
+    try:
+        import ctypes
+
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)  # PR_SET_PDEATHSIG
+    except Exception:  # noqa: BLE001  (not Linux / no libc: the signal handlers and the timeout remain)
+        pass
+
+
+def _stop_ranks(procs: list, grace: float = 20.0) -> None:
+    """SIGTERM every live rank's process group, SIGKILL what is left after ``grace`` seconds."""
+    live = [p for p in procs if p.poll() is None]
+    for p in live:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)  # (each rank leads its own session: the group is the rank + its helpers)
+        except (ProcessLookupError, PermissionError):
+            pass
+    deadline = time.monotonic() + grace
+    for p in live:
+        try:
+            p.wait(timeout=max(0.0, deadline - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            p.wait()
+
+
+def _tail(f, lines: int = 25) -> str:
+    f.flush()
+    f.seek(0)
+    return "".join(f.readlines()[-lines:])
+
+
 def launch_ranks(world: int, argv: list[str], *, script: str = os.path.abspath(__file__),
                  timeout: None | float = None) -> tuple[int, str]:
     """Start ``world`` fresh child processes of ``script`` (one per GPU), wait for
     them, return (exit code, rank 0's stdout). The caller has not touched a GPU
     and does not here: children are spawned (never exec'ed over this process) and
-    each initialises its own device. If a rank fails the others are stopped by
-    PID; the first non-zero exit code is returned (124 on timeout)."""
+    each initialises its own device. Every rank leads its own session and asks the
+    kernel for SIGTERM when this process dies; SIGTERM / SIGINT to this process stop
+    the ranks (then exit 128 + signal). If a rank fails the others are stopped and
+    the tail of its stderr (and rank 0's) is printed; the first non-zero exit code
+    is returned (124 on timeout). Rank stderr is passed through line by line."""
     import tempfile
+    import threading
 
     port = free_port()
     deadline = None if timeout is None else time.monotonic() + timeout
+    procs: list = []
+    logs = [tempfile.TemporaryFile("w+") for _ in range(world)]
+
+    def pump(rank: int, stream) -> None:  # rank stderr -> ours (live progress) and -> its log (tail on failure)
+        for line in stream:
+            logs[rank].write(line)
+            sys.stderr.write(line if world == 1 else f"[rank {rank}] {line}")
+            sys.stderr.flush()
+
+    def on_signal(signum, _frame):
+        print(f"bench.py: signal {signum}: stopping {len(procs)} ranks", file=sys.stderr, flush=True)
+        _stop_ranks(procs, grace=10.0)
+        os._exit(128 + signum)
+
+    previous = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)} \
+        if threading.current_thread() is threading.main_thread() else {}
     with tempfile.TemporaryFile("w+") as rank0_out:
-        procs = [
-            subprocess.Popen([sys.executable, script, *argv], env=rank_environment(rank, world, port),
-                             stdout=rank0_out if rank == 0 else subprocess.DEVNULL)
-            for rank in range(world)
-        ]
-        rc, pending = 0, set(range(world))
+        pumps = []
         try:
+            for rank in range(world):
+                procs.append(subprocess.Popen([sys.executable, script, *argv], env=rank_environment(rank, world, port),
+                                              stdout=rank0_out if rank == 0 else subprocess.DEVNULL,
+                                              stderr=subprocess.PIPE, text=True, preexec_fn=_die_with_parent))
+                pumps.append(threading.Thread(target=pump, args=(rank, procs[-1].stderr), daemon=True))
+                pumps[-1].start()
+            rc, pending, failed = 0, set(range(world)), None
             while pending and rc == 0:
                 for rank in sorted(pending):
                     code = procs[rank].poll()
@@ -202,22 +276,26 @@ def launch_ranks(world: int, argv: list[str], *, script: str = os.path.abspath(_
                         continue
                     pending.discard(rank)
                     if code != 0 and rc == 0:
-                        rc = code
+                        rc, failed = code, rank
                         print(f"bench.py: rank {rank} exited with {code}; stopping the other ranks", file=sys.stderr)
                 if pending and rc == 0:
                     if deadline is not None and time.monotonic() > deadline:
                         rc = 124
-                        print("bench.py: ranks timed out", file=sys.stderr)
+                        print(f"bench.py: ranks timed out after {timeout:.0f} s (--launch-timeout); still running:"
+                              f" {sorted(pending)}", file=sys.stderr)
                     else:
                         time.sleep(0.05)
         finally:
-            for rank in pending:
-                procs[rank].terminate()
-            for rank in pending:
-                try:
-                    procs[rank].wait(timeout=20)
-                except subprocess.TimeoutExpired:
-                    procs[rank].kill()
+            _stop_ranks(procs)
+            for t in pumps:
+                t.join(timeout=5)
+            for sig, handler in previous.items():
+                signal.signal(sig, handler)
+        if rc != 0:
+            for rank in sorted({r for r in (failed, 0) if r is not None}):
+                print(f"bench.py: ---- last lines of rank {rank}'s stderr ----\n{_tail(logs[rank])}", file=sys.stderr, flush=True)
+        for f in logs:
+            f.close()
         rank0_out.seek(0)
         return rc, rank0_out.read()
 
@@ -293,7 +371,8 @@ def main() -> None:
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process starts the ranks and stays off the GPU
-        rc, out = launch_ranks(args.gpus, sys.argv[1:])
+        limit = args.launch_timeout if args.launch_timeout is not None else default_launch_timeout(args.steps, args.warmup)
+        rc, out = launch_ranks(args.gpus, sys.argv[1:], timeout=limit)
         # stdout carries the ONE JSON line; anything else rank 0 wrote there (gloo's
         # connection banner) goes to stderr
         for text in out.splitlines():
@@ -316,6 +395,12 @@ def run(args: argparse.Namespace) -> None:
         raise SystemExit("bench.py: --single-device needs --backend gloo")
     device_index = 0 if args.single_device else local_rank
     backend = None
+    visible = torch.cuda.device_count()  # (counting devices does not initialise one)
+    if world > 1 and args.backend == "nccl" and visible < world:
+        # fail before any rendezvous: RCCL wants one device per rank, and a rank without one would hang the others
+        raise SystemExit(f"bench.py: rank {rank}: --gpus {world} with --backend nccl needs {world} HIP devices,"
+                         f" {visible} visible (HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')},"
+                         f" ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')})")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -328,6 +413,13 @@ def run(args: argparse.Namespace) -> None:
         print(f"bench.py: rank {dist.get_rank()}/{world} up, backend {backend}", file=sys.stderr, flush=True)
     if torch.cuda.is_available():
         torch.cuda.set_device(device_index)
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else "-"
+        except Exception as exc:  # noqa: BLE001
+            rccl = f"? ({exc.__class__.__name__})"
+        print(f"bench.py: rank {rank}: device {device_index} of {visible} = {torch.cuda.get_device_name(device_index)},"
+              f" RCCL {rccl}, torch {torch.__version__}, HSA_ENABLE_IPC_MODE_LEGACY="
+              f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
     # no HIP device / no librl8_amd.so: AlgorithmConfig.build() raises HipExtensionError below
 
     from rl8_amd import AlgorithmConfig, RecurrentAlgorithmConfig, hip
@@ -378,10 +470,13 @@ def run(args: argparse.Namespace) -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     hip.timer.enabled = False
+    rank_elapsed = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)   # (outside the timed region: a straggling rank shows in the line)
+        rank_elapsed = [float(v) for v in every]
+        elapsed = max(rank_elapsed)
 
     kernels = {}
     obs_dim = int(algo.env.observation_spec.shape[0])
@@ -493,7 +588,7 @@ def run(args: argparse.Namespace) -> None:
             # bf16-plane kernel: priced in the bf16 multiply-adds the matrix pipe executes
             # (6 per fp32 multiply-add of the algorithm) against the dense bf16 peak
             roofline = {
-                "kernel": {"mlp_wgrad": "rl8_mlp_wgrad_fused_split_f32", "mlp_wgrad_gate": "rl8_mlp_wgrad_fused_split_f32 (n_out = 1) / rl8_mlp_wgrad_fused_pair_f32",
+                "kernel": {"mlp_wgrad": "rl8_mlp_wgrad_fused_split_f32", "mlp_wgrad_gate": "rl8_mlp_wgrad_gate_bits_f32 (rank-one heads: one output, or a pair of opposite gradients)",
                            "mlp_tower_backward_gate": "rl8_mlp_tower_backward_gate_f16_f32"}.get(
                     dominant, f"rl8_{dominant}_{'f16' if top['gemm'] == 'f16x2-split' else 'split'}_f32"),
                 "bound": "mfma",
@@ -548,6 +643,8 @@ def run(args: argparse.Namespace) -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "rank_ms_per_step": {"min": min(rank_elapsed) / args.steps * 1e3, "max": max(rank_elapsed) / args.steps * 1e3,
+                                 "per_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed]},
             "collect_ms_per_step": collect_ms / args.steps,
             "update_ms_per_step": step_ms / args.steps,
             "higher_is_better": True,

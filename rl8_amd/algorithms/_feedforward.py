@@ -27,6 +27,7 @@ unbuffered, the stat keys -- follows the reference's
 
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import Any, Literal
 
@@ -50,6 +51,7 @@ from ..data import (
 from ..distributions import Categorical, Distribution, NoiseStream, Normal, SquashedNormal
 from ..env import Env, EnvFactory
 from ..models import Model, ModelFactory
+from ..nn import fused_mlp
 from ..nn.functional import fused_ppo_loss, gae_launch, has_fused_loss, losses_from_sums
 from ..parallel import EnvShards
 from ..policies import Policy
@@ -755,7 +757,11 @@ class Algorithm:
             stop = min(rows, start + self.max_rows_per_pass)
             chunk = {k: v[start:stop] for k, v in batch.items()}
             n = stop - start
-            with amp.autocast("cuda", enabled=hp.enable_amp):
+            # A two-way Categorical under the fused loss: rl8_ppo_loss_categorical_fwd_bwd_f32 emits logit gradients
+            # that are exact negatives of each other, so the policy tower may keep only the gate bits of h2 from the
+            # first SGD iteration on (fused_mlp.expect_pair_gradients; still checked on the device in the backward).
+            pair = fused_mlp.expect_pair_gradients() if fused and issubclass(dist_cls, Categorical) else contextlib.nullcontext()
+            with amp.autocast("cuda", enabled=hp.enable_amp), pair:
                 views = chunk[DataKeys.VIEWS] if DataKeys.VIEWS in chunk else TensorDict(
                     {DataKeys.OBS: chunk[DataKeys.OBS]}, batch_size=n)
                 sample = self.policy.sample(

@@ -1065,6 +1065,12 @@ RL8_API int rl8_mlp_pack_w2_f16(const float *w2, int transposed, void *packed, v
   return launch_status();
 }
 
+namespace rl8 {
+int mlp_rows_forward_dispatch(int mode, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1, const float *b1,
+                              const void *w2s, const float *b2, const float *w3, const float *b3, int n_out, float *out,
+                              float *h2, uint32_t *gate);
+}
+
 RL8_API int rl8_mlp_forward_f16_supports(int d_in, int n_out) {
   return (d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5) && n_out >= 1 && n_out <= 3;
 }
@@ -1078,11 +1084,18 @@ RL8_API int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, c
   if (save_h1 && !save_h2) return RL8_ENULL;  // (the gate bits alone are allowed: SAVE mode 2)
   if (((uintptr_t)w2_f16 & 15) != 0 || !aligned16(save_h1) || !aligned16(save_h2) || !aligned16(save_gate2))
     return RL8_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  if (!save_h1) {  // rows-per-wave generation (mlp_rows_kernels.hip); experiment switch read per call
+    const int mode = env_int("RL8_MLP_FWD_ROWS");
+    if (mode > 0) {
+      const int st = mlp_rows_forward_dispatch(mode, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, n_out, out, save_h2, save_gate2);
+      if (st != -1) return st;
+    }
+  }
   const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
   static const int cap = env_int("RL8_MLP_GRID_CAP");
   const int max_grid = cap > 0 ? cap : 2 * kCUs;
   const int grid = (int)(tiles < max_grid ? tiles : max_grid);
-  hipStream_t s = (hipStream_t)stream;
   switch (d_in) {
     case 1: return dispatch_forward_f16_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, out, save_h1, save_h2, save_gate2);
     case 2: return dispatch_forward_f16_nout<2>(n_out, grid, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, out, save_h1, save_h2, save_gate2);

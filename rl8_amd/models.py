@@ -256,7 +256,10 @@ class DefaultDiscreteModel(Model):
         from .nn import fused_mlp
 
         obs = batch[DataKeys.OBS]
-        logits = fused_mlp.tower_forward(self.feature_model[:2], [self.feature_model[2]], obs)
+        # (two actions: under the fused PPO loss the two logit gradients are exact negatives, and Algorithm says so)
+        two_way = self.action_spec.shape[0] == 1 and self.action_spec.space.n == 2
+        logits = fused_mlp.tower_forward(self.feature_model[:2], [self.feature_model[2]], obs,
+                                         pair_gradients=True if two_way and fused_mlp.pair_hint() else None)
         if logits is None:
             logits = self.feature_model(obs)
         logits = logits.reshape(-1, self.action_spec.shape[0], self.action_spec.space.n)

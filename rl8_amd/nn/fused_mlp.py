@@ -60,13 +60,15 @@ def _packed(layer: nn.Linear, transposed: bool, split: bool | str = False) -> to
     return packed
 
 
-def _packed_gate(layer: nn.Linear, w3: torch.Tensor) -> torch.Tensor:
+def _packed_gate(layer: nn.Linear, w3: torch.Tensor, w3_key: tuple) -> torch.Tensor:
     """``hip.mlp_pack_w2_f16_gate(layer.weight, w3)``, cached on the layer like ``_packed`` and re-made when
-    either weight has changed."""
+    either weight has changed. ``w3_key`` identifies the head PARAMETERS (version counters and addresses):
+    ``w3`` itself is a fresh ``torch.cat`` temporary for multi-head towers, whose version is always 0 and whose
+    address the caching allocator may hand out again."""
     w2 = layer.weight
     cache = layer.__dict__.setdefault("_rl8_w2_packs", {})
     hit = cache.get("gate")
-    key = (w2._version, w2.data_ptr(), w3._version, w3.data_ptr(), tuple(w3.shape))
+    key = (w2._version, w2.data_ptr(), w3_key, tuple(w3.shape))
     if hit is not None and hit[0] == key:
         return hit[1]
     packed = hip.mlp_pack_w2_f16_gate(w2, w3)
@@ -78,9 +80,36 @@ def _gates_off() -> bool:
     return bool(int(os.environ.get("RL8_WGRAD_GATE_OFF", "0") or 0))
 
 
+_PAIR_HINT = False
+
+
+class expect_pair_gradients:
+    """Context manager for callers that KNOW the gradients of a two-output tower evaluated inside it will be exact
+    negatives of each other (``Algorithm``: a two-way ``Categorical`` policy under the fused PPO loss, whose kernel
+    emits antisymmetric logit gradients by construction). Towers that ask (``pair_gradients=None`` resolves to
+    this hint) then keep only the gate bits of h2 from the first iteration on. The promise is still checked on the
+    device in every backward (``rl8_mlp_dout_pair_check``); a broken one costs a re-run of the forward, never a
+    wrong gradient."""
+
+    def __enter__(self):
+        global _PAIR_HINT
+        self._before = _PAIR_HINT
+        _PAIR_HINT = True
+        return self
+
+    def __exit__(self, *exc):
+        global _PAIR_HINT
+        _PAIR_HINT = self._before
+        return False
+
+
+def pair_hint() -> bool:
+    return _PAIR_HINT
+
+
 class _FusedTower(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, layer2, grad_mode):  # type: ignore[override]
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, layer2, grad_mode, pair, w3_key):  # type: ignore[override]
         # needs_input_grad reflects the parameters' requires_grad even when the
         # caller runs under no_grad (rollouts), and inside forward() grad mode is
         # always off: the caller's grad mode comes in as an argument, so that
@@ -96,7 +125,7 @@ class _FusedTower(torch.autograd.Function):
             n_out = w3.shape[0]
             gate_only = (need_grad and f16 and not keep_h1 and BACKWARD_GEMM == "f16"
                          and hip.mlp_backward_f16_supports(x.shape[1], n_out) and not _gates_off()
-                         and (n_out == 1 or (n_out == 2 and layer2.__dict__.get("_rl8_rank_one", False))))
+                         and (n_out == 1 or (n_out == 2 and pair)))
             out, h1, h2, gate = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16" if f16 else True),
                                                             b2, w3, b3, save=need_grad, save_h1=keep_h1, save_gate=True,
                                                             save_h2=not gate_only)
@@ -105,18 +134,21 @@ class _FusedTower(torch.autograd.Function):
             gate = None
         if need_grad:
             ctx.layer2 = layer2
-            ctx.save_for_backward(x, h1, h2, w3, w1, b1, gate, b2, b3)
+            ctx.w3_key = w3_key
+            # (w2 is saved although the kernels read its packed copies: autograd's version check then refuses a
+            # backward after an in-place change of the weight, as it would for the eager modules)
+            ctx.save_for_backward(x, h1, h2, w3, w1, b1, gate, b2, b3, w2)
         return out
 
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
-        x, h1, h2, w3, w1, b1, gate, b2, b3 = ctx.saved_tensors
+        x, h1, h2, w3, w1, b1, gate, b2, b3, w2 = ctx.saved_tensors
         split: bool | str = BACKWARD_GEMM in ("split", "f16") and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0])
         if split and BACKWARD_GEMM == "f16" and gate is not None and hip.mlp_backward_f16_supports(x.shape[1], w3.shape[0]):
             split = "f16"
-        # (w3 as saved is the parameter itself for a single head: its version counter tracks the optimizer)
-        gate_pack = (lambda: _packed_gate(ctx.layer2, w3)) if split == "f16" and w3.shape[0] <= 2 else None
         layer2 = ctx.layer2
+        w3_key = ctx.w3_key
+        gate_pack = (lambda: _packed_gate(layer2, w3, w3_key)) if split == "f16" and w3.shape[0] <= 2 else None
 
         def h2_again():  # (a two-output head that is not rank-one after all: the forward once more, with h2)
             return hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16"), b2, w3, b3, save=True,
@@ -125,10 +157,10 @@ class _FusedTower(torch.autograd.Function):
         info: dict = {}
         g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(layer2, True, split), w3,
                                    w1, b1, wgrad_split=BACKWARD_GEMM in ("split", "f16"), gate2=gate if split else None,
-                                   gate_pack=gate_pack, w2=layer2.weight, b2=b2, h2_fn=h2_again, info=info)
-        if w3.shape[0] == 2:
+                                   gate_pack=gate_pack, w2=w2, b2=b2, h2_fn=h2_again, info=info)
+        if w3.shape[0] == 2:  # what this backward found, for callers that give no hint (see tower_forward)
             layer2.__dict__["_rl8_rank_one"] = bool(info.get("rank_one", False))
-        return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None
+        return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None, None, None
 
 
 def _match(trunk: nn.Module, heads: Sequence[nn.Linear]) -> None | tuple[nn.Linear, nn.Linear]:
@@ -153,10 +185,16 @@ def _match(trunk: nn.Module, heads: Sequence[nn.Linear]) -> None | tuple[nn.Line
     return l1, l2
 
 
-def tower_forward(trunk: nn.Sequential, heads: Sequence[nn.Linear], x: torch.Tensor) -> None | torch.Tensor:
+def tower_forward(trunk: nn.Sequential, heads: Sequence[nn.Linear], x: torch.Tensor, *,
+                  pair_gradients: None | bool = None) -> None | torch.Tensor:
     """``cat([head(trunk(x)) for head in heads], -1)`` through the fused kernels,
     or ``None`` when this tower / input is not eligible (caller then runs the
-    modules eagerly)."""
+    modules eagerly).
+
+    ``pair_gradients`` (two-output towers only): ``True`` -- the caller expects the two outputs' gradients to be
+    exact negatives (a two-way categorical under the fused loss), so the forward keeps the gate bits of h2 alone;
+    ``False`` -- h2 is stored; ``None`` -- whatever this tower's previous backward found (a tower used outside
+    ``Algorithm``). Checked on the device in the backward either way."""
     if not ENABLED or not x.is_cuda or x.dtype != torch.float32 or x.ndim != 2:
         return None
     layers = _match(trunk, heads)
@@ -168,5 +206,8 @@ def tower_forward(trunk: nn.Sequential, heads: Sequence[nn.Linear], x: torch.Ten
     else:
         w3 = torch.cat([h.weight for h in heads], 0)
         b3 = torch.cat([h.bias for h in heads], 0)
+    if pair_gradients is None:
+        pair_gradients = bool(l2.__dict__.get("_rl8_rank_one", False))
+    w3_key = tuple((h.weight._version, h.weight.data_ptr()) for h in heads)
     return _FusedTower.apply(x.contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3, l2,
-                             torch.is_grad_enabled())
+                             torch.is_grad_enabled(), bool(pair_gradients), w3_key)

@@ -721,6 +721,79 @@ def gen_first_updates() -> None:
         gen_first_update(name, trace_name, envs[env], cfg, recurrent=recurrent)
 
 
+# --------------------------------------------------------------------------- #
+# F8: config 3 end to end: CartPole (examples/cartpole/env.py:12-64,101-150)
+#     through Algorithm.collect() / .step() (src/rl8/algorithms/_feedforward.py:301-615): the only
+#     built-in path through a three-way Categorical head on a five-wide observation. Self-contained
+#     fixture: initial weights, reset STATE (the reference's reset returns observations only), the
+#     multinomial noise per timestep, buffer + CollectStats, every StatTracker.update of the default
+#     4-iteration step, and a one-iteration run with its first clipped gradient and weights.
+#     The eager body of the @torch.compile'd step is used (<= 1 ulp from the compiled one).
+# --------------------------------------------------------------------------- #
+def gen_cartpole_first_update() -> None:
+    from examples.cartpole import env as cp_env
+
+    cp_env.step = _eager(cp_env.step)
+    arrays = {}
+
+    def run(tag, **overrides):
+        torch.manual_seed(42)
+        algo = AlgorithmConfig(num_envs=64, horizon=32, device="cpu", **overrides).build(cp_env.CartPole)
+        init = {k: v.clone() for k, v in algo.policy.model.state_dict().items()}
+        states = []
+        with Recorder() as rec:
+            real_reset = algo.env.reset
+
+            def reset(*, config=None):
+                out = real_reset(config=config)
+                states.append(algo.env.state.clone())
+                return out
+
+            algo.env.reset = reset
+            collect_stats = algo.collect()
+            algo.env.reset = real_reset
+            buffer = {}
+            snapshot_buffer(algo.buffer, "it0_collect", buffer)
+            reward_scale = np.float64(algo.state.reward_scale)
+            with UpdateRecorder(algo) as urec:
+                step_stats = algo.step()
+        return algo, init, states, rec, collect_stats, buffer, reward_scale, urec, step_stats
+
+    algo, init, states, rec, collect_stats, buffer, reward_scale, urec, step_stats = run("traced")
+    for k, v in init.items():
+        arrays[f"init_{k}"] = v
+    arrays["it0_reset_state"] = states[0]                      # [4, N]: x, x_dot, theta, theta_dot
+    arrays["it0_cat_q"] = torch.stack(rec.cat_q)
+    arrays["it0_perms"] = torch.stack(rec.perms)
+    arrays.update(buffer)
+    arrays["it0_reward_scale"] = reward_scale
+    collect_keys = sorted(k for k in collect_stats if not k.startswith("profiling"))
+    step_keys = sorted(k for k in step_stats if not k.startswith("profiling"))
+    arrays["it0_collect_stats"] = np.array([collect_stats[k] for k in collect_keys], np.float64)
+    arrays["it0_step_stats"] = np.array([step_stats[k] for k in step_keys], np.float64)
+    arrays["collect_stat_keys"] = np.array(collect_keys)
+    arrays["step_stat_keys"] = np.array(step_keys)
+    arrays["traced_updates"] = np.array(urec.updates, np.float64)
+
+    algo1, init1, states1, rec1, _, buffer1, _, urec1, step_stats1 = run("sgd1", num_sgd_iters=1)
+    for k, v in init1.items():
+        assert np.array_equal(v.numpy(), init[k].numpy()), k
+    for k, v in buffer1.items():
+        assert np.array_equal(v.numpy(), buffer[k].numpy()), f"the two rollouts differ: {k}"
+    assert len(urec1.updates) == 1
+    arrays["sgd1_updates"] = np.array(urec1.updates, np.float64)
+    arrays["sgd1_step_stats"] = np.array([step_stats1[k] for k in step_keys], np.float64)
+    total_sq = 0.0
+    for k, gval in urec1.first_grads.items():
+        arrays[f"sgd1_grad_{k}"] = gval
+        total_sq += float((gval.double() ** 2).sum())
+    arrays["sgd1_clipped_grad_norm"] = np.float64(total_sq ** 0.5)
+    for k, v in algo1.policy.model.state_dict().items():
+        arrays[f"sgd1_final_{k}"] = v.clone()
+    arrays["stat_keys"] = np.array(STAT_KEYS + ("reduce",))
+    save("first_update_ff_cartpole.npz", **arrays)
+
+
 def gen_early_stop() -> None:
     """KL early stop (src/rl8/algorithms/_feedforward.py:577-582) on the rollout of
     trace_ff_discrete.npz with four minibatches per SGD iteration. The reference
@@ -775,6 +848,9 @@ def main() -> None:
         gen_first_updates()
         gen_early_stop()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "cartpole":
+        gen_cartpole_first_update()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "views":
         gen_views()
         return
@@ -818,6 +894,7 @@ def main() -> None:
     )
     gen_first_updates()
     gen_early_stop()
+    gen_cartpole_first_update()
 
 
 if __name__ == "__main__":

@@ -46,6 +46,9 @@ def inject(algo, g, it):
         def reset(*, config=None):
             real_reset(config=config)
             algo.env.state.copy_(reset_state)
+            if type(algo.env).__name__ == "CartPole":  # the reference's reset returns observations of the state
+                x, x_dot, theta, theta_dot = algo.env.state
+                return torch.vstack((x, x_dot, torch.cos(theta), torch.sin(theta), theta_dot)).T.contiguous()
             return algo.env.state
 
         algo.env.reset = reset
@@ -596,3 +599,34 @@ def test_enable_amp_keeps_the_fused_fp32_towers():
     for k in ("losses/policy", "losses/vf", "losses/total"):
         assert s0[k] == pytest.approx(s1[k], rel=1e-5, abs=1e-8), k
     torch.testing.assert_close(p0, p1, rtol=1e-4, atol=1e-6)
+
+
+def test_first_sgd_iteration_of_a_two_action_policy_stores_no_h2():
+    """Algorithm knows its policy is a two-way Categorical under the fused loss (logit gradients exact negatives by
+    construction) and says so to the tower: from the FIRST iteration of a fresh model the training forwards keep the
+    gate bits only and both towers' backward passes run in gate mode."""
+    from rl8_amd import hip
+
+    torch.manual_seed(0)
+    algo = AlgorithmConfig(num_envs=256, horizon=8, num_sgd_iters=2).build(DiscreteDummyEnv)
+    stored = []
+    real = hip.mlp_tower_forward_split
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        if k.get("save"):
+            stored.append(out[2] is not None)
+        return out
+
+    algo.collect()
+    hip.timer.reset()
+    hip.timer.enabled = True
+    try:
+        with patch.object(hip, "mlp_tower_forward_split", spy):
+            algo.step()
+        launched = hip.timer.summary()
+    finally:
+        hip.timer.enabled = False
+    assert stored == [False] * 4, stored              # 2 iterations x (policy, value) towers: never h2
+    assert "mlp_tower_backward_gate" in launched and "mlp_wgrad_gate" in launched
+    assert "mlp_tower_backward" not in launched and "mlp_wgrad" not in launched

@@ -95,3 +95,106 @@ def test_self_launched_ranks_rendezvous_then_stop_at_no_hip_device():
     assert "rank 0/2 up, backend gloo" in proc.stderr and "rank 1/2 up, backend gloo" in proc.stderr
     assert "HipExtensionError" in proc.stderr and "needs a HIP device" in proc.stderr
     assert proc.stdout.strip() == ""  # no JSON line from a run that measured nothing
+
+
+def test_launch_timeout_is_finite_by_default():
+    a = bench.parse_args(["--gpus", "8"])
+    assert a.launch_timeout is None                       # -> default_launch_timeout(steps, warmup) in main()
+    limit = bench.default_launch_timeout(a.steps, a.warmup)
+    assert 600 < limit < 3600 and bench.default_launch_timeout(20, 5) > limit
+    assert bench.parse_args(["--launch-timeout", "30"]).launch_timeout == 30.0
+
+
+def test_failed_rank_stderr_tail_is_forwarded(tmp_path, capfd):
+    script = tmp_path / "child.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, time
+        print(f"hello from rank {os.environ['RANK']}", file=sys.stderr, flush=True)
+        if os.environ["RANK"] == "1":
+            print("RuntimeError: boom in rank one", file=sys.stderr, flush=True)
+            sys.exit(7)
+        time.sleep(120)
+    """))
+    rc, _ = bench.launch_ranks(2, [], script=str(script))
+    err = capfd.readouterr().err
+    assert rc == 7
+    assert "[rank 1] RuntimeError: boom in rank one" in err            # passed through live, tagged
+    assert "last lines of rank 1's stderr" in err and "last lines of rank 0's stderr" in err
+    assert err.count("boom in rank one") >= 2                           # ... and again in the tail
+
+
+def _alive(pid: int) -> bool:
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    try:  # a zombie still answers kill(0)
+        with open(f"/proc/{pid}/stat") as f:
+            return f.read().split(") ")[1][0] != "Z"
+    except OSError:
+        return False
+
+
+@pytest.mark.parametrize("sig", ["SIGTERM", "SIGKILL"])
+def test_no_rank_survives_a_killed_parent(tmp_path, sig):
+    """SIGTERM: the launcher's handler stops the ranks' process groups. SIGKILL (no handler can run): every rank asked
+    the kernel for SIGTERM on parent death. Either way nothing is left holding a GPU."""
+    import signal
+
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent("""
+        import os, subprocess, sys, time
+        helper = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(300)"])  # a rank's own helper process
+        open(os.path.join(os.path.dirname(__file__), f"pid{os.environ['RANK']}"), "w").write(f"{os.getpid()} {helper.pid}")
+        time.sleep(300)
+    """))
+    parent_code = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.launch_ranks(3, [], script={str(child)!r})"
+    parent = subprocess.Popen([sys.executable, "-c", parent_code], stderr=subprocess.DEVNULL)
+    try:
+        deadline = time.monotonic() + 60
+        while time.monotonic() < deadline and not all((tmp_path / f"pid{r}").exists() and (tmp_path / f"pid{r}").read_text().count(" ") for r in range(3)):
+            time.sleep(0.05)
+        pids = [[int(v) for v in (tmp_path / f"pid{r}").read_text().split()] for r in range(3)]
+        assert all(_alive(p[0]) for p in pids)
+        parent.send_signal(getattr(signal, sig))
+        parent.wait(timeout=60)
+        if sig == "SIGTERM":
+            assert parent.returncode == 128 + signal.SIGTERM
+        deadline = time.monotonic() + 30
+        ranks = [p[0] for p in pids]
+        while time.monotonic() < deadline and any(_alive(p) for p in ranks):
+            time.sleep(0.1)
+        assert not any(_alive(p) for p in ranks), "a rank outlived its launcher"
+        if sig == "SIGTERM":  # the handler signals the whole process GROUP of each rank: helpers go too
+            helpers = [p[1] for p in pids]
+            while time.monotonic() < deadline and any(_alive(p) for p in helpers):
+                time.sleep(0.1)
+            assert not any(_alive(p) for p in helpers)
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+        for r in range(3):
+            f = tmp_path / f"pid{r}"
+            if f.exists():
+                for p in f.read_text().split():
+                    try:
+                        os.kill(int(p), signal.SIGKILL)
+                    except (ProcessLookupError, ValueError):
+                        pass
+
+
+def test_rccl_run_without_enough_devices_fails_before_any_rendezvous():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than two HIP devices")
+    t0 = time.monotonic()
+    proc = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--num-envs", "64"],
+        capture_output=True, text=True, timeout=600,
+        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+    )
+    assert proc.returncode != 0 and proc.stdout.strip() == ""
+    assert "needs 2 HIP devices" in proc.stderr and "up, backend" not in proc.stderr   # no process group was formed
+    assert "last lines of rank" in proc.stderr
+    assert time.monotonic() - t0 < 300

@@ -10,7 +10,10 @@ reference's, so the first ``StatTracker.update`` of a ``step()``
 LSTM forward and backward, fused loss -- from optimizer drift. All six traced
 variants are held to that: feed-forward discrete (full batch / minibatched +
 entropy + dual clip), feed-forward Normal + entropy, feed-forward
-SquashedNormal, recurrent discrete, recurrent continuous minibatched.
+SquashedNormal, recurrent discrete, recurrent continuous minibatched -- and
+(round 3) CartPole, the only built-in path through a three-way head on a
+five-wide observation (the general, non-rank-one tower kernels), whose rollout is
+also compared with the reference's buffer here (no separate trace exists for it).
 """
 
 import numpy as np
@@ -19,10 +22,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from rl8_amd import AlgorithmConfig, RecurrentAlgorithmConfig  # noqa: E402
+from rl8_amd import AlgorithmConfig, RecurrentAlgorithmConfig, hip  # noqa: E402
 from rl8_amd import _utils as host_utils  # noqa: E402
 from rl8_amd.distributions import SquashedNormal  # noqa: E402
 from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv  # noqa: E402
+from rl8_amd.envs.cartpole import CartPole  # noqa: E402
 
 from .test_algorithm_gpu import inject  # noqa: E402
 
@@ -42,6 +46,9 @@ VARIANTS = {
         "trace_rec_continuous_minibatch.npz", ContinuousDummyEnv,
         dict(sgd_minibatch_size=128, entropy_coeff=1e-2, seq_len=8, seqs_per_state_reset=2,
              horizons_per_env_reset=2), True),
+    # config 3: the reference's CartPole (examples/cartpole/env.py) through collect() / step();
+    # the fixture is self-contained (initial weights, reset state, noise, rollout, updates, first gradient)
+    "ff_cartpole": ("first_update_ff_cartpole.npz", CartPole, {}, False),
 }
 
 STAT_KEYS = ("coefficients/entropy", "coefficients/vf", "losses/entropy", "losses/policy", "losses/vf",
@@ -110,8 +117,21 @@ def test_one_sgd_iteration_matches_reference_to_1e5(golden, variant):
     g = golden(f"first_update_{variant}.npz")
     algo, _ = build(golden, variant, num_sgd_iters=1, sgd_minibatch_size=None)
     algo.collect()
-    with Recorder(algo) as rec:
-        stats = algo.step()
+    hip.timer.reset()
+    hip.timer.enabled = True
+    try:
+        with Recorder(algo) as rec:
+            stats = algo.step()
+        launched = set(hip.timer.summary())
+    finally:
+        hip.timer.enabled = False
+    # which tower kernels these reference-held numbers pin: a two-action policy runs the gate-mode (rank-one)
+    # backward kernels from its FIRST update (Algorithm's pair hint), like every value tower; CartPole's three-way
+    # head and the continuous (mean | log_std) heads the general ones
+    if variant.startswith("ff_"):
+        assert {"mlp_tower_backward_gate", "mlp_wgrad_gate"} <= launched, launched
+        general = {"mlp_tower_backward", "mlp_wgrad"} <= launched
+        assert general == (variant not in ("ff_discrete", "ff_discrete_minibatch")), (variant, launched)
     assert len(rec.updates) == 1
     assert_update(rec.updates[0], g["sgd1_updates"][0], variant)
     for k, w in zip(g["step_stat_keys"], g["sgd1_step_stats"]):
@@ -182,3 +202,24 @@ def test_kl_early_stop_matches_reference(golden):
     assert all(p.grad is None for p in algo.policy.model.parameters())
     for k, p in algo.policy.model.named_parameters():
         np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"final_{k}"], rtol=0, atol=2e-4, err_msg=k)
+
+
+def test_cartpole_rollout_matches_reference(golden):
+    """collect() on the reference's CartPole rollout inputs (reset state, initial weights, multinomial noise):
+    action indices bit-exact, physics 1e-6 absolute per step (obs, rewards; one sin / cos per step differs by an ulp
+    between devices), log-probabilities / values / CollectStats at 1e-5."""
+    from rl8_amd.data import DataKeys
+
+    g = golden("first_update_ff_cartpole.npz")
+    algo, _ = build(golden, "ff_cartpole")
+    stats = algo.collect()
+    buf = algo.buffer
+    assert np.array_equal(buf[DataKeys.ACTIONS][:, :HORIZON].cpu().numpy(), g["it0_collect_actions"][:, :HORIZON])
+    for key in ("obs", "rewards", "reversed_discounted_returns"):
+        np.testing.assert_allclose(buf[key].cpu().numpy(), g[f"it0_collect_{key}"], rtol=2e-6, atol=2e-6, err_msg=key)
+    np.testing.assert_allclose(buf[DataKeys.LOGP].cpu().numpy()[:, :HORIZON], g["it0_collect_logp"][:, :HORIZON],
+                               rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(buf[DataKeys.VALUES].cpu().numpy(), g["it0_collect_values"], rtol=1e-5, atol=2e-6)
+    for k, w in zip(g["collect_stat_keys"], g["it0_collect_stats"]):
+        assert stats[str(k)] == pytest.approx(w, rel=1e-5, abs=1e-5), k
+    assert algo.state.reward_scale == pytest.approx(float(g["it0_reward_scale"]), rel=1e-5)

@@ -599,6 +599,109 @@ def test_fused_tower_keeps_only_gate_bits_for_rank_one_heads_and_recovers_when_w
         fused_mlp.hip.mlp_tower_forward_split = real
 
 
+def test_fused_tower_refuses_a_backward_after_an_in_place_weight_change():
+    """The wrapper saves W2 itself (not only its packed copies), so autograd's version check fires exactly as it
+    would for the eager modules: a drop-in must fail loudly, not differentiate through the new weights."""
+    from rl8_amd.nn import fused_mlp
+
+    torch.manual_seed(2)
+    mlp = torch.nn.Sequential(torch.nn.Linear(1, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
+    trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
+    head = torch.nn.Linear(256, 2).to(DEV)
+    x = torch.randn(500, 1, device=DEV)
+    for target in (mlp[2].weight, mlp[0].weight, head.weight):
+        out = fused_mlp.tower_forward(trunk, [head], x)
+        with torch.no_grad():
+            target.mul_(1.5)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            out.sum().backward()
+
+
+def test_fused_tower_takes_the_pair_decision_from_the_caller():
+    """`pair_gradients=True` (what Algorithm passes for a two-way Categorical under the fused loss): no h2 from the
+    FIRST forward of a fresh tower; the device-side check stays the guard -- a gradient that is not a pair re-runs the
+    forward for h2 and the general kernels give eager PyTorch's gradients; `False` always stores h2."""
+    from rl8_amd.nn import fused_mlp
+
+    torch.manual_seed(13)
+    mlp = torch.nn.Sequential(torch.nn.Linear(1, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
+    trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
+    head = torch.nn.Linear(256, 2).to(DEV)
+    x = torch.randn(4000, 1, device=DEV) * 20
+    saved = []
+    real = hip.mlp_tower_forward_split
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        if k.get("save"):
+            saved.append(out[2] is not None)
+        return out
+
+    def check(weights, hint):
+        params = list(trunk.parameters()) + list(head.parameters())
+        for q in params:
+            q.grad = None
+        hip.timer.reset()
+        hip.timer.enabled = True
+        try:
+            (fused_mlp.tower_forward(trunk, [head], x, pair_gradients=hint) * weights).sum().backward()
+            launched = set(hip.timer.summary())
+        finally:
+            hip.timer.enabled = False
+        got = [q.grad.clone() for q in params]
+        for q in params:
+            q.grad = None
+        (head(trunk(x)) * weights).sum().backward()
+        for a, q in zip(got, params):
+            assert _rel(a, q.grad.double()) < 2e-5
+        return launched
+
+    fused_mlp.hip.mlp_tower_forward_split = spy
+    try:
+        pair = torch.tensor([1.0, -1.0], device=DEV) / 4000
+        launched = check(pair, True)
+        assert saved == [False] and {"mlp_tower_backward_gate", "mlp_wgrad_gate"} <= launched
+        saved.clear()
+        launched = check(torch.tensor([1.0, 0.25], device=DEV) / 4000, True)   # the promise broken: forward re-run
+        assert saved == [False, True] and "mlp_tower_backward_gate" not in launched
+        saved.clear()
+        check(pair, False)
+        assert saved == [True]
+        saved.clear()
+        with fused_mlp.expect_pair_gradients():
+            assert fused_mlp.pair_hint()
+        assert not fused_mlp.pair_hint()
+    finally:
+        fused_mlp.hip.mlp_tower_forward_split = real
+
+
+def test_gate_pack_follows_the_head_parameters_not_the_concatenated_temporary():
+    """Two heads: w3 is a fresh torch.cat every forward (version 0, recycled address); the cached W2*w3e pack must be
+    re-made when a HEAD parameter changes while W2 does not."""
+    from rl8_amd.nn import fused_mlp
+
+    torch.manual_seed(17)
+    mlp = torch.nn.Sequential(torch.nn.Linear(1, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
+    trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
+    heads = [torch.nn.Linear(256, 1).to(DEV), torch.nn.Linear(256, 1).to(DEV)]
+    x = torch.randn(3000, 1, device=DEV) * 10
+    pair = torch.tensor([1.0, -1.0], device=DEV) / 3000
+    params = list(trunk.parameters()) + [q for h in heads for q in h.parameters()]
+    for it in range(3):
+        for q in params:
+            q.grad = None
+        (fused_mlp.tower_forward(trunk, heads, x, pair_gradients=True) * pair).sum().backward()
+        got = [q.grad.clone() for q in params]
+        for q in params:
+            q.grad = None
+        (torch.cat([h(trunk(x)) for h in heads], -1) * pair).sum().backward()
+        for a, q in zip(got, params):
+            assert _rel(a, q.grad.double()) < 2e-5, it
+        with torch.no_grad():  # only the heads move (a frozen trunk): W2's version stays
+            heads[0].weight.add_(torch.randn_like(heads[0].weight) * 0.05)
+            heads[1].weight.mul_(0.5)
+
+
 @pytest.mark.parametrize("scheme", ["bf16x3", "f16x2", "f16x2-gate"])
 @pytest.mark.parametrize("m,parts", [(1 << 23, 8), (1 << 25, 4)])
 def test_full_size_launch_equals_its_chunks(m, parts, scheme):

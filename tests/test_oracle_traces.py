@@ -78,3 +78,41 @@ def test_oracle_first_update_matches_reference_to_1e5(golden, name, kw):
         err_sq += float(((got - w) ** 2).sum())
         ref_sq += float((w ** 2).sum())
     assert (err_sq / ref_sq) ** 0.5 < 1e-5
+
+
+def test_oracle_cartpole_first_update_matches_reference(golden):
+    """Config 3 end to end on the CPU restatement (tests/golden/first_update_ff_cartpole.npz: the reference's
+    CartPole through collect() / step(), eager Euler physics): rollout buffer, CollectStats, then one SGD iteration
+    over the full buffer -- StepStats and the gradient at the first optimizer.step() at 1e-5."""
+    torch.set_num_threads(8)
+    g = golden("first_update_ff_cartpole.npz")
+    algo = OraclePPO(env="cartpole", num_envs=64, horizon=32, num_sgd_iters=1)
+    load_reference_weights(algo.model, g)
+    stats = algo.collect(noise=g["it0_cat_q"], reset_state=g["it0_reset_state"])
+    assert np.array_equal(algo.buf["actions"][:, :32], g["it0_collect_actions"][:, :32])
+    for key in ("obs", "rewards", "reversed_discounted_returns"):
+        # physics: 1e-6 absolute per step (one sin / cos per step differs by an ulp); the discounted sums relative
+        np.testing.assert_allclose(algo.buf[key], g[f"it0_collect_{key}"], rtol=2e-6, atol=2e-6, err_msg=key)
+    for key in ("values", "logp"):
+        np.testing.assert_allclose(algo.buf[key], g[f"it0_collect_{key}"], rtol=1e-5, atol=2e-6, err_msg=key)
+    for k, w in zip(g["collect_stat_keys"], g["it0_collect_stats"]):
+        assert stats[str(k)] == pytest.approx(w, rel=2e-6, abs=1e-6), k
+    assert algo.reward_scale == pytest.approx(float(g["it0_reward_scale"]), rel=2e-6)
+    grads = {}
+    real_step = algo.optimizer.step
+
+    def recording_step(*a, **k):
+        grads.update({n: p.grad.detach().clone().numpy() for n, p in algo.model.named_parameters()})
+        return real_step(*a, **k)
+
+    algo.optimizer.step = recording_step
+    step = algo.step(perms=None)
+    floors = {"losses/policy": 1e-6, "losses/total": 1e-6, "monitors/kl_div": 1e-7}
+    for k, w in zip(g["step_stat_keys"], g["sgd1_step_stats"]):
+        assert step[str(k)] == pytest.approx(w, rel=1e-5, abs=floors.get(str(k), 1e-9)), (k, step[str(k)], w)
+    err_sq = ref_sq = 0.0
+    for k, got in grads.items():
+        w = g[f"sgd1_grad_{k}"].astype(np.float64)
+        err_sq += float(((got - w) ** 2).sum())
+        ref_sq += float((w ** 2).sum())
+    assert (err_sq / ref_sq) ** 0.5 < 1e-5

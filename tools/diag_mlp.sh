@@ -9,7 +9,10 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_diag
 for what in "$@"; do
-  if [ "$what" = trace ]; then
+  if [ "$what" = stamp ]; then
+    make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/objstamp" OUT="$PWD/build_diag/librl8_amd_stamp.so" \
+         FLAGS_EXTRA="-DRL8_ROWS_STAMP"
+  elif [ "$what" = trace ]; then
     make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/objtrace" OUT="$PWD/build_diag/librl8_amd_trace.so" \
          FLAGS_EXTRA="-DRL8_PHASE_TRACE"
   else
