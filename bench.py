@@ -126,7 +126,17 @@ PMC_KERNEL_GATE = {  # gate-mode kernels (heads whose dZ2 is gate * d * w3e)
 }
 
 
+# Traffic that does NOT scale with the rows of a launch: the weight-gradient kernels end with one 256 x 256 fp32 slab per
+# workgroup (one workgroup per CU) which a reduction kernel then reads back; the ABI call cuts its rows into segments of
+# 2^23, each its own launch.  (scaling the 2^20-row profile linearly counted these 64 B/row instead of 8.)
+WGRAD_SEGMENT_ROWS = 1 << 23
+WGRAD_SLAB_BYTES = 256 * 256 * 256 * 4.0   # written by the 256 workgroups of one launch
+PMC_FIXED_BYTES = {"mlp_wgrad_gate": WGRAD_SLAB_BYTES, "mlp_wgrad": WGRAD_SLAB_BYTES}
+
+
 def pmc_traffic(name: str, units_per_launch: float, gemm: str = "f32"):
+    """HBM bytes of one ABI call of ``units_per_launch`` rows, from the profiled launch of the same kernel: the part
+    that scales with rows is scaled, the per-launch part (PMC_FIXED_BYTES) is counted once per launched segment."""
     try:
         summary = json.load(open(PMC_SUMMARY))
     except OSError:
@@ -136,7 +146,9 @@ def pmc_traffic(name: str, units_per_launch: float, gemm: str = "f32"):
     needle, units = table.get(name, (None, 1))
     for kernel, rec in summary.items():
         if needle and needle in kernel:
-            return rec["traffic_bytes_per_launch"] / units * units_per_launch
+            fixed = min(PMC_FIXED_BYTES.get(name, 0.0), rec["traffic_bytes_per_launch"])
+            launches = max(1.0, -(-units_per_launch // WGRAD_SEGMENT_ROWS)) if fixed else 1.0
+            return (rec["traffic_bytes_per_launch"] - fixed) / units * units_per_launch + fixed * launches
     return None
 
 

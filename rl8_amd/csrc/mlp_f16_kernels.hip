@@ -33,9 +33,12 @@ constexpr int kF16ScratchTail = 4 * 64 * (128 + 16) - kF16StageBytes;  // the h2
 // w3 != NULL (with transposed): the planes are those of W2[k][col] * w3e[k], w3e = W3[0] (n_w3 = 1) or
 // W3[0] - W3[1] (n_w3 = 2) -- the B operand of the data-gradient kernel's gate mode, where the ReLU gate is
 // the A operand and dZ2's dense factors moved into B.
+// layout 1 (the 16x16x32 kernels of mlp_rows_kernels.hip): unit ((hs*8 + ctl)*2 + p)*64 + l holds
+//   B(col = 16 (8 (hs & 1) + ctl) + (l & 15), k = 32 (hs >> 1) + 8 (l >> 4) + e), e = 0..7.
 __global__ __launch_bounds__(1024) void mlp_pack_w2_f16_kernel(const float *__restrict__ w2, int transposed,
                                                                uint32_t *__restrict__ packed,
-                                                               const float *__restrict__ w3 = nullptr, int n_w3 = 0) {
+                                                               const float *__restrict__ w3 = nullptr, int n_w3 = 0,
+                                                               int layout = 0) {
   __shared__ float red[1024];
   __shared__ float w3e[kHidden];
   const int tid = threadIdx.x;
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(1024) void mlp_pack_w2_f16_kernel(const float *__re
   }
   for (int unit = tid; unit < kSplitSteps * 8 * 64; unit += 1024) {
     const int l = unit & 63, ct = (unit >> 6) & 7, s = unit >> 9;
-    const int col = 32 * ct + (l & 31), k0 = 16 * s + 8 * (l >> 5);
+    const int col = layout == 1 ? 16 * (8 * (s & 1) + ct) + (l & 15) : 32 * ct + (l & 31);
+    const int k0 = layout == 1 ? 32 * (s >> 1) + 8 * (l >> 4) : 16 * s + 8 * (l >> 5);
     u32x4 hi, lo;
 #pragma unroll
     for (int e2 = 0; e2 < 8; e2 += 2) {
@@ -1061,7 +1065,8 @@ RL8_API int64_t rl8_mlp_f16_packed_bytes(void) { return kF16PackedBytes + 16; }
 RL8_API int rl8_mlp_pack_w2_f16(const float *w2, int transposed, void *packed, void *stream) {
   if (!w2 || !packed) return RL8_ENULL;
   if (((uintptr_t)packed & 15) != 0) return RL8_EALIGN;
-  mlp_pack_w2_f16_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(w2, transposed, reinterpret_cast<uint32_t *>(packed));
+  mlp_pack_w2_f16_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(w2, transposed, reinterpret_cast<uint32_t *>(packed), nullptr, 0,
+                                                              env_int("RL8_MLP_PACK_LAYOUT"));  // (experiment switch)
   return launch_status();
 }
 
