@@ -1,9 +1,10 @@
-// N1, third generation of the tower forward (round 2): the
-// 256x256 layer as an fp32-accurate product on the fp16 matrix pipe with TWO planes per
-// operand and THREE products per fp32 product -- half the matrix-pipe cycles of the bf16
-// three-plane scheme of mlp_split_kernels.hip, whose structure this kernel keeps (both
-// operands through LDS in 16-k chunks, W2 by direct-to-LDS loads, the next h1 chunk computed
-// on the VALU beside the current step's MFMAs, transposed accumulators, the same epilogue).
+// N1, the fp16 two-plane scheme (round 2): the 256x256 layer as an
+// fp32-accurate product on the fp16 matrix pipe with TWO planes per operand and THREE products
+// per fp32 product -- half the matrix-pipe cycles of the bf16 three-plane scheme of
+// mlp_split_kernels.hip.  This file: the pack kernel, the data-gradient kernel (structure of the
+// bf16-plane one: both operands through LDS in 16-k chunks, W2 by direct-to-LDS loads, the next
+// chunk produced on the VALU beside the current step's MFMAs) and the ABI entry points.  The
+// FORWARD kernel of the scheme lives in mlp_rows_kernels.hip (round 3: rows-per-wave, 16x16x32).
 //
 // Why it is still fp32-accurate.  With x scaled by a power of two into fp16's range,
 //   hi = fp16_rn(x), lo = fp16_rn(x - hi)    =>   |x - hi - lo| <= 2^-23 |x|  (11 + 11 bits, two
@@ -24,7 +25,6 @@ constexpr int kF16ABytes = 2 * kSplitPlaneStride;          // [plane][k-half][ro
 constexpr int kF16BBytes = 2 * 8 * 1024;                   // [column tile][plane] x 1 KiB
 constexpr int kF16StageBytes = kF16ABytes + kF16BBytes;    // 24 832
 constexpr int kF16PackedBytes = kSplitSteps * kF16BBytes;  // 262 144 (+ 16 bytes: scale, 1 / scale)
-constexpr int kF16ScratchTail = 4 * 64 * (128 + 16) - kF16StageBytes;  // the h2 transpose scratch beyond stage 1
 
 // w2 [256][256] fp32 -> two fp16 planes of w2 * 2^k in fragment order, k chosen so that
 // max |w2| * 2^k < 2^14: 16-byte unit ((s*8 + ct)*2 + p)*64 + l holds, for plane p,
@@ -78,571 +78,6 @@ __global__ __launch_bounds__(1024) void mlp_pack_w2_f16_kernel(const float *__re
     }
     reinterpret_cast<u32x4 *>(packed)[((s * 8 + ct) * 2 + 0) * 64 + l] = hi;
     reinterpret_cast<u32x4 *>(packed)[((s * 8 + ct) * 2 + 1) * 64 + l] = lo;
-  }
-}
-
-// [stage 0][stage 1][scratch tail][row scales: 2 x 128][head partials of the upper column half: [128 rows][k_out]]
-// [b2 | w3: (1 + k_out) x 1 KiB]; the h2 transpose scratch is stage 1 + the tail
-constexpr int kF16Fixed = 2 * kF16StageBytes + kF16ScratchTail + 2 * kSplitRows * 4;
-constexpr int f16_forward_lds_bytes(int k_out) { return kF16Fixed + kSplitRows * k_out * 4 + (1 + k_out) * kHidden * 4; }
-static_assert(f16_forward_lds_bytes(4) <= 80 * 1024, "two workgroups per CU");
-
-// SAVE: 0 inference; 1 training with h2 (and, on request, h1 and the gate bits of h2) stored; 2 training with
-// the gate bits ALONE -- what the backward pass of a rank-one head needs (gate-mode data gradient, gate-plane
-// weight gradient with dW3 taken from the weight-gradient sums: rl8_mlp_wgrad_gate_bits_f32): 32 bytes per row
-// instead of 1 KiB, and none of the h2 store path.
-template <int DIN, int NOUT, int SAVE>
-__global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_tower_forward_f16_kernel(
-    const float *__restrict__ x, int64_t m, int d_in_rt, const float *__restrict__ w1,
-    const float *__restrict__ b1, const void *__restrict__ w2s, const float *__restrict__ b2,
-    const float *__restrict__ w3, const float *__restrict__ b3, int n_out_rt,
-    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2,
-    uint32_t *__restrict__ save_gate2) {
-  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
-  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
-  const int d_in = DIN > 0 ? DIN : d_in_rt;
-  const int n_out = NOUT > 0 ? NOUT : n_out_rt;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // [stage 0: A | B][stage 1: A | B][head partials: [2 column halves][128 rows][kOut]]
-  const unsigned lds0 = lds_offset(smem);
-  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;  // rows [64 wr, +64), columns [128 wc, +128)
-  // Producer role: row `prow` of the macro tile and k-half `pkh` of every step; the
-  // k-half is wave-uniform, so the eight rows of W1 / b1 a step needs come through
-  // the scalar cache (no vector loads, no registers) and are used as scalar operands.
-  // (Lanes 4i..4i+3 = one row -- 64 contiguous bytes per row for the h1 stores -- was
-  // tried while h1 was still stored; it measured no faster and needs per-lane weights.)
-  const int prow = tid & 127, pkh = wave >> 1;
-
-  // Per-lane LDS addresses (stage 0; stage 1 = + kF16StageBytes).
-  const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
-  const unsigned b_read = lds0 + kF16ABytes + (4 * wc * 2) * 1024 + lane * 16;
-  const unsigned a_write = lds0 + pkh * kSplitKhStride + prow * 16;
-  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2s, kF16PackedBytes);
-  // operand scales (powers of two): W2's, set by the pack kernel behind the planes
-  const float inv_w2_scale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(w2s) + kF16PackedBytes)[1];
-
-  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
-  const int64_t stride = gridDim.x;
-
-  // Producer state: the tile whose h1 chunks are being produced (runs one step
-  // ahead of the consumer, so it moves to the next tile before step 15).
-  float px[kIn];
-  [[maybe_unused]] float xn[kIn];
-  int64_t p_r0 = (int64_t)blockIdx.x * kSplitRows;
-  auto rows_from = [&](int64_t r0) {
-    const int64_t left = m - r0;
-    return left <= 0 ? 0 : left < kSplitRows ? (int)left : kSplitRows;
-  };
-  int p_rows = rows_from(p_r0);
-  // (addresses: uniform tile base + 32-bit lane offset -- 64-bit per-lane pointers cost
-  // registers the matrix loop does not have)
-  auto load_x = [&](float (&dst)[kIn], int64_t r0) {
-    const int rows = rows_from(r0);
-    const float *base = x + r0 * d_in;
-#pragma unroll
-    for (int i = 0; i < kIn; ++i) dst[i] = (prow < rows && i < d_in) ? base[(unsigned)(prow * d_in + i)] : 0.0f;
-  };
-  // (wide observations: the next tile's row is loaded at the tile switch instead of a tile ahead)
-  constexpr bool kPrefetchX = DIN > 0;  // (compiled widths: a tile ahead; run-time widths: at the tile switch)
-  load_x(px, p_r0);
-  if constexpr (kPrefetchX) load_x(xn, p_r0 + stride * kSplitRows);
-
-  // Operand scaling.  fp16 planes hold 11 + 11 significand bits but only 5 exponent bits,
-  // so each activation ROW is multiplied by a power of two that puts a bound of the row,
-  //   |h1[row][k]| <= max|b1| + sum_i |x[row][i]| * max_k |w1[k][i]|,
-  // at 2^14 (exact; undone on the accumulators, where lane = row), W2 likewise by one
-  // power of two per matrix (the pack kernel's).  Elements far below their row's bound end
-  // in fp16's subnormals: an absolute error below 2^-25 of the bound, i.e. below fp32's own
-  // rounding of the dot product.  The factors of the producer's tile go to LDS for the
-  // epilogue ([tile parity][row]); the producer runs a tile ahead, so two copies.
-  float b1max = 0.0f, w1max[kIn];
-  {
-    float *red = reinterpret_cast<float *>(smem);  // (before any stage is used)
-    float v = __builtin_fabsf(b1[tid]);
-    red[tid] = v;
-    __syncthreads();
-    for (int i = 0; i < kHidden; ++i) b1max = __builtin_fmaxf(b1max, red[i]);
-    b1max = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b1max)));  // (uniform: scalar registers)
-#pragma unroll
-    for (int c = 0; c < kIn; ++c) {
-      __syncthreads();
-      red[tid] = (DIN > 0 || c < d_in) ? __builtin_fabsf(w1[tid * d_in + c]) : 0.0f;
-      __syncthreads();
-      float mx = 0.0f;
-      for (int i = 0; i < kHidden; ++i) mx = __builtin_fmaxf(mx, red[i]);
-      w1max[c] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
-    }
-    __syncthreads();
-  }
-  float p_scale = 1.0f;   // of row prow of the producer's tile
-  int p_parity = 0, c_parity = 0;
-  const unsigned scale_lds = lds0 + 2 * kF16StageBytes + kF16ScratchTail;
-  auto set_row_scale = [&]() {
-    float bound = b1max;
-#pragma unroll
-    for (int i = 0; i < kIn; ++i) bound = __builtin_fmaf(__builtin_fabsf(px[i]), w1max[i], bound);
-    const int e = f16_bound_exponent(bound);  // bound < 2^e
-    p_scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
-    if (tid < kSplitRows) lds_write_b32(scale_lds + (p_parity * kSplitRows + prow) * 4, __builtin_amdgcn_ldexpf(inv_w2_scale, e - kF16Top));
-  };
-
-  // Chunk `ks` of the producer's tile -> stage `stage`.
-  [[maybe_unused]] int diag_b_loads = 0;  // (tuning builds, bit 2^20: only the first two chunks are loaded -- no L2 latency in the steps)
-  auto request_b = [&](int ks, int stage) {
-    if constexpr ((kSplitDiagSkip & (1 << 20)) != 0) {
-      if (diag_b_loads >= 2) return;
-      ++diag_b_loads;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int block = wave * 4 + u;  // 16 one-KiB blocks per step, four per wave
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, smem + stage * kF16StageBytes + kF16ABytes + block * 1024,
-                                               16, lane * 16, (ks * 16 + block) * 1024, 0, 0);
-    }
-  };
-  // planes[p]: this thread's fragment (row prow, eight k) of plane p.
-  auto produce_a = [&](int ks, u32x4 (&planes)[2]) {
-    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);
-    float h[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = b1[kb + e];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i)
-        if (DIN > 0 || i < d_in) v = __builtin_fmaf(px[i], w1[(kb + e) * d_in + i], v);
-      h[e] = relu1(v);
-    }
-    if constexpr (SAVE == 1 && !(kSplitDiagSkip & 32)) {
-      if (save_h1 != nullptr && prow < p_rows) {  // (h1 is optional: the bf16-plane backward recomputes it)
-        f32x4 *dst = reinterpret_cast<f32x4 *>(save_h1 + p_r0 * kHidden + kb + (unsigned)(prow * kHidden));
-        dst[0] = f32x4{h[0], h[1], h[2], h[3]};
-        dst[1] = f32x4{h[4], h[5], h[6], h[7]};
-      }
-    }
-    if constexpr ((kSplitDiagSkip & (1 << 21)) != 0) {  // tuning builds: no split arithmetic
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        planes[0][e >> 1] = __float_as_uint(h[e]);
-        planes[1][e >> 1] = __float_as_uint(h[e + 1]);
-      }
-      return;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {  // scaled by this row's power of two (exact), then hi + lo in fp16
-      uint32_t hi, lo;
-      f16_pair(h[e] * p_scale, h[e + 1] * p_scale, hi, lo);
-      planes[0][e >> 1] = hi;
-      planes[1][e >> 1] = lo;
-    }
-  };
-  auto write_a = [&](int stage, const u32x4 (&planes)[2]) {
-    const unsigned addr = a_write + stage * kF16StageBytes;
-    lds_write_b128<0>(addr, planes[0]);
-    lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
-  };
-  auto step_barrier = [&]() {
-    // vmcnt(0): the direct-to-LDS weight loads have landed (and, in-order, every
-    // older store -- this step's h1 stores were issued a matrix group or more ago).
-    // NOT vmcnt(2) "everything but the step's two stores": a register spill
-    // anywhere behind those stores is a vector-memory instruction the count does
-    // not know about, and it measured no faster.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-
-  // Epilogue constants, per register rather than per lane in the transposed
-  // accumulator layout: b2 and the rows of W3 (zero rows up to kOut) live in LDS and
-  // are fetched as 16-byte quads of four consecutive columns.
-  {
-    float *consts = reinterpret_cast<float *>(smem + kF16Fixed + kSplitRows * kOut * 4);
-    consts[tid] = b2[tid];
-#pragma unroll
-    for (int q = 0; q < kOut; ++q) consts[(1 + q) * kHidden + tid] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
-    // (visible to every wave behind the prologue's step barrier below)
-  }
-
-  f32x16 acc[2][4];
-  int64_t r0 = p_r0;  // consumer's tile
-
-  // One k-step: consume stage P (chunk s) while producing chunk s+1 -- of the next tile when
-  // s = 15 -- into the other stage.  The step barrier sits in FRONT of the step's last group of
-  // products (hi x hi, whose operands are in registers by then): behind it the chunk in the other
-  // stage is complete, so the fragments the next step opens with (A lo planes, B hi planes) are
-  // fetched into the registers the first two groups have released, and the W2 chunk after next is
-  // requested into the stage just read -- a step opens with eight products instead of an LDS round
-  // trip.  The B registers trade roles each step for that (hi planes in f.bh in even steps, in
-  // f.bm in odd ones).  KIND 0: first step of a tile (nothing fetched ahead: the epilogue of the
-  // previous tile lies in between and has the registers); KIND 2: last step (fetches nothing).
-  SplitFrags f;
-  auto open_reads = [&](auto parity_tag) {  // of the chunk in stage P: A lo planes -> am, B hi planes -> that step's first B set
-    constexpr int P = decltype(parity_tag)::value;
-    const unsigned ar = a_read + P * kF16StageBytes, br = b_read + P * kF16StageBytes;
-    u32x4(&BH)[4] = *(P == 0 ? &f.bh : &f.bm);
-    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
-    BH[0] = lds_read_b128<0>(br);
-    BH[1] = lds_read_b128<2 * 1024>(br);
-    BH[2] = lds_read_b128<4 * 1024>(br);
-    BH[3] = lds_read_b128<6 * 1024>(br);
-    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
-  };
-  auto do_step = [&](auto first_tag, auto parity_tag, auto kind_tag, int s) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    constexpr int P = decltype(parity_tag)::value;
-    constexpr int KIND = decltype(kind_tag)::value;
-    const int ks = (s + 1) & (kSplitSteps - 1);
-    const unsigned ar = a_read + P * kF16StageBytes, br = b_read + P * kF16StageBytes;
-    u32x4(&BH)[4] = *(P == 0 ? &f.bh : &f.bm);
-    u32x4(&BL)[4] = *(P == 0 ? &f.bm : &f.bh);
-    if constexpr (KIND == 0) {
-      request_b(1, 1);  // (late by one group: once per tile)
-      open_reads(parity_tag);
-    }
-    // am and BH are in (or on their way, KIND 0); the other two planes:
-    f.ah[0] = lds_read_b128<0>(ar);
-    f.ah[1] = lds_read_b128<512>(ar);
-    BL[0] = lds_read_b128<1024>(br);
-    BL[1] = lds_read_b128<3 * 1024>(br);
-    BL[2] = lds_read_b128<5 * 1024>(br);
-    BL[3] = lds_read_b128<7 * 1024>(br);
-    if constexpr (KIND == 0) wait_lds_all(f);
-    __builtin_amdgcn_sched_barrier(0);
-    f16_mma_t<FIRST>(f.am, BH, acc);   // lo x hi: at once
-    if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
-      p_r0 += stride * kSplitRows;
-      p_rows = rows_from(p_r0);
-      if constexpr (kPrefetchX) {
-#pragma unroll
-        for (int i = 0; i < kIn; ++i) px[i] = xn[i];
-        load_x(xn, p_r0 + stride * kSplitRows);
-      } else {
-        load_x(px, p_r0);
-      }
-      p_parity ^= 1;
-      set_row_scale();
-    }
-    // The next chunk's arithmetic is left to the scheduler to interleave with the
-    // first matrix group (VALU instructions issue beside the MFMAs for free).
-    u32x4 planes[2];
-    produce_a(ks, planes);
-    if constexpr (KIND != 0) wait_lds<0>(f.ah[0], f.ah[1], BL[0], BL[1], BL[2], BL[3]);
-    f16_mma_t<false>(f.ah, BL, acc);   // hi x lo: last use of BL
-    __builtin_amdgcn_sched_barrier(0);
-    write_a(P ^ 1, planes);
-    __builtin_amdgcn_sched_barrier(0);
-    step_barrier();
-    if constexpr (KIND != 2) {
-      request_b((s + 2) & (kSplitSteps - 1), P);  // (s = 14: chunk 0 of the next tile)
-      if constexpr (P == 0) open_reads(std::integral_constant<int, 1>{});
-      else open_reads(std::integral_constant<int, 0>{});
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f16_mma_t<false>(f.ah, BH, acc);   // hi x hi
-    __builtin_amdgcn_sched_barrier(0);
-    // landed before anything can copy or carry these registers (loop back-edge)
-    if constexpr (KIND != 2) wait_lds<0>(f.am[0], f.am[1], BL[0], BL[1], BL[2], BL[3]);
-  };
-  // Prologue: chunk 0 of the first tile.
-  using T = std::true_type;
-  using F = std::false_type;
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-
-  if ((int64_t)blockIdx.x < tiles) {
-    set_row_scale();
-    request_b(0, 0);
-    u32x4 planes[2];
-    produce_a(0, planes);
-    write_a(0, planes);
-    step_barrier();
-  }
-
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
-    r0 = tile * kSplitRows;
-    const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
-    using K0 = std::integral_constant<int, 0>;
-    using K1 = std::integral_constant<int, 1>;
-    using K2 = std::integral_constant<int, 2>;
-    do_step(T{}, P0{}, K0{}, 0);
-    do_step(F{}, P1{}, K1{}, 1);
-#pragma unroll 1
-    for (int s = 2; s < kSplitSteps - 2; s += 2) {
-      do_step(F{}, P0{}, K1{}, s);
-      do_step(F{}, P1{}, K1{}, s + 1);
-    }
-    do_step(F{}, P0{}, K1{}, kSplitSteps - 2);
-    do_step(F{}, P1{}, K2{}, kSplitSteps - 1);
-
-    // Epilogue on the TRANSPOSED accumulators (split_mma_t): this lane holds sample
-    // row 64 wr + 32 mt + l32 and, of column block 128 wc + 32 nt, the sixteen columns
-    // 8 g + 4 hh + e (register r = 4 g + e).  So
-    //   * h2 leaves as 16-byte stores (four consecutive columns per lane, the two
-    //     half-waves side by side: 32 contiguous bytes per row and instruction, a full
-    //     128-byte line per row over g = 0..3) -- 32 stores per wave and tile instead
-    //     of 128 dword stores, the largest item of the old epilogue;
-    //   * the ReLU gate bits of a row are built in that row's own lane (add + funnel
-    //     shift per element) instead of 128 ballots and 256 v_writelane;
-    //   * the head is a dot product down the lane's registers against W3 quads from
-    //     LDS plus ONE half-wave exchange, instead of a five-level DPP reduction per
-    //     eight rows.
-    // b2 / W3 come from the constants block in LDS (hand-issued reads, explicit waits).
-    // (tuning builds, bit 4096: every tile's h2 lands on the first tile's lines -- the stores are issued but stay in L2)
-        const __amdgpu_buffer_rsrc_t h2rsrc =
-        buffer_rsrc(SAVE == 1 ? save_h2 + ((kSplitDiagSkip & 4096) ? (r0 & 0x1ffff) : r0) * kHidden : nullptr, rows * kHidden * 4);
-    const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
-    const unsigned outp = lds_offset(smem) + kF16Fixed;
-    const unsigned constp = outp + kSplitRows * kOut * 4 + (128 * wc + 4 * hh) * 4;
-    // this lane's two rows: the factor that undoes the operand scaling (row's and W2's powers of two)
-    const unsigned scale_at = lds_offset(smem) + 2 * kF16StageBytes + kF16ScratchTail + (c_parity * kSplitRows + 64 * wr + l32) * 4;
-    const float inv_scale[2] = {lds_read_b32(scale_at), lds_read_b32(scale_at + 32 * 4)};
-    c_parity ^= 1;
-    constexpr int kChains = kOut <= 2 ? 4 : 2;  // (registers: three outputs x four chains spilled)
-    float part[2][kOut][kChains];
-    [[maybe_unused]] uint32_t gate_words[2][4];
-    // h2 goes to HBM through a per-wave transpose in LDS (stage 1 is dead between the
-    // barrier of step 15 and the barrier of this epilogue, for every wave): written as
-    // the accumulators hold it (lane = row), read back eight lanes per row, so a store
-    // instruction is eight full 128-byte lines instead of thirty-two 32-byte pieces
-    // (scattered 32-byte pieces measured 712 us per 2^20 rows at best, 1 185 us with
-    // the streaming policy, against 588 us with the stores compiled out).
-    constexpr int kH2Pitch = 128 + 16;
-    static_assert(4 * 64 * kH2Pitch <= kF16StageBytes + kF16ScratchTail, "transpose scratch = stage 1 + the tail");
-    [[maybe_unused]] const unsigned t_base = lds_offset(smem) + kF16StageBytes + wave * (64 * kH2Pitch);
-    [[maybe_unused]] const unsigned t_write = t_base + l32 * kH2Pitch + 16 * hh;
-    [[maybe_unused]] const unsigned t_read = t_base + (lane_id() >> 3) * kH2Pitch + (lane_id() & 7) * 16;
-    [[maybe_unused]] const int h2_voff = ((64 * wr + (lane_id() >> 3)) * kHidden + 128 * wc + 4 * (lane_id() & 7)) * 4;
-    // The column blocks in groups of kGroup quads (g = eight columns): b2 and the kOut
-    // rows of W3 for the group from LDS, then bias + ReLU, the h2 quads into the transpose
-    // scratch, gate nibbles and head products.  (Wide heads take two quads at a time:
-    // sixteen W3 quads plus the block read back would not fit.)
-    // Software-pipelined over the groups: the LDS is busy with the CU's other workgroup's
-    // operand reads, so every lgkmcnt(0) in here cost 500+ cycles (twelve of them per tile
-    // measured 13 500 cycles for ~800 VALU instructions).  The next group's b2 quads are
-    // requested as soon as bias + ReLU has consumed this group's, its W3 quads as soon as
-    // the head products have, and the transposed block is waited for by COUNT (in-order
-    // LDS returns; no scalar load is in flight here), behind the gate and head arithmetic.
-    constexpr int kGroup = kOut >= 4 ? 1 : kOut >= 2 ? 2 : 4;  // (registers: more W3 quads in flight beside the block spilled)
-    constexpr int kStages = 4 * (4 / kGroup);  // (nt, g0) pairs
-    constexpr bool kStore = SAVE == 1 && !(kSplitDiagSkip & 8);
-    u32x4 bq[kGroup], wq[kOut][kGroup];
-    auto request_b2 = [&](int stage) {
-      const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
-#pragma unroll
-      for (int gi = 0; gi < kGroup; ++gi) bq[gi] = lds_read_b128<0>(constp + (32 * nt + 8 * (g0 + gi)) * 4);
-    };
-    auto request_w3 = [&](int stage) {
-      const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
-#pragma unroll
-      for (int gi = 0; gi < kGroup; ++gi) {
-        const unsigned a = constp + (32 * nt + 8 * (g0 + gi)) * 4;
-#pragma unroll
-        for (int q = 0; q < kOut; ++q)
-          wq[q][gi] = q == 0   ? lds_read_b128<1 * kHidden * 4>(a)
-                      : q == 1 ? lds_read_b128<2 * kHidden * 4>(a)
-                      : q == 2 ? lds_read_b128<3 * kHidden * 4>(a)
-                      : q == 3 ? lds_read_b128<4 * kHidden * 4>(a)
-                      : q == 4 ? lds_read_b128<5 * kHidden * 4>(a)
-                      : q == 5 ? lds_read_b128<6 * kHidden * 4>(a)
-                      : q == 6 ? lds_read_b128<7 * kHidden * 4>(a)
-                               : lds_read_b128<8 * kHidden * 4>(a);
-      }
-    };
-    request_b2(0);
-    request_w3(0);
-    [[maybe_unused]] u32x4 t_rows[8];
-    auto read_block = [&]() {  // the block back, eight lanes per row (in order behind the writes: same wave)
-      t_rows[0] = lds_read_b128<0 * 8 * kH2Pitch>(t_read);
-      t_rows[1] = lds_read_b128<1 * 8 * kH2Pitch>(t_read);
-      t_rows[2] = lds_read_b128<2 * 8 * kH2Pitch>(t_read);
-      t_rows[3] = lds_read_b128<3 * 8 * kH2Pitch>(t_read);
-      t_rows[4] = lds_read_b128<4 * 8 * kH2Pitch>(t_read);
-      t_rows[5] = lds_read_b128<5 * 8 * kH2Pitch>(t_read);
-      t_rows[6] = lds_read_b128<6 * 8 * kH2Pitch>(t_read);
-      t_rows[7] = lds_read_b128<7 * 8 * kH2Pitch>(t_read);
-    };
-#pragma unroll
-    for (int stage = 0; stage < kStages; ++stage) {
-      const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
-      const bool last_of_block = g0 + kGroup == 4;
-      // this group's quads (requested a stage ago; everything older has landed too)
-#pragma unroll
-      for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(bq[gi]);
-#pragma unroll
-      for (int q = 0; q < kOut; ++q)
-#pragma unroll
-        for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(wq[q][gi]);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int gi = 0; gi < kGroup; ++gi) {
-          const int g = g0 + gi;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)  // (not __builtin_bit_cast on a vector-element lvalue: it reads element 0)
-            acc[mt][nt][4 * g + e] = relu1(__builtin_fmaf(acc[mt][nt][4 * g + e], inv_scale[mt], __uint_as_float(bq[gi][e])));
-        }
-      if (stage + 1 < kStages) request_b2(stage + 1);
-      if constexpr (kStore) {
-        // h2 block [64 rows][32 columns] of this wave -> its transpose scratch (row pitch
-        // 144 B: the eight lanes of a b128 phase hit eight distinct 16-byte slots, writing
-        // as well as reading)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int gi = 0; gi < kGroup; ++gi) {
-            const int g = g0 + gi;
-            const f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
-            const u32x4 u = __builtin_bit_cast(u32x4, v);
-            if (mt == 0) {
-              g == 0 ? lds_write_b128<0>(t_write, u) : g == 1 ? lds_write_b128<32>(t_write, u)
-              : g == 2 ? lds_write_b128<64>(t_write, u) : lds_write_b128<96>(t_write, u);
-            } else {
-              g == 0 ? lds_write_b128<32 * kH2Pitch>(t_write, u) : g == 1 ? lds_write_b128<32 * kH2Pitch + 32>(t_write, u)
-              : g == 2 ? lds_write_b128<32 * kH2Pitch + 64>(t_write, u) : lds_write_b128<32 * kH2Pitch + 96>(t_write, u);
-            }
-          }
-        if (last_of_block) read_block();
-      }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int gi = 0; gi < kGroup; ++gi) {
-          const int g = g0 + gi;
-          if constexpr (SAVE != 0 && !(kSplitDiagSkip & 65536)) {  // (tuning builds, bit 65536: no gate bits)
-            // gate of h2, bit c of word [row][4 wc + nt] <=> column 32 (4 wc + nt) + c > 0.
-            // h2 >= +0 here, so "h2 > 0" is bit 31 of (bits(h2) + 0x7fffffff); four of
-            // them are funnel-shifted into a nibble (element 0 lowest), the nibble goes
-            // to bit 8 g + 4 hh.  The other half-wave holds the interleaved nibbles.
-            uint32_t nib = 0;
-#pragma unroll
-            for (int e = 3; e >= 0; --e)
-              nib = __builtin_amdgcn_alignbit(nib, __float_as_uint(acc[mt][nt][4 * g + e]) + 0x7fffffffu, 31);
-            gate_words[mt][nt] = (g == 0 ? 0u : gate_words[mt][nt]) | (nib << (8 * g + 4 * hh));
-          }
-          // head partials of this row: four (two for wide heads) independent chains per
-          // output, 16 (32) terms each over the tile, so the sum is not one 64-term
-          // chain and the fmas do not wait on each other
-#pragma unroll
-          for (int q = 0; q < kOut; ++q) {
-            float p = (nt == 0 && g < kChains) ? 0.0f : part[mt][q][g % kChains];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) p = __builtin_fmaf(acc[mt][nt][4 * g + e], __uint_as_float(wq[q][gi][e]), p);
-            part[mt][q][g % kChains] = p;
-          }
-        }
-      }
-      if (stage + 1 < kStages) request_w3(stage + 1);
-      if constexpr (kStore) {
-        if (last_of_block) {
-          // the block's eight reads are older than the next stage's W3 quads just requested
-          // (its b2 quads went out ahead of the block): wait for "all but those" (in-order
-          // returns; tools/check_inflight_regs.py caught the first version counting both)
-          constexpr int kNewer = kGroup * kOut;
-          if (stage + 1 < kStages) {
-            wait_lds<kNewer>(t_rows[0], t_rows[1], t_rows[2], t_rows[3]);
-            wait_lds<kNewer>(t_rows[4], t_rows[5], t_rows[6], t_rows[7]);
-          } else {
-            wait_lds<0>(t_rows[0], t_rows[1], t_rows[2], t_rows[3]);
-            wait_lds<0>(t_rows[4], t_rows[5], t_rows[6], t_rows[7]);
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {  // rows 8 i + (lane >> 3), columns 32 nt + 4 (lane & 7) .. + 3
-            if constexpr ((kSplitDiagSkip & 32768) != 0) {  // tuning builds: transposes without the global stores
-              asm volatile("" ::"v"(t_rows[i]));
-            } else {
-              __builtin_amdgcn_raw_buffer_store_b128(t_rows[i], h2rsrc, h2_voff + (8 * i * kHidden + 32 * nt) * 4, 0, RL8_H2_STORE_AUX);
-            }
-          }
-          if constexpr ((kSplitDiagSkip & 16384) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tuning builds: expose the store latency
-        }
-      }
-    }
-    // Half-wave exchange: lane (l32, hh) ends with the total of row 64 wr + 32 hh + l32
-    // over this wave's 128 columns (v_permlane32_swap: [A_lo, B_lo] and [A_hi, B_hi]).
-    float total[kOut];
-#pragma unroll
-    for (int q = 0; q < kOut; ++q) {
-      float p0 = part[0][q][0] + part[0][q][1], p1 = part[1][q][0] + part[1][q][1];
-      if constexpr (kChains == 4) {
-        p0 += part[0][q][2] + part[0][q][3];
-        p1 += part[1][q][2] + part[1][q][3];
-      }
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-      total[q] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    const int my_row = 64 * wr + lane_id();
-    if constexpr (SAVE != 0 && !(kSplitDiagSkip & 65536)) {
-      if (save_gate2 != nullptr) {
-        // full words = own nibbles | the other half-wave's; lane (l32, hh) keeps row
-        // 64 wr + 32 hh + l32's four words and stores them as one 16-byte piece
-        u32x4 words;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const auto s0 = __builtin_amdgcn_permlane32_swap(gate_words[0][nt], gate_words[0][nt], false, false);
-          const auto s1 = __builtin_amdgcn_permlane32_swap(gate_words[1][nt], gate_words[1][nt], false, false);
-          const uint32_t w0 = s0[0] | s0[1], w1 = s1[0] | s1[1];
-          words[nt] = hh ? w1 : w0;
-        }
-        if (my_row < rows) {
-          uint32_t *dst = save_gate2 + r0 * 8;  // uniform base, 32-bit lane offset
-          *reinterpret_cast<u32x4 *>(dst + (unsigned)(my_row * 8 + 4 * wc)) = words;
-        }
-      }
-    }
-    // The two column halves of the workgroup meet in LDS: the upper half (wc = 1)
-    // parks its totals, the lower half adds its own and stores the outputs.
-    if (wc == 1) {
-#pragma unroll
-      for (int q = 0; q < kOut; ++q)
-        if (q < n_out) lds_write_b32(outp + (my_row * kOut + q) * 4, total[q]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (wc == 0 && my_row < rows) {
-#pragma unroll
-      for (int q = 0; q < kOut; ++q)
-        if (q < n_out)
-          (out + r0 * n_out)[(unsigned)(my_row * n_out + q)] = total[q] + lds_read_b32(outp + (my_row * kOut + q) * 4) + b3[q];
-    }
-    // (the next tile's head partials are parked a full tile later, behind sixteen
-    // barriers: no extra barrier needed here)
-  }
-}
-
-template <int DIN, int NOUT, int SAVE>
-static int launch_forward_f16(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
-                                const float *b1, const void *w2s, const float *b2, const float *w3,
-                                const float *b3, int n_out, float *out, float *h1, float *h2, uint32_t *gate) {
-  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_forward_f16_kernel<DIN, NOUT, SAVE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
-  mlp_tower_forward_f16_kernel<DIN, NOUT, SAVE><<<grid, kBlock, f16_forward_lds_bytes(kOut), s>>>(
-      x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-  return launch_status();
-}
-
-template <int DIN, int NOUT>
-static int launch_forward_f16_save(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
-                                     const float *b1, const void *w2s, const float *b2, const float *w3,
-                                     const float *b3, int n_out, float *out, float *h1, float *h2, uint32_t *gate) {
-  return h2     ? launch_forward_f16<DIN, NOUT, 1>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate)
-         : gate ? launch_forward_f16<DIN, NOUT, 2>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate)
-                : launch_forward_f16<DIN, NOUT, 0>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-}
-
-template <int DIN>
-static int dispatch_forward_f16_nout(int n_out, int grid, hipStream_t s, const float *x, int64_t m, int d_in,
-                                       const float *w1, const float *b1, const void *w2s, const float *b2,
-                                       const float *w3, const float *b3, float *out, float *h1, float *h2,
-                                       uint32_t *gate) {
-  switch (n_out) {
-    case 1: return launch_forward_f16_save<DIN, 1>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-    case 2: return launch_forward_f16_save<DIN, 2>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-    case 3: return launch_forward_f16_save<DIN, 3>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-    default: return RL8_ESIZE;
   }
 }
 
@@ -1065,15 +500,16 @@ RL8_API int64_t rl8_mlp_f16_packed_bytes(void) { return kF16PackedBytes + 16; }
 RL8_API int rl8_mlp_pack_w2_f16(const float *w2, int transposed, void *packed, void *stream) {
   if (!w2 || !packed) return RL8_ENULL;
   if (((uintptr_t)packed & 15) != 0) return RL8_EALIGN;
+  // (forward operand: the 16x16x32 fragment order of mlp_rows_kernels.hip; transposed, for the data gradient: 32x32x16)
   mlp_pack_w2_f16_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(w2, transposed, reinterpret_cast<uint32_t *>(packed), nullptr, 0,
-                                                              env_int("RL8_MLP_PACK_LAYOUT"));  // (experiment switch)
+                                                              transposed ? 0 : 1);
   return launch_status();
 }
 
 namespace rl8 {
-int mlp_rows_forward_dispatch(int mode, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1, const float *b1,
+int mlp_rows_forward_dispatch(hipStream_t s, const float *x, int64_t m, int d_in, const float *w1, const float *b1,
                               const void *w2s, const float *b2, const float *w3, const float *b3, int n_out, float *out,
-                              float *h2, uint32_t *gate);
+                              float *h1, float *h2, uint32_t *gate);
 }
 
 RL8_API int rl8_mlp_forward_f16_supports(int d_in, int n_out) {
@@ -1089,24 +525,8 @@ RL8_API int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, c
   if (save_h1 && !save_h2) return RL8_ENULL;  // (the gate bits alone are allowed: SAVE mode 2)
   if (((uintptr_t)w2_f16 & 15) != 0 || !aligned16(save_h1) || !aligned16(save_h2) || !aligned16(save_gate2))
     return RL8_EALIGN;
-  hipStream_t s = (hipStream_t)stream;
-  if (!save_h1) {  // rows-per-wave generation (mlp_rows_kernels.hip); experiment switch read per call
-    const int mode = env_int("RL8_MLP_FWD_ROWS");
-    if (mode > 0) {
-      const int st = mlp_rows_forward_dispatch(mode, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, n_out, out, save_h2, save_gate2);
-      if (st != -1) return st;
-    }
-  }
-  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
-  static const int cap = env_int("RL8_MLP_GRID_CAP");
-  const int max_grid = cap > 0 ? cap : 2 * kCUs;
-  const int grid = (int)(tiles < max_grid ? tiles : max_grid);
-  switch (d_in) {
-    case 1: return dispatch_forward_f16_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, out, save_h1, save_h2, save_gate2);
-    case 2: return dispatch_forward_f16_nout<2>(n_out, grid, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, out, save_h1, save_h2, save_gate2);
-    case 3: return dispatch_forward_f16_nout<3>(n_out, grid, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, out, save_h1, save_h2, save_gate2);
-    default: return dispatch_forward_f16_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, out, save_h1, save_h2, save_gate2);
-  }
+  return mlp_rows_forward_dispatch((hipStream_t)stream, x, m, d_in, w1, b1, w2_f16, b2, w3, b3, n_out, out, save_h1, save_h2,
+                                   save_gate2);
 }
 
 RL8_API int rl8_mlp_backward_f16_supports(int d_in, int n_out) { return rl8_mlp_forward_f16_supports(d_in, n_out); }

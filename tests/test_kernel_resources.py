@@ -218,7 +218,7 @@ def test_compiled_lstm_split_kernels_resources(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_compiled_f16_kernels_resources(tmp_path):
-    """The fp16 two-plane forward and data-gradient kernels (mlp_f16_kernels.hip): no scratch,
+    """The fp16 two-plane data-gradient kernels (mlp_f16_kernels.hip): no scratch,
     two workgroups per CU, fp16 MFMAs only, no packed fp32 arithmetic and no hand-issued
     load's destination touched before its wait."""
     csrc = os.path.join(ROOT, "rl8_amd", "csrc")
@@ -238,12 +238,47 @@ def test_compiled_f16_kernels_resources(tmp_path):
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
         assert scratch == 0, (name, scratch)
-        if "mlp_tower_forward_f16_kernel" in name or "mlp_tower_backward_f16_kernel" in name:
+        if "mlp_tower_backward_f16_kernel" in name:
             assert vgprs <= 256 and lds <= 80 * 1024, (name, vgprs, lds)
             checked += 1
-    # d_in in {1, 2, 3, 5} x n_out in {1, 2, 3} x {inference, training with h2, training with gate bits only, data gradient}
-    # + the data gradient's gate mode (n_out 1, 2)
-    assert checked == 36 + 12 + 8
-    assert_no_inflight_register_access(text, "mlp_tower_(forward|backward)_f16_kernel", min_hand_loads=56 * 40)
+    # d_in in {1, 2, 3, 5} x n_out in {1, 2, 3} data-gradient kernels + their gate mode (n_out 1, 2)
+    assert checked == 12 + 8
+    assert_no_inflight_register_access(text, "mlp_tower_backward_f16_kernel", min_hand_loads=20 * 40)
+    for name, body in inflight.kernels_of(text):
+        assert inflight.packed_war(body) == [], name
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_compiled_rows_forward_kernels_resources(tmp_path):
+    """The rows-per-wave forward (mlp_rows_kernels.hip, round 3): every compiled variant (d_in in {1, 2, 3, 5} x n_out
+    in {1, 2, 3} x {inference, training with h2, training with the gate bits alone}) free of scratch (its fragment and
+    record reads are hand-issued with counted waits: a spill between a read and its wait would save stale data), two
+    workgroups per CU, 16x16x32 fp16 MFMAs only, no packed fp32 arithmetic beside them, no hand-issued load's
+    destination touched before a covering wait, no scalar load in flight at a counted wait, and every mid-step
+    barrier behind a counted vmcnt."""
+    csrc = os.path.join(ROOT, "rl8_amd", "csrc")
+    asm = tmp_path / "mlp_rows.s"
+    subprocess.run(
+        [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/include", f"-I{csrc}",
+         "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", str(asm), os.path.join(csrc, "mlp_rows_kernels.hip")],
+        check=True, capture_output=True, timeout=900,
+    )
+    text = asm.read_text()
+    assert not re.search(r"\bv_pk_(fma|add|mul)_f32\b", text)
+    assert "v_mfma_f32_16x16x32_f16" in text and "v_mfma_f32_32x32x16" not in text
+    kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
+    checked = 0
+    for name, body in kernels:
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        assert "mlp_rows_forward_kernel" in name
+        assert scratch == 0 and vgprs <= 256, (name, scratch, vgprs)
+        checked += 1
+    assert checked == 36
+    # ring discipline: the barrier inside a half-step waits for "all but the pieces of one younger chunk" (four-chunk
+    # rings: inference, gate bits only) or for everything (three-chunk rings: h2 stored)
+    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)\n\ts_barrier", text)
+    assert len(waits) >= 36 * 12 and set(waits) <= {"0", "4", "8"} and "4" in waits
+    assert_no_inflight_register_access(text, "mlp_rows_forward_kernel", min_hand_loads=36 * 100)
     for name, body in inflight.kernels_of(text):
         assert inflight.packed_war(body) == [], name

@@ -107,9 +107,14 @@ def test_f16_planes_reconstruct_the_scaled_weights_to_22_bits():
         assert scale * inv == 1.0 and 2.0**13 <= top < 2.0**14   # a power of two placing max |w| below 2^14
         planes = packed[:-16].view(torch.float16).view(16, 8, 2, 64, 8).double().sum(2)  # [step][col tile][lane][e]
         lane = torch.arange(64, device=DEV)
-        col = (32 * torch.arange(8, device=DEV)[None, :, None, None] + (lane & 31)[None, None, :, None]).expand(16, 8, 64, 8)
-        k = (16 * torch.arange(16, device=DEV)[:, None, None, None] + 8 * (lane >> 5)[None, None, :, None]
-             + torch.arange(8, device=DEV)[None, None, None, :]).expand(16, 8, 64, 8)
+        step, tile, e = torch.arange(16, device=DEV), torch.arange(8, device=DEV), torch.arange(8, device=DEV)
+        if transposed:  # the data-gradient kernel's operand: 32x32x16 fragments, unit [k step][column tile][plane][lane]
+            col = (32 * tile[None, :, None, None] + (lane & 31)[None, None, :, None]).expand(16, 8, 64, 8)
+            k = (16 * step[:, None, None, None] + 8 * (lane >> 5)[None, None, :, None] + e[None, None, None, :]).expand(16, 8, 64, 8)
+        else:           # the forward kernel's: 16x16x32 fragments, unit [half-step = 2 k-block + column half][local tile][plane][lane]
+            col = (16 * (8 * (step & 1)[:, None, None, None] + tile[None, :, None, None])
+                   + (lane & 15)[None, None, :, None]).expand(16, 8, 64, 8)
+            k = (32 * (step >> 1)[:, None, None, None] + 8 * (lane >> 4)[None, None, :, None] + e[None, None, None, :]).expand(16, 8, 64, 8)
         want = (w[k, col] if transposed else w[col, k]).double() * scale
         # hi = fp16(v), lo = fp16(v - hi): 22 significand bits, or the fp16 subnormal quantum
         assert bool(((planes - want).abs() <= want.abs() * 2.0**-22 + 2.0**-25).all())

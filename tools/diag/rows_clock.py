@@ -1,4 +1,4 @@
-"""In-kernel clock and matrix-pipe occupancy of the rows-per-wave forward (diagnostic build with -DRL8_ROWS_STAMP:
+"""In-kernel clock and matrix-pipe occupancy of the rows-per-wave forward (mlp_rows_kernels.hip) (diagnostic build with -DRL8_ROWS_STAMP:
 `tools/diag_mlp.sh stamp`).  After >= 2 s of back-to-back launches on random data, each wave's
 delta s_memtime / delta s_memrealtime x 100 MHz is the clock the chip held inside the kernel
 (MI355X_MICROARCH.md, DVFS give-back item 6); MFMA issue cycles / wave cycles is how busy the SIMD's matrix pipe was.
@@ -26,18 +26,15 @@ b2 = torch.randn(256, device=dev, generator=g)
 w3 = torch.randn(2, 256, device=dev, generator=g) / 16
 b3 = torch.randn(2, device=dev, generator=g)
 w2h = hip.mlp_pack_w2_f16(w2)
-stamps = torch.zeros(512 * 4 * 4, dtype=torch.int64, device=dev)
+stamps = torch.zeros(512 * 4 * 4, dtype=torch.int64, device=dev)  # [workgroup][wave][cycles, real time, tiles, -]
 os.environ["RL8_ROWS_STAMP_PTR"] = str(stamps.data_ptr())
-CASES = [(1, {}, "rows1 inference", 0), (2, {}, "rows2 inference", 0),
-         (1, dict(save=True, save_gate=True, save_h2=False), "rows1 gate-only", 0),
-         (1, dict(save=True, save_h1=False, save_gate=True), "rows1 with h2", 0)]
-for mode in (1, 2):  # cut-down variants of the inference kernel (DIAG bits: 1 production, 2 epilogue, 4 matrix work, 8 LDS reads)
-    for diag, what in ((1, "no production"), (2, "no epilogue"), (3, "no production, no epilogue"), (4, "no matrix work"),
-                       (8, "LDS reads once per step"), (7, "nothing but LDS reads + ring"), (11, "matrix work only (reads once)"),
-                       (15, "ring + barriers only")):
-        CASES.append((mode, {}, f"rows{mode} {what}", diag))
+CASES = [(1, {}, "inference", 0), (1, dict(save=True, save_gate=True, save_h2=False), "gate bits only", 0),
+         (1, dict(save=True, save_h1=False, save_gate=True), "with h2", 0)]
+# cut-down variants of the inference kernel (DIAG bits: 1 production, 2 epilogue, 4 matrix work)
+for diag, what in ((1, "no production"), (2, "no epilogue"), (3, "no production, no epilogue"), (4, "no matrix work"),
+                   (7, "ring + fragment reads only")):
+    CASES.append((1, {}, what, diag))
 for mode, kw, label, diag in CASES:
-    os.environ["RL8_MLP_FWD_ROWS"] = str(mode)
     os.environ["RL8_ROWS_DIAG"] = str(diag)
     t_end = time.time() + 2.1
     while time.time() < t_end:
@@ -54,12 +51,10 @@ for mode, kw, label, diag in CASES:
     st = stamps.cpu().view(-1, 4)
     st = st[st[:, 1] > 0]
     clk = [float(c) / float(r) * 100 for c, r, _, _ in st.tolist()]
-    mt = mode
-    waves_per_simd = 2 if mode == 1 else 1
-    # per wave: tiles x 16 steps x 24 MT products x 32 cycles of pipe; the SIMD's pipe serves waves_per_simd such waves
+    # per wave: tiles x 16 half-steps x 8 column tiles x 2 row tiles x 3 products x 16 cycles of the SIMD's matrix
+    # pipe, which serves two such waves
     per_block = 1 if diag & 4 else 3
-    busy = [waves_per_simd * t * 16 * 8 * per_block * mt * 32 / float(c) for c, _, t, _ in st.tolist()]
+    busy = [2 * t * 16 * 8 * 2 * per_block * 16 / float(c) for c, _, t, _ in st.tolist()]
     cyc_tile = [float(c) / t for c, _, t, _ in st.tolist()]
     print(f"{label:44s} {us:7.1f} us  clock median {statistics.median(clk):6.0f} MHz (min {min(clk):.0f} max {max(clk):.0f})"
           f"  wave cycles per tile {statistics.median(cyc_tile):8.0f}  matrix pipe busy {statistics.median(busy):.3f}", flush=True)
-os.environ["RL8_MLP_FWD_ROWS"] = "0"

@@ -172,27 +172,7 @@ def split_wgrad_fused():  # weight-gradient kernel: re-forms dZ2 and h1, accumul
                                        _p(_ws), _p(_dw2), _p(_partials), hip._stream())
 
 
-os.environ["RL8_MLP_PACK_LAYOUT"] = "1"
-mlp_w2h16 = hip.mlp_pack_w2_f16(mlp_w2)  # 16x16x32 fragment order
-os.environ["RL8_MLP_PACK_LAYOUT"] = "0"
-
-
-def _rows(mode, **kw):  # the rows-per-wave forward (mlp_rows_kernels.hip) through the same ABI entry, switch read per call
-    def run():
-        os.environ["RL8_MLP_FWD_ROWS"] = str(mode)
-        hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h16 if mode == 16 else mlp_w2h, mlp_b2, mlp_w3, mlp_b3, **kw)
-        os.environ["RL8_MLP_FWD_ROWS"] = "0"
-    return run
-
-
 KERNELS = {
-    "mlp_rows16_forward": (_rows(16), MLP_FLOP / 1000),
-    "mlp_rows16_forward_gate_only": (_rows(16, save=True, save_gate=True, save_h2=False), MLP_FLOP / 1000),
-    "mlp_rows16_forward_save": (_rows(16, save=True, save_h1=False, save_gate=True), MLP_FLOP / 1000),
-    "mlp_rows1_forward": (_rows(1), MLP_FLOP / 1000),
-    "mlp_rows2_forward": (_rows(2), MLP_FLOP / 1000),
-    "mlp_rows1_forward_gate_only": (_rows(1, save=True, save_gate=True, save_h2=False), MLP_FLOP / 1000),
-    "mlp_rows1_forward_save": (_rows(1, save=True, save_h1=False, save_gate=True), MLP_FLOP / 1000),
     # bf16-plane kernels: "GB/s" column = fp32-equivalent TFLOP/s (algorithmic FLOP / 1000 as bytes)
     "mlp_tower_forward_split": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2s, mlp_b2, mlp_w3, mlp_b3), MLP_FLOP / 1000),
     "mlp_tower_forward_save_split": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2s, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False, save_gate=True), MLP_FLOP / 1000),
