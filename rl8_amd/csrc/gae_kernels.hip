@@ -161,27 +161,35 @@ __global__ void gae_scan_env_major_kernel(
         const float4 *gv = reinterpret_cast<const float4 *>(values + base);
         float4 *lr = reinterpret_cast<float4 *>(tile_r);
         float4 *lv = reinterpret_cast<float4 *>(tile_v);
-        for (int i0 = tid; i0 < nvec; i0 += nthreads * kStageUnroll) {
+        // kStageUnroll loads in flight per lane.  The guarded form of this loop (`if (i < nvec)` around each load
+        // into r4[u] / v4[u]) left the two arrays in SCRATCH (80 bytes per thread: round 2's "WRITE_SIZE 1.44x the
+        // bytes it stores, cause not found" -- rocprof counted the spill traffic); full groups are therefore
+        // unguarded, the last partial group goes one element at a time.
+        int i0 = tid;
+        for (; i0 + (kStageUnroll - 1) * nthreads < nvec; i0 += nthreads * kStageUnroll) {
           float4 r4[kStageUnroll], v4[kStageUnroll];
 #pragma unroll
           for (int u = 0; u < kStageUnroll; ++u) {
-            const int i = i0 + u * nthreads;
-            if (i < nvec) {
-              r4[u] = gr[i];
-              v4[u] = gv[i];
-            }
+            r4[u] = gr[i0 + u * nthreads];
+            v4[u] = gv[i0 + u * nthreads];
           }
 #pragma unroll
           for (int u = 0; u < kStageUnroll; ++u) {
             const int i = i0 + u * nthreads;
-            if (i < nvec) {
-              r4[u].x = r4[u].x / denom; r4[u].y = r4[u].y / denom;
-              r4[u].z = r4[u].z / denom; r4[u].w = r4[u].w / denom;
-              lr[i] = r4[u];
-              lv[i] = v4[u];
-              if (write_back) reinterpret_cast<float4 *>(rewards + base)[i] = r4[u];
-            }
+            r4[u].x = r4[u].x / denom; r4[u].y = r4[u].y / denom;
+            r4[u].z = r4[u].z / denom; r4[u].w = r4[u].w / denom;
+            lr[i] = r4[u];
+            lv[i] = v4[u];
+            if (write_back) reinterpret_cast<float4 *>(rewards + base)[i] = r4[u];
           }
+        }
+        for (int i = i0; i < nvec; i += nthreads) {
+          float4 r = gr[i];
+          const float4 v = gv[i];
+          r.x = r.x / denom; r.y = r.y / denom; r.z = r.z / denom; r.w = r.w / denom;
+          lr[i] = r;
+          lv[i] = v;
+          if (write_back) reinterpret_cast<float4 *>(rewards + base)[i] = r;
         }
         for (int i = (nvec << 2) + tid; i < count; i += nthreads) {  // < 4 leftovers
           const float r = rewards[base + i] / denom;

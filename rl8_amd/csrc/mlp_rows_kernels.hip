@@ -633,6 +633,408 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
 #endif
 }
 
+// ---- data gradient of rank-one heads (gate mode) in the same structure ------------------------------------------
+// dZ2[s][k] = G[s][k] d[s] w3e[k] (one output, or two outputs with exactly opposite gradients), so
+//   dH1[s][i] = d[s] sum_k G[s][k] (w3e[k] W2[k][i]):
+// the A operand is the ReLU gate of h2 itself -- ONE fp16 plane of zeros and ones made from the forward's gate BITS
+// without any arithmetic -- and B the two planes of w3e[k] W2[k][i] (rl8_mlp_pack_w2_f16_gate): two products per
+// fragment pair.  dZ1 = dH1 * (h1 > 0) is folded into db1 / dW1 in the epilogue, the gate of h1 recomputed from the
+// observations (the forward's own fma chain).
+//
+// What differs from the forward kernel above:
+//   * the product is NOT transposed (first MFMA operand = the gate fragment): a lane holds, for column
+//     16 ct + (lane & 15) and row tile rt, the four rows 16 rt + 4 (lane >> 4) + r -- the column sums over rows that
+//     db1 / dW1 are start as in-lane sums over registers;
+//   * B arrives in rl8_mlp_pack_w2_f16's 32x32x16 unit order (the pack is shared with the previous kernel): a
+//     16x16x32 fragment's units exist there one for one, at other addresses -- a chunk is the two 8-KiB runs of k
+//     steps 2 S and 2 S + 1 over column tiles 4 C .. 4 C + 3, read with per-lane bases;
+//   * the wave's gate bits (32 rows x 32 B = 1 KiB) come by ONE direct-to-LDS load per tile into a per-wave block,
+//     requested behind the last fragment production of the tile before (counted in the barriers' vmcnt);
+//   * per-row factors (d[s] / W2's power of two) and observations go through a per-wave LDS exchange: the lane that
+//     loads a row is not the lane that holds its accumulators;
+//   * running column sums [256][db1 | dW1 row | pad] per WAVE in LDS, updated per tile by the wave alone (no workgroup
+//     barrier), added over the four waves in order at the end.
+constexpr int rows_dgrad_lds_bytes(int ring, int k_in) {
+  return ring * kRowsChunk + rows_record(k_in) * kHidden * 4 + 4 * (1024 + 32 * (1 + k_in) * 4 + rows_record(k_in) * kHidden * 4);
+}
+
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_b64(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_read_u8(unsigned addr) {
+  uint32_t v;
+  asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+template <int DIN, int NOUT, int RING>
+__global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
+    const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+    const float *__restrict__ dout, int64_t m, const void *__restrict__ w2ts, float *__restrict__ partials,
+    int partial_stride, int head_rows, const uint32_t *__restrict__ gate2) {
+  constexpr int kIn = DIN, d_in = DIN;
+  constexpr int kTile = 128;
+  constexpr int kAhead = RING - 1;
+  constexpr int kRec = rows_record(DIN);
+  static_assert(DIN >= 1 && DIN <= 3, "wider observations keep the previous kernel (LDS: running sums per wave)");
+  static_assert(rows_dgrad_lds_bytes(RING, kIn) <= 80 * 1024, "two workgroups per CU");
+  static_assert(kAhead >= 2, "the mid-step barrier publishes a chunk requested at least a half-step earlier");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [ring][layer-1 records [256][kRec]][per wave: gate block 1 KiB | factors [32] | observations [DIN][32] | sums [256][kRec]]
+  const unsigned lds0 = lds_offset(smem);
+  constexpr int kRecOff = RING * kRowsChunk;
+  constexpr int kWaveOff = kRecOff + kRec * kHidden * 4;
+  constexpr int kWaveBytes = 1024 + 32 * (1 + kIn) * 4 + kRec * kHidden * 4;
+  constexpr int kFacOff = 1024, kObsOff = kFacOff + 32 * 4, kSumOff = kObsOff + 32 * kIn * 4;
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2ts, kRowsPacked);
+  const float inv_w2_scale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(w2ts) + kRowsPacked)[1];
+  const unsigned wave_lds = lds0 + kWaveOff + wave * kWaveBytes;
+
+  const int64_t tiles = (m + kTile - 1) / kTile;
+  const int64_t stride = gridDim.x;
+
+  // layer-1 records (columns of this kernel = hidden units of layer 1) and zeroed running sums
+  {
+    float *rec = reinterpret_cast<float *>(smem + kRecOff);
+    rec[tid * kRec] = b1[tid];
+#pragma unroll
+    for (int i = 0; i < kRec - 1; ++i) rec[tid * kRec + 1 + i] = i < kIn ? w1[tid * d_in + (i < kIn ? i : 0)] : 0.0f;
+    float *sums = reinterpret_cast<float *>(smem + kWaveOff + wave * kWaveBytes + kSumOff);
+    for (int idx = lane; idx < kRec * kHidden; idx += kWave) sums[idx] = 0.0f;
+  }
+
+  // rows of a tile that exist for this wave, and this lane's two rows' d = dOut[row][0] (0 past the end)
+  auto wave_rows = [&](int64_t tile) {
+    const int64_t left = tile < tiles ? m - tile * kTile - 32 * wave : 0;
+    return left <= 0 ? 0 : left < 32 ? (int)left : 32;
+  };
+  auto load_rows = [&](float (&d)[2], float (&xs)[2][kIn], int64_t tile) {
+    const int rows = wave_rows(tile);
+    const int64_t r0 = tile * kTile + 32 * wave;
+    const __amdgpu_buffer_rsrc_t drsrc = buffer_rsrc(rows > 0 ? dout + r0 * NOUT : dout, rows * NOUT * 4);
+    const __amdgpu_buffer_rsrc_t xrsrc = buffer_rsrc(rows > 0 ? x + r0 * d_in : x, rows * d_in * 4);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      d[rt] = buffer_load_f32(drsrc, (16 * rt + l16) * NOUT * 4, 0);
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) xs[rt][i] = buffer_load_f32(xrsrc, ((16 * rt + l16) * d_in + i) * 4, 0);
+    }
+  };
+  // the wave's gate block of `tile` -> its LDS block (rows past the end arrive as zeros: gate closed)
+  auto request_gate = [&](int64_t tile) {
+    const int rows = wave_rows(tile);
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? gate2 + (tile * kTile + 32 * wave) * 8 : gate2, rows * 32);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, smem + kWaveOff + wave * kWaveBytes, 16, lane * 16, 0, 0, 0);
+  };
+  // chunk hs = (S, C): k steps 2 S, 2 S + 1 of the pack, column tiles (of 32) 4 C .. 4 C + 3, both planes: two runs of 8 KiB
+  auto chunk_piece = [&](int hs, int stage, int piece) {
+    const int S = hs >> 1, C = hs & 1;
+    const int src = ((2 * S + (piece >> 3)) * 8 + 4 * C) * 2048 + (piece & 7) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, smem + stage * kRowsChunk + piece * 1024, 16, lane * 16, src, 0, 0);
+  };
+  // this lane's 16-byte unit of local column tile ctl (of 16), plane p: k step kq / 2, k half kq & 1, column tile ctl / 2
+  const unsigned b_lane = lds0 + (kq >> 1) * 8192 + ((kq & 1) * 32 + l16) * 16;
+  const unsigned g_lane = wave_lds + l16 * 32 + kq;  // the gate byte of k block S: + 4 S (+ 512 for row tile 1)
+
+  float dc[2], dn[2], xc[2][kIn], xn[2][kIn];  // this tile's / the next tile's d and observations of this lane's rows
+  f32x4 acc[2][16];
+  u32x4 a_g[2][2];     // gate fragments: [set = k block parity][row tile]
+  u32x4 bh[2], bl[2];  // B fragments of local column tile ctl: set ctl % 2, requested one slot ahead
+  auto request_block = [&](unsigned br, int ctl, int set) {
+    bh[set] = ctl == 0   ? lds_read_b128<0>(br)
+              : ctl == 1 ? lds_read_b128<256>(br)
+              : ctl == 2 ? lds_read_b128<2048>(br)
+              : ctl == 3 ? lds_read_b128<2048 + 256>(br)
+              : ctl == 4 ? lds_read_b128<4096>(br)
+              : ctl == 5 ? lds_read_b128<4096 + 256>(br)
+              : ctl == 6 ? lds_read_b128<6144>(br)
+                         : lds_read_b128<6144 + 256>(br);
+    bl[set] = ctl == 0   ? lds_read_b128<1024>(br)
+              : ctl == 1 ? lds_read_b128<1024 + 256>(br)
+              : ctl == 2 ? lds_read_b128<3072>(br)
+              : ctl == 3 ? lds_read_b128<3072 + 256>(br)
+              : ctl == 4 ? lds_read_b128<5120>(br)
+              : ctl == 5 ? lds_read_b128<5120 + 256>(br)
+              : ctl == 6 ? lds_read_b128<7168>(br)
+                         : lds_read_b128<7168 + 256>(br);
+  };
+  // bits -> fp16 1.0 / 0.0 (element 0 in the low half)
+  auto gate_fragment = [&](uint32_t byte) {
+    u32x4 g;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2)
+      g[e >> 1] = (((byte >> e) & 1u) ? 0x00003c00u : 0u) | (((byte >> (e + 1)) & 1u) ? 0x3c000000u : 0u);
+    return g;
+  };
+
+  // One half-step (see the forward kernel): KIND 0 produces row tile C of block S + 1 (its gate byte is requested in
+  // slot 0 and used from slot 2 on); 2 = (7, 0): nothing produced, and the NEXT tile's gate block is requested (the
+  // block's last reader was half-step (6, 1)); 3 = (7, 1): nothing requested for a successor.  The barriers of (7, 0)
+  // and (7, 1) leave one more vector-memory operation in flight: that gate block, younger than the chunk they publish.
+  auto do_half = [&](auto first_tag, auto cur_tag, auto c_tag, auto kind_tag, int hs, int stage, int64_t tile) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int CUR = decltype(cur_tag)::value;
+    constexpr int C = decltype(c_tag)::value;
+    constexpr int KIND = decltype(kind_tag)::value;
+    constexpr bool kProduce = KIND == 0, kEnd = KIND == 3;
+    const int stage_next = stage + 1 == RING ? 0 : stage + 1, stage_free = stage == 0 ? RING - 1 : stage - 1;
+    const unsigned br = b_lane + stage * kRowsChunk, br_next = b_lane + stage_next * kRowsChunk;
+    const int S = hs >> 1;
+    [[maybe_unused]] uint32_t byte = 0;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+      const int set = sl & 1, ahead = set ^ 1, ct = 8 * C + sl;
+      if (kProduce && sl == 0) byte = C == 0 ? lds_read_u8<0>(g_lane + 4 * (S + 1)) : lds_read_u8<512>(g_lane + 4 * (S + 1));
+      if (KIND == 2 && sl == 0) request_gate(tile + stride);
+      if (sl < 7) request_block(br, sl + 1, ahead);
+      else if (!kEnd) request_block(br_next, 0, ahead);
+      {
+        const int allowed = ((kProduce && sl == 0) ? 1 : 0) + ((kEnd && sl == 7) ? 0 : 2);
+        allowed == 0 ? wait_lds<0>(bh[set], bl[set]) : allowed == 2 ? wait_lds<2>(bh[set], bl[set]) : wait_lds<3>(bh[set], bl[set]);
+      }
+      const f32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_g[CUR][rt]), __builtin_bit_cast(half8, bl[set]),
+                                                             FIRST ? zero : acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_g[CUR][rt]), __builtin_bit_cast(half8, bh[set]),
+                                                             acc[rt][ct], 0, 0, 0);
+      }
+      if (kProduce && sl == 2) {  // (the byte is older than slot 1's fragment request: landed behind that slot's wait)
+        asm volatile("" : "+v"(byte));
+        a_g[CUR ^ 1][C] = gate_fragment(byte);
+      }
+      if (sl == 3) {
+        // younger than the chunk this barrier publishes: the pieces of kAhead - 2 chunks, plus the gate block ((7, 0),
+        // (7, 1)) or the next tile's row loads (the tile's first two half-steps: 2 (1 + DIN) load instructions)
+        constexpr int kExtra = KIND >= 2 ? 1 : FIRST ? 2 * (1 + kIn) : 0;
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kAhead - 2) + kExtra) : "memory");
+      }
+      if (sl >= 4) chunk_piece((hs + kAhead) & (kRowsHalfSteps - 1), stage_free, wave * 4 + (sl - 4));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  using T = std::true_type;
+  using F = std::false_type;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using K0 = I0;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+
+  // ---- prologue: the first tile's gate block, then the first kAhead chunks; everything before them landed --------------
+  __syncthreads();  // (records and zeroed sums in LDS)
+  if ((int64_t)blockIdx.x < tiles) {
+    request_gate(blockIdx.x);
+#pragma unroll
+    for (int d = 0; d < kAhead; ++d)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) chunk_piece(d, d, wave * 4 + u);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kAhead - 1)) : "memory");
+    load_rows(dc, xc, blockIdx.x);
+  }
+
+  int stage = 0;
+  auto next_stage = [&]() { stage = stage + 1 == RING ? 0 : stage + 1; };
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
+    // ---- open the tile: this tile's gate block has landed (requested two half-steps and an epilogue ago: only the
+    // eight pieces behind it may still be in flight); block 0's gate fragments; factors and observations of the wave's
+    // rows to the per-wave exchange; the first B fragments
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    load_rows(dn, xn, tile + stride);  // the next tile's rows: in flight through this tile (counted in its first two barriers)
+    {
+      uint32_t b0 = lds_read_u8<0>(g_lane), b1v = lds_read_u8<512>(g_lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1v));
+      a_g[0][0] = gate_fragment(b0);
+      a_g[0][1] = gate_fragment(b1v);
+      if (kq == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          lds_write_b32(wave_lds + kFacOff + (16 * rt + l16) * 4, dc[rt] * inv_w2_scale);
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) lds_write_b32(wave_lds + kObsOff + (32 * i + 16 * rt + l16) * 4, xc[rt][i]);
+        }
+      }
+      request_block(b_lane + stage * kRowsChunk, 0, 0);
+    }
+    do_half(T{}, I0{}, I0{}, K0{}, 0, stage, tile);  next_stage();
+    do_half(T{}, I0{}, I1{}, K0{}, 1, stage, tile);  next_stage();
+    do_half(F{}, I1{}, I0{}, K0{}, 2, stage, tile);  next_stage();
+    do_half(F{}, I1{}, I1{}, K0{}, 3, stage, tile);  next_stage();
+#pragma unroll 1
+    for (int hs = 4; hs < kRowsHalfSteps - 4; hs += 4) {
+      do_half(F{}, I0{}, I0{}, K0{}, hs, stage, tile);      next_stage();
+      do_half(F{}, I0{}, I1{}, K0{}, hs + 1, stage, tile);  next_stage();
+      do_half(F{}, I1{}, I0{}, K0{}, hs + 2, stage, tile);  next_stage();
+      do_half(F{}, I1{}, I1{}, K0{}, hs + 3, stage, tile);  next_stage();
+    }
+    do_half(F{}, I0{}, I0{}, K0{}, kRowsHalfSteps - 4, stage, tile);  next_stage();
+    do_half(F{}, I0{}, I1{}, K0{}, kRowsHalfSteps - 3, stage, tile);  next_stage();
+    do_half(F{}, I1{}, I0{}, K2{}, kRowsHalfSteps - 2, stage, tile);  next_stage();
+    do_half(F{}, I1{}, I1{}, K3{}, kRowsHalfSteps - 1, stage, tile);  next_stage();
+
+    // ---- epilogue: dZ1 = dH1 * factor * (h1 > 0), folded into the wave's running column sums ---------------------------
+    // this lane: columns 16 ct + l16; rows 16 rt + 4 kq + r.  Factors / observations of those rows from the exchange.
+    int lane_e = lane;  // (opaque copy: see the forward kernel's epilogue)
+    asm volatile("" : "+v"(lane_e));
+    const int l16e = lane_e & 15, kqe = lane_e >> 4;
+    const unsigned wl = lds0 + kWaveOff + wave * kWaveBytes;
+    u32x4 fq[2], xq[2][kIn];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      fq[rt] = rt == 0 ? lds_read_b128<kFacOff>(wl + 16 * kqe) : lds_read_b128<kFacOff + 64>(wl + 16 * kqe);
+#pragma unroll
+      for (int i = 0; i < kIn; ++i)
+        xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
+                               : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
+                                        : lds_read_b128<kObsOff + 256>(wl + 16 * kqe))
+                            : (i == 0   ? lds_read_b128<kObsOff + 64>(wl + 16 * kqe)
+                               : i == 1 ? lds_read_b128<kObsOff + 128 + 64>(wl + 16 * kqe)
+                                        : lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe));
+    }
+    // per column tile: the column's layer-1 record and its running sums (read-modify-write by the lanes kq == ct % 4)
+    const unsigned rec_at = lds0 + kRecOff + l16e * (kRec * 4), sum_at = wl + kSumOff + l16e * (kRec * 4);
+    typedef typename std::conditional<kRec == 2, u32x2, u32x4>::type rec_t;
+    rec_t rq[2], sq[2];
+    auto request_col = [&](int ct, int set) {
+      const unsigned ra = rec_at + ct * (16 * kRec * 4), sa = sum_at + ct * (16 * kRec * 4);
+      if constexpr (kRec == 2) {
+        rq[set] = lds_read_b64<0>(ra);
+        sq[set] = lds_read_b64<0>(sa);
+      } else {
+        rq[set] = lds_read_b128<0>(ra);
+        sq[set] = lds_read_b128<0>(sa);
+      }
+    };
+    request_col(0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct) {
+      const int set = ct & 1;
+      if (ct + 1 < 16) request_col(ct + 1, set ^ 1);
+      if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
+      if (ct == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          asm volatile("" : "+v"(fq[rt]));
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
+        }
+      }
+      const float b1c = __uint_as_float(rq[set][0]);
+      float w1c[kIn];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
+      float db = 0.0f, dw[kIn];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        float pre[4];
+        unsigned long long open[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pre[r] = b1c;
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) pre[r] = __builtin_fmaf(__uint_as_float(xq[rt][i][r]), w1c[i], pre[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) open[r] = positive_mask(pre[r]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
+          db += dz;
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
+        }
+      }
+      // the four lanes of a column (kq = 0..3) in a fixed order, then the running sums by one of them
+      auto across = [&](float v) {
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const float u = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+        return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+      };
+      db = across(db);
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
+      if (kqe == (ct & 3)) {
+        const unsigned sa = sum_at + ct * (16 * kRec * 4);
+        lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the workgroup's next tile
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      dc[rt] = dn[rt];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) xc[rt][i] = xn[rt][i];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // Workgroup partial row: [dW1 (256 * d_in) | db1 (256) | head gradients (the weight-gradient kernel's)], the four
+  // waves' sums added in wave order.
+  float *row = partials + (int64_t)blockIdx.x * partial_stride;
+  {
+    const int t = tid;
+    float tot[1 + kIn];
+#pragma unroll
+    for (int i = 0; i < 1 + kIn; ++i) tot[i] = 0.0f;
+    for (int w = 0; w < 4; ++w) {
+      const float *sums = reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff);
+#pragma unroll
+      for (int i = 0; i < 1 + kIn; ++i) tot[i] += sums[t * kRec + i];
+    }
+    row[kHidden * d_in + t] = tot[0];
+#pragma unroll
+    for (int i = 0; i < kIn; ++i) row[t * d_in + i] = tot[1 + i];
+    // the head-gradient segments of the first head_rows rows belong to the weight-gradient kernel; rows beyond them are zero
+    if ((int)blockIdx.x >= head_rows)
+      for (int idx = kHidden * d_in + kHidden + t; idx < partial_stride; idx += kBlock) row[idx] = 0.0f;
+  }
+}
+
+template <int DIN, int NOUT>
+static int launch_rows_backward_gate(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
+                                     int64_t m, const void *w2ts, float *partials, int stride, int head_rows,
+                                     const uint32_t *gate2) {
+  constexpr int kRing = DIN == 1 ? 4 : 3;
+  auto kernel = &mlp_rows_backward_gate_kernel<DIN, NOUT, kRing>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    attr_set = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+  }
+  kernel<<<grid, kBlock, rows_dgrad_lds_bytes(kRing, DIN), s>>>(x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2);
+  return launch_status();
+}
+
+// The gate-mode data gradient behind rl8_mlp_tower_backward_gate_f16_f32 for d_in <= 3 (-1: no variant: the caller keeps
+// the previous kernel).  Same grid and partial rows as that kernel.
+int mlp_rows_backward_gate_dispatch(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
+                                    int64_t m, int d_in, const void *w2ts, int n_out, float *partials, int stride, int head_rows,
+                                    const uint32_t *gate2) {
+#define RL8_ROWS_BWD(D, N) \
+  if (d_in == D && n_out == N) return launch_rows_backward_gate<D, N>(grid, s, x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2);
+  RL8_ROWS_BWD(1, 1) RL8_ROWS_BWD(1, 2) RL8_ROWS_BWD(2, 1) RL8_ROWS_BWD(2, 2) RL8_ROWS_BWD(3, 1) RL8_ROWS_BWD(3, 2)
+#undef RL8_ROWS_BWD
+  return -1;
+}
+
 template <int DIN, int NOUT, int SAVE>
 static int launch_rows_forward(hipStream_t s, const float *x, int64_t m, const float *w1, const float *b1, const void *w2s,
                                const float *b2, const float *w3, const float *b3, float *out, float *h1, float *h2,
