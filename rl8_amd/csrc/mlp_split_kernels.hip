@@ -1703,9 +1703,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   // mid planes into the other set, the lo planes into the first set once the hi products
   // are issued, and the next step's hi planes into the second behind the barrier.
   SplitFrags f;  // ah / am: gate fragments of even / odd steps; bh / bm: the B sets X / Y
-  auto first_reads = [&](auto parity_tag) {  // ... of the chunk in stage P: gate -> that step's G, hi planes -> its first set
+  auto first_reads = [&](auto parity_tag, auto stage_tag) {  // ... of the chunk in stage S: gate -> role P's G, hi planes -> its first set
     constexpr int P = decltype(parity_tag)::value;
-    const unsigned ar = a_read + P * kWgStageBytes, br = b_read + P * kWgStageBytes;
+    constexpr int S = decltype(stage_tag)::value;
+    const unsigned ar = a_read + S * kWgStageBytes, br = b_read + S * kWgStageBytes;
     u32x4(&G)[2] = *(P == 0 ? &f.ah : &f.am);
     u32x4(&B0)[4] = *(P == 0 ? &f.bh : &f.bm);
     G[0] = lds_read_b128<0>(ar);
@@ -1717,10 +1718,14 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   };
   // (Round 3: a stagger of the SIMD's two waves -- waves 4..7 forming their operands one group of products later, beside
   // the mid planes' products -- measured no change: 87.1 against 87.4 ms per step of the headline bench.  Not kept.)
-  auto do_step = [&](auto first_tag, auto parity_tag, int64_t n) {
+  // Round 3: FOUR stages and one barrier per TWO steps (SQ counters had the waves parked at waits and barriers for 27 %
+  // of their cycles): chunks n, n + 1 are consumed while n + 2, n + 3 are produced; the register roles still alternate
+  // per step (P = n % 2), the stage is S = n % 4, and only odd steps end in a barrier.
+  auto do_step = [&](auto first_tag, auto parity_tag, auto stage_tag, int64_t n) {
     constexpr bool FIRST = decltype(first_tag)::value;
     constexpr int P = decltype(parity_tag)::value;
-    const unsigned br = b_read + P * kWgStageBytes;
+    constexpr int S = decltype(stage_tag)::value;
+    const unsigned br = b_read + S * kWgStageBytes;
     u32x4(&G)[2] = *(P == 0 ? &f.ah : &f.am);
     u32x4(&B0)[4] = *(P == 0 ? &f.bh : &f.bm);
     u32x4(&B1)[4] = *(P == 0 ? &f.bm : &f.bh);
@@ -1731,8 +1736,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     B1[3] = lds_read_b128<kWsPlane + 1536>(br);
     __builtin_amdgcn_sched_barrier(0);
     split_mma<FIRST>(G, B0, acc);  // gate x hi: at once, nothing in front of the first products
-    load_h2(hq[P], n + 2);
-    produce(hq[P ^ 1], P ^ 1);
+    load_h2(hq[P], n + 3);
+    produce(hq[P ^ 1], (S + 2) & 3);
     wait_lds<0>(B1[0], B1[1], B1[2], B1[3]);  // (only LDS operations are in flight)
     __builtin_amdgcn_sched_barrier(0);
     // the lo planes, into the hi planes' registers (their products are issued)
@@ -1742,13 +1747,15 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     B0[3] = lds_read_b128<2 * kWsPlane + 1536>(br);
     split_mma<false>(G, B1, acc);  // gate x mid: last use of B1
     __builtin_amdgcn_sched_barrier(0);
-    request_scalars(n + 2);  // for the chunk the NEXT step produces
+    request_scalars(n + 3);  // for the chunk the NEXT step produces
     wait_lds<0>(B0[0], B0[1], B0[2], B0[3]);  // (the scalar loads with them: nothing counts on order here)
     __builtin_amdgcn_sched_barrier(0);
-    lds_barrier();
+    if constexpr ((S & 1) != 0) lds_barrier();  // end of a pair of steps: the next pair's chunks are complete, this pair's stages free
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     scalars_landed();
-    if constexpr (P == 0) first_reads(P1{});  // into the other gate pair and B1's registers (= the next step's first set)
-    else first_reads(P0{});
+    // into the other gate pair and B1's registers (= the next step's first set)
+    if constexpr (P == 0) first_reads(P1{}, std::integral_constant<int, (S + 1) & 3>{});
+    else first_reads(P0{}, std::integral_constant<int, (S + 1) & 3>{});
     __builtin_amdgcn_sched_barrier(0);
     split_mma<false>(G, B0, acc);  // gate x lo
     __builtin_amdgcn_sched_barrier(0);
@@ -1759,6 +1766,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     }
   };
 
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
   {
     load_h2(hq[0], 0);
     load_h2(hq[1], 1);
@@ -1767,20 +1778,29 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     scalars_landed();
     produce(hq[0], 0);
     request_scalars(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    scalars_landed();
+    produce(hq[1], 1);
+    load_h2(hq[1], 2);  // (step 0 produces chunk 2 from hq[1] and loads chunk 3 into hq[0])
+    request_scalars(2);
     lds_barrier();
     scalars_landed();
-    first_reads(P0{});
+    first_reads(P0{}, S0{});
     wait_lds<0>(f.ah[0], f.ah[1], f.bh[0], f.bh[1], f.bh[2], f.bh[3]);
   }
-  do_step(T{}, P0{}, 0);
   {
-    // an odd number of steps, the last one on an all-zero chunk past the end if need be
-    // (see mlp_wgrad_split_kernel's two-operand mode)
-    const int64_t steps = mine | 1;
+    // a multiple of four steps, the last ones on all-zero chunks past the end if need be
+    const int64_t steps = (mine + 3) & ~(int64_t)3;
+    do_step(T{}, P0{}, S0{}, 0);
+    do_step(F{}, P1{}, S1{}, 1);
+    do_step(F{}, P0{}, S2{}, 2);
+    do_step(F{}, P1{}, S3{}, 3);
 #pragma unroll 1
-    for (int64_t n = 1; n < steps; n += 2) {
-      do_step(F{}, P1{}, n);
-      do_step(F{}, P0{}, n + 1);
+    for (int64_t n = 4; n < steps; n += 4) {
+      do_step(F{}, P0{}, S0{}, n);
+      do_step(F{}, P1{}, S1{}, n + 1);
+      do_step(F{}, P0{}, S2{}, n + 2);
+      do_step(F{}, P1{}, S3{}, n + 3);
     }
   }
 
@@ -1921,7 +1941,7 @@ static int launch_wgrad_gate(int grid, hipStream_t s, const float *h2, const flo
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_wgrad_gate_kernel<DIN, PAIR, BITS><<<grid, kWsThreads, 2 * kWgStageBytes, s>>>(h2, x, w1, b1, m, slabs, fused);
+  mlp_wgrad_gate_kernel<DIN, PAIR, BITS><<<grid, kWsThreads, 4 * kWgStageBytes, s>>>(h2, x, w1, b1, m, slabs, fused);
   return launch_status();
 }
 
