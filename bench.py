@@ -84,7 +84,9 @@ ALGORITHMIC_BYTES = {
     "advantage_normalise": 8.0,
     "rollout_step_dummy": 52.0,     # logits 8 value 4 state 4 rdr 4 | action 8 logp 4 value 4 reward 4 obs 4 state 4 rdr 4
     "rollout_stats": 8.0,
-    "gather_minibatch": 56.0,
+    "gather_minibatch": 56.0,       # index 8 + 24 read + 24 written per sample
+    "gather_packed": 56.0,          # the same minibatch out of rows packed once per step()
+    "pack_samples": 56.0,           # 24 B read + 32 B written per sample of the buffer, once per step()
 }
 
 
@@ -102,6 +104,8 @@ PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in
     "rollout_step_dummy": ("rollout_step_dummy_kernel", 1 << 20),
     "rollout_stats": ("rollout_stats_kernel", (1 << 20) * 32),
     "gather_minibatch": ("gather_minibatch_kernel", 1 << 22),
+    "gather_packed": ("gather_packed_kernel", 1 << 22),
+    "pack_samples": ("pack_samples_kernel", (1 << 20) * 32),
     # the towers, profiled at 2^20 rows (policy tower of the discrete dummy env)
     "mlp_tower_forward": ("mlp_tower_forward_kernel<1, 2, false>", 1 << 20),
     "mlp_tower_forward_save": ("mlp_tower_forward_kernel<1, 2, true>", 1 << 20),
@@ -164,6 +168,10 @@ def parse_args(argv: None | list[str] = None) -> argparse.Namespace:
     p.add_argument("--env", default="discrete", choices=["discrete", "continuous", "cartpole", "mountain_car", "pendulum"])
     p.add_argument("--distribution", default="default", choices=["default", "squashed"])
     p.add_argument("--recurrent", action="store_true", help="RecurrentAlgorithmConfig (LSTM, seq_len 4)")
+    p.add_argument("--minibatches", type=int, default=1,
+                   help="K > 1: sgd_minibatch_size = num_envs * horizon / K per rank, i.e. the SHUFFLED path of step()"
+                        " (randperm, pack_samples once, gather_packed per minibatch: reference src/rl8/_utils.py:211-225);"
+                        " 1 = the defaults (one full-buffer minibatch, whose mean needs no shuffle)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (production); gloo stages the tiny messages through the host"
                         " (rehearsals: CPU rendezvous tests, several ranks on one GPU)")
@@ -457,6 +465,10 @@ def run(args: argparse.Namespace) -> None:
     envs_per_gpu = global_envs // world
     config_cls = RecurrentAlgorithmConfig if args.recurrent else AlgorithmConfig
     extra = {"distribution_cls": SquashedNormal} if args.distribution == "squashed" else {}
+    if args.minibatches > 1:
+        if (global_envs * args.horizon) % args.minibatches:
+            raise SystemExit(f"bench.py: --minibatches {args.minibatches} does not divide num_envs * horizon")
+        extra["sgd_minibatch_size"] = global_envs * args.horizon // args.minibatches
     algo = config_cls(num_envs=global_envs, horizon=args.horizon, **extra).build(env_cls)
     horizon = algo.hparams.horizon
 
@@ -671,7 +683,9 @@ def run(args: argparse.Namespace) -> None:
             "config": {
                 "workload": f"{env_cls.__name__}{variant} collect()+step(), num_envs={envs_per_gpu} per GPU"
                             f" ({global_envs} total), horizon={horizon}, AlgorithmConfig defaults"
-                            " (4 SGD iters, one full-buffer minibatch, Adam 1e-3)",
+                            + (" (4 SGD iters, one full-buffer minibatch, Adam 1e-3)" if args.minibatches == 1 else
+                               f" except sgd_minibatch_size = buffer / {args.minibatches} (4 SGD iters x {args.minibatches}"
+                               " shuffled minibatches, Adam 1e-3)"),
                 "num_envs_per_gpu": envs_per_gpu,
                 "num_envs_global": global_envs,
                 "horizon": horizon,

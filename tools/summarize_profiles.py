@@ -7,13 +7,19 @@ summaries under profiles/ that DESIGN.md and bench.py cite.
 
 PMC correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports
 half the bytes of a wide coalesced streaming read, WRITE_SIZE is exact; both are
-in KiB. traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch.
+in KiB. traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch -- except
+for kernels whose reads are RANDOM ROWS (RANDOM_ROW_KERNELS): calibrated on known
+byte counts (profiles/r03_fetch_calibration.txt), a random 32- or 64-byte row is one
+64-byte request counted whole, so their FETCH_SIZE is taken as reported.
 """
 
 import collections
 import csv
 import json
 import sys
+
+
+RANDOM_ROW_KERNELS = ("gather_packed_kernel", "gather_minibatch_kernel")
 
 
 def short(name: str) -> str:
@@ -59,13 +65,15 @@ def pmc(fetch_csv: str, write_csv: str, dst: str) -> None:
     out = {}
     for k in fetch:
         f, w = median(fetch[k]), median(write.get(k, [0.0]))
+        random_rows = any(n in k for n in RANDOM_ROW_KERNELS)
         out[k] = {
             "launches_sampled": len(fetch[k]),
             "grid_size": grid[k],
             "FETCH_SIZE_KiB_median": f,
             "WRITE_SIZE_KiB_median": w,
-            "traffic_bytes_per_launch": (2 * f + w) * 1024,
-            "note": "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction), KiB -> bytes",
+            "traffic_bytes_per_launch": ((1 if random_rows else 2) * f + w) * 1024,
+            "note": ("FETCH_SIZE (random rows: counted whole, profiles/r03_fetch_calibration.txt) + WRITE_SIZE, KiB -> bytes"
+                     if random_rows else "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction), KiB -> bytes"),
         }
     json.dump(out, open(dst, "w"), indent=1)
     print(f"wrote {dst}: {len(out)} kernels")
