@@ -87,15 +87,41 @@ __device__ __forceinline__ double read_partial(const double *slot) {
   return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Call from every thread after thread 0 has published the block's row.
-__device__ __forceinline__ bool last_block_arrives(unsigned *ticket_word) {
+// The arrival count is kept on two levels: 32 consecutive blocks share a group
+// word, and only the last arriver of a group takes a ticket on the top word.
+// One word for the whole grid serialises every block's atomic on one address
+// at the memory side: 11.6 ns each, 13.6 us for 1024 blocks against 0.6 us here
+// (tools/probes/ticket_probe.hip, profiles/r03_experiments.md).  Group words
+// sit 4 KiB apart so that different groups' atomics land on different channels.
+constexpr int kTicketGroup = 32;
+constexpr int kTicketWordPitch = 1024;  // unsigneds between group words (4 KiB)
+
+__device__ __forceinline__ unsigned *ticket_word(double *scratch) {
+  return reinterpret_cast<unsigned *>(scratch + (int64_t)RL8_MAX_PARTIALS * 16);
+}
+
+// Call from every thread after thread 0 has published the block's row.  True in
+// every thread of the one block that arrived after all others; that block
+// zeroes the top word when it is done (`*ticket_word(scratch) = 0u`), the group
+// words are zeroed here by their last arrivers.
+__device__ __forceinline__ bool last_block_arrives(unsigned *top) {
   __shared__ int is_last;
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket =
-        __hip_atomic_fetch_add(ticket_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = ticket == gridDim.x - 1;
-    if (is_last) {
+    const unsigned group = blockIdx.x / kTicketGroup;
+    const unsigned groups = (gridDim.x + kTicketGroup - 1) / kTicketGroup;
+    const unsigned members =
+        group == groups - 1 ? gridDim.x - group * kTicketGroup : (unsigned)kTicketGroup;
+    unsigned *word = top + (int64_t)(1 + group) * kTicketWordPitch;
+    int last = 0;
+    if (__hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+        members - 1) {
+      __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+             groups - 1;
+    }
+    is_last = last;
+    if (last) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -104,8 +130,27 @@ __device__ __forceinline__ bool last_block_arrives(unsigned *ticket_word) {
   return is_last != 0;
 }
 
-__device__ __forceinline__ unsigned *ticket_word(double *scratch) {
-  return reinterpret_cast<unsigned *>(scratch + (int64_t)RL8_MAX_PARTIALS * 16);
+// The last block's walk over the published rows: thread t takes rows t,
+// t + blockDim, ... in that order (the order the sums have always been taken
+// in), with the loads of kFoldRows rows in the air at once instead of one
+// row's (6.8 us per 1024 rows of 10 columns otherwise: latency, not bytes).
+constexpr int kFoldRows = 4;
+
+template <int NC, class F>
+__device__ __forceinline__ void fold_partial_rows(const double *partials, int rows, F &&f) {
+  const int step = (int)blockDim.x;
+  for (int r0 = threadIdx.x; r0 < rows; r0 += step * kFoldRows) {
+    double v[kFoldRows][NC];
+#pragma unroll
+    for (int u = 0; u < kFoldRows; ++u) {
+      const int r = r0 + u * step < rows ? r0 + u * step : r0;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[u][c] = read_partial(partials + (int64_t)r * kPartialWidth + c);
+    }
+#pragma unroll
+    for (int u = 0; u < kFoldRows; ++u)
+      if (r0 + u * step < rows) f(v[u]);
+  }
 }
 
 inline int grid_for(int64_t work_items, int items_per_block, int cap = kMaxGrid) {

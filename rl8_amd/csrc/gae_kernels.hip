@@ -56,10 +56,10 @@ __device__ __forceinline__ void publish_moments(double (&acc)[2], double *partia
   }
   if (!last_block_arrives(ticket_word(partials))) return;
   double tot[2] = {0.0, 0.0};
-  for (int r = threadIdx.x; r < (int)gridDim.x; r += blockDim.x) {
-    tot[0] += read_partial(partials + (int64_t)r * kPartialWidth + 0);
-    tot[1] += read_partial(partials + (int64_t)r * kPartialWidth + 1);
-  }
+  fold_partial_rows<2>(partials, (int)gridDim.x, [&](const double(&row)[2]) {
+    tot[0] += row[0];
+    tot[1] += row[1];
+  });
   block_reduce<2, SumOp>(tot, smem);
   if (threadIdx.x == 0) {
     moments_out[0] = count;

@@ -35,11 +35,10 @@ __device__ __forceinline__ void publish_loss_row(double (&acc)[kLossCols], doubl
   }
   if (!last_block_arrives(ticket_word(partials))) return;
   double tot[kLossCols] = {0.0, 0.0, 0.0, 0.0};
-  for (int r = threadIdx.x; r < rows; r += kBlock) {
+  fold_partial_rows<kLossCols>(partials, rows, [&](const double(&v)[kLossCols]) {
 #pragma unroll
-    for (int c = 0; c < kLossCols; ++c)
-      tot[c] += read_partial(partials + (int64_t)r * kPartialWidth + c);
-  }
+    for (int c = 0; c < kLossCols; ++c) tot[c] += v[c];
+  });
   block_reduce<kLossCols, SumOp>(tot, smem);
   if (threadIdx.x == 0) {
     out[0] = tot[0];

@@ -1290,13 +1290,20 @@ def lstm_pack_transposed(w_hh: torch.Tensor) -> torch.Tensor:
     return torch.cat([mlp_pack_w2(w_hh[LSTM_HIDDEN * q : LSTM_HIDDEN * (q + 1)], transposed=True) for q in range(4)])
 
 
+#: column-sum partial rows of the fused LSTM weight gradient, per (device, stream, L, d_in)
+_lstm_colsum_ws: dict[tuple[int, int, int, int], torch.Tensor] = {}
+
+
 def lstm_backward(
     x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, hs: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor,
-    dhs: torch.Tensor, whht_packed: torch.Tensor,
+    dhs: torch.Tensor, whht_packed: torch.Tensor, *, split: None | bool = None,
 ) -> dict[str, torch.Tensor]:
     """Parameter gradients of the LSTM given ``dhs`` [B, L, 256] (gradient of every
     ``h_t``) and what ``lstm_forward(..., save=True)`` returned. Returns ``w_ih``,
-    ``w_hh``, ``b`` (the gradient of each of the two bias vectors)."""
+    ``w_hh``, ``b`` (the gradient of each of the two bias vectors). ``split``: the
+    weight-gradient GEMMs on bf16 planes (True) or the fp32 MFMA (False); the caller
+    passes the mode its forward ran in (``fused_lstm.use_split``), None reads
+    ``RL8_AMD_LSTM_GEMM`` as the forward's module switch does at import."""
     x = _dense(x.detach(), torch.float32, "x")
     b, l, d_in = x.shape
     for name, t, shape in (("h0", h0, (b, LSTM_HIDDEN)), ("c0", c0, (b, LSTM_HIDDEN)), ("hs", hs, (b, l, LSTM_HIDDEN)),
@@ -1308,7 +1315,8 @@ def lstm_backward(
     lib = load()
     dev = x.device
     H = LSTM_HIDDEN
-    split = os.environ.get("RL8_AMD_LSTM_GEMM", "split") == "split"
+    if split is None:
+        split = os.environ.get("RL8_AMD_LSTM_GEMM", "split") == "split"
     # With the bf16-plane weight-gradient kernel and a compiled input width, dW_ih and the
     # bias gradient come out of that kernel as column sums of the dG it reads anyway; else
     # the backward call makes one more pass over dG for them.
@@ -1334,7 +1342,10 @@ def lstm_backward(
     dgp, hsp, h0p, wsp, dwp, stream = _ptr(dgates), _ptr(hs), _ptr(h0), _ptr(ws), _ptr(dw_hh), _stream()
     if fused_colsums:
         xt = [x[:, t].contiguous() for t in range(l)]            # dense [B][d] per step (the kernel's scalar loads)
-        cols = torch.empty(4, l, 256, H * (d_in + 1), dtype=torch.float32, device=dev)   # [gate][step][workgroup][...]
+        ckey = (dev.index or 0, _stream() or 0, l, d_in)
+        cols = _lstm_colsum_ws.get(ckey)                          # [gate][step][workgroup][...], kept between calls
+        if cols is None:
+            cols = _lstm_colsum_ws[ckey] = torch.empty(4, l, 256, H * (d_in + 1), dtype=torch.float32, device=dev)
         crow = C.c_int(0)
         with _timed("lstm_wgrad", m):
             for q in range(4):

@@ -94,7 +94,7 @@ class _FusedLSTM(torch.autograd.Function):
         if dhn is not None:  # h_n is h_{L-1}
             dhs = dhs.clone()
             dhs[:, -1] += dhn
-        g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, _packs(ctx.lstm, True))
+        g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, _packs(ctx.lstm, True), split=use_split(ctx.lstm))
         return None, None, None, g["w_ih"], g["w_hh"], g["b"], g["b"], None, None
 
 

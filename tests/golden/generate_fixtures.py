@@ -722,6 +722,48 @@ def gen_first_updates() -> None:
 
 
 # --------------------------------------------------------------------------- #
+# F7b: the SECOND iteration teacher-forced: the traces' iteration 1 is compared
+#      free-running, on weights that drifted through iteration 0's Adam steps, at a wide band.
+#      Here the reference's own iteration-1 numbers are recorded per minibatch, with the gradient
+#      of its first optimizer step, so that a test can load the reference's it0_final weights
+#      (already in the trace), replay iteration 1 and hold the first update to 1e-5 again:
+#      a second rollout (carried observations, non-zero reward scale, used Adam state untouched
+#      by the first update's statistics) through the shuffled / packed path.
+# --------------------------------------------------------------------------- #
+def gen_second_iteration(name, trace_name, env_cls, config_kwargs) -> None:
+    trace = dict(np.load(os.path.join(HERE, trace_name)))
+    torch.manual_seed(42)
+    algo = AlgorithmConfig(num_envs=64, horizon=32, device="cpu", **config_kwargs).build(env_cls)
+    algo.collect()
+    algo.step()
+    for k, v in algo.policy.model.state_dict().items():
+        assert np.array_equal(v.numpy(), trace[f"it0_final_{k}"]), f"{trace_name}: it0 weights differ: {k}"
+    algo.collect()
+    for k, v in algo.buffer.items():
+        if torch.is_tensor(v):
+            assert np.array_equal(v.numpy(), trace[f"it1_collect_{k}"]), f"{trace_name}: it1 collect differs: {k}"
+    with UpdateRecorder(algo) as rec:
+        step_stats = algo.step()
+    keys = [str(k) for k in trace["step_stat_keys"]]
+    for k, w in zip(keys, trace["it1_step_stats"]):
+        assert step_stats[k] == w, f"{trace_name}: it1 re-run differs at {k}"
+    arrays = {"it1_updates": np.array(rec.updates, np.float64), "stat_keys": np.array(STAT_KEYS + ("reduce",))}
+    total_sq = 0.0
+    for k, gval in rec.first_grads.items():
+        arrays[f"it1_first_grad_{k}"] = gval
+        total_sq += float((gval.double() ** 2).sum())
+    arrays["it1_first_clipped_grad_norm"] = np.float64(total_sq ** 0.5)
+    save(name, **arrays)
+
+
+def gen_second_iterations() -> None:
+    envs = {"discrete": DiscreteDummyEnv, "continuous": ContinuousDummyEnv}
+    for name, trace_name, env, cfg, recurrent in TRACED_VARIANTS:
+        if not recurrent:
+            gen_second_iteration(name.replace("first_update_", "second_iteration_"), trace_name, envs[env], cfg)
+
+
+# --------------------------------------------------------------------------- #
 # F8: config 3 end to end: CartPole (examples/cartpole/env.py:12-64,101-150)
 #     through Algorithm.collect() / .step() (src/rl8/algorithms/_feedforward.py:301-615): the only
 #     built-in path through a three-way Categorical head on a five-wide observation. Self-contained
@@ -848,6 +890,9 @@ def main() -> None:
         gen_first_updates()
         gen_early_stop()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "second_iterations":
+        gen_second_iterations()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cartpole":
         gen_cartpole_first_update()
         return
@@ -894,6 +939,7 @@ def main() -> None:
     )
     gen_first_updates()
     gen_early_stop()
+    gen_second_iterations()
     gen_cartpole_first_update()
 
 

@@ -28,7 +28,7 @@ from rl8_amd.distributions import SquashedNormal  # noqa: E402
 from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv  # noqa: E402
 from rl8_amd.envs.cartpole import CartPole  # noqa: E402
 
-from .test_algorithm_gpu import inject  # noqa: E402
+from .test_algorithm_gpu import compare_collect, inject  # noqa: E402
 
 NUM_ENVS, HORIZON = 64, 32
 
@@ -177,6 +177,46 @@ def test_first_minibatch_of_traced_config_matches_reference_to_1e5(golden, varia
     got = np.array(rec.updates)
     assert np.array_equal(got[:, -1], want[:, -1])
     np.testing.assert_allclose(got[1:, :-1], want[1:, :-1], rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("variant", [v for v in VARIANTS if v.startswith("ff_") and v != "ff_cartpole"])
+def test_second_iteration_teacher_forced_matches_reference_to_1e5(golden, variant):
+    """Iteration 1 of the traced configs from the REFERENCE's weights after iteration 0
+    (``it0_final_*`` of the trace) instead of this build's drifted ones: a second rollout
+    (carried or re-drawn states, reward scale of a used buffer) and the first per-minibatch
+    update + gradient of a ``step()`` whose optimizer has history, held to the first-update
+    bar (tests/golden/second_iteration_*.npz). The free-running comparison of the same
+    iteration keeps its wide band in test_algorithm_gpu.run_trace."""
+    from rl8_amd.data import DataKeys
+
+    g2 = golden(f"second_iteration_{variant}.npz")
+    algo, trace = build(golden, variant)
+    algo.collect()
+    algo.step()
+    model = algo.policy.model
+    model.load_state_dict({k: torch.from_numpy(trace[f"it0_final_{k}"]) for k in model.state_dict()})
+    final_obs = torch.from_numpy(trace["it0_final_obs"]).to(algo.policy.device)
+    algo.buffer[DataKeys.OBS][:, -1].copy_(final_obs)  # carried when horizons_per_env_reset > 1
+    algo.env.state.copy_(final_obs)  # the dummy envs' observation is their state
+    inject(algo, trace, 1)
+    algo.collect()
+    compare_collect(algo, trace, 1, discrete=variant.startswith("ff_discrete"), loose=1.0)
+    assert algo.state.reward_scale == pytest.approx(float(trace["it1_reward_scale"]), rel=1e-5)
+    with Recorder(algo) as rec:
+        algo.step()
+    want = g2["it1_updates"]
+    assert len(rec.updates) == len(want)
+    assert_update(rec.updates[0], want[0], variant)
+    grads = {k[len("it1_first_grad_"):]: g2[k] for k in g2 if k.startswith("it1_first_grad_")}
+    assert set(grads) == set(rec.first_grads)
+    err_sq = ref_sq = 0.0
+    for k, w in grads.items():
+        got = rec.first_grads[k].double().cpu().numpy()
+        err_sq += float(((got - w) ** 2).sum())
+        ref_sq += float((w.astype(np.float64) ** 2).sum())
+        np.testing.assert_allclose(got, w, rtol=0, atol=2e-5 * float(np.abs(w).max()) + 1e-9, err_msg=f"{variant} {k}")
+    assert (err_sq / ref_sq) ** 0.5 < 1e-5, (variant, (err_sq / ref_sq) ** 0.5)
+    assert ref_sq ** 0.5 == pytest.approx(float(g2["it1_first_clipped_grad_norm"]), rel=1e-6)
 
 
 def test_kl_early_stop_matches_reference(golden):
