@@ -573,6 +573,25 @@ int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, const floa
                           const float *whht_packed, float *dgates, float *partials,
                           int *partial_rows_out /*host*/, void *stream);
 
+/* The same data gradient with the recurrent product dL/dh_{t-1} = sum_q dG_q x W_hh[q] on the
+ * 16-bit matrix pipe (bf16 planes, three per operand, six plane products: fp32-accurate), a
+ * wave per 32 sequences for all L steps (lstm_rows_kernels.hip).  What torch.nn.LSTM's backward
+ * computes for the module of src/rl8/models/_recurrent.py:201-321 when
+ * src/rl8/algorithms/_recurrent.py calls loss.backward().
+ * rl8_lstm_rows_backward_pack: w_hh [1024][256] (torch layout, gates i, f, g, o) -> `packed`
+ *   (rl8_lstm_rows_backward_pack_bytes() bytes, 16-byte aligned): the planes of W_hh^T in the
+ *   order the kernel streams them.  Re-pack when w_hh changes.
+ * rl8_lstm_rows_backward_f32: c0 [B][256], gates [B][L][4][256] and cs [B][L][256] as the
+ *   forward saved them, dhs [B][L][256] -> dgates [B][L][4][256]; `dc_scratch` [B][256] floats
+ *   (contents irrelevant on entry, undefined on return).  All arrays 16-byte aligned;
+ *   32 * L * 4096 < 2^31.  The input-weight, bias and recurrent-weight gradients come from
+ *   rl8_mlp_wgrad_split_strided_f32 on dgates as before. */
+int64_t rl8_lstm_rows_backward_pack_bytes(void);
+int rl8_lstm_rows_backward_pack(const float *w_hh, void *packed, void *stream);
+int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs,
+                               const float *dhs, const void *packed, float *dgates, float *dc_scratch,
+                               void *stream);
+
 /* The recurrent models' output heads (src/rl8/models/_recurrent.py:230-236, 287-292),
  * all of them at once: out [M][n] = h [M][256] x w^T + b, w [n][256] (the heads'
  * nn.Linear weights stacked), n <= 8.  Backward: dh_out [M][256] = dout x w and

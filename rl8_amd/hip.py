@@ -131,6 +131,9 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_pack_split": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "rl8_lstm_split_state": [_vp, _i64, _i64, _vp, _vp],
     "rl8_lstm_step_split_f32": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
+    "rl8_lstm_rows_backward_pack_bytes": [],
+    "rl8_lstm_rows_backward_pack": [_vp, _vp, _vp],
+    "rl8_lstm_rows_backward_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rl8_lstm_backward_partial_floats": [_i32],
     "rl8_lstm_backward_max_rows": [],
     "rl8_lstm_backward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp],
@@ -192,7 +195,7 @@ def load() -> C.CDLL:
                 if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes",
                             "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats", "rl8_mlp_split_packed_bytes",
                             "rl8_lstm_split_packed_bytes", "rl8_lstm_split_wb_floats", "rl8_lstm_split_state_bytes",
-                            "rl8_mlp_f16_packed_bytes")
+                            "rl8_mlp_f16_packed_bytes", "rl8_lstm_rows_backward_pack_bytes")
                 else C.c_int
             )
         _lib = lib
@@ -1288,6 +1291,37 @@ def lstm_pack_transposed(w_hh: torch.Tensor) -> torch.Tensor:
     if tuple(w_hh.shape) != (4 * LSTM_HIDDEN, LSTM_HIDDEN):
         raise ValueError("w_hh must be [1024, 256]")
     return torch.cat([mlp_pack_w2(w_hh[LSTM_HIDDEN * q : LSTM_HIDDEN * (q + 1)], transposed=True) for q in range(4)])
+
+
+def lstm_rows_backward_pack(w_hh: torch.Tensor) -> torch.Tensor:
+    """``w_hh`` [1024, 256] -> the bf16 planes of ``W_hh^T`` in the order
+    ``rl8_lstm_rows_backward_f32`` streams them."""
+    w_hh = _dense(w_hh.detach(), torch.float32, "w_hh")
+    if tuple(w_hh.shape) != (4 * LSTM_HIDDEN, LSTM_HIDDEN):
+        raise ValueError("w_hh must be [1024, 256]")
+    lib = load()
+    packed = torch.empty(int(lib.rl8_lstm_rows_backward_pack_bytes()), dtype=torch.uint8, device=w_hh.device)
+    _check(lib.rl8_lstm_rows_backward_pack(_ptr(w_hh), _ptr(packed), _stream()), "rl8_lstm_rows_backward_pack")
+    return packed
+
+
+def lstm_rows_backward(c0: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor, dhs: torch.Tensor,
+                       packed: torch.Tensor) -> torch.Tensor:
+    """dgates [B, L, 4, 256] from what the forward saved and dhs [B, L, 256]: the
+    backward through time with the recurrent product on bf16 planes."""
+    b, l = dhs.shape[0], dhs.shape[1]
+    for name, t, shape in (("c0", c0, (b, LSTM_HIDDEN)), ("gates", gates, (b, l, 4, LSTM_HIDDEN)),
+                           ("cs", cs, (b, l, LSTM_HIDDEN)), ("dhs", dhs, (b, l, LSTM_HIDDEN))):
+        _dense(t, torch.float32, name)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+    dev = dhs.device
+    dgates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    dc = torch.empty(b, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    with _timed("lstm_rows_backward", b * l):
+        _check(load().rl8_lstm_rows_backward_f32(b, l, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dhs), _ptr(packed),
+                                                 _ptr(dgates), _ptr(dc), _stream()), "rl8_lstm_rows_backward_f32")
+    return dgates
 
 
 #: column-sum partial rows of the fused LSTM weight gradient, per (device, stream, L, d_in)
