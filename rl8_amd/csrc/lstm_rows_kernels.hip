@@ -16,17 +16,25 @@
 //       direct-to-LDS loads and read as fragments (the only operand that goes through LDS);
 //   B = dG^T planes, gate row x sequence: a lane's B fragment is eight gate rows of ITS OWN sequence (lane & 31), which
 //       it has just computed from its own loads -- no exchange, no LDS;
-//   D = dh_{t-1}^T: lane = sequence again, registers = out units.  With the out units of a tile permuted (lr_out_unit)
-//       the sixteen registers of tile mo are units 32 mo + 16 (r >> 3) + 8 (lane >> 5) + (r & 7): exactly the eight-unit
-//       runs this lane needs as the NEXT step's dh_carry when it computes gate rows 16 c + 8 (lane >> 5) + e of chunk
-//       c = 2 mo + (r >> 3).  So dh never leaves the registers between steps, and every global access of a lane is two
-//       16-byte pieces of one row (lanes n and n + 32 together: one 64-byte sector).
-// k order of a step: unit chunk c = 0..15 (sixteen hidden units), gates o, i, g, f within it: 64 gate-steps of 16 k,
-// each 8 out tiles x 6 plane products = 48 MFMAs (32x32x16).  The slot of a gate-step in the four-slot ring is its
-// gate position, so the chunk loop is a runtime loop over c with a fixed body.
+//   D = dh_{t-1}^T: lane = sequence again, registers = out units: register r of tile mo is unit 32 mo + 8 (r >> 2) +
+//       4 (lane >> 5) + (r & 3).  Those sixteen units are exactly what this lane needs as the NEXT step's dh_carry when
+//       it computes the gate rows of chunk mo (its B fragments are made of the same sixteen units, in the same register
+//       order: lr_in_unit), so dh never leaves the registers between steps; and four consecutive registers are four
+//       consecutive units: 16 bytes of a row, next to the 16 of lane + 32.
+// k order of a step: unit chunk c = 0..7 (the 32 hidden units of out tile c: a lane's sixteen are the registers of
+// accumulator c), gates o, i, g, f within it, two k-steps of 16 per gate: 64 gate-steps of 16 k, each 8 out tiles x 6
+// plane products = 48 MFMAs (32x32x16).  The slot of a gate-step in the four-slot ring is its position in the chunk
+// mod 4, so the chunk loop is a runtime loop over c with a fixed body of eight gate-steps.
+// Row accesses are whole 128-byte lines: per array and chunk a lane reads its sixteen units with four 16-byte loads
+// issued together, and lanes n, n + 32 cover the line between them.  (The first version worked on chunks of sixteen
+// units -- half a line now, the other half a chunk-time later -- and ran at the 2.7 TB/s HBM gives 64-byte pieces:
+// tools/probes/piece_size_probe.hip; 128-byte pieces get 4.2.)  To fit the registers the chunk's loads come in three
+// phases, each requested five or more gate-steps before its arithmetic: A = {o, c_t, dh_t, dc} -> dG_o, dc;
+// B = {i, g} -> dG_i, dG_g; C = {f, c_{t-1}} -> dG_f, dc out.  A waits in registers; B and C are direct-to-LDS loads into
+// a per-wave park (each lane reads back exactly the 16 bytes it asked for) and cost no registers while in flight.
 // Carries: dh in registers (copied out of the accumulators once per step, read per chunk by a dynamic register index
 // c); dc through a [b][256] scratch in HBM (2 KiB of traffic per row-step; in registers it would take the 128 the row
-// loads in flight need: 512 per lane = 128 accumulators + 128 dh + loads, planes, fragments).
+// loads in flight need: 512 per lane = 128 accumulators + 128 dh + loads, dG, planes, fragments).
 // HBM per row-step: gates 4 KiB, c_t, c_{t-1}, dh_t 1 KiB each, dc in/out 2 KiB, dG 4 KiB out = 13 KiB (the fp32 kernel
 // moves 11); matrix pipe 3072 cycles per row-step.
 #include "split_tile.hip.h"
@@ -34,15 +42,37 @@
 namespace rl8 {
 
 constexpr int kLrRows = 128;                 // sequences per workgroup (32 per wave)
-constexpr int kLrChunks = 16;                // unit chunks per step
-constexpr int kLrGateSteps = 4 * kLrChunks;  // k-chunks of 16 per step
+constexpr int kLrChunks = 8;                 // unit chunks (out tiles) per step
+constexpr int kLrGateSteps = 8 * kLrChunks;  // k-chunks of 16 per step
 constexpr int kLrSlotBytes = 3 * 8 * 1024;   // one gate-step of W_hh^T: [plane][out tile] x 1 KiB
 constexpr int kLrRing = 4;
 constexpr int kLrPackedBytes = kLrGateSteps * kLrSlotBytes;  // 1.5 MiB
-constexpr int kLrLdsBytes = kLrRing * kLrSlotBytes;
-constexpr int kLrRowLoads = 16;              // 16-byte loads a lane issues per chunk
-constexpr int kLrStores = 10;                // 16-byte stores per chunk: dG 8, dc 2
+constexpr int kLrStageBytes = 4 * 8 * 1024;  // one load phase of two arrays, parked in LDS: [wave][array][piece] x 1 KiB
+constexpr int kLrLdsBytes = kLrRing * kLrSlotBytes + 2 * kLrStageBytes;  // 160 KiB: the whole CU
 constexpr int kLrDma = 6;                    // 1-KiB direct-to-LDS loads per wave and gate-step
+// 16-byte row operations a lane issues in gate-step k of a chunk (k = 2 pos + half): loads in front of the step's
+// request, stores behind its matrix work
+constexpr int kLrLoadsAt[8] = {8, 0, 16, 0, 8, 0, 0, 0};   // C of this chunk | A of the next | B of the next
+constexpr int kLrStoresAt[8] = {0, 8, 0, 0, 0, 8, 0, 4};   // dG_i, dG_g | dG_f, dc | dG_o of the next chunk
+// operations a wave has issued behind its request for gate-step k's chunk of W_hh^T (made in step k - 3)
+constexpr int lr_behind(int k) {
+  return kLrStoresAt[(k + 5) & 7] + kLrLoadsAt[(k + 6) & 7] + kLrDma + kLrStoresAt[(k + 6) & 7] + kLrLoadsAt[(k + 7) & 7] +
+         kLrDma + kLrStoresAt[(k + 7) & 7];
+}
+static_assert(lr_behind(0) == 24 && lr_behind(3) == 36 && lr_behind(6) == 28, "see the table in open_step");
+// ... and behind the phase-B loads (made in step 4, read after step 1's matrix work) and the phase-C loads (step 0 -> 5);
+// vmcnt has six bits: waiting for all but the 63 youngest covers anything further back
+constexpr int lr_behind_loads(int from, int to) {  // from the loads of step `from` to the end of step `to`'s matrix work
+  int n = kLrDma;
+  for (int k = (from + 1) & 7;; k = (k + 1) & 7) {
+    n += kLrStoresAt[(k + 7) & 7] + kLrLoadsAt[k] + kLrDma;
+    if (k == to) break;
+  }
+  return n < 63 ? n : 63;
+}
+constexpr int kLrBehindB = lr_behind_loads(4, 1);
+constexpr int kLrBehindC = lr_behind_loads(0, 5);
+static_assert(kLrBehindB == 56 && kLrBehindC == 63, "see the table in open_step");
 #ifndef RL8_LR_DIAG
 #define RL8_LR_DIAG 0  // tuning builds (tools/diag_mlp.sh lr<bits>): 1 no stores reach memory, 2 no row loads do, 4 one plane
 #endif                 // product of six, 8 no W_hh^T traffic (wrong results, same instruction stream)
@@ -53,28 +83,28 @@ constexpr int kLrDiag = RL8_LR_DIAG;
 
 // gate position within a unit chunk -> gate of torch's [i | f | g | o] layout
 __host__ __device__ constexpr int lr_gate(int pos) { return pos == 0 ? 3 : pos == 1 ? 0 : pos == 2 ? 2 : 1; }
-// row m of out tile mo of the transposed product -> hidden unit (see the header: makes a lane's registers runs of eight)
-__host__ __device__ constexpr int lr_out_unit(int mo, int m) {
-  return 32 * mo + 16 * (m >> 4) + 8 * ((m >> 2) & 1) + 4 * ((m >> 3) & 1) + (m & 3);
-}
+// gate row (k) that slot e of k-half kb stands for in the 16-k step `c16` of a gate: the lane's B fragment of step
+// c16 = 2 c + h is registers 8 h .. 8 h + 7 of its sixteen units of chunk c, and register r of a transposed 32 x 32
+// accumulator is out unit 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of the tile
+__host__ __device__ constexpr int lr_in_unit(int c16, int kb, int e) { return 16 * c16 + 8 * (e >> 2) + 4 * kb + (e & 3); }
 
 __device__ __forceinline__ float lr_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
 // W_hh [1024][256] -> bf16 planes of W_hh^T in fragment order:
-// packed[gs][plane][mo][lane][e] = plane of W_hh[256 q + 16 c + 8 (lane >> 5) + e][lr_out_unit(mo, lane & 31)],
-// gs = 4 c + pos, q = lr_gate(pos).
+// packed[gs][plane][mo][lane][e] = plane of W_hh[256 q + lr_in_unit(c16, lane >> 5, e)][32 mo + (lane & 31)],
+// gs = 4 c16 + pos, q = lr_gate(pos).
 __global__ __launch_bounds__(kBlock) void lstm_rows_pack_kernel(const float *__restrict__ w_hh, uint32_t *__restrict__ packed) {
   const int idx = blockIdx.x * kBlock + threadIdx.x;  // (gs, mo, lane)
   if (idx >= kLrGateSteps * 8 * 64) return;
   const int lane = idx & 63, mo = (idx >> 6) & 7, gs = idx >> 9;
   const int q = lr_gate(gs & 3), c = gs >> 2;
-  const int out = lr_out_unit(mo, lane & 31);
-  const float *src = w_hh + (int64_t)(kHidden * q + 16 * c + 8 * (lane >> 5)) * kHidden + out;
+  const int out = 32 * mo + (lane & 31);
+  const float *src = w_hh + (int64_t)(kHidden * q) * kHidden + out;
   u32x4 planes[3];
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
     uint32_t hi, mid, lo;
-    split_pair(src[e * kHidden], src[(e + 1) * kHidden], hi, mid, lo);
+    split_pair(src[lr_in_unit(c, lane >> 5, e) * kHidden], src[lr_in_unit(c, lane >> 5, e + 1) * kHidden], hi, mid, lo);
     planes[0][e >> 1] = hi;
     planes[1][e >> 1] = mid;
     planes[2][e >> 1] = lo;
@@ -94,14 +124,12 @@ struct LrArgs {
   float *dc;           // [b][256] scratch: the carried dL/dc between steps
   int64_t b;
   int l;
+  unsigned long long *stamps;  // tuning builds (RL8_LR_STAMP): cycles per wait site, summed over waves; else null
 };
 
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 
-// what a lane loads for one unit chunk: eight consecutive units of its sequence from each array
-struct LrLoads {
-  u32x4 g[4][2], ct[2], cp[2], dh[2], dc[2];
-};
+// what a lane loads for one unit chunk: its sixteen units (two runs of eight, 64 bytes apart) of its sequence
 struct LrLoadDesc {
   __amdgpu_buffer_rsrc_t gates, cs, cprev, dhs, dcin;
   int v_cp;  // this lane's offset into cprev (cs of t - 1: sequence pitch; c0: 1 KiB)
@@ -119,17 +147,21 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   const __amdgpu_buffer_rsrc_t wrsrc = buffer_rsrc(w_planes, (kLrDiag & 8) ? 0 : kLrPackedBytes);
   const unsigned a_read = lds0 + lane * 16;
 
-  // per-lane byte offsets: sequence n of the wave's 32, units 8 hh .. 8 hh + 7 of a chunk
-  const int v_gates = n * l * (4 * kHidden * 4) + hh * 32;
-  const int v_seq = n * l * (kHidden * 4) + hh * 32;
-  const int v_state = n * (kHidden * 4) + hh * 32;
+  // per-lane byte offsets: sequence n of the wave's 32; piece j (registers 4 j .. 4 j + 3) of a lane's sixteen units of
+  // a chunk is units 8 j + 4 hh ..+3: lanes n and n + 32 move 32 adjacent bytes per instruction, a 128-byte line in four
+  const int v_gates = n * l * (4 * kHidden * 4) + hh * 16;
+  const int v_seq = n * l * (kHidden * 4) + hh * 16;
+  const int v_state = n * (kHidden * 4) + hh * 16;
+  auto piece = [](int j) { return j * 32; };
 
-  auto request = [&](int gs, int slot) {
+  // gate-step k of chunk c -> ring slot: the packed order is [16-unit chunk 2 c + half][gate position]
+  auto request = [&](int c, int k, int slot) {
+    const int src = (4 * (2 * c + (k & 1)) + (k >> 1)) & (kLrGateSteps - 1);
 #pragma unroll
     for (int u = 0; u < kLrDma; ++u) {
       const int block = wave * kLrDma + u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, smem + slot * kLrSlotBytes + block * 1024, 16, lane * 16,
-                                               gs * kLrSlotBytes + block * 1024, 0, 0);
+                                               src * kLrSlotBytes + block * 1024, 0, 0);
     }
   };
 
@@ -167,75 +199,128 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     d.dcout = state_rsrc(a.dc, tile, rows);
     return d;
   };
-  auto issue_loads = [&](LrLoads &ld, const LrLoadDesc &d, int c) {
-    const int soff = c * 64;
+  auto load4 = [&](u32x4 (&dst)[4], const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
+    for (int j = 0; j < 4; ++j) dst[j] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + piece(j), soff, 0);
+  };
+  auto store4 = [&](const float (&v)[16], const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        ld.g[q][h2] = __builtin_amdgcn_raw_buffer_load_b128(d.gates, v_gates + h2 * 16, soff + q * (kHidden * 4), 0);
-      ld.ct[h2] = __builtin_amdgcn_raw_buffer_load_b128(d.cs, v_seq + h2 * 16, soff, 0);
-      ld.cp[h2] = __builtin_amdgcn_raw_buffer_load_b128(d.cprev, d.v_cp + h2 * 16, soff, 0);
-      ld.dh[h2] = __builtin_amdgcn_raw_buffer_load_b128(d.dhs, v_seq + h2 * 16, soff, 0);
-      ld.dc[h2] = __builtin_amdgcn_raw_buffer_load_b128(d.dcin, v_state + h2 * 16, soff, 0);
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4 * j]), __float_as_uint(v[4 * j + 1]),
+                                                   __float_as_uint(v[4 * j + 2]), __float_as_uint(v[4 * j + 3])},
+                                             r, voff + piece(j), soff, 0);
+  };
+  auto at = [](const u32x4 (&v)[4], int e) { return __uint_as_float(v[e >> 2][e & 3]); };
+
+#ifdef RL8_LR_STAMP
+  unsigned long long tw[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 0..7 the barriers' vmcnt, 8 B unpark, 9 C unpark, 10 barrier itself, 11 all,
+  // 12 fragment waits, 13 issue of row operations and requests, 14 gate arithmetic (with its waits and stores), 15 plane split
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#define RL8_LR_T0 const unsigned long long t0_ = __builtin_readcyclecounter()
+#define RL8_LR_T1(i) tw[i] += __builtin_readcyclecounter() - t0_
+#else
+#define RL8_LR_T0
+#define RL8_LR_T1(i)
+#endif
+  // the three load phases of a chunk (see the header) and the arithmetic behind each
+  u32x4 la_o[4], la_ct[4], la_dh[4], la_dc[4];
+  auto issue_a = [&](const LrLoadDesc &d, int c) {
+    load4(la_o, d.gates, v_gates, c * 128 + 3 * (kHidden * 4));
+    load4(la_ct, d.cs, v_seq, c * 128);
+    load4(la_dh, d.dhs, v_seq, c * 128);
+    load4(la_dc, d.dcin, v_state, c * 128);
+  };
+  // park PH (0: phase B, 1: phase C), array AR, piece j of this wave: 1 KiB, lane's 16 bytes at lane * 16
+  auto park4 = [&](int ph, int ar, const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          r, smem + kLrRing * kLrSlotBytes + ph * kLrStageBytes + ((wave * 2 + ar) * 4 + j) * 1024, 16, voff + piece(j), soff, 0, 0);
+  };
+  const unsigned park_read = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + lane * 16;
+  auto issue_b = [&](const LrLoadDesc &d, int c) {
+    park4(0, 0, d.gates, v_gates, c * 128);
+    park4(0, 1, d.gates, v_gates, c * 128 + 2 * (kHidden * 4));
+  };
+  auto issue_c = [&](const LrLoadDesc &d, int c) {
+    park4(1, 0, d.gates, v_gates, c * 128 + 1 * (kHidden * 4));
+    park4(1, 1, d.cprev, d.v_cp, c * 128);
+  };
+  // the parked phase PH back into registers; N = operations the wave has issued behind those loads
+  auto unpark = [&](auto ph_tag, auto n_tag, u32x4 (&x)[4], u32x4 (&y)[4]) {
+    constexpr int PH = decltype(ph_tag)::value;
+    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : decltype(n_tag)::value;
+    {
+      RL8_LR_T0;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+      RL8_LR_T1(8 + PH);
     }
+    const unsigned rd = park_read + PH * kLrStageBytes;
+    x[0] = lds_read_b128<0 * 1024>(rd), x[1] = lds_read_b128<1 * 1024>(rd), x[2] = lds_read_b128<2 * 1024>(rd), x[3] = lds_read_b128<3 * 1024>(rd);
+    y[0] = lds_read_b128<4 * 1024>(rd), y[1] = lds_read_b128<5 * 1024>(rd), y[2] = lds_read_b128<6 * 1024>(rd), y[3] = lds_read_b128<7 * 1024>(rd);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
   };
 
-  // dh carried into the step being computed: dhv[e][c] = dL/dh of unit 16 c + 8 hh + e from the step after it
-  f32x16v dhv[8];
+  // dh carried into the step being computed: dhe[e][c] = dL/dh of unit 32 c + 8 (e >> 2) + 4 hh + (e & 3) from the step
+  // after it (register e of accumulator c)
+  typedef float f32x8v __attribute__((ext_vector_type(8)));
+  f32x8v dhe[16];
   f32x16 acc[8];
-  float dg[4][8];  // [gate position][e]: dG of the chunk whose matrix work comes next
+  float dg[4][16];  // [gate position][e]: dG of the chunk whose matrix work is under way / comes next
+  float dcv[16];    // dL/dc of that chunk (between its phases A and C)
 
-  // the gate arithmetic of chunk c of the step `sd` stores for: loads -> dg, stores of dG and dc
-  auto gate_math = [&](const LrLoads &ld, const LrStoreDesc &sd, int c) {
-    float dc_out[8];
+  auto math_a = [&](const LrStoreDesc &sd, int c) {  // -> dg[0] (o), dcv
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int h2 = e >> 2, j = e & 3;
-      const float gi = __uint_as_float(ld.g[0][h2][j]), gf = __uint_as_float(ld.g[1][h2][j]),
-                  gg = __uint_as_float(ld.g[2][h2][j]), go = __uint_as_float(ld.g[3][h2][j]);
-      const float ct = __uint_as_float(ld.ct[h2][j]), cp = __uint_as_float(ld.cp[h2][j]);
-      const float dh = __uint_as_float(ld.dh[h2][j]) + dhv[e][c];
+    for (int e = 0; e < 16; ++e) {
+      const float go = at(la_o, e), ct = at(la_ct, e);
+      const float dh = at(la_dh, e) + dhe[e][c];
       const float tc = lr_tanh(ct);
-      const float d_o = dh * tc * (go * (1.0f - go));
-      const float dc = __builtin_fmaf(dh * go, 1.0f - tc * tc, __uint_as_float(ld.dc[h2][j]));
-      dg[0][e] = d_o;
-      dg[1][e] = dc * gg * (gi * (1.0f - gi));
-      dg[2][e] = dc * gi * (1.0f - gg * gg);
-      dg[3][e] = dc * cp * (gf * (1.0f - gf));
-      dc_out[e] = dc * gf;
+      dg[0][e] = dh * tc * (go * (1.0f - go));
+      dcv[e] = __builtin_fmaf(dh * go, 1.0f - tc * tc, at(la_dc, e));
     }
-    const int soff = c * 64;
+    store4(dg[0], sd.dgates, v_gates, c * 128 + 3 * (kHidden * 4));
+  };
+  auto math_b = [&](const LrStoreDesc &sd, int c) {  // -> dg[1] (i), dg[2] (g)
+    u32x4 lb_i[4], lb_g[4];
+    unpark(std::integral_constant<int, 0>{}, std::integral_constant<int, kLrBehindB>{}, lb_i, lb_g);
 #pragma unroll
-    for (int pos = 0; pos < 4; ++pos)
+    for (int e = 0; e < 16; ++e) {
+      const float gi = at(lb_i, e), gg = at(lb_g, e);
+      dg[1][e] = dcv[e] * gg * (gi * (1.0f - gi));
+      dg[2][e] = dcv[e] * gi * (1.0f - gg * gg);
+    }
+    store4(dg[1], sd.dgates, v_gates, c * 128);
+    store4(dg[2], sd.dgates, v_gates, c * 128 + 2 * (kHidden * 4));
+  };
+  auto math_c = [&](const LrStoreDesc &sd, int c) {  // -> dg[3] (f), dc out
+    u32x4 lc_f[4], lc_cp[4];
+    unpark(std::integral_constant<int, 1>{}, std::integral_constant<int, kLrBehindC>{}, lc_f, lc_cp);
+    float dc_out[16];
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-        __builtin_amdgcn_raw_buffer_store_b128(
-            u32x4{__float_as_uint(dg[pos][4 * h2]), __float_as_uint(dg[pos][4 * h2 + 1]), __float_as_uint(dg[pos][4 * h2 + 2]),
-                  __float_as_uint(dg[pos][4 * h2 + 3])},
-            sd.dgates, v_gates + h2 * 16, soff + lr_gate(pos) * (kHidden * 4), 0);
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-      __builtin_amdgcn_raw_buffer_store_b128(
-          u32x4{__float_as_uint(dc_out[4 * h2]), __float_as_uint(dc_out[4 * h2 + 1]), __float_as_uint(dc_out[4 * h2 + 2]),
-                __float_as_uint(dc_out[4 * h2 + 3])},
-          sd.dcout, v_state + h2 * 16, soff, 0);
+    for (int e = 0; e < 16; ++e) {
+      const float gf = at(lc_f, e), cp = at(lc_cp, e);
+      dg[3][e] = dcv[e] * cp * (gf * (1.0f - gf));
+      dc_out[e] = dcv[e] * gf;
+    }
+    store4(dg[3], sd.dgates, v_gates, c * 128 + 1 * (kHidden * 4));
+    store4(dc_out, sd.dcout, v_state, c * 128);
   };
 
-  // one gate-step: 16 k of the product, W_hh^T planes from ring slot POS, B planes from dg[POS].  Out tiles in pairs:
-  // two accumulators alternate, so no MFMA waits for the one before it.
-  auto matrix_step = [&](auto pos_tag) {
-    constexpr int POS = decltype(pos_tag)::value;
+  // one gate-step: 16 k of the product, W_hh^T planes from ring slot K & 3, B planes from dg[K >> 1][8 (K & 1) ..+7].
+  // Out tiles in pairs: two accumulators alternate, so no MFMA waits for the one before it.
+  auto matrix_step = [&](auto k_tag) {
+    constexpr int K = decltype(k_tag)::value;
+    constexpr int POS = K >> 1, E0 = 8 * (K & 1);
     u32x4 bh, bm, bl;
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
       uint32_t hi, mid, lo;
-      split_pair(dg[POS][e], dg[POS][e + 1], hi, mid, lo);
+      split_pair(dg[POS][E0 + e], dg[POS][E0 + e + 1], hi, mid, lo);
       bh[e >> 1] = hi;
       bm[e >> 1] = mid;
       bl[e >> 1] = lo;
     }
-    const unsigned ar = a_read + POS * kLrSlotBytes;
+    const unsigned ar = a_read + (K & 3) * kLrSlotBytes;
     u32x4 ah[2][2], am[2][2], al[2][2];  // [buffer][tile of the pair]
     auto fetch = [&](int mp, int s) {
       ah[s][0] = mp == 0 ? lds_read_b128<0 * 1024>(ar) : mp == 1 ? lds_read_b128<2 * 1024>(ar) : mp == 2 ? lds_read_b128<4 * 1024>(ar) : lds_read_b128<6 * 1024>(ar);
@@ -251,8 +336,12 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
       const int s = mp & 1;
       // everything outstanding is this pair's six fragments (lgkmcnt(0): a stray scalar load cannot spoil the count);
       // the next pair's are requested behind the wait and land under this pair's twelve MFMAs
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(ah[s][0]), "+v"(ah[s][1]), "+v"(am[s][0]), "+v"(am[s][1]), "+v"(al[s][0]), "+v"(al[s][1]));
+      {
+        RL8_LR_T0;
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah[s][0]), "+v"(ah[s][1]), "+v"(am[s][0]), "+v"(am[s][1]), "+v"(al[s][0]), "+v"(al[s][1]));
+        RL8_LR_T1(12);
+      }
       if (mp < 3) fetch(mp + 1, s ^ 1);
       f32x16 d0 = acc[2 * mp], d1 = acc[2 * mp + 1];
 #define RL8_LR_MMA(A, B)                                                                                              \
@@ -272,41 +361,58 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     }
   };
 
-  // The barrier that opens gate-step gs: this wave's share of chunk gs has landed (vector-memory operations complete in
-  // issue order: all but the N youngest are done) and every wave is through with the slot the next request overwrites.
-  // N = what the wave has issued behind its request for chunk gs, three gate-steps ago: per position of gs in its unit
-  // chunk, with the order of a chunk's operations [row loads (16) | request (6)] [request] [request] [request | stores (10)].
-  auto open_step = [&](auto pos_tag) {
-    constexpr int POS = decltype(pos_tag)::value;
-    constexpr int N = RL8_LR_SAFE_WAITS ? 0
-                      : POS == 0 ? 2 * kLrDma + kLrStores
-                      : POS == 1 ? 2 * kLrDma + kLrStores + kLrRowLoads
-                      : POS == 2 ? kLrStores + kLrRowLoads + 2 * kLrDma
-                                 : 2 * kLrDma;
+  // The barrier that opens gate-step K of a chunk: this wave's share of its chunk of W_hh^T has landed (vector-memory
+  // operations complete in issue order: all but the N youngest are done) and every wave is through with the slot the
+  // next request overwrites.  N = lr_behind(K): what the wave has issued behind that request, made three gate-steps
+  // earlier, with the order of a gate-step's operations [row loads | request | matrix work | stores]:
+  //   K        0   1   2   3   4   5   6   7
+  //   loads    8   .  16   .   8   .   .   .      (C | A of the next chunk | B of the next chunk)
+  //   stores   .   8   .   .   .   8   .   4      (dG_i, dG_g | dG_f, dc | dG_o of the next chunk)
+  //   N       24  24  32  36  36  20  28  20
+  auto open_step = [&](auto k_tag) {
+    constexpr int K = decltype(k_tag)::value;
+    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : lr_behind(K);
+#ifdef RL8_LR_STAMP
+    {
+      RL8_LR_T0;
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+      RL8_LR_T1(K);
+    }
+    {
+      RL8_LR_T0;
+      asm volatile("s_barrier" ::: "memory");
+      RL8_LR_T1(10);
+    }
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
   };
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-  using P2 = std::integral_constant<int, 2>;
-  using P3 = std::integral_constant<int, 3>;
+  auto K_ = [](auto i) { return std::integral_constant<int, decltype(i)::value>{}; };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+  using K4 = std::integral_constant<int, 4>;
+  using K5 = std::integral_constant<int, 5>;
+  using K6 = std::integral_constant<int, 6>;
+  using K7 = std::integral_constant<int, 7>;
+  (void)K_;
 
   int64_t tile = blockIdx.x;
   if (tile >= tiles) return;  // (the host launches no more workgroups than tiles)
   int t = l - 1;
-  LrLoads ld;
   LrStoreDesc sd = store_desc(tile, t);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) dhv[e] = f32x16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  {
-    const LrLoadDesc d0 = load_desc(tile, t);
-    issue_loads(ld, d0, 0);
-    asm volatile("" ::: "memory");
-    request(0, 0);
-    request(1, 1);
-    request(2, 2);
-    gate_math(ld, sd, 0);
-  }
-  LrLoadDesc nd = load_desc(tile, t);  // where the NEXT chunk's loads come from
+  for (int e = 0; e < 16; ++e) dhe[e] = f32x8v{0, 0, 0, 0, 0, 0, 0, 0};
+  LrLoadDesc nd = load_desc(tile, t);  // where the loads of the current step come from
+  issue_a(nd, 0);
+  issue_b(nd, 0);
+  request(0, 0, 0);
+  request(0, 1, 1);
+  request(0, 2, 2);
+  math_a(sd, 0);
+  // the counted waits of the first chunk assume a full chunk of operations behind each request: drain instead
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   while (true) {
     // position behind this step: the same sequences one step earlier, or the next tile's last step, or nothing
@@ -316,35 +422,53 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     const LrLoadDesc after = load_desc(ntile, nt);
 #pragma unroll 1
     for (int c = 0; c < kLrChunks; ++c) {
-      const int gs = 4 * c;
       const bool wrap = c == kLrChunks - 1;
-      open_step(P0{});
-      issue_loads(ld, wrap ? after : nd, wrap ? 0 : c + 1);
+      const int cn = wrap ? 0 : c + 1;
+      open_step(K0{});
+      { RL8_LR_T0; issue_c(nd, c); RL8_LR_T1(13); }
       asm volatile("" ::: "memory");
-      request((gs + 3) & (kLrGateSteps - 1), 3);
+      { RL8_LR_T0; request(c, 3, 3); RL8_LR_T1(13); }
       if (c == 0) {
 #pragma unroll
         for (int mo = 0; mo < 8; ++mo) acc[mo] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       }
-      matrix_step(P0{});
-      open_step(P1{});
-      request((gs + 4) & (kLrGateSteps - 1), 0);
-      matrix_step(P1{});
-      open_step(P2{});
-      request((gs + 5) & (kLrGateSteps - 1), 1);
-      matrix_step(P2{});
-      open_step(P3{});
-      request((gs + 6) & (kLrGateSteps - 1), 2);
-      matrix_step(P3{});
+      matrix_step(K0{});
+      open_step(K1{});
+      { RL8_LR_T0; request(c, 4, 0); RL8_LR_T1(13); }
+      matrix_step(K1{});
+      { RL8_LR_T0; math_b(sd, c); RL8_LR_T1(14); }
+      open_step(K2{});
+      { RL8_LR_T0; issue_a(wrap ? after : nd, cn); RL8_LR_T1(13); }
+      asm volatile("" ::: "memory");
+      { RL8_LR_T0; request(c, 5, 1); RL8_LR_T1(13); }
+      matrix_step(K2{});
+      open_step(K3{});
+      { RL8_LR_T0; request(c, 6, 2); RL8_LR_T1(13); }
+      matrix_step(K3{});
+      open_step(K4{});
+      { RL8_LR_T0; issue_b(wrap ? after : nd, cn); RL8_LR_T1(13); }
+      asm volatile("" ::: "memory");
+      { RL8_LR_T0; request(c, 7, 3); RL8_LR_T1(13); }
+      matrix_step(K4{});
+      open_step(K5{});
+      { RL8_LR_T0; request(cn, 0, 0); RL8_LR_T1(13); }
+      matrix_step(K5{});
+      { RL8_LR_T0; math_c(sd, c); RL8_LR_T1(14); }
+      open_step(K6{});
+      { RL8_LR_T0; request(cn, 1, 1); RL8_LR_T1(13); }
+      matrix_step(K6{});
+      open_step(K7{});
+      { RL8_LR_T0; request(cn, 2, 2); RL8_LR_T1(13); }
+      matrix_step(K7{});
       if (wrap) {
         // the step's dh is complete: it becomes the carry of the step the next arithmetic belongs to (zero for a new tile)
 #pragma unroll
         for (int cc = 0; cc < kLrChunks; ++cc)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dhv[e][cc] = last_step ? 0.0f : acc[cc >> 1][8 * (cc & 1) + e];
+          for (int e = 0; e < 16; ++e) dhe[e][cc] = last_step ? 0.0f : acc[cc][e];
         sd = store_desc(ntile, nt);
       }
-      gate_math(ld, sd, wrap ? 0 : c + 1);
+      { RL8_LR_T0; math_a(sd, cn); RL8_LR_T1(14); }
     }
     if (last_step && ntile >= tiles) break;
     tile = ntile;
@@ -352,6 +476,11 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     nd = after;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no request may still be writing LDS when the workgroup ends
+#ifdef RL8_LR_STAMP
+  tw[11] = __builtin_readcyclecounter() - t_begin;
+  if (a.stamps && lane == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(a.stamps + i, tw[i]);
+#endif
 }
 
 }  // namespace rl8
@@ -385,7 +514,11 @@ RL8_API int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const 
   }
   const int64_t tiles = (b + kLrRows - 1) / kLrRows;
   const int grid = (int)(tiles < kCUs ? tiles : kCUs);
-  const LrArgs args = {c0, gates, cs, dhs, dgates, dc_scratch, b, l};
+  unsigned long long *stamps = nullptr;
+#ifdef RL8_LR_STAMP
+  if (const char *v = getenv("RL8_LR_STAMP_PTR")) stamps = reinterpret_cast<unsigned long long *>(strtoull(v, nullptr, 0));
+#endif
+  const LrArgs args = {c0, gates, cs, dhs, dgates, dc_scratch, b, l, stamps};
   lstm_rows_backward_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
   return launch_status();
 }

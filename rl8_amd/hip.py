@@ -1330,14 +1330,19 @@ _lstm_colsum_ws: dict[tuple[int, int, int, int], torch.Tensor] = {}
 
 def lstm_backward(
     x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, hs: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor,
-    dhs: torch.Tensor, whht_packed: torch.Tensor, *, split: None | bool = None,
+    dhs: torch.Tensor, whht_packed: None | torch.Tensor, *, split: None | bool = None,
+    rows_packed: None | torch.Tensor = None,
 ) -> dict[str, torch.Tensor]:
     """Parameter gradients of the LSTM given ``dhs`` [B, L, 256] (gradient of every
     ``h_t``) and what ``lstm_forward(..., save=True)`` returned. Returns ``w_ih``,
     ``w_hh``, ``b`` (the gradient of each of the two bias vectors). ``split``: the
     weight-gradient GEMMs on bf16 planes (True) or the fp32 MFMA (False); the caller
     passes the mode its forward ran in (``fused_lstm.use_split``), None reads
-    ``RL8_AMD_LSTM_GEMM`` as the forward's module switch does at import."""
+    ``RL8_AMD_LSTM_GEMM`` as the forward's module switch does at import.
+    ``rows_packed`` (:func:`lstm_rows_backward_pack`): the backward through time runs
+    on bf16 planes too (``rl8_lstm_rows_backward_f32``) instead of the fp32-MFMA kernel
+    that reads ``whht_packed``; only with ``split`` (its dW_ih / bias sums come from the
+    weight-gradient kernel)."""
     x = _dense(x.detach(), torch.float32, "x")
     b, l, d_in = x.shape
     for name, t, shape in (("h0", h0, (b, LSTM_HIDDEN)), ("c0", c0, (b, LSTM_HIDDEN)), ("hs", hs, (b, l, LSTM_HIDDEN)),
@@ -1355,16 +1360,21 @@ def lstm_backward(
     # bias gradient come out of that kernel as column sums of the dG it reads anyway; else
     # the backward call makes one more pass over dG for them.
     fused_colsums = split and lstm_split_supports(d_in)
-    dgates = torch.empty(b, l, 4, H, dtype=torch.float32, device=dev)
     rows = C.c_int(0)
     partials = None
-    if not fused_colsums:
-        width = int(lib.rl8_lstm_backward_partial_floats(d_in))
-        partials = torch.empty(int(lib.rl8_lstm_backward_max_rows()), width, dtype=torch.float32, device=dev)
-    with _timed("lstm_backward", b * l):
-        _check(lib.rl8_lstm_backward_f32(_ptr(x), b, l, d_in, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dhs),
-                                         _ptr(whht_packed), _ptr(dgates), _ptr(partials), C.byref(rows), _stream()),
-               "rl8_lstm_backward_f32")
+    if rows_packed is not None:
+        if not fused_colsums:
+            raise ValueError("rows_packed needs the bf16-plane weight gradient (split) and a compiled input width")
+        dgates = lstm_rows_backward(c0, gates, cs, dhs, rows_packed)
+    else:
+        dgates = torch.empty(b, l, 4, H, dtype=torch.float32, device=dev)
+        if not fused_colsums:
+            width = int(lib.rl8_lstm_backward_partial_floats(d_in))
+            partials = torch.empty(int(lib.rl8_lstm_backward_max_rows()), width, dtype=torch.float32, device=dev)
+        with _timed("lstm_backward", b * l):
+            _check(lib.rl8_lstm_backward_f32(_ptr(x), b, l, d_in, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dhs),
+                                             _ptr(whht_packed), _ptr(dgates), _ptr(partials), C.byref(rows), _stream()),
+                   "rl8_lstm_backward_f32")
     m = b * l
     key = (dev.index or 0, _stream() or 0)
     ws = _wgrad_ws.get(key)

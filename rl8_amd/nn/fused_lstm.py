@@ -27,6 +27,8 @@ ENABLED = True
 #: lstm_split_kernels.hip) where the input width has a compiled variant; "f32": the
 #: fp32-MFMA kernel with the time loop inside (lstm_kernels.hip).
 FORWARD_GEMM = os.environ.get("RL8_AMD_LSTM_GEMM", "split")
+#: The backward through time on bf16 planes, a wave per 32 sequences (lstm_rows_kernels.hip); 0: the fp32-MFMA kernel.
+BACKWARD_ROWS = os.environ.get("RL8_AMD_LSTM_BACKWARD_ROWS", "1") != "0"
 
 
 def _eligible(lstm: nn.LSTM, x: torch.Tensor) -> bool:
@@ -58,6 +60,8 @@ def _packs(lstm: nn.LSTM, transposed: bool) -> torch.Tensor:
         return hit[1]
     if transposed == "split":
         packed = hip.lstm_pack_split(*params)
+    elif transposed == "rows":
+        packed = hip.lstm_rows_backward_pack(params[1])
     else:
         packed = hip.lstm_pack_transposed(params[1]) if transposed else hip.lstm_pack(*params)
     cache[transposed] = (stamp, packed)
@@ -94,7 +98,10 @@ class _FusedLSTM(torch.autograd.Function):
         if dhn is not None:  # h_n is h_{L-1}
             dhs = dhs.clone()
             dhs[:, -1] += dhn
-        g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, _packs(ctx.lstm, True), split=use_split(ctx.lstm))
+        if use_split(ctx.lstm) and BACKWARD_ROWS:
+            g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, split=True, rows_packed=_packs(ctx.lstm, "rows"))
+        else:
+            g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, _packs(ctx.lstm, True), split=use_split(ctx.lstm))
         return None, None, None, g["w_ih"], g["w_hh"], g["b"], g["b"], None, None
 
 

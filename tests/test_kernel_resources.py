@@ -286,3 +286,38 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
     assert_no_inflight_register_access(text, "mlp_rows_backward_gate_kernel", min_hand_loads=6 * 50)
     for name, body in inflight.kernels_of(text):
         assert inflight.packed_war(body) == [], name
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_compiled_lstm_rows_backward_kernel_resources(tmp_path):
+    """lstm_rows_kernels.hip: the barriers of the backward-through-time kernel count the wave's vector-memory operations
+    (s_waitcnt vmcnt(N) with N from a table of loads / stores / requests per gate-step), so the compiled stream must hold
+    exactly those: no scratch (a spill is a vector-memory operation), and between consecutive barriers of the chunk loop
+    the numbers of loads, direct-to-LDS loads and stores of the table; bf16 32x32x16 MFMAs only, no packed fp32."""
+    csrc = os.path.join(ROOT, "rl8_amd", "csrc")
+    asm = tmp_path / "lstm_rows.s"
+    subprocess.run(
+        [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/include", f"-I{csrc}",
+         "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", str(asm), os.path.join(csrc, "lstm_rows_kernels.hip")],
+        check=True, capture_output=True, timeout=900,
+    )
+    text = asm.read_text()
+    assert not re.search(r"\bv_pk_(fma|add|mul)_f32\b", text)
+    body = re.search(r"\.amdhsa_kernel (\S*lstm_rows_backward_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S).group(2)
+    assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0
+    assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 512
+    code = next(b for n, b in inflight.kernels_of(text) if "lstm_rows_backward_kernel" in n)
+    assert "v_mfma_f32_32x32x16_bf16" in code and "scratch_" not in code
+    # the chunk loop: the eight counted barriers in order, and what the wave issues between them
+    ops = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)\n\ts_barrier|(buffer_load_dwordx4[^\n]* lds)|(buffer_load_dwordx4)|(buffer_store_dwordx4)", code)
+    seq = ["B" + w if w else "D" if d else "L" if ld else "S" for w, d, ld, st in ops]
+    bars = [i for i, x in enumerate(seq) if x.startswith("B")]
+    want = ["B24", "B24", "B32", "B36", "B36", "B20", "B28", "B20"]
+    first = next(j for j in range(len(bars) - 7) if [seq[i] for i in bars[j:j + 8]] == want)
+    ends = bars[first + 1:first + 9] if first + 8 < len(bars) else bars[first + 1:first + 8] + [len(seq)]
+    groups = [seq[lo + 1:hi] for lo, hi in zip(bars[first:first + 8], ends)]
+    counts = [(g.count("L"), g.count("D"), g.count("S")) for g in groups]
+    # [row loads, direct-to-LDS loads (parked row loads + 6 of W_hh^T), stores] per gate-step; the four stores of the next
+    # chunk's dG_o follow step 7 on the loop's back edge
+    assert counts[:7] == [(0, 14, 0), (0, 6, 8), (16, 6, 0), (0, 6, 0), (0, 14, 0), (0, 6, 8), (0, 6, 0)], counts
+    assert counts[7][:2] == (0, 6), counts

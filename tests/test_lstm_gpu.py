@@ -200,3 +200,84 @@ def test_lstm_split_step_matches_the_fp32_kernel_and_fp64(b, l, d):
     # inference launch (no saved gates) returns the same states
     again = hip.lstm_forward_split(x, h0, c0, packed, wb, save=False)
     assert torch.equal(again[0], got[0]) and again[3] is None
+
+
+def _rows_backward_inputs(b, l, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    r = lambda *s: torch.rand(*s, device=DEV, generator=g)  # noqa: E731
+    gates = r(b, l, 4, 256)
+    gates[:, :, 2] = gates[:, :, 2] * 2 - 1            # i, f, o in (0, 1), g in (-1, 1)
+    cs = (r(b, l, 256) * 2 - 1) * 1.5
+    c0 = (r(b, 256) * 2 - 1) * 1.5
+    # gradients of a mean loss: tiny, and of very different size from sequence to sequence
+    dhs = (r(b, l, 256) * 2 - 1) * torch.exp(-12 * r(b, 1, 1)) * 1e-3
+    w_hh = (r(1024, 256) * 2 - 1) / 16
+    return c0, gates, cs, dhs, w_hh
+
+
+def _backward_through_time_fp64(c0, gates, cs, dhs, w_hh):
+    b, l = dhs.shape[:2]
+    c0, gates, cs, dhs, w = (t.double() for t in (c0, gates, cs, dhs, w_hh))
+    dg = torch.zeros(b, l, 4, 256, dtype=torch.float64, device=DEV)
+    dh_carry = torch.zeros(b, 256, dtype=torch.float64, device=DEV)
+    dc_carry = torch.zeros_like(dh_carry)
+    for t in range(l - 1, -1, -1):
+        i, f, g, o = gates[:, t, 0], gates[:, t, 1], gates[:, t, 2], gates[:, t, 3]
+        c_prev = cs[:, t - 1] if t > 0 else c0
+        dh = dhs[:, t] + dh_carry
+        tc = torch.tanh(cs[:, t])
+        dg[:, t, 3] = dh * tc * o * (1 - o)
+        dc = dh * o * (1 - tc * tc) + dc_carry
+        dg[:, t, 0] = dc * g * i * (1 - i)
+        dg[:, t, 2] = dc * i * (1 - g * g)
+        dg[:, t, 1] = dc * c_prev * f * (1 - f)
+        dc_carry = dc * f
+        dh_carry = dg[:, t].reshape(b, 1024) @ w
+    return dg
+
+
+@pytest.mark.parametrize("b,l", [(1, 1), (31, 4), (32, 2), (100, 7), (128, 4), (129, 3), (1000, 4), (4101, 2), (33000, 4)])
+def test_lstm_rows_backward_matches_fp64(b, l):
+    """The backward through time on bf16 planes (rl8_lstm_rows_backward_f32; a wave per 32 sequences, ragged last wave and
+    last workgroup, one to seven steps) against an fp64 model of the recurrences: per sequence within 2e-6 of that
+    sequence's largest gate gradient, whatever the sequence's scale (dh spans five decades between sequences: nothing in the
+    kernel is scaled per launch)."""
+    c0, gates, cs, dhs, w_hh = _rows_backward_inputs(b, l, 1000 * b + l)
+    got = hip.lstm_rows_backward(c0, gates, cs, dhs, hip.lstm_rows_backward_pack(w_hh))
+    want = _backward_through_time_fp64(c0, gates, cs, dhs, w_hh)
+    assert bool(torch.isfinite(got).all())
+    scale = want.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-300)
+    assert float(((got.double() - want).abs() / scale).max()) < 2e-6
+
+
+@pytest.mark.parametrize("b,l,d_in", [(33, 3, 1), (300, 5, 5), (2000, 8, 1), (4097, 2, 3)])
+def test_lstm_backward_on_planes_matches_autograd(b, l, d_in):
+    """hip.lstm_backward with the rows kernel (what fused_lstm runs by default) against torch's autograd, as
+    test_lstm_backward_matches_autograd holds the fp32-MFMA kernel; and the two kernels' gradients beside each other."""
+    lstm = reference_lstm(d_in, b + 7 * l)
+    g = torch.Generator(device=DEV).manual_seed(b + 1)
+    x = torch.randn(b, l, d_in, device=DEV, generator=g) * 3
+    h0 = torch.randn(b, 256, device=DEV, generator=g) * 0.5
+    c0 = torch.randn(b, 256, device=DEV, generator=g)
+    dhs = torch.randn(b, l, 256, device=DEV, generator=g) / (b * l)
+    with torch.backends.cudnn.flags(enabled=False):
+        out, _ = lstm(x, (h0.unsqueeze(0), c0.unsqueeze(0)))
+    out.backward(dhs)
+    hs, hn, cn, gates, cs = hip.lstm_forward(x, h0, c0, pack(lstm), save=True)
+    grads = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, split=True,
+                              rows_packed=hip.lstm_rows_backward_pack(lstm.weight_hh_l0))
+    old = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, hip.lstm_pack_transposed(lstm.weight_hh_l0), split=True)
+    for name, want in (("w_hh", lstm.weight_hh_l0.grad), ("w_ih", lstm.weight_ih_l0.grad), ("b", lstm.bias_ih_l0.grad)):
+        scale = float(want.abs().max()) + 1e-12
+        assert float((grads[name] - want).abs().max()) / scale < 2e-5, name
+        assert float((grads[name] - old[name]).abs().max()) / scale < 5e-6, name
+    with pytest.raises(ValueError, match="rows_packed needs"):
+        hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, split=False, rows_packed=hip.lstm_rows_backward_pack(lstm.weight_hh_l0))
+
+
+def test_lstm_rows_backward_repeats_bit_for_bit():
+    c0, gates, cs, dhs, w_hh = _rows_backward_inputs(8192, 4, 5)
+    packed = hip.lstm_rows_backward_pack(w_hh)
+    first = hip.lstm_rows_backward(c0, gates, cs, dhs, packed)
+    for trial in range(20):
+        assert torch.equal(first, hip.lstm_rows_backward(c0, gates, cs, dhs, packed)), trial

@@ -13,7 +13,9 @@ for what in "$@"; do
     make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/objstamp" OUT="$PWD/build_diag/librl8_amd_stamp.so" \
          FLAGS_EXTRA="-DRL8_ROWS_STAMP"
   elif [ "${what#lr}" != "$what" ]; then  # lr<bits>: RL8_LR_DIAG of lstm_rows_kernels.hip; lrsafe: vmcnt(0) at every barrier
-    if [ "$what" = lrsafe ]; then extra="-DRL8_LR_SAFE_WAITS=1"; else extra="-DRL8_LR_DIAG=${what#lr}"; fi
+    if [ "$what" = lrsafe ]; then extra="-DRL8_LR_SAFE_WAITS=1"
+    elif [ "$what" = lrstamp ]; then extra="-DRL8_LR_STAMP"
+    else extra="-DRL8_LR_DIAG=${what#lr}"; fi
     make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/obj$what" OUT="$PWD/build_diag/librl8_amd_$what.so" FLAGS_EXTRA="$extra"
   elif [ "$what" = trace ]; then
     make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/objtrace" OUT="$PWD/build_diag/librl8_amd_trace.so" \
