@@ -969,6 +969,22 @@ def mlp_tower_forward_split(
     return (out, h1, h2, gate) if save_gate else (out, h1, h2)
 
 
+def _column_sums(t: torch.Tensor) -> torch.Tensor:
+    """``t.sum(0)`` of a tall ``[m, n]`` matrix with a few columns.  torch's reduction over
+    the long dimension of a [2^23, 3] tensor runs at 24 GB/s (4.1 ms per call, 14 % of the
+    CartPole bench's kernel time); folded to [m / 1024, 1024 n] the same sum is a column
+    reduction with a contiguous inner dimension."""
+    m, n = t.shape
+    fold = 1024
+    if n == 1 or m < 64 * fold or not t.is_contiguous():
+        return t.sum(0)
+    groups = m // fold
+    out = t[: groups * fold].view(groups, fold * n).sum(0).view(fold, n).sum(0)
+    if groups * fold < m:
+        out = out + t[groups * fold :].sum(0)
+    return out
+
+
 def mlp_tower_backward(
     x: torch.Tensor, h1: None | torch.Tensor, h2: None | torch.Tensor, dout: torch.Tensor,
     w2t_packed: torch.Tensor, w3: torch.Tensor,
@@ -1108,7 +1124,7 @@ def mlp_tower_backward(
         "b2": small[o1 + MLP_HIDDEN : o1 + 2 * MLP_HIDDEN],
         "w3": small[o1 + 2 * MLP_HIDDEN : o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN].view(n_out, MLP_HIDDEN),
         # (the fused bf16-plane backward leaves db3 -- a column sum of dout -- to the caller)
-        "b3": dout.sum(0) if split else small[o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN :],
+        "b3": _column_sums(dout) if split else small[o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN :],
         "w2": dw2 if split else (mlp_wgrad_split(dz2, x, w1, b1) if wgrad_split else mlp_wgrad(dz2, h1)),
     }
     return grads
