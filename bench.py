@@ -94,8 +94,8 @@ ALGORITHMIC_BYTES = {
 # passes over tools/kernel_microbench.py at config-2 shapes; corrected as
 # MI355X_MICROARCH.md prescribes; summary committed under profiles/). Scaled by
 # units to the launch size bench.py uses.
-PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_microbench.json") for r in (2, 1))
-                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r02_pmc_traffic_microbench.json"))
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_microbench.json") for r in (3, 2, 1))
+                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r03_pmc_traffic_microbench.json"))
 PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in that profiled launch)
     "ppo_loss_categorical": ("ppo_loss_categorical_kernel", 1 << 22),
     "ppo_loss_normal": ("ppo_loss_normal_kernel", 1 << 22),
@@ -113,9 +113,10 @@ PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in
     "mlp_wgrad": ("mlp_wgrad_kernel", 1 << 20),
 }
 PMC_KERNEL_F16 = {  # the fp16-plane kernels (forward, data gradient), same profiled shapes
-    "mlp_tower_forward": ("mlp_tower_forward_f16_kernel<1, 2, 0>", 1 << 20),
+    # (round 3: the rows-per-wave forward, mlp_rows_kernels.hip; template <d_in, n_out, SAVE, ring, diag>)
+    "mlp_tower_forward": ("mlp_rows_forward_kernel<1, 2, 0, 4, 0>", 1 << 20),
     # (training forward of a rank-one head keeps the gate bits only: SAVE mode 2; mode 1 stores h2 as well)
-    "mlp_tower_forward_save": ("mlp_tower_forward_f16_kernel<1, 2, 2>", 1 << 20),
+    "mlp_tower_forward_save": ("mlp_rows_forward_kernel<1, 2, 2, 4, 0>", 1 << 20),
     "mlp_tower_backward": ("mlp_tower_backward_f16_kernel<1, 2, false>", 1 << 20),
 }
 PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
@@ -126,7 +127,7 @@ PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
 }
 PMC_KERNEL_GATE = {  # gate-mode kernels (heads whose dZ2 is gate * d * w3e)
     "mlp_wgrad_gate": ("mlp_wgrad_gate_kernel<1, false, true>", 1 << 20),
-    "mlp_tower_backward_gate": ("mlp_tower_backward_f16_kernel<1, 1, true>", 1 << 20),
+    "mlp_tower_backward_gate": ("mlp_rows_backward_gate_kernel<1, 1, 4>", 1 << 20),
 }
 
 

@@ -353,7 +353,12 @@ int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const f
  * as rl8_mlp_tower_forward_split_f32 (and save_gate2 may be given WITHOUT save_h2: see rl8_mlp_wgrad_gate_bits_f32);
  * w2_f16 (rl8_mlp_f16_packed_bytes() bytes:
  * two fp16 planes in fragment order + {scale, 1/scale}) comes from
- * rl8_mlp_pack_w2_f16.  Replaces the same reference call sites
+ * rl8_mlp_pack_w2_f16.  The fragment order depends on `transposed`: 0 (this forward; since round 3 a kernel of
+ * v_mfma_f32_16x16x32_f16, a wave per 32 rows) packs 16-byte unit ((hs*8 + ct)*2 + plane)*64 + lane with
+ * B(col = 16 (8 (hs & 1) + ct) + (lane & 15), k = 32 (hs >> 1) + 8 (lane >> 4) + e), e = 0..7; 1 (the data-gradient
+ * kernels, 32x32x16) keeps unit ((s*8 + ct)*2 + plane)*64 + lane with B(col = 32 ct + (lane & 31),
+ * k = 16 s + 8 (lane >> 5) + e) of the transposed matrix.  A pack made for one is not valid for the other.
+ * Replaces the same reference call sites
  * (rl8/models/_feedforward.py:115-132 forward of the 256-256 towers). */
 int64_t rl8_mlp_f16_packed_bytes(void);
 int rl8_mlp_forward_f16_supports(int d_in, int n_out); /* as rl8_mlp_forward_split_supports */

@@ -13,10 +13,12 @@ timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gputests.
 timeout -k 10 400 python tools/kernel_microbench.py --rounds 20 > gpurun_out/${TAG}_kernel_microbench.txt 2>&1 || { echo microbench failed; tail -5 gpurun_out/${TAG}_kernel_microbench.txt; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_${TAG}" -o bench --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof_bench.log" 2>&1 || { echo "rocprof stats failed"; exit 1; }
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$R/gpurun_out/pmc_fetch" -o mb --output-format csv -- python3 "$R/tools/kernel_microbench.py" --rounds 1 > "$R/gpurun_out/pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; exit 1; }
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$R/gpurun_out/pmc_write" -o mb --output-format csv -- python3 "$R/tools/kernel_microbench.py" --rounds 1 > "$R/gpurun_out/pmc_write.log" 2>&1 || { echo "pmc write failed"; exit 1; }
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_${TAG}_cfg5" -o bench --output-format csv -- python3 "$R/bench.py" --recurrent --num-envs 8192 --horizon 256 --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof_cfg5.log" 2>&1 || echo "rocprof stats (recurrent) failed"
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$R/gpurun_out/pmc_fetch" -o mb --output-format csv -- python3 "$R/tools/kernel_microbench.py" --rounds 1 > "$R/gpurun_out/pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; exit 1; }
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$R/gpurun_out/pmc_write" -o mb --output-format csv -- python3 "$R/tools/kernel_microbench.py" --rounds 1 > "$R/gpurun_out/pmc_write.log" 2>&1 || { echo "pmc write failed"; exit 1; }
 cd "$R"
 python tools/summarize_profiles.py stats "$(find gpurun_out/prof_${TAG} -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_bench_kernel_stats.csv || exit 1
+python tools/summarize_profiles.py stats "$(find gpurun_out/prof_${TAG}_cfg5 -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_cfg5_kernel_stats.csv || echo "no recurrent kernel stats"
 python tools/summarize_profiles.py pmc "$(find gpurun_out/pmc_fetch -name '*counter_collection.csv' | head -1)" "$(find gpurun_out/pmc_write -name '*counter_collection.csv' | head -1)" gpurun_out/${TAG}_pmc_traffic_microbench.json || exit 1
 cp gpurun_out/${TAG}_pmc_traffic_microbench.json profiles/${TAG}_pmc_traffic_microbench.json   # the bench lines below carry this build's traffic
 timeout -k 10 500 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err || { echo bench failed; tail -5 gpurun_out/${TAG}_bench_n1.err; exit 1; }
@@ -25,8 +27,10 @@ timeout -k 10 300 python bench.py --env continuous --distribution squashed --ste
 timeout -k 10 300 python bench.py --recurrent --num-envs 8192 --horizon 256 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg5.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --env mountain_car --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_mountain_car.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --env pendulum --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_pendulum.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --minibatches 8 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_minibatches8.json 2>/dev/null || echo "minibatch bench failed"
+timeout -k 10 300 python tools/diag/lstm_rows_check.py --time > gpurun_out/${TAG}_lstm_rows_backward.txt 2>&1 || echo "lstm rows check failed"
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --single-device --num-envs 262144 --steps 3 --warmup 1 > gpurun_out/${TAG}_b_2rank_rehearsal.json 2>/dev/null || exit 1
-for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_mountain_car b_pendulum b_2rank_rehearsal; do python -c "
+for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_mountain_car b_pendulum b_minibatches8 b_2rank_rehearsal; do python -c "
 import json; d=json.loads(open('gpurun_out/${TAG}_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value']), round(d['ms_per_step'],1), round(d['collect_ms_per_step'],1), round(d['update_ms_per_step'],1))"; done
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 echo done
