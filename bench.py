@@ -67,7 +67,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy 
 HBM_COPY_CEILING_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (= fp32 vector) peak, MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (spec), MI355X_MICROARCH.md; 1750 sustained on changing operands
-PLANE_PRODUCTS = {"bf16x3-split": 6, "f16x2-split": 3, "bf16-gate-x3": 3, "f16-gate-x2": 2}  # 16-bit MFMA products per fp32 product, by scheme
+PLANE_PRODUCTS = {"bf16x3-split": 6, "f16x2-split": 3, "bf16-gate-x3": 3, "f16-gate-x2": 2, "f16-gatebits-x2": 2}  # 16-bit MFMA products per fp32 product, by scheme
 
 # MFMA-bound kernels: algorithmic FLOP per unit (row) for the default towers,
 # 2 * (256*d_in + 256*256 + 256*n_out); the backward kernel does the data-gradient
@@ -126,7 +126,8 @@ PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
     "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2>", 1 << 20),
 }
 PMC_KERNEL_GATE = {  # gate-mode kernels (heads whose dZ2 is gate * d * w3e)
-    "mlp_wgrad_gate": ("mlp_wgrad_gate_kernel<1, false, true>", 1 << 20),
+    # (template <d_in, PAIR, BITS, F16>: the value tower's kernel, gate bits, two fp16 planes)
+    "mlp_wgrad_gate": ("mlp_wgrad_gate_kernel<1, false, true, true>", 1 << 20),
     "mlp_tower_backward_gate": ("mlp_rows_backward_gate_kernel<1, 1, 4>", 1 << 20),
 }
 
@@ -147,7 +148,7 @@ def pmc_traffic(name: str, units_per_launch: float, gemm: str = "f32"):
     except OSError:
         return None
     table = {"f16x2-split": PMC_KERNEL_F16, "bf16x3-split": PMC_KERNEL_SPLIT, "bf16-gate-x3": PMC_KERNEL_GATE,
-             "f16-gate-x2": PMC_KERNEL_GATE}.get(gemm, PMC_KERNEL)
+             "f16-gate-x2": PMC_KERNEL_GATE, "f16-gatebits-x2": PMC_KERNEL_GATE}.get(gemm, PMC_KERNEL)
     needle, units = table.get(name, (None, 1))
     for kernel, rec in summary.items():
         if needle and needle in kernel:
@@ -523,8 +524,8 @@ def run(args: argparse.Namespace) -> None:
         if name in ("mlp_tower_forward", "mlp_tower_forward_save"):
             ok = fused_mlp.FORWARD_GEMM in planes and all(hip.mlp_forward_split_supports(d, n) for d, n in widths)
             f16 = ok and fused_mlp.FORWARD_GEMM == "f16" and all(hip.mlp_forward_f16_supports(d, n) for d, n in widths)
-        elif name == "mlp_wgrad_gate":  # rank-one heads: gate plane x three planes of dOut * h1
-            return "bf16-gate-x3"
+        elif name == "mlp_wgrad_gate":  # rank-one heads: gate plane x the planes of dOut * h1 (two fp16, or three bf16)
+            return "bf16-gate-x3" if os.environ.get("RL8_WGRAD_GATE_PLANES", "f16").startswith("b") else "f16-gatebits-x2"
         elif name == "mlp_tower_backward_gate":  # rank-one heads: gate plane x two planes of w3e * W2
             return "f16-gate-x2"
         elif name == "mlp_wgrad":  # the bf16-plane weight-gradient kernel takes any width (and stays on bf16 planes)
@@ -624,6 +625,8 @@ def run(args: argparse.Namespace) -> None:
                 "flop_per_launch": top["executed_bf16_flop_per_launch"],
                 "flop_definition": ("3 bf16 plane products x 2*256*256 per row (ReLU gate as one exact bf16 plane x the three"
                                     " planes of dOut*h1, fp32 accumulate)" if top["gemm"] == "bf16-gate-x3" else
+                                    "2 fp16 plane products x 2*256*256 per row (ReLU gate as one exact fp16 plane x the two"
+                                    " planes of dOut*h1 scaled per column, fp32 accumulate)" if top["gemm"] == "f16-gatebits-x2" else
                                     "2 fp16 plane products x 2*256*256 per row (ReLU gate as one exact fp16 plane x the two"
                                     " planes of w3e*W2, fp32 accumulate)" if top["gemm"] == "f16-gate-x2" else
                                     "3 fp16 plane products x 2*256*256 per row (fp32 operands scaled by powers of two and"

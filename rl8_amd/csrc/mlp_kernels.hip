@@ -923,7 +923,8 @@ RL8_API int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const fl
 }
 
 RL8_API int64_t rl8_mlp_wgrad_workspace_bytes(void) {
-  return (int64_t)kCUs * kHidden * kHidden * (int64_t)sizeof(float);
+  // one 256 x 256 slab per CU, and 256 bytes behind them (rl8_mlp_wgrad_gate_bits_f32's operand bounds)
+  return (int64_t)kCUs * kHidden * kHidden * (int64_t)sizeof(float) + 256;
 }
 
 RL8_API int rl8_mlp_wgrad_strided_f32(const float *dz2, int64_t dz2_pitch, const float *h1,

@@ -1123,6 +1123,9 @@ struct WgradFusedArgs {
   // gate-plane kernel in BITS mode only: the gate bits of h2 ([m][8] words) instead of h2 itself, and b2
   const uint32_t *gate2 = nullptr;
   const float *b2 = nullptr;
+  // ... on fp16 planes (F16): {max |dOut column 0|, max |x column c|, c < d_in} over the rows of the whole call
+  // (wgrad_gate_bounds_kernel), as the bit patterns of non-negative floats
+  const uint32_t *bounds = nullptr;
 };
 
 // LOADH: both operands come from memory -- dZ rows at pitch `ops.dz_pitch`, h1 rows at
@@ -1566,11 +1569,21 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 constexpr int kWgOperandA = 2 * kHidden * 16;             // gate plane: [sample half][column] x 16 B
 constexpr int kWgStageBytes = kWgOperandA + kWsOperandBytes;  // gate | three planes of dOut * h1
 
-template <int DIN, bool PAIR = false, bool BITS = false>
+// F16 (round 3, with BITS): the second operand dOut[s] * h1[s][i] as TWO fp16 planes of its value times a power of two
+// per COLUMN i -- the reduction runs over samples, so a factor that depends on i alone comes out of the sum -- chosen
+// from a bound on the column: max_s |dOut[s]| * (|b1[i]| + sum_c max_s |x[s][c]| |w1[i][c]|), placed below 2^14.  The
+// maxima over the call's rows come from one pass over dOut and x in front of the first segment
+// (wgrad_gate_bounds_kernel: 0.5 % of the call).  TWO plane products per 16 samples instead of three, four VALU
+// instructions per pair to form the planes instead of eleven.  Accuracy: the planes carry 22 bits of every term within
+// 2^-17 of its column's bound; smaller terms keep an absolute error of 2^-39 of the bound (fp16's subnormal spacing) --
+// of the column's sum that is far below what the fp32 accumulation over 2^23 samples itself leaves.  Against fp64:
+// tests/test_mlp_split_gpu.py (same bars as the bf16 planes: error / max |dW2|).
+template <int DIN, bool PAIR = false, bool BITS = false, bool F16 = false>
 __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     const float *__restrict__ h2, const float *__restrict__ x, const float *__restrict__ w1,
     const float *__restrict__ b1, int64_t m, float *__restrict__ slabs, WgradFusedArgs fused) {
   static_assert(DIN > 0, "compiled input widths only");
+  static_assert(!F16 || BITS, "the fp16 planes go with the gate bits");
   constexpr int kIn = DIN, d_in = DIN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = lds_offset(smem);
@@ -1579,6 +1592,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   const int wj = wave >> 1, wi = wave & 1;  // j-tiles {2wj, 2wj+1}, i-tiles {4wi .. 4wi+3}
   const int col = tid & 255;                // producer: column (j of the gate and i of h1) ...
   const int kh = wave >> 2;                 // ... and which eight samples of the chunk (wave-uniform)
+  [[maybe_unused]] float col_scale = 1.0f;  // F16: this thread's column's power of two
+  [[maybe_unused]] float *inv_scales = reinterpret_cast<float *>(smem + 4 * kWgStageBytes);  // F16: [256], for the epilogue
 
   const unsigned a_read = lds0 + (hh * kHidden + 64 * wj + l32) * 16;
   const unsigned b_read = lds0 + kWgOperandA + (hh * kHidden + 128 * wi + l32) * 16;
@@ -1589,6 +1604,15 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   for (int c = 0; c < kIn; ++c) w1r[c] = w1[col * d_in + c];
   const float b1r = b1[col];
   float gsum = 0.0f, dw3a = 0.0f;  // sum_s G dOut (db2 / W3) and dW3 of this thread's column and sample half
+  if constexpr (F16) {
+    float hb = __builtin_fabsf(b1r);
+#pragma unroll
+    for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[1 + c]), __builtin_fabsf(w1r[c]), hb);
+    // (fp32 rounding of the bound itself: a hair above)
+    const int e = f16_bound_exponent(__uint_as_float(fused.bounds[0]) * hb * 1.0001f);
+    col_scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
+    if (kh == 0) inv_scales[col] = __builtin_amdgcn_ldexpf(1.0f, e - kF16Top);
+  }
 
   const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
   const int64_t stride = gridDim.x;
@@ -1652,7 +1676,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
         for (int e = 0; e < 8; e += 2) {
           const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)__float_as_uint(h2v[e]), (unsigned)(col & 31), 1u);
           const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)__float_as_uint(h2v[e + 1]), (unsigned)(col & 31), 1u);
-          g[e >> 1] = (m0 & 0x00003f80u) | (m1 & 0x3f800000u);  // bf16 1.0 / 0.0
+          g[e >> 1] = F16 ? (m0 & 0x00003c00u) | (m1 & 0x3c000000u)   // fp16 1.0 / 0.0
+                          : (m0 & 0x00003f80u) | (m1 & 0x3f800000u);  // bf16 1.0 / 0.0
           gsum += __uint_as_float(m0 & __float_as_uint(dout_of(e)));
           gsum += __uint_as_float(m1 & __float_as_uint(dout_of(e + 1)));
         }
@@ -1675,6 +1700,19 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
 #pragma unroll
       for (int c = 0; c < kIn; ++c) v = __builtin_fmaf(xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], w1r[c], v);
       b[e] = relu1(v) * dout_of(e);
+    }
+    if constexpr (F16) {
+      u32x4 planes[2];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        uint32_t hi, lo;
+        f16_pair_scaled(b[e], b[e + 1], col_scale, hi, lo);
+        planes[0][e >> 1] = hi;
+        planes[1][e >> 1] = lo;
+      }
+      lds_write_b128<kWgOperandA>(addr, planes[0]);
+      lds_write_b128<kWgOperandA + kWsPlane>(addr, planes[1]);
+      return;
     }
     u32x4 planes[3];
 #pragma unroll
@@ -1708,7 +1746,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     constexpr int S = decltype(stage_tag)::value;
     const unsigned ar = a_read + S * kWgStageBytes, br = b_read + S * kWgStageBytes;
     u32x4(&G)[2] = *(P == 0 ? &f.ah : &f.am);
-    u32x4(&B0)[4] = *(P == 0 ? &f.bh : &f.bm);
+    u32x4(&B0)[4] = *((F16 || P == 0) ? &f.bh : &f.bm);  // (F16: the hi planes always in X, the lo planes in Y)
     G[0] = lds_read_b128<0>(ar);
     B0[0] = lds_read_b128<0>(br);
     B0[1] = lds_read_b128<512>(br);
@@ -1727,6 +1765,36 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     constexpr int S = decltype(stage_tag)::value;
     const unsigned br = b_read + S * kWgStageBytes;
     u32x4(&G)[2] = *(P == 0 ? &f.ah : &f.am);
+    if constexpr (F16) {
+      // two planes: X = f.bh holds the hi planes (in from the previous step / prologue), Y = f.bm takes the lo planes;
+      // the next chunk's gate and hi planes are fetched behind the barrier under the lo products
+      u32x4(&X)[4] = f.bh;
+      u32x4(&Y)[4] = f.bm;
+      Y[0] = lds_read_b128<kWsPlane>(br);
+      Y[1] = lds_read_b128<kWsPlane + 512>(br);
+      Y[2] = lds_read_b128<kWsPlane + 1024>(br);
+      Y[3] = lds_read_b128<kWsPlane + 1536>(br);
+      __builtin_amdgcn_sched_barrier(0);
+      f16_mma<FIRST>(G, X, acc);  // gate x hi
+      load_h2(hq[P], n + 3);
+      produce(hq[P ^ 1], (S + 2) & 3);
+      request_scalars(n + 3);
+      wait_lds<0>(Y[0], Y[1], Y[2], Y[3]);  // (with the scalar loads: nothing counts on order here)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((S & 1) != 0) lds_barrier();
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      scalars_landed();
+      if constexpr (P == 0) first_reads(P1{}, std::integral_constant<int, (S + 1) & 3>{});
+      else first_reads(P0{}, std::integral_constant<int, (S + 1) & 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+      f16_mma<false>(G, Y, acc);  // gate x lo
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        u32x4(&GN)[2] = *(P == 0 ? &f.am : &f.ah);
+        wait_lds<0>(GN[0], GN[1], X[0], X[1], X[2], X[3]);
+      }
+      return;
+    }
     u32x4(&B0)[4] = *(P == 0 ? &f.bh : &f.bm);
     u32x4(&B1)[4] = *(P == 0 ? &f.bm : &f.bh);
     // G and B0 (hi planes) are in (previous step / prologue); the mid planes:
@@ -1814,7 +1882,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
       const int j = 64 * wj + 32 * ja + (r & 3) + 8 * (r >> 2) + 4 * hh;
       const float w3j = BITS ? 1.0f : w3_of(j);  // (BITS: the slabs hold M; the reduction applies W3)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) slab[j * kHidden + 128 * wi + 32 * t + l32] = acc[ja][t][r] * w3j;
+      for (int t = 0; t < 4; ++t) {
+        const int i = 128 * wi + 32 * t + l32;
+        slab[j * kHidden + i] = F16 ? acc[ja][t][r] * inv_scales[i] : acc[ja][t][r] * w3j;
+      }
     }
 
   // Head gradients: fold the two sample halves (kh) of a column through LDS in a fixed
@@ -1931,18 +2002,71 @@ static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const fl
   return launch_status();
 }
 
-template <int DIN, bool PAIR = false, bool BITS = false>
+template <int DIN, bool PAIR = false, bool BITS = false, bool F16 = false>
 static int launch_wgrad_gate(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
                              const float *b1, int64_t m, float *slabs, WgradFusedArgs fused) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN, PAIR, BITS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN, PAIR, BITS, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_wgrad_gate_kernel<DIN, PAIR, BITS><<<grid, kWsThreads, 4 * kWgStageBytes, s>>>(h2, x, w1, b1, m, slabs, fused);
+  // (F16: + the columns' inverse powers of two behind the four stages)
+  mlp_wgrad_gate_kernel<DIN, PAIR, BITS, F16><<<grid, kWsThreads, 4 * kWgStageBytes + (F16 ? kHidden * 4 : 0), s>>>(
+      h2, x, w1, b1, m, slabs, fused);
   return launch_status();
+}
+
+// max |dOut[s][0]| and max |x[s][c]| per column c over m rows -> bounds[0], bounds[1 + c] (bit patterns of non-negative
+// floats, combined with atomic max on words the caller zeroed).  dOut rows have NOUT floats, x rows DIN; both are read
+// as flat 16-byte vectors wherever aligned, the column of a flat index being its remainder.
+template <int DIN, int NOUT>
+__global__ __launch_bounds__(kBlock) void wgrad_gate_bounds_kernel(const float *__restrict__ dout, const float *__restrict__ x,
+                                                                   int64_t m, uint32_t *__restrict__ bounds) {
+  __shared__ float red[kBlock / kWave][1 + DIN];
+  float mx[DIN], md = 0.0f;
+#pragma unroll
+  for (int c = 0; c < DIN; ++c) mx[c] = 0.0f;
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x, threads = (int64_t)gridDim.x * kBlock;
+  auto scan = [&](const float *p, int64_t n, auto fold) {  // fold(flat index, value) over p[0 .. n)
+    const int64_t vecs = ((uintptr_t)p & 15) == 0 ? n / 4 : 0;
+    for (int64_t q = tid; q < vecs; q += threads) {
+      const f32x4 v = reinterpret_cast<const f32x4 *>(p)[q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fold(4 * q + i, v[i]);
+    }
+    for (int64_t idx = 4 * vecs + tid; idx < n; idx += threads) fold(idx, p[idx]);
+  };
+  scan(dout, m * NOUT, [&](int64_t idx, float v) {
+    if (NOUT == 1 || idx % NOUT == 0) md = __builtin_fmaxf(md, __builtin_fabsf(v));
+  });
+  scan(x, m * DIN, [&](int64_t idx, float v) {
+    const int c = (int)(idx % DIN);
+#pragma unroll
+    for (int k = 0; k < DIN; ++k)
+      if (k == c) mx[k] = __builtin_fmaxf(mx[k], __builtin_fabsf(v));
+  });
+  auto wave_max = [](float v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_down(v, off, kWave));
+    return v;
+  };
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  md = wave_max(md);
+#pragma unroll
+  for (int c = 0; c < DIN; ++c) mx[c] = wave_max(mx[c]);
+  if (lane == 0) {
+    red[wave][0] = md;
+#pragma unroll
+    for (int c = 0; c < DIN; ++c) red[wave][1 + c] = mx[c];
+  }
+  __syncthreads();
+  if (threadIdx.x <= DIN) {
+    float v = red[0][threadIdx.x];
+    for (int w = 1; w < kBlock / kWave; ++w) v = __builtin_fmaxf(v, red[w][threadIdx.x]);
+    atomicMax(bounds + threadIdx.x, __float_as_uint(v));
+  }
 }
 
 // flag[0] |= 1 if any row has dout[s][0] + dout[s][1] != 0 (bit patterns: g1 must be exactly -g0).
@@ -2256,16 +2380,36 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   const int off_dw3 = kHidden * d_in + 2 * kHidden;
   hipStream_t s = (hipStream_t)stream;
+  // RL8_WGRAD_GATE_PLANES=bf16: the three-plane kernel (A/B runs); default: two fp16 planes
+  static const bool f16 = [] {
+    const char *v = getenv("RL8_WGRAD_GATE_PLANES");
+    return !(v && v[0] == 'b');
+  }();
+  // the bounds live behind the slabs in the workspace (rl8_mlp_wgrad_workspace_bytes)
+  uint32_t *bounds = reinterpret_cast<uint32_t *>(workspace + (int64_t)kCUs * kHidden * kHidden);
+  if (f16) {
+    if (hipMemsetAsync(bounds, 0, 32, s) != hipSuccess) return launch_status();
+    const int bgrid = (int)(m / (4 * kBlock) < 1 ? 1 : m / (4 * kBlock) > kCUs ? kCUs : m / (4 * kBlock));
+#define RL8_WGRAD_BOUNDS(D) \
+  if (d_in == D) { \
+    if (n_out == 2) wgrad_gate_bounds_kernel<D, 2><<<bgrid, kBlock, 0, s>>>(dout, x, m, bounds); \
+    else wgrad_gate_bounds_kernel<D, 1><<<bgrid, kBlock, 0, s>>>(dout, x, m, bounds); \
+  }
+    RL8_WGRAD_BOUNDS(1) RL8_WGRAD_BOUNDS(2) RL8_WGRAD_BOUNDS(3) RL8_WGRAD_BOUNDS(5)
+#undef RL8_WGRAD_BOUNDS
+  }
   for (int64_t at = 0; at < m; at += kWgradSegmentRows) {  // segments summed in order, as rl8_mlp_wgrad_fused_split_f32
     const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
     const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
     const int grid = at == 0 ? g2 : (int)(chunks < g2 ? chunks : g2);
-    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0, gate2 + at * 8, b2};
+    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0, gate2 + at * 8, b2, bounds};
     const float *xs = x + at * d_in;
     int status = RL8_ESIZE;
 #define RL8_WGRAD_BITS(D) \
   if (d_in == D) \
-    status = n_out == 2 ? launch_wgrad_gate<D, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
+    status = f16 ? (n_out == 2 ? launch_wgrad_gate<D, true, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
+                               : launch_wgrad_gate<D, false, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused)) \
+           : n_out == 2 ? launch_wgrad_gate<D, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
                         : launch_wgrad_gate<D, false, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused);
     RL8_WGRAD_BITS(1) RL8_WGRAD_BITS(2) RL8_WGRAD_BITS(3) RL8_WGRAD_BITS(5)
 #undef RL8_WGRAD_BITS

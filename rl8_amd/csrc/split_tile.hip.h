@@ -262,6 +262,20 @@ __device__ __forceinline__ void f16_pair(float x0, float x1, uint32_t &hi, uint3
   lo = __builtin_bit_cast(uint32_t, lp);
 }
 
+// (x0, x1) * s -> packed fp16 pairs hi = fp16(x * s), lo = fp16(x * s - hi), s a power of two (x * s exact),
+// element 0 in the low half.  v_fma_mix{lo,hi}_f16 compute fma(a, b, c) in fp32 from fp32 or fp16 sources
+// (op_sel_hi: which sources are fp16, op_sel: their half) and round ONCE to fp16 into one half of the
+// destination, keeping the other: four instructions per pair where cvt / cvt back / sub / cvt takes eight.
+// (The compiler itself pairs mixlo + mixhi on one register like this -- no wait state between them.)
+__device__ __forceinline__ void f16_pair_scaled(float x0, float x1, float s, uint32_t &hi, uint32_t &lo) {
+  asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+      "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+      "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(hi), "=&v"(lo)
+      : "v"(x0), "v"(x1), "v"(s));
+}
+
 // bound < 2^e for the power of two that scales an operand (2^(14 - e)); bounds below 2^-80
 // (and zero) keep a finite factor: such operands are far below fp16's top anyway.
 __device__ __forceinline__ int f16_bound_exponent(float bound) {
