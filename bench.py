@@ -118,6 +118,7 @@ PMC_KERNEL_F16 = {  # the fp16-plane kernels (forward, data gradient), same prof
     # (training forward of a rank-one head keeps the gate bits only: SAVE mode 2; mode 1 stores h2 as well)
     "mlp_tower_forward_save": ("mlp_rows_forward_kernel<1, 2, 2, 4, 0>", 1 << 20),
     "mlp_tower_backward": ("mlp_tower_backward_f16_kernel<1, 2, false>", 1 << 20),
+    "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2, false, true>", 1 << 20),  # template <d_in, n_out, LOADH, F16>
 }
 PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
     "mlp_tower_forward": ("mlp_tower_forward_split_kernel<1, 2, false>", 1 << 20),
@@ -528,8 +529,10 @@ def run(args: argparse.Namespace) -> None:
             return "bf16-gate-x3" if os.environ.get("RL8_WGRAD_GATE_PLANES", "f16").startswith("b") else "f16-gatebits-x2"
         elif name == "mlp_tower_backward_gate":  # rank-one heads: gate plane x two planes of w3e * W2
             return "f16-gate-x2"
-        elif name == "mlp_wgrad":  # the bf16-plane weight-gradient kernel takes any width (and stays on bf16 planes)
-            ok, f16 = fused_mlp.BACKWARD_GEMM in planes, False
+        elif name == "mlp_wgrad":  # general heads: both operands as planes (two fp16 each: three products; or three bf16: six)
+            ok = fused_mlp.BACKWARD_GEMM in planes
+            f16 = ok and not os.environ.get("RL8_WGRAD_PLANES", "f16").startswith("b") and all(
+                hip.mlp_backward_f16_supports(d, n) for d, n in widths)
         else:
             ok = fused_mlp.BACKWARD_GEMM in planes and all(hip.mlp_backward_split_supports(d, n) for d, n in widths)
             f16 = ok and fused_mlp.BACKWARD_GEMM == "f16" and all(hip.mlp_backward_f16_supports(d, n) for d, n in widths)

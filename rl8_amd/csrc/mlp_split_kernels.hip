@@ -1123,8 +1123,8 @@ struct WgradFusedArgs {
   // gate-plane kernel in BITS mode only: the gate bits of h2 ([m][8] words) instead of h2 itself, and b2
   const uint32_t *gate2 = nullptr;
   const float *b2 = nullptr;
-  // ... on fp16 planes (F16): {max |dOut column 0|, max |x column c|, c < d_in} over the rows of the whole call
-  // (wgrad_gate_bounds_kernel), as the bit patterns of non-negative floats
+  // ... on fp16 planes (F16): max |dOut column q| at [q], max |x column c| at [4 + c], over the rows of the whole call
+  // (wgrad_bounds_kernel), as the bit patterns of non-negative floats
   const uint32_t *bounds = nullptr;
 };
 
@@ -1144,12 +1144,17 @@ struct WgradOperands {
   int colsum_accumulate;  // a later segment: add to the rows the first one wrote
 };
 
-template <int DIN, int FUSED = 0, bool LOADH = false>
+// F16 (round 3, fused mode with compiled widths): BOTH operands as two fp16 planes, each scaled by a power of two per
+// column of the OUTPUT it indexes -- dZ2[s][j] by 2^a(j) from sum_q max|dOut_q| |W3[q][j]|, h1[s][i] by 2^b(i) from
+// |b1[i]| + sum_c max|x_c| |w1[i][c]| -- so the factors leave the sum over samples; THREE plane products per 16 samples
+// instead of six (see mlp_wgrad_gate_kernel's F16 for the accuracy argument; here both operands carry 22 bits).
+template <int DIN, int FUSED = 0, bool LOADH = false, bool F16 = false>
 __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     const float *__restrict__ dz2, const float *__restrict__ x, const float *__restrict__ w1,
     const float *__restrict__ b1, int64_t m, int d_in_rt, float *__restrict__ slabs, WgradFusedArgs fused,
     WgradOperands ops) {
   static_assert(!LOADH || (DIN > 0 && FUSED == 0), "the two-operand mode: compiled input widths, no head fusion");
+  static_assert(!F16 || (DIN > 0 && FUSED > 0), "fp16 planes: the fused mode of compiled widths");
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = FUSED > 0 ? FUSED : 1;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
@@ -1176,6 +1181,22 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     for (int q = 0; q < kOut; ++q) {
       w3r[q] = fused.w3[q * kHidden + col];
       dw3a[q] = 0.0f;
+    }
+  }
+  [[maybe_unused]] float scale_a = 1.0f, scale_b = 1.0f;  // F16: this thread's column as j of dZ2 and as i of h1
+  [[maybe_unused]] float *inv_a = reinterpret_cast<float *>(smem + 2 * kWsStageBytes), *inv_b = inv_a + kHidden;
+  if constexpr (F16) {
+    float za = 0.0f, hb = __builtin_fabsf(b1r);
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) za = __builtin_fmaf(__uint_as_float(fused.bounds[q]), __builtin_fabsf(w3r[q]), za);
+#pragma unroll
+    for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[4 + c]), __builtin_fabsf(w1r[c]), hb);
+    const int ea = f16_bound_exponent(za * 1.0001f), eb = f16_bound_exponent(hb * 1.0001f);
+    scale_a = __builtin_amdgcn_ldexpf(1.0f, kF16Top - ea);
+    scale_b = __builtin_amdgcn_ldexpf(1.0f, kF16Top - eb);
+    if (kh == 0) {
+      inv_a[col] = __builtin_amdgcn_ldexpf(1.0f, ea - kF16Top);
+      inv_b[col] = __builtin_amdgcn_ldexpf(1.0f, eb - kF16Top);
     }
   }
 
@@ -1211,6 +1232,15 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       planes[0][e >> 1] = hi;
       planes[1][e >> 1] = mid;
       planes[2][e >> 1] = lo;
+    }
+  };
+  [[maybe_unused]] auto split8h = [&](const float (&v)[8], float scale, u32x4 (&planes)[3]) {  // F16: hi, lo (planes[2] unused)
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t hi, lo;
+      f16_pair_scaled(v[e], v[e + 1], scale, hi, lo);
+      planes[0][e >> 1] = hi;
+      planes[1][e >> 1] = lo;
     }
   };
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -1285,7 +1315,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
         dz[e] = dzv[e] > 0.0f ? g : 0.0f;
         db2a += dz[e];
       }
-      split8(dz, pa);
+      if constexpr (F16) split8h(dz, scale_a, pa);
+      else split8(dz, pa);
     } else {
       split8(dzv, pa);
     }
@@ -1300,16 +1331,17 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       }
       h[e] = relu1(v);
     }
-    split8(h, pb);
+    if constexpr (F16) split8h(h, scale_b, pb);
+    else split8(h, pb);
   };
   auto write_planes = [&](int stage, const u32x4 (&pa)[3], const u32x4 (&pb)[3]) {
     const unsigned addr = p_write + stage * kWsStageBytes;
     lds_write_b128<0>(addr, pa[0]);
     lds_write_b128<kWsPlane>(addr, pa[1]);
-    lds_write_b128<2 * kWsPlane>(addr, pa[2]);
+    if constexpr (!F16) lds_write_b128<2 * kWsPlane>(addr, pa[2]);
     lds_write_b128<kWsOperandBytes>(addr, pb[0]);
     lds_write_b128<kWsOperandBytes + kWsPlane>(addr, pb[1]);
-    lds_write_b128<kWsOperandBytes + 2 * kWsPlane>(addr, pb[2]);
+    if constexpr (!F16) lds_write_b128<kWsOperandBytes + 2 * kWsPlane>(addr, pb[2]);
   };
 
   f32x16 acc[2][4];
@@ -1336,6 +1368,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   SplitFrags f;
   auto first_reads = [&](auto parity_tag) {  // ... of the chunk in stage P, into am and that step's BM
     constexpr int P = decltype(parity_tag)::value;
+    if constexpr (F16) return;  // (the fp16 step fetches its twelve fragments itself, under its own production)
     const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
     u32x4(&BM)[4] = *(P == 0 ? &f.bm : &f.bh);
     f.am[0] = lds_read_b128<kWsPlane>(ar);
@@ -1349,6 +1382,42 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     constexpr bool FIRST = decltype(first_tag)::value;
     constexpr int P = decltype(parity_tag)::value;
     const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
+    if constexpr (F16) {
+      // ah / am: hi / lo planes of dZ2^T, bh / bm: of h1.  The first product's six fragments are requested in front of
+      // the next chunk's production (which does not depend on them), the other six behind it: they land under the
+      // first product.  (All twelve in front: the wider variants spilled.)
+      f.am[0] = lds_read_b128<kWsPlane>(ar);
+      f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
+      f.bh[0] = lds_read_b128<0>(br);
+      f.bh[1] = lds_read_b128<512>(br);
+      f.bh[2] = lds_read_b128<1024>(br);
+      f.bh[3] = lds_read_b128<1536>(br);
+      {
+        // (the other stage's last readers passed the previous step's barrier: its planes can go out as soon as they exist)
+        u32x4 pa[3], pb[3];
+        load_dz(dzq[P], n + 2);
+        produce(dzq[P ^ 1], dzq[P ^ 1], n + 1, pa, pb);
+        write_planes(P ^ 1, pa, pb);
+      }
+      f.ah[0] = lds_read_b128<0>(ar);
+      f.ah[1] = lds_read_b128<512>(ar);
+      f.bm[0] = lds_read_b128<kWsPlane>(br);
+      f.bm[1] = lds_read_b128<kWsPlane + 512>(br);
+      f.bm[2] = lds_read_b128<kWsPlane + 1024>(br);
+      f.bm[3] = lds_read_b128<kWsPlane + 1536>(br);
+      wait_lds<6>(f.am[0], f.am[1], f.bh[0], f.bh[1], f.bh[2], f.bh[3]);  // only LDS operations in flight: in-order count
+      __builtin_amdgcn_sched_barrier(0);
+      f16_mma<FIRST>(f.am, f.bh, acc);  // lo x hi
+      request_scalars(n + 2);
+      wait_lds<0>(f.ah[0], f.ah[1], f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
+      __builtin_amdgcn_sched_barrier(0);
+      f16_mma<false>(f.ah, f.bm, acc);  // hi x lo
+      f16_mma<false>(f.ah, f.bh, acc);  // hi x hi
+      __builtin_amdgcn_sched_barrier(0);
+      lds_barrier();
+      scalars_landed();
+      return;
+    }
     u32x4(&BM)[4] = *(P == 0 ? &f.bm : &f.bh);
     u32x4(&BH)[4] = *(P == 0 ? &f.bh : &f.bm);
     // am and BM are in (previous step / prologue); the hi planes:
@@ -1487,7 +1556,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       for (int r = 0; r < 16; ++r) {
         const int j = 64 * wj + 32 * ja + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const int i = 128 * wi + 32 * t + l32;
-        slab[j * kHidden + i] = acc[ja][t][r];
+        slab[j * kHidden + i] = F16 ? acc[ja][t][r] * (inv_a[j] * inv_b[i]) : acc[ja][t][r];
       }
 
   if constexpr (LOADH) {
@@ -1607,7 +1676,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   if constexpr (F16) {
     float hb = __builtin_fabsf(b1r);
 #pragma unroll
-    for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[1 + c]), __builtin_fabsf(w1r[c]), hb);
+    for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[4 + c]), __builtin_fabsf(w1r[c]), hb);
     // (fp32 rounding of the bound itself: a hair above)
     const int e = f16_bound_exponent(__uint_as_float(fused.bounds[0]) * hb * 1.0001f);
     col_scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
@@ -1987,18 +2056,19 @@ static int launch_wgrad_split(int grid, hipStream_t s, const float *dz2, const f
   return launch_status();
 }
 
-template <int DIN, int NOUT>
+template <int DIN, int NOUT, bool F16 = false>
 static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
                               const float *b1, int64_t m, int d_in, float *slabs, WgradFusedArgs fused) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, NOUT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, NOUT, false, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_wgrad_split_kernel<DIN, NOUT><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(h2, x, w1, b1, m, d_in, slabs, fused,
-                                                                                 WgradOperands{});
+  // (F16: + the inverse powers of two of the 256 columns of each operand behind the two stages)
+  mlp_wgrad_split_kernel<DIN, NOUT, false, F16><<<grid, kWsThreads, 2 * kWsStageBytes + (F16 ? 2 * kHidden * 4 : 0), s>>>(
+      h2, x, w1, b1, m, d_in, slabs, fused, WgradOperands{});
   return launch_status();
 }
 
@@ -2018,16 +2088,18 @@ static int launch_wgrad_gate(int grid, hipStream_t s, const float *h2, const flo
   return launch_status();
 }
 
-// max |dOut[s][0]| and max |x[s][c]| per column c over m rows -> bounds[0], bounds[1 + c] (bit patterns of non-negative
-// floats, combined with atomic max on words the caller zeroed).  dOut rows have NOUT floats, x rows DIN; both are read
-// as flat 16-byte vectors wherever aligned, the column of a flat index being its remainder.
+// max |dOut[s][q]| per output q and max |x[s][c]| per column c over m rows -> bounds[q], bounds[4 + c] (bit patterns of
+// non-negative floats, combined with atomic max on words the caller zeroed).  dOut rows have NOUT floats, x rows DIN;
+// both are read as flat 16-byte vectors wherever aligned, the column of a flat index being its remainder.
 template <int DIN, int NOUT>
-__global__ __launch_bounds__(kBlock) void wgrad_gate_bounds_kernel(const float *__restrict__ dout, const float *__restrict__ x,
-                                                                   int64_t m, uint32_t *__restrict__ bounds) {
-  __shared__ float red[kBlock / kWave][1 + DIN];
-  float mx[DIN], md = 0.0f;
+__global__ __launch_bounds__(kBlock) void wgrad_bounds_kernel(const float *__restrict__ dout, const float *__restrict__ x,
+                                                              int64_t m, uint32_t *__restrict__ bounds) {
+  __shared__ float red[kBlock / kWave][NOUT + DIN];
+  float mx[DIN], md[NOUT];
 #pragma unroll
   for (int c = 0; c < DIN; ++c) mx[c] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < NOUT; ++q) md[q] = 0.0f;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x, threads = (int64_t)gridDim.x * kBlock;
   auto scan = [&](const float *p, int64_t n, auto fold) {  // fold(flat index, value) over p[0 .. n)
     const int64_t vecs = ((uintptr_t)p & 15) == 0 ? n / 4 : 0;
@@ -2039,7 +2111,10 @@ __global__ __launch_bounds__(kBlock) void wgrad_gate_bounds_kernel(const float *
     for (int64_t idx = 4 * vecs + tid; idx < n; idx += threads) fold(idx, p[idx]);
   };
   scan(dout, m * NOUT, [&](int64_t idx, float v) {
-    if (NOUT == 1 || idx % NOUT == 0) md = __builtin_fmaxf(md, __builtin_fabsf(v));
+    const int c = (int)(idx % NOUT);
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k)
+      if (k == c) md[k] = __builtin_fmaxf(md[k], __builtin_fabsf(v));
   });
   scan(x, m * DIN, [&](int64_t idx, float v) {
     const int c = (int)(idx % DIN);
@@ -2053,20 +2128,37 @@ __global__ __launch_bounds__(kBlock) void wgrad_gate_bounds_kernel(const float *
     return v;
   };
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  md = wave_max(md);
+#pragma unroll
+  for (int q = 0; q < NOUT; ++q) md[q] = wave_max(md[q]);
 #pragma unroll
   for (int c = 0; c < DIN; ++c) mx[c] = wave_max(mx[c]);
   if (lane == 0) {
-    red[wave][0] = md;
 #pragma unroll
-    for (int c = 0; c < DIN; ++c) red[wave][1 + c] = mx[c];
+    for (int q = 0; q < NOUT; ++q) red[wave][q] = md[q];
+#pragma unroll
+    for (int c = 0; c < DIN; ++c) red[wave][NOUT + c] = mx[c];
   }
   __syncthreads();
-  if (threadIdx.x <= DIN) {
+  if (threadIdx.x < NOUT + DIN) {
     float v = red[0][threadIdx.x];
     for (int w = 1; w < kBlock / kWave; ++w) v = __builtin_fmaxf(v, red[w][threadIdx.x]);
-    atomicMax(bounds + threadIdx.x, __float_as_uint(v));
+    atomicMax(bounds + (threadIdx.x < NOUT ? threadIdx.x : 4 + threadIdx.x - NOUT), __float_as_uint(v));
   }
+}
+
+// the bounds behind the slabs of the caller's workspace (rl8_mlp_wgrad_workspace_bytes), filled for the whole call
+template <int NOUT>
+static uint32_t *launch_wgrad_bounds(hipStream_t s, const float *dout, const float *x, int64_t m, int d_in, float *workspace) {
+  uint32_t *bounds = reinterpret_cast<uint32_t *>(workspace + (int64_t)kCUs * kHidden * kHidden);
+  if (hipMemsetAsync(bounds, 0, 64, s) != hipSuccess) return nullptr;
+  const int64_t want = m / (4 * kBlock);
+  const int grid = (int)(want < 1 ? 1 : want > kCUs ? kCUs : want);
+  if (d_in == 1) wgrad_bounds_kernel<1, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
+  else if (d_in == 2) wgrad_bounds_kernel<2, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
+  else if (d_in == 3) wgrad_bounds_kernel<3, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
+  else if (d_in == 5) wgrad_bounds_kernel<5, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
+  else return nullptr;
+  return bounds;
 }
 
 // flag[0] |= 1 if any row has dout[s][0] + dout[s][1] != 0 (bit patterns: g1 must be exactly -g0).
@@ -2280,6 +2372,18 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
   fused_backward_grids(m, &g1, &g2);
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
+  // RL8_WGRAD_PLANES=bf16: the six-product kernel (A/B runs); default: two fp16 planes per operand, three products
+  static const bool f16 = [] {
+    const char *v = getenv("RL8_WGRAD_PLANES");
+    return !(v && v[0] == 'b');
+  }();
+  uint32_t *bounds = nullptr;
+  if (f16) {
+    bounds = n_out == 1 ? launch_wgrad_bounds<1>(s, dout, x, m, d_in, workspace)
+             : n_out == 2 ? launch_wgrad_bounds<2>(s, dout, x, m, d_in, workspace)
+                          : launch_wgrad_bounds<3>(s, dout, x, m, d_in, workspace);
+    if (!bounds) return launch_status() ? launch_status() : RL8_ESIZE;
+  }
   // Segments of kWgradSegmentRows samples, summed in order (see there).  The first one
   // runs the grid the data-gradient kernel counted on (g2 rows of partials written, the
   // rest zeroed); later ones add to as many of those rows as they have workgroups.
@@ -2287,7 +2391,7 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
     const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
     const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
     const int grid = at == 0 ? g2 : (int)(chunks < g2 ? chunks : g2);
-    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0};
+    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0, nullptr, nullptr, bounds};
     const float *h2s = h2 + at * kHidden, *xs = x + at * d_in;
     int status = RL8_ESIZE;
     // one output: the gate-plane kernel (three plane products per 16 samples instead of six)
@@ -2304,7 +2408,9 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
       continue;
     }
 #define RL8_WGRAD_FUSED(D, N) \
-  if (d_in == D && n_out == N) status = launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused);
+  if (d_in == D && n_out == N) \
+    status = f16 ? launch_wgrad_fused<D, N, true>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused) \
+                 : launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused);
     RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3)
     RL8_WGRAD_FUSED(2, 1) RL8_WGRAD_FUSED(2, 2) RL8_WGRAD_FUSED(2, 3)
     RL8_WGRAD_FUSED(3, 1) RL8_WGRAD_FUSED(3, 2) RL8_WGRAD_FUSED(3, 3)
@@ -2385,18 +2491,10 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
     const char *v = getenv("RL8_WGRAD_GATE_PLANES");
     return !(v && v[0] == 'b');
   }();
-  // the bounds live behind the slabs in the workspace (rl8_mlp_wgrad_workspace_bytes)
-  uint32_t *bounds = reinterpret_cast<uint32_t *>(workspace + (int64_t)kCUs * kHidden * kHidden);
+  uint32_t *bounds = nullptr;
   if (f16) {
-    if (hipMemsetAsync(bounds, 0, 32, s) != hipSuccess) return launch_status();
-    const int bgrid = (int)(m / (4 * kBlock) < 1 ? 1 : m / (4 * kBlock) > kCUs ? kCUs : m / (4 * kBlock));
-#define RL8_WGRAD_BOUNDS(D) \
-  if (d_in == D) { \
-    if (n_out == 2) wgrad_gate_bounds_kernel<D, 2><<<bgrid, kBlock, 0, s>>>(dout, x, m, bounds); \
-    else wgrad_gate_bounds_kernel<D, 1><<<bgrid, kBlock, 0, s>>>(dout, x, m, bounds); \
-  }
-    RL8_WGRAD_BOUNDS(1) RL8_WGRAD_BOUNDS(2) RL8_WGRAD_BOUNDS(3) RL8_WGRAD_BOUNDS(5)
-#undef RL8_WGRAD_BOUNDS
+    bounds = n_out == 2 ? launch_wgrad_bounds<2>(s, dout, x, m, d_in, workspace) : launch_wgrad_bounds<1>(s, dout, x, m, d_in, workspace);
+    if (!bounds) return launch_status() ? launch_status() : RL8_ESIZE;
   }
   for (int64_t at = 0; at < m; at += kWgradSegmentRows) {  // segments summed in order, as rl8_mlp_wgrad_fused_split_f32
     const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
