@@ -588,14 +588,22 @@ int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, const floa
  *   order the kernel streams them.  Re-pack when w_hh changes.
  * rl8_lstm_rows_backward_f32: c0 [B][256], gates [B][L][4][256] and cs [B][L][256] as the
  *   forward saved them, dhs [B][L][256] -> dgates [B][L][4][256]; `dc_scratch` [B][256] floats
- *   (contents irrelevant on entry, undefined on return).  All arrays 16-byte aligned;
- *   32 * L * 4096 < 2^31.  The input-weight, bias and recurrent-weight gradients come from
+ *   (contents irrelevant on entry, undefined on return); dg_bound_out (device word, may be NULL) receives the bit
+ *   pattern of max |dgates|: the bound rl8_mlp_wgrad_f16_strided_f32 scales its fp16 planes by.  All arrays 16-byte
+ *   aligned; 32 * L * 4096 < 2^31.  The input-weight, bias and recurrent-weight gradients come from
  *   rl8_mlp_wgrad_split_strided_f32 on dgates as before. */
 int64_t rl8_lstm_rows_backward_pack_bytes(void);
 int rl8_lstm_rows_backward_pack(const float *w_hh, void *packed, void *stream);
 int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs,
                                const float *dhs, const void *packed, float *dgates, float *dc_scratch,
-                               void *stream);
+                               uint32_t *dg_bound_out, void *stream);
+/* rl8_mlp_wgrad_split_strided_f32 on fp16 planes (three plane products instead of six): dz and h each scaled by one
+ * power of two taken from *dz_bound / *h_bound -- device words holding a float >= max |dz| / max |h| over all rows
+ * read (dg_bound_out above; 1.0f for an LSTM's outputs). */
+int rl8_mlp_wgrad_f16_strided_f32(const float *dz, int64_t dz_pitch, const uint32_t *dz_bound, const float *h,
+                                  int64_t h_pitch, const uint32_t *h_bound, int64_t m, float *workspace,
+                                  float *dw_out, int accumulate, const float *x, int d_in, float *colsums,
+                                  int *colsum_rows_out, void *stream);
 
 /* The recurrent models' output heads (src/rl8/models/_recurrent.py:230-236, 287-292),
  * all of them at once: out [M][n] = h [M][256] x w^T + b, w [n][256] (the heads'

@@ -125,6 +125,7 @@ struct LrArgs {
   int64_t b;
   int l;
   unsigned long long *stamps;  // tuning builds (RL8_LR_STAMP): cycles per wait site, summed over waves; else null
+  uint32_t *dg_bound;          // max |dG| over everything written, as the bits of a non-negative float (atomic max); or null
 };
 
 typedef float f32x16v __attribute__((ext_vector_type(16)));
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   f32x16 acc[8];
   float dg[4][16];  // [gate position][e]: dG of the chunk whose matrix work is under way / comes next
   float dcv[16];    // dL/dc of that chunk (between its phases A and C)
+  float dg_max = 0.0f;  // of everything this lane has stored (the weight-gradient kernels scale dG by a bound on it)
 
   auto math_a = [&](const LrStoreDesc &sd, int c) {  // -> dg[0] (o), dcv
 #pragma unroll
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
       const float tc = lr_tanh(ct);
       dg[0][e] = dh * tc * (go * (1.0f - go));
       dcv[e] = __builtin_fmaf(dh * go, 1.0f - tc * tc, at(la_dc, e));
+      dg_max = __builtin_fmaxf(dg_max, __builtin_fabsf(dg[0][e]));
     }
     store4(dg[0], sd.dgates, v_gates, c * 128 + 3 * (kHidden * 4));
   };
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
       const float gi = at(lb_i, e), gg = at(lb_g, e);
       dg[1][e] = dcv[e] * gg * (gi * (1.0f - gi));
       dg[2][e] = dcv[e] * gi * (1.0f - gg * gg);
+      dg_max = __builtin_fmaxf(dg_max, __builtin_fmaxf(__builtin_fabsf(dg[1][e]), __builtin_fabsf(dg[2][e])));
     }
     store4(dg[1], sd.dgates, v_gates, c * 128);
     store4(dg[2], sd.dgates, v_gates, c * 128 + 2 * (kHidden * 4));
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
       const float gf = at(lc_f, e), cp = at(lc_cp, e);
       dg[3][e] = dcv[e] * cp * (gf * (1.0f - gf));
       dc_out[e] = dcv[e] * gf;
+      dg_max = __builtin_fmaxf(dg_max, __builtin_fabsf(dg[3][e]));
     }
     store4(dg[3], sd.dgates, v_gates, c * 128 + 1 * (kHidden * 4));
     store4(dc_out, sd.dcout, v_state, c * 128);
@@ -476,6 +481,12 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     nd = after;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no request may still be writing LDS when the workgroup ends
+  if (a.dg_bound) {
+    // (rows past the end contributed zeros: their loads returned 0.0)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dg_max = __builtin_fmaxf(dg_max, __shfl_down(dg_max, off, 64));
+    if (lane == 0) atomicMax(a.dg_bound, __float_as_uint(dg_max));
+  }
 #ifdef RL8_LR_STAMP
   tw[11] = __builtin_readcyclecounter() - t_begin;
   if (a.stamps && lane == 0)
@@ -497,7 +508,8 @@ RL8_API int rl8_lstm_rows_backward_pack(const float *w_hh, void *packed, void *s
 }
 
 RL8_API int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs, const float *dhs,
-                                       const void *packed, float *dgates, float *dc_scratch, void *stream) {
+                                       const void *packed, float *dgates, float *dc_scratch, uint32_t *dg_bound_out,
+                                       void *stream) {
   if (!c0 || !gates || !cs || !dhs || !packed || !dgates || !dc_scratch) return RL8_ENULL;
   if (b <= 0 || l <= 0) return RL8_ESIZE;
   // a wave addresses its 32 sequences with 32-bit offsets
@@ -518,7 +530,8 @@ RL8_API int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const 
 #ifdef RL8_LR_STAMP
   if (const char *v = getenv("RL8_LR_STAMP_PTR")) stamps = reinterpret_cast<unsigned long long *>(strtoull(v, nullptr, 0));
 #endif
-  const LrArgs args = {c0, gates, cs, dhs, dgates, dc_scratch, b, l, stamps};
+  if (dg_bound_out && hipMemsetAsync(dg_bound_out, 0, 4, (hipStream_t)stream) != hipSuccess) return launch_status();
+  const LrArgs args = {c0, gates, cs, dhs, dgates, dc_scratch, b, l, stamps, dg_bound_out};
   lstm_rows_backward_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
   return launch_status();
 }

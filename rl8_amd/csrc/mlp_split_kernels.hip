@@ -1142,6 +1142,9 @@ struct WgradOperands {
   // x dense [m][DIN] in the kernel's `x` argument.  NULL: none.
   float *colsums;
   int colsum_accumulate;  // a later segment: add to the rows the first one wrote
+  // F16: the operands as two fp16 planes each, times a power of two from *dz_bound / *h_bound (device words: bit
+  // patterns of bounds on |dZ| / |h| over everything this call reads, e.g. rl8_lstm_rows_backward_f32's dg_bound_out)
+  const uint32_t *dz_bound = nullptr, *h_bound = nullptr;
 };
 
 // F16 (round 3, fused mode with compiled widths): BOTH operands as two fp16 planes, each scaled by a power of two per
@@ -1154,7 +1157,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     const float *__restrict__ b1, int64_t m, int d_in_rt, float *__restrict__ slabs, WgradFusedArgs fused,
     WgradOperands ops) {
   static_assert(!LOADH || (DIN > 0 && FUSED == 0), "the two-operand mode: compiled input widths, no head fusion");
-  static_assert(!F16 || (DIN > 0 && FUSED > 0), "fp16 planes: the fused mode of compiled widths");
+  static_assert(!F16 || (DIN > 0 && (FUSED > 0 || LOADH)), "fp16 planes: the fused mode of compiled widths, or both operands loaded");
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = FUSED > 0 ? FUSED : 1;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
@@ -1187,10 +1190,15 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   [[maybe_unused]] float *inv_a = reinterpret_cast<float *>(smem + 2 * kWsStageBytes), *inv_b = inv_a + kHidden;
   if constexpr (F16) {
     float za = 0.0f, hb = __builtin_fabsf(b1r);
+    if constexpr (LOADH) {  // one power of two per operand for the launch
+      za = __uint_as_float(*ops.dz_bound);
+      hb = __uint_as_float(*ops.h_bound);
+    } else {
 #pragma unroll
-    for (int q = 0; q < kOut; ++q) za = __builtin_fmaf(__uint_as_float(fused.bounds[q]), __builtin_fabsf(w3r[q]), za);
+      for (int q = 0; q < kOut; ++q) za = __builtin_fmaf(__uint_as_float(fused.bounds[q]), __builtin_fabsf(w3r[q]), za);
 #pragma unroll
-    for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[4 + c]), __builtin_fabsf(w1r[c]), hb);
+      for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[4 + c]), __builtin_fabsf(w1r[c]), hb);
+    }
     const int ea = f16_bound_exponent(za * 1.0001f), eb = f16_bound_exponent(hb * 1.0001f);
     scale_a = __builtin_amdgcn_ldexpf(1.0f, kF16Top - ea);
     scale_b = __builtin_amdgcn_ldexpf(1.0f, kF16Top - eb);
@@ -1290,8 +1298,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   auto produce = [&](const float (&dzv)[8], [[maybe_unused]] const float (&hv)[8], int64_t n, u32x4 (&pa)[3],
                      u32x4 (&pb)[3]) {
     if constexpr (LOADH) {
-      split8(dzv, pa);
-      split8(hv, pb);
+      if constexpr (F16) {
+        split8h(dzv, scale_a, pa);
+        split8h(hv, scale_b, pb);
+      } else {
+        split8(dzv, pa);
+        split8(hv, pb);
+      }
       return;
     }
     // (runtime d_in only: per-row loads, rows past the end clamped as above)
@@ -1392,7 +1405,27 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       f.bh[1] = lds_read_b128<512>(br);
       f.bh[2] = lds_read_b128<1024>(br);
       f.bh[3] = lds_read_b128<1536>(br);
-      {
+      if constexpr (LOADH) {
+        // one register set per operand (as in the bf16 step below): split, write, re-request
+        const unsigned addr = p_write + (P ^ 1) * kWsStageBytes;
+        if (want_colsums) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            cs_b += dzq[0][e];
+#pragma unroll
+            for (int c = 0; c < kIn; ++c) cs_w[c] = __builtin_fmaf(dzq[0][e], xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], cs_w[c]);
+          }
+        }
+        u32x4 pl[3];
+        split8h(dzq[0], scale_a, pl);
+        lds_write_b128<0>(addr, pl[0]);
+        lds_write_b128<kWsPlane>(addr, pl[1]);
+        load_dz(dzq[0], n + 2);
+        split8h(hq[0], scale_b, pl);
+        lds_write_b128<kWsOperandBytes>(addr, pl[0]);
+        lds_write_b128<kWsOperandBytes + kWsPlane>(addr, pl[1]);
+        load_h(hq[0], n + 2);
+      } else {
         // (the other stage's last readers passed the previous step's barrier: its planes can go out as soon as they exist)
         u32x4 pa[3], pb[3];
         load_dz(dzq[P], n + 2);
@@ -2292,18 +2325,18 @@ RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const floa
   return launch_status();
 }
 
-template <int DIN>
+template <int DIN, bool F16 = false>
 static int launch_wgrad_loadh(int grid, hipStream_t s, const float *dz, const float *x, int64_t rows, float *workspace,
                               const WgradOperands &ops) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, 0, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, 0, true, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr_set = true;
   }
-  mlp_wgrad_split_kernel<DIN, 0, true><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(dz, x, nullptr, nullptr, rows, DIN,
-                                                                                 workspace, WgradFusedArgs{}, ops);
+  mlp_wgrad_split_kernel<DIN, 0, true, F16><<<grid, kWsThreads, 2 * kWsStageBytes + (F16 ? 2 * kHidden * 4 : 0), s>>>(
+      dz, x, nullptr, nullptr, rows, DIN, workspace, WgradFusedArgs{}, ops);
   return launch_status();
 }
 
@@ -2314,10 +2347,9 @@ static int launch_wgrad_loadh(int grid, hipStream_t s, const float *dz, const fl
  * per workgroup (rows of 256 * (d_in + 1) floats, *colsum_rows_out of them; the caller adds them
  * up in row order) -- the LSTM's dW_ih and bias gradients of that gate; x dense [m][d_in],
  * d_in in {1, 2, 3, 5}. */
-RL8_API int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const float *h, int64_t h_pitch,
-                                            int64_t m, float *workspace, float *dw_out, int accumulate,
-                                            const float *x, int d_in, float *colsums, int *colsum_rows_out,
-                                            void *stream) {
+static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int64_t h_pitch, int64_t m, float *workspace,
+                         float *dw_out, int accumulate, const float *x, int d_in, float *colsums, int *colsum_rows_out,
+                         const uint32_t *dz_bound, const uint32_t *h_bound, void *stream) {
   if (!dz || !h || !workspace || !dw_out) return RL8_ENULL;
   if (m <= 0 || dz_pitch < kHidden || h_pitch < kHidden) return RL8_ESIZE;
   if ((int64_t)kWsChunk * (dz_pitch > h_pitch ? dz_pitch : h_pitch) * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
@@ -2334,14 +2366,23 @@ RL8_API int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, c
     int grid = (int)(chunks < kCUs ? chunks : kCUs);
     if (at == 0) first_grid = grid;
     if (grid > first_grid) grid = first_grid;  // (later segments add to the first one's rows)
-    const WgradOperands ops{h + at * h_pitch, (int)dz_pitch, (int)h_pitch, colsums, at > 0};
+    const WgradOperands ops{h + at * h_pitch, (int)dz_pitch, (int)h_pitch, colsums, at > 0, dz_bound, h_bound};
     const float *xs = colsums ? x + at * d_in : nullptr;
     int status;
-    switch (colsums ? d_in : 1) {
-      case 1: status = launch_wgrad_loadh<1>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
-      case 2: status = launch_wgrad_loadh<2>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
-      case 3: status = launch_wgrad_loadh<3>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
-      default: status = launch_wgrad_loadh<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+    if (dz_bound) {
+      switch (colsums ? d_in : 1) {
+        case 1: status = launch_wgrad_loadh<1, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 2: status = launch_wgrad_loadh<2, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 3: status = launch_wgrad_loadh<3, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        default: status = launch_wgrad_loadh<5, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+      }
+    } else {
+      switch (colsums ? d_in : 1) {
+        case 1: status = launch_wgrad_loadh<1>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 2: status = launch_wgrad_loadh<2>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 3: status = launch_wgrad_loadh<3>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        default: status = launch_wgrad_loadh<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+      }
     }
     if (status != 0) return status;
     mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw_out,
@@ -2349,6 +2390,28 @@ RL8_API int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, c
   }
   if (colsum_rows_out) *colsum_rows_out = first_grid;
   return launch_status();
+}
+
+RL8_API int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const float *h, int64_t h_pitch,
+                                            int64_t m, float *workspace, float *dw_out, int accumulate,
+                                            const float *x, int d_in, float *colsums, int *colsum_rows_out,
+                                            void *stream) {
+  return wgrad_strided(dz, dz_pitch, h, h_pitch, m, workspace, dw_out, accumulate, x, d_in, colsums, colsum_rows_out, nullptr,
+                       nullptr, stream);
+}
+
+/* The same product on fp16 planes (three plane products per 16 rows instead of six): dZ scaled by one power of two taken
+ * from *dz_bound -- a device word holding the bit pattern of a bound on |dZ| over every row this call reads, e.g. what
+ * rl8_lstm_rows_backward_f32 leaves in dg_bound_out -- and h by one from *h_bound (a device float >= max |h|; 1 for an
+ * LSTM's outputs).  Entries far below the bound keep an absolute, not a relative, accuracy (2^-39 of the bound per
+ * term). */
+RL8_API int rl8_mlp_wgrad_f16_strided_f32(const float *dz, int64_t dz_pitch, const uint32_t *dz_bound, const float *h,
+                                          int64_t h_pitch, const uint32_t *h_bound, int64_t m, float *workspace,
+                                          float *dw_out, int accumulate, const float *x, int d_in, float *colsums,
+                                          int *colsum_rows_out, void *stream) {
+  if (!dz_bound || !h_bound) return RL8_ENULL;
+  return wgrad_strided(dz, dz_pitch, h, h_pitch, m, workspace, dw_out, accumulate, x, d_in, colsums, colsum_rows_out, dz_bound,
+                       h_bound, stream);
 }
 
 // Grids of the two halves of the fused backward (both derive them from m alone,

@@ -133,7 +133,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_step_split_f32": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
     "rl8_lstm_rows_backward_pack_bytes": [],
     "rl8_lstm_rows_backward_pack": [_vp, _vp, _vp],
-    "rl8_lstm_rows_backward_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rl8_lstm_rows_backward_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rl8_mlp_wgrad_f16_strided_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
     "rl8_lstm_backward_partial_floats": [_i32],
     "rl8_lstm_backward_max_rows": [],
     "rl8_lstm_backward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp],
@@ -1322,9 +1323,11 @@ def lstm_rows_backward_pack(w_hh: torch.Tensor) -> torch.Tensor:
 
 
 def lstm_rows_backward(c0: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor, dhs: torch.Tensor,
-                       packed: torch.Tensor) -> torch.Tensor:
+                       packed: torch.Tensor, *, with_bound: bool = False):
     """dgates [B, L, 4, 256] from what the forward saved and dhs [B, L, 256]: the
-    backward through time with the recurrent product on bf16 planes."""
+    backward through time with the recurrent product on bf16 planes. ``with_bound``:
+    also a one-element device tensor holding max |dgates| (what the fp16-plane weight
+    gradient scales its first operand by)."""
     b, l = dhs.shape[0], dhs.shape[1]
     for name, t, shape in (("c0", c0, (b, LSTM_HIDDEN)), ("gates", gates, (b, l, 4, LSTM_HIDDEN)),
                            ("cs", cs, (b, l, LSTM_HIDDEN)), ("dhs", dhs, (b, l, LSTM_HIDDEN))):
@@ -1334,10 +1337,11 @@ def lstm_rows_backward(c0: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor, 
     dev = dhs.device
     dgates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev)
     dc = torch.empty(b, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+    bound = torch.empty(1, dtype=torch.float32, device=dev) if with_bound else None
     with _timed("lstm_rows_backward", b * l):
         _check(load().rl8_lstm_rows_backward_f32(b, l, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dhs), _ptr(packed),
-                                                 _ptr(dgates), _ptr(dc), _stream()), "rl8_lstm_rows_backward_f32")
-    return dgates
+                                                 _ptr(dgates), _ptr(dc), _ptr(bound), _stream()), "rl8_lstm_rows_backward_f32")
+    return (dgates, bound) if with_bound else dgates
 
 
 #: column-sum partial rows of the fused LSTM weight gradient, per (device, stream, L, d_in)
@@ -1378,10 +1382,11 @@ def lstm_backward(
     fused_colsums = split and lstm_split_supports(d_in)
     rows = C.c_int(0)
     partials = None
+    dg_bound = None
     if rows_packed is not None:
         if not fused_colsums:
             raise ValueError("rows_packed needs the bf16-plane weight gradient (split) and a compiled input width")
-        dgates = lstm_rows_backward(c0, gates, cs, dhs, rows_packed)
+        dgates, dg_bound = lstm_rows_backward(c0, gates, cs, dhs, rows_packed, with_bound=True)
     else:
         dgates = torch.empty(b, l, 4, H, dtype=torch.float32, device=dev)
         if not fused_colsums:
@@ -1407,10 +1412,22 @@ def lstm_backward(
         if cols is None:
             cols = _lstm_colsum_ws[ckey] = torch.empty(4, l, 256, H * (d_in + 1), dtype=torch.float32, device=dev)
         crow = C.c_int(0)
+        # with the backward kernel's bound on |dG| the products run on fp16 planes (three instead of six): dG scaled by
+        # one power of two for the tensor, h_{t-1} by one from max |h0| (t = 0) or 1 (an LSTM's own outputs)
+        f16 = dg_bound is not None and os.environ.get("RL8_AMD_LSTM_WGRAD_PLANES", "f16") != "bf16"
+        if f16:
+            h0_bound = h0.abs().amax().reshape(1).clamp_min(1e-30)
+            one = torch.ones(1, dtype=torch.float32, device=dev)
         with _timed("lstm_wgrad", m):
             for q in range(4):
                 for t in range(l):
                     h_prev, h_pitch = (h0p, H) if t == 0 else (hsp + (t - 1) * H * 4, l * H)
+                    if f16:
+                        _check(lib.rl8_mlp_wgrad_f16_strided_f32(
+                            dgp + (t * 4 * H + q * H) * 4, l * 4 * H, _ptr(dg_bound), h_prev, h_pitch,
+                            _ptr(h0_bound if t == 0 else one), b, wsp, dwp + 4 * H * H * q, int(t > 0),
+                            _ptr(xt[t]), d_in, _ptr(cols[q, t]), C.byref(crow), stream), "rl8_mlp_wgrad_f16_strided_f32")
+                        continue
                     _check(lib.rl8_mlp_wgrad_split_strided_f32(
                         dgp + (t * 4 * H + q * H) * 4, l * 4 * H, h_prev, h_pitch, b, wsp, dwp + 4 * H * H * q, int(t > 0),
                         _ptr(xt[t]), d_in, _ptr(cols[q, t]), C.byref(crow), stream), "rl8_mlp_wgrad_split_strided_f32")
