@@ -269,9 +269,19 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   f32x16 acc[8];
   float dg[4][16];  // [gate position][e]: dG of the chunk whose matrix work is under way / comes next
   float dcv[16];    // dL/dc of that chunk (between its phases A and C)
-  float dg_max = 0.0f;  // of everything this lane has stored (the weight-gradient kernels scale dG by a bound on it)
+  // max |dG| of everything this lane has stored (the weight-gradient kernels scale dG by a bound on it), parked in an
+  // accumulator register between the three places per chunk that fold into it: the vector registers are all taken
+  float dg_max;
+  asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(dg_max));
+  auto fold_max = [&](float m) {
+    float t;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(dg_max));
+    t = __builtin_fmaxf(t, m);
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dg_max) : "v"(t));
+  };
 
   auto math_a = [&](const LrStoreDesc &sd, int c) {  // -> dg[0] (o), dcv
+    float lmax = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float go = at(la_o, e), ct = at(la_ct, e);
@@ -279,34 +289,38 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
       const float tc = lr_tanh(ct);
       dg[0][e] = dh * tc * (go * (1.0f - go));
       dcv[e] = __builtin_fmaf(dh * go, 1.0f - tc * tc, at(la_dc, e));
-      dg_max = __builtin_fmaxf(dg_max, __builtin_fabsf(dg[0][e]));
+      lmax = __builtin_fmaxf(lmax, __builtin_fabsf(dg[0][e]));
     }
+    fold_max(lmax);
     store4(dg[0], sd.dgates, v_gates, c * 128 + 3 * (kHidden * 4));
   };
   auto math_b = [&](const LrStoreDesc &sd, int c) {  // -> dg[1] (i), dg[2] (g)
     u32x4 lb_i[4], lb_g[4];
     unpark(std::integral_constant<int, 0>{}, std::integral_constant<int, kLrBehindB>{}, lb_i, lb_g);
+    float lmax = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float gi = at(lb_i, e), gg = at(lb_g, e);
       dg[1][e] = dcv[e] * gg * (gi * (1.0f - gi));
       dg[2][e] = dcv[e] * gi * (1.0f - gg * gg);
-      dg_max = __builtin_fmaxf(dg_max, __builtin_fmaxf(__builtin_fabsf(dg[1][e]), __builtin_fabsf(dg[2][e])));
+      lmax = __builtin_fmaxf(lmax, __builtin_fmaxf(__builtin_fabsf(dg[1][e]), __builtin_fabsf(dg[2][e])));
     }
+    fold_max(lmax);
     store4(dg[1], sd.dgates, v_gates, c * 128);
     store4(dg[2], sd.dgates, v_gates, c * 128 + 2 * (kHidden * 4));
   };
   auto math_c = [&](const LrStoreDesc &sd, int c) {  // -> dg[3] (f), dc out
     u32x4 lc_f[4], lc_cp[4];
     unpark(std::integral_constant<int, 1>{}, std::integral_constant<int, kLrBehindC>{}, lc_f, lc_cp);
-    float dc_out[16];
+    float dc_out[16], lmax = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float gf = at(lc_f, e), cp = at(lc_cp, e);
       dg[3][e] = dcv[e] * cp * (gf * (1.0f - gf));
       dc_out[e] = dcv[e] * gf;
-      dg_max = __builtin_fmaxf(dg_max, __builtin_fabsf(dg[3][e]));
+      lmax = __builtin_fmaxf(lmax, __builtin_fabsf(dg[3][e]));
     }
+    fold_max(lmax);
     store4(dg[3], sd.dgates, v_gates, c * 128 + 1 * (kHidden * 4));
     store4(dc_out, sd.dcout, v_state, c * 128);
   };
@@ -483,9 +497,11 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no request may still be writing LDS when the workgroup ends
   if (a.dg_bound) {
     // (rows past the end contributed zeros: their loads returned 0.0)
+    float t;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(dg_max));
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) dg_max = __builtin_fmaxf(dg_max, __shfl_down(dg_max, off, 64));
-    if (lane == 0) atomicMax(a.dg_bound, __float_as_uint(dg_max));
+    for (int off = 32; off > 0; off >>= 1) t = __builtin_fmaxf(t, __shfl_down(t, off, 64));
+    if (lane == 0) atomicMax(a.dg_bound, __float_as_uint(t));
   }
 #ifdef RL8_LR_STAMP
   tw[11] = __builtin_readcyclecounter() - t_begin;
