@@ -133,7 +133,7 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 // what a lane loads for one unit chunk: its sixteen units (two runs of eight, 64 bytes apart) of its sequence
 struct LrLoadDesc {
   __amdgpu_buffer_rsrc_t gates, cs, cprev, dhs, dcin;
-  int v_cp;  // this lane's offset into cprev (cs of t - 1: sequence pitch; c0: 1 KiB)
+  int cp_pitch;  // bytes between sequences in cprev (cs of t - 1: the sequence pitch; c0: 1 KiB)
 };
 struct LrStoreDesc {
   __amdgpu_buffer_rsrc_t dgates, dcout;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     d.cs = seq_rsrc(a.cs, tile, t, kHidden, rows);
     d.dhs = seq_rsrc(a.dhs, tile, t, kHidden, rows);
     d.cprev = t > 0 ? seq_rsrc(a.cs, tile, t - 1, kHidden, rows) : state_rsrc(a.c0, tile, rows);
-    d.v_cp = t > 0 ? v_seq : v_state;
+    d.cp_pitch = t > 0 ? l * (kHidden * 4) : kHidden * 4;
     d.dcin = state_rsrc(a.dc, tile, t == l - 1 ? 0 : rows);  // the last step of a sequence starts from dc = 0
     return d;
   };
@@ -231,21 +231,33 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     load4(la_dh, d.dhs, v_seq, c * 128);
     load4(la_dc, d.dcin, v_state, c * 128);
   };
-  // park PH (0: phase B, 1: phase C), array AR, piece j of this wave: 1 KiB, lane's 16 bytes at lane * 16
-  auto park4 = [&](int ph, int ar, const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
+  // park PH (0: phase B, 1: phase C), array AR of this wave: 32 rows x 128 bytes, fetched COALESCED -- instruction k
+  // brings rows 8 k .. 8 k + 7 whole, eight lanes per row (8 tag look-ups instead of the 64 of a lane-per-row load) --
+  // and laid out row-major in LDS, the eight 16-byte pieces of row r permuted by XOR with (r >> 1) & 7 so that the
+  // lane = row reads below fall on sixteen different bank groups per quarter wave.  Lane i of instruction k: row
+  // 8 k + (i >> 3), LDS slot i & 7 <- piece (i & 7) ^ ((4 k + (i >> 4)) & 7) of the row.
+  const int park_piece = (lane & 7) ^ (lane >> 4);  // k even; k odd: ^ 4
+  auto park4 = [&](int ph, int ar, const __amdgpu_buffer_rsrc_t &r, int pitch_bytes, int soff) {
+    const int v_row = (lane >> 3) * pitch_bytes;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int k = 0; k < 4; ++k)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          r, smem + kLrRing * kLrSlotBytes + ph * kLrStageBytes + ((wave * 2 + ar) * 4 + j) * 1024, 16, voff + piece(j), soff, 0, 0);
+          r, smem + kLrRing * kLrSlotBytes + ph * kLrStageBytes + ((wave * 2 + ar) * 4 + k) * 1024, 16,
+          v_row + ((k & 1) ? (park_piece ^ 4) : park_piece) * 16, soff + 8 * k * pitch_bytes, 0, 0);
   };
-  const unsigned park_read = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + lane * 16;
+  // lane (n, hh) reads piece 2 j + hh of row n: slot (2 j + hh) ^ ((n >> 1) & 7)
+  unsigned park_read[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    park_read[j] = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + n * 128 + (((2 * j + hh) ^ ((n >> 1) & 7)) * 16);
+  const int pitch_gates = l * (4 * kHidden * 4), pitch_seq = l * (kHidden * 4);
   auto issue_b = [&](const LrLoadDesc &d, int c) {
-    park4(0, 0, d.gates, v_gates, c * 128);
-    park4(0, 1, d.gates, v_gates, c * 128 + 2 * (kHidden * 4));
+    park4(0, 0, d.gates, pitch_gates, c * 128);
+    park4(0, 1, d.gates, pitch_gates, c * 128 + 2 * (kHidden * 4));
   };
   auto issue_c = [&](const LrLoadDesc &d, int c) {
-    park4(1, 0, d.gates, v_gates, c * 128 + 1 * (kHidden * 4));
-    park4(1, 1, d.cprev, d.v_cp, c * 128);
+    park4(1, 0, d.gates, pitch_gates, c * 128 + 1 * (kHidden * 4));
+    park4(1, 1, d.cprev, d.cp_pitch, c * 128);
   };
   // the parked phase PH back into registers; N = operations the wave has issued behind those loads
   auto unpark = [&](auto ph_tag, auto n_tag, u32x4 (&x)[4], u32x4 (&y)[4]) {
@@ -256,9 +268,11 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
       RL8_LR_T1(8 + PH);
     }
-    const unsigned rd = park_read + PH * kLrStageBytes;
-    x[0] = lds_read_b128<0 * 1024>(rd), x[1] = lds_read_b128<1 * 1024>(rd), x[2] = lds_read_b128<2 * 1024>(rd), x[3] = lds_read_b128<3 * 1024>(rd);
-    y[0] = lds_read_b128<4 * 1024>(rd), y[1] = lds_read_b128<5 * 1024>(rd), y[2] = lds_read_b128<6 * 1024>(rd), y[3] = lds_read_b128<7 * 1024>(rd);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[j] = lds_read_b128<PH * kLrStageBytes>(park_read[j]);
+      y[j] = lds_read_b128<PH * kLrStageBytes + 4 * 1024>(park_read[j]);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
   };
 
