@@ -35,6 +35,7 @@ constexpr int kF16PackedBytes = kSplitSteps * kF16BBytes;  // 262 144 (+ 16 byte
 // the A operand and dZ2's dense factors moved into B.
 // layout 1 (the 16x16x32 kernels of mlp_rows_kernels.hip): unit ((hs*8 + ctl)*2 + p)*64 + l holds
 //   B(col = 16 (8 (hs & 1) + ctl) + (l & 15), k = 32 (hs >> 1) + 8 (l >> 4) + e), e = 0..7.
+constexpr int kF16PackGrid = 8;  // 8192 units of 16 bytes per plane pair: one per thread
 __global__ __launch_bounds__(1024) void mlp_pack_w2_f16_kernel(const float *__restrict__ w2, int transposed,
                                                                uint32_t *__restrict__ packed,
                                                                const float *__restrict__ w3 = nullptr, int n_w3 = 0,
@@ -46,8 +47,14 @@ __global__ __launch_bounds__(1024) void mlp_pack_w2_f16_kernel(const float *__re
   __syncthreads();
   float mx = 0.0f;
   // (row k of w2 is w2[k][.]: the factor belongs to the REDUCTION index of the transposed product)
+  // (every workgroup of the launch takes the maximum over the whole matrix -- 256 KiB out of L2 -- and packs its share)
 #pragma clang loop vectorize(disable) interleave(disable)  // (no packed fp32 ops anywhere in this file: the ISA test's rule)
-  for (int i = tid; i < kHidden * kHidden; i += 1024) mx = __builtin_fmaxf(mx, __builtin_fabsf(w2[i] * w3e[i >> 8]));
+  for (int i = 4 * tid; i < kHidden * kHidden; i += 4 * 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(w2 + i);
+    const float f = w3e[i >> 8];
+    mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0] * f), __builtin_fabsf(v[1] * f)),
+                                             __builtin_fmaxf(__builtin_fabsf(v[2] * f), __builtin_fabsf(v[3] * f))));
+  }
   red[tid] = mx;
   __syncthreads();
   for (int half = 512; half > 0; half >>= 1) {
@@ -56,13 +63,13 @@ __global__ __launch_bounds__(1024) void mlp_pack_w2_f16_kernel(const float *__re
   }
   const int e = f16_bound_exponent(red[0]);  // max < 2^e
   const float scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
-  if (tid == 0) {
+  if (tid == 0 && blockIdx.x == 0) {
     float *tail = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(packed) + kF16PackedBytes);
     tail[0] = scale;
     tail[1] = __builtin_amdgcn_ldexpf(1.0f, e - kF16Top);
     tail[2] = tail[3] = 0.0f;
   }
-  for (int unit = tid; unit < kSplitSteps * 8 * 64; unit += 1024) {
+  for (int unit = blockIdx.x * 1024 + tid; unit < kSplitSteps * 8 * 64; unit += gridDim.x * 1024) {
     const int l = unit & 63, ct = (unit >> 6) & 7, s = unit >> 9;
     const int col = layout == 1 ? 16 * (8 * (s & 1) + ct) + (l & 15) : 32 * ct + (l & 31);
     const int k0 = layout == 1 ? 32 * (s >> 1) + 8 * (l >> 4) : 16 * s + 8 * (l >> 5);
@@ -499,9 +506,9 @@ RL8_API int64_t rl8_mlp_f16_packed_bytes(void) { return kF16PackedBytes + 16; }
 
 RL8_API int rl8_mlp_pack_w2_f16(const float *w2, int transposed, void *packed, void *stream) {
   if (!w2 || !packed) return RL8_ENULL;
-  if (((uintptr_t)packed & 15) != 0) return RL8_EALIGN;
+  if (((uintptr_t)packed & 15) != 0 || !aligned16(w2)) return RL8_EALIGN;  // (w2 is read as 16-byte vectors)
   // (forward operand: the 16x16x32 fragment order of mlp_rows_kernels.hip; transposed, for the data gradient: 32x32x16)
-  mlp_pack_w2_f16_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(w2, transposed, reinterpret_cast<uint32_t *>(packed), nullptr, 0,
+  mlp_pack_w2_f16_kernel<<<kF16PackGrid, 1024, 0, (hipStream_t)stream>>>(w2, transposed, reinterpret_cast<uint32_t *>(packed), nullptr, 0,
                                                               transposed ? 0 : 1);
   return launch_status();
 }
@@ -573,8 +580,8 @@ RL8_API int rl8_mlp_tower_backward_f16_f32(const float *x, const float *w1, cons
 RL8_API int rl8_mlp_pack_w2_f16_gate(const float *w2, const float *w3, int n_out, void *packed, void *stream) {
   if (!w2 || !w3 || !packed) return RL8_ENULL;
   if (n_out != 1 && n_out != 2) return RL8_ESIZE;
-  if (((uintptr_t)packed & 15) != 0) return RL8_EALIGN;
-  mlp_pack_w2_f16_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(w2, 1, reinterpret_cast<uint32_t *>(packed), w3, n_out);
+  if (((uintptr_t)packed & 15) != 0 || !aligned16(w2)) return RL8_EALIGN;
+  mlp_pack_w2_f16_kernel<<<kF16PackGrid, 1024, 0, (hipStream_t)stream>>>(w2, 1, reinterpret_cast<uint32_t *>(packed), w3, n_out);
   return launch_status();
 }
 
