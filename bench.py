@@ -120,11 +120,8 @@ PMC_KERNEL_F16 = {  # the fp16-plane kernels (forward, data gradient), same prof
     "mlp_tower_backward": ("mlp_tower_backward_f16_kernel<1, 2, false>", 1 << 20),
     "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2, false, true>", 1 << 20),  # template <d_in, n_out, LOADH, F16>
 }
-PMC_KERNEL_SPLIT = {  # the bf16-plane kernels, same profiled shapes
-    "mlp_tower_forward": ("mlp_tower_forward_split_kernel<1, 2, false>", 1 << 20),
-    "mlp_tower_forward_save": ("mlp_tower_forward_split_kernel<1, 2, true>", 1 << 20),
-    "mlp_tower_backward": ("mlp_tower_backward_split_kernel<1, 2>", 1 << 20),
-    "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2>", 1 << 20),
+PMC_KERNEL_SPLIT = {  # the six-product bf16-plane weight gradient (RL8_WGRAD_PLANES=bf16), same profiled shape
+    "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2, false, false>", 1 << 20),
 }
 PMC_KERNEL_GATE = {  # gate-mode kernels (heads whose dZ2 is gate * d * w3e)
     # (template <d_in, PAIR, BITS, F16>: the value tower's kernel, gate bits, two fp16 planes)
@@ -521,21 +518,18 @@ def run(args: argparse.Namespace) -> None:
         if not tower_heads:
             return "f32"
         widths = [(obs_dim, n) for n in tower_heads]
-        planes = ("split", "f16")
         if name in ("mlp_tower_forward", "mlp_tower_forward_save"):
-            ok = fused_mlp.FORWARD_GEMM in planes and all(hip.mlp_forward_split_supports(d, n) for d, n in widths)
-            f16 = ok and fused_mlp.FORWARD_GEMM == "f16" and all(hip.mlp_forward_f16_supports(d, n) for d, n in widths)
+            ok = f16 = fused_mlp.FORWARD_GEMM == "f16" and all(hip.mlp_forward_f16_supports(d, n) for d, n in widths)
         elif name == "mlp_wgrad_gate":  # rank-one heads: gate plane x the planes of dOut * h1 (two fp16, or three bf16)
             return "bf16-gate-x3" if os.environ.get("RL8_WGRAD_GATE_PLANES", "f16").startswith("b") else "f16-gatebits-x2"
         elif name == "mlp_tower_backward_gate":  # rank-one heads: gate plane x two planes of w3e * W2
             return "f16-gate-x2"
         elif name == "mlp_wgrad":  # general heads: both operands as planes (two fp16 each: three products; or three bf16: six)
-            ok = fused_mlp.BACKWARD_GEMM in planes
+            ok = fused_mlp.BACKWARD_GEMM == "f16"
             f16 = ok and not os.environ.get("RL8_WGRAD_PLANES", "f16").startswith("b") and all(
                 hip.mlp_backward_f16_supports(d, n) for d, n in widths)
         else:
-            ok = fused_mlp.BACKWARD_GEMM in planes and all(hip.mlp_backward_split_supports(d, n) for d, n in widths)
-            f16 = ok and fused_mlp.BACKWARD_GEMM == "f16" and all(hip.mlp_backward_f16_supports(d, n) for d, n in widths)
+            ok = f16 = fused_mlp.BACKWARD_GEMM == "f16" and all(hip.mlp_backward_f16_supports(d, n) for d, n in widths)
         return "f16x2-split" if f16 else "bf16x3-split" if ok else "f32"
 
     lstm_gemm = {  # the recurrent models' LSTM (config 5): FLOP per row-step, matrix pipe

@@ -321,36 +321,21 @@ int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *
                               const float *w3, const float *b3, int n_out, float *out,
                               float *save_h1, float *save_h2, void *stream);
 
-/* The same forward with the 256x256 product on the bf16 matrix pipe at fp32
- * accuracy: both operands are split exactly into three bf16 planes
- * (x = hi + mid + lo) and six of the nine plane products are accumulated in fp32
- * (the three dropped ones are below one fp32 ulp of the product) -- 6 MFMAs of
- * 16x the fp32 MFMA rate per 16 k instead of 8.  Inputs, outputs and saved
- * activations are fp32 exactly as above; h1 is bit-identical, out / h2 agree
- * with rl8_mlp_tower_forward_f32 to fp32 rounding.  save_h1 may be NULL while
- * save_h2 is given: the bf16-plane backward kernels recompute h1 from the
- * observations and never read it.  save_gate2 (optional, with save_h2) [M][8]
- * words receives the ReLU gate of layer 2, bit j of row s = (h2[s][j] > 0): the
- * data-gradient kernel needs only that bit of h2 (32 B per row instead of 1 KiB).
- * w2_split
- * (rl8_mlp_split_packed_bytes() bytes, 16-byte aligned) comes from
- * rl8_mlp_pack_w2_split (transposed as for rl8_mlp_pack_w2_f32). */
-int64_t rl8_mlp_split_packed_bytes(void);
-int rl8_mlp_forward_split_supports(int d_in, int n_out); /* d_in 1, 2, 3, 5 x n_out 1..3; else RL8_ESIZE */
-int rl8_mlp_pack_w2_split(const float *w2 /*[256][256]*/, int transposed, void *w2_split, void *stream);
-int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const float *w1,
-                                    const float *b1, const void *w2_split, const float *b2,
-                                    const float *w3, const float *b3, int n_out, float *out,
-                                    float *save_h1, float *save_h2, uint32_t *save_gate2, void *stream);
-
 /* The same forward with the 256x256 product as THREE fp16 MFMAs per 16 k: each
  * activation row of h1 is scaled by a power of two chosen from a bound on its
  * magnitude (max|b1| + sum_i |x_i| max|w1[:, i]|, placed at 2^14) and W2 by one
  * power of two for the matrix, so both operands sit in the upper fp16 exponent
  * range; each is then split into hi = fp16(v), lo = fp16(v - hi) (22 significand
  * bits) and lo.hi + hi.lo + hi.hi is accumulated in fp32; the epilogue multiplies
- * by the inverse powers of two (exact).  Same arguments, outputs and save options
- * as rl8_mlp_tower_forward_split_f32 (and save_gate2 may be given WITHOUT save_h2: see rl8_mlp_wgrad_gate_bits_f32);
+ * by the inverse powers of two (exact).  Inputs, outputs and saved activations are fp32
+ * exactly as for rl8_mlp_tower_forward_f32 (h1 bit-identical, out / h2 equal to fp32 rounding).
+ * save_h1 may be NULL while save_h2 is given: the plane backward kernels recompute h1 from the
+ * observations and never read it.  save_gate2 (optional) [M][8] words receives the ReLU gate of
+ * layer 2, bit j of row s = (h2[s][j] > 0): the data-gradient kernels need only that bit of h2
+ * (32 B per row instead of 1 KiB), and it may be given WITHOUT save_h2 (rank-one heads: see
+ * rl8_mlp_wgrad_gate_bits_f32).  Widths: d_in 1, 2, 3, 5 x n_out 1..3 (rl8_mlp_forward_f16_supports),
+ * else RL8_ESIZE -- other widths run rl8_mlp_tower_forward_f32.  (The bf16-plane forward / data-gradient
+ * entries of rounds 1-2, rl8_mlp_tower_{forward,backward}_split_f32, were removed in round 3.)
  * w2_f16 (rl8_mlp_f16_packed_bytes() bytes:
  * two fp16 planes in fragment order + {scale, 1/scale}) comes from
  * rl8_mlp_pack_w2_f16.  The fragment order depends on `transposed`: 0 (this forward; since round 3 a kernel of
@@ -361,7 +346,7 @@ int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const f
  * Replaces the same reference call sites
  * (rl8/models/_feedforward.py:115-132 forward of the 256-256 towers). */
 int64_t rl8_mlp_f16_packed_bytes(void);
-int rl8_mlp_forward_f16_supports(int d_in, int n_out); /* as rl8_mlp_forward_split_supports */
+int rl8_mlp_forward_f16_supports(int d_in, int n_out);
 int rl8_mlp_pack_w2_f16(const float *w2 /*[256][256]*/, int transposed, void *w2_f16, void *stream);
 int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, const float *w1,
                                   const float *b1, const void *w2_f16, const float *b2,
@@ -395,14 +380,13 @@ int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout, const 
                                 float *partials, void *stream);
 
 /* The data-gradient half of the fused backward pass on the same fp16 planes (three MFMAs
- * per 16 k): the fused mode of rl8_mlp_tower_backward_split_f32 (no dZ2 store; gate2 -- the
- * forward's save_gate2 -- is required; w2t_f16 from rl8_mlp_pack_w2_f16(..., transposed = 1)).
+ * per 16 k): no dZ2 store; instead of the saved h1 the kernel takes layer 1 itself (w1, b1) and recomputes
+ * the ReLU gate h1 > 0 <=> b1 + x . w1 > 0 with the forward pass's own fma chain; gate2 -- the
+ * forward's save_gate2 -- is required; w2t_f16 from rl8_mlp_pack_w2_f16(..., transposed = 1).
  * dZ2 rows are scaled by a power of two from the row bound sum_q |dOut_q| max|W3_q|, W2^T
  * by the pack's, both undone on the accumulators.  Fills [dW1 | db1] of `*partial_rows_out`
- * partial rows (same layout and row count as the bf16-plane kernel); the caller follows with
- * rl8_mlp_wgrad_fused_split_f32 for dW2 and the head segments -- the weight gradient sums
- * over samples, where fp16's range cannot be recovered by a power of two per row, and stays
- * on bf16 planes (two fp16 versions measured slower and less accurate: mlp_f16_kernels.hip).
+ * partial rows (layout of rl8_mlp_tower_backward_f32); the caller follows with
+ * rl8_mlp_wgrad_fused_split_f32 for dW2 and the head segments.
  * Replaces the autograd backward of the 256-256 towers
  * (rl8/algorithms/_feedforward.py:374-386 loss.backward()). */
 int rl8_mlp_backward_f16_supports(int d_in, int n_out);
@@ -439,38 +423,20 @@ int rl8_mlp_tower_backward_f32(const float *x, const float *h1, const float *h2,
                                const float *w3, int n_out, float *dz2_out, float *partials,
                                int *partial_rows_out /*host*/, void *stream);
 
-/* The data-gradient half of the backward pass with dH1 = dZ2 x W2 as bf16-plane
- * products (see rl8_mlp_tower_forward_split_f32).  Same outputs and partial-row
- * layout as rl8_mlp_tower_backward_f32; differences in the arguments: w2t_split
- * comes from rl8_mlp_pack_w2_split(..., transposed = 1), and instead of the saved
- * h1 the kernel takes layer 1 itself (w1, b1) and recomputes the ReLU gate
- * h1 > 0 <=> b1 + x . w1 > 0 with the forward pass's own fma chain (1 KiB per row
- * less HBM traffic).  Two launches: the matrix kernel (dZ2, dW1, db1) and an
- * HBM-streaming kernel for the head gradients (db2, dW3, db3), which are column
- * sums over rows.  dz2_out = NULL selects the first half of the fused backward
- * (see rl8_mlp_wgrad_fused_split_f32).  gate2 (the forward's save_gate2) replaces the
- * h2 reads of the matrix kernel by 32 B of gate bits per row; h2 may then be NULL
- * in the fused mode. */
-int rl8_mlp_backward_split_supports(int d_in, int n_out); /* the same widths */
-int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, const float *b1, const float *h2,
-                                     const float *dout, int64_t m, int d_in, const void *w2t_split,
-                                     const float *w3, int n_out, float *dz2_out, float *partials,
-                                     int *partial_rows_out /*host*/, const uint32_t *gate2 /*or NULL*/,
-                                     void *stream);
-
 /* dW2 (+)= dZ2^T h1 on bf16 planes, with h1 = relu(x W1^T + b1) recomputed from the
  * observations instead of read back (workspace: rl8_mlp_wgrad_workspace_bytes()). */
 int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const float *w1, const float *b1,
                             int64_t m, int d_in, float *workspace, float *dw2_out, int accumulate,
                             void *stream);
 
-/* The fused backward: rl8_mlp_tower_backward_split_f32 with dz2_out = NULL (no dZ2
- * store, no head-gradient launch) followed by this call, whose weight-gradient
+/* The fused backward: rl8_mlp_tower_backward_f16_f32 followed by this call, whose weight-gradient
  * kernel re-forms dZ2 = (dOut x W3) * (h2 > 0) and h1 itself (thread = column) and
  * accumulates the head gradients on the way.  dw2_out [256][256] receives dW2; the
  * head segments [db2 | dW3] of `partials` (the same buffer and row count the first
  * call reported) are filled and the db3 segment is zeroed: db3 = the column sums of
- * dOut, which the caller forms itself.  Widths: rl8_mlp_backward_split_supports.
+ * dOut, which the caller forms itself.  Widths: rl8_mlp_backward_f16_supports.  Since round 3 the
+ * products run on two fp16 planes per operand, each scaled by a power of two per column of the
+ * output it indexes (three plane products per 16 rows; RL8_WGRAD_PLANES=bf16: the six bf16 ones).
  * Inputs longer than 2^23 rows are summed in 2^23-row segments, in order (this call and
  * rl8_mlp_wgrad_split_f32): the fp32 accumulation chains do not grow with m. */
 int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, const float *x, const float *w1,

@@ -1,1077 +1,22 @@
-// N1, second generation of the tower forward: the 256x256 layer as an
-// fp32-ACCURATE product on the bf16 matrix pipe.
+// N1: the weight gradients of the default towers' 256x256 layer (and, strided, of the LSTM's recurrent
+// weights) as fp32-ACCURATE products on the 16-bit matrix pipes.
 //
-// Why.  gfx950 runs fp32 MFMAs and the VALU on the same multipliers: 155 TFLOP/s,
-// and nothing overlaps with them (tools/probes/mfma_valu_probe.hip).  The bf16
-// matrix pipe sustains 1.75 PFLOP/s on changing operands and VALU work DOES run
-// beside it (tools/probes/bf16_split_probe.hip).  An fp32 value is exactly the sum
-// of three bf16 values (8 + 8 + 8 significand bits, by truncation:
-// hi = top16(x), mid = top16(x - hi), lo = x - hi - mid), bf16 x bf16 products
-// are exact in fp32 and the MFMA accumulates in fp32, so
+// An fp32 value is exactly the sum of three bf16 values (8 + 8 + 8 significand bits, by truncation: hi = top16(x),
+// mid = top16(x - hi), lo = x - hi - mid), bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so
 //   a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh) + O(2^-24 |a*b|)
-// -- six bf16 MFMAs per 16 k instead of eight fp32 MFMAs of 1/16 the rate.  The
-// dropped terms (am*bl, al*bm, al*bl) are below one fp32 ulp of the product; the
-// measured error of a K=256 dot product against fp64 is the same as that of an
-// fp32 fma chain.  This is NOT a bf16 tower: inputs,
-// outputs, saved activations and accumulation are fp32.
-//
-// Shape.  Both operands go through LDS, K-chunked, because at this rate the
-// weights can no longer stream from L2 per wave: a workgroup (4 waves) owns a
-// 128-row x 256-column macro tile, 128 accumulator registers per wave (wave =
-// 64 rows x 128 columns), and walks K in 16 steps of 16:
-//   B chunk (W2, three planes, fragment-ordered by rl8_mlp_pack_w2_split) comes
-//     HBM/L2 -> LDS by direct-to-LDS buffer loads: no registers, no VALU;
-//   A chunk (h1 = relu(x W1^T + b1), 128 rows x 16 k) is COMPUTED on the VALU for
-//     the next step while the matrix pipe works on the current one, split into
-//     the three planes and written to LDS as ready-made 16-byte fragments.
-// Two chunk buffers; one barrier per step.  Every LDS access of the loop is inline
-// asm with hand-placed s_waitcnt: the compiler serialises compiler-visible LDS
-// accesses behind outstanding direct-to-LDS loads (vmcnt(0) before each).
+// -- six bf16 MFMAs per 16 k instead of eight fp32 MFMAs of 1/16 the rate (the fp32 MFMAs share the VALU's multipliers:
+// 155 TFLOP/s and nothing overlaps with them, tools/probes/mfma_valu_probe.hip; the 16-bit pipe sustains 1.5-1.7 PFLOP/s
+// with VALU work beside it).  Round 3 moved the default paths to two fp16 planes per operand, each scaled by a power of
+// two per column of the OUTPUT it indexes (three plane products; two when one operand is the ReLU gate itself): see the
+// F16 template parameters below.  The bf16 forms stay for A/B runs (RL8_WGRAD_PLANES / RL8_WGRAD_GATE_PLANES=bf16) and for
+// operands without a bound (rl8_mlp_wgrad_split_f32, rl8_mlp_wgrad_split_strided_f32).
+// The forward and data-gradient kernels of this scheme (round 1-2: mlp_tower_{forward,backward}_split_kernel) were
+// removed in round 3: every width they served runs the rows-per-wave kernels of mlp_rows_kernels.hip /
+// mlp_f16_kernels.hip, everything else the fp32-MFMA generation of mlp_kernels.hip.
 #include <type_traits>
 #include "split_tile.hip.h"
 
 namespace rl8 {
-
-// w2 [256][256] row-major fp32 -> three bf16 planes in fragment order:
-// 16-byte unit ((s*8 + ct)*3 + p)*64 + l holds, for plane p, the eight values
-//   B(col = 32 ct + (l & 31), k = 16 s + 8 (l >> 5) + e), e = 0..7,
-// B(col, k) = w2[col][k] (forward) or w2[k][col] (transposed: the data-gradient
-// product dH1 = dZ2 x W2).  One k-step of all eight column tiles is 24 KiB
-// contiguous: the direct-to-LDS copy of a step is 24 one-KiB loads.
-__global__ __launch_bounds__(kBlock) void mlp_pack_w2_split_kernel(const float *__restrict__ w2, int transposed,
-                                                                   uint32_t *__restrict__ packed) {
-  const int unit = blockIdx.x * kBlock + threadIdx.x;  // (s, ct, l): one 16-byte unit of each plane
-  if (unit >= kSplitSteps * 8 * 64) return;
-  const int l = unit & 63, ct = (unit >> 6) & 7, s = unit >> 9;
-  const int col = 32 * ct + (l & 31), k0 = 16 * s + 8 * (l >> 5);
-  uint32_t plane[3][4];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float v = transposed ? w2[(k0 + e) * kHidden + col] : w2[col * kHidden + k0 + e];
-    const uint32_t hi = __float_as_uint(v) & 0xffff0000u;
-    const float r1 = v - __uint_as_float(hi);
-    const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mid);
-    const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;
-    const uint32_t parts[3] = {hi, mid, lo};
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      if (e & 1)
-        plane[p][e >> 1] |= parts[p];
-      else
-        plane[p][e >> 1] = parts[p] >> 16;
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    uint32_t *dst = packed + ((((s * 8 + ct) * 3 + p) * 64 + l) << 2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = plane[p][q];
-  }
-}
-
-// Kernel-tuning builds only (-DRL8_SPLIT_TRACE): shader-clock stamps of the forward
-// kernel's k-steps (tile iteration 3 of every workgroup, every wave), read back with
-// rl8_debug_split_trace().  Compiled out of the shipped library.
-#ifdef RL8_SPLIT_TRACE
-__device__ unsigned long long g_split_trace[512 * 4 * 16 * 4];
-__device__ __forceinline__ void split_stamp(int iteration, int wave, int step, int slot) {
-  if (iteration == 3 && (threadIdx.x & 63) == 0)
-    g_split_trace[((blockIdx.x * 4 + wave) * 16 + step) * 4 + slot] = __builtin_amdgcn_s_memtime();
-}
-__device__ unsigned long long g_split_trace_epilogue[512 * 4 * 4];
-__device__ __forceinline__ void split_stamp_epilogue(int iteration, int wave, int slot) {
-  if (iteration == 3 && (threadIdx.x & 63) == 0) g_split_trace_epilogue[(blockIdx.x * 4 + wave) * 4 + slot] = __builtin_amdgcn_s_memtime();
-}
-#define RL8_SPLIT_STAMP(it, w, s, slot) split_stamp(it, w, s, slot)
-#define RL8_SPLIT_STAMP_E(it, w, slot) split_stamp_epilogue(it, w, slot)
-#else
-#define RL8_SPLIT_STAMP(it, w, s, slot)
-#define RL8_SPLIT_STAMP_E(it, w, slot)
-#endif
-
-// [stage 0][stage 1][head partials of the upper column half: [128 rows][k_out]][b2 | w3: (1 + k_out) x 1 KiB]
-constexpr int split_forward_lds_bytes(int k_out) {
-  return 2 * kSplitStageBytes + kSplitRows * k_out * 4 + (1 + k_out) * kHidden * 4;
-}
-static_assert(split_forward_lds_bytes(4) <= 80 * 1024, "two workgroups per CU");
-
-template <int DIN, int NOUT, bool SAVE>
-__global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_tower_forward_split_kernel(
-    const float *__restrict__ x, int64_t m, int d_in_rt, const float *__restrict__ w1,
-    const float *__restrict__ b1, const void *__restrict__ w2s, const float *__restrict__ b2,
-    const float *__restrict__ w3, const float *__restrict__ b3, int n_out_rt,
-    float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2,
-    uint32_t *__restrict__ save_gate2) {
-  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
-  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
-  const int d_in = DIN > 0 ? DIN : d_in_rt;
-  const int n_out = NOUT > 0 ? NOUT : n_out_rt;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // [stage 0: A | B][stage 1: A | B][head partials: [2 column halves][128 rows][kOut]]
-  const unsigned lds0 = lds_offset(smem);
-  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;  // rows [64 wr, +64), columns [128 wc, +128)
-  // Producer role: row `prow` of the macro tile and k-half `pkh` of every step; the
-  // k-half is wave-uniform, so the eight rows of W1 / b1 a step needs come through
-  // the scalar cache (no vector loads, no registers) and are used as scalar operands.
-  // (Lanes 4i..4i+3 = one row -- 64 contiguous bytes per row for the h1 stores -- was
-  // tried while h1 was still stored; it measured no faster and needs per-lane weights.)
-  const int prow = tid & 127, pkh = wave >> 1;
-
-  // Per-lane LDS addresses (stage 0; stage 1 = + kSplitStageBytes).
-  const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
-  const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
-  const unsigned a_write = lds0 + pkh * kSplitKhStride + prow * 16;
-  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2s, kSplitPackedBytes);
-
-  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
-  const int64_t stride = gridDim.x;
-
-  // Producer state: the tile whose h1 chunks are being produced (runs one step
-  // ahead of the consumer, so it moves to the next tile before step 15).
-  float px[kIn];
-  [[maybe_unused]] float xn[kIn];
-  int64_t p_r0 = (int64_t)blockIdx.x * kSplitRows;
-  auto rows_from = [&](int64_t r0) {
-    const int64_t left = m - r0;
-    return left <= 0 ? 0 : left < kSplitRows ? (int)left : kSplitRows;
-  };
-  int p_rows = rows_from(p_r0);
-  // (addresses: uniform tile base + 32-bit lane offset -- 64-bit per-lane pointers cost
-  // registers the matrix loop does not have)
-  auto load_x = [&](float (&dst)[kIn], int64_t r0) {
-    const int rows = rows_from(r0);
-    const float *base = x + r0 * d_in;
-#pragma unroll
-    for (int i = 0; i < kIn; ++i) dst[i] = (prow < rows && i < d_in) ? base[(unsigned)(prow * d_in + i)] : 0.0f;
-  };
-  // (wide observations: the next tile's row is loaded at the tile switch instead of a tile ahead)
-  constexpr bool kPrefetchX = DIN > 0;  // (compiled widths: a tile ahead; run-time widths: at the tile switch)
-  load_x(px, p_r0);
-  if constexpr (kPrefetchX) load_x(xn, p_r0 + stride * kSplitRows);
-
-  // Chunk `ks` of the producer's tile -> stage `stage`.
-  auto request_b = [&](int ks, int stage) {
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int block = wave * 6 + u;  // 24 one-KiB blocks per step, six per wave
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, smem + stage * kSplitStageBytes + kSplitABytes + block * 1024,
-                                               16, lane * 16, (ks * 24 + block) * 1024, 0, 0);
-    }
-  };
-  // planes[p]: this thread's fragment (row prow, eight k) of plane p.
-  auto produce_a = [&](int ks, u32x4 (&planes)[3]) {
-    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);
-    float h[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = b1[kb + e];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i)
-        if (DIN > 0 || i < d_in) v = __builtin_fmaf(px[i], w1[(kb + e) * d_in + i], v);
-      h[e] = relu1(v);
-    }
-    if constexpr (SAVE && !(kSplitDiagSkip & 32)) {
-      if (save_h1 != nullptr && prow < p_rows) {  // (h1 is optional: the bf16-plane backward recomputes it)
-        f32x4 *dst = reinterpret_cast<f32x4 *>(save_h1 + p_r0 * kHidden + kb + (unsigned)(prow * kHidden));
-        dst[0] = f32x4{h[0], h[1], h[2], h[3]};
-        dst[1] = f32x4{h[4], h[5], h[6], h[7]};
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      uint32_t hi, mid, lo;
-      split_pair(h[e], h[e + 1], hi, mid, lo);
-      planes[0][e >> 1] = hi;
-      planes[1][e >> 1] = mid;
-      planes[2][e >> 1] = lo;
-    }
-  };
-  auto write_a = [&](int stage, const u32x4 (&planes)[3]) {
-    const unsigned addr = a_write + stage * kSplitStageBytes;
-    lds_write_b128<0>(addr, planes[0]);
-    lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
-    lds_write_b128<2 * kSplitPlaneStride>(addr, planes[2]);
-  };
-  auto step_barrier = [&]() {
-    // vmcnt(0): the direct-to-LDS weight loads have landed (and, in-order, every
-    // older store -- this step's h1 stores were issued a matrix group or more ago).
-    // NOT vmcnt(2) "everything but the step's two stores": a register spill
-    // anywhere behind those stores is a vector-memory instruction the count does
-    // not know about, and it measured no faster.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-
-  // Epilogue constants, per register rather than per lane in the transposed
-  // accumulator layout: b2 and the rows of W3 (zero rows up to kOut) live in LDS and
-  // are fetched as 16-byte quads of four consecutive columns.
-  {
-    float *consts = reinterpret_cast<float *>(smem + 2 * kSplitStageBytes + kSplitRows * kOut * 4);
-    consts[tid] = b2[tid];
-#pragma unroll
-    for (int q = 0; q < kOut; ++q) consts[(1 + q) * kHidden + tid] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
-    // (visible to every wave behind the prologue's step barrier below)
-  }
-
-  f32x16 acc[2][4];
-  [[maybe_unused]] int trace_it = -1;  // (tuning builds: tile iteration, see RL8_SPLIT_STAMP)
-  int64_t r0 = p_r0;  // consumer's tile
-
-  // One k-step: consume stage P (chunk s) while producing chunk s+1 -- of the
-  // next tile when s = 15 -- into the other stage.
-  auto do_step = [&](auto first_tag, auto parity_tag, int s) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    constexpr int P = decltype(parity_tag)::value;
-    const int ks = (s + 1) & (kSplitSteps - 1);
-    RL8_SPLIT_STAMP(trace_it, wave, s, 0);
-    request_b(ks, P ^ 1);
-    const unsigned ar = a_read + P * kSplitStageBytes, br = b_read + P * kSplitStageBytes;
-    SplitFrags f;
-    f.ah[0] = lds_read_b128<0>(ar);
-    f.ah[1] = lds_read_b128<512>(ar);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) f.bh[nt] = nt == 0   ? lds_read_b128<0>(br)
-                                              : nt == 1 ? lds_read_b128<3 * 1024>(br)
-                                              : nt == 2 ? lds_read_b128<6 * 1024>(br)
-                                                        : lds_read_b128<9 * 1024>(br);
-    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
-    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<1024>(br)
-                                              : nt == 1 ? lds_read_b128<4 * 1024>(br)
-                                              : nt == 2 ? lds_read_b128<7 * 1024>(br)
-                                                        : lds_read_b128<10 * 1024>(br);
-    if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
-      p_r0 += stride * kSplitRows;
-      p_rows = rows_from(p_r0);
-      if constexpr (kPrefetchX) {
-#pragma unroll
-        for (int i = 0; i < kIn; ++i) px[i] = xn[i];
-        load_x(xn, p_r0 + stride * kSplitRows);
-      } else {
-        load_x(px, p_r0);
-      }
-    }
-    // The next chunk's arithmetic is left to the scheduler to interleave with the
-    // first matrix group (VALU instructions issue beside bf16 MFMAs for free);
-    // its fragments go to LDS behind that group.
-    u32x4 planes[3];
-    produce_a(ks, planes);
-    wait_lds_all(f);
-    RL8_SPLIT_STAMP(trace_it, wave, s, 1);
-    split_mma_t<FIRST>(f.am, f.bm, acc);
-    split_mma_t<false>(f.ah, f.bm, acc);
-    split_mma_t<false>(f.am, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    write_a(P ^ 1, planes);
-    // lo planes into the registers of the mid planes
-    f.am[0] = lds_read_b128<2 * kSplitPlaneStride>(ar);
-    f.am[1] = lds_read_b128<2 * kSplitPlaneStride + 512>(ar);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) f.bm[nt] = nt == 0   ? lds_read_b128<2 * 1024>(br)
-                                              : nt == 1 ? lds_read_b128<5 * 1024>(br)
-                                              : nt == 2 ? lds_read_b128<8 * 1024>(br)
-                                                        : lds_read_b128<11 * 1024>(br);
-    __builtin_amdgcn_sched_barrier(0);
-    split_mma_t<false>(f.ah, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_lds_all(f);
-    split_mma_t<false>(f.ah, f.bm, acc);
-    split_mma_t<false>(f.am, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    RL8_SPLIT_STAMP(trace_it, wave, s, 2);
-    step_barrier();
-    RL8_SPLIT_STAMP(trace_it, wave, s, 3);
-  };
-  // Prologue: chunk 0 of the first tile.
-  using T = std::true_type;
-  using F = std::false_type;
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-
-  if ((int64_t)blockIdx.x < tiles) {
-    request_b(0, 0);
-    u32x4 planes[3];
-    produce_a(0, planes);
-    write_a(0, planes);
-    step_barrier();
-  }
-
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
-    ++trace_it;
-    r0 = tile * kSplitRows;
-    const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
-    do_step(T{}, P0{}, 0);
-    do_step(F{}, P1{}, 1);
-#pragma unroll 1
-    for (int s = 2; s < kSplitSteps - 2; s += 2) {
-      do_step(F{}, P0{}, s);
-      do_step(F{}, P1{}, s + 1);
-    }
-    do_step(F{}, P0{}, kSplitSteps - 2);
-    do_step(F{}, P1{}, kSplitSteps - 1);
-
-    // Epilogue on the TRANSPOSED accumulators (split_mma_t): this lane holds sample
-    // row 64 wr + 32 mt + l32 and, of column block 128 wc + 32 nt, the sixteen columns
-    // 8 g + 4 hh + e (register r = 4 g + e).  So
-    //   * h2 leaves as 16-byte stores (four consecutive columns per lane, the two
-    //     half-waves side by side: 32 contiguous bytes per row and instruction, a full
-    //     128-byte line per row over g = 0..3) -- 32 stores per wave and tile instead
-    //     of 128 dword stores, the largest item of the old epilogue;
-    //   * the ReLU gate bits of a row are built in that row's own lane (add + funnel
-    //     shift per element) instead of 128 ballots and 256 v_writelane;
-    //   * the head is a dot product down the lane's registers against W3 quads from
-    //     LDS plus ONE half-wave exchange, instead of a five-level DPP reduction per
-    //     eight rows.
-    // b2 / W3 come from the constants block in LDS (hand-issued reads, explicit waits).
-    // (tuning builds, bit 4096: every tile's h2 lands on the first tile's lines -- the stores are issued but stay in L2)
-    RL8_SPLIT_STAMP_E(trace_it, wave, 0);
-    const __amdgpu_buffer_rsrc_t h2rsrc =
-        buffer_rsrc(SAVE ? save_h2 + ((kSplitDiagSkip & 4096) ? (r0 & 0x1ffff) : r0) * kHidden : nullptr, rows * kHidden * 4);
-    const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
-    const unsigned outp = lds_offset(smem) + 2 * kSplitStageBytes;
-    const unsigned constp = outp + kSplitRows * kOut * 4 + (128 * wc + 4 * hh) * 4;
-    constexpr int kChains = kOut <= 2 ? 4 : 2;  // (registers: three outputs x four chains spilled)
-    float part[2][kOut][kChains];
-    [[maybe_unused]] uint32_t gate_words[2][4];
-    // h2 goes to HBM through a per-wave transpose in LDS (stage 1 is dead between the
-    // barrier of step 15 and the barrier of this epilogue, for every wave): written as
-    // the accumulators hold it (lane = row), read back eight lanes per row, so a store
-    // instruction is eight full 128-byte lines instead of thirty-two 32-byte pieces
-    // (scattered 32-byte pieces measured 712 us per 2^20 rows at best, 1 185 us with
-    // the streaming policy, against 588 us with the stores compiled out).
-    constexpr int kH2Pitch = 128 + 16;
-    static_assert(4 * 64 * kH2Pitch <= kSplitStageBytes, "transpose scratch fits in stage 1");
-    [[maybe_unused]] const unsigned t_base = lds_offset(smem) + kSplitStageBytes + wave * (64 * kH2Pitch);
-    [[maybe_unused]] const unsigned t_write = t_base + l32 * kH2Pitch + 16 * hh;
-    [[maybe_unused]] const unsigned t_read = t_base + (lane_id() >> 3) * kH2Pitch + (lane_id() & 7) * 16;
-    [[maybe_unused]] const int h2_voff = ((64 * wr + (lane_id() >> 3)) * kHidden + 128 * wc + 4 * (lane_id() & 7)) * 4;
-    // The column blocks in groups of kGroup quads (g = eight columns): b2 and the kOut
-    // rows of W3 for the group from LDS, then bias + ReLU, the h2 quads into the transpose
-    // scratch, gate nibbles and head products.  (Wide heads take two quads at a time:
-    // sixteen W3 quads plus the block read back would not fit.)
-    // Software-pipelined over the groups: the LDS is busy with the CU's other workgroup's
-    // operand reads, so every lgkmcnt(0) in here cost 500+ cycles (twelve of them per tile
-    // measured 13 500 cycles for ~800 VALU instructions).  The next group's b2 quads are
-    // requested as soon as bias + ReLU has consumed this group's, its W3 quads as soon as
-    // the head products have, and the transposed block is waited for by COUNT (in-order
-    // LDS returns; no scalar load is in flight here), behind the gate and head arithmetic.
-    constexpr int kGroup = kOut >= 4 ? 1 : kOut >= 2 ? 2 : 4;  // (registers: more W3 quads in flight beside the block spilled)
-    constexpr int kStages = 4 * (4 / kGroup);  // (nt, g0) pairs
-    constexpr bool kStore = SAVE && !(kSplitDiagSkip & 8);
-    u32x4 bq[kGroup], wq[kOut][kGroup];
-    auto request_b2 = [&](int stage) {
-      const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
-#pragma unroll
-      for (int gi = 0; gi < kGroup; ++gi) bq[gi] = lds_read_b128<0>(constp + (32 * nt + 8 * (g0 + gi)) * 4);
-    };
-    auto request_w3 = [&](int stage) {
-      const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
-#pragma unroll
-      for (int gi = 0; gi < kGroup; ++gi) {
-        const unsigned a = constp + (32 * nt + 8 * (g0 + gi)) * 4;
-#pragma unroll
-        for (int q = 0; q < kOut; ++q)
-          wq[q][gi] = q == 0   ? lds_read_b128<1 * kHidden * 4>(a)
-                      : q == 1 ? lds_read_b128<2 * kHidden * 4>(a)
-                      : q == 2 ? lds_read_b128<3 * kHidden * 4>(a)
-                      : q == 3 ? lds_read_b128<4 * kHidden * 4>(a)
-                      : q == 4 ? lds_read_b128<5 * kHidden * 4>(a)
-                      : q == 5 ? lds_read_b128<6 * kHidden * 4>(a)
-                      : q == 6 ? lds_read_b128<7 * kHidden * 4>(a)
-                               : lds_read_b128<8 * kHidden * 4>(a);
-      }
-    };
-    request_b2(0);
-    request_w3(0);
-    [[maybe_unused]] u32x4 t_rows[8];
-    auto read_block = [&]() {  // the block back, eight lanes per row (in order behind the writes: same wave)
-      t_rows[0] = lds_read_b128<0 * 8 * kH2Pitch>(t_read);
-      t_rows[1] = lds_read_b128<1 * 8 * kH2Pitch>(t_read);
-      t_rows[2] = lds_read_b128<2 * 8 * kH2Pitch>(t_read);
-      t_rows[3] = lds_read_b128<3 * 8 * kH2Pitch>(t_read);
-      t_rows[4] = lds_read_b128<4 * 8 * kH2Pitch>(t_read);
-      t_rows[5] = lds_read_b128<5 * 8 * kH2Pitch>(t_read);
-      t_rows[6] = lds_read_b128<6 * 8 * kH2Pitch>(t_read);
-      t_rows[7] = lds_read_b128<7 * 8 * kH2Pitch>(t_read);
-    };
-#pragma unroll
-    for (int stage = 0; stage < kStages; ++stage) {
-      const int nt = stage / (4 / kGroup), g0 = (stage % (4 / kGroup)) * kGroup;
-      const bool last_of_block = g0 + kGroup == 4;
-      // this group's quads (requested a stage ago; everything older has landed too)
-#pragma unroll
-      for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(bq[gi]);
-#pragma unroll
-      for (int q = 0; q < kOut; ++q)
-#pragma unroll
-        for (int gi = 0; gi < kGroup; ++gi) wait_lds<0>(wq[q][gi]);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int gi = 0; gi < kGroup; ++gi) {
-          const int g = g0 + gi;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)  // (not __builtin_bit_cast on a vector-element lvalue: it reads element 0)
-            acc[mt][nt][4 * g + e] = relu1(acc[mt][nt][4 * g + e] + __uint_as_float(bq[gi][e]));
-        }
-      if (stage + 1 < kStages) request_b2(stage + 1);
-      if constexpr (kStore) {
-        // h2 block [64 rows][32 columns] of this wave -> its transpose scratch (row pitch
-        // 144 B: the eight lanes of a b128 phase hit eight distinct 16-byte slots, writing
-        // as well as reading)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int gi = 0; gi < kGroup; ++gi) {
-            const int g = g0 + gi;
-            const f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
-            const u32x4 u = __builtin_bit_cast(u32x4, v);
-            if (mt == 0) {
-              g == 0 ? lds_write_b128<0>(t_write, u) : g == 1 ? lds_write_b128<32>(t_write, u)
-              : g == 2 ? lds_write_b128<64>(t_write, u) : lds_write_b128<96>(t_write, u);
-            } else {
-              g == 0 ? lds_write_b128<32 * kH2Pitch>(t_write, u) : g == 1 ? lds_write_b128<32 * kH2Pitch + 32>(t_write, u)
-              : g == 2 ? lds_write_b128<32 * kH2Pitch + 64>(t_write, u) : lds_write_b128<32 * kH2Pitch + 96>(t_write, u);
-            }
-          }
-        if (last_of_block) read_block();
-      }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int gi = 0; gi < kGroup; ++gi) {
-          const int g = g0 + gi;
-          if constexpr (SAVE && !(kSplitDiagSkip & 65536)) {  // (tuning builds, bit 65536: no gate bits)
-            // gate of h2, bit c of word [row][4 wc + nt] <=> column 32 (4 wc + nt) + c > 0.
-            // h2 >= +0 here, so "h2 > 0" is bit 31 of (bits(h2) + 0x7fffffff); four of
-            // them are funnel-shifted into a nibble (element 0 lowest), the nibble goes
-            // to bit 8 g + 4 hh.  The other half-wave holds the interleaved nibbles.
-            uint32_t nib = 0;
-#pragma unroll
-            for (int e = 3; e >= 0; --e)
-              nib = __builtin_amdgcn_alignbit(nib, __float_as_uint(acc[mt][nt][4 * g + e]) + 0x7fffffffu, 31);
-            gate_words[mt][nt] = (g == 0 ? 0u : gate_words[mt][nt]) | (nib << (8 * g + 4 * hh));
-          }
-          // head partials of this row: four (two for wide heads) independent chains per
-          // output, 16 (32) terms each over the tile, so the sum is not one 64-term
-          // chain and the fmas do not wait on each other
-#pragma unroll
-          for (int q = 0; q < kOut; ++q) {
-            float p = (nt == 0 && g < kChains) ? 0.0f : part[mt][q][g % kChains];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) p = __builtin_fmaf(acc[mt][nt][4 * g + e], __uint_as_float(wq[q][gi][e]), p);
-            part[mt][q][g % kChains] = p;
-          }
-        }
-      }
-      if (stage + 1 < kStages) request_w3(stage + 1);
-      if constexpr (kStore) {
-        if (last_of_block) {
-          // the block's eight reads are older than the next stage's W3 quads just requested
-          // (its b2 quads went out ahead of the block): wait for "all but those" (in-order
-          // returns; tools/check_inflight_regs.py caught the first version counting both)
-          constexpr int kNewer = kGroup * kOut;
-          if (stage + 1 < kStages) {
-            wait_lds<kNewer>(t_rows[0], t_rows[1], t_rows[2], t_rows[3]);
-            wait_lds<kNewer>(t_rows[4], t_rows[5], t_rows[6], t_rows[7]);
-          } else {
-            wait_lds<0>(t_rows[0], t_rows[1], t_rows[2], t_rows[3]);
-            wait_lds<0>(t_rows[4], t_rows[5], t_rows[6], t_rows[7]);
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {  // rows 8 i + (lane >> 3), columns 32 nt + 4 (lane & 7) .. + 3
-            if constexpr ((kSplitDiagSkip & 32768) != 0) {  // tuning builds: transposes without the global stores
-              asm volatile("" ::"v"(t_rows[i]));
-            } else {
-              __builtin_amdgcn_raw_buffer_store_b128(t_rows[i], h2rsrc, h2_voff + (8 * i * kHidden + 32 * nt) * 4, 0, RL8_H2_STORE_AUX);
-            }
-          }
-          if constexpr ((kSplitDiagSkip & 16384) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tuning builds: expose the store latency
-        }
-      }
-    }
-    RL8_SPLIT_STAMP_E(trace_it, wave, 1);
-    // Half-wave exchange: lane (l32, hh) ends with the total of row 64 wr + 32 hh + l32
-    // over this wave's 128 columns (v_permlane32_swap: [A_lo, B_lo] and [A_hi, B_hi]).
-    float total[kOut];
-#pragma unroll
-    for (int q = 0; q < kOut; ++q) {
-      float p0 = part[0][q][0] + part[0][q][1], p1 = part[1][q][0] + part[1][q][1];
-      if constexpr (kChains == 4) {
-        p0 += part[0][q][2] + part[0][q][3];
-        p1 += part[1][q][2] + part[1][q][3];
-      }
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-      total[q] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    const int my_row = 64 * wr + lane_id();
-    if constexpr (SAVE && !(kSplitDiagSkip & 65536)) {
-      if (save_gate2 != nullptr) {
-        // full words = own nibbles | the other half-wave's; lane (l32, hh) keeps row
-        // 64 wr + 32 hh + l32's four words and stores them as one 16-byte piece
-        u32x4 words;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const auto s0 = __builtin_amdgcn_permlane32_swap(gate_words[0][nt], gate_words[0][nt], false, false);
-          const auto s1 = __builtin_amdgcn_permlane32_swap(gate_words[1][nt], gate_words[1][nt], false, false);
-          const uint32_t w0 = s0[0] | s0[1], w1 = s1[0] | s1[1];
-          words[nt] = hh ? w1 : w0;
-        }
-        if (my_row < rows) {
-          uint32_t *dst = save_gate2 + r0 * 8;  // uniform base, 32-bit lane offset
-          *reinterpret_cast<u32x4 *>(dst + (unsigned)(my_row * 8 + 4 * wc)) = words;
-        }
-      }
-    }
-    // The two column halves of the workgroup meet in LDS: the upper half (wc = 1)
-    // parks its totals, the lower half adds its own and stores the outputs.
-    if (wc == 1) {
-#pragma unroll
-      for (int q = 0; q < kOut; ++q)
-        if (q < n_out) lds_write_b32(outp + (my_row * kOut + q) * 4, total[q]);
-    }
-    RL8_SPLIT_STAMP_E(trace_it, wave, 2);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    RL8_SPLIT_STAMP_E(trace_it, wave, 3);
-    if (wc == 0 && my_row < rows) {
-#pragma unroll
-      for (int q = 0; q < kOut; ++q)
-        if (q < n_out)
-          (out + r0 * n_out)[(unsigned)(my_row * n_out + q)] = total[q] + lds_read_b32(outp + (my_row * kOut + q) * 4) + b3[q];
-    }
-    // (the next tile's head partials are parked a full tile later, behind sixteen
-    // barriers: no extra barrier needed here)
-  }
-}
-
-template <int DIN, int NOUT, bool SAVE>
-static int launch_forward_split(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
-                                const float *b1, const void *w2s, const float *b2, const float *w3,
-                                const float *b3, int n_out, float *out, float *h1, float *h2, uint32_t *gate) {
-  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_forward_split_kernel<DIN, NOUT, SAVE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
-  mlp_tower_forward_split_kernel<DIN, NOUT, SAVE><<<grid, kBlock, split_forward_lds_bytes(kOut), s>>>(
-      x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-  return launch_status();
-}
-
-template <int DIN, int NOUT>
-static int launch_forward_split_save(int grid, hipStream_t s, const float *x, int64_t m, int d_in, const float *w1,
-                                     const float *b1, const void *w2s, const float *b2, const float *w3,
-                                     const float *b3, int n_out, float *out, float *h1, float *h2, uint32_t *gate) {
-  return h2 ? launch_forward_split<DIN, NOUT, true>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate)
-            : launch_forward_split<DIN, NOUT, false>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-}
-
-template <int DIN>
-static int dispatch_forward_split_nout(int n_out, int grid, hipStream_t s, const float *x, int64_t m, int d_in,
-                                       const float *w1, const float *b1, const void *w2s, const float *b2,
-                                       const float *w3, const float *b3, float *out, float *h1, float *h2,
-                                       uint32_t *gate) {
-  switch (n_out) {
-    case 1: return launch_forward_split_save<DIN, 1>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-    case 2: return launch_forward_split_save<DIN, 2>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-    case 3: return launch_forward_split_save<DIN, 3>(grid, s, x, m, d_in, w1, b1, w2s, b2, w3, b3, n_out, out, h1, h2, gate);
-    default: return RL8_ESIZE;
-  }
-}
-
-// ---- backward ("dgrad" half) on the same scheme --------------------------------
-//   dZ2 = (dOut x W3) * (h2 > 0)   computed per k-chunk on the VALU (thread = row,
-//                                  eight columns), stored for the weight-gradient
-//                                  product and split into the A planes;
-//   dH1 = dZ2 x W2                 bf16-plane MFMAs (B = W2 packed transposed);
-//   dZ1 = dH1 * (h1 > 0)           accumulator epilogue, folded into dW1 / db1
-//                                  (lane = column: per-lane running sums).
-// The head gradients (db2, dW3, db3) are column sums over rows of quantities that
-// this kernel holds row-per-thread; they are formed by mlp_head_grads_kernel, an
-// HBM-streaming kernel with thread = column, into the same partial rows.
-template <int DIN, int NOUT>
-__global__ __launch_bounds__(kBlock, (DIN == 0 || NOUT == 0) ? 1 : 2) void mlp_tower_backward_split_kernel(
-    const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
-    const float *__restrict__ h2, const float *__restrict__ dout, int64_t m, int d_in_rt,
-    const void *__restrict__ w2ts, const float *__restrict__ w3, int n_out_rt, float *__restrict__ dz2_out,
-    float *__restrict__ partials, int partial_stride, int head_rows, const uint32_t *__restrict__ gate2) {
-  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
-  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
-  const int d_in = DIN > 0 ? DIN : d_in_rt;
-  const int n_out = NOUT > 0 ? NOUT : n_out_rt;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const unsigned lds0 = lds_offset(smem);
-  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int prow = tid & 127, pkh = wave >> 1;  // producer role: row, wave-uniform k-half (see the forward kernel)
-  // gate2 given: the ReLU gate of h2 comes as bits (the forward kernel's save_gate2),
-  // one 4-KiB block per tile copied to LDS by direct-to-LDS loads, instead of 1 KiB
-  // of h2 per row through registers a step ahead -- that HBM latency, forced to
-  // fit one k-step by the step barrier's vmcnt(0), was 40 % of this kernel.
-  const bool use_bits = gate2 != nullptr;
-  const unsigned gate_lds = lds0 + 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4;  // [128 rows][8 words]
-  uint32_t g0 = 0u;  // word 0 of row prow of the NEXT tile (its chunk 0 is produced before the block lands)
-  // Wide observations (d_in >= 3): the running column sums [256][1 + d_in] and the 4-KiB
-  // gate block do not both fit beside the two chunk stages in 80 KB, and at one workgroup
-  // per CU this kernel lost a third of its speed (CartPole: 29 ms per 2^25 rows against 19
-  // for d_in = 1).  There the gate word of (row, two k-steps) is fetched into a register two
-  // steps ahead instead (4 bytes per thread and pair of steps, L2 hits after a row's first
-  // word): `g0` is the word in use, `gnext` the one on its way.  No gate block in LDS.
-  constexpr bool kRegGate = kIn >= 3 && DIN > 0;
-  [[maybe_unused]] uint32_t gnext = 0u;
-  const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
-  const unsigned b_read = lds0 + kSplitABytes + (4 * wc * 3) * 1024 + lane * 16;
-  const unsigned a_write = lds0 + pkh * kSplitKhStride + prow * 16;
-  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2ts, kSplitPackedBytes);
-
-  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
-  const int64_t stride = gridDim.x;
-
-  // Producer state (one step ahead of the consumer; moves to the next tile before step 15).
-  int64_t p_tile = blockIdx.x;
-  int p_rows;                // valid rows of the producer's tile
-  float dr[kOut], dn[kOut];  // dOut of row prow of the producer's tile / of the tile after
-  auto rows_in_tile = [&](int64_t tile) {
-    const int64_t left = m - tile * kSplitRows;
-    return left <= 0 ? 0 : left < kSplitRows ? (int)left : kSplitRows;
-  };
-  // (addresses: uniform tile base + 32-bit lane offset -- 64-bit per-lane pointers cost
-  // registers the matrix loop does not have)
-  auto load_dout = [&](float (&dst)[kOut], int64_t tile) {
-    const int rows = rows_in_tile(tile);
-    const float *base = dout + tile * kSplitRows * n_out;
-#pragma unroll
-    for (int q = 0; q < kOut; ++q) dst[q] = (prow < rows && q < n_out) ? base[(unsigned)(prow * n_out + q)] : 0.0f;
-  };
-  [[maybe_unused]] auto load_gate_word = [&](int64_t tile, int word) {
-    const int rows = rows_in_tile(tile);
-    gnext = prow < rows ? (gate2 + tile * (kSplitRows * 8))[(unsigned)(prow * 8 + word)] : 0u;
-  };
-  load_dout(dr, p_tile);
-  load_dout(dn, p_tile + stride);
-  // h2 of the chunk produced next (only without gate bits): this thread's eight columns,
-  // requested a step ahead; rows past the end read as zero (gate closed).
-  float4 hq[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-  const unsigned lane_off = prow * kHidden + 8 * pkh;
-  auto load_h2 = [&](float4 (&dst)[2], int64_t tile, int ks) {
-    const int rows = rows_in_tile(tile);
-    const float *base = h2 + tile * (kSplitRows * kHidden) + 16 * ks;
-    dst[0] = dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);  // (rows past the end: gate closed)
-    if (!(kSplitDiagSkip & 64) && prow < rows) {
-      dst[0] = *reinterpret_cast<const float4 *>(base + lane_off);
-      dst[1] = *reinterpret_cast<const float4 *>(base + lane_off + 4);
-    }
-  };
-  auto request_b = [&](int ks, int stage) {
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int block = wave * 6 + u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, smem + stage * kSplitStageBytes + kSplitABytes + block * 1024,
-                                               16, lane * 16, (ks * 24 + block) * 1024, 0, 0);
-    }
-  };
-  // Gate block of `tile` -> LDS: wave w copies rows 32w .. 32w+31 (1 KiB, contiguous);
-  // rows past the end of the data arrive as zeros (gate closed).
-  auto request_gate = [&](int64_t tile) {
-    const int rows = rows_in_tile(tile);
-    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? gate2 + tile * (kSplitRows * 8) : gate2, rows * 32);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, smem + 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4 + wave * 1024, 16,
-                                             lane * 16, wave * 1024, 0, 0);
-  };
-  auto load_g0 = [&](int64_t tile) {
-    const int rows = rows_in_tile(tile);
-    g0 = prow < rows ? (gate2 + tile * (kSplitRows * 8))[(unsigned)(prow * 8)] : 0u;
-  };
-  // hv: h2 values (use_bits false) -- or unused; from_regs: chunk 0 of a tile whose
-  // gate block has not landed yet takes its bits from g0.
-  auto produce_a = [&](const float4 (&hv)[2], int ks, u32x4 (&planes)[3], bool from_regs = false) {
-    const int kb = __builtin_amdgcn_readfirstlane(16 * ks + 8 * pkh);  // W3[q][kb + e]: uniform, through the scalar cache
-    uint32_t gword = g0;
-    if constexpr (!kRegGate) {
-      if (use_bits && !from_regs) gword = __float_as_uint(lds_read_b32(gate_lds + (prow * 8 + (ks >> 1)) * 4));
-    }
-    const uint32_t byte = gword >> (16 * (ks & 1) + 8 * pkh);
-    const float hval[8] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w};
-    float dz[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float g = dr[0] * w3[kb + e];
-#pragma unroll
-      for (int q = 1; q < kOut; ++q)
-        if (NOUT > 0 ? q < NOUT : q < n_out) g = __builtin_fmaf(dr[q], w3[q * kHidden + kb + e], g);
-      const bool open = use_bits ? ((byte >> e) & 1u) != 0 : hval[e] > 0.0f;
-      dz[e] = open ? g : 0.0f;
-    }
-    if constexpr (!(kSplitDiagSkip & 128)) {
-      if (dz2_out != nullptr && prow < p_rows) {  // (optional: the fused weight-gradient kernel re-forms dZ2)
-        f32x4 *dst = reinterpret_cast<f32x4 *>(dz2_out + p_tile * (kSplitRows * kHidden) + 16 * ks + lane_off);
-        dst[0] = f32x4{dz[0], dz[1], dz[2], dz[3]};
-        dst[1] = f32x4{dz[4], dz[5], dz[6], dz[7]};
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      uint32_t hi, mid, lo;
-      split_pair(dz[e], dz[e + 1], hi, mid, lo);
-      planes[0][e >> 1] = hi;
-      planes[1][e >> 1] = mid;
-      planes[2][e >> 1] = lo;
-    }
-  };
-  auto write_a = [&](int stage, const u32x4 (&planes)[3]) {
-    const unsigned addr = a_write + stage * kSplitStageBytes;
-    lds_write_b128<0>(addr, planes[0]);
-    lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
-    lds_write_b128<2 * kSplitPlaneStride>(addr, planes[2]);
-  };
-  auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  f32x16 acc[2][4];
-  // Running column sums [256][1 + kIn] (db1 | dW1 row) live in LDS behind the two
-  // chunk stages, not in registers: the matrix loop has none to spare.
-  const unsigned colsum = lds0 + 2 * kSplitStageBytes;
-  for (int idx = tid; idx < kHidden * (1 + kIn); idx += kBlock) lds_write_b32(colsum + idx * 4, 0.0f);
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-  auto do_step = [&](auto first_tag, auto parity_tag, int s) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    constexpr int P = decltype(parity_tag)::value;
-    const int ks = (s + 1) & (kSplitSteps - 1);
-    request_b(ks, P ^ 1);
-    const unsigned ar = a_read + P * kSplitStageBytes, br = b_read + P * kSplitStageBytes;
-    SplitFrags f;
-    f.ah[0] = lds_read_b128<0>(ar);
-    f.ah[1] = lds_read_b128<512>(ar);
-    f.bh[0] = lds_read_b128<0>(br);
-    f.bh[1] = lds_read_b128<3 * 1024>(br);
-    f.bh[2] = lds_read_b128<6 * 1024>(br);
-    f.bh[3] = lds_read_b128<9 * 1024>(br);
-    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
-    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
-    f.bm[0] = lds_read_b128<1024>(br);
-    f.bm[1] = lds_read_b128<4 * 1024>(br);
-    f.bm[2] = lds_read_b128<7 * 1024>(br);
-    f.bm[3] = lds_read_b128<10 * 1024>(br);
-    if (s == kSplitSteps - 1) {  // the producer moves on to the next tile
-#pragma unroll
-      for (int q = 0; q < kOut; ++q) dr[q] = dn[q];
-      p_tile += stride;
-      p_rows = rows_in_tile(p_tile);
-      load_dout(dn, p_tile + stride);
-      // every wave is past barrier(14): nobody reads the old gate block any more;
-      // the new one lands by this step's barrier, chunk 0 uses g0 meanwhile
-      if constexpr (!kRegGate) {
-        if (use_bits) request_gate(p_tile);
-      }
-    }
-    if constexpr (kRegGate) {
-      // chunk ks opens word ks / 2 when ks is even: take the prefetched word, request the
-      // next one (ks = 14: word 0 of the producer's next tile; ks = 0: p_tile has moved on)
-      if (use_bits && !(ks & 1)) {
-        g0 = gnext;
-        load_gate_word(ks == kSplitSteps - 2 ? p_tile + stride : p_tile, ((ks >> 1) + 1) & 7);
-      }
-    }
-    u32x4 planes[3];
-    produce_a(hq, ks, planes, s == kSplitSteps - 1);
-    if (use_bits) {
-      if constexpr (!kRegGate) {
-        if (s == kSplitSteps - 3) load_g0(p_tile + stride);  // two steps ahead of its use
-      }
-    } else {
-      // h2 of the chunk after next, into the registers just consumed: used by the
-      // next step's produce_a (the step barrier waits for it; it has this step to arrive).
-      load_h2(hq, s == kSplitSteps - 2 ? p_tile + stride : p_tile, (s + 2) & (kSplitSteps - 1));
-    }
-    wait_lds_all(f);
-    split_mma<FIRST>(f.am, f.bm, acc);
-    split_mma<false>(f.ah, f.bm, acc);
-    split_mma<false>(f.am, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    write_a(P ^ 1, planes);
-    f.am[0] = lds_read_b128<2 * kSplitPlaneStride>(ar);
-    f.am[1] = lds_read_b128<2 * kSplitPlaneStride + 512>(ar);
-    f.bm[0] = lds_read_b128<2 * 1024>(br);
-    f.bm[1] = lds_read_b128<5 * 1024>(br);
-    f.bm[2] = lds_read_b128<8 * 1024>(br);
-    f.bm[3] = lds_read_b128<11 * 1024>(br);
-    __builtin_amdgcn_sched_barrier(0);
-    split_mma<false>(f.ah, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_lds_all(f);
-    split_mma<false>(f.ah, f.bm, acc);
-    split_mma<false>(f.am, f.bh, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    step_barrier();
-  };
-  using T = std::true_type;
-  using F = std::false_type;
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-
-  p_rows = rows_in_tile(p_tile);
-  if ((int64_t)blockIdx.x < tiles) {
-    if (use_bits) {
-      if constexpr (kRegGate) {
-        load_gate_word(p_tile, 0);
-        g0 = gnext;
-        load_gate_word(p_tile, 1);  // opened by chunk 2, i.e. in step 1
-      } else {
-        request_gate(p_tile);
-        step_barrier();  // (once per kernel: the first gate block has landed)
-      }
-    } else {
-      load_h2(hq, p_tile, 0);
-    }
-    request_b(0, 0);
-    u32x4 planes[3];
-    produce_a(hq, 0, planes);
-    write_a(0, planes);
-    if (!use_bits) load_h2(hq, p_tile, 1);
-    step_barrier();
-  }
-
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
-    const int64_t r0 = tile * kSplitRows;
-    const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
-    do_step(T{}, P0{}, 0);
-    do_step(F{}, P1{}, 1);
-#pragma unroll 1
-    for (int s = 2; s < kSplitSteps - 2; s += 2) {
-      do_step(F{}, P0{}, s);
-      do_step(F{}, P1{}, s + 1);
-    }
-    do_step(F{}, P0{}, kSplitSteps - 2);
-    do_step(F{}, P1{}, kSplitSteps - 1);
-
-    // Epilogue: dZ1 = dH1 * (h1 > 0) folded into db1 / dW1.  The gate is RECOMPUTED
-    // from the observations -- h1 > 0 <=> b1 + x . w1 > 0, the same fma chain as the
-    // forward pass, so the same decision bit for bit -- instead of reading 1 KiB of
-    // h1 per row back from HBM (d_in is tiny; the observations are needed for dW1
-    // anyway).  They arrive through a tile-sized descriptor: rows past the end of
-    // a partial tile read as zero and their dH1 is zero (zero dOut).
-    const __amdgpu_buffer_rsrc_t xrsrc = buffer_rsrc(x + r0 * d_in, rows * d_in * 4);
-    const int l32 = lane_id() & 31, hh = lane_id() >> 5;  // (recomputed: see lane_id)
-    const unsigned colsum = lds_offset(smem) + 2 * kSplitStageBytes;
-    float w1c[4][kIn], b1c[4];  // this lane's four columns of layer 1 (reloaded per tile: L1 hits)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int col = 128 * wc + 32 * nt + l32;
-      b1c[nt] = b1[col];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) w1c[nt][i] = (DIN > 0 || i < d_in) ? w1[col * d_in + i] : 0.0f;
-    }
-    float db1[4], dw1[4][kIn];  // this tile: this lane's four columns, its half of the rows
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      db1[nt] = 0.0f;
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) dw1[nt][i] = 0.0f;
-    }
-    // (narrow observations: the sixteen rows a row tile needs are requested together, up
-    // front -- per batch of four, their L1 round trip sat in front of every batch)
-    constexpr int kXRows = kIn <= 2 ? 16 : 4;
-    constexpr int kBatches = 2 * 16 / kXRows;  // batches of kXRows rows over both row tiles
-    auto load_rows = [&](float (&dst)[kXRows][kIn], int batch) {
-      const int mt = batch / (16 / kXRows), rx = (batch % (16 / kXRows)) * kXRows;
-#pragma unroll
-      for (int u = 0; u < kXRows; ++u) {
-        const int r = rx + u;
-        const int sr = 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2);  // + 4*hh
-#pragma unroll
-        for (int i = 0; i < kIn; ++i)
-          dst[u][i] = (DIN > 0 || i < d_in) ? buffer_load_f32(xrsrc, (4 * hh * d_in + i) * 4, sr * d_in * 4) : 0.0f;
-      }
-    };
-    // (wide observations: batches of four rows, the NEXT batch's rows requested before the
-    // current batch is folded -- eight L1 round trips per tile sat in front of the batches)
-    float xbuf[2][kXRows][kIn];
-    load_rows(xbuf[0], 0);
-#pragma unroll
-    for (int batch = 0; batch < kBatches; ++batch) {
-      const int mt = batch / (16 / kXRows), rx = (batch % (16 / kXRows)) * kXRows;
-      if (batch + 1 < kBatches) load_rows(xbuf[(batch + 1) & 1], batch + 1);
-      float (&xv)[kXRows][kIn] = xbuf[batch & 1];
-#pragma unroll
-      for (int rb = 0; rb < kXRows; rb += 4)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          float pre[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            pre[u] = b1c[nt];
-#pragma unroll
-            for (int i = 0; i < kIn; ++i) pre[u] = __builtin_fmaf(xv[rb + u][i], w1c[nt][i], pre[u]);
-          }
-          unsigned long long gate[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) gate[u] = positive_mask(pre[u]);
-          __builtin_amdgcn_sched_barrier(0);
-          float dz[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) dz[u] = select_or_zero(gate[u], acc[mt][nt][rx + rb + u]);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            db1[nt] += dz[u];
-#pragma unroll
-            for (int i = 0; i < kIn; ++i) dw1[nt][i] = __builtin_fmaf(dz[u], xv[rb + u][i], dw1[nt][i]);
-          }
-        }
-    }
-    // Into the running sums, in a fixed order: the two row halves of a lane pair
-    // (DPP-free: one cross-half shuffle), then the wave of rows 0..63, a barrier,
-    // the wave of rows 64..127.  (The next tile touches them sixteen barriers later.)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      db1[nt] += __shfl_xor(db1[nt], 32, kWave);
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) dw1[nt][i] += __shfl_xor(dw1[nt][i], 32, kWave);
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (wr == half && hh == 0) {
-        // all reads, one wait, all writes (one read-modify-write at a time is a chain of LDS round trips)
-        float cur[4][1 + kIn];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int i = 0; i < 1 + kIn; ++i)
-            asm volatile("ds_read_b32 %0, %1" : "=v"(cur[nt][i]) : "v"(colsum + ((128 * wc + 32 * nt + l32) * (1 + kIn) + i) * 4));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const unsigned a = colsum + (128 * wc + 32 * nt + l32) * (1 + kIn) * 4;
-          float v0 = cur[nt][0];
-          asm volatile("" : "+v"(v0));  // (use behind the wait)
-          lds_write_b32(a, v0 + db1[nt]);
-#pragma unroll
-          for (int i = 0; i < kIn; ++i) {
-            float vi = cur[nt][1 + i];
-            asm volatile("" : "+v"(vi));
-            lds_write_b32(a + 4 + 4 * i, vi + dw1[nt][i]);
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-  }
-
-  // Workgroup partial row: [dW1 (256*d_in) | db1 (256) | ... head gradients (mlp_head_grads_kernel)].
-  float *row = partials + (int64_t)blockIdx.x * partial_stride;
-  {
-    const int t = 64 * wave + lane_id();
-    const unsigned a = lds_offset(smem) + 2 * kSplitStageBytes + t * (1 + kIn) * 4;
-    row[kHidden * d_in + t] = lds_read_b32(a);
-#pragma unroll
-    for (int i = 0; i < kIn; ++i)
-      if (DIN > 0 || i < d_in) row[t * d_in + i] = lds_read_b32(a + 4 + 4 * i);
-    // head_rows >= 0: the head-gradient segments of the first head_rows rows belong
-    // to the fused weight-gradient kernel; rows beyond them are zero.
-    if (head_rows >= 0 && (int)blockIdx.x >= head_rows)
-      for (int idx = kHidden * d_in + kHidden + t; idx < partial_stride; idx += kBlock) row[idx] = 0.0f;
-  }
-}
-
-// db2 = sum_rows dZ2, dW3 = dOut^T h2, db3 = sum_rows dOut: thread = column, rows
-// streamed from HBM (h2: 1 KiB per row; dOut through the scalar cache).  Workgroup
-// b covers the same 128-row tiles as workgroup b of the kernel above and writes
-// the remaining segments of the same partial row.
-template <int NOUT>
-__global__ __launch_bounds__(kBlock) void mlp_head_grads_kernel(
-    const float *__restrict__ h2, const float *__restrict__ dout, int64_t m, const float *__restrict__ w3,
-    int n_out_rt, int d_in, float *__restrict__ partials, int partial_stride) {
-  constexpr int kOut = NOUT > 0 ? pad_out(NOUT) : kMaxOut;
-  const int n_out = NOUT > 0 ? NOUT : n_out_rt;
-  const int tid = threadIdx.x;
-  float w3r[kOut];
-#pragma unroll
-  for (int q = 0; q < kOut; ++q) w3r[q] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
-  float db2[2] = {0.0f, 0.0f}, dw3[kOut][2], db3[kOut];
-#pragma unroll
-  for (int q = 0; q < kOut; ++q) dw3[q][0] = dw3[q][1] = db3[q] = 0.0f;
-  constexpr int kBatch = 16;
-  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t r0 = tile * kSplitRows;
-    const int rows = (int)((m - r0) < kSplitRows ? (m - r0) : kSplitRows);
-    const __amdgpu_buffer_rsrc_t h2rsrc = buffer_rsrc(h2 + r0 * kHidden, rows * kHidden * 4);
-    for (int s0 = 0; s0 < rows; s0 += kBatch) {
-      float hv[kBatch];
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u) hv[u] = buffer_load_f32(h2rsrc, tid * 4, (s0 + u) * (kHidden * 4));
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
-        const int s = s0 + u;
-        const bool valid = s < rows;
-        const int64_t srow = r0 + (valid ? s : rows - 1);
-        float g = 0.0f;
-#pragma unroll
-        for (int q = 0; q < kOut; ++q) {
-          if (NOUT > 0 ? q < NOUT : q < n_out) {
-            const float d = valid ? dout[srow * n_out + q] : 0.0f;
-            g = __builtin_fmaf(d, w3r[q], g);
-            dw3[q][u & 1] = __builtin_fmaf(d, hv[u], dw3[q][u & 1]);
-            db3[q] += d;
-          }
-        }
-        db2[u & 1] += hv[u] > 0.0f ? g : 0.0f;
-      }
-    }
-  }
-  float *row = partials + (int64_t)blockIdx.x * partial_stride;
-  const int off_db2 = kHidden * d_in + kHidden, off_dw3 = off_db2 + kHidden, off_db3 = off_dw3 + n_out * kHidden;
-  row[off_db2 + tid] = db2[0] + db2[1];
-#pragma unroll
-  for (int q = 0; q < kOut; ++q)
-    if (q < n_out) {
-      row[off_dw3 + q * kHidden + tid] = dw3[q][0] + dw3[q][1];
-      if (tid == q) row[off_db3 + q] = db3[q];
-    }
-}
-
-template <int DIN, int NOUT>
-static int launch_backward_split(int grid, hipStream_t s, const float *x, const float *w1, const float *b1,
-                                 const float *h2, const float *dout, int64_t m, int d_in, const void *w2ts,
-                                 const float *w3, int n_out, float *dz2_out, float *partials, int stride,
-                                 int head_rows = -1, const uint32_t *gate2 = nullptr) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_split_kernel<DIN, NOUT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
-  constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
-  constexpr int kGateBlock = (kIn >= 3 && DIN > 0) ? 0 : kSplitRows * 32;  // (wide inputs: gate words through registers)
-  static_assert(DIN == 0 || NOUT == 0 || 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4 + kGateBlock <= 80 * 1024,
-                "two workgroups per CU");
-  mlp_tower_backward_split_kernel<DIN, NOUT><<<grid, kBlock, 2 * kSplitStageBytes + kHidden * (1 + kIn) * 4 + kGateBlock, s>>>(
-      x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
-  const int status = launch_status();
-  if (status != 0 || head_rows >= 0) return status;  // (fused: the weight-gradient kernel forms the head gradients)
-  mlp_head_grads_kernel<NOUT><<<grid, kBlock, 0, s>>>(h2, dout, m, w3, n_out, d_in, partials, stride);
-  return launch_status();
-}
-
-template <int DIN>
-static int dispatch_backward_split_nout(int n_out, int grid, hipStream_t s, const float *x, const float *w1,
-                                        const float *b1, const float *h2, const float *dout, int64_t m, int d_in,
-                                        const void *w2ts, const float *w3, float *dz2_out, float *partials,
-                                        int stride, int head_rows, const uint32_t *gate2) {
-  switch (n_out) {
-    case 1: return launch_backward_split<DIN, 1>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
-    case 2: return launch_backward_split<DIN, 2>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
-    case 3: return launch_backward_split<DIN, 3>(grid, s, x, w1, b1, h2, dout, m, d_in, w2ts, w3, n_out, dz2_out, partials, stride, head_rows, gate2);
-    default: return RL8_ESIZE;
-  }
-}
 
 // ---- weight gradient of the 256x256 layer on the same scheme -------------------
 //   dW2[j][i] = sum over samples s of dZ2[s][j] * h1[s][i]
@@ -2220,91 +1165,8 @@ __global__ __launch_bounds__(kBlock) void dout_pair_check_kernel(const uint32_t 
 
 using namespace rl8;
 
-#ifdef RL8_SPLIT_TRACE
-RL8_API int rl8_debug_split_trace(unsigned long long *host_dst) {
-  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_split_trace), sizeof(g_split_trace));
-}
-RL8_API int rl8_debug_split_trace_epilogue(unsigned long long *host_dst) {
-  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_split_trace_epilogue), sizeof(g_split_trace_epilogue));
-}
-#endif
-
-RL8_API int64_t rl8_mlp_split_packed_bytes(void) { return kSplitPackedBytes; }
-
-RL8_API int rl8_mlp_pack_w2_split(const float *w2, int transposed, void *packed, void *stream) {
-  if (!w2 || !packed) return RL8_ENULL;
-  if (((uintptr_t)packed & 15) != 0) return RL8_EALIGN;
-  mlp_pack_w2_split_kernel<<<(kSplitSteps * 8 * 64 + kBlock - 1) / kBlock, kBlock, 0, (hipStream_t)stream>>>(
-      w2, transposed, reinterpret_cast<uint32_t *>(packed));
-  return launch_status();
-}
-
-RL8_API int rl8_mlp_tower_forward_split_f32(const float *x, int64_t m, int d_in, const float *w1,
-                                            const float *b1, const void *w2_split, const float *b2,
-                                            const float *w3, const float *b3, int n_out, float *out,
-                                            float *save_h1, float *save_h2, uint32_t *save_gate2, void *stream) {
-  if (!x || !w1 || !b1 || !w2_split || !b2 || !w3 || !b3 || !out) return RL8_ENULL;
-  if ((save_h1 != nullptr || save_gate2 != nullptr) && save_h2 == nullptr) return RL8_ENULL;  // h2 alone is allowed
-  if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
-  if (((uintptr_t)w2_split & 15) != 0 || !aligned16(w1) || !aligned16(b1) || (save_h1 && !aligned16(save_h1)) ||
-      (save_h2 && !aligned16(save_h2)))
-    return RL8_EALIGN;
-  const int64_t tiles = (m + kSplitRows - 1) / kSplitRows;
-  static const int cap = env_int("RL8_MLP_GRID_CAP");
-  const int max_grid = cap > 0 ? cap : 2 * kCUs;
-  const int grid = (int)(tiles < max_grid ? tiles : max_grid);
-  hipStream_t s = (hipStream_t)stream;
-  // Only the widths whose kernels are verified spill-free are compiled (see
-  // rl8_mlp_forward_split_supports); the rest keep rl8_mlp_tower_forward_f32.
-  switch (d_in) {
-    case 1: return dispatch_forward_split_nout<1>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
-    case 2: return dispatch_forward_split_nout<2>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
-    case 3: return dispatch_forward_split_nout<3>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
-    case 5: return dispatch_forward_split_nout<5>(n_out, grid, s, x, m, d_in, w1, b1, w2_split, b2, w3, b3, out, save_h1, save_h2, save_gate2);
-    default: return RL8_ESIZE;
-  }
-}
-
-// These kernels read LDS through inline asm the compiler cannot see; a register
-// spill placed between such a read and its wait could save a register whose data
-// has not arrived.  So a width is offered only if its kernel compiles WITHOUT
-// scratch (tests/test_kernel_resources.py holds the list to that); other widths
-// use the fp32-MFMA kernels.
-RL8_API int rl8_mlp_forward_split_supports(int d_in, int n_out) {
-  return (d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5) && n_out >= 1 && n_out <= 3;
-}
-
+// Grids of the two halves of the fused backward: see fused_backward_grids below.
 static void fused_backward_grids(int64_t m, int *g1, int *g2);
-
-RL8_API int rl8_mlp_tower_backward_split_f32(const float *x, const float *w1, const float *b1,
-                                             const float *h2, const float *dout, int64_t m, int d_in,
-                                             const void *w2t_split, const float *w3, int n_out,
-                                             float *dz2_out, float *partials, int *partial_rows_out,
-                                             const uint32_t *gate2, void *stream) {
-  if (!x || !w1 || !b1 || (!h2 && (!gate2 || dz2_out)) || !dout || !w2t_split || !w3 || !partials || !partial_rows_out)
-    return RL8_ENULL;
-  if (m <= 0 || d_in <= 0 || d_in > kMaxIn || n_out <= 0 || n_out > kMaxOut) return RL8_ESIZE;
-  if (((uintptr_t)w2t_split & 15) != 0 || !aligned16(h2) || !aligned16(dz2_out) || !aligned16(w3)) return RL8_EALIGN;
-  int grid, g2;
-  fused_backward_grids(m, &grid, &g2);
-  // dz2_out == NULL: first half of the fused backward -- no dZ2 store, no head-gradient
-  // launch; rl8_mlp_wgrad_fused_split_f32 fills the head segments of rows < g2.
-  const int head_rows = dz2_out ? -1 : g2;
-  *partial_rows_out = dz2_out ? grid : (grid > g2 ? grid : g2);
-  const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
-  hipStream_t s = (hipStream_t)stream;
-  switch (d_in) {
-    case 1: return dispatch_backward_split_nout<1>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows, gate2);
-    case 2: return dispatch_backward_split_nout<2>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows, gate2);
-    case 3: return dispatch_backward_split_nout<3>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows, gate2);
-    case 5: return dispatch_backward_split_nout<5>(n_out, grid, s, x, w1, b1, h2, dout, m, d_in, w2t_split, w3, dz2_out, partials, stride, head_rows, gate2);
-    default: return RL8_ESIZE;  // rl8_mlp_backward_split_supports(): other widths use rl8_mlp_tower_backward_f32
-  }
-}
-
-RL8_API int rl8_mlp_backward_split_supports(int d_in, int n_out) {
-  return rl8_mlp_forward_split_supports(d_in, n_out);  // spill-free widths only
-}
 
 /* dW2 (+)= dZ2^T h1 with h1 recomputed from the observations (see the kernel). */
 RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const float *w1, const float *b1,
@@ -2439,7 +1301,7 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
                                           const float *b1, const float *w3, int64_t m, int d_in, int n_out,
                                           float *workspace, float *dw2_out, float *partials, void *stream) {
   if (!h2 || !dout || !x || !w1 || !b1 || !w3 || !workspace || !dw2_out || !partials) return RL8_ENULL;
-  if (m <= 0 || !rl8_mlp_backward_split_supports(d_in, n_out)) return RL8_ESIZE;
+  if (m <= 0 || !rl8_mlp_backward_f16_supports(d_in, n_out)) return RL8_ESIZE;
   if (!aligned16(h2) || !aligned16(workspace) || !aligned16(dw2_out)) return RL8_EALIGN;
   int g1, g2;
   fused_backward_grids(m, &g1, &g2);
@@ -2516,7 +1378,7 @@ RL8_API int rl8_mlp_wgrad_fused_pair_f32(const float *h2, const float *dout, con
                                          const float *b1, const float *w3, int64_t m, int d_in,
                                          float *workspace, float *dw2_out, float *partials, void *stream) {
   if (!h2 || !dout || !x || !w1 || !b1 || !w3 || !workspace || !dw2_out || !partials) return RL8_ENULL;
-  if (m <= 0 || !rl8_mlp_backward_split_supports(d_in, 2)) return RL8_ESIZE;
+  if (m <= 0 || !rl8_mlp_backward_f16_supports(d_in, 2)) return RL8_ESIZE;
   if (!aligned16(h2) || !aligned16(workspace) || !aligned16(dw2_out) || ((uintptr_t)dout & 7) != 0) return RL8_EALIGN;
   int g1, g2;
   fused_backward_grids(m, &g1, &g2);
@@ -2552,7 +1414,7 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
                                         int64_t m, int d_in, int n_out, float *workspace, float *dw2_out,
                                         float *partials, void *stream) {
   if (!gate2 || !dout || !x || !w1 || !b1 || !w2 || !b2 || !w3 || !workspace || !dw2_out || !partials) return RL8_ENULL;
-  if (m <= 0 || (n_out != 1 && n_out != 2) || !rl8_mlp_backward_split_supports(d_in, n_out)) return RL8_ESIZE;
+  if (m <= 0 || (n_out != 1 && n_out != 2) || !rl8_mlp_backward_f16_supports(d_in, n_out)) return RL8_ESIZE;
   if (!aligned16(gate2) || !aligned16(workspace) || !aligned16(dw2_out) || ((uintptr_t)dout & 7) != 0) return RL8_EALIGN;
   int g1, g2;
   fused_backward_grids(m, &g1, &g2);

@@ -145,9 +145,6 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_wgrad_split_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_pack_w2_f32": [_vp, _vp, _i32, _vp],
     "rl8_mlp_tower_forward_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
-    "rl8_mlp_split_packed_bytes": [],
-    "rl8_mlp_pack_w2_split": [_vp, _i32, _vp, _vp],
-    "rl8_mlp_tower_forward_split_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "rl8_mlp_backward_partial_floats": [_i32, _i32],
     "rl8_mlp_backward_max_rows": [],
     "rl8_mlp_tower_backward_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
@@ -162,9 +159,6 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_mlp_forward_f16_supports": [_i32, _i32],
     "rl8_mlp_pack_w2_f16": [_vp, _i32, _vp, _vp],
     "rl8_mlp_tower_forward_f16_f32": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
-    "rl8_mlp_backward_split_supports": [_i32, _i32],
-    "rl8_mlp_forward_split_supports": [_i32, _i32],
-    "rl8_mlp_tower_backward_split_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp, _vp],
     "rl8_mlp_wgrad_split_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "rl8_mlp_wgrad_fused_split_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "rl8_mlp_wgrad_workspace_bytes": [],
@@ -194,7 +188,7 @@ def load() -> C.CDLL:
             fn.restype = (
                 C.c_int64
                 if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes",
-                            "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats", "rl8_mlp_split_packed_bytes",
+                            "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats",
                             "rl8_lstm_split_packed_bytes", "rl8_lstm_split_wb_floats", "rl8_lstm_split_state_bytes",
                             "rl8_mlp_f16_packed_bytes", "rl8_lstm_rows_backward_pack_bytes")
                 else C.c_int
@@ -870,14 +864,6 @@ def mlp_tower_forward(
     return out, h1, h2
 
 
-def mlp_forward_split_supports(d_in: int, n_out: int) -> bool:
-    return bool(load().rl8_mlp_forward_split_supports(int(d_in), int(n_out)))
-
-
-def mlp_backward_split_supports(d_in: int, n_out: int) -> bool:
-    return bool(load().rl8_mlp_backward_split_supports(int(d_in), int(n_out)))
-
-
 def mlp_forward_f16_supports(d_in: int, n_out: int) -> bool:
     return bool(load().rl8_mlp_forward_f16_supports(int(d_in), int(n_out)))
 
@@ -912,26 +898,15 @@ def mlp_pack_w2_f16_gate(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
     return packed
 
 
-def mlp_pack_w2_split(w2: torch.Tensor, *, transposed: bool = False) -> torch.Tensor:
-    """[256, 256] nn.Linear weight -> three bf16 planes (w = hi + mid + lo exactly)
-    in the fragment order of the split-product kernels (393216 bytes, uint8)."""
-    w2 = _dense(w2.detach(), torch.float32, "w2")
-    if tuple(w2.shape) != (MLP_HIDDEN, MLP_HIDDEN):
-        raise ValueError("w2 must be [256, 256]")
-    lib = load()
-    packed = torch.empty(int(lib.rl8_mlp_split_packed_bytes()), dtype=torch.uint8, device=w2.device)
-    _check(lib.rl8_mlp_pack_w2_split(_ptr(w2), int(transposed), _ptr(packed), _stream()), "rl8_mlp_pack_w2_split")
-    return packed
-
-
 def mlp_tower_forward_split(
     x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2_split: torch.Tensor, b2: torch.Tensor,
     w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False, save_h1: bool = True, save_gate: bool = False,
     save_h2: bool = True,
 ) -> tuple[torch.Tensor, ...]:
-    """``mlp_tower_forward`` with the 256x256 product as six bf16-plane MFMAs per
-    16 k (fp32 accuracy, fp32 in / out / accumulate). ``save_h1=False`` keeps only
-    h2 (the bf16-plane backward kernels recompute h1). ``save_gate=True`` (with
+    """``mlp_tower_forward`` with the 256x256 product as three fp16-plane MFMAs per
+    16 k (fp32 accuracy, fp32 in / out / accumulate; ``w2_split`` from
+    ``mlp_pack_w2_f16``). ``save_h1=False`` keeps only h2 (the plane backward kernels
+    recompute h1). ``save_gate=True`` (with
     ``save``) appends a fourth result, the ReLU gate of h2 as bits ([M, 8] int32:
     bit j of row s = h2[s, j] > 0), which the data-gradient kernel reads instead of h2.
     ``save_h2=False`` (fp16-plane pack, with ``save_gate``): the gate bits ALONE are kept -- all the
@@ -947,14 +922,12 @@ def mlp_tower_forward_split(
     lib = load()
     if w2_split.dtype == torch.uint8 and w2_split.numel() == int(lib.rl8_mlp_f16_packed_bytes()):
         fn, fn_name = lib.rl8_mlp_tower_forward_f16_f32, "rl8_mlp_tower_forward_f16_f32"  # fp16 two-plane pack
-    elif w2_split.dtype == torch.uint8 and w2_split.numel() == int(lib.rl8_mlp_split_packed_bytes()):
-        fn, fn_name = lib.rl8_mlp_tower_forward_split_f32, "rl8_mlp_tower_forward_split_f32"
     else:
-        raise ValueError("w2_split must come from mlp_pack_w2_split or mlp_pack_w2_f16")
+        raise ValueError("w2_split must come from mlp_pack_w2_f16")
     out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
     if save and not save_h2:
-        if fn_name != "rl8_mlp_tower_forward_f16_f32" or not save_gate:
-            raise ValueError("save_h2=False needs the fp16-plane pack and save_gate=True")
+        if not save_gate:
+            raise ValueError("save_h2=False needs save_gate=True")
         save_h1 = False
     h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save and save_h1 else None
     h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save and save_h2 else None
@@ -997,14 +970,12 @@ def mlp_tower_backward(
     activations saved by the forward pass. Returns ``w1, b1, w2, b2, w3, b3``.
 
     ``w2t_packed`` from ``mlp_pack_w2(..., transposed=True)`` selects the fp32 MFMA
-    kernel; from ``mlp_pack_w2_split(..., transposed=True)`` (uint8) the bf16-plane
-    kernel, which also needs layer 1 (``w1``, ``b1``): it recomputes the ReLU gate
-    of h1 instead of reading h1 back. ``wgrad_split`` forms dW2 with the bf16-plane
+    kernel; from ``mlp_pack_w2_f16(..., transposed=True)`` (uint8) the fp16-plane
+    kernels (fused mode), which also need layer 1 (``w1``, ``b1``) -- they recompute
+    the ReLU gate of h1 instead of reading h1 back -- and ``gate2`` (``save_gate`` of
+    the forward): the gate bits of h2. ``wgrad_split`` forms dW2 with the plane
     weight-gradient kernel (any width; needs ``w1``, ``b1``) even when the
-    data-gradient half runs on the fp32 kernel. ``gate2`` (``save_gate`` of the
-    bf16-plane forward): gate bits of h2 for the data-gradient kernel. A pack from
-    ``mlp_pack_w2_f16(..., transposed=True)`` selects the fp16-plane data-gradient kernel
-    (fused mode: ``gate2`` required; the weight gradient stays on bf16 planes). ``gate_pack``: a
+    data-gradient half runs on the fp32 kernel. ``gate_pack``: a
     callable returning ``mlp_pack_w2_f16_gate(w2, w3)`` -- with it, single-output heads and two-output
     heads whose gradients are exact negatives (checked on ``dout``) run the data gradient in gate mode.
     ``h2=None`` (a forward with ``save_h2=False``: gate bits only) with the layer's own ``w2`` [256, 256] and
@@ -1014,11 +985,13 @@ def mlp_tower_backward(
     m, d_in = x.shape
     n_out = w3.shape[0]
     split = w2t_packed.dtype == torch.uint8
-    f16 = split and w2t_packed.numel() == int(load().rl8_mlp_f16_packed_bytes())
+    f16 = split
+    if split and w2t_packed.numel() != int(load().rl8_mlp_f16_packed_bytes()):
+        raise ValueError("w2t_packed: a uint8 pack must come from mlp_pack_w2_f16(..., transposed=True)")
     if f16 and gate2 is None:
         raise ValueError("the fp16-plane backward needs gate2 (mlp_tower_forward_split(save_gate=True))")
     if h1 is None and not split:
-        raise ValueError("h1 may be omitted only on the bf16-plane path")
+        raise ValueError("h1 may be omitted only on the fp16-plane path")
     for name, t, numel in (("x", x, m * d_in), ("h1", h1, m * MLP_HIDDEN), ("h2", h2, m * MLP_HIDDEN),
                            ("dout", dout, m * n_out)):
         if t is None:
@@ -1038,7 +1011,7 @@ def mlp_tower_backward(
         # fused: the data-gradient kernel stores no dZ2; the weight-gradient kernel
         # re-forms it (and h1) and accumulates the head gradients
         if w1 is None or b1 is None:
-            raise ValueError("the bf16-plane backward needs w1 and b1")
+            raise ValueError("the fp16-plane backward needs w1 and b1")
         w1p, b1p = _ptr(_dense(w1.detach(), torch.float32, "w1")), _ptr(_dense(b1.detach(), torch.float32, "b1"))
         # two outputs with exactly opposite gradients (a two-way categorical head): the weight
         # gradient can take the gate-plane kernel; checked on the data, the answer read back
@@ -1064,19 +1037,12 @@ def mlp_tower_backward(
                         _ptr(partials), C.byref(rows), _ptr(gate2), _stream()),
                     "rl8_mlp_tower_backward_gate_f16_f32",
                 )
-            elif f16:
+            else:
                 _check(
                     lib.rl8_mlp_tower_backward_f16_f32(
                         _ptr(x), w1p, b1p, _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
                         _ptr(partials), C.byref(rows), _ptr(gate2), _stream()),
                     "rl8_mlp_tower_backward_f16_f32",
-                )
-            else:
-                _check(
-                    lib.rl8_mlp_tower_backward_split_f32(
-                        _ptr(x), w1p, b1p, _ptr(h2), _ptr(dout), m, d_in, _ptr(w2t_packed), _ptr(w3.detach()), n_out,
-                        None, _ptr(partials), C.byref(rows), _ptr(gate2), _stream()),
-                    "rl8_mlp_tower_backward_split_f32",
                 )
         dw2 = torch.empty(MLP_HIDDEN, MLP_HIDDEN, dtype=torch.float32, device=x.device)
         # (bf16 planes for both generations: see rl8_mlp_tower_backward_f16_f32; single-output towers
@@ -1124,7 +1090,7 @@ def mlp_tower_backward(
         "b1": small[o1 : o1 + MLP_HIDDEN],
         "b2": small[o1 + MLP_HIDDEN : o1 + 2 * MLP_HIDDEN],
         "w3": small[o1 + 2 * MLP_HIDDEN : o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN].view(n_out, MLP_HIDDEN),
-        # (the fused bf16-plane backward leaves db3 -- a column sum of dout -- to the caller)
+        # (the fused plane backward leaves db3 -- a column sum of dout -- to the caller)
         "b3": _column_sums(dout) if split else small[o1 + 2 * MLP_HIDDEN + n_out * MLP_HIDDEN :],
         "w2": dw2 if split else (mlp_wgrad_split(dz2, x, w1, b1) if wgrad_split else mlp_wgrad(dz2, h1)),
     }

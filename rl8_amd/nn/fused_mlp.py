@@ -35,13 +35,13 @@ ENABLED = True
 #: operands scaled by powers of two (per activation row / per weight matrix) and
 #: split into two fp16 planes, three plane products per 16 k on the fp16 matrix
 #: pipe, fp32 accumulate (fp32 accuracy: same fp64 bars as the others);
-#: "split" = exact 3-way bf16 split, six plane products per 16 k (1.5x slower);
-#: "f32" = v_mfma_f32_32x32x2_f32 (2.7x slower).  ``RL8_AMD_TOWER_GEMM`` /
+#: "f32" = v_mfma_f32_32x32x2_f32 (2.7x slower; also what widths without a plane
+#: kernel run).  (The six-product bf16-plane forward / data-gradient kernels of rounds 1-2,
+#: "split", were removed in round 3.)  ``RL8_AMD_TOWER_GEMM`` /
 #: ``RL8_AMD_TOWER_FORWARD_GEMM`` / ``RL8_AMD_TOWER_BACKWARD_GEMM`` override.
 FORWARD_GEMM = os.environ.get("RL8_AMD_TOWER_FORWARD_GEMM", os.environ.get("RL8_AMD_TOWER_GEMM", "f16"))
 #: Same choice for the data-gradient product of the backward pass (the weight
-#: gradient dW2 stays on bf16 planes under "f16": it sums over samples, where a
-#: per-row power of two cannot be taken out of the sum).
+#: gradient runs on fp16 planes scaled per output column, ``hip`` / mlp_split_kernels.hip).
 BACKWARD_GEMM = os.environ.get("RL8_AMD_TOWER_BACKWARD_GEMM", os.environ.get("RL8_AMD_TOWER_GEMM", "f16"))
 
 
@@ -54,7 +54,7 @@ def _packed(layer: nn.Linear, transposed: bool, split: bool | str = False) -> to
     hit = cache.get((transposed, split))
     if hit is not None and hit[0] == w2._version and hit[1] == w2.data_ptr():
         return hit[2]
-    pack = hip.mlp_pack_w2_f16 if split == "f16" else hip.mlp_pack_w2_split if split else hip.mlp_pack_w2
+    pack = hip.mlp_pack_w2_f16 if split == "f16" else hip.mlp_pack_w2
     packed = pack(w2, transposed=transposed)
     cache[(transposed, split)] = (w2._version, w2.data_ptr(), packed)
     return packed
@@ -115,10 +115,10 @@ class _FusedTower(torch.autograd.Function):
         # always off: the caller's grad mode comes in as an argument, so that
         # activations are kept only when a backward can follow.
         need_grad = grad_mode and any(ctx.needs_input_grad[1:7])
-        if FORWARD_GEMM in ("split", "f16") and hip.mlp_forward_split_supports(x.shape[1], w3.shape[0]):
-            # h1 is stored only if a backward kernel will read it (the bf16-plane ones recompute it)
-            keep_h1 = not (BACKWARD_GEMM in ("split", "f16") and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0]))
-            f16 = FORWARD_GEMM == "f16" and hip.mlp_forward_f16_supports(x.shape[1], w3.shape[0])
+        if FORWARD_GEMM == "f16" and hip.mlp_forward_f16_supports(x.shape[1], w3.shape[0]):
+            # h1 is stored only if a backward kernel will read it (the plane kernels recompute it)
+            keep_h1 = not (BACKWARD_GEMM == "f16" and hip.mlp_backward_f16_supports(x.shape[1], w3.shape[0]))
+            f16 = True
             # Rank-one heads (one output; two outputs with exactly opposite gradients, as the last backward of
             # this tower found them) need only the gate bits of h2 in the backward pass: no h2 store, no h2
             # read.  Should a two-output head stop being rank-one, its backward re-runs this forward for h2.
@@ -126,7 +126,7 @@ class _FusedTower(torch.autograd.Function):
             gate_only = (need_grad and f16 and not keep_h1 and BACKWARD_GEMM == "f16"
                          and hip.mlp_backward_f16_supports(x.shape[1], n_out) and not _gates_off()
                          and (n_out == 1 or (n_out == 2 and pair)))
-            out, h1, h2, gate = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16" if f16 else True),
+            out, h1, h2, gate = hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16"),
                                                             b2, w3, b3, save=need_grad, save_h1=keep_h1, save_gate=True,
                                                             save_h2=not gate_only)
         else:
@@ -143,8 +143,8 @@ class _FusedTower(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
         x, h1, h2, w3, w1, b1, gate, b2, b3, w2 = ctx.saved_tensors
-        split: bool | str = BACKWARD_GEMM in ("split", "f16") and hip.mlp_backward_split_supports(x.shape[1], w3.shape[0])
-        if split and BACKWARD_GEMM == "f16" and gate is not None and hip.mlp_backward_f16_supports(x.shape[1], w3.shape[0]):
+        split: bool | str = False
+        if BACKWARD_GEMM == "f16" and gate is not None and hip.mlp_backward_f16_supports(x.shape[1], w3.shape[0]):
             split = "f16"
         layer2 = ctx.layer2
         w3_key = ctx.w3_key
@@ -156,7 +156,7 @@ class _FusedTower(torch.autograd.Function):
 
         info: dict = {}
         g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(layer2, True, split), w3,
-                                   w1, b1, wgrad_split=BACKWARD_GEMM in ("split", "f16"), gate2=gate if split else None,
+                                   w1, b1, wgrad_split=BACKWARD_GEMM == "f16", gate2=gate if split else None,
                                    gate_pack=gate_pack, w2=w2, b2=b2, h2_fn=h2_again, info=info)
         if w3.shape[0] == 2:  # what this backward found, for callers that give no hint (see tower_forward)
             layer2.__dict__["_rl8_rank_one"] = bool(info.get("rank_one", False))

@@ -98,9 +98,8 @@ def test_compiled_tower_kernels_do_not_use_scratch(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_compiled_split_kernels_resources(tmp_path):
-    """The bf16-plane tower kernels: every variant that is compiled (and so can be
-    dispatched: rl8_mlp_*_split_supports) must be free of scratch and fit two
-    workgroups per CU."""
+    """The plane weight-gradient kernels of mlp_split_kernels.hip (bf16 and fp16 planes; the forward and data-gradient
+    kernels of this file were removed in round 3): every compiled variant free of scratch, 256 registers at most."""
     csrc = os.path.join(ROOT, "rl8_amd", "csrc")
     asm = tmp_path / "split.s"
     subprocess.run(
@@ -109,8 +108,7 @@ def test_compiled_split_kernels_resources(tmp_path):
         check=True, capture_output=True, timeout=900,
     )
     text = asm.read_text()
-    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)\n\ts_barrier", text)
-    assert len(waits) >= 14 * 6 and set(waits) == {"0"}  # the hand-written step barriers
+    assert len(re.findall(r"s_waitcnt lgkmcnt\(0\)\n\ts_barrier", text)) >= 40  # the hand-written step barriers
     # no packed fp32 arithmetic in these kernels (a hazard beside the bf16 MFMAs: see split_pair())
     assert not re.search(r"\bv_pk_(fma|add|mul)_f32\b", text)
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
@@ -118,14 +116,16 @@ def test_compiled_split_kernels_resources(tmp_path):
     for name, body in kernels:
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
-        if re.search(r"mlp_tower_(forward|backward)_split_kernel|mlp_wgrad_split_kernel|mlp_wgrad_gate_kernel", name):
+        assert not re.search(r"mlp_tower_(forward|backward)_split_kernel", name)
+        if re.search(r"mlp_wgrad_split_kernel|mlp_wgrad_gate_kernel", name):
             # every compiled (= dispatched) variant: no scratch at all -- these kernels read
             # LDS through inline asm, so a spill between a read and its wait is a hazard,
             # not just a slowdown -- and two workgroups per CU
             assert scratch == 0, (name, scratch)
             assert vgprs <= 256, (name, vgprs)
             checked += 1
-    assert checked >= 24 + 12 + 5 + 12 + 1 + 8  # (+ the two-operand weight-gradient mode, + the gate-plane kernels)
+    # general (5 run-time/compiled widths from memory + 12 fused, bf16 and fp16 planes), two-operand (4 + 4), gate-plane kernels
+    assert checked >= 5 + 12 + 12 + 4 + 4 + 8 + 8, checked
     _check_wgrad_scalar_windows(text)
     # Every hand-issued load (ds_read_b128, s_buffer_load_dwordx8, ...) of every kernel: nothing
     # reads or overwrites its destination before a wait that covers it, on any path.

@@ -38,34 +38,18 @@ def _rel(got, want):
     return float((got.double() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
 
 
-def test_split_planes_reconstruct_the_weights_exactly():
-    """hi + mid + lo == w bit for bit (truncation splits an fp32 significand 8+8+8)."""
-    g = torch.Generator(device=DEV).manual_seed(3)
-    w = torch.randn(256, 256, device=DEV, generator=g) * torch.logspace(-12, 6, 256, device=DEV)[:, None]
-    for transposed in (False, True):
-        packed = hip.mlp_pack_w2_split(w, transposed=transposed)
-        words = packed.view(torch.int16).view(16, 8, 3, 64, 8).to(torch.int32)  # [step][col tile][plane][lane][e]
-        planes = (words << 16).view(torch.float32).double().sum(2)              # [step][col tile][lane][e]
-        lane = torch.arange(64, device=DEV)
-        col = (32 * torch.arange(8, device=DEV)[None, :, None, None] + (lane & 31)[None, None, :, None]).expand(16, 8, 64, 8)
-        k = (16 * torch.arange(16, device=DEV)[:, None, None, None] + 8 * (lane >> 5)[None, None, :, None]
-             + torch.arange(8, device=DEV)[None, None, None, :]).expand(16, 8, 64, 8)
-        want = (w[k, col] if transposed else w[col, k]).double()
-        assert torch.equal(planes, want)
-
-
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (127, 1, 1), (128, 1, 2), (129, 2, 3), (1000, 5, 3), (4097, 1, 3),
                                           (5000, 3, 2), (70_001, 1, 2), (33_333, 5, 1), (20_000, 2, 2)])
-@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("scheme", ["f16x2"])
 def test_forward_split_is_fp32_accurate(m, d_in, n_out, scheme):
     """Both generations of the plane-product forward against the SAME bars: six
     bf16 plane products per 16 k ("bf16x3") and three scaled fp16 ones ("f16x2")."""
-    assert hip.mlp_forward_split_supports(d_in, n_out) and hip.mlp_forward_f16_supports(d_in, n_out)
+    assert hip.mlp_forward_f16_supports(d_in, n_out)
     g = torch.Generator(device=DEV).manual_seed(m + d_in)
     x = torch.randn(m, d_in, device=DEV, generator=g) * 30
     p = _params(g, d_in, n_out)
     want, h1w, h2w = _tower(x.double(), {k: v.double() for k, v in p.items()})
-    packed = (hip.mlp_pack_w2_f16 if scheme == "f16x2" else hip.mlp_pack_w2_split)(p["w2"])
+    packed = hip.mlp_pack_w2_f16(p["w2"])
     out, h1, h2 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"], save=True)
     assert _rel(out, want) < 4e-6 and _rel(h2, h2w) < 2e-6 and _rel(h1, h1w) < 1e-6
     # the same layer-1 fma chain as the fp32-MFMA kernel: h1 bit for bit
@@ -147,8 +131,8 @@ def test_forward_f16_scaling_holds_over_the_dynamic_range(case):
     want, h1w, h2w = _tower(x.double(), {k: v.double() for k, v in p.items()})
     out, _, h2 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
                                              save=True)
-    out6, _, h2_6 = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_split(p["w2"]), p["b2"], p["w3"], p["b3"],
-                                                save=True)
+    # yardstick: the fp32-MFMA kernel (the six-product bf16-plane forward of rounds 1-2 is gone)
+    out6, _, h2_6 = hip.mlp_tower_forward(x, p["w1"], p["b1"], hip.mlp_pack_w2(p["w2"]), p["b2"], p["w3"], p["b3"], save=True)
     assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(h2).all())
     # per ROW against that row's own magnitude (a global relative error would hide the small rows)
     row = h2w.abs().amax(1, keepdim=True) + p["b2"].abs().max().double()
@@ -161,25 +145,25 @@ def test_forward_f16_scaling_holds_over_the_dynamic_range(case):
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 5, 3), (4097, 3, 2), (40_000, 1, 2), (9000, 2, 1),
                                           (33_000, 1, 2), (33_000, 5, 3), (20_000, 3, 1), (16_500, 2, 3)])
-@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("scheme", ["f16x2"])
 def test_backward_split_matches_fp64(m, d_in, n_out, scheme):
     """Against an fp64 evaluation of the backward formulas on the SAVED activations
     (the ReLU gates are part of the input of a backward pass: an autograd run in
     fp64 flips the gates of pre-activations within fp32 rounding of zero, which
     says nothing about these kernels).  Both plane schemes against the same bars."""
-    assert hip.mlp_backward_split_supports(d_in, n_out) and hip.mlp_backward_f16_supports(d_in, n_out)
+    assert hip.mlp_backward_f16_supports(d_in, n_out)
     g = torch.Generator(device=DEV).manual_seed(7 * m + d_in)
     x = torch.randn(m, d_in, device=DEV, generator=g) * 3
     p = _params(g, d_in, n_out)
     dout = torch.randn(m, n_out, device=DEV, generator=g) / m
-    out, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_split(p["w2"]), p["b2"], p["w3"],
+    out, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"],
                                                     p["b3"], save=True, save_gate=True)
     d, a1, a2 = dout.double(), h1.double(), h2.double()
     dz2 = (d @ p["w3"].double()) * (a2 > 0)
     dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
     want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0), "w2": dz2.T @ a1, "b2": dz2.sum(0), "w3": d.T @ a2, "b3": d.sum(0)}
     f16 = scheme == "f16x2"
-    w2t = (hip.mlp_pack_w2_f16 if f16 else hip.mlp_pack_w2_split)(p["w2"], transposed=True)
+    w2t = hip.mlp_pack_w2_f16(p["w2"], transposed=True)
     grads = hip.mlp_tower_backward(x, h1, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate if f16 else None)
     grads32 = hip.mlp_tower_backward(x, h1, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
     for k in p:
@@ -211,8 +195,13 @@ def test_backward_split_matches_fp64(m, d_in, n_out, scheme):
 def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
     """dOut as PPO produces it is heavy-tailed (clipped samples contribute exactly zero, a few
     samples carry most of the gradient): the data-gradient kernel scales per ROW, the
-    weight-gradient kernel per LAUNCH.  Every gradient against fp64 on the saved activations
-    and against the six-product bf16 kernels' own error."""
+    weight-gradient kernel per output COLUMN (its sum runs over the rows).  Every gradient against
+    fp64 on the saved activations, entry by entry relative to the sum of the magnitudes of the
+    entry's terms, beside the fp32-MFMA kernels' own error.  dW2 is the one place where the planes
+    give up something against fp32 products: a term 2^17 below its column's bound no longer carries
+    22 bits, so an entry made only of small rows keeps ~1e-5 of its own size (measured: 1.6e-5 /
+    4.7e-5 with rows six decades apart; fp32 MFMAs 6e-7 / 2e-6) -- against the tensor it is held
+    to the fp32 kernels' level."""
     m, d_in = 20_000, 3
     g = torch.Generator(device=DEV).manual_seed(23)
     x = torch.randn(m, d_in, device=DEV, generator=g) * 3
@@ -230,7 +219,7 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
     elif case == "outlier_weights":
         p["w2"][torch.randint(0, 256, (20,), device=DEV, generator=g), torch.randint(0, 256, (20,), device=DEV, generator=g)] = 40.0
         p["w3"][0, 5] = 30.0
-    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_split(p["w2"]), p["b2"], p["w3"],
+    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"],
                                                   p["b3"], save=True, save_gate=True)
     d, a1, a2 = dout.double(), h1.double(), h2.double()
     dz2 = (d @ p["w3"].double()) * (a2 > 0)
@@ -241,15 +230,21 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
             "w3": d.abs().T @ a2}
     got = hip.mlp_tower_backward(x, None, h2, dout, hip.mlp_pack_w2_f16(p["w2"], transposed=True), p["w3"], p["w1"], p["b1"],
                                  gate2=gate)
-    got6 = hip.mlp_tower_backward(x, None, h2, dout, hip.mlp_pack_w2_split(p["w2"], transposed=True), p["w3"], p["w1"],
-                                  p["b1"], gate2=gate)
+    # yardstick: the fp32-MFMA generation on the same saved activations
+    got6 = hip.mlp_tower_backward(x, h1, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
     for k in want:
         assert bool(torch.isfinite(got[k]).all()), k
         floor = size[k].max() * 1e-30 + 1e-300
         err = float(((got[k].double() - want[k]).abs() / (size[k] + floor)).max())
         err6 = float(((got6[k].double() - want[k]).abs() / (size[k] + floor)).max())
-        # (the absolute bar is the fp32 accumulators' own: with one row 10^6 above the rest both schemes sit at 5e-6 .. 3e-5)
-        assert err < 1e-4 and err <= 3 * err6 + 2e-7, (k, err, err6)
+        # (the absolute bar is the fp32 accumulators' own: with one row 10^6 above the rest both generations sit at 5e-6 .. 3e-5)
+        assert err < 1e-4, (k, err, err6)
+        if k == "w2":  # entrywise see the docstring; against the tensor's largest entry: the fp32 kernels' level
+            top = float(want[k].abs().max()) + 1e-300
+            norm, norm6 = (float((t[k].double() - want[k]).abs().max()) / top for t in (got, got6))
+            assert norm <= 3 * norm6 + 5e-7, (k, norm, norm6)
+        else:
+            assert err <= 3 * err6 + 2e-7, (k, err, err6)
 
 
 @pytest.mark.parametrize("case", ["plain", "rows_of_mixed_magnitude", "one_outlier_row", "clipped_rows", "outlier_weights"])
@@ -429,7 +424,7 @@ def test_pair_weight_gradient_of_a_two_way_head(m, d_in, monkeypatch):
 
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (13, 1, 1), (4099, 2, 3), (20_003, 5, 3), (33_001, 3, 2), (9, 5, 1)])
-@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("scheme", ["f16x2"])
 def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out, scheme):
     """The kernels fetch whole windows of rows (eight samples of x / dOut through scalar
     buffer descriptors, 16-sample chunks of h2, 128-row tiles) and rely on descriptors
@@ -447,7 +442,7 @@ def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out, scheme):
     x = torch.randn(m, d_in, device=DEV, generator=g)
     p = _params(g, d_in, n_out)
     dout = torch.randn(m, n_out, device=DEV, generator=g) / m
-    pack = hip.mlp_pack_w2_f16 if scheme == "f16x2" else hip.mlp_pack_w2_split
+    pack = hip.mlp_pack_w2_f16
     w2p, w2t = pack(p["w2"]), pack(p["w2"], transposed=True)
     _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True, save_gate=True)
     want = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate)
@@ -467,17 +462,17 @@ def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out, scheme):
 def test_unsupported_widths_are_refused_not_miscomputed():
     """Only widths whose kernels compile without scratch are offered
     (tests/test_kernel_resources.py); anything else must fail loudly."""
-    assert not hip.mlp_backward_split_supports(7, 2) and not hip.mlp_forward_split_supports(4, 1)
-    assert not hip.mlp_forward_split_supports(1, 4)
+    assert not hip.mlp_backward_f16_supports(7, 2) and not hip.mlp_forward_f16_supports(4, 1)
+    assert not hip.mlp_forward_f16_supports(1, 4)
     x = torch.zeros(256, 7, device=DEV)
     h = torch.zeros(256, 256, device=DEV)
     w7, b = torch.zeros(256, 7, device=DEV), torch.zeros(256, device=DEV)
     w3, b3 = torch.zeros(3, 256, device=DEV), torch.zeros(3, device=DEV)
     w2 = torch.zeros(256, 256, device=DEV)
     with pytest.raises(ValueError):
-        hip.mlp_tower_backward(x, h, h, torch.zeros(256, 3, device=DEV), hip.mlp_pack_w2_split(w2, transposed=True), w3, w7, b)
+        hip.mlp_tower_backward(x, h, h, torch.zeros(256, 3, device=DEV), hip.mlp_pack_w2_f16(w2, transposed=True), w3, w7, b)
     with pytest.raises(ValueError):
-        hip.mlp_tower_forward_split(x, w7, b, hip.mlp_pack_w2_split(w2), b, w3, b3)
+        hip.mlp_tower_forward_split(x, w7, b, hip.mlp_pack_w2_f16(w2), b, w3, b3)
 
 
 def test_wider_towers_mix_fp32_and_split_kernels():
@@ -707,7 +702,7 @@ def test_gate_pack_follows_the_head_parameters_not_the_concatenated_temporary():
             heads[1].weight.mul_(0.5)
 
 
-@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2", "f16x2-gate"])
+@pytest.mark.parametrize("scheme", ["f16x2", "f16x2-gate"])
 @pytest.mark.parametrize("m,parts", [(1 << 23, 8), (1 << 25, 4)])
 def test_full_size_launch_equals_its_chunks(m, parts, scheme):
     """BASELINE's training launch (2^25 rows: `Algorithm.step` feeds the towers the whole
@@ -723,7 +718,7 @@ def test_full_size_launch_equals_its_chunks(m, parts, scheme):
     if scheme == "f16x2-gate":  # the headline's own kernels: a two-way categorical's gradients, gate-mode backward
         dout[:, 1] = -dout[:, 0]
         gate_pack = lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])  # noqa: E731
-    pack = hip.mlp_pack_w2_split if scheme == "bf16x3" else hip.mlp_pack_w2_f16
+    pack = hip.mlp_pack_w2_f16
     w2s, w2ts = pack(p["w2"]), pack(p["w2"], transposed=True)
     out, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2s, p["b2"], p["w3"], p["b3"], save=True,
                                                    save_h1=False, save_gate=True)
@@ -756,7 +751,7 @@ def test_full_size_launch_equals_its_chunks(m, parts, scheme):
     assert torch.equal(o_inf, out[: 1 << 20])
 
 
-@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("scheme", ["f16x2"])
 def test_split_kernels_are_deterministic_and_head_gradients_exact(scheme):
     """Run-to-run determinism of every bf16- / fp16-plane kernel at the rollout launch size (a
     property the fixed summation orders promise), and the head gradients against fp64.
@@ -771,7 +766,7 @@ def test_split_kernels_are_deterministic_and_head_gradients_exact(scheme):
     x = torch.empty(m, 1, device=DEV).uniform_(-3, 3, generator=g)
     p = _params(g, 1, 2)
     dout = torch.randn(m, 2, device=DEV, generator=g) / m
-    pack = hip.mlp_pack_w2_f16 if scheme == "f16x2" else hip.mlp_pack_w2_split
+    pack = hip.mlp_pack_w2_f16
     w2s, w2ts = pack(p["w2"]), pack(p["w2"], transposed=True)
 
     def run():
@@ -810,7 +805,7 @@ def test_fp32_mfma_kernels_are_deterministic():
             assert torch.equal(a, b), trial
 
 
-@pytest.mark.parametrize("planes", ["split", "f16"])
+@pytest.mark.parametrize("planes", ["f16"])
 def test_algorithm_agrees_between_the_tower_generations(planes):
     """collect() + step() with the bf16-plane / fp16-plane towers against the same seeded
     run on the fp32-MFMA towers: same actions, same statistics, losses to 1e-5 (the

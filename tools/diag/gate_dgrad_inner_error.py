@@ -24,8 +24,7 @@ for seed in range(200):
     want = terms.sum(0) * (h1[0].double() > 0)
     size = terms.abs().sum(0) + 1e-300
     for name, pack, gp in (("general", hip.mlp_pack_w2_f16, None),
-                           ("gate", hip.mlp_pack_w2_f16, lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])),
-                           ("bf16x3", hip.mlp_pack_w2_split, None)):
+                           ("gate", hip.mlp_pack_w2_f16, lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"]))):
         got = hip.mlp_tower_backward(x, None, h2, dout, pack(p["w2"], transposed=True), p["w3"], p["w1"], p["b1"], gate2=gate,
                                      gate_pack=gp)["b1"].double()          # m = 1: db1 = dZ1 itself
         worst[name] = max(worst[name], float(((got - want).abs() / size).max()))

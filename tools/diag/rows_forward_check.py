@@ -22,11 +22,11 @@ for d_in, n_out in ((1, 2), (1, 1), (1, 3), (2, 2), (2, 1), (3, 1), (3, 3), (5, 
     b2 = torch.randn(256, device=dev, generator=g)
     w3 = torch.randn(n_out, 256, device=dev, generator=g) / 16
     b3 = torch.randn(n_out, device=dev, generator=g)
-    w2h, w2s = hip.mlp_pack_w2_f16(w2), hip.mlp_pack_w2_split(w2)
+    w2h, w2p = hip.mlp_pack_w2_f16(w2), hip.mlp_pack_w2(w2)
     for m in (1, 31, 100, 128, 129, 257, 1000, 4096 + 5, (1 << 17) + 77):
         x = torch.randn(m, d_in, device=dev, generator=g) * 30
         x[::7] *= 1e-3
-        ref = hip.mlp_tower_forward_split(x, w1, b1, w2s, b2, w3, b3, save=True, save_h1=True, save_gate=True)
+        ref = hip.mlp_tower_forward(x, w1, b1, w2p, b2, w3, b3, save=True)  # the fp32-MFMA kernel as the yardstick
         h1 = torch.relu(x.double() @ w1.double().T + b1.double())
         h2 = torch.relu(h1 @ w2.double().T + b2.double())
         out64 = h2 @ w3.double().T + b3.double()

@@ -20,10 +20,10 @@ from rl8_amd.nn import fused_mlp  # noqa: E402
 g = dict(np.load(os.path.join(ROOT, "tests", "golden", "trace_ff_discrete_minibatch.npz"), allow_pickle=True))
 keys = [str(k) for k in g["step_stat_keys"]]
 result = {"golden": {f"it{it}": dict(zip(keys, map(float, g[f"it{it}_step_stats"]))) for it in range(2)}}
-for mode in ("eager", "f32", "split", "f16"):
+for mode in ("eager", "f32", "f16"):  # (round 2 also ran "split", the bf16-plane forward / data gradient removed in round 3)
     fused_mlp.ENABLED = mode != "eager"
-    fused_mlp.FORWARD_GEMM = mode if mode != "eager" else "split"
-    fused_mlp.BACKWARD_GEMM = mode if mode != "eager" else "split"
+    fused_mlp.FORWARD_GEMM = mode if mode != "eager" else "f16"
+    fused_mlp.BACKWARD_GEMM = mode if mode != "eager" else "f16"
     algo = t.build_from_trace(g, DiscreteDummyEnv, sgd_minibatch_size=256, entropy_coeff=1e-2, dual_clip_param=5.0,
                               horizons_per_env_reset=2)
     out = {}

@@ -110,25 +110,18 @@ mlp_dout = torch.randn(N, 2, device=dev, generator=g) / N
 mlp_dz2 = torch.randn(N, 256, device=dev, generator=g)
 mlp_zero = torch.zeros(N, 256, device=dev)
 
-# bf16-plane kernels (fp32 operands split exactly into 3 bf16 planes; 6 plane products per 16 k)
+# plane kernels (fp32 operands as scaled fp16 planes: 3 plane products per 16 k; 2 with the ReLU gate as an operand)
 import ctypes as C  # noqa: E402
 
-mlp_w2s = hip.mlp_pack_w2_split(mlp_w2)
-mlp_gate = hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2s, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False,
+mlp_w2h = hip.mlp_pack_w2_f16(mlp_w2)  # scaled fp16 two-plane pack
+mlp_gate = hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False,
                                        save_gate=True)[3]
-mlp_w2ts = hip.mlp_pack_w2_split(mlp_w2, transposed=True)
-mlp_w2h = hip.mlp_pack_w2_f16(mlp_w2)  # scaled fp16 two-plane pack (3 plane products per 16 k)
 _lib = hip.load()
 _partials = torch.empty(int(_lib.rl8_mlp_backward_max_rows()), int(_lib.rl8_mlp_backward_partial_floats(1, 2)), device=dev)
 _dw2 = torch.empty(256, 256, device=dev)
 _ws = torch.empty(int(_lib.rl8_mlp_wgrad_workspace_bytes()) // 4, device=dev)
 _rows = C.c_int(0)
 _p = hip._ptr
-
-
-def split_dgrad():  # data-gradient kernel alone (first half of the fused backward)
-    _lib.rl8_mlp_tower_backward_split_f32(_p(mlp_x), _p(mlp_w1), _p(mlp_b1), _p(mlp_h2), _p(mlp_dout), N, 1, _p(mlp_w2ts),
-                                          _p(mlp_w3), 2, None, _p(_partials), C.byref(_rows), _p(mlp_gate), hip._stream())
 
 
 mlp_w2th = hip.mlp_pack_w2_f16(mlp_w2, transposed=True)
@@ -180,12 +173,9 @@ def split_wgrad_fused():  # weight-gradient kernel: re-forms dZ2 and h1, accumul
 
 KERNELS = {
     # bf16-plane kernels: "GB/s" column = fp32-equivalent TFLOP/s (algorithmic FLOP / 1000 as bytes)
-    "mlp_tower_forward_split": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2s, mlp_b2, mlp_w3, mlp_b3), MLP_FLOP / 1000),
-    "mlp_tower_forward_save_split": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2s, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False, save_gate=True), MLP_FLOP / 1000),
     "mlp_tower_forward_f16": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h, mlp_b2, mlp_w3, mlp_b3), MLP_FLOP / 1000),
     "mlp_tower_forward_save_f16": (lambda: hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h, mlp_b2, mlp_w3, mlp_b3, save=True, save_h1=False, save_gate=True), MLP_FLOP / 1000),
     "mlp_tower_backward_f16": (f16_dgrad, MLP_FLOP / 1000),
-    "mlp_tower_backward_split": (split_dgrad, MLP_FLOP / 1000),
     "mlp_wgrad_fused_split": (split_wgrad_fused, 2 * N * 65536 / 1000),
     "mlp_wgrad_fused_gate": (gate_wgrad_fused, 2 * N * 65536 / 1000),
     "mlp_wgrad_gate_bits": (gate_bits_wgrad, 2 * N * 65536 / 1000),
