@@ -799,9 +799,20 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
         a_g[CUR ^ 1][C] = gate_fragment(byte);
       }
       if (sl == 3) {
-        // younger than the chunk this barrier publishes: the pieces of kAhead - 2 chunks, plus the gate block ((7, 0),
-        // (7, 1)) or the next tile's row loads (the tile's first two half-steps: 2 (1 + DIN) load instructions)
-        constexpr int kExtra = KIND >= 2 ? 1 : FIRST ? 2 * (1 + kIn) : 0;
+        // Younger than the chunk this barrier publishes (chunk hs + 1, whose pieces went out in half-step hs + 1 - kAhead
+        // behind THAT half-step's barrier): the pieces of kAhead - 2 chunks, plus
+        //   the gate block, requested in slot 0 of half-step 14: behind the pieces of half-step 15 - kAhead (barrier of
+        //     half-step 14) always, behind those of half-step 16 - kAhead (barrier of half-step 15) only if kAhead >= 3;
+        //   the next tile's row loads (2 (1 + DIN) instructions at the tile's opening): behind the pieces of the previous
+        //     tile's half-step 17 - kAhead (barrier of half-step 0) always, behind those published in half-step 1 only if
+        //     they too went out in the previous tile (kAhead >= 3; with kAhead = 2 they follow the row loads).
+        // (Round 3, found by an intermittent 5e-6 in dW1 at d_in = 3: the three-chunk ring counted the gate block in
+        // half-step 15 and the row loads in half-step 1 as well -- one piece, resp. all four, of the chunk being published
+        // were allowed to be still in flight.  The four-chunk ring of d_in = 1 was right.)
+        constexpr int kExtra = KIND == 2                 ? 1
+                               : KIND == 3               ? (kAhead >= 3 ? 1 : 0)
+                               : (FIRST && (C == 0 || kAhead >= 3)) ? 2 * (1 + kIn)
+                                                         : 0;
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kAhead - 2) + kExtra) : "memory");
       }
       if (sl >= 4) chunk_piece((hs + kAhead) & (kRowsHalfSteps - 1), stage_free, wave * 4 + (sl - 4));

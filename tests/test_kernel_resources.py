@@ -284,6 +284,22 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
     # the rows-per-wave data gradient: same rules (its barriers also count the next tile's row loads and the wave's
     # gate block, so their vmcnt values are not a fixed set)
     assert_no_inflight_register_access(text, "mlp_rows_backward_gate_kernel", min_hand_loads=6 * 50)
+    # ... and exactly these: per tile twelve instances of the half-step (0, 1, 2, 3, the loop body's four, 12, 13, 14, 15).
+    # A barrier publishes the chunk whose pieces went out kAhead - 1 half-steps earlier; what may be in flight behind those
+    # pieces: kAhead - 2 chunks, the row loads of the next tile (half-step 0; half-step 1 only with a four-chunk ring), the
+    # gate block (half-step 14; 15 only with a four-chunk ring).  (The three-chunk ring once counted both twice: an
+    # intermittent 5e-6 in dW1 at d_in = 3.)
+    for name, body in inflight.kernels_of(text):
+        m = re.search(r"mlp_rows_backward_gate_kernelILi(\d)ELi(\d)ELi(\d)E", name)
+        if not m:
+            continue
+        d_in, ring = int(m.group(1)), int(m.group(3))
+        ahead, rows = ring - 1, 2 * (1 + d_in)
+        base = 4 * (ahead - 2)
+        want = sorted([base + rows, base + (rows if ahead >= 3 else 0)] + [base] * 8 + [base + 1, base + (1 if ahead >= 3 else 0)]
+                      + [4 * (ahead - 1)])  # (+ the prologue's)
+        got = sorted(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)\n\ts_barrier", body))
+        assert got == want, (name, got, want)
     for name, body in inflight.kernels_of(text):
         assert inflight.packed_war(body) == [], name
 
