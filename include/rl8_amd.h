@@ -373,7 +373,12 @@ int rl8_mlp_wgrad_fused_pair_f32(const float *h2, const float *dout, const float
  * rl8_mlp_wgrad_gate_bits_f32: outputs of rl8_mlp_wgrad_fused_split_f32 (n_out = 1) / _pair_f32 (n_out = 2, after
  * a clean rl8_mlp_dout_pair_check) from gate2 [m][8] instead of h2; w2 [256][256] and b2 [256] are the layer's
  * own parameters.  In fp32 the result differs from the direct sum by the rounding the forward's own 256-term dot
- * products put into h2 -- what another fp32 evaluation of h2 (the reference's) differs from this one by. */
+ * products put into h2 -- what another fp32 evaluation of h2 (the reference's) differs from this one by.
+ * Since round 3 the second operand dOut[s] * h1[s][i] is carried as two fp16 planes times a power of two per column i
+ * (two plane products per 16 rows; the column bounds come from one pass over dout and x in front of the first
+ * segment and live in the 256 bytes behind the slabs of `workspace`); RL8_WGRAD_GATE_PLANES=bf16 in the environment
+ * selects the three exact bf16 planes of round 2.  dW2 stays within the fp32 kernels' error against the tensor's
+ * largest entry; an entry made only of rows 2^17 below its column's bound keeps ~1e-5 of its own size. */
 int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout, const float *x, const float *w1,
                                 const float *b1, const float *w2, const float *b2, const float *w3,
                                 int64_t m, int d_in, int n_out, float *workspace, float *dw2_out,
@@ -445,7 +450,8 @@ int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, const floa
 
 /* Weight gradient of the 256x256 layer: dw2_out [256][256] (+)= dZ2^T h1 over M
  * rows (fp32 MFMA; per-workgroup partial slabs in `workspace`, summed in a fixed
- * order).  workspace: rl8_mlp_wgrad_workspace_bytes() bytes, no initialisation. */
+ * order).  workspace: rl8_mlp_wgrad_workspace_bytes() bytes (one 256 x 256 slab per CU + 256 bytes of operand
+ * bounds for the fp16-plane kernels), no initialisation. */
 int64_t rl8_mlp_wgrad_workspace_bytes(void);
 int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, float *workspace,
                       float *dw2_out, int accumulate, void *stream);
