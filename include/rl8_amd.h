@@ -577,6 +577,14 @@ int rl8_mlp_wgrad_f16_strided_f32(const float *dz, int64_t dz_pitch, const uint3
                                   float *dw_out, int accumulate, const float *x, int d_in, float *colsums,
                                   int *colsum_rows_out, void *stream);
 
+/* The four gates of one LSTM timestep in one launch of the fp16-plane weight gradient: dz = the step's dG rows ([m] rows
+ * of dz_pitch >= 1024 floats, gate q at columns [256 q, 256 q + 256)), dw_out [4][256][256] (+)= dG_q^T h per gate,
+ * colsums (optional, with x / d_in) [4][*colsum_rows_out][256 (d_in + 1)]; h is then read from HBM once instead of four
+ * times.  m >= 128 (RL8_ESIZE below: use rl8_mlp_wgrad_f16_strided_f32 per gate); bounds as there. */
+int rl8_lstm_wgrad_f16_f32(const float *dz, int64_t dz_pitch, const uint32_t *dz_bound, const float *h, int64_t h_pitch,
+                           const uint32_t *h_bound, int64_t m, float *workspace, float *dw_out, int accumulate,
+                           const float *x, int d_in, float *colsums, int *colsum_rows_out, void *stream);
+
 /* The recurrent models' output heads (src/rl8/models/_recurrent.py:230-236, 287-292),
  * all of them at once: out [M][n] = h [M][256] x w^T + b, w [n][256] (the heads'
  * nn.Linear weights stacked), n <= 8.  Backward: dh_out [M][256] = dout x w and

@@ -90,6 +90,12 @@ struct WgradOperands {
   // F16: the operands as two fp16 planes each, times a power of two from *dz_bound / *h_bound (device words: bit
   // patterns of bounds on |dZ| / |h| over everything this call reads, e.g. rl8_lstm_rows_backward_f32's dg_bound_out)
   const uint32_t *dz_bound = nullptr, *h_bound = nullptr;
+  // groups = 4: FOUR products over the same h rows in one launch -- the LSTM's four gates, dZ of gate q = columns
+  // [256 q, 256 q + 256) of the rows at `dz` (group_dz_offset = 256 floats) -- so that h is read from HBM once: workgroup
+  // b works for gate (b >> 3) & 3 as number (b & 7) | (b >> 5 << 3) of its gate's gridDim.x / 4 workgroups; the four that
+  // share a number sit on one XCD (b mod 8) and walk the same rows at the same time, three of them out of L2.  Slabs and
+  // column-sum rows are numbered gate-major (gate q: [q gridDim.x / 4, (q + 1) gridDim.x / 4)).  gridDim.x a multiple of 32.
+  int groups = 1, group_dz_offset = 0;
 };
 
 // F16 (round 3, fused mode with compiled widths): BOTH operands as two fp16 planes, each scaled by a power of two per
@@ -154,22 +160,28 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   }
 
   const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
-  const int64_t stride = gridDim.x;
-  const int64_t mine = (chunks - blockIdx.x + stride - 1) / stride;  // >= 1 (grid <= chunks)
+  // (two-operand mode with gate groups: see WgradOperands::groups)
+  const bool grouped = LOADH && ops.groups == 4;
+  const int gate_q = grouped ? ((int)blockIdx.x >> 3) & 3 : 0;
+  const int64_t bid = grouped ? ((blockIdx.x & 7) | ((blockIdx.x >> 5) << 3)) : blockIdx.x;  // this workgroup's number in its group
+  const int64_t stride = grouped ? gridDim.x / 4 : gridDim.x;
+  const int64_t out_id = grouped ? gate_q * stride + bid : blockIdx.x;                          // its slab / column-sum row
+  const float *dzp = dz2 + (grouped ? gate_q * ops.group_dz_offset : 0);
+  const int64_t mine = (chunks - bid + stride - 1) / stride;  // >= 1 (workgroups per group <= chunks)
 
   // dZ2 of chunk number n of this workgroup: this thread's column, its eight samples.
   // Chunks past the end (and samples past m) read as zero through the descriptor.
   auto load_dz = [&](float (&dst)[8], int64_t n) {
-    const int64_t chunk = blockIdx.x + n * stride;
+    const int64_t chunk = bid + n * stride;
     const int64_t left = m - chunk * kWsChunk;
     const int rows = left <= 0 ? 0 : left < kWsChunk ? (int)left : kWsChunk;
-    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? dz2 + chunk * kWsChunk * dz_pitch : dz2,
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? dzp + chunk * kWsChunk * dz_pitch : dzp,
                                                     rows > 0 ? ((rows - 1) * dz_pitch + kHidden) * 4 : 0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) dst[e] = buffer_load_f32(rsrc, col * 4, (8 * kh + e) * (dz_pitch * 4));
   };
   [[maybe_unused]] auto load_h = [&](float (&dst)[8], int64_t n) {  // LOADH: the same for the h1 operand
-    const int64_t chunk = blockIdx.x + n * stride;
+    const int64_t chunk = bid + n * stride;
     const int64_t left = m - chunk * kWsChunk;
     const int rows = left <= 0 ? 0 : left < kWsChunk ? (int)left : kWsChunk;
     const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? ops.h + chunk * kWsChunk * ops.h_pitch : ops.h,
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   constexpr bool kScalars = DIN > 0;  // (two-operand mode: the observations feed the column sums only)
   constexpr int kXq = kScalars ? kIn : 1, kDq = (kScalars && FUSED > 0) ? kOut : 1;
   [[maybe_unused]] f32x8 xq[kXq], dq[kDq];
-  auto row0_of = [&](int64_t n) { return (blockIdx.x + n * stride) * kWsChunk + 8 * kh; };
+  auto row0_of = [&](int64_t n) { return (bid + n * stride) * kWsChunk + 8 * kh; };
   // ... of chunk n of this workgroup: requested through buffer descriptors that end at
   // sample m, so samples past the end read as zero (as their h2 / dZ2 do: whatever
   // they contribute is multiplied by zero) and no step needs a slow path.  No wait
@@ -525,7 +537,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     if (n < mine) do_step(F{}, P1{}, n);
   }
 
-  float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;
+  float *slab = slabs + out_id * kHidden * kHidden;
 #pragma unroll
   for (int ja = 0; ja < 2; ++ja)
 #pragma unroll
@@ -548,7 +560,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       }
       __syncthreads();
       if (kh == 0) {
-        float *row = ops.colsums + (int64_t)blockIdx.x * (kHidden * (kIn + 1));
+        float *row = ops.colsums + out_id * (kHidden * (kIn + 1));
         const bool more = ops.colsum_accumulate != 0;
         const float b = cs_b + red[col * (1 + kIn)];
         row[kHidden * kIn + col] = more ? row[kHidden * kIn + col] + b : b;
@@ -1221,7 +1233,7 @@ static int launch_wgrad_loadh(int grid, hipStream_t s, const float *dz, const fl
  * d_in in {1, 2, 3, 5}. */
 static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int64_t h_pitch, int64_t m, float *workspace,
                          float *dw_out, int accumulate, const float *x, int d_in, float *colsums, int *colsum_rows_out,
-                         const uint32_t *dz_bound, const uint32_t *h_bound, void *stream) {
+                         const uint32_t *dz_bound, const uint32_t *h_bound, void *stream, int groups = 1) {
   if (!dz || !h || !workspace || !dw_out) return RL8_ENULL;
   if (m <= 0 || dz_pitch < kHidden || h_pitch < kHidden) return RL8_ESIZE;
   if ((int64_t)kWsChunk * (dz_pitch > h_pitch ? dz_pitch : h_pitch) * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
@@ -1236,9 +1248,15 @@ static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int6
     const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
     const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
     int grid = (int)(chunks < kCUs ? chunks : kCUs);
+    if (groups == 4) {  // a multiple of 32 workgroups, a quarter of them per gate (each gate's share <= chunks)
+      const int64_t per_gate = chunks < kCUs / 4 ? chunks : kCUs / 4;
+      grid = (int)((per_gate / 8) * 8) * 4;
+      if (grid == 0) return RL8_ESIZE;  // (fewer than 128 rows: the caller uses the per-gate call)
+    }
     if (at == 0) first_grid = grid;
     if (grid > first_grid) grid = first_grid;  // (later segments add to the first one's rows)
-    const WgradOperands ops{h + at * h_pitch, (int)dz_pitch, (int)h_pitch, colsums, at > 0, dz_bound, h_bound};
+    const WgradOperands ops{h + at * h_pitch, (int)dz_pitch, (int)h_pitch, colsums, at > 0, dz_bound, h_bound,
+                            groups, groups == 4 ? kHidden : 0};
     const float *xs = colsums ? x + at * d_in : nullptr;
     int status;
     if (dz_bound) {
@@ -1257,10 +1275,12 @@ static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int6
       }
     }
     if (status != 0) return status;
-    mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw_out,
-                                                                                 accumulate || at > 0);
+    for (int q = 0; q < groups; ++q)  // (gate q: slabs [q grid / groups, ...), dW block q)
+      mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(
+          workspace + (int64_t)q * (grid / groups) * kHidden * kHidden, grid / groups, dw_out + (int64_t)q * kHidden * kHidden,
+          accumulate || at > 0);
   }
-  if (colsum_rows_out) *colsum_rows_out = first_grid;
+  if (colsum_rows_out) *colsum_rows_out = first_grid / groups;
   return launch_status();
 }
 
@@ -1284,6 +1304,21 @@ RL8_API int rl8_mlp_wgrad_f16_strided_f32(const float *dz, int64_t dz_pitch, con
   if (!dz_bound || !h_bound) return RL8_ENULL;
   return wgrad_strided(dz, dz_pitch, h, h_pitch, m, workspace, dw_out, accumulate, x, d_in, colsums, colsum_rows_out, dz_bound,
                        h_bound, stream);
+}
+
+/* The four gates of an LSTM timestep in ONE launch: dz = the step's dG rows ([m] rows of dz_pitch floats, gate q at
+ * columns [256 q, 256 q + 256)), dw_out [4][256][256] (+)= dG_q^T h per gate, colsums (optional, with x / d_in)
+ * [4][*colsum_rows_out][256 (d_in + 1)] -- so that h is read from HBM once instead of four times (three of the four
+ * workgroups that walk the same rows find them in their XCD's L2).  m >= 128; otherwise as
+ * rl8_mlp_wgrad_f16_strided_f32. */
+RL8_API int rl8_lstm_wgrad_f16_f32(const float *dz, int64_t dz_pitch, const uint32_t *dz_bound, const float *h,
+                                   int64_t h_pitch, const uint32_t *h_bound, int64_t m, float *workspace, float *dw_out,
+                                   int accumulate, const float *x, int d_in, float *colsums, int *colsum_rows_out,
+                                   void *stream) {
+  if (!dz_bound || !h_bound) return RL8_ENULL;
+  if (dz_pitch < 4 * kHidden) return RL8_ESIZE;
+  return wgrad_strided(dz, dz_pitch, h, h_pitch, m, workspace, dw_out, accumulate, x, d_in, colsums, colsum_rows_out, dz_bound,
+                       h_bound, stream, 4);
 }
 
 // Grids of the two halves of the fused backward (both derive them from m alone,

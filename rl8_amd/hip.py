@@ -135,6 +135,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_rows_backward_pack": [_vp, _vp, _vp],
     "rl8_lstm_rows_backward_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rl8_mlp_wgrad_f16_strided_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
+    "rl8_lstm_wgrad_f16_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
     "rl8_lstm_backward_partial_floats": [_i32],
     "rl8_lstm_backward_max_rows": [],
     "rl8_lstm_backward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp],
@@ -1311,7 +1312,7 @@ def lstm_rows_backward(c0: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor, 
 
 
 #: column-sum partial rows of the fused LSTM weight gradient, per (device, stream, L, d_in)
-_lstm_colsum_ws: dict[tuple[int, int, int, int], torch.Tensor] = {}
+_lstm_colsum_ws: dict[tuple, torch.Tensor] = {}
 
 
 def lstm_backward(
@@ -1384,6 +1385,22 @@ def lstm_backward(
         if f16:
             h0_bound = h0.abs().amax().reshape(1).clamp_min(1e-30)
             one = torch.ones(1, dtype=torch.float32, device=dev)
+        if f16 and b >= 128 and os.environ.get("RL8_AMD_LSTM_WGRAD_GATES", "fused") != "separate":
+            # the four gates of a timestep in one launch: h_{t-1} comes out of HBM once instead of four times
+            gkey = (dev.index or 0, _stream() or 0, l, d_in, "gates")
+            gcols = _lstm_colsum_ws.get(gkey)                     # [step][gate][workgroup of the gate][...]
+            if gcols is None:
+                gcols = _lstm_colsum_ws[gkey] = torch.empty(l, 4, 64, H * (d_in + 1), dtype=torch.float32, device=dev)
+            with _timed("lstm_wgrad", m):
+                for t in range(l):
+                    h_prev, h_pitch = (h0p, H) if t == 0 else (hsp + (t - 1) * H * 4, l * H)
+                    _check(lib.rl8_lstm_wgrad_f16_f32(
+                        dgp + t * 4 * H * 4, l * 4 * H, _ptr(dg_bound), h_prev, h_pitch, _ptr(h0_bound if t == 0 else one), b,
+                        wsp, dwp, int(t > 0), _ptr(xt[t]), d_in, _ptr(gcols[t]), C.byref(crow), stream), "rl8_lstm_wgrad_f16_f32")
+            # (a step's rows sit gate-major, crow.value per gate -- 64 at the sizes that fill the chip)
+            width = H * (d_in + 1)
+            sums = gcols.view(l, -1)[:, : 4 * crow.value * width].reshape(l, 4, crow.value, width).sum(dim=(0, 2))
+            return {"w_ih": sums[:, : H * d_in].reshape(4 * H, d_in), "w_hh": dw_hh, "b": sums[:, H * d_in :].reshape(4 * H)}
         with _timed("lstm_wgrad", m):
             for q in range(4):
                 for t in range(l):
