@@ -25,13 +25,17 @@
 // accumulator c), gates o, i, g, f within it, two k-steps of 16 per gate: 64 gate-steps of 16 k, each 8 out tiles x 6
 // plane products = 48 MFMAs (32x32x16).  The slot of a gate-step in the four-slot ring is its position in the chunk
 // mod 4, so the chunk loop is a runtime loop over c with a fixed body of eight gate-steps.
-// Row accesses are whole 128-byte lines: per array and chunk a lane reads its sixteen units with four 16-byte loads
-// issued together, and lanes n, n + 32 cover the line between them.  (The first version worked on chunks of sixteen
-// units -- half a line now, the other half a chunk-time later -- and ran at the 2.7 TB/s HBM gives 64-byte pieces:
-// tools/probes/piece_size_probe.hip; 128-byte pieces get 4.2.)  To fit the registers the chunk's loads come in three
-// phases, each requested five or more gate-steps before its arithmetic: A = {o, c_t, dh_t, dc} -> dG_o, dc;
-// B = {i, g} -> dG_i, dG_g; C = {f, c_{t-1}} -> dG_f, dc out.  A waits in registers; B and C are direct-to-LDS loads into
-// a per-wave park (each lane reads back exactly the 16 bytes it asked for) and cost no registers while in flight.
+// Row accesses are whole 128-byte lines AND coalesced: lane = sequence would make every lane of a load or store address
+// its own cache line (64 tag look-ups per instruction: with one wave per SIMD the wave stood at the ISSUE of its row
+// operations for 28 % of its time).  So every row array goes through a per-wave park in LDS, 32 rows x 128 bytes per array
+// and chunk: loads are direct-to-LDS, instruction k bringing rows 8 k .. 8 k + 7 whole (eight lanes per row), read back
+// lane = sequence; stores are written lane = sequence into a park and read back eight lanes per row.  The eight 16-byte
+// pieces of a row are XOR-swizzled by (row >> 1) & 7: both views are free of bank conflicts.  Two parks of two arrays
+// per wave (the LDS is full: 96 KiB ring + 64 KiB parks), three load phases per chunk, each requested where its park
+// falls free: B = {i, g} in gate-step 0 -> dG_i, dG_g behind step 1; C = {f, c_{t-1}} in 2 -> dG_f, dc behind 5;
+// A of the NEXT chunk = {o, c_t | dh_t, dc} (both parks) in 6 -> dG_o, dc behind 7.
+// (Rounds of this kernel: chunks of sixteen units, half a line per access: 10.4 ms per 2^21 row-steps; whole lines, lane
+// per row, loads in registers: 9.0; phases B, C parked and coalesced: 8.6; everything through the parks: this one.)
 // Carries: dh in registers (copied out of the accumulators once per step, read per chunk by a dynamic register index
 // c); dc through a [b][256] scratch in HBM (2 KiB of traffic per row-step; in registers it would take the 128 the row
 // loads in flight need: 512 per lane = 128 accumulators + 128 dh + loads, dG, planes, fragments).
@@ -47,21 +51,21 @@ constexpr int kLrGateSteps = 8 * kLrChunks;  // k-chunks of 16 per step
 constexpr int kLrSlotBytes = 3 * 8 * 1024;   // one gate-step of W_hh^T: [plane][out tile] x 1 KiB
 constexpr int kLrRing = 4;
 constexpr int kLrPackedBytes = kLrGateSteps * kLrSlotBytes;  // 1.5 MiB
-constexpr int kLrStageBytes = 4 * 8 * 1024;  // one load phase of two arrays, parked in LDS: [wave][array][piece] x 1 KiB
+constexpr int kLrStageBytes = 4 * 8 * 1024;  // one park of two arrays: [wave][array][instruction] x 1 KiB; two parks
 constexpr int kLrLdsBytes = kLrRing * kLrSlotBytes + 2 * kLrStageBytes;  // 160 KiB: the whole CU
 constexpr int kLrDma = 6;                    // 1-KiB direct-to-LDS loads per wave and gate-step
 // 16-byte row operations a lane issues in gate-step k of a chunk (k = 2 pos + half): loads in front of the step's
 // request, stores behind its matrix work
-constexpr int kLrLoadsAt[8] = {8, 0, 16, 0, 8, 0, 0, 0};   // C of this chunk | A of the next | B of the next
+constexpr int kLrLoadsAt[8] = {8, 0, 8, 0, 0, 0, 16, 0};   // B of this chunk | C of this chunk | A of the next
 constexpr int kLrStoresAt[8] = {0, 8, 0, 0, 0, 8, 0, 4};   // dG_i, dG_g | dG_f, dc | dG_o of the next chunk
 // operations a wave has issued behind its request for gate-step k's chunk of W_hh^T (made in step k - 3)
 constexpr int lr_behind(int k) {
   return kLrStoresAt[(k + 5) & 7] + kLrLoadsAt[(k + 6) & 7] + kLrDma + kLrStoresAt[(k + 6) & 7] + kLrLoadsAt[(k + 7) & 7] +
          kLrDma + kLrStoresAt[(k + 7) & 7];
 }
-static_assert(lr_behind(0) == 24 && lr_behind(3) == 36 && lr_behind(6) == 28, "see the table in open_step");
-// ... and behind the phase-B loads (made in step 4, read after step 1's matrix work) and the phase-C loads (step 0 -> 5);
-// vmcnt has six bits: waiting for all but the 63 youngest covers anything further back
+static_assert(lr_behind(0) == 40 && lr_behind(3) == 28 && lr_behind(5) == 12 && lr_behind(7) == 36, "see the table in open_step");
+// ... and behind the parked loads of a phase, from the step that makes them to the end of the matrix work of the step that
+// reads them: B 0 -> 1, C 2 -> 5, A 6 -> 7 (vmcnt has six bits: all but the 63 youngest covers anything further back)
 constexpr int lr_behind_loads(int from, int to) {  // from the loads of step `from` to the end of step `to`'s matrix work
   int n = kLrDma;
   for (int k = (from + 1) & 7;; k = (k + 1) & 7) {
@@ -70,9 +74,10 @@ constexpr int lr_behind_loads(int from, int to) {  // from the loads of step `fr
   }
   return n < 63 ? n : 63;
 }
-constexpr int kLrBehindB = lr_behind_loads(4, 1);
-constexpr int kLrBehindC = lr_behind_loads(0, 5);
-static_assert(kLrBehindB == 56 && kLrBehindC == 63, "see the table in open_step");
+constexpr int kLrBehindB = lr_behind_loads(0, 1);
+constexpr int kLrBehindC = lr_behind_loads(2, 5);
+constexpr int kLrBehindA = lr_behind_loads(6, 7);
+static_assert(kLrBehindB == 12 && kLrBehindC == 24 && kLrBehindA == 12, "see the table in open_step");
 #ifndef RL8_LR_DIAG
 #define RL8_LR_DIAG 0  // tuning builds (tools/diag_mlp.sh lr<bits>): 1 no stores reach memory, 2 no row loads do, 4 one plane
 #endif                 // product of six, 8 no W_hh^T traffic (wrong results, same instruction stream)
@@ -156,10 +161,10 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   auto piece = [](int j) { return j * 32; };
 
   // gate-step k of chunk c -> ring slot: the packed order is [16-unit chunk 2 c + half][gate position]
-  auto request = [&](int c, int k, int slot) {
+  auto request = [&](int c, int k, int slot, int u0 = 0, int u1 = kLrDma) {  // pieces u0 .. u1 - 1 of the wave's six
     const int src = (4 * (2 * c + (k & 1)) + (k >> 1)) & (kLrGateSteps - 1);
 #pragma unroll
-    for (int u = 0; u < kLrDma; ++u) {
+    for (int u = u0; u < u1; ++u) {
       const int block = wave * kLrDma + u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, smem + slot * kLrSlotBytes + block * 1024, 16, lane * 16,
                                                src * kLrSlotBytes + block * 1024, 0, 0);
@@ -200,17 +205,6 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     d.dcout = state_rsrc(a.dc, tile, rows);
     return d;
   };
-  auto load4 = [&](u32x4 (&dst)[4], const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dst[j] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + piece(j), soff, 0);
-  };
-  auto store4 = [&](const float (&v)[16], const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4 * j]), __float_as_uint(v[4 * j + 1]),
-                                                   __float_as_uint(v[4 * j + 2]), __float_as_uint(v[4 * j + 3])},
-                                             r, voff + piece(j), soff, 0);
-  };
   auto at = [](const u32x4 (&v)[4], int e) { return __uint_as_float(v[e >> 2][e & 3]); };
 
 #ifdef RL8_LR_STAMP
@@ -223,58 +217,80 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
 #define RL8_LR_T0
 #define RL8_LR_T1(i)
 #endif
-  // the three load phases of a chunk (see the header) and the arithmetic behind each
-  u32x4 la_o[4], la_ct[4], la_dh[4], la_dc[4];
-  auto issue_a = [&](const LrLoadDesc &d, int c) {
-    load4(la_o, d.gates, v_gates, c * 128 + 3 * (kHidden * 4));
-    load4(la_ct, d.cs, v_seq, c * 128);
-    load4(la_dh, d.dhs, v_seq, c * 128);
-    load4(la_dc, d.dcin, v_state, c * 128);
-  };
-  // park PH (0: phase B, 1: phase C), array AR of this wave: 32 rows x 128 bytes, fetched COALESCED -- instruction k
-  // brings rows 8 k .. 8 k + 7 whole, eight lanes per row (8 tag look-ups instead of the 64 of a lane-per-row load) --
-  // and laid out row-major in LDS, the eight 16-byte pieces of row r permuted by XOR with (r >> 1) & 7 so that the
-  // lane = row reads below fall on sixteen different bank groups per quarter wave.  Lane i of instruction k: row
-  // 8 k + (i >> 3), LDS slot i & 7 <- piece (i & 7) ^ ((4 k + (i >> 4)) & 7) of the row.
+  // Parks: PARK 0 / 1, array AR (0 / 1) of this wave = four 1-KiB blocks; instruction k moves rows 8 k .. 8 k + 7.
+  // Lane i of instruction k: row 8 k + (i >> 3), LDS slot i & 7 <-> piece (i & 7) ^ ((4 k + (i >> 4)) & 7) of the row.
   const int park_piece = (lane & 7) ^ (lane >> 4);  // k even; k odd: ^ 4
-  auto park4 = [&](int ph, int ar, const __amdgpu_buffer_rsrc_t &r, int pitch_bytes, int soff) {
+  auto park_lds = [&](int park, int ar, int k) { return kLrRing * kLrSlotBytes + park * kLrStageBytes + ((wave * 2 + ar) * 4 + k) * 1024; };
+  auto park4 = [&](int park, int ar, const __amdgpu_buffer_rsrc_t &r, int pitch_bytes, int soff, int k0 = 0, int k1 = 4) {
+    const int v_row = (lane >> 3) * pitch_bytes;
+#pragma unroll
+    for (int k = k0; k < k1; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, smem + park_lds(park, ar, k), 16,
+                                               v_row + ((k & 1) ? (park_piece ^ 4) : park_piece) * 16, soff + 8 * k * pitch_bytes, 0, 0);
+  };
+  // lane (n, hh) holds piece 2 j + hh of row n: slot (2 j + hh) ^ ((n >> 1) & 7)
+  unsigned park_at[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    park_at[j] = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + n * 128 + (((2 * j + hh) ^ ((n >> 1) & 7)) * 16);
+  const unsigned park_line = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + lane * 16;  // the instruction view
+  const int pitch_gates = l * (4 * kHidden * 4), pitch_seq = l * (kHidden * 4), pitch_state = kHidden * 4;
+  // (each in parts, so that a gate-step can spread them between its MFMA groups: a direct-to-LDS load costs the wave
+  // ~75 cycles at issue, and issued in one run at the head of a step those were 19 % of its time with the pipe idle)
+  auto issue_b = [&](const LrLoadDesc &d, int c, int part = -1) {
+    if (part != 1) park4(0, 0, d.gates, pitch_gates, c * 128);
+    if (part != 0) park4(0, 1, d.gates, pitch_gates, c * 128 + 2 * (kHidden * 4));
+  };
+  auto issue_c = [&](const LrLoadDesc &d, int c, int part = -1) {
+    if (part != 1) park4(1, 0, d.gates, pitch_gates, c * 128 + 1 * (kHidden * 4));
+    if (part != 0) park4(1, 1, d.cprev, d.cp_pitch, c * 128);
+  };
+  auto issue_a = [&](const LrLoadDesc &d, int c, int part = -1) {  // parts 0, 1, 2: six, six and four of the sixteen
+    if (part < 0 || part == 0) {
+      park4(0, 0, d.gates, pitch_gates, c * 128 + 3 * (kHidden * 4));
+      park4(0, 1, d.cs, pitch_seq, c * 128, 0, 2);
+    }
+    if (part < 0 || part == 1) {
+      park4(0, 1, d.cs, pitch_seq, c * 128, 2, 4);
+      park4(1, 0, d.dhs, pitch_seq, c * 128);
+    }
+    if (part < 0 || part == 2) park4(1, 1, d.dcin, pitch_state, c * 128);
+  };
+  // array AR of park PARK into this lane's registers (its sixteen units); the wait for the loads is the caller's
+  auto unpark = [&](auto park_tag, auto ar_tag, u32x4 (&x)[4]) {
+    constexpr int OFF = decltype(park_tag)::value * kLrStageBytes + decltype(ar_tag)::value * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = lds_read_b128<OFF>(park_at[j]);
+  };
+  auto loads_landed = [&](auto n_tag, int stamp) {  // N = operations the wave has issued behind the phase's loads
+    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : decltype(n_tag)::value;
+    RL8_LR_T0;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    RL8_LR_T1(stamp);
+    (void)stamp;
+  };
+  // sixteen values per lane -> array AR of park PARK (lane = sequence view), then out of it eight lanes per row
+  auto repark = [&](auto park_tag, auto ar_tag, const float (&v)[16]) {
+    constexpr int OFF = decltype(park_tag)::value * kLrStageBytes + decltype(ar_tag)::value * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      lds_write_b128<OFF>(park_at[j], u32x4{__float_as_uint(v[4 * j]), __float_as_uint(v[4 * j + 1]), __float_as_uint(v[4 * j + 2]),
+                                            __float_as_uint(v[4 * j + 3])});
+  };
+  auto store_park = [&](auto park_tag, auto ar_tag, const __amdgpu_buffer_rsrc_t &r, int pitch_bytes, int soff) {
+    constexpr int OFF = decltype(park_tag)::value * kLrStageBytes + decltype(ar_tag)::value * 4096;
+    u32x4 v[4];
+    v[0] = lds_read_b128<OFF>(park_line), v[1] = lds_read_b128<OFF + 1024>(park_line);
+    v[2] = lds_read_b128<OFF + 2048>(park_line), v[3] = lds_read_b128<OFF + 3072>(park_line);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
     const int v_row = (lane >> 3) * pitch_bytes;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          r, smem + kLrRing * kLrSlotBytes + ph * kLrStageBytes + ((wave * 2 + ar) * 4 + k) * 1024, 16,
-          v_row + ((k & 1) ? (park_piece ^ 4) : park_piece) * 16, soff + 8 * k * pitch_bytes, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v[k], r, v_row + ((k & 1) ? (park_piece ^ 4) : park_piece) * 16,
+                                             soff + 8 * k * pitch_bytes, 0);
   };
-  // lane (n, hh) reads piece 2 j + hh of row n: slot (2 j + hh) ^ ((n >> 1) & 7)
-  unsigned park_read[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    park_read[j] = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + n * 128 + (((2 * j + hh) ^ ((n >> 1) & 7)) * 16);
-  const int pitch_gates = l * (4 * kHidden * 4), pitch_seq = l * (kHidden * 4);
-  auto issue_b = [&](const LrLoadDesc &d, int c) {
-    park4(0, 0, d.gates, pitch_gates, c * 128);
-    park4(0, 1, d.gates, pitch_gates, c * 128 + 2 * (kHidden * 4));
-  };
-  auto issue_c = [&](const LrLoadDesc &d, int c) {
-    park4(1, 0, d.gates, pitch_gates, c * 128 + 1 * (kHidden * 4));
-    park4(1, 1, d.cprev, d.cp_pitch, c * 128);
-  };
-  // the parked phase PH back into registers; N = operations the wave has issued behind those loads
-  auto unpark = [&](auto ph_tag, auto n_tag, u32x4 (&x)[4], u32x4 (&y)[4]) {
-    constexpr int PH = decltype(ph_tag)::value;
-    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : decltype(n_tag)::value;
-    {
-      RL8_LR_T0;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-      RL8_LR_T1(8 + PH);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      x[j] = lds_read_b128<PH * kLrStageBytes>(park_read[j]);
-      y[j] = lds_read_b128<PH * kLrStageBytes + 4 * 1024>(park_read[j]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
-  };
+  using Z0 = std::integral_constant<int, 0>;
+  using Z1 = std::integral_constant<int, 1>;
 
   // dh carried into the step being computed: dhe[e][c] = dL/dh of unit 32 c + 8 (e >> 2) + 4 hh + (e & 3) from the step
   // after it (register e of accumulator c)
@@ -295,6 +311,17 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   };
 
   auto math_a = [&](const LrStoreDesc &sd, int c) {  // -> dg[0] (o), dcv
+    u32x4 la_o[4], la_ct[4], la_dh[4], la_dc[4];
+    loads_landed(std::integral_constant<int, kLrBehindA>{}, 8);
+    unpark(Z0{}, Z0{}, la_o);
+    unpark(Z0{}, Z1{}, la_ct);
+    unpark(Z1{}, Z0{}, la_dh);
+    unpark(Z1{}, Z1{}, la_dc);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(la_o[0]), "+v"(la_o[1]), "+v"(la_o[2]), "+v"(la_o[3]), "+v"(la_ct[0]), "+v"(la_ct[1]), "+v"(la_ct[2]),
+                   "+v"(la_ct[3]));
+    asm volatile("" : "+v"(la_dh[0]), "+v"(la_dh[1]), "+v"(la_dh[2]), "+v"(la_dh[3]), "+v"(la_dc[0]), "+v"(la_dc[1]), "+v"(la_dc[2]),
+                 "+v"(la_dc[3]));
     float lmax = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -306,11 +333,16 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
       lmax = __builtin_fmaxf(lmax, __builtin_fabsf(dg[0][e]));
     }
     fold_max(lmax);
-    store4(dg[0], sd.dgates, v_gates, c * 128 + 3 * (kHidden * 4));
+    repark(Z0{}, Z0{}, dg[0]);
+    store_park(Z0{}, Z0{}, sd.dgates, pitch_gates, c * 128 + 3 * (kHidden * 4));
   };
   auto math_b = [&](const LrStoreDesc &sd, int c) {  // -> dg[1] (i), dg[2] (g)
     u32x4 lb_i[4], lb_g[4];
-    unpark(std::integral_constant<int, 0>{}, std::integral_constant<int, kLrBehindB>{}, lb_i, lb_g);
+    loads_landed(std::integral_constant<int, kLrBehindB>{}, 8);
+    unpark(Z0{}, Z0{}, lb_i);
+    unpark(Z0{}, Z1{}, lb_g);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(lb_i[0]), "+v"(lb_i[1]), "+v"(lb_i[2]), "+v"(lb_i[3]), "+v"(lb_g[0]), "+v"(lb_g[1]), "+v"(lb_g[2]), "+v"(lb_g[3]));
     float lmax = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -320,12 +352,19 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
       lmax = __builtin_fmaxf(lmax, __builtin_fmaxf(__builtin_fabsf(dg[1][e]), __builtin_fabsf(dg[2][e])));
     }
     fold_max(lmax);
-    store4(dg[1], sd.dgates, v_gates, c * 128);
-    store4(dg[2], sd.dgates, v_gates, c * 128 + 2 * (kHidden * 4));
+    repark(Z0{}, Z0{}, dg[1]);
+    repark(Z0{}, Z1{}, dg[2]);
+    store_park(Z0{}, Z0{}, sd.dgates, pitch_gates, c * 128);
+    store_park(Z0{}, Z1{}, sd.dgates, pitch_gates, c * 128 + 2 * (kHidden * 4));
   };
   auto math_c = [&](const LrStoreDesc &sd, int c) {  // -> dg[3] (f), dc out
     u32x4 lc_f[4], lc_cp[4];
-    unpark(std::integral_constant<int, 1>{}, std::integral_constant<int, kLrBehindC>{}, lc_f, lc_cp);
+    loads_landed(std::integral_constant<int, kLrBehindC>{}, 9);
+    unpark(Z1{}, Z0{}, lc_f);
+    unpark(Z1{}, Z1{}, lc_cp);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(lc_f[0]), "+v"(lc_f[1]), "+v"(lc_f[2]), "+v"(lc_f[3]), "+v"(lc_cp[0]), "+v"(lc_cp[1]), "+v"(lc_cp[2]),
+                   "+v"(lc_cp[3]));
     float dc_out[16], lmax = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -335,13 +374,15 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
       lmax = __builtin_fmaxf(lmax, __builtin_fabsf(dg[3][e]));
     }
     fold_max(lmax);
-    store4(dg[3], sd.dgates, v_gates, c * 128 + 1 * (kHidden * 4));
-    store4(dc_out, sd.dcout, v_state, c * 128);
+    repark(Z1{}, Z0{}, dg[3]);
+    repark(Z1{}, Z1{}, dc_out);
+    store_park(Z1{}, Z0{}, sd.dgates, pitch_gates, c * 128 + 1 * (kHidden * 4));
+    store_park(Z1{}, Z1{}, sd.dcout, pitch_state, c * 128);
   };
 
   // one gate-step: 16 k of the product, W_hh^T planes from ring slot K & 3, B planes from dg[K >> 1][8 (K & 1) ..+7].
   // Out tiles in pairs: two accumulators alternate, so no MFMA waits for the one before it.
-  auto matrix_step = [&](auto k_tag) {
+  auto matrix_step = [&](auto k_tag, auto &&side) {  // side(mp): what the step issues behind the MFMAs of tile pair mp
     constexpr int K = decltype(k_tag)::value;
     constexpr int POS = K >> 1, E0 = 8 * (K & 1);
     u32x4 bh, bm, bl;
@@ -391,6 +432,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
 #undef RL8_LR_MMA
       acc[2 * mp] = d0;
       acc[2 * mp + 1] = d1;
+      side(mp);
     }
   };
 
@@ -399,9 +441,9 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   // next request overwrites.  N = lr_behind(K): what the wave has issued behind that request, made three gate-steps
   // earlier, with the order of a gate-step's operations [row loads | request | matrix work | stores]:
   //   K        0   1   2   3   4   5   6   7
-  //   loads    8   .  16   .   8   .   .   .      (C | A of the next chunk | B of the next chunk)
+  //   loads    8   .   8   .   .   .  16   .      (B | C | A of the next chunk; all parked: direct-to-LDS)
   //   stores   .   8   .   .   .   8   .   4      (dG_i, dG_g | dG_f, dc | dG_o of the next chunk)
-  //   N       24  24  32  36  36  20  28  20
+  //   N       40  24  32  28  28  12  20  36
   auto open_step = [&](auto k_tag) {
     constexpr int K = decltype(k_tag)::value;
     constexpr int N = RL8_LR_SAFE_WAITS ? 0 : lr_behind(K);
@@ -439,12 +481,12 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   for (int e = 0; e < 16; ++e) dhe[e] = f32x8v{0, 0, 0, 0, 0, 0, 0, 0};
   LrLoadDesc nd = load_desc(tile, t);  // where the loads of the current step come from
   issue_a(nd, 0);
-  issue_b(nd, 0);
   request(0, 0, 0);
   request(0, 1, 1);
   request(0, 2, 2);
+  // (the counted waits of the first chunk assume a full chunk of operations behind each request: drain instead)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   math_a(sd, 0);
-  // the counted waits of the first chunk assume a full chunk of operations behind each request: drain instead
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   while (true) {
@@ -457,42 +499,54 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     for (int c = 0; c < kLrChunks; ++c) {
       const bool wrap = c == kLrChunks - 1;
       const int cn = wrap ? 0 : c + 1;
+      // Within a step the order of the vector-memory operations is [parked row loads | request | stores], as the wait
+      // table assumes; they go out behind the MFMA groups of the step, a few at a time.
+      const LrLoadDesc &ad = wrap ? after : nd;
+      auto only_request = [&](int cc, int k, int slot) {
+        return [&, cc, k, slot](int mp) {
+          if (mp < 3) request(cc, k, slot, 2 * mp, 2 * mp + 2);
+        };
+      };
       open_step(K0{});
-      { RL8_LR_T0; issue_c(nd, c); RL8_LR_T1(13); }
-      asm volatile("" ::: "memory");
-      { RL8_LR_T0; request(c, 3, 3); RL8_LR_T1(13); }
       if (c == 0) {
 #pragma unroll
         for (int mo = 0; mo < 8; ++mo) acc[mo] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       }
-      matrix_step(K0{});
+      matrix_step(K0{}, [&](int mp) {
+        if (mp == 0) issue_b(nd, c, 0);
+        else if (mp == 1) issue_b(nd, c, 1);
+        else if (mp == 2) request(c, 3, 3, 0, 3);
+        else request(c, 3, 3, 3, 6);
+      });
       open_step(K1{});
-      { RL8_LR_T0; request(c, 4, 0); RL8_LR_T1(13); }
-      matrix_step(K1{});
+      matrix_step(K1{}, only_request(c, 4, 0));
       { RL8_LR_T0; math_b(sd, c); RL8_LR_T1(14); }
       open_step(K2{});
-      { RL8_LR_T0; issue_a(wrap ? after : nd, cn); RL8_LR_T1(13); }
-      asm volatile("" ::: "memory");
-      { RL8_LR_T0; request(c, 5, 1); RL8_LR_T1(13); }
-      matrix_step(K2{});
+      matrix_step(K2{}, [&](int mp) {
+        if (mp == 0) issue_c(nd, c, 0);
+        else if (mp == 1) issue_c(nd, c, 1);
+        else if (mp == 2) request(c, 5, 1, 0, 3);
+        else request(c, 5, 1, 3, 6);
+      });
       open_step(K3{});
-      { RL8_LR_T0; request(c, 6, 2); RL8_LR_T1(13); }
-      matrix_step(K3{});
+      matrix_step(K3{}, only_request(c, 6, 2));
       open_step(K4{});
-      { RL8_LR_T0; issue_b(wrap ? after : nd, cn); RL8_LR_T1(13); }
-      asm volatile("" ::: "memory");
-      { RL8_LR_T0; request(c, 7, 3); RL8_LR_T1(13); }
-      matrix_step(K4{});
+      matrix_step(K4{}, only_request(c, 7, 3));
       open_step(K5{});
-      { RL8_LR_T0; request(cn, 0, 0); RL8_LR_T1(13); }
-      matrix_step(K5{});
+      matrix_step(K5{}, only_request(cn, 0, 0));
       { RL8_LR_T0; math_c(sd, c); RL8_LR_T1(14); }
       open_step(K6{});
-      { RL8_LR_T0; request(cn, 1, 1); RL8_LR_T1(13); }
-      matrix_step(K6{});
+      matrix_step(K6{}, [&](int mp) {
+        if (mp == 0) issue_a(ad, cn, 0);
+        else if (mp == 1) issue_a(ad, cn, 1);
+        else if (mp == 2) {
+          issue_a(ad, cn, 2);
+          asm volatile("" ::: "memory");
+          request(cn, 1, 1, 0, 2);
+        } else request(cn, 1, 1, 2, 6);
+      });
       open_step(K7{});
-      { RL8_LR_T0; request(cn, 2, 2); RL8_LR_T1(13); }
-      matrix_step(K7{});
+      matrix_step(K7{}, only_request(cn, 2, 2));
       if (wrap) {
         // the step's dh is complete: it becomes the carry of the step the next arithmetic belongs to (zero for a new tile)
 #pragma unroll
