@@ -275,6 +275,108 @@ __global__ void gae_scan_env_major_kernel(
   publish_moments(acc, partials, (double)n * (double)h, moments_out, smem);
 }
 
+// The flat case again (whole rows in one chunk, H + 1 odd and <= 4 KMAX), software-pipelined over the workgroup's tiles.
+// The kernel above runs its three phases one behind the other, and a wave's vector-memory operations retire through ONE
+// in-order counter: the wait for a tile's loads also waits for the stores of the tile before it, so the chip alternates
+// between reading and writing (loads alone 71 us, loads + stores 147 us per 2^20 x 32; RL8_GAE_DIAG runs of round 3).
+// Here the NEXT tile's rows are requested into registers before this tile's scan: they are older than this tile's
+// stores, land under the scan, and the wait for them (written by the compiler: all but the stores issued behind them)
+// no longer sees the stores.  Buffer descriptors end at the tile's last float: no guarded tails.
+template <int KMAX>
+__global__ __launch_bounds__(256) void gae_scan_env_major_pipelined_kernel(
+    float *__restrict__ rewards, const float *__restrict__ values, float *__restrict__ adv,
+    float *__restrict__ ret, int64_t n, int64_t h, float gamma, float gamma_lambda, float denom,
+    int write_back, double *__restrict__ partials, double *__restrict__ moments_out) {
+  extern __shared__ float lds[];
+  __shared__ double smem[2 * kWavesPerBlock];
+  const int envs_per_block = blockDim.x, nthreads = blockDim.x, tid = threadIdx.x;
+  const int stride = (int)h + 1;  // = the LDS row stride (odd: conflict-free column walks)
+  float *tile_r = lds, *tile_v = lds + envs_per_block * stride;
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  double acc[2] = {0.0, 0.0};
+  const int64_t tiles = (n + envs_per_block - 1) / envs_per_block;
+  auto envs_of = [&](int64_t tile) {
+    const int64_t left = tile < tiles ? n - tile * envs_per_block : 0;
+    return (int)(left < envs_per_block ? left : envs_per_block);
+  };
+  auto rsrc_of = [&](const float *base, int64_t tile) {
+    const int ne = envs_of(tile);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ne > 0 ? base + tile * envs_per_block * stride : base), 0,
+                                             ne * stride * 4, 0x00020000);
+  };
+  u4 r4[KMAX], v4[KMAX];
+  auto request = [&](int64_t tile) {
+    const __amdgpu_buffer_rsrc_t rr = rsrc_of(rewards, tile), vr = rsrc_of(values, tile);
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+      r4[u] = __builtin_amdgcn_raw_buffer_load_b128(rr, (tid + u * nthreads) * 16, 0, 0);
+      v4[u] = __builtin_amdgcn_raw_buffer_load_b128(vr, (tid + u * nthreads) * 16, 0, 0);
+    }
+  };
+  int64_t tile = blockIdx.x;
+  request(tile);
+  for (; tile < tiles; tile += gridDim.x) {
+    const int ne = envs_of(tile);
+    const int nvec = (ne * stride + 3) >> 2;
+    const __amdgpu_buffer_rsrc_t wr = rsrc_of(rewards, tile);
+    // registers -> LDS (the previous tile's stores have read it: barrier at the end of the loop body)
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+      const int i = tid + u * nthreads;
+      if (i < nvec) {
+        float4 r;
+        r.x = __uint_as_float(r4[u][0]) / denom, r.y = __uint_as_float(r4[u][1]) / denom;
+        r.z = __uint_as_float(r4[u][2]) / denom, r.w = __uint_as_float(r4[u][3]) / denom;
+        reinterpret_cast<float4 *>(tile_r)[i] = r;
+        reinterpret_cast<float4 *>(tile_v)[i] =
+            make_float4(__uint_as_float(v4[u][0]), __uint_as_float(v4[u][1]), __uint_as_float(v4[u][2]), __uint_as_float(v4[u][3]));
+        if (write_back)
+          __builtin_amdgcn_raw_buffer_store_b128(
+              u4{__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w)}, wr, i * 16, 0, 0);
+      }
+    }
+    __syncthreads();
+    request(tile + gridDim.x);  // in flight through the scan and the stores below; zero records past the last tile
+    if (tid < ne) {
+      float *row_r = tile_r + tid * stride, *row_v = tile_v + tid * stride;
+      float prev = 0.0f, v_next = 0.0f;
+#pragma unroll 4
+      for (int j = stride - 1; j >= 0; --j) {
+        const float v = row_v[j];
+        if (j == (int)h) {  // column H: adv = 0, ret = values (:105, :117)
+          prev = 0.0f;
+          row_r[j] = 0.0f;
+          row_v[j] = 0.0f + v;
+        } else {
+          const float delta = row_r[j] + (gamma * v_next - v);
+          prev = delta + gamma_lambda * prev;
+          row_r[j] = prev;
+          row_v[j] = prev + v;
+          acc[0] += (double)prev;
+          acc[1] += (double)prev * (double)prev;
+        }
+        v_next = v;
+      }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t ar = rsrc_of(adv, tile), qr = rsrc_of(ret, tile);
+#pragma unroll
+    for (int u = 0; u < KMAX; ++u) {
+      const int i = tid + u * nthreads;
+      if (i < nvec) {
+        const float4 a4 = reinterpret_cast<const float4 *>(tile_r)[i], q4 = reinterpret_cast<const float4 *>(tile_v)[i];
+        __builtin_amdgcn_raw_buffer_store_b128(
+            u4{__float_as_uint(a4.x), __float_as_uint(a4.y), __float_as_uint(a4.z), __float_as_uint(a4.w)}, ar, i * 16, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(
+            u4{__float_as_uint(q4.x), __float_as_uint(q4.y), __float_as_uint(q4.z), __float_as_uint(q4.w)}, qr, i * 16, 0, 0);
+      }
+    }
+    __syncthreads();  // the tile has been read out: the next one may overwrite it
+  }
+  block_reduce<2, SumOp>(acc, smem);
+  publish_moments(acc, partials, (double)n * (double)h, moments_out, smem);
+}
+
 struct NormConsts {
   float mean, sd;
 };
@@ -357,6 +459,11 @@ RL8_API int rl8_gae_scan_f32(float *rewards, const float *values, float *adv_out
     }
     int e = (int)(73728 / ((int64_t)lds_stride * 8) / kWave) * kWave;
     if (e > 256) e = 256;
+    // (the pipelined flat kernel below: 128 envs per workgroup, two workgroups per CU measured best -- 122.6-124.2 us per
+    // 2^20 x 32 against 126.5-128 for the other shapes)
+    static const int no_pipeline = env_int("RL8_GAE_NO_PIPELINE");  // (A/B runs)
+    const bool pipelined_shape = !no_pipeline && chunk == cols && (cols & 1) && cols <= 36;
+    if (pipelined_shape && e > 128) e = 128;
     if (env_override >= kWave && env_override <= 256 && env_override % kWave == 0) e = env_override;
     if (e < kWave) e = kWave;
     const size_t lds_bytes = (size_t)2 * e * lds_stride * sizeof(float);
@@ -372,7 +479,27 @@ RL8_API int rl8_gae_scan_f32(float *rewards, const float *values, float *adv_out
       attr_set = true;
     }
     rows = grid_for(n, e);
-    if (flat)
+    if (flat && pipelined_shape) {
+      static bool attr9 = false;
+      if (!attr9) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gae_scan_env_major_pipelined_kernel<9>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr9 = true;
+      }
+      // as many workgroups as are resident at once (each runs its tiles back to back, the next one's rows in flight):
+      // a second round of workgroups would start with nothing requested
+      static const int per_cu_cap = env_int("RL8_GAE_BLOCKS_PER_CU");
+      int per_cu = (int)((160 * 1024) / (lds_bytes + 16 + 1024));
+      if (per_cu > 2) per_cu = 2;
+      if (per_cu_cap > 0 && per_cu_cap < per_cu) per_cu = per_cu_cap;
+      if (per_cu < 1) per_cu = 1;
+      if (rows > kCUs * per_cu) rows = kCUs * per_cu;
+      // (a lane's sixteen-byte piece of the tile's tail may reach past E * cols floats by up to 12 bytes: + one vector)
+      gae_scan_env_major_pipelined_kernel<9><<<rows, e, lds_bytes + 16, s>>>(
+          rewards, values, adv_out, ret_out, n, h, gamma, gamma_lambda, reward_denominator, write_scaled_rewards, partials,
+          moments_out);
+    } else if (flat)
       gae_scan_env_major_kernel<true><<<rows, e, lds_bytes, s>>>(
           rewards, values, adv_out, ret_out, n, h, gamma, gamma_lambda, reward_denominator,
           write_scaled_rewards, chunk, lds_stride, partials, moments_out);
