@@ -484,7 +484,8 @@ int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const flo
  *   bytes: W_hh as two fp16 planes in the kernel's fragment order + its power of two) and `wb`
  *   (rl8_lstm_split_wb_floats() floats: [1024][8] = [w_ih row | 0.. | b_ih + b_hh]).
  * rl8_lstm_split_state: h [B][pitch] fp32 -> `planes` (rl8_lstm_split_state_bytes(B) bytes),
- *   the step kernel's A operand.
+ *   the step kernel's A operand.  rl8_lstm_split_state_bound: the same, and max |h| over the rows as a float's bit
+ *   pattern in *bound_out (what rl8_lstm_wgrad_f16_f32 takes as h_bound for the first timestep).
  * rl8_lstm_step_split_f32: x row r at x + r * x_pitch (d_in floats); h_planes of h_{t-1};
  *   c_prev row r at c_prev + r * c_prev_pitch; writes h_t, c_t rows at the given pitches
  *   (floats) and, when `gates` is not NULL, the post-activation gates i, f, g, o as
@@ -500,6 +501,8 @@ int64_t rl8_lstm_split_state_bytes(int64_t b);
 int rl8_lstm_pack_split(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
                         int d_in, void *packed, float *wb, void *stream);
 int rl8_lstm_split_state(const float *h, int64_t pitch, int64_t b, void *planes, void *stream);
+int rl8_lstm_split_state_bound(const float *h, int64_t pitch, int64_t b, void *planes, uint32_t *bound_out,
+                               void *stream);
 int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, const void *h_planes,
                             const float *c_prev, int64_t c_prev_pitch, const void *w_planes,
                             const float *wb, int64_t b, float *h_out, int64_t h_out_pitch, float *c_out,
@@ -589,10 +592,16 @@ int rl8_lstm_wgrad_f16_f32(const float *dz, int64_t dz_pitch, const uint32_t *dz
  * all of them at once: out [M][n] = h [M][256] x w^T + b, w [n][256] (the heads'
  * nn.Linear weights stacked), n <= 8.  Backward: dh_out [M][256] = dout x w and
  * `*partial_rows_out` rows (<= rl8_linear_heads_max_rows()) of [dW (n*256) | db (n)]
- * whose column sums are the parameter gradients. */
+ * whose column sums are the parameter gradients.
+ * rl8_linear_heads_forward_pair_f32: two layers that stay separate arrays (the rollout's logits head and value head,
+ * algorithms/_recurrent.py:400-420 via policy.sample()) in one pass over h: out_a [M][n_a], out_b [M][n_b],
+ * n_a + n_b <= 8. */
 int rl8_linear_heads_max_rows(void);
 int rl8_linear_heads_forward_f32(const float *h, int64_t m, const float *w, const float *b, int n_out,
                                  float *out, void *stream);
+int rl8_linear_heads_forward_pair_f32(const float *h, int64_t m, const float *w_a, const float *b_a, int n_a,
+                                      float *out_a, const float *w_b, const float *b_b, int n_b, float *out_b,
+                                      void *stream);
 int rl8_linear_heads_backward_f32(const float *h, const float *dout, int64_t m, const float *w,
                                   int n_out, float *dh_out, float *partials,
                                   int *partial_rows_out /*host*/, void *stream);

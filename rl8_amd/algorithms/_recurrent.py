@@ -146,10 +146,14 @@ class _LeanRollout:
                                                     hs, at(self.h, t + 1), at(self.c, t + 1), None, None, stream),
                            "rl8_lstm_forward_f32")
         with hip._timed("linear_heads_forward", n) if timed else _NO_TIMER:
-            hip._check(lib.rl8_linear_heads_forward_f32(hs, n, w_pol, b_pol, self.k, logits, stream),
-                       "rl8_linear_heads_forward_f32")
-            hip._check(lib.rl8_linear_heads_forward_f32(hs, n, w_vf, b_vf, 1, value, stream),
-                       "rl8_linear_heads_forward_f32")
+            if self.k + 1 <= hip.HEADS_MAX_OUT:  # both heads in one pass over h_t
+                hip._check(lib.rl8_linear_heads_forward_pair_f32(hs, n, w_pol, b_pol, self.k, logits, w_vf, b_vf, 1, value,
+                                                                 stream), "rl8_linear_heads_forward_pair_f32")
+            else:
+                hip._check(lib.rl8_linear_heads_forward_f32(hs, n, w_pol, b_pol, self.k, logits, stream),
+                           "rl8_linear_heads_forward_f32")
+                hip._check(lib.rl8_linear_heads_forward_f32(hs, n, w_vf, b_vf, 1, value, stream),
+                           "rl8_linear_heads_forward_f32")
         with hip._timed("rollout_step_dummy", n) if timed else _NO_TIMER:
             hip._check(lib.rl8_rollout_step_dummy_f32(
                 1, 0, logits, None, value, noise.data_ptr() if noise is not None else None, self.state_ptr,

@@ -482,15 +482,25 @@ namespace rl8 {
 constexpr int kHeadsMaxOut = 8;
 
 // Forward: 4 lanes per row (a quarter of the 256 inputs each, 16-byte loads), the
-// weights broadcast from LDS, two shuffles.
+// weights broadcast from LDS, two shuffles.  The NOUT outputs may belong to two layers
+// (the first n_a to {w, bias, out}, the rest to {w_b, bias_b, out_b}; n_a = NOUT: one
+// layer): the rollout's logits and value heads are one pass over h_t, one launch.
+struct HeadsForwardArgs {
+  const float *w, *bias;
+  float *out;
+  int n_a;
+  const float *w_b, *bias_b;
+  float *out_b;
+};
+
 template <int NOUT>
-__global__ __launch_bounds__(kBlock) void linear_heads_forward_kernel(const float4 *__restrict__ h,
-                                                                      int64_t m,
-                                                                      const float *__restrict__ w,
-                                                                      const float *__restrict__ bias,
-                                                                      float *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void linear_heads_forward_kernel(const float4 *__restrict__ h, int64_t m,
+                                                                      HeadsForwardArgs a) {
   __shared__ float4 ws[NOUT * kHidden / 4];
-  for (int i = threadIdx.x; i < NOUT * kHidden / 4; i += kBlock) ws[i] = reinterpret_cast<const float4 *>(w)[i];
+  const int n_a = a.n_a, n_b = NOUT - n_a;
+  for (int i = threadIdx.x; i < NOUT * kHidden / 4; i += kBlock)
+    ws[i] = i < n_a * (kHidden / 4) ? reinterpret_cast<const float4 *>(a.w)[i]
+                                    : reinterpret_cast<const float4 *>(a.w_b)[i - n_a * (kHidden / 4)];
   __syncthreads();
   const int q4 = threadIdx.x & 3;
   const int64_t stride = (int64_t)gridDim.x * (kBlock / 4);
@@ -516,7 +526,10 @@ __global__ __launch_bounds__(kBlock) void linear_heads_forward_kernel(const floa
       float v = o[q];
       v += __shfl_xor(v, 1, kWave);
       v += __shfl_xor(v, 2, kWave);
-      if (q4 == 0) out[row * NOUT + q] = v + bias[q];
+      if (q4 == 0) {
+        if (q < n_a) a.out[row * n_a + q] = v + a.bias[q];
+        else a.out_b[row * n_b + (q - n_a)] = v + a.bias_b[q - n_a];
+      }
     }
   }
 }
@@ -567,25 +580,39 @@ __global__ __launch_bounds__(kBlock) void linear_heads_backward_kernel(const flo
 
 RL8_API int rl8_linear_heads_max_rows(void) { return kMaxGrid; }
 
+static int heads_forward(const float *h, int64_t m, const rl8::HeadsForwardArgs &a, int n_out, void *stream) {
+  const int grid = grid_for(m, kBlock / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const float4 *h4 = reinterpret_cast<const float4 *>(h);
+  switch (n_out) {
+    case 1: linear_heads_forward_kernel<1><<<grid, kBlock, 0, s>>>(h4, m, a); break;
+    case 2: linear_heads_forward_kernel<2><<<grid, kBlock, 0, s>>>(h4, m, a); break;
+    case 3: linear_heads_forward_kernel<3><<<grid, kBlock, 0, s>>>(h4, m, a); break;
+    case 4: linear_heads_forward_kernel<4><<<grid, kBlock, 0, s>>>(h4, m, a); break;
+    case 5: linear_heads_forward_kernel<5><<<grid, kBlock, 0, s>>>(h4, m, a); break;
+    case 6: linear_heads_forward_kernel<6><<<grid, kBlock, 0, s>>>(h4, m, a); break;
+    case 7: linear_heads_forward_kernel<7><<<grid, kBlock, 0, s>>>(h4, m, a); break;
+    default: linear_heads_forward_kernel<8><<<grid, kBlock, 0, s>>>(h4, m, a); break;
+  }
+  return launch_status();
+}
+
 RL8_API int rl8_linear_heads_forward_f32(const float *h, int64_t m, const float *w, const float *b,
                                          int n_out, float *out, void *stream) {
   if (!h || !w || !b || !out) return RL8_ENULL;
   if (m <= 0 || n_out <= 0 || n_out > kHeadsMaxOut) return RL8_ESIZE;
   if (!aligned16(h) || !aligned16(w)) return RL8_EALIGN;
-  const int grid = grid_for(m, kBlock / 4);
-  hipStream_t s = (hipStream_t)stream;
-  const float4 *h4 = reinterpret_cast<const float4 *>(h);
-  switch (n_out) {
-    case 1: linear_heads_forward_kernel<1><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
-    case 2: linear_heads_forward_kernel<2><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
-    case 3: linear_heads_forward_kernel<3><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
-    case 4: linear_heads_forward_kernel<4><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
-    case 5: linear_heads_forward_kernel<5><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
-    case 6: linear_heads_forward_kernel<6><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
-    case 7: linear_heads_forward_kernel<7><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
-    default: linear_heads_forward_kernel<8><<<grid, kBlock, 0, s>>>(h4, m, w, b, out); break;
-  }
-  return launch_status();
+  return heads_forward(h, m, HeadsForwardArgs{w, b, out, n_out, nullptr, nullptr, nullptr}, n_out, stream);
+}
+
+// Two layers on the same rows in one pass: out_a [M][n_a] = h x w_a^T + b_a, out_b [M][n_b] = h x w_b^T + b_b.
+RL8_API int rl8_linear_heads_forward_pair_f32(const float *h, int64_t m, const float *w_a, const float *b_a, int n_a,
+                                              float *out_a, const float *w_b, const float *b_b, int n_b, float *out_b,
+                                              void *stream) {
+  if (!h || !w_a || !b_a || !out_a || !w_b || !b_b || !out_b) return RL8_ENULL;
+  if (m <= 0 || n_a <= 0 || n_b <= 0 || n_a + n_b > kHeadsMaxOut) return RL8_ESIZE;
+  if (!aligned16(h) || !aligned16(w_a) || !aligned16(w_b)) return RL8_EALIGN;
+  return heads_forward(h, m, HeadsForwardArgs{w_a, b_a, out_a, n_a, w_b, b_b, out_b}, n_a + n_b, stream);
 }
 
 RL8_API int rl8_linear_heads_backward_f32(const float *h, const float *dout, int64_t m,

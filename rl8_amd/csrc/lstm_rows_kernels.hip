@@ -153,13 +153,6 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   const __amdgpu_buffer_rsrc_t wrsrc = buffer_rsrc(w_planes, (kLrDiag & 8) ? 0 : kLrPackedBytes);
   const unsigned a_read = lds0 + lane * 16;
 
-  // per-lane byte offsets: sequence n of the wave's 32; piece j (registers 4 j .. 4 j + 3) of a lane's sixteen units of
-  // a chunk is units 8 j + 4 hh ..+3: lanes n and n + 32 move 32 adjacent bytes per instruction, a 128-byte line in four
-  const int v_gates = n * l * (4 * kHidden * 4) + hh * 16;
-  const int v_seq = n * l * (kHidden * 4) + hh * 16;
-  const int v_state = n * (kHidden * 4) + hh * 16;
-  auto piece = [](int j) { return j * 32; };
-
   // gate-step k of chunk c -> ring slot: the packed order is [16-unit chunk 2 c + half][gate position]
   auto request = [&](int c, int k, int slot, int u0 = 0, int u1 = kLrDma) {  // pieces u0 .. u1 - 1 of the wave's six
     const int src = (4 * (2 * c + (k & 1)) + (k >> 1)) & (kLrGateSteps - 1);

@@ -130,6 +130,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_split_state_bytes": [_i64],
     "rl8_lstm_pack_split": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "rl8_lstm_split_state": [_vp, _i64, _i64, _vp, _vp],
+    "rl8_lstm_split_state_bound": [_vp, _i64, _i64, _vp, _vp, _vp],
     "rl8_lstm_step_split_f32": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
     "rl8_lstm_rows_backward_pack_bytes": [],
     "rl8_lstm_rows_backward_pack": [_vp, _vp, _vp],
@@ -141,6 +142,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_backward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_linear_heads_max_rows": [],
     "rl8_linear_heads_forward_f32": [_vp, _i64, _vp, _vp, _i32, _vp, _vp],
+    "rl8_linear_heads_forward_pair_f32": [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "rl8_linear_heads_backward_f32": [_vp, _vp, _i64, _vp, _i32, _vp, _vp, C.POINTER(C.c_int), _vp],
     "rl8_mlp_wgrad_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp],
     "rl8_mlp_wgrad_split_strided_f32": [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
@@ -1233,9 +1235,12 @@ def lstm_state_planes(rows: int, device: torch.device | str, copies: int = 1) ->
 
 
 def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, packed: torch.Tensor, wb: torch.Tensor,
-                       *, save: bool = False, planes: None | torch.Tensor = None):
-    """As :func:`lstm_forward` on the bf16-plane step kernel: one state split + one step
-    launch per timestep. Same outputs and saved layouts (``gates`` [B, L, 4, 256], ``cs``)."""
+                       *, save: bool = False, planes: None | torch.Tensor = None,
+                       h0_bound_out: None | torch.Tensor = None):
+    """As :func:`lstm_forward` on the fp16-plane step kernel: one state split + one step
+    launch per timestep. Same outputs and saved layouts (``gates`` [B, L, 4, 256], ``cs``).
+    ``h0_bound_out`` (one float32 element): receives max |h0|, which the state split sees
+    anyway (:func:`lstm_backward`'s ``h0_bound``)."""
     x = _dense(x.detach(), torch.float32, "x")
     b, l, d_in = x.shape
     for name, t in (("h0", h0), ("c0", c0)):
@@ -1255,7 +1260,12 @@ def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, pack
         raise ValueError("lstm_forward_split: `planes` must hold two state-plane buffers for L > 1")
     H, stream = LSTM_HIDDEN, _stream()
     xp, hsp, csp, gp, pp = _ptr(x), _ptr(hs), _ptr(cs), _ptr(gates), _ptr(planes)
-    _check(lib.rl8_lstm_split_state(_ptr(h0), H, b, pp, stream), "rl8_lstm_split_state")
+    if h0_bound_out is not None:
+        if h0_bound_out.dtype != torch.float32 or h0_bound_out.numel() != 1 or h0_bound_out.device != dev:
+            raise ValueError("h0_bound_out must be one float32 element on x's device")
+        _check(lib.rl8_lstm_split_state_bound(_ptr(h0), H, b, pp, _ptr(h0_bound_out), stream), "rl8_lstm_split_state_bound")
+    else:
+        _check(lib.rl8_lstm_split_state(_ptr(h0), H, b, pp, stream), "rl8_lstm_split_state")
     for t in range(l):
         c_prev, c_pitch = (_ptr(c0), H) if t == 0 else (csp + (t - 1) * H * 4, l * H)
         p_in, p_out = pp + (t & 1) * half, (pp + ((t + 1) & 1) * half) if t + 1 < l else None
@@ -1318,7 +1328,7 @@ _lstm_colsum_ws: dict[tuple, torch.Tensor] = {}
 def lstm_backward(
     x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, hs: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor,
     dhs: torch.Tensor, whht_packed: None | torch.Tensor, *, split: None | bool = None,
-    rows_packed: None | torch.Tensor = None,
+    rows_packed: None | torch.Tensor = None, h0_bound: None | torch.Tensor = None,
 ) -> dict[str, torch.Tensor]:
     """Parameter gradients of the LSTM given ``dhs`` [B, L, 256] (gradient of every
     ``h_t``) and what ``lstm_forward(..., save=True)`` returned. Returns ``w_ih``,
@@ -1329,7 +1339,8 @@ def lstm_backward(
     ``rows_packed`` (:func:`lstm_rows_backward_pack`): the backward through time runs
     on bf16 planes too (``rl8_lstm_rows_backward_f32``) instead of the fp32-MFMA kernel
     that reads ``whht_packed``; only with ``split`` (its dW_ih / bias sums come from the
-    weight-gradient kernel)."""
+    weight-gradient kernel). ``h0_bound``: one float32 element >= max |h0| when the caller
+    has it (:func:`lstm_forward_split`'s ``h0_bound_out``); computed here otherwise."""
     x = _dense(x.detach(), torch.float32, "x")
     b, l, d_in = x.shape
     for name, t, shape in (("h0", h0, (b, LSTM_HIDDEN)), ("c0", c0, (b, LSTM_HIDDEN)), ("hs", hs, (b, l, LSTM_HIDDEN)),
@@ -1383,7 +1394,10 @@ def lstm_backward(
         # one power of two for the tensor, h_{t-1} by one from max |h0| (t = 0) or 1 (an LSTM's own outputs)
         f16 = dg_bound is not None and os.environ.get("RL8_AMD_LSTM_WGRAD_PLANES", "f16") != "bf16"
         if f16:
-            h0_bound = h0.abs().amax().reshape(1).clamp_min(1e-30)
+            if h0_bound is None:
+                h0_bound = torch.linalg.vector_norm(h0, ord=float("inf")).reshape(1)
+            elif h0_bound.dtype != torch.float32 or h0_bound.numel() != 1 or h0_bound.device != dev:
+                raise ValueError("h0_bound must be one float32 element on x's device")
             one = torch.ones(1, dtype=torch.float32, device=dev)
         if f16 and b >= 128 and os.environ.get("RL8_AMD_LSTM_WGRAD_GATES", "fused") != "separate":
             # the four gates of a timestep in one launch: h_{t-1} comes out of HBM once instead of four times
@@ -1430,6 +1444,27 @@ def lstm_backward(
                           int(t > 0), *extra, stream), name)
     return {"w_ih": small[: 4 * LSTM_HIDDEN * d_in].view(4 * LSTM_HIDDEN, d_in), "w_hh": dw_hh,
             "b": small[4 * LSTM_HIDDEN * d_in :]}
+
+
+HEADS_MAX_OUT = 8  # outputs of one linear-heads launch
+
+
+def linear_heads_forward_pair(h: torch.Tensor, w_a: torch.Tensor, b_a: torch.Tensor, w_b: torch.Tensor,
+                              b_b: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Two layers on the same rows in one pass: (h x w_a^T + b_a [M, n_a], h x w_b^T + b_b [M, n_b])."""
+    h = _dense(h.detach(), torch.float32, "h")
+    w_a, b_a, w_b, b_b = (_dense(t.detach(), torch.float32, n) for t, n in ((w_a, "w_a"), (b_a, "b_a"), (w_b, "w_b"), (b_b, "b_b")))
+    m, n_a, n_b = h.shape[0], w_a.shape[0], w_b.shape[0]
+    if h.shape[1] != LSTM_HIDDEN or w_a.shape[1] != LSTM_HIDDEN or w_b.shape[1] != LSTM_HIDDEN or b_a.numel() != n_a \
+            or b_b.numel() != n_b:
+        raise ValueError("linear_heads_forward_pair: h [M, 256], w [n, 256], b [n]")
+    out_a = torch.empty(m, n_a, dtype=torch.float32, device=h.device)
+    out_b = torch.empty(m, n_b, dtype=torch.float32, device=h.device)
+    with _timed("linear_heads_forward", m):
+        _check(load().rl8_linear_heads_forward_pair_f32(_ptr(h), m, _ptr(w_a), _ptr(b_a), n_a, _ptr(out_a), _ptr(w_b),
+                                                        _ptr(b_b), n_b, _ptr(out_b), _stream()),
+               "rl8_linear_heads_forward_pair_f32")
+    return out_a, out_b
 
 
 def linear_heads_forward(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -78,28 +78,31 @@ class _FusedLSTM(torch.autograd.Function):
         need_grad = grad_mode and any(ctx.needs_input_grad[3:7])
         if use_split(lstm):
             packed, wb = _packs(lstm, "split")
-            hs, hn, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=need_grad)
-            hn, cn = hn.contiguous(), cn.contiguous()
+            # max |h0| for the backward's fp16-plane weight gradient comes out of the state split
+            bound = torch.empty(1, dtype=torch.float32, device=x.device) if need_grad else None
+            hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=need_grad, h0_bound_out=bound)
         else:
-            hs, hn, cn, gates, cs = hip.lstm_forward(x, h0, c0, _packs(lstm, False), save=need_grad)
+            bound = None
+            hs, _, cn, gates, cs = hip.lstm_forward(x, h0, c0, _packs(lstm, False), save=need_grad)
         ctx.set_materialize_grads(False)
         if need_grad:
             ctx.lstm = lstm
+            ctx.h0_bound = bound
             ctx.save_for_backward(x, h0, c0, hs, gates, cs)
         ctx.mark_non_differentiable(cn)
-        return hs, hn, cn
+        # (c_n may be the last column of the saved cell states, strided: a training pass, which drops the final
+        # states, must not pay for a dense copy of 2^19 rows -- 1.6 ms per iteration of the recurrent bench)
+        return hs, cn
 
     @staticmethod
-    def backward(ctx, dhs, dhn, dcn):  # type: ignore[override]
+    def backward(ctx, dhs, dcn):  # type: ignore[override]
         x, h0, c0, hs, gates, cs = ctx.saved_tensors
         if dhs is None:
             dhs = torch.zeros_like(hs)
         dhs = dhs.contiguous().float()
-        if dhn is not None:  # h_n is h_{L-1}
-            dhs = dhs.clone()
-            dhs[:, -1] += dhn
         if use_split(ctx.lstm) and BACKWARD_ROWS:
-            g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, split=True, rows_packed=_packs(ctx.lstm, "rows"))
+            g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, split=True, rows_packed=_packs(ctx.lstm, "rows"),
+                                  h0_bound=ctx.h0_bound)
         else:
             g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, _packs(ctx.lstm, True), split=use_split(ctx.lstm))
         return None, None, None, g["w_ih"], g["w_hh"], g["b"], g["b"], None, None
@@ -112,10 +115,11 @@ def lstm_forward(lstm: nn.LSTM, x: torch.Tensor, h0: torch.Tensor, c0: torch.Ten
     ``h0``, ``c0`` (rollout-buffer data) nor out of ``c_n``."""
     if not _eligible(lstm, x):
         return None
-    return _FusedLSTM.apply(
+    hs, cn = _FusedLSTM.apply(
         x.contiguous(), h0.contiguous().float(), c0.contiguous().float(), lstm.weight_ih_l0, lstm.weight_hh_l0,
         lstm.bias_ih_l0, lstm.bias_hh_l0, lstm, torch.is_grad_enabled(),
     )
+    return hs, hs[:, -1], cn  # h_n is h_{L-1}: a view, so a gradient into it reaches dhs by itself
 
 
 class _FusedHeads(torch.autograd.Function):

@@ -100,6 +100,36 @@ def test_linear_heads_match_torch(m, n):
     torch.testing.assert_close(db.double(), b.grad.double(), rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("m,n_a,n_b", [(1, 1, 1), (67, 2, 1), (8192, 2, 1), (100_001, 5, 3)])
+def test_linear_heads_pair_is_the_two_single_launches(m, n_a, n_b):
+    """The rollout's logits + value heads in one pass over h: bit-identical to one launch per layer."""
+    g = torch.Generator(device=DEV).manual_seed(m + n_a)
+    h = torch.randn(m, 256, device=DEV, generator=g)
+    w_a, w_b = torch.randn(n_a, 256, device=DEV, generator=g) / 16, torch.randn(n_b, 256, device=DEV, generator=g) / 16
+    b_a, b_b = torch.randn(n_a, device=DEV, generator=g), torch.randn(n_b, device=DEV, generator=g)
+    out_a, out_b = hip.linear_heads_forward_pair(h, w_a, b_a, w_b, b_b)
+    assert torch.equal(out_a, hip.linear_heads_forward(h, w_a, b_a))
+    assert torch.equal(out_b, hip.linear_heads_forward(h, w_b, b_b))
+
+
+@pytest.mark.parametrize("b", [1, 127, 128, 1000, 40_000])
+def test_state_split_reports_max_abs_h0(b):
+    """rl8_lstm_split_state_bound: the same planes as rl8_lstm_split_state, and max |h| exactly."""
+    g = torch.Generator(device=DEV).manual_seed(b)
+    h = (torch.rand(b, 256, device=DEV, generator=g) * 2 - 1) * 3.5
+    h[b // 2, 17] = -7.25 if b > 1 else 0.5
+    lib = hip.load()
+    n = int(lib.rl8_lstm_split_state_bytes(b))
+    planes, planes_b = torch.zeros(n, dtype=torch.uint8, device=DEV), torch.zeros(n, dtype=torch.uint8, device=DEV)
+    bound = torch.full((1,), -1.0, device=DEV)
+    hip._check(lib.rl8_lstm_split_state(hip._ptr(h), 256, b, hip._ptr(planes), hip._stream()), "rl8_lstm_split_state")
+    hip._check(lib.rl8_lstm_split_state_bound(hip._ptr(h), 256, b, hip._ptr(planes_b), hip._ptr(bound), hip._stream()),
+               "rl8_lstm_split_state_bound")
+    assert torch.equal(planes, planes_b)
+    assert float(bound) == float(h.abs().max())
+    assert lib.rl8_lstm_split_state_bound(hip._ptr(h), 256, b, hip._ptr(planes_b), None, hip._stream()) != 0
+
+
 def test_fused_recurrent_model_matches_the_eager_modules():
     """The default recurrent model through the fused LSTM + heads must give the
     outputs and parameter gradients of the same modules run by PyTorch."""
