@@ -572,6 +572,12 @@ int rl8_lstm_rows_backward_pack(const float *w_hh, void *packed, void *stream);
 int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs,
                                const float *dhs, const void *packed, float *dgates, float *dc_scratch,
                                uint32_t *dg_bound_out, void *stream);
+/* The same with dL/dh_t of the output heads formed inside from heads_dout [b][l][4] (the gradient of the heads' outputs,
+ * zero-padded to four per row-step) and heads_w [4][256] (their nn.Linear weights stacked, zero rows past their number):
+ * the [b][l][256] array is neither written by rl8_linear_heads_backward_f32 (dh_out NULL) nor read here. */
+int rl8_lstm_rows_backward_heads_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs,
+                                     const float *heads_dout, const float *heads_w, const void *packed, float *dgates,
+                                     float *dc_scratch, uint32_t *dg_bound_out, void *stream);
 /* rl8_mlp_wgrad_split_strided_f32 on fp16 planes (three plane products instead of six): dz and h each scaled by one
  * power of two taken from *dz_bound / *h_bound -- device words holding a float >= max |dz| / max |h| over all rows
  * read (dg_bound_out above; 1.0f for an LSTM's outputs). */
@@ -592,7 +598,8 @@ int rl8_lstm_wgrad_f16_f32(const float *dz, int64_t dz_pitch, const uint32_t *dz
  * all of them at once: out [M][n] = h [M][256] x w^T + b, w [n][256] (the heads'
  * nn.Linear weights stacked), n <= 8.  Backward: dh_out [M][256] = dout x w and
  * `*partial_rows_out` rows (<= rl8_linear_heads_max_rows()) of [dW (n*256) | db (n)]
- * whose column sums are the parameter gradients.
+ * whose column sums are the parameter gradients; dh_out NULL: the parameter gradients only (the recurrent models'
+ * backward forms dh inside rl8_lstm_rows_backward_heads_f32).
  * rl8_linear_heads_forward_pair_f32: two layers that stay separate arrays (the rollout's logits head and value head,
  * algorithms/_recurrent.py:400-420 via policy.sample()) in one pass over h: out_a [M][n_a], out_b [M][n_b],
  * n_a + n_b <= 8. */

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(kBlock) void linear_heads_backward_kernel(const flo
       dw[q] = __builtin_fmaf(d, hv, dw[q]);
       db[q] += d;
     }
-    dh[s * kHidden + j] = g;
+    if (dh) dh[s * kHidden + j] = g;  // (null: parameter gradients only -- the caller forms dh where it is used)
   }
   float *row = partials + (int64_t)blockIdx.x * (NOUT * kHidden + NOUT);
 #pragma unroll
@@ -618,7 +618,7 @@ RL8_API int rl8_linear_heads_forward_pair_f32(const float *h, int64_t m, const f
 RL8_API int rl8_linear_heads_backward_f32(const float *h, const float *dout, int64_t m,
                                           const float *w, int n_out, float *dh_out, float *partials,
                                           int *partial_rows_out, void *stream) {
-  if (!h || !dout || !w || !dh_out || !partials || !partial_rows_out) return RL8_ENULL;
+  if (!h || !dout || !w || !partials || !partial_rows_out) return RL8_ENULL;  // (dh_out may be null)
   if (m <= 0 || n_out <= 0 || n_out > kHeadsMaxOut) return RL8_ESIZE;
   const int grid = (int)(m < kMaxGrid ? m : kMaxGrid);
   *partial_rows_out = grid;

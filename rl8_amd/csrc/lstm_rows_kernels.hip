@@ -56,28 +56,41 @@ constexpr int kLrLdsBytes = kLrRing * kLrSlotBytes + 2 * kLrStageBytes;  // 160 
 constexpr int kLrDma = 6;                    // 1-KiB direct-to-LDS loads per wave and gate-step
 // 16-byte row operations a lane issues in gate-step k of a chunk (k = 2 pos + half): loads in front of the step's
 // request, stores behind its matrix work
-constexpr int kLrLoadsAt[8] = {8, 0, 8, 0, 0, 0, 16, 0};   // B of this chunk | C of this chunk | A of the next
+// HEADS (the kernel's second form): dL/dh_t of the output heads is not read as a [b][l][256] array but formed from the
+// heads' own gradient, four floats per row-step, and their weights: phase A then brings the chunk's rows of the heads'
+// weights and the rows' four floats (one instruction each) instead of the four of dh_t.
+constexpr int lr_loads_at(int k, bool heads) {  // B of this chunk | C of this chunk | A of the next
+  return k == 0 || k == 2 ? 8 : k == 6 ? (heads ? 14 : 16) : 0;
+}
 constexpr int kLrStoresAt[8] = {0, 8, 0, 0, 0, 8, 0, 4};   // dG_i, dG_g | dG_f, dc | dG_o of the next chunk
 // operations a wave has issued behind its request for gate-step k's chunk of W_hh^T (made in step k - 3)
-constexpr int lr_behind(int k) {
-  return kLrStoresAt[(k + 5) & 7] + kLrLoadsAt[(k + 6) & 7] + kLrDma + kLrStoresAt[(k + 6) & 7] + kLrLoadsAt[(k + 7) & 7] +
-         kLrDma + kLrStoresAt[(k + 7) & 7];
+constexpr int lr_behind(int k, bool heads) {
+  return kLrStoresAt[(k + 5) & 7] + lr_loads_at((k + 6) & 7, heads) + kLrDma + kLrStoresAt[(k + 6) & 7] +
+         lr_loads_at((k + 7) & 7, heads) + kLrDma + kLrStoresAt[(k + 7) & 7];
 }
-static_assert(lr_behind(0) == 40 && lr_behind(3) == 28 && lr_behind(5) == 12 && lr_behind(7) == 36, "see the table in open_step");
+static_assert(lr_behind(0, false) == 40 && lr_behind(3, false) == 28 && lr_behind(5, false) == 12 && lr_behind(7, false) == 36,
+              "see the table in open_step");
+static_assert(lr_behind(0, true) == 38 && lr_behind(1, true) == 24 && lr_behind(6, true) == 20 && lr_behind(7, true) == 34,
+              "see the table in open_step");
 // ... and behind the parked loads of a phase, from the step that makes them to the end of the matrix work of the step that
 // reads them: B 0 -> 1, C 2 -> 5, A 6 -> 7 (vmcnt has six bits: all but the 63 youngest covers anything further back)
-constexpr int lr_behind_loads(int from, int to) {  // from the loads of step `from` to the end of step `to`'s matrix work
+constexpr int lr_behind_loads(int from, int to, bool heads) {  // from the loads of step `from` to the end of step `to`'s matrix work
   int n = kLrDma;
   for (int k = (from + 1) & 7;; k = (k + 1) & 7) {
-    n += kLrStoresAt[(k + 7) & 7] + kLrLoadsAt[k] + kLrDma;
+    n += kLrStoresAt[(k + 7) & 7] + lr_loads_at(k, heads) + kLrDma;
     if (k == to) break;
   }
   return n < 63 ? n : 63;
 }
-constexpr int kLrBehindB = lr_behind_loads(0, 1);
-constexpr int kLrBehindC = lr_behind_loads(2, 5);
-constexpr int kLrBehindA = lr_behind_loads(6, 7);
+// (none of the three spans contains gate-step 6: the same with and without HEADS)
+constexpr int kLrBehindB = lr_behind_loads(0, 1, false);
+constexpr int kLrBehindC = lr_behind_loads(2, 5, false);
+constexpr int kLrBehindA = lr_behind_loads(6, 7, false);
 static_assert(kLrBehindB == 12 && kLrBehindC == 24 && kLrBehindA == 12, "see the table in open_step");
+static_assert(kLrBehindB == lr_behind_loads(0, 1, true) && kLrBehindC == lr_behind_loads(2, 5, true) &&
+                  kLrBehindA == lr_behind_loads(6, 7, true),
+              "the spans do not contain gate-step 6");
+constexpr int kLrHeads = 4;  // outputs of the heads the HEADS form takes (their gradient padded to four floats per row-step)
 #ifndef RL8_LR_DIAG
 #define RL8_LR_DIAG 0  // tuning builds (tools/diag_mlp.sh lr<bits>): 1 no stores reach memory, 2 no row loads do, 4 one plane
 #endif                 // product of six, 8 no W_hh^T traffic (wrong results, same instruction stream)
@@ -124,7 +137,8 @@ struct LrArgs {
   const float *c0;     // [b][256]
   const float *gates;  // [b][l][4][256] post-activation i, f, g, o
   const float *cs;     // [b][l][256]
-  const float *dhs;    // [b][l][256]
+  const float *dhs;    // [b][l][256]; HEADS: [b][l][4], the gradient of the heads' outputs (zero-padded)
+  const float *heads_w;  // HEADS: [4][256], the heads' weights (rows past their number zero); else unused
   float *dgates;       // [b][l][4][256]
   float *dc;           // [b][256] scratch: the carried dL/dc between steps
   int64_t b;
@@ -137,14 +151,15 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 
 // what a lane loads for one unit chunk: its sixteen units (two runs of eight, 64 bytes apart) of its sequence
 struct LrLoadDesc {
-  __amdgpu_buffer_rsrc_t gates, cs, cprev, dhs, dcin;
+  __amdgpu_buffer_rsrc_t gates, cs, cprev, dhs, dcin;  // (HEADS: dhs = the rows' four floats)
   int cp_pitch;  // bytes between sequences in cprev (cs of t - 1: the sequence pitch; c0: 1 KiB)
 };
 struct LrStoreDesc {
   __amdgpu_buffer_rsrc_t dgates, dcout;
 };
 
-__global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a, const void *__restrict__ w_planes) {
+template <bool HEADS>
+__device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const void *__restrict__ w_planes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = lds_offset(smem);
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     LrLoadDesc d;
     d.gates = seq_rsrc(a.gates, tile, t, 4 * kHidden, rows);
     d.cs = seq_rsrc(a.cs, tile, t, kHidden, rows);
-    d.dhs = seq_rsrc(a.dhs, tile, t, kHidden, rows);
+    d.dhs = seq_rsrc(a.dhs, tile, t, HEADS ? kLrHeads : kHidden, rows);
     d.cprev = t > 0 ? seq_rsrc(a.cs, tile, t - 1, kHidden, rows) : state_rsrc(a.c0, tile, rows);
     d.cp_pitch = t > 0 ? l * (kHidden * 4) : kHidden * 4;
     d.dcin = state_rsrc(a.dc, tile, t == l - 1 ? 0 : rows);  // the last step of a sequence starts from dc = 0
@@ -238,14 +253,25 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
     if (part != 1) park4(1, 0, d.gates, pitch_gates, c * 128 + 1 * (kHidden * 4));
     if (part != 0) park4(1, 1, d.cprev, d.cp_pitch, c * 128);
   };
-  auto issue_a = [&](const LrLoadDesc &d, int c, int part = -1) {  // parts 0, 1, 2: six, six and four of the sixteen
+  const __amdgpu_buffer_rsrc_t hwrsrc = buffer_rsrc(HEADS ? a.heads_w : nullptr, HEADS ? kLrHeads * kHidden * 4 : 0);
+  auto issue_a = [&](const LrLoadDesc &d, int c, int part = -1) {  // parts 0, 1, 2: six, six (HEADS: four) and four of the sixteen
     if (part < 0 || part == 0) {
       park4(0, 0, d.gates, pitch_gates, c * 128 + 3 * (kHidden * 4));
       park4(0, 1, d.cs, pitch_seq, c * 128, 0, 2);
     }
     if (part < 0 || part == 1) {
       park4(0, 1, d.cs, pitch_seq, c * 128, 2, 4);
-      park4(1, 0, d.dhs, pitch_seq, c * 128);
+      if constexpr (HEADS) {
+        // park 1, array 0: block 0 = [head q][this chunk's 32 units] (lanes 0..31: q = lane >> 3, 16 bytes each; the rest
+        // of the instruction is out of range: zeros), block 1 = [sequence] x the four floats of its row-step
+        const int far = 0x7fffff00;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hwrsrc, smem + park_lds(1, 0, 0), 16,
+                                                 lane < 32 ? (lane >> 3) * (kHidden * 4) + (lane & 7) * 16 : far, c * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d.dhs, smem + park_lds(1, 0, 1), 16, lane < 32 ? lane * (l * kLrHeads * 4) : far,
+                                                 0, 0, 0);
+      } else {
+        park4(1, 0, d.dhs, pitch_seq, c * 128);
+      }
     }
     if (part < 0 || part == 2) park4(1, 1, d.dcin, pitch_state, c * 128);
   };
@@ -306,9 +332,33 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   auto math_a = [&](const LrStoreDesc &sd, int c) {  // -> dg[0] (o), dcv
     u32x4 la_o[4], la_ct[4], la_dh[4], la_dc[4];
     loads_landed(std::integral_constant<int, kLrBehindA>{}, 8);
+    if constexpr (HEADS) {
+      // dL/dh_t of the heads for this lane's sixteen units: sum_q dOut[n][q] W[q][unit], the weights broadcast from the
+      // park (two addresses per instruction: the lane halves), head by head
+      const unsigned pk = lds0 + kLrRing * kLrSlotBytes + kLrStageBytes + (wave * 2) * 4096;
+      u32x4 dv = lds_read_b128<1024>(pk + n * 16);
+      u32x4 wq[4];
+#pragma unroll
+      for (int q = 0; q < kLrHeads; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          wq[j] = q == 0   ? lds_read_b128<0>(pk + (8 * j + 4 * hh) * 4)
+                  : q == 1 ? lds_read_b128<128>(pk + (8 * j + 4 * hh) * 4)
+                  : q == 2 ? lds_read_b128<256>(pk + (8 * j + 4 * hh) * 4)
+                           : lds_read_b128<384>(pk + (8 * j + 4 * hh) * 4);
+        if (q == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(dv));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]));
+        const float d = __uint_as_float(dv[q]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float term = d * at(wq, e);
+          la_dh[e >> 2][e & 3] = __float_as_uint(q == 0 ? term : __uint_as_float(la_dh[e >> 2][e & 3]) + term);
+        }
+      }
+    }
     unpark(Z0{}, Z0{}, la_o);
     unpark(Z0{}, Z1{}, la_ct);
-    unpark(Z1{}, Z0{}, la_dh);
+    if constexpr (!HEADS) unpark(Z1{}, Z0{}, la_dh);
     unpark(Z1{}, Z1{}, la_dc);
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(la_o[0]), "+v"(la_o[1]), "+v"(la_o[2]), "+v"(la_o[3]), "+v"(la_ct[0]), "+v"(la_ct[1]), "+v"(la_ct[2]),
@@ -439,7 +489,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
   //   N       40  24  32  28  28  12  20  36
   auto open_step = [&](auto k_tag) {
     constexpr int K = decltype(k_tag)::value;
-    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : lr_behind(K);
+    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : lr_behind(K, HEADS);
 #ifdef RL8_LR_STAMP
     {
       RL8_LR_T0;
@@ -571,6 +621,15 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
 #endif
 }
 
+// The two forms as plain kernels around the body (as a kernel TEMPLATE the host side of this body is not emitted by
+// hipcc 7.2 -- the launches then link against nothing).
+__global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a, const void *__restrict__ w_planes) {
+  lstm_rows_backward_body<false>(a, w_planes);
+}
+__global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_heads_kernel(LrArgs a, const void *__restrict__ w_planes) {
+  lstm_rows_backward_body<true>(a, w_planes);
+}
+
 }  // namespace rl8
 
 using namespace rl8;
@@ -584,19 +643,21 @@ RL8_API int rl8_lstm_rows_backward_pack(const float *w_hh, void *packed, void *s
   return launch_status();
 }
 
-RL8_API int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs, const float *dhs,
-                                       const void *packed, float *dgates, float *dc_scratch, uint32_t *dg_bound_out,
-                                       void *stream) {
+static int rows_backward(int64_t b, int l, const float *c0, const float *gates, const float *cs, const float *dhs,
+                         const float *heads_w, const void *packed, float *dgates, float *dc_scratch, uint32_t *dg_bound_out,
+                         void *stream) {
   if (!c0 || !gates || !cs || !dhs || !packed || !dgates || !dc_scratch) return RL8_ENULL;
   if (b <= 0 || l <= 0) return RL8_ESIZE;
   // a wave addresses its 32 sequences with 32-bit offsets
   if ((int64_t)32 * l * 4 * kHidden * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
   if (!aligned16(packed) || !aligned16(c0) || !aligned16(gates) || !aligned16(cs) || !aligned16(dhs) || !aligned16(dgates) ||
-      !aligned16(dc_scratch))
+      !aligned16(dc_scratch) || !aligned16(heads_w))
     return RL8_EALIGN;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rows_backward_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLrLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rows_backward_heads_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLrLdsBytes);
     (void)hipGetLastError();
     attr_set = true;
@@ -608,7 +669,23 @@ RL8_API int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const 
   if (const char *v = getenv("RL8_LR_STAMP_PTR")) stamps = reinterpret_cast<unsigned long long *>(strtoull(v, nullptr, 0));
 #endif
   if (dg_bound_out && hipMemsetAsync(dg_bound_out, 0, 4, (hipStream_t)stream) != hipSuccess) return launch_status();
-  const LrArgs args = {c0, gates, cs, dhs, dgates, dc_scratch, b, l, stamps, dg_bound_out};
-  lstm_rows_backward_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
+  const LrArgs args = {c0, gates, cs, dhs, heads_w, dgates, dc_scratch, b, l, stamps, dg_bound_out};
+  if (heads_w) lstm_rows_backward_heads_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
+  else lstm_rows_backward_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
   return launch_status();
+}
+
+RL8_API int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs, const float *dhs,
+                                       const void *packed, float *dgates, float *dc_scratch, uint32_t *dg_bound_out,
+                                       void *stream) {
+  return rows_backward(b, l, c0, gates, cs, dhs, nullptr, packed, dgates, dc_scratch, dg_bound_out, stream);
+}
+
+// The same with dL/dh_t = heads_dout[b][l][0..3] x heads_w [4][256] formed inside (both zero-padded to four heads): the
+// output heads' data gradient is never written to memory nor read back.
+RL8_API int rl8_lstm_rows_backward_heads_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs,
+                                             const float *heads_dout, const float *heads_w, const void *packed, float *dgates,
+                                             float *dc_scratch, uint32_t *dg_bound_out, void *stream) {
+  if (!heads_w) return RL8_ENULL;
+  return rows_backward(b, l, c0, gates, cs, heads_dout, heads_w, packed, dgates, dc_scratch, dg_bound_out, stream);
 }

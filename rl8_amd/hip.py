@@ -135,6 +135,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_rows_backward_pack_bytes": [],
     "rl8_lstm_rows_backward_pack": [_vp, _vp, _vp],
     "rl8_lstm_rows_backward_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rl8_lstm_rows_backward_heads_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rl8_mlp_wgrad_f16_strided_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
     "rl8_lstm_wgrad_f16_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
     "rl8_lstm_backward_partial_floats": [_i32],
@@ -1299,22 +1300,46 @@ def lstm_rows_backward_pack(w_hh: torch.Tensor) -> torch.Tensor:
     return packed
 
 
-def lstm_rows_backward(c0: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor, dhs: torch.Tensor,
-                       packed: torch.Tensor, *, with_bound: bool = False):
+ROWS_BACKWARD_HEADS = 4  # head outputs rl8_lstm_rows_backward_heads_f32 takes
+
+
+def lstm_rows_backward(c0: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor, dhs: None | torch.Tensor,
+                       packed: torch.Tensor, *, with_bound: bool = False,
+                       heads: None | tuple[torch.Tensor, torch.Tensor] = None):
     """dgates [B, L, 4, 256] from what the forward saved and dhs [B, L, 256]: the
     backward through time with the recurrent product on bf16 planes. ``with_bound``:
     also a one-element device tensor holding max |dgates| (what the fp16-plane weight
-    gradient scales its first operand by)."""
-    b, l = dhs.shape[0], dhs.shape[1]
-    for name, t, shape in (("c0", c0, (b, LSTM_HIDDEN)), ("gates", gates, (b, l, 4, LSTM_HIDDEN)),
-                           ("cs", cs, (b, l, LSTM_HIDDEN)), ("dhs", dhs, (b, l, LSTM_HIDDEN))):
+    gradient scales its first operand by). ``heads`` = (dout [B * L, n], w [n, 256]),
+    n <= 4, instead of ``dhs`` (None): dL/dh_t = dout x w is formed inside the kernel."""
+    b, l = gates.shape[0], gates.shape[1]
+    checks = [("c0", c0, (b, LSTM_HIDDEN)), ("gates", gates, (b, l, 4, LSTM_HIDDEN)), ("cs", cs, (b, l, LSTM_HIDDEN))]
+    if heads is None:
+        checks.append(("dhs", dhs, (b, l, LSTM_HIDDEN)))
+    elif dhs is not None:
+        raise ValueError("lstm_rows_backward: either dhs or heads")
+    for name, t, shape in checks:
         _dense(t, torch.float32, name)
         if tuple(t.shape) != shape:
             raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
-    dev = dhs.device
+    dev = gates.device
     dgates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev)
     dc = torch.empty(b, LSTM_HIDDEN, dtype=torch.float32, device=dev)
     bound = torch.empty(1, dtype=torch.float32, device=dev) if with_bound else None
+    if heads is not None:
+        dout, w = heads
+        n = w.shape[0]
+        if n > ROWS_BACKWARD_HEADS or tuple(w.shape) != (n, LSTM_HIDDEN) or dout.numel() != b * l * n:
+            raise ValueError(f"heads: dout [B * L, n], w [n, 256], n <= {ROWS_BACKWARD_HEADS}")
+        # four floats per row-step, four weight rows: one 16-byte piece per sequence and head-row segment
+        dout4 = torch.zeros(b * l, ROWS_BACKWARD_HEADS, dtype=torch.float32, device=dev)
+        dout4[:, :n] = dout.reshape(b * l, n)
+        w4 = torch.zeros(ROWS_BACKWARD_HEADS, LSTM_HIDDEN, dtype=torch.float32, device=dev)
+        w4[:n] = w.detach()
+        with _timed("lstm_rows_backward", b * l):
+            _check(load().rl8_lstm_rows_backward_heads_f32(b, l, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dout4), _ptr(w4),
+                                                           _ptr(packed), _ptr(dgates), _ptr(dc), _ptr(bound), _stream()),
+                   "rl8_lstm_rows_backward_heads_f32")
+        return (dgates, bound) if with_bound else dgates
     with _timed("lstm_rows_backward", b * l):
         _check(load().rl8_lstm_rows_backward_f32(b, l, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dhs), _ptr(packed),
                                                  _ptr(dgates), _ptr(dc), _ptr(bound), _stream()), "rl8_lstm_rows_backward_f32")
@@ -1327,8 +1352,9 @@ _lstm_colsum_ws: dict[tuple, torch.Tensor] = {}
 
 def lstm_backward(
     x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, hs: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor,
-    dhs: torch.Tensor, whht_packed: None | torch.Tensor, *, split: None | bool = None,
+    dhs: None | torch.Tensor, whht_packed: None | torch.Tensor, *, split: None | bool = None,
     rows_packed: None | torch.Tensor = None, h0_bound: None | torch.Tensor = None,
+    heads: None | tuple[torch.Tensor, torch.Tensor] = None,
 ) -> dict[str, torch.Tensor]:
     """Parameter gradients of the LSTM given ``dhs`` [B, L, 256] (gradient of every
     ``h_t``) and what ``lstm_forward(..., save=True)`` returned. Returns ``w_ih``,
@@ -1340,12 +1366,15 @@ def lstm_backward(
     on bf16 planes too (``rl8_lstm_rows_backward_f32``) instead of the fp32-MFMA kernel
     that reads ``whht_packed``; only with ``split`` (its dW_ih / bias sums come from the
     weight-gradient kernel). ``h0_bound``: one float32 element >= max |h0| when the caller
-    has it (:func:`lstm_forward_split`'s ``h0_bound_out``); computed here otherwise."""
+    has it (:func:`lstm_forward_split`'s ``h0_bound_out``); computed here otherwise.
+    ``heads`` (with ``rows_packed``, ``dhs`` None): see :func:`lstm_rows_backward`."""
     x = _dense(x.detach(), torch.float32, "x")
     b, l, d_in = x.shape
+    if heads is not None and (rows_packed is None or dhs is not None):
+        raise ValueError("lstm_backward: heads needs rows_packed and no dhs")
     for name, t, shape in (("h0", h0, (b, LSTM_HIDDEN)), ("c0", c0, (b, LSTM_HIDDEN)), ("hs", hs, (b, l, LSTM_HIDDEN)),
                            ("gates", gates, (b, l, 4, LSTM_HIDDEN)), ("cs", cs, (b, l, LSTM_HIDDEN)),
-                           ("dhs", dhs, (b, l, LSTM_HIDDEN))):
+                           *([("dhs", dhs, (b, l, LSTM_HIDDEN))] if heads is None else [])):
         _dense(t, torch.float32, name)
         if tuple(t.shape) != shape:
             raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
@@ -1364,7 +1393,7 @@ def lstm_backward(
     if rows_packed is not None:
         if not fused_colsums:
             raise ValueError("rows_packed needs the bf16-plane weight gradient (split) and a compiled input width")
-        dgates, dg_bound = lstm_rows_backward(c0, gates, cs, dhs, rows_packed, with_bound=True)
+        dgates, dg_bound = lstm_rows_backward(c0, gates, cs, dhs, rows_packed, with_bound=True, heads=heads)
     else:
         dgates = torch.empty(b, l, 4, H, dtype=torch.float32, device=dev)
         if not fused_colsums:
@@ -1482,8 +1511,9 @@ def linear_heads_forward(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> t
     return out
 
 
-def linear_heads_backward(h: torch.Tensor, dout: torch.Tensor, w: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """-> (dh [M, 256], dw [n, 256], db [n])."""
+def linear_heads_backward(h: torch.Tensor, dout: torch.Tensor, w: torch.Tensor, *,
+                          need_dh: bool = True) -> tuple[None | torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (dh [M, 256], dw [n, 256], db [n]); ``need_dh=False``: dh is None and never written."""
     h = _dense(h.detach(), torch.float32, "h")
     dout = _dense(dout, torch.float32, "dout")
     w = _dense(w.detach(), torch.float32, "w")
@@ -1491,7 +1521,7 @@ def linear_heads_backward(h: torch.Tensor, dout: torch.Tensor, w: torch.Tensor) 
     if tuple(dout.shape) != (m, n):
         raise ValueError("linear_heads_backward: dout must be [M, n]")
     lib = load()
-    dh = torch.empty(m, LSTM_HIDDEN, dtype=torch.float32, device=h.device)
+    dh = torch.empty(m, LSTM_HIDDEN, dtype=torch.float32, device=h.device) if need_dh else None
     partials = torch.empty(int(lib.rl8_linear_heads_max_rows()), n * LSTM_HIDDEN + n, dtype=torch.float32, device=h.device)
     rows = C.c_int(0)
     with _timed("linear_heads_backward", m):

@@ -124,6 +124,30 @@ def _run_lstm(lstm: nn.LSTM, obs: torch.Tensor, states: TensorDict) -> tuple[tor
     return latents, new_states, obs.size(0)
 
 
+def _run_lstm_heads(lstm: nn.LSTM, heads: list[nn.Linear], obs: torch.Tensor,
+                    states: TensorDict) -> tuple[list[torch.Tensor], TensorDict]:
+    """``[head(lstm(obs)) for head in heads]`` and the new states: a training pass as ONE fused autograd node where
+    that applies (``fused_lstm.lstm_heads_forward``), else the LSTM (fused or the module) and then the heads."""
+    from .nn import fused_lstm
+
+    if lstm.num_layers == 1 and torch.is_grad_enabled():
+        h_first = states[DataKeys.HIDDEN_STATES][:, 0, 0]
+        c_first = states[DataKeys.CELL_STATES][:, 0, 0]
+        fused = fused_lstm.lstm_heads_forward(lstm, heads, obs, h_first, c_first)
+        if fused is not None:
+            outs, _, h_last, c_last = fused
+            new_states = TensorDict(
+                {DataKeys.HIDDEN_STATES: h_last.unsqueeze(1), DataKeys.CELL_STATES: c_last.unsqueeze(1)},
+                batch_size=obs.size(0),
+            )
+            return outs, new_states
+    latents, new_states, _ = _run_lstm(lstm, obs, states)
+    outs = fused_lstm.heads_forward(heads, latents)
+    if outs is None:
+        outs = [head(latents) for head in heads]
+    return outs, new_states
+
+
 class DefaultContinuousRecurrentModel(RecurrentModel):
     """LSTM + ``mean`` / ``log_std`` heads + a value head."""
 
@@ -147,12 +171,7 @@ class DefaultContinuousRecurrentModel(RecurrentModel):
 
     def forward(self, batch: TensorDict, states: TensorDict, /) -> tuple[TensorDict, TensorDict]:
         obs = batch[DataKeys.OBS]
-        latents, new_states, _ = _run_lstm(self.lstm, obs, states)
-        from .nn import fused_lstm
-
-        outs = fused_lstm.heads_forward([self.action_mean, self.action_log_std, self.vf_model], latents)
-        if outs is None:
-            outs = [self.action_mean(latents), self.action_log_std(latents), self.vf_model(latents)]
+        outs, new_states = _run_lstm_heads(self.lstm, [self.action_mean, self.action_log_std, self.vf_model], obs, states)
         action_mean = outs[0].reshape(-1, self.action_spec.shape[0])
         action_log_std = outs[1].reshape(-1, self.action_spec.shape[0])
         self._value = outs[2].reshape(-1, 1)
@@ -196,12 +215,7 @@ class DefaultDiscreteRecurrentModel(RecurrentModel):
 
     def forward(self, batch: TensorDict, states: TensorDict, /) -> tuple[TensorDict, TensorDict]:
         obs = batch[DataKeys.OBS]
-        latents, new_states, _ = _run_lstm(self.lstm, obs, states)
-        from .nn import fused_lstm
-
-        outs = fused_lstm.heads_forward([self.feature_head, self.vf_head], latents)
-        if outs is None:
-            outs = [self.feature_head(latents), self.vf_head(latents)]
+        outs, new_states = _run_lstm_heads(self.lstm, [self.feature_head, self.vf_head], obs, states)
         logits = outs[0].reshape(-1, self.action_spec.shape[0], self.action_spec.space.n)
         self._value = outs[1].reshape(-1, 1)
         return TensorDict({"logits": logits}, batch_size=logits.size(0), device=obs.device), new_states

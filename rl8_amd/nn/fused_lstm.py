@@ -29,6 +29,9 @@ ENABLED = True
 FORWARD_GEMM = os.environ.get("RL8_AMD_LSTM_GEMM", "split")
 #: The backward through time on bf16 planes, a wave per 32 sequences (lstm_rows_kernels.hip); 0: the fp32-MFMA kernel.
 BACKWARD_ROWS = os.environ.get("RL8_AMD_LSTM_BACKWARD_ROWS", "1") != "0"
+#: Training passes through LSTM + heads as one autograd node whose backward forms the heads' data gradient inside the
+#: backward-through-time kernel (lstm_heads_forward); 0: two nodes, dL/dh through HBM.
+FUSE_HEADS = os.environ.get("RL8_AMD_LSTM_FUSE_HEADS", "1") != "0"
 
 
 def _eligible(lstm: nn.LSTM, x: torch.Tensor) -> bool:
@@ -134,6 +137,68 @@ class _FusedHeads(torch.autograd.Function):
         h, w = ctx.saved_tensors
         dh, dw, db = hip.linear_heads_backward(h, dout.contiguous().float(), w)
         return dh, dw, db
+
+
+class _FusedLSTMHeads(torch.autograd.Function):
+    """LSTM + output heads of a training pass as one node: the heads' data gradient dL/dh_t = dOut x W (a rank-n
+    product, n <= 4) is formed inside the backward-through-time kernel from the 16 bytes per row-step it is made
+    of, instead of being written as [B, L, 256] by the heads' backward and read back (4 KiB of traffic per
+    row-step of the recurrent bench less)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, w_heads, b_heads, lstm):  # type: ignore[override]
+        packed, wb = _packs(lstm, "split")
+        bound = torch.empty(1, dtype=torch.float32, device=x.device)
+        hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=True, h0_bound_out=bound)
+        out = hip.linear_heads_forward(hs.view(-1, hip.LSTM_HIDDEN), w_heads, b_heads)
+        ctx.set_materialize_grads(False)
+        ctx.lstm, ctx.h0_bound = lstm, bound
+        ctx.save_for_backward(x, h0, c0, hs, gates, cs, w_heads)
+        ctx.mark_non_differentiable(cn)
+        return out, hs, cn
+
+    @staticmethod
+    def backward(ctx, dout, dhs, dcn):  # type: ignore[override]
+        x, h0, c0, hs, gates, cs, w_heads = ctx.saved_tensors
+        flat = hs.view(-1, hip.LSTM_HIDDEN)
+        if dout is None:
+            dout = torch.zeros(flat.shape[0], w_heads.shape[0], dtype=torch.float32, device=flat.device)
+        dout = dout.contiguous().float()
+        common = dict(split=True, rows_packed=_packs(ctx.lstm, "rows"), h0_bound=ctx.h0_bound)
+        if dhs is None:  # nothing but the heads reads the latents: the usual case
+            _, dw, db = hip.linear_heads_backward(flat, dout, w_heads, need_dh=False)
+            g = hip.lstm_backward(x, h0, c0, hs, gates, cs, None, None, heads=(dout, w_heads), **common)
+        else:
+            dh, dw, db = hip.linear_heads_backward(flat, dout, w_heads)
+            g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dh.view_as(hs) + dhs.float(), None, **common)
+        return None, None, None, g["w_ih"], g["w_hh"], g["b"], g["b"], dw, db, None
+
+
+def _heads_eligible(heads: list[nn.Linear], max_out: int) -> bool:
+    if any(h.in_features != hip.LSTM_HIDDEN or h.bias is None or h.weight.dtype != torch.float32 for h in heads):
+        return False
+    return sum(h.out_features for h in heads) <= max_out
+
+
+def lstm_heads_forward(lstm: nn.LSTM, heads: list[nn.Linear], x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor):
+    """A training pass through ``lstm`` and ``Linear(256, n_i)`` heads on its outputs as one autograd node
+    (:class:`_FusedLSTMHeads`): ``([head_i(hs) as [B * L, n_i]], hs [B, L, 256], h_n, c_n)``, or ``None`` when this
+    combination is not eligible (no gradient wanted, more than four head outputs, an LSTM the fp16-plane forward or
+    the plane-product backward does not take): the caller then runs :func:`lstm_forward` and :func:`heads_forward`."""
+    if not (FUSE_HEADS and torch.is_grad_enabled() and _eligible(lstm, x) and use_split(lstm) and BACKWARD_ROWS):
+        return None
+    if not _heads_eligible(heads, hip.ROWS_BACKWARD_HEADS):
+        return None
+    if not any(p.requires_grad for p in lstm.parameters()):
+        return None
+    widths = [h.out_features for h in heads]
+    w = torch.cat([h.weight for h in heads], 0) if len(heads) > 1 else heads[0].weight
+    b = torch.cat([h.bias for h in heads], 0) if len(heads) > 1 else heads[0].bias
+    out, hs, cn = _FusedLSTMHeads.apply(
+        x.contiguous(), h0.contiguous().float(), c0.contiguous().float(), lstm.weight_ih_l0, lstm.weight_hh_l0,
+        lstm.bias_ih_l0, lstm.bias_hh_l0, w, b, lstm,
+    )
+    return list(out.split(widths, dim=1)), hs, hs[:, -1], cn
 
 
 def heads_forward(heads: list[nn.Linear], latents: torch.Tensor) -> None | list[torch.Tensor]:

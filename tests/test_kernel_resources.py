@@ -319,22 +319,30 @@ def test_compiled_lstm_rows_backward_kernel_resources(tmp_path):
     )
     text = asm.read_text()
     assert not re.search(r"\bv_pk_(fma|add|mul)_f32\b", text)
-    body = re.search(r"\.amdhsa_kernel (\S*lstm_rows_backward_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S).group(2)
-    assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0
-    assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 512
-    code = next(b for n, b in inflight.kernels_of(text) if "lstm_rows_backward_kernel" in n)
-    assert "v_mfma_f32_32x32x16_bf16" in code and "scratch_" not in code
-    # the chunk loop: the eight counted barriers in order, and what the wave issues between them
-    ops = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)\n\ts_barrier|(buffer_load_dwordx4[^\n]* lds)|(buffer_load_dwordx4)|(buffer_store_dwordx4)", code)
-    seq = ["B" + w if w else "D" if d else "L" if ld else "S" for w, d, ld, st in ops]
-    bars = [i for i, x in enumerate(seq) if x.startswith("B")]
-    want = ["B40", "B24", "B32", "B28", "B28", "B12", "B20", "B36"]
-    first = next(j for j in range(len(bars) - 7) if [seq[i] for i in bars[j:j + 8]] == want)
-    ends = bars[first + 1:first + 9] if first + 8 < len(bars) else bars[first + 1:first + 8] + [len(seq)]
-    groups = [seq[lo + 1:hi] for lo, hi in zip(bars[first:first + 8], ends)]
-    counts = [(g.count("L"), g.count("D"), g.count("S")) for g in groups]
-    # [row loads, direct-to-LDS loads (parked row loads + 6 of W_hh^T), stores] per gate-step; the four stores of the next
-    # chunk's dG_o follow step 7 on the loop's back edge
-    # (every row load is parked: direct-to-LDS, eight per two-array phase, sixteen for phase A)
-    assert counts[:7] == [(0, 14, 0), (0, 6, 8), (0, 14, 0), (0, 6, 0), (0, 6, 0), (0, 6, 8), (0, 22, 0)], counts
-    assert counts[7][:2] == (0, 6), counts
+    # both forms: dL/dh_t read as an array, or formed from the heads' gradient and weights (_heads_kernel: phase A of
+    # gate-step 6 is fourteen direct-to-LDS loads instead of sixteen, and the barriers that look back over it count two less)
+    forms = {
+        "lstm_rows_backward_kernel": (["B40", "B24", "B32", "B28", "B28", "B12", "B20", "B36"], 22),
+        "lstm_rows_backward_heads_kernel": (["B38", "B24", "B32", "B28", "B28", "B12", "B20", "B34"], 20),
+    }
+    bodies = dict(re.findall(r"\.amdhsa_kernel (\S*lstm_rows_backward\w*_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S))
+    assert len(bodies) == 2
+    for form, (want, step6) in forms.items():
+        body = next(b for n, b in bodies.items() if form in n)
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 512
+        code = next(b for n, b in inflight.kernels_of(text) if form in n)
+        assert "v_mfma_f32_32x32x16_bf16" in code and "scratch_" not in code
+        # the chunk loop: the eight counted barriers in order, and what the wave issues between them
+        ops = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)\n\ts_barrier|(buffer_load_dwordx4[^\n]* lds)|(buffer_load_dwordx4)|(buffer_store_dwordx4)", code)
+        seq = ["B" + w if w else "D" if d else "L" if ld else "S" for w, d, ld, st in ops]
+        bars = [i for i, x in enumerate(seq) if x.startswith("B")]
+        first = next(j for j in range(len(bars) - 7) if [seq[i] for i in bars[j:j + 8]] == want)
+        ends = bars[first + 1:first + 9] if first + 8 < len(bars) else bars[first + 1:first + 8] + [len(seq)]
+        groups = [seq[lo + 1:hi] for lo, hi in zip(bars[first:first + 8], ends)]
+        counts = [(g.count("L"), g.count("D"), g.count("S")) for g in groups]
+        # [row loads, direct-to-LDS loads (parked row loads + 6 of W_hh^T), stores] per gate-step; the four stores of the
+        # next chunk's dG_o follow step 7 on the loop's back edge
+        # (every row load is parked: direct-to-LDS, eight per two-array phase, sixteen / fourteen for phase A)
+        assert counts[:7] == [(0, 14, 0), (0, 6, 8), (0, 14, 0), (0, 6, 0), (0, 6, 0), (0, 6, 8), (0, step6, 0)], (form, counts)
+        assert counts[7][:2] == (0, 6), (form, counts)

@@ -280,6 +280,76 @@ def test_lstm_rows_backward_matches_fp64(b, l):
     assert float(((got.double() - want).abs() / scale).max()) < 2e-6
 
 
+@pytest.mark.parametrize("b,l,n", [(1, 1, 1), (31, 4, 3), (100, 7, 2), (128, 4, 4), (129, 3, 3), (4101, 2, 1), (33000, 4, 3)])
+def test_lstm_rows_backward_with_the_heads_gradient_formed_inside(b, l, n):
+    """rl8_lstm_rows_backward_heads_f32: dL/dh_t = dOut x W of the output heads formed in the kernel from four floats per
+    row-step, against the fp64 recurrences fed with that product -- the bound of the array form -- and against the array
+    form itself; the bound on |dG| it leaves is the maximum of what it wrote; repeated launches agree bit for bit."""
+    c0, gates, cs, _, w_hh = _rows_backward_inputs(b, l, 77 * b + l + n)
+    g = torch.Generator(device=DEV).manual_seed(b + n)
+    dout = (torch.rand(b * l, n, device=DEV, generator=g) * 2 - 1) * torch.exp(-12 * torch.rand(b, 1, device=DEV, generator=g)).repeat_interleave(l, 0) * 1e-3
+    w = (torch.rand(n, 256, device=DEV, generator=g) * 2 - 1) / 16
+    packed = hip.lstm_rows_backward_pack(w_hh)
+    got, bound = hip.lstm_rows_backward(c0, gates, cs, None, packed, with_bound=True, heads=(dout, w))
+    dhs64 = (dout.double() @ w.double()).view(b, l, 256)
+    want = _backward_through_time_fp64(c0, gates, cs, dhs64, w_hh)
+    assert bool(torch.isfinite(got).all())
+    scale = want.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-300)
+    assert float(((got.double() - want).abs() / scale).max()) < 2e-6
+    array_form = hip.lstm_rows_backward(c0, gates, cs, dhs64.float(), packed)
+    assert float(((got.double() - array_form.double()).abs() / scale).max()) < 1e-6
+    assert float(bound) == float(got.abs().max())
+    assert torch.equal(got, hip.lstm_rows_backward(c0, gates, cs, None, packed, heads=(dout, w)))
+    with pytest.raises(ValueError, match="either dhs or heads"):
+        hip.lstm_rows_backward(c0, gates, cs, array_form[:, :, 0], packed, heads=(dout, w))
+
+
+def test_recurrent_model_with_and_without_the_fused_heads_node():
+    """A training pass of the default recurrent models as one LSTM + heads node (fused_lstm.lstm_heads_forward) and as
+    the two nodes it replaces: same outputs bit for bit (the same forward kernels), parameter gradients to 2e-6 of each
+    tensor's largest entry -- for the discrete model (3 head outputs) and the continuous one (3), and with a consumer of
+    the final hidden state beside the heads (the node then falls back to the array form inside)."""
+    from rl8_amd.data import DataKeys
+    from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv
+    from rl8_amd.models_recurrent import DefaultContinuousRecurrentModel, DefaultDiscreteRecurrentModel
+    from rl8_amd.nn import fused_lstm
+    from rl8_amd.tensordict import TensorDict
+
+    b, l = 517, 4
+    g = torch.Generator(device=DEV).manual_seed(3)
+    obs = torch.randn(b, l, 1, device=DEV, generator=g) * 10
+    states = TensorDict(
+        {DataKeys.HIDDEN_STATES: torch.randn(b, l, 1, 256, device=DEV, generator=g) * 0.3,
+         DataKeys.CELL_STATES: torch.randn(b, l, 1, 256, device=DEV, generator=g)}, batch_size=[b, l])
+    for env_cls, model_cls in ((DiscreteDummyEnv, DefaultDiscreteRecurrentModel), (ContinuousDummyEnv, DefaultContinuousRecurrentModel)):
+        env = env_cls(4, 8, device=DEV)
+        torch.manual_seed(5)
+        model = model_cls(env.observation_spec, env.action_spec).to(DEV)
+        w_value = torch.randn(b * l, 1, device=DEV, generator=g) / (b * l)
+        w_state = torch.randn(b, 1, 256, device=DEV, generator=g) / b
+        for use_state in (False, True):
+            def run(fuse):
+                fused_lstm.FUSE_HEADS = fuse
+                try:
+                    model.zero_grad()
+                    feats, new_states = model(TensorDict({DataKeys.OBS: obs}, batch_size=[b, l]), states)
+                    loss = sum((v * (i + 1)).sum() for i, v in enumerate(feats.values())) / (b * l) + (model.value_function() * w_value).sum()
+                    if use_state:
+                        loss = loss + (new_states[DataKeys.HIDDEN_STATES] * w_state).sum()
+                    loss.backward()
+                    return ([v.detach().clone() for v in feats.values()] + [model.value_function().detach().clone()],
+                            {k: p.grad.clone() for k, p in model.named_parameters()})
+                finally:
+                    fused_lstm.FUSE_HEADS = True
+
+            one, two = run(True), run(False)
+            for a, e in zip(one[0], two[0]):
+                assert torch.equal(a, e)
+            for k in two[1]:
+                scale = float(two[1][k].abs().max()) + 1e-30
+                assert float((one[1][k] - two[1][k]).abs().max()) / scale < 2e-6, (model_cls.__name__, use_state, k)
+
+
 @pytest.mark.parametrize("b,l,d_in", [(33, 3, 1), (300, 5, 5), (2000, 8, 1), (4097, 2, 3)])
 def test_lstm_backward_on_planes_matches_autograd(b, l, d_in):
     """hip.lstm_backward with the rows kernel (what fused_lstm runs by default) against torch's autograd, as
