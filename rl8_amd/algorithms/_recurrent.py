@@ -261,6 +261,7 @@ class RecurrentAlgorithm(Algorithm):
         H, N = hp.horizon, self.local_num_envs
         tm, stm = self._tm, self._tm_states
         rdr = tm.get(DataKeys.REVERSED_DISCOUNTED_RETURNS)
+        self._flat_full = None  # (a sequence-major copy of the buffer this collect() overwrites)
         with profile_ms() as collect_timer:
             env_was_reset = False
             carry = (self.state.horizons and hp.horizons_per_env_reset < 0) or (
@@ -376,9 +377,17 @@ class RecurrentAlgorithm(Algorithm):
         H, L = hp.horizon, hp.seq_len
         local_seqs = self.local_num_envs * (H // L)
         local_mb = hp.sgd_minibatch_size // self.shards.world_size
-        perm = self._permutation(sgd_iter, local_seqs)
-        steps = torch.arange(L, device=perm.device)
         state_keys = list(self._tm_states)
+        whole = local_mb >= local_seqs and self.injected_permutations is None
+        if whole and getattr(self, "_flat_full", None) is not None:
+            yield self._flat_full
+            return
+        # One minibatch that is the whole buffer: its mean does not depend on the order of the sequences (the
+        # feed-forward algorithm's full-buffer rule), so they are laid sequence-major ONCE per step() in buffer order
+        # and every SGD iteration reads that copy -- no permutation, one gather instead of num_sgd_iters.
+        perm = (torch.arange(local_seqs, device=self._tm[DataKeys.LOGP].device) if whole
+                else self._permutation(sgd_iter, local_seqs))
+        steps = torch.arange(L, device=perm.device)
         for seq_index in torch.split(perm, local_mb):
             # reference sequence id q = env * (H/L) + s  ->  sample ids q*L + j
             sample_ids = (seq_index[:, None] * L + steps[None, :]).reshape(-1).contiguous()
@@ -390,6 +399,8 @@ class RecurrentAlgorithm(Algorithm):
             )
             batch["_states"] = dict(zip(state_keys, states))
             batch["_num_seqs"] = seq_index.numel()
+            if whole:
+                self._flat_full = batch  # (dropped at the end of step(), with the buffer it was read from)
             yield batch
 
     def _minibatch_forward_backward(

@@ -631,3 +631,38 @@ def test_first_sgd_iteration_of_a_two_action_policy_stores_no_h2():
     assert stored == [False] * 4, stored              # 2 iterations x (policy, value) towers: never h2
     assert "mlp_tower_backward_gate" in launched and "mlp_wgrad_gate" in launched
     assert "mlp_tower_backward" not in launched and "mlp_wgrad" not in launched
+
+
+def test_recurrent_full_buffer_minibatch_is_gathered_once_in_buffer_order():
+    """One minibatch = the whole buffer: the recurrent step() lays the sequences out once, in buffer order, and reads
+    that copy in every SGD iteration -- bit for bit what injecting the identity permutation (a gather per iteration)
+    gives; with several minibatches a fresh permutation is drawn per iteration as before."""
+    from rl8_amd import RecurrentAlgorithmConfig
+
+    def run(inject, **kw):
+        torch.manual_seed(11)
+        algo = RecurrentAlgorithmConfig(num_envs=96, horizon=32, **kw).build(DiscreteDummyEnv)
+        out = []
+        for _ in range(2):
+            collect = algo.collect()
+            if inject:
+                seqs = 96 * (32 // algo.hparams.seq_len)
+                algo.injected_permutations = [torch.arange(seqs) for _ in range(algo.hparams.num_sgd_iters)]
+            out.append((collect, algo.step()))
+            assert algo._flat_full is None
+        return out, torch.cat([p.detach().flatten() for p in algo.policy.model.parameters()])
+
+    once, once_params = run(False)
+    every, every_params = run(True)
+    for (c0, s0), (c1, s1) in zip(once, every):
+        assert c0["returns/mean"] == c1["returns/mean"]
+        for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+            assert s0[k] == s1[k], k
+    assert torch.equal(once_params, every_params)
+    # several minibatches: shuffled (two runs with different generator states differ)
+    torch.manual_seed(11)
+    algo = RecurrentAlgorithmConfig(num_envs=96, horizon=32, sgd_minibatch_size=192).build(DiscreteDummyEnv)
+    algo.collect()
+    first = [b[DataKeys.OBS].clone() for b in algo._iter_minibatches(0)]
+    second = [b[DataKeys.OBS].clone() for b in algo._iter_minibatches(1)]
+    assert len(first) == 4 and not all(torch.equal(a, b) for a, b in zip(first, second))
