@@ -334,6 +334,9 @@ class Algorithm:
                 device = storage.device
         self.buffer = TensorDict(views, batch_size=[num_envs, horizon + 1], device=device)
 
+    def _release_step_caches(self) -> None:
+        """What a subclass kept for the SGD iterations of the step() that is ending."""
+
     def _reset_buffer(self) -> None:
         """``buffer_spec.zero(...)`` then ``obs[:, -1] = final_obs`` (and the final
         recurrent states) of the reference (:603-609), in place: storage is
@@ -661,6 +664,7 @@ class Algorithm:
             self._flat_full = None
             self._views_all = None
             self._packed = None
+            self._release_step_caches()
             step_stats = stat_tracker.items()
         step_stats["profiling/step_ms"] = step_timer()
         return step_stats  # type: ignore[return-value]

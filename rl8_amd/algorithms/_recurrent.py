@@ -369,6 +369,11 @@ class RecurrentAlgorithm(Algorithm):
         return collect_stats
 
     # -- step ---------------------------------------------------------------------
+    def _release_step_caches(self) -> None:
+        from ..nn import fused_lstm
+
+        fused_lstm.clear_state_cache()  # the planes of the initial hidden states, shared by the SGD iterations
+
     def _iter_minibatches(self, sgd_iter: int):
         """Minibatches of SEQUENCES: per-sample leaves as ``[B*L, ...]`` in
         (sequence, step) order, observations as ``[B, L, ...]``, and each

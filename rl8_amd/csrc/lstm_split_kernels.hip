@@ -187,7 +187,11 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int ub = blockIdx.x & (kLsBlocks - 1);
+  // Work item = (tile, unit block); the four unit blocks of a tile read the same h planes (1 KiB per row), so they sit
+  // on ONE XCD -- workgroup b runs on XCD b & 7 -- and next to each other in time: workgroups b, b + 8, b + 16, b + 24.
+  // (With tile = b / 4 the four were on four XCDs, each L2 fetched the planes itself: 2.6x the algorithmic reads.)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ub = slot & (kLsBlocks - 1);
   const unsigned a_read = lds0 + hh * kSplitKhStride + (64 * wr + l32) * 16;
   const unsigned b_read = lds0 + kLsABytes + (4 * wc * 2) * 1024 + lane * 16;
   const __amdgpu_buffer_rsrc_t wrsrc =
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
 
-  int64_t tile = blockIdx.x / kLsBlocks;
+  int64_t tile = (slot >> 2) * 8 + xcd;  // (gridDim.x is a multiple of 32: gridDim.x / 4 tiles in flight)
   if (tile < tiles) {
     request(a_rsrc(tile), 0, 0);
     step_barrier();
@@ -501,7 +505,7 @@ RL8_API int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, c
   if (!aligned16(h_planes) || !aligned16(w_planes)) return RL8_EALIGN;
   const int64_t tiles = (b + kSplitRows - 1) / kSplitRows;
   const int64_t items = tiles * kLsBlocks;
-  const int grid = (int)(items < 2 * kCUs ? items : 2 * kCUs);  // both multiples of 4
+  const int grid = (int)(items < 2 * kCUs ? (items + 31) / 32 * 32 : 2 * kCUs);  // a multiple of 32: see the kernel's tile mapping
   if (planes_out && (!aligned16(planes_out) || planes_out == h_planes)) return RL8_EALIGN;
   const LstmStepArgs args = {x, c_prev, h_out, c_out, gates, planes_out, x_pitch, c_prev_pitch, h_out_pitch, c_out_pitch,
                              gates_pitch};

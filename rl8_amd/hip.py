@@ -1235,13 +1235,36 @@ def lstm_state_planes(rows: int, device: torch.device | str, copies: int = 1) ->
     return torch.empty(copies * int(load().rl8_lstm_split_state_bytes(int(rows))), dtype=torch.uint8, device=device)
 
 
+def lstm_split_state(h: torch.Tensor, *, out: None | torch.Tensor = None,
+                     bound_out: None | torch.Tensor = None) -> torch.Tensor:
+    """``h`` [B, 256] -> its fp16 planes in the step kernel's operand order (``out`` or a fresh buffer);
+    ``bound_out`` (one float32 element) receives max |h|."""
+    h = _dense(h, torch.float32, "h")
+    b, dev, lib = h.shape[0], h.device, load()
+    if h.ndim != 2 or h.shape[1] != LSTM_HIDDEN:
+        raise ValueError("lstm_split_state: h must be [B, 256]")
+    if out is None:
+        out = lstm_state_planes(b, dev)
+    elif out.dtype != torch.uint8 or out.device != dev or out.numel() < int(lib.rl8_lstm_split_state_bytes(b)):
+        raise ValueError("lstm_split_state: `out` must hold the planes of b rows")
+    if bound_out is not None:
+        if bound_out.dtype != torch.float32 or bound_out.numel() != 1 or bound_out.device != dev:
+            raise ValueError("bound_out must be one float32 element on h's device")
+        _check(lib.rl8_lstm_split_state_bound(_ptr(h), LSTM_HIDDEN, b, _ptr(out), _ptr(bound_out), _stream()),
+               "rl8_lstm_split_state_bound")
+    else:
+        _check(lib.rl8_lstm_split_state(_ptr(h), LSTM_HIDDEN, b, _ptr(out), _stream()), "rl8_lstm_split_state")
+    return out
+
+
 def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, packed: torch.Tensor, wb: torch.Tensor,
                        *, save: bool = False, planes: None | torch.Tensor = None,
-                       h0_bound_out: None | torch.Tensor = None):
+                       h0_bound_out: None | torch.Tensor = None, h0_planes: None | torch.Tensor = None):
     """As :func:`lstm_forward` on the fp16-plane step kernel: one state split + one step
     launch per timestep. Same outputs and saved layouts (``gates`` [B, L, 4, 256], ``cs``).
     ``h0_bound_out`` (one float32 element): receives max |h0|, which the state split sees
-    anyway (:func:`lstm_backward`'s ``h0_bound``)."""
+    anyway (:func:`lstm_backward`'s ``h0_bound``). ``h0_planes``: the planes of ``h0`` from an
+    earlier :func:`lstm_split_state` (read only; no split is made here)."""
     x = _dense(x.detach(), torch.float32, "x")
     b, l, d_in = x.shape
     for name, t in (("h0", h0), ("c0", c0)):
@@ -1261,15 +1284,18 @@ def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, pack
         raise ValueError("lstm_forward_split: `planes` must hold two state-plane buffers for L > 1")
     H, stream = LSTM_HIDDEN, _stream()
     xp, hsp, csp, gp, pp = _ptr(x), _ptr(hs), _ptr(cs), _ptr(gates), _ptr(planes)
-    if h0_bound_out is not None:
-        if h0_bound_out.dtype != torch.float32 or h0_bound_out.numel() != 1 or h0_bound_out.device != dev:
-            raise ValueError("h0_bound_out must be one float32 element on x's device")
-        _check(lib.rl8_lstm_split_state_bound(_ptr(h0), H, b, pp, _ptr(h0_bound_out), stream), "rl8_lstm_split_state_bound")
+    if h0_planes is not None:
+        if h0_bound_out is not None:
+            raise ValueError("lstm_forward_split: h0_bound_out comes from the split that made h0_planes")
+        if h0_planes.dtype != torch.uint8 or h0_planes.device != dev or h0_planes.numel() < int(lib.rl8_lstm_split_state_bytes(b)):
+            raise ValueError("lstm_forward_split: h0_planes must hold the planes of b rows")
     else:
-        _check(lib.rl8_lstm_split_state(_ptr(h0), H, b, pp, stream), "rl8_lstm_split_state")
+        lstm_split_state(h0, out=planes, bound_out=h0_bound_out)
     for t in range(l):
         c_prev, c_pitch = (_ptr(c0), H) if t == 0 else (csp + (t - 1) * H * 4, l * H)
         p_in, p_out = pp + (t & 1) * half, (pp + ((t + 1) & 1) * half) if t + 1 < l else None
+        if t == 0 and h0_planes is not None:
+            p_in = _ptr(h0_planes)
         with _timed("lstm_step_save" if save else "lstm_step", b):
             _check(lib.rl8_lstm_step_split_f32(
                 xp + t * d_in * 4, l * d_in, d_in, p_in, c_prev, c_pitch, _ptr(packed), _ptr(wb), b,

@@ -75,6 +75,30 @@ def use_split(lstm: nn.LSTM) -> bool:
     return FORWARD_GEMM == "split" and hip.lstm_split_supports(lstm.input_size)
 
 
+#: The fp16 planes of the last training pass's initial hidden states and max |h0|: the SGD iterations of one step() read
+#: the same rows of the buffer (the sequence-major copy of a full-buffer minibatch), whose split is 0.5 GB in, 0.5 GB out.
+_h0_cache: dict[str, tuple] = {}
+
+
+def _h0_planes(h0: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """(planes, max |h0|) of ``h0``, re-made unless this very memory, unmodified since, was split last time (the entry
+    keeps ``h0`` alive, so the address cannot have been handed to another tensor)."""
+    key = (h0.data_ptr(), tuple(h0.shape), tuple(h0.stride()), h0._version, h0.device)
+    hit = _h0_cache.get("entry")
+    if hit is not None and hit[0] == key:
+        return hit[2], hit[3]
+    _h0_cache.pop("entry", None)
+    bound = torch.empty(1, dtype=torch.float32, device=h0.device)
+    planes = hip.lstm_split_state(h0, bound_out=bound)
+    _h0_cache["entry"] = (key, h0, planes, bound)
+    return planes, bound
+
+
+def clear_state_cache() -> None:
+    """Drops the cached planes (and the reference to the rows they were made from)."""
+    _h0_cache.clear()
+
+
 class _FusedLSTM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, lstm, grad_mode):  # type: ignore[override]
@@ -82,8 +106,8 @@ class _FusedLSTM(torch.autograd.Function):
         if use_split(lstm):
             packed, wb = _packs(lstm, "split")
             # max |h0| for the backward's fp16-plane weight gradient comes out of the state split
-            bound = torch.empty(1, dtype=torch.float32, device=x.device) if need_grad else None
-            hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=need_grad, h0_bound_out=bound)
+            planes0, bound = _h0_planes(h0) if need_grad else (None, None)
+            hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=need_grad, h0_planes=planes0)
         else:
             bound = None
             hs, _, cn, gates, cs = hip.lstm_forward(x, h0, c0, _packs(lstm, False), save=need_grad)
@@ -148,8 +172,8 @@ class _FusedLSTMHeads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, w_heads, b_heads, lstm):  # type: ignore[override]
         packed, wb = _packs(lstm, "split")
-        bound = torch.empty(1, dtype=torch.float32, device=x.device)
-        hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=True, h0_bound_out=bound)
+        planes0, bound = _h0_planes(h0)
+        hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=True, h0_planes=planes0)
         out = hip.linear_heads_forward(hs.view(-1, hip.LSTM_HIDDEN), w_heads, b_heads)
         ctx.set_materialize_grads(False)
         ctx.lstm, ctx.h0_bound = lstm, bound
