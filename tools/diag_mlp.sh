@@ -17,6 +17,8 @@ for what in "$@"; do
     elif [ "$what" = lrstamp ]; then extra="-DRL8_LR_STAMP"
     else extra="-DRL8_LR_DIAG=${what#lr}"; fi
     make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/obj$what" OUT="$PWD/build_diag/librl8_amd_$what.so" FLAGS_EXTRA="$extra"
+  elif [ "${what#ls}" != "$what" ]; then  # ls<bits>: RL8_LS_DIAG of lstm_split_kernels.hip (1 no h/c/gate stores, 2 no transcendentals)
+    make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/obj$what" OUT="$PWD/build_diag/librl8_amd_$what.so" FLAGS_EXTRA="-DRL8_LS_DIAG=${what#ls}"
   elif [ "$what" = trace ]; then
     make -s -C rl8_amd/csrc BUILD="$PWD/build_diag/objtrace" OUT="$PWD/build_diag/librl8_amd_trace.so" \
          FLAGS_EXTRA="-DRL8_PHASE_TRACE"
