@@ -466,9 +466,11 @@ def run(args: argparse.Namespace) -> None:
     config_cls = RecurrentAlgorithmConfig if args.recurrent else AlgorithmConfig
     extra = {"distribution_cls": SquashedNormal} if args.distribution == "squashed" else {}
     if args.minibatches > 1:
-        if (global_envs * args.horizon) % args.minibatches:
-            raise SystemExit(f"bench.py: --minibatches {args.minibatches} does not divide num_envs * horizon")
-        extra["sgd_minibatch_size"] = global_envs * args.horizon // args.minibatches
+        # the recurrent algorithm counts a minibatch in sequences (seq_len 4 by default), the feed-forward one in samples
+        units = global_envs * args.horizon // (RecurrentAlgorithmConfig.seq_len if args.recurrent else 1)
+        if units % args.minibatches:
+            raise SystemExit(f"bench.py: --minibatches {args.minibatches} does not divide the {units} units of the buffer")
+        extra["sgd_minibatch_size"] = units // args.minibatches
     algo = config_cls(num_envs=global_envs, horizon=args.horizon, **extra).build(env_cls)
     horizon = algo.hparams.horizon
 

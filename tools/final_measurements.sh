@@ -28,9 +28,11 @@ timeout -k 10 300 python bench.py --recurrent --num-envs 8192 --horizon 256 --st
 timeout -k 10 300 python bench.py --env mountain_car --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_mountain_car.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --env pendulum --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_pendulum.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --minibatches 8 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_minibatches8.json 2>/dev/null || echo "minibatch bench failed"
+timeout -k 10 300 python bench.py --recurrent --num-envs 8192 --horizon 256 --minibatches 4 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg5_minibatches4.json 2>/dev/null || echo "recurrent minibatch bench failed"
+timeout -k 10 300 python tools/diag/lstm_forward_time.py > gpurun_out/${TAG}_lstm_forward.txt 2>&1 || echo "lstm forward timing failed"
 timeout -k 10 300 python tools/diag/lstm_rows_check.py --time > gpurun_out/${TAG}_lstm_rows_backward.txt 2>&1 || echo "lstm rows check failed"
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --single-device --num-envs 262144 --steps 3 --warmup 1 > gpurun_out/${TAG}_b_2rank_rehearsal.json 2>/dev/null || exit 1
-for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_mountain_car b_pendulum b_minibatches8 b_2rank_rehearsal; do python -c "
+for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_cfg5_minibatches4 b_mountain_car b_pendulum b_minibatches8 b_2rank_rehearsal; do python -c "
 import json; d=json.loads(open('gpurun_out/${TAG}_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value']), round(d['ms_per_step'],1), round(d['collect_ms_per_step'],1), round(d['update_ms_per_step'],1))"; done
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 echo done
