@@ -11,7 +11,15 @@ Built on :class:`Algorithm`: same time-major buffer (the ``states`` leaves are
 copy, not the reference's strided one), same fused per-timestep launch, same GAE
 and fused loss kernels. A minibatch of sequences is assembled by
 ``rl8_gather_minibatch``: per-sample leaves through the narrow path, the initial
-states of each sequence (1 KiB rows) through the wave-per-row path.
+states of each sequence (1 KiB rows) through the wave-per-row path. As in the
+feed-forward algorithm, a minibatch that is the whole buffer (the default) is not
+shuffled -- its mean does not depend on the order of the sequences: they are laid
+sequence-major once per ``step()`` in buffer order and every SGD iteration reads
+that copy (the reference draws ``randperm`` and gathers per iteration,
+``src/rl8/_utils.py:211-225``; ``bench.py --recurrent --minibatches 4`` times the
+shuffled path). A training pass through the default models is ONE autograd node
+(``nn/fused_lstm.py:_FusedLSTMHeads``): the heads' data gradient is formed inside
+the backward-through-time kernel.
 
 """
 
