@@ -538,7 +538,13 @@ def run(args: argparse.Namespace) -> None:
         "lstm_step": (2.0 * 256 * 1024, "f16x2-split"), "lstm_step_save": (2.0 * 256 * 1024, "f16x2-split"),
         "lstm_forward": (2.0 * 264 * 1024, "f32"), "lstm_forward_save": (2.0 * 264 * 1024, "f32"),
         "lstm_backward": (2.0 * 1024 * 256, "f32"),
-        "lstm_wgrad": (2.0 * 1024 * 256, "bf16x3-split" if os.environ.get("RL8_AMD_LSTM_GEMM", "split") == "split" else "f32"),
+        # backward through time on bf16 planes (six products): the recurrent product dG x W_hh of a row-step
+        "lstm_rows_backward": (2.0 * 1024 * 256, "bf16x3-split"),
+        # weight gradient: fp16 planes (three products) behind the rows kernel's bound on |dG|, bf16 planes (six) else
+        "lstm_wgrad": (2.0 * 1024 * 256,
+                       "f32" if os.environ.get("RL8_AMD_LSTM_GEMM", "split") != "split" else
+                       "f16x2-split" if (os.environ.get("RL8_AMD_LSTM_BACKWARD_ROWS", "1") != "0"
+                                         and os.environ.get("RL8_AMD_LSTM_WGRAD_PLANES", "f16") != "bf16") else "bf16x3-split"),
     }
     for name, rec in hip.timer.summary().items():
         if name in lstm_gemm:
@@ -614,7 +620,9 @@ def run(args: argparse.Namespace) -> None:
             # (6 per fp32 multiply-add of the algorithm) against the dense bf16 peak
             roofline = {
                 "kernel": {"mlp_wgrad": "rl8_mlp_wgrad_fused_split_f32", "mlp_wgrad_gate": "rl8_mlp_wgrad_gate_bits_f32 (rank-one heads: one output, or a pair of opposite gradients)",
-                           "mlp_tower_backward_gate": "rl8_mlp_tower_backward_gate_f16_f32"}.get(
+                           "mlp_tower_backward_gate": "rl8_mlp_tower_backward_gate_f16_f32",
+                           "lstm_rows_backward": "rl8_lstm_rows_backward_heads_f32 (backward through time of the recurrent models' LSTM)",
+                           "lstm_wgrad": "rl8_lstm_wgrad_f16_f32", "lstm_step_save": "rl8_lstm_step_split_f32"}.get(
                     dominant, f"rl8_{dominant}_{'f16' if top['gemm'] == 'f16x2-split' else 'split'}_f32"),
                 "bound": "mfma",
                 "achieved": top["executed_bf16_TFLOPs"],
@@ -622,7 +630,10 @@ def run(args: argparse.Namespace) -> None:
                 "unit": "TFLOP/s",
                 "frac": top["frac_of_bf16_mfma_peak"],
                 "flop_per_launch": top["executed_bf16_flop_per_launch"],
-                "flop_definition": ("3 bf16 plane products x 2*256*256 per row (ReLU gate as one exact bf16 plane x the three"
+                "flop_definition": (f"{top['plane_products']} 16-bit plane products x 2*1024*256 per row-step (the recurrent product of"
+                                    " the LSTM: fp32 operands as 3 exact bf16 planes / 2 scaled fp16 planes, fp32 accumulate)"
+                                    if dominant.startswith("lstm_") else
+                                    "3 bf16 plane products x 2*256*256 per row (ReLU gate as one exact bf16 plane x the three"
                                     " planes of dOut*h1, fp32 accumulate)" if top["gemm"] == "bf16-gate-x3" else
                                     "2 fp16 plane products x 2*256*256 per row (ReLU gate as one exact fp16 plane x the two"
                                     " planes of dOut*h1 scaled per column, fp32 accumulate)" if top["gemm"] == "f16-gatebits-x2" else
