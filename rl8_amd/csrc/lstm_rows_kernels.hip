@@ -40,7 +40,10 @@
 // c); dc through a [b][256] scratch in HBM (2 KiB of traffic per row-step; in registers it would take the 128 the row
 // loads in flight need: 512 per lane = 128 accumulators + 128 dh + loads, dG, planes, fragments).
 // HBM per row-step: gates 4 KiB, c_t, c_{t-1}, dh_t 1 KiB each, dc in/out 2 KiB, dG 4 KiB out = 13 KiB (the fp32 kernel
-// moves 11); matrix pipe 3072 cycles per row-step.
+// moves 11); matrix pipe 3072 cycles per row-step.  Measured (profiles/r03_lstm_traffic.txt): fabric traffic 1.00x / 1.03x
+// of that, 28.4 GB per 2^21 row-steps at 3.7 TB/s -- the rate HBM gives 128-byte pieces (a chunk's 32 units of a row).
+// Second form (lstm_rows_backward_heads_kernel): dL/dh_t of the models' output heads is not an array but
+// dOut[row-step][0..3] x W_heads[4][256], formed in phase A from two direct-to-LDS loads per chunk (12 KiB per row-step).
 #include "split_tile.hip.h"
 
 namespace rl8 {
