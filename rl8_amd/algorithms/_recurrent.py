@@ -270,6 +270,7 @@ class RecurrentAlgorithm(Algorithm):
         tm, stm = self._tm, self._tm_states
         rdr = tm.get(DataKeys.REVERSED_DISCOUNTED_RETURNS)
         self._flat_full = None  # (a sequence-major copy of the buffer this collect() overwrites)
+        self._release_step_caches()
         with profile_ms() as collect_timer:
             env_was_reset = False
             carry = (self.state.horizons and hp.horizons_per_env_reset < 0) or (
@@ -392,6 +393,10 @@ class RecurrentAlgorithm(Algorithm):
         local_mb = hp.sgd_minibatch_size // self.shards.world_size
         state_keys = list(self._tm_states)
         whole = local_mb >= local_seqs and self.injected_permutations is None
+        if whole:
+            from ..nn import fused_lstm
+
+            fused_lstm.SHARE_H0_PLANES = True  # until _release_step_caches(): every pass reads the same initial states
         if whole and getattr(self, "_flat_full", None) is not None:
             yield self._flat_full
             return

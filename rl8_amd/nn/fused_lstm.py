@@ -78,24 +78,30 @@ def use_split(lstm: nn.LSTM) -> bool:
 #: The fp16 planes of the last training pass's initial hidden states and max |h0|: the SGD iterations of one step() read
 #: the same rows of the buffer (the sequence-major copy of a full-buffer minibatch), whose split is 0.5 GB in, 0.5 GB out.
 _h0_cache: dict[str, tuple] = {}
+#: Set by ``RecurrentAlgorithm.step()`` while it reads its sequence-major copy of the buffer; off, every pass splits its
+#: own h0 (a version counter does not see writes made through raw pointers, e.g. the rollout's into the buffer).
+SHARE_H0_PLANES = False
 
 
 def _h0_planes(h0: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
-    """(planes, max |h0|) of ``h0``, re-made unless this very memory, unmodified since, was split last time (the entry
-    keeps ``h0`` alive, so the address cannot have been handed to another tensor)."""
+    """(planes, max |h0|) of ``h0``; with ``SHARE_H0_PLANES`` re-made only unless this very memory, unmodified since,
+    was split last time (the entry keeps ``h0`` alive, so the address cannot have been handed to another tensor)."""
     key = (h0.data_ptr(), tuple(h0.shape), tuple(h0.stride()), h0._version, h0.device)
-    hit = _h0_cache.get("entry")
+    hit = _h0_cache.get("entry") if SHARE_H0_PLANES else None
     if hit is not None and hit[0] == key:
         return hit[2], hit[3]
     _h0_cache.pop("entry", None)
     bound = torch.empty(1, dtype=torch.float32, device=h0.device)
     planes = hip.lstm_split_state(h0, bound_out=bound)
-    _h0_cache["entry"] = (key, h0, planes, bound)
+    if SHARE_H0_PLANES:
+        _h0_cache["entry"] = (key, h0, planes, bound)
     return planes, bound
 
 
 def clear_state_cache() -> None:
-    """Drops the cached planes (and the reference to the rows they were made from)."""
+    """Drops the cached planes (and the reference to the rows they were made from) and stops sharing."""
+    global SHARE_H0_PLANES
+    SHARE_H0_PLANES = False
     _h0_cache.clear()
 
 

@@ -381,3 +381,38 @@ def test_lstm_rows_backward_repeats_bit_for_bit():
     first = hip.lstm_rows_backward(c0, gates, cs, dhs, packed)
     for trial in range(20):
         assert torch.equal(first, hip.lstm_rows_backward(c0, gates, cs, dhs, packed)), trial
+
+
+def test_h0_planes_are_shared_only_on_request():
+    """fused_lstm's cache of the initial hidden states' planes: off by default (a raw-pointer write into the same memory
+    is invisible to the version counter: every pass must split what is there NOW), on between RecurrentAlgorithm's
+    SHARE_H0_PLANES = True and clear_state_cache()."""
+    from rl8_amd.nn import fused_lstm
+
+    lstm = reference_lstm(1, 3)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(200, 4, 1, device=DEV, generator=g)
+    h0 = torch.rand(200, 256, device=DEV, generator=g) - 0.5
+    c0 = torch.randn(200, 256, device=DEV, generator=g)
+
+    def out():
+        hs, _, _ = fused_lstm.lstm_forward(lstm, x, h0, c0)
+        return hs.detach().clone()
+
+    fused_lstm.clear_state_cache()
+    first = out()
+    h0_new = torch.rand(200, 256, device=DEV, generator=g) - 0.5
+    torch.cuda.synchronize()
+    # overwrite h0's memory behind torch's back (as a kernel of the library would)
+    import ctypes as C
+    C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(h0.data_ptr()), C.c_void_p(h0_new.data_ptr()), C.c_size_t(h0.numel() * 4), 3)
+    second = out()
+    assert not torch.equal(first, second) and fused_lstm._h0_cache == {}
+    fused_lstm.SHARE_H0_PLANES = True
+    try:
+        third = out()
+        assert torch.equal(second, third) and "entry" in fused_lstm._h0_cache
+        assert torch.equal(out(), third)
+    finally:
+        fused_lstm.clear_state_cache()
+    assert fused_lstm._h0_cache == {} and not fused_lstm.SHARE_H0_PLANES
