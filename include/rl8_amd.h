@@ -131,6 +131,16 @@ int rl8_rollout_step_dummy_f32(int is_discrete, int squashed, const float *featu
                                float *rdr_t1, float gamma, int64_t n, uint64_t seed, uint64_t step,
                                int64_t env_offset, int deterministic, void *stream);
 
+/* The discrete form for the default recurrent model (models/_recurrent.py:287-321: a two-way logits head and a value
+ * head on the LSTM's output), heads included: h [N][256] = h_t, w_pol [2][256], b_pol [2], w_vf [1][256], b_vf [1];
+ * logits and value are formed in the kernel exactly as rl8_linear_heads_forward_f32 forms them, the rest as
+ * rl8_rollout_step_dummy_f32(is_discrete = 1): one launch per rollout timestep behind the LSTM step instead of three. */
+int rl8_rollout_step_dummy_heads_f32(const float *h, const float *w_pol, const float *b_pol, const float *w_vf,
+                                     const float *b_vf, const float *noise, float *state, int64_t *action_col,
+                                     float *logp_col, float *value_col, float *reward_col, float *obs_col_next,
+                                     const float *rdr_t, float *rdr_t1, float gamma, int64_t n, uint64_t seed,
+                                     uint64_t step, int64_t env_offset, int deterministic, void *stream);
+
 /* Fused per-timestep kernel for CartPole (K = 3): sampler + physics +
  * bookkeeping.  obs_col_next is a [N][5] slab. */
 int rl8_rollout_step_cartpole_f32(const float *logits, const float *value, const float *noise,

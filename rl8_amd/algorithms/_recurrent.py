@@ -25,6 +25,7 @@ the backward-through-time kernel.
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Any
 
@@ -110,6 +111,8 @@ class _LeanRollout:
         self.split_ptrs = (self.planes.data_ptr(), self.wb.data_ptr() if self.wb is not None else None)
         self.planes_half = self.planes.numel() // 2
         self.planes_of = -1   # timestep whose hidden state the planes buffer (t & 1) holds (-1: none)
+        # two-way categorical + value head: evaluated inside the timestep's last kernel (RL8_AMD_ROLLOUT_FUSE_HEADS=0: two launches)
+        self.fuse_heads = self.k == 2 and os.environ.get("RL8_AMD_ROLLOUT_FUSE_HEADS", "1") != "0"
 
     @staticmethod
     def available(algo: "RecurrentAlgorithm") -> bool:
@@ -153,6 +156,15 @@ class _LeanRollout:
                 hip._check(lib.rl8_lstm_forward_f32(at(self.obs, t), n, 1, self.d_in, at(self.h, t), at(self.c, t), packed,
                                                     hs, at(self.h, t + 1), at(self.c, t + 1), None, None, stream),
                            "rl8_lstm_forward_f32")
+        if self.fuse_heads:
+            # the two heads inside the sampler + env.step + bookkeeping kernel: one launch instead of two
+            with hip._timed("rollout_step_dummy", n) if timed else _NO_TIMER:
+                hip._check(lib.rl8_rollout_step_dummy_heads_f32(
+                    hs, w_pol, b_pol, w_vf, b_vf, noise.data_ptr() if noise is not None else None, self.state_ptr,
+                    at(self.act, t), at(self.logp, t), at(self.val, t), at(self.rew, t), at(self.obs, t + 1),
+                    at(self.rdr, t) if self.rdr else None, at(self.rdr, t + 1) if self.rdr else None, self.gamma, n,
+                    self.seed, step_id, self.env_offset, self.deterministic, stream), "rl8_rollout_step_dummy_heads_f32")
+            return
         with hip._timed("linear_heads_forward", n) if timed else _NO_TIMER:
             if self.k + 1 <= hip.HEADS_MAX_OUT:  # both heads in one pass over h_t
                 hip._check(lib.rl8_linear_heads_forward_pair_f32(hs, n, w_pol, b_pol, self.k, logits, w_vf, b_vf, 1, value,

@@ -222,6 +222,67 @@ __global__ __launch_bounds__(kBlock) void rollout_step_dummy_kernel(
   }
 }
 
+// The same for the recurrent discrete model (two-way categorical) with the two output heads evaluated in the kernel:
+// logits = h x w_pol^T + b_pol, value = h x w_vf^T + b_vf from the LSTM's h_t [N][256] -- four lanes per env, each a
+// quarter of the 256 inputs, the arithmetic and its order those of linear_heads_forward_kernel (lstm_kernels.hip), so
+// the rollout is bit for bit the one of the two launches it replaces -- then lane 0 of the four draws the action and
+// steps the env.  At the recurrent bench's 8 192 envs per GPU both launches were a few microseconds of work behind a
+// launch each.
+__global__ __launch_bounds__(kBlock) void rollout_step_dummy_heads_kernel(
+    const float4 *__restrict__ h, const float *__restrict__ w_pol, const float *__restrict__ b_pol,
+    const float *__restrict__ w_vf, const float *__restrict__ b_vf, const float *__restrict__ noise,
+    float *__restrict__ state, int64_t *__restrict__ action_col, float *__restrict__ logp_col,
+    float *__restrict__ value_col, float *__restrict__ reward_col, float *__restrict__ obs_col_next,
+    const float *__restrict__ rdr_t, float *__restrict__ rdr_t1, float gamma, int64_t n, uint64_t seed, uint64_t step,
+    int64_t env_offset, int deterministic) {
+  constexpr int kIn = 256, kOut = 3;
+  __shared__ float4 ws[kOut * kIn / 4];
+  for (int i = threadIdx.x; i < kOut * kIn / 4; i += kBlock)
+    ws[i] = i < 2 * (kIn / 4) ? reinterpret_cast<const float4 *>(w_pol)[i] : reinterpret_cast<const float4 *>(w_vf)[i - 2 * (kIn / 4)];
+  __syncthreads();
+  const int q4 = threadIdx.x & 3;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / 4);
+  for (int64_t i = (int64_t)blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2); i < n; i += stride) {
+    float o[kOut] = {0.0f, 0.0f, 0.0f};
+    const float4 *hr = h + i * (kIn / 4) + q4 * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 v = hr[k];
+#pragma unroll
+      for (int q = 0; q < kOut; ++q) {
+        const float4 wv = ws[q * (kIn / 4) + q4 * 16 + k];
+        o[q] = __builtin_fmaf(v.x, wv.x, o[q]);
+        o[q] = __builtin_fmaf(v.y, wv.y, o[q]);
+        o[q] = __builtin_fmaf(v.z, wv.z, o[q]);
+        o[q] = __builtin_fmaf(v.w, wv.w, o[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kOut; ++q) {
+      o[q] += __shfl_xor(o[q], 1, kWave);
+      o[q] += __shfl_xor(o[q], 2, kWave);
+    }
+    if (q4 != 0) continue;
+    const float x[2] = {o[0] + b_pol[0], o[1] + b_pol[1]};
+    float q[2], lp;
+    if (noise) {
+      const float2 qn = *reinterpret_cast<const float2 *>(noise + 2 * i);
+      q[0] = qn.x; q[1] = qn.y;
+    }
+    const int act = categorical_draw<2>(x, noise ? q : nullptr, seed, (uint64_t)(i + env_offset), step, 0u,
+                                        deterministic != 0, &lp);
+    action_col[i] = act;
+    const float s = dummy_step_discrete(state[i], act);
+    const float r = -fabsf(s);
+    state[i] = s;
+    obs_col_next[i] = s;
+    reward_col[i] = r;
+    logp_col[i] = lp;
+    value_col[i] = o[2] + b_vf[0];
+    if (rdr_t1) rdr_t1[i] = gamma * rdr_t[i] + r;
+  }
+}
+
 // CartPole (K = 3): one lane per env; obs[t+1] rows are 20 B so the five
 // components of 64 consecutive envs fill 1280 contiguous bytes per wave.
 __global__ __launch_bounds__(kBlock) void rollout_step_cartpole_kernel(
@@ -365,6 +426,24 @@ RL8_API int rl8_rollout_step_dummy_f32(int is_discrete, int squashed, const floa
     rollout_step_dummy_kernel<false><<<grid, kBlock, 0, s>>>(
         squashed, features, features2, value, noise, state, action_col, logp_col, value_col,
         reward_col, obs_col_next, rdr_t, rdr_t1, gamma, n, seed, step, env_offset, deterministic);
+  return launch_status();
+}
+
+RL8_API int rl8_rollout_step_dummy_heads_f32(const float *h, const float *w_pol, const float *b_pol, const float *w_vf,
+                                             const float *b_vf, const float *noise, float *state, int64_t *action_col,
+                                             float *logp_col, float *value_col, float *reward_col, float *obs_col_next,
+                                             const float *rdr_t, float *rdr_t1, float gamma, int64_t n, uint64_t seed,
+                                             uint64_t step, int64_t env_offset, int deterministic, void *stream) {
+  if (!h || !w_pol || !b_pol || !w_vf || !b_vf || !state || !action_col || !logp_col || !value_col || !reward_col ||
+      !obs_col_next)
+    return RL8_ENULL;
+  if ((rdr_t == nullptr) != (rdr_t1 == nullptr)) return RL8_ENULL;
+  if (n <= 0) return RL8_ESIZE;
+  if (!aligned16(h) || !aligned16(w_pol) || !aligned16(w_vf) || (noise && (reinterpret_cast<uintptr_t>(noise) & 7u)))
+    return RL8_EALIGN;
+  rollout_step_dummy_heads_kernel<<<grid_for(n, kBlock / 4), kBlock, 0, (hipStream_t)stream>>>(
+      reinterpret_cast<const float4 *>(h), w_pol, b_pol, w_vf, b_vf, noise, state, action_col, logp_col, value_col,
+      reward_col, obs_col_next, rdr_t, rdr_t1, gamma, n, seed, step, env_offset, deterministic);
   return launch_status();
 }
 

@@ -105,6 +105,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_normal_sample_logp_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _u64, _u64, _i64, _i32, _vp],
     "rl8_rollout_scatter_f32": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp],
     "rl8_rollout_step_dummy_f32": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _u64, _u64, _i64, _i32, _vp],
+    "rl8_rollout_step_dummy_heads_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _u64,
+                                         _u64, _i64, _i32, _vp],
     "rl8_mountain_car_step_f32": [_vp, _vp, C.POINTER(MountainCarCfg), _vp, _i64, _vp, _i64, _vp],
     "rl8_mountain_car_reset_f32": [_vp, _i64, _u64, _u64, _i64, _vp, _i64, _vp],
     "rl8_rollout_step_mountain_car_f32": [_vp, _vp, _vp, _vp, C.POINTER(MountainCarCfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _u64, _u64, _i64, _i32, _vp],

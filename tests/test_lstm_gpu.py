@@ -416,3 +416,36 @@ def test_h0_planes_are_shared_only_on_request():
     finally:
         fused_lstm.clear_state_cache()
     assert fused_lstm._h0_cache == {} and not fused_lstm.SHARE_H0_PLANES
+
+
+@pytest.mark.parametrize("n,with_noise,deterministic", [(1, False, 0), (67, True, 0), (8192, False, 0), (10_001, False, 1), (10_001, True, 0)])
+def test_rollout_step_with_the_heads_inside_is_the_three_launches(n, with_noise, deterministic):
+    """rl8_rollout_step_dummy_heads_f32 (the recurrent rollout's per-timestep tail) against the launches it replaces --
+    rl8_linear_heads_forward_f32 for the logits, for the value, then rl8_rollout_step_dummy_f32 -- bit for bit: actions,
+    log-probabilities, values, rewards, next observations, env state, discounted-return recurrence."""
+    g = torch.Generator(device=DEV).manual_seed(n)
+    h = torch.randn(n, 256, device=DEV, generator=g)
+    w_pol, b_pol = torch.randn(2, 256, device=DEV, generator=g) / 16, torch.randn(2, device=DEV, generator=g)
+    w_vf, b_vf = torch.randn(1, 256, device=DEV, generator=g) / 16, torch.randn(1, device=DEV, generator=g)
+    noise = torch.rand(n, 2, device=DEV, generator=g) + 0.01 if with_noise else None
+    state0 = (torch.rand(n, device=DEV, generator=g) * 2 - 1) * 100
+    rdr_t = torch.randn(n, device=DEV, generator=g)
+    lib = hip.load()
+
+    def outputs():
+        return dict(state=state0.clone(), action=torch.zeros(n, dtype=torch.int64, device=DEV),
+                    logp=torch.zeros(n, device=DEV), value=torch.zeros(n, device=DEV), reward=torch.zeros(n, device=DEV),
+                    obs=torch.zeros(n, device=DEV), rdr=torch.zeros(n, device=DEV))
+
+    a, b = outputs(), outputs()
+    tail = lambda o: (hip._ptr(o["state"]), hip._ptr(o["action"]), hip._ptr(o["logp"]), hip._ptr(o["value"]),  # noqa: E731
+                      hip._ptr(o["reward"]), hip._ptr(o["obs"]), hip._ptr(rdr_t), hip._ptr(o["rdr"]), 0.95, n, 1234, 7, 5,
+                      deterministic, hip._stream())
+    hip._check(lib.rl8_rollout_step_dummy_heads_f32(hip._ptr(h), hip._ptr(w_pol), hip._ptr(b_pol), hip._ptr(w_vf), hip._ptr(b_vf),
+                                                    hip._ptr(noise), *tail(a)), "rl8_rollout_step_dummy_heads_f32")
+    logits, value = hip.linear_heads_forward(h, w_pol, b_pol), hip.linear_heads_forward(h, w_vf, b_vf)
+    hip._check(lib.rl8_rollout_step_dummy_f32(1, 0, hip._ptr(logits), None, hip._ptr(value), hip._ptr(noise), *tail(b)),
+               "rl8_rollout_step_dummy_f32")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert int(a["action"].min()) >= 0 and int(a["action"].max()) <= 1
