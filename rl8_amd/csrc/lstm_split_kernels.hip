@@ -41,7 +41,7 @@ constexpr int kLsATileBytes = kSplitSteps * kLsAChunkBytes;
 constexpr int kLsInCols = 8;                      // [w_ih (d_in <= 7) ... | b_ih + b_hh] per gate row
 constexpr int kLsXBytes = 7 * kSplitRows * 4;     // x tile in LDS, [input][row]
 #ifndef RL8_LS_DIAG
-#define RL8_LS_DIAG 0   // tuning builds: 1 no h/c/gate stores (one checksum store per lane), 2 no transcendentals
+#define RL8_LS_DIAG 0   // tuning builds: 1 no h/c/gate stores (one checksum store per lane), 2 no transcendentals, 4 one plane product of three
 #endif
 constexpr int kLsDiag = RL8_LS_DIAG;
 
@@ -254,9 +254,13 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
     f.bm[2] = lds_read_b128<5 * 1024>(br);
     f.bm[3] = lds_read_b128<7 * 1024>(br);
     wait_lds_all(f);
-    f16_mma<FIRST>(f.am, f.bh, acc);  // lo x hi
-    f16_mma<false>(f.ah, f.bm, acc);  // hi x lo
-    f16_mma<false>(f.ah, f.bh, acc);  // hi x hi
+    if constexpr ((kLsDiag & 4) != 0) {  // tuning builds: one plane product of three
+      f16_mma<FIRST>(f.ah, f.bh, acc);
+    } else {
+      f16_mma<FIRST>(f.am, f.bh, acc);  // lo x hi
+      f16_mma<false>(f.ah, f.bm, acc);  // hi x lo
+      f16_mma<false>(f.ah, f.bh, acc);  // hi x hi
+    }
     __builtin_amdgcn_sched_barrier(0);
     step_barrier();
   };
