@@ -28,6 +28,7 @@ unbuffered, the stat keys -- follows the reference's
 from __future__ import annotations
 
 import contextlib
+import os
 from dataclasses import dataclass
 from typing import Any, Literal
 
@@ -266,6 +267,13 @@ class Algorithm:
         self.optimizer = optimizer
         self.grad_scaler = GradScaler(device="cuda", enabled=config.enable_amp)
         self.max_rows_per_pass = DEFAULT_MAX_ROWS_PER_PASS
+        #: Keep what the towers compute during ``collect()`` (outputs + gate bits) and let the SGD passes that
+        #: still see the rollout's weights -- iteration 0 up to the first optimizer step -- start from it instead
+        #: of running the forward kernels again on the same rows (``fused_mlp.RolloutRecord``; bit-identical).
+        self.reuse_rollout_forward = os.environ.get("RL8_AMD_REUSE_ROLLOUT", "1") != "0"
+        self._record: None | fused_mlp.RolloutRecord = None
+        self._record_obs_version = -1
+        self._batch_rows: None | tuple[str, None | torch.Tensor] = None
         #: Parity hooks: noise / permutations recorded from a reference run.
         self.injected_noise: None | torch.Tensor = None  # [H, N, ...]
         self.injected_permutations: None | list[torch.Tensor] = None
@@ -445,12 +453,18 @@ class Algorithm:
 
             fused = self._fusable()
             gamma = float(torch.tensor(hp.gamma, dtype=torch.float32))
+            record = self._rollout_record() if fused else None
+            self._record_obs_version = -1
+            dist_cls = self.policy.distribution_cls
+            pair = (fused_mlp.expect_pair_gradients() if record is not None and issubclass(dist_cls, Categorical)
+                    else contextlib.nullcontext())
             for t in range(H):
                 obs_t = tm[DataKeys.OBS][t]
                 noise_t = self.injected_noise[t] if self.injected_noise is not None else None
                 step_id = self.noise.next_step()
                 if fused:
-                    features, values = self._forward(obs_t, deterministic=deterministic)
+                    with (record.at(t) if record is not None else contextlib.nullcontext()), pair:
+                        features, values = self._forward(obs_t, deterministic=deterministic)
                     self._fused_step(features, values, noise_t, t, gamma, step_id, deterministic)
                 else:
                     self._generic_step(obs_t, noise_t, t, gamma, step_id, deterministic)
@@ -476,11 +490,27 @@ class Algorithm:
             self.state.buffered = True
             self.state.reward_scale = reward_scale if hp.normalize_rewards else 1.0
             self.injected_noise = None
+            if record is not None:  # (a Python-level write to the observations before step() voids the record)
+                self._record_obs_version = tm[DataKeys.OBS]._version
 
         collect_stats["env/resets"] = hp.num_envs * int(env_was_reset)
         collect_stats["env/steps"] = hp.num_envs * hp.horizon
         collect_stats["profiling/collect_ms"] = collect_timer()
         return collect_stats
+
+    def _rollout_record(self) -> None | fused_mlp.RolloutRecord:
+        """The record this ``collect()`` fills (made once, its slabs reused by every rollout), or ``None``."""
+        if not self.reuse_rollout_forward or not has_fused_loss(self.policy.distribution_cls):
+            return None
+        hp = self.hparams
+        rec = self._record
+        if rec is None or (rec.steps, rec.rows_per_step) != (hp.horizon, self.local_num_envs):
+            rec = self._record = fused_mlp.RolloutRecord(hp.horizon, self.local_num_envs, keep_general=False)
+        # heads that need h2 (1 KiB per row) are recorded only when every row is read back: one optimizer step per
+        # SGD iteration.  Gate-bit towers (32 B per row) always.
+        rec.keep_general = hp.num_minibatches == 1 or hp.accumulate_grads
+        rec.begin()
+        return rec
 
     def _fused_step(
         self, features: TensorDict, values: torch.Tensor, noise: None | torch.Tensor, t: int,
@@ -693,6 +723,7 @@ class Algorithm:
         hp = self.hparams
         H, tm = hp.horizon, self._tm
         local_samples = self.local_num_envs * H
+        self._batch_rows = None
         if not self._identity_views():
             yield from self._iter_view_minibatches(sgd_iter)
             return
@@ -704,6 +735,7 @@ class Algorithm:
                 self._flat_full = {
                     k: tm[k][:H].reshape(local_samples, *tm[k].shape[2:]) for k in self.TRAIN_KEYS
                 }
+            self._batch_rows = ("all", None)
             yield self._flat_full
             return
         local_mb = hp.sgd_minibatch_size // self.shards.world_size
@@ -713,7 +745,9 @@ class Algorithm:
             # sample's fields side by side once, then every gather reads one row
             self._packed = hip.PackedSamples(H, [self.buffer[k] for k in self.TRAIN_KEYS])
         for index in torch.split(perm, local_mb):
-            yield dict(zip(self.TRAIN_KEYS, self._packed.gather(index.contiguous())))
+            index = index.contiguous()
+            self._batch_rows = ("index", index)
+            yield dict(zip(self.TRAIN_KEYS, self._packed.gather(index)))
 
     def _iter_view_minibatches(self, sgd_iter: int):
         """Minibatches for models with rolling-window view requirements
@@ -757,15 +791,25 @@ class Algorithm:
         scale = None
         if hp.enable_amp:
             scale = self.grad_scaler.scale(torch.ones((), device=batch[DataKeys.LOGP].device))
+        # Rows the rollout already took through the towers with the weights they still have (iteration 0, before the
+        # first optimizer step): start from the record instead of launching the forward again.
+        recorded: None | dict[int, tuple] = None
+        rec, batch_rows = getattr(self, "_record", None), getattr(self, "_batch_rows", None)
+        if (rec is not None and batch_rows is not None and DataKeys.OBS in batch
+                and self._record_obs_version == self._tm[DataKeys.OBS]._version and rec.valid()):
+            recorded = rec.rows(0, rows) if batch_rows[0] == "all" else rec.gather(batch_rows[1])
         for start in range(0, rows, self.max_rows_per_pass):
             stop = min(rows, start + self.max_rows_per_pass)
             chunk = {k: v[start:stop] for k, v in batch.items()}
             n = stop - start
+            replayed = contextlib.nullcontext() if not recorded else fused_mlp.replay(
+                {k: (key, *[None if t is None else t[start:stop] for t in rest]) for k, (key, *rest) in recorded.items()},
+                chunk[DataKeys.OBS])
             # A two-way Categorical under the fused loss: rl8_ppo_loss_categorical_fwd_bwd_f32 emits logit gradients
             # that are exact negatives of each other, so the policy tower may keep only the gate bits of h2 from the
             # first SGD iteration on (fused_mlp.expect_pair_gradients; still checked on the device in the backward).
             pair = fused_mlp.expect_pair_gradients() if fused and issubclass(dist_cls, Categorical) else contextlib.nullcontext()
-            with amp.autocast("cuda", enabled=hp.enable_amp), pair:
+            with amp.autocast("cuda", enabled=hp.enable_amp), pair, replayed:
                 views = chunk[DataKeys.VIEWS] if DataKeys.VIEWS in chunk else TensorDict(
                     {DataKeys.OBS: chunk[DataKeys.OBS]}, batch_size=n)
                 sample = self.policy.sample(

@@ -907,7 +907,8 @@ def mlp_pack_w2_f16_gate(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
 def mlp_tower_forward_split(
     x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2_split: torch.Tensor, b2: torch.Tensor,
     w3: torch.Tensor, b3: torch.Tensor, *, save: bool = False, save_h1: bool = True, save_gate: bool = False,
-    save_h2: bool = True,
+    save_h2: bool = True, out: None | torch.Tensor = None, h2_out: None | torch.Tensor = None,
+    gate_out: None | torch.Tensor = None, timer_name: None | str = None,
 ) -> tuple[torch.Tensor, ...]:
     """``mlp_tower_forward`` with the 256x256 product as three fp16-plane MFMAs per
     16 k (fp32 accuracy, fp32 in / out / accumulate; ``w2_split`` from
@@ -916,7 +917,10 @@ def mlp_tower_forward_split(
     ``save``) appends a fourth result, the ReLU gate of h2 as bits ([M, 8] int32:
     bit j of row s = h2[s, j] > 0), which the data-gradient kernel reads instead of h2.
     ``save_h2=False`` (fp16-plane pack, with ``save_gate``): the gate bits ALONE are kept -- all the
-    backward pass of a rank-one head needs (``mlp_tower_backward(..., h2=None, w2=..., b2=...)``)."""
+    backward pass of a rank-one head needs (``mlp_tower_backward(..., h2=None, w2=..., b2=...)``).
+    ``out`` / ``h2_out`` / ``gate_out``: caller-owned dense destinations ([M, n_out] fp32, [M, 256] fp32,
+    [M, 8] int32) instead of fresh tensors -- the rollout writes each timestep's rows straight into the slabs the
+    first SGD pass reads back (``fused_mlp.RolloutRecord``)."""
     x = _dense(x.detach(), torch.float32, "x")
     m, d_in = x.shape
     n_out = w3.shape[0]
@@ -930,15 +934,24 @@ def mlp_tower_forward_split(
         fn, fn_name = lib.rl8_mlp_tower_forward_f16_f32, "rl8_mlp_tower_forward_f16_f32"  # fp16 two-plane pack
     else:
         raise ValueError("w2_split must come from mlp_pack_w2_f16")
-    out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
+    for name, t, dtype, shape in (("out", out, torch.float32, (m, n_out)), ("h2_out", h2_out, torch.float32, (m, MLP_HIDDEN)),
+                                  ("gate_out", gate_out, torch.int32, (m, 8))):
+        if t is not None:
+            _dense(t, dtype, name)
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+    if out is None:
+        out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
     if save and not save_h2:
         if not save_gate:
             raise ValueError("save_h2=False needs save_gate=True")
         save_h1 = False
     h1 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save and save_h1 else None
-    h2 = torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device) if save and save_h2 else None
-    gate = torch.empty(m, 8, dtype=torch.int32, device=x.device) if save and save_gate else None
-    with _timed("mlp_tower_forward_save" if save else "mlp_tower_forward", m):
+    h2 = (h2_out if h2_out is not None else torch.empty(m, MLP_HIDDEN, dtype=torch.float32, device=x.device)) \
+        if save and save_h2 else None
+    gate = (gate_out if gate_out is not None else torch.empty(m, 8, dtype=torch.int32, device=x.device)) \
+        if save and save_gate else None
+    with _timed(timer_name or ("mlp_tower_forward_save" if save else "mlp_tower_forward"), m):
         _check(
             fn(
                 _ptr(x), m, d_in, _ptr(w1.detach()), _ptr(b1.detach()), _ptr(w2_split), _ptr(b2.detach()),

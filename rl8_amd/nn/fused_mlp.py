@@ -142,25 +142,193 @@ class _FusedTower(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):  # type: ignore[override]
-        x, h1, h2, w3, w1, b1, gate, b2, b3, w2 = ctx.saved_tensors
-        split: bool | str = False
-        if BACKWARD_GEMM == "f16" and gate is not None and hip.mlp_backward_f16_supports(x.shape[1], w3.shape[0]):
-            split = "f16"
-        layer2 = ctx.layer2
-        w3_key = ctx.w3_key
-        gate_pack = (lambda: _packed_gate(layer2, w3, w3_key)) if split == "f16" and w3.shape[0] <= 2 else None
+        return _tower_backward(ctx, dout)
 
-        def h2_again():  # (a two-output head that is not rank-one after all: the forward once more, with h2)
-            return hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16"), b2, w3, b3, save=True,
-                                               save_h1=False, save_gate=True)[2]
 
-        info: dict = {}
-        g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(layer2, True, split), w3,
-                                   w1, b1, wgrad_split=BACKWARD_GEMM == "f16", gate2=gate if split else None,
-                                   gate_pack=gate_pack, w2=w2, b2=b2, h2_fn=h2_again, info=info)
-        if w3.shape[0] == 2:  # what this backward found, for callers that give no hint (see tower_forward)
-            layer2.__dict__["_rl8_rank_one"] = bool(info.get("rank_one", False))
-        return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None, None, None
+def _tower_backward(ctx, dout):
+    """Backward of ``_FusedTower`` and of ``_ReplayedTower`` (same saved tensors, same kernels)."""
+    x, h1, h2, w3, w1, b1, gate, b2, b3, w2 = ctx.saved_tensors
+    split: bool | str = False
+    if BACKWARD_GEMM == "f16" and gate is not None and hip.mlp_backward_f16_supports(x.shape[1], w3.shape[0]):
+        split = "f16"
+    layer2 = ctx.layer2
+    w3_key = ctx.w3_key
+    gate_pack = (lambda: _packed_gate(layer2, w3, w3_key)) if split == "f16" and w3.shape[0] <= 2 else None
+
+    def h2_again():  # (a two-output head that is not rank-one after all: the forward once more, with h2)
+        return hip.mlp_tower_forward_split(x, w1, b1, _packed(layer2, False, "f16"), b2, w3, b3, save=True,
+                                           save_h1=False, save_gate=True)[2]
+
+    info: dict = {}
+    g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(layer2, True, split), w3,
+                               w1, b1, wgrad_split=BACKWARD_GEMM == "f16", gate2=gate if split else None,
+                               gate_pack=gate_pack, w2=w2, b2=b2, h2_fn=h2_again, info=info)
+    if w3.shape[0] == 2:  # what this backward found, for callers that give no hint (see tower_forward)
+        layer2.__dict__["_rl8_rank_one"] = bool(info.get("rank_one", False))
+    return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# The rollout's forward passes, kept for the first SGD pass (VERDICT r3 item 2).
+#
+# ``Algorithm.collect()`` evaluates both towers on every observation of the buffer
+# (reference ``algorithms/_feedforward.py:362-367``); SGD iteration 0 of ``step()``
+# then evaluates them AGAIN on the same observations with the same weights
+# (``:519-524``).  The forward kernel is deterministic per row, so that second pass
+# reproduces numbers that already exist.  A ``RolloutRecord`` makes the rollout's
+# launches run in the training forward's save mode (gate bits of h2, 32 B per row;
+# h2 too for heads that are not rank-one) into ``[H][N]`` slabs -- the row order of
+# the time-major buffer's flat full batch -- and ``replay`` hands those to autograd
+# in place of a forward launch.  Used only while every parameter of the tower is
+# what the rollout saw (version counters and addresses).
+# --------------------------------------------------------------------------- #
+class _TowerRecord:
+    def __init__(self, params: list[torch.Tensor], n_out: int, gate_only: bool, rows: int, device) -> None:
+        self.params = params
+        self.n_out, self.gate_only, self.rows = n_out, gate_only, rows
+        self.out = torch.empty(rows, n_out, dtype=torch.float32, device=device)
+        self.gate = torch.empty(rows, 8, dtype=torch.int32, device=device)
+        self.h2 = None if gate_only else torch.empty(rows, hip.MLP_HIDDEN, dtype=torch.float32, device=device)
+        self.key: None | tuple = None
+        self.seen: set[int] = set()
+
+    def current_key(self) -> tuple:
+        return tuple((p._version, p.data_ptr()) for p in self.params)
+
+    def leaves(self) -> list[torch.Tensor]:
+        return [t for t in (self.out, self.gate, self.h2) if t is not None]
+
+
+class RolloutRecord:
+    """Outputs, gate bits (and h2 where needed) of the towers for the ``steps x rows_per_step`` observations of one
+    rollout, in time-major row order. ``at(t)`` is the context ``collect()`` evaluates timestep ``t`` in."""
+
+    def __init__(self, steps: int, rows_per_step: int, *, keep_general: bool) -> None:
+        self.steps, self.rows_per_step = steps, rows_per_step
+        self.keep_general = keep_general
+        self.towers: dict[int, _TowerRecord] = {}
+        self.t = -1
+        self.refused: set[int] = set()
+
+    def begin(self) -> None:
+        for tr in self.towers.values():
+            tr.seen.clear()
+            tr.key = None
+
+    def at(self, t: int) -> "_Recording":
+        return _Recording(self, t)
+
+    def bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for tr in self.towers.values() for t in tr.leaves())
+
+    def _tower(self, layer2: nn.Linear, params: list[torch.Tensor], n_out: int, gate_only: bool, device) -> None | _TowerRecord:
+        tr = self.towers.get(id(layer2))
+        rows = self.steps * self.rows_per_step
+        if tr is not None and (tr.n_out, tr.gate_only, tr.rows) == (n_out, gate_only, rows) and tr.out.device == device:
+            tr.params = params
+            return tr
+        if id(layer2) in self.refused:
+            return None
+        if not gate_only:
+            # h2 is 1 KiB per row (34 GB per tower at 2^25 rows): only where every row is read back and it fits easily
+            need = rows * (hip.MLP_HIDDEN * 4 + 32 + 4 * n_out)
+            free, _ = torch.cuda.mem_get_info(device)
+            if not self.keep_general or need > free // 3:
+                self.refused.add(id(layer2))
+                return None
+        self.towers.pop(id(layer2), None)
+        tr = self.towers[id(layer2)] = _TowerRecord(params, n_out, gate_only, rows, device)
+        return tr
+
+    def _usable(self, tr: _TowerRecord) -> bool:
+        """The tower saw all the timesteps, with the parameters it has now."""
+        return tr.key is not None and len(tr.seen) == self.steps and tr.current_key() == tr.key
+
+    def valid(self) -> bool:
+        """Some recorded tower can still be replayed."""
+        return any(self._usable(tr) for tr in self.towers.values())
+
+    def rows(self, start: int, stop: int) -> dict[int, tuple]:
+        """Record rows ``[start, stop)`` (time-major order) of every usable tower."""
+        return {k: (tr.key, tr.out[start:stop], tr.gate[start:stop], tr.h2[start:stop] if tr.h2 is not None else None)
+                for k, tr in self.towers.items() if self._usable(tr)}
+
+    def gather(self, index: torch.Tensor) -> dict[int, tuple]:
+        """The same for the samples ``index`` names (reference sample ids ``env * H + t``): one strided gather per
+        tower (``rl8_gather_minibatch``) out of the ``[H][N]`` slabs seen as ``[N, H, ...]`` leaves."""
+        H, N = self.steps, self.rows_per_step
+        got: dict[int, tuple] = {}
+        for k, tr in self.towers.items():
+            if not self._usable(tr):
+                continue
+            leaves = [t.view(H, N, t.shape[1]).transpose(0, 1) for t in tr.leaves()]
+            dense = hip.gather_minibatch(index, H, leaves)
+            got[k] = (tr.key, dense[0], dense[1], dense[2] if tr.h2 is not None else None)
+        return got
+
+
+_RECORDING: None | RolloutRecord = None
+_REPLAY: None | tuple[dict[int, tuple], torch.Tensor] = None
+
+
+class _Recording:
+    def __init__(self, record: RolloutRecord, t: int) -> None:
+        self.record, self.t = record, t
+
+    def __enter__(self):
+        global _RECORDING
+        self._before = _RECORDING
+        self.record.t = self.t
+        _RECORDING = self.record
+        return self.record
+
+    def __exit__(self, *exc):
+        global _RECORDING
+        _RECORDING = self._before
+        return False
+
+
+class replay:
+    """Context for a grad-enabled pass over ``x`` (a dense ``[m, d]`` tensor): towers found in ``rows`` (from
+    ``RolloutRecord.rows`` / ``.gather``) whose parameters are still the recorded ones skip their forward launch."""
+
+    def __init__(self, rows: dict[int, tuple], x: torch.Tensor) -> None:
+        self.rows, self.x = rows, x
+
+    def __enter__(self):
+        global _REPLAY
+        self._before = _REPLAY
+        _REPLAY = (self.rows, self.x)
+        return self
+
+    def __exit__(self, *exc):
+        global _REPLAY
+        _REPLAY = self._before
+        return False
+
+
+#: Counts for tests / the bench line: towers evaluated from the record, rows recorded.
+replay_stats = {"replayed_towers": 0, "replayed_rows": 0, "recorded_rows": 0}
+
+
+class _ReplayedTower(torch.autograd.Function):
+    """``_FusedTower`` whose forward already ran (during the rollout): returns the recorded output and saves the
+    recorded gate bits / h2 for the same backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, layer2, w3_key, out, gate, h2):  # type: ignore[override]
+        ctx.layer2 = layer2
+        ctx.w3_key = w3_key
+        ctx.save_for_backward(x, None, h2, w3, w1, b1, gate, b2, b3, w2)
+        return out.detach()
+
+    @staticmethod
+    def backward(ctx, dout):  # type: ignore[override]
+        return _tower_backward(ctx, dout) + (None,)
+
+
+def _tower_params(l1: nn.Linear, l2: nn.Linear, heads: Sequence[nn.Linear]) -> list[torch.Tensor]:
+    return [l1.weight, l1.bias, l2.weight, l2.bias, *[h.weight for h in heads], *[h.bias for h in heads]]
 
 
 def _match(trunk: nn.Module, heads: Sequence[nn.Linear]) -> None | tuple[nn.Linear, nn.Linear]:
@@ -209,5 +377,37 @@ def tower_forward(trunk: nn.Sequential, heads: Sequence[nn.Linear], x: torch.Ten
     if pair_gradients is None:
         pair_gradients = bool(l2.__dict__.get("_rl8_rank_one", False))
     w3_key = tuple((h.weight._version, h.weight.data_ptr()) for h in heads)
+    n_out, d_in = w3.shape[0], x.shape[1]
+    plane_path = (FORWARD_GEMM == "f16" and BACKWARD_GEMM == "f16" and hip.mlp_forward_f16_supports(d_in, n_out)
+                  and hip.mlp_backward_f16_supports(d_in, n_out))
+    if _RECORDING is not None and not torch.is_grad_enabled() and plane_path and x.shape[0] == _RECORDING.rows_per_step:
+        rec = _RECORDING
+        gate_only = not _gates_off() and (n_out == 1 or (n_out == 2 and bool(pair_gradients)))
+        params = _tower_params(l1, l2, heads)
+        tr = rec._tower(l2, params, n_out, gate_only, x.device)
+        if tr is not None:
+            key = tr.current_key()
+            if tr.key != key:
+                tr.key, tr.seen = key, set()
+            lo = rec.t * rec.rows_per_step
+            sl = slice(lo, lo + rec.rows_per_step)
+            out = hip.mlp_tower_forward_split(
+                x.contiguous(), l1.weight, l1.bias, _packed(l2, False, "f16"), l2.bias, w3, b3, save=True,
+                save_h1=False, save_gate=True, save_h2=not gate_only, out=tr.out[sl], gate_out=tr.gate[sl],
+                h2_out=None if gate_only else tr.h2[sl], timer_name="mlp_tower_forward_record")[0]
+            tr.seen.add(rec.t)
+            replay_stats["recorded_rows"] += rec.rows_per_step
+            return out
+    if _REPLAY is not None and torch.is_grad_enabled() and plane_path:
+        rows, expect = _REPLAY
+        hit = rows.get(id(l2))
+        if (hit is not None and x.data_ptr() == expect.data_ptr() and x.shape == expect.shape and x.is_contiguous()
+                and hit[0] == tuple((p._version, p.data_ptr()) for p in _tower_params(l1, l2, heads))
+                and hit[1].shape == (x.shape[0], n_out)
+                and (hit[3] is not None or n_out == 1 or (n_out == 2 and bool(pair_gradients)))):
+            replay_stats["replayed_towers"] += 1
+            replay_stats["replayed_rows"] += x.shape[0]
+            return _ReplayedTower.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, w3, b3, l2, w3_key,
+                                        hit[1], hit[2], hit[3])
     return _FusedTower.apply(x.contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3, l2,
                              torch.is_grad_enabled(), bool(pair_gradients), w3_key)

@@ -730,10 +730,11 @@ def gen_first_updates() -> None:
 #      a second rollout (carried observations, non-zero reward scale, used Adam state untouched
 #      by the first update's statistics) through the shuffled / packed path.
 # --------------------------------------------------------------------------- #
-def gen_second_iteration(name, trace_name, env_cls, config_kwargs) -> None:
+def gen_second_iteration(name, trace_name, env_cls, config_kwargs, recurrent=False) -> None:
     trace = dict(np.load(os.path.join(HERE, trace_name)))
     torch.manual_seed(42)
-    algo = AlgorithmConfig(num_envs=64, horizon=32, device="cpu", **config_kwargs).build(env_cls)
+    cfg_cls = RecurrentAlgorithmConfig if recurrent else AlgorithmConfig
+    algo = cfg_cls(num_envs=64, horizon=32, device="cpu", **config_kwargs).build(env_cls)
     algo.collect()
     algo.step()
     for k, v in algo.policy.model.state_dict().items():
@@ -759,8 +760,90 @@ def gen_second_iteration(name, trace_name, env_cls, config_kwargs) -> None:
 def gen_second_iterations() -> None:
     envs = {"discrete": DiscreteDummyEnv, "continuous": ContinuousDummyEnv}
     for name, trace_name, env, cfg, recurrent in TRACED_VARIANTS:
-        if not recurrent:
-            gen_second_iteration(name.replace("first_update_", "second_iteration_"), trace_name, envs[env], cfg)
+        gen_second_iteration(name.replace("first_update_", "second_iteration_"), trace_name, envs[env], cfg,
+                             recurrent=recurrent)
+
+
+# --------------------------------------------------------------------------- #
+# F7c: self-contained two-iteration fixtures for what the traces do not reach:
+#      * a recurrent config whose LSTM states ARE carried across collect() calls
+#        (src/rl8/algorithms/_recurrent.py:380-392: last column -> first column; :384-392: re-initialised only
+#        where state.seqs hits seqs_per_state_reset) -- both traced recurrent configs re-initialise at t = 0 of
+#        every collect(), so their second iteration never reads a carried state;
+#      * CartPole with horizons_per_env_reset = 2: the [4, N] physics state (examples/cartpole/env.py:128-150)
+#        and the last observation / reversed discounted return carried into a used buffer.
+#      Everything a teacher-forced replay of iteration 1 needs is recorded: iteration 0's inputs, the reference's
+#      weights / env state / carried columns after iteration 0, iteration 1's noise and permutations, its rollout,
+#      every StatTracker.update and the gradient at its first optimizer step.
+# --------------------------------------------------------------------------- #
+def gen_two_iterations(name, env_cls, config_kwargs, *, recurrent=False, env_state=None) -> None:
+    arrays = {}
+    torch.manual_seed(42)
+    cfg_cls = RecurrentAlgorithmConfig if recurrent else AlgorithmConfig
+    algo = cfg_cls(num_envs=64, horizon=32, device="cpu", **config_kwargs).build(env_cls)
+    env_state = env_state or (lambda env: env.state)
+    for k, v in algo.policy.model.state_dict().items():
+        arrays[f"init_{k}"] = v.clone()
+    keys = step_keys = None
+    for it in range(2):
+        with Recorder() as rec:
+            real_reset = algo.env.reset
+            resets = []
+
+            def reset(*, config=None, _r=real_reset):
+                out = _r(config=config)
+                resets.append(env_state(algo.env).clone())
+                return out
+
+            algo.env.reset = reset
+            collect_stats = algo.collect()
+            algo.env.reset = real_reset
+            snapshot_buffer(algo.buffer, f"it{it}_collect", arrays)
+            arrays[f"it{it}_reward_scale"] = np.float64(algo.state.reward_scale)
+            arrays[f"it{it}_env_state"] = env_state(algo.env).clone()
+            with UpdateRecorder(algo) as urec:
+                step_stats = algo.step()
+        assert len(resets) == (1 if it == 0 else 0), "the point of this fixture is a carried environment"
+        if resets:
+            arrays[f"it{it}_reset_state"] = resets[0]
+        if rec.cat_q:
+            arrays[f"it{it}_cat_q"] = torch.stack(rec.cat_q)
+        if rec.normal_eps:
+            arrays[f"it{it}_normal_eps"] = torch.stack(rec.normal_eps)
+        arrays[f"it{it}_perms"] = torch.stack(rec.perms)
+        keys = sorted(k for k in collect_stats if not k.startswith("profiling"))
+        step_keys = sorted(k for k in step_stats if not k.startswith("profiling"))
+        arrays[f"it{it}_collect_stats"] = np.array([collect_stats[k] for k in keys], np.float64)
+        arrays[f"it{it}_step_stats"] = np.array([step_stats[k] for k in step_keys], np.float64)
+        arrays[f"it{it}_updates"] = np.array(urec.updates, np.float64)
+        arrays[f"it{it}_final_obs"] = algo.buffer[DataKeys.OBS][:, -1].clone()
+        arrays[f"it{it}_final_rdr"] = algo.buffer[DataKeys.REVERSED_DISCOUNTED_RETURNS][:, -1].clone()
+        if it == 0:  # what iteration 1 starts from
+            for k, v in algo.policy.model.state_dict().items():
+                arrays[f"it0_final_{k}"] = v.clone()
+        else:
+            total_sq = 0.0
+            for k, gval in urec.first_grads.items():
+                arrays[f"it1_first_grad_{k}"] = gval
+                total_sq += float((gval.double() ** 2).sum())
+            arrays["it1_first_clipped_grad_norm"] = np.float64(total_sq ** 0.5)
+    arrays["collect_stat_keys"] = np.array(keys)
+    arrays["step_stat_keys"] = np.array(step_keys)
+    arrays["stat_keys"] = np.array(STAT_KEYS + ("reduce",))
+    arrays["config"] = np.array([f"{k}={v}" for k, v in config_kwargs.items()])
+    save(name, **arrays)
+
+
+def gen_carried_second_iterations() -> None:
+    from examples.cartpole import env as cp_env
+
+    # states re-initialised every 16 sequences of 4 steps = 64 steps = with the environment (data.py:296-309 wants
+    # seq_len * seqs_per_state_reset to divide horizon * horizons_per_env_reset): all of iteration 1 runs on the
+    # states, observations and returns carried over from iteration 0
+    gen_two_iterations("second_iteration_rec_carry.npz", DiscreteDummyEnv,
+                       dict(seq_len=4, seqs_per_state_reset=16, horizons_per_env_reset=2), recurrent=True)
+    cp_env.step = _eager(cp_env.step)
+    gen_two_iterations("second_iteration_ff_cartpole.npz", cp_env.CartPole, dict(horizons_per_env_reset=2))
 
 
 # --------------------------------------------------------------------------- #
@@ -892,6 +975,10 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "second_iterations":
         gen_second_iterations()
+        gen_carried_second_iterations()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "carried":
+        gen_carried_second_iterations()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "cartpole":
         gen_cartpole_first_update()
@@ -940,6 +1027,7 @@ def main() -> None:
     gen_first_updates()
     gen_early_stop()
     gen_second_iterations()
+    gen_carried_second_iterations()
     gen_cartpole_first_update()
 
 

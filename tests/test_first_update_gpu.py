@@ -179,6 +179,136 @@ def test_first_minibatch_of_traced_config_matches_reference_to_1e5(golden, varia
     np.testing.assert_allclose(got[1:, :-1], want[1:, :-1], rtol=2e-2, atol=2e-3)
 
 
+def compare_recurrent_collect(algo, g, it, *, discrete):
+    """Rollout of a recurrent algorithm against the reference's buffer snapshot (actions bit-exact when discrete,
+    floats at the bars of test_algorithm_gpu.run_recurrent_trace with weights identical to the reference's)."""
+    from rl8_amd.data import DataKeys
+
+    buf = algo.buffer
+    got_actions = buf[DataKeys.ACTIONS][:, :HORIZON].cpu().numpy()
+    if discrete:
+        assert np.array_equal(got_actions, g[f"it{it}_collect_actions"][:, :HORIZON])
+    else:
+        np.testing.assert_allclose(got_actions, g[f"it{it}_collect_actions"][:, :HORIZON], rtol=1e-4, atol=1e-4)
+    for key in ("obs", "rewards", "reversed_discounted_returns"):
+        np.testing.assert_allclose(buf[key].cpu().numpy(), g[f"it{it}_collect_{key}"], rtol=1e-5, atol=2e-4, err_msg=key)
+    np.testing.assert_allclose(buf[DataKeys.VALUES].cpu().numpy(), g[f"it{it}_collect_values"], rtol=1e-4, atol=5e-5)
+    for sk in ("hidden_states", "cell_states"):
+        leaf = buf[DataKeys.STATES][sk].cpu().numpy()
+        np.testing.assert_allclose(leaf[:, -1], g[f"it{it}_collect_states_{sk}_last"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(leaf[:, 6], g[f"it{it}_collect_states_{sk}_col6"], rtol=1e-4, atol=2e-5)
+
+
+def teacher_force(algo, g):
+    """Put the algorithm where the REFERENCE stood after its iteration 0: weights, environment state, and the
+    columns collect() carries over (last observation, reversed discounted return, recurrent states:
+    src/rl8/algorithms/_feedforward.py:336-357, _recurrent.py:380-392)."""
+    from rl8_amd.data import DataKeys
+
+    dev = algo.policy.device
+    model = algo.policy.model
+    model.load_state_dict({k: torch.from_numpy(g[f"it0_final_{k}"]) for k in model.state_dict()})
+    algo.buffer[DataKeys.OBS][:, -1].copy_(torch.from_numpy(g["it0_final_obs"]).to(dev))
+    if "it0_final_rdr" in g:
+        algo.buffer[DataKeys.REVERSED_DISCOUNTED_RETURNS][:, -1].copy_(torch.from_numpy(g["it0_final_rdr"]).to(dev))
+    if "it0_env_state" in g:
+        algo.env.state.copy_(torch.from_numpy(g["it0_env_state"]).to(dev))
+    else:
+        algo.env.state.copy_(torch.from_numpy(g["it0_final_obs"]).to(dev))  # the dummy envs' observation is their state
+    if DataKeys.STATES in algo.buffer.keys():
+        for sk in ("hidden_states", "cell_states"):
+            last = torch.from_numpy(g[f"it0_collect_states_{sk}_last"]).to(dev)
+            algo.buffer[DataKeys.STATES][sk][:, -1].copy_(last)
+
+
+def assert_first_update_and_gradient(rec, g2, label):
+    want = g2["it1_updates"]
+    assert len(rec.updates) == len(want)
+    assert_update(rec.updates[0], want[0], label)
+    grads = {k[len("it1_first_grad_"):]: g2[k] for k in g2 if k.startswith("it1_first_grad_")}
+    assert set(grads) == set(rec.first_grads)
+    err_sq = ref_sq = 0.0
+    for k, w in grads.items():
+        got = rec.first_grads[k].double().cpu().numpy()
+        err_sq += float(((got - w) ** 2).sum())
+        ref_sq += float((w.astype(np.float64) ** 2).sum())
+        np.testing.assert_allclose(got, w, rtol=0, atol=2e-5 * float(np.abs(w).max()) + 1e-9, err_msg=f"{label} {k}")
+    assert (err_sq / ref_sq) ** 0.5 < 1e-5, (label, (err_sq / ref_sq) ** 0.5)
+    assert ref_sq ** 0.5 == pytest.approx(float(g2["it1_first_clipped_grad_norm"]), rel=1e-6)
+
+
+@pytest.mark.parametrize("variant", ["rec_discrete", "rec_continuous_minibatch"])
+def test_second_iteration_recurrent_teacher_forced_matches_reference_to_1e5(golden, variant):
+    """The recurrent twins of the test below (tests/golden/second_iteration_rec_*.npz): iteration 1 from the
+    reference's weights after iteration 0, its first update and first gradient at the first-update bar."""
+    g2 = golden(f"second_iteration_{variant}.npz")
+    algo, trace = build(golden, variant)
+    algo.collect()
+    algo.step()
+    teacher_force(algo, trace)
+    inject(algo, trace, 1)
+    algo.collect()
+    compare_recurrent_collect(algo, trace, 1, discrete=variant == "rec_discrete")
+    assert algo.state.reward_scale == pytest.approx(float(trace["it1_reward_scale"]), rel=1e-5)
+    with Recorder(algo) as rec:
+        algo.step()
+    assert_first_update_and_gradient(rec, g2, variant)
+
+
+CARRIED = {
+    # recurrent states, observation and returns carried through a second collect() (nothing re-initialised)
+    "rec_carry": (DiscreteDummyEnv, dict(seq_len=4, seqs_per_state_reset=16, horizons_per_env_reset=2), True),
+    # CartPole's [4, N] physics state carried through a second collect() on a used buffer
+    "ff_cartpole": (CartPole, dict(horizons_per_env_reset=2), False),
+}
+
+
+@pytest.mark.parametrize("variant", list(CARRIED))
+def test_second_iteration_on_carried_state_matches_reference_to_1e5(golden, variant):
+    """Self-contained two-iteration fixtures (generate_fixtures.gen_two_iterations): iteration 0 on the
+    reference's inputs, then iteration 1 teacher-forced from the reference's weights / env state / carried
+    columns -- a rollout that starts from carried LSTM states (src/rl8/algorithms/_recurrent.py:380-392, no
+    re-initialisation inside it) or from CartPole's carried state (examples/cartpole/env.py:138-150), its
+    statistics, the first StatTracker.update and the first gradient at 1e-5."""
+    from rl8_amd.data import DataKeys
+
+    env_cls, config, recurrent = CARRIED[variant]
+    g = golden(f"second_iteration_{variant}.npz")
+    cfg_cls = RecurrentAlgorithmConfig if recurrent else AlgorithmConfig
+    algo = cfg_cls(num_envs=NUM_ENVS, horizon=HORIZON, **config).build(env_cls)
+    algo.policy.model.load_state_dict({k[len("init_"):]: torch.from_numpy(g[k]) for k in g if k.startswith("init_")})
+
+    def check_collect(it):
+        buf = algo.buffer
+        if recurrent:
+            compare_recurrent_collect(algo, g, it, discrete=True)
+        else:
+            assert np.array_equal(buf[DataKeys.ACTIONS][:, :HORIZON].cpu().numpy(), g[f"it{it}_collect_actions"][:, :HORIZON])
+            for key in ("obs", "rewards", "reversed_discounted_returns"):
+                np.testing.assert_allclose(buf[key].cpu().numpy(), g[f"it{it}_collect_{key}"], rtol=2e-6, atol=2e-6,
+                                           err_msg=key)
+            np.testing.assert_allclose(buf[DataKeys.LOGP].cpu().numpy()[:, :HORIZON], g[f"it{it}_collect_logp"][:, :HORIZON],
+                                       rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(buf[DataKeys.VALUES].cpu().numpy(), g[f"it{it}_collect_values"], rtol=1e-5, atol=2e-6)
+
+    inject(algo, g, 0)
+    stats = algo.collect()
+    assert stats["env/resets"] == NUM_ENVS
+    check_collect(0)
+    algo.step()
+    teacher_force(algo, g)
+    inject(algo, g, 1)
+    stats = algo.collect()
+    assert stats["env/resets"] == 0  # nothing was reset: the whole rollout runs on carried state
+    check_collect(1)
+    for k, w in zip(g["collect_stat_keys"], g["it1_collect_stats"]):
+        assert stats[str(k)] == pytest.approx(w, rel=1e-5, abs=1e-5), k
+    assert algo.state.reward_scale == pytest.approx(float(g["it1_reward_scale"]), rel=1e-5)
+    with Recorder(algo) as rec:
+        algo.step()
+    assert_first_update_and_gradient(rec, g, variant)
+
+
 @pytest.mark.parametrize("variant", [v for v in VARIANTS if v.startswith("ff_") and v != "ff_cartpole"])
 def test_second_iteration_teacher_forced_matches_reference_to_1e5(golden, variant):
     """Iteration 1 of the traced configs from the REFERENCE's weights after iteration 0
@@ -204,19 +334,7 @@ def test_second_iteration_teacher_forced_matches_reference_to_1e5(golden, varian
     assert algo.state.reward_scale == pytest.approx(float(trace["it1_reward_scale"]), rel=1e-5)
     with Recorder(algo) as rec:
         algo.step()
-    want = g2["it1_updates"]
-    assert len(rec.updates) == len(want)
-    assert_update(rec.updates[0], want[0], variant)
-    grads = {k[len("it1_first_grad_"):]: g2[k] for k in g2 if k.startswith("it1_first_grad_")}
-    assert set(grads) == set(rec.first_grads)
-    err_sq = ref_sq = 0.0
-    for k, w in grads.items():
-        got = rec.first_grads[k].double().cpu().numpy()
-        err_sq += float(((got - w) ** 2).sum())
-        ref_sq += float((w.astype(np.float64) ** 2).sum())
-        np.testing.assert_allclose(got, w, rtol=0, atol=2e-5 * float(np.abs(w).max()) + 1e-9, err_msg=f"{variant} {k}")
-    assert (err_sq / ref_sq) ** 0.5 < 1e-5, (variant, (err_sq / ref_sq) ** 0.5)
-    assert ref_sq ** 0.5 == pytest.approx(float(g2["it1_first_clipped_grad_norm"]), rel=1e-6)
+    assert_first_update_and_gradient(rec, g2, variant)
 
 
 def test_kl_early_stop_matches_reference(golden):

@@ -12,42 +12,51 @@ from rl8_amd.views import (PaddedRollingWindow, RollingWindow, ViewRequirement, 
                            pad_whole_sequence, rolling_window)
 
 
-def check(prefix, item, g):
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+
+
+def check(prefix, item, g, device="cpu"):
     """Recursively compare a tensor / tensordict with the flattened fixture."""
     if torch.is_tensor(item):
         want = g[prefix]
+        assert item.device.type == device, (prefix, item.device)
         assert tuple(item.shape) == want.shape, (prefix, item.shape, want.shape)
-        assert np.array_equal(item.numpy(), want), prefix
+        assert np.array_equal(item.cpu().numpy(), want), prefix
         return 1
     assert list(item.batch_size) == g[prefix + "__batch"].tolist(), prefix
     keys = sorted(k[len(prefix) + 2:].split("__")[0] for k in g if k.startswith(prefix + "__") and not k.endswith("__batch"))
     assert sorted(item.keys()) == sorted(set(keys)), (prefix, list(item.keys()), keys)
-    return sum(check(f"{prefix}__{k}", item[k], g) for k in item.keys())
+    return sum(check(f"{prefix}__{k}", item[k], g, device) for k in item.keys())
 
 
-def test_view_functions_match_reference_outputs(golden):
+@pytest.mark.parametrize("device", DEVICES)
+def test_view_functions_match_reference_outputs(golden, device):
+    """src/rl8/views.py:121-309 on the device the product runs on: the fixtures hold the
+    reference's outputs, the comparison is exact."""
     g = golden("views.npz")
     checked = 0
     for tag in g["tensor_cases"].tolist():
         name, size = tag.split("_s")
         size = int(size)
-        x = torch.from_numpy(g[f"{name}_x"])
-        checked += check(f"{tag}_pad_last", pad_last_sequence(x, size), g)
-        checked += check(f"{tag}_pad_whole", pad_whole_sequence(x, size), g)
-        checked += check(f"{tag}_padded_all", PaddedRollingWindow.apply_all(x, size), g)
-        checked += check(f"{tag}_padded_last", PaddedRollingWindow.apply_last(x, size), g)
-        checked += check(f"{tag}_rolling_last", RollingWindow.apply_last(x, size), g)
+        x = torch.from_numpy(g[f"{name}_x"]).to(device)
+        checked += check(f"{tag}_pad_last", pad_last_sequence(x, size), g, device)
+        checked += check(f"{tag}_pad_whole", pad_whole_sequence(x, size), g, device)
+        checked += check(f"{tag}_padded_all", PaddedRollingWindow.apply_all(x, size), g, device)
+        checked += check(f"{tag}_padded_last", PaddedRollingWindow.apply_last(x, size), g, device)
+        checked += check(f"{tag}_rolling_last", RollingWindow.apply_last(x, size), g, device)
         if size <= x.shape[1]:
-            checked += check(f"{tag}_window", rolling_window(x, size), g)
-            checked += check(f"{tag}_window_step2", rolling_window(x, size, step=2), g)
-            checked += check(f"{tag}_rolling_all", RollingWindow.apply_all(x, size), g)
+            checked += check(f"{tag}_window", rolling_window(x, size), g, device)
+            checked += check(f"{tag}_window_step2", rolling_window(x, size, step=2), g, device)
+            checked += check(f"{tag}_rolling_all", RollingWindow.apply_all(x, size), g, device)
     assert checked > 150
 
 
-def test_view_requirement_on_nested_tensordict_matches_reference(golden):
+@pytest.mark.parametrize("device", DEVICES)
+def test_view_requirement_on_nested_tensordict_matches_reference(golden, device):
     g = golden("views.npz")
     td = TensorDict(
-        {"obs": TensorDict({"prices": torch.from_numpy(g["td_prices"]), "volume": torch.from_numpy(g["td_volume"])},
+        {"obs": TensorDict({"prices": torch.from_numpy(g["td_prices"]).to(device),
+                            "volume": torch.from_numpy(g["td_volume"]).to(device)},
                            batch_size=[3, 6])},
         batch_size=[3, 6],
     )
@@ -55,29 +64,31 @@ def test_view_requirement_on_nested_tensordict_matches_reference(golden):
         for shift in (0, 2):
             vr = ViewRequirement(shift=shift, method=method)
             tag = f"td_{method}_shift{shift}"
-            check(f"{tag}_all", vr.apply_all("obs", td), g)
-            check(f"{tag}_last", vr.apply_last("obs", td), g)
-            check(f"{tag}_all_leaf", vr.apply_all(("obs", "prices"), td), g)
-            check(f"{tag}_last_leaf", vr.apply_last(("obs", "prices"), td), g)
+            check(f"{tag}_all", vr.apply_all("obs", td), g, device)
+            check(f"{tag}_last", vr.apply_last("obs", td), g, device)
+            check(f"{tag}_all_leaf", vr.apply_all(("obs", "prices"), td), g, device)
+            check(f"{tag}_last_leaf", vr.apply_last(("obs", "prices"), td), g, device)
             assert vr.drop_size == int(g[f"{tag}_drop_size"])
             assert vr.is_identity == (shift == 0)
 
 
-def test_spelled_out_cases():
+@pytest.mark.parametrize("device", DEVICES)
+def test_spelled_out_cases(device):
+    """The exact-tensor cases of the reference's tests/test_views.py:104-498."""
     # pad_last_sequence: T = 1 < size = 2 -> one zero step in front, masked
-    out = pad_last_sequence(torch.arange(4).reshape(4, 1).float(), 2)
+    out = pad_last_sequence(torch.arange(4, device=device).reshape(4, 1).float(), 2)
     assert out[DataKeys.INPUTS].tolist() == [[0, 0], [0, 1], [0, 2], [0, 3]]
     assert out[DataKeys.PADDING_MASK].tolist() == [[True, False]] * 4
     # T = 4 > size = 2 -> the last two steps, nothing masked
-    x = torch.arange(8).reshape(2, 4, 1, 1, 1).float()
+    x = torch.arange(8, device=device).reshape(2, 4, 1, 1, 1).float()
     out = pad_last_sequence(x, 2)
     assert torch.equal(out[DataKeys.INPUTS], x[:, -2:]) and not out[DataKeys.PADDING_MASK].any()
     # pad_whole_sequence: size - 1 zeros in front
-    out = pad_whole_sequence(torch.arange(4).reshape(2, 2).float(), 3)
+    out = pad_whole_sequence(torch.arange(4, device=device).reshape(2, 2).float(), 3)
     assert out[DataKeys.INPUTS].tolist() == [[0, 0, 0, 1], [0, 0, 2, 3]]
     assert out[DataKeys.PADDING_MASK].tolist() == [[True, True, False, False]] * 2
     # rolling_window is a view (no copy) with the window in dimension 2
-    x = torch.arange(12).reshape(2, 6).float()
+    x = torch.arange(12, device=device).reshape(2, 6).float()
     w = rolling_window(x, 3)
     assert w.shape == (2, 4, 3) and w.untyped_storage().data_ptr() == x.untyped_storage().data_ptr()
     assert w[1, 2].tolist() == [8, 9, 10]
