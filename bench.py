@@ -117,6 +117,8 @@ PMC_KERNEL_F16 = {  # the fp16-plane kernels (forward, data gradient), same prof
     "mlp_tower_forward": ("mlp_rows_forward_kernel<1, 2, 0, 4, 0>", 1 << 20),
     # (training forward of a rank-one head keeps the gate bits only: SAVE mode 2; mode 1 stores h2 as well)
     "mlp_tower_forward_save": ("mlp_rows_forward_kernel<1, 2, 2, 4, 0>", 1 << 20),
+    # (round 4: the rollout's launches run in that save mode into the slabs SGD iteration 0 replays: fused_mlp.RolloutRecord)
+    "mlp_tower_forward_record": ("mlp_rows_forward_kernel<1, 2, 2, 4, 0>", 1 << 20),
     "mlp_tower_backward": ("mlp_tower_backward_f16_kernel<1, 2, false>", 1 << 20),
     "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2, false, true>", 1 << 20),  # template <d_in, n_out, LOADH, F16>
 }
@@ -520,7 +522,7 @@ def run(args: argparse.Namespace) -> None:
         if not tower_heads:
             return "f32"
         widths = [(obs_dim, n) for n in tower_heads]
-        if name in ("mlp_tower_forward", "mlp_tower_forward_save"):
+        if name in ("mlp_tower_forward", "mlp_tower_forward_save", "mlp_tower_forward_record"):
             ok = f16 = fused_mlp.FORWARD_GEMM == "f16" and all(hip.mlp_forward_f16_supports(d, n) for d, n in widths)
         elif name == "mlp_wgrad_gate":  # rank-one heads: gate plane x the planes of dOut * h1 (two fp16, or three bf16)
             return "bf16-gate-x3" if os.environ.get("RL8_WGRAD_GATE_PLANES", "f16").startswith("b") else "f16-gatebits-x2"

@@ -619,16 +619,19 @@ def test_first_sgd_iteration_of_a_two_action_policy_stores_no_h2():
             stored.append(out[2] is not None)
         return out
 
-    algo.collect()
     hip.timer.reset()
     hip.timer.enabled = True
     try:
         with patch.object(hip, "mlp_tower_forward_split", spy):
+            algo.collect()
+            # (round 4) the rollout's own launches keep the gate bits of both towers for SGD iteration 0
+            assert stored == [False] * 16, stored     # 8 timesteps x (policy, value): gate bits, never h2
+            del stored[:]
             algo.step()
         launched = hip.timer.summary()
     finally:
         hip.timer.enabled = False
-    assert stored == [False] * 4, stored              # 2 iterations x (policy, value) towers: never h2
+    assert stored == [False] * 2, stored              # iteration 1 x (policy, value) towers: never h2; iteration 0 replays
     assert "mlp_tower_backward_gate" in launched and "mlp_wgrad_gate" in launched
     assert "mlp_tower_backward" not in launched and "mlp_wgrad" not in launched
 
