@@ -460,8 +460,16 @@ int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, const floa
 
 /* Weight gradient of the 256x256 layer: dw2_out [256][256] (+)= dZ2^T h1 over M
  * rows (fp32 MFMA; per-workgroup partial slabs in `workspace`, summed in a fixed
- * order).  workspace: rl8_mlp_wgrad_workspace_bytes() bytes (one 256 x 256 slab per CU + 256 bytes of operand
- * bounds for the fp16-plane kernels), no initialisation. */
+ * order).  workspace: rl8_mlp_wgrad_workspace_bytes() bytes (one 256 x 256 slab per CU + 256 bytes for the
+ * fp16-plane kernels: operand bounds, the guard's sample counts and decision -- written per call -- and, in the
+ * last 128 bytes, two uint32 counters that only grow: [32] calls that consulted the guard, [33] calls it sent to
+ * the exact bf16 planes).  No initialisation needed; zero the last 256 bytes once if the counters are to be read.
+ *
+ * The guard (round 4): the fp16 planes of rl8_mlp_wgrad_fused_split_f32 / rl8_mlp_wgrad_gate_bits_f32 carry 22 bits
+ * of a term within 2^-17 of its column's bound.  Each call samples dOut (one KiB in sixteen) behind the pass that
+ * takes the bounds; if more than 2^-7 of the non-zero entries lie below 2^-12 of the largest, the call's sums are
+ * formed on three exact bf16 planes instead (both generations are launched, one leaves at once: no host round
+ * trip).  RL8_WGRAD_PLANES / RL8_WGRAD_GATE_PLANES = bf16: always the exact planes; = f16!: never (diagnostics). */
 int64_t rl8_mlp_wgrad_workspace_bytes(void);
 int rl8_mlp_wgrad_f32(const float *dz2, const float *h1, int64_t m, float *workspace,
                       float *dw2_out, int accumulate, void *stream);

@@ -71,7 +71,30 @@ struct WgradFusedArgs {
   // ... on fp16 planes (F16): max |dOut column q| at [q], max |x column c| at [4 + c], over the rows of the whole call
   // (wgrad_bounds_kernel), as the bit patterns of non-negative floats
   const uint32_t *bounds = nullptr;
+  // The data-driven choice of planes (round 4): bounds[kGuardFlag] is what wgrad_tail_kernel decided for this call
+  // (0: fp16 planes, 1: the exact bf16 planes); a kernel launched with `guard` set leaves at once unless the flag
+  // equals `guard_want` -- both generations are launched, one of them runs, no host round trip.
+  const uint32_t *guard = nullptr;
+  int guard_want = 0;
 };
+
+// Words of the 64 behind the slabs of the weight-gradient workspace: [0 .. 3] max |dOut column|, [4 .. 8] max |x column|
+// (wgrad_bounds_kernel), then the guard's sample counts, its ticket and its decision -- all zeroed per call -- and two
+// counters that only ever grow (calls that consulted the guard, calls it sent to the bf16 planes), zeroed by whoever
+// allocates the workspace if they are to be read.
+constexpr int kGuardSmall = 9, kGuardNonzero = 10, kGuardTicket = 11, kGuardFlag = 12;
+constexpr int kGuardCalls = 32, kGuardFires = 33;
+// A sampled dOut entry is "small" when it is non-zero and below 2^-kGuardBits of the call's largest; the call goes to
+// the bf16 planes when more than 2^-kGuardShare of the non-zero entries are small.  The fp16 planes carry 22 bits of
+// a term within 2^-17 of its column's bound; a dOut 2^-12 below the largest leaves 5 binades for h1's own range
+// below ITS bound before bits go.  PPO's gradients (a clipped smooth-L1 residual, a normalised advantage times a
+// probability) have a few 1e-4 of their rows that far down; data with rows decades apart (one outlier row, rows of
+// mixed magnitude) has most of them there.
+constexpr int kGuardBits = 12, kGuardShare = 7;
+
+__device__ __forceinline__ bool guard_says_leave(const WgradFusedArgs &fused) {
+  return fused.guard != nullptr && (int)(fused.guard[kGuardFlag] != 0u) != fused.guard_want;
+}
 
 // LOADH: both operands come from memory -- dZ rows at pitch `ops.dz_pitch`, h1 rows at
 // ops.h + row * ops.h_pitch -- instead of h1 being recomputed from the observations:
@@ -109,6 +132,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     WgradOperands ops) {
   static_assert(!LOADH || (DIN > 0 && FUSED == 0), "the two-operand mode: compiled input widths, no head fusion");
   static_assert(!F16 || (DIN > 0 && (FUSED > 0 || LOADH)), "fp16 planes: the fused mode of compiled widths, or both operands loaded");
+  if (guard_says_leave(fused)) return;  // (uniform: the other generation of planes forms this call's sums)
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = FUSED > 0 ? FUSED : 1;
   const int d_in = DIN > 0 ? DIN : d_in_rt;
@@ -643,6 +667,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     const float *__restrict__ b1, int64_t m, float *__restrict__ slabs, WgradFusedArgs fused) {
   static_assert(DIN > 0, "compiled input widths only");
   static_assert(!F16 || BITS, "the fp16 planes go with the gate bits");
+  if (guard_says_leave(fused)) return;  // (uniform: the other generation of planes forms this call's sums)
   constexpr int kIn = DIN, d_in = DIN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = lds_offset(smem);
@@ -1161,6 +1186,95 @@ static uint32_t *launch_wgrad_bounds(hipStream_t s, const float *dout, const flo
   return bounds;
 }
 
+// The guard of the fp16 planes: over a sample of dOut (one KiB in every sixteen, every entry of it) count the non-zero
+// entries and those below 2^-kGuardBits of the call's largest (bounds[0 .. 3], complete when this kernel starts); the
+// last workgroup to arrive turns the counts into the call's flag and bumps the two lifetime counters.
+__global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restrict__ dout, int64_t floats,
+                                                            uint32_t *__restrict__ bounds) {
+  float top = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) top = __builtin_fmaxf(top, __uint_as_float(bounds[q]));
+  const float thr = __builtin_amdgcn_ldexpf(top, -kGuardBits);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kWave, waves = (int64_t)gridDim.x * (kBlock / kWave);
+  constexpr int64_t kPiece = 256, kEvery = 16;  // floats per sampled piece (a wave's 64 x 16 bytes), one piece in sixteen
+  const int64_t pieces = (floats + kPiece * kEvery - 1) / (kPiece * kEvery);
+  const bool vec = ((uintptr_t)dout & 15) == 0;
+  unsigned small = 0, nonzero = 0;
+  for (int64_t p = wave; p < pieces; p += waves) {
+    const int64_t at = p * kPiece * kEvery + 4 * lane;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (vec && at + 4 <= floats) {
+      const f32x4 t = *reinterpret_cast<const f32x4 *>(dout + at);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = t[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (at + i < floats) v[i] = dout[at + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = __builtin_fabsf(v[i]);
+      nonzero += a > 0.0f;
+      small += a > 0.0f && a < thr;
+    }
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    small += __shfl_down(small, off, kWave);
+    nonzero += __shfl_down(nonzero, off, kWave);
+  }
+  __shared__ unsigned red[2][kBlock / kWave];
+  __shared__ bool last;
+  if (lane == 0) {
+    red[0][threadIdx.x / kWave] = small;
+    red[1][threadIdx.x / kWave] = nonzero;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = 0, b = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      a += red[0][w];
+      b += red[1][w];
+    }
+    if (a) atomicAdd(bounds + kGuardSmall, a);
+    if (b) atomicAdd(bounds + kGuardNonzero, b);
+    __threadfence();
+    last = atomicAdd(bounds + kGuardTicket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    const uint64_t a = __hip_atomic_load(bounds + kGuardSmall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t b = __hip_atomic_load(bounds + kGuardNonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned fire = (a << kGuardShare) > b ? 1u : 0u;
+    bounds[kGuardFlag] = fire;
+    bounds[kGuardCalls] += 1u;
+    bounds[kGuardFires] += fire;
+  }
+}
+
+// mode of the planes of a weight-gradient call: RL8_WGRAD_PLANES / RL8_WGRAD_GATE_PLANES = "f16" (default): fp16 planes
+// under the guard; "f16!": fp16 planes whatever the data (diagnostics); "bf16": the exact planes always.  Read per call,
+// so that a diagnostic can form the same gradient all three ways in one process.
+enum PlaneMode { kPlanesGuarded = 0, kPlanesF16 = 1, kPlanesBf16 = 2 };
+static PlaneMode plane_mode(const char *name) {
+  const char *v = getenv(name);
+  if (!v || !v[0]) return kPlanesGuarded;
+  if (v[0] == 'b') return kPlanesBf16;
+  return (v[0] == 'f' && v[1] == '1' && v[2] == '6' && v[3] == '!') ? kPlanesF16 : kPlanesGuarded;
+}
+
+// the guard's decision for the call whose bounds were just requested (same stream, behind wgrad_bounds_kernel)
+static int launch_wgrad_tail(hipStream_t s, const float *dout, int64_t floats, uint32_t *bounds) {
+  const int64_t pieces = (floats + 4095) / 4096;
+  const int64_t want = (pieces + (kBlock / kWave) - 1) / (kBlock / kWave);
+  const int grid = (int)(want < 1 ? 1 : want > 2 * kCUs ? 2 * kCUs : want);
+  wgrad_tail_kernel<<<grid, kBlock, 0, s>>>(dout, floats, bounds);
+  return launch_status();
+}
+
 // flag[0] |= 1 if any row has dout[s][0] + dout[s][1] != 0 (bit patterns: g1 must be exactly -g0).
 __global__ __launch_bounds__(kBlock) void dout_pair_check_kernel(const uint32_t *__restrict__ dout, int64_t m,
                                                                int *__restrict__ flag) {
@@ -1342,18 +1456,21 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
   fused_backward_grids(m, &g1, &g2);
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
-  // RL8_WGRAD_PLANES=bf16: the six-product kernel (A/B runs); default: two fp16 planes per operand, three products
-  static const bool f16 = [] {
-    const char *v = getenv("RL8_WGRAD_PLANES");
-    return !(v && v[0] == 'b');
-  }();
+  // Two fp16 planes per operand, three products -- unless the guard finds this call's dOut spread over too many
+  // binades, or RL8_WGRAD_PLANES=bf16 asks for them always: the six-product kernel on exact bf16 planes.
+  const PlaneMode planes = plane_mode("RL8_WGRAD_PLANES");
+  static const bool gate_kernel = env_int("RL8_WGRAD_GATE_OFF") == 0;
+  // (one output with h2 given: the gate-plane kernel on three exact bf16 planes -- no bounds, nothing to guard)
+  const bool f16 = planes != kPlanesBf16 && !(n_out == 1 && gate_kernel);
   uint32_t *bounds = nullptr;
   if (f16) {
     bounds = n_out == 1 ? launch_wgrad_bounds<1>(s, dout, x, m, d_in, workspace)
              : n_out == 2 ? launch_wgrad_bounds<2>(s, dout, x, m, d_in, workspace)
                           : launch_wgrad_bounds<3>(s, dout, x, m, d_in, workspace);
     if (!bounds) return launch_status() ? launch_status() : RL8_ESIZE;
+    if (planes == kPlanesGuarded && launch_wgrad_tail(s, dout, m * n_out, bounds) != 0) return launch_status();
   }
+  const uint32_t *guard = planes == kPlanesGuarded && f16 ? bounds : nullptr;
   // Segments of kWgradSegmentRows samples, summed in order (see there).  The first one
   // runs the grid the data-gradient kernel counted on (g2 rows of partials written, the
   // rest zeroed); later ones add to as many of those rows as they have workgroups.
@@ -1361,11 +1478,12 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
     const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
     const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
     const int grid = at == 0 ? g2 : (int)(chunks < g2 ? chunks : g2);
-    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0, nullptr, nullptr, bounds};
+    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0, nullptr, nullptr, bounds, guard, 0};
+    WgradFusedArgs exact = fused;  // the same segment on the bf16 planes, should the guard have said so
+    exact.guard_want = 1;
     const float *h2s = h2 + at * kHidden, *xs = x + at * d_in;
     int status = RL8_ESIZE;
     // one output: the gate-plane kernel (three plane products per 16 samples instead of six)
-    static const bool gate_kernel = env_int("RL8_WGRAD_GATE_OFF") == 0;
     if (n_out == 1 && gate_kernel) {
       switch (d_in) {
         case 1: status = launch_wgrad_gate<1>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
@@ -1378,9 +1496,11 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
       continue;
     }
 #define RL8_WGRAD_FUSED(D, N) \
-  if (d_in == D && n_out == N) \
+  if (d_in == D && n_out == N) { \
     status = f16 ? launch_wgrad_fused<D, N, true>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused) \
-                 : launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused);
+                 : launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused); \
+    if (status == 0 && guard) status = launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, exact); \
+  }
     RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3)
     RL8_WGRAD_FUSED(2, 1) RL8_WGRAD_FUSED(2, 2) RL8_WGRAD_FUSED(2, 3)
     RL8_WGRAD_FUSED(3, 1) RL8_WGRAD_FUSED(3, 2) RL8_WGRAD_FUSED(3, 3)
@@ -1456,29 +1576,36 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   const int off_dw3 = kHidden * d_in + 2 * kHidden;
   hipStream_t s = (hipStream_t)stream;
-  // RL8_WGRAD_GATE_PLANES=bf16: the three-plane kernel (A/B runs); default: two fp16 planes
-  static const bool f16 = [] {
-    const char *v = getenv("RL8_WGRAD_GATE_PLANES");
-    return !(v && v[0] == 'b');
-  }();
+  // Two fp16 planes of dOut * h1 -- unless the guard finds this call's dOut spread over too many binades, or
+  // RL8_WGRAD_GATE_PLANES=bf16 asks for them always: the three exact bf16 planes.
+  const PlaneMode planes = plane_mode("RL8_WGRAD_GATE_PLANES");
+  const bool f16 = planes != kPlanesBf16;
   uint32_t *bounds = nullptr;
   if (f16) {
     bounds = n_out == 2 ? launch_wgrad_bounds<2>(s, dout, x, m, d_in, workspace) : launch_wgrad_bounds<1>(s, dout, x, m, d_in, workspace);
     if (!bounds) return launch_status() ? launch_status() : RL8_ESIZE;
+    if (planes == kPlanesGuarded && launch_wgrad_tail(s, dout, m * n_out, bounds) != 0) return launch_status();
   }
+  const uint32_t *guard = planes == kPlanesGuarded ? bounds : nullptr;
   for (int64_t at = 0; at < m; at += kWgradSegmentRows) {  // segments summed in order, as rl8_mlp_wgrad_fused_split_f32
     const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
     const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
     const int grid = at == 0 ? g2 : (int)(chunks < g2 ? chunks : g2);
-    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0, gate2 + at * 8, b2, bounds};
+    const WgradFusedArgs fused{dout + at * n_out, w3, partials, stride, g1, at > 0, gate2 + at * 8, b2, bounds, guard, 0};
+    WgradFusedArgs exact = fused;  // the same segment on the bf16 planes, should the guard have said so
+    exact.guard_want = 1;
     const float *xs = x + at * d_in;
     int status = RL8_ESIZE;
 #define RL8_WGRAD_BITS(D) \
-  if (d_in == D) \
+  if (d_in == D) { \
     status = f16 ? (n_out == 2 ? launch_wgrad_gate<D, true, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
                                : launch_wgrad_gate<D, false, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused)) \
            : n_out == 2 ? launch_wgrad_gate<D, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
-                        : launch_wgrad_gate<D, false, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused);
+                        : launch_wgrad_gate<D, false, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused); \
+    if (status == 0 && guard) \
+      status = n_out == 2 ? launch_wgrad_gate<D, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, exact) \
+                          : launch_wgrad_gate<D, false, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, exact); \
+  }
     RL8_WGRAD_BITS(1) RL8_WGRAD_BITS(2) RL8_WGRAD_BITS(3) RL8_WGRAD_BITS(5)
 #undef RL8_WGRAD_BITS
     if (status != 0) return status;

@@ -1135,8 +1135,19 @@ def _wgrad_workspace(device: torch.device) -> torch.Tensor:
     ws = _wgrad_ws.get(key)
     if ws is None:
         ws = torch.empty(int(load().rl8_mlp_wgrad_workspace_bytes()) // 4, dtype=torch.float32, device=device)
+        ws[-64:].zero_()  # (the guard's lifetime counters live there: include/rl8_amd.h, rl8_mlp_wgrad_workspace_bytes)
         _wgrad_ws[key] = ws
     return ws
+
+
+def wgrad_guard_counts() -> tuple[int, int]:
+    """(weight-gradient calls that consulted the guard of the fp16 planes, calls it sent to the exact bf16 planes)
+    over the lifetime of this process's workspaces; one host sync."""
+    calls = fires = 0
+    for ws in _wgrad_ws.values():
+        words = ws[-64:].view(torch.int32)[32:34].tolist()
+        calls, fires = calls + words[0], fires + words[1]
+    return calls, fires
 
 
 def mlp_wgrad_split(dz2: torch.Tensor, x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
@@ -1163,11 +1174,7 @@ def mlp_wgrad(dz2: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
     if dz2.shape != h1.shape or dz2.shape[1] != MLP_HIDDEN:
         raise ValueError("dz2 and h1 must both be [M, 256]")
     lib = load()
-    key = (dz2.device.index if dz2.device.index is not None else torch.cuda.current_device(), _stream())
-    ws = _wgrad_ws.get(key)
-    if ws is None:
-        ws = torch.empty(int(lib.rl8_mlp_wgrad_workspace_bytes()) // 4, dtype=torch.float32, device=dz2.device)
-        _wgrad_ws[key] = ws
+    ws = _wgrad_workspace(dz2.device)
     out = torch.empty(MLP_HIDDEN, MLP_HIDDEN, dtype=torch.float32, device=dz2.device)
     with _timed("mlp_wgrad", dz2.shape[0]):
         _check(lib.rl8_mlp_wgrad_f32(_ptr(dz2), _ptr(h1), dz2.shape[0], _ptr(ws), _ptr(out), 0, _stream()),
@@ -1445,10 +1452,7 @@ def lstm_backward(
                                              _ptr(whht_packed), _ptr(dgates), _ptr(partials), C.byref(rows), _stream()),
                    "rl8_lstm_backward_f32")
     m = b * l
-    key = (dev.index or 0, _stream() or 0)
-    ws = _wgrad_ws.get(key)
-    if ws is None:
-        ws = _wgrad_ws[key] = torch.empty(int(lib.rl8_mlp_wgrad_workspace_bytes()) // 4, dtype=torch.float32, device=dev)
+    ws = _wgrad_workspace(dev)
     dw_hh = torch.empty(4 * H, H, dtype=torch.float32, device=dev)
     # per gate and timestep dW_hh[q] += dG_q^T h_{t-1} over the B rows of that step: h_{t-1} is
     # h0 for t = 0 and hs[:, t-1] (row pitch L*256) after, so no shifted copy of hs is made

@@ -333,6 +333,44 @@ def test_cartpole_learns():
     assert last > first + 0.2 * abs(first), (first, last)
 
 
+def learning_curve_ends(env_cls, iterations, monkeypatch, **config):
+    """Last mean return of a short run, for two seeds, under the shipped weight-gradient planes (fp16 under the guard)
+    and under the exact bf16 planes (RL8_WGRAD_PLANES / RL8_WGRAD_GATE_PLANES = bf16)."""
+    ends = {}
+    for planes in ("f16", "bf16"):
+        for name in ("RL8_WGRAD_PLANES", "RL8_WGRAD_GATE_PLANES"):
+            if planes == "bf16":
+                monkeypatch.setenv(name, "bf16")
+            else:
+                monkeypatch.delenv(name, raising=False)
+        for seed in (0, 1):
+            torch.manual_seed(seed)
+            algo = AlgorithmConfig(**config).build(env_cls)
+            first = algo.collect()["returns/mean"]
+            algo.step()
+            for _ in range(iterations):
+                last = algo.collect()["returns/mean"]
+                algo.step()
+            ends[planes, seed] = (first, last)
+    return ends
+
+
+def assert_same_learning(ends, gain):
+    """Every run improves by `gain`; the two plane schemes end within the seed-to-seed spread of each other (VERDICT r3
+    item 3c: the fp16 planes must not change what is learned)."""
+    for (planes, seed), (first, last) in ends.items():
+        assert last > first + gain * abs(first), (planes, seed, first, last)
+    mean = {p: 0.5 * (ends[p, 0][1] + ends[p, 1][1]) for p in ("f16", "bf16")}
+    spread = max(abs(ends[p, 0][1] - ends[p, 1][1]) for p in ("f16", "bf16"))
+    assert abs(mean["f16"] - mean["bf16"]) <= spread + 0.05 * abs(mean["bf16"]), (ends, spread)
+
+
+def test_cartpole_learns_the_same_under_both_plane_schemes(monkeypatch):
+    from rl8_amd.envs.cartpole import CartPole
+
+    assert_same_learning(learning_curve_ends(CartPole, 30, monkeypatch, horizon=64, num_envs=4096), 0.2)
+
+
 # --- recurrent algorithm (BASELINE config 5 shape, small) ----------------------
 def run_recurrent_trace(golden, name, env_cls, *, discrete, **config):
     from rl8_amd import RecurrentAlgorithmConfig

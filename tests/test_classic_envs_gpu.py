@@ -203,3 +203,10 @@ def test_pendulum_learns():
         last = algo.collect()["returns/mean"]
         algo.step()
     assert last > first + 0.1 * abs(first), (first, last)
+
+
+def test_pendulum_learns_the_same_under_both_plane_schemes(monkeypatch):
+    from .test_algorithm_gpu import assert_same_learning, learning_curve_ends
+
+    ends = learning_curve_ends(Pendulum, 40, monkeypatch, horizon=128, num_envs=4096, horizons_per_env_reset=4)
+    assert_same_learning(ends, 0.1)

@@ -197,11 +197,11 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
     samples carry most of the gradient): the data-gradient kernel scales per ROW, the
     weight-gradient kernel per output COLUMN (its sum runs over the rows).  Every gradient against
     fp64 on the saved activations, entry by entry relative to the sum of the magnitudes of the
-    entry's terms, beside the fp32-MFMA kernels' own error.  dW2 is the one place where the planes
+    entry's terms, beside the fp32-MFMA kernels' own error.  dW2 is the one place where the fp16 planes
     give up something against fp32 products: a term 2^17 below its column's bound no longer carries
-    22 bits, so an entry made only of small rows keeps ~1e-5 of its own size (measured: 1.6e-5 /
-    4.7e-5 with rows six decades apart; fp32 MFMAs 6e-7 / 2e-6) -- against the tensor it is held
-    to the fp32 kernels' level."""
+    22 bits, so an entry made only of small rows keeps ~1e-5 of its own size (round 3, unguarded: 1.6e-5 /
+    4.7e-5 with rows six decades apart; fp32 MFMAs 6e-7 / 2e-6).  Since round 4 a guard looks at the spread of
+    |dOut| in every call (wgrad_tail_kernel) and sends such calls to the exact bf16 planes."""
     m, d_in = 20_000, 3
     g = torch.Generator(device=DEV).manual_seed(23)
     x = torch.randn(m, d_in, device=DEV, generator=g) * 3
@@ -228,8 +228,17 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
     # the scale of a gradient entry: the sum of the magnitudes of its terms (what an fp32 sum is accurate against)
     size = {"w1": dz1.abs().T @ x.double().abs(), "b1": dz1.abs().sum(0), "w2": dz2.abs().T @ a1, "b2": dz2.abs().sum(0),
             "w3": d.abs().T @ a2}
+    consulted0, fired0 = hip.wgrad_guard_counts()
     got = hip.mlp_tower_backward(x, None, h2, dout, hip.mlp_pack_w2_f16(p["w2"], transposed=True), p["w3"], p["w1"], p["b1"],
                                  gate2=gate)
+    consulted, fired = (a - b for a, b in zip(hip.wgrad_guard_counts(), (consulted0, fired0)))
+    # Round 4: the guard.  dOut with rows decades apart goes to the exact bf16 planes by itself (device-side flag);
+    # what it lets through the fp16 planes holds the fp32 kernels' bar ENTRY BY ENTRY again.  (One output with h2
+    # given runs the gate kernel on exact bf16 planes: nothing to guard.)
+    if n_out == 2:
+        assert consulted == 1 and fired == int(case in ("rows_of_mixed_magnitude", "one_outlier_row")), (case, consulted, fired)
+    else:
+        assert consulted == 0
     # yardstick: the fp32-MFMA generation on the same saved activations
     got6 = hip.mlp_tower_backward(x, h1, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
     for k in want:
@@ -239,12 +248,7 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
         err6 = float(((got6[k].double() - want[k]).abs() / (size[k] + floor)).max())
         # (the absolute bar is the fp32 accumulators' own: with one row 10^6 above the rest both generations sit at 5e-6 .. 3e-5)
         assert err < 1e-4, (k, err, err6)
-        if k == "w2":  # entrywise see the docstring; against the tensor's largest entry: the fp32 kernels' level
-            top = float(want[k].abs().max()) + 1e-300
-            norm, norm6 = (float((t[k].double() - want[k]).abs().max()) / top for t in (got, got6))
-            assert norm <= 3 * norm6 + 5e-7, (k, norm, norm6)
-        else:
-            assert err <= 3 * err6 + 2e-7, (k, err, err6)
+        assert err <= 3 * err6 + 2e-7, (case, k, err, err6)
 
 
 @pytest.mark.parametrize("case", ["plain", "rows_of_mixed_magnitude", "one_outlier_row", "clipped_rows", "outlier_weights"])
@@ -371,6 +375,60 @@ def test_rank_one_backward_from_the_gate_bits_alone(m, d_in, n_out, x_scale):
         assert calls == [1] and not info["rank_one"]
         for k in late:
             assert torch.equal(late[k], general[k]), k
+
+
+@pytest.mark.parametrize("n_out", [1, 2])
+@pytest.mark.parametrize("case,fires", [("plain", False), ("clipped_rows", False), ("rows_of_mixed_magnitude", True),
+                                         ("one_outlier_row", True), ("few_small_rows", False), ("many_small_rows", True)])
+def test_guard_picks_the_planes_of_the_gate_bits_weight_gradient_from_the_data(case, fires, n_out, monkeypatch):
+    """rl8_mlp_wgrad_gate_bits_f32 (the headline's weight gradient) under its guard: the call's dOut is sampled on the
+    device; spread over too many binades it is summed on the exact bf16 planes -- bit for bit what
+    RL8_WGRAD_GATE_PLANES=bf16 gives -- otherwise on the two fp16 planes, bit for bit the unguarded kernel; no host
+    round trip either way, and the lifetime counters say which way it went.  Entry by entry against fp64, relative
+    to the entry's own sum of |terms|: what the guard lets through stays within 3x the exact planes' error + 2e-7."""
+    m, d_in = 150_000, 1
+    g = torch.Generator(device=DEV).manual_seed(3 + n_out)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 40
+    p = _params(g, d_in, n_out)
+    g0 = torch.randn(m, device=DEV, generator=g) / m
+    if case == "clipped_rows":
+        g0[torch.rand(m, device=DEV, generator=g) < 0.7] = 0.0
+    elif case == "rows_of_mixed_magnitude":
+        g0 *= 10.0 ** torch.randint(-4, 3, (m,), device=DEV, generator=g).float()
+    elif case == "one_outlier_row":
+        g0[m // 3] *= 1e6
+    elif case == "few_small_rows":     # 0.2 % of the rows 2^-20 down: below the guard's share (2^-7)
+        g0[torch.rand(m, device=DEV, generator=g) < 0.002] *= 2.0 ** -20
+    elif case == "many_small_rows":    # 5 % of them: above it
+        g0[torch.rand(m, device=DEV, generator=g) < 0.05] *= 2.0 ** -20
+    dout = (torch.stack([g0, -g0], 1) if n_out == 2 else g0[:, None]).contiguous()
+    w2p, w2t = hip.mlp_pack_w2_f16(p["w2"]), hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+    _, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True,
+                                                 save_h1=False, save_gate=True)
+    gate_pack = lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])  # noqa: E731
+
+    def backward(mode):
+        if mode is None:
+            monkeypatch.delenv("RL8_WGRAD_GATE_PLANES", raising=False)
+        else:
+            monkeypatch.setenv("RL8_WGRAD_GATE_PLANES", mode)
+        before = hip.wgrad_guard_counts()
+        out = hip.mlp_tower_backward(x, None, None, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack,
+                                     w2=p["w2"], b2=p["b2"])
+        return out, tuple(a - b for a, b in zip(hip.wgrad_guard_counts(), before))
+
+    shipped, counts = backward(None)
+    unguarded, counts_f16 = backward("f16!")
+    exact, counts_bf16 = backward("bf16")
+    assert counts == (1, int(fires)) and counts_f16 == (0, 0) and counts_bf16 == (0, 0)
+    for k in shipped:
+        assert torch.equal(shipped[k], (exact if fires else unguarded)[k]), (case, k)
+    h1 = torch.relu(x @ p["w1"].T + p["b1"]).double()
+    dz2 = (dout.double() @ p["w3"].double()) * (h2 > 0)
+    want, size = dz2.T @ h1, dz2.abs().T @ h1
+    floor = size.max() * 1e-30 + 1e-300
+    err, err_exact = (float(((t["w2"].double() - want).abs() / (size + floor)).max()) for t in (shipped, exact))
+    assert err <= 3 * err_exact + 2e-7, (case, err, err_exact)
 
 
 @pytest.mark.parametrize("m,d_in", [(1, 1), (129, 1), (1000, 5), (4097, 3), (40_000, 1), (9000, 2)])
