@@ -79,18 +79,21 @@ struct WgradFusedArgs {
 };
 
 // Words of the 64 behind the slabs of the weight-gradient workspace: [0 .. 3] max |dOut column|, [4 .. 8] max |x column|
-// (wgrad_bounds_kernel), then the guard's sample counts, its ticket and its decision -- all zeroed per call -- and two
+// (wgrad_bounds_kernel), then the guard's sample sums, its ticket and its decision -- all zeroed per call -- and two
 // counters that only ever grow (calls that consulted the guard, calls it sent to the bf16 planes), zeroed by whoever
 // allocates the workspace if they are to be read.
-constexpr int kGuardSmall = 9, kGuardNonzero = 10, kGuardTicket = 11, kGuardFlag = 12;
+constexpr int kGuardSum = 8 + 2 /* two words: a uint64, 8-byte aligned */, kGuardNonzero = 12, kGuardTicket = 13, kGuardFlag = 14;
 constexpr int kGuardCalls = 32, kGuardFires = 33;
-// A sampled dOut entry is "small" when it is non-zero and below 2^-kGuardBits of the call's largest; the call goes to
-// the bf16 planes when more than 2^-kGuardShare of the non-zero entries are small.  The fp16 planes carry 22 bits of
-// a term within 2^-17 of its column's bound; a dOut 2^-12 below the largest leaves 5 binades for h1's own range
-// below ITS bound before bits go.  PPO's gradients (a clipped smooth-L1 residual, a normalised advantage times a
-// probability) have a few 1e-4 of their rows that far down; data with rows decades apart (one outlier row, rows of
-// mixed magnitude) has most of them there.
-constexpr int kGuardBits = 12, kGuardShare = 7;
+// What the guard measures ("bound / mean |term|"): how far below the largest |dOut| of the call the
+// non-zero entries sit ON AVERAGE.  The planes are scaled by the column's bound, which carries max |dOut| as a factor;
+// a term 2^-a below the bound keeps min(22, 39 - a) bits (fp16 planes; 50 - a with the wide low plane of the gate
+// kernel).  When max / mean is moderate -- PPO's gradients at 2^25 rows: 2^1 .. 2^5, tools/diag/wgrad_planes_real_ppo.py
+// -- an entry of the sum is dominated by terms that keep all their bits, however long the tail of small rows is (those
+// add an absolute error of 2^-39 of the bound each: with R = max / mean the sum is off by at most 2^-39 R of its own
+// size).  One row 10^6 above the rest turns that around: every other term is "small", R = 2^20 and more.  The call goes
+// to the exact bf16 planes when R > 2^kGuardRatio.  (Integer arithmetic on 24-bit fractions of the maximum: the decision
+// does not depend on the order of the atomics.)
+constexpr int kGuardRatio = 12;
 
 __device__ __forceinline__ bool guard_says_leave(const WgradFusedArgs &fused) {
   return fused.guard != nullptr && (int)(fused.guard[kGuardFlag] != 0u) != fused.guard_want;
@@ -232,6 +235,19 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       planes[1][e >> 1] = lo;
     }
   };
+  // (round 4) the dZ2 operand -- the one that carries dOut's dynamic range -- with a WIDE low plane: 2^11 x the residual,
+  // 22 bits of a value down to 2^-27 of its column's bound instead of 2^-17 (f16_pair_scaled_wide)
+  [[maybe_unused]] const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));  // 2048.0f, scalar
+  [[maybe_unused]] const uint32_t k_low = (uint32_t)__builtin_amdgcn_readfirstlane((int)kF16GateLowMask);   // fp16 {2^-11, 2^-11}
+  [[maybe_unused]] auto split8h_wide = [&](const float (&v)[8], float scale, u32x4 (&planes)[3]) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      uint32_t hi, lo;
+      f16_pair_scaled_wide(v[e], v[e + 1], scale, k2048, hi, lo);
+      planes[0][e >> 1] = hi;
+      planes[1][e >> 1] = lo;
+    }
+  };
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   // Observations and dOut of the eight samples a wave produces are wave-uniform: with
   // DIN known they sit in scalar registers, fetched (kIn + kOut loads of eight floats)
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
                      u32x4 (&pb)[3]) {
     if constexpr (LOADH) {
       if constexpr (F16) {
-        split8h(dzv, scale_a, pa);
+        split8h_wide(dzv, scale_a, pa);
         split8h(hv, scale_b, pb);
       } else {
         split8(dzv, pa);
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
         dz[e] = dzv[e] > 0.0f ? g : 0.0f;
         db2a += dz[e];
       }
-      if constexpr (F16) split8h(dz, scale_a, pa);
+      if constexpr (F16) split8h_wide(dz, scale_a, pa);
       else split8(dz, pa);
     } else {
       split8(dzv, pa);
@@ -380,8 +396,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       // ah / am: hi / lo planes of dZ2^T, bh / bm: of h1.  The first product's six fragments are requested in front of
       // the next chunk's production (which does not depend on them), the other six behind it: they land under the
       // first product.  (All twelve in front: the wider variants spilled.)
-      f.am[0] = lds_read_b128<kWsPlane>(ar);
-      f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
+      // (round 4: hi x hi first, lo x hi last -- the wide low plane of dZ2, 2^11 x its residual, meets the h1 hi
+      // fragments times 2^-11, formed in place once hi x hi, the product that reads them as they are, is issued)
+      f.ah[0] = lds_read_b128<0>(ar);
+      f.ah[1] = lds_read_b128<512>(ar);
       f.bh[0] = lds_read_b128<0>(br);
       f.bh[1] = lds_read_b128<512>(br);
       f.bh[2] = lds_read_b128<1024>(br);
@@ -398,7 +416,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
           }
         }
         u32x4 pl[3];
-        split8h(dzq[0], scale_a, pl);
+        split8h_wide(dzq[0], scale_a, pl);
         lds_write_b128<0>(addr, pl[0]);
         lds_write_b128<kWsPlane>(addr, pl[1]);
         load_dz(dzq[0], n + 2);
@@ -413,20 +431,24 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
         produce(dzq[P ^ 1], dzq[P ^ 1], n + 1, pa, pb);
         write_planes(P ^ 1, pa, pb);
       }
-      f.ah[0] = lds_read_b128<0>(ar);
-      f.ah[1] = lds_read_b128<512>(ar);
+      f.am[0] = lds_read_b128<kWsPlane>(ar);
+      f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
       f.bm[0] = lds_read_b128<kWsPlane>(br);
       f.bm[1] = lds_read_b128<kWsPlane + 512>(br);
       f.bm[2] = lds_read_b128<kWsPlane + 1024>(br);
       f.bm[3] = lds_read_b128<kWsPlane + 1536>(br);
-      wait_lds<6>(f.am[0], f.am[1], f.bh[0], f.bh[1], f.bh[2], f.bh[3]);  // only LDS operations in flight: in-order count
+      wait_lds<6>(f.ah[0], f.ah[1], f.bh[0], f.bh[1], f.bh[2], f.bh[3]);  // only LDS operations in flight: in-order count
       __builtin_amdgcn_sched_barrier(0);
-      f16_mma<FIRST>(f.am, f.bh, acc);  // lo x hi
+      f16_mma<FIRST>(f.ah, f.bh, acc);  // hi x hi
       request_scalars(n + 2);
-      wait_lds<0>(f.ah[0], f.ah[1], f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
+      wait_lds<0>(f.am[0], f.am[1], f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
       __builtin_amdgcn_sched_barrier(0);
       f16_mma<false>(f.ah, f.bm, acc);  // hi x lo
-      f16_mma<false>(f.ah, f.bh, acc);  // hi x hi
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f.bh[t][r] = f16_pair_times(f.bh[t][r], k_low);  // h1 hi planes x 2^-11, in place
+      f16_mma<false>(f.am, f.bh, acc);  // (2^11 lo) x (2^-11 hi)
       __builtin_amdgcn_sched_barrier(0);
       lds_barrier();
       scalars_landed();
@@ -687,6 +709,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
 #pragma unroll
   for (int c = 0; c < kIn; ++c) w1r[c] = w1[col * d_in + c];
   const float b1r = b1[col];
+  [[maybe_unused]] float b1r_scaled = b1r;  // F16: b1 times the column's power of two
   float gsum = 0.0f, dw3a = 0.0f;  // sum_s G dOut (db2 / W3) and dW3 of this thread's column and sample half
   if constexpr (F16) {
     float hb = __builtin_fabsf(b1r);
@@ -696,6 +719,11 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     const int e = f16_bound_exponent(__uint_as_float(fused.bounds[0]) * hb * 1.0001f);
     col_scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
     if (kh == 0) inv_scales[col] = __builtin_amdgcn_ldexpf(1.0f, e - kF16Top);
+    // (round 4) the power of two goes into layer 1 itself -- relu(x . (s w1) + s b1) = s h1 exactly -- and the planes are
+    // formed from the exact product (s h1) * dOut: one multiplication less per element, one rounding less per term
+#pragma unroll
+    for (int c = 0; c < kIn; ++c) w1r[c] *= col_scale;
+    b1r_scaled = b1r * col_scale;
   }
 
   const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
@@ -747,6 +775,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     scalar_tie(dq);
     if constexpr (PAIR) scalar_tie(dq_hi);
   };
+  [[maybe_unused]] const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));  // 2048.0f, scalar
   // The chunk's operands -> stage `stage` (free from the previous step's barrier on): the
   // gate plane, then the three planes of dOut * h1, each written as soon as it is formed.
   auto produce = [&](const float (&h2v)[8], int stage) {
@@ -780,17 +809,17 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     float b[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = b1r;
+      float v = F16 ? b1r_scaled : b1r;
 #pragma unroll
       for (int c = 0; c < kIn; ++c) v = __builtin_fmaf(xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], w1r[c], v);
-      b[e] = relu1(v) * dout_of(e);
+      b[e] = F16 ? relu1(v) : relu1(v) * dout_of(e);
     }
     if constexpr (F16) {
       u32x4 planes[2];
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
         uint32_t hi, lo;
-        f16_pair_scaled(b[e], b[e + 1], col_scale, hi, lo);
+        f16_pair_product_wide(b[e], b[e + 1], dout_of(e), dout_of(e + 1), k2048, hi, lo);
         planes[0][e >> 1] = hi;
         planes[1][e >> 1] = lo;
       }
@@ -871,7 +900,15 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
       if constexpr (P == 0) first_reads(P1{}, std::integral_constant<int, (S + 1) & 3>{});
       else first_reads(P0{}, std::integral_constant<int, (S + 1) & 3>{});
       __builtin_amdgcn_sched_barrier(0);
-      f16_mma<false>(G, Y, acc);  // gate x lo
+      {
+        // the wide low plane holds 2^11 x the residual: its gate is 2^-11 where the hi product's is 1.0
+        u32x4 GL[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) GL[t][r] = G[t][r] & kF16GateLowMask;
+        f16_mma<false>(GL, Y, acc);  // (2^-11 gate) x (2^11 lo)
+      }
       __builtin_amdgcn_sched_barrier(0);
       {
         u32x4(&GN)[2] = *(P == 0 ? &f.am : &f.ah);
@@ -1187,20 +1224,22 @@ static uint32_t *launch_wgrad_bounds(hipStream_t s, const float *dout, const flo
 }
 
 // The guard of the fp16 planes: over a sample of dOut (one KiB in every sixteen, every entry of it) count the non-zero
-// entries and those below 2^-kGuardBits of the call's largest (bounds[0 .. 3], complete when this kernel starts); the
-// last workgroup to arrive turns the counts into the call's flag and bumps the two lifetime counters.
+// entries and add up |entry| / max as 24-bit fractions (max: the call's largest, bounds[0 .. 3], complete when this kernel
+// starts); the last workgroup to arrive turns the sums into the call's flag and bumps the two lifetime counters.
 __global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restrict__ dout, int64_t floats,
                                                             uint32_t *__restrict__ bounds) {
   float top = 0.0f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) top = __builtin_fmaxf(top, __uint_as_float(bounds[q]));
-  const float thr = __builtin_amdgcn_ldexpf(top, -kGuardBits);
+  // (max == 0: no entry counts)
+  const float inv = top > 0.0f ? 1.0f / top : 0.0f;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kWave, waves = (int64_t)gridDim.x * (kBlock / kWave);
   constexpr int64_t kPiece = 256, kEvery = 16;  // floats per sampled piece (a wave's 64 x 16 bytes), one piece in sixteen
   const int64_t pieces = (floats + kPiece * kEvery - 1) / (kPiece * kEvery);
   const bool vec = ((uintptr_t)dout & 15) == 0;
-  unsigned small = 0, nonzero = 0;
+  unsigned long long sum = 0;
+  unsigned nonzero = 0;
   for (int64_t p = wave; p < pieces; p += waves) {
     const int64_t at = p * kPiece * kEvery + 4 * lane;
     float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1217,28 +1256,32 @@ __global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restr
     for (int i = 0; i < 4; ++i) {
       const float a = __builtin_fabsf(v[i]);
       nonzero += a > 0.0f;
-      small += a > 0.0f && a < thr;
+      const float frac = a > 0.0f ? __builtin_fminf(a * inv, 1.0f) * 16777216.0f : 0.0f;  // (NaN: fminf -> 1)
+      sum += (unsigned long long)(unsigned)frac;
     }
   }
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) {
-    small += __shfl_down(small, off, kWave);
+    sum += __shfl_down(sum, off, kWave);
     nonzero += __shfl_down(nonzero, off, kWave);
   }
-  __shared__ unsigned red[2][kBlock / kWave];
+  __shared__ unsigned long long red_sum[kBlock / kWave];
+  __shared__ unsigned red_nz[kBlock / kWave];
   __shared__ bool last;
   if (lane == 0) {
-    red[0][threadIdx.x / kWave] = small;
-    red[1][threadIdx.x / kWave] = nonzero;
+    red_sum[threadIdx.x / kWave] = sum;
+    red_nz[threadIdx.x / kWave] = nonzero;
   }
   __syncthreads();
+  unsigned long long *total = reinterpret_cast<unsigned long long *>(bounds + kGuardSum);
   if (threadIdx.x == 0) {
-    unsigned a = 0, b = 0;
+    unsigned long long a = 0;
+    unsigned b = 0;
     for (int w = 0; w < kBlock / kWave; ++w) {
-      a += red[0][w];
-      b += red[1][w];
+      a += red_sum[w];
+      b += red_nz[w];
     }
-    if (a) atomicAdd(bounds + kGuardSmall, a);
+    if (a) atomicAdd(total, a);
     if (b) atomicAdd(bounds + kGuardNonzero, b);
     __threadfence();
     last = atomicAdd(bounds + kGuardTicket, 1u) == gridDim.x - 1;
@@ -1246,9 +1289,10 @@ __global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restr
   __syncthreads();
   if (last && threadIdx.x == 0) {
     __threadfence();
-    const uint64_t a = __hip_atomic_load(bounds + kGuardSmall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t b = __hip_atomic_load(bounds + kGuardNonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned fire = (a << kGuardShare) > b ? 1u : 0u;
+    const unsigned long long a = __hip_atomic_load(total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(bounds + kGuardNonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // max / mean > 2^kGuardRatio  <=>  count * 2^24 > 2^kGuardRatio * sum of the 24-bit fractions
+    const unsigned fire = (b << (24 - kGuardRatio)) > a ? 1u : 0u;
     bounds[kGuardFlag] = fire;
     bounds[kGuardCalls] += 1u;
     bounds[kGuardFires] += fire;

@@ -276,6 +276,49 @@ __device__ __forceinline__ void f16_pair_scaled(float x0, float x1, float s, uin
       : "v"(x0), "v"(x1), "v"(s));
 }
 
+// The product t0 * d0, t1 * d1 (t in vector registers, d wave-uniform in scalar registers) as a packed fp16 pair
+// hi = fp16(t * d) -- ONE rounding of the exact product -- and a WIDE low plane lo = fp16(2^11 (t * d - hi)): the residual
+// (exact in fp32: v_fma_mix_f32 subtracts the fp16 value it just formed from the exact product) is scaled up before it
+// is rounded, so that it stays a normal fp16 number for |t * d| down to 2^-13 instead of 2^-3 -- 27 binades below the
+// top (2^14) with all 22 bits, not 17 -- and its absolute resolution is 2^-35, not 2^-24.  The matrix instruction undoes
+// the factor: its other operand is the ReLU gate, 1.0 for the hi product and 2^-11 = fp16 0x1000 for this one (one
+// v_and on the gate fragment: 0x3c00 & 0x1000).  k2048: a scalar register holding 2048.0f.  Six instructions per pair.
+__device__ __forceinline__ void f16_pair_product_wide(float t0, float t1, float d0, float d1, float k2048, uint32_t &hi,
+                                                      uint32_t &lo) {
+  float r0, r1;
+  asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %7, 0\n\t"
+      "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %3, %5, %7, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %1, %2, %8, 0\n\t"
+      "v_fma_mixhi_f16 %1, %3, %8, 0"
+      : "=&v"(hi), "=&v"(lo), "=&v"(r0), "=&v"(r1)
+      : "v"(t0), "v"(t1), "s"(d0), "s"(d1), "s"(k2048));
+}
+constexpr uint32_t kF16GateLowMask = 0x10001000u;  // fp16 1.0 (0x3c00) -> 2^-11 (0x1000), both halves
+
+// The same wide low plane for an operand that is a value times a power of two (the general weight gradient's dZ2):
+// hi = fp16(x s), lo = fp16(2^11 (x s - hi)).  Its partner in the hi x lo product must carry the 2^-11: the OTHER
+// operand's hi plane times 2^-11, formed on the fragment registers (f16_pair_times) once their own product is issued.
+__device__ __forceinline__ void f16_pair_scaled_wide(float x0, float x1, float s, float k2048, uint32_t &hi, uint32_t &lo) {
+  float r0, r1;
+  asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %6, 0\n\t"
+      "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %3, %5, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %1, %2, %7, 0\n\t"
+      "v_fma_mixhi_f16 %1, %3, %7, 0"
+      : "=&v"(hi), "=&v"(lo), "=&v"(r0), "=&v"(r1)
+      : "v"(x0), "v"(x1), "v"(s), "s"(k2048));
+}
+// packed fp16 pair times a packed fp16 constant in a scalar register (0x10001000: both halves times 2^-11; exact for
+// halves of 2^-3 and more, the fp16 subnormal quantum below)
+__device__ __forceinline__ uint32_t f16_pair_times(uint32_t v, uint32_t packed_constant) {
+  uint32_t out;
+  asm("v_pk_mul_f16 %0, %1, %2" : "=v"(out) : "v"(v), "s"(packed_constant));
+  return out;
+}
+
 // bound < 2^e for the power of two that scales an operand (2^(14 - e)); bounds below 2^-80
 // (and zero) keep a finite factor: such operands are far below fp16's top anyway.
 __device__ __forceinline__ int f16_bound_exponent(float bound) {

@@ -236,14 +236,16 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
     # what it lets through the fp16 planes holds the fp32 kernels' bar ENTRY BY ENTRY again.  (One output with h2
     # given runs the gate kernel on exact bf16 planes: nothing to guard.)
     if n_out == 2:
-        assert consulted == 1 and fired == int(case in ("rows_of_mixed_magnitude", "one_outlier_row")), (case, consulted, fired)
+        assert consulted == 1 and fired == int(case == "one_outlier_row"), (case, consulted, fired)
     else:
         assert consulted == 0
     # yardstick: the fp32-MFMA generation on the same saved activations
     got6 = hip.mlp_tower_backward(x, h1, h2, dout, hip.mlp_pack_w2(p["w2"], transposed=True), p["w3"])
     for k in want:
         assert bool(torch.isfinite(got[k]).all()), k
-        floor = size[k].max() * 1e-30 + 1e-300
+        # dW2's planes resolve 2^-50 of a column's bound (wide low plane): entries whose whole sum of |terms| lies 2^40 below
+        # the largest entry's -- a single row near its ReLU kink, tens of binades down -- are measured against that floor
+        floor = size[k].max() * (2.0 ** -40 if k == "w2" else 1e-30) + 1e-300
         err = float(((got[k].double() - want[k]).abs() / (size[k] + floor)).max())
         err6 = float(((got6[k].double() - want[k]).abs() / (size[k] + floor)).max())
         # (the absolute bar is the fp32 accumulators' own: with one row 10^6 above the rest both generations sit at 5e-6 .. 3e-5)
@@ -378,14 +380,18 @@ def test_rank_one_backward_from_the_gate_bits_alone(m, d_in, n_out, x_scale):
 
 
 @pytest.mark.parametrize("n_out", [1, 2])
-@pytest.mark.parametrize("case,fires", [("plain", False), ("clipped_rows", False), ("rows_of_mixed_magnitude", True),
-                                         ("one_outlier_row", True), ("few_small_rows", False), ("many_small_rows", True)])
+@pytest.mark.parametrize("case,fires", [("plain", False), ("clipped_rows", False), ("rows_of_mixed_magnitude", False),
+                                         ("one_outlier_row", True), ("many_small_rows", False), ("two_populations", True)])
 def test_guard_picks_the_planes_of_the_gate_bits_weight_gradient_from_the_data(case, fires, n_out, monkeypatch):
     """rl8_mlp_wgrad_gate_bits_f32 (the headline's weight gradient) under its guard: the call's dOut is sampled on the
-    device; spread over too many binades it is summed on the exact bf16 planes -- bit for bit what
+    device; when its largest entry stands more than 2^12 above the mean of the non-zero ones (one outlier row; a few
+    rows that dwarf all others) the sums are formed on the exact bf16 planes -- bit for bit what
     RL8_WGRAD_GATE_PLANES=bf16 gives -- otherwise on the two fp16 planes, bit for bit the unguarded kernel; no host
-    round trip either way, and the lifetime counters say which way it went.  Entry by entry against fp64, relative
-    to the entry's own sum of |terms|: what the guard lets through stays within 3x the exact planes' error + 2e-7."""
+    round trip either way, and the lifetime counters say which way it went.  A long TAIL of small rows (PPO's
+    converged policies: a fifth of the rows 2^-12 below the largest, tools/diag/wgrad_planes_real_ppo.py) does not
+    trip it: the wide low plane keeps 22 bits of a term down to 2^-27 of its column's bound.  Entry by entry against
+    fp64, relative to the entry's own sum of |terms|: what the guard lets through stays within 3x the exact planes'
+    error + 2e-7."""
     m, d_in = 150_000, 1
     g = torch.Generator(device=DEV).manual_seed(3 + n_out)
     x = torch.randn(m, d_in, device=DEV, generator=g) * 40
@@ -397,14 +403,14 @@ def test_guard_picks_the_planes_of_the_gate_bits_weight_gradient_from_the_data(c
         g0 *= 10.0 ** torch.randint(-4, 3, (m,), device=DEV, generator=g).float()
     elif case == "one_outlier_row":
         g0[m // 3] *= 1e6
-    elif case == "few_small_rows":     # 0.2 % of the rows 2^-20 down: below the guard's share (2^-7)
-        g0[torch.rand(m, device=DEV, generator=g) < 0.002] *= 2.0 ** -20
-    elif case == "many_small_rows":    # 5 % of them: above it
-        g0[torch.rand(m, device=DEV, generator=g) < 0.05] *= 2.0 ** -20
+    elif case == "many_small_rows":    # a third of the rows 2^-20 down: a long tail, the mean hardly moves
+        g0[torch.rand(m, device=DEV, generator=g) < 0.33] *= 2.0 ** -20
+    elif case == "two_populations":    # one row in ten thousand 2^20 above all others: the bound belongs to them
+        g0[torch.rand(m, device=DEV, generator=g) < 0.0001] *= 2.0 ** 20
     dout = (torch.stack([g0, -g0], 1) if n_out == 2 else g0[:, None]).contiguous()
     w2p, w2t = hip.mlp_pack_w2_f16(p["w2"]), hip.mlp_pack_w2_f16(p["w2"], transposed=True)
-    _, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True,
-                                                 save_h1=False, save_gate=True)
+    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True,
+                                                  save_gate=True)  # (h1 as the kernels form it: one fp32 fma chain)
     gate_pack = lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])  # noqa: E731
 
     def backward(mode):
@@ -423,10 +429,11 @@ def test_guard_picks_the_planes_of_the_gate_bits_weight_gradient_from_the_data(c
     assert counts == (1, int(fires)) and counts_f16 == (0, 0) and counts_bf16 == (0, 0)
     for k in shipped:
         assert torch.equal(shipped[k], (exact if fires else unguarded)[k]), (case, k)
-    h1 = torch.relu(x @ p["w1"].T + p["b1"]).double()
     dz2 = (dout.double() @ p["w3"].double()) * (h2 > 0)
-    want, size = dz2.T @ h1, dz2.abs().T @ h1
-    floor = size.max() * 1e-30 + 1e-300
+    want, size = dz2.T @ h1.double(), dz2.abs().T @ h1.double()
+    # (entries whose whole sum of |terms| lies 2^40 below the largest entry's -- one row near its ReLU kink, tens of
+    # binades down -- are measured against that floor: the planes resolve 2^-50 of a column's bound)
+    floor = size.max() * 2.0 ** -40 + 1e-300
     err, err_exact = (float(((t["w2"].double() - want).abs() / (size + floor)).max()) for t in (shipped, exact))
     assert err <= 3 * err_exact + 2e-7, (case, err, err_exact)
 
