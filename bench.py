@@ -66,7 +66,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290
 HBM_COPY_CEILING_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (= fp32 vector) peak, MI355X_MICROARCH.md
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (spec), MI355X_MICROARCH.md; 1750 sustained on changing operands
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense 16-bit MFMA peak (spec), MI355X_MICROARCH.md
+# What the chip holds under power with random operands, two waves per SIMD (tools/probes/mfma_shape_probe.hip, round 3:
+# 16x16x32 f16 1677-1687 TFLOP/s at 1.82 GHz, 32x32x16 1483-1520 at 1.72 GHz; round 1's 1750 was on constant-ish data)
+MFMA_16BIT_SUSTAINED_TFLOPS = 1680.0
 PLANE_PRODUCTS = {"bf16x3-split": 6, "f16x2-split": 3, "bf16-gate-x3": 3, "f16-gate-x2": 2, "f16-gatebits-x2": 2}  # 16-bit MFMA products per fp32 product, by scheme
 
 # MFMA-bound kernels: algorithmic FLOP per unit (row) for the default towers,
@@ -87,7 +90,39 @@ ALGORITHMIC_BYTES = {
     "gather_minibatch": 56.0,       # index 8 + 24 read + 24 written per sample
     "gather_packed": 56.0,          # the same minibatch out of rows packed once per step()
     "pack_samples": 56.0,           # 24 B read + 32 B written per sample of the buffer, once per step()
+    # the recurrent models' heads: a row of the LSTM's output (256 floats) in, the logits + value (3 floats) out /
+    # their gradient in (these lines printed 0 GB/s for 12 ms of kernels)
+    "linear_heads_forward": 1024.0 + 12.0,
+    "linear_heads_backward": 1024.0 + 12.0,
 }
+
+# Fabric traffic of the recurrent bench's kernels (rocprofv3 --pmc TCC_EA0_* per launch at 8 192 envs x 256 steps,
+# tools/diag/recurrent_bench_pmc.sh -> profiles/r03_cfg5_fabric_traffic.txt): bytes per unit of the launch that was profiled
+FABRIC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_cfg5_fabric_traffic.txt") for r in (4, 3))
+                       if os.path.exists(p)), "")
+FABRIC_KERNEL = {  # bench name -> (substring of the profiled kernel's name, units of that launch)
+    "lstm_rows_backward": ("lstm_rows_backward_heads_kernel", 1 << 21),
+    "lstm_step_save": ("lstm_step_split_kernel<1, true>", 1 << 19),
+    "lstm_wgrad": ("mlp_wgrad_split_kernel<1, 0, true, true>", 1 << 19),
+    "linear_heads_forward": ("linear_heads_forward_kernel<3>", 1 << 21),
+    "linear_heads_backward": ("linear_heads_backward_kernel<3>", 1 << 21),
+}
+
+
+def fabric_traffic(name: str, units_per_launch: float):
+    """Bytes one launch of ``units_per_launch`` units moves over the fabric, scaled from the profiled launch."""
+    needle, units = FABRIC_KERNEL.get(name, (None, 1))
+    if not needle or not FABRIC_SUMMARY:
+        return None
+    try:
+        for line in open(FABRIC_SUMMARY):
+            if needle in line and "reads/launch" in line:
+                reads = float(line.split("reads/launch")[1].split()[0])
+                writes = float(line.split("writes/launch")[1].split()[0])
+                return (reads * 128.0 + writes * 64.0) / units * units_per_launch
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
 
 
 # HBM traffic from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
@@ -98,7 +133,7 @@ PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_tr
                     if os.path.exists(p)), os.path.join(ROOT, "profiles", "r03_pmc_traffic_microbench.json"))
 PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in that profiled launch)
     "ppo_loss_categorical": ("ppo_loss_categorical_kernel", 1 << 22),
-    "ppo_loss_normal": ("ppo_loss_normal_kernel", 1 << 22),
+    "ppo_loss_normal": ("ppo_loss_normal1_kernel", 1 << 22),  # (the one-action-dim vector kernel: what configs 4 launches)
     "gae_scan": ("gae_scan_time_major_kernel", (1 << 20) * 32),
     "advantage_normalise": ("advantage_normalise_flat_kernel", (1 << 20) * 32),
     "rollout_step_dummy": ("rollout_step_dummy_kernel", 1 << 20),
@@ -214,14 +249,20 @@ def default_launch_timeout(steps: int, warmup: int) -> float:
     return 900.0 + 120.0 * (steps + warmup)
 
 
-def _die_with_parent() -> None:  # preexec_fn of a rank: new session + SIGTERM when the launcher dies (Linux)
-    os.setsid()
+def die_with_parent(parent_pid: int) -> None:
+    """Called by a self-launched rank as its first action (``RL8_BENCH_PARENT`` in its environment): ask the kernel
+    for SIGTERM when the launcher dies (Linux ``PR_SET_PDEATHSIG``), then check that it has not died already -- the
+    request only covers deaths from now on.  Done here, in the child's own interpreter, not in a ``preexec_fn``: code
+    between fork and exec of a threaded parent (its pump threads) is not safe to run."""
     try:
         import ctypes
 
         ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)  # PR_SET_PDEATHSIG
-    except Exception:  # noqa: BLE001  (not Linux / no libc: the signal handlers and the timeout remain)
+    except Exception:  # noqa: BLE001  (not Linux / no libc: the launcher's signal handlers and its timeout remain)
         pass
+    if os.getppid() != parent_pid:
+        print(f"bench.py: launcher {parent_pid} is gone (parent is now {os.getppid()}): rank exits", file=sys.stderr, flush=True)
+        os._exit(1)
 
 
 def _stop_ranks(procs: list, grace: float = 20.0) -> None:
@@ -284,11 +325,17 @@ def launch_ranks(world: int, argv: list[str], *, script: str = os.path.abspath(_
     with tempfile.TemporaryFile("w+") as rank0_out:
         pumps = []
         try:
+            # every rank is forked before the first pump thread exists (fork from a single-threaded parent), leads its
+            # own session (start_new_session: setsid in the child by the C runtime, no Python between fork and exec)
+            # and arranges its own death with the launcher's (die_with_parent, first thing in main())
             for rank in range(world):
-                procs.append(subprocess.Popen([sys.executable, script, *argv], env=rank_environment(rank, world, port),
+                env = rank_environment(rank, world, port)
+                env["RL8_BENCH_PARENT"] = str(os.getpid())
+                procs.append(subprocess.Popen([sys.executable, script, *argv], env=env,
                                               stdout=rank0_out if rank == 0 else subprocess.DEVNULL,
-                                              stderr=subprocess.PIPE, text=True, preexec_fn=_die_with_parent))
-                pumps.append(threading.Thread(target=pump, args=(rank, procs[-1].stderr), daemon=True))
+                                              stderr=subprocess.PIPE, text=True, start_new_session=True))
+            for rank in range(world):
+                pumps.append(threading.Thread(target=pump, args=(rank, procs[rank].stderr), daemon=True))
                 pumps[-1].start()
             rc, pending, failed = 0, set(range(world)), None
             while pending and rc == 0:
@@ -390,6 +437,8 @@ def cpu_baseline(budget_s: float) -> dict:
 
 
 def main() -> None:
+    if os.environ.get("RL8_BENCH_PARENT", "").isdigit():  # a rank of launch_ranks()
+        die_with_parent(int(os.environ.pop("RL8_BENCH_PARENT")))
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process starts the ranks and stays off the GPU
@@ -557,7 +606,7 @@ def run(args: argparse.Namespace) -> None:
                 "bound": "mfma", "gemm": gemm, "launches": rec["launches"], "avg_ms": round(rec["avg_ms"], 5),
                 "total_ms": round(rec["total_ms"], 3), "algorithmic_flop_per_launch": flops_per_launch,
                 "achieved_TFLOPs": round(tflops, 2), "frac_of_f32_mfma_peak": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                "pmc_traffic_bytes_per_launch": None,
+                "pmc_traffic_bytes_per_launch": fabric_traffic(name, rec["units_per_launch"]),
             }
             if gemm != "f32":
                 executed = PLANE_PRODUCTS[gemm] * flops_per_launch
@@ -607,7 +656,8 @@ def run(args: argparse.Namespace) -> None:
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "achieved_GBps": round(gbs, 1),
             "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
-            "pmc_traffic_bytes_per_launch": pmc_traffic(name, rec["units_per_launch"]),
+            "pmc_traffic_bytes_per_launch": (pmc_traffic(name, rec["units_per_launch"]) if name not in FABRIC_KERNEL
+                                             else fabric_traffic(name, rec["units_per_launch"])),
         }
 
     if rank == 0:
@@ -648,8 +698,10 @@ def run(args: argparse.Namespace) -> None:
                 "f32_equivalent_TFLOPs": top["achieved_TFLOPs"],   # the algorithm's fp32 FLOP / time
                 "f32_mfma_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
                 "f32_equivalent_frac_of_f32_mfma_peak": top["frac_of_f32_mfma_peak"],  # > 1: beyond the fp32 matrix roofline
-                "bf16_sustained_TFLOPs_measured": 1750.0,          # tools/probes/bf16_split_probe.hip, changing operands
-                "frac_of_sustained": round(top["executed_bf16_TFLOPs"] / 1750.0, 4),
+                "sustained_TFLOPs_measured": MFMA_16BIT_SUSTAINED_TFLOPS,  # tools/probes/mfma_shape_probe.hip (power-limited)
+                "frac_of_sustained": round(top["executed_bf16_TFLOPs"] / MFMA_16BIT_SUSTAINED_TFLOPS, 4),
+                # the ALGORITHM's fp32 FLOP (one product, not the plane products executed) against the 16-bit peak
+                "algorithmic_frac": round(top["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, 4),
                 "algorithmic_flop_per_launch": top["algorithmic_flop_per_launch"],
                 "avg_launch_ms": top["avg_ms"],
                 "launches": top["launches"],

@@ -40,8 +40,12 @@ extern "C" {
 #define RL8_MAX_CLASSES 64 /* K upper bound for the categorical kernels */
 #define RL8_MAX_PARTIALS 2048 /* upper bound on per-launch partial rows */
 
-/* ABI / build identification: returns e.g. 100 for 1.0.0; `arch` (host
- * pointer, may be NULL) receives "gfx950". */
+/* ABI / build identification: returns RL8_ABI_VERSION of the library's build; `arch` (host pointer, may be NULL)
+ * receives "gfx950".  A binding compares it with the header it was written against (rl8_amd/hip.py refuses a
+ * mismatch).  History: 100 rounds 1-2; 103 round 3 (bf16-plane forward / data-gradient entries removed, reduction
+ * scratch doubled with two-level tickets -- bump owed since then); 104 round 4 (weight-gradient
+ * workspace: guard words and lifetime counters behind the slabs; caller-owned outputs of the forward unchanged). */
+#define RL8_ABI_VERSION 104
 int rl8_abi_version(char *arch, int arch_len);
 
 /* Scratch the reductions need (bytes); the caller allocates it once per stream

@@ -592,6 +592,15 @@ class Algorithm:
                 f"{self.__class__.__name__} is not buffered. "
                 "Call `collect` once prior to `step`."
             )
+        try:
+            return self._step()
+        except BaseException:
+            # whatever the SGD passes shared between them (the recurrent algorithm: the fp16 planes of the sequences'
+            # initial hidden states, a module-level switch in nn.fused_lstm) must not outlive a step() that failed
+            self._release_step_caches()
+            raise
+
+    def _step(self) -> StepStats:
         hp = self.hparams
         H, tm = hp.horizon, self._tm
         world = self.shards.world_size

@@ -6,6 +6,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "rl8_amd.h"
 
 #define RL8_API extern "C" __attribute__((visibility("default")))
@@ -20,6 +22,28 @@ constexpr int kMaxGrid = 2048;   // 8 blocks/CU: grid-stride beyond this
 constexpr int kPartialWidth = 16;  // doubles per partial row in scratch
 
 static_assert(kMaxGrid <= RL8_MAX_PARTIALS, "partials must fit the scratch");
+
+// Dynamic-LDS opt-in of a kernel on the device that is current NOW: once per device and kernel (the attribute belongs to
+// the device's copy of the function), safe to race from several host threads, and the error comes back instead of
+// being dropped (a process-wide `static bool` set the attribute on the first device only and launched on
+// the others without it).  One `static LdsOptIn` per call site and kernel.
+struct LdsOptIn {
+  std::atomic<unsigned long long> devices{0};
+};
+inline int allow_dynamic_lds(LdsOptIn &state, const void *kernel, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (state.devices.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return (int)e;
+  }
+  state.devices.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
 
 struct SumOp {
   __device__ __forceinline__ static double apply(double a, double b) { return a + b; }

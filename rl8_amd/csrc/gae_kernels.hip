@@ -469,24 +469,14 @@ RL8_API int rl8_gae_scan_f32(float *rewards, const float *values, float *adv_out
     const size_t lds_bytes = (size_t)2 * e * lds_stride * sizeof(float);
     const bool flat = chunk == cols && lds_stride == cols && (e % 4 == 0) && aligned16(rewards) &&
                       aligned16(values) && aligned16(adv_out) && aligned16(ret_out);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gae_scan_env_major_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gae_scan_env_major_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipGetLastError();
-      attr_set = true;
-    }
+    static LdsOptIn lds_attr_set_0;
+    if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&gae_scan_env_major_kernel<true>), 160 * 1024)) return e_lds_attr_set_0;
+    static LdsOptIn lds_attr_set_1;
+    if (const int e_lds_attr_set_1 = allow_dynamic_lds(lds_attr_set_1, reinterpret_cast<const void *>(&gae_scan_env_major_kernel<false>), 160 * 1024)) return e_lds_attr_set_1;
     rows = grid_for(n, e);
     if (flat && pipelined_shape) {
-      static bool attr9 = false;
-      if (!attr9) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gae_scan_env_major_pipelined_kernel<9>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipGetLastError();
-        attr9 = true;
-      }
+      static LdsOptIn lds_attr9_0;
+      if (const int e_lds_attr9_0 = allow_dynamic_lds(lds_attr9_0, reinterpret_cast<const void *>(&gae_scan_env_major_pipelined_kernel<9>), 160 * 1024)) return e_lds_attr9_0;
       // as many workgroups as are resident at once (each runs its tiles back to back, the next one's rows in flight):
       // a second round of workgroups would start with nothing requested
       static const int per_cu_cap = env_int("RL8_GAE_BLOCKS_PER_CU");

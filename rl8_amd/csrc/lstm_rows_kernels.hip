@@ -656,15 +656,10 @@ static int rows_backward(int64_t b, int l, const float *c0, const float *gates, 
   if (!aligned16(packed) || !aligned16(c0) || !aligned16(gates) || !aligned16(cs) || !aligned16(dhs) || !aligned16(dgates) ||
       !aligned16(dc_scratch) || !aligned16(heads_w))
     return RL8_EALIGN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rows_backward_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLrLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rows_backward_heads_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLrLdsBytes);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&lstm_rows_backward_kernel), kLrLdsBytes)) return e_lds_attr_set_0;
+  static LdsOptIn lds_attr_set_1;
+  if (const int e_lds_attr_set_1 = allow_dynamic_lds(lds_attr_set_1, reinterpret_cast<const void *>(&lstm_rows_backward_heads_kernel), kLrLdsBytes)) return e_lds_attr_set_1;
   const int64_t tiles = (b + kLrRows - 1) / kLrRows;
   const int grid = (int)(tiles < kCUs ? tiles : kCUs);
   unsigned long long *stamps = nullptr;

@@ -477,15 +477,10 @@ RL8_API int rl8_lstm_split_state_bound(const float *h, int64_t pitch, int64_t b,
 template <int DIN>
 static int launch_lstm_step(int grid, hipStream_t s, const void *a_planes, const void *w_planes, const float *wb, int64_t b,
                             const LstmStepArgs &args) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_step_split_kernel<DIN, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_step_split_kernel<DIN, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&lstm_step_split_kernel<DIN, true>), 160 * 1024)) return e_lds_attr_set_0;
+  static LdsOptIn lds_attr_set_1;
+  if (const int e_lds_attr_set_1 = allow_dynamic_lds(lds_attr_set_1, reinterpret_cast<const void *>(&lstm_step_split_kernel<DIN, false>), 160 * 1024)) return e_lds_attr_set_1;
   if (args.gates)
     lstm_step_split_kernel<DIN, true><<<grid, kBlock, lstm_step_lds_bytes(), s>>>(a_planes, w_planes, wb, b, args);
   else

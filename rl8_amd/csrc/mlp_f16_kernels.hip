@@ -486,13 +486,8 @@ template <int DIN, int NOUT, bool GATE = false>
 static int launch_backward_f16(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                int64_t m, const void *w2ts, const float *w3, float *partials, int stride, int head_rows,
                                const uint32_t *gate2) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_tower_backward_f16_kernel<DIN, NOUT, GATE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_tower_backward_f16_kernel<DIN, NOUT, GATE>), 160 * 1024)) return e_lds_attr_set_0;
   mlp_tower_backward_f16_kernel<DIN, NOUT, GATE><<<grid, kBlock, f16_backward_lds_bytes(DIN), s>>>(
       x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2);
   return launch_status();

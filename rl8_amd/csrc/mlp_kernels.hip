@@ -595,14 +595,8 @@ static int launch_forward_save(int grid, hipStream_t s, const float *x, int64_t 
                                const float *w1, const float *b1, const float4 *w2p,
                                const float *b2, const float *w3, const float *b3, int n_out,
                                float *out, float *save_h1, float *save_h2) {
-  static bool attr_set = false;  // one flag per instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(
-        reinterpret_cast<const void *>(&mlp_tower_forward_kernel<DIN, NOUT, SAVE>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_tower_forward_kernel<DIN, NOUT, SAVE>), 160 * 1024)) return e_lds_attr_set_0;
   mlp_tower_forward_kernel<DIN, NOUT, SAVE><<<grid, kBlock, mlp_forward_lds_bytes(), s>>>(
       x, m, d_in, w1, b1, w2p, b2, w3, b3, n_out, out, save_h1, save_h2);
   return launch_status();
@@ -870,14 +864,8 @@ static int launch_backward(int grid, hipStream_t s, const float *x, const float 
                            const float *h2, const float *dout, int64_t m, int d_in,
                            const float4 *w2tp, const float *w3, int n_out, float *dz2_out,
                            float *partials, int stride) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(
-        reinterpret_cast<const void *>(&mlp_tower_backward_kernel<DIN, NOUT>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_tower_backward_kernel<DIN, NOUT>), 160 * 1024)) return e_lds_attr_set_0;
   mlp_tower_backward_kernel<DIN, NOUT><<<grid, kBlock, mlp_backward_lds_bytes(), s>>>(
       x, h1, h2, dout, m, d_in, w2tp, w3, n_out, dz2_out, partials, stride);
   return launch_status();
@@ -936,13 +924,8 @@ RL8_API int rl8_mlp_wgrad_strided_f32(const float *dz2, int64_t dz2_pitch, const
     return RL8_ESIZE;
   if (!aligned16(dz2) || !aligned16(h1) || !aligned16(workspace) || !aligned16(dw2_out))
     return RL8_EALIGN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_kernel), 160 * 1024)) return e_lds_attr_set_0;
   const int64_t tiles = (m + kWgradRows - 1) / kWgradRows;
   const int grid = (int)(tiles < kCUs ? tiles : kCUs);
   hipStream_t s = (hipStream_t)stream;

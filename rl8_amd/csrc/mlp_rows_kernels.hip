@@ -1012,12 +1012,8 @@ static int launch_rows_backward_gate(int grid, hipStream_t s, const float *x, co
                                      const uint32_t *gate2) {
   constexpr int kRing = DIN == 1 ? 4 : 3;
   auto kernel = &mlp_rows_backward_gate_kernel<DIN, NOUT, kRing>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    attr_set = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(kernel), 160 * 1024)) return e_lds_attr_set_0;
   kernel<<<grid, kBlock, rows_dgrad_lds_bytes(kRing, DIN), s>>>(x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2);
   return launch_status();
 }
@@ -1052,15 +1048,14 @@ static int launch_rows_forward(hipStream_t s, const float *x, int64_t m, const f
              : diag == 7 ? &mlp_rows_forward_kernel<DIN, NOUT, SAVE, kRing, 7>
                          : kernel;
   }
-  {
+  // (tuning builds pick the kernel at run time: the attribute is set on every call)
+  if (const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      e != hipSuccess)
+    return (int)e;
 #else
-  static bool attr_set = false;
-  if (!attr_set) {
-    attr_set = true;
+  static LdsOptIn lds_forward;
+  if (const int e = allow_dynamic_lds(lds_forward, reinterpret_cast<const void *>(kernel), 160 * 1024)) return e;
 #endif
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-  }
   const int64_t tiles = (m + 127) / 128;
   static const int cap = env_int("RL8_MLP_GRID_CAP");
   const int max_grid = cap > 0 ? cap : 2 * kCUs;

@@ -1096,13 +1096,8 @@ __global__ __launch_bounds__(kBlock) void mlp_wgrad_split_reduce_kernel(const fl
 template <int DIN>
 static int launch_wgrad_split(int grid, hipStream_t s, const float *dz2, const float *x, const float *w1,
                               const float *b1, int64_t m, int d_in, float *slabs) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN>), 160 * 1024)) return e_lds_attr_set_0;
   mlp_wgrad_split_kernel<DIN><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(dz2, x, w1, b1, m, d_in, slabs, WgradFusedArgs{},
                                                                            WgradOperands{});
   return launch_status();
@@ -1111,13 +1106,8 @@ static int launch_wgrad_split(int grid, hipStream_t s, const float *dz2, const f
 template <int DIN, int NOUT, bool F16 = false>
 static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
                               const float *b1, int64_t m, int d_in, float *slabs, WgradFusedArgs fused) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, NOUT, false, F16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, NOUT, false, F16>), 160 * 1024)) return e_lds_attr_set_0;
   // (F16: + the inverse powers of two of the 256 columns of each operand behind the two stages)
   mlp_wgrad_split_kernel<DIN, NOUT, false, F16><<<grid, kWsThreads, 2 * kWsStageBytes + (F16 ? 2 * kHidden * 4 : 0), s>>>(
       h2, x, w1, b1, m, d_in, slabs, fused, WgradOperands{});
@@ -1127,13 +1117,8 @@ static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const fl
 template <int DIN, bool PAIR = false, bool BITS = false, bool F16 = false>
 static int launch_wgrad_gate(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
                              const float *b1, int64_t m, float *slabs, WgradFusedArgs fused) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN, PAIR, BITS, F16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN, PAIR, BITS, F16>), 160 * 1024)) return e_lds_attr_set_0;
   // (F16: + the columns' inverse powers of two behind the four stages)
   mlp_wgrad_gate_kernel<DIN, PAIR, BITS, F16><<<grid, kWsThreads, 4 * kWgStageBytes + (F16 ? kHidden * 4 : 0), s>>>(
       h2, x, w1, b1, m, slabs, fused);
@@ -1370,13 +1355,8 @@ RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const floa
 template <int DIN, bool F16 = false>
 static int launch_wgrad_loadh(int grid, hipStream_t s, const float *dz, const float *x, int64_t rows, float *workspace,
                               const WgradOperands &ops) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, 0, true, F16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  static LdsOptIn lds_attr_set_0;
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, 0, true, F16>), 160 * 1024)) return e_lds_attr_set_0;
   mlp_wgrad_split_kernel<DIN, 0, true, F16><<<grid, kWsThreads, 2 * kWsStageBytes + (F16 ? 2 * kHidden * 4 : 0), s>>>(
       dz, x, nullptr, nullptr, rows, DIN, workspace, WgradFusedArgs{}, ops);
   return launch_status();

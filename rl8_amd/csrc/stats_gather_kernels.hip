@@ -289,7 +289,7 @@ RL8_API int rl8_abi_version(char *arch, int arch_len) {
     for (; a[i] && i < arch_len - 1; ++i) arch[i] = a[i];
     arch[i] = 0;
   }
-  return 100;
+  return RL8_ABI_VERSION;
 }
 
 RL8_API int64_t rl8_scratch_bytes(void) {

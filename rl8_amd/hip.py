@@ -172,6 +172,10 @@ SIGNATURES: dict[str, list[Any]] = {
 }
 
 
+#: RL8_ABI_VERSION of include/rl8_amd.h this binding is written against (checked against the library in ``load``).
+ABI_VERSION = 104
+
+
 def library_path() -> str:
     return _LIB_PATH
 
@@ -198,6 +202,12 @@ def load() -> C.CDLL:
                             "rl8_lstm_split_packed_bytes", "rl8_lstm_split_wb_floats", "rl8_lstm_split_state_bytes",
                             "rl8_mlp_f16_packed_bytes", "rl8_lstm_rows_backward_pack_bytes")
                 else C.c_int
+            )
+        built = int(lib.rl8_abi_version(None, 0))
+        if built != ABI_VERSION:
+            raise HipExtensionError(
+                f"{_LIB_PATH} was built with ABI version {built}, this binding is written against {ABI_VERSION}"
+                " (include/rl8_amd.h: RL8_ABI_VERSION): rebuild with `make -C rl8_amd/csrc`."
             )
         _lib = lib
     return _lib
@@ -1402,7 +1412,7 @@ def lstm_backward(
     x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, hs: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor,
     dhs: None | torch.Tensor, whht_packed: None | torch.Tensor, *, split: None | bool = None,
     rows_packed: None | torch.Tensor = None, h0_bound: None | torch.Tensor = None,
-    heads: None | tuple[torch.Tensor, torch.Tensor] = None,
+    heads: None | tuple[torch.Tensor, torch.Tensor] = None, hs_bound: None | float = None,
 ) -> dict[str, torch.Tensor]:
     """Parameter gradients of the LSTM given ``dhs`` [B, L, 256] (gradient of every
     ``h_t``) and what ``lstm_forward(..., save=True)`` returned. Returns ``w_ih``,
@@ -1415,7 +1425,10 @@ def lstm_backward(
     that reads ``whht_packed``; only with ``split`` (its dW_ih / bias sums come from the
     weight-gradient kernel). ``h0_bound``: one float32 element >= max |h0| when the caller
     has it (:func:`lstm_forward_split`'s ``h0_bound_out``); computed here otherwise.
-    ``heads`` (with ``rows_packed``, ``dhs`` None): see :func:`lstm_rows_backward`."""
+    ``heads`` (with ``rows_packed``, ``dhs`` None): see :func:`lstm_rows_backward`.
+    ``hs_bound``: a number >= max |hs| the caller vouches for -- 1.0 when ``hs`` is this LSTM's own output
+    (|o * tanh(c)| < 1), which is what ``nn.fused_lstm`` passes; None: taken from ``hs`` here (one reduction over it).
+    The fp16 planes of the weight gradient are scaled by it: a value above the bound would overflow them."""
     x = _dense(x.detach(), torch.float32, "x")
     b, l, d_in = x.shape
     if heads is not None and (rows_packed is None or dhs is not None):
@@ -1472,7 +1485,10 @@ def lstm_backward(
                 h0_bound = torch.linalg.vector_norm(h0, ord=float("inf")).reshape(1)
             elif h0_bound.dtype != torch.float32 or h0_bound.numel() != 1 or h0_bound.device != dev:
                 raise ValueError("h0_bound must be one float32 element on x's device")
-            one = torch.ones(1, dtype=torch.float32, device=dev)
+            if hs_bound is None:  # (one pass over hs: callers that know their hs say so)
+                one = torch.linalg.vector_norm(hs, ord=float("inf")).reshape(1) if l > 1 else torch.ones(1, dtype=torch.float32, device=dev)
+            else:
+                one = torch.full((1,), float(hs_bound), dtype=torch.float32, device=dev)
         if f16 and b >= 128 and os.environ.get("RL8_AMD_LSTM_WGRAD_GATES", "fused") != "separate":
             # the four gates of a timestep in one launch: h_{t-1} comes out of HBM once instead of four times
             gkey = (dev.index or 0, _stream() or 0, l, d_in, "gates")

@@ -135,7 +135,7 @@ class _FusedLSTM(torch.autograd.Function):
         dhs = dhs.contiguous().float()
         if use_split(ctx.lstm) and BACKWARD_ROWS:
             g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, split=True, rows_packed=_packs(ctx.lstm, "rows"),
-                                  h0_bound=ctx.h0_bound)
+                                  h0_bound=ctx.h0_bound, hs_bound=1.0)  # (hs: this LSTM's own outputs, |o tanh c| < 1)
         else:
             g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, _packs(ctx.lstm, True), split=use_split(ctx.lstm))
         return None, None, None, g["w_ih"], g["w_hh"], g["b"], g["b"], None, None
@@ -194,7 +194,7 @@ class _FusedLSTMHeads(torch.autograd.Function):
         if dout is None:
             dout = torch.zeros(flat.shape[0], w_heads.shape[0], dtype=torch.float32, device=flat.device)
         dout = dout.contiguous().float()
-        common = dict(split=True, rows_packed=_packs(ctx.lstm, "rows"), h0_bound=ctx.h0_bound)
+        common = dict(split=True, rows_packed=_packs(ctx.lstm, "rows"), h0_bound=ctx.h0_bound, hs_bound=1.0)
         if dhs is None:  # nothing but the heads reads the latents: the usual case
             _, dw, db = hip.linear_heads_backward(flat, dout, w_heads, need_dh=False)
             g = hip.lstm_backward(x, h0, c0, hs, gates, cs, None, None, heads=(dout, w_heads), **common)

@@ -43,6 +43,12 @@ FORWARD_GEMM = os.environ.get("RL8_AMD_TOWER_FORWARD_GEMM", os.environ.get("RL8_
 #: Same choice for the data-gradient product of the backward pass (the weight
 #: gradient runs on fp16 planes scaled per output column, ``hip`` / mlp_split_kernels.hip).
 BACKWARD_GEMM = os.environ.get("RL8_AMD_TOWER_BACKWARD_GEMM", os.environ.get("RL8_AMD_TOWER_GEMM", "f16"))
+for _name, _value in (("forward", FORWARD_GEMM), ("backward", BACKWARD_GEMM)):
+    if _value not in ("f16", "f32"):
+        # ("split", the bf16-plane forward / data-gradient generation, was removed in round 3: say so instead of
+        # silently running the fp32-MFMA kernels -- ADVICE r3)
+        raise ValueError(f"RL8_AMD_TOWER_GEMM / RL8_AMD_TOWER_{_name.upper()}_GEMM = {_value!r}: the towers' {_name} product"
+                         " runs as 'f16' (fp16 planes, default) or 'f32' (fp32 MFMA); 'split' no longer exists")
 
 
 def _packed(layer: nn.Linear, transposed: bool, split: bool | str = False) -> torch.Tensor:

@@ -138,14 +138,18 @@ def _alive(pid: int) -> bool:
 @pytest.mark.parametrize("sig", ["SIGTERM", "SIGKILL"])
 def test_no_rank_survives_a_killed_parent(tmp_path, sig):
     """SIGTERM: the launcher's handler stops the ranks' process groups. SIGKILL (no handler can run): every rank asked
-    the kernel for SIGTERM on parent death. Either way nothing is left holding a GPU."""
+    the kernel for SIGTERM on parent death (bench.die_with_parent, first thing in a launched rank; it also leaves if
+    the launcher is already gone by then). Either way nothing is left holding a GPU."""
     import signal
 
     child = tmp_path / "child.py"
-    child.write_text(textwrap.dedent("""
+    child.write_text(textwrap.dedent(f"""
         import os, subprocess, sys, time
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        bench.die_with_parent(int(os.environ["RL8_BENCH_PARENT"]))  # what bench.main() does first in a launched rank
         helper = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(300)"])  # a rank's own helper process
-        open(os.path.join(os.path.dirname(__file__), f"pid{os.environ['RANK']}"), "w").write(f"{os.getpid()} {helper.pid}")
+        open(os.path.join(os.path.dirname(__file__), f"pid{{os.environ['RANK']}}"), "w").write(f"{{os.getpid()}} {{helper.pid}}")
         time.sleep(300)
     """))
     parent_code = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.launch_ranks(3, [], script={str(child)!r})"
