@@ -36,6 +36,14 @@ inline int allow_dynamic_lds(LdsOptIn &state, const void *kernel, int bytes) {
   if (e != hipSuccess) return (int)e;
   const unsigned long long bit = 1ull << (dev & 63);
   if (state.devices.load(std::memory_order_acquire) & bit) return 0;
+  // (a kernel's static LDS counts against the CU's 160 KiB too: ask for what is left at most)
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) {
+    const int left = 160 * 1024 - (int)attr.sharedSizeBytes;
+    if (bytes > left) bytes = left;
+  } else {
+    (void)hipGetLastError();
+  }
   e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();

@@ -43,7 +43,7 @@ def raw_stats(rewards: np.ndarray, rdr: np.ndarray) -> torch.Tensor:
     ], dtype=torch.float64)
 
 
-def worker(rank: int, port: int, results) -> None:
+def worker(rank: int, port: int, results, WORLD: int = WORLD) -> None:  # noqa: N803
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
@@ -121,17 +121,18 @@ def worker(rank: int, port: int, results) -> None:
         for i, q in enumerate(model):
             q.grad = torch.full_like(q, float(rank + 1) * (i + 1))
         window = [torch.full((5,), float(rank + 1), dtype=torch.float64) for _ in range(3)]
+        total = WORLD * (WORLD + 1) / 2.0
         shards.sum_gradients_(model, window)  # (first call allocates the message)
         message = shards._message
         for i, q in enumerate(model):
-            assert bool((q.grad == 3.0 * (i + 1)).all())  # ranks 1 + 2
+            assert bool((q.grad == total * (i + 1)).all())  # ranks 1 + 2 + ...
             q.grad.fill_(float(rank + 1))
-        assert all(bool((t == 3.0).all()) for t in window)
+        assert all(bool((t == total).all()) for t in window)
         with Count():
             shards.sum_gradients_(model, window)
         tensor_ops = [op for op in Count.ops if "c10d" not in op and "record_stream" not in op and "detach" not in op]
         assert len(tensor_ops) <= 6, tensor_ops
-        assert shards._message is message and all(bool((q.grad == 3.0).all()) for q in model)
+        assert shards._message is message and all(bool((q.grad == total).all()) for q in model)
         got = losses_from_sums(*sums.tolist(), entropy_coeff=ent_coeff, vf_coeff=1.0)
         for k in ("entropy", "policy", "vf", "total", "kl"):
             assert got[k] == pytest.approx(want_losses[k], rel=1e-9, abs=1e-12), k
@@ -160,11 +161,13 @@ def worker(rank: int, port: int, results) -> None:
         dist.destroy_process_group()
 
 
-def test_env_shard_collectives_world_size_2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_env_shard_collectives(world):
+    """World size 2, and 8 -- the node the driver scales to: the same contract with an eight-way rendezvous."""
     ctx = mp.get_context("spawn")
     results = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, port, results)) for r in range(WORLD)]
+    procs = [ctx.Process(target=worker, args=(r, port, results, world)) for r in range(world)]
     for p in procs:
         p.start()
     outcomes = [results.get(timeout=180) for _ in procs]
