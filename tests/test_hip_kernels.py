@@ -315,6 +315,37 @@ def test_categorical_sampler_philox_bit_exact_vs_oracle():
     np.testing.assert_allclose(host(got_lp), want_lp, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("k", [2, 3, 5])
+def test_categorical_draw_ties_near_ties_and_large_logits_agree_with_the_oracle(k):
+    """The sampler against the oracle bit for bit where a shortcut would be tempted to differ: logits of three scales
+    (1e-3, 1, 30), exact ties (the first index wins), scores a few ulps apart, injected noise that is zero.  (Round 4
+    tried deciding the index from fp32 log-scores behind a margin, with the reference's operations as the fallback:
+    it passed this test and moved nothing -- the kernel issues ~420 VALU instructions per env either way,
+    profiles/r04_experiments.md -- so the sampler stays the reference's arithmetic, operation by operation.)"""
+    rng = np.random.default_rng(100 + k)
+    m = 300_000
+    logits = (rng.standard_normal((m, 1, k)) * rng.choice([1e-3, 1.0, 30.0], (m, 1, 1))).astype(np.float32)
+    want_a, want_lp = oracle.categorical_sample(logits, seed=9, step=3, row_offset=17)
+    got_a, got_lp = hip.categorical_sample_logp(dev(logits), None, seed=9, step=3, row_offset=17)
+    assert np.array_equal(host(got_a), want_a) and np.array_equal(host(got_lp), want_lp)
+    assert len(np.unique(want_a)) == k
+    n = 60_000
+    q = rng.exponential(1.0, (n, 1, k)).astype(np.float32)
+    x = rng.standard_normal((n, 1, k)).astype(np.float32)
+    tie = rng.integers(0, 3, n)
+    # class 1 made to score exactly / almost what class 0 does: x1 - ln q1 = x0 - ln q0 (+ a few ulps)
+    x[:, 0, 1] = (x[:, 0, 0] - np.log(q[:, 0, 0].astype(np.float64)) + np.log(q[:, 0, 1].astype(np.float64))
+                  + (tie == 1) * rng.standard_normal(n) * 3e-7 + (tie == 2) * rng.standard_normal(n) * 1e-5).astype(np.float32)
+    q[:100, 0, 1] = q[:100, 0, 0]
+    x[:100, 0, 1] = x[:100, 0, 0]          # exact ties: the first index wins
+    q[100:110, 0, 0] = 0.0                 # (the reference divides by zero: inf wins)
+    want_a, want_lp = oracle.categorical_sample(x, q)
+    got_a, got_lp = hip.categorical_sample_logp(dev(x), dev(q), seed=0, step=0)
+    assert np.array_equal(host(got_a), want_a) and np.array_equal(host(got_lp), want_lp)
+    assert (want_a[:100] != 1).all()       # class 1 never beats class 0 on an exact tie
+    assert 0.1 < (want_a[110:, 0] == 1).mean() < 0.6
+
+
 def assert_logp_close(got, want, actions, *, squashed):
     """Sampler log-probs at 2e-5 (north_star's 1e-5 bar, one ulp of slack on either
     side). ``Normal``: plain ``|d| <= 2e-5 * (1 + |want|)``.
