@@ -574,6 +574,32 @@ def test_gather_minibatch_bit_exact(time_major):
     assert np.array_equal(host(whole[0]), flat)
 
 
+@pytest.mark.parametrize("n,h,widths", [(1, 1, (1,)), (63, 5, (1, 2)), (64, 32, (1, 1, 1, 1)), (65, 33, (5, 1, 1)),
+                                        (1000, 100, (7, 3, 1)), (130, 256, (28,)), (4100, 7, (3, 2, 2, 1, 1, 1, 1, 1))])
+@pytest.mark.parametrize("time_major", [False, True])
+def test_pack_samples_tiles_ragged_shapes(n, h, widths, time_major):
+    """rl8_pack_samples as a tiled transposition (64 envs x up to 32 steps through LDS): the packed buffer itself --
+    every sample's fields side by side in the reference's sample order env * H + t (src/rl8/_utils.py:211-225), zero
+    padding to whole 16-byte vectors -- for ragged env / step counts, rows of 16 to 128 bytes, 4- and 8-byte elements,
+    both buffer layouts."""
+    g = torch.Generator(device=DEV).manual_seed(n + h)
+    leaves = []
+    for i, d in enumerate(widths):
+        shape = (h + 1, n, d) if time_major else (n, h + 1, d)
+        t = (torch.randint(-5, 9, shape, device=DEV, generator=g) if i == 1 else torch.randn(shape, device=DEV, generator=g))
+        leaves.append(t.transpose(0, 1) if time_major else t)
+    packed = hip.PackedSamples(h, leaves)
+    words = sum(d * (2 if i == 1 else 1) for i, d in enumerate(widths))
+    assert packed.row_words == (words + 3) // 4 * 4
+    got = packed.packed.view(n * h, packed.row_words)
+    want = torch.cat([leaf[:, :h].reshape(n * h, -1).contiguous().view(torch.int32) for leaf in leaves], 1)
+    assert torch.equal(got[:, :words], want)
+    assert not bool(got[:, words:].any())
+    index = torch.randperm(n * h, device=DEV, generator=g)[: max(1, n * h // 3)]
+    for leaf, out in zip(leaves, packed.gather(index.contiguous())):
+        assert torch.equal(out, leaf[index // h, index % h])
+
+
 # --------------------------------------------------------------------------- #
 # Single-launch reductions: the last-arriving block must see every other
 # block's partial row (cross-CU / cross-XCD hand-off) on every launch.
