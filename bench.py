@@ -92,6 +92,9 @@ ALGORITHMIC_BYTES = {
     "pack_samples": 56.0,           # 24 B read + 32 B written per sample of the buffer, once per step()
     # the recurrent models' heads: a row of the LSTM's output (256 floats) in, the logits + value (3 floats) out /
     # their gradient in (these lines printed 0 GB/s for 12 ms of kernels)
+    # opt-in piecewise towers (scalar observation): x in, the outputs out / x and dOut in (n_out 1 and 2: 1.5 on average)
+    "pw_tower_forward": 4.0 + 6.0,
+    "pw_segment_sums": 4.0 + 6.0,
     "linear_heads_forward": 1024.0 + 12.0,
     "linear_heads_backward": 1024.0 + 12.0,
 }
@@ -217,6 +220,10 @@ def parse_args(argv: None | list[str] = None) -> argparse.Namespace:
     p.add_argument("--launch-timeout", type=float, default=None,
                    help="self-launched ranks (--gpus N without torchrun): seconds before the parent stops them all"
                         " (default: 900 + 120 per step and warm-up step)")
+    p.add_argument("--towers", default="matrix", choices=["matrix", "piecewise"],
+                   help="matrix (default, the product): the MFMA tower kernels.  piecewise: OPT-IN round-4 prototype for scalar"
+                        " observations only (rl8_amd/nn/piecewise_mlp.py: each tower as an exact piecewise-linear table) -- a"
+                        " labelled extra line, never the headline")
     p.add_argument("--cpu-baseline-seconds", type=float, default=45.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args(argv)
@@ -506,6 +513,10 @@ def run(args: argparse.Namespace) -> None:
     else:
         env_cls = DiscreteDummyEnv if args.env == "discrete" else ContinuousDummyEnv
 
+    if args.towers == "piecewise":
+        from rl8_amd.nn import piecewise_mlp
+
+        piecewise_mlp.ENABLED = True
     torch.manual_seed(0)
     if args.scaling == "strong":
         if args.num_envs % world:
@@ -662,6 +673,10 @@ def run(args: argparse.Namespace) -> None:
 
     if rank == 0:
         hbm_dominant = "ppo_loss_categorical" if "ppo_loss_categorical" in kernels else "ppo_loss_normal"
+        if args.towers == "piecewise":
+            line_extra = {"piecewise": dict(piecewise_mlp.stats)}
+        else:
+            line_extra = {}
         variant = ("Recurrent" if args.recurrent else "") + (" SquashedNormal" if args.distribution == "squashed" else "")
         dom = kernels[hbm_dominant]
         # The kernel the timed region spends most of its time in.
@@ -789,7 +804,11 @@ def run(args: argparse.Namespace) -> None:
                             " launches are sampled (every 16th timestep), so their `launches` / `total_ms` are of the sample",
             "hand_kernel_ms_per_step": round(sum(k["total_ms"] for k in kernels.values()) / args.steps, 3),
             "fused_towers": True,
+            "towers": ("matrix kernels (the product path)" if args.towers == "matrix" else
+                       "OPT-IN PROTOTYPE: exact piecewise-linear tables of a scalar observation (rl8_amd/nn/piecewise_mlp.py);"
+                       " table build and gradient algebra still torch fp64 ops; not the headline"),
         }
+        line.update(line_extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)

@@ -635,6 +635,27 @@ int rl8_linear_heads_backward_f32(const float *h, const float *dout, int64_t m, 
                                   int n_out, float *dh_out, float *partials,
                                   int *partial_rows_out /*host*/, void *stream);
 
+/* ---- OPT-IN: towers of a SCALAR observation as exact piecewise-linear tables (round 4 prototype; VERDICT r3 item 10,
+ * DESIGN.md section 9).  Special to d_in = 1 -- the dummy envs of BASELINE configs 2 and 4 -- and never a replacement
+ * for the general tower kernels above, which every other shape runs and against which this path is tested.  The
+ * table (breakpoints ascending, then per interval an anchor, n_out values at the anchor, n_out slopes) is built by
+ * the caller in fp64 from the tower's weights (rl8_amd/nn/piecewise_mlp.py; reference arithmetic:
+ * src/rl8/models/_feedforward.py:336-375) and handed over as floats:
+ *   table = [ breaks[p] | anchor[p + 1] | value[(p + 1) * n_out] | slope[(p + 1) * n_out] ]
+ *   out[r][q] = value[i][q] + slope[i][q] * (x[r] - anchor[i]),   i = number of breakpoints < x[r].
+ * p <= rl8_pw_max_breaks(), n_out <= 3. */
+int rl8_pw_max_breaks(void);
+int rl8_pw_tower_forward_f32(const float *x, int64_t m, const float *table, int p, int n_out, float *out, void *stream);
+/* Per interval i the sums over its rows of dOut and of dOut * x, all the backward pass of such a tower needs from the
+ * rows: sums_out[i][0][q] = sum dout[r][q], sums_out[i][1][q] = sum dout[r][q] * x[r]  (fp64, [(p + 1)][2][n_out]).
+ * Accumulated EXACTLY on a common power-of-two scale in 64-bit integers (two per sum, 74 bits), so the result does not
+ * depend on the order of the atomics: bitwise reproducible.  m <= 2^25 per call.  workspace:
+ * rl8_pw_workspace_bytes(p, n_out) bytes, 16-byte aligned, no initialisation.  A non-finite dOut or x makes every sum
+ * NaN.  RL8_ESIZE when the accumulators do not fit LDS (p * n_out beyond ~3000): the caller keeps the general path. */
+int64_t rl8_pw_workspace_bytes(int p, int n_out);
+int rl8_pw_segment_sums_f32(const float *x, const float *dout, int64_t m, int n_out, const float *breaks, int p,
+                            void *workspace, double *sums_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

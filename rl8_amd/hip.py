@@ -96,6 +96,10 @@ _vp, _i64, _u64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_fl
 # name -> argtypes, mirroring include/rl8_amd.h one to one.
 SIGNATURES: dict[str, list[Any]] = {
     "rl8_abi_version": [C.c_char_p, _i32],
+    "rl8_pw_max_breaks": [],
+    "rl8_pw_workspace_bytes": [_i32, _i32],
+    "rl8_pw_tower_forward_f32": [_vp, _i64, _vp, _i32, _i32, _vp, _vp],
+    "rl8_pw_segment_sums_f32": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp],
     "rl8_scratch_bytes": [],
     "rl8_dummy_env_step_f32": [_vp, _vp, _i32, _vp, _i64, _vp],
     "rl8_dummy_env_reset_f32": [_vp, _i64, _f32, _u64, _u64, _i64, _vp],
@@ -200,7 +204,7 @@ def load() -> C.CDLL:
                 if name in ("rl8_scratch_bytes", "rl8_mlp_backward_partial_floats", "rl8_mlp_wgrad_workspace_bytes",
                             "rl8_lstm_pack_floats", "rl8_lstm_backward_partial_floats",
                             "rl8_lstm_split_packed_bytes", "rl8_lstm_split_wb_floats", "rl8_lstm_split_state_bytes",
-                            "rl8_mlp_f16_packed_bytes", "rl8_lstm_rows_backward_pack_bytes")
+                            "rl8_mlp_f16_packed_bytes", "rl8_lstm_rows_backward_pack_bytes", "rl8_pw_workspace_bytes")
                 else C.c_int
             )
         built = int(lib.rl8_abi_version(None, 0))
@@ -1190,6 +1194,55 @@ def mlp_wgrad(dz2: torch.Tensor, h1: torch.Tensor) -> torch.Tensor:
         _check(lib.rl8_mlp_wgrad_f32(_ptr(dz2), _ptr(h1), dz2.shape[0], _ptr(ws), _ptr(out), 0, _stream()),
                "rl8_mlp_wgrad_f32")
     return out
+
+
+# --------------------------------------------------------------------------- #
+# OPT-IN: towers of a scalar observation as piecewise-linear tables (nn/piecewise_mlp.py).
+# --------------------------------------------------------------------------- #
+def pw_max_breaks() -> int:
+    return int(load().rl8_pw_max_breaks())
+
+
+def pw_tower_forward(x: torch.Tensor, table: torch.Tensor, p: int, n_out: int) -> torch.Tensor:
+    """x [M, 1] -> out [M, n_out] from ``table`` = [breaks p | anchor p + 1 | value (p + 1) n | slope (p + 1) n] (fp32)."""
+    x = _dense(x.detach(), torch.float32, "x")
+    _dense(table, torch.float32, "table")
+    m = x.shape[0]
+    if x.numel() != m or table.numel() != p + (p + 1) * (1 + 2 * n_out):
+        raise ValueError("pw_tower_forward: x must be [M, 1] and the table p + (p + 1) (1 + 2 n_out) floats")
+    out = torch.empty(m, n_out, dtype=torch.float32, device=x.device)
+    with _timed("pw_tower_forward", m):
+        _check(load().rl8_pw_tower_forward_f32(_ptr(x), m, _ptr(table), p, n_out, _ptr(out), _stream()),
+               "rl8_pw_tower_forward_f32")
+    return out
+
+
+_pw_ws: dict[tuple, torch.Tensor] = {}
+
+
+def pw_segment_sums(x: torch.Tensor, dout: torch.Tensor, breaks: torch.Tensor, p: int) -> torch.Tensor:
+    """[(p + 1), 2, n_out] fp64: per interval the sums of dout and of dout * x over its rows (exact, order-independent)."""
+    x = _dense(x.detach(), torch.float32, "x")
+    dout = _dense(dout.detach(), torch.float32, "dout")
+    m, n_out = dout.shape
+    if x.numel() != m:
+        raise ValueError("pw_segment_sums: x must be [M, 1] with M = dout.shape[0]")
+    lib = load()
+    key = (x.device.index if x.device.index is not None else torch.cuda.current_device(), _stream(), p, n_out)
+    ws = _pw_ws.get(key)
+    if ws is None:
+        _pw_ws.clear()  # (one table shape at a time per process is the common case)
+        ws = _pw_ws[key] = torch.empty(int(lib.rl8_pw_workspace_bytes(p, n_out)) // 8 + 2, dtype=torch.int64, device=x.device)
+    sums = torch.empty(p + 1, 2, n_out, dtype=torch.float64, device=x.device)
+    with _timed("pw_segment_sums", m):
+        for lo in range(0, m, 1 << 25):  # (2^25 rows per call: the integer accumulators' headroom)
+            hi = min(m, lo + (1 << 25))
+            part = sums if lo == 0 else torch.empty_like(sums)
+            _check(lib.rl8_pw_segment_sums_f32(_ptr(x[lo:hi]), _ptr(dout[lo:hi]), hi - lo, n_out, _ptr(breaks), p, _ptr(ws),
+                                               _ptr(part), _stream()), "rl8_pw_segment_sums_f32")
+            if lo:
+                sums += part
+    return sums
 
 
 # --------------------------------------------------------------------------- #

@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from . import piecewise_mlp
 
 #: Set to False to evaluate towers with eager PyTorch (A/B comparisons).
 ENABLED = True
@@ -375,6 +376,10 @@ def tower_forward(trunk: nn.Sequential, heads: Sequence[nn.Linear], x: torch.Ten
     if layers is None or x.shape[1] != layers[0].in_features:
         return None
     l1, l2 = layers
+    if piecewise_mlp.ENABLED and x.shape[1] == 1:  # opt-in prototype: scalar observations from an exact piecewise-linear table
+        out = piecewise_mlp.tower_forward(l1, l2, heads, x)
+        if out is not None:
+            return out
     if len(heads) == 1:
         w3, b3 = heads[0].weight, heads[0].bias
     else:

@@ -114,6 +114,10 @@ def assert_update(got, want, label):
 def test_one_sgd_iteration_matches_reference_to_1e5(golden, variant):
     """``num_sgd_iters=1`` over one full-buffer minibatch: StepStats, the clipped
     gradient of the optimizer step and the weights after it."""
+    check_one_sgd_iteration(golden, variant)
+
+
+def check_one_sgd_iteration(golden, variant, towers="matrix"):
     g = golden(f"first_update_{variant}.npz")
     algo, _ = build(golden, variant, num_sgd_iters=1, sgd_minibatch_size=None)
     algo.collect()
@@ -128,7 +132,9 @@ def test_one_sgd_iteration_matches_reference_to_1e5(golden, variant):
     # which tower kernels these reference-held numbers pin: a two-action policy runs the gate-mode (rank-one)
     # backward kernels from its FIRST update (Algorithm's pair hint), like every value tower; CartPole's three-way
     # head and the continuous (mean | log_std) heads the general ones
-    if variant.startswith("ff_"):
+    if towers == "piecewise":  # (tests/test_piecewise_gpu.py: the opt-in tables of a scalar observation)
+        assert {"pw_tower_forward", "pw_segment_sums"} <= launched and not any(k.startswith("mlp_") for k in launched), launched
+    elif variant.startswith("ff_"):
         assert {"mlp_tower_backward_gate", "mlp_wgrad_gate"} <= launched, launched
         general = {"mlp_tower_backward", "mlp_wgrad"} <= launched
         assert general == (variant not in ("ff_discrete", "ff_discrete_minibatch")), (variant, launched)
