@@ -22,9 +22,9 @@ python tools/summarize_profiles.py stats "$(find gpurun_out/prof_${TAG}_cfg5 -na
 python tools/summarize_profiles.py pmc "$(find gpurun_out/pmc_fetch -name '*counter_collection.csv' | head -1)" "$(find gpurun_out/pmc_write -name '*counter_collection.csv' | head -1)" gpurun_out/${TAG}_pmc_traffic_microbench.json || exit 1
 cp gpurun_out/${TAG}_pmc_traffic_microbench.json profiles/${TAG}_pmc_traffic_microbench.json   # the bench lines below carry this build's traffic
 timeout -k 10 500 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err || { echo bench failed; tail -5 gpurun_out/${TAG}_bench_n1.err; exit 1; }
-timeout -k 10 300 python bench.py --env cartpole --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg3.json 2>/dev/null || exit 1
-timeout -k 10 300 python bench.py --env continuous --distribution squashed --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg4.json 2>/dev/null || exit 1
-timeout -k 10 300 python bench.py --recurrent --num-envs 8192 --horizon 256 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg5.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --env cartpole --num-envs 262144 --horizon 128 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg3.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --env continuous --distribution squashed --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg4.json 2>/dev/null || exit 1
+timeout -k 10 300 python bench.py --recurrent --num-envs 8192 --horizon 256 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg5.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --env mountain_car --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_mountain_car.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --env pendulum --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_pendulum.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --minibatches 8 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_minibatches8.json 2>/dev/null || echo "minibatch bench failed"
@@ -32,7 +32,12 @@ timeout -k 10 300 python bench.py --recurrent --num-envs 8192 --horizon 256 --mi
 timeout -k 10 300 python tools/diag/lstm_forward_time.py > gpurun_out/${TAG}_lstm_forward.txt 2>&1 || echo "lstm forward timing failed"
 timeout -k 10 300 python tools/diag/lstm_rows_check.py --time > gpurun_out/${TAG}_lstm_rows_backward.txt 2>&1 || echo "lstm rows check failed"
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --single-device --num-envs 262144 --steps 3 --warmup 1 > gpurun_out/${TAG}_b_2rank_rehearsal.json 2>/dev/null || exit 1
-for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_cfg5_minibatches4 b_mountain_car b_pendulum b_minibatches8 b_2rank_rehearsal; do python -c "
+# (a GPU box admits six processes on its card: four ranks + the launcher, not eight)
+timeout -k 10 300 python bench.py --gpus 4 --backend gloo --single-device --num-envs 262144 --steps 3 --warmup 1 > gpurun_out/${TAG}_b_4rank_rehearsal.json 2>/dev/null || echo "4-rank rehearsal failed"
+# opt-in prototype lines (never the headline): towers of a scalar observation from piecewise-linear tables
+timeout -k 10 300 python bench.py --towers piecewise --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_b_piecewise_optin.json 2>/dev/null || echo "piecewise line failed"
+timeout -k 10 300 python bench.py --towers piecewise --env continuous --distribution squashed --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg4_piecewise_optin.json 2>/dev/null || echo "piecewise cfg4 line failed"
+for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_cfg5_minibatches4 b_mountain_car b_pendulum b_minibatches8 b_2rank_rehearsal b_4rank_rehearsal b_piecewise_optin b_cfg4_piecewise_optin; do python -c "
 import json; d=json.loads(open('gpurun_out/${TAG}_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value']), round(d['ms_per_step'],1), round(d['collect_ms_per_step'],1), round(d['update_ms_per_step'],1))"; done
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 echo done
