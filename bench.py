@@ -132,8 +132,8 @@ def fabric_traffic(name: str, units_per_launch: float):
 # passes over tools/kernel_microbench.py at config-2 shapes; corrected as
 # MI355X_MICROARCH.md prescribes; summary committed under profiles/). Scaled by
 # units to the launch size bench.py uses.
-PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_microbench.json") for r in (3, 2, 1))
-                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r03_pmc_traffic_microbench.json"))
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_microbench.json") for r in (4, 3, 2, 1))
+                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc_traffic_microbench.json"))
 PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in that profiled launch)
     "ppo_loss_categorical": ("ppo_loss_categorical_kernel", 1 << 22),
     "ppo_loss_normal": ("ppo_loss_normal1_kernel", 1 << 22),  # (the one-action-dim vector kernel: what configs 4 launches)
@@ -165,7 +165,8 @@ PMC_KERNEL_SPLIT = {  # the six-product bf16-plane weight gradient (RL8_WGRAD_PL
 }
 PMC_KERNEL_GATE = {  # gate-mode kernels (heads whose dZ2 is gate * d * w3e)
     # (template <d_in, PAIR, BITS, F16>: the value tower's kernel, gate bits, two fp16 planes)
-    "mlp_wgrad_gate": ("mlp_wgrad_gate_kernel<1, false, true, true>", 1 << 20),
+    # (round 4: the sixteen-wave kernel, template <d_in, PAIR>; the eight-wave one <d_in, PAIR, BITS, F16> in older summaries)
+    "mlp_wgrad_gate": ("mlp_wgrad_gate16_kernel<1, false>", 1 << 20),
     "mlp_tower_backward_gate": ("mlp_rows_backward_gate_kernel<1, 1, 4>", 1 << 20),
 }
 

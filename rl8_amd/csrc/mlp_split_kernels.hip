@@ -1037,6 +1037,221 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     for (int idx = tid; idx < kHidden * d_in + kHidden; idx += kWsThreads) row[idx] = 0.0f;
 }
 
+// ---- the gate-bits weight gradient on SIXTEEN waves (round 4) -----------------------------------------------------------
+// The kernel above spends four fifths of its time on the operand side (the build without matrix work: 224 of 279 us per
+// 2^20 rows) with no unit busy -- VALU 37 %, LDS 46 %, matrix pipe 59 %: a latency chain (load, produce, write, barrier,
+// read, multiply) behind two waves per SIMD.  Same arithmetic, same slabs, same partial rows here, with 1024 threads:
+// four waves per SIMD, a wave owns 2 x 2 tiles of 32 x 32 (64 accumulator registers instead of 128), a thread produces
+// FOUR samples of its column per 16-sample step instead of eight, one barrier per step over a four-stage ring, and the
+// waits are the compiler's.  BITS + F16 planes (wide low plane) only: what rl8_mlp_wgrad_gate_bits_f32 runs.
+constexpr int kW16Threads = 1024;
+constexpr int kW16StageBytes = 3 * 2 * kHidden * 16;  // gate plane | hi plane | lo plane, each [sample half][column] x 16 B
+constexpr int kW16Stages = 4;
+
+template <int DIN, bool PAIR>
+__global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_gate16_kernel(
+    const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1, int64_t m,
+    float *__restrict__ slabs, WgradFusedArgs fused) {
+  if (guard_says_leave(fused)) return;
+  constexpr int kIn = DIN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *inv_scales = reinterpret_cast<float *>(smem + kW16Stages * kW16StageBytes);  // [256]
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wj = wave >> 2, wi = wave & 3;       // consumer: j-tiles {2 wj, 2 wj + 1}, i-tiles {2 wi, 2 wi + 1}
+  const int col = tid & 255, q = wave >> 2;      // producer: column, and samples 4 q .. 4 q + 3 of a chunk (wave-uniform)
+
+  float w1r[kIn];
+#pragma unroll
+  for (int c = 0; c < kIn; ++c) w1r[c] = w1[col * kIn + c];
+  float b1r = b1[col];
+  {
+    float hb = __builtin_fabsf(b1r);
+#pragma unroll
+    for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[4 + c]), __builtin_fabsf(w1r[c]), hb);
+    const int e = f16_bound_exponent(__uint_as_float(fused.bounds[0]) * hb * 1.0001f);
+    const float col_scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
+    if (q == 0) inv_scales[col] = __builtin_amdgcn_ldexpf(1.0f, e - kF16Top);
+#pragma unroll
+    for (int c = 0; c < kIn; ++c) w1r[c] *= col_scale;  // relu(x . (s w1) + s b1) = s h1 exactly
+    b1r *= col_scale;
+  }
+  const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+  float gsum = 0.0f;
+
+  const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
+  const int64_t stride = gridDim.x;
+  const int64_t mine = (chunks - blockIdx.x + stride - 1) / stride;  // >= 1
+
+  // what a thread holds of a chunk before it produces it: its column's gate word of its four rows, and (wave-uniform)
+  // the rows' observations and dOut
+  struct Raw {
+    uint32_t g[4];
+    f32x8 dv, xv[(4 * kIn + 7) / 8];  // scalar registers: requested by issue(), usable behind land()
+  };
+  // (32-bit offsets through buffer descriptors that end at row m: rows past the end read as zero, no branches.  No wait
+  // here: the loads fly under the step's production and products; land() is the wait and the compiler's fence)
+  auto issue = [&](Raw &r, int64_t n) {
+    const int64_t row0 = (blockIdx.x + n * stride) * kWsChunk + 4 * q;
+    const int64_t left = m - row0;
+    const int rows = left <= 0 ? 0 : left < 4 ? (int)left : 4;
+    const int64_t at = rows > 0 ? row0 : 0;
+    const __amdgpu_buffer_rsrc_t g = buffer_rsrc(fused.gate2 + at * 8, rows * 32);
+    const u32x4 rx = scalar_rsrc(x + at * kIn, rows * kIn * 4);
+    const u32x4 rd = scalar_rsrc(fused.dout + at * (PAIR ? 2 : 1), rows * (PAIR ? 8 : 4));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.g[e] = __float_as_uint(buffer_load_f32(g, (col >> 5) * 4, e * 32));
+    r.dv = scalar_buffer_load_x8<0>(rd);
+    r.xv[0] = scalar_buffer_load_x8<0>(rx);
+    if constexpr (4 * kIn > 8) r.xv[1] = scalar_buffer_load_x8<32>(rx);
+    if constexpr (4 * kIn > 16) r.xv[2] = scalar_buffer_load_x8<64>(rx);
+  };
+  auto land = [&](Raw &r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    scalar_tie(r.dv);
+#pragma unroll
+    for (int i = 0; i < (4 * kIn + 7) / 8; ++i) scalar_tie(r.xv[i]);
+  };
+  auto d_of = [&](const Raw &r, int e) { return r.dv[PAIR ? 2 * e : e]; };
+  auto x_of = [&](const Raw &r, int e, int c) { return r.xv[(e * kIn + c) >> 3][(e * kIn + c) & 7]; };
+  auto produce = [&](const Raw &r, int stage) {
+    unsigned char *base = smem + stage * kW16StageBytes + ((q >> 1) * kHidden + col) * 16 + (q & 1) * 8;
+    uint32_t gw[2], hi[2], lo[2];
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = b1r;
+#pragma unroll
+      for (int c = 0; c < kIn; ++c) v = __builtin_fmaf(x_of(r, e, c), w1r[c], v);
+      t[e] = relu1(v);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)r.g[e], (unsigned)(col & 31), 1u);
+      const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)r.g[e + 1], (unsigned)(col & 31), 1u);
+      gw[e >> 1] = (m0 & 0x00003c00u) | (m1 & 0x3c000000u);
+      gsum += __uint_as_float(m0 & __float_as_uint(d_of(r, e)));
+      gsum += __uint_as_float(m1 & __float_as_uint(d_of(r, e + 1)));
+      f16_pair_product_wide(t[e], t[e + 1], d_of(r, e), d_of(r, e + 1), k2048, hi[e >> 1], lo[e >> 1]);
+    }
+    *reinterpret_cast<u32x2 *>(base) = u32x2{gw[0], gw[1]};
+    *reinterpret_cast<u32x2 *>(base + 2 * kHidden * 16) = u32x2{hi[0], hi[1]};
+    *reinterpret_cast<u32x2 *>(base + 4 * kHidden * 16) = u32x2{lo[0], lo[1]};
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  auto consume = [&](int stage) {
+    const unsigned char *base = smem + stage * kW16StageBytes;
+    const unsigned char *ap = base + (hh * kHidden + 64 * wj + l32) * 16;
+    const unsigned char *bp = base + 2 * kHidden * 16 + (hh * kHidden + 64 * wi + l32) * 16;
+    u32x4 g[2], gl[2], bh[2], bl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      g[t] = *reinterpret_cast<const u32x4 *>(ap + t * 512);
+      bh[t] = *reinterpret_cast<const u32x4 *>(bp + t * 512);
+      bl[t] = *reinterpret_cast<const u32x4 *>(bp + 2 * kHidden * 16 + t * 512);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gl[t][r] = g[t][r] & kF16GateLowMask;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, g[a]), __builtin_bit_cast(half8, bh[b]),
+                                                          acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, gl[a]), __builtin_bit_cast(half8, bl[b]),
+                                                          acc[a][b], 0, 0, 0);
+      }
+  };
+
+  // Ring: chunk n lives in stage n % 4.  Step n: load chunk n + 3, produce chunk n + 2 (loaded a step ago), consume chunk n
+  // (produced two steps ago), barrier.  Stage (n + 2) % 4 was last read in step n - 2: two barriers back.
+  Raw ra, rb;
+  issue(ra, 0);
+  land(ra);
+  produce(ra, 0);
+  issue(ra, 1);
+  land(ra);
+  produce(ra, 1);
+  issue(ra, 2);
+  land(ra);
+  __syncthreads();
+  const int64_t steps = (mine + 3) & ~(int64_t)3;  // (a multiple of four: chunks past the end are all zero)
+#pragma unroll 1
+  for (int64_t n = 0; n < steps; n += 4) {
+    // (one barrier per TWO steps: stages 2, 3 are written while 0, 1 are read, and the other way round)
+    issue(rb, n + 3);
+    consume(0);
+    produce(ra, 2);
+    land(rb);
+    issue(ra, n + 4);
+    consume(1);
+    produce(rb, 3);
+    land(ra);
+    __syncthreads();
+    issue(rb, n + 5);
+    consume(2);
+    produce(ra, 0);
+    land(rb);
+    issue(ra, n + 6);
+    consume(3);
+    produce(rb, 1);
+    land(ra);
+    __syncthreads();
+  }
+
+  float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 64 * wj + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int i = 64 * wi + 32 * b + l32;
+        slab[j * kHidden + i] = acc[a][b][r] * inv_scales[i];
+      }
+    }
+
+  // head sums: the four sample quarters of a column folded in a fixed order; the partial row as the eight-wave kernel writes it
+  float *red = reinterpret_cast<float *>(smem);  // [4][256]
+  __syncthreads();
+  red[q * kHidden + col] = gsum;
+  __syncthreads();
+  float *row = fused.partials + (int64_t)blockIdx.x * fused.partial_stride;
+  constexpr int kOut = PAIR ? 2 : 1;
+  constexpr int off_db2 = kHidden * kIn + kHidden, off_dw3 = off_db2 + kHidden, off_db3 = off_dw3 + kOut * kHidden;
+  const bool more = fused.accumulate != 0;
+  if (q == 0) {
+    const float total = ((red[col] + red[kHidden + col]) + red[2 * kHidden + col]) + red[3 * kHidden + col];
+    const float w3e = PAIR ? fused.w3[col] - fused.w3[kHidden + col] : fused.w3[col];
+    const float sum_b2 = total * w3e, sum_w3 = total * fused.b2[col];
+    row[off_db2 + col] = more ? row[off_db2 + col] + sum_b2 : sum_b2;
+    row[off_dw3 + col] = more ? row[off_dw3 + col] + sum_w3 : sum_w3;
+    if constexpr (PAIR) row[off_dw3 + kHidden + col] = more ? row[off_dw3 + kHidden + col] - sum_w3 : -sum_w3;
+    if (col < kOut && !more) row[off_db3 + col] = 0.0f;
+  }
+  if (!more && (int)blockIdx.x >= fused.other_rows)
+    for (int idx = tid; idx < kHidden * kIn + kHidden; idx += kW16Threads) row[idx] = 0.0f;
+}
+
+template <int DIN, bool PAIR>
+static int launch_wgrad_gate16(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, int64_t m,
+                               float *slabs, WgradFusedArgs fused) {
+  static LdsOptIn opt;
+  if (const int e = allow_dynamic_lds(opt, reinterpret_cast<const void *>(&mlp_wgrad_gate16_kernel<DIN, PAIR>), 160 * 1024)) return e;
+  mlp_wgrad_gate16_kernel<DIN, PAIR><<<grid, kW16Threads, kW16Stages * kW16StageBytes + kHidden * 4, s>>>(x, w1, b1, m, slabs, fused);
+  return launch_status();
+}
+
 // BITS mode of the gate-plane kernel: M = sum over slabs (slab order); dW2[j][i] (+)= w3e[j] M[j][i]; and the row
 // dots sum_i W2[j][i] M[j][i] join dW3 in partial row 0 (PAIR: with opposite signs in the two rows of dW3).
 // Workgroup = row j of the 256 x 256 output.
@@ -1611,6 +1826,11 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
     if (planes == kPlanesGuarded && launch_wgrad_tail(s, dout, m * n_out, bounds) != 0) return launch_status();
   }
   const uint32_t *guard = planes == kPlanesGuarded ? bounds : nullptr;
+  // the sixteen-wave kernel (round 4: 249 against 266 us per 2^20 rows); RL8_WGRAD_GATE16=0: the eight-wave one
+  static const bool sixteen = [] {
+    const char *v = getenv("RL8_WGRAD_GATE16");
+    return !(v && v[0] == '0');
+  }();
   for (int64_t at = 0; at < m; at += kWgradSegmentRows) {  // segments summed in order, as rl8_mlp_wgrad_fused_split_f32
     const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
     const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
@@ -1622,7 +1842,9 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
     int status = RL8_ESIZE;
 #define RL8_WGRAD_BITS(D) \
   if (d_in == D) { \
-    status = f16 ? (n_out == 2 ? launch_wgrad_gate<D, true, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
+    status = f16 && sixteen ? (n_out == 2 ? launch_wgrad_gate16<D, true>(grid, s, xs, w1, b1, rows, workspace, fused) \
+                                          : launch_wgrad_gate16<D, false>(grid, s, xs, w1, b1, rows, workspace, fused)) \
+           : f16 ? (n_out == 2 ? launch_wgrad_gate<D, true, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
                                : launch_wgrad_gate<D, false, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused)) \
            : n_out == 2 ? launch_wgrad_gate<D, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
                         : launch_wgrad_gate<D, false, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused); \

@@ -333,9 +333,12 @@ def test_cartpole_learns():
     assert last > first + 0.2 * abs(first), (first, last)
 
 
+SEEDS = 6
+
+
 def learning_curve_ends(env_cls, iterations, monkeypatch, **config):
-    """Last mean return of a short run, for two seeds, under the shipped weight-gradient planes (fp16 under the guard)
-    and under the exact bf16 planes (RL8_WGRAD_PLANES / RL8_WGRAD_GATE_PLANES = bf16)."""
+    """(first, last) mean return of a short run, for six seeds, under the shipped weight-gradient planes (fp16 under the
+    guard) and under the exact bf16 planes (RL8_WGRAD_PLANES / RL8_WGRAD_GATE_PLANES = bf16)."""
     ends = {}
     for planes in ("f16", "bf16"):
         for name in ("RL8_WGRAD_PLANES", "RL8_WGRAD_GATE_PLANES"):
@@ -343,7 +346,7 @@ def learning_curve_ends(env_cls, iterations, monkeypatch, **config):
                 monkeypatch.setenv(name, "bf16")
             else:
                 monkeypatch.delenv(name, raising=False)
-        for seed in (0, 1):
+        for seed in range(SEEDS):
             torch.manual_seed(seed)
             algo = AlgorithmConfig(**config).build(env_cls)
             first = algo.collect()["returns/mean"]
@@ -356,13 +359,16 @@ def learning_curve_ends(env_cls, iterations, monkeypatch, **config):
 
 
 def assert_same_learning(ends, gain):
-    """Every run improves by `gain`; the two plane schemes end within the seed-to-seed spread of each other (VERDICT r3
-    item 3c: the fp16 planes must not change what is learned)."""
+    """Every run improves by `gain`; the two plane schemes end within seed noise of each other (the
+    fp16 planes must not change what is learned).  A run is chaotic in its last digits -- any difference in arithmetic
+    moves a 40-iteration curve by as much as another seed does (tools/diag/pendulum_plane_schemes.py: eight seeds,
+    -366 +- 55 against -356 +- 64) -- so the comparison is of the two MEANS against their standard errors."""
     for (planes, seed), (first, last) in ends.items():
         assert last > first + gain * abs(first), (planes, seed, first, last)
-    mean = {p: 0.5 * (ends[p, 0][1] + ends[p, 1][1]) for p in ("f16", "bf16")}
-    spread = max(abs(ends[p, 0][1] - ends[p, 1][1]) for p in ("f16", "bf16"))
-    assert abs(mean["f16"] - mean["bf16"]) <= spread + 0.05 * abs(mean["bf16"]), (ends, spread)
+    last = {p: np.array([ends[p, s][1] for s in range(SEEDS)]) for p in ("f16", "bf16")}
+    gap = abs(last["f16"].mean() - last["bf16"].mean())
+    noise = math.sqrt(last["f16"].var(ddof=1) / SEEDS + last["bf16"].var(ddof=1) / SEEDS)
+    assert gap <= 2.5 * noise + 0.03 * abs(last["bf16"].mean()), (ends, gap, noise)
 
 
 def test_cartpole_learns_the_same_under_both_plane_schemes(monkeypatch):
