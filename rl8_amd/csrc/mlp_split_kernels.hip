@@ -1252,6 +1252,245 @@ static int launch_wgrad_gate16(int grid, hipStream_t s, const float *x, const fl
   return launch_status();
 }
 
+// ---- the general fused weight gradient on sixteen waves (round 4), same recipe ---------------------------------------------
+// mlp_wgrad_split_kernel<DIN, NOUT, false, true> (dZ2 formed from h2, dOut and W3; h1 recomputed; both operands two fp16
+// planes scaled per output column, dZ2's low plane wide; three products) with 1024 threads: a wave owns 2 x 2 tiles, a
+// thread produces four samples of its column as j of dZ2 AND as i of h1, four LDS stages of four planes, one barrier per
+// two steps.  Same slabs and partial rows.  RL8_WGRAD_16=0: the eight-wave kernel.
+constexpr int kW16FusedStageBytes = 4 * 2 * kHidden * 16;  // dZ2 hi | dZ2 lo (wide) | h1 hi | h1 lo
+
+template <int DIN, int NOUT>
+__global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_fused16_kernel(
+    const float *__restrict__ h2, const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+    int64_t m, float *__restrict__ slabs, WgradFusedArgs fused) {
+  if (guard_says_leave(fused)) return;
+  constexpr int kIn = DIN, kOut = NOUT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *inv_a = reinterpret_cast<float *>(smem + kW16Stages * kW16FusedStageBytes), *inv_b = inv_a + kHidden;
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wj = wave >> 2, wi = wave & 3;
+  const int col = tid & 255, q = wave >> 2;
+
+  float w1r[kIn], w3r[kOut], dw3a[kOut], db2a = 0.0f;
+#pragma unroll
+  for (int c = 0; c < kIn; ++c) w1r[c] = w1[col * kIn + c];
+  const float b1r = b1[col];
+#pragma unroll
+  for (int o = 0; o < kOut; ++o) {
+    w3r[o] = fused.w3[o * kHidden + col];
+    dw3a[o] = 0.0f;
+  }
+  float scale_a, scale_b;
+  {
+    float za = 0.0f, hb = __builtin_fabsf(b1r);
+#pragma unroll
+    for (int o = 0; o < kOut; ++o) za = __builtin_fmaf(__uint_as_float(fused.bounds[o]), __builtin_fabsf(w3r[o]), za);
+#pragma unroll
+    for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[4 + c]), __builtin_fabsf(w1r[c]), hb);
+    const int ea = f16_bound_exponent(za * 1.0001f), eb = f16_bound_exponent(hb * 1.0001f);
+    scale_a = __builtin_amdgcn_ldexpf(1.0f, kF16Top - ea);
+    scale_b = __builtin_amdgcn_ldexpf(1.0f, kF16Top - eb);
+    if (q == 0) {
+      inv_a[col] = __builtin_amdgcn_ldexpf(1.0f, ea - kF16Top);
+      inv_b[col] = __builtin_amdgcn_ldexpf(1.0f, eb - kF16Top);
+    }
+  }
+  const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+  const uint32_t k_low = (uint32_t)__builtin_amdgcn_readfirstlane((int)kF16GateLowMask);
+
+  const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
+  const int64_t stride = gridDim.x;
+  const int64_t mine = (chunks - blockIdx.x + stride - 1) / stride;
+
+  constexpr int kDv = (4 * kOut + 7) / 8, kXv = (4 * kIn + 7) / 8;
+  struct Raw {
+    float h[4];               // h2 of this thread's column, its four rows
+    f32x8 dv[kDv], xv[kXv];   // scalar registers: requested by issue(), usable behind land()
+  };
+  auto issue = [&](Raw &r, int64_t n) {
+    const int64_t row0 = (blockIdx.x + n * stride) * kWsChunk + 4 * q;
+    const int64_t left = m - row0;
+    const int rows = left <= 0 ? 0 : left < 4 ? (int)left : 4;
+    const int64_t at = rows > 0 ? row0 : 0;
+    const __amdgpu_buffer_rsrc_t hr = buffer_rsrc(h2 + at * kHidden, rows * kHidden * 4);
+    const u32x4 rx = scalar_rsrc(x + at * kIn, rows * kIn * 4);
+    const u32x4 rd = scalar_rsrc(fused.dout + at * kOut, rows * kOut * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.h[e] = buffer_load_f32(hr, col * 4, e * (kHidden * 4));
+    r.dv[0] = scalar_buffer_load_x8<0>(rd);
+    if constexpr (kDv > 1) r.dv[1] = scalar_buffer_load_x8<32>(rd);
+    r.xv[0] = scalar_buffer_load_x8<0>(rx);
+    if constexpr (kXv > 1) r.xv[1] = scalar_buffer_load_x8<32>(rx);
+    if constexpr (kXv > 2) r.xv[2] = scalar_buffer_load_x8<64>(rx);
+  };
+  auto land = [&](Raw &r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < kDv; ++i) scalar_tie(r.dv[i]);
+#pragma unroll
+    for (int i = 0; i < kXv; ++i) scalar_tie(r.xv[i]);
+  };
+  auto produce = [&](const Raw &r, int stage) {
+    unsigned char *base = smem + stage * kW16FusedStageBytes + ((q >> 1) * kHidden + col) * 16 + (q & 1) * 8;
+    float dz[4], h[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g = 0.0f;
+#pragma unroll
+      for (int o = 0; o < kOut; ++o) {
+        const float d = r.dv[(e * kOut + o) >> 3][(e * kOut + o) & 7];
+        g = __builtin_fmaf(d, w3r[o], g);
+        dw3a[o] = __builtin_fmaf(d, r.h[e], dw3a[o]);
+      }
+      dz[e] = r.h[e] > 0.0f ? g : 0.0f;
+      db2a += dz[e];
+      float v = b1r;
+#pragma unroll
+      for (int c = 0; c < kIn; ++c) v = __builtin_fmaf(r.xv[(e * kIn + c) >> 3][(e * kIn + c) & 7], w1r[c], v);
+      h[e] = relu1(v);
+    }
+    uint32_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      f16_pair_scaled_wide(dz[e], dz[e + 1], scale_a, k2048, ah[e >> 1], al[e >> 1]);
+      f16_pair_scaled(h[e], h[e + 1], scale_b, bh[e >> 1], bl[e >> 1]);
+    }
+    *reinterpret_cast<u32x2 *>(base) = u32x2{ah[0], ah[1]};
+    *reinterpret_cast<u32x2 *>(base + 2 * kHidden * 16) = u32x2{al[0], al[1]};
+    *reinterpret_cast<u32x2 *>(base + 4 * kHidden * 16) = u32x2{bh[0], bh[1]};
+    *reinterpret_cast<u32x2 *>(base + 6 * kHidden * 16) = u32x2{bl[0], bl[1]};
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  auto consume = [&](int stage) {
+    const unsigned char *base = smem + stage * kW16FusedStageBytes;
+    const unsigned char *ap = base + (hh * kHidden + 64 * wj + l32) * 16;
+    const unsigned char *bp = base + 4 * kHidden * 16 + (hh * kHidden + 64 * wi + l32) * 16;
+    // hi x hi and hi x lo first; then the h1 hi fragments become 2^-11 x themselves in place (the wide low plane's
+    // partner) for lo x hi: no third set of B registers
+    u32x4 ah[2], bh[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ah[t] = *reinterpret_cast<const u32x4 *>(ap + t * 512);
+      bh[t] = *reinterpret_cast<const u32x4 *>(bp + t * 512);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ah[a]), __builtin_bit_cast(half8, bh[b]), acc[a][b], 0, 0, 0);
+    {
+      u32x4 bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bl[t] = *reinterpret_cast<const u32x4 *>(bp + 2 * kHidden * 16 + t * 512);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ah[a]), __builtin_bit_cast(half8, bl[b]), acc[a][b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ah[t] = *reinterpret_cast<const u32x4 *>(ap + 2 * kHidden * 16 + t * 512);  // dZ2's wide low plane, into the hi plane's registers
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bh[t][r] = f16_pair_times(bh[t][r], k_low);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ah[a]), __builtin_bit_cast(half8, bh[b]), acc[a][b], 0, 0, 0);
+  };
+
+  Raw ra, rb;
+  issue(ra, 0);
+  land(ra);
+  produce(ra, 0);
+  issue(ra, 1);
+  land(ra);
+  produce(ra, 1);
+  issue(ra, 2);
+  land(ra);
+  __syncthreads();
+  const int64_t steps = (mine + 3) & ~(int64_t)3;
+#pragma unroll 1
+  for (int64_t n = 0; n < steps; n += 4) {
+    issue(rb, n + 3);
+    consume(0);
+    produce(ra, 2);
+    land(rb);
+    issue(ra, n + 4);
+    consume(1);
+    produce(rb, 3);
+    land(ra);
+    __syncthreads();
+    issue(rb, n + 5);
+    consume(2);
+    produce(ra, 0);
+    land(rb);
+    issue(ra, n + 6);
+    consume(3);
+    produce(rb, 1);
+    land(ra);
+    __syncthreads();
+  }
+
+  float *slab = slabs + (int64_t)blockIdx.x * kHidden * kHidden;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 64 * wj + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int i = 64 * wi + 32 * b + l32;
+        slab[j * kHidden + i] = acc[a][b][r] * (inv_a[j] * inv_b[i]);
+      }
+    }
+
+  float *red = reinterpret_cast<float *>(smem);  // [4][256][1 + kOut]
+  __syncthreads();
+  red[(q * kHidden + col) * (1 + kOut)] = db2a;
+#pragma unroll
+  for (int o = 0; o < kOut; ++o) red[(q * kHidden + col) * (1 + kOut) + 1 + o] = dw3a[o];
+  __syncthreads();
+  float *row = fused.partials + (int64_t)blockIdx.x * fused.partial_stride;
+  constexpr int off_db2 = kHidden * kIn + kHidden, off_dw3 = off_db2 + kHidden, off_db3 = off_dw3 + kOut * kHidden;
+  const bool more = fused.accumulate != 0;
+  if (q == 0) {
+    auto total = [&](int k) {
+      return ((red[col * (1 + kOut) + k] + red[(kHidden + col) * (1 + kOut) + k]) + red[(2 * kHidden + col) * (1 + kOut) + k]) +
+             red[(3 * kHidden + col) * (1 + kOut) + k];
+    };
+    const float sum_b2 = total(0);
+    row[off_db2 + col] = more ? row[off_db2 + col] + sum_b2 : sum_b2;
+#pragma unroll
+    for (int o = 0; o < kOut; ++o) {
+      const float sum_w3 = total(1 + o);
+      row[off_dw3 + o * kHidden + col] = more ? row[off_dw3 + o * kHidden + col] + sum_w3 : sum_w3;
+    }
+    if (col < kOut && !more) row[off_db3 + col] = 0.0f;
+  }
+  if (!more && (int)blockIdx.x >= fused.other_rows)
+    for (int idx = tid; idx < kHidden * kIn + kHidden; idx += kW16Threads) row[idx] = 0.0f;
+}
+
+template <int DIN, int NOUT>
+static int launch_wgrad_fused16(int grid, hipStream_t s, const float *h2, const float *x, const float *w1, const float *b1,
+                                int64_t m, float *slabs, WgradFusedArgs fused) {
+  static LdsOptIn opt;
+  if (const int e = allow_dynamic_lds(opt, reinterpret_cast<const void *>(&mlp_wgrad_fused16_kernel<DIN, NOUT>), 160 * 1024)) return e;
+  mlp_wgrad_fused16_kernel<DIN, NOUT><<<grid, kW16Threads, kW16Stages * kW16FusedStageBytes + 2 * kHidden * 4, s>>>(h2, x, w1, b1, m, slabs, fused);
+  return launch_status();
+}
+
 // BITS mode of the gate-plane kernel: M = sum over slabs (slab order); dW2[j][i] (+)= w3e[j] M[j][i]; and the row
 // dots sum_i W2[j][i] M[j][i] join dW3 in partial row 0 (PAIR: with opposite signs in the two rows of dW3).
 // Workgroup = row j of the 256 x 256 output.
@@ -1710,6 +1949,10 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
     if (planes == kPlanesGuarded && launch_wgrad_tail(s, dout, m * n_out, bounds) != 0) return launch_status();
   }
   const uint32_t *guard = planes == kPlanesGuarded && f16 ? bounds : nullptr;
+  static const bool sixteen = [] {  // the sixteen-wave kernel (round 4); RL8_WGRAD_16=0: the eight-wave one
+    const char *v = getenv("RL8_WGRAD_16");
+    return !(v && v[0] == '0');
+  }();
   // Segments of kWgradSegmentRows samples, summed in order (see there).  The first one
   // runs the grid the data-gradient kernel counted on (g2 rows of partials written, the
   // rest zeroed); later ones add to as many of those rows as they have workgroups.
@@ -1736,8 +1979,9 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
     }
 #define RL8_WGRAD_FUSED(D, N) \
   if (d_in == D && n_out == N) { \
-    status = f16 ? launch_wgrad_fused<D, N, true>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused) \
-                 : launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused); \
+    status = f16 && sixteen ? launch_wgrad_fused16<D, N>(grid, s, h2s, xs, w1, b1, rows, workspace, fused) \
+             : f16 ? launch_wgrad_fused<D, N, true>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused) \
+                   : launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused); \
     if (status == 0 && guard) status = launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, exact); \
   }
     RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3)
