@@ -203,9 +203,6 @@ class DefaultContinuousModel(Model):
         from .nn import fused_mlp
 
         obs = batch[DataKeys.OBS]
-        # (a recording rollout runs the value tower's launch on a second stream beside the policy tower's)
-        with fused_mlp.value_tower_beside(obs, self.vf_model[:2]) as beside:
-            value = fused_mlp.tower_forward(self.vf_model[:2], [self.vf_model[2]], obs)
         fused = fused_mlp.tower_forward(self.latent_model, [self.action_mean, self.action_log_std], obs)
         if fused is not None:
             a = self.action_mean.out_features
@@ -214,8 +211,8 @@ class DefaultContinuousModel(Model):
             latents = self.latent_model(obs)
             action_mean = self.action_mean(latents)
             action_log_std = self.action_log_std(latents)
+        value = fused_mlp.tower_forward(self.vf_model[:2], [self.vf_model[2]], obs)
         self._value = value if value is not None else self.vf_model(obs)
-        beside.join()
         return TensorDict(
             {"mean": action_mean, "log_std": torch.tanh(action_log_std)},
             batch_size=batch.batch_size,
@@ -261,16 +258,13 @@ class DefaultDiscreteModel(Model):
         obs = batch[DataKeys.OBS]
         # (two actions: under the fused PPO loss the two logit gradients are exact negatives, and Algorithm says so)
         two_way = self.action_spec.shape[0] == 1 and self.action_spec.space.n == 2
-        # (a recording rollout runs the value tower's launch on a second stream beside the policy tower's)
-        with fused_mlp.value_tower_beside(obs, self.vf_model[:2]) as beside:
-            value = fused_mlp.tower_forward(self.vf_model[:2], [self.vf_model[2]], obs)
         logits = fused_mlp.tower_forward(self.feature_model[:2], [self.feature_model[2]], obs,
                                          pair_gradients=True if two_way and fused_mlp.pair_hint() else None)
         if logits is None:
             logits = self.feature_model(obs)
         logits = logits.reshape(-1, self.action_spec.shape[0], self.action_spec.space.n)
+        value = fused_mlp.tower_forward(self.vf_model[:2], [self.vf_model[2]], obs)
         self._value = value if value is not None else self.vf_model(obs)
-        beside.join()
         return TensorDict({"logits": logits}, batch_size=batch.batch_size, device=obs.device)
 
     def to(self, device: Device) -> "DefaultDiscreteModel":  # type: ignore[override]

@@ -334,55 +334,6 @@ class _ReplayedTower(torch.autograd.Function):
         return _tower_backward(ctx, dout) + (None,)
 
 
-#: Rollout launches of the VALUE tower go to a second HIP stream while the policy tower's run on the current one
-#: (``value_tower_beside``): at 2^18 rows a launch does not fill the chip for its whole length (CartPole's rollout
-#: forwards ran at 0.22 of peak against 0.40 for the 2^25-row training launch), and the two towers of a timestep are
-#: independent.  Only while recording (outputs land in pre-allocated slabs: no allocator traffic across streams).
-#: ``RL8_AMD_TOWER_STREAMS=1`` switches it off.
-TWO_STREAMS = os.environ.get("RL8_AMD_TOWER_STREAMS", "2") != "1"
-_side_streams: dict[int, torch.cuda.Stream] = {}
-
-
-class value_tower_beside:
-    """``with value_tower_beside(x): value = tower_forward(...)`` -- inside a recording rollout the launch goes to the
-    side stream (which first waits for everything issued so far on the current one); ``join()`` afterwards makes the current
-    stream wait for it.  Outside a recording rollout: a no-op."""
-
-    def __init__(self, x: torch.Tensor, trunk: None | nn.Module = None) -> None:
-        self.active = (TWO_STREAMS and _RECORDING is not None and not torch.is_grad_enabled() and x.is_cuda
-                       and not piecewise_mlp.ENABLED)
-        if self.active and trunk is not None:
-            # the cached W2 pack is (re-)made HERE, on the current stream: a tensor allocated on the side stream and
-            # later read by the training passes on this one would sit in the wrong pool of the caching allocator
-            layers = _match(trunk, [])
-            if layers is not None and FORWARD_GEMM == "f16":
-                _packed(layers[1], False, "f16")
-        self.ctx = None
-        if self.active:
-            index = x.device.index if x.device.index is not None else torch.cuda.current_device()
-            side = _side_streams.get(index)
-            if side is None:
-                side = _side_streams[index] = torch.cuda.Stream(device=x.device)
-            self.side = side
-
-    def __enter__(self):
-        if self.active:
-            self.main = torch.cuda.current_stream()
-            self.side.wait_stream(self.main)
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-    def join(self) -> None:
-        if self.active:
-            self.main.wait_stream(self.side)
-
-
 def _tower_params(l1: nn.Linear, l2: nn.Linear, heads: Sequence[nn.Linear]) -> list[torch.Tensor]:
     return [l1.weight, l1.bias, l2.weight, l2.bias, *[h.weight for h in heads], *[h.bias for h in heads]]
 
