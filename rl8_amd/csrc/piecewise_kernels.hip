@@ -57,17 +57,36 @@ __global__ __launch_bounds__(kBlock) void pw_bounds_kernel(const float *__restri
                                                            int64_t m, int n_out, uint32_t *__restrict__ bounds) {
   float mx = 0.0f, md = 0.0f;
   bool bad = false;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) {
-    const float a = fabsf(x[i]);
-    bad |= !(a < INFINITY);
-    mx = fmaxf(mx, a);
-    for (int q = 0; q < n_out; ++q) {
-      const float b = fabsf(dout[i * n_out + q]);
-      bad |= !(b < INFINITY);
-      md = fmaxf(md, b);
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x, threads = (int64_t)gridDim.x * kBlock;
+  // both arrays as flat streams of 16-byte vectors (x: m floats, dOut: m * n_out), four loads in flight per lane
+  auto scan = [&](const float *p, int64_t n, float &top) {
+    const int64_t vecs = ((uintptr_t)p & 15) == 0 ? n / 4 : 0;
+    int64_t q = tid;
+    for (; q + 3 * threads < vecs; q += 4 * threads) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4 *>(p)[q + u * threads];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float a = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+        // (fmaxf drops a NaN operand: test the sum, which keeps it)
+        bad |= !(fabsf(v[u].x) + fabsf(v[u].y) + fabsf(v[u].z) + fabsf(v[u].w) < INFINITY);
+        top = fmaxf(top, a);
+      }
     }
-  }
+    for (; q < vecs; q += threads) {
+      const float4 v = reinterpret_cast<const float4 *>(p)[q];
+      bad |= !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < INFINITY);
+      top = fmaxf(top, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (int64_t i = 4 * vecs + tid; i < n; i += threads) {
+      const float a = fabsf(p[i]);
+      bad |= !(a < INFINITY);
+      top = fmaxf(top, a);
+    }
+  };
+  scan(x, m, mx);
+  scan(dout, m * n_out, md);
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) {
     mx = fmaxf(mx, __shfl_down(mx, off, kWave));
@@ -104,16 +123,14 @@ __global__ __launch_bounds__(kBlock) void pw_segment_sums_kernel(const float *__
   const int e = pw_scale_exponent(bounds);
   const double up = ldexp(1.0, kPwHiBits - e), down = ldexp(1.0, e - kPwHiBits), up_lo = ldexp(1.0, kPwHiBits - e + kPwLoBits);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) {
-    const float xv = x[i];
-    const int at = pw_interval(breaks, p, top, xv);
+  auto add_row = [&](float xv, int at, const float *d) {
     unsigned long long *row = lacc + (int64_t)at * (2 * NOUT * 2);
 #pragma unroll
     for (int q = 0; q < NOUT; ++q) {
-      const double d = (double)dout[i * NOUT + q];
+      const double dq = (double)d[q];
 #pragma unroll
       for (int kind = 0; kind < 2; ++kind) {
-        const double v = kind ? d * (double)xv : d;  // (exact: 24 x 24 bits)
+        const double v = kind ? dq * (double)xv : dq;  // (exact: 24 x 24 bits)
         if (v != 0.0) {
           const long long hi = __double2ll_rn(v * up);
           const long long lo = __double2ll_rn((v - (double)hi * down) * up_lo);
@@ -122,6 +139,35 @@ __global__ __launch_bounds__(kBlock) void pw_segment_sums_kernel(const float *__
         }
       }
     }
+  };
+  // four rows per lane and trip: four independent searches in flight (the search is a chain of dependent LDS reads)
+  const int64_t quads = m / 4;
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < quads; g += stride) {
+    float xv[4], dv[4][NOUT];
+    int at[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xv[u] = x[4 * g + u];
+#pragma unroll
+      for (int q = 0; q < NOUT; ++q) dv[u][q] = dout[(4 * g + u) * NOUT + q];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) at[u] = 0;
+    for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int probe = at[u] + step;
+        if (probe <= p && breaks[probe - 1] < xv[u]) at[u] = probe;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) add_row(xv[u], at[u], dv[u]);
+  }
+  for (int64_t i = 4 * quads + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) {
+    float dv[NOUT];
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) dv[q] = dout[i * NOUT + q];
+    add_row(x[i], pw_interval(breaks, p, top, x[i]), dv);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < slots; i += kBlock)
