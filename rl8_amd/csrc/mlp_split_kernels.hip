@@ -1816,6 +1816,212 @@ static int launch_wgrad_loadh(int grid, hipStream_t s, const float *dz, const fl
   return launch_status();
 }
 
+// ---- the two-operand weight gradient (the LSTM's dW_hh per gate) on sixteen waves (round 4) ---------------------------
+// mlp_wgrad_split_kernel<DIN, 0, true, true> -- both operands read from memory, each two fp16 planes on one power of two
+// per launch, dZ's low plane wide, optional column sums for dW_ih / db -- with 1024 threads: twice the loads in flight
+// per CU on a kernel that runs at the rate HBM delivers its 1-KiB row pieces.  Same grouping (four gates per launch, the
+// four workgroups that walk the same rows on one XCD), slabs and column-sum rows.  RL8_WGRAD_16=0: the eight-wave kernel.
+template <int DIN>
+__global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_loadh16_kernel(
+    const float *__restrict__ dz, const float *__restrict__ x, int64_t m, float *__restrict__ slabs, WgradOperands ops) {
+  constexpr int kIn = DIN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wj = wave >> 2, wi = wave & 3;
+  const int col = tid & 255, q = wave >> 2;
+
+  const int ea = f16_bound_exponent(__uint_as_float(*ops.dz_bound) * 1.0001f);
+  const int eb = f16_bound_exponent(__uint_as_float(*ops.h_bound) * 1.0001f);
+  const float scale_a = __builtin_amdgcn_ldexpf(1.0f, kF16Top - ea), scale_b = __builtin_amdgcn_ldexpf(1.0f, kF16Top - eb);
+  const float inv_ab = __builtin_amdgcn_ldexpf(1.0f, ea + eb - 2 * kF16Top);
+  const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+  const uint32_t k_low = (uint32_t)__builtin_amdgcn_readfirstlane((int)kF16GateLowMask);
+
+  const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
+  const bool grouped = ops.groups == 4;
+  const int gate_q = grouped ? ((int)blockIdx.x >> 3) & 3 : 0;
+  const int64_t bid = grouped ? ((blockIdx.x & 7) | ((blockIdx.x >> 5) << 3)) : blockIdx.x;
+  const int64_t stride = grouped ? gridDim.x / 4 : gridDim.x;
+  const int64_t out_id = grouped ? gate_q * stride + bid : blockIdx.x;
+  const float *dzp = dz + (grouped ? gate_q * ops.group_dz_offset : 0);
+  const int64_t mine = (chunks - bid + stride - 1) / stride;
+  const bool want_colsums = ops.colsums != nullptr;
+  float cs_b = 0.0f, cs_w[kIn];
+#pragma unroll
+  for (int c = 0; c < kIn; ++c) cs_w[c] = 0.0f;
+
+  constexpr int kXv = (4 * kIn + 7) / 8;
+  struct Raw {
+    float a[4], b[4];
+    f32x8 xv[kXv];
+  };
+  auto issue = [&](Raw &r, int64_t n) {
+    const int64_t row0 = (bid + n * stride) * kWsChunk + 4 * q;
+    const int64_t left = m - row0;
+    const int rows = left <= 0 ? 0 : left < 4 ? (int)left : 4;
+    const int64_t at = rows > 0 ? row0 : 0;
+    const __amdgpu_buffer_rsrc_t ar = buffer_rsrc(dzp + at * ops.dz_pitch, rows > 0 ? ((rows - 1) * ops.dz_pitch + kHidden) * 4 : 0);
+    const __amdgpu_buffer_rsrc_t br = buffer_rsrc(ops.h + at * ops.h_pitch, rows > 0 ? ((rows - 1) * ops.h_pitch + kHidden) * 4 : 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r.a[e] = buffer_load_f32(ar, col * 4, e * (ops.dz_pitch * 4));
+      r.b[e] = buffer_load_f32(br, col * 4, e * (ops.h_pitch * 4));
+    }
+    const u32x4 rx = scalar_rsrc(want_colsums ? x + at * kIn : reinterpret_cast<const float *>(slabs), want_colsums ? rows * kIn * 4 : 0);
+    r.xv[0] = scalar_buffer_load_x8<0>(rx);
+    if constexpr (kXv > 1) r.xv[1] = scalar_buffer_load_x8<32>(rx);
+    if constexpr (kXv > 2) r.xv[2] = scalar_buffer_load_x8<64>(rx);
+  };
+  auto land = [&](Raw &r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < kXv; ++i) scalar_tie(r.xv[i]);
+  };
+  auto produce = [&](const Raw &r, int stage) {
+    unsigned char *base = smem + stage * kW16FusedStageBytes + ((q >> 1) * kHidden + col) * 16 + (q & 1) * 8;
+    if (want_colsums) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cs_b += r.a[e];
+#pragma unroll
+        for (int c = 0; c < kIn; ++c) cs_w[c] = __builtin_fmaf(r.a[e], r.xv[(e * kIn + c) >> 3][(e * kIn + c) & 7], cs_w[c]);
+      }
+    }
+    uint32_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      f16_pair_scaled_wide(r.a[e], r.a[e + 1], scale_a, k2048, ah[e >> 1], al[e >> 1]);
+      f16_pair_scaled(r.b[e], r.b[e + 1], scale_b, bh[e >> 1], bl[e >> 1]);
+    }
+    *reinterpret_cast<u32x2 *>(base) = u32x2{ah[0], ah[1]};
+    *reinterpret_cast<u32x2 *>(base + 2 * kHidden * 16) = u32x2{al[0], al[1]};
+    *reinterpret_cast<u32x2 *>(base + 4 * kHidden * 16) = u32x2{bh[0], bh[1]};
+    *reinterpret_cast<u32x2 *>(base + 6 * kHidden * 16) = u32x2{bl[0], bl[1]};
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  auto consume = [&](int stage) {  // (as mlp_wgrad_fused16_kernel's)
+    const unsigned char *base = smem + stage * kW16FusedStageBytes;
+    const unsigned char *ap = base + (hh * kHidden + 64 * wj + l32) * 16;
+    const unsigned char *bp = base + 4 * kHidden * 16 + (hh * kHidden + 64 * wi + l32) * 16;
+    u32x4 ah[2], bh[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ah[t] = *reinterpret_cast<const u32x4 *>(ap + t * 512);
+      bh[t] = *reinterpret_cast<const u32x4 *>(bp + t * 512);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ah[a]), __builtin_bit_cast(half8, bh[b]), acc[a][b], 0, 0, 0);
+    {
+      u32x4 bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bl[t] = *reinterpret_cast<const u32x4 *>(bp + 2 * kHidden * 16 + t * 512);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ah[a]), __builtin_bit_cast(half8, bl[b]), acc[a][b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ah[t] = *reinterpret_cast<const u32x4 *>(ap + 2 * kHidden * 16 + t * 512);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bh[t][r] = f16_pair_times(bh[t][r], k_low);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ah[a]), __builtin_bit_cast(half8, bh[b]), acc[a][b], 0, 0, 0);
+  };
+
+  Raw ra, rb;
+  issue(ra, 0);
+  land(ra);
+  produce(ra, 0);
+  issue(ra, 1);
+  land(ra);
+  produce(ra, 1);
+  issue(ra, 2);
+  land(ra);
+  __syncthreads();
+  const int64_t steps = (mine + 3) & ~(int64_t)3;
+#pragma unroll 1
+  for (int64_t n = 0; n < steps; n += 4) {
+    issue(rb, n + 3);
+    consume(0);
+    produce(ra, 2);
+    land(rb);
+    issue(ra, n + 4);
+    consume(1);
+    produce(rb, 3);
+    land(ra);
+    __syncthreads();
+    issue(rb, n + 5);
+    consume(2);
+    produce(ra, 0);
+    land(rb);
+    issue(ra, n + 6);
+    consume(3);
+    produce(rb, 1);
+    land(ra);
+    __syncthreads();
+  }
+
+  float *slab = slabs + out_id * kHidden * kHidden;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 64 * wj + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) slab[j * kHidden + 64 * wi + 32 * b + l32] = acc[a][b][r] * inv_ab;
+    }
+
+  if (want_colsums) {  // the four sample quarters of a column folded in a fixed order
+    float *red = reinterpret_cast<float *>(smem);  // [4][256][1 + kIn]
+    __syncthreads();
+    red[(q * kHidden + col) * (1 + kIn)] = cs_b;
+#pragma unroll
+    for (int c = 0; c < kIn; ++c) red[(q * kHidden + col) * (1 + kIn) + 1 + c] = cs_w[c];
+    __syncthreads();
+    if (q == 0) {
+      auto total = [&](int k) {
+        return ((red[col * (1 + kIn) + k] + red[(kHidden + col) * (1 + kIn) + k]) + red[(2 * kHidden + col) * (1 + kIn) + k]) +
+               red[(3 * kHidden + col) * (1 + kIn) + k];
+      };
+      float *row = ops.colsums + out_id * (kHidden * (kIn + 1));
+      const bool more = ops.colsum_accumulate != 0;
+      const float b = total(0);
+      row[kHidden * kIn + col] = more ? row[kHidden * kIn + col] + b : b;
+#pragma unroll
+      for (int c = 0; c < kIn; ++c) {
+        const float w = total(1 + c);
+        row[col * kIn + c] = more ? row[col * kIn + c] + w : w;
+      }
+    }
+  }
+}
+
+template <int DIN>
+static int launch_wgrad_loadh16(int grid, hipStream_t s, const float *dz, const float *x, int64_t rows, float *workspace,
+                                const WgradOperands &ops) {
+  static LdsOptIn opt;
+  if (const int e = allow_dynamic_lds(opt, reinterpret_cast<const void *>(&mlp_wgrad_loadh16_kernel<DIN>), 160 * 1024)) return e;
+  mlp_wgrad_loadh16_kernel<DIN><<<grid, kW16Threads, kW16Stages * kW16FusedStageBytes, s>>>(dz, x, rows, workspace, ops);
+  return launch_status();
+}
+
 /* dW (+)= dZ^T h with BOTH operands strided in memory (dZ rows at dz_pitch, h rows at
  * h_pitch floats, 256 columns each): the LSTM's recurrent weight gradient per gate.
  * x / d_in / colsums (all optional together): also the column sums
@@ -1851,7 +2057,18 @@ static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int6
                             groups, groups == 4 ? kHidden : 0};
     const float *xs = colsums ? x + at * d_in : nullptr;
     int status;
-    if (dz_bound) {
+    static const bool sixteen = [] {  // the sixteen-wave kernel (round 4); RL8_WGRAD_16=0: the eight-wave one
+      const char *v = getenv("RL8_WGRAD_16");
+      return !(v && v[0] == '0');
+    }();
+    if (dz_bound && sixteen) {
+      switch (colsums ? d_in : 1) {
+        case 1: status = launch_wgrad_loadh16<1>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 2: status = launch_wgrad_loadh16<2>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 3: status = launch_wgrad_loadh16<3>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        default: status = launch_wgrad_loadh16<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+      }
+    } else if (dz_bound) {
       switch (colsums ? d_in : 1) {
         case 1: status = launch_wgrad_loadh<1, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
         case 2: status = launch_wgrad_loadh<2, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;

@@ -117,7 +117,7 @@ def test_compiled_split_kernels_resources(tmp_path):
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         assert not re.search(r"mlp_tower_(forward|backward)_split_kernel", name)
-        if "mlp_wgrad_gate16_kernel" in name or "mlp_wgrad_fused16_kernel" in name:  # (round 4) sixteen waves: four per SIMD, 128 registers each
+        if re.search(r"mlp_wgrad_(gate16|fused16|loadh16)_kernel", name):  # (round 4) sixteen waves: four per SIMD, 128 registers each
             assert scratch == 0 and vgprs <= 128, (name, scratch, vgprs)
             checked += 1
         if re.search(r"mlp_wgrad_split_kernel|mlp_wgrad_gate_kernel", name):
@@ -128,7 +128,7 @@ def test_compiled_split_kernels_resources(tmp_path):
             assert vgprs <= 256, (name, vgprs)
             checked += 1
     # general (5 run-time/compiled widths from memory + 12 fused, bf16 and fp16 planes), two-operand (4 + 4), gate-plane kernels
-    assert checked >= 5 + 12 + 12 + 4 + 4 + 8 + 8 + 8 + 12, checked
+    assert checked >= 5 + 12 + 12 + 4 + 4 + 8 + 8 + 8 + 12 + 4, checked
     _check_wgrad_scalar_windows(text)
     # Every hand-issued load (ds_read_b128, s_buffer_load_dwordx8, ...) of every kernel: nothing
     # reads or overwrites its destination before a wait that covers it, on any path.
