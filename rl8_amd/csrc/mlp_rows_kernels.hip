@@ -109,15 +109,31 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     consts[kRec * kHidden + tid] = b2[tid];
 #pragma unroll
     for (int q = 0; q < kOut; ++q) consts[(kRec + 1 + q) * kHidden + tid] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
-    __syncthreads();
-    for (int k = 0; k < kHidden; ++k) b1max = __builtin_fmaxf(b1max, __builtin_fabsf(consts[k * kRec]));
-    b1max = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b1max)));  // (uniform: scalar registers)
+    // max |b1|, max_k |w1[k][i]|: thread = k; a wave's 64 by lane exchange, the four waves' through LDS (the ring's
+    // first bytes: nothing is requested into it before the prologue's barrier).  (Round 4: every thread used to walk
+    // all 256 records in LDS, (1 + DIN) x 256 dependent reads -- 36 us of every launch at DIN = 1, 86 us at DIN = 5:
+    // a fifth of a rollout timestep's launch of 2^20 rows, half of one of 2^18; tools/diag/forward_size_sweep.py.)
+    float mine[1 + kIn];
+    mine[0] = __builtin_fabsf(consts[tid * kRec]);
 #pragma unroll
-    for (int i = 0; i < kIn; ++i) {
-      float mx = 0.0f;
-      for (int k = 0; k < kHidden; ++k) mx = __builtin_fmaxf(mx, __builtin_fabsf(consts[k * kRec + 1 + i]));
-      w1max[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+    for (int i = 0; i < kIn; ++i) mine[1 + i] = __builtin_fabsf(consts[tid * kRec + 1 + i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int j = 0; j < 1 + kIn; ++j) mine[j] = __builtin_fmaxf(mine[j], __shfl_xor(mine[j], off, 64));
+    float *red = reinterpret_cast<float *>(smem);  // [wave][1 + kIn]
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 1 + kIn; ++j) red[wave * (1 + kIn) + j] = mine[j];
     }
+    __syncthreads();
+    auto of_all = [&](int j) {
+      const float mx = __builtin_fmaxf(__builtin_fmaxf(red[j], red[(1 + kIn) + j]), __builtin_fmaxf(red[2 * (1 + kIn) + j], red[3 * (1 + kIn) + j]));
+      return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(__builtin_fmaxf(mx, 0.0f))));  // (uniform: scalar registers)
+    };
+    b1max = of_all(0);
+#pragma unroll
+    for (int i = 0; i < kIn; ++i) w1max[i] = of_all(1 + i);
   }
 
   // ---- per-lane state -------------------------------------------------------------------------------
