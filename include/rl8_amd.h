@@ -44,8 +44,9 @@ extern "C" {
  * receives "gfx950".  A binding compares it with the header it was written against (rl8_amd/hip.py refuses a
  * mismatch).  History: 100 rounds 1-2; 103 round 3 (bf16-plane forward / data-gradient entries removed, reduction
  * scratch doubled with two-level tickets -- bump owed since then); 104 round 4 (weight-gradient
- * workspace: guard words and lifetime counters behind the slabs; caller-owned outputs of the forward unchanged). */
-#define RL8_ABI_VERSION 104
+ * workspace: guard words and lifetime counters behind the slabs; caller-owned outputs of the forward unchanged);
+ * 105 round 4 (rl8_gather_minibatch takes index = NULL: all samples in order). */
+#define RL8_ABI_VERSION 105
 int rl8_abi_version(char *arch, int arch_len);
 
 /* Scratch the reductions need (bytes); the caller allocates it once per stream
@@ -285,6 +286,10 @@ int rl8_ppo_loss_normal_fwd_bwd_f32(const float *mean, const float *log_std, con
  * _feedforward.py:481).  Each of the `n_fields` sources is a buffer leaf with
  * element strides; the matching destination is a dense [M][row_elems] array.
  * Elements are 4 or 8 bytes wide (f32 / int64).
+ * index = NULL (ABI 105): every sample of the buffer in order, s = 0 .. m - 1 with m = N h -- the sequence-major
+ * copy of a time-major buffer that the recurrent algorithm trains on -- as a transposition through LDS tiles
+ * (each byte read and written once, where the indexed kernel moves 6x that for 4-byte leaves); rows of at most
+ * 128 bytes summed over the fields, else RL8_ESIZE.
  * ---------------------------------------------------------------------- */
 typedef struct {
   const void *src;

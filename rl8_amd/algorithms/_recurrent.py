@@ -421,7 +421,9 @@ class RecurrentAlgorithm(Algorithm):
         for seq_index in torch.split(perm, local_mb):
             # reference sequence id q = env * (H/L) + s  ->  sample ids q*L + j
             sample_ids = (seq_index[:, None] * L + steps[None, :]).reshape(-1).contiguous()
-            gathered = hip.gather_minibatch(sample_ids, H, [self.buffer[k] for k in self.TRAIN_KEYS])
+            # (the whole buffer in order: a transposition through LDS tiles, every byte moved once -- the indexed
+            # gather reads a 64-byte sector per 4-byte cell of a time-major leaf)
+            gathered = hip.gather_minibatch(None if whole else sample_ids, H, [self.buffer[k] for k in self.TRAIN_KEYS])
             batch = dict(zip(self.TRAIN_KEYS, gathered))
             first_ids = (seq_index * L).contiguous()
             states = hip.gather_minibatch(

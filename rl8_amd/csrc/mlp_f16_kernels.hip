@@ -160,25 +160,15 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
 #pragma unroll
     for (int q = 0; q < kOut; ++q) w3max[q] = 0.0f;
   } else {
-    // (thread = k: a wave's 64 by lane exchange, the four waves' through LDS -- not 256 dependent LDS reads per thread
-    // and output: see mlp_rows_forward_kernel's prologue)
-    float *red = reinterpret_cast<float *>(smem);  // [wave][kOut]
-    float mine[kOut];
-#pragma unroll
-    for (int q = 0; q < kOut; ++q) mine[q] = q < n_out ? __builtin_fabsf(w3[q * kHidden + tid]) : 0.0f;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int q = 0; q < kOut; ++q) mine[q] = __builtin_fmaxf(mine[q], __shfl_xor(mine[q], off, 64));
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < kOut; ++q) red[wave * kOut + q] = mine[q];
-    }
-    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);
 #pragma unroll
     for (int q = 0; q < kOut; ++q) {
-      const float mx = __builtin_fmaxf(__builtin_fmaxf(red[q], red[kOut + q]), __builtin_fmaxf(red[2 * kOut + q], red[3 * kOut + q]));
-      w3max[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(__builtin_fmaxf(mx, 0.0f))));
+      __syncthreads();
+      red[tid] = q < n_out ? __builtin_fabsf(w3[q * kHidden + tid]) : 0.0f;
+      __syncthreads();
+      float mx = 0.0f;
+      for (int i = 0; i < kHidden; ++i) mx = __builtin_fmaxf(mx, red[i]);
+      w3max[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
     }
     __syncthreads();
   }

@@ -213,6 +213,9 @@ __global__ __launch_bounds__(kBlock) void pack_samples_kernel(int64_t n, int64_t
 // wave store.  Any strides (an env-major buffer reads poorly and still writes well).
 constexpr int kPackEnvs = 64, kPackSteps = 32;
 constexpr int kMaxPackedVecsDecl = 8;  // (= kMaxPackedVecs below: rows of up to 128 bytes)
+// DENSE (round 4; rl8_gather_minibatch with index = NULL): the same tiles leave as the DENSE per-field rows of a gather of
+// every sample in order -- dst_f[(env h + t)] -- instead of packed rows: an env's `steps` rows of a field are contiguous.
+template <bool DENSE>
 __global__ __launch_bounds__(kBlock) void pack_samples_tiled_kernel(int64_t n, int64_t h, uint32_t *__restrict__ packed,
                                                                     PackedArgs args, int tile_steps) {
   extern __shared__ uint32_t tile[];  // [step][env][row_words + 1]
@@ -260,13 +263,29 @@ __global__ __launch_bounds__(kBlock) void pack_samples_tiled_kernel(int64_t n, i
     __syncthreads();
     // out: env-major, this tile's `steps` rows of an env contiguous in memory -- a wave takes every fourth env and
     // writes its steps x row bytes front to back, 1 KiB per store instruction
-    const int vecs = rw / 4, per_env = steps * vecs;
-    for (int el = wave; el < envs; el += kBlock / kWave) {
-      uint4 *out = reinterpret_cast<uint4 *>(packed + ((e0 + el) * h + t0) * rw);
-      for (int i = lane; i < per_env; i += kWave) {
-        const int tl = i / vecs, q = i - tl * vecs;
-        const uint32_t *w = tile + (tl * kPackEnvs + el) * pitch + 4 * q;
-        out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    if constexpr (DENSE) {
+      for (int el = wave; el < envs; el += kBlock / kWave) {
+        int off = 0;
+        for (int f = 0; f < args.n_fields; ++f) {
+          const rl8_gather_field &fd = args.f[f];
+          const int words = fd.row_elems * (fd.elem_bytes / 4), per_env = steps * words;
+          uint32_t *out = static_cast<uint32_t *>(fd.dst) + ((e0 + el) * h + t0) * words;
+          for (int i = lane; i < per_env; i += kWave) {
+            const int tl = i / words, c = i - tl * words;
+            out[i] = tile[(tl * kPackEnvs + el) * pitch + off + c];
+          }
+          off += words;
+        }
+      }
+    } else {
+      const int vecs = rw / 4, per_env = steps * vecs;
+      for (int el = wave; el < envs; el += kBlock / kWave) {
+        uint4 *out = reinterpret_cast<uint4 *>(packed + ((e0 + el) * h + t0) * rw);
+        for (int i = lane; i < per_env; i += kWave) {
+          const int tl = i / vecs, q = i - tl * vecs;
+          const uint32_t *w = tile + (tl * kPackEnvs + el) * pitch + 4 * q;
+          out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
       }
     }
     __syncthreads();
@@ -389,10 +408,22 @@ RL8_API int rl8_rollout_stats_f32(const float *rewards, const float *rdr, int64_
   return launch_status();
 }
 
+static int packed_args(const rl8_gather_field *fields, int n_fields, int row_words, bool need_src, bool need_dst, PackedArgs *args);
+template <bool DENSE>
+static int launch_pack_tiled(const PackedArgs &args, int64_t n, int64_t h, uint32_t *packed, hipStream_t stream);
+
 RL8_API int rl8_gather_minibatch(const int64_t *index, int64_t m, int64_t h,
                                  const rl8_gather_field *fields, int n_fields, void *stream) {
-  if (!index || !fields) return RL8_ENULL;
+  if (!fields) return RL8_ENULL;
   if (m <= 0 || h <= 0 || n_fields <= 0 || n_fields > RL8_MAX_GATHER_FIELDS) return RL8_ESIZE;
+  if (!index) {  // every sample of the buffer in order (m = n h): a tiled transposition, each byte read and written once
+    if (m % h) return RL8_ESIZE;
+    int words = 0;
+    for (int f = 0; f < n_fields; ++f) words += fields[f].row_elems > 0 ? fields[f].row_elems * (fields[f].elem_bytes / 4) : 0;
+    PackedArgs tiled;
+    if (const int st = packed_args(fields, n_fields, (words + 3) / 4 * 4, true, true, &tiled)) return st;
+    return launch_pack_tiled<true>(tiled, m / h, h, nullptr, (hipStream_t)stream);
+  }
   GatherArgs args;
   args.n_fields = 0;
   hipStream_t s = (hipStream_t)stream;
@@ -437,6 +468,26 @@ static int packed_args(const rl8_gather_field *fields, int n_fields, int row_wor
   return RL8_OK;
 }
 
+// The tiled transposition behind rl8_pack_samples (packed rows) and rl8_gather_minibatch(index = NULL) (dense fields).
+template <bool DENSE>
+static int launch_pack_tiled(const PackedArgs &args, int64_t n, int64_t h, uint32_t *packed, hipStream_t stream) {
+  // timesteps per tile: 36 KiB of LDS (16 steps of 32-byte rows), four workgroups per CU -- measured at 2^20 x 32:
+  // 18 KiB 463 us, 36 KiB 471, 72 KiB (32 steps, two per CU) 632, the lane-per-sample kernel 967
+  const int per_step = kPackEnvs * (args.row_words + 1) * 4;
+  static const int lds_kib = env_int("RL8_PACK_TILE_KIB") > 0 ? env_int("RL8_PACK_TILE_KIB") : 36;
+  int tile_steps = (lds_kib * 1024 + per_step - 1) / per_step;
+  tile_steps = tile_steps > kPackSteps ? kPackSteps : tile_steps < 1 ? 1 : tile_steps;
+  if (tile_steps > h) tile_steps = (int)h;
+  const int64_t tiles = ((n + kPackEnvs - 1) / kPackEnvs) * ((h + tile_steps - 1) / tile_steps);
+  const int lds = tile_steps * per_step;
+  static LdsOptIn lds_pack;
+  if (const int e = allow_dynamic_lds(lds_pack, reinterpret_cast<const void *>(&pack_samples_tiled_kernel<DENSE>), 160 * 1024)) return e;
+  const int per_cu = (160 * 1024) / (lds + 512) < 1 ? 1 : (160 * 1024) / (lds + 512);
+  const int grid = (int)(tiles < (int64_t)per_cu * kCUs ? tiles : (int64_t)per_cu * kCUs);
+  pack_samples_tiled_kernel<DENSE><<<grid, kBlock, lds, stream>>>(n, h, packed, args, tile_steps);
+  return launch_status();
+}
+
 RL8_API int rl8_pack_samples(const rl8_gather_field *fields, int n_fields, int64_t n, int64_t h,
                              void *packed, int row_words, void *stream) {
   if (!packed) return RL8_ENULL;
@@ -449,21 +500,7 @@ RL8_API int rl8_pack_samples(const rl8_gather_field *fields, int n_fields, int64
   if (untiled)
     return dispatch_packed(true, grid_for(n * h, kBlock), (hipStream_t)stream, n, h, nullptr, 0,
                            static_cast<uint32_t *>(packed), args);
-  // timesteps per tile: 36 KiB of LDS (16 steps of 32-byte rows), four workgroups per CU -- measured at 2^20 x 32:
-  // 18 KiB 463 us, 36 KiB 471, 72 KiB (32 steps, two per CU) 632, the lane-per-sample kernel 967
-  const int per_step = kPackEnvs * (args.row_words + 1) * 4;
-  static const int lds_kib = env_int("RL8_PACK_TILE_KIB") > 0 ? env_int("RL8_PACK_TILE_KIB") : 36;
-  int tile_steps = (lds_kib * 1024 + per_step - 1) / per_step;
-  tile_steps = tile_steps > kPackSteps ? kPackSteps : tile_steps < 1 ? 1 : tile_steps;
-  if (tile_steps > h) tile_steps = (int)h;
-  const int64_t tiles = ((n + kPackEnvs - 1) / kPackEnvs) * ((h + tile_steps - 1) / tile_steps);
-  const int lds = tile_steps * per_step;
-  static LdsOptIn lds_pack;
-  if (const int e = allow_dynamic_lds(lds_pack, reinterpret_cast<const void *>(&pack_samples_tiled_kernel), 160 * 1024)) return e;
-  const int per_cu = (160 * 1024) / (lds + 512) < 1 ? 1 : (160 * 1024) / (lds + 512);
-  const int grid = (int)(tiles < (int64_t)per_cu * kCUs ? tiles : (int64_t)per_cu * kCUs);
-  pack_samples_tiled_kernel<<<grid, kBlock, lds, (hipStream_t)stream>>>(n, h, static_cast<uint32_t *>(packed), args, tile_steps);
-  return launch_status();
+  return launch_pack_tiled<false>(args, n, h, static_cast<uint32_t *>(packed), (hipStream_t)stream);
 }
 
 RL8_API int rl8_gather_packed(const int64_t *index, int64_t m, const void *packed, int row_words,

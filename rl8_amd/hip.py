@@ -177,7 +177,7 @@ SIGNATURES: dict[str, list[Any]] = {
 
 
 #: RL8_ABI_VERSION of include/rl8_amd.h this binding is written against (checked against the library in ``load``).
-ABI_VERSION = 104
+ABI_VERSION = 105
 
 
 def library_path() -> str:
@@ -754,12 +754,16 @@ def ppo_loss_normal(
 # --------------------------------------------------------------------------- #
 # Minibatch gather.
 # --------------------------------------------------------------------------- #
-def gather_minibatch(index: torch.Tensor, h: int, leaves: Sequence[torch.Tensor]) -> list[torch.Tensor]:
+def gather_minibatch(index: None | torch.Tensor, h: int, leaves: Sequence[torch.Tensor]) -> list[torch.Tensor]:
     """index [M] int64 of reference sample ids (env*H + t); leaves are [N, T, d]
     buffer leaves (any stride over env/time, dense over d). Returns dense [M, d]
-    tensors."""
-    _dense(index, torch.int64, "index")
-    m = index.numel()
+    tensors. ``index=None``: every sample in order (``M = N * h``), as a tiled
+    transposition (narrow leaves only: at most 128 bytes per sample in all)."""
+    if index is None:
+        m = leaves[0].shape[0] * h
+    else:
+        _dense(index, torch.int64, "index")
+        m = index.numel()
     if len(leaves) > MAX_GATHER_FIELDS:
         raise ValueError(f"at most {MAX_GATHER_FIELDS} leaves per gather")
     fields = (GatherField * len(leaves))()
@@ -783,7 +787,7 @@ def gather_minibatch(index: torch.Tensor, h: int, leaves: Sequence[torch.Tensor]
         fields[i] = GatherField(_ptr(leaf), _ptr(dst), leaf.stride(0), leaf.stride(1), row, leaf.element_size())
         outs.append(dst)
     with _timed("gather_minibatch", m):
-        _check(load().rl8_gather_minibatch(_ptr(index), m, h, fields, len(leaves), _stream()),
+        _check(load().rl8_gather_minibatch(_ptr(index) if index is not None else None, m, h, fields, len(leaves), _stream()),
                "rl8_gather_minibatch")
     return outs
 

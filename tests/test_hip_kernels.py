@@ -35,7 +35,7 @@ def host(t):
 
 def test_abi_loads_on_device():
     version, arch = hip.abi_version()
-    assert version == hip.ABI_VERSION == 104 and arch == "gfx950"
+    assert version == hip.ABI_VERSION == 105 and arch == "gfx950"
     assert torch.cuda.get_device_properties(0).gcnArchName.startswith("gfx950")
 
 
@@ -598,6 +598,11 @@ def test_pack_samples_tiles_ragged_shapes(n, h, widths, time_major):
     index = torch.randperm(n * h, device=DEV, generator=g)[: max(1, n * h // 3)]
     for leaf, out in zip(leaves, packed.gather(index.contiguous())):
         assert torch.equal(out, leaf[index // h, index % h])
+    # rl8_gather_minibatch(index = NULL): the same tiles leave as the dense fields of a gather of every sample in order
+    everything = torch.arange(n * h, device=DEV)
+    for dense, indexed, leaf in zip(hip.gather_minibatch(None, h, leaves), hip.gather_minibatch(everything, h, leaves), leaves):
+        assert dense.dtype == leaf.dtype and torch.equal(dense, indexed)
+        assert torch.equal(dense, leaf[:, :h].reshape(n * h, *leaf.shape[2:]))
 
 
 # --------------------------------------------------------------------------- #
