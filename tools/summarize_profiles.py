@@ -41,6 +41,24 @@ def stats(src: str, dst: str, keep: int = 25) -> None:
             w.writerow([short(r["Name"]), r["Calls"], f"{float(r['AverageNs']) / 1e3:.2f}",
                         f"{float(r['TotalDurationNs']) / 1e6:.3f}", f"{100 * float(r['TotalDurationNs']) / total:.3f}"])
         w.writerow(["TOTAL (all kernels)", sum(int(r["Calls"]) for r in rows), "", f"{total / 1e6:.3f}", "100"])
+        # One symbol, two launch sizes (since round 4 the rollout's recording launches of 2^20 rows and the training
+        # launches of 2^25 run the same forward kernel): rocprofv3's average mixes them.  From the dispatch trace beside
+        # the stats file: kernels whose longest dispatch is 8x their shortest, split at the geometric mean.
+        trace = src.replace("kernel_stats.csv", "kernel_trace.csv")
+        try:
+            per = collections.defaultdict(list)
+            for r in csv.DictReader(open(trace)):
+                if "rl8::" in r["Kernel_Name"]:
+                    per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            for name, us in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                if len(us) < 2 or max(us) < 8 * min(us):
+                    continue
+                cut = (max(us) * min(us)) ** 0.5
+                for label, part in (("long", [u for u in us if u >= cut]), ("short", [u for u in us if u < cut])):
+                    w.writerow([f"{name} [{label} launches]", len(part), f"{sum(part) / len(part):.2f}",
+                                f"{sum(part) / 1e3:.3f}", f"{100 * sum(part) * 1e3 / total:.3f}"])
+        except FileNotFoundError:
+            pass
     print(f"wrote {dst}: {len(picked)} rows")
 
 
