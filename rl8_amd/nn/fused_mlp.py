@@ -167,9 +167,11 @@ def _tower_backward(ctx, dout):
                                            save_h1=False, save_gate=True)[2]
 
     info: dict = {}
+    # (a two-output head an earlier backward found NOT to be a pair -- mean / log_std of a normal -- is not asked again)
+    known_general = w3.shape[0] == 2 and layer2.__dict__.get("_rl8_rank_one") is False
     g = hip.mlp_tower_backward(x, h1, h2, dout.contiguous().float(), _packed(layer2, True, split), w3,
                                w1, b1, wgrad_split=BACKWARD_GEMM == "f16", gate2=gate if split else None,
-                               gate_pack=gate_pack, w2=w2, b2=b2, h2_fn=h2_again, info=info)
+                               gate_pack=gate_pack, w2=w2, b2=b2, h2_fn=h2_again, info=info, assume_general=known_general)
     if w3.shape[0] == 2:  # what this backward found, for callers that give no hint (see tower_forward)
         layer2.__dict__["_rl8_rank_one"] = bool(info.get("rank_one", False))
     return None, g["w1"], g["b1"], g["w2"], g["b2"], g["w3"], g["b3"], None, None, None, None
