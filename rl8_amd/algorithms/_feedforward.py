@@ -343,7 +343,10 @@ class Algorithm:
         self.buffer = TensorDict(views, batch_size=[num_envs, horizon + 1], device=device)
 
     def _release_step_caches(self) -> None:
-        """What a subclass kept for the SGD iterations of the step() that is ending."""
+        """What was kept for the SGD iterations of the step() that is ending (subclasses add theirs)."""
+        from ..nn import fused_mlp
+
+        fused_mlp._TRUSTED_PAIRS.clear()  # (a loss gradient nobody ran a backward on)
 
     def _reset_buffer(self) -> None:
         """``buffer_spec.zero(...)`` then ``obs[:, -1] = final_obs`` (and the final

@@ -393,6 +393,8 @@ class RecurrentAlgorithm(Algorithm):
     def _release_step_caches(self) -> None:
         from ..nn import fused_lstm
 
+        super()._release_step_caches()
+
         fused_lstm.clear_state_cache()  # the planes of the initial hidden states, shared by the SGD iterations
 
     def _iter_minibatches(self, sgd_iter: int):

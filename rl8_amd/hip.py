@@ -1001,7 +1001,7 @@ def mlp_tower_backward(
     w2t_packed: torch.Tensor, w3: torch.Tensor,
     w1: None | torch.Tensor = None, b1: None | torch.Tensor = None, *, wgrad_split: bool = False,
     gate2: None | torch.Tensor = None, gate_pack=None, w2: None | torch.Tensor = None, b2: None | torch.Tensor = None,
-    h2_fn=None, info: None | dict = None, assume_general: bool = False,
+    h2_fn=None, info: None | dict = None, assume_general: bool = False, assume_pair: bool = False,
 ) -> dict[str, torch.Tensor]:
     """Gradients of one tower's parameters given ``dout`` [M, n_out] and the
     activations saved by the forward pass. Returns ``w1, b1, w2, b2, w3, b3``.
@@ -1020,7 +1020,8 @@ def mlp_tower_backward(
     h2 is never touched; if the head turns out not to be rank-one, ``h2_fn()`` must supply h2 (a forward re-run).
     ``info`` (a dict) receives ``rank_one``: whether the gate kernels ran.  ``assume_general`` (with ``h2``): a
     two-output head already known not to be a pair skips the check of ``dout`` (a pass over it and a host read per
-    call) and runs the general kernels, which are right for any ``dout``."""
+    call) and runs the general kernels, which are right for any ``dout``.  ``assume_pair``: ``dout`` [M, 2] is an exact
+    pair by construction (the caller vouches: the two-class loss kernel's own output) -- no check either."""
     m, d_in = x.shape
     n_out = w3.shape[0]
     split = w2t_packed.dtype == torch.uint8
@@ -1057,7 +1058,9 @@ def mlp_tower_backward(
         # behind the data-gradient launch so that the GPU has work while the host waits
         gates_on = not int(os.environ.get("RL8_WGRAD_GATE_OFF", "0") or 0)
         pair_flag, pair = None, False
-        if n_out == 2 and gates_on and not (assume_general and h2 is not None):
+        if n_out == 2 and gates_on and assume_pair:
+            pair = True
+        elif n_out == 2 and gates_on and not (assume_general and h2 is not None):
             pair_flag = _pair_flag(x.device)
             _check(lib.rl8_mlp_dout_pair_check(_ptr(dout), m, _ptr(pair_flag), _stream()), "rl8_mlp_dout_pair_check")
             if f16 and (gate_pack is not None or h2 is None):  # needed before the data gradient: read it now (a short bubble)

@@ -246,7 +246,12 @@ def fused_ppo_loss(
         )
         if not with_grad:
             return sums, [], []
-        return sums, [logits, values], [g_logits.to(logits.dtype), g_values.to(values.dtype)]
+        g_logits = g_logits.to(logits.dtype)
+        if logits.shape[-1] == 2 and logits.numel() == 2 * values.numel() and g_logits.dtype == torch.float32:
+            from . import fused_mlp
+
+            fused_mlp.trust_pair_gradient(g_logits)  # (one action dimension, two classes: the kernel stored g and -g)
+        return sums, [logits, values], [g_logits, g_values.to(values.dtype)]
     if issubclass(distribution_cls, Normal):
         if issubclass(distribution_cls, SquashedNormal) and entropy_coeff != 0:
             raise NotImplementedError(

@@ -23,10 +23,12 @@ def main() -> None:
     ap.add_argument("--num-envs", type=int, default=1 << 20)
     ap.add_argument("--horizon", type=int, default=32)
     ap.add_argument("--env", default="discrete")
+    ap.add_argument("--minibatches", type=int, default=1, help="shuffled minibatches per SGD iteration")
     args = ap.parse_args()
     torch.manual_seed(0)
     env = DiscreteDummyEnv if args.env == "discrete" else ContinuousDummyEnv
-    algo = AlgorithmConfig(num_envs=args.num_envs, horizon=args.horizon).build(env)
+    size = None if args.minibatches == 1 else args.num_envs * args.horizon // args.minibatches
+    algo = AlgorithmConfig(num_envs=args.num_envs, horizon=args.horizon, sgd_minibatch_size=size).build(env)
     algo.collect()
     algo.step()
     torch.cuda.synchronize()
