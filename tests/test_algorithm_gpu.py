@@ -680,6 +680,42 @@ def test_first_sgd_iteration_of_a_two_action_policy_stores_no_h2():
     assert "mlp_tower_backward" not in launched and "mlp_wgrad" not in launched
 
 
+def test_pair_check_is_skipped_only_for_the_loss_kernels_own_gradient():
+    """The two-class loss kernel stores g and -g, and ``fused_ppo_loss`` vouches for exactly that tensor: the policy
+    tower's backward then neither launches ``rl8_mlp_dout_pair_check`` nor reads its answer (a host round trip per
+    backward).  Without the registration -- or when the gradient reaching the tower is another tensor, e.g. modified in
+    place after the loss -- the check runs as before; the update is bit for bit the same either way."""
+    from rl8_amd import hip
+    from rl8_amd.nn import fused_mlp
+
+    def run(register, touch=False):
+        torch.manual_seed(3)
+        algo = AlgorithmConfig(num_envs=512, horizon=8, num_sgd_iters=3).build(DiscreteDummyEnv)
+        algo.collect()
+        checks = []
+        real_flag, real_trust = hip._pair_flag, fused_mlp.trust_pair_gradient
+
+        def trust(g):
+            if register:
+                real_trust(g)
+                if touch:
+                    g.mul_(1.0)  # (same values, new version: no longer the tensor that was vouched for)
+
+        with patch.object(hip, "_pair_flag", lambda dev: checks.append(1) or real_flag(dev)), \
+                patch.object(fused_mlp, "trust_pair_gradient", trust):
+            stats = algo.step()
+        assert not fused_mlp._TRUSTED_PAIRS  # (consumed or released with the step)
+        return len(checks), stats, torch.cat([p.detach().flatten() for p in algo.policy.model.parameters()])
+
+    n_trusted, s0, p0 = run(True)
+    n_checked, s1, p1 = run(False)
+    n_touched, s2, p2 = run(True, touch=True)
+    assert n_trusted == 0 and n_checked == 3 and n_touched == 3, (n_trusted, n_checked, n_touched)
+    assert torch.equal(p0, p1) and torch.equal(p0, p2)
+    for k in s0:
+        assert s0[k] == s1[k] or (isinstance(s0[k], float) and math.isnan(s0[k])) or k.startswith("profiling"), k
+
+
 def test_recurrent_full_buffer_minibatch_is_gathered_once_in_buffer_order():
     """One minibatch = the whole buffer: the recurrent step() lays the sequences out once, in buffer order, and reads
     that copy in every SGD iteration -- bit for bit what injecting the identity permutation (a gather per iteration)
