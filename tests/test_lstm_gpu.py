@@ -375,6 +375,38 @@ def test_lstm_backward_on_planes_matches_autograd(b, l, d_in):
         hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, split=False, rows_packed=hip.lstm_rows_backward_pack(lstm.weight_hh_l0))
 
 
+@pytest.mark.parametrize("case", ["plain", "one_outlier_sequence", "six_decades"])
+def test_lstm_weight_gradient_planes_hold_over_the_dynamic_range(case, monkeypatch):
+    """The LSTM's weight gradient runs on two fp16 planes per operand WITHOUT a guard on the data:
+    dG is scaled by its true maximum and its low plane is wide.  Entry by entry against fp64 on the kernel's own dG,
+    relative to the entry's sum of |terms|: with one sequence 10^6 above all others, or sequences spread over six
+    decades, the fp16 planes stay within 3 x the exact bf16 planes' error + 2e-7."""
+    b, l, d_in = 3000, 4, 1
+    lstm = reference_lstm(d_in, 77)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(b, l, d_in, device=DEV, generator=g) * 3
+    h0 = torch.randn(b, 256, device=DEV, generator=g) * 0.5
+    c0 = torch.randn(b, 256, device=DEV, generator=g)
+    dhs = torch.randn(b, l, 256, device=DEV, generator=g) / (b * l)
+    if case == "one_outlier_sequence":
+        dhs[b // 3] *= 1e6
+    elif case == "six_decades":
+        dhs *= 10.0 ** torch.randint(-4, 3, (b, 1, 1), device=DEV, generator=g).float()
+    hs, hn, cn, gates, cs = hip.lstm_forward(x, h0, c0, pack(lstm), save=True)
+    packed = hip.lstm_rows_backward_pack(lstm.weight_hh_l0)
+    run = lambda: hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, split=True, rows_packed=packed)  # noqa: E731
+    f16 = run()
+    monkeypatch.setenv("RL8_AMD_LSTM_WGRAD_PLANES", "bf16")
+    exact = run()
+    dg = hip.lstm_rows_backward(c0, gates, cs, dhs, packed).double().reshape(b, l, 1024)
+    h_prev = torch.cat([h0[:, None], hs[:, :-1]], 1).double()
+    want = torch.einsum("blj,bli->ji", dg, h_prev)
+    size = torch.einsum("blj,bli->ji", dg.abs(), h_prev.abs()) + 1e-300
+    err16 = float(((f16["w_hh"].double() - want).abs() / size).max())
+    err_exact = float(((exact["w_hh"].double() - want).abs() / size).max())
+    assert err16 <= 3 * err_exact + 2e-7, (case, err16, err_exact)
+
+
 def test_lstm_rows_backward_repeats_bit_for_bit():
     c0, gates, cs, dhs, w_hh = _rows_backward_inputs(8192, 4, 5)
     packed = hip.lstm_rows_backward_pack(w_hh)
