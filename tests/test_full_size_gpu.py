@@ -191,3 +191,6 @@ def test_pack_and_gather_full_size_bit_exact():
     idx = perm[:chunk].contiguous()
     for leaf, out in zip(leaves, hip.gather_minibatch(idx, H, leaves)):
         assert torch.equal(out, leaf[idx // H, idx % H])
+    # ... and every sample in order (index = NULL: the tiled transposition) = the leaves' own [N, H] prefix
+    for leaf, out in zip(leaves, hip.gather_minibatch(None, H, leaves)):
+        assert torch.equal(out, leaf[:, :H].reshape(N * H, 1))

@@ -38,6 +38,25 @@ def _rel(got, want):
     return float((got.double() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
 
 
+@pytest.mark.parametrize("d_in", [1, 2, 3, 5])
+@pytest.mark.parametrize("where", [0, 63, 64, 191, 255])
+def test_forward_row_scale_sees_the_largest_layer_one_entry_wherever_it_sits(d_in, where):
+    """The row factor of the fp16 planes comes from max |b1| and max_k |w1[k][i]| -- a workgroup reduction over the 256
+    units (one per thread: lane exchange within a wave, LDS across the four waves).  One unit with a bias and weights a
+    thousand times the others', at the first / last lane of a wave and of the workgroup: missed, its h1 would overflow
+    the fp16 planes (inf / NaN in the output); found, the forward stays at fp32 accuracy."""
+    g = torch.Generator(device=DEV).manual_seed(100 * d_in + where)
+    m, n_out = 777, 2
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 20
+    p = _params(g, d_in, n_out)
+    p["b1"][where] = 300.0
+    p["w1"][where] = 150.0 * torch.sign(torch.randn(d_in, device=DEV, generator=g))
+    out = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"])[0]
+    want = _tower(x.double(), {k: v.double() for k, v in p.items()})[0]
+    assert torch.isfinite(out).all()
+    assert _rel(out, want) < 5e-6
+
+
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (127, 1, 1), (128, 1, 2), (129, 2, 3), (1000, 5, 3), (4097, 1, 3),
                                           (5000, 3, 2), (70_001, 1, 2), (33_333, 5, 1), (20_000, 2, 2)])
 @pytest.mark.parametrize("scheme", ["f16x2"])
