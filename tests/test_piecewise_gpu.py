@@ -168,3 +168,34 @@ def test_a_table_too_large_for_the_kernels_steps_aside(monkeypatch):
     assert torch.equal(out, hip.mlp_tower_forward_split(x, *[t.detach() for t in (tower[0].weight, tower[0].bias)],
                                                         hip.mlp_pack_w2_f16(tower[2].weight.detach()), tower[2].bias.detach(),
                                                         tower[4].weight.detach(), tower[4].bias.detach())[0])
+
+
+@pytest.mark.parametrize("env_name", ["discrete", "continuous_squashed"])
+def test_six_updates_from_tables_track_the_matrix_towers(env_name, monkeypatch):
+    """Six collect() + step() rounds of the same seeded algorithm with the towers from tables and from the matrix kernels:
+    the two evaluate the same function to fp32 rounding, so rollouts (same Philox noise), losses and the weights after
+    six updates stay together -- collect statistics to 1e-4, losses to 2e-3 of their size, weights to 1e-3 of the
+    largest (a rare action that flips on a last-bit difference of a logit moves one env's trajectory, no more)."""
+    from rl8_amd import AlgorithmConfig
+    from rl8_amd.distributions import SquashedNormal
+    from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv
+
+    def run(tables):
+        monkeypatch.setattr(piecewise_mlp, "ENABLED", tables)
+        torch.manual_seed(5)
+        if env_name == "discrete":
+            algo = AlgorithmConfig(num_envs=4096, horizon=16).build(DiscreteDummyEnv)
+        else:
+            algo = AlgorithmConfig(num_envs=4096, horizon=16, distribution_cls=SquashedNormal).build(ContinuousDummyEnv)
+        out = [(algo.collect(), algo.step()) for _ in range(6)]
+        return out, torch.cat([p.detach().flatten() for p in algo.policy.model.parameters()])
+
+    before = dict(piecewise_mlp.stats)
+    (matrix, w_matrix), (tables, w_tables) = run(False), run(True)
+    assert piecewise_mlp.stats["forwards"] > before["forwards"] and piecewise_mlp.stats["backwards"] > before["backwards"]
+    for (c0, s0), (c1, s1) in zip(matrix, tables):
+        for k in ("returns/mean", "rewards/mean", "returns/std"):
+            assert c1[k] == pytest.approx(c0[k], rel=1e-4), k
+        for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+            assert s1[k] == pytest.approx(s0[k], rel=2e-3, abs=2e-6), k
+    assert float((w_tables - w_matrix).abs().max()) <= 1e-3 * float(w_matrix.abs().max())
