@@ -1,7 +1,7 @@
 """Which kernels run inside one feed-forward collect() + step() of the headline configuration (2^20 envs x 32), torch's
 own (copies, fills, reductions) beside the library's, by total device time.
 
-    python tools/diag/feedforward_aten_ops.py [--num-envs 1048576] [--horizon 32] [--env discrete|continuous]
+    python tools/diag/feedforward_aten_ops.py [--num-envs 1048576] [--horizon 32] [--env discrete|continuous|cartpole|mountain_car|pendulum] [--minibatches K]
 """
 from __future__ import annotations
 
@@ -26,7 +26,14 @@ def main() -> None:
     ap.add_argument("--minibatches", type=int, default=1, help="shuffled minibatches per SGD iteration")
     args = ap.parse_args()
     torch.manual_seed(0)
-    env = DiscreteDummyEnv if args.env == "discrete" else ContinuousDummyEnv
+    if args.env == "cartpole":
+        from rl8_amd.envs.cartpole import CartPole as env
+    elif args.env == "mountain_car":
+        from rl8_amd.envs import MountainCar as env
+    elif args.env == "pendulum":
+        from rl8_amd.envs import Pendulum as env
+    else:
+        env = DiscreteDummyEnv if args.env == "discrete" else ContinuousDummyEnv
     size = None if args.minibatches == 1 else args.num_envs * args.horizon // args.minibatches
     algo = AlgorithmConfig(num_envs=args.num_envs, horizon=args.horizon, sgd_minibatch_size=size).build(env)
     algo.collect()
