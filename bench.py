@@ -101,7 +101,7 @@ ALGORITHMIC_BYTES = {
 
 # Fabric traffic of the recurrent bench's kernels (rocprofv3 --pmc TCC_EA0_* per launch at 8 192 envs x 256 steps,
 # tools/diag/recurrent_bench_pmc.sh -> profiles/r03_cfg5_fabric_traffic.txt): bytes per unit of the launch that was profiled
-FABRIC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_cfg5_fabric_traffic.txt") for r in (4, 3))
+FABRIC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_cfg5_fabric_traffic.txt") for r in (5, 4, 3))
                        if os.path.exists(p)), "")
 FABRIC_KERNEL = {  # bench name -> (substring of the profiled kernel's name, units of that launch)
     "lstm_rows_backward": ("lstm_rows_backward_heads_kernel", 1 << 21),
@@ -132,8 +132,8 @@ def fabric_traffic(name: str, units_per_launch: float):
 # passes over tools/kernel_microbench.py at config-2 shapes; corrected as
 # MI355X_MICROARCH.md prescribes; summary committed under profiles/). Scaled by
 # units to the launch size bench.py uses.
-PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_microbench.json") for r in (4, 3, 2, 1))
-                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc_traffic_microbench.json"))
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_microbench.json") for r in (5, 4, 3, 2, 1))
+                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r05_pmc_traffic_microbench.json"))
 PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in that profiled launch)
     "ppo_loss_categorical": ("ppo_loss_categorical_kernel", 1 << 22),
     "ppo_loss_normal": ("ppo_loss_normal1_kernel", 1 << 22),  # (the one-action-dim vector kernel: what configs 4 launches)
@@ -225,7 +225,11 @@ def parse_args(argv: None | list[str] = None) -> argparse.Namespace:
                    help="matrix (default, the product): the MFMA tower kernels.  piecewise: OPT-IN round-4 prototype for scalar"
                         " observations only (rl8_amd/nn/piecewise_mlp.py: each tower as an exact piecewise-linear table) -- a"
                         " labelled extra line, never the headline")
-    p.add_argument("--cpu-baseline-seconds", type=float, default=45.0)
+    p.add_argument("--uninstrumented-steps", type=int, default=10,
+                   help="after the timed region: this many more steps with the per-kernel HIP-event timers OFF, reported as"
+                        " value_uninstrumented / ms_per_step_uninstrumented beside the headline (0: skip)")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=120.0,
+                   help="cap on the CPU baseline's wall time (3 sweep points + 10 timed iterations take ~65 s on the GPU hosts)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args(argv)
 
@@ -399,7 +403,7 @@ def cpu_baseline(budget_s: float) -> dict:
 
     host_cpus = os.cpu_count() or 1
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus
-    candidates = sorted({t for t in (8, 16, 32, 64, 128) if t <= usable} | {min(usable, 8)})
+    candidates = sorted({t for t in (16, 32, 64) if t <= usable} | ({min(usable, 8)} if usable < 16 else set()))
     n = 8192 * 32
     torch.manual_seed(0)
     algo = OraclePPO("discrete", num_envs=8192, horizon=32)
@@ -410,27 +414,36 @@ def cpu_baseline(budget_s: float) -> dict:
         algo.step()
         return time.perf_counter() - t0
 
+    # warm-ups, then >= 10 timed collect()+step() iterations, median.  The warm-ups double as
+    # the thread-count sweep (one iteration per candidate after a first untimed one); the ten timed iterations all run
+    # at the fastest candidate.  ``budget_s`` caps the whole thing on a slow host (then fewer iterations, stated).
     t_start = time.perf_counter()
     sweep: dict[int, float] = {}
-    # likeliest optimum first: if the budget runs out early it has been seen
-    order = [t for t in (32, 64, 16, 8, 128) if t in candidates] + [t for t in candidates if t not in (32, 64, 16, 8, 128)]
+    order = [t for t in (32, 64, 16) if t in candidates] + [t for t in candidates if t not in (32, 64, 16)]
     torch.set_num_threads(order[0])
-    iteration()  # warm-up: thread pools, allocator, first-touch
+    iteration()  # thread pools, allocator, first touch
     for threads in order:
-        if sweep and time.perf_counter() - t_start > 0.6 * budget_s:
-            break
         torch.set_num_threads(threads)
         sweep[threads] = iteration()
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    times = [sweep[best]]
-    while time.perf_counter() - t_start < budget_s and len(times) < 50:
+    warmups = 1 + len(sweep)
+    while warmups < 3:
+        iteration()
+        warmups += 1
+    times: list[float] = []
+    while len(times) < 10 and (len(times) < 3 or time.perf_counter() - t_start < budget_s):
         times.append(iteration())
     elapsed = sum(times)
+    median = sorted(times)[len(times) // 2] if len(times) % 2 else 0.5 * (sorted(times)[len(times) // 2 - 1] + sorted(times)[len(times) // 2])
     return {
-        "value": n * len(times) / elapsed,
+        "value": n / median,
         "unit": "env transitions/sec",
-        "policy_updates_per_sec": len(times) / elapsed,
+        "policy_updates_per_sec": 1.0 / median,
+        "mean_value": n * len(times) / elapsed,
+        "iterations": len(times),
+        "warmup_iterations": warmups,
+        "iteration_seconds": {"median": round(median, 4), "min": round(min(times), 4), "max": round(max(times), 4)},
         "cores": best,
         "threads": best,
         "host_cpus": host_cpus,
@@ -438,9 +451,9 @@ def cpu_baseline(budget_s: float) -> dict:
         "cpu_model": cpu_model(),
         "sweep_transitions_per_sec": {str(t): round(n / v, 1) for t, v in sorted(sweep.items())},
         "kind": "port",
-        "sample": f"{len(times)} x (collect+step) at {best} torch threads (best of sweep {sorted(sweep)}),"
-                  f" DiscreteDummyEnv num_envs=8192 horizon=32 defaults (BASELINE configs[0]), {elapsed:.1f} s,"
-                  " oracle C kernels + torch-CPU MLP",
+        "sample": f"median of {len(times)} x (collect+step) after {warmups} warm-ups at {best} torch threads (best of sweep"
+                  f" {sorted(sweep)}), DiscreteDummyEnv num_envs=8192 horizon=32 defaults (BASELINE configs[0]),"
+                  f" {elapsed:.1f} s timed, oracle C kernels + torch-CPU MLP",
     }
 
 
@@ -559,6 +572,21 @@ def run(args: argparse.Namespace) -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     hip.timer.enabled = False
+    # The same loop without the per-kernel HIP-event pairs (~127 timed ABI calls per step above), same process, same
+    # barriers: what the instrumentation costs shows as the difference.
+    plain_elapsed = None
+    if args.uninstrumented_steps > 0:
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.uninstrumented_steps):
+            algo.collect()
+            algo.step()
+        barrier()
+        plain_elapsed = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([plain_elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            plain_elapsed = float(t)
     rank_elapsed = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
@@ -693,11 +721,18 @@ def run(args: argparse.Namespace) -> None:
                            "lstm_wgrad": "rl8_lstm_wgrad_f16_f32", "lstm_step_save": "rl8_lstm_step_split_f32"}.get(
                     dominant, f"rl8_{dominant}_{'f16' if top['gemm'] == 'f16x2-split' else 'split'}_f32"),
                 "bound": "mfma",
-                "achieved": top["executed_bf16_TFLOPs"],
+                # ALGORITHMIC FLOP of the launch (one fp32 product per multiply-add of the reference's
+                # arithmetic) / HIP-event time, against the dense 16-bit MFMA peak the kernel's products run on
+                "achieved": top["achieved_TFLOPs"],
                 "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": top["frac_of_bf16_mfma_peak"],
-                "flop_per_launch": top["executed_bf16_flop_per_launch"],
+                "frac": round(top["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                # what the matrix pipe EXECUTES: plane_products 16-bit products per fp32 product (fp32 accuracy on a
+                # 16-bit pipe), against the same peak -- the ceiling of this scheme is 1 / plane_products
+                "executed_TFLOPs": top["executed_bf16_TFLOPs"],
+                "executed_frac": top["frac_of_bf16_mfma_peak"],
+                "plane_products": top["plane_products"],
+                "executed_flop_per_launch": top["executed_bf16_flop_per_launch"],
                 "flop_definition": (f"{top['plane_products']} 16-bit plane products x 2*1024*256 per row-step (the recurrent product of"
                                     " the LSTM: fp32 operands as 3 exact bf16 planes / 2 scaled fp16 planes, fp32 accumulate)"
                                     if dominant.startswith("lstm_") else
@@ -716,8 +751,6 @@ def run(args: argparse.Namespace) -> None:
                 "f32_equivalent_frac_of_f32_mfma_peak": top["frac_of_f32_mfma_peak"],  # > 1: beyond the fp32 matrix roofline
                 "sustained_TFLOPs_measured": MFMA_16BIT_SUSTAINED_TFLOPS,  # tools/probes/mfma_shape_probe.hip (power-limited)
                 "frac_of_sustained": round(top["executed_bf16_TFLOPs"] / MFMA_16BIT_SUSTAINED_TFLOPS, 4),
-                # the ALGORITHM's fp32 FLOP (one product, not the plane products executed) against the 16-bit peak
-                "algorithmic_frac": round(top["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, 4),
                 "algorithmic_flop_per_launch": top["algorithmic_flop_per_launch"],
                 "avg_launch_ms": top["avg_ms"],
                 "launches": top["launches"],
@@ -751,6 +784,10 @@ def run(args: argparse.Namespace) -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "value_uninstrumented": (global_envs * horizon * args.uninstrumented_steps / plain_elapsed
+                                     if plain_elapsed else None),
+            "ms_per_step_uninstrumented": plain_elapsed / args.uninstrumented_steps * 1e3 if plain_elapsed else None,
+            "uninstrumented_steps": args.uninstrumented_steps if plain_elapsed else 0,
             "rank_ms_per_step": {"min": min(rank_elapsed) / args.steps * 1e3, "max": max(rank_elapsed) / args.steps * 1e3,
                                  "per_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed]},
             "collect_ms_per_step": collect_ms / args.steps,

@@ -18,7 +18,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "librl8_oracle.so")
+# RL8_ORACLE_LIB: another build of the same source (tests/test_oracle_sanitizers.py points it at the ASan + UBSan one)
+_LIB_PATH = os.environ.get("RL8_ORACLE_LIB") or os.path.join(_HERE, "_build", "librl8_oracle.so")
 _lib: None | C.CDLL = None
 
 
@@ -26,6 +27,8 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (a few seconds); returns the library path."""
     src = os.path.join(_HERE, "rl8_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "rl8_philox.h")
+    if os.environ.get("RL8_ORACLE_LIB"):
+        return _LIB_PATH  # (built by whoever set it)
     stale = not os.path.exists(_LIB_PATH) or any(
         os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH)
         for p in (src, hdr)

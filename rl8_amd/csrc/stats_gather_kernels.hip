@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void gather_minibatch_kernel(
     const int64_t *__restrict__ index, int64_t m, int64_t h, GatherArgs args) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) {
-    const int64_t s = index[i];
+    const int64_t s = index ? index[i] : i;  // (index = NULL: every sample in order)
     const int64_t env = s / h, t = s - env * h;
 #pragma unroll 1
     for (int f = 0; f < args.n_fields; ++f) {
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void gather_wide_rows_kernel(
   const int64_t waves = (int64_t)gridDim.x * kWavesPerBlock;
   const int vecs = (int)((int64_t)fd.row_elems * fd.elem_bytes / 16);
   for (int64_t i = wave0; i < m; i += waves) {
-    const int64_t s = index[i];
+    const int64_t s = index ? index[i] : i;
     const int64_t env = s / h, t = s - env * h;
     const char *src = static_cast<const char *>(fd.src) +
                       (env * fd.env_stride + t * fd.time_stride) * fd.elem_bytes;
@@ -416,13 +416,43 @@ RL8_API int rl8_gather_minibatch(const int64_t *index, int64_t m, int64_t h,
                                  const rl8_gather_field *fields, int n_fields, void *stream) {
   if (!fields) return RL8_ENULL;
   if (m <= 0 || h <= 0 || n_fields <= 0 || n_fields > RL8_MAX_GATHER_FIELDS) return RL8_ESIZE;
-  if (!index) {  // every sample of the buffer in order (m = n h): a tiled transposition, each byte read and written once
+  rl8_gather_field rest[RL8_MAX_GATHER_FIELDS];
+  if (!index) {
+    // Every sample of the buffer in order (m = n h): a tiled transposition, each byte read and written once.  A tile's
+    // row holds at most 4 kMaxPackedVecs words, so the fields go in groups that fit (in the order given); a field wider
+    // than that on its own takes the general kernels below with the implicit index i (the recurrent
+    // algorithm's whole-buffer copy returned RL8_ESIZE for observations of 28 floats and more).
     if (m % h) return RL8_ESIZE;
-    int words = 0;
-    for (int f = 0; f < n_fields; ++f) words += fields[f].row_elems > 0 ? fields[f].row_elems * (fields[f].elem_bytes / 4) : 0;
-    PackedArgs tiled;
-    if (const int st = packed_args(fields, n_fields, (words + 3) / 4 * 4, true, true, &tiled)) return st;
-    return launch_pack_tiled<true>(tiled, m / h, h, nullptr, (hipStream_t)stream);
+    constexpr int kTileWords = 4 * kMaxPackedVecsDecl;
+    int n_rest = 0, first = 0, words = 0;
+    auto flush = [&](int stop) -> int {
+      if (stop == first) return RL8_OK;
+      PackedArgs tiled;
+      if (const int st = packed_args(fields + first, stop - first, (words + 3) / 4 * 4, true, true, &tiled)) return st;
+      return launch_pack_tiled<true>(tiled, m / h, h, nullptr, (hipStream_t)stream);
+    };
+    for (int f = 0; f < n_fields; ++f) {
+      const rl8_gather_field &fd = fields[f];
+      if (!fd.src || !fd.dst) return RL8_ENULL;
+      if (fd.elem_bytes != 4 && fd.elem_bytes != 8) return RL8_ECONFIG;
+      if (fd.row_elems <= 0) return RL8_ESIZE;
+      const int w = fd.row_elems * (fd.elem_bytes / 4);
+      if (w > kTileWords) {  // (closes the current group: groups are runs of consecutive fields)
+        if (const int st = flush(f)) return st;
+        first = f + 1, words = 0;
+        rest[n_rest++] = fd;
+        continue;
+      }
+      if (words + w > kTileWords) {
+        if (const int st = flush(f)) return st;
+        first = f, words = 0;
+      }
+      words += w;
+    }
+    if (const int st = flush(n_fields)) return st;
+    if (n_rest == 0) return launch_status();
+    fields = rest;
+    n_fields = n_rest;
   }
   GatherArgs args;
   args.n_fields = 0;

@@ -757,8 +757,9 @@ def ppo_loss_normal(
 def gather_minibatch(index: None | torch.Tensor, h: int, leaves: Sequence[torch.Tensor]) -> list[torch.Tensor]:
     """index [M] int64 of reference sample ids (env*H + t); leaves are [N, T, d]
     buffer leaves (any stride over env/time, dense over d). Returns dense [M, d]
-    tensors. ``index=None``: every sample in order (``M = N * h``), as a tiled
-    transposition (narrow leaves only: at most 128 bytes per sample in all)."""
+    tensors. ``index=None``: every sample in order (``M = N * h``): a tiled
+    transposition for leaves of up to 128 bytes per sample (in groups that fit a
+    tile row), the general kernels with the implicit index for wider ones."""
     if index is None:
         m = leaves[0].shape[0] * h
     else:

@@ -90,12 +90,15 @@ class EnvShards:
         flat = torch.empty(self.world_size * raw.numel(), dtype=raw.dtype, device=src.device)
         dist.all_gather_into_tensor(flat, src, group=self.group)
         self.collectives += 1
-        gathered = flat.view(self.world_size, raw.numel()).to(raw.device)
-        out = torch.empty_like(raw)
-        out[list(STAT_SUM)] = gathered[:, list(STAT_SUM)].sum(0)
-        out[list(STAT_MIN)] = gathered[:, list(STAT_MIN)].min(0).values
-        out[list(STAT_MAX)] = gathered[:, list(STAT_MAX)].max(0).values
-        return out
+        # The caller reads the twelve numbers on the host next (``raw.tolist()``: the one sync of collect()), so the
+        # combination runs THERE on the gathered [world, 12] block -- sums, minima, maxima picked per column by two
+        # masks -- and launches nothing on the device (round 4: three list-indexed gathers + scatters, ~10 launches).
+        gathered = flat.view(self.world_size, raw.numel()).cpu()
+        is_min = torch.zeros(raw.numel(), dtype=torch.bool)
+        is_min[list(STAT_MIN)] = True
+        is_max = torch.zeros(raw.numel(), dtype=torch.bool)
+        is_max[list(STAT_MAX)] = True
+        return torch.where(is_min, gathered.min(0).values, torch.where(is_max, gathered.max(0).values, gathered.sum(0)))
 
     def sum_gradients_(self, params: Iterable[torch.nn.Parameter], sums: Sequence[torch.Tensor] = ()) -> None:
         """ONE SUM all-reduce per optimizer step: the flattened gradient of ``params``

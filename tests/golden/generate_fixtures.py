@@ -859,11 +859,51 @@ def gen_cartpole_first_update() -> None:
     from examples.cartpole import env as cp_env
 
     cp_env.step = _eager(cp_env.step)
+    gen_env_first_update("first_update_ff_cartpole.npz", cp_env.CartPole)
+
+
+def walk_env(d: int, a: int):
+    """The tests' own small environment (tests/_envs.py: same arithmetic against this build's ``Env``) written
+    against the REFERENCE's ``Env`` (src/rl8/env.py:16-128): a point in ``d`` dimensions, discrete action ``k`` of
+    ``a`` pushes coordinate ``k % d``; every operation is one fp32 rounding per element."""
+    from rl8.env import Env
+    from torchrl.data import Categorical as CategoricalSpec
+    from torchrl.data import Unbounded
+
+    class Walk(Env):
+        def __init__(self, num_envs, /, horizon=None, *, device="cpu"):
+            super().__init__(num_envs, horizon, device=device)
+            self.observation_spec = Unbounded(d, device=device)
+            self.action_spec = CategoricalSpec(a, shape=torch.Size([1]), device=device)
+
+        def reset(self, *, config=None):
+            self.state = torch.empty(self.num_envs, d, device=self.device).uniform_(-1.0, 1.0)
+            return self.state
+
+        def step(self, action):
+            push = torch.zeros_like(self.state)
+            push.scatter_(1, action.reshape(-1, 1) % d, 1.0)
+            self.state = 0.75 * self.state + push - 0.25
+            rewards = -self.state.abs().sum(-1, keepdim=True)
+            return TensorDict({DataKeys.OBS: self.state, DataKeys.REWARDS: rewards}, batch_size=self.num_envs,
+                              device=self.device)
+
+    return Walk
+
+
+def gen_walk_first_update() -> None:
+    """F10 (round 5): the reference's DefaultDiscreteModel (src/rl8/models/_feedforward.py:313-383)
+    on a 4-wide observation with a 4-way head -- widths none of the built-in environments has -- through collect() /
+    step(): rollout, the traced 4-iteration step's updates, and a one-iteration run's first gradient and weights."""
+    gen_env_first_update("first_update_ff_walk4.npz", walk_env(4, 4))
+
+
+def gen_env_first_update(fixture: str, env_cls) -> None:
     arrays = {}
 
     def run(tag, **overrides):
         torch.manual_seed(42)
-        algo = AlgorithmConfig(num_envs=64, horizon=32, device="cpu", **overrides).build(cp_env.CartPole)
+        algo = AlgorithmConfig(num_envs=64, horizon=32, device="cpu", **overrides).build(env_cls)
         init = {k: v.clone() for k, v in algo.policy.model.state_dict().items()}
         states = []
         with Recorder() as rec:
@@ -916,7 +956,7 @@ def gen_cartpole_first_update() -> None:
     for k, v in algo1.policy.model.state_dict().items():
         arrays[f"sgd1_final_{k}"] = v.clone()
     arrays["stat_keys"] = np.array(STAT_KEYS + ("reduce",))
-    save("first_update_ff_cartpole.npz", **arrays)
+    save(fixture, **arrays)
 
 
 def gen_early_stop() -> None:
@@ -983,6 +1023,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "cartpole":
         gen_cartpole_first_update()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "walk":
+        gen_walk_first_update()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "views":
         gen_views()
         return
@@ -1029,6 +1072,7 @@ def main() -> None:
     gen_second_iterations()
     gen_carried_second_iterations()
     gen_cartpole_first_update()
+    gen_walk_first_update()
 
 
 if __name__ == "__main__":

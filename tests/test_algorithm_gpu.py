@@ -749,3 +749,28 @@ def test_recurrent_full_buffer_minibatch_is_gathered_once_in_buffer_order():
     first = [b[DataKeys.OBS].clone() for b in algo._iter_minibatches(0)]
     second = [b[DataKeys.OBS].clone() for b in algo._iter_minibatches(1)]
     assert len(first) == 4 and not all(torch.equal(a, b) for a, b in zip(first, second))
+
+
+def test_recurrent_step_with_wide_observations():
+    """the recurrent step()'s whole-buffer copy (``rl8_gather_minibatch(index = NULL)``) with more
+    than 128 bytes per sample -- a 40-float observation -- used to return RL8_ESIZE.  Same update as the indexed
+    gather of the identity permutation, bit for bit (reference ``src/rl8/algorithms/_recurrent.py:510-518``: the
+    default models take any 1-D observation width)."""
+    from rl8_amd import RecurrentAlgorithmConfig
+
+    from ._envs import walk_env
+
+    def run(inject):
+        torch.manual_seed(5)
+        algo = RecurrentAlgorithmConfig(num_envs=48, horizon=16).build(walk_env(40, 2))
+        algo.collect()
+        if inject:
+            seqs = 48 * (16 // algo.hparams.seq_len)
+            algo.injected_permutations = [torch.arange(seqs) for _ in range(algo.hparams.num_sgd_iters)]
+        stats = algo.step()
+        return stats, torch.cat([p.detach().flatten() for p in algo.policy.model.parameters()])
+
+    (s0, p0), (s1, p1) = run(False), run(True)
+    for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+        assert math.isfinite(s0[k]) and s0[k] == s1[k], k
+    assert torch.equal(p0, p1)

@@ -28,6 +28,7 @@ from rl8_amd.distributions import SquashedNormal  # noqa: E402
 from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv  # noqa: E402
 from rl8_amd.envs.cartpole import CartPole  # noqa: E402
 
+from ._envs import walk_env  # noqa: E402
 from .test_algorithm_gpu import compare_collect, inject  # noqa: E402
 
 NUM_ENVS, HORIZON = 64, 32
@@ -49,6 +50,9 @@ VARIANTS = {
     # config 3: the reference's CartPole (examples/cartpole/env.py) through collect() / step();
     # the fixture is self-contained (initial weights, reset state, noise, rollout, updates, first gradient)
     "ff_cartpole": ("first_update_ff_cartpole.npz", CartPole, {}, False),
+    # round 5: widths outside the built-in environments' -- a 4-wide observation and a 4-way head
+    # (tests/_envs.py; the reference ran the same arithmetic through its DefaultDiscreteModel) on the plane kernels
+    "ff_walk4": ("first_update_ff_walk4.npz", walk_env(4, 4), {}, False),
 }
 
 STAT_KEYS = ("coefficients/entropy", "coefficients/vf", "losses/entropy", "losses/policy", "losses/vf",
@@ -315,7 +319,7 @@ def test_second_iteration_on_carried_state_matches_reference_to_1e5(golden, vari
     assert_first_update_and_gradient(rec, g, variant)
 
 
-@pytest.mark.parametrize("variant", [v for v in VARIANTS if v.startswith("ff_") and v != "ff_cartpole"])
+@pytest.mark.parametrize("variant", [v for v in VARIANTS if v.startswith("ff_") and v not in ("ff_cartpole", "ff_walk4")])
 def test_second_iteration_teacher_forced_matches_reference_to_1e5(golden, variant):
     """Iteration 1 of the traced configs from the REFERENCE's weights after iteration 0
     (``it0_final_*`` of the trace) instead of this build's drifted ones: a second rollout
@@ -368,14 +372,16 @@ def test_kl_early_stop_matches_reference(golden):
         np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"final_{k}"], rtol=0, atol=2e-4, err_msg=k)
 
 
-def test_cartpole_rollout_matches_reference(golden):
-    """collect() on the reference's CartPole rollout inputs (reset state, initial weights, multinomial noise):
-    action indices bit-exact, physics 1e-6 absolute per step (obs, rewards; one sin / cos per step differs by an ulp
-    between devices), log-probabilities / values / CollectStats at 1e-5."""
+@pytest.mark.parametrize("variant", ["ff_cartpole", "ff_walk4"])
+def test_env_rollout_matches_reference(golden, variant):
+    """collect() on the reference's rollout inputs (reset state, initial weights, multinomial noise) for the
+    self-contained fixtures -- CartPole, and the 4-wide / 4-way walk of tests/_envs.py: action indices bit-exact,
+    physics 1e-6 absolute per step (obs, rewards; one sin / cos per step differs by an ulp between devices),
+    log-probabilities / values / CollectStats at 1e-5."""
     from rl8_amd.data import DataKeys
 
-    g = golden("first_update_ff_cartpole.npz")
-    algo, _ = build(golden, "ff_cartpole")
+    g = golden(f"first_update_{variant}.npz")
+    algo, _ = build(golden, variant)
     stats = algo.collect()
     buf = algo.buffer
     assert np.array_equal(buf[DataKeys.ACTIONS][:, :HORIZON].cpu().numpy(), g["it0_collect_actions"][:, :HORIZON])

@@ -194,3 +194,109 @@ def test_pack_and_gather_full_size_bit_exact():
     # ... and every sample in order (index = NULL: the tiled transposition) = the leaves' own [N, H] prefix
     for leaf, out in zip(leaves, hip.gather_minibatch(None, H, leaves)):
         assert torch.equal(out, leaf[:, :H].reshape(N * H, 1))
+
+
+# --------------------------------------------------------------------------- #
+# Configs 3 and 4 at their own sizes: the fused CartPole step at 2^18 envs, the squashed-normal
+# loss at 2^25 samples, the continuous squashed rollout step at 2^20 envs -- index arithmetic and grid-stride tails of
+# those kernels at full grid, against the oracle on the same seeded inputs.
+# --------------------------------------------------------------------------- #
+def test_fused_cartpole_step_full_size():
+    """BASELINE configs[2]: CartPole, 2^18 environments (examples/cartpole/env.py:12-64 of the reference + the
+    sampler and bookkeeping of algorithms/_feedforward.py:362-393 in one launch): action indices and their
+    log-probabilities bit-exact, physics 1e-6."""
+    n = 1 << 18
+    rng = np.random.default_rng(33)
+    logits = rng.standard_normal((n, 1, 3)).astype(np.float32)
+    value = rng.standard_normal((n, 1)).astype(np.float32)
+    state0 = (rng.standard_normal((4, n)) * 0.5).astype(np.float32)
+    rdr0 = rng.standard_normal((n, 1)).astype(np.float32)
+    for integrator in (0, 1):
+        want_a, want_lp = oracle.categorical_sample(logits, seed=21, step=97, row_offset=0)
+        want_s, want_obs, want_r = oracle.cartpole_step(state0, want_a, oracle.cartpole_cfg(kinematics_integrator="semi-implicit" if integrator else "euler"))
+        state = dev(state0)
+        cfg = hip.CartPoleCfg(5.0, 9.8, 0.5, 0.1, 0.05, 1.1, 0.02, integrator)
+        action_col = torch.empty(n, 1, dtype=torch.int64, device=DEV)
+        cols = {k: torch.empty(n, 1, device=DEV) for k in ("logp", "value", "reward", "rdr1")}
+        obs = torch.empty(n, 5, device=DEV)
+        hip.rollout_step_cartpole(
+            logits=dev(logits), value=dev(value), noise=None, state=state, cfg=cfg, action_col=action_col,
+            logp_col=cols["logp"], value_col=cols["value"], reward_col=cols["reward"], obs_col_next=obs,
+            rdr_t=dev(rdr0), rdr_t1=cols["rdr1"], gamma=float(np.float32(0.95)), seed=21, step=97, env_offset=0,
+            deterministic=False)
+        assert np.array_equal(host(action_col), want_a)
+        assert set(np.unique(want_a)) == {0, 1, 2}
+        assert np.array_equal(host(cols["logp"]), want_lp)
+        assert np.array_equal(host(cols["value"]), value)
+        np.testing.assert_allclose(host(state), want_s, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(host(obs), want_obs, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(host(cols["reward"]), want_r, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(host(cols["rdr1"]), oracle.rdr_step(rdr0, want_r, 0.95), rtol=1e-6, atol=1e-6)
+
+
+def test_fused_continuous_squashed_step_full_size():
+    """BASELINE configs[3]'s rollout step: ContinuousDummyEnv + SquashedNormal at 2^20 environments
+    (src/rl8/distributions.py:147-170, env.py:224-230) with the build's own Philox noise."""
+    from .test_hip_kernels import assert_logp_close
+
+    n = N
+    rng = np.random.default_rng(41)
+    mean = rng.standard_normal((n, 1)).astype(np.float32)
+    log_std = np.tanh(rng.standard_normal((n, 1))).astype(np.float32)
+    value = rng.standard_normal((n, 1)).astype(np.float32)
+    state0 = rng.uniform(-100, 100, (n, 1)).astype(np.float32)
+    rdr0 = rng.standard_normal((n, 1)).astype(np.float32)
+    want_a, want_lp = oracle.normal_sample(mean, log_std, squashed=True, seed=9, step=31, row_offset=0)
+    want_s, want_r = oracle.dummy_env_step(state0, want_a)
+    state = dev(state0)
+    cols = {k: torch.empty(n, 1, device=DEV) for k in ("action", "logp", "value", "reward", "obs", "rdr1")}
+    hip.rollout_step_dummy(
+        discrete=False, squashed=True, features=dev(mean), features2=dev(log_std), value=dev(value), noise=None,
+        state=state, action_col=cols["action"], logp_col=cols["logp"], value_col=cols["value"],
+        reward_col=cols["reward"], obs_col_next=cols["obs"], rdr_t=dev(rdr0), rdr_t1=cols["rdr1"],
+        gamma=float(np.float32(0.95)), seed=9, step=31, env_offset=0, deterministic=False)
+    got_a = host(cols["action"])
+    np.testing.assert_allclose(got_a, want_a, rtol=1e-6, atol=1e-6)
+    assert (np.abs(got_a) < 1).all()
+    assert_logp_close(host(cols["logp"]), want_lp, got_a, squashed=True)
+    # the env step on the DEVICE's own action is exact fp32 arithmetic: state + a, -|state|
+    assert np.array_equal(host(state), state0 + got_a)
+    assert np.array_equal(host(cols["obs"]), host(state))
+    assert np.array_equal(host(cols["reward"]), -np.abs(host(state)))
+    assert np.array_equal(host(cols["value"]), value)
+    np.testing.assert_allclose(host(state), want_s, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(host(cols["rdr1"]), oracle.rdr_step(rdr0, host(cols["reward"]), 0.95), rtol=1e-6, atol=1e-5)
+
+
+def test_ppo_loss_squashed_normal_full_size():
+    """BASELINE configs[3]'s loss: SquashedNormal at 2^25 samples (src/rl8/nn/functional.py:316-363,
+    distributions.py:147-170): sums 1e-5, gradients at the small-size bar, sub-launches bit for bit."""
+    m = N * H
+    rng = np.random.default_rng(6)
+    mean = rng.standard_normal((m, 1), dtype=np.float32)
+    log_std = np.tanh(rng.standard_normal((m, 1), dtype=np.float32))
+    values = rng.standard_normal((m, 1), dtype=np.float32) * 3
+    returns = values + rng.standard_normal((m, 1), dtype=np.float32) * 2
+    eps = rng.standard_normal((m, 1), dtype=np.float32)
+    actions, logp = oracle.normal_sample(mean, log_std, eps, squashed=True)
+    logp_old = (logp + rng.standard_normal((m, 1), dtype=np.float32) * np.float32(0.3)).astype(np.float32)
+    adv = rng.standard_normal((m, 1), dtype=np.float32)
+    kw = dict(clip_param=0.2, dual_clip_param=None, entropy_coeff=0.0, vf_clip_param=5.0, vf_coeff=1.0)
+    want, wg_mean, wg_ls, wg_values = oracle.ppo_loss_normal(
+        mean, log_std, values, actions, logp_old, adv, returns, oracle.ppo_hparams(grad_accumulation_steps=1, **kw),
+        squashed=True)
+    hp = hip.ppo_hparams(grad_scale=1.0 / m, **kw)
+    d = [dev(a) for a in (mean, log_std, values, actions, logp_old, adv, returns)]
+    sums, g_mean, g_ls, g_value = hip.ppo_loss_normal(*d, hp, squashed=True)
+    s = host(sums)
+    assert s[3] == m
+    got = {"policy": s[1] / m, "vf": s[2] / m, "kl": s[4] / m}
+    got["total"] = kw["vf_coeff"] * got["vf"] - got["policy"]
+    for name, val in got.items():
+        assert val == pytest.approx(want[name], rel=1e-5, abs=1e-7), name
+    for got_g, want_g, name in ((g_mean, wg_mean, "mean"), (g_ls, wg_ls, "log_std"), (g_value, wg_values, "value")):
+        np.testing.assert_allclose(host(got_g), want_g, rtol=2e-5, atol=1e-6 * float(np.abs(want_g).max()), err_msg=name)
+    part = (1 << 20) + 4
+    for sl in (slice(0, part), slice(m - part, m)):
+        _, pm, pl, pv = hip.ppo_loss_normal(*[t[sl].contiguous() for t in d], hp, squashed=True)
+        assert torch.equal(pm, g_mean[sl]) and torch.equal(pl, g_ls[sl]) and torch.equal(pv, g_value[sl])

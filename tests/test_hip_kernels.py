@@ -577,6 +577,27 @@ def test_gather_minibatch_bit_exact(time_major):
 @pytest.mark.parametrize("n,h,widths", [(1, 1, (1,)), (63, 5, (1, 2)), (64, 32, (1, 1, 1, 1)), (65, 33, (5, 1, 1)),
                                         (1000, 100, (7, 3, 1)), (130, 256, (28,)), (4100, 7, (3, 2, 2, 1, 1, 1, 1, 1))])
 @pytest.mark.parametrize("time_major", [False, True])
+def test_identity_gather_of_wide_leaves(n, h, widths, time_major):
+    """``rl8_gather_minibatch(index = NULL)`` beyond one tile row (128 bytes per sample): narrow leaves go through the
+    tiled transposition in groups that fit, a leaf wider than a tile row through the general kernels with the implicit
+    index -- the same dense rows as the indexed gather of ``arange`` either way."""
+    g = torch.Generator(device=DEV).manual_seed(n * 31 + h)
+    widths = (40,) + tuple(widths) + (9, 64, 20)
+    leaves = []
+    for i, d in enumerate(widths):
+        shape = (h + 1, n, d) if time_major else (n, h + 1, d)
+        t = (torch.randint(-5, 9, shape, device=DEV, generator=g) if i == 2 else torch.randn(shape, device=DEV, generator=g))
+        leaves.append(t.transpose(0, 1) if time_major else t)
+    leaves = leaves[:hip.MAX_GATHER_FIELDS]
+    everything = torch.arange(n * h, device=DEV)
+    for dense, indexed, leaf in zip(hip.gather_minibatch(None, h, leaves), hip.gather_minibatch(everything, h, leaves), leaves):
+        assert dense.dtype == leaf.dtype and torch.equal(dense, indexed)
+        assert torch.equal(dense, leaf[:, :h].reshape(n * h, *leaf.shape[2:]))
+
+
+@pytest.mark.parametrize("n,h,widths", [(1, 1, (1,)), (63, 5, (1, 2)), (64, 32, (1, 1, 1, 1)), (65, 33, (5, 1, 1)),
+                                        (1000, 100, (7, 3, 1)), (130, 256, (28,)), (4100, 7, (3, 2, 2, 1, 1, 1, 1, 1))])
+@pytest.mark.parametrize("time_major", [False, True])
 def test_pack_samples_tiles_ragged_shapes(n, h, widths, time_major):
     """rl8_pack_samples as a tiled transposition (64 envs x up to 32 steps through LDS): the packed buffer itself --
     every sample's fields side by side in the reference's sample order env * H + t (src/rl8/_utils.py:211-225), zero
