@@ -762,10 +762,10 @@ def test_recurrent_step_with_wide_observations():
 
     def run(inject):
         torch.manual_seed(5)
-        algo = RecurrentAlgorithmConfig(num_envs=48, horizon=16).build(walk_env(40, 2))
+        algo = RecurrentAlgorithmConfig(num_envs=48, horizon=32).build(walk_env(40, 2))
         algo.collect()
         if inject:
-            seqs = 48 * (16 // algo.hparams.seq_len)
+            seqs = 48 * (32 // algo.hparams.seq_len)
             algo.injected_permutations = [torch.arange(seqs) for _ in range(algo.hparams.num_sgd_iters)]
         stats = algo.step()
         return stats, torch.cat([p.detach().flatten() for p in algo.policy.model.parameters()])

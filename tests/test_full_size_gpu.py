@@ -257,7 +257,7 @@ def test_fused_continuous_squashed_step_full_size():
         gamma=float(np.float32(0.95)), seed=9, step=31, env_offset=0, deterministic=False)
     got_a = host(cols["action"])
     np.testing.assert_allclose(got_a, want_a, rtol=1e-6, atol=1e-6)
-    assert (np.abs(got_a) < 1).all()
+    assert (np.abs(got_a) <= 1).all()  # (tanh rounds to 1.0 in fp32 beyond |u| ~ 9: the reference's logp clamps for that)
     assert_logp_close(host(cols["logp"]), want_lp, got_a, squashed=True)
     # the env step on the DEVICE's own action is exact fp32 arithmetic: state + a, -|state|
     assert np.array_equal(host(state), state0 + got_a)
@@ -294,8 +294,17 @@ def test_ppo_loss_squashed_normal_full_size():
     got["total"] = kw["vf_coeff"] * got["vf"] - got["policy"]
     for name, val in got.items():
         assert val == pytest.approx(want[name], rel=1e-5, abs=1e-7), name
+    # A sample whose probability ratio sits within rounding of a clip boundary (1 +- clip_param) has a gradient of 0 on
+    # one side and of full size on the other, in ANY evaluation order: those few (5 of 2^25 here) are exempt from the
+    # entrywise bar, every other entry is held to it, and the exempt ones must really sit on a boundary.
+    ratio = np.exp(logp.astype(np.float64) - logp_old.astype(np.float64))
+    on_boundary = (np.minimum(np.abs(ratio - 0.8), np.abs(ratio - 1.2)) < 1e-5).reshape(-1)
+    assert on_boundary.sum() < 4096
     for got_g, want_g, name in ((g_mean, wg_mean, "mean"), (g_ls, wg_ls, "log_std"), (g_value, wg_values, "value")):
-        np.testing.assert_allclose(host(got_g), want_g, rtol=2e-5, atol=1e-6 * float(np.abs(want_g).max()), err_msg=name)
+        got_h = host(got_g)
+        bad = (np.abs(got_h - want_g) > 2e-5 * np.abs(want_g) + 1e-6 * float(np.abs(want_g).max())).reshape(-1)
+        assert not (bad & ~on_boundary).any(), (name, int((bad & ~on_boundary).sum()))
+        assert bad.sum() <= 64, (name, int(bad.sum()))
     part = (1 << 20) + 4
     for sl in (slice(0, part), slice(m - part, m)):
         _, pm, pl, pv = hip.ppo_loss_normal(*[t[sl].contiguous() for t in d], hp, squashed=True)
