@@ -517,8 +517,12 @@ int mlp_rows_forward_dispatch(hipStream_t s, const float *x, int64_t m, int d_in
                               float *h1, float *h2, uint32_t *gate);
 }
 
+namespace rl8 {
+int rows_in_class(int d_in);
+int rows_out_class(int n_out);
+}
 RL8_API int rl8_mlp_forward_f16_supports(int d_in, int n_out) {
-  return (d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5) && n_out >= 1 && n_out <= 3;
+  return d_in >= 1 && rows_in_class(d_in) != 0 && rows_out_class(n_out) != 0;
 }
 
 RL8_API int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, const float *w1,
@@ -534,7 +538,10 @@ RL8_API int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, c
                                    save_gate2);
 }
 
-RL8_API int rl8_mlp_backward_f16_supports(int d_in, int n_out) { return rl8_mlp_forward_f16_supports(d_in, n_out); }
+/* The backward kernels are compiled per width (their observations and dOut arrive through scalar loads of rows whose
+ * stride is a compile-time constant): d_in 1..5, n_out 1..4.  Wider towers train through the fp32-MFMA kernels (their
+ * rollouts still run the plane forward: rl8_mlp_forward_f16_supports). */
+RL8_API int rl8_mlp_backward_f16_supports(int d_in, int n_out) { return d_in >= 1 && d_in <= 5 && n_out >= 1 && n_out <= 4; }
 
 // Grids of the two halves of the fused backward (as in mlp_split_kernels.hip: both derive
 // them from m alone, so that each can zero the partial-row segments the other does not cover).
@@ -562,10 +569,11 @@ RL8_API int rl8_mlp_tower_backward_f16_f32(const float *x, const float *w1, cons
   int status = RL8_ESIZE;
 #define RL8_BACKWARD_F16(D, N) \
   if (d_in == D && n_out == N) status = launch_backward_f16<D, N>(grid, s, x, w1, b1, dout, m, w2t_f16, w3, partials, stride, g2, gate2);
-  RL8_BACKWARD_F16(1, 1) RL8_BACKWARD_F16(1, 2) RL8_BACKWARD_F16(1, 3)
-  RL8_BACKWARD_F16(2, 1) RL8_BACKWARD_F16(2, 2) RL8_BACKWARD_F16(2, 3)
-  RL8_BACKWARD_F16(3, 1) RL8_BACKWARD_F16(3, 2) RL8_BACKWARD_F16(3, 3)
-  RL8_BACKWARD_F16(5, 1) RL8_BACKWARD_F16(5, 2) RL8_BACKWARD_F16(5, 3)
+  RL8_BACKWARD_F16(1, 1) RL8_BACKWARD_F16(1, 2) RL8_BACKWARD_F16(1, 3) RL8_BACKWARD_F16(1, 4)
+  RL8_BACKWARD_F16(2, 1) RL8_BACKWARD_F16(2, 2) RL8_BACKWARD_F16(2, 3) RL8_BACKWARD_F16(2, 4)
+  RL8_BACKWARD_F16(3, 1) RL8_BACKWARD_F16(3, 2) RL8_BACKWARD_F16(3, 3) RL8_BACKWARD_F16(3, 4)
+  RL8_BACKWARD_F16(4, 1) RL8_BACKWARD_F16(4, 2) RL8_BACKWARD_F16(4, 3) RL8_BACKWARD_F16(4, 4)
+  RL8_BACKWARD_F16(5, 1) RL8_BACKWARD_F16(5, 2) RL8_BACKWARD_F16(5, 3) RL8_BACKWARD_F16(5, 4)
 #undef RL8_BACKWARD_F16
   return status;
 }
@@ -605,7 +613,8 @@ RL8_API int rl8_mlp_tower_backward_gate_f16_f32(const float *x, const float *w1,
   if (d_in == D && n_out == N) \
     status = launch_backward_f16<D, N, true>(grid, s, x, w1, b1, dout, m, w2t_gate, nullptr, partials, stride, g2, gate2);
   RL8_BACKWARD_GATE(1, 1) RL8_BACKWARD_GATE(1, 2) RL8_BACKWARD_GATE(2, 1) RL8_BACKWARD_GATE(2, 2)
-  RL8_BACKWARD_GATE(3, 1) RL8_BACKWARD_GATE(3, 2) RL8_BACKWARD_GATE(5, 1) RL8_BACKWARD_GATE(5, 2)
+  RL8_BACKWARD_GATE(3, 1) RL8_BACKWARD_GATE(3, 2) RL8_BACKWARD_GATE(4, 1) RL8_BACKWARD_GATE(4, 2)
+  RL8_BACKWARD_GATE(5, 1) RL8_BACKWARD_GATE(5, 2)
 #undef RL8_BACKWARD_GATE
   return status;
 }

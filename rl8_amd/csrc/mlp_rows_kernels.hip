@@ -38,13 +38,16 @@ namespace rl8 {
 constexpr int kRowsChunk = 16 * 1024;                  // one half-step of W2: [column tile 0..7][plane hi | lo] x 1 KiB
 constexpr int kRowsHalfSteps = 16;
 constexpr int kRowsPacked = kRowsHalfSteps * kRowsChunk;  // (= kF16PackedBytes; two floats behind: scale, 1 / scale)
-constexpr int kRowsPitch = 128 + 16;                   // h2 transpose scratch: row pitch (conflict-free 16-byte accesses both ways)
+constexpr int kRowsPitch = 128 + 16;                   // h2 transpose scratch (16 rows per wave): row pitch (conflict-free 16-byte accesses both ways)
 
 // floats per k of the layer-1 record [b1 | w1[k][0..DIN-1] | pad]
-constexpr int rows_record(int d_in) { return d_in == 1 ? 2 : d_in <= 3 ? 4 : 8; }
+// (width CLASSES since round 5: a kernel compiled for class DIN serves every run-time d_in <= DIN -- weights past d_in
+// are zero in the records, observations past d_in are not loaded -- so d_in = 4 runs class 5, 6..8 class 8)
+constexpr int rows_record(int d_in) { return d_in == 1 ? 2 : d_in <= 3 ? 4 : d_in <= 7 ? 8 : 12; }
+constexpr int rows_record_vecs(int d_in) { return d_in <= 3 ? 1 : rows_record(d_in) / 4; }  // 16-byte reads per record
 constexpr int rows_consts_bytes(int k_in, int k_out) { return (rows_record(k_in) + 1 + k_out) * kHidden * 4; }
 constexpr int rows_lds_bytes(int ring, int k_in, int k_out, bool store) {
-  return ring * kRowsChunk + rows_consts_bytes(k_in, k_out) + (store ? 4 * 32 * kRowsPitch : 0);
+  return ring * kRowsChunk + rows_consts_bytes(k_in, k_out) + (store ? 4 * 16 * kRowsPitch : 0);
 }
 
 // (f16_pair_scaled: split_tile.hip.h)
@@ -55,7 +58,7 @@ template <int DIN>
 constexpr int rows_record_reads(int s, bool produce, bool next_produces) {
   const bool on = s == 7 ? next_produces : produce;
   if (DIN == 1) return (s & 1) && on ? 1 : 0;
-  return on ? (DIN == 5 ? 2 : 1) : 0;
+  return on ? rows_record_vecs(DIN) : 0;
 }
 
 // SAVE: 0 inference; 1 training with h2 and its gate bits (and, on request, h1) stored; 2 training with the gate bits
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     const float *__restrict__ x, int64_t m, const float *__restrict__ w1, const float *__restrict__ b1,
     const void *__restrict__ w2s, const float *__restrict__ b2, const float *__restrict__ w3,
     const float *__restrict__ b3, float *__restrict__ out, float *__restrict__ save_h1, float *__restrict__ save_h2,
-    uint32_t *__restrict__ save_gate2
+    uint32_t *__restrict__ save_gate2, int d_in, int n_out  // run-time widths: d_in <= DIN, n_out <= NOUT
 #ifdef RL8_ROWS_STAMP  // tuning builds (tools/diag/rows_clock.py): shader-clock / real-time stamps around the kernel
     , unsigned long long *__restrict__ stamps
 #endif
@@ -75,13 +78,14 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
 #ifdef RL8_ROWS_STAMP
   const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  constexpr int kIn = DIN, d_in = DIN, n_out = NOUT;
-  constexpr int kOut = pad_out(NOUT);
+  constexpr int kIn = DIN;
+  constexpr int kOut = NOUT;
   constexpr int kTile = 128;
   constexpr int kAhead = RING - 1;
   constexpr bool kStore = SAVE == 1;
   constexpr int kRec = rows_record(DIN);
-  static_assert(DIN == 1 || DIN == 2 || DIN == 3 || DIN == 5, "layer-1 records are written out for these widths");
+  static_assert(DIN == 1 || DIN == 2 || DIN == 3 || DIN == 5 || DIN == 8, "width classes of the layer-1 records");
+  static_assert(NOUT == pad_out(NOUT), "output classes: 1, 2, 4, 8");
   static_assert(rows_lds_bytes(RING, kIn, kOut, kStore) <= 80 * 1024, "two workgroups per CU");
   static_assert(kAhead >= 2, "the mid-step barrier publishes a chunk requested at least a half-step earlier");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     float *consts = reinterpret_cast<float *>(smem + kConstOff);
     consts[tid * kRec] = b1[tid];
 #pragma unroll
-    for (int i = 0; i < kRec - 1; ++i) consts[tid * kRec + 1 + i] = i < kIn ? w1[tid * d_in + (i < kIn ? i : 0)] : 0.0f;
+    for (int i = 0; i < kRec - 1; ++i) consts[tid * kRec + 1 + i] = i < d_in ? w1[tid * d_in + i] : 0.0f;
     consts[kRec * kHidden + tid] = b2[tid];
 #pragma unroll
     for (int q = 0; q < kOut; ++q) consts[(kRec + 1 + q) * kHidden + tid] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
@@ -146,7 +150,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) dst[rt][i] = buffer_load_f32(xrsrc, ((32 * wave + 16 * rt + l16) * d_in + i) * 4, 0);
+      for (int i = 0; i < kIn; ++i)  // (d_in is uniform: a scalar branch per i, nothing loaded past the row's end)
+        dst[rt][i] = i < d_in ? buffer_load_f32(xrsrc, ((32 * wave + 16 * rt + l16) * d_in + i) * 4, 0) : 0.0f;
   };
   // Row factor: |h1[row][k]| <= max|b1| + sum_i |x_i| max_k |w1[k][i]| < 2^e  =>  planes of h1 * 2^(14 - e)
   // (exact); the accumulators are multiplied back by 2^(e - 14) / (W2's power of two).
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
   //   DIN = 1: one 16-byte read holds the records of an element PAIR (requested in the odd slot in front of it);
   //   DIN = 2, 3: one read per element;  DIN = 5: two reads per element.  Two register sets each.
   constexpr int kCSets = 2;
-  constexpr int kCReads = DIN == 5 ? 2 : 1;
+  constexpr int kCReads = rows_record_vecs(DIN);
   u32x4 cq[kCSets][kCReads];
   auto request_record = [&](int S, int e) {  // the reads for element e (0..7) of block S
     const unsigned a = c_lane + S * (32 * kRec * 4);
@@ -202,6 +207,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
                    : e == 5 ? lds_read_b128<80>(a)
                    : e == 6 ? lds_read_b128<96>(a)
                             : lds_read_b128<112>(a);
+    } else if constexpr (DIN > 5) {  // three reads per 48-byte record: the element's address in a register
+      const int set = e & 1;
+      const unsigned ae = a + e * (kRec * 4);
+      cq[set][0] = lds_read_b128<0>(ae);
+      cq[set][1] = lds_read_b128<16>(ae);
+      cq[set][2] = lds_read_b128<32>(ae);
     } else {
       const int set = e & 1;
       cq[set][0] = e == 0   ? lds_read_b128<0>(a)
@@ -316,6 +327,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
         : allowed == 2 ? wait_lds<2>(bh[set], bl[set])
         : allowed == 3 ? wait_lds<3>(bh[set], bl[set])
         : allowed == 4 ? wait_lds<4>(bh[set], bl[set])
+        : allowed == 5 ? wait_lds<5>(bh[set], bl[set])
                        : wait_lds<0>(bh[set], bl[set]);
       }
       const f32x4 zero = {0, 0, 0, 0};
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     constexpr int kChains = kOut <= 2 ? 4 : 2;
     float part[2][kOut][kChains];
     [[maybe_unused]] uint32_t gate_words[2][8];
-    [[maybe_unused]] const unsigned t_base = lds0 + kScratchOff + wave * (32 * kRowsPitch);
+    [[maybe_unused]] const unsigned t_base = lds0 + kScratchOff + wave * (16 * kRowsPitch);
     [[maybe_unused]] const unsigned t_write = t_base + l16e * kRowsPitch + 16 * kqe;
     [[maybe_unused]] const unsigned t_read = t_base + (lane_e >> 3) * kRowsPitch + (lane_e & 7) * 16;
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t h2rsrc =
@@ -469,10 +481,14 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
           wq[q][gi] = q == 0   ? lds_read_b128<1 * kHidden * 4>(a)
                       : q == 1 ? lds_read_b128<2 * kHidden * 4>(a)
                       : q == 2 ? lds_read_b128<3 * kHidden * 4>(a)
-                               : lds_read_b128<4 * kHidden * 4>(a);
+                      : q == 3 ? lds_read_b128<4 * kHidden * 4>(a)
+                      : q == 4 ? lds_read_b128<5 * kHidden * 4>(a)
+                      : q == 5 ? lds_read_b128<6 * kHidden * 4>(a)
+                      : q == 6 ? lds_read_b128<7 * kHidden * 4>(a)
+                               : lds_read_b128<8 * kHidden * 4>(a);
       }
     };
-    static_assert(kOut <= 4, "request_w3 is written out for four outputs");
+    static_assert(kOut <= 8, "request_w3 is written out for eight outputs");
     if constexpr ((DIAG & 2) != 0) {  // tuning builds: the accumulators are consumed, nothing else
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
@@ -512,25 +528,19 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
         }
       if (st + 1 < kStages) request_b2(st + 1);
       if constexpr (kStore) {
-        // block [32 rows][32 columns] -> the wave's transpose scratch (pitch 144 B), back as eight lanes per row: a
-        // store instruction is then eight full 128-byte lines
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int gi = 0; gi < kGroup; ++gi) {
-            const int ct = st * kGroup + gi;
-            const u32x4 u = __builtin_bit_cast(u32x4, acc[rt][ct]);
-            if (rt == 0) {
-              (ct & 1) == 0 ? lds_write_b128<0>(t_write, u) : lds_write_b128<64>(t_write, u);
-            } else {
-              (ct & 1) == 0 ? lds_write_b128<16 * kRowsPitch>(t_write, u) : lds_write_b128<16 * kRowsPitch + 64>(t_write, u);
-            }
-          }
+        // block [32 rows][32 columns], one row tile (16 rows) at a time -> the wave's transpose scratch (pitch 144 B),
+        // back as eight lanes per row: a store instruction is then eight full 128-byte lines.  Both column tiles of the
+        // block are final here (bias + ReLU of the even one ran a stage ago when kGroup = 1); the second row tile's
+        // writes follow the first one's reads into the same 16 rows -- a wave's LDS operations execute in order.
         if (last_of_block) {
-          t_rows[0] = lds_read_b128<0 * 8 * kRowsPitch>(t_read);
-          t_rows[1] = lds_read_b128<1 * 8 * kRowsPitch>(t_read);
-          t_rows[2] = lds_read_b128<2 * 8 * kRowsPitch>(t_read);
-          t_rows[3] = lds_read_b128<3 * 8 * kRowsPitch>(t_read);
+          const int c0 = (st * kGroup + kGroup - 1) & ~1;
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            lds_write_b128<0>(t_write, __builtin_bit_cast(u32x4, acc[rt][c0]));
+            lds_write_b128<64>(t_write, __builtin_bit_cast(u32x4, acc[rt][c0 + 1]));
+            t_rows[2 * rt] = lds_read_b128<0>(t_read);
+            t_rows[2 * rt + 1] = lds_read_b128<8 * kRowsPitch>(t_read);
+          }
         }
       }
 #pragma unroll
@@ -658,8 +668,15 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
 //     loads a row is not the lane that holds its accumulators;
 //   * running column sums [256][db1 | dW1 row | pad] per WAVE in LDS, updated per tile by the wave alone (no workgroup
 //     barrier), added over the four waves in order at the end.
+// (round 5) d_in 4, 5: the running sums live in REGISTERS -- the lane that owns column tile ct of a column (kq = ct % 4)
+// keeps (1 + d_in) sums for each of its four tiles -- because their LDS copies (8 KiB per wave) do not fit beside the
+// ring at two workgroups per CU.
+constexpr bool rows_dgrad_sums_in_lds(int k_in) { return k_in <= 3; }
+constexpr int rows_dgrad_wave_bytes(int k_in) {
+  return 1024 + 32 * (1 + k_in) * 4 + (rows_dgrad_sums_in_lds(k_in) ? rows_record(k_in) * kHidden * 4 : 0);
+}
 constexpr int rows_dgrad_lds_bytes(int ring, int k_in) {
-  return ring * kRowsChunk + rows_record(k_in) * kHidden * 4 + 4 * (1024 + 32 * (1 + k_in) * 4 + rows_record(k_in) * kHidden * 4);
+  return ring * kRowsChunk + rows_record(k_in) * kHidden * 4 + 4 * rows_dgrad_wave_bytes(k_in);
 }
 
 template <int OFF>
@@ -684,15 +701,18 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
   constexpr int kTile = 128;
   constexpr int kAhead = RING - 1;
   constexpr int kRec = rows_record(DIN);
-  static_assert(DIN >= 1 && DIN <= 3, "wider observations keep the previous kernel (LDS: running sums per wave)");
+  static_assert(DIN >= 1 && DIN <= 5, "wider observations keep the previous kernel");
   static_assert(rows_dgrad_lds_bytes(RING, kIn) <= 80 * 1024, "two workgroups per CU");
+  static_assert(RING * kRowsChunk >= 4 * kRec * kHidden * 4, "the ring holds the four waves' sums at the end");
+  constexpr bool kSumsInLds = rows_dgrad_sums_in_lds(DIN);
+  constexpr int kRecVecs = kRec <= 4 ? 1 : kRec / 4;  // 16-byte reads per layer-1 record in the epilogue
   static_assert(kAhead >= 2, "the mid-step barrier publishes a chunk requested at least a half-step earlier");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [ring][layer-1 records [256][kRec]][per wave: gate block 1 KiB | factors [32] | observations [DIN][32] | sums [256][kRec]]
   const unsigned lds0 = lds_offset(smem);
   constexpr int kRecOff = RING * kRowsChunk;
   constexpr int kWaveOff = kRecOff + kRec * kHidden * 4;
-  constexpr int kWaveBytes = 1024 + 32 * (1 + kIn) * 4 + kRec * kHidden * 4;
+  constexpr int kWaveBytes = rows_dgrad_wave_bytes(DIN);
   constexpr int kFacOff = 1024, kObsOff = kFacOff + 32 * 4, kSumOff = kObsOff + 32 * kIn * 4;
   const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -709,9 +729,17 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
     rec[tid * kRec] = b1[tid];
 #pragma unroll
     for (int i = 0; i < kRec - 1; ++i) rec[tid * kRec + 1 + i] = i < kIn ? w1[tid * d_in + (i < kIn ? i : 0)] : 0.0f;
-    float *sums = reinterpret_cast<float *>(smem + kWaveOff + wave * kWaveBytes + kSumOff);
-    for (int idx = lane; idx < kRec * kHidden; idx += kWave) sums[idx] = 0.0f;
+    if constexpr (kSumsInLds) {
+      float *sums = reinterpret_cast<float *>(smem + kWaveOff + wave * kWaveBytes + kSumOff);
+      for (int idx = lane; idx < kRec * kHidden; idx += kWave) sums[idx] = 0.0f;
+    }
   }
+  // register sums (d_in 4, 5): [j][0] = db1, [j][1 + i] = dW1[.][i] of column 16 (4 j + kq) + l16
+  [[maybe_unused]] float rsum[4][1 + kIn];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 1 + kIn; ++i) rsum[j][i] = 0.0f;
 
   // rows of a tile that exist for this wave, and this lane's two rows' d = dOut[row][0] (0 past the end)
   auto wave_rows = [&](int64_t tile) {
@@ -909,23 +937,32 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
       for (int i = 0; i < kIn; ++i)
         xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
                                : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
-                                        : lds_read_b128<kObsOff + 256>(wl + 16 * kqe))
+                               : i == 2 ? lds_read_b128<kObsOff + 256>(wl + 16 * kqe)
+                               : i == 3 ? lds_read_b128<kObsOff + 384>(wl + 16 * kqe)
+                                        : lds_read_b128<kObsOff + 512>(wl + 16 * kqe))
                             : (i == 0   ? lds_read_b128<kObsOff + 64>(wl + 16 * kqe)
                                : i == 1 ? lds_read_b128<kObsOff + 128 + 64>(wl + 16 * kqe)
-                                        : lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe));
+                               : i == 2 ? lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe)
+                               : i == 3 ? lds_read_b128<kObsOff + 384 + 64>(wl + 16 * kqe)
+                                        : lds_read_b128<kObsOff + 512 + 64>(wl + 16 * kqe));
     }
     // per column tile: the column's layer-1 record and its running sums (read-modify-write by the lanes kq == ct % 4)
     const unsigned rec_at = lds0 + kRecOff + l16e * (kRec * 4), sum_at = wl + kSumOff + l16e * (kRec * 4);
     typedef typename std::conditional<kRec == 2, u32x2, u32x4>::type rec_t;
-    rec_t rq[2], sq[2];
-    auto request_col = [&](int ct, int set) {
+    rec_t rq[2][kRecVecs];
+    [[maybe_unused]] rec_t sq[2];
+    auto request_col = [&](int ct, int set) {  // TWO reads either way: record + sums (d_in <= 3), or the record's two halves
       const unsigned ra = rec_at + ct * (16 * kRec * 4), sa = sum_at + ct * (16 * kRec * 4);
       if constexpr (kRec == 2) {
-        rq[set] = lds_read_b64<0>(ra);
+        rq[set][0] = lds_read_b64<0>(ra);
         sq[set] = lds_read_b64<0>(sa);
-      } else {
-        rq[set] = lds_read_b128<0>(ra);
+      } else if constexpr (kSumsInLds) {
+        rq[set][0] = lds_read_b128<0>(ra);
         sq[set] = lds_read_b128<0>(sa);
+      } else {
+        static_assert(kSumsInLds || kRecVecs == 2, "the counted waits below assume two reads per column tile");
+        rq[set][0] = lds_read_b128<0>(ra);
+        rq[set][1] = lds_read_b128<16>(ra);
       }
     };
     request_col(0, 0);
@@ -933,8 +970,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
     for (int ct = 0; ct < 16; ++ct) {
       const int set = ct & 1;
       if (ct + 1 < 16) request_col(ct + 1, set ^ 1);
-      if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
+      if constexpr (kSumsInLds) {
+        if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set][0]), "+v"(sq[set]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set][0]), "+v"(sq[set]));
+      } else {
+        if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set][0]), "+v"(rq[set][1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set][0]), "+v"(rq[set][1]));
+      }
       if (ct == 0) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -943,10 +985,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
           for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
         }
       }
-      const float b1c = __uint_as_float(rq[set][0]);
+      const float b1c = __uint_as_float(rq[set][0][0]);
       float w1c[kIn];
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
+      for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][(1 + i) >> 2][(1 + i) & 3]);
       float db = 0.0f, dw[kIn];
 #pragma unroll
       for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
@@ -981,11 +1023,18 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
       db = across(db);
 #pragma unroll
       for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
-      if (kqe == (ct & 3)) {
-        const unsigned sa = sum_at + ct * (16 * kRec * 4);
-        lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
+      if constexpr (kSumsInLds) {
+        if (kqe == (ct & 3)) {
+          const unsigned sa = sum_at + ct * (16 * kRec * 4);
+          lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
 #pragma unroll
-        for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
+          for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
+        }
+      } else {  // (every lane adds: its own tile's sums, or zero)
+        const bool mine = kqe == (ct & 3);
+        rsum[ct >> 2][0] += mine ? db : 0.0f;
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) rsum[ct >> 2][1 + i] += mine ? dw[i] : 0.0f;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -999,6 +1048,14 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (!kSumsInLds) {  // the register sums to [wave][256][kRec] in the ring (nothing reads or fills it any more)
+    float *sums = reinterpret_cast<float *>(smem) + wave * (kRec * kHidden);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 1 + kIn; ++i) sums[(16 * (4 * j + kq) + l16) * kRec + i] = rsum[j][i];
+    __syncthreads();
+  }
 
   // Workgroup partial row: [dW1 (256 * d_in) | db1 (256) | head gradients (the weight-gradient kernel's)], the four
   // waves' sums added in wave order.
@@ -1009,7 +1066,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
 #pragma unroll
     for (int i = 0; i < 1 + kIn; ++i) tot[i] = 0.0f;
     for (int w = 0; w < 4; ++w) {
-      const float *sums = reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff);
+      const float *sums = kSumsInLds ? reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff)
+                                     : reinterpret_cast<const float *>(smem) + w * (kRec * kHidden);
 #pragma unroll
       for (int i = 0; i < 1 + kIn; ++i) tot[i] += sums[t * kRec + i];
     }
@@ -1026,7 +1084,7 @@ template <int DIN, int NOUT>
 static int launch_rows_backward_gate(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                      int64_t m, const void *w2ts, float *partials, int stride, int head_rows,
                                      const uint32_t *gate2) {
-  constexpr int kRing = DIN == 1 ? 4 : 3;
+  constexpr int kRing = (DIN == 1 || DIN > 3) ? 4 : 3;
   auto kernel = &mlp_rows_backward_gate_kernel<DIN, NOUT, kRing>;
   static LdsOptIn lds_attr_set_0;
   if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(kernel), 160 * 1024)) return e_lds_attr_set_0;
@@ -1042,6 +1100,7 @@ int mlp_rows_backward_gate_dispatch(int grid, hipStream_t s, const float *x, con
 #define RL8_ROWS_BWD(D, N) \
   if (d_in == D && n_out == N) return launch_rows_backward_gate<D, N>(grid, s, x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2);
   RL8_ROWS_BWD(1, 1) RL8_ROWS_BWD(1, 2) RL8_ROWS_BWD(2, 1) RL8_ROWS_BWD(2, 2) RL8_ROWS_BWD(3, 1) RL8_ROWS_BWD(3, 2)
+  RL8_ROWS_BWD(4, 1) RL8_ROWS_BWD(4, 2) RL8_ROWS_BWD(5, 1) RL8_ROWS_BWD(5, 2)
 #undef RL8_ROWS_BWD
   return -1;
 }
@@ -1049,9 +1108,10 @@ int mlp_rows_backward_gate_dispatch(int grid, hipStream_t s, const float *x, con
 template <int DIN, int NOUT, int SAVE>
 static int launch_rows_forward(hipStream_t s, const float *x, int64_t m, const float *w1, const float *b1, const void *w2s,
                                const float *b2, const float *w3, const float *b3, float *out, float *h1, float *h2,
-                               uint32_t *gate) {
-  constexpr int kOut = pad_out(NOUT);
-  constexpr int kRing = SAVE == 1 ? 3 : 4;  // (the h2 transpose scratch takes the fourth chunk's place)
+                               uint32_t *gate, int d_in, int n_out) {
+  constexpr int kOut = NOUT;
+  // four chunks of W2 in flight where they fit beside the class's constants (and the h2 transpose scratch), else three
+  constexpr int kRing = rows_lds_bytes(4, DIN, kOut, SAVE == 1) <= 80 * 1024 ? 4 : 3;
   constexpr int kLds = rows_lds_bytes(kRing, DIN, kOut, SAVE == 1);
   auto kernel = &mlp_rows_forward_kernel<DIN, NOUT, SAVE, kRing>;
 #ifdef RL8_ROWS_STAMP
@@ -1078,10 +1138,10 @@ static int launch_rows_forward(hipStream_t s, const float *x, int64_t m, const f
   const int grid = (int)(tiles < max_grid ? tiles : max_grid);
 #ifdef RL8_ROWS_STAMP
   const char *sp = getenv("RL8_ROWS_STAMP_PTR");
-  kernel<<<grid, kBlock, kLds, s>>>(x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate,
+  kernel<<<grid, kBlock, kLds, s>>>(x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate, d_in, n_out,
                                     sp ? reinterpret_cast<unsigned long long *>(strtoull(sp, nullptr, 0)) : nullptr);
 #else
-  kernel<<<grid, kBlock, kLds, s>>>(x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate);
+  kernel<<<grid, kBlock, kLds, s>>>(x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate, d_in, n_out);
 #endif
   return launch_status();
 }
@@ -1089,22 +1149,28 @@ static int launch_rows_forward(hipStream_t s, const float *x, int64_t m, const f
 template <int DIN, int NOUT>
 static int launch_rows_forward_save(hipStream_t s, const float *x, int64_t m, const float *w1, const float *b1, const void *w2s,
                                     const float *b2, const float *w3, const float *b3, float *out, float *h1, float *h2,
-                                    uint32_t *gate) {
-  return h2     ? launch_rows_forward<DIN, NOUT, 1>(s, x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate)
-         : gate ? launch_rows_forward<DIN, NOUT, 2>(s, x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate)
-                : launch_rows_forward<DIN, NOUT, 0>(s, x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate);
+                                    uint32_t *gate, int d_in, int n_out) {
+  return h2     ? launch_rows_forward<DIN, NOUT, 1>(s, x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate, d_in, n_out)
+         : gate ? launch_rows_forward<DIN, NOUT, 2>(s, x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate, d_in, n_out)
+                : launch_rows_forward<DIN, NOUT, 0>(s, x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate, d_in, n_out);
 }
+
+// Width classes (round 5): the smallest compiled class that holds the run-time width.
+int rows_in_class(int d_in) { return d_in <= 3 ? d_in : d_in <= 5 ? 5 : d_in <= 8 ? 8 : 0; }
+int rows_out_class(int n_out) { return n_out >= 1 && n_out <= 8 ? pad_out(n_out) : 0; }
 
 // The forward behind rl8_mlp_tower_forward_f16_f32 (mlp_f16_kernels.hip checks the arguments and dispatches here).
 int mlp_rows_forward_dispatch(hipStream_t s, const float *x, int64_t m, int d_in, const float *w1, const float *b1,
                               const void *w2s, const float *b2, const float *w3, const float *b3, int n_out, float *out,
                               float *h1, float *h2, uint32_t *gate) {
+  const int dc = rows_in_class(d_in), nc = rows_out_class(n_out);
 #define RL8_ROWS(D, N) \
-  if (d_in == D && n_out == N) return launch_rows_forward_save<D, N>(s, x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate);
-  RL8_ROWS(1, 1) RL8_ROWS(1, 2) RL8_ROWS(1, 3)
-  RL8_ROWS(2, 1) RL8_ROWS(2, 2) RL8_ROWS(2, 3)
-  RL8_ROWS(3, 1) RL8_ROWS(3, 2) RL8_ROWS(3, 3)
-  RL8_ROWS(5, 1) RL8_ROWS(5, 2) RL8_ROWS(5, 3)
+  if (dc == D && nc == N) return launch_rows_forward_save<D, N>(s, x, m, w1, b1, w2s, b2, w3, b3, out, h1, h2, gate, d_in, n_out);
+  RL8_ROWS(1, 1) RL8_ROWS(1, 2) RL8_ROWS(1, 4) RL8_ROWS(1, 8)
+  RL8_ROWS(2, 1) RL8_ROWS(2, 2) RL8_ROWS(2, 4) RL8_ROWS(2, 8)
+  RL8_ROWS(3, 1) RL8_ROWS(3, 2) RL8_ROWS(3, 4) RL8_ROWS(3, 8)
+  RL8_ROWS(5, 1) RL8_ROWS(5, 2) RL8_ROWS(5, 4) RL8_ROWS(5, 8)
+  RL8_ROWS(8, 1) RL8_ROWS(8, 2) RL8_ROWS(8, 4) RL8_ROWS(8, 8)
 #undef RL8_ROWS
   return RL8_ESIZE;
 }

@@ -279,6 +279,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
         dq[0] = scalar_buffer_load_x8<0>(rd);
         if constexpr (kOut > 1) dq[1] = scalar_buffer_load_x8<32>(rd);
         if constexpr (kOut > 2) dq[2] = scalar_buffer_load_x8<64>(rd);
+        if constexpr (kOut > 3) dq[3] = scalar_buffer_load_x8<96>(rd);
       }
     }
   };
@@ -1657,6 +1658,7 @@ static uint32_t *launch_wgrad_bounds(hipStream_t s, const float *dout, const flo
   if (d_in == 1) wgrad_bounds_kernel<1, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
   else if (d_in == 2) wgrad_bounds_kernel<2, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
   else if (d_in == 3) wgrad_bounds_kernel<3, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
+  else if (d_in == 4) wgrad_bounds_kernel<4, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
   else if (d_in == 5) wgrad_bounds_kernel<5, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
   else return nullptr;
   return bounds;
@@ -2161,7 +2163,8 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
   if (f16) {
     bounds = n_out == 1 ? launch_wgrad_bounds<1>(s, dout, x, m, d_in, workspace)
              : n_out == 2 ? launch_wgrad_bounds<2>(s, dout, x, m, d_in, workspace)
-                          : launch_wgrad_bounds<3>(s, dout, x, m, d_in, workspace);
+             : n_out == 3 ? launch_wgrad_bounds<3>(s, dout, x, m, d_in, workspace)
+                          : launch_wgrad_bounds<4>(s, dout, x, m, d_in, workspace);
     if (!bounds) return launch_status() ? launch_status() : RL8_ESIZE;
     if (planes == kPlanesGuarded && launch_wgrad_tail(s, dout, m * n_out, bounds) != 0) return launch_status();
   }
@@ -2188,6 +2191,7 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
         case 1: status = launch_wgrad_gate<1>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
         case 2: status = launch_wgrad_gate<2>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
         case 3: status = launch_wgrad_gate<3>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+        case 4: status = launch_wgrad_gate<4>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
         default: status = launch_wgrad_gate<5>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
       }
       if (status != 0) return status;
@@ -2201,10 +2205,11 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
                    : launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused); \
     if (status == 0 && guard) status = launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, exact); \
   }
-    RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3)
-    RL8_WGRAD_FUSED(2, 1) RL8_WGRAD_FUSED(2, 2) RL8_WGRAD_FUSED(2, 3)
-    RL8_WGRAD_FUSED(3, 1) RL8_WGRAD_FUSED(3, 2) RL8_WGRAD_FUSED(3, 3)
-    RL8_WGRAD_FUSED(5, 1) RL8_WGRAD_FUSED(5, 2) RL8_WGRAD_FUSED(5, 3)
+    RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3) RL8_WGRAD_FUSED(1, 4)
+    RL8_WGRAD_FUSED(2, 1) RL8_WGRAD_FUSED(2, 2) RL8_WGRAD_FUSED(2, 3) RL8_WGRAD_FUSED(2, 4)
+    RL8_WGRAD_FUSED(3, 1) RL8_WGRAD_FUSED(3, 2) RL8_WGRAD_FUSED(3, 3) RL8_WGRAD_FUSED(3, 4)
+    RL8_WGRAD_FUSED(4, 1) RL8_WGRAD_FUSED(4, 2) RL8_WGRAD_FUSED(4, 3) RL8_WGRAD_FUSED(4, 4)
+    RL8_WGRAD_FUSED(5, 1) RL8_WGRAD_FUSED(5, 2) RL8_WGRAD_FUSED(5, 3) RL8_WGRAD_FUSED(5, 4)
 #undef RL8_WGRAD_FUSED
     if (status != 0) return status;
     mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0);
@@ -2250,6 +2255,7 @@ RL8_API int rl8_mlp_wgrad_fused_pair_f32(const float *h2, const float *dout, con
       case 1: status = launch_wgrad_gate<1, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
       case 2: status = launch_wgrad_gate<2, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
       case 3: status = launch_wgrad_gate<3, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+      case 4: status = launch_wgrad_gate<4, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
       default: status = launch_wgrad_gate<5, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
     }
     if (status != 0) return status;
@@ -2313,7 +2319,7 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
       status = n_out == 2 ? launch_wgrad_gate<D, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, exact) \
                           : launch_wgrad_gate<D, false, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, exact); \
   }
-    RL8_WGRAD_BITS(1) RL8_WGRAD_BITS(2) RL8_WGRAD_BITS(3) RL8_WGRAD_BITS(5)
+    RL8_WGRAD_BITS(1) RL8_WGRAD_BITS(2) RL8_WGRAD_BITS(3) RL8_WGRAD_BITS(4) RL8_WGRAD_BITS(5)
 #undef RL8_WGRAD_BITS
     if (status != 0) return status;
     if (n_out == 2)

@@ -38,7 +38,7 @@ def _rel(got, want):
     return float((got.double() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
 
 
-@pytest.mark.parametrize("d_in", [1, 2, 3, 5])
+@pytest.mark.parametrize("d_in", [1, 2, 3, 4, 5, 6, 8])
 @pytest.mark.parametrize("where", [0, 63, 64, 191, 255])
 def test_forward_row_scale_sees_the_largest_layer_one_entry_wherever_it_sits(d_in, where):
     """The row factor of the fp16 planes comes from max |b1| and max_k |w1[k][i]| -- a workgroup reduction over the 256
@@ -58,7 +58,10 @@ def test_forward_row_scale_sees_the_largest_layer_one_entry_wherever_it_sits(d_i
 
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (127, 1, 1), (128, 1, 2), (129, 2, 3), (1000, 5, 3), (4097, 1, 3),
-                                          (5000, 3, 2), (70_001, 1, 2), (33_333, 5, 1), (20_000, 2, 2)])
+                                          (5000, 3, 2), (70_001, 1, 2), (33_333, 5, 1), (20_000, 2, 2),
+                                          # round 5: run-time widths inside the compiled classes (d_in <= 8, n_out <= 8)
+                                          (1000, 4, 4), (5000, 4, 1), (3001, 6, 5), (777, 7, 3), (2000, 8, 8), (129, 8, 2),
+                                          (4100, 2, 7), (33_000, 5, 6), (1, 8, 8)])
 @pytest.mark.parametrize("scheme", ["f16x2"])
 def test_forward_split_is_fp32_accurate(m, d_in, n_out, scheme):
     """Both generations of the plane-product forward against the SAME bars: six
@@ -163,7 +166,9 @@ def test_forward_f16_scaling_holds_over_the_dynamic_range(case):
 
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 5, 3), (4097, 3, 2), (40_000, 1, 2), (9000, 2, 1),
-                                          (33_000, 1, 2), (33_000, 5, 3), (20_000, 3, 1), (16_500, 2, 3)])
+                                          (33_000, 1, 2), (33_000, 5, 3), (20_000, 3, 1), (16_500, 2, 3),
+                                          # round 5: four-wide observations, four-way heads
+                                          (1000, 4, 4), (4097, 4, 1), (9000, 5, 4), (3000, 2, 4), (33_000, 4, 3)])
 @pytest.mark.parametrize("scheme", ["f16x2"])
 def test_backward_split_matches_fp64(m, d_in, n_out, scheme):
     """Against an fp64 evaluation of the backward formulas on the SAVED activations
@@ -274,7 +279,7 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
 
 @pytest.mark.parametrize("case", ["plain", "rows_of_mixed_magnitude", "one_outlier_row", "clipped_rows", "outlier_weights"])
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 1), (129, 1, 2), (1000, 5, 1), (4097, 3, 2), (40_000, 1, 1), (9000, 2, 2),
-                                          (20_000, 3, 1), (33_000, 5, 2)])
+                                          (20_000, 3, 1), (33_000, 5, 2), (1000, 4, 1), (4097, 4, 2)])
 def test_gate_mode_data_gradient(m, d_in, n_out, case):
     """Heads whose dZ2 is gate * d[s] * w3e[k] (one output; two outputs with exactly opposite gradients):
     the data-gradient kernel takes the ReLU gate itself as its A operand and the planes of w3e[k] W2[k][i] as B.
@@ -338,7 +343,7 @@ def test_gate_mode_data_gradient(m, d_in, n_out, case):
 
 @pytest.mark.parametrize("x_scale", [3.0, 100.0])
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 1), (129, 1, 2), (1000, 5, 1), (4097, 3, 2), (40_000, 1, 2), (9000, 2, 1),
-                                          (100_000, 1, 1)])
+                                          (100_000, 1, 1), (1000, 4, 1), (4097, 4, 2)])
 def test_rank_one_backward_from_the_gate_bits_alone(m, d_in, n_out, x_scale):
     """A forward that keeps ONLY the gate bits of h2 (32 bytes per row) and a backward that never sees h2: the gate
     modes of the data and weight gradients, with dW3 = sum_i W2[.][i] M[.][i] + b2 sum_s G dOut taken from the sums M
@@ -507,7 +512,8 @@ def test_pair_weight_gradient_of_a_two_way_head(m, d_in, monkeypatch):
     assert "mlp_wgrad" in launched_b and "mlp_wgrad_gate" not in launched_b
 
 
-@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (13, 1, 1), (4099, 2, 3), (20_003, 5, 3), (33_001, 3, 2), (9, 5, 1)])
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (13, 1, 1), (4099, 2, 3), (20_003, 5, 3), (33_001, 3, 2), (9, 5, 1),
+                                          (4099, 4, 4), (131, 4, 2)])
 @pytest.mark.parametrize("scheme", ["f16x2"])
 def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out, scheme):
     """The kernels fetch whole windows of rows (eight samples of x / dOut through scalar
@@ -546,11 +552,12 @@ def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out, scheme):
 def test_unsupported_widths_are_refused_not_miscomputed():
     """Only widths whose kernels compile without scratch are offered
     (tests/test_kernel_resources.py); anything else must fail loudly."""
-    assert not hip.mlp_backward_f16_supports(7, 2) and not hip.mlp_forward_f16_supports(4, 1)
-    assert not hip.mlp_forward_f16_supports(1, 4)
-    x = torch.zeros(256, 7, device=DEV)
+    assert not hip.mlp_backward_f16_supports(7, 2) and not hip.mlp_backward_f16_supports(1, 5)
+    assert hip.mlp_backward_f16_supports(4, 4) and hip.mlp_forward_f16_supports(8, 8)  # round 5
+    assert not hip.mlp_forward_f16_supports(9, 1) and not hip.mlp_forward_f16_supports(1, 9)
+    x = torch.zeros(256, 9, device=DEV)
     h = torch.zeros(256, 256, device=DEV)
-    w7, b = torch.zeros(256, 7, device=DEV), torch.zeros(256, device=DEV)
+    w7, b = torch.zeros(256, 9, device=DEV), torch.zeros(256, device=DEV)
     w3, b3 = torch.zeros(3, 256, device=DEV), torch.zeros(3, device=DEV)
     w2 = torch.zeros(256, 256, device=DEV)
     with pytest.raises(ValueError):
@@ -560,13 +567,13 @@ def test_unsupported_widths_are_refused_not_miscomputed():
 
 
 def test_wider_towers_mix_fp32_and_split_kernels():
-    """CartPole's tower (5 -> 256 -> 256 -> 3) through the fused autograd function --
-    and an unlisted width (7 -> 256 -> 256 -> 2: fp32-MFMA forward / data gradient,
-    bf16-plane weight gradient); both must match eager."""
+    """CartPole's tower (5 -> 256 -> 256 -> 3) and a 4 -> 4 one through the fused autograd function (plane kernels
+    throughout) -- and widths whose backward has no plane kernel (7 -> 2, 8 -> 5: fp16-plane forward with h1 and h2
+    stored, fp32-MFMA data gradient, bf16-plane weight gradient; 12 -> 2: fp32-MFMA forward too); all must match eager."""
     from rl8_amd.nn import fused_mlp
 
     torch.manual_seed(6)
-    for d_in, n_out in ((5, 3), (7, 2)):
+    for d_in, n_out in ((5, 3), (4, 4), (7, 2), (8, 5), (3, 6), (12, 2)):
         mlp = torch.nn.Sequential(torch.nn.Linear(d_in, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
         trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
         head = torch.nn.Linear(256, n_out).to(DEV)
