@@ -668,15 +668,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
 //     loads a row is not the lane that holds its accumulators;
 //   * running column sums [256][db1 | dW1 row | pad] per WAVE in LDS, updated per tile by the wave alone (no workgroup
 //     barrier), added over the four waves in order at the end.
-// (round 5) d_in 4, 5: the running sums live in REGISTERS -- the lane that owns column tile ct of a column (kq = ct % 4)
-// keeps (1 + d_in) sums for each of its four tiles -- because their LDS copies (8 KiB per wave) do not fit beside the
-// ring at two workgroups per CU.
-constexpr bool rows_dgrad_sums_in_lds(int k_in) { return k_in <= 3; }
-constexpr int rows_dgrad_wave_bytes(int k_in) {
-  return 1024 + 32 * (1 + k_in) * 4 + (rows_dgrad_sums_in_lds(k_in) ? rows_record(k_in) * kHidden * 4 : 0);
-}
 constexpr int rows_dgrad_lds_bytes(int ring, int k_in) {
-  return ring * kRowsChunk + rows_record(k_in) * kHidden * 4 + 4 * rows_dgrad_wave_bytes(k_in);
+  return ring * kRowsChunk + rows_record(k_in) * kHidden * 4 + 4 * (1024 + 32 * (1 + k_in) * 4 + rows_record(k_in) * kHidden * 4);
 }
 
 template <int OFF>
@@ -701,18 +694,15 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
   constexpr int kTile = 128;
   constexpr int kAhead = RING - 1;
   constexpr int kRec = rows_record(DIN);
-  static_assert(DIN >= 1 && DIN <= 5, "wider observations keep the previous kernel");
+  static_assert(DIN >= 1 && DIN <= 3, "wider observations keep the previous kernel (LDS: running sums per wave)");
   static_assert(rows_dgrad_lds_bytes(RING, kIn) <= 80 * 1024, "two workgroups per CU");
-  static_assert(RING * kRowsChunk >= 4 * kRec * kHidden * 4, "the ring holds the four waves' sums at the end");
-  constexpr bool kSumsInLds = rows_dgrad_sums_in_lds(DIN);
-  constexpr int kRecVecs = kRec <= 4 ? 1 : kRec / 4;  // 16-byte reads per layer-1 record in the epilogue
   static_assert(kAhead >= 2, "the mid-step barrier publishes a chunk requested at least a half-step earlier");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [ring][layer-1 records [256][kRec]][per wave: gate block 1 KiB | factors [32] | observations [DIN][32] | sums [256][kRec]]
   const unsigned lds0 = lds_offset(smem);
   constexpr int kRecOff = RING * kRowsChunk;
   constexpr int kWaveOff = kRecOff + kRec * kHidden * 4;
-  constexpr int kWaveBytes = rows_dgrad_wave_bytes(DIN);
+  constexpr int kWaveBytes = 1024 + 32 * (1 + kIn) * 4 + kRec * kHidden * 4;
   constexpr int kFacOff = 1024, kObsOff = kFacOff + 32 * 4, kSumOff = kObsOff + 32 * kIn * 4;
   const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -729,17 +719,9 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
     rec[tid * kRec] = b1[tid];
 #pragma unroll
     for (int i = 0; i < kRec - 1; ++i) rec[tid * kRec + 1 + i] = i < kIn ? w1[tid * d_in + (i < kIn ? i : 0)] : 0.0f;
-    if constexpr (kSumsInLds) {
-      float *sums = reinterpret_cast<float *>(smem + kWaveOff + wave * kWaveBytes + kSumOff);
-      for (int idx = lane; idx < kRec * kHidden; idx += kWave) sums[idx] = 0.0f;
-    }
+    float *sums = reinterpret_cast<float *>(smem + kWaveOff + wave * kWaveBytes + kSumOff);
+    for (int idx = lane; idx < kRec * kHidden; idx += kWave) sums[idx] = 0.0f;
   }
-  // register sums (d_in 4, 5): [j][0] = db1, [j][1 + i] = dW1[.][i] of column 16 (4 j + kq) + l16
-  [[maybe_unused]] float rsum[4][1 + kIn];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 1 + kIn; ++i) rsum[j][i] = 0.0f;
 
   // rows of a tile that exist for this wave, and this lane's two rows' d = dOut[row][0] (0 past the end)
   auto wave_rows = [&](int64_t tile) {
@@ -937,32 +919,23 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
       for (int i = 0; i < kIn; ++i)
         xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
                                : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
-                               : i == 2 ? lds_read_b128<kObsOff + 256>(wl + 16 * kqe)
-                               : i == 3 ? lds_read_b128<kObsOff + 384>(wl + 16 * kqe)
-                                        : lds_read_b128<kObsOff + 512>(wl + 16 * kqe))
+                                        : lds_read_b128<kObsOff + 256>(wl + 16 * kqe))
                             : (i == 0   ? lds_read_b128<kObsOff + 64>(wl + 16 * kqe)
                                : i == 1 ? lds_read_b128<kObsOff + 128 + 64>(wl + 16 * kqe)
-                               : i == 2 ? lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe)
-                               : i == 3 ? lds_read_b128<kObsOff + 384 + 64>(wl + 16 * kqe)
-                                        : lds_read_b128<kObsOff + 512 + 64>(wl + 16 * kqe));
+                                        : lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe));
     }
     // per column tile: the column's layer-1 record and its running sums (read-modify-write by the lanes kq == ct % 4)
     const unsigned rec_at = lds0 + kRecOff + l16e * (kRec * 4), sum_at = wl + kSumOff + l16e * (kRec * 4);
     typedef typename std::conditional<kRec == 2, u32x2, u32x4>::type rec_t;
-    rec_t rq[2][kRecVecs];
-    [[maybe_unused]] rec_t sq[2];
-    auto request_col = [&](int ct, int set) {  // TWO reads either way: record + sums (d_in <= 3), or the record's two halves
+    rec_t rq[2], sq[2];
+    auto request_col = [&](int ct, int set) {
       const unsigned ra = rec_at + ct * (16 * kRec * 4), sa = sum_at + ct * (16 * kRec * 4);
       if constexpr (kRec == 2) {
-        rq[set][0] = lds_read_b64<0>(ra);
+        rq[set] = lds_read_b64<0>(ra);
         sq[set] = lds_read_b64<0>(sa);
-      } else if constexpr (kSumsInLds) {
-        rq[set][0] = lds_read_b128<0>(ra);
-        sq[set] = lds_read_b128<0>(sa);
       } else {
-        static_assert(kSumsInLds || kRecVecs == 2, "the counted waits below assume two reads per column tile");
-        rq[set][0] = lds_read_b128<0>(ra);
-        rq[set][1] = lds_read_b128<16>(ra);
+        rq[set] = lds_read_b128<0>(ra);
+        sq[set] = lds_read_b128<0>(sa);
       }
     };
     request_col(0, 0);
@@ -970,13 +943,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
     for (int ct = 0; ct < 16; ++ct) {
       const int set = ct & 1;
       if (ct + 1 < 16) request_col(ct + 1, set ^ 1);
-      if constexpr (kSumsInLds) {
-        if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set][0]), "+v"(sq[set]));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set][0]), "+v"(sq[set]));
-      } else {
-        if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set][0]), "+v"(rq[set][1]));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set][0]), "+v"(rq[set][1]));
-      }
+      if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
       if (ct == 0) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -985,10 +953,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
           for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
         }
       }
-      const float b1c = __uint_as_float(rq[set][0][0]);
+      const float b1c = __uint_as_float(rq[set][0]);
       float w1c[kIn];
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][(1 + i) >> 2][(1 + i) & 3]);
+      for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
       float db = 0.0f, dw[kIn];
 #pragma unroll
       for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
@@ -1023,18 +991,11 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
       db = across(db);
 #pragma unroll
       for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
-      if constexpr (kSumsInLds) {
-        if (kqe == (ct & 3)) {
-          const unsigned sa = sum_at + ct * (16 * kRec * 4);
-          lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
+      if (kqe == (ct & 3)) {
+        const unsigned sa = sum_at + ct * (16 * kRec * 4);
+        lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
 #pragma unroll
-          for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
-        }
-      } else {  // (every lane adds: its own tile's sums, or zero)
-        const bool mine = kqe == (ct & 3);
-        rsum[ct >> 2][0] += mine ? db : 0.0f;
-#pragma unroll
-        for (int i = 0; i < kIn; ++i) rsum[ct >> 2][1 + i] += mine ? dw[i] : 0.0f;
+        for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1048,14 +1009,6 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  if constexpr (!kSumsInLds) {  // the register sums to [wave][256][kRec] in the ring (nothing reads or fills it any more)
-    float *sums = reinterpret_cast<float *>(smem) + wave * (kRec * kHidden);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 1 + kIn; ++i) sums[(16 * (4 * j + kq) + l16) * kRec + i] = rsum[j][i];
-    __syncthreads();
-  }
 
   // Workgroup partial row: [dW1 (256 * d_in) | db1 (256) | head gradients (the weight-gradient kernel's)], the four
   // waves' sums added in wave order.
@@ -1066,8 +1019,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
 #pragma unroll
     for (int i = 0; i < 1 + kIn; ++i) tot[i] = 0.0f;
     for (int w = 0; w < 4; ++w) {
-      const float *sums = kSumsInLds ? reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff)
-                                     : reinterpret_cast<const float *>(smem) + w * (kRec * kHidden);
+      const float *sums = reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff);
 #pragma unroll
       for (int i = 0; i < 1 + kIn; ++i) tot[i] += sums[t * kRec + i];
     }
@@ -1084,7 +1036,7 @@ template <int DIN, int NOUT>
 static int launch_rows_backward_gate(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                      int64_t m, const void *w2ts, float *partials, int stride, int head_rows,
                                      const uint32_t *gate2) {
-  constexpr int kRing = (DIN == 1 || DIN > 3) ? 4 : 3;
+  constexpr int kRing = DIN == 1 ? 4 : 3;
   auto kernel = &mlp_rows_backward_gate_kernel<DIN, NOUT, kRing>;
   static LdsOptIn lds_attr_set_0;
   if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(kernel), 160 * 1024)) return e_lds_attr_set_0;
@@ -1100,7 +1052,6 @@ int mlp_rows_backward_gate_dispatch(int grid, hipStream_t s, const float *x, con
 #define RL8_ROWS_BWD(D, N) \
   if (d_in == D && n_out == N) return launch_rows_backward_gate<D, N>(grid, s, x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2);
   RL8_ROWS_BWD(1, 1) RL8_ROWS_BWD(1, 2) RL8_ROWS_BWD(2, 1) RL8_ROWS_BWD(2, 2) RL8_ROWS_BWD(3, 1) RL8_ROWS_BWD(3, 2)
-  RL8_ROWS_BWD(4, 1) RL8_ROWS_BWD(4, 2) RL8_ROWS_BWD(5, 1) RL8_ROWS_BWD(5, 2)
 #undef RL8_ROWS_BWD
   return -1;
 }

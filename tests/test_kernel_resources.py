@@ -124,7 +124,11 @@ def test_compiled_split_kernels_resources(tmp_path):
             # every compiled (= dispatched) variant: no scratch at all -- these kernels read
             # LDS through inline asm, so a spill between a read and its wait is a hazard,
             # not just a slowdown -- and two workgroups per CU
-            assert scratch == 0, (name, scratch)
+            # (round 5: the widest fused variant on the exact bf16 planes, d_in 5 x n_out 4 -- 72 scalar registers of
+            # observations and dOut per step -- keeps three registers in scratch; the walkers below hold for it as for
+            # the others: no hand-issued load's destination, vector or scalar, is touched before its wait)
+            widest = "mlp_wgrad_split_kernelILi5ELi4ELb0ELb0E" in name
+            assert scratch == 0 or (widest and scratch <= 16), (name, scratch)
             assert vgprs <= 256, (name, vgprs)
             checked += 1
     # general (5 run-time/compiled widths from memory + 12 fused, bf16 and fp16 planes), two-operand (4 + 4), gate-plane kernels
@@ -244,8 +248,8 @@ def test_compiled_f16_kernels_resources(tmp_path):
         if "mlp_tower_backward_f16_kernel" in name:
             assert vgprs <= 256 and lds <= 80 * 1024, (name, vgprs, lds)
             checked += 1
-    # d_in in {1, 2, 3, 5} x n_out in {1, 2, 3} data-gradient kernels + their gate mode (n_out 1, 2)
-    assert checked == 12 + 8
+    # d_in in 1..5 x n_out in 1..4 data-gradient kernels + their gate mode (n_out 1, 2)
+    assert checked == 20 + 10
     assert_no_inflight_register_access(text, "mlp_tower_backward_f16_kernel", min_hand_loads=20 * 40)
     for name, body in inflight.kernels_of(text):
         assert inflight.packed_war(body) == [], name
@@ -253,8 +257,9 @@ def test_compiled_f16_kernels_resources(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_compiled_rows_forward_kernels_resources(tmp_path):
-    """The rows-per-wave forward (mlp_rows_kernels.hip, round 3): every compiled variant (d_in in {1, 2, 3, 5} x n_out
-    in {1, 2, 3} x {inference, training with h2, training with the gate bits alone}) free of scratch (its fragment and
+    """The rows-per-wave forward (mlp_rows_kernels.hip, round 3; width classes since round 5): every compiled variant
+    (d_in class in {1, 2, 3, 5, 8} x n_out class in {1, 2, 4, 8} x {inference, training with h2, training with the gate
+    bits alone}) free of scratch -- class 8 excepted, see below -- (its fragment and
     record reads are hand-issued with counted waits: a spill between a read and its wait would save stale data), two
     workgroups per CU, 16x16x32 fp16 MFMAs only, no packed fp32 arithmetic beside them, no hand-issued load's
     destination touched before a covering wait, no scalar load in flight at a counted wait, and every mid-step
@@ -275,15 +280,27 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         assert "mlp_rows_forward_kernel" in name or "mlp_rows_backward_gate_kernel" in name
-        assert scratch == 0 and vgprs <= 256, (name, scratch, vgprs)
+        # width class 8 (d_in 6..8: nine fmas and three record reads per element) does not fit 256 registers: 19-33 of them
+        # live in scratch, none inside the inner loop of eight half-steps and none a hand-issued load's destination (the
+        # walker below holds for these variants too); every other class: no scratch at all
+        wide = re.search(r"mlp_rows_forward_kernelILi8E", name) is not None
+        assert vgprs <= 256 and (scratch <= 160 if wide else scratch == 0), (name, scratch, vgprs)
         checked += "mlp_rows_forward_kernel" in name
-    assert checked == 36 and len(kernels) == 36 + 6  # + the gate-mode data gradient, d_in in {1, 2, 3} x n_out in {1, 2}
+    # width classes {1, 2, 3, 5, 8} x output classes {1, 2, 4, 8} x {inference, h2 stored, gate bits only}
+    assert checked == 60 and len(kernels) == 60 + 6  # + the gate-mode data gradient, d_in in {1, 2, 3} x n_out in {1, 2}
+    for name, body in inflight.kernels_of(text):
+        # the spilling class: the inner loop of the rollout's (SAVE 0) and the gate-bits (SAVE 2) variants stays free of
+        # scratch; the h2-storing one (SAVE 1, which also carries the optional h1 store) reloads inside it (measured:
+        # +17 % over class 5, as the other two -- profiles/r05_experiments.md)
+        if re.search(r"mlp_rows_forward_kernelILi8ELi\dELi[02]E", name):
+            loop = re.search(r"Inner Loop Header.*?s_cbranch_scc0", body, re.S)
+            assert loop is not None and "scratch_" not in loop.group(0), name
     # ring discipline: the barrier inside a half-step waits for "all but the pieces of one younger chunk" (four-chunk
     # rings: inference, gate bits only) or for everything (three-chunk rings: h2 stored)
     forward = "".join(body for name, body in inflight.kernels_of(text) if "mlp_rows_forward_kernel" in name)
     waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)\n\ts_barrier", forward)
-    assert len(waits) >= 36 * 12 and set(waits) <= {"0", "4", "8"} and "4" in waits
-    assert_no_inflight_register_access(text, "mlp_rows_forward_kernel", min_hand_loads=36 * 100)
+    assert len(waits) >= 60 * 12 and set(waits) <= {"0", "4", "8"} and "4" in waits
+    assert_no_inflight_register_access(text, "mlp_rows_forward_kernel", min_hand_loads=60 * 100)
     # the rows-per-wave data gradient: same rules (its barriers also count the next tile's row loads and the wave's
     # gate block, so their vmcnt values are not a fixed set)
     assert_no_inflight_register_access(text, "mlp_rows_backward_gate_kernel", min_hand_loads=6 * 50)
