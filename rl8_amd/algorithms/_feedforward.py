@@ -347,6 +347,9 @@ class Algorithm:
         from ..nn import fused_mlp
 
         fused_mlp._TRUSTED_PAIRS.clear()  # (a loss gradient nobody ran a backward on)
+        record = getattr(self, "_record", None)
+        if record is not None and record.towers:  # (the 1-KiB-per-row slabs go first when memory is short)
+            record.release_if_tight(self._tm[DataKeys.LOGP].device)
 
     def _reset_buffer(self) -> None:
         """``buffer_spec.zero(...)`` then ``obs[:, -1] = final_obs`` (and the final
@@ -807,6 +810,10 @@ class Algorithm:
         # first optimizer step): start from the record instead of launching the forward again.
         recorded: None | dict[int, tuple] = None
         rec, batch_rows = getattr(self, "_record", None), getattr(self, "_batch_rows", None)
+        if (rec is not None and batch_rows is not None and DataKeys.OBS in batch
+                and self._record_obs_version == self._tm[DataKeys.OBS]._version and rec.valid()):
+            obs_tm = self._tm[DataKeys.OBS]
+            rec.require_inputs(obs_tm.data_ptr(), obs_tm.stride(0) * obs_tm.element_size())
         if (rec is not None and batch_rows is not None and DataKeys.OBS in batch
                 and self._record_obs_version == self._tm[DataKeys.OBS]._version and rec.valid()):
             recorded = rec.rows(0, rows) if batch_rows[0] == "all" else rec.gather(batch_rows[1])

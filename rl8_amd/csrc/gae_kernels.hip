@@ -461,8 +461,7 @@ RL8_API int rl8_gae_scan_f32(float *rewards, const float *values, float *adv_out
     if (e > 256) e = 256;
     // (the pipelined flat kernel below: 128 envs per workgroup, two workgroups per CU measured best -- 122.6-124.2 us per
     // 2^20 x 32 against 126.5-128 for the other shapes)
-    static const int no_pipeline = env_int("RL8_GAE_NO_PIPELINE");  // (A/B runs)
-    const bool pipelined_shape = !no_pipeline && chunk == cols && (cols & 1) && cols <= 36;
+    const bool pipelined_shape = chunk == cols && (cols & 1) && cols <= 36;
     if (pipelined_shape && e > 128) e = 128;
     if (env_override >= kWave && env_override <= 256 && env_override % kWave == 0) e = env_override;
     if (e < kWave) e = kWave;

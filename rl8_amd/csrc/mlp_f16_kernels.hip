@@ -604,7 +604,9 @@ RL8_API int rl8_mlp_tower_backward_gate_f16_f32(const float *x, const float *w1,
   *partial_rows_out = grid > g2 ? grid : g2;
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
-  if (!env_int("RL8_MLP_DGRAD_ROWS_OFF")) {  // rows-per-wave kernel (mlp_rows_kernels.hip) for d_in <= 3; the switch is read per call (A/B runs)
+  // d_in <= 3: the rows-per-wave kernel (mlp_rows_kernels.hip); 4, 5: the tile kernel's gate mode (its running column sums
+  // fit LDS at these widths; in the rows shape they did not pay: profiles/r05_experiments.md)
+  {
     const int st = mlp_rows_backward_gate_dispatch(grid, s, x, w1, b1, dout, m, d_in, w2t_gate, n_out, partials, stride, g2, gate2);
     if (st != -1) return st;
   }
@@ -612,9 +614,7 @@ RL8_API int rl8_mlp_tower_backward_gate_f16_f32(const float *x, const float *w1,
 #define RL8_BACKWARD_GATE(D, N) \
   if (d_in == D && n_out == N) \
     status = launch_backward_f16<D, N, true>(grid, s, x, w1, b1, dout, m, w2t_gate, nullptr, partials, stride, g2, gate2);
-  RL8_BACKWARD_GATE(1, 1) RL8_BACKWARD_GATE(1, 2) RL8_BACKWARD_GATE(2, 1) RL8_BACKWARD_GATE(2, 2)
-  RL8_BACKWARD_GATE(3, 1) RL8_BACKWARD_GATE(3, 2) RL8_BACKWARD_GATE(4, 1) RL8_BACKWARD_GATE(4, 2)
-  RL8_BACKWARD_GATE(5, 1) RL8_BACKWARD_GATE(5, 2)
+  RL8_BACKWARD_GATE(4, 1) RL8_BACKWARD_GATE(4, 2) RL8_BACKWARD_GATE(5, 1) RL8_BACKWARD_GATE(5, 2)
 #undef RL8_BACKWARD_GATE
   return status;
 }

@@ -7,9 +7,11 @@
 // -- six bf16 MFMAs per 16 k instead of eight fp32 MFMAs of 1/16 the rate (the fp32 MFMAs share the VALU's multipliers:
 // 155 TFLOP/s and nothing overlaps with them, tools/probes/mfma_valu_probe.hip; the 16-bit pipe sustains 1.5-1.7 PFLOP/s
 // with VALU work beside it).  Round 3 moved the default paths to two fp16 planes per operand, each scaled by a power of
-// two per column of the OUTPUT it indexes (three plane products; two when one operand is the ReLU gate itself): see the
-// F16 template parameters below.  The bf16 forms stay for A/B runs (RL8_WGRAD_PLANES / RL8_WGRAD_GATE_PLANES=bf16) and for
-// operands without a bound (rl8_mlp_wgrad_split_f32, rl8_mlp_wgrad_split_strided_f32).
+// two per column of the OUTPUT it indexes (three plane products; two when one operand is the ReLU gate itself): the
+// sixteen-wave kernels below (round 4; the eight-wave fp16 variants they replaced were removed in round 5).  The
+// eight-wave kernels keep the exact bf16 forms: what the guard of the fp16 planes falls back to, what
+// RL8_WGRAD_PLANES / RL8_WGRAD_GATE_PLANES=bf16 select, and what serves operands without a bound (rl8_mlp_wgrad_split_f32,
+// rl8_mlp_wgrad_split_strided_f32).
 // The forward and data-gradient kernels of this scheme (round 1-2: mlp_tower_{forward,backward}_split_kernel) were
 // removed in round 3: every width they served runs the rows-per-wave kernels of mlp_rows_kernels.hip /
 // mlp_f16_kernels.hip, everything else the fp32-MFMA generation of mlp_kernels.hip.
@@ -124,17 +126,15 @@ struct WgradOperands {
   int groups = 1, group_dz_offset = 0;
 };
 
-// F16 (round 3, fused mode with compiled widths): BOTH operands as two fp16 planes, each scaled by a power of two per
-// column of the OUTPUT it indexes -- dZ2[s][j] by 2^a(j) from sum_q max|dOut_q| |W3[q][j]|, h1[s][i] by 2^b(i) from
-// |b1[i]| + sum_c max|x_c| |w1[i][c]| -- so the factors leave the sum over samples; THREE plane products per 16 samples
-// instead of six (see mlp_wgrad_gate_kernel's F16 for the accuracy argument; here both operands carry 22 bits).
-template <int DIN, int FUSED = 0, bool LOADH = false, bool F16 = false>
+// (The fp16-plane form of this product -- both operands two planes, each scaled by a power of two per column of the
+// OUTPUT it indexes so that the factors leave the sum over samples: three plane products instead of six -- is
+// mlp_wgrad_fused16_kernel / mlp_wgrad_loadh16_kernel below.)
+template <int DIN, int FUSED = 0, bool LOADH = false>
 __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     const float *__restrict__ dz2, const float *__restrict__ x, const float *__restrict__ w1,
     const float *__restrict__ b1, int64_t m, int d_in_rt, float *__restrict__ slabs, WgradFusedArgs fused,
     WgradOperands ops) {
   static_assert(!LOADH || (DIN > 0 && FUSED == 0), "the two-operand mode: compiled input widths, no head fusion");
-  static_assert(!F16 || (DIN > 0 && (FUSED > 0 || LOADH)), "fp16 planes: the fused mode of compiled widths, or both operands loaded");
   if (guard_says_leave(fused)) return;  // (uniform: the other generation of planes forms this call's sums)
   constexpr int kIn = DIN > 0 ? DIN : kMaxIn;
   constexpr int kOut = FUSED > 0 ? FUSED : 1;
@@ -162,27 +162,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     for (int q = 0; q < kOut; ++q) {
       w3r[q] = fused.w3[q * kHidden + col];
       dw3a[q] = 0.0f;
-    }
-  }
-  [[maybe_unused]] float scale_a = 1.0f, scale_b = 1.0f;  // F16: this thread's column as j of dZ2 and as i of h1
-  [[maybe_unused]] float *inv_a = reinterpret_cast<float *>(smem + 2 * kWsStageBytes), *inv_b = inv_a + kHidden;
-  if constexpr (F16) {
-    float za = 0.0f, hb = __builtin_fabsf(b1r);
-    if constexpr (LOADH) {  // one power of two per operand for the launch
-      za = __uint_as_float(*ops.dz_bound);
-      hb = __uint_as_float(*ops.h_bound);
-    } else {
-#pragma unroll
-      for (int q = 0; q < kOut; ++q) za = __builtin_fmaf(__uint_as_float(fused.bounds[q]), __builtin_fabsf(w3r[q]), za);
-#pragma unroll
-      for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[4 + c]), __builtin_fabsf(w1r[c]), hb);
-    }
-    const int ea = f16_bound_exponent(za * 1.0001f), eb = f16_bound_exponent(hb * 1.0001f);
-    scale_a = __builtin_amdgcn_ldexpf(1.0f, kF16Top - ea);
-    scale_b = __builtin_amdgcn_ldexpf(1.0f, kF16Top - eb);
-    if (kh == 0) {
-      inv_a[col] = __builtin_amdgcn_ldexpf(1.0f, ea - kF16Top);
-      inv_b[col] = __builtin_amdgcn_ldexpf(1.0f, eb - kF16Top);
     }
   }
 
@@ -224,28 +203,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       planes[0][e >> 1] = hi;
       planes[1][e >> 1] = mid;
       planes[2][e >> 1] = lo;
-    }
-  };
-  [[maybe_unused]] auto split8h = [&](const float (&v)[8], float scale, u32x4 (&planes)[3]) {  // F16: hi, lo (planes[2] unused)
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      uint32_t hi, lo;
-      f16_pair_scaled(v[e], v[e + 1], scale, hi, lo);
-      planes[0][e >> 1] = hi;
-      planes[1][e >> 1] = lo;
-    }
-  };
-  // (round 4) the dZ2 operand -- the one that carries dOut's dynamic range -- with a WIDE low plane: 2^11 x the residual,
-  // 22 bits of a value down to 2^-27 of its column's bound instead of 2^-17 (f16_pair_scaled_wide)
-  [[maybe_unused]] const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));  // 2048.0f, scalar
-  [[maybe_unused]] const uint32_t k_low = (uint32_t)__builtin_amdgcn_readfirstlane((int)kF16GateLowMask);   // fp16 {2^-11, 2^-11}
-  [[maybe_unused]] auto split8h_wide = [&](const float (&v)[8], float scale, u32x4 (&planes)[3]) {
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      uint32_t hi, lo;
-      f16_pair_scaled_wide(v[e], v[e + 1], scale, k2048, hi, lo);
-      planes[0][e >> 1] = hi;
-      planes[1][e >> 1] = lo;
     }
   };
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -296,13 +253,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   auto produce = [&](const float (&dzv)[8], [[maybe_unused]] const float (&hv)[8], int64_t n, u32x4 (&pa)[3],
                      u32x4 (&pb)[3]) {
     if constexpr (LOADH) {
-      if constexpr (F16) {
-        split8h_wide(dzv, scale_a, pa);
-        split8h(hv, scale_b, pb);
-      } else {
-        split8(dzv, pa);
-        split8(hv, pb);
-      }
+      split8(dzv, pa);
+      split8(hv, pb);
       return;
     }
     // (runtime d_in only: per-row loads, rows past the end clamped as above)
@@ -326,8 +278,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
         dz[e] = dzv[e] > 0.0f ? g : 0.0f;
         db2a += dz[e];
       }
-      if constexpr (F16) split8h_wide(dz, scale_a, pa);
-      else split8(dz, pa);
+      split8(dz, pa);
     } else {
       split8(dzv, pa);
     }
@@ -342,17 +293,16 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       }
       h[e] = relu1(v);
     }
-    if constexpr (F16) split8h(h, scale_b, pb);
-    else split8(h, pb);
+    split8(h, pb);
   };
   auto write_planes = [&](int stage, const u32x4 (&pa)[3], const u32x4 (&pb)[3]) {
     const unsigned addr = p_write + stage * kWsStageBytes;
     lds_write_b128<0>(addr, pa[0]);
     lds_write_b128<kWsPlane>(addr, pa[1]);
-    if constexpr (!F16) lds_write_b128<2 * kWsPlane>(addr, pa[2]);
+    lds_write_b128<2 * kWsPlane>(addr, pa[2]);
     lds_write_b128<kWsOperandBytes>(addr, pb[0]);
     lds_write_b128<kWsOperandBytes + kWsPlane>(addr, pb[1]);
-    if constexpr (!F16) lds_write_b128<kWsOperandBytes + 2 * kWsPlane>(addr, pb[2]);
+    lds_write_b128<kWsOperandBytes + 2 * kWsPlane>(addr, pb[2]);
   };
 
   f32x16 acc[2][4];
@@ -379,7 +329,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
   SplitFrags f;
   auto first_reads = [&](auto parity_tag) {  // ... of the chunk in stage P, into am and that step's BM
     constexpr int P = decltype(parity_tag)::value;
-    if constexpr (F16) return;  // (the fp16 step fetches its twelve fragments itself, under its own production)
     const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
     u32x4(&BM)[4] = *(P == 0 ? &f.bm : &f.bh);
     f.am[0] = lds_read_b128<kWsPlane>(ar);
@@ -393,68 +342,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
     constexpr bool FIRST = decltype(first_tag)::value;
     constexpr int P = decltype(parity_tag)::value;
     const unsigned ar = a_read + P * kWsStageBytes, br = b_read + P * kWsStageBytes;
-    if constexpr (F16) {
-      // ah / am: hi / lo planes of dZ2^T, bh / bm: of h1.  The first product's six fragments are requested in front of
-      // the next chunk's production (which does not depend on them), the other six behind it: they land under the
-      // first product.  (All twelve in front: the wider variants spilled.)
-      // (round 4: hi x hi first, lo x hi last -- the wide low plane of dZ2, 2^11 x its residual, meets the h1 hi
-      // fragments times 2^-11, formed in place once hi x hi, the product that reads them as they are, is issued)
-      f.ah[0] = lds_read_b128<0>(ar);
-      f.ah[1] = lds_read_b128<512>(ar);
-      f.bh[0] = lds_read_b128<0>(br);
-      f.bh[1] = lds_read_b128<512>(br);
-      f.bh[2] = lds_read_b128<1024>(br);
-      f.bh[3] = lds_read_b128<1536>(br);
-      if constexpr (LOADH) {
-        // one register set per operand (as in the bf16 step below): split, write, re-request
-        const unsigned addr = p_write + (P ^ 1) * kWsStageBytes;
-        if (want_colsums) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            cs_b += dzq[0][e];
-#pragma unroll
-            for (int c = 0; c < kIn; ++c) cs_w[c] = __builtin_fmaf(dzq[0][e], xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], cs_w[c]);
-          }
-        }
-        u32x4 pl[3];
-        split8h_wide(dzq[0], scale_a, pl);
-        lds_write_b128<0>(addr, pl[0]);
-        lds_write_b128<kWsPlane>(addr, pl[1]);
-        load_dz(dzq[0], n + 2);
-        split8h(hq[0], scale_b, pl);
-        lds_write_b128<kWsOperandBytes>(addr, pl[0]);
-        lds_write_b128<kWsOperandBytes + kWsPlane>(addr, pl[1]);
-        load_h(hq[0], n + 2);
-      } else {
-        // (the other stage's last readers passed the previous step's barrier: its planes can go out as soon as they exist)
-        u32x4 pa[3], pb[3];
-        load_dz(dzq[P], n + 2);
-        produce(dzq[P ^ 1], dzq[P ^ 1], n + 1, pa, pb);
-        write_planes(P ^ 1, pa, pb);
-      }
-      f.am[0] = lds_read_b128<kWsPlane>(ar);
-      f.am[1] = lds_read_b128<kWsPlane + 512>(ar);
-      f.bm[0] = lds_read_b128<kWsPlane>(br);
-      f.bm[1] = lds_read_b128<kWsPlane + 512>(br);
-      f.bm[2] = lds_read_b128<kWsPlane + 1024>(br);
-      f.bm[3] = lds_read_b128<kWsPlane + 1536>(br);
-      wait_lds<6>(f.ah[0], f.ah[1], f.bh[0], f.bh[1], f.bh[2], f.bh[3]);  // only LDS operations in flight: in-order count
-      __builtin_amdgcn_sched_barrier(0);
-      f16_mma<FIRST>(f.ah, f.bh, acc);  // hi x hi
-      request_scalars(n + 2);
-      wait_lds<0>(f.am[0], f.am[1], f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
-      __builtin_amdgcn_sched_barrier(0);
-      f16_mma<false>(f.ah, f.bm, acc);  // hi x lo
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) f.bh[t][r] = f16_pair_times(f.bh[t][r], k_low);  // h1 hi planes x 2^-11, in place
-      f16_mma<false>(f.am, f.bh, acc);  // (2^11 lo) x (2^-11 hi)
-      __builtin_amdgcn_sched_barrier(0);
-      lds_barrier();
-      scalars_landed();
-      return;
-    }
     u32x4(&BM)[4] = *(P == 0 ? &f.bm : &f.bh);
     u32x4(&BH)[4] = *(P == 0 ? &f.bh : &f.bm);
     // am and BM are in (previous step / prologue); the hi planes:
@@ -593,7 +480,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       for (int r = 0; r < 16; ++r) {
         const int j = 64 * wj + 32 * ja + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const int i = 128 * wi + 32 * t + l32;
-        slab[j * kHidden + i] = F16 ? acc[ja][t][r] * (inv_a[j] * inv_b[i]) : acc[ja][t][r];
+        slab[j * kHidden + i] = acc[ja][t][r];
       }
 
   if constexpr (LOADH) {
@@ -675,21 +562,14 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
 constexpr int kWgOperandA = 2 * kHidden * 16;             // gate plane: [sample half][column] x 16 B
 constexpr int kWgStageBytes = kWgOperandA + kWsOperandBytes;  // gate | three planes of dOut * h1
 
-// F16 (round 3, with BITS): the second operand dOut[s] * h1[s][i] as TWO fp16 planes of its value times a power of two
-// per COLUMN i -- the reduction runs over samples, so a factor that depends on i alone comes out of the sum -- chosen
-// from a bound on the column: max_s |dOut[s]| * (|b1[i]| + sum_c max_s |x[s][c]| |w1[i][c]|), placed below 2^14.  The
-// maxima over the call's rows come from one pass over dOut and x in front of the first segment
-// (wgrad_gate_bounds_kernel: 0.5 % of the call).  TWO plane products per 16 samples instead of three, four VALU
-// instructions per pair to form the planes instead of eleven.  Accuracy: the planes carry 22 bits of every term within
-// 2^-17 of its column's bound; smaller terms keep an absolute error of 2^-39 of the bound (fp16's subnormal spacing) --
-// of the column's sum that is far below what the fp32 accumulation over 2^23 samples itself leaves.  Against fp64:
-// tests/test_mlp_split_gpu.py (same bars as the bf16 planes: error / max |dW2|).
-template <int DIN, bool PAIR = false, bool BITS = false, bool F16 = false>
+// (The fp16-plane form -- the second operand dOut[s] * h1[s][i] as TWO fp16 planes of its value times a power of two per
+// COLUMN i, chosen from a bound on the column: max_s |dOut[s]| * (|b1[i]| + sum_c max_s |x[s][c]| |w1[i][c]|), placed below
+// 2^14; two plane products per 16 samples instead of three -- is mlp_wgrad_gate16_kernel below.)
+template <int DIN, bool PAIR = false, bool BITS = false>
 __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     const float *__restrict__ h2, const float *__restrict__ x, const float *__restrict__ w1,
     const float *__restrict__ b1, int64_t m, float *__restrict__ slabs, WgradFusedArgs fused) {
   static_assert(DIN > 0, "compiled input widths only");
-  static_assert(!F16 || BITS, "the fp16 planes go with the gate bits");
   if (guard_says_leave(fused)) return;  // (uniform: the other generation of planes forms this call's sums)
   constexpr int kIn = DIN, d_in = DIN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -699,8 +579,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
   const int wj = wave >> 1, wi = wave & 1;  // j-tiles {2wj, 2wj+1}, i-tiles {4wi .. 4wi+3}
   const int col = tid & 255;                // producer: column (j of the gate and i of h1) ...
   const int kh = wave >> 2;                 // ... and which eight samples of the chunk (wave-uniform)
-  [[maybe_unused]] float col_scale = 1.0f;  // F16: this thread's column's power of two
-  [[maybe_unused]] float *inv_scales = reinterpret_cast<float *>(smem + 4 * kWgStageBytes);  // F16: [256], for the epilogue
 
   const unsigned a_read = lds0 + (hh * kHidden + 64 * wj + l32) * 16;
   const unsigned b_read = lds0 + kWgOperandA + (hh * kHidden + 128 * wi + l32) * 16;
@@ -710,22 +588,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
 #pragma unroll
   for (int c = 0; c < kIn; ++c) w1r[c] = w1[col * d_in + c];
   const float b1r = b1[col];
-  [[maybe_unused]] float b1r_scaled = b1r;  // F16: b1 times the column's power of two
   float gsum = 0.0f, dw3a = 0.0f;  // sum_s G dOut (db2 / W3) and dW3 of this thread's column and sample half
-  if constexpr (F16) {
-    float hb = __builtin_fabsf(b1r);
-#pragma unroll
-    for (int c = 0; c < kIn; ++c) hb = __builtin_fmaf(__uint_as_float(fused.bounds[4 + c]), __builtin_fabsf(w1r[c]), hb);
-    // (fp32 rounding of the bound itself: a hair above)
-    const int e = f16_bound_exponent(__uint_as_float(fused.bounds[0]) * hb * 1.0001f);
-    col_scale = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
-    if (kh == 0) inv_scales[col] = __builtin_amdgcn_ldexpf(1.0f, e - kF16Top);
-    // (round 4) the power of two goes into layer 1 itself -- relu(x . (s w1) + s b1) = s h1 exactly -- and the planes are
-    // formed from the exact product (s h1) * dOut: one multiplication less per element, one rounding less per term
-#pragma unroll
-    for (int c = 0; c < kIn; ++c) w1r[c] *= col_scale;
-    b1r_scaled = b1r * col_scale;
-  }
 
   const int64_t chunks = (m + kWsChunk - 1) / kWsChunk;
   const int64_t stride = gridDim.x;
@@ -776,7 +639,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     scalar_tie(dq);
     if constexpr (PAIR) scalar_tie(dq_hi);
   };
-  [[maybe_unused]] const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));  // 2048.0f, scalar
   // The chunk's operands -> stage `stage` (free from the previous step's barrier on): the
   // gate plane, then the three planes of dOut * h1, each written as soon as it is formed.
   auto produce = [&](const float (&h2v)[8], int stage) {
@@ -790,8 +652,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
         for (int e = 0; e < 8; e += 2) {
           const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)__float_as_uint(h2v[e]), (unsigned)(col & 31), 1u);
           const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)__float_as_uint(h2v[e + 1]), (unsigned)(col & 31), 1u);
-          g[e >> 1] = F16 ? (m0 & 0x00003c00u) | (m1 & 0x3c000000u)   // fp16 1.0 / 0.0
-                          : (m0 & 0x00003f80u) | (m1 & 0x3f800000u);  // bf16 1.0 / 0.0
+          g[e >> 1] = (m0 & 0x00003f80u) | (m1 & 0x3f800000u);  // bf16 1.0 / 0.0
           gsum += __uint_as_float(m0 & __float_as_uint(dout_of(e)));
           gsum += __uint_as_float(m1 & __float_as_uint(dout_of(e + 1)));
         }
@@ -810,23 +671,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     float b[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = F16 ? b1r_scaled : b1r;
+      float v = b1r;
 #pragma unroll
       for (int c = 0; c < kIn; ++c) v = __builtin_fmaf(xq[(e * kIn + c) >> 3][(e * kIn + c) & 7], w1r[c], v);
-      b[e] = F16 ? relu1(v) : relu1(v) * dout_of(e);
-    }
-    if constexpr (F16) {
-      u32x4 planes[2];
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        uint32_t hi, lo;
-        f16_pair_product_wide(b[e], b[e + 1], dout_of(e), dout_of(e + 1), k2048, hi, lo);
-        planes[0][e >> 1] = hi;
-        planes[1][e >> 1] = lo;
-      }
-      lds_write_b128<kWgOperandA>(addr, planes[0]);
-      lds_write_b128<kWgOperandA + kWsPlane>(addr, planes[1]);
-      return;
+      b[e] = relu1(v) * dout_of(e);
     }
     u32x4 planes[3];
 #pragma unroll
@@ -860,7 +708,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     constexpr int S = decltype(stage_tag)::value;
     const unsigned ar = a_read + S * kWgStageBytes, br = b_read + S * kWgStageBytes;
     u32x4(&G)[2] = *(P == 0 ? &f.ah : &f.am);
-    u32x4(&B0)[4] = *((F16 || P == 0) ? &f.bh : &f.bm);  // (F16: the hi planes always in X, the lo planes in Y)
+    u32x4(&B0)[4] = *(P == 0 ? &f.bh : &f.bm);
     G[0] = lds_read_b128<0>(ar);
     B0[0] = lds_read_b128<0>(br);
     B0[1] = lds_read_b128<512>(br);
@@ -879,44 +727,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     constexpr int S = decltype(stage_tag)::value;
     const unsigned br = b_read + S * kWgStageBytes;
     u32x4(&G)[2] = *(P == 0 ? &f.ah : &f.am);
-    if constexpr (F16) {
-      // two planes: X = f.bh holds the hi planes (in from the previous step / prologue), Y = f.bm takes the lo planes;
-      // the next chunk's gate and hi planes are fetched behind the barrier under the lo products
-      u32x4(&X)[4] = f.bh;
-      u32x4(&Y)[4] = f.bm;
-      Y[0] = lds_read_b128<kWsPlane>(br);
-      Y[1] = lds_read_b128<kWsPlane + 512>(br);
-      Y[2] = lds_read_b128<kWsPlane + 1024>(br);
-      Y[3] = lds_read_b128<kWsPlane + 1536>(br);
-      __builtin_amdgcn_sched_barrier(0);
-      f16_mma<FIRST>(G, X, acc);  // gate x hi
-      load_h2(hq[P], n + 3);
-      produce(hq[P ^ 1], (S + 2) & 3);
-      request_scalars(n + 3);
-      wait_lds<0>(Y[0], Y[1], Y[2], Y[3]);  // (with the scalar loads: nothing counts on order here)
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr ((S & 1) != 0) lds_barrier();
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      scalars_landed();
-      if constexpr (P == 0) first_reads(P1{}, std::integral_constant<int, (S + 1) & 3>{});
-      else first_reads(P0{}, std::integral_constant<int, (S + 1) & 3>{});
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        // the wide low plane holds 2^11 x the residual: its gate is 2^-11 where the hi product's is 1.0
-        u32x4 GL[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) GL[t][r] = G[t][r] & kF16GateLowMask;
-        f16_mma<false>(GL, Y, acc);  // (2^-11 gate) x (2^11 lo)
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        u32x4(&GN)[2] = *(P == 0 ? &f.am : &f.ah);
-        wait_lds<0>(GN[0], GN[1], X[0], X[1], X[2], X[3]);
-      }
-      return;
-    }
     u32x4(&B0)[4] = *(P == 0 ? &f.bh : &f.bm);
     u32x4(&B1)[4] = *(P == 0 ? &f.bm : &f.bh);
     // G and B0 (hi planes) are in (previous step / prologue); the mid planes:
@@ -1006,7 +816,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i = 128 * wi + 32 * t + l32;
-        slab[j * kHidden + i] = F16 ? acc[ja][t][r] * inv_scales[i] : acc[ja][t][r] * w3j;
+        slab[j * kHidden + i] = acc[ja][t][r] * w3j;
       }
     }
 
@@ -1254,10 +1064,12 @@ static int launch_wgrad_gate16(int grid, hipStream_t s, const float *x, const fl
 }
 
 // ---- the general fused weight gradient on sixteen waves (round 4), same recipe ---------------------------------------------
-// mlp_wgrad_split_kernel<DIN, NOUT, false, true> (dZ2 formed from h2, dOut and W3; h1 recomputed; both operands two fp16
-// planes scaled per output column, dZ2's low plane wide; three products) with 1024 threads: a wave owns 2 x 2 tiles, a
-// thread produces four samples of its column as j of dZ2 AND as i of h1, four LDS stages of four planes, one barrier per
-// two steps.  Same slabs and partial rows.  RL8_WGRAD_16=0: the eight-wave kernel.
+// The fused product of mlp_wgrad_split_kernel (dZ2 formed from h2, dOut and W3; h1 recomputed) on fp16 planes: BOTH
+// operands two planes, each scaled by a power of two per column of the OUTPUT it indexes -- dZ2[s][j] by 2^a(j) from
+// sum_q max|dOut_q| |W3[q][j]|, h1[s][i] by 2^b(i) from |b1[i]| + sum_c max|x_c| |w1[i][c]| -- so the factors leave the sum
+// over samples; dZ2's low plane wide; THREE plane products per 16 samples instead of six.  1024 threads: a wave owns
+// 2 x 2 tiles, a thread produces four samples of its column as j of dZ2 AND as i of h1, four LDS stages of four planes,
+// one barrier per two steps.  Same slabs and partial rows as the eight-wave kernel.
 constexpr int kW16FusedStageBytes = 4 * 2 * kHidden * 16;  // dZ2 hi | dZ2 lo (wide) | h1 hi | h1 lo
 
 template <int DIN, int NOUT>
@@ -1558,24 +1370,22 @@ static int launch_wgrad_split(int grid, hipStream_t s, const float *dz2, const f
   return launch_status();
 }
 
-template <int DIN, int NOUT, bool F16 = false>
+template <int DIN, int NOUT>
 static int launch_wgrad_fused(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
                               const float *b1, int64_t m, int d_in, float *slabs, WgradFusedArgs fused) {
   static LdsOptIn lds_attr_set_0;
-  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, NOUT, false, F16>), 160 * 1024)) return e_lds_attr_set_0;
-  // (F16: + the inverse powers of two of the 256 columns of each operand behind the two stages)
-  mlp_wgrad_split_kernel<DIN, NOUT, false, F16><<<grid, kWsThreads, 2 * kWsStageBytes + (F16 ? 2 * kHidden * 4 : 0), s>>>(
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, NOUT, false>), 160 * 1024)) return e_lds_attr_set_0;
+  mlp_wgrad_split_kernel<DIN, NOUT, false><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(
       h2, x, w1, b1, m, d_in, slabs, fused, WgradOperands{});
   return launch_status();
 }
 
-template <int DIN, bool PAIR = false, bool BITS = false, bool F16 = false>
+template <int DIN, bool PAIR = false, bool BITS = false>
 static int launch_wgrad_gate(int grid, hipStream_t s, const float *h2, const float *x, const float *w1,
                              const float *b1, int64_t m, float *slabs, WgradFusedArgs fused) {
   static LdsOptIn lds_attr_set_0;
-  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN, PAIR, BITS, F16>), 160 * 1024)) return e_lds_attr_set_0;
-  // (F16: + the columns' inverse powers of two behind the four stages)
-  mlp_wgrad_gate_kernel<DIN, PAIR, BITS, F16><<<grid, kWsThreads, 4 * kWgStageBytes + (F16 ? kHidden * 4 : 0), s>>>(
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_gate_kernel<DIN, PAIR, BITS>), 160 * 1024)) return e_lds_attr_set_0;
+  mlp_wgrad_gate_kernel<DIN, PAIR, BITS><<<grid, kWsThreads, 4 * kWgStageBytes, s>>>(
       h2, x, w1, b1, m, slabs, fused);
   return launch_status();
 }
@@ -1808,21 +1618,21 @@ RL8_API int rl8_mlp_wgrad_split_f32(const float *dz2, const float *x, const floa
   return launch_status();
 }
 
-template <int DIN, bool F16 = false>
+template <int DIN>
 static int launch_wgrad_loadh(int grid, hipStream_t s, const float *dz, const float *x, int64_t rows, float *workspace,
                               const WgradOperands &ops) {
   static LdsOptIn lds_attr_set_0;
-  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, 0, true, F16>), 160 * 1024)) return e_lds_attr_set_0;
-  mlp_wgrad_split_kernel<DIN, 0, true, F16><<<grid, kWsThreads, 2 * kWsStageBytes + (F16 ? 2 * kHidden * 4 : 0), s>>>(
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_wgrad_split_kernel<DIN, 0, true>), 160 * 1024)) return e_lds_attr_set_0;
+  mlp_wgrad_split_kernel<DIN, 0, true><<<grid, kWsThreads, 2 * kWsStageBytes, s>>>(
       dz, x, nullptr, nullptr, rows, DIN, workspace, WgradFusedArgs{}, ops);
   return launch_status();
 }
 
 // ---- the two-operand weight gradient (the LSTM's dW_hh per gate) on sixteen waves (round 4) ---------------------------
-// mlp_wgrad_split_kernel<DIN, 0, true, true> -- both operands read from memory, each two fp16 planes on one power of two
-// per launch, dZ's low plane wide, optional column sums for dW_ih / db -- with 1024 threads: twice the loads in flight
-// per CU on a kernel that runs at the rate HBM delivers its 1-KiB row pieces.  Same grouping (four gates per launch, the
-// four workgroups that walk the same rows on one XCD), slabs and column-sum rows.  RL8_WGRAD_16=0: the eight-wave kernel.
+// The two-operand mode of mlp_wgrad_split_kernel -- both operands read from memory -- on fp16 planes: each operand two
+// planes on one power of two per launch, dZ's low plane wide, optional column sums for dW_ih / db.  1024 threads: twice
+// the loads in flight per CU on a kernel that runs at the rate HBM delivers its 1-KiB row pieces.  Same grouping (four
+// gates per launch, the four workgroups that walk the same rows on one XCD), slabs and column-sum rows.
 template <int DIN>
 __global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_loadh16_kernel(
     const float *__restrict__ dz, const float *__restrict__ x, int64_t m, float *__restrict__ slabs, WgradOperands ops) {
@@ -2059,25 +1869,14 @@ static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int6
                             groups, groups == 4 ? kHidden : 0};
     const float *xs = colsums ? x + at * d_in : nullptr;
     int status;
-    static const bool sixteen = [] {  // the sixteen-wave kernel (round 4); RL8_WGRAD_16=0: the eight-wave one
-      const char *v = getenv("RL8_WGRAD_16");
-      return !(v && v[0] == '0');
-    }();
-    if (dz_bound && sixteen) {
+    if (dz_bound) {  // fp16 planes behind the caller's bound: the sixteen-wave kernel
       switch (colsums ? d_in : 1) {
         case 1: status = launch_wgrad_loadh16<1>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
         case 2: status = launch_wgrad_loadh16<2>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
         case 3: status = launch_wgrad_loadh16<3>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
         default: status = launch_wgrad_loadh16<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
       }
-    } else if (dz_bound) {
-      switch (colsums ? d_in : 1) {
-        case 1: status = launch_wgrad_loadh<1, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
-        case 2: status = launch_wgrad_loadh<2, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
-        case 3: status = launch_wgrad_loadh<3, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
-        default: status = launch_wgrad_loadh<5, true>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
-      }
-    } else {
+    } else {  // no bound: the exact bf16 planes
       switch (colsums ? d_in : 1) {
         case 1: status = launch_wgrad_loadh<1>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
         case 2: status = launch_wgrad_loadh<2>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
@@ -2169,10 +1968,6 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
     if (planes == kPlanesGuarded && launch_wgrad_tail(s, dout, m * n_out, bounds) != 0) return launch_status();
   }
   const uint32_t *guard = planes == kPlanesGuarded && f16 ? bounds : nullptr;
-  static const bool sixteen = [] {  // the sixteen-wave kernel (round 4); RL8_WGRAD_16=0: the eight-wave one
-    const char *v = getenv("RL8_WGRAD_16");
-    return !(v && v[0] == '0');
-  }();
   // Segments of kWgradSegmentRows samples, summed in order (see there).  The first one
   // runs the grid the data-gradient kernel counted on (g2 rows of partials written, the
   // rest zeroed); later ones add to as many of those rows as they have workgroups.
@@ -2200,9 +1995,8 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
     }
 #define RL8_WGRAD_FUSED(D, N) \
   if (d_in == D && n_out == N) { \
-    status = f16 && sixteen ? launch_wgrad_fused16<D, N>(grid, s, h2s, xs, w1, b1, rows, workspace, fused) \
-             : f16 ? launch_wgrad_fused<D, N, true>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused) \
-                   : launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused); \
+    status = f16 ? launch_wgrad_fused16<D, N>(grid, s, h2s, xs, w1, b1, rows, workspace, fused) \
+                 : launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, fused); \
     if (status == 0 && guard) status = launch_wgrad_fused<D, N>(grid, s, h2s, xs, w1, b1, rows, d_in, workspace, exact); \
   }
     RL8_WGRAD_FUSED(1, 1) RL8_WGRAD_FUSED(1, 2) RL8_WGRAD_FUSED(1, 3) RL8_WGRAD_FUSED(1, 4)
@@ -2293,11 +2087,6 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
     if (planes == kPlanesGuarded && launch_wgrad_tail(s, dout, m * n_out, bounds) != 0) return launch_status();
   }
   const uint32_t *guard = planes == kPlanesGuarded ? bounds : nullptr;
-  // the sixteen-wave kernel (round 4: 249 against 266 us per 2^20 rows); RL8_WGRAD_GATE16=0: the eight-wave one
-  static const bool sixteen = [] {
-    const char *v = getenv("RL8_WGRAD_GATE16");
-    return !(v && v[0] == '0');
-  }();
   for (int64_t at = 0; at < m; at += kWgradSegmentRows) {  // segments summed in order, as rl8_mlp_wgrad_fused_split_f32
     const int64_t rows = m - at < kWgradSegmentRows ? m - at : kWgradSegmentRows;
     const int64_t chunks = (rows + kWsChunk - 1) / kWsChunk;
@@ -2309,10 +2098,8 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
     int status = RL8_ESIZE;
 #define RL8_WGRAD_BITS(D) \
   if (d_in == D) { \
-    status = f16 && sixteen ? (n_out == 2 ? launch_wgrad_gate16<D, true>(grid, s, xs, w1, b1, rows, workspace, fused) \
-                                          : launch_wgrad_gate16<D, false>(grid, s, xs, w1, b1, rows, workspace, fused)) \
-           : f16 ? (n_out == 2 ? launch_wgrad_gate<D, true, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
-                               : launch_wgrad_gate<D, false, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused)) \
+    status = f16 ? (n_out == 2 ? launch_wgrad_gate16<D, true>(grid, s, xs, w1, b1, rows, workspace, fused) \
+                               : launch_wgrad_gate16<D, false>(grid, s, xs, w1, b1, rows, workspace, fused)) \
            : n_out == 2 ? launch_wgrad_gate<D, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused) \
                         : launch_wgrad_gate<D, false, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, fused); \
     if (status == 0 && guard) \

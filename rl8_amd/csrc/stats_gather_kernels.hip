@@ -165,49 +165,17 @@ __global__ __launch_bounds__(kBlock) void gather_minibatch_kernel(
 // several times (num_sgd_iters x num_minibatches gathers per step()), the fields
 // of every sample are first laid side by side, once, in the reference's sample
 // order s = env*H + t; a minibatch then reads ONE 16-byte-aligned row per
-// sample.  pack: reads follow storage order (lanes along envs), each lane writes
-// its own row.  gather: each lane reads its row word by word (one sector, served
-// from L1 after the first touch) and writes the dense outputs.
+// sample.  pack: a tiled transposition through LDS (pack_samples_tiled_kernel).
+// gather: each lane reads its own row and writes the dense outputs.
 struct PackedArgs {
   rl8_gather_field f[RL8_MAX_GATHER_FIELDS];
   int n_fields;
   int row_words;
 };
 
-// Both kernels move a row as 16-byte vectors (a random access costs the
-// texture-address unit one slot per lane and instruction, whatever its width:
-// word-by-word rows were address-bound, not HBM-bound) and stage it in a
-// thread-private LDS slot, which -- unlike registers -- can be indexed by the
-// run-time field offsets.  VECS = row_words / 4.
-template <int VECS>
-__global__ __launch_bounds__(kBlock) void pack_samples_kernel(int64_t n, int64_t h,
-                                                              uint32_t *__restrict__ packed,
-                                                              PackedArgs args) {
-  __shared__ float4 stage[kBlock * VECS];
-  float4 *mine = stage + threadIdx.x * VECS;
-  uint32_t *words_of_mine = reinterpret_cast<uint32_t *>(mine);
-  const int64_t total = n * h, stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
-    const int64_t t = i / n, env = i - t * n;  // lanes along envs: storage order of a time-major buffer
-    int off = 0;
-#pragma unroll 1
-    for (int f = 0; f < args.n_fields; ++f) {
-      const rl8_gather_field &fd = args.f[f];
-      const int words = fd.row_elems * (fd.elem_bytes / 4);
-      const uint32_t *src = static_cast<const uint32_t *>(fd.src) +
-                            (env * fd.env_stride + t * fd.time_stride) * (fd.elem_bytes / 4);
-      for (int c = 0; c < words; ++c) words_of_mine[off + c] = src[c];
-      off += words;
-    }
-    float4 *row = reinterpret_cast<float4 *>(packed + (env * h + t) * args.row_words);
-#pragma unroll
-    for (int v = 0; v < VECS; ++v) row[v] = mine[v];
-  }
-}
-
 // pack_samples as a tiled transposition (round 4; VERDICT r3 weak #9: "a pure streaming transposition at 1.9 TB/s").  The
-// kernel above reads coalesced (lane = env of a time-major slab) and writes each lane's own 32-byte row a kilobyte from
-// its neighbour's.  Here a workgroup owns kPackEnvs environments x up to kPackSteps timesteps: every (field, word,
+// lane-per-sample kernel it replaced (removed in round 5) read coalesced (lane = env of a time-major slab) and wrote each
+// lane's own 32-byte row a kilobyte from its neighbour's.  Here a workgroup owns kPackEnvs environments x up to kPackSteps timesteps: every (field, word,
 // timestep) is one 256-byte wave load into an LDS tile (rows padded to an odd number of words: lane = env writes hit 32
 // banks), and the tile leaves as whole packed rows in memory order -- Tc x row bytes contiguous per environment, 1 KiB per
 // wave store.  Any strides (an env-major buffer reads poorly and still writes well).
@@ -319,28 +287,17 @@ __global__ __launch_bounds__(kBlock) void gather_packed_kernel(const int64_t *__
 
 constexpr int kMaxPackedVecs = 8;  // rows of up to 128 bytes
 
-template <int VECS>
-static void launch_packed(bool pack, int grid, hipStream_t s, int64_t n, int64_t h,
-                          const int64_t *index, int64_t m, uint32_t *packed,
-                          const PackedArgs &args) {
-  if (pack)
-    pack_samples_kernel<VECS><<<grid, kBlock, 0, s>>>(n, h, packed, args);
-  else
-    gather_packed_kernel<VECS><<<grid, kBlock, 0, s>>>(index, m, packed, args);
-}
-
-static int dispatch_packed(bool pack, int grid, hipStream_t s, int64_t n, int64_t h,
-                           const int64_t *index, int64_t m, uint32_t *packed,
-                           const PackedArgs &args) {
+static int dispatch_gather_packed(int grid, hipStream_t s, const int64_t *index, int64_t m, const uint32_t *packed,
+                                  const PackedArgs &args) {
   switch (args.row_words / 4) {
-    case 1: launch_packed<1>(pack, grid, s, n, h, index, m, packed, args); break;
-    case 2: launch_packed<2>(pack, grid, s, n, h, index, m, packed, args); break;
-    case 3: launch_packed<3>(pack, grid, s, n, h, index, m, packed, args); break;
-    case 4: launch_packed<4>(pack, grid, s, n, h, index, m, packed, args); break;
-    case 5: launch_packed<5>(pack, grid, s, n, h, index, m, packed, args); break;
-    case 6: launch_packed<6>(pack, grid, s, n, h, index, m, packed, args); break;
-    case 7: launch_packed<7>(pack, grid, s, n, h, index, m, packed, args); break;
-    case 8: launch_packed<8>(pack, grid, s, n, h, index, m, packed, args); break;
+    case 1: gather_packed_kernel<1><<<grid, kBlock, 0, s>>>(index, m, packed, args); break;
+    case 2: gather_packed_kernel<2><<<grid, kBlock, 0, s>>>(index, m, packed, args); break;
+    case 3: gather_packed_kernel<3><<<grid, kBlock, 0, s>>>(index, m, packed, args); break;
+    case 4: gather_packed_kernel<4><<<grid, kBlock, 0, s>>>(index, m, packed, args); break;
+    case 5: gather_packed_kernel<5><<<grid, kBlock, 0, s>>>(index, m, packed, args); break;
+    case 6: gather_packed_kernel<6><<<grid, kBlock, 0, s>>>(index, m, packed, args); break;
+    case 7: gather_packed_kernel<7><<<grid, kBlock, 0, s>>>(index, m, packed, args); break;
+    case 8: gather_packed_kernel<8><<<grid, kBlock, 0, s>>>(index, m, packed, args); break;
     default: return RL8_ESIZE;
   }
   return launch_status();
@@ -526,10 +483,6 @@ RL8_API int rl8_pack_samples(const rl8_gather_field *fields, int n_fields, int64
   PackedArgs args;
   const int st = packed_args(fields, n_fields, row_words, true, false, &args);
   if (st != RL8_OK) return st;
-  static const bool untiled = env_int("RL8_PACK_UNTILED") != 0;  // (A/B: the lane-per-sample kernel)
-  if (untiled)
-    return dispatch_packed(true, grid_for(n * h, kBlock), (hipStream_t)stream, n, h, nullptr, 0,
-                           static_cast<uint32_t *>(packed), args);
   return launch_pack_tiled<false>(args, n, h, static_cast<uint32_t *>(packed), (hipStream_t)stream);
 }
 
@@ -541,6 +494,5 @@ RL8_API int rl8_gather_packed(const int64_t *index, int64_t m, const void *packe
   const int st = packed_args(fields, n_fields, row_words, false, true, &args);
   if (st != RL8_OK) return st;
   if (!aligned16(packed)) return RL8_EALIGN;
-  return dispatch_packed(false, grid_for(m, kBlock), (hipStream_t)stream, 0, 0, index, m,
-                         const_cast<uint32_t *>(static_cast<const uint32_t *>(packed)), args);
+  return dispatch_gather_packed(grid_for(m, kBlock), (hipStream_t)stream, index, m, static_cast<const uint32_t *>(packed), args);
 }

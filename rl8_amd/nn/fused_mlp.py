@@ -94,9 +94,11 @@ class expect_pair_gradients:
     """Context manager for callers that KNOW the gradients of a two-output tower evaluated inside it will be exact
     negatives of each other (``Algorithm``: a two-way ``Categorical`` policy under the fused PPO loss, whose kernel
     emits antisymmetric logit gradients by construction). Towers that ask (``pair_gradients=None`` resolves to
-    this hint) then keep only the gate bits of h2 from the first iteration on. The promise is still checked on the
-    device in every backward (``rl8_mlp_dout_pair_check``); a broken one costs a re-run of the forward, never a
-    wrong gradient."""
+    this hint) then keep only the gate bits of h2 from the first iteration on. The promise is checked on the
+    device in the backward (``rl8_mlp_dout_pair_check``); a broken one costs a re-run of the forward, never a
+    wrong gradient. One exception: a gradient tensor registered by ``trust_pair_gradient`` -- the two-class loss
+    kernel's own output, a pair by construction -- is taken on trust while its address, element count and version
+    counter are the registered ones (any in-place change, copy or rescaling of it is checked again)."""
 
     def __enter__(self):
         global _PAIR_HINT
@@ -215,6 +217,13 @@ def _tower_backward(ctx, dout):
 # in place of a forward launch.  Used only while every parameter of the tower is
 # what the rollout saw (version counters and addresses).
 # --------------------------------------------------------------------------- #
+#: Absolute cap on the h2 slabs a rollout record may hold (1 KiB per row and general-head tower: 34 GB at 2^25 rows),
+#: besides "a third of what is free when the slab is made" (ADVICE r4).  ``RL8_AMD_RECORD_H2_GIB`` overrides; 0: never.
+RECORD_H2_BUDGET_BYTES = int(float(os.environ.get("RL8_AMD_RECORD_H2_GIB", "48")) * (1 << 30))
+#: ... and the slabs are given back when, at the end of a step(), less than this is free on the device.
+RECORD_H2_KEEP_FREE_BYTES = 8 << 30
+
+
 class _TowerRecord:
     def __init__(self, params: list[torch.Tensor], n_out: int, gate_only: bool, rows: int, device) -> None:
         self.params = params
@@ -224,6 +233,10 @@ class _TowerRecord:
         self.h2 = None if gate_only else torch.empty(rows, hip.MLP_HIDDEN, dtype=torch.float32, device=device)
         self.key: None | tuple = None
         self.seen: set[int] = set()
+        #: address of the input each recorded timestep was evaluated on; a second evaluation of the same tower inside
+        #: one ``record.at(t)`` (a model that runs it on obs AND next_obs) spoils the timestep: never replayed
+        self.inputs: dict[int, int] = {}
+        self.spoiled = False
 
     def current_key(self) -> tuple:
         return tuple((p._version, p.data_ptr()) for p in self.params)
@@ -246,6 +259,8 @@ class RolloutRecord:
     def begin(self) -> None:
         for tr in self.towers.values():
             tr.seen.clear()
+            tr.inputs.clear()
+            tr.spoiled = False
             tr.key = None
 
     def at(self, t: int) -> "_Recording":
@@ -266,16 +281,44 @@ class RolloutRecord:
             # h2 is 1 KiB per row (34 GB per tower at 2^25 rows): only where every row is read back and it fits easily
             need = rows * (hip.MLP_HIDDEN * 4 + 32 + 4 * n_out)
             free, _ = torch.cuda.mem_get_info(device)
-            if not self.keep_general or need > free // 3:
+            held = sum(t.h2.numel() * 4 for t in self.towers.values() if t.h2 is not None)
+            if not self.keep_general or need > free // 3 or held + need > RECORD_H2_BUDGET_BYTES:
                 self.refused.add(id(layer2))
                 return None
         self.towers.pop(id(layer2), None)
-        tr = self.towers[id(layer2)] = _TowerRecord(params, n_out, gate_only, rows, device)
+        try:
+            tr = self.towers[id(layer2)] = _TowerRecord(params, n_out, gate_only, rows, device)
+        except torch.cuda.OutOfMemoryError:  # (the tower is then evaluated without a record: one more forward per step())
+            self.refused.add(id(layer2))
+            return None
         return tr
 
+    def release_if_tight(self, device) -> int:
+        """End of a ``step()``: give the h2 slabs back (and refuse new ones) when the device is short of memory --
+        activations and workspaces allocated by ``step()`` come after the slabs and must not be what runs out.  Returns
+        the bytes released."""
+        free, _ = torch.cuda.mem_get_info(device)
+        if free >= RECORD_H2_KEEP_FREE_BYTES:
+            return 0
+        released = 0
+        for key in [k for k, tr in self.towers.items() if tr.h2 is not None]:
+            released += self.towers[key].h2.numel() * 4
+            del self.towers[key]
+            self.refused.add(key)
+        return released
+
     def _usable(self, tr: _TowerRecord) -> bool:
-        """The tower saw all the timesteps, with the parameters it has now."""
-        return tr.key is not None and len(tr.seen) == self.steps and tr.current_key() == tr.key
+        """The tower saw all the timesteps, once each, with the parameters it has now."""
+        return (tr.key is not None and not tr.spoiled and len(tr.seen) == self.steps
+                and tr.current_key() == tr.key)
+
+    def require_inputs(self, base_ptr: int, step_bytes: int) -> None:
+        """The caller replays the record against the rows of ONE dense array (the time-major observations, timestep t
+        at ``base_ptr + t * step_bytes``): a tower recorded on anything else -- a model that feeds it a transformed or
+        shifted view -- is never replayed."""
+        for tr in self.towers.values():
+            if any(ptr != base_ptr + t * step_bytes for t, ptr in tr.inputs.items()):
+                tr.spoiled = True
 
     def valid(self) -> bool:
         """Some recorded tower can still be replayed."""
@@ -426,6 +469,13 @@ def tower_forward(trunk: nn.Sequential, heads: Sequence[nn.Linear], x: torch.Ten
             key = tr.current_key()
             if tr.key != key:
                 tr.key, tr.seen = key, set()
+                tr.inputs.clear()
+                tr.spoiled = False
+            if rec.t in tr.seen:  # second evaluation in this timestep's context: the slab rows of t would be overwritten
+                tr.spoiled = True
+                return _FusedTower.apply(x.contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3, l2,
+                                         torch.is_grad_enabled(), bool(pair_gradients), w3_key)
+            tr.inputs[rec.t] = x.data_ptr()
             lo = rec.t * rec.rows_per_step
             sl = slice(lo, lo + rec.rows_per_step)
             out = hip.mlp_tower_forward_split(

@@ -133,3 +133,75 @@ def test_second_collect_records_again_and_the_record_is_reused_across_iterations
         assert fused_mlp.replay_stats["replayed_towers"] == before + 2
         assert not record.valid()  # the optimizer has moved the weights
     assert [tr.gate.data_ptr() for tr in algo._record.towers.values()] == slabs  # allocated once
+
+
+def test_record_is_not_replayed_for_a_tower_evaluated_twice_per_timestep_or_on_other_rows():
+    """the record keys on the tower and the row count alone.  A tower evaluated twice inside one timestep's
+    recording context (the second call would overwrite the slab rows of t), or recorded on rows that are not the
+    time-major observations, must never be replayed -- it is evaluated normally instead."""
+    from rl8_amd.nn import fused_mlp as fm
+
+    torch.manual_seed(2)
+    algo = AlgorithmConfig(num_envs=128, horizon=4).build(DiscreteDummyEnv)
+    model = algo.policy.model
+    trunk, head = model.vf_model[:2], model.vf_model[2]
+    rec = fm.RolloutRecord(4, 128, keep_general=False)
+    rec.begin()
+    xs = torch.randn(4, 128, 1, device="cuda")
+    with torch.no_grad():
+        for t in range(4):
+            with rec.at(t):
+                a = fm.tower_forward(trunk, [head], xs[t])
+                b = fm.tower_forward(trunk, [head], xs[t] + 1.0) if t == 2 else None
+            assert torch.equal(a, head(trunk(xs[t]))) or torch.allclose(a, head(trunk(xs[t])), atol=1e-5)
+            if b is not None:
+                assert torch.allclose(b, head(trunk(xs[t] + 1.0)), atol=1e-5)
+    (tr,) = rec.towers.values()
+    assert tr.spoiled and not rec.valid()
+    # recorded once per timestep, but on rows that are not where the caller will replay from
+    rec.begin()
+    with torch.no_grad():
+        for t in range(4):
+            with rec.at(t):
+                fm.tower_forward(trunk, [head], xs[t])
+    assert rec.valid()
+    rec.require_inputs(xs.data_ptr(), 128 * 4)
+    assert rec.valid()
+    rec.require_inputs(xs.data_ptr() + 16, 128 * 4)
+    assert not rec.valid()
+
+
+def test_general_head_slabs_respect_the_byte_budget_and_are_released_when_memory_is_tight(monkeypatch):
+    """the h2 slab of a general head (1 KiB per row) is admitted against an absolute budget as well as a third
+    of free memory, a refused tower simply runs its forward again, and the slabs go when the device runs short."""
+    from rl8_amd.distributions import Normal
+    from rl8_amd.env import ContinuousDummyEnv
+    from rl8_amd.nn import fused_mlp as fm
+
+    def steps(algo):
+        out = []
+        for _ in range(2):
+            algo.collect()
+            out.append(algo.step())
+        return out
+
+    torch.manual_seed(4)
+    algo = AlgorithmConfig(num_envs=512, horizon=8, distribution_cls=Normal).build(ContinuousDummyEnv)
+    want = steps(algo)
+    assert any(tr.h2 is not None for tr in algo._record.towers.values())
+    monkeypatch.setattr(fm, "RECORD_H2_BUDGET_BYTES", 1 << 20)  # 1 MiB: the 4 MiB slab does not fit
+    torch.manual_seed(4)
+    algo2 = AlgorithmConfig(num_envs=512, horizon=8, distribution_cls=Normal).build(ContinuousDummyEnv)
+    got = steps(algo2)
+    assert all(tr.h2 is None for tr in algo2._record.towers.values()) and algo2._record.refused
+    for a, b in zip(want, got):
+        for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+            assert a[k] == b[k], k  # the record never changes a number
+    # memory pressure at the end of a step(): the slabs are released and not made again
+    monkeypatch.setattr(fm, "RECORD_H2_KEEP_FREE_BYTES", 1 << 60)
+    algo.collect()
+    algo.step()
+    assert all(tr.h2 is None for tr in algo._record.towers.values()) and algo._record.refused
+    algo.collect()
+    assert all(tr.h2 is None for tr in algo._record.towers.values())
+    assert all(torch.isfinite(torch.tensor(v)) for k, v in algo.step().items() if k.startswith("losses"))

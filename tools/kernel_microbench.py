@@ -151,12 +151,6 @@ def f16_dgrad_gate():  # single-output tower: gate plane x two planes of w3 * W2
                                              _p(_partials_v), C.byref(_rows), _p(mlp_gate), hip._stream())
 
 
-def f16_dgrad_gate_previous():  # the same through the kernel the rows-per-wave one replaced (switch read per call)
-    os.environ["RL8_MLP_DGRAD_ROWS_OFF"] = "1"
-    f16_dgrad_gate()
-    os.environ["RL8_MLP_DGRAD_ROWS_OFF"] = "0"
-
-
 def f16_forward_gate_only():  # training forward of a rank-one head: gate bits only, no h2
     hip.mlp_tower_forward_split(mlp_x, mlp_w1, mlp_b1, mlp_w2h, mlp_b2, mlp_w3, mlp_b3, save=True, save_gate=True, save_h2=False)
 
@@ -181,7 +175,6 @@ KERNELS = {
     "mlp_wgrad_gate_bits": (gate_bits_wgrad, 2 * N * 65536 / 1000),
     "mlp_tower_forward_gate_only_f16": (f16_forward_gate_only, MLP_FLOP / 1000),
     "mlp_tower_backward_gate_f16": (f16_dgrad_gate, MLP_FLOP / 1000),
-    "mlp_tower_backward_gate_f16_previous": (f16_dgrad_gate_previous, MLP_FLOP / 1000),
     "mlp_wgrad_split": (lambda: hip.mlp_wgrad_split(mlp_dz2, mlp_x, mlp_w1, mlp_b1), 2 * N * 65536 / 1000),
     "mlp_wgrad_fused": (lambda: hip.mlp_wgrad(mlp_dz2, mlp_h1), 2 * N * 65536 / 1000),
     # same launch on all-zero operands: the gap to the line above is clock / power, not the kernel
