@@ -45,10 +45,8 @@ extern "C" {
  * mismatch).  History: 100 rounds 1-2; 103 round 3 (bf16-plane forward / data-gradient entries removed, reduction
  * scratch doubled with two-level tickets -- bump owed since then); 104 round 4 (weight-gradient
  * workspace: guard words and lifetime counters behind the slabs; caller-owned outputs of the forward unchanged);
- * 105 round 4 (rl8_gather_minibatch takes index = NULL: all samples in order); 106 round 5 (the tiled "T32" layout of
- * the LSTM's saved gates and gate gradients: one more argument on rl8_lstm_step_split_f32, rl8_lstm_rows_backward_f32 /
- * _heads_f32 and rl8_lstm_wgrad_f16_f32; plane tower kernels take run-time widths inside compiled classes). */
-#define RL8_ABI_VERSION 106
+ * 105 round 4 (rl8_gather_minibatch takes index = NULL: all samples in order). */
+#define RL8_ABI_VERSION 105
 int rl8_abi_version(char *arch, int arch_len);
 
 /* Scratch the reductions need (bytes); the caller allocates it once per stream
@@ -522,14 +520,6 @@ int rl8_mlp_wgrad_split_strided_f32(const float *dz, int64_t dz_pitch, const flo
  *   `planes_out` is not NULL, h_t also as fp16 planes (rl8_lstm_split_state's layout) for the
  *   next timestep's call, so that only the first step of a sequence needs rl8_lstm_split_state.
  *   d_in in {1, 2, 3, 5} (rl8_lstm_split_supports); other widths keep rl8_lstm_forward_f32.
- *   gates_tiled_l = L > 0 (round 5; B a multiple of 32, gates 16-byte aligned, gates_pitch ignored): `gates` is the
- *   T32 array of sequences of L steps, ADVANCED to this launch's step t (base + t * 32768 floats):
- *       T32[B / 32][L][4 gates][8 chunks][32 rows][32 units]:  row r, step t, gate q, unit u at
- *       ((((r >> 5) * L + t) * 4 + q) * 8 + (u >> 5)) * 1024 + (r & 31) * 32 + (u & 31) floats.
- *   A wave's 32 rows x 32 units of one gate are then 4 KiB contiguous -- for this kernel's stores, for the backward
- *   kernel's loads and stores (rl8_lstm_rows_backward_f32, tiled = 1) and for the weight gradient's loads
- *   (rl8_lstm_wgrad_f16_f32, dz_tiled_l = L) -- instead of 32 pieces of 128 bytes a sequence pitch apart (HBM delivers
- *   128-byte pieces at 4.1 TB/s, 512-byte ones at 4.7: tools/probes/piece_size_probe.hip).  0: rows at gates_pitch.
  * ---------------------------------------------------------------------- */
 int rl8_lstm_split_supports(int d_in);
 int64_t rl8_lstm_split_packed_bytes(void);
@@ -545,7 +535,7 @@ int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, const voi
                             const float *wb, int64_t b, float *h_out, int64_t h_out_pitch, float *c_out,
                             int64_t c_out_pitch, float *gates, int64_t gates_pitch,
                             void *planes_out /* h_t as planes for the next step (another buffer than h_planes), or NULL */,
-                            int gates_tiled_l, void *stream);
+                            void *stream);
 
 /* ---------------------------------------------------------------------- *
  * a-9  Default recurrent models' LSTM, fused
@@ -603,20 +593,18 @@ int rl8_lstm_backward_f32(const float *x, int64_t b, int l, int d_in, const floa
  *   (contents irrelevant on entry, undefined on return); dg_bound_out (device word, may be NULL) receives the bit
  *   pattern of max |dgates|: the bound rl8_mlp_wgrad_f16_strided_f32 scales its fp16 planes by.  All arrays 16-byte
  *   aligned; 32 * L * 4096 < 2^31.  The input-weight, bias and recurrent-weight gradients come from
- *   rl8_mlp_wgrad_split_strided_f32 on dgates as before.
- *   tiled = 1 (round 5; B a multiple of 32): gates is read, and dgates written, in the T32 layout described at
- *   rl8_lstm_step_split_f32 (whole arrays, not advanced); cs, c0, dhs stay row-major. */
+ *   rl8_mlp_wgrad_split_strided_f32 on dgates as before. */
 int64_t rl8_lstm_rows_backward_pack_bytes(void);
 int rl8_lstm_rows_backward_pack(const float *w_hh, void *packed, void *stream);
 int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs,
                                const float *dhs, const void *packed, float *dgates, float *dc_scratch,
-                               uint32_t *dg_bound_out, int tiled, void *stream);
+                               uint32_t *dg_bound_out, void *stream);
 /* The same with dL/dh_t of the output heads formed inside from heads_dout [b][l][4] (the gradient of the heads' outputs,
  * zero-padded to four per row-step) and heads_w [4][256] (their nn.Linear weights stacked, zero rows past their number):
  * the [b][l][256] array is neither written by rl8_linear_heads_backward_f32 (dh_out NULL) nor read here. */
 int rl8_lstm_rows_backward_heads_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs,
                                      const float *heads_dout, const float *heads_w, const void *packed, float *dgates,
-                                     float *dc_scratch, uint32_t *dg_bound_out, int tiled, void *stream);
+                                     float *dc_scratch, uint32_t *dg_bound_out, void *stream);
 /* rl8_mlp_wgrad_split_strided_f32 on fp16 planes (three plane products instead of six): dz and h each scaled by one
  * power of two taken from *dz_bound / *h_bound -- device words holding a float >= max |dz| / max |h| over all rows
  * read (dg_bound_out above; 1.0f for an LSTM's outputs). */
@@ -628,12 +616,10 @@ int rl8_mlp_wgrad_f16_strided_f32(const float *dz, int64_t dz_pitch, const uint3
 /* The four gates of one LSTM timestep in one launch of the fp16-plane weight gradient: dz = the step's dG rows ([m] rows
  * of dz_pitch >= 1024 floats, gate q at columns [256 q, 256 q + 256)), dw_out [4][256][256] (+)= dG_q^T h per gate,
  * colsums (optional, with x / d_in) [4][*colsum_rows_out][256 (d_in + 1)]; h is then read from HBM once instead of four
- * times.  m >= 128 (RL8_ESIZE below: use rl8_mlp_wgrad_f16_strided_f32 per gate); bounds as there.
- * dz_tiled_l = L > 0 (round 5; m a multiple of 32, dz_pitch ignored): dz is the T32 array of gate gradients
- * (rl8_lstm_rows_backward_f32 with tiled = 1) advanced to the step: base + t * 32768 floats. */
+ * times.  m >= 128 (RL8_ESIZE below: use rl8_mlp_wgrad_f16_strided_f32 per gate); bounds as there. */
 int rl8_lstm_wgrad_f16_f32(const float *dz, int64_t dz_pitch, const uint32_t *dz_bound, const float *h, int64_t h_pitch,
                            const uint32_t *h_bound, int64_t m, float *workspace, float *dw_out, int accumulate,
-                           const float *x, int d_in, float *colsums, int *colsum_rows_out, int dz_tiled_l, void *stream);
+                           const float *x, int d_in, float *colsums, int *colsum_rows_out, void *stream);
 
 /* The recurrent models' output heads (src/rl8/models/_recurrent.py:230-236, 287-292),
  * all of them at once: out [M][n] = h [M][256] x w^T + b, w [n][256] (the heads'

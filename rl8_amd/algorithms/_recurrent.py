@@ -148,7 +148,7 @@ class _LeanRollout:
             with hip._timed("lstm_step", n) if timed else _NO_TIMER:
                 hip._check(lib.rl8_lstm_step_split_f32(at(self.obs, t), self.d_in, self.d_in, p_in, at(self.c, t), H,
                                                        packed, wb, n, at(self.h, t + 1), H, at(self.c, t + 1), H, None,
-                                                       0, p_out, 0, stream), "rl8_lstm_step_split_f32")
+                                                       0, p_out, stream), "rl8_lstm_step_split_f32")
             self.planes_of = t + 1
             hs = at(self.h, t + 1)  # the heads read h_t where the buffer keeps it
         else:

@@ -148,10 +148,6 @@ struct LrArgs {
   int l;
   unsigned long long *stamps;  // tuning builds (RL8_LR_STAMP): cycles per wait site, summed over waves; else null
   uint32_t *dg_bound;          // max |dG| over everything written, as the bits of a non-negative float (atomic max); or null
-  // T32 (round 5): `gates` and `dgates` in the tiled layout of include/rl8_amd.h -- [b / 32][l][4][8][32 rows][32 units],
-  // so that the 32 rows x 128 bytes a wave moves per array and chunk are 4 KiB contiguous instead of 32 pieces at the
-  // sequence pitch -- and the dc scratch, which only this kernel reads, as [b / 32][8][32][32].  b a multiple of 32.
-  int tiled;
 };
 
 typedef float f32x16v __attribute__((ext_vector_type(16)));
@@ -193,16 +189,10 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
     const int64_t left = tile < tiles ? a.b - (tile * kLrRows + 32 * wave) : 0;
     return (int)(left < 0 ? 0 : left > 32 ? 32 : left);
   };
-  const bool tiled = a.tiled != 0;
   auto seq_rsrc = [&](const float *base, int64_t tile, int t, int per_row, int rows) {
     const int64_t r0 = tile * kLrRows + 32 * wave;
     return buffer_rsrc(rows > 0 ? base + (r0 * l + t) * (int64_t)per_row : base,
                        rows > 0 ? (uint32_t)(((rows - 1) * l + 1) * per_row * 4) : 0u);
-  };
-  // the wave's 32 sequences at step t of a T32 array: one block of 32 x per_row floats
-  auto tile_rsrc = [&](const float *base, int64_t tile, int t, int per_row, int rows) {
-    const int64_t t32 = tile * (kLrRows / 32) + wave;
-    return buffer_rsrc(rows > 0 ? base + (t32 * l + t) * (int64_t)(32 * per_row) : base, rows > 0 ? (uint32_t)(32 * per_row * 4) : 0u);
   };
   auto state_rsrc = [&](const float *base, int64_t tile, int rows) {
     const int64_t r0 = tile * kLrRows + 32 * wave;
@@ -211,7 +201,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   auto load_desc = [&](int64_t tile, int t) {
     const int rows = (kLrDiag & 2) ? 0 : wave_rows(tile);
     LrLoadDesc d;
-    d.gates = tiled ? tile_rsrc(a.gates, tile, t, 4 * kHidden, rows) : seq_rsrc(a.gates, tile, t, 4 * kHidden, rows);
+    d.gates = seq_rsrc(a.gates, tile, t, 4 * kHidden, rows);
     d.cs = seq_rsrc(a.cs, tile, t, kHidden, rows);
     d.dhs = seq_rsrc(a.dhs, tile, t, HEADS ? kLrHeads : kHidden, rows);
     d.cprev = t > 0 ? seq_rsrc(a.cs, tile, t - 1, kHidden, rows) : state_rsrc(a.c0, tile, rows);
@@ -222,8 +212,8 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   auto store_desc = [&](int64_t tile, int t) {
     const int rows = (kLrDiag & 1) ? 0 : wave_rows(tile);
     LrStoreDesc d;
-    d.dgates = tiled ? tile_rsrc(a.dgates, tile, t, 4 * kHidden, rows) : seq_rsrc(a.dgates, tile, t, 4 * kHidden, rows);
-    d.dcout = state_rsrc(a.dc, tile, rows);  // (T32: the same 32 KiB of the scratch, laid out [8][32][32])
+    d.dgates = seq_rsrc(a.dgates, tile, t, 4 * kHidden, rows);
+    d.dcout = state_rsrc(a.dc, tile, rows);
     return d;
   };
   auto at = [](const u32x4 (&v)[4], int e) { return __uint_as_float(v[e >> 2][e & 3]); };
@@ -255,24 +245,21 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   for (int j = 0; j < 4; ++j)
     park_at[j] = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + n * 128 + (((2 * j + hh) ^ ((n >> 1) & 7)) * 16);
   const unsigned park_line = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + lane * 16;  // the instruction view
-  // row pitch, distance between a row's chunks and between its gates, per array (bytes)
-  const int pitch_gates = tiled ? 128 : l * (4 * kHidden * 4), chunk_gates = tiled ? 4096 : 128, gate_gates = tiled ? 8 * 4096 : kHidden * 4;
-  const int pitch_dc = tiled ? 128 : kHidden * 4, chunk_dc = tiled ? 4096 : 128;
-  const int pitch_seq = l * (kHidden * 4);
+  const int pitch_gates = l * (4 * kHidden * 4), pitch_seq = l * (kHidden * 4), pitch_state = kHidden * 4;
   // (each in parts, so that a gate-step can spread them between its MFMA groups: a direct-to-LDS load costs the wave
   // ~75 cycles at issue, and issued in one run at the head of a step those were 19 % of its time with the pipe idle)
   auto issue_b = [&](const LrLoadDesc &d, int c, int part = -1) {
-    if (part != 1) park4(0, 0, d.gates, pitch_gates, c * chunk_gates);
-    if (part != 0) park4(0, 1, d.gates, pitch_gates, c * chunk_gates + 2 * gate_gates);
+    if (part != 1) park4(0, 0, d.gates, pitch_gates, c * 128);
+    if (part != 0) park4(0, 1, d.gates, pitch_gates, c * 128 + 2 * (kHidden * 4));
   };
   auto issue_c = [&](const LrLoadDesc &d, int c, int part = -1) {
-    if (part != 1) park4(1, 0, d.gates, pitch_gates, c * chunk_gates + 1 * gate_gates);
+    if (part != 1) park4(1, 0, d.gates, pitch_gates, c * 128 + 1 * (kHidden * 4));
     if (part != 0) park4(1, 1, d.cprev, d.cp_pitch, c * 128);
   };
   const __amdgpu_buffer_rsrc_t hwrsrc = buffer_rsrc(HEADS ? a.heads_w : nullptr, HEADS ? kLrHeads * kHidden * 4 : 0);
   auto issue_a = [&](const LrLoadDesc &d, int c, int part = -1) {  // parts 0, 1, 2: six, six (HEADS: four) and four of the sixteen
     if (part < 0 || part == 0) {
-      park4(0, 0, d.gates, pitch_gates, c * chunk_gates + 3 * gate_gates);
+      park4(0, 0, d.gates, pitch_gates, c * 128 + 3 * (kHidden * 4));
       park4(0, 1, d.cs, pitch_seq, c * 128, 0, 2);
     }
     if (part < 0 || part == 1) {
@@ -289,7 +276,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
         park4(1, 0, d.dhs, pitch_seq, c * 128);
       }
     }
-    if (part < 0 || part == 2) park4(1, 1, d.dcin, pitch_dc, c * chunk_dc);
+    if (part < 0 || part == 2) park4(1, 1, d.dcin, pitch_state, c * 128);
   };
   // array AR of park PARK into this lane's registers (its sixteen units); the wait for the loads is the caller's
   auto unpark = [&](auto park_tag, auto ar_tag, u32x4 (&x)[4]) {
@@ -393,7 +380,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
     }
     fold_max(lmax);
     repark(Z0{}, Z0{}, dg[0]);
-    store_park(Z0{}, Z0{}, sd.dgates, pitch_gates, c * chunk_gates + 3 * gate_gates);
+    store_park(Z0{}, Z0{}, sd.dgates, pitch_gates, c * 128 + 3 * (kHidden * 4));
   };
   auto math_b = [&](const LrStoreDesc &sd, int c) {  // -> dg[1] (i), dg[2] (g)
     u32x4 lb_i[4], lb_g[4];
@@ -413,8 +400,8 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
     fold_max(lmax);
     repark(Z0{}, Z0{}, dg[1]);
     repark(Z0{}, Z1{}, dg[2]);
-    store_park(Z0{}, Z0{}, sd.dgates, pitch_gates, c * chunk_gates);
-    store_park(Z0{}, Z1{}, sd.dgates, pitch_gates, c * chunk_gates + 2 * gate_gates);
+    store_park(Z0{}, Z0{}, sd.dgates, pitch_gates, c * 128);
+    store_park(Z0{}, Z1{}, sd.dgates, pitch_gates, c * 128 + 2 * (kHidden * 4));
   };
   auto math_c = [&](const LrStoreDesc &sd, int c) {  // -> dg[3] (f), dc out
     u32x4 lc_f[4], lc_cp[4];
@@ -435,8 +422,8 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
     fold_max(lmax);
     repark(Z1{}, Z0{}, dg[3]);
     repark(Z1{}, Z1{}, dc_out);
-    store_park(Z1{}, Z0{}, sd.dgates, pitch_gates, c * chunk_gates + 1 * gate_gates);
-    store_park(Z1{}, Z1{}, sd.dcout, pitch_dc, c * chunk_dc);
+    store_park(Z1{}, Z0{}, sd.dgates, pitch_gates, c * 128 + 1 * (kHidden * 4));
+    store_park(Z1{}, Z1{}, sd.dcout, pitch_state, c * 128);
   };
 
   // one gate-step: 16 k of the product, W_hh^T planes from ring slot K & 3, B planes from dg[K >> 1][8 (K & 1) ..+7].
@@ -661,9 +648,9 @@ RL8_API int rl8_lstm_rows_backward_pack(const float *w_hh, void *packed, void *s
 
 static int rows_backward(int64_t b, int l, const float *c0, const float *gates, const float *cs, const float *dhs,
                          const float *heads_w, const void *packed, float *dgates, float *dc_scratch, uint32_t *dg_bound_out,
-                         int tiled, void *stream) {
+                         void *stream) {
   if (!c0 || !gates || !cs || !dhs || !packed || !dgates || !dc_scratch) return RL8_ENULL;
-  if (b <= 0 || l <= 0 || (tiled && (b & 31))) return RL8_ESIZE;
+  if (b <= 0 || l <= 0) return RL8_ESIZE;
   // a wave addresses its 32 sequences with 32-bit offsets
   if ((int64_t)32 * l * 4 * kHidden * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
   if (!aligned16(packed) || !aligned16(c0) || !aligned16(gates) || !aligned16(cs) || !aligned16(dhs) || !aligned16(dgates) ||
@@ -680,7 +667,7 @@ static int rows_backward(int64_t b, int l, const float *c0, const float *gates, 
   if (const char *v = getenv("RL8_LR_STAMP_PTR")) stamps = reinterpret_cast<unsigned long long *>(strtoull(v, nullptr, 0));
 #endif
   if (dg_bound_out && hipMemsetAsync(dg_bound_out, 0, 4, (hipStream_t)stream) != hipSuccess) return launch_status();
-  const LrArgs args = {c0, gates, cs, dhs, heads_w, dgates, dc_scratch, b, l, stamps, dg_bound_out, tiled != 0};
+  const LrArgs args = {c0, gates, cs, dhs, heads_w, dgates, dc_scratch, b, l, stamps, dg_bound_out};
   if (heads_w) lstm_rows_backward_heads_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
   else lstm_rows_backward_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
   return launch_status();
@@ -688,15 +675,15 @@ static int rows_backward(int64_t b, int l, const float *c0, const float *gates, 
 
 RL8_API int rl8_lstm_rows_backward_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs, const float *dhs,
                                        const void *packed, float *dgates, float *dc_scratch, uint32_t *dg_bound_out,
-                                       int tiled, void *stream) {
-  return rows_backward(b, l, c0, gates, cs, dhs, nullptr, packed, dgates, dc_scratch, dg_bound_out, tiled, stream);
+                                       void *stream) {
+  return rows_backward(b, l, c0, gates, cs, dhs, nullptr, packed, dgates, dc_scratch, dg_bound_out, stream);
 }
 
 // The same with dL/dh_t = heads_dout[b][l][0..3] x heads_w [4][256] formed inside (both zero-padded to four heads): the
 // output heads' data gradient is never written to memory nor read back.
 RL8_API int rl8_lstm_rows_backward_heads_f32(int64_t b, int l, const float *c0, const float *gates, const float *cs,
                                              const float *heads_dout, const float *heads_w, const void *packed, float *dgates,
-                                             float *dc_scratch, uint32_t *dg_bound_out, int tiled, void *stream) {
+                                             float *dc_scratch, uint32_t *dg_bound_out, void *stream) {
   if (!heads_w) return RL8_ENULL;
-  return rows_backward(b, l, c0, gates, cs, heads_dout, heads_w, packed, dgates, dc_scratch, dg_bound_out, tiled, stream);
+  return rows_backward(b, l, c0, gates, cs, heads_dout, heads_w, packed, dgates, dc_scratch, dg_bound_out, stream);
 }

@@ -168,10 +168,6 @@ struct LstmStepArgs {
   float *gates;         // [B][gates_pitch] -> [4][256] post-activation i, f, g, o; or null
   void *planes_out;     // h_t as fp16 planes for the NEXT step (rl8_lstm_split_state's layout); or null
   int64_t x_pitch, c_prev_pitch, h_out_pitch, c_out_pitch, gates_pitch;
-  // > 0: `gates` is the T32 layout of include/rl8_amd.h for sequences of this many steps, already advanced to this
-  // launch's step -- row r, gate q, unit u at ((((r >> 5) * L) * 4 + q) * 8 + (u >> 5)) * 1024 + (r & 31) * 32 + (u & 31)
-  // floats behind it: a wave's 32 rows x 32 units of one gate are 4 KiB contiguous instead of 32 pieces of 128 bytes
-  int gates_tiled_l;
 };
 
 constexpr int kLsHPitch = 32 * 4 + 16;                                  // h scratch of the plane emission: [64 rows][144 B] per wave
@@ -318,22 +314,15 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
         buffer_rsrc(args.h_out + r0 * args.h_out_pitch, (uint32_t)(((rows - 1) * args.h_out_pitch + kHidden) * 4));
     const __amdgpu_buffer_rsrc_t cors =
         buffer_rsrc(args.c_out + r0 * args.c_out_pitch, (uint32_t)(((rows - 1) * args.c_out_pitch + kHidden) * 4));
-    const bool gates_tiled = SAVE && args.gates_tiled_l > 0;  // (rows is then a multiple of 32)
-    const int g_tile = args.gates_tiled_l * (4 * 8 * 4096);   // bytes from a tile of 32 rows to the next, at one step
-    const __amdgpu_buffer_rsrc_t grsrc =
-        gates_tiled ? buffer_rsrc(args.gates + (r0 >> 5) * (int64_t)args.gates_tiled_l * (4 * 8 * 1024),
-                                  (uint32_t)(((rows >> 5) - 1) * g_tile + 4 * 8 * 4096))
-                    : buffer_rsrc(SAVE ? args.gates + r0 * args.gates_pitch : nullptr,
-                                  (uint32_t)(((rows - 1) * args.gates_pitch + 4 * kHidden) * 4));
+    const __amdgpu_buffer_rsrc_t grsrc = buffer_rsrc(
+        SAVE ? args.gates + r0 * args.gates_pitch : nullptr, (uint32_t)(((rows - 1) * args.gates_pitch + 4 * kHidden) * 4));
     // row pitches in bytes (scalar); per array the lane part (unit column + this lane's
     // 64 wr + 4 hh rows) is ONE vector offset, the rest of the row index is scalar
     const int cp4 = (int)args.c_prev_pitch * 4, hp4 = (int)args.h_out_pitch * 4, co4 = (int)args.c_out_pitch * 4,
               gp4 = (int)args.gates_pitch * 4;
     const int lane_rows = 64 * wr + 4 * hhe;
-    const int v_cp = col4 + lane_rows * cp4, v_h = col4 + lane_rows * hp4, v_co = col4 + lane_rows * co4;
-    // gates: row 64 wr + 32 mt + (8 rg + e) + 4 hh, unit 64 ub + 32 wc + l32 -> [tile 2 wr + mt][gate][chunk 2 ub + wc][row][unit]
-    const int v_g = gates_tiled ? 2 * wr * g_tile + (2 * ub + wc) * 4096 + 4 * hhe * 128 + l32e * 4 : col4 + lane_rows * gp4;
-    const int g_gate = gates_tiled ? 8 * 4096 : kHidden * 4;
+    const int v_cp = col4 + lane_rows * cp4, v_h = col4 + lane_rows * hp4, v_co = col4 + lane_rows * co4,
+              v_g = col4 + lane_rows * gp4;
     // c_{t-1} of all thirty-two (row, unit) pairs of this lane, requested up front: fetched
     // per group of four rows, their HBM round trip sat in front of every group (eight per
     // item, ~1.5 us each of a 50 us item)
@@ -401,11 +390,10 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
           buffer_store_f32(h, hrsrc, v_h, srow * hp4);
           buffer_store_f32(c, cors, v_co, srow * co4);
           if constexpr (SAVE) {
-            const int s_g = gates_tiled ? mt * g_tile + (8 * rg + e) * 128 : srow * gp4;
-            buffer_store_f32(gi, grsrc, v_g, s_g);
-            buffer_store_f32(gf, grsrc, v_g + g_gate, s_g);
-            buffer_store_f32(gg, grsrc, v_g + 2 * g_gate, s_g);
-            buffer_store_f32(go, grsrc, v_g + 3 * g_gate, s_g);
+            buffer_store_f32(gi, grsrc, v_g, srow * gp4);
+            buffer_store_f32(gf, grsrc, v_g + kHidden * 4, srow * gp4);
+            buffer_store_f32(gg, grsrc, v_g + 2 * kHidden * 4, srow * gp4);
+            buffer_store_f32(go, grsrc, v_g + 3 * kHidden * 4, srow * gp4);
           }
         }
       }
@@ -504,16 +492,14 @@ RL8_API int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, c
                                     const float *c_prev, int64_t c_prev_pitch, const void *w_planes,
                                     const float *wb, int64_t b, float *h_out, int64_t h_out_pitch, float *c_out,
                                     int64_t c_out_pitch, float *gates, int64_t gates_pitch, void *planes_out,
-                                    int gates_tiled_l, void *stream) {
+                                    void *stream) {
   if (!x || !h_planes || !c_prev || !w_planes || !wb || !h_out || !c_out) return RL8_ENULL;
   if (b <= 0 || !rl8_lstm_split_supports(d_in)) return RL8_ESIZE;
   if (x_pitch < d_in || c_prev_pitch < kHidden || h_out_pitch < kHidden || c_out_pitch < kHidden ||
-      (gates && !gates_tiled_l && gates_pitch < 4 * kHidden))
+      (gates && gates_pitch < 4 * kHidden))
     return RL8_ESIZE;
-  // T32 gates: whole tiles of 32 rows, a 128-row tile's four within 32-bit byte offsets
-  if (gates_tiled_l < 0 || (gates_tiled_l > 0 && (!gates || (b & 31) || !aligned16(gates) || gates_tiled_l >= 2048))) return RL8_ESIZE;
   // a tile's rows are addressed with 32-bit byte offsets
-  const int64_t widest = gates && !gates_tiled_l ? gates_pitch : (h_out_pitch > c_prev_pitch ? h_out_pitch : c_prev_pitch);
+  const int64_t widest = gates ? gates_pitch : (h_out_pitch > c_prev_pitch ? h_out_pitch : c_prev_pitch);
   if ((int64_t)kSplitRows * widest * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
   if (!aligned16(h_planes) || !aligned16(w_planes)) return RL8_EALIGN;
   const int64_t tiles = (b + kSplitRows - 1) / kSplitRows;
@@ -521,7 +507,7 @@ RL8_API int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, c
   const int grid = (int)(items < 2 * kCUs ? (items + 31) / 32 * 32 : 2 * kCUs);  // a multiple of 32: see the kernel's tile mapping
   if (planes_out && (!aligned16(planes_out) || planes_out == h_planes)) return RL8_EALIGN;
   const LstmStepArgs args = {x, c_prev, h_out, c_out, gates, planes_out, x_pitch, c_prev_pitch, h_out_pitch, c_out_pitch,
-                             gates_pitch, gates ? gates_tiled_l : 0};
+                             gates_pitch};
   hipStream_t s = (hipStream_t)stream;
   switch (d_in) {
     case 1: return launch_lstm_step<1>(grid, s, h_planes, w_planes, wb, b, args);

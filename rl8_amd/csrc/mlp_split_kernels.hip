@@ -124,10 +124,6 @@ struct WgradOperands {
   // share a number sit on one XCD (b mod 8) and walk the same rows at the same time, three of them out of L2.  Slabs and
   // column-sum rows are numbered gate-major (gate q: [q gridDim.x / 4, (q + 1) gridDim.x / 4)).  gridDim.x a multiple of 32.
   int groups = 1, group_dz_offset = 0;
-  // > 0 (the sixteen-wave fp16 kernel only): dZ in the T32 layout of include/rl8_amd.h for sequences of this many steps,
-  // `dz` advanced to the launch's step: row r, gate q, column u at ((((r >> 5) * L) * 4 + q) * 8 + (u >> 5)) * 1024 +
-  // (r & 31) * 32 + (u & 31) floats (group_dz_offset = 8 * 1024); m a multiple of 32
-  int dz_tiled_l = 0;
 };
 
 // (The fp16-plane form of this product -- both operands two planes, each scaled by a power of two per column of the
@@ -1677,16 +1673,11 @@ __global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_loadh16_kernel(
     const int64_t left = m - row0;
     const int rows = left <= 0 ? 0 : left < 4 ? (int)left : 4;
     const int64_t at = rows > 0 ? row0 : 0;
-    const bool tiled = ops.dz_tiled_l > 0;  // (four rows starting at a multiple of four: one tile of 32)
-    const __amdgpu_buffer_rsrc_t ar =
-        tiled ? buffer_rsrc(dzp + (at >> 5) * (int64_t)ops.dz_tiled_l * (4 * 8 * 1024), rows > 0 ? 8 * 4096 : 0)
-              : buffer_rsrc(dzp + at * ops.dz_pitch, rows > 0 ? ((rows - 1) * ops.dz_pitch + kHidden) * 4 : 0);
+    const __amdgpu_buffer_rsrc_t ar = buffer_rsrc(dzp + at * ops.dz_pitch, rows > 0 ? ((rows - 1) * ops.dz_pitch + kHidden) * 4 : 0);
     const __amdgpu_buffer_rsrc_t br = buffer_rsrc(ops.h + at * ops.h_pitch, rows > 0 ? ((rows - 1) * ops.h_pitch + kHidden) * 4 : 0);
-    const int a_lane = tiled ? (col >> 5) * 4096 + (col & 31) * 4 : col * 4;
-    const int a_row0 = tiled ? (int)(at & 31) * 128 : 0, a_pitch = tiled ? 128 : (int)ops.dz_pitch * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      r.a[e] = buffer_load_f32(ar, a_lane, a_row0 + e * a_pitch);
+      r.a[e] = buffer_load_f32(ar, col * 4, e * (ops.dz_pitch * 4));
       r.b[e] = buffer_load_f32(br, col * 4, e * (ops.h_pitch * 4));
     }
     const u32x4 rx = scalar_rsrc(want_colsums ? x + at * kIn : reinterpret_cast<const float *>(slabs), want_colsums ? rows * kIn * 4 : 0);
@@ -1852,10 +1843,9 @@ static int launch_wgrad_loadh16(int grid, hipStream_t s, const float *dz, const 
  * d_in in {1, 2, 3, 5}. */
 static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int64_t h_pitch, int64_t m, float *workspace,
                          float *dw_out, int accumulate, const float *x, int d_in, float *colsums, int *colsum_rows_out,
-                         const uint32_t *dz_bound, const uint32_t *h_bound, void *stream, int groups = 1, int dz_tiled_l = 0) {
+                         const uint32_t *dz_bound, const uint32_t *h_bound, void *stream, int groups = 1) {
   if (!dz || !h || !workspace || !dw_out) return RL8_ENULL;
-  if (m <= 0 || (!dz_tiled_l && dz_pitch < kHidden) || h_pitch < kHidden) return RL8_ESIZE;
-  if (dz_tiled_l < 0 || (dz_tiled_l > 0 && (!dz_bound || groups != 4 || (m & 31) || !aligned16(dz)))) return RL8_ESIZE;
+  if (m <= 0 || dz_pitch < kHidden || h_pitch < kHidden) return RL8_ESIZE;
   if ((int64_t)kWsChunk * (dz_pitch > h_pitch ? dz_pitch : h_pitch) * 4 >= (int64_t)1 << 31) return RL8_ESIZE;
   if (!aligned16(workspace) || !aligned16(dw_out)) return RL8_EALIGN;
   if (colsums) {
@@ -1876,17 +1866,15 @@ static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int6
     if (at == 0) first_grid = grid;
     if (grid > first_grid) grid = first_grid;  // (later segments add to the first one's rows)
     const WgradOperands ops{h + at * h_pitch, (int)dz_pitch, (int)h_pitch, colsums, at > 0, dz_bound, h_bound,
-                            groups, groups == 4 ? (dz_tiled_l ? 8 * 1024 : kHidden) : 0, dz_tiled_l};
-    // (a segment starts at a multiple of 2^23 rows: whole tiles of 32)
-    const float *dz_at = dz_tiled_l ? dz + (at >> 5) * (int64_t)dz_tiled_l * (4 * 8 * 1024) : dz + at * dz_pitch;
+                            groups, groups == 4 ? kHidden : 0};
     const float *xs = colsums ? x + at * d_in : nullptr;
     int status;
     if (dz_bound) {  // fp16 planes behind the caller's bound: the sixteen-wave kernel
       switch (colsums ? d_in : 1) {
-        case 1: status = launch_wgrad_loadh16<1>(grid, s, dz_at, xs, rows, workspace, ops); break;
-        case 2: status = launch_wgrad_loadh16<2>(grid, s, dz_at, xs, rows, workspace, ops); break;
-        case 3: status = launch_wgrad_loadh16<3>(grid, s, dz_at, xs, rows, workspace, ops); break;
-        default: status = launch_wgrad_loadh16<5>(grid, s, dz_at, xs, rows, workspace, ops); break;
+        case 1: status = launch_wgrad_loadh16<1>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 2: status = launch_wgrad_loadh16<2>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 3: status = launch_wgrad_loadh16<3>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        default: status = launch_wgrad_loadh16<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
       }
     } else {  // no bound: the exact bf16 planes
       switch (colsums ? d_in : 1) {
@@ -1936,11 +1924,11 @@ RL8_API int rl8_mlp_wgrad_f16_strided_f32(const float *dz, int64_t dz_pitch, con
 RL8_API int rl8_lstm_wgrad_f16_f32(const float *dz, int64_t dz_pitch, const uint32_t *dz_bound, const float *h,
                                    int64_t h_pitch, const uint32_t *h_bound, int64_t m, float *workspace, float *dw_out,
                                    int accumulate, const float *x, int d_in, float *colsums, int *colsum_rows_out,
-                                   int dz_tiled_l, void *stream) {
+                                   void *stream) {
   if (!dz_bound || !h_bound) return RL8_ENULL;
-  if (!dz_tiled_l && dz_pitch < 4 * kHidden) return RL8_ESIZE;
+  if (dz_pitch < 4 * kHidden) return RL8_ESIZE;
   return wgrad_strided(dz, dz_pitch, h, h_pitch, m, workspace, dw_out, accumulate, x, d_in, colsums, colsum_rows_out, dz_bound,
-                       h_bound, stream, 4, dz_tiled_l);
+                       h_bound, stream, 4);
 }
 
 // Grids of the two halves of the fused backward (both derive them from m alone,

@@ -137,13 +137,13 @@ SIGNATURES: dict[str, list[Any]] = {
     "rl8_lstm_pack_split": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "rl8_lstm_split_state": [_vp, _i64, _i64, _vp, _vp],
     "rl8_lstm_split_state_bound": [_vp, _i64, _i64, _vp, _vp, _vp],
-    "rl8_lstm_step_split_f32": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp],
+    "rl8_lstm_step_split_f32": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
     "rl8_lstm_rows_backward_pack_bytes": [],
     "rl8_lstm_rows_backward_pack": [_vp, _vp, _vp],
-    "rl8_lstm_rows_backward_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
-    "rl8_lstm_rows_backward_heads_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
+    "rl8_lstm_rows_backward_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rl8_lstm_rows_backward_heads_f32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "rl8_mlp_wgrad_f16_strided_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
-    "rl8_lstm_wgrad_f16_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _i32, _vp],
+    "rl8_lstm_wgrad_f16_f32": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, C.POINTER(C.c_int), _vp],
     "rl8_lstm_backward_partial_floats": [_i32],
     "rl8_lstm_backward_max_rows": [],
     "rl8_lstm_backward_f32": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _vp],
@@ -177,7 +177,7 @@ SIGNATURES: dict[str, list[Any]] = {
 
 
 #: RL8_ABI_VERSION of include/rl8_amd.h this binding is written against (checked against the library in ``load``).
-ABI_VERSION = 106
+ABI_VERSION = 105
 
 
 def library_path() -> str:
@@ -1352,38 +1352,16 @@ def lstm_split_state(h: torch.Tensor, *, out: None | torch.Tensor = None,
     return out
 
 
-def lstm_tiled_ok(b: int, l: int) -> bool:
-    """Whether the T32 layout of the saved gates / gate gradients (include/rl8_amd.h) applies: whole tiles of 32
-    sequences (and enough of them for the four-gates-per-launch weight gradient)."""
-    return b % 32 == 0 and b >= 128 and 1 <= l < 2048
-
-
-def lstm_untile(t: torch.Tensor, b: int, l: int) -> torch.Tensor:
-    """T32 ``[b / 32, l, 4, 8, 32, 32]`` -> ``[b, l, 4, 256]`` (a copy; tests and diagnostics)."""
-    return t.view(b // 32, l, 4, 8, 32, 32).permute(0, 4, 1, 2, 3, 5).reshape(b, l, 4, LSTM_HIDDEN)
-
-
-def lstm_tile(t: torch.Tensor) -> torch.Tensor:
-    """``[b, l, 4, 256]`` -> its T32 layout ``[b / 32, l, 4, 8, 32, 32]`` (a copy; tests and diagnostics)."""
-    b, l = t.shape[:2]
-    return t.view(b // 32, 32, l, 4, 8, 32).permute(0, 2, 3, 4, 1, 5).contiguous()
-
-
 def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, packed: torch.Tensor, wb: torch.Tensor,
                        *, save: bool = False, planes: None | torch.Tensor = None,
-                       h0_bound_out: None | torch.Tensor = None, h0_planes: None | torch.Tensor = None,
-                       tiled: bool = False):
+                       h0_bound_out: None | torch.Tensor = None, h0_planes: None | torch.Tensor = None):
     """As :func:`lstm_forward` on the fp16-plane step kernel: one state split + one step
     launch per timestep. Same outputs and saved layouts (``gates`` [B, L, 4, 256], ``cs``).
     ``h0_bound_out`` (one float32 element): receives max |h0|, which the state split sees
     anyway (:func:`lstm_backward`'s ``h0_bound``). ``h0_planes``: the planes of ``h0`` from an
-    earlier :func:`lstm_split_state` (read only; no split is made here). ``tiled`` (with ``save``): ``gates`` comes
-    back in the T32 layout ``[B / 32, L, 4, 8, 32, 32]`` (:func:`lstm_tiled_ok`) that :func:`lstm_rows_backward` and
-    the weight gradient read 4 KiB at a time."""
+    earlier :func:`lstm_split_state` (read only; no split is made here)."""
     x = _dense(x.detach(), torch.float32, "x")
     b, l, d_in = x.shape
-    if tiled and not (save and lstm_tiled_ok(b, l)):
-        raise ValueError("lstm_forward_split: tiled needs save=True and lstm_tiled_ok(b, l)")
     for name, t in (("h0", h0), ("c0", c0)):
         _dense(t, torch.float32, name)
         if tuple(t.shape) != (b, LSTM_HIDDEN):
@@ -1392,8 +1370,7 @@ def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, pack
     lib = load()
     hs = torch.empty(b, l, LSTM_HIDDEN, dtype=torch.float32, device=dev)
     cs = torch.empty(b, l, LSTM_HIDDEN, dtype=torch.float32, device=dev)
-    gates = (torch.empty((b // 32, l, 4, 8, 32, 32) if tiled else (b, l, 4, LSTM_HIDDEN), dtype=torch.float32, device=dev)
-             if save else None)
+    gates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev) if save else None
     if planes is None:
         planes = lstm_state_planes(b, dev, copies=2 if l > 1 else 1)
     # two plane buffers: a step reads h_{t-1}'s planes from one and leaves h_t's in the other
@@ -1417,8 +1394,8 @@ def lstm_forward_split(x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, pack
         with _timed("lstm_step_save" if save else "lstm_step", b):
             _check(lib.rl8_lstm_step_split_f32(
                 xp + t * d_in * 4, l * d_in, d_in, p_in, c_prev, c_pitch, _ptr(packed), _ptr(wb), b,
-                hsp + t * H * 4, l * H, csp + t * H * 4, l * H, (gp + t * 4 * H * 32 * 4 if tiled else gp + t * 4 * H * 4) if save else None,
-                l * 4 * H, p_out, l if tiled else 0, stream), "rl8_lstm_step_split_f32")
+                hsp + t * H * 4, l * H, csp + t * H * 4, l * H, (gp + t * 4 * H * 4) if save else None, l * 4 * H,
+                p_out, stream), "rl8_lstm_step_split_f32")
     hn, cn = hs[:, l - 1], cs[:, l - 1]
     return hs, hn, cn, gates, (cs if save else None)
 
@@ -1449,18 +1426,14 @@ ROWS_BACKWARD_HEADS = 4  # head outputs rl8_lstm_rows_backward_heads_f32 takes
 
 def lstm_rows_backward(c0: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor, dhs: None | torch.Tensor,
                        packed: torch.Tensor, *, with_bound: bool = False,
-                       heads: None | tuple[torch.Tensor, torch.Tensor] = None, tiled: bool = False):
+                       heads: None | tuple[torch.Tensor, torch.Tensor] = None):
     """dgates [B, L, 4, 256] from what the forward saved and dhs [B, L, 256]: the
     backward through time with the recurrent product on bf16 planes. ``with_bound``:
     also a one-element device tensor holding max |dgates| (what the fp16-plane weight
     gradient scales its first operand by). ``heads`` = (dout [B * L, n], w [n, 256]),
-    n <= 4, instead of ``dhs`` (None): dL/dh_t = dout x w is formed inside the kernel. ``tiled``: ``gates`` is the
-    T32 array of :func:`lstm_forward_split` (``tiled=True``) and ``dgates`` comes back in the same layout."""
-    b, l = cs.shape[0], cs.shape[1]
-    if tiled and not lstm_tiled_ok(b, l):
-        raise ValueError("lstm_rows_backward: tiled needs lstm_tiled_ok(b, l)")
-    gshape = (b // 32, l, 4, 8, 32, 32) if tiled else (b, l, 4, LSTM_HIDDEN)
-    checks = [("c0", c0, (b, LSTM_HIDDEN)), ("gates", gates, gshape), ("cs", cs, (b, l, LSTM_HIDDEN))]
+    n <= 4, instead of ``dhs`` (None): dL/dh_t = dout x w is formed inside the kernel."""
+    b, l = gates.shape[0], gates.shape[1]
+    checks = [("c0", c0, (b, LSTM_HIDDEN)), ("gates", gates, (b, l, 4, LSTM_HIDDEN)), ("cs", cs, (b, l, LSTM_HIDDEN))]
     if heads is None:
         checks.append(("dhs", dhs, (b, l, LSTM_HIDDEN)))
     elif dhs is not None:
@@ -1470,7 +1443,7 @@ def lstm_rows_backward(c0: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor, 
         if tuple(t.shape) != shape:
             raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
     dev = gates.device
-    dgates = torch.empty(gshape, dtype=torch.float32, device=dev)
+    dgates = torch.empty(b, l, 4, LSTM_HIDDEN, dtype=torch.float32, device=dev)
     dc = torch.empty(b, LSTM_HIDDEN, dtype=torch.float32, device=dev)
     bound = torch.empty(1, dtype=torch.float32, device=dev) if with_bound else None
     if heads is not None:
@@ -1485,19 +1458,13 @@ def lstm_rows_backward(c0: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor, 
         w4[:n] = w.detach()
         with _timed("lstm_rows_backward", b * l):
             _check(load().rl8_lstm_rows_backward_heads_f32(b, l, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dout4), _ptr(w4),
-                                                           _ptr(packed), _ptr(dgates), _ptr(dc), _ptr(bound), int(tiled), _stream()),
+                                                           _ptr(packed), _ptr(dgates), _ptr(dc), _ptr(bound), _stream()),
                    "rl8_lstm_rows_backward_heads_f32")
         return (dgates, bound) if with_bound else dgates
     with _timed("lstm_rows_backward", b * l):
         _check(load().rl8_lstm_rows_backward_f32(b, l, _ptr(c0), _ptr(gates), _ptr(cs), _ptr(dhs), _ptr(packed),
-                                                 _ptr(dgates), _ptr(dc), _ptr(bound), int(tiled), _stream()), "rl8_lstm_rows_backward_f32")
+                                                 _ptr(dgates), _ptr(dc), _ptr(bound), _stream()), "rl8_lstm_rows_backward_f32")
     return (dgates, bound) if with_bound else dgates
-
-
-def lstm_wgrad_fused_gates_ok(b: int) -> bool:
-    """The weight gradient of a timestep runs its four gates in one launch (h read once)."""
-    return (b >= 128 and os.environ.get("RL8_AMD_LSTM_WGRAD_PLANES", "f16") != "bf16"
-            and os.environ.get("RL8_AMD_LSTM_WGRAD_GATES", "fused") != "separate")
 
 
 #: column-sum partial rows of the fused LSTM weight gradient, per (device, stream, L, d_in)
@@ -1508,7 +1475,7 @@ def lstm_backward(
     x: torch.Tensor, h0: torch.Tensor, c0: torch.Tensor, hs: torch.Tensor, gates: torch.Tensor, cs: torch.Tensor,
     dhs: None | torch.Tensor, whht_packed: None | torch.Tensor, *, split: None | bool = None,
     rows_packed: None | torch.Tensor = None, h0_bound: None | torch.Tensor = None,
-    heads: None | tuple[torch.Tensor, torch.Tensor] = None, hs_bound: None | float = None, tiled: bool = False,
+    heads: None | tuple[torch.Tensor, torch.Tensor] = None, hs_bound: None | float = None,
 ) -> dict[str, torch.Tensor]:
     """Parameter gradients of the LSTM given ``dhs`` [B, L, 256] (gradient of every
     ``h_t``) and what ``lstm_forward(..., save=True)`` returned. Returns ``w_ih``,
@@ -1524,18 +1491,13 @@ def lstm_backward(
     ``heads`` (with ``rows_packed``, ``dhs`` None): see :func:`lstm_rows_backward`.
     ``hs_bound``: a number >= max |hs| the caller vouches for -- 1.0 when ``hs`` is this LSTM's own output
     (|o * tanh(c)| < 1), which is what ``nn.fused_lstm`` passes; None: taken from ``hs`` here (one reduction over it).
-    The fp16 planes of the weight gradient are scaled by it: a value above the bound would overflow them.
-    ``tiled``: ``gates`` is :func:`lstm_forward_split`'s T32 array; the gate gradients then stay in that layout between
-    the backward through time and the weight gradient (``rows_packed``, fp16 planes, four gates per launch only)."""
+    The fp16 planes of the weight gradient are scaled by it: a value above the bound would overflow them."""
     x = _dense(x.detach(), torch.float32, "x")
     b, l, d_in = x.shape
-    if tiled and not (rows_packed is not None and lstm_tiled_ok(b, l) and lstm_wgrad_fused_gates_ok(b)):
-        raise ValueError("lstm_backward: tiled needs rows_packed, lstm_tiled_ok(b, l) and the four-gates weight gradient")
     if heads is not None and (rows_packed is None or dhs is not None):
         raise ValueError("lstm_backward: heads needs rows_packed and no dhs")
     for name, t, shape in (("h0", h0, (b, LSTM_HIDDEN)), ("c0", c0, (b, LSTM_HIDDEN)), ("hs", hs, (b, l, LSTM_HIDDEN)),
-                           ("gates", gates, (b // 32, l, 4, 8, 32, 32) if tiled else (b, l, 4, LSTM_HIDDEN)),
-                           ("cs", cs, (b, l, LSTM_HIDDEN)),
+                           ("gates", gates, (b, l, 4, LSTM_HIDDEN)), ("cs", cs, (b, l, LSTM_HIDDEN)),
                            *([("dhs", dhs, (b, l, LSTM_HIDDEN))] if heads is None else [])):
         _dense(t, torch.float32, name)
         if tuple(t.shape) != shape:
@@ -1555,7 +1517,7 @@ def lstm_backward(
     if rows_packed is not None:
         if not fused_colsums:
             raise ValueError("rows_packed needs the bf16-plane weight gradient (split) and a compiled input width")
-        dgates, dg_bound = lstm_rows_backward(c0, gates, cs, dhs, rows_packed, with_bound=True, heads=heads, tiled=tiled)
+        dgates, dg_bound = lstm_rows_backward(c0, gates, cs, dhs, rows_packed, with_bound=True, heads=heads)
     else:
         dgates = torch.empty(b, l, 4, H, dtype=torch.float32, device=dev)
         if not fused_colsums:
@@ -1580,7 +1542,7 @@ def lstm_backward(
         crow = C.c_int(0)
         # with the backward kernel's bound on |dG| the products run on fp16 planes (three instead of six): dG scaled by
         # one power of two for the tensor, h_{t-1} by one from max |h0| (t = 0) or 1 (an LSTM's own outputs)
-        f16 = dg_bound is not None and (tiled or os.environ.get("RL8_AMD_LSTM_WGRAD_PLANES", "f16") != "bf16")
+        f16 = dg_bound is not None and os.environ.get("RL8_AMD_LSTM_WGRAD_PLANES", "f16") != "bf16"
         if f16:
             if h0_bound is None:
                 h0_bound = torch.linalg.vector_norm(h0, ord=float("inf")).reshape(1)
@@ -1590,7 +1552,7 @@ def lstm_backward(
                 one = torch.linalg.vector_norm(hs, ord=float("inf")).reshape(1) if l > 1 else torch.ones(1, dtype=torch.float32, device=dev)
             else:
                 one = torch.full((1,), float(hs_bound), dtype=torch.float32, device=dev)
-        if f16 and (tiled or lstm_wgrad_fused_gates_ok(b)):
+        if f16 and b >= 128 and os.environ.get("RL8_AMD_LSTM_WGRAD_GATES", "fused") != "separate":
             # the four gates of a timestep in one launch: h_{t-1} comes out of HBM once instead of four times
             gkey = (dev.index or 0, _stream() or 0, l, d_in, "gates")
             gcols = _lstm_colsum_ws.get(gkey)                     # [step][gate][workgroup of the gate][...]
@@ -1600,9 +1562,8 @@ def lstm_backward(
                 for t in range(l):
                     h_prev, h_pitch = (h0p, H) if t == 0 else (hsp + (t - 1) * H * 4, l * H)
                     _check(lib.rl8_lstm_wgrad_f16_f32(
-                        dgp + (t * 4 * H * 32 * 4 if tiled else t * 4 * H * 4), l * 4 * H, _ptr(dg_bound), h_prev, h_pitch,
-                        _ptr(h0_bound if t == 0 else one), b, wsp, dwp, int(t > 0), _ptr(xt[t]), d_in, _ptr(gcols[t]),
-                        C.byref(crow), l if tiled else 0, stream), "rl8_lstm_wgrad_f16_f32")
+                        dgp + t * 4 * H * 4, l * 4 * H, _ptr(dg_bound), h_prev, h_pitch, _ptr(h0_bound if t == 0 else one), b,
+                        wsp, dwp, int(t > 0), _ptr(xt[t]), d_in, _ptr(gcols[t]), C.byref(crow), stream), "rl8_lstm_wgrad_f16_f32")
             # (a step's rows sit gate-major, crow.value per gate -- 64 at the sizes that fill the chip)
             width = H * (d_in + 1)
             sums = gcols.view(l, -1)[:, : 4 * crow.value * width].reshape(l, 4, crow.value, width).sum(dim=(0, 2))

@@ -105,15 +105,6 @@ def clear_state_cache() -> None:
     _h0_cache.clear()
 
 
-#: Saved gates / gate gradients in the T32 layout (include/rl8_amd.h: 4 KiB contiguous per wave, gate and 32-unit chunk)
-#: whenever the pass qualifies; False keeps the row-major arrays (A/B runs, diagnostics).
-TILED_SAVED = True
-
-
-def _tiled(b: int, l: int) -> bool:
-    return bool(TILED_SAVED and BACKWARD_ROWS and hip.lstm_tiled_ok(b, l) and hip.lstm_wgrad_fused_gates_ok(b))
-
-
 class _FusedLSTM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, lstm, grad_mode):  # type: ignore[override]
@@ -122,12 +113,9 @@ class _FusedLSTM(torch.autograd.Function):
             packed, wb = _packs(lstm, "split")
             # max |h0| for the backward's fp16-plane weight gradient comes out of the state split
             planes0, bound = _h0_planes(h0) if need_grad else (None, None)
-            ctx.tiled = need_grad and _tiled(x.shape[0], x.shape[1])
-            hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=need_grad, h0_planes=planes0,
-                                                          tiled=ctx.tiled)
+            hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=need_grad, h0_planes=planes0)
         else:
             bound = None
-            ctx.tiled = False
             hs, _, cn, gates, cs = hip.lstm_forward(x, h0, c0, _packs(lstm, False), save=need_grad)
         ctx.set_materialize_grads(False)
         if need_grad:
@@ -147,8 +135,7 @@ class _FusedLSTM(torch.autograd.Function):
         dhs = dhs.contiguous().float()
         if use_split(ctx.lstm) and BACKWARD_ROWS:
             g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, split=True, rows_packed=_packs(ctx.lstm, "rows"),
-                                  h0_bound=ctx.h0_bound, hs_bound=1.0,  # (hs: this LSTM's own outputs, |o tanh c| < 1)
-                                  tiled=ctx.tiled)
+                                  h0_bound=ctx.h0_bound, hs_bound=1.0)  # (hs: this LSTM's own outputs, |o tanh c| < 1)
         else:
             g = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, _packs(ctx.lstm, True), split=use_split(ctx.lstm))
         return None, None, None, g["w_ih"], g["w_hh"], g["b"], g["b"], None, None
@@ -192,8 +179,7 @@ class _FusedLSTMHeads(torch.autograd.Function):
     def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, w_heads, b_heads, lstm):  # type: ignore[override]
         packed, wb = _packs(lstm, "split")
         planes0, bound = _h0_planes(h0)
-        ctx.tiled = _tiled(x.shape[0], x.shape[1])
-        hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=True, h0_planes=planes0, tiled=ctx.tiled)
+        hs, _, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=True, h0_planes=planes0)
         out = hip.linear_heads_forward(hs.view(-1, hip.LSTM_HIDDEN), w_heads, b_heads)
         ctx.set_materialize_grads(False)
         ctx.lstm, ctx.h0_bound = lstm, bound
@@ -208,7 +194,7 @@ class _FusedLSTMHeads(torch.autograd.Function):
         if dout is None:
             dout = torch.zeros(flat.shape[0], w_heads.shape[0], dtype=torch.float32, device=flat.device)
         dout = dout.contiguous().float()
-        common = dict(split=True, rows_packed=_packs(ctx.lstm, "rows"), h0_bound=ctx.h0_bound, hs_bound=1.0, tiled=ctx.tiled)
+        common = dict(split=True, rows_packed=_packs(ctx.lstm, "rows"), h0_bound=ctx.h0_bound, hs_bound=1.0)
         if dhs is None:  # nothing but the heads reads the latents: the usual case
             _, dw, db = hip.linear_heads_backward(flat, dout, w_heads, need_dh=False)
             g = hip.lstm_backward(x, h0, c0, hs, gates, cs, None, None, heads=(dout, w_heads), **common)

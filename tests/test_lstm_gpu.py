@@ -481,90 +481,3 @@ def test_rollout_step_with_the_heads_inside_is_the_three_launches(n, with_noise,
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert int(a["action"].min()) >= 0 and int(a["action"].max()) <= 1
-
-
-@pytest.mark.parametrize("b,l,d", [(128, 4, 1), (160, 1, 2), (4128, 7, 5), (33024, 4, 1)])
-def test_tiled_saved_gates_are_the_row_major_ones_rearranged(b, l, d):
-    """Round 5: the T32 layout of the saved gates and gate gradients (include/rl8_amd.h: a wave's
-    32 rows x 32 units of one gate 4 KiB contiguous) is a layout, not an algorithm: the training forward writes the same
-    numbers, the backward through time reads them and writes the same dG, the weight gradient sums the same rows in the
-    same order -- everything bit for bit what the row-major arrays give (torch.nn.LSTM of
-    src/rl8/models/_recurrent.py:201-321 under src/rl8/algorithms/_recurrent.py's loss.backward())."""
-    assert hip.lstm_tiled_ok(b, l)
-    g = torch.Generator(device=DEV).manual_seed(b + 10 * l + d)
-    lstm = torch.nn.LSTM(d, 256, batch_first=True).to(DEV)
-    with torch.no_grad():
-        for p in lstm.parameters():
-            p.copy_(torch.randn(p.shape, device=DEV, generator=g) * 0.2)
-    x = torch.randn(b, l, d, device=DEV, generator=g) * 2
-    h0 = torch.randn(b, 256, device=DEV, generator=g) * 0.5
-    c0 = torch.randn(b, 256, device=DEV, generator=g)
-    packed, wb = hip.lstm_pack_split(lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
-    hs, hn, cn, gates, cs = hip.lstm_forward_split(x, h0, c0, packed, wb, save=True)
-    hs_t, hn_t, cn_t, gates_t, cs_t = hip.lstm_forward_split(x, h0, c0, packed, wb, save=True, tiled=True)
-    assert tuple(gates_t.shape) == (b // 32, l, 4, 8, 32, 32)
-    assert torch.equal(hs, hs_t) and torch.equal(cs, cs_t) and torch.equal(cn, cn_t)
-    assert torch.equal(gates_t, hip.lstm_tile(gates)) and torch.equal(hip.lstm_untile(gates_t, b, l), gates)
-    # backward through time, both forms
-    rows = hip.lstm_rows_backward_pack(lstm.weight_hh_l0)
-    dhs = (torch.rand(b, l, 256, device=DEV, generator=g) * 2 - 1) * torch.exp(-8 * torch.rand(b, 1, 1, device=DEV, generator=g)) * 1e-3
-    dg, bound = hip.lstm_rows_backward(c0, gates, cs, dhs, rows, with_bound=True)
-    dg_t, bound_t = hip.lstm_rows_backward(c0, gates_t, cs, dhs, rows, with_bound=True, tiled=True)
-    assert torch.equal(hip.lstm_untile(dg_t, b, l), dg) and torch.equal(bound, bound_t)
-    n = 3
-    dout = (torch.rand(b * l, n, device=DEV, generator=g) * 2 - 1) * 1e-3
-    w = (torch.rand(n, 256, device=DEV, generator=g) * 2 - 1) / 16
-    dgh = hip.lstm_rows_backward(c0, gates, cs, None, rows, heads=(dout, w))
-    dgh_t = hip.lstm_rows_backward(c0, gates_t, cs, None, rows, heads=(dout, w), tiled=True)
-    assert torch.equal(hip.lstm_untile(dgh_t, b, l), dgh)
-    # the whole parameter gradient
-    common = dict(split=True, rows_packed=rows, hs_bound=1.0)
-    want = hip.lstm_backward(x, h0, c0, hs, gates, cs, dhs, None, **common)
-    got = hip.lstm_backward(x, h0, c0, hs, gates_t, cs, dhs, None, tiled=True, **common)
-    for k in want:
-        assert torch.equal(got[k], want[k]), k
-    got_h = hip.lstm_backward(x, h0, c0, hs, gates_t, cs, None, None, heads=(dout, w), tiled=True, **common)
-    want_h = hip.lstm_backward(x, h0, c0, hs, gates, cs, None, None, heads=(dout, w), **common)
-    for k in want_h:
-        assert torch.equal(got_h[k], want_h[k]), k
-
-
-def test_tiled_layout_is_refused_where_it_does_not_apply():
-    assert not hip.lstm_tiled_ok(100, 4) and not hip.lstm_tiled_ok(96, 4) and hip.lstm_tiled_ok(128, 1)
-    x = torch.zeros(100, 2, 1, device=DEV)
-    z = torch.zeros(100, 256, device=DEV)
-    lstm = torch.nn.LSTM(1, 256, batch_first=True).to(DEV)
-    packed, wb = hip.lstm_pack_split(lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
-    with pytest.raises(ValueError, match="tiled"):
-        hip.lstm_forward_split(x, z, z, packed, wb, save=True, tiled=True)
-    lib = hip.load()
-    # the C layer too: B not a multiple of 32
-    assert lib.rl8_lstm_rows_backward_f32(100, 2, hip._ptr(z), hip._ptr(z), hip._ptr(z), hip._ptr(z), hip._ptr(packed), hip._ptr(z),
-                                          hip._ptr(z), None, 1, None) == -2
-
-
-def test_recurrent_step_is_the_same_with_and_without_the_tiled_layout():
-    """End to end: a recurrent collect() + step() with the T32 arrays (the default) lands on the update the row-major
-    arrays give, bit for bit."""
-    from rl8_amd import RecurrentAlgorithmConfig
-    from rl8_amd.env import DiscreteDummyEnv
-    from rl8_amd.nn import fused_lstm
-
-    def run(tiled):
-        fused_lstm.TILED_SAVED = tiled
-        try:
-            torch.manual_seed(21)
-            algo = RecurrentAlgorithmConfig(num_envs=64, horizon=32).build(DiscreteDummyEnv)
-            out = []
-            for _ in range(2):
-                algo.collect()
-                out.append(algo.step())
-            return out, torch.cat([p.detach().flatten() for p in algo.policy.model.parameters()])
-        finally:
-            fused_lstm.TILED_SAVED = True
-
-    (a, pa), (b_, pb) = run(True), run(False)
-    for s0, s1 in zip(a, b_):
-        for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
-            assert s0[k] == s1[k], k
-    assert torch.equal(pa, pb)

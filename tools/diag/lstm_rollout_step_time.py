@@ -26,7 +26,7 @@ hip.lstm_split_state(h0, out=planes)
 def step(t):
     p_in, p_out = hip._ptr(planes) + (t & 1) * half, hip._ptr(planes) + ((t + 1) & 1) * half
     hip._check(lib.rl8_lstm_step_split_f32(hip._ptr(x), d, d, p_in, hip._ptr(c0), 256, hip._ptr(packed), hip._ptr(wb), b,
-                                           hip._ptr(hs), 256, hip._ptr(cs), 256, None, 0, p_out, 0, hip._stream()), "step")
+                                           hip._ptr(hs), 256, hip._ptr(cs), 256, None, 0, p_out, hip._stream()), "step")
 
 
 for t in range(10):
