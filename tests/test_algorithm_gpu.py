@@ -361,7 +361,7 @@ def learning_curve_ends(env_cls, iterations, monkeypatch, **config):
 def assert_same_learning(ends, gain):
     """Every run improves by `gain`; the two plane schemes end within seed noise of each other (the
     fp16 planes must not change what is learned).  A run is chaotic in its last digits -- any difference in arithmetic
-    moves a 40-iteration curve by as much as another seed does (tools/diag/pendulum_plane_schemes.py: eight seeds,
+    moves a 40-iteration curve by as much as another seed does (a round-4 diagnostic, profiles/r04_experiments.md: eight seeds,
     -366 +- 55 against -356 +- 64) -- so the comparison is of the two MEANS against their standard errors."""
     for (planes, seed), (first, last) in ends.items():
         assert last > first + gain * abs(first), (planes, seed, first, last)

@@ -309,7 +309,7 @@ def test_gate_mode_data_gradient(m, d_in, n_out, case):
     want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0), "w2": dz2.T @ a1, "b2": dz2.sum(0), "w3": d.T @ a2}
     # the yardstick of dW1 / db1: the sum of the magnitudes of ALL terms, those of the inner products
     # dH1[s][i] = sum_k dZ2[s][k] W2[k][i] included (an inner product that cancels is not the kernel's error;
-    # tools/diag/gate_dgrad_inner_error.py measures the three kernels on it: 1.3e-7 gate, 2.4e-7 general, 3.4e-7 bf16)
+    # profiles/r02_gate_dgrad_inner_error.txt has the three kernels on it: 1.3e-7 gate, 2.4e-7 general, 3.4e-7 bf16)
     inner = (dz2.abs() @ p["w2"].double().abs()) * (a1 > 0)
     size = {"w1": inner.T @ x.double().abs(), "b1": inner.sum(0)}
     w2t = hip.mlp_pack_w2_f16(p["w2"], transposed=True)
@@ -412,7 +412,7 @@ def test_guard_picks_the_planes_of_the_gate_bits_weight_gradient_from_the_data(c
     rows that dwarf all others) the sums are formed on the exact bf16 planes -- bit for bit what
     RL8_WGRAD_GATE_PLANES=bf16 gives -- otherwise on the two fp16 planes, bit for bit the unguarded kernel; no host
     round trip either way, and the lifetime counters say which way it went.  A long TAIL of small rows (PPO's
-    converged policies: a fifth of the rows 2^-12 below the largest, tools/diag/wgrad_planes_real_ppo.py) does not
+    converged policies: a fifth of the rows 2^-12 below the largest, profiles/r04_wgrad_planes_real_ppo.json) does not
     trip it: the wide low plane keeps 22 bits of a term down to 2^-27 of its column's bound.  Entry by entry against
     fp64, relative to the entry's own sum of |terms|: what the guard lets through stays within 3x the exact planes'
     error + 2e-7."""
