@@ -352,8 +352,13 @@ int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *
  * observations and never read it.  save_gate2 (optional) [M][8] words receives the ReLU gate of
  * layer 2, bit j of row s = (h2[s][j] > 0): the data-gradient kernels need only that bit of h2
  * (32 B per row instead of 1 KiB), and it may be given WITHOUT save_h2 (rank-one heads: see
- * rl8_mlp_wgrad_gate_bits_f32).  Widths: d_in 1, 2, 3, 5 x n_out 1..3 (rl8_mlp_forward_f16_supports),
- * else RL8_ESIZE -- other widths run rl8_mlp_tower_forward_f32.  (The bf16-plane forward / data-gradient
+ * rl8_mlp_wgrad_gate_bits_f32).  Widths (round 5): any d_in <= 8 and n_out <= 8 (rl8_mlp_forward_f16_supports) -- the
+ * kernels are compiled for width CLASSES d_in {1, 2, 3, 5, 8} x n_out {1, 2, 4, 8} and a class serves every run-time
+ * width it holds (layer-1 records zero past d_in, observations past d_in not loaded, output rows past n_out zero and
+ * not stored) -- else RL8_ESIZE: wider towers run rl8_mlp_tower_forward_f32.  The plane BACKWARD entries below are
+ * compiled per width, d_in 1..5 x n_out 1..4 (rl8_mlp_backward_f16_supports): their observations and dOut arrive through
+ * scalar loads of rows with a compile-time stride; a tower inside the forward's envelope but outside theirs is trained
+ * through the fp32-MFMA data gradient + bf16-plane weight gradient (save_h1 given).  (The bf16-plane forward / data-gradient
  * entries of rounds 1-2, rl8_mlp_tower_{forward,backward}_split_f32, were removed in round 3.)
  * w2_f16 (rl8_mlp_f16_packed_bytes() bytes:
  * two fp16 planes in fragment order + {scale, 1/scale}) comes from

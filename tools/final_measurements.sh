@@ -6,7 +6,7 @@
 # be judged are copied into profiles/ by hand afterwards.
 #   gpurun --timeout 1200 -- 'tools/final_measurements.sh r02'
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r02}
+TAG=${1:-r05}
 cd "$R"
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gputests.log 2>&1; tail -2 gpurun_out/${TAG}_gputests.log
@@ -25,6 +25,9 @@ timeout -k 10 500 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_ou
 timeout -k 10 300 python bench.py --env cartpole --num-envs 262144 --horizon 128 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg3.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --env continuous --distribution squashed --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg4.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --recurrent --num-envs 8192 --horizon 256 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg5.json 2>/dev/null || exit 1
+# configs[4] at its stated size on ONE device (2 x 17.2 GB of LSTM states in the buffer)
+timeout -k 10 400 python bench.py --recurrent --num-envs 65536 --horizon 256 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg5_full.json 2>/dev/null || echo "full-size recurrent line failed"
+timeout -k 10 300 python tools/diag/tower_width_sweep.py --reps 20 > gpurun_out/${TAG}_tower_width_sweep.txt 2>&1 || echo "width sweep failed"
 timeout -k 10 300 python bench.py --env mountain_car --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_mountain_car.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --env pendulum --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_pendulum.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --minibatches 8 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_minibatches8.json 2>/dev/null || echo "minibatch bench failed"
@@ -37,7 +40,7 @@ timeout -k 10 300 python bench.py --gpus 4 --backend gloo --single-device --num-
 # opt-in prototype lines (never the headline): towers of a scalar observation from piecewise-linear tables
 timeout -k 10 300 python bench.py --towers piecewise --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_b_piecewise_optin.json 2>/dev/null || echo "piecewise line failed"
 timeout -k 10 300 python bench.py --towers piecewise --env continuous --distribution squashed --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg4_piecewise_optin.json 2>/dev/null || echo "piecewise cfg4 line failed"
-for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_cfg5_minibatches4 b_mountain_car b_pendulum b_minibatches8 b_2rank_rehearsal b_4rank_rehearsal b_piecewise_optin b_cfg4_piecewise_optin; do python -c "
+for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_cfg5_full b_cfg5_minibatches4 b_mountain_car b_pendulum b_minibatches8 b_2rank_rehearsal b_4rank_rehearsal b_piecewise_optin b_cfg4_piecewise_optin; do python -c "
 import json; d=json.loads(open('gpurun_out/${TAG}_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value']), round(d['ms_per_step'],1), round(d['collect_ms_per_step'],1), round(d['update_ms_per_step'],1))"; done
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 echo done
