@@ -796,7 +796,8 @@ def run(args: argparse.Namespace) -> None:
             "scaling": args.scaling,
             "world_size": world,
             "backend": backend,
-            "collectives_per_step": algo.shards.collectives / max(args.steps + args.warmup, 1),
+            "collectives_per_step": algo.shards.collectives / max(args.steps + args.warmup
+                                                                   + (args.uninstrumented_steps if plain_elapsed else 0), 1),
             "vs_baseline": None,
             "dtype": "f32",
             "gemm": sorted({k["gemm"] for k in kernels.values() if k["bound"] == "mfma"}),

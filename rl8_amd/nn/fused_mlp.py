@@ -297,6 +297,9 @@ class RolloutRecord:
         """End of a ``step()``: give the h2 slabs back (and refuse new ones) when the device is short of memory --
         activations and workspaces allocated by ``step()`` come after the slabs and must not be what runs out.  Returns
         the bytes released."""
+        if not any(tr.h2 is not None for tr in self.towers.values()):
+            return 0  # (nothing to give back: no driver query -- hipMemGetInfo costs ~100 ms per call when several
+            #            processes share the device, as the multi-rank rehearsals on one GPU do)
         free, _ = torch.cuda.mem_get_info(device)
         if free >= RECORD_H2_KEEP_FREE_BYTES:
             return 0

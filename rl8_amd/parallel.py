@@ -82,23 +82,28 @@ class EnvShards:
                 t.copy_(buf)
         return t
 
-    def combine_rollout_stats(self, raw: torch.Tensor) -> torch.Tensor:
-        """12 raw stats of this shard -> 12 raw stats of the global rollout."""
+    def combine_rollout_stats(self, raw: torch.Tensor):
+        """12 raw stats of this shard -> 12 raw stats of the global rollout (the input itself when not sharded, else a
+        host array: both answer ``.tolist()``)."""
         if not self.active:
             return raw
         src, staged = self._staged(raw.contiguous().reshape(-1))
         flat = torch.empty(self.world_size * raw.numel(), dtype=raw.dtype, device=src.device)
         dist.all_gather_into_tensor(flat, src, group=self.group)
         self.collectives += 1
-        # The caller reads the twelve numbers on the host next (``raw.tolist()``: the one sync of collect()), so the
-        # combination runs THERE on the gathered [world, 12] block -- sums, minima, maxima picked per column by two
-        # masks -- and launches nothing on the device (round 4: three list-indexed gathers + scatters, ~10 launches).
-        gathered = flat.view(self.world_size, raw.numel()).cpu()
-        is_min = torch.zeros(raw.numel(), dtype=torch.bool)
-        is_min[list(STAT_MIN)] = True
-        is_max = torch.zeros(raw.numel(), dtype=torch.bool)
-        is_max[list(STAT_MAX)] = True
-        return torch.where(is_min, gathered.min(0).values, torch.where(is_max, gathered.max(0).values, gathered.sum(0)))
+        # The caller reads the twelve numbers on the host next (``.tolist()``: the one sync of collect()), so the
+        # combination runs THERE on the gathered [world, 12] block -- sums, minima, maxima picked per column -- and
+        # launches nothing on the device (round 4: three list-indexed gathers + scatters, ~10 launches).  In numpy, not
+        # in torch: a rank's first torch CPU operator brings up torch's intra-op thread pool, whose workers then compete
+        # with the rank's own launch thread -- measured on a 16-core share with two ranks per GPU: 74 instead of 161 M
+        # transitions/s (profiles/r05_experiments.md).
+        import numpy as np
+
+        gathered = flat.view(self.world_size, raw.numel()).cpu().numpy()
+        out = gathered.sum(0)
+        out[list(STAT_MIN)] = gathered[:, list(STAT_MIN)].min(0)
+        out[list(STAT_MAX)] = gathered[:, list(STAT_MAX)].max(0)
+        return out  # (a numpy array: ``.tolist()`` as the tensor it replaces)
 
     def sum_gradients_(self, params: Iterable[torch.nn.Parameter], sums: Sequence[torch.Tensor] = ()) -> None:
         """ONE SUM all-reduce per optimizer step: the flattened gradient of ``params``
