@@ -81,7 +81,8 @@ struct WgradFusedArgs {
 };
 
 // Words of the 64 behind the slabs of the weight-gradient workspace: [0 .. 3] max |dOut column|, [4 .. 8] max |x column|
-// (wgrad_bounds_kernel), then the guard's sample sums, its ticket and its decision -- all zeroed per call -- and two
+// (wgrad_bounds_kernel), then the guard's sample sums, its ticket, its decision, the entries it found at the maximum and
+// the NaNs it saw (words 10 .. 16) -- the first 32 words are zeroed per call -- and two
 // counters that only ever grow (calls that consulted the guard, calls it sent to the bf16 planes), zeroed by whoever
 // allocates the workspace if they are to be read.
 constexpr int kGuardSum = 8 + 2 /* two words: a uint64, 8-byte aligned */, kGuardNonzero = 12, kGuardTicket = 13, kGuardFlag = 14;
@@ -1462,7 +1463,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_bounds_kernel(const float *__res
 template <int NOUT>
 static uint32_t *launch_wgrad_bounds(hipStream_t s, const float *dout, const float *x, int64_t m, int d_in, float *workspace) {
   uint32_t *bounds = reinterpret_cast<uint32_t *>(workspace + (int64_t)kCUs * kHidden * kHidden);
-  if (hipMemsetAsync(bounds, 0, 64, s) != hipSuccess) return nullptr;
+  if (hipMemsetAsync(bounds, 0, 128, s) != hipSuccess) return nullptr;  // words 0 .. 31; the lifetime counters sit at 32, 33
   const int64_t want = m / (4 * kBlock);
   const int grid = (int)(want < 1 ? 1 : want > 4 * kCUs ? 4 * kCUs : want);  // (one atomic per block and column: 12 ns each)
   if (d_in == 1) wgrad_bounds_kernel<1, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
@@ -1474,11 +1475,16 @@ static uint32_t *launch_wgrad_bounds(hipStream_t s, const float *dout, const flo
   return bounds;
 }
 
-// The guard of the fp16 planes: over a sample of dOut (one KiB in every sixteen, every entry of it) count the non-zero
-// entries and add up |entry| / max as 24-bit fractions (max: the call's largest, bounds[0 .. 3], complete when this kernel
-// starts); the last workgroup to arrive turns the sums into the call's flag and bumps the two lifetime counters.
+// The guard of the fp16 planes: over a sample of dOut (one KiB in every `every`, every entry of it; every = 1 -- all of it
+// -- for calls of up to 2^20 floats, 16 beyond) count the non-zero entries and add up |entry| / max as 24-bit fractions
+// (max: the call's largest, bounds[0 .. 3], complete when this kernel starts); the last workgroup to arrive turns the
+// sums into the call's flag and bumps the two lifetime counters.  Entries AT the maximum are counted apart and left out
+// of both sums (with the maximum inside a small sample its own 2^24 kept "count * 2^12 > sum" from ever
+// holding: what is asked is how far the OTHER entries sit below it); a NaN anywhere in the sample sends the call to the
+// exact planes.
+constexpr int kGuardTop = 15, kGuardNan = 16;  // words of the workspace tail: entries at the maximum, NaNs seen
 __global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restrict__ dout, int64_t floats,
-                                                            uint32_t *__restrict__ bounds) {
+                                                            uint32_t *__restrict__ bounds, int every) {
   float top = 0.0f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) top = __builtin_fmaxf(top, __uint_as_float(bounds[q]));
@@ -1486,11 +1492,12 @@ __global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restr
   const float inv = top > 0.0f ? 1.0f / top : 0.0f;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kWave, waves = (int64_t)gridDim.x * (kBlock / kWave);
-  constexpr int64_t kPiece = 256, kEvery = 16;  // floats per sampled piece (a wave's 64 x 16 bytes), one piece in sixteen
+  constexpr int64_t kPiece = 256;  // floats per sampled piece (a wave's 64 x 16 bytes)
+  const int64_t kEvery = every;
   const int64_t pieces = (floats + kPiece * kEvery - 1) / (kPiece * kEvery);
   const bool vec = ((uintptr_t)dout & 15) == 0;
   unsigned long long sum = 0;
-  unsigned nonzero = 0;
+  unsigned nonzero = 0, at_top = 0, nans = 0;
   for (int64_t p = wave; p < pieces; p += waves) {
     const int64_t at = p * kPiece * kEvery + 4 * lane;
     float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1506,8 +1513,12 @@ __global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float a = __builtin_fabsf(v[i]);
-      nonzero += a > 0.0f;
-      const float frac = a > 0.0f ? __builtin_fminf(a * inv, 1.0f) * 16777216.0f : 0.0f;  // (NaN: fminf -> 1)
+      nans += a != a;
+      const bool top_entry = a > 0.0f && a >= top;  // (NaN: every comparison false -- counted above, in no sum)
+      at_top += top_entry;
+      const bool counted = a > 0.0f && !top_entry;
+      nonzero += counted;
+      const float frac = counted ? __builtin_fminf(a * inv, 1.0f) * 16777216.0f : 0.0f;
       sum += (unsigned long long)(unsigned)frac;
     }
   }
@@ -1515,25 +1526,33 @@ __global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restr
   for (int off = kWave / 2; off > 0; off >>= 1) {
     sum += __shfl_down(sum, off, kWave);
     nonzero += __shfl_down(nonzero, off, kWave);
+    at_top += __shfl_down(at_top, off, kWave);
+    nans += __shfl_down(nans, off, kWave);
   }
   __shared__ unsigned long long red_sum[kBlock / kWave];
-  __shared__ unsigned red_nz[kBlock / kWave];
+  __shared__ unsigned red_nz[kBlock / kWave], red_top[kBlock / kWave], red_nan[kBlock / kWave];
   __shared__ bool last;
   if (lane == 0) {
     red_sum[threadIdx.x / kWave] = sum;
     red_nz[threadIdx.x / kWave] = nonzero;
+    red_top[threadIdx.x / kWave] = at_top;
+    red_nan[threadIdx.x / kWave] = nans;
   }
   __syncthreads();
   unsigned long long *total = reinterpret_cast<unsigned long long *>(bounds + kGuardSum);
   if (threadIdx.x == 0) {
     unsigned long long a = 0;
-    unsigned b = 0;
+    unsigned b = 0, c = 0, d = 0;
     for (int w = 0; w < kBlock / kWave; ++w) {
       a += red_sum[w];
       b += red_nz[w];
+      c += red_top[w];
+      d += red_nan[w];
     }
     if (a) atomicAdd(total, a);
     if (b) atomicAdd(bounds + kGuardNonzero, b);
+    if (c) atomicAdd(bounds + kGuardTop, c);
+    if (d) atomicAdd(bounds + kGuardNan, d);
     __threadfence();
     last = atomicAdd(bounds + kGuardTicket, 1u) == gridDim.x - 1;
   }
@@ -1542,8 +1561,10 @@ __global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restr
     __threadfence();
     const unsigned long long a = __hip_atomic_load(total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long b = __hip_atomic_load(bounds + kGuardNonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // max / mean > 2^kGuardRatio  <=>  count * 2^24 > 2^kGuardRatio * sum of the 24-bit fractions
-    const unsigned fire = (b << (24 - kGuardRatio)) > a ? 1u : 0u;
+    const unsigned nan_seen = __hip_atomic_load(bounds + kGuardNan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // max / mean of the entries below the maximum > 2^kGuardRatio  <=>  count * 2^24 > 2^kGuardRatio * sum of their
+    // 24-bit fractions (no entry below the maximum in the sample: nothing to lose, fp16 planes); NaN: the exact planes
+    const unsigned fire = (nan_seen != 0u || (b << (24 - kGuardRatio)) > a) ? 1u : 0u;
     bounds[kGuardFlag] = fire;
     bounds[kGuardCalls] += 1u;
     bounds[kGuardFires] += fire;
@@ -1563,10 +1584,11 @@ static PlaneMode plane_mode(const char *name) {
 
 // the guard's decision for the call whose bounds were just requested (same stream, behind wgrad_bounds_kernel)
 static int launch_wgrad_tail(hipStream_t s, const float *dout, int64_t floats, uint32_t *bounds) {
-  const int64_t pieces = (floats + 4095) / 4096;
+  const int every = floats <= ((int64_t)1 << 20) ? 1 : 16;  // small calls (minibatches, tests): every entry
+  const int64_t pieces = (floats + 256 * every - 1) / (256 * every);
   const int64_t want = (pieces + (kBlock / kWave) - 1) / (kBlock / kWave);
   const int grid = (int)(want < 1 ? 1 : want > 2 * kCUs ? 2 * kCUs : want);
-  wgrad_tail_kernel<<<grid, kBlock, 0, s>>>(dout, floats, bounds);
+  wgrad_tail_kernel<<<grid, kBlock, 0, s>>>(dout, floats, bounds, every);
   return launch_status();
 }
 

@@ -405,7 +405,10 @@ def test_rank_one_backward_from_the_gate_bits_alone(m, d_in, n_out, x_scale):
 
 @pytest.mark.parametrize("n_out", [1, 2])
 @pytest.mark.parametrize("case,fires", [("plain", False), ("clipped_rows", False), ("rows_of_mixed_magnitude", False),
-                                         ("one_outlier_row", True), ("many_small_rows", False), ("two_populations", True)])
+                                         ("one_outlier_row", True), ("many_small_rows", False), ("two_populations", True),
+                                         # round 5: calls small enough to be sampled whole -- the maximum is
+                                         # then IN the sample, and must not count towards the mean it is compared with
+                                         ("small_outlier", True), ("small_plain", False), ("small_all_equal", False)])
 def test_guard_picks_the_planes_of_the_gate_bits_weight_gradient_from_the_data(case, fires, n_out, monkeypatch):
     """rl8_mlp_wgrad_gate_bits_f32 (the headline's weight gradient) under its guard: the call's dOut is sampled on the
     device; when its largest entry stands more than 2^12 above the mean of the non-zero ones (one outlier row; a few
@@ -416,12 +419,16 @@ def test_guard_picks_the_planes_of_the_gate_bits_weight_gradient_from_the_data(c
     trip it: the wide low plane keeps 22 bits of a term down to 2^-27 of its column's bound.  Entry by entry against
     fp64, relative to the entry's own sum of |terms|: what the guard lets through stays within 3x the exact planes'
     error + 2e-7."""
-    m, d_in = 150_000, 1
+    m, d_in = (3000 if case.startswith("small") else 150_000), 1
     g = torch.Generator(device=DEV).manual_seed(3 + n_out)
     x = torch.randn(m, d_in, device=DEV, generator=g) * 40
     p = _params(g, d_in, n_out)
     g0 = torch.randn(m, device=DEV, generator=g) / m
-    if case == "clipped_rows":
+    if case == "small_outlier":
+        g0[m // 3] *= 1e6
+    elif case == "small_all_equal":
+        g0 = torch.full((m,), 1.0 / m, device=DEV) * torch.sign(g0)
+    elif case == "clipped_rows":
         g0[torch.rand(m, device=DEV, generator=g) < 0.7] = 0.0
     elif case == "rows_of_mixed_magnitude":
         g0 *= 10.0 ** torch.randint(-4, 3, (m,), device=DEV, generator=g).float()
@@ -926,3 +933,23 @@ def test_algorithm_agrees_between_the_tower_generations(planes):
             assert c_split[k] == pytest.approx(c_f32[k], rel=1e-6, abs=1e-6), k
     for k in ("losses/policy", "losses/vf", "losses/total"):
         assert s_split[k] == pytest.approx(s_f32[k], rel=1e-5, abs=1e-5), k
+
+
+def test_guard_sends_a_call_with_a_nan_to_the_exact_planes():
+    """a NaN in dOut is not a "small entry" -- it used to be skipped by the guard's sample (every comparison
+    with NaN is false).  The call now goes to the exact bf16 planes, and the NaN reaches the gradients as it would
+    through torch's own backward."""
+    m, d_in, n_out = 2048, 1, 1
+    g = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 3
+    p = _params(g, d_in, n_out)
+    dout = torch.randn(m, n_out, device=DEV, generator=g) / m
+    dout[m // 2, 0] = float("nan")
+    w2p, w2t = hip.mlp_pack_w2_f16(p["w2"]), hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+    _, _, _, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True, save_gate=True)
+    before = hip.wgrad_guard_counts()
+    out = hip.mlp_tower_backward(x, None, None, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate,
+                                 gate_pack=lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"]), w2=p["w2"], b2=p["b2"])
+    calls, fires = (a - b for a, b in zip(hip.wgrad_guard_counts(), before))
+    assert (calls, fires) == (1, 1)
+    assert bool(torch.isnan(out["w2"]).any()) and bool(torch.isnan(out["b3"]).any())
