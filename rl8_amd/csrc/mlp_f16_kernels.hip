@@ -512,6 +512,9 @@ namespace rl8 {
 int mlp_rows_backward_gate_dispatch(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                     int64_t m, int d_in, const void *w2ts, int n_out, float *partials, int stride, int head_rows,
                                     const uint32_t *gate2);
+int mlp_rows_backward_general_dispatch(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
+                                       int64_t m, int d_in, const void *w2ts, const float *w3, int n_out, float *partials, int stride,
+                                       int head_rows, const uint32_t *gate2);
 int mlp_rows_forward_dispatch(hipStream_t s, const float *x, int64_t m, int d_in, const float *w1, const float *b1,
                               const void *w2s, const float *b2, const float *w3, const float *b3, int n_out, float *out,
                               float *h1, float *h2, uint32_t *gate);
@@ -566,6 +569,11 @@ RL8_API int rl8_mlp_tower_backward_f16_f32(const float *x, const float *w1, cons
   *partial_rows_out = grid > g2 ? grid : g2;
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
+  if (!env_int("RL8_MLP_DGRAD_GENERAL_TILE")) {  // (diagnostics: 1 = the tile kernel for every width; read per call)
+    // d_in <= 3, n_out 2..4: the rows-per-wave kernel (mlp_rows_kernels.hip, round 5)
+    const int st = mlp_rows_backward_general_dispatch(grid, s, x, w1, b1, dout, m, d_in, w2t_f16, w3, n_out, partials, stride, g2, gate2);
+    if (st != -1) return st;
+  }
   int status = RL8_ESIZE;
 #define RL8_BACKWARD_F16(D, N) \
   if (d_in == D && n_out == N) status = launch_backward_f16<D, N>(grid, s, x, w1, b1, dout, m, w2t_f16, w3, partials, stride, g2, gate2);

@@ -1056,6 +1056,490 @@ int mlp_rows_backward_gate_dispatch(int grid, hipStream_t s, const float *x, con
   return -1;
 }
 
+// ---- data gradient of GENERAL heads in the same structure (round 5) ------------------------
+// dZ2[s][k] = G[s][k] * sum_o dOut[s][o] W3[o][k] has no rank-one form, so the A operand is what the forward's is: TWO
+// fp16 planes, here of dZ2 scaled by a power of two per row (bound: sum_o |dOut[s][o]| max_k |W3[o][k]|), produced by the
+// wave in fragment layout one element per slot -- the forward's producer with W3's column k as the "layer-1 record"
+// ([256][KOUT] floats in LDS), the row's dOut as its observations, no bias, and the gate BIT of h2 where the forward has
+// the ReLU -- and three plane products per fragment pair against the planes of W2^T (rl8_mlp_pack_w2_f16, transposed).
+// Everything else is the gate-mode kernel above: the product is not transposed, B arrives in the 32x32x16 unit order of
+// the shared pack, the wave's gate block comes by one direct-to-LDS load per tile, row factors and observations go
+// through the per-wave exchange, running column sums [256][db1 | dW1 row] per wave in LDS.  d_in <= 3 (the sums' LDS);
+// n_out <= KOUT in {2, 4} at run time (rows of W3 past n_out are zero records, dOut past n_out reads as zero).
+constexpr int rows_dgrad_general_lds_bytes(int ring, int k_in, int k_out) {
+  return rows_dgrad_lds_bytes(ring, k_in) + k_out * kHidden * 4;
+}
+
+template <int DIN, int KOUT, int RING>
+__global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
+    const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+    const float *__restrict__ dout, int64_t m, const void *__restrict__ w2ts, const float *__restrict__ w3,
+    float *__restrict__ partials, int partial_stride, int head_rows, const uint32_t *__restrict__ gate2, int n_out) {
+  constexpr int kIn = DIN, d_in = DIN;
+  constexpr int kTile = 128;
+  constexpr int kAhead = RING - 1;
+  constexpr int kRec = rows_record(DIN);
+  static_assert(DIN >= 1 && DIN <= 3, "wider observations keep the tile kernel (LDS: running sums per wave)");
+  static_assert(KOUT == 2 || KOUT == 4, "W3 records of 8 or 16 bytes");
+  static_assert(rows_dgrad_general_lds_bytes(RING, kIn, KOUT) <= 80 * 1024, "two workgroups per CU");
+  static_assert(kAhead >= 2, "the mid-step barrier publishes a chunk requested at least a half-step earlier");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [ring][layer-1 records [256][kRec]][W3 records [256][KOUT]][per wave: gate block | factors [32] | observations [DIN][32] | sums [256][kRec]]
+  const unsigned lds0 = lds_offset(smem);
+  constexpr int kRecOff = RING * kRowsChunk;
+  constexpr int kW3Off = kRecOff + kRec * kHidden * 4;
+  constexpr int kWaveOff = kW3Off + KOUT * kHidden * 4;
+  constexpr int kWaveBytes = 1024 + 32 * (1 + kIn) * 4 + kRec * kHidden * 4;
+  constexpr int kFacOff = 1024, kObsOff = kFacOff + 32 * 4, kSumOff = kObsOff + 32 * kIn * 4;
+  constexpr int kFar = 0x7fffff00;  // beyond every descriptor: reads as zero
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const __amdgpu_buffer_rsrc_t w2rsrc = buffer_rsrc(w2ts, kRowsPacked);
+  const float inv_w2_scale = reinterpret_cast<const float *>(static_cast<const unsigned char *>(w2ts) + kRowsPacked)[1];
+  const unsigned wave_lds = lds0 + kWaveOff + wave * kWaveBytes;
+
+  const int64_t tiles = (m + kTile - 1) / kTile;
+  const int64_t stride = gridDim.x;
+
+  // layer-1 records, W3 records (column k of W3: [k][KOUT]), zeroed running sums; max_k |W3[o][k]| over the workgroup
+  float w3max[KOUT];
+  {
+    float *rec = reinterpret_cast<float *>(smem + kRecOff);
+    rec[tid * kRec] = b1[tid];
+#pragma unroll
+    for (int i = 0; i < kRec - 1; ++i) rec[tid * kRec + 1 + i] = i < kIn ? w1[tid * d_in + (i < kIn ? i : 0)] : 0.0f;
+    float *w3r = reinterpret_cast<float *>(smem + kW3Off);
+    float mine[KOUT];
+#pragma unroll
+    for (int q = 0; q < KOUT; ++q) {
+      const float v = q < n_out ? w3[q * kHidden + tid] : 0.0f;
+      w3r[tid * KOUT + q] = v;
+      mine[q] = __builtin_fabsf(v);
+    }
+    float *sums = reinterpret_cast<float *>(smem + kWaveOff + wave * kWaveBytes + kSumOff);
+    for (int idx = lane; idx < kRec * kHidden; idx += kWave) sums[idx] = 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int q = 0; q < KOUT; ++q) mine[q] = __builtin_fmaxf(mine[q], __shfl_xor(mine[q], off, 64));
+    float *red = reinterpret_cast<float *>(smem);  // [wave][KOUT] (the ring's first bytes: nothing is requested into it yet)
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < KOUT; ++q) red[wave * KOUT + q] = mine[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < KOUT; ++q) {
+      const float mx = __builtin_fmaxf(__builtin_fmaxf(red[q], red[KOUT + q]), __builtin_fmaxf(red[2 * KOUT + q], red[3 * KOUT + q]));
+      w3max[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mx)));
+    }
+  }
+
+  auto wave_rows = [&](int64_t tile) {
+    const int64_t left = tile < tiles ? m - tile * kTile - 32 * wave : 0;
+    return left <= 0 ? 0 : left < 32 ? (int)left : 32;
+  };
+  // this lane's two rows: dOut[row][0 .. n_out) (zeros past n_out and past the end) and the observations: ALWAYS
+  // 2 (KOUT + DIN) load instructions (the barriers count them)
+  auto load_rows = [&](float (&d)[2][KOUT], float (&xs)[2][kIn], int64_t tile) {
+    const int rows = wave_rows(tile);
+    const int64_t r0 = tile * kTile + 32 * wave;
+    const __amdgpu_buffer_rsrc_t drsrc = buffer_rsrc(rows > 0 ? dout + r0 * n_out : dout, rows * n_out * 4);
+    const __amdgpu_buffer_rsrc_t xrsrc = buffer_rsrc(rows > 0 ? x + r0 * d_in : x, rows * d_in * 4);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+      for (int q = 0; q < KOUT; ++q) d[rt][q] = buffer_load_f32(drsrc, q < n_out ? ((16 * rt + l16) * n_out + q) * 4 : kFar, 0);
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) xs[rt][i] = buffer_load_f32(xrsrc, ((16 * rt + l16) * d_in + i) * 4, 0);
+    }
+  };
+  auto request_gate = [&](int64_t tile) {
+    const int rows = wave_rows(tile);
+    const __amdgpu_buffer_rsrc_t rsrc = buffer_rsrc(rows > 0 ? gate2 + (tile * kTile + 32 * wave) * 8 : gate2, rows * 32);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, smem + kWaveOff + wave * kWaveBytes, 16, lane * 16, 0, 0, 0);
+  };
+  auto chunk_piece = [&](int hs, int stage, int piece) {
+    const int S = hs >> 1, C = hs & 1;
+    const int src = ((2 * S + (piece >> 3)) * 8 + 4 * C) * 2048 + (piece & 7) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, smem + stage * kRowsChunk + piece * 1024, 16, lane * 16, src, 0, 0);
+  };
+  const unsigned b_lane = lds0 + (kq >> 1) * 8192 + ((kq & 1) * 32 + l16) * 16;
+  const unsigned g_lane = wave_lds + l16 * 32 + kq;              // the gate byte of k block S: + 4 S (+ 512 for row tile 1)
+  const unsigned c_lane = lds0 + kW3Off + kq * (8 * KOUT * 4);   // this lane's eight W3 records of block S: + 32 KOUT 4 S
+
+  float dc[2][KOUT], xc[2][kIn];  // this tile's dOut rows and observations of this lane's rows
+  float sc[2];          // power of two that places this tile's dZ2 rows in fp16's range
+  f32x4 acc[2][16];
+  u32x4 a_hi[2][2], a_lo[2][2];  // dZ2 fragments: [set = k block parity][row tile]
+  u32x4 bh[2], bl[2];
+  uint32_t gbyte[2];    // gate bytes of the block being produced: [row tile]
+  auto request_block = [&](unsigned br, int ctl, int set) {
+    bh[set] = ctl == 0   ? lds_read_b128<0>(br)
+              : ctl == 1 ? lds_read_b128<256>(br)
+              : ctl == 2 ? lds_read_b128<2048>(br)
+              : ctl == 3 ? lds_read_b128<2048 + 256>(br)
+              : ctl == 4 ? lds_read_b128<4096>(br)
+              : ctl == 5 ? lds_read_b128<4096 + 256>(br)
+              : ctl == 6 ? lds_read_b128<6144>(br)
+                         : lds_read_b128<6144 + 256>(br);
+    bl[set] = ctl == 0   ? lds_read_b128<1024>(br)
+              : ctl == 1 ? lds_read_b128<1024 + 256>(br)
+              : ctl == 2 ? lds_read_b128<3072>(br)
+              : ctl == 3 ? lds_read_b128<3072 + 256>(br)
+              : ctl == 4 ? lds_read_b128<5120>(br)
+              : ctl == 5 ? lds_read_b128<5120 + 256>(br)
+              : ctl == 6 ? lds_read_b128<7168>(br)
+                         : lds_read_b128<7168 + 256>(br);
+  };
+  // W3 records: KOUT = 2: one 16-byte read holds an element PAIR (requested in the odd slot in front of it, or at e = 0);
+  // KOUT = 4: one read per element.  Two register sets.
+  u32x4 cq[2];
+  auto request_record = [&](int S, int e) {
+    const unsigned a = c_lane + S * (32 * KOUT * 4);
+    if constexpr (KOUT == 2) {  // e even: the pair (e, e + 1)
+      const int set = (e >> 1) & 1;
+      cq[set] = e == 0 ? lds_read_b128<0>(a) : e == 2 ? lds_read_b128<16>(a) : e == 4 ? lds_read_b128<32>(a) : lds_read_b128<48>(a);
+    } else {
+      const int set = e & 1;
+      cq[set] = e == 0   ? lds_read_b128<0>(a)
+                : e == 1 ? lds_read_b128<16>(a)
+                : e == 2 ? lds_read_b128<32>(a)
+                : e == 3 ? lds_read_b128<48>(a)
+                : e == 4 ? lds_read_b128<64>(a)
+                : e == 5 ? lds_read_b128<80>(a)
+                : e == 6 ? lds_read_b128<96>(a)
+                         : lds_read_b128<112>(a);
+    }
+  };
+  auto request_byte = [&](int S, int C) {  // gate byte of block S, row tile C
+    gbyte[C] = C == 0 ? lds_read_u8<0>(g_lane + 4 * S) : lds_read_u8<512>(g_lane + 4 * S);
+  };
+  // dZ2 of element e (k = 32 S + 8 kq + e) of row tile rt, behind a wait that covers its record and the byte
+  auto dz_element = [&](const float (&d)[2][KOUT], int rt, int e) {
+    const int set = KOUT == 2 ? (e >> 1) & 1 : e & 1;
+    {
+      u32x4 &q = cq[set];
+      asm volatile("" : "+v"(q));
+    }
+    const int at = KOUT == 2 ? 2 * (e & 1) : 0;
+    float g = d[rt][0] * __uint_as_float(cq[set][at]);
+#pragma unroll
+    for (int o = 1; o < KOUT; ++o) g = __builtin_fmaf(d[rt][o], __uint_as_float(cq[set][at + o]), g);
+    const uint32_t open = (uint32_t)__builtin_amdgcn_sbfe((int)gbyte[rt], (unsigned)e, 1u);  // 0 or ~0
+    return __uint_as_float(open & __float_as_uint(g));
+  };
+  constexpr int kRowLoads = 2 * (KOUT + kIn);
+
+  auto do_half = [&](auto first_tag, auto cur_tag, auto c_tag, auto kind_tag, int hs, int stage, int64_t tile) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int CUR = decltype(cur_tag)::value;
+    constexpr int C = decltype(c_tag)::value;
+    constexpr int KIND = decltype(kind_tag)::value;
+    // KIND 0: produces row tile C of block S + 1 and its successor produces too; 1 = (6, 1): produces, the successor does
+    // not; 2 = (7, 0): nothing produced, the NEXT tile's gate block is requested; 3 = (7, 1): nothing requested for a successor
+    constexpr bool kProduce = KIND <= 1, kNextProduces = KIND == 0, kEnd = KIND == 3;
+    const int stage_next = stage + 1 == RING ? 0 : stage + 1, stage_free = stage == 0 ? RING - 1 : stage - 1;
+    const unsigned br = b_lane + stage * kRowsChunk, br_next = b_lane + stage_next * kRowsChunk;
+    const int S = hs >> 1;
+    [[maybe_unused]] float h[2];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+      const int set = sl & 1, ahead = set ^ 1, ct = 8 * C + sl;
+      // requests of this slot, oldest first: [record of the element one slot on] [gate byte of the next half-step's
+      // block (slot 7)] [fragments of the column tile one slot on]
+      int newer = 0;
+      {
+        const bool on = sl == 7 ? kNextProduces : kProduce;
+        const int S1 = sl == 7 ? S + 1 + C : S + 1, e1 = (sl + 1) & 7;
+        if (on && (KOUT != 2 || (sl & 1))) {
+          request_record(S1, e1);
+          ++newer;
+        }
+        if (sl == 7 && kNextProduces) {
+          request_byte(S + 1 + C, C ^ 1);
+          ++newer;
+        }
+      }
+      if (KIND == 2 && sl == 0) request_gate(tile + stride);
+      if (sl < 7) request_block(br, sl + 1, ahead);
+      else if (!kEnd) request_block(br_next, 0, ahead);
+      newer += (kEnd && sl == 7) ? 0 : 2;
+      newer == 0   ? wait_lds<0>(bh[set], bl[set])
+      : newer == 2 ? wait_lds<2>(bh[set], bl[set])
+      : newer == 3 ? wait_lds<3>(bh[set], bl[set])
+                   : wait_lds<4>(bh[set], bl[set]);
+      const f32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_lo[CUR][rt]), __builtin_bit_cast(half8, bh[set]),
+                                                             FIRST ? zero : acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_hi[CUR][rt]), __builtin_bit_cast(half8, bl[set]),
+                                                             acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a_hi[CUR][rt]), __builtin_bit_cast(half8, bh[set]),
+                                                             acc[rt][ct], 0, 0, 0);
+      }
+      if constexpr (kProduce) {  // element sl of row tile C of block S + 1
+        if (sl == 0) asm volatile("" : "+v"(gbyte[C]));  // (requested a half-step ago: landed behind this slot's wait)
+        h[sl & 1] = dz_element(dc, C, sl);
+        if (sl & 1) {
+          uint32_t hi, lo;
+          f16_pair_scaled(h[0], h[1], sc[C], hi, lo);
+          a_hi[CUR ^ 1][C][sl >> 1] = hi;
+          a_lo[CUR ^ 1][C][sl >> 1] = lo;
+        }
+      }
+      if (sl == 3) {
+        // (the counts of the gate-mode kernel above, with this kernel's row loads)
+        constexpr int kExtra = KIND == 2                 ? 1
+                               : KIND == 3               ? (kAhead >= 3 ? 1 : 0)
+                               : (FIRST && (C == 0 || kAhead >= 3)) ? kRowLoads
+                                                         : 0;
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kAhead - 2) + kExtra) : "memory");
+      }
+      if (sl >= 4) chunk_piece((hs + kAhead) & (kRowsHalfSteps - 1), stage_free, wave * 4 + (sl - 4));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  using T = std::true_type;
+  using F = std::false_type;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using K0 = I0;
+  using K1 = I1;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+
+  // ---- prologue: the first tile's gate block, then the first kAhead chunks; everything before them landed --------------
+  __syncthreads();  // (records and zeroed sums in LDS; the reduction's words in the ring are read)
+  if ((int64_t)blockIdx.x < tiles) {
+    request_gate(blockIdx.x);
+#pragma unroll
+    for (int d = 0; d < kAhead; ++d)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) chunk_piece(d, d, wave * 4 + u);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kAhead - 1)) : "memory");
+    load_rows(dc, xc, blockIdx.x);
+  }
+
+  int stage = 0;
+  auto next_stage = [&]() { stage = stage + 1 == RING ? 0 : stage + 1; };
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
+    // ---- open the tile (see the gate-mode kernel): the gate block has landed; the next tile's rows requested; row
+    // scales; factors and observations to the exchange; block 0's fragments of both row tiles; the first requests
+    // (the next tile's rows are requested from the middle of this tile's epilogue, into dc / xc themselves: dOut is last
+    // read in half-step 13, the observations here -- and in the order of the wave's vector-memory operations they still
+    // lie between half-step 15's pieces and the next tile's half-step 0's, as the barriers' counts assume)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    {
+      float fac[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        float bound = 0.0f;
+#pragma unroll
+        for (int q = 0; q < KOUT; ++q) bound = __builtin_fmaf(__builtin_fabsf(dc[rt][q]), w3max[q], bound);
+        const int e = f16_bound_exponent(bound);
+        sc[rt] = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
+        fac[rt] = __builtin_amdgcn_ldexpf(inv_w2_scale, e - kF16Top);
+      }
+      if (kq == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          lds_write_b32(wave_lds + kFacOff + (16 * rt + l16) * 4, fac[rt]);
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) lds_write_b32(wave_lds + kObsOff + (32 * i + 16 * rt + l16) * 4, xc[rt][i]);
+        }
+      }
+      request_byte(0, 0);
+      request_byte(0, 1);
+      float hv[2][8];
+      constexpr int kBatch = KOUT == 2 ? 4 : 2;  // elements whose records fit the two register sets at once
+#pragma unroll
+      for (int e0 = 0; e0 < 8; e0 += kBatch) {
+#pragma unroll
+        for (int e = e0; e < e0 + kBatch; ++e)
+          if (KOUT != 2 || (e & 1) == 0) request_record(0, e);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gbyte[0]), "+v"(gbyte[1]));
+#pragma unroll
+        for (int e = e0; e < e0 + kBatch; ++e)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) hv[rt][e] = dz_element(dc, rt, e);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          uint32_t hi, lo;
+          f16_pair_scaled(hv[rt][e], hv[rt][e + 1], sc[rt], hi, lo);
+          a_hi[0][rt][e >> 1] = hi;
+          a_lo[0][rt][e >> 1] = lo;
+        }
+      // what half-step (0, 0) expects to be on its way, oldest first: [record 0 of block 1] [gate byte of (block 1, row
+      // tile 0)] [column tile 0]
+      request_record(1, 0);
+      request_byte(1, 0);
+      request_block(b_lane + stage * kRowsChunk, 0, 0);
+    }
+    do_half(T{}, I0{}, I0{}, K0{}, 0, stage, tile);  next_stage();
+    do_half(T{}, I0{}, I1{}, K0{}, 1, stage, tile);  next_stage();
+    do_half(F{}, I1{}, I0{}, K0{}, 2, stage, tile);  next_stage();
+    do_half(F{}, I1{}, I1{}, K0{}, 3, stage, tile);  next_stage();
+#pragma unroll 1
+    for (int hs = 4; hs < kRowsHalfSteps - 4; hs += 4) {
+      do_half(F{}, I0{}, I0{}, K0{}, hs, stage, tile);      next_stage();
+      do_half(F{}, I0{}, I1{}, K0{}, hs + 1, stage, tile);  next_stage();
+      do_half(F{}, I1{}, I0{}, K0{}, hs + 2, stage, tile);  next_stage();
+      do_half(F{}, I1{}, I1{}, K0{}, hs + 3, stage, tile);  next_stage();
+    }
+    do_half(F{}, I0{}, I0{}, K0{}, kRowsHalfSteps - 4, stage, tile);  next_stage();
+    do_half(F{}, I0{}, I1{}, K1{}, kRowsHalfSteps - 3, stage, tile);  next_stage();
+    do_half(F{}, I1{}, I0{}, K2{}, kRowsHalfSteps - 2, stage, tile);  next_stage();
+    do_half(F{}, I1{}, I1{}, K3{}, kRowsHalfSteps - 1, stage, tile);  next_stage();
+
+    // ---- epilogue: dZ1 = dH1 * factor * (h1 > 0), folded into the wave's running column sums (the gate-mode kernel's) -------
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int l16e = lane_e & 15, kqe = lane_e >> 4;
+    const unsigned wl = lds0 + kWaveOff + wave * kWaveBytes;
+    u32x4 fq[2], xq[2][kIn];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      fq[rt] = rt == 0 ? lds_read_b128<kFacOff>(wl + 16 * kqe) : lds_read_b128<kFacOff + 64>(wl + 16 * kqe);
+#pragma unroll
+      for (int i = 0; i < kIn; ++i)
+        xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
+                               : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
+                                        : lds_read_b128<kObsOff + 256>(wl + 16 * kqe))
+                            : (i == 0   ? lds_read_b128<kObsOff + 64>(wl + 16 * kqe)
+                               : i == 1 ? lds_read_b128<kObsOff + 128 + 64>(wl + 16 * kqe)
+                                        : lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe));
+    }
+    const unsigned rec_at = lds0 + kRecOff + l16e * (kRec * 4), sum_at = wl + kSumOff + l16e * (kRec * 4);
+    typedef typename std::conditional<kRec == 2, u32x2, u32x4>::type rec_t;
+    rec_t rq[2], sq[2];
+    auto request_col = [&](int ct, int set) {
+      const unsigned ra = rec_at + ct * (16 * kRec * 4), sa = sum_at + ct * (16 * kRec * 4);
+      if constexpr (kRec == 2) {
+        rq[set] = lds_read_b64<0>(ra);
+        sq[set] = lds_read_b64<0>(sa);
+      } else {
+        rq[set] = lds_read_b128<0>(ra);
+        sq[set] = lds_read_b128<0>(sa);
+      }
+    };
+    request_col(0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct) {
+      const int set = ct & 1;
+      if (ct == 8) load_rows(dc, xc, tile + stride);
+      if (ct + 1 < 16) request_col(ct + 1, set ^ 1);
+      if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
+      if (ct == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          asm volatile("" : "+v"(fq[rt]));
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
+        }
+      }
+      const float b1c = __uint_as_float(rq[set][0]);
+      float w1c[kIn];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
+      float db = 0.0f, dw[kIn];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        float pre[4];
+        unsigned long long open[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pre[r] = b1c;
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) pre[r] = __builtin_fmaf(__uint_as_float(xq[rt][i][r]), w1c[i], pre[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) open[r] = positive_mask(pre[r]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
+          db += dz;
+#pragma unroll
+          for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
+        }
+      }
+      auto across = [&](float v) {
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const float u = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+        return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+      };
+      db = across(db);
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
+      if (kqe == (ct & 3)) {
+        const unsigned sa = sum_at + ct * (16 * kRec * 4);
+        lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // Workgroup partial row: [dW1 (256 * d_in) | db1 (256) | head gradients (the weight-gradient kernel's)], the four
+  // waves' sums added in wave order.
+  float *row = partials + (int64_t)blockIdx.x * partial_stride;
+  {
+    const int t = tid;
+    float tot[1 + kIn];
+#pragma unroll
+    for (int i = 0; i < 1 + kIn; ++i) tot[i] = 0.0f;
+    for (int w = 0; w < 4; ++w) {
+      const float *sums = reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff);
+#pragma unroll
+      for (int i = 0; i < 1 + kIn; ++i) tot[i] += sums[t * kRec + i];
+    }
+    row[kHidden * d_in + t] = tot[0];
+#pragma unroll
+    for (int i = 0; i < kIn; ++i) row[t * d_in + i] = tot[1 + i];
+    if ((int)blockIdx.x >= head_rows)
+      for (int idx = kHidden * d_in + kHidden + t; idx < partial_stride; idx += kBlock) row[idx] = 0.0f;
+  }
+}
+
+template <int DIN, int KOUT>
+static int launch_rows_backward_general(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
+                                        int64_t m, const void *w2ts, const float *w3, float *partials, int stride, int head_rows,
+                                        const uint32_t *gate2, int n_out) {
+  constexpr int kRing = 3;
+  auto kernel = &mlp_rows_backward_general_kernel<DIN, KOUT, kRing>;
+  static LdsOptIn opt;
+  if (const int e = allow_dynamic_lds(opt, reinterpret_cast<const void *>(kernel), 160 * 1024)) return e;
+  kernel<<<grid, kBlock, rows_dgrad_general_lds_bytes(kRing, DIN, KOUT), s>>>(x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows,
+                                                                             gate2, n_out);
+  return launch_status();
+}
+
+// The general data gradient behind rl8_mlp_tower_backward_f16_f32 for d_in <= 3, n_out 2..4 (-1: no variant: the caller
+// keeps the tile kernel).  Same grid and partial rows as that kernel.
+int mlp_rows_backward_general_dispatch(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
+                                       int64_t m, int d_in, const void *w2ts, const float *w3, int n_out, float *partials, int stride,
+                                       int head_rows, const uint32_t *gate2) {
+#define RL8_ROWS_BWD_GENERAL(D) \
+  if (d_in == D && n_out == 2) return launch_rows_backward_general<D, 2>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out); \
+  if (d_in == D && (n_out == 3 || n_out == 4)) return launch_rows_backward_general<D, 4>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out);
+  RL8_ROWS_BWD_GENERAL(1) RL8_ROWS_BWD_GENERAL(2) RL8_ROWS_BWD_GENERAL(3)
+#undef RL8_ROWS_BWD_GENERAL
+  return -1;
+}
+
 template <int DIN, int NOUT, int SAVE>
 static int launch_rows_forward(hipStream_t s, const float *x, int64_t m, const float *w1, const float *b1, const void *w2s,
                                const float *b2, const float *w3, const float *b3, float *out, float *h1, float *h2,

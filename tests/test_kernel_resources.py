@@ -279,7 +279,8 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
     for name, body in kernels:
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
-        assert "mlp_rows_forward_kernel" in name or "mlp_rows_backward_gate_kernel" in name
+        assert ("mlp_rows_forward_kernel" in name or "mlp_rows_backward_gate_kernel" in name
+                or "mlp_rows_backward_general_kernel" in name)
         # width class 8 (d_in 6..8: nine fmas and three record reads per element) does not fit 256 registers: 19-33 of them
         # live in scratch, none inside the inner loop of eight half-steps and none a hand-issued load's destination (the
         # walker below holds for these variants too); every other class: no scratch at all
@@ -287,7 +288,8 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
         assert vgprs <= 256 and (scratch <= 160 if wide else scratch == 0), (name, scratch, vgprs)
         checked += "mlp_rows_forward_kernel" in name
     # width classes {1, 2, 3, 5, 8} x output classes {1, 2, 4, 8} x {inference, h2 stored, gate bits only}
-    assert checked == 60 and len(kernels) == 60 + 6  # + the gate-mode data gradient, d_in in {1, 2, 3} x n_out in {1, 2}
+    # + the gate-mode data gradient, d_in in {1, 2, 3} x n_out in {1, 2}, + the general one, d_in in {1, 2, 3} x KOUT in {2, 4}
+    assert checked == 60 and len(kernels) == 60 + 6 + 6
     for name, body in inflight.kernels_of(text):
         # the spilling class: the inner loop of the rollout's (SAVE 0) and the gate-bits (SAVE 2) variants stays free of
         # scratch; the h2-storing one (SAVE 1, which also carries the optional h1 store) reloads inside it (measured:
@@ -320,6 +322,27 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
                       + [4 * (ahead - 1)])  # (+ the prologue's)
         got = sorted(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)\n\ts_barrier", body))
         assert got == want, (name, got, want)
+    # the general-head data gradient (round 5): the same ring discipline with 2 (KOUT + d_in) row loads per tile and a
+    # three-chunk ring
+    assert_no_inflight_register_access(text, "mlp_rows_backward_general_kernel", min_hand_loads=6 * 100)
+    seen = 0
+    for name, body in inflight.kernels_of(text):
+        m = re.search(r"mlp_rows_backward_general_kernelILi(\d)ELi(\d)ELi(\d)E", name)
+        if not m:
+            continue
+        d_in, k_out, ring = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        ahead, rows = ring - 1, 2 * (k_out + d_in)
+        base = 4 * (ahead - 2)
+        # (+ the prologue's; and, in some variants, the compiler's own wait in front of the final __syncthreads, which lets
+        # the last tile's never-used row loads -- requested in its epilogue for a tile past the end -- stay in flight
+        # behind the kernel's hand-written vmcnt(0))
+        want = sorted([base + rows, base + (rows if ahead >= 3 else 0)] + [base] * 8 + [base + 1, base + (1 if ahead >= 3 else 0)]
+                      + [4 * (ahead - 1)])
+        got = [int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)\n\ts_barrier", body)]
+        assert sorted(got[:13]) == want and len(got) <= 14 and all(v <= rows for v in got[13:]), (name, got, want)
+        assert "v_mfma_f32_16x16x32_f16" in body
+        seen += 1
+    assert seen == 6
     for name, body in inflight.kernels_of(text):
         assert inflight.packed_war(body) == [], name
 

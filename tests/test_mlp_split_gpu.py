@@ -953,3 +953,35 @@ def test_guard_sends_a_call_with_a_nan_to_the_exact_planes():
     calls, fires = (a - b for a, b in zip(hip.wgrad_guard_counts(), before))
     assert (calls, fires) == (1, 1)
     assert bool(torch.isnan(out["w2"]).any()) and bool(torch.isnan(out["b3"]).any())
+
+
+@pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (127, 2, 3), (128, 3, 4), (4097, 1, 3), (33_000, 3, 2), (70_001, 2, 4)])
+def test_general_data_gradient_rows_and_tile_kernels_agree(m, d_in, n_out, monkeypatch):
+    """Round 5: the general-head data gradient in the rows shape (mlp_rows_backward_general_kernel: d_in <= 3, n_out 2..4)
+    beside the tile kernel it replaced there (RL8_MLP_DGRAD_GENERAL_TILE=1; still what d_in 4, 5 run): dW1 / db1 of both
+    against fp64 on the saved activations, the new one no further off than 3x the old one + 1e-6, everything else of the
+    backward (the weight-gradient kernel's outputs) bit for bit the same."""
+    g = torch.Generator(device=DEV).manual_seed(31 * m + d_in + n_out)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 3
+    p = _params(g, d_in, n_out)
+    dout = torch.randn(m, n_out, device=DEV, generator=g) / m
+    dout *= 10.0 ** torch.randint(-3, 2, (m, 1), device=DEV, generator=g).float()   # rows of mixed magnitude
+    w2p, w2t = hip.mlp_pack_w2_f16(p["w2"]), hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], w2p, p["b2"], p["w3"], p["b3"], save=True, save_gate=True)
+    dz2 = (dout.double() @ p["w3"].double()) * (h2 > 0)
+    dz1 = (dz2 @ p["w2"].double()) * (h1 > 0)
+    want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0)}
+
+    def run(tile):
+        monkeypatch.setenv("RL8_MLP_DGRAD_GENERAL_TILE", "1" if tile else "0")
+        return hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, assume_general=True)
+
+    rows, tile = run(False), run(True)
+    for k in ("w1", "b1"):
+        err_rows, err_tile = _rel(rows[k], want[k]), _rel(tile[k], want[k])
+        assert err_rows < 2e-5 and err_rows <= 3 * err_tile + 1e-6, (k, err_rows, err_tile)
+    for k in ("w2", "b2", "w3", "b3"):
+        assert torch.equal(rows[k], tile[k]), k
+    again = run(False)
+    for k in rows:
+        assert torch.equal(rows[k], again[k]), k  # fixed summation order, no race
