@@ -42,9 +42,11 @@ constexpr int kRowsPitch = 128 + 16;                   // h2 transpose scratch (
 
 // floats per k of the layer-1 record [b1 | w1[k][0..DIN-1] | pad]
 // (width CLASSES since round 5: a kernel compiled for class DIN serves every run-time d_in <= DIN -- weights past d_in
-// are zero in the records, observations past d_in are not loaded -- so d_in = 4 runs class 5, 6..8 class 8)
-constexpr int rows_record(int d_in) { return d_in == 1 ? 2 : d_in <= 3 ? 4 : d_in <= 7 ? 8 : 12; }
-constexpr int rows_record_vecs(int d_in) { return d_in <= 3 ? 1 : rows_record(d_in) / 4; }  // 16-byte reads per record
+// are zero, observations past d_in are not loaded.  Classes 1, 2, 3 form h1 with one fma per input on the vector ALU
+// from these records; class 8 -- d_in = 4..8 -- forms it on the MATRIX pipe, see "layer 1 as a matrix product" in the
+// kernel: its "record" is 8 KiB of W1 fragments + 1 KiB of b1, nine floats per k.)
+constexpr int rows_record(int d_in) { return d_in == 1 ? 2 : d_in <= 3 ? 4 : 9; }
+constexpr int rows_record_vecs(int d_in) { return d_in <= 3 ? 1 : 4; }  // 16-byte reads per record (class 8: per k BLOCK)
 constexpr int rows_consts_bytes(int k_in, int k_out) { return (rows_record(k_in) + 1 + k_out) * kHidden * 4; }
 constexpr int rows_lds_bytes(int ring, int k_in, int k_out, bool store) {
   return ring * kRowsChunk + rows_consts_bytes(k_in, k_out) + (store ? 4 * 16 * kRowsPitch : 0);
@@ -57,6 +59,7 @@ constexpr int rows_lds_bytes(int ring, int k_in, int k_out, bool store) {
 template <int DIN>
 constexpr int rows_record_reads(int s, bool produce, bool next_produces) {
   const bool on = s == 7 ? next_produces : produce;
+  if (DIN > 3) return s == 7 && on ? 4 : 0;  // (one request per k block: two W1 fragments, eight b1)
   if (DIN == 1) return (s & 1) && on ? 1 : 0;
   return on ? rows_record_vecs(DIN) : 0;
 }
@@ -84,7 +87,19 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
   constexpr int kAhead = RING - 1;
   constexpr bool kStore = SAVE == 1;
   constexpr int kRec = rows_record(DIN);
-  static_assert(DIN == 1 || DIN == 2 || DIN == 3 || DIN == 5 || DIN == 8, "width classes of the layer-1 records");
+  // Layer 1 as a matrix product (class 8).  z1 = W1 x is ONE 16x16x32 MFMA per sixteen hidden units and row tile: the
+  // 32 k slots hold the FOUR plane products of up to eight inputs -- lanes 0..15 W1hi . xhi, 16..31 W1hi . xlo,
+  // 32..47 W1lo . xhi, 48..63 W1lo . xlo -- so z1 carries all 22 + 22 operand bits (nothing dropped, unlike the
+  // three-product layers) and costs the same whatever d_in is: 32 MFMAs per 32 rows (4 % of the layer-2 work) where the
+  // vector ALU spent d_in fmas per element (d_in = 5: a quarter of the kernel's time, tools/diag/tower_width_sweep.py).
+  // The product is transposed like layer 2's (first operand = the W1 fragment), and the fragment's sixteen M slots are
+  // the hidden units 32 S + 8 (i >> 2) + 4 hf + (i & 3): lane (row l16, k block kq) then receives, from the two
+  // fragments hf = 0, 1 of block S, exactly the eight k of its own layer-2 A fragment.  x is scaled per row, W1 per
+  // tensor, by powers of two; bias, ReLU and the plane split of h1 stay on the vector ALU (four instructions per
+  // element, what class 1 spends).
+  constexpr bool kMma1 = DIN > 3;
+  constexpr int kW1Planes = 8 * 1024;  // [S][hf][plane hi | lo][M slot] x 16 B (lanes kq and kq ^ 1 read the same plane)
+  static_assert(DIN == 1 || DIN == 2 || DIN == 3 || DIN == 8, "width classes of layer 1");
   static_assert(NOUT == pad_out(NOUT), "output classes: 1, 2, 4, 8");
   static_assert(rows_lds_bytes(RING, kIn, kOut, kStore) <= 80 * 1024, "two workgroups per CU");
   static_assert(kAhead >= 2, "the mid-step barrier publishes a chunk requested at least a half-step earlier");
@@ -105,11 +120,19 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
 
   // ---- constants into LDS; bounds of layer 1 for the row factors ---------------------------------
   float b1max = 0.0f, w1max[kIn];
+  [[maybe_unused]] float inv_w1 = 1.0f;  // class 8: 1 / (W1's power of two)
   {
     float *consts = reinterpret_cast<float *>(smem + kConstOff);
-    consts[tid * kRec] = b1[tid];
+    [[maybe_unused]] float wv[kIn];  // class 8: this thread's unit's weights, until the tensor's bound is known
+    if constexpr (kMma1) {
+      consts[kW1Planes / 4 + tid] = b1[tid];
 #pragma unroll
-    for (int i = 0; i < kRec - 1; ++i) consts[tid * kRec + 1 + i] = i < d_in ? w1[tid * d_in + i] : 0.0f;
+      for (int i = 0; i < kIn; ++i) wv[i] = i < d_in ? w1[tid * d_in + i] : 0.0f;
+    } else {
+      consts[tid * kRec] = b1[tid];
+#pragma unroll
+      for (int i = 0; i < kRec - 1; ++i) consts[tid * kRec + 1 + i] = i < d_in ? w1[tid * d_in + i] : 0.0f;
+    }
     consts[kRec * kHidden + tid] = b2[tid];
 #pragma unroll
     for (int q = 0; q < kOut; ++q) consts[(kRec + 1 + q) * kHidden + tid] = q < n_out ? w3[q * kHidden + tid] : 0.0f;
@@ -118,9 +141,9 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     // all 256 records in LDS, (1 + DIN) x 256 dependent reads -- 36 us of every launch at DIN = 1, 86 us at DIN = 5:
     // a fifth of a rollout timestep's launch of 2^20 rows, half of one of 2^18; tools/diag/forward_size_sweep.py.)
     float mine[1 + kIn];
-    mine[0] = __builtin_fabsf(consts[tid * kRec]);
+    mine[0] = __builtin_fabsf(kMma1 ? consts[kW1Planes / 4 + tid] : consts[tid * kRec]);
 #pragma unroll
-    for (int i = 0; i < kIn; ++i) mine[1 + i] = __builtin_fabsf(consts[tid * kRec + 1 + i]);
+    for (int i = 0; i < kIn; ++i) mine[1 + i] = __builtin_fabsf(kMma1 ? wv[i] : consts[tid * kRec + 1 + i]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
@@ -138,6 +161,27 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     b1max = of_all(0);
 #pragma unroll
     for (int i = 0; i < kIn; ++i) w1max[i] = of_all(1 + i);
+    if constexpr (kMma1) {
+      // this unit's two planes into its M slot of fragment (S, hf): |w 2^(14 - e)| < 2^14 for the tensor's bound 2^e
+      float all = 0.0f;
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) all = __builtin_fmaxf(all, w1max[i]);
+      const int ew = f16_bound_exponent(all);
+      const float sw = __builtin_amdgcn_ldexpf(1.0f, kF16Top - ew);
+      inv_w1 = __builtin_amdgcn_ldexpf(1.0f, ew - kF16Top);
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t h, l;
+        f16_pair_scaled(wv[2 * j], wv[2 * j + 1], sw, h, l);
+        hi[j] = h;
+        lo[j] = l;
+      }
+      const int slot = 4 * ((tid >> 3) & 3) + (tid & 3), frag = 2 * (tid >> 5) + ((tid >> 2) & 1);
+      u32x4 *planes = reinterpret_cast<u32x4 *>(smem + kConstOff);
+      planes[(frag * 2 + 0) * 16 + slot] = hi;
+      planes[(frag * 2 + 1) * 16 + slot] = lo;
+    }
   }
 
   // ---- per-lane state -------------------------------------------------------------------------------
@@ -166,13 +210,70 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
       inv[rt] = __builtin_amdgcn_ldexpf(inv_w2_scale, e - kF16Top);
     }
   };
-  constexpr bool kPrefetchX = DIN <= 3;  // (wide observations: the next tile's rows are loaded at the tile switch)
-  float xc[2][kIn];
-  [[maybe_unused]] float xn[2][kIn];
+  // Class 8: a lane loads only the input PAIR 2 kq, 2 kq + 1 of its rows (inputs past d_in: an offset past the
+  // descriptor's end, which reads as zero); the four lanes of a row exchange bounds and fp16 words at the tile switch.
+  auto row4 = [&](uint32_t v, auto combine) {  // over the four lanes of equal l16
+    const auto s16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    const uint32_t u = combine(s16[0], s16[1]);
+    const auto s32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return combine(s32[0], s32[1]);
+  };
+  auto load_pair = [&](float (&dst)[2][2], int64_t tile) {
+    const int64_t left = tile < tiles ? m - tile * kTile : 0;
+    const int rows = left <= 0 ? 0 : left < kTile ? (int)left : kTile;
+    const __amdgpu_buffer_rsrc_t xrsrc = buffer_rsrc(rows > 0 ? x + tile * kTile * d_in : x, rows * d_in * 4);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int f = 2 * kq + j;
+        dst[rt][j] = buffer_load_f32(xrsrc, f < d_in ? ((32 * wave + 16 * rt + l16) * d_in + f) * 4 : 0x7ffffff0, 0);
+      }
+  };
+  [[maybe_unused]] float wmx[2] = {0.0f, 0.0f};  // max_k |w1[k][2 kq + j]|
+  if constexpr (kMma1) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      wmx[j] = kq == 0 ? w1max[j] : kq == 1 ? w1max[2 + j] : kq == 2 ? w1max[4 + j] : w1max[6 + j];
+  }
+  [[maybe_unused]] u32x4 xf[2];     // class 8: the rows' layer-1 fragments (plane hi in even k blocks, lo in odd ones)
+  [[maybe_unused]] float inv_x[2];  // ... and 1 / (the row's power of two x W1's)
+  // from the pair: the factor of h1 (as row_scales), the factor of x (|x_i| < 2^e over the row) and the fragment
+  auto row_fragments = [&](const float (&xs)[2][2], float (&scale)[2], float (&inv)[2]) {
+    const auto fmax_u = [](uint32_t a, uint32_t b) { return __float_as_uint(__builtin_fmaxf(__uint_as_float(a), __uint_as_float(b))); };
+    const auto fadd_u = [](uint32_t a, uint32_t b) { return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); };
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float a0 = __builtin_fabsf(xs[rt][0]), a1 = __builtin_fabsf(xs[rt][1]);
+      const float most = __uint_as_float(row4(__float_as_uint(__builtin_fmaxf(a0, a1)), fmax_u));
+      const float part = __uint_as_float(row4(__float_as_uint(__builtin_fmaf(a0, wmx[0], a1 * wmx[1])), fadd_u));
+      const int e = f16_bound_exponent(b1max + part);
+      scale[rt] = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
+      inv[rt] = __builtin_amdgcn_ldexpf(inv_w2_scale, e - kF16Top);
+      const int ex = f16_bound_exponent(most);
+      inv_x[rt] = __builtin_amdgcn_ldexpf(inv_w1, ex - kF16Top);
+      uint32_t hi, lo;
+      f16_pair_scaled(xs[rt][0], xs[rt][1], __builtin_amdgcn_ldexpf(1.0f, kF16Top - ex), hi, lo);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // inputs 2 j, 2 j + 1 live in lane l16 + 16 j
+        const uint32_t h = __shfl(hi, l16 + 16 * j, kWave), l = __shfl(lo, l16 + 16 * j, kWave);
+        xf[rt][j] = (kq & 1) ? l : h;
+      }
+    }
+  };
+  constexpr int kXRegs = kMma1 ? 2 : kIn;
+  [[maybe_unused]] float xc[2][kXRegs];
+  float xn[2][kXRegs];
   float sc[2], inv_c[2];
-  load_x(xc, blockIdx.x);
-  if constexpr (kPrefetchX) load_x(xn, blockIdx.x + stride);
-  row_scales(xc, sc, inv_c);
+  if constexpr (kMma1) {
+    load_pair(xn, blockIdx.x);
+    row_fragments(xn, sc, inv_c);
+    load_pair(xn, blockIdx.x + stride);
+  } else {
+    load_x(xc, blockIdx.x);
+    load_x(xn, blockIdx.x + stride);
+    row_scales(xc, sc, inv_c);
+  }
 
   // ---- W2 ring ------------------------------------------------------------------------------------------
   auto request_chunk = [&](int hs, int stage) {  // sixteen one-KiB pieces, four per wave
@@ -184,15 +285,27 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     }
   };
   const unsigned b_lane = lds0 + lane * 16;
-  const unsigned c_lane = lds0 + kConstOff + kq * (8 * kRec * 4);  // this lane's eight k of a block: + 32 kRec 4 S
+  // this lane's eight k of a block: + 32 kRec 4 S  (class 8: its M slot of the plane its k block multiplies: + 1024 S
+  // + 512 hf; and the eight b1 of its k: + 128 S)
+  const unsigned c_lane = kMma1 ? lds0 + kConstOff + (kq >> 1) * 256 + l16 * 16 : lds0 + kConstOff + kq * (8 * kRec * 4);
+  [[maybe_unused]] const unsigned b1_lane = lds0 + kConstOff + kW1Planes + kq * 32;
 
   // ---- layer-1 records: requested one slot ahead of the element they serve ------------------------------------------
   //   DIN = 1: one 16-byte read holds the records of an element PAIR (requested in the odd slot in front of it);
   //   DIN = 2, 3: one read per element;  DIN = 5: two reads per element.  Two register sets each.
-  constexpr int kCSets = 2;
+  //   class 8: four reads per k BLOCK (two W1 fragments, eight b1), requested in the last slot of the half-step before.
+  constexpr int kCSets = kMma1 ? 1 : 2;
   constexpr int kCReads = rows_record_vecs(DIN);
   u32x4 cq[kCSets][kCReads];
   auto request_record = [&](int S, int e) {  // the reads for element e (0..7) of block S
+    if constexpr (kMma1) {  // (the whole block's: fragments hf = 0, 1 and b1 of the lane's eight k)
+      const unsigned a = c_lane + S * 1024, b = b1_lane + S * 128;
+      cq[0][0] = lds_read_b128<0>(a);
+      cq[0][1] = lds_read_b128<512>(a);
+      cq[0][2] = lds_read_b128<0>(b);
+      cq[0][3] = lds_read_b128<16>(b);
+      return;
+    }
     const unsigned a = c_lane + S * (32 * kRec * 4);
     if constexpr (DIN == 1) {  // e even: the pair (e, e + 1)
       const int set = (e >> 1) & 1;
@@ -207,48 +320,46 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
                    : e == 5 ? lds_read_b128<80>(a)
                    : e == 6 ? lds_read_b128<96>(a)
                             : lds_read_b128<112>(a);
-    } else if constexpr (DIN > 5) {  // three reads per 48-byte record: the element's address in a register
-      const int set = e & 1;
-      const unsigned ae = a + e * (kRec * 4);
-      cq[set][0] = lds_read_b128<0>(ae);
-      cq[set][1] = lds_read_b128<16>(ae);
-      cq[set][2] = lds_read_b128<32>(ae);
-    } else {
-      const int set = e & 1;
-      cq[set][0] = e == 0   ? lds_read_b128<0>(a)
-                   : e == 1 ? lds_read_b128<32>(a)
-                   : e == 2 ? lds_read_b128<64>(a)
-                   : e == 3 ? lds_read_b128<96>(a)
-                   : e == 4 ? lds_read_b128<128>(a)
-                   : e == 5 ? lds_read_b128<160>(a)
-                   : e == 6 ? lds_read_b128<192>(a)
-                            : lds_read_b128<224>(a);
-      cq[set][kCReads - 1] = e == 0   ? lds_read_b128<16>(a)
-                             : e == 1 ? lds_read_b128<48>(a)
-                             : e == 2 ? lds_read_b128<80>(a)
-                             : e == 3 ? lds_read_b128<112>(a)
-                             : e == 4 ? lds_read_b128<144>(a)
-                             : e == 5 ? lds_read_b128<176>(a)
-                             : e == 6 ? lds_read_b128<208>(a)
-                                      : lds_read_b128<240>(a);
     }
   };
   // element e of row tile rt from its record (behind a counted wait that covers it)
-  auto h1_element = [&](const float (&xs)[2][kIn], int rt, int e) {
-    const int set = DIN == 1 ? (e >> 1) & 1 : e & 1;
+  auto h1_element = [&](const float (&xs)[2][kXRegs], int rt, int e) {
+    if constexpr (kMma1) {
+      return 0.0f;
+    } else {
+      const int set = DIN == 1 ? (e >> 1) & 1 : e & 1;
 #pragma unroll
-    for (int r = 0; r < kCReads; ++r) {
-      u32x4 &q = cq[set][r];  // (named outside the asm: operands alone do not capture in a generic lambda)
-      asm volatile("" : "+v"(q));
-    }
-    const int at = DIN == 1 ? 2 * (e & 1) : 0;
-    float v = __uint_as_float(cq[set][0][at]);
+      for (int r = 0; r < kCReads; ++r) {
+        u32x4 &q = cq[set][r];  // (named outside the asm: operands alone do not capture in a generic lambda)
+        asm volatile("" : "+v"(q));
+      }
+      const int at = DIN == 1 ? 2 * (e & 1) : 0;
+      float v = __uint_as_float(cq[set][0][at]);
 #pragma unroll
-    for (int i = 0; i < kIn; ++i) {
-      const int j = at + 1 + i;
-      v = __builtin_fmaf(xs[rt][i], __uint_as_float(cq[set][j >> 2][j & 3]), v);
+      for (int i = 0; i < kIn; ++i) {
+        const int j = at + 1 + i;
+        v = __builtin_fmaf(xs[rt][i], __uint_as_float(cq[set][j >> 2][j & 3]), v);
+      }
+      return relu1(v);
     }
-    return relu1(v);
+  };
+  // class 8: z1 of the eight k of block S (its four reads have landed) for row tile rt; then + b1, before the ReLU
+  auto l1_products = [&](int rt, f32x4 (&z)[2]) {
+    if constexpr (kMma1) {
+      asm volatile("" : "+v"(cq[0][0]), "+v"(cq[0][1]), "+v"(cq[0][2]), "+v"(cq[0][3]));
+      const f32x4 zero = {0, 0, 0, 0};
+      z[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cq[0][0]), __builtin_bit_cast(half8, xf[rt]), zero, 0, 0, 0);
+      z[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cq[0][1]), __builtin_bit_cast(half8, xf[rt]), zero, 0, 0, 0);
+    }
+  };
+  auto l1_bias = [&](int rt, const f32x4 (&z)[2], float (&h)[8]) {
+    if constexpr (kMma1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h[r] = __builtin_fmaf(z[0][r], inv_x[rt], __uint_as_float(cq[0][2][r]));
+        h[4 + r] = __builtin_fmaf(z[1][r], inv_x[rt], __uint_as_float(cq[0][3][r]));
+      }
+    }
   };
 
   f32x4 acc[2][16];
@@ -306,6 +417,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     const unsigned br = b_lane + stage * kRowsChunk, br_next = b_lane + stage_next * kRowsChunk;
     const int S = hs >> 1;
     [[maybe_unused]] float h[8];
+    [[maybe_unused]] f32x4 z1v[2];
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl) {
       const int set = sl & 1, ahead = set ^ 1, ct = 8 * C + sl;
@@ -314,7 +426,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
       {
         const bool on = sl == 7 ? kNextProduces : kProduce;
         const int S1 = sl == 7 ? S + 1 + C : S + 1, e1 = (sl + 1) & 7;
-        if (on && (DIN != 1 || (sl & 1))) request_record(S1, e1);
+        if (on && (kMma1 ? sl == 7 : (DIN != 1 || (sl & 1)))) request_record(S1, e1);
       }
       // ... then the fragments of the column tile one slot on (two waves share a SIMD's matrix pipe: a slot's six
       // products take ~190 cycles of wall time, more than an LDS round trip)
@@ -328,7 +440,11 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
         : allowed == 3 ? wait_lds<3>(bh[set], bl[set])
         : allowed == 4 ? wait_lds<4>(bh[set], bl[set])
         : allowed == 5 ? wait_lds<5>(bh[set], bl[set])
+        : allowed == 6 ? wait_lds<6>(bh[set], bl[set])
                        : wait_lds<0>(bh[set], bl[set]);
+      }
+      if constexpr (kProduce && kMma1) {  // the two small products of this half-step's k block, ahead of the slot's six
+        if (sl == 0) l1_products(C, z1v);
       }
       const f32x4 zero = {0, 0, 0, 0};
 #pragma unroll
@@ -346,7 +462,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
                                                              __builtin_bit_cast(half8, a_hi[CUR][rt]), acc[rt][ct], 0, 0, 0);
       }
       if constexpr (kProduce) {  // element sl of row tile C of block S + 1
-        h[sl] = h1_element(xc, C, sl);
+        if constexpr (kMma1) {
+          if (sl == 0) l1_bias(C, z1v, h);  // (behind this slot's six products: the two small ones finished under them)
+          h[sl] = relu1(h[sl]);
+        } else {
+          h[sl] = h1_element(xc, C, sl);
+        }
         if (sl & 1) {
           uint32_t hi, lo;
           f16_pair_scaled(h[sl - 1], h[sl], sc[C], hi, lo);
@@ -375,17 +496,30 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
   auto open_tile = [&](int stage) {
     {
       float h[2][8];
-      constexpr int kBatch = DIN == 1 ? 4 : 2;  // elements whose records fit the two register sets at once
-#pragma unroll
-      for (int e0 = 0; e0 < 8; e0 += kBatch) {
-#pragma unroll
-        for (int e = e0; e < e0 + kBatch; ++e)
-          if (DIN != 1 || (e & 1) == 0) request_record(0, e);
+      if constexpr (kMma1) {
+        request_record(0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int e = e0; e < e0 + kBatch; ++e)
+        for (int rt = 0; rt < 2; ++rt) {
+          f32x4 z[2];
+          l1_products(rt, z);
+          l1_bias(rt, z, h[rt]);
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) h[rt][e] = h1_element(xc, rt, e);
+          for (int e = 0; e < 8; ++e) h[rt][e] = relu1(h[rt][e]);
+        }
+      } else {
+        constexpr int kBatch = DIN == 1 ? 4 : 2;  // elements whose records fit the two register sets at once
+#pragma unroll
+        for (int e0 = 0; e0 < 8; e0 += kBatch) {
+#pragma unroll
+          for (int e = e0; e < e0 + kBatch; ++e)
+            if (DIN != 1 || (e & 1) == 0) request_record(0, e);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int e = e0; e < e0 + kBatch; ++e)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) h[rt][e] = h1_element(xc, rt, e);
+        }
       }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
@@ -622,16 +756,17 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
       }
     }
     // the workgroup's next tile
-    if constexpr (kPrefetchX) {
+    if constexpr (kMma1) {
+      row_fragments(xn, sc, inv_c);
+      load_pair(xn, tile + 2 * stride);
+    } else {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int i = 0; i < kIn; ++i) xc[rt][i] = xn[rt][i];
       load_x(xn, tile + 2 * stride);
-    } else {
-      load_x(xc, tile + stride);
+      row_scales(xc, sc, inv_c);
     }
-    row_scales(xc, sc, inv_c);
   }
   // (the ring's last requests ran past the last tile: nothing may land in LDS after the workgroup is gone)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1591,7 +1726,7 @@ static int launch_rows_forward_save(hipStream_t s, const float *x, int64_t m, co
 }
 
 // Width classes (round 5): the smallest compiled class that holds the run-time width.
-int rows_in_class(int d_in) { return d_in <= 3 ? d_in : d_in <= 5 ? 5 : d_in <= 8 ? 8 : 0; }
+int rows_in_class(int d_in) { return d_in <= 3 ? d_in : d_in <= 8 ? 8 : 0; }
 int rows_out_class(int n_out) { return n_out >= 1 && n_out <= 8 ? pad_out(n_out) : 0; }
 
 // The forward behind rl8_mlp_tower_forward_f16_f32 (mlp_f16_kernels.hip checks the arguments and dispatches here).
@@ -1604,7 +1739,6 @@ int mlp_rows_forward_dispatch(hipStream_t s, const float *x, int64_t m, int d_in
   RL8_ROWS(1, 1) RL8_ROWS(1, 2) RL8_ROWS(1, 4) RL8_ROWS(1, 8)
   RL8_ROWS(2, 1) RL8_ROWS(2, 2) RL8_ROWS(2, 4) RL8_ROWS(2, 8)
   RL8_ROWS(3, 1) RL8_ROWS(3, 2) RL8_ROWS(3, 4) RL8_ROWS(3, 8)
-  RL8_ROWS(5, 1) RL8_ROWS(5, 2) RL8_ROWS(5, 4) RL8_ROWS(5, 8)
   RL8_ROWS(8, 1) RL8_ROWS(8, 2) RL8_ROWS(8, 4) RL8_ROWS(8, 8)
 #undef RL8_ROWS
   return RL8_ESIZE;
