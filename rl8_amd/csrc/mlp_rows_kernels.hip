@@ -820,24 +820,296 @@ __device__ __forceinline__ uint32_t lds_read_u8(unsigned addr) {
   return v;
 }
 
+// ---- the data gradients' class 8 (d_in = 4..7): layer 1 on the matrix pipe here too ---------------------------------------
+// Per element of dZ1 the vector ALU spent 2 d_in + 3 instructions -- d_in fmas for the gate of h1, d_in for dW1 -- and the
+// wave's running sums [256][1 + d_in] took (1 + d_in) KiB of LDS, four times per workgroup: d_in = 3 was the last width
+// that fit.  Class 8 moves both onto MFMAs:
+//   * the gate of h1 is the FORWARD's z1 again -- the same fragments (x scaled per row, W1 per tensor, four plane
+//     products in the 32 k slots), one product per column tile and row tile, then fma(z, 1 / scale, b1) > 0: the very
+//     value the forward rounded, so the two kernels never disagree on a gate;
+//   * dW1 / db1 of the wave's 32 rows: K = rows.  dZ1's eight values per lane ARE a B fragment of that product (column
+//     = lane & 15, k slot (kq, j) = row 16 (j >> 2) + 4 kq + (j & 3)) once scaled by a power of two per WAVE and split in
+//     two planes; the A fragment holds x~ = x * 2^s (per wave again: rows are summed inside the instruction) with the hi
+//     planes of inputs 0..6 and a column of ones in M slots 0..7 and the lo planes in slots 8..15, so
+//     mfma(A, Dhi) + mfma(A, Dlo) delivers all four plane products, db1 in slot 7; the lanes of slots 8..15 hand their
+//     part to those of slots 0..7 (one swap);
+//   * the running sums are ONE array [256][8] per workgroup, updated block by block in wave order: wave w adds its
+//     part of column tile ct once wave w - 1 has published "ct done" (a counter in LDS, polled; the sums' read rides
+//     on the poll: LDS executes a wave's operations in order, and both are repeated if the counter was not there yet).
+//     The order is fixed, so the sums repeat bit for bit; no wave waits for a later one, so the chain cannot lock; the
+//     sixteen barriers of the next tile's matrix loop separate one tile's updates from the next one's.
+constexpr int kRows8Planes = 8 * 1024;                     // W1 planes, [column tile][hi | lo][unit] x 16 B
+constexpr int kRows8Sums = kHidden * 8 * 4;                // [unit][dW1 row 0..6 | db1]
+constexpr int kRows8FacOff = 1024, kRows8InvOff = kRows8FacOff + 128, kRows8XtOff = kRows8InvOff + 128;
+constexpr int kRows8Wave = kRows8XtOff + 1024;            // gate block | row factors | rows' 1 / x scale | x~ [slot][row] fp16
+constexpr int rows8_dgrad_lds_bytes(int ring, int k_out) {
+  return ring * kRowsChunk + kRows8Planes + 1024 + kRows8Sums + 64 + 4 * kRows8Wave + k_out * kHidden * 4;
+}
+__device__ __forceinline__ void lds_write_b16(unsigned addr, uint32_t v) {
+  asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write_b16_hi(unsigned addr, uint32_t v) {
+  asm volatile("ds_write_b16_d16_hi %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_read_b32_nowait(unsigned addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ float rows8_row4(float v, bool sum) {  // over the four lanes of equal lane & 15
+  const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float a = __uint_as_float(s16[0]), b = __uint_as_float(s16[1]);
+  const float u = sum ? a + b : __builtin_fmaxf(a, b);
+  const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+  const float c = __uint_as_float(s32[0]), d = __uint_as_float(s32[1]);
+  return sum ? c + d : __builtin_fmaxf(c, d);
+}
+
+// Prologue: W1's planes (the forward's power of two: the tensor's bound) and b1 into LDS, sums zeroed, the chain's
+// counters set (word 0: "wave -1", always done).  `red`: sixteen bytes of LDS nobody else uses before the next barrier.
+// Returns 1 / (W1's power of two).  Contains a workgroup barrier.
+__device__ __forceinline__ float rows8_constants(unsigned char *base, float *red, const float *__restrict__ w1,
+                                                 const float *__restrict__ b1, int d_in, int tid) {
+  float wv[8], mx = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    wv[i] = i < d_in ? w1[tid * d_in + i] : 0.0f;
+    mx = __builtin_fmaxf(mx, __builtin_fabsf(wv[i]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  reinterpret_cast<float *>(base + kRows8Planes)[tid] = b1[tid];
+  float *sums = reinterpret_cast<float *>(base + kRows8Planes + 1024);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sums[i * kBlock + tid] = 0.0f;
+  if (tid < 8) reinterpret_cast<int *>(base + kRows8Planes + 1024 + kRows8Sums)[tid] = tid == 0 ? 0x7fffffff : 0;
+  __syncthreads();
+  const float all = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+  const int ew = f16_bound_exponent(__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(all))));
+  const float sw = __builtin_amdgcn_ldexpf(1.0f, kF16Top - ew);
+  u32x4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t h, l;
+    f16_pair_scaled(wv[2 * j], wv[2 * j + 1], sw, h, l);
+    hi[j] = h;
+    lo[j] = l;
+  }
+  u32x4 *planes = reinterpret_cast<u32x4 *>(base);
+  planes[((tid >> 4) * 2 + 0) * 16 + (tid & 15)] = hi;
+  planes[((tid >> 4) * 2 + 1) * 16 + (tid & 15)] = lo;
+  return __builtin_amdgcn_ldexpf(1.0f, ew - kF16Top);
+}
+
+// Tile opening: from this lane's rows' factors (dZ1 = acc * factor) and input pair 2 kq, 2 kq + 1 -- the rows' z1
+// fragments (the forward's), factors and 1 / x-scale to the wave's exchange, x~ to its [slot][row] block.
+// acc_exponent: |acc| < 2^acc_exponent.
+// Scales of the dW1 product.  Rows are summed INSIDE the instruction, so dZ1~[r] x~[r] must carry one common power of two
+// S; but one power of two per operand for the whole wave would push the rows of a wave that holds one outlier (|d| 10^6
+// times the others') to the bottom of fp16's range -- and where the outlier's own gate is closed those rows ARE the sum.
+// So each row gets its own split: with g[r] = (exponent of the wave's largest |factor|) - (the row's), dZ1~[r] is raised
+// by 2^(g/2) and x~[r] (the column of ones with it) lowered by the same -- written into the row's factor and x~ here, at
+// no cost in the epilogue -- and both low planes are WIDE (f16_pair_scaled_wide: the residual times 2^11, the product
+// rescaled when the parts are added), which keeps all 22 bits of an operand down to 2^-13: gaps up to 2^34 lose nothing.
+struct Rows8Scales {
+  float sd, inv_sum, inv_sd;  // dZ1's power of two; 1 / (x~'s times dZ1's); 1 / dZ1's (M slot 7, the ones: no x scale)
+};
+__device__ __forceinline__ Rows8Scales rows8_open(const float (&fac)[2], const float (&xs)[2][2], float inv_w1, int acc_exponent,
+                                                  unsigned wl, int l16, int kq, u32x4 (&xf)[2]) {
+  float most[2];
+  int ex[2], ef[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    most[rt] = rows8_row4(__builtin_fmaxf(__builtin_fabsf(xs[rt][0]), __builtin_fabsf(xs[rt][1])), false);
+    ex[rt] = f16_bound_exponent(most[rt]);
+    ef[rt] = f16_bound_exponent(__builtin_fabsf(fac[rt]));
+    uint32_t hi, lo;
+    f16_pair_scaled(xs[rt][0], xs[rt][1], __builtin_amdgcn_ldexpf(1.0f, kF16Top - ex[rt]), hi, lo);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t h = __shfl(hi, l16 + 16 * j, kWave), l = __shfl(lo, l16 + 16 * j, kWave);
+      xf[rt][j] = (kq & 1) ? l : h;
+    }
+  }
+  int exw = ex[0] > ex[1] ? ex[0] : ex[1], efw = ef[0] > ef[1] ? ef[0] : ef[1];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    const int a = __shfl_xor(exw, off, kWave), b = __shfl_xor(efw, off, kWave);
+    exw = a > exw ? a : exw;
+    efw = b > efw ? b : efw;
+  }
+  const float k2048 = 2048.0f;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int gap = efw - ef[rt], half = (gap > 48 ? 48 : gap) >> 1;
+    if (kq == 0) {
+      lds_write_b32(wl + kRows8FacOff + (16 * rt + l16) * 4, __builtin_amdgcn_ldexpf(fac[rt], half));
+      lds_write_b32(wl + kRows8InvOff + (16 * rt + l16) * 4, __builtin_amdgcn_ldexpf(inv_w1, ex[rt] - kF16Top));
+    }
+    uint32_t hi, lo;
+    f16_pair_scaled_wide(xs[rt][0], xs[rt][1], __builtin_amdgcn_ldexpf(1.0f, kF16Top - exw - half), k2048, hi, lo);
+    if (kq == 3) {  // slot 7: the column of ones (db1), 2^-half as the row's x~ is; slot 15: nothing
+      const uint32_t one = half <= 14 ? (uint32_t)(15 - half) << 10 : 1u << (24 - half);
+      hi = (hi & 0xffffu) | (one << 16);
+      lo &= 0xffffu;
+    }
+    const unsigned at = wl + kRows8XtOff + (2 * kq * 32 + 16 * rt + l16) * 2;
+    lds_write_b16(at, hi);
+    lds_write_b16_hi(at + 64, hi);
+    lds_write_b16(at + 8 * 64, lo);
+    lds_write_b16_hi(at + 9 * 64, lo);
+  }
+  Rows8Scales out;
+  out.sd = __builtin_amdgcn_ldexpf(1.0f, kF16Top - acc_exponent - efw);
+  out.inv_sum = __builtin_amdgcn_ldexpf(1.0f, (exw - kF16Top) + (efw + acc_exponent - kF16Top));
+  out.inv_sd = __builtin_amdgcn_ldexpf(1.0f, efw + acc_exponent - kF16Top);
+  return out;
+}
+
+// Epilogue: dZ1 = acc * factor * (h1 > 0), folded into the workgroup's running sums (see above).  `base`: LDS address
+// of the W1 planes (b1, sums, counters behind them); `done`: column tiles this wave has published before this tile.
+__device__ __forceinline__ void rows8_epilogue(const f32x4 (&acc)[2][16], const u32x4 (&xf)[2], unsigned wl, unsigned base,
+                                               int wave, int done, Rows8Scales scales, int lane) {
+  int lane_e = lane;  // (opaque copy: see the forward kernel's epilogue)
+  asm volatile("" : "+v"(lane_e));
+  const int l16e = lane_e & 15, kqe = lane_e >> 4;
+  const unsigned planes_at = base + (kqe >> 1) * 256 + l16e * 16, b1_at = base + kRows8Planes + l16e * 4;
+  const unsigned sums_at = base + kRows8Planes + 1024 + l16e * 32 + (kqe & 1) * 16;
+  const unsigned prog_at = base + kRows8Planes + 1024 + kRows8Sums + 4 * wave;  // the predecessor's counter; own: + 4
+  u32x4 fq[2], iq[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    fq[rt] = rt == 0 ? lds_read_b128<kRows8FacOff>(wl + 16 * kqe) : lds_read_b128<kRows8FacOff + 64>(wl + 16 * kqe);
+    iq[rt] = rt == 0 ? lds_read_b128<kRows8InvOff>(wl + 16 * kqe) : lds_read_b128<kRows8InvOff + 64>(wl + 16 * kqe);
+  }
+  const u32x2 xa0 = lds_read_b64<kRows8XtOff>(wl + l16e * 64 + kqe * 8), xa1 = lds_read_b64<kRows8XtOff + 32>(wl + l16e * 64 + kqe * 8);
+  u32x4 w1f[2];
+  uint32_t b1c[2];
+  auto request_consts = [&](int ct, int set) {
+    w1f[set] = lds_read_b128<0>(planes_at + ct * 512);
+    b1c[set] = lds_read_b32_nowait<0>(b1_at + ct * 64);
+  };
+  request_consts(0, 0);
+  u32x4 xa;
+  const float k2048 = 2048.0f;
+#pragma unroll
+  for (int ct = 0; ct < 16; ++ct) {
+    const int set = ct & 1;
+    uint32_t pr = lds_read_b32_nowait<0>(prog_at);
+    u32x4 sq = lds_read_b128<0>(sums_at + ct * 512);
+    if (ct + 1 < 16) request_consts(ct + 1, set ^ 1);
+    if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w1f[set]), "+v"(b1c[set]));
+    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w1f[set]), "+v"(b1c[set]));
+    if (ct == 0) {
+      u32x2 a0 = xa0, a1 = xa1;
+      asm volatile("" : "+v"(fq[0]), "+v"(fq[1]), "+v"(iq[0]), "+v"(iq[1]), "+v"(a0), "+v"(a1));
+      xa = u32x4{a0[0], a0[1], a1[0], a1[1]};
+    }
+    const f32x4 zero = {0, 0, 0, 0};
+    float dz[8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const f32x4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, xf[rt]), __builtin_bit_cast(half8, w1f[set]), zero, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pre = __builtin_fmaf(z[r], __uint_as_float(iq[rt][r]), __uint_as_float(b1c[set]));
+        dz[4 * rt + r] = select_or_zero(positive_mask(pre), acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
+      }
+    }
+    u32x4 dh, dl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t h, l;
+      f16_pair_scaled_wide(dz[2 * j], dz[2 * j + 1], scales.sd, k2048, h, l);
+      dh[j] = h;
+      dl[j] = l;
+    }
+    // slots 0..7: x~hi . (Dhi | Dlo'), slots 8..15: x~lo' . (Dhi | Dlo'); the primes carry 2^11
+    const f32x4 o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, xa), __builtin_bit_cast(half8, dh), zero, 0, 0, 0);
+    const f32x4 o2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, xa), __builtin_bit_cast(half8, dl), zero, 0, 0, 0);
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // the lanes of slots 8..15 hand their parts to those of slots 0..7
+      const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(o1[r]), __float_as_uint(o1[r]), false, false);
+      const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(o2[r]), __float_as_uint(o2[r]), false, false);
+      const float mid = __uint_as_float(s1[1]) + __uint_as_float(s2[0]);  // x~lo' . Dhi + x~hi . Dlo'
+      v[r] = __builtin_fmaf(__uint_as_float(s2[1]), 0x1p-22f, __builtin_fmaf(mid, 0x1p-11f, __uint_as_float(s1[0])));
+    }
+    // this block's sums as the predecessor left them: once its counter says so (polled inside ONE asm statement: a C++
+    // loop per block costs the register allocator its grip on the whole kernel -- 936 bytes of scratch)
+    const int need = done + ct + 1;
+    {
+      const unsigned sa = sums_at + ct * 512;
+      int seen;
+      if (ct + 1 < 16)
+        asm volatile("s_waitcnt lgkmcnt(2)\n"
+                     ".Lrows8_poll_%=:\n\t"
+                     "v_readfirstlane_b32 %2, %0\n\t"
+                     "s_nop 3\n\t"
+                     "s_cmp_ge_i32 %2, %5\n\t"
+                     "s_cbranch_scc1 .Lrows8_done_%=\n\t"
+                     "ds_read_b32 %0, %3\n\t"
+                     "ds_read_b128 %1, %4\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "s_branch .Lrows8_poll_%=\n"
+                     ".Lrows8_done_%=:"
+                     : "+v"(pr), "+v"(sq), "=&s"(seen)
+                     : "v"(prog_at), "v"(sa), "s"(need)
+                     : "scc", "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)\n"
+                     ".Lrows8_poll_%=:\n\t"
+                     "v_readfirstlane_b32 %2, %0\n\t"
+                     "s_nop 3\n\t"
+                     "s_cmp_ge_i32 %2, %5\n\t"
+                     "s_cbranch_scc1 .Lrows8_done_%=\n\t"
+                     "ds_read_b32 %0, %3\n\t"
+                     "ds_read_b128 %1, %4\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "s_branch .Lrows8_poll_%=\n"
+                     ".Lrows8_done_%=:"
+                     : "+v"(pr), "+v"(sq), "=&s"(seen)
+                     : "v"(prog_at), "v"(sa), "s"(need)
+                     : "scc", "memory");
+    }
+    if (kqe < 2) {
+      u32x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        w[r] = __float_as_uint(__builtin_fmaf(v[r], r == 3 && kqe == 1 ? scales.inv_sd : scales.inv_sum, __uint_as_float(sq[r])));
+      lds_write_b128<0>(sums_at + ct * 512, w);
+    }
+    if (lane_e == 0) lds_write_b32(prog_at + 4, __int_as_float(need));
+    __builtin_amdgcn_sched_barrier(0);  // (a block's arithmetic stays in its block: sixteen z1 products hoisted are 64 registers)
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <int DIN, int NOUT, int RING>
 __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
     const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ dout, int64_t m, const void *__restrict__ w2ts, float *__restrict__ partials,
-    int partial_stride, int head_rows, const uint32_t *__restrict__ gate2) {
-  constexpr int kIn = DIN, d_in = DIN;
+    int partial_stride, int head_rows, const uint32_t *__restrict__ gate2, int d_in_arg) {
+  constexpr bool kMma1 = DIN > 3;  // class 8: run-time d_in = 4..7, layer 1 on the matrix pipe (rows8_* above)
+  constexpr int kIn = DIN;
+  const int d_in = kMma1 ? d_in_arg : DIN;
+  constexpr int kXRegs = kMma1 ? 2 : kIn;          // inputs a lane loads per row (class 8: the pair 2 kq, 2 kq + 1)
+  constexpr int kRowLoads = 2 * (1 + kXRegs);      // a tile's row loads per lane
   constexpr int kTile = 128;
   constexpr int kAhead = RING - 1;
-  constexpr int kRec = rows_record(DIN);
-  static_assert(DIN >= 1 && DIN <= 3, "wider observations keep the previous kernel (LDS: running sums per wave)");
-  static_assert(rows_dgrad_lds_bytes(RING, kIn) <= 80 * 1024, "two workgroups per CU");
+  constexpr int kRec = kMma1 ? 0 : rows_record(DIN);
+  static_assert((DIN >= 1 && DIN <= 3) || DIN == 8, "width classes");
+  static_assert((kMma1 ? rows8_dgrad_lds_bytes(RING, 0) : rows_dgrad_lds_bytes(RING, kIn)) <= 80 * 1024, "two workgroups per CU");
   static_assert(kAhead >= 2, "the mid-step barrier publishes a chunk requested at least a half-step earlier");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [ring][layer-1 records [256][kRec]][per wave: gate block 1 KiB | factors [32] | observations [DIN][32] | sums [256][kRec]]
   const unsigned lds0 = lds_offset(smem);
+  // (class 8: [ring][W1 planes | b1 | sums [256][8] | counters][per wave: gate block | factors | 1 / x scale | x~])
   constexpr int kRecOff = RING * kRowsChunk;
-  constexpr int kWaveOff = kRecOff + kRec * kHidden * 4;
-  constexpr int kWaveBytes = 1024 + 32 * (1 + kIn) * 4 + kRec * kHidden * 4;
+  constexpr int kWaveOff = kMma1 ? kRecOff + kRows8Planes + 1024 + kRows8Sums + 64 : kRecOff + kRec * kHidden * 4;
+  constexpr int kWaveBytes = kMma1 ? kRows8Wave : 1024 + 32 * (1 + kIn) * 4 + kRec * kHidden * 4;
   constexpr int kFacOff = 1024, kObsOff = kFacOff + 32 * 4, kSumOff = kObsOff + 32 * kIn * 4;
   const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -849,7 +1121,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
   const int64_t stride = gridDim.x;
 
   // layer-1 records (columns of this kernel = hidden units of layer 1) and zeroed running sums
-  {
+  [[maybe_unused]] float inv_w1 = 1.0f;
+  if constexpr (kMma1) {
+    inv_w1 = rows8_constants(smem + kRecOff, reinterpret_cast<float *>(smem), w1, b1, d_in, tid);
+  } else {
     float *rec = reinterpret_cast<float *>(smem + kRecOff);
     rec[tid * kRec] = b1[tid];
 #pragma unroll
@@ -863,7 +1138,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
     const int64_t left = tile < tiles ? m - tile * kTile - 32 * wave : 0;
     return left <= 0 ? 0 : left < 32 ? (int)left : 32;
   };
-  auto load_rows = [&](float (&d)[2], float (&xs)[2][kIn], int64_t tile) {
+  auto load_rows = [&](float (&d)[2], float (&xs)[2][kXRegs], int64_t tile) {
     const int rows = wave_rows(tile);
     const int64_t r0 = tile * kTile + 32 * wave;
     const __amdgpu_buffer_rsrc_t drsrc = buffer_rsrc(rows > 0 ? dout + r0 * NOUT : dout, rows * NOUT * 4);
@@ -871,8 +1146,14 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       d[rt] = buffer_load_f32(drsrc, (16 * rt + l16) * NOUT * 4, 0);
+      if constexpr (kMma1) {  // (inputs past d_in: an offset past the descriptor's end, which reads as zero)
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) xs[rt][i] = buffer_load_f32(xrsrc, ((16 * rt + l16) * d_in + i) * 4, 0);
+        for (int j = 0; j < 2; ++j)
+          xs[rt][j] = buffer_load_f32(xrsrc, 2 * kq + j < d_in ? ((16 * rt + l16) * d_in + 2 * kq + j) * 4 : 0x7ffffff0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) xs[rt][i] = buffer_load_f32(xrsrc, ((16 * rt + l16) * d_in + i) * 4, 0);
+      }
     }
   };
   // the wave's gate block of `tile` -> its LDS block (rows past the end arrive as zeros: gate closed)
@@ -891,7 +1172,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
   const unsigned b_lane = lds0 + (kq >> 1) * 8192 + ((kq & 1) * 32 + l16) * 16;
   const unsigned g_lane = wave_lds + l16 * 32 + kq;  // the gate byte of k block S: + 4 S (+ 512 for row tile 1)
 
-  float dc[2], dn[2], xc[2][kIn], xn[2][kIn];  // this tile's / the next tile's d and observations of this lane's rows
+  float dc[2], dn[2], xc[2][kXRegs], xn[2][kXRegs];  // this tile's / the next tile's d and observations of this lane's rows
+  [[maybe_unused]] u32x4 xf[2];         // class 8: the rows' z1 fragments
+  [[maybe_unused]] Rows8Scales scales8 = {1.0f, 1.0f, 1.0f};
+  [[maybe_unused]] int done8 = 0;       // class 8: column tiles this wave has published
   f32x4 acc[2][16];
   u32x4 a_g[2][2];     // gate fragments: [set = k block parity][row tile]
   u32x4 bh[2], bl[2];  // B fragments of local column tile ctl: set ctl % 2, requested one slot ahead
@@ -972,7 +1256,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
         // were allowed to be still in flight.  The four-chunk ring of d_in = 1 was right.)
         constexpr int kExtra = KIND == 2                 ? 1
                                : KIND == 3               ? (kAhead >= 3 ? 1 : 0)
-                               : (FIRST && (C == 0 || kAhead >= 3)) ? 2 * (1 + kIn)
+                               : (FIRST && (C == 0 || kAhead >= 3)) ? kRowLoads
                                                          : 0;
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (kAhead - 2) + kExtra) : "memory");
       }
@@ -1014,7 +1298,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1v));
       a_g[0][0] = gate_fragment(b0);
       a_g[0][1] = gate_fragment(b1v);
-      if (kq == 0) {
+      if constexpr (kMma1) {
+        const float fac[2] = {dc[0] * inv_w2_scale, dc[1] * inv_w2_scale};
+        scales8 = rows8_open(fac, xc, inv_w1, 22, wave_lds, l16, kq, xf);  // |acc| < 256 x 2^14: gate x planes below 2^14
+      } else if (kq == 0) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           lds_write_b32(wave_lds + kFacOff + (16 * rt + l16) * 4, dc[rt] * inv_w2_scale);
@@ -1041,105 +1328,110 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
     do_half(F{}, I1{}, I1{}, K3{}, kRowsHalfSteps - 1, stage, tile);  next_stage();
 
     // ---- epilogue: dZ1 = dH1 * factor * (h1 > 0), folded into the wave's running column sums ---------------------------
-    // this lane: columns 16 ct + l16; rows 16 rt + 4 kq + r.  Factors / observations of those rows from the exchange.
-    int lane_e = lane;  // (opaque copy: see the forward kernel's epilogue)
-    asm volatile("" : "+v"(lane_e));
-    const int l16e = lane_e & 15, kqe = lane_e >> 4;
-    const unsigned wl = lds0 + kWaveOff + wave * kWaveBytes;
-    u32x4 fq[2], xq[2][kIn];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      fq[rt] = rt == 0 ? lds_read_b128<kFacOff>(wl + 16 * kqe) : lds_read_b128<kFacOff + 64>(wl + 16 * kqe);
-#pragma unroll
-      for (int i = 0; i < kIn; ++i)
-        xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
-                               : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
-                                        : lds_read_b128<kObsOff + 256>(wl + 16 * kqe))
-                            : (i == 0   ? lds_read_b128<kObsOff + 64>(wl + 16 * kqe)
-                               : i == 1 ? lds_read_b128<kObsOff + 128 + 64>(wl + 16 * kqe)
-                                        : lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe));
-    }
-    // per column tile: the column's layer-1 record and its running sums (read-modify-write by the lanes kq == ct % 4)
-    const unsigned rec_at = lds0 + kRecOff + l16e * (kRec * 4), sum_at = wl + kSumOff + l16e * (kRec * 4);
-    typedef typename std::conditional<kRec == 2, u32x2, u32x4>::type rec_t;
-    rec_t rq[2], sq[2];
-    auto request_col = [&](int ct, int set) {
-      const unsigned ra = rec_at + ct * (16 * kRec * 4), sa = sum_at + ct * (16 * kRec * 4);
-      if constexpr (kRec == 2) {
-        rq[set] = lds_read_b64<0>(ra);
-        sq[set] = lds_read_b64<0>(sa);
-      } else {
-        rq[set] = lds_read_b128<0>(ra);
-        sq[set] = lds_read_b128<0>(sa);
-      }
-    };
-    request_col(0, 0);
-#pragma unroll
-    for (int ct = 0; ct < 16; ++ct) {
-      const int set = ct & 1;
-      if (ct + 1 < 16) request_col(ct + 1, set ^ 1);
-      if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
-      if (ct == 0) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          asm volatile("" : "+v"(fq[rt]));
-#pragma unroll
-          for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
-        }
-      }
-      const float b1c = __uint_as_float(rq[set][0]);
-      float w1c[kIn];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
-      float db = 0.0f, dw[kIn];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
-#pragma unroll
+    if constexpr (kMma1) {
+      rows8_epilogue(acc, xf, lds0 + kWaveOff + wave * kWaveBytes, lds0 + kRecOff, wave, done8, scales8, lane);
+      done8 += 16;
+    } else {
+      // this lane: columns 16 ct + l16; rows 16 rt + 4 kq + r.  Factors / observations of those rows from the exchange.
+      int lane_e = lane;  // (opaque copy: see the forward kernel's epilogue)
+      asm volatile("" : "+v"(lane_e));
+      const int l16e = lane_e & 15, kqe = lane_e >> 4;
+      const unsigned wl = lds0 + kWaveOff + wave * kWaveBytes;
+      u32x4 fq[2], xq[2][kIn];
+  #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        float pre[4];
-        unsigned long long open[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pre[r] = b1c;
-#pragma unroll
-          for (int i = 0; i < kIn; ++i) pre[r] = __builtin_fmaf(__uint_as_float(xq[rt][i][r]), w1c[i], pre[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) open[r] = positive_mask(pre[r]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
-          db += dz;
-#pragma unroll
-          for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
-        }
+        fq[rt] = rt == 0 ? lds_read_b128<kFacOff>(wl + 16 * kqe) : lds_read_b128<kFacOff + 64>(wl + 16 * kqe);
+  #pragma unroll
+        for (int i = 0; i < kIn; ++i)
+          xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
+                                 : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
+                                          : lds_read_b128<kObsOff + 256>(wl + 16 * kqe))
+                              : (i == 0   ? lds_read_b128<kObsOff + 64>(wl + 16 * kqe)
+                                 : i == 1 ? lds_read_b128<kObsOff + 128 + 64>(wl + 16 * kqe)
+                                          : lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe));
       }
-      // the four lanes of a column (kq = 0..3) in a fixed order, then the running sums by one of them
-      auto across = [&](float v) {
-        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        const float u = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
-        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
-        return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+      // per column tile: the column's layer-1 record and its running sums (read-modify-write by the lanes kq == ct % 4)
+      const unsigned rec_at = lds0 + kRecOff + l16e * (kRec * 4), sum_at = wl + kSumOff + l16e * (kRec * 4);
+      typedef typename std::conditional<kRec == 2, u32x2, u32x4>::type rec_t;
+      rec_t rq[2], sq[2];
+      auto request_col = [&](int ct, int set) {
+        const unsigned ra = rec_at + ct * (16 * kRec * 4), sa = sum_at + ct * (16 * kRec * 4);
+        if constexpr (kRec == 2) {
+          rq[set] = lds_read_b64<0>(ra);
+          sq[set] = lds_read_b64<0>(sa);
+        } else {
+          rq[set] = lds_read_b128<0>(ra);
+          sq[set] = lds_read_b128<0>(sa);
+        }
       };
-      db = across(db);
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
-      if (kqe == (ct & 3)) {
-        const unsigned sa = sum_at + ct * (16 * kRec * 4);
-        lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
-#pragma unroll
-        for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
+      request_col(0, 0);
+  #pragma unroll
+      for (int ct = 0; ct < 16; ++ct) {
+        const int set = ct & 1;
+        if (ct + 1 < 16) request_col(ct + 1, set ^ 1);
+        if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
+        if (ct == 0) {
+  #pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            asm volatile("" : "+v"(fq[rt]));
+  #pragma unroll
+            for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
+          }
+        }
+        const float b1c = __uint_as_float(rq[set][0]);
+        float w1c[kIn];
+  #pragma unroll
+        for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
+        float db = 0.0f, dw[kIn];
+  #pragma unroll
+        for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
+  #pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          float pre[4];
+          unsigned long long open[4];
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pre[r] = b1c;
+  #pragma unroll
+            for (int i = 0; i < kIn; ++i) pre[r] = __builtin_fmaf(__uint_as_float(xq[rt][i][r]), w1c[i], pre[r]);
+          }
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) open[r] = positive_mask(pre[r]);
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
+            db += dz;
+  #pragma unroll
+            for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
+          }
+        }
+        // the four lanes of a column (kq = 0..3) in a fixed order, then the running sums by one of them
+        auto across = [&](float v) {
+          const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+          const float u = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+          const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+          return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+        };
+        db = across(db);
+  #pragma unroll
+        for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
+        if (kqe == (ct & 3)) {
+          const unsigned sa = sum_at + ct * (16 * kRec * 4);
+          lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
+  #pragma unroll
+          for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // the workgroup's next tile
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       dc[rt] = dn[rt];
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) xc[rt][i] = xn[rt][i];
+      for (int i = 0; i < kXRegs; ++i) xc[rt][i] = xn[rt][i];
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1150,17 +1442,25 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
   float *row = partials + (int64_t)blockIdx.x * partial_stride;
   {
     const int t = tid;
-    float tot[1 + kIn];
+    if constexpr (kMma1) {  // the workgroup's one array: [unit][dW1 row 0..6 | db1]
+      const float *sums = reinterpret_cast<const float *>(smem + kRecOff + kRows8Planes + 1024);
+      row[kHidden * d_in + t] = sums[t * 8 + 7];
 #pragma unroll
-    for (int i = 0; i < 1 + kIn; ++i) tot[i] = 0.0f;
-    for (int w = 0; w < 4; ++w) {
-      const float *sums = reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff);
+      for (int i = 0; i < 7; ++i)
+        if (i < d_in) row[t * d_in + i] = sums[t * 8 + i];
+    } else {
+      float tot[1 + kIn];
 #pragma unroll
-      for (int i = 0; i < 1 + kIn; ++i) tot[i] += sums[t * kRec + i];
+      for (int i = 0; i < 1 + kIn; ++i) tot[i] = 0.0f;
+      for (int w = 0; w < 4; ++w) {
+        const float *sums = reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff);
+#pragma unroll
+        for (int i = 0; i < 1 + kIn; ++i) tot[i] += sums[t * kRec + i];
+      }
+      row[kHidden * d_in + t] = tot[0];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) row[t * d_in + i] = tot[1 + i];
     }
-    row[kHidden * d_in + t] = tot[0];
-#pragma unroll
-    for (int i = 0; i < kIn; ++i) row[t * d_in + i] = tot[1 + i];
     // the head-gradient segments of the first head_rows rows belong to the weight-gradient kernel; rows beyond them are zero
     if ((int)blockIdx.x >= head_rows)
       for (int idx = kHidden * d_in + kHidden + t; idx < partial_stride; idx += kBlock) row[idx] = 0.0f;
@@ -1170,12 +1470,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
 template <int DIN, int NOUT>
 static int launch_rows_backward_gate(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                      int64_t m, const void *w2ts, float *partials, int stride, int head_rows,
-                                     const uint32_t *gate2) {
+                                     const uint32_t *gate2, int d_in) {
   constexpr int kRing = DIN == 1 ? 4 : 3;
   auto kernel = &mlp_rows_backward_gate_kernel<DIN, NOUT, kRing>;
   static LdsOptIn lds_attr_set_0;
   if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(kernel), 160 * 1024)) return e_lds_attr_set_0;
-  kernel<<<grid, kBlock, rows_dgrad_lds_bytes(kRing, DIN), s>>>(x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2);
+  constexpr int kLds = DIN > 3 ? rows8_dgrad_lds_bytes(kRing, 0) : rows_dgrad_lds_bytes(kRing, DIN);
+  kernel<<<grid, kBlock, kLds, s>>>(x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2, d_in);
   return launch_status();
 }
 
@@ -1184,9 +1485,12 @@ static int launch_rows_backward_gate(int grid, hipStream_t s, const float *x, co
 int mlp_rows_backward_gate_dispatch(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                     int64_t m, int d_in, const void *w2ts, int n_out, float *partials, int stride, int head_rows,
                                     const uint32_t *gate2) {
+  const int dc = d_in <= 3 ? d_in : d_in <= 7 ? 8 : 0;  // (class 8 keeps M slot 7 for db1: seven inputs)
+  if (dc == 8 && env_int("RL8_MLP_DGRAD_WIDE_TILE")) return -1;  // (A/B: the tile kernel at d_in = 4, 5)
 #define RL8_ROWS_BWD(D, N) \
-  if (d_in == D && n_out == N) return launch_rows_backward_gate<D, N>(grid, s, x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2);
+  if (dc == D && n_out == N) return launch_rows_backward_gate<D, N>(grid, s, x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2, d_in);
   RL8_ROWS_BWD(1, 1) RL8_ROWS_BWD(1, 2) RL8_ROWS_BWD(2, 1) RL8_ROWS_BWD(2, 2) RL8_ROWS_BWD(3, 1) RL8_ROWS_BWD(3, 2)
+  RL8_ROWS_BWD(8, 1) RL8_ROWS_BWD(8, 2)
 #undef RL8_ROWS_BWD
   return -1;
 }
@@ -1209,22 +1513,27 @@ template <int DIN, int KOUT, int RING>
 __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
     const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ dout, int64_t m, const void *__restrict__ w2ts, const float *__restrict__ w3,
-    float *__restrict__ partials, int partial_stride, int head_rows, const uint32_t *__restrict__ gate2, int n_out) {
-  constexpr int kIn = DIN, d_in = DIN;
+    float *__restrict__ partials, int partial_stride, int head_rows, const uint32_t *__restrict__ gate2, int n_out,
+    int d_in_arg) {
+  constexpr bool kMma1 = DIN > 3;  // class 8: run-time d_in = 4..7, layer 1 on the matrix pipe (rows8_* above)
+  constexpr int kIn = DIN;
+  const int d_in = kMma1 ? d_in_arg : DIN;
+  constexpr int kXRegs = kMma1 ? 2 : kIn;
   constexpr int kTile = 128;
   constexpr int kAhead = RING - 1;
-  constexpr int kRec = rows_record(DIN);
-  static_assert(DIN >= 1 && DIN <= 3, "wider observations keep the tile kernel (LDS: running sums per wave)");
+  constexpr int kRec = kMma1 ? 0 : rows_record(DIN);
+  static_assert((DIN >= 1 && DIN <= 3) || DIN == 8, "width classes");
   static_assert(KOUT == 2 || KOUT == 4, "W3 records of 8 or 16 bytes");
-  static_assert(rows_dgrad_general_lds_bytes(RING, kIn, KOUT) <= 80 * 1024, "two workgroups per CU");
+  static_assert((kMma1 ? rows8_dgrad_lds_bytes(RING, KOUT) : rows_dgrad_general_lds_bytes(RING, kIn, KOUT)) <= 80 * 1024, "two workgroups per CU");
   static_assert(kAhead >= 2, "the mid-step barrier publishes a chunk requested at least a half-step earlier");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [ring][layer-1 records [256][kRec]][W3 records [256][KOUT]][per wave: gate block | factors [32] | observations [DIN][32] | sums [256][kRec]]
   const unsigned lds0 = lds_offset(smem);
   constexpr int kRecOff = RING * kRowsChunk;
-  constexpr int kW3Off = kRecOff + kRec * kHidden * 4;
+  // (class 8: [ring][W1 planes | b1 | sums [256][8] | counters][W3 records][per wave: gate block | factors | 1 / x scale | x~])
+  constexpr int kW3Off = kRecOff + (kMma1 ? kRows8Planes + 1024 + kRows8Sums + 64 : kRec * kHidden * 4);
   constexpr int kWaveOff = kW3Off + KOUT * kHidden * 4;
-  constexpr int kWaveBytes = 1024 + 32 * (1 + kIn) * 4 + kRec * kHidden * 4;
+  constexpr int kWaveBytes = kMma1 ? kRows8Wave : 1024 + 32 * (1 + kIn) * 4 + kRec * kHidden * 4;
   constexpr int kFacOff = 1024, kObsOff = kFacOff + 32 * 4, kSumOff = kObsOff + 32 * kIn * 4;
   constexpr int kFar = 0x7fffff00;  // beyond every descriptor: reads as zero
   const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
@@ -1238,11 +1547,15 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
 
   // layer-1 records, W3 records (column k of W3: [k][KOUT]), zeroed running sums; max_k |W3[o][k]| over the workgroup
   float w3max[KOUT];
+  [[maybe_unused]] float inv_w1 = 1.0f;
+  if constexpr (kMma1) inv_w1 = rows8_constants(smem + kRecOff, reinterpret_cast<float *>(smem) + 16, w1, b1, d_in, tid);
   {
-    float *rec = reinterpret_cast<float *>(smem + kRecOff);
-    rec[tid * kRec] = b1[tid];
+    if constexpr (!kMma1) {
+      float *rec = reinterpret_cast<float *>(smem + kRecOff);
+      rec[tid * kRec] = b1[tid];
 #pragma unroll
-    for (int i = 0; i < kRec - 1; ++i) rec[tid * kRec + 1 + i] = i < kIn ? w1[tid * d_in + (i < kIn ? i : 0)] : 0.0f;
+      for (int i = 0; i < kRec - 1; ++i) rec[tid * kRec + 1 + i] = i < kIn ? w1[tid * d_in + (i < kIn ? i : 0)] : 0.0f;
+    }
     float *w3r = reinterpret_cast<float *>(smem + kW3Off);
     float mine[KOUT];
 #pragma unroll
@@ -1251,8 +1564,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
       w3r[tid * KOUT + q] = v;
       mine[q] = __builtin_fabsf(v);
     }
-    float *sums = reinterpret_cast<float *>(smem + kWaveOff + wave * kWaveBytes + kSumOff);
-    for (int idx = lane; idx < kRec * kHidden; idx += kWave) sums[idx] = 0.0f;
+    if constexpr (!kMma1) {
+      float *sums = reinterpret_cast<float *>(smem + kWaveOff + wave * kWaveBytes + kSumOff);
+      for (int idx = lane; idx < kRec * kHidden; idx += kWave) sums[idx] = 0.0f;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
@@ -1276,7 +1591,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
   };
   // this lane's two rows: dOut[row][0 .. n_out) (zeros past n_out and past the end) and the observations: ALWAYS
   // 2 (KOUT + DIN) load instructions (the barriers count them)
-  auto load_rows = [&](float (&d)[2][KOUT], float (&xs)[2][kIn], int64_t tile) {
+  auto load_rows = [&](float (&d)[2][KOUT], float (&xs)[2][kXRegs], int64_t tile) {
     const int rows = wave_rows(tile);
     const int64_t r0 = tile * kTile + 32 * wave;
     const __amdgpu_buffer_rsrc_t drsrc = buffer_rsrc(rows > 0 ? dout + r0 * n_out : dout, rows * n_out * 4);
@@ -1285,8 +1600,14 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
     for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
       for (int q = 0; q < KOUT; ++q) d[rt][q] = buffer_load_f32(drsrc, q < n_out ? ((16 * rt + l16) * n_out + q) * 4 : kFar, 0);
+      if constexpr (kMma1) {  // the pair 2 kq, 2 kq + 1 (inputs past d_in read as zero)
 #pragma unroll
-      for (int i = 0; i < kIn; ++i) xs[rt][i] = buffer_load_f32(xrsrc, ((16 * rt + l16) * d_in + i) * 4, 0);
+        for (int j = 0; j < 2; ++j)
+          xs[rt][j] = buffer_load_f32(xrsrc, 2 * kq + j < d_in ? ((16 * rt + l16) * d_in + 2 * kq + j) * 4 : kFar, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < kIn; ++i) xs[rt][i] = buffer_load_f32(xrsrc, ((16 * rt + l16) * d_in + i) * 4, 0);
+      }
     }
   };
   auto request_gate = [&](int64_t tile) {
@@ -1303,7 +1624,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
   const unsigned g_lane = wave_lds + l16 * 32 + kq;              // the gate byte of k block S: + 4 S (+ 512 for row tile 1)
   const unsigned c_lane = lds0 + kW3Off + kq * (8 * KOUT * 4);   // this lane's eight W3 records of block S: + 32 KOUT 4 S
 
-  float dc[2][KOUT], xc[2][kIn];  // this tile's dOut rows and observations of this lane's rows
+  float dc[2][KOUT], xc[2][kXRegs];  // this tile's dOut rows and observations of this lane's rows
+  [[maybe_unused]] u32x4 xf[2];         // class 8: the rows' z1 fragments
+  [[maybe_unused]] Rows8Scales scales8 = {1.0f, 1.0f, 1.0f};
+  [[maybe_unused]] int done8 = 0;       // class 8: column tiles this wave has published
   float sc[2];          // power of two that places this tile's dZ2 rows in fp16's range
   f32x4 acc[2][16];
   u32x4 a_hi[2][2], a_lo[2][2];  // dZ2 fragments: [set = k block parity][row tile]
@@ -1364,7 +1688,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
     const uint32_t open = (uint32_t)__builtin_amdgcn_sbfe((int)gbyte[rt], (unsigned)e, 1u);  // 0 or ~0
     return __uint_as_float(open & __float_as_uint(g));
   };
-  constexpr int kRowLoads = 2 * (KOUT + kIn);
+  constexpr int kRowLoads = 2 * (KOUT + kXRegs);
 
   auto do_half = [&](auto first_tag, auto cur_tag, auto c_tag, auto kind_tag, int hs, int stage, int64_t tile) {
     constexpr bool FIRST = decltype(first_tag)::value;
@@ -1478,7 +1802,9 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
         sc[rt] = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
         fac[rt] = __builtin_amdgcn_ldexpf(inv_w2_scale, e - kF16Top);
       }
-      if (kq == 0) {
+      if constexpr (kMma1) {
+        scales8 = rows8_open(fac, xc, inv_w1, 36, wave_lds, l16, kq, xf);  // |acc| < 256 x 2^14 x 2^14
+      } else if (kq == 0) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           lds_write_b32(wave_lds + kFacOff + (16 * rt + l16) * 4, fac[rt]);
@@ -1533,97 +1859,103 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
     do_half(F{}, I1{}, I1{}, K3{}, kRowsHalfSteps - 1, stage, tile);  next_stage();
 
     // ---- epilogue: dZ1 = dH1 * factor * (h1 > 0), folded into the wave's running column sums (the gate-mode kernel's) -------
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int l16e = lane_e & 15, kqe = lane_e >> 4;
-    const unsigned wl = lds0 + kWaveOff + wave * kWaveBytes;
-    u32x4 fq[2], xq[2][kIn];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      fq[rt] = rt == 0 ? lds_read_b128<kFacOff>(wl + 16 * kqe) : lds_read_b128<kFacOff + 64>(wl + 16 * kqe);
-#pragma unroll
-      for (int i = 0; i < kIn; ++i)
-        xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
-                               : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
-                                        : lds_read_b128<kObsOff + 256>(wl + 16 * kqe))
-                            : (i == 0   ? lds_read_b128<kObsOff + 64>(wl + 16 * kqe)
-                               : i == 1 ? lds_read_b128<kObsOff + 128 + 64>(wl + 16 * kqe)
-                                        : lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe));
-    }
-    const unsigned rec_at = lds0 + kRecOff + l16e * (kRec * 4), sum_at = wl + kSumOff + l16e * (kRec * 4);
-    typedef typename std::conditional<kRec == 2, u32x2, u32x4>::type rec_t;
-    rec_t rq[2], sq[2];
-    auto request_col = [&](int ct, int set) {
-      const unsigned ra = rec_at + ct * (16 * kRec * 4), sa = sum_at + ct * (16 * kRec * 4);
-      if constexpr (kRec == 2) {
-        rq[set] = lds_read_b64<0>(ra);
-        sq[set] = lds_read_b64<0>(sa);
-      } else {
-        rq[set] = lds_read_b128<0>(ra);
-        sq[set] = lds_read_b128<0>(sa);
-      }
-    };
-    request_col(0, 0);
-#pragma unroll
-    for (int ct = 0; ct < 16; ++ct) {
-      const int set = ct & 1;
-      if (ct == 8) load_rows(dc, xc, tile + stride);
-      if (ct + 1 < 16) request_col(ct + 1, set ^ 1);
-      if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
-      if (ct == 0) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          asm volatile("" : "+v"(fq[rt]));
-#pragma unroll
-          for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
-        }
-      }
-      const float b1c = __uint_as_float(rq[set][0]);
-      float w1c[kIn];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
-      float db = 0.0f, dw[kIn];
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
-#pragma unroll
+    if constexpr (kMma1) {
+      load_rows(dc, xc, tile + stride);  // (both are dead since half-step 13 / the opening)
+      rows8_epilogue(acc, xf, lds0 + kWaveOff + wave * kWaveBytes, lds0 + kRecOff, wave, done8, scales8, lane);
+      done8 += 16;
+    } else {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int l16e = lane_e & 15, kqe = lane_e >> 4;
+      const unsigned wl = lds0 + kWaveOff + wave * kWaveBytes;
+      u32x4 fq[2], xq[2][kIn];
+  #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        float pre[4];
-        unsigned long long open[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pre[r] = b1c;
-#pragma unroll
-          for (int i = 0; i < kIn; ++i) pre[r] = __builtin_fmaf(__uint_as_float(xq[rt][i][r]), w1c[i], pre[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) open[r] = positive_mask(pre[r]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
-          db += dz;
-#pragma unroll
-          for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
-        }
+        fq[rt] = rt == 0 ? lds_read_b128<kFacOff>(wl + 16 * kqe) : lds_read_b128<kFacOff + 64>(wl + 16 * kqe);
+  #pragma unroll
+        for (int i = 0; i < kIn; ++i)
+          xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
+                                 : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
+                                          : lds_read_b128<kObsOff + 256>(wl + 16 * kqe))
+                              : (i == 0   ? lds_read_b128<kObsOff + 64>(wl + 16 * kqe)
+                                 : i == 1 ? lds_read_b128<kObsOff + 128 + 64>(wl + 16 * kqe)
+                                          : lds_read_b128<kObsOff + 256 + 64>(wl + 16 * kqe));
       }
-      auto across = [&](float v) {
-        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        const float u = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
-        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
-        return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+      const unsigned rec_at = lds0 + kRecOff + l16e * (kRec * 4), sum_at = wl + kSumOff + l16e * (kRec * 4);
+      typedef typename std::conditional<kRec == 2, u32x2, u32x4>::type rec_t;
+      rec_t rq[2], sq[2];
+      auto request_col = [&](int ct, int set) {
+        const unsigned ra = rec_at + ct * (16 * kRec * 4), sa = sum_at + ct * (16 * kRec * 4);
+        if constexpr (kRec == 2) {
+          rq[set] = lds_read_b64<0>(ra);
+          sq[set] = lds_read_b64<0>(sa);
+        } else {
+          rq[set] = lds_read_b128<0>(ra);
+          sq[set] = lds_read_b128<0>(sa);
+        }
       };
-      db = across(db);
-#pragma unroll
-      for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
-      if (kqe == (ct & 3)) {
-        const unsigned sa = sum_at + ct * (16 * kRec * 4);
-        lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
-#pragma unroll
-        for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
+      request_col(0, 0);
+  #pragma unroll
+      for (int ct = 0; ct < 16; ++ct) {
+        const int set = ct & 1;
+        if (ct == 8) load_rows(dc, xc, tile + stride);
+        if (ct + 1 < 16) request_col(ct + 1, set ^ 1);
+        if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
+        if (ct == 0) {
+  #pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            asm volatile("" : "+v"(fq[rt]));
+  #pragma unroll
+            for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
+          }
+        }
+        const float b1c = __uint_as_float(rq[set][0]);
+        float w1c[kIn];
+  #pragma unroll
+        for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
+        float db = 0.0f, dw[kIn];
+  #pragma unroll
+        for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
+  #pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          float pre[4];
+          unsigned long long open[4];
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pre[r] = b1c;
+  #pragma unroll
+            for (int i = 0; i < kIn; ++i) pre[r] = __builtin_fmaf(__uint_as_float(xq[rt][i][r]), w1c[i], pre[r]);
+          }
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) open[r] = positive_mask(pre[r]);
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
+            db += dz;
+  #pragma unroll
+            for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
+          }
+        }
+        auto across = [&](float v) {
+          const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+          const float u = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+          const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+          return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+        };
+        db = across(db);
+  #pragma unroll
+        for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
+        if (kqe == (ct & 3)) {
+          const unsigned sa = sum_at + ct * (16 * kRec * 4);
+          lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
+  #pragma unroll
+          for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1633,17 +1965,25 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
   float *row = partials + (int64_t)blockIdx.x * partial_stride;
   {
     const int t = tid;
-    float tot[1 + kIn];
+    if constexpr (kMma1) {  // the workgroup's one array: [unit][dW1 row 0..6 | db1]
+      const float *sums = reinterpret_cast<const float *>(smem + kRecOff + kRows8Planes + 1024);
+      row[kHidden * d_in + t] = sums[t * 8 + 7];
 #pragma unroll
-    for (int i = 0; i < 1 + kIn; ++i) tot[i] = 0.0f;
-    for (int w = 0; w < 4; ++w) {
-      const float *sums = reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff);
+      for (int i = 0; i < 7; ++i)
+        if (i < d_in) row[t * d_in + i] = sums[t * 8 + i];
+    } else {
+      float tot[1 + kIn];
 #pragma unroll
-      for (int i = 0; i < 1 + kIn; ++i) tot[i] += sums[t * kRec + i];
+      for (int i = 0; i < 1 + kIn; ++i) tot[i] = 0.0f;
+      for (int w = 0; w < 4; ++w) {
+        const float *sums = reinterpret_cast<const float *>(smem + kWaveOff + w * kWaveBytes + kSumOff);
+#pragma unroll
+        for (int i = 0; i < 1 + kIn; ++i) tot[i] += sums[t * kRec + i];
+      }
+      row[kHidden * d_in + t] = tot[0];
+#pragma unroll
+      for (int i = 0; i < kIn; ++i) row[t * d_in + i] = tot[1 + i];
     }
-    row[kHidden * d_in + t] = tot[0];
-#pragma unroll
-    for (int i = 0; i < kIn; ++i) row[t * d_in + i] = tot[1 + i];
     if ((int)blockIdx.x >= head_rows)
       for (int idx = kHidden * d_in + kHidden + t; idx < partial_stride; idx += kBlock) row[idx] = 0.0f;
   }
@@ -1652,13 +1992,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
 template <int DIN, int KOUT>
 static int launch_rows_backward_general(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                         int64_t m, const void *w2ts, const float *w3, float *partials, int stride, int head_rows,
-                                        const uint32_t *gate2, int n_out) {
+                                        const uint32_t *gate2, int n_out, int d_in) {
   constexpr int kRing = 3;
   auto kernel = &mlp_rows_backward_general_kernel<DIN, KOUT, kRing>;
   static LdsOptIn opt;
   if (const int e = allow_dynamic_lds(opt, reinterpret_cast<const void *>(kernel), 160 * 1024)) return e;
-  kernel<<<grid, kBlock, rows_dgrad_general_lds_bytes(kRing, DIN, KOUT), s>>>(x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows,
-                                                                             gate2, n_out);
+  constexpr int kLds = DIN > 3 ? rows8_dgrad_lds_bytes(kRing, KOUT) : rows_dgrad_general_lds_bytes(kRing, DIN, KOUT);
+  kernel<<<grid, kBlock, kLds, s>>>(x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out, d_in);
   return launch_status();
 }
 
@@ -1667,10 +2007,12 @@ static int launch_rows_backward_general(int grid, hipStream_t s, const float *x,
 int mlp_rows_backward_general_dispatch(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                        int64_t m, int d_in, const void *w2ts, const float *w3, int n_out, float *partials, int stride,
                                        int head_rows, const uint32_t *gate2) {
+  const int dc = d_in <= 3 ? d_in : d_in <= 7 ? 8 : 0;  // (class 8 keeps M slot 7 for db1: seven inputs)
+  if (dc == 8 && env_int("RL8_MLP_DGRAD_WIDE_TILE")) return -1;  // (A/B: the tile kernel at d_in = 4, 5)
 #define RL8_ROWS_BWD_GENERAL(D) \
-  if (d_in == D && n_out == 2) return launch_rows_backward_general<D, 2>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out); \
-  if (d_in == D && (n_out == 3 || n_out == 4)) return launch_rows_backward_general<D, 4>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out);
-  RL8_ROWS_BWD_GENERAL(1) RL8_ROWS_BWD_GENERAL(2) RL8_ROWS_BWD_GENERAL(3)
+  if (dc == D && n_out == 2) return launch_rows_backward_general<D, 2>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out, d_in); \
+  if (dc == D && (n_out == 3 || n_out == 4)) return launch_rows_backward_general<D, 4>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out, d_in);
+  RL8_ROWS_BWD_GENERAL(1) RL8_ROWS_BWD_GENERAL(2) RL8_ROWS_BWD_GENERAL(3) RL8_ROWS_BWD_GENERAL(8)
 #undef RL8_ROWS_BWD_GENERAL
   return -1;
 }

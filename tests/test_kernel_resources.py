@@ -286,11 +286,16 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
         # twenty live in scratch, none inside the inner loop of eight half-steps and none a hand-issued load's destination
         # (the walker below holds for these variants too); every other class: no scratch at all
         wide = re.search(r"mlp_rows_forward_kernelILi8E", name) is not None
-        assert vgprs <= 256 and (scratch <= 80 if wide else scratch == 0), (name, scratch, vgprs)
+        # the general data gradient's class 8 parks the rows' z1 fragments and the tile's scales (8 + 3 registers, used at
+        # the opening and in the epilogue only) in scratch across the matrix loop: stored at the opening, reloaded behind
+        # the last half-step
+        parked = re.search(r"mlp_rows_backward_general_kernelILi8E", name) is not None
+        assert vgprs <= 256 and (scratch <= 96 if wide or parked else scratch == 0), (name, scratch, vgprs)
         checked += "mlp_rows_forward_kernel" in name
     # width classes {1, 2, 3, 8} x output classes {1, 2, 4, 8} x {inference, h2 stored, gate bits only}
-    # + the gate-mode data gradient, d_in in {1, 2, 3} x n_out in {1, 2}, + the general one, d_in in {1, 2, 3} x KOUT in {2, 4}
-    assert checked == 48 and len(kernels) == 48 + 6 + 6
+    # + the gate-mode data gradient, d_in class in {1, 2, 3, 8} x n_out in {1, 2}, + the general one, the same classes x
+    # KOUT in {2, 4}
+    assert checked == 48 and len(kernels) == 48 + 8 + 8
     for name, body in inflight.kernels_of(text):
         # the spilling class: the inner loop of the rollout's (SAVE 0) and the gate-bits (SAVE 2) variants stays free of
         # scratch; the h2-storing one (SAVE 1, which also carries the optional h1 store) reloads inside it
@@ -305,7 +310,7 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
     assert_no_inflight_register_access(text, "mlp_rows_forward_kernel", min_hand_loads=48 * 100)
     # the rows-per-wave data gradient: same rules (its barriers also count the next tile's row loads and the wave's
     # gate block, so their vmcnt values are not a fixed set)
-    assert_no_inflight_register_access(text, "mlp_rows_backward_gate_kernel", min_hand_loads=6 * 50)
+    assert_no_inflight_register_access(text, "mlp_rows_backward_gate_kernel", min_hand_loads=8 * 50)
     # ... and exactly these: per tile twelve instances of the half-step (0, 1, 2, 3, the loop body's four, 12, 13, 14, 15).
     # A barrier publishes the chunk whose pieces went out kAhead - 1 half-steps earlier; what may be in flight behind those
     # pieces: kAhead - 2 chunks, the row loads of the next tile (half-step 0; half-step 1 only with a four-chunk ring), the
@@ -316,22 +321,25 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
         if not m:
             continue
         d_in, ring = int(m.group(1)), int(m.group(3))
-        ahead, rows = ring - 1, 2 * (1 + d_in)
+        ahead, rows = ring - 1, 2 * (1 + (2 if d_in == 8 else d_in))  # (class 8: a lane loads an input PAIR per row)
         base = 4 * (ahead - 2)
         want = sorted([base + rows, base + (rows if ahead >= 3 else 0)] + [base] * 8 + [base + 1, base + (1 if ahead >= 3 else 0)]
                       + [4 * (ahead - 1)])  # (+ the prologue's)
-        got = sorted(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)\n\ts_barrier", body))
-        assert got == want, (name, got, want)
+        got = [int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)\n\ts_barrier", body)]
+        if d_in == 8 and len(got) == len(want) + 1:  # (class 8: the compiler's own wait in front of the FINAL barrier)
+            assert got[-1] == 0
+            got = got[:-1]
+        assert sorted(got) == want, (name, got, want)
     # the general-head data gradient (round 5): the same ring discipline with 2 (KOUT + d_in) row loads per tile and a
     # three-chunk ring
-    assert_no_inflight_register_access(text, "mlp_rows_backward_general_kernel", min_hand_loads=6 * 100)
+    assert_no_inflight_register_access(text, "mlp_rows_backward_general_kernel", min_hand_loads=8 * 100)
     seen = 0
     for name, body in inflight.kernels_of(text):
         m = re.search(r"mlp_rows_backward_general_kernelILi(\d)ELi(\d)ELi(\d)E", name)
         if not m:
             continue
         d_in, k_out, ring = int(m.group(1)), int(m.group(2)), int(m.group(3))
-        ahead, rows = ring - 1, 2 * (k_out + d_in)
+        ahead, rows = ring - 1, 2 * (k_out + (2 if d_in == 8 else d_in))
         base = 4 * (ahead - 2)
         # (+ the prologue's; and, in some variants, the compiler's own wait in front of the final __syncthreads, which lets
         # the last tile's never-used row loads -- requested in its epilogue for a tile past the end -- stay in flight
@@ -339,10 +347,12 @@ def test_compiled_rows_forward_kernels_resources(tmp_path):
         want = sorted([base + rows, base + (rows if ahead >= 3 else 0)] + [base] * 8 + [base + 1, base + (1 if ahead >= 3 else 0)]
                       + [4 * (ahead - 1)])
         got = [int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)\n\ts_barrier", body)]
-        assert sorted(got[:13]) == want and len(got) <= 14 and all(v <= rows for v in got[13:]), (name, got, want)
+        # (class 8: ... or one of its parked registers' reloads, by the compiler's count; the hand-written vmcnt(0) stands in front)
+        slack = rows + (1 if d_in == 8 else 0)
+        assert sorted(got[:13]) == want and len(got) <= 14 and all(v <= slack for v in got[13:]), (name, got, want)
         assert "v_mfma_f32_16x16x32_f16" in body
         seen += 1
-    assert seen == 6
+    assert seen == 8
     for name, body in inflight.kernels_of(text):
         assert inflight.packed_war(body) == [], name
 

@@ -310,9 +310,10 @@ def test_gate_mode_data_gradient(m, d_in, n_out, case):
         p["w2"][torch.randint(0, 256, (20,), device=DEV, generator=g), torch.randint(0, 256, (20,), device=DEV, generator=g)] = 40.0
         p["w3"][0, 5] = 30.0
     dout = (torch.stack([g0, -g0], 1) if n_out == 2 else g0[:, None]).contiguous()
-    _, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
-                                                 save=True, save_h1=False, save_gate=True)
-    h1 = torch.relu(x @ p["w1"].T + p["b1"])
+    # (h1 as the forward kernel formed it: the backward recomputes ITS pre-activations, bit for bit -- at d_in >= 4 on the
+    # matrix pipe -- so the two never disagree on a gate; torch's own fp32 product may, where z1 rounds to about zero)
+    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                                  save=True, save_gate=True)
     d, a1, a2 = dout.double(), h1.double(), h2.double()
     dz2 = (d @ p["w3"].double()) * (a2 > 0)
     dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
@@ -372,7 +373,7 @@ def test_rank_one_backward_from_the_gate_bits_alone(m, d_in, n_out, x_scale):
     out, _, h2, gate = hip.mlp_tower_forward_split(*args, save=True, save_h1=False, save_gate=True)
     out_b, h1_b, h2_b, gate_b = hip.mlp_tower_forward_split(*args, save=True, save_gate=True, save_h2=False)
     assert h1_b is None and h2_b is None and torch.equal(out_b, out) and torch.equal(gate_b, gate)
-    h1 = torch.relu(x @ p["w1"].T + p["b1"])
+    h1 = hip.mlp_tower_forward_split(*args, save=True)[1]  # (the forward's own: see test_gate_mode_data_gradient)
     d, a1, a2 = dout.double(), h1.double(), h2.double()
     dz2 = (d @ p["w3"].double()) * (a2 > 0)
     dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
@@ -491,9 +492,10 @@ def test_pair_weight_gradient_of_a_two_way_head(m, d_in, monkeypatch):
     g0 = torch.randn(m, device=DEV, generator=g) / m
     g0[torch.rand(m, device=DEV, generator=g) < 0.3] = 0.0   # clipped samples: exact zeros (of either sign below)
     dout = torch.stack([g0, -g0], 1).contiguous()
-    _, _, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
-                                                 save=True, save_h1=False, save_gate=True)
-    h1 = torch.relu(x @ p["w1"].T + p["b1"])
+    # (h1 as the forward kernel formed it: the backward recomputes ITS pre-activations, bit for bit -- at d_in >= 4 on the
+    # matrix pipe -- so the two never disagree on a gate; torch's own fp32 product may, where z1 rounds to about zero)
+    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                                  save=True, save_gate=True)
     d, a1, a2 = dout.double(), h1.double(), h2.double()
     dz2 = (d @ p["w3"].double()) * (a2 > 0)
     dz1 = (dz2 @ p["w2"].double()) * (a1 > 0)
@@ -995,3 +997,51 @@ def test_general_data_gradient_rows_and_tile_kernels_agree(m, d_in, n_out, monke
     again = run(False)
     for k in rows:
         assert torch.equal(rows[k], again[k]), k  # fixed summation order, no race
+
+
+@pytest.mark.parametrize("m,d_in,n_out,pair", [(1, 4, 1, False), (127, 5, 2, True), (4097, 4, 3, False), (33_000, 5, 3, False),
+                                              (70_001, 5, 4, False), (5000, 4, 2, False), (9000, 5, 1, False)])
+def test_wide_data_gradients_follow_the_forwards_gates(m, d_in, n_out, pair, monkeypatch):
+    """Round 5, d_in = 4, 5: the rows-shape data gradients with layer 1 on the matrix pipe (class 8: the gate of h1 is the
+    forward kernel's own z1 again, dW1 / db1 are MFMAs over the wave's rows, one running-sums array per workgroup updated
+    in wave order) beside the tile kernels they replaced (RL8_MLP_DGRAD_WIDE_TILE=1, which recompute the gate with an fp32
+    fma chain).  Reference: fp64 on the forward's saved activations -- h1 included, so a gate the backward opens where
+    the forward closed it shows as an error of the size of one row's term: the class-8 kernels stay at rounding level
+    (2e-6 of the sum of the magnitudes of all terms), the tile kernels within one such term."""
+    g = torch.Generator(device=DEV).manual_seed(11 * m + d_in + n_out)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 3
+    p = _params(g, d_in, n_out)
+    if pair:
+        g0 = torch.randn(m, device=DEV, generator=g) / m
+        dout = torch.stack([g0, -g0], 1).contiguous()
+    else:
+        dout = torch.randn(m, n_out, device=DEV, generator=g) / m
+    dout *= 10.0 ** torch.randint(-3, 2, (m, 1), device=DEV, generator=g).float()
+    w2t = hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                                  save=True, save_gate=True)
+    dz2 = (dout.double() @ p["w3"].double()) * (h2 > 0)
+    dz1 = (dz2 @ p["w2"].double()) * (h1 > 0)
+    want = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0)}
+    inner = (dz2.abs() @ p["w2"].double().abs()) * (h1 > 0)
+    size = {"w1": inner.T @ x.double().abs(), "b1": inner.sum(0)}
+    gate_mode = n_out == 1 or pair
+
+    def run(tile):
+        monkeypatch.setenv("RL8_MLP_DGRAD_WIDE_TILE", "1" if tile else "0")
+        return hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate,
+                                      gate_pack=(lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])) if gate_mode else None,
+                                      assume_general=not gate_mode and n_out == 2)
+
+    rows, tile = run(False), run(True)
+    for k in ("w1", "b1"):
+        floor = size[k].max() * 1e-30 + 1e-300
+        err_rows = float(((rows[k].double() - want[k]).abs() / (size[k] + floor)).max())
+        err_tile = float(((tile[k].double() - want[k]).abs() / (size[k] + floor)).max())
+        assert err_rows < 2e-6, (k, err_rows, err_tile)
+        assert err_tile < 2e-6 + 4.0 / m, (k, err_tile)
+    for k in ("w2", "b2", "w3", "b3"):
+        assert torch.equal(rows[k], tile[k]), k  # (the weight-gradient kernel's: the same launch both times)
+    again = run(False)
+    for k in rows:
+        assert torch.equal(rows[k], again[k]), k  # the chain of waves adds in a fixed order: bit for bit
