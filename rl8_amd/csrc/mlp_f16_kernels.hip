@@ -117,13 +117,11 @@ constexpr int f16_backward_lds_bytes(int k_in) {
   return 2 * kF16StageBytes + kHidden * (1 + k_in) * 4 + kSplitRows * 32 + 2 * kSplitRows * 4;
 }
 
-// GATE: heads whose dZ2 is rank one in (sample, unit) -- one output, or two outputs with exactly opposite
-// gradients (a two-way categorical): dZ2[s][k] = G[s][k] * d[s] * w3e[k], so
-//   dH1[s][i] = d[s] * sum_k G[s][k] * (w3e[k] W2[k][i]):
-// the A operand is the gate itself, ONE fp16 plane of zeros and ones made from the gate bits without any
-// arithmetic, B the two planes of w3e[k] W2[k][i] (rl8_mlp_pack_w2_f16_gate): TWO products per 16 k instead
-// of three, no split on the VALU, and d[s] joins the row factor applied to the accumulators.
-template <int DIN, int NOUT, bool GATE = false>
+// (Round 5: this tile-shaped kernel is the REFERENCE implementation of the general data gradient -- what the rows-shape
+// kernels of mlp_rows_kernels.hip are checked against in tests/, RL8_MLP_DGRAD_TILE=1 --
+// and the path of single-output heads when the gate kernels are switched off; its own gate mode went with the rows
+// kernels' class 8.)
+template <int DIN, int NOUT>
 __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
     const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ dout, int64_t m, const void *__restrict__ w2ts, const float *__restrict__ w3,
@@ -156,10 +154,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
 
   // max_k |W3[q][k]| (uniform: scalar registers), before any stage is in use
   float w3max[kOut];
-  if constexpr (GATE) {
-#pragma unroll
-    for (int q = 0; q < kOut; ++q) w3max[q] = 0.0f;
-  } else {
+  {
     float *red = reinterpret_cast<float *>(smem);
 #pragma unroll
     for (int q = 0; q < kOut; ++q) {
@@ -191,10 +186,6 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
   float p_scale = 1.0f;  // of row prow of the producer's tile
   int p_parity = 0, c_parity = 0;
   auto set_row_scale = [&]() {
-    if constexpr (GATE) {  // the row's factor is its dOut times W2's power of two (no row scaling: the operand is the gate)
-      if (tid < kSplitRows) lds_write_b32(scale_lds + (p_parity * kSplitRows + prow) * 4, dr[0] * inv_w2_scale);
-      return;
-    }
     float bound = 0.0f;
 #pragma unroll
     for (int q = 0; q < kOut; ++q) bound = __builtin_fmaf(__builtin_fabsf(dr[q]), w3max[q], bound);
@@ -232,12 +223,6 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
     uint32_t gword = g0;
     if (!from_regs) gword = __float_as_uint(lds_read_b32(gate_lds + (prow * 8 + (ks >> 1)) * 4));
     const uint32_t byte = gword >> (16 * (ks & 1) + 8 * pkh);
-    if constexpr (GATE) {  // bit -> fp16 1.0 / 0.0
-#pragma unroll
-      for (int e = 0; e < 8; e += 2)
-        planes[0][e >> 1] = (((byte >> e) & 1u) ? 0x00003c00u : 0u) | (((byte >> (e + 1)) & 1u) ? 0x3c000000u : 0u);
-      return;
-    }
     float dz[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -258,7 +243,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
   auto write_a = [&](int stage, const u32x4 (&planes)[2]) {
     const unsigned addr = a_write + stage * kF16StageBytes;
     lds_write_b128<0>(addr, planes[0]);
-    if constexpr (!GATE) lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
+    lds_write_b128<kSplitPlaneStride>(addr, planes[1]);
   };
   auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
@@ -281,13 +266,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
     f.bh[1] = lds_read_b128<2 * 1024>(br);
     f.bh[2] = lds_read_b128<4 * 1024>(br);
     f.bh[3] = lds_read_b128<6 * 1024>(br);
-    if constexpr (GATE) {
-      f.am[0] = f.ah[0];  // (one A plane; the pair keeps wait_lds_all's operand list whole)
-      f.am[1] = f.ah[1];
-    } else {
-      f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
-      f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
-    }
+    f.am[0] = lds_read_b128<kSplitPlaneStride>(ar);
+    f.am[1] = lds_read_b128<kSplitPlaneStride + 512>(ar);
     f.bm[0] = lds_read_b128<1024>(br);
     f.bm[1] = lds_read_b128<3 * 1024>(br);
     f.bm[2] = lds_read_b128<5 * 1024>(br);
@@ -306,18 +286,6 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
     u32x4 planes[2];
     produce_a(ks, planes, s == kSplitSteps - 1);
     if (s == kSplitSteps - 3) load_g0(p_tile + stride);  // two steps ahead of its use
-    if constexpr (GATE) {
-      wait_lds<0>(f.ah[0], f.ah[1], f.bh[0], f.bh[1], f.bh[2], f.bh[3]);
-      wait_lds<0>(f.bm[0], f.bm[1], f.bm[2], f.bm[3]);
-      f16_mma<FIRST>(f.ah, f.bm, acc);  // gate x lo
-      __builtin_amdgcn_sched_barrier(0);
-      write_a(P ^ 1, planes);
-      __builtin_amdgcn_sched_barrier(0);
-      f16_mma<false>(f.ah, f.bh, acc);  // gate x hi
-      __builtin_amdgcn_sched_barrier(0);
-      step_barrier();
-      return;
-    }
     wait_lds_all(f);
     f16_mma<FIRST>(f.am, f.bh, acc);  // lo x hi
     f16_mma<false>(f.ah, f.bm, acc);  // hi x lo
@@ -482,13 +450,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_tower_backward_f16_kernel(
   }
 }
 
-template <int DIN, int NOUT, bool GATE = false>
+template <int DIN, int NOUT>
 static int launch_backward_f16(int grid, hipStream_t s, const float *x, const float *w1, const float *b1, const float *dout,
                                int64_t m, const void *w2ts, const float *w3, float *partials, int stride, int head_rows,
                                const uint32_t *gate2) {
   static LdsOptIn lds_attr_set_0;
-  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_tower_backward_f16_kernel<DIN, NOUT, GATE>), 160 * 1024)) return e_lds_attr_set_0;
-  mlp_tower_backward_f16_kernel<DIN, NOUT, GATE><<<grid, kBlock, f16_backward_lds_bytes(DIN), s>>>(
+  if (const int e_lds_attr_set_0 = allow_dynamic_lds(lds_attr_set_0, reinterpret_cast<const void *>(&mlp_tower_backward_f16_kernel<DIN, NOUT>), 160 * 1024)) return e_lds_attr_set_0;
+  mlp_tower_backward_f16_kernel<DIN, NOUT><<<grid, kBlock, f16_backward_lds_bytes(DIN), s>>>(
       x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2);
   return launch_status();
 }
@@ -569,7 +537,7 @@ RL8_API int rl8_mlp_tower_backward_f16_f32(const float *x, const float *w1, cons
   *partial_rows_out = grid > g2 ? grid : g2;
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
-  if (!env_int("RL8_MLP_DGRAD_GENERAL_TILE")) {  // (diagnostics: 1 = the tile kernel for every width; read per call)
+  if (!env_int("RL8_MLP_DGRAD_TILE")) {  // (diagnostics: 1 = the tile kernel for every width; read per call)
     // d_in <= 3, n_out 2..4: the rows-per-wave kernel (mlp_rows_kernels.hip, round 5)
     const int st = mlp_rows_backward_general_dispatch(grid, s, x, w1, b1, dout, m, d_in, w2t_f16, w3, n_out, partials, stride, g2, gate2);
     if (st != -1) return st;
@@ -612,17 +580,7 @@ RL8_API int rl8_mlp_tower_backward_gate_f16_f32(const float *x, const float *w1,
   *partial_rows_out = grid > g2 ? grid : g2;
   const int stride = (int)rl8_mlp_backward_partial_floats(d_in, n_out);
   hipStream_t s = (hipStream_t)stream;
-  // d_in <= 3: the rows-per-wave kernel (mlp_rows_kernels.hip); 4, 5: the tile kernel's gate mode (its running column sums
-  // fit LDS at these widths; in the rows shape they did not pay: profiles/r05_experiments.md)
-  {
-    const int st = mlp_rows_backward_gate_dispatch(grid, s, x, w1, b1, dout, m, d_in, w2t_gate, n_out, partials, stride, g2, gate2);
-    if (st != -1) return st;
-  }
-  int status = RL8_ESIZE;
-#define RL8_BACKWARD_GATE(D, N) \
-  if (d_in == D && n_out == N) \
-    status = launch_backward_f16<D, N, true>(grid, s, x, w1, b1, dout, m, w2t_gate, nullptr, partials, stride, g2, gate2);
-  RL8_BACKWARD_GATE(4, 1) RL8_BACKWARD_GATE(4, 2) RL8_BACKWARD_GATE(5, 1) RL8_BACKWARD_GATE(5, 2)
-#undef RL8_BACKWARD_GATE
-  return status;
+  // the rows-per-wave kernels (mlp_rows_kernels.hip): d_in <= 3 with the layer-1 fma chain, 4 and 5 in class 8
+  const int st = mlp_rows_backward_gate_dispatch(grid, s, x, w1, b1, dout, m, d_in, w2t_gate, n_out, partials, stride, g2, gate2);
+  return st == -1 ? RL8_ESIZE : st;
 }

@@ -1486,7 +1486,6 @@ int mlp_rows_backward_gate_dispatch(int grid, hipStream_t s, const float *x, con
                                     int64_t m, int d_in, const void *w2ts, int n_out, float *partials, int stride, int head_rows,
                                     const uint32_t *gate2) {
   const int dc = d_in <= 3 ? d_in : d_in <= 7 ? 8 : 0;  // (class 8 keeps M slot 7 for db1: seven inputs)
-  if (dc == 8 && env_int("RL8_MLP_DGRAD_WIDE_TILE")) return -1;  // (A/B: the tile kernel at d_in = 4, 5)
 #define RL8_ROWS_BWD(D, N) \
   if (dc == D && n_out == N) return launch_rows_backward_gate<D, N>(grid, s, x, w1, b1, dout, m, w2ts, partials, stride, head_rows, gate2, d_in);
   RL8_ROWS_BWD(1, 1) RL8_ROWS_BWD(1, 2) RL8_ROWS_BWD(2, 1) RL8_ROWS_BWD(2, 2) RL8_ROWS_BWD(3, 1) RL8_ROWS_BWD(3, 2)
@@ -2008,7 +2007,6 @@ int mlp_rows_backward_general_dispatch(int grid, hipStream_t s, const float *x, 
                                        int64_t m, int d_in, const void *w2ts, const float *w3, int n_out, float *partials, int stride,
                                        int head_rows, const uint32_t *gate2) {
   const int dc = d_in <= 3 ? d_in : d_in <= 7 ? 8 : 0;  // (class 8 keeps M slot 7 for db1: seven inputs)
-  if (dc == 8 && env_int("RL8_MLP_DGRAD_WIDE_TILE")) return -1;  // (A/B: the tile kernel at d_in = 4, 5)
 #define RL8_ROWS_BWD_GENERAL(D) \
   if (dc == D && n_out == 2) return launch_rows_backward_general<D, 2>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out, d_in); \
   if (dc == D && (n_out == 3 || n_out == 4)) return launch_rows_backward_general<D, 4>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out, d_in);
