@@ -174,8 +174,13 @@ def test_a_table_too_large_for_the_kernels_steps_aside(monkeypatch):
 def test_six_updates_from_tables_track_the_matrix_towers(env_name, monkeypatch):
     """Six collect() + step() rounds of the same seeded algorithm with the towers from tables and from the matrix kernels:
     the two evaluate the same function to fp32 rounding, so rollouts (same Philox noise), losses and the weights after
-    six updates stay together -- collect statistics to 1e-4, losses to 2e-3 of their size, weights to 1e-3 of the
-    largest (a rare action that flips on a last-bit difference of a logit moves one env's trajectory, no more)."""
+    six updates stay together -- collect statistics to 1e-4, losses to 2e-3 of their size (the KL monitor to 1e-2),
+    weights to 1e-3 of the largest.  What separates two roundings of the same update (traced in round 5, when the
+    rows-shape general data gradient changed dW1's last bits and moved the KL of update 3 by 0.4 %): a nearly dead ReLU
+    unit of layer 2 that ONE sample opens in one run and not in the other -- its row of dW2 goes from exactly zero to
+    something tiny, and Adam's normalisation makes a full-size step of it (109 entries of W2 moved by 1e-4, everything
+    else agreed to 6e-8).  A property of ReLU + Adam, not of either kernel: each kernel matches fp64 on the same
+    inputs to rounding (tests/test_mlp_split_gpu.py)."""
     from rl8_amd import AlgorithmConfig
     from rl8_amd.distributions import SquashedNormal
     from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv
@@ -196,6 +201,7 @@ def test_six_updates_from_tables_track_the_matrix_towers(env_name, monkeypatch):
     for (c0, s0), (c1, s1) in zip(matrix, tables):
         for k in ("returns/mean", "rewards/mean", "returns/std"):
             assert c1[k] == pytest.approx(c0[k], rel=1e-4), k
-        for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+        for k in ("losses/policy", "losses/vf", "losses/total"):
             assert s1[k] == pytest.approx(s0[k], rel=2e-3, abs=2e-6), k
+        assert s1["monitors/kl_div"] == pytest.approx(s0["monitors/kl_div"], rel=1e-2, abs=2e-6)
     assert float((w_tables - w_matrix).abs().max()) <= 1e-3 * float(w_matrix.abs().max())
