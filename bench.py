@@ -157,8 +157,10 @@ PMC_KERNEL_F16 = {  # the fp16-plane kernels (forward, data gradient), same prof
     "mlp_tower_forward_save": ("mlp_rows_forward_kernel<1, 2, 2, 4, 0>", 1 << 20),
     # (round 4: the rollout's launches run in that save mode into the slabs SGD iteration 0 replays: fused_mlp.RolloutRecord)
     "mlp_tower_forward_record": ("mlp_rows_forward_kernel<1, 2, 2, 4, 0>", 1 << 20),
-    "mlp_tower_backward": ("mlp_tower_backward_f16_kernel<1, 2, false>", 1 << 20),
-    "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2, false, true>", 1 << 20),  # template <d_in, n_out, LOADH, F16>
+    # (round 5: general heads -- configs[3]'s mean / log_std tower -- run the rows-shape data gradient <d_in, KOUT, ring> and
+    # the sixteen-wave weight gradient <d_in, n_out>; "mlp_tower_backward_f16_kernel<1, 2>" in older summaries)
+    "mlp_tower_backward": ("mlp_rows_backward_general_kernel<1, 2, 3>", 1 << 20),
+    "mlp_wgrad": ("mlp_wgrad_fused16_kernel<1, 2>", 1 << 20),
 }
 PMC_KERNEL_SPLIT = {  # the six-product bf16-plane weight gradient (RL8_WGRAD_PLANES=bf16), same profiled shape
     "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2, false, false>", 1 << 20),

@@ -347,17 +347,20 @@ int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *
  * range; each is then split into hi = fp16(v), lo = fp16(v - hi) (22 significand
  * bits) and lo.hi + hi.lo + hi.hi is accumulated in fp32; the epilogue multiplies
  * by the inverse powers of two (exact).  Inputs, outputs and saved activations are fp32
- * exactly as for rl8_mlp_tower_forward_f32 (h1 bit-identical, out / h2 equal to fp32 rounding).
+ * exactly as for rl8_mlp_tower_forward_f32 (h1 bit-identical at d_in <= 3 and equal to fp32 rounding above -- there layer 1
+ * runs on the matrix pipe too; out / h2 equal to fp32 rounding).
  * save_h1 may be NULL while save_h2 is given: the plane backward kernels recompute h1 from the
  * observations and never read it.  save_gate2 (optional) [M][8] words receives the ReLU gate of
  * layer 2, bit j of row s = (h2[s][j] > 0): the data-gradient kernels need only that bit of h2
  * (32 B per row instead of 1 KiB), and it may be given WITHOUT save_h2 (rank-one heads: see
  * rl8_mlp_wgrad_gate_bits_f32).  Widths (round 5): any d_in <= 8 and n_out <= 8 (rl8_mlp_forward_f16_supports) -- the
- * kernels are compiled for width CLASSES d_in {1, 2, 3, 5, 8} x n_out {1, 2, 4, 8} and a class serves every run-time
- * width it holds (layer-1 records zero past d_in, observations past d_in not loaded, output rows past n_out zero and
- * not stored) -- else RL8_ESIZE: wider towers run rl8_mlp_tower_forward_f32.  The plane BACKWARD entries below are
- * compiled per width, d_in 1..5 x n_out 1..4 (rl8_mlp_backward_f16_supports): their observations and dOut arrive through
- * scalar loads of rows with a compile-time stride; a tower inside the forward's envelope but outside theirs is trained
+ * kernels are compiled for width CLASSES d_in {1, 2, 3, 8} x n_out {1, 2, 4, 8} and a class serves every run-time
+ * width it holds (weights past d_in zero, observations past d_in not loaded, output rows past n_out zero and not stored;
+ * class 8, d_in = 4..8, forms z1 = W1 x as ONE 16x16x32 MFMA per sixteen units and rows that holds the four fp16 plane
+ * products of eight inputs) -- else RL8_ESIZE: wider towers run rl8_mlp_tower_forward_f32.  The plane BACKWARD entries
+ * below serve d_in 1..5 x n_out 1..4 (rl8_mlp_backward_f16_supports; the weight-gradient kernels are compiled per width,
+ * the data-gradient kernels per class -- d_in 4, 5 in class 8, which recomputes the forward's z1 product bit for bit and
+ * forms dW1 / db1 as MFMAs over the wave's rows); a tower inside the forward's envelope but outside theirs is trained
  * through the fp32-MFMA data gradient + bf16-plane weight gradient (save_h1 given).  (The bf16-plane forward / data-gradient
  * entries of rounds 1-2, rl8_mlp_tower_{forward,backward}_split_f32, were removed in round 3.)
  * w2_f16 (rl8_mlp_f16_packed_bytes() bytes:

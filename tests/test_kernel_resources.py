@@ -127,7 +127,7 @@ def test_compiled_split_kernels_resources(tmp_path):
             # (round 5: the widest fused variant on the exact bf16 planes, d_in 5 x n_out 4 -- 72 scalar registers of
             # observations and dOut per step -- keeps three registers in scratch; the walkers below hold for it as for
             # the others: no hand-issued load's destination, vector or scalar, is touched before its wait)
-            widest = "mlp_wgrad_split_kernelILi5ELi4ELb0ELb0E" in name
+            widest = "mlp_wgrad_split_kernelILi5ELi4ELb0EE" in name
             assert scratch == 0 or (widest and scratch <= 16), (name, scratch)
             assert vgprs <= 256, (name, vgprs)
             checked += 1
