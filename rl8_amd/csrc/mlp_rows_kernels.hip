@@ -994,6 +994,7 @@ __device__ __forceinline__ void rows8_epilogue(const f32x4 (&acc)[2][16], const 
   request_consts(0, 0);
   u32x4 xa;
   const float k2048 = 2048.0f;
+  const float c_first = kqe < 2 ? 1.0f : 0x1p-11f, c_second = kqe < 2 ? 0x1p-11f : 0x1p-22f;
 #pragma unroll
   for (int ct = 0; ct < 16; ++ct) {
     const int set = ct & 1;
@@ -1006,6 +1007,10 @@ __device__ __forceinline__ void rows8_epilogue(const f32x4 (&acc)[2][16], const 
       u32x2 a0 = xa0, a1 = xa1;
       asm volatile("" : "+v"(fq[0]), "+v"(fq[1]), "+v"(iq[0]), "+v"(iq[1]), "+v"(a0), "+v"(a1));
       xa = u32x4{a0[0], a0[1], a1[0], a1[1]};
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)  // the rows' factors times dZ1's power of two, once per tile: the plane split multiplies
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fq[rt][r] = __float_as_uint(__uint_as_float(fq[rt][r]) * scales.sd);
     }
     const f32x4 zero = {0, 0, 0, 0};
     float dz[8];
@@ -1015,27 +1020,30 @@ __device__ __forceinline__ void rows8_epilogue(const f32x4 (&acc)[2][16], const 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pre = __builtin_fmaf(z[r], __uint_as_float(iq[rt][r]), __uint_as_float(b1c[set]));
-        dz[4 * rt + r] = select_or_zero(positive_mask(pre), acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
+        dz[4 * rt + r] = select_or_zero(positive_mask(pre), acc[rt][ct][r]);
       }
     }
     u32x4 dh, dl;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       uint32_t h, l;
-      f16_pair_scaled_wide(dz[2 * j], dz[2 * j + 1], scales.sd, k2048, h, l);
+      f16_pair_scaled2_wide(dz[2 * j], dz[2 * j + 1], __uint_as_float(fq[j >> 1][2 * (j & 1)]), __uint_as_float(fq[j >> 1][2 * (j & 1) + 1]), k2048, h, l);
       dh[j] = h;
       dl[j] = l;
     }
     // slots 0..7: x~hi . (Dhi | Dlo'), slots 8..15: x~lo' . (Dhi | Dlo'); the primes carry 2^11
     const f32x4 o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, xa), __builtin_bit_cast(half8, dh), zero, 0, 0, 0);
     const f32x4 o2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, xa), __builtin_bit_cast(half8, dl), zero, 0, 0, 0);
+    // The lanes of slots 8..15 hand their parts to those of slots 0..7.  One swap of (o1, o2) gives the lower lanes
+    // (o1 own, o1 of the partner) and the upper lanes (o2 of the partner below, o2 own): each half weighs its pair
+    // (1, 2^-11 below; 2^-11, 2^-22 above), a second swap brings the upper half's sum down.
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {  // the lanes of slots 8..15 hand their parts to those of slots 0..7
-      const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(o1[r]), __float_as_uint(o1[r]), false, false);
-      const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(o2[r]), __float_as_uint(o2[r]), false, false);
-      const float mid = __uint_as_float(s1[1]) + __uint_as_float(s2[0]);  // x~lo' . Dhi + x~hi . Dlo'
-      v[r] = __builtin_fmaf(__uint_as_float(s2[1]), 0x1p-22f, __builtin_fmaf(mid, 0x1p-11f, __uint_as_float(s1[0])));
+    for (int r = 0; r < 4; ++r) {
+      const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(o1[r]), __float_as_uint(o2[r]), false, false);
+      const float t = __builtin_fmaf(__uint_as_float(s1[1]), c_second, __uint_as_float(s1[0]) * c_first);
+      const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+      v[r] = __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
     }
     // this block's sums as the predecessor left them: once its counter says so (polled inside ONE asm statement: a C++
     // loop per block costs the register allocator its grip on the whole kernel -- 936 bytes of scratch)

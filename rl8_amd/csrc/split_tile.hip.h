@@ -311,6 +311,20 @@ __device__ __forceinline__ void f16_pair_scaled_wide(float x0, float x1, float s
       : "=&v"(hi), "=&v"(lo), "=&v"(r0), "=&v"(r1)
       : "v"(x0), "v"(x1), "v"(s), "s"(k2048));
 }
+// ... with a factor per element (not powers of two: hi = fp16(x s) is ONE rounding of the exact product, the residual
+// fma(x, s, -hi) one fp32 rounding of the exact difference): the rows-shape data gradients' class 8, whose two elements of
+// a pair are two ROWS with their own factors.
+__device__ __forceinline__ void f16_pair_scaled2_wide(float x0, float x1, float s0, float s1, float k2048, uint32_t &hi, uint32_t &lo) {
+  float r0, r1;
+  asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %7, 0\n\t"
+      "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %3, %5, %7, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %1, %2, %8, 0\n\t"
+      "v_fma_mixhi_f16 %1, %3, %8, 0"
+      : "=&v"(hi), "=&v"(lo), "=&v"(r0), "=&v"(r1)
+      : "v"(x0), "v"(x1), "v"(s0), "v"(s1), "s"(k2048));
+}
 // packed fp16 pair times a packed fp16 constant in a scalar register (0x10001000: both halves times 2^-11; exact for
 // halves of 2^-3 and more, the fp16 subnormal quantum below)
 __device__ __forceinline__ uint32_t f16_pair_times(uint32_t v, uint32_t packed_constant) {
