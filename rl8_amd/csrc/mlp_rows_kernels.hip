@@ -1345,11 +1345,15 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
       asm volatile("" : "+v"(lane_e));
       const int l16e = lane_e & 15, kqe = lane_e >> 4;
       const unsigned wl = lds0 + kWaveOff + wave * kWaveBytes;
+      // (narrow observations: dZ1 = a x factor is never formed -- the sums take a with the factor, resp. factor x
+      // observation, as the fma's multiplier: one instruction per element less; d_in = 3 has no registers for 24 products)
+      constexpr bool kFoldFactor = kIn <= 2;
+      [[maybe_unused]] float fx[2][kFoldFactor ? kIn : 1][4];
       u32x4 fq[2], xq[2][kIn];
-  #pragma unroll
+#pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         fq[rt] = rt == 0 ? lds_read_b128<kFacOff>(wl + 16 * kqe) : lds_read_b128<kFacOff + 64>(wl + 16 * kqe);
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < kIn; ++i)
           xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
                                  : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
@@ -1373,46 +1377,61 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
         }
       };
       request_col(0, 0);
-  #pragma unroll
+#pragma unroll
       for (int ct = 0; ct < 16; ++ct) {
         const int set = ct & 1;
         if (ct + 1 < 16) request_col(ct + 1, set ^ 1);
         if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
         if (ct == 0) {
-  #pragma unroll
+#pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
             asm volatile("" : "+v"(fq[rt]));
-  #pragma unroll
+#pragma unroll
             for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
+          }
+          if constexpr (kFoldFactor) {  // factor x observation per row, once per tile: one fma per sum and element below
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+              for (int i = 0; i < kIn; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fx[rt][i][r] = __uint_as_float(fq[rt][r]) * __uint_as_float(xq[rt][i][r]);
           }
         }
         const float b1c = __uint_as_float(rq[set][0]);
         float w1c[kIn];
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
         float db = 0.0f, dw[kIn];
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
-  #pragma unroll
+#pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           float pre[4];
           unsigned long long open[4];
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < 4; ++r) {
             pre[r] = b1c;
-  #pragma unroll
+#pragma unroll
             for (int i = 0; i < kIn; ++i) pre[r] = __builtin_fmaf(__uint_as_float(xq[rt][i][r]), w1c[i], pre[r]);
           }
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < 4; ++r) open[r] = positive_mask(pre[r]);
           __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
-            db += dz;
-  #pragma unroll
-            for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
+            if constexpr (kFoldFactor) {
+              const float a = select_or_zero(open[r], acc[rt][ct][r]);
+              db = __builtin_fmaf(a, __uint_as_float(fq[rt][r]), db);
+#pragma unroll
+              for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(a, fx[rt][i][r], dw[i]);
+            } else {
+              const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
+              db += dz;
+#pragma unroll
+              for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
+            }
           }
         }
         // the four lanes of a column (kq = 0..3) in a fixed order, then the running sums by one of them
@@ -1423,12 +1442,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
           return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
         };
         db = across(db);
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
         if (kqe == (ct & 3)) {
           const unsigned sa = sum_at + ct * (16 * kRec * 4);
           lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
-  #pragma unroll
+#pragma unroll
           for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
         }
       }
@@ -1875,11 +1894,15 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
       asm volatile("" : "+v"(lane_e));
       const int l16e = lane_e & 15, kqe = lane_e >> 4;
       const unsigned wl = lds0 + kWaveOff + wave * kWaveBytes;
+      // (narrow observations: dZ1 = a x factor is never formed -- the sums take a with the factor, resp. factor x
+      // observation, as the fma's multiplier: one instruction per element less; d_in = 3 has no registers for 24 products)
+      constexpr bool kFoldFactor = kIn <= 2;
+      [[maybe_unused]] float fx[2][kFoldFactor ? kIn : 1][4];
       u32x4 fq[2], xq[2][kIn];
-  #pragma unroll
+#pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         fq[rt] = rt == 0 ? lds_read_b128<kFacOff>(wl + 16 * kqe) : lds_read_b128<kFacOff + 64>(wl + 16 * kqe);
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < kIn; ++i)
           xq[rt][i] = rt == 0 ? (i == 0   ? lds_read_b128<kObsOff>(wl + 16 * kqe)
                                  : i == 1 ? lds_read_b128<kObsOff + 128>(wl + 16 * kqe)
@@ -1902,7 +1925,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
         }
       };
       request_col(0, 0);
-  #pragma unroll
+#pragma unroll
       for (int ct = 0; ct < 16; ++ct) {
         const int set = ct & 1;
         if (ct == 8) load_rows(dc, xc, tile + stride);
@@ -1910,39 +1933,54 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
         if (ct + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rq[set]), "+v"(sq[set]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[set]), "+v"(sq[set]));
         if (ct == 0) {
-  #pragma unroll
+#pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
             asm volatile("" : "+v"(fq[rt]));
-  #pragma unroll
+#pragma unroll
             for (int i = 0; i < kIn; ++i) asm volatile("" : "+v"(xq[rt][i]));
+          }
+          if constexpr (kFoldFactor) {  // factor x observation per row, once per tile: one fma per sum and element below
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+              for (int i = 0; i < kIn; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fx[rt][i][r] = __uint_as_float(fq[rt][r]) * __uint_as_float(xq[rt][i][r]);
           }
         }
         const float b1c = __uint_as_float(rq[set][0]);
         float w1c[kIn];
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < kIn; ++i) w1c[i] = __uint_as_float(rq[set][1 + i]);
         float db = 0.0f, dw[kIn];
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < kIn; ++i) dw[i] = 0.0f;
-  #pragma unroll
+#pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           float pre[4];
           unsigned long long open[4];
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < 4; ++r) {
             pre[r] = b1c;
-  #pragma unroll
+#pragma unroll
             for (int i = 0; i < kIn; ++i) pre[r] = __builtin_fmaf(__uint_as_float(xq[rt][i][r]), w1c[i], pre[r]);
           }
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < 4; ++r) open[r] = positive_mask(pre[r]);
           __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
+#pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
-            db += dz;
-  #pragma unroll
-            for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
+            if constexpr (kFoldFactor) {
+              const float a = select_or_zero(open[r], acc[rt][ct][r]);
+              db = __builtin_fmaf(a, __uint_as_float(fq[rt][r]), db);
+#pragma unroll
+              for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(a, fx[rt][i][r], dw[i]);
+            } else {
+              const float dz = select_or_zero(open[r], acc[rt][ct][r]) * __uint_as_float(fq[rt][r]);
+              db += dz;
+#pragma unroll
+              for (int i = 0; i < kIn; ++i) dw[i] = __builtin_fmaf(dz, __uint_as_float(xq[rt][i][r]), dw[i]);
+            }
           }
         }
         auto across = [&](float v) {
@@ -1952,12 +1990,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
           return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
         };
         db = across(db);
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < kIn; ++i) dw[i] = across(dw[i]);
         if (kqe == (ct & 3)) {
           const unsigned sa = sum_at + ct * (16 * kRec * 4);
           lds_write_b32(sa, __uint_as_float(sq[set][0]) + db);
-  #pragma unroll
+#pragma unroll
           for (int i = 0; i < kIn; ++i) lds_write_b32(sa + 4 + 4 * i, __uint_as_float(sq[set][1 + i]) + dw[i]);
         }
       }
