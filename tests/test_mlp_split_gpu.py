@@ -7,6 +7,8 @@ be as close to fp64 as those are. Run-to-run bit equality is checked for every
 kernel (fixed summation orders; it is also what exposes a synchronisation bug).
 """
 
+import math
+
 import pytest
 import torch
 
@@ -1046,3 +1048,40 @@ def test_wide_data_gradients_follow_the_forwards_gates(m, d_in, n_out, pair, mon
     again = run(False)
     for k in rows:
         assert torch.equal(rows[k], again[k]), k  # the chain of waves adds in a fixed order: bit for bit
+
+
+@pytest.mark.parametrize("x_scale", [1e-12, 1e-3, 1.0, 3e5])
+@pytest.mark.parametrize("d_in,n_out", [(5, 3), (4, 1), (8, 2)])
+def test_class8_scales_over_observation_magnitudes(d_in, n_out, x_scale):
+    """Class 8 carries three powers of two per row (x for z1, h1 for layer 2, dZ1 / x~ for dW1): observations from 1e-12
+    to 3e5, rows of exact zeros and rows a million times the others beside each other, forward against fp64 and (where the
+    plane backward serves the width) dW1 / db1 against fp64 on the forward's own activations."""
+    m = 3000
+    g = torch.Generator(device=DEV).manual_seed(int(d_in * 100 + n_out + abs(math.log10(x_scale)) * 7))
+    x = torch.randn(m, d_in, device=DEV, generator=g) * x_scale
+    x[::7] = 0.0
+    x[5::11] *= 1e6 if x_scale < 1.0 else 1e-6
+    x[3::13, 1] = 0.0
+    p = _params(g, d_in, n_out)
+    want, h1w, h2w = _tower(x.double(), {k: v.double() for k, v in p.items()})
+    packed = hip.mlp_pack_w2_f16(p["w2"])
+    out, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], packed, p["b2"], p["w3"], p["b3"], save=True, save_gate=True)
+    assert bool(torch.isfinite(out).all())
+    assert _rel(out, want) < 5e-6 and _rel(h1, h1w) < 1e-6 and _rel(h2, h2w) < 3e-6
+    # rows of zeros: h1 = relu(b1) exactly
+    assert torch.equal(h1[::7], torch.relu(p["b1"]).expand_as(h1[::7]))
+    if not hip.mlp_backward_f16_supports(d_in, n_out):
+        return
+    dout = torch.randn(m, n_out, device=DEV, generator=g) / m
+    dz2 = (dout.double() @ p["w3"].double()) * (h2 > 0)
+    dz1 = (dz2 @ p["w2"].double()) * (h1 > 0)
+    want_g = {"w1": dz1.T @ x.double(), "b1": dz1.sum(0)}
+    inner = (dz2.abs() @ p["w2"].double().abs()) * (h1 > 0)
+    size = {"w1": inner.T @ x.double().abs(), "b1": inner.sum(0)}
+    w2t = hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+    got = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate,
+                                 gate_pack=(lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])) if n_out == 1 else None)
+    for k in ("w1", "b1"):
+        assert bool(torch.isfinite(got[k]).all()), k
+        floor = size[k].max() * 1e-30 + 1e-300
+        assert float(((got[k].double() - want_g[k]).abs() / (size[k] + floor)).max()) < 2e-6, k
