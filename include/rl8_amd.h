@@ -353,11 +353,12 @@ int rl8_mlp_tower_forward_f32(const float *x, int64_t m, int d_in, const float *
  * observations and never read it.  save_gate2 (optional) [M][8] words receives the ReLU gate of
  * layer 2, bit j of row s = (h2[s][j] > 0): the data-gradient kernels need only that bit of h2
  * (32 B per row instead of 1 KiB), and it may be given WITHOUT save_h2 (rank-one heads: see
- * rl8_mlp_wgrad_gate_bits_f32).  Widths (round 5): any d_in <= 8 and n_out <= 8 (rl8_mlp_forward_f16_supports) -- the
- * kernels are compiled for width CLASSES d_in {1, 2, 3, 8} x n_out {1, 2, 4, 8} and a class serves every run-time
+ * rl8_mlp_wgrad_gate_bits_f32).  Widths (round 5): any d_in <= 8 with n_out <= 8, and d_in 9..16 with n_out <= 4
+ * (rl8_mlp_forward_f16_supports) -- the
+ * kernels are compiled for width CLASSES d_in {1, 2, 3, 8, 16} x n_out {1, 2, 4, 8} and a class serves every run-time
  * width it holds (weights past d_in zero, observations past d_in not loaded, output rows past n_out zero and not stored;
  * class 8, d_in = 4..8, forms z1 = W1 x as ONE 16x16x32 MFMA per sixteen units and rows that holds the four fp16 plane
- * products of eight inputs) -- else RL8_ESIZE: wider towers run rl8_mlp_tower_forward_f32.  The plane BACKWARD entries
+ * products of eight inputs; class 16 chains two of them) -- else RL8_ESIZE: wider towers run rl8_mlp_tower_forward_f32.  The plane BACKWARD entries
  * below serve d_in 1..5 x n_out 1..4 (rl8_mlp_backward_f16_supports; the weight-gradient kernels are compiled per width,
  * the data-gradient kernels per class -- d_in 4, 5 in class 8, which recomputes the forward's z1 product bit for bit and
  * forms dW1 / db1 as MFMAs over the wave's rows); a tower inside the forward's envelope but outside theirs is trained

@@ -493,7 +493,8 @@ int rows_in_class(int d_in);
 int rows_out_class(int n_out);
 }
 RL8_API int rl8_mlp_forward_f16_supports(int d_in, int n_out) {
-  return d_in >= 1 && rows_in_class(d_in) != 0 && rows_out_class(n_out) != 0;
+  // (class 16 x output class 8 has no variant: its constants and the h2 scratch do not fit beside three chunks of W2)
+  return d_in >= 1 && rows_in_class(d_in) != 0 && rows_out_class(n_out) != 0 && !(rows_in_class(d_in) == 16 && rows_out_class(n_out) == 8);
 }
 
 RL8_API int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, const float *w1,

@@ -43,10 +43,11 @@ constexpr int kRowsPitch = 128 + 16;                   // h2 transpose scratch (
 // floats per k of the layer-1 record [b1 | w1[k][0..DIN-1] | pad]
 // (width CLASSES since round 5: a kernel compiled for class DIN serves every run-time d_in <= DIN -- weights past d_in
 // are zero, observations past d_in are not loaded.  Classes 1, 2, 3 form h1 with one fma per input on the vector ALU
-// from these records; class 8 -- d_in = 4..8 -- forms it on the MATRIX pipe, see "layer 1 as a matrix product" in the
+// from these records; class 8 -- d_in = 4..8 -- and class 16 -- 9..16 -- form it on the MATRIX pipe, see "layer 1 as a matrix product" in the
 // kernel: its "record" is 8 KiB of W1 fragments + 1 KiB of b1, nine floats per k.)
-constexpr int rows_record(int d_in) { return d_in == 1 ? 2 : d_in <= 3 ? 4 : 9; }
-constexpr int rows_record_vecs(int d_in) { return d_in <= 3 ? 1 : 4; }  // 16-byte reads per record (class 8: per k BLOCK)
+// (class 16 -- d_in = 9..16 -- is class 8 with a second pass of eight inputs: 16 KiB of fragments, two chained MFMAs)
+constexpr int rows_record(int d_in) { return d_in == 1 ? 2 : d_in <= 3 ? 4 : d_in <= 8 ? 9 : 17; }
+constexpr int rows_record_vecs(int d_in) { return d_in <= 3 ? 1 : d_in <= 8 ? 4 : 6; }  // 16-byte reads per record (classes 8, 16: per k BLOCK)
 constexpr int rows_consts_bytes(int k_in, int k_out) { return (rows_record(k_in) + 1 + k_out) * kHidden * 4; }
 constexpr int rows_lds_bytes(int ring, int k_in, int k_out, bool store) {
   return ring * kRowsChunk + rows_consts_bytes(k_in, k_out) + (store ? 4 * 16 * kRowsPitch : 0);
@@ -59,7 +60,7 @@ constexpr int rows_lds_bytes(int ring, int k_in, int k_out, bool store) {
 template <int DIN>
 constexpr int rows_record_reads(int s, bool produce, bool next_produces) {
   const bool on = s == 7 ? next_produces : produce;
-  if (DIN > 3) return s == 7 && on ? 4 : 0;  // (one request per k block: two W1 fragments, eight b1)
+  if (DIN > 3) return s == 7 && on ? rows_record_vecs(DIN) : 0;  // (one request per k block: two W1 fragments per pass, eight b1)
   if (DIN == 1) return (s & 1) && on ? 1 : 0;
   return on ? rows_record_vecs(DIN) : 0;
 }
@@ -98,8 +99,9 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
   // tensor, by powers of two; bias, ReLU and the plane split of h1 stay on the vector ALU (four instructions per
   // element, what class 1 spends).
   constexpr bool kMma1 = DIN > 3;
-  constexpr int kW1Planes = 8 * 1024;  // [S][hf][plane hi | lo][M slot] x 16 B (lanes kq and kq ^ 1 read the same plane)
-  static_assert(DIN == 1 || DIN == 2 || DIN == 3 || DIN == 8, "width classes of layer 1");
+  constexpr int kPasses = DIN > 8 ? 2 : 1;          // eight inputs per MFMA: class 16 chains two
+  constexpr int kW1Planes = kPasses * 8 * 1024;     // [pass][S][hf][plane hi | lo][M slot] x 16 B (lanes kq and kq ^ 1 read the same plane)
+  static_assert(DIN == 1 || DIN == 2 || DIN == 3 || DIN == 8 || DIN == 16, "width classes of layer 1");
   static_assert(NOUT == pad_out(NOUT), "output classes: 1, 2, 4, 8");
   static_assert(rows_lds_bytes(RING, kIn, kOut, kStore) <= 80 * 1024, "two workgroups per CU");
   static_assert(kAhead >= 2, "the mid-step barrier publishes a chunk requested at least a half-step earlier");
@@ -169,18 +171,21 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
       const int ew = f16_bound_exponent(all);
       const float sw = __builtin_amdgcn_ldexpf(1.0f, kF16Top - ew);
       inv_w1 = __builtin_amdgcn_ldexpf(1.0f, ew - kF16Top);
-      u32x4 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint32_t h, l;
-        f16_pair_scaled(wv[2 * j], wv[2 * j + 1], sw, h, l);
-        hi[j] = h;
-        lo[j] = l;
-      }
       const int slot = 4 * ((tid >> 3) & 3) + (tid & 3), frag = 2 * (tid >> 5) + ((tid >> 2) & 1);
       u32x4 *planes = reinterpret_cast<u32x4 *>(smem + kConstOff);
-      planes[(frag * 2 + 0) * 16 + slot] = hi;
-      planes[(frag * 2 + 1) * 16 + slot] = lo;
+#pragma unroll
+      for (int pass = 0; pass < kPasses; ++pass) {
+        u32x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint32_t h, l;
+          f16_pair_scaled(wv[8 * pass + 2 * j], wv[8 * pass + 2 * j + 1], sw, h, l);
+          hi[j] = h;
+          lo[j] = l;
+        }
+        planes[pass * 512 + (frag * 2 + 0) * 16 + slot] = hi;
+        planes[pass * 512 + (frag * 2 + 1) * 16 + slot] = lo;
+      }
     }
   }
 
@@ -218,50 +223,60 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     const auto s32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return combine(s32[0], s32[1]);
   };
-  auto load_pair = [&](float (&dst)[2][2], int64_t tile) {
+  auto load_pair = [&](float (&dst)[2][2 * kPasses], int64_t tile) {
     const int64_t left = tile < tiles ? m - tile * kTile : 0;
     const int rows = left <= 0 ? 0 : left < kTile ? (int)left : kTile;
     const __amdgpu_buffer_rsrc_t xrsrc = buffer_rsrc(rows > 0 ? x + tile * kTile * d_in : x, rows * d_in * 4);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int f = 2 * kq + j;
+      for (int j = 0; j < 2 * kPasses; ++j) {  // (j >> 1: the pass)
+        const int f = 8 * (j >> 1) + 2 * kq + (j & 1);
         dst[rt][j] = buffer_load_f32(xrsrc, f < d_in ? ((32 * wave + 16 * rt + l16) * d_in + f) * 4 : 0x7ffffff0, 0);
       }
   };
-  [[maybe_unused]] float wmx[2] = {0.0f, 0.0f};  // max_k |w1[k][2 kq + j]|
+  [[maybe_unused]] float wmx[2 * kPasses];  // max_k |w1[k][8 pass + 2 kq + j]|
   if constexpr (kMma1) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      wmx[j] = kq == 0 ? w1max[j] : kq == 1 ? w1max[2 + j] : kq == 2 ? w1max[4 + j] : w1max[6 + j];
+    for (int j = 0; j < 2 * kPasses; ++j) {
+      const int b = 8 * (j >> 1) + (j & 1);
+      wmx[j] = kq == 0 ? w1max[b] : kq == 1 ? w1max[b + 2] : kq == 2 ? w1max[b + 4] : w1max[b + 6];
+    }
   }
-  [[maybe_unused]] u32x4 xf[2];     // class 8: the rows' layer-1 fragments (plane hi in even k blocks, lo in odd ones)
+  [[maybe_unused]] u32x4 xf[2][kPasses];  // classes 8, 16: the rows' layer-1 fragments (plane hi in even k blocks, lo in odd ones)
   [[maybe_unused]] float inv_x[2];  // ... and 1 / (the row's power of two x W1's)
   // from the pair: the factor of h1 (as row_scales), the factor of x (|x_i| < 2^e over the row) and the fragment
-  auto row_fragments = [&](const float (&xs)[2][2], float (&scale)[2], float (&inv)[2]) {
+  auto row_fragments = [&](const float (&xs)[2][2 * kPasses], float (&scale)[2], float (&inv)[2]) {
     const auto fmax_u = [](uint32_t a, uint32_t b) { return __float_as_uint(__builtin_fmaxf(__uint_as_float(a), __uint_as_float(b))); };
     const auto fadd_u = [](uint32_t a, uint32_t b) { return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); };
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      const float a0 = __builtin_fabsf(xs[rt][0]), a1 = __builtin_fabsf(xs[rt][1]);
-      const float most = __uint_as_float(row4(__float_as_uint(__builtin_fmaxf(a0, a1)), fmax_u));
-      const float part = __uint_as_float(row4(__float_as_uint(__builtin_fmaf(a0, wmx[0], a1 * wmx[1])), fadd_u));
+      float big = 0.0f, weighed = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 2 * kPasses; ++j) {
+        big = __builtin_fmaxf(big, __builtin_fabsf(xs[rt][j]));
+        weighed = __builtin_fmaf(__builtin_fabsf(xs[rt][j]), wmx[j], weighed);
+      }
+      const float most = __uint_as_float(row4(__float_as_uint(big), fmax_u));
+      const float part = __uint_as_float(row4(__float_as_uint(weighed), fadd_u));
       const int e = f16_bound_exponent(b1max + part);
       scale[rt] = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
       inv[rt] = __builtin_amdgcn_ldexpf(inv_w2_scale, e - kF16Top);
       const int ex = f16_bound_exponent(most);
       inv_x[rt] = __builtin_amdgcn_ldexpf(inv_w1, ex - kF16Top);
-      uint32_t hi, lo;
-      f16_pair_scaled(xs[rt][0], xs[rt][1], __builtin_amdgcn_ldexpf(1.0f, kF16Top - ex), hi, lo);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {  // inputs 2 j, 2 j + 1 live in lane l16 + 16 j
-        const uint32_t h = __shfl(hi, l16 + 16 * j, kWave), l = __shfl(lo, l16 + 16 * j, kWave);
-        xf[rt][j] = (kq & 1) ? l : h;
+      for (int pass = 0; pass < kPasses; ++pass) {
+        uint32_t hi, lo;
+        f16_pair_scaled(xs[rt][2 * pass], xs[rt][2 * pass + 1], __builtin_amdgcn_ldexpf(1.0f, kF16Top - ex), hi, lo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // inputs 8 pass + 2 j, + 1 live in lane l16 + 16 j
+          const uint32_t h = __shfl(hi, l16 + 16 * j, kWave), l = __shfl(lo, l16 + 16 * j, kWave);
+          xf[rt][pass][j] = (kq & 1) ? l : h;
+        }
       }
     }
   };
-  constexpr int kXRegs = kMma1 ? 2 : kIn;
+  constexpr int kXRegs = kMma1 ? 2 * kPasses : kIn;
   [[maybe_unused]] float xc[2][kXRegs];
   float xn[2][kXRegs];
   float sc[2], inv_c[2];
@@ -304,6 +319,10 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
       cq[0][1] = lds_read_b128<512>(a);
       cq[0][2] = lds_read_b128<0>(b);
       cq[0][3] = lds_read_b128<16>(b);
+      if constexpr (kPasses == 2) {
+        cq[0][4] = lds_read_b128<8192>(a);
+        cq[0][5] = lds_read_b128<8192 + 512>(a);
+      }
       return;
     }
     const unsigned a = c_lane + S * (32 * kRec * 4);
@@ -348,8 +367,13 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
     if constexpr (kMma1) {
       asm volatile("" : "+v"(cq[0][0]), "+v"(cq[0][1]), "+v"(cq[0][2]), "+v"(cq[0][3]));
       const f32x4 zero = {0, 0, 0, 0};
-      z[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cq[0][0]), __builtin_bit_cast(half8, xf[rt]), zero, 0, 0, 0);
-      z[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cq[0][1]), __builtin_bit_cast(half8, xf[rt]), zero, 0, 0, 0);
+      z[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cq[0][0]), __builtin_bit_cast(half8, xf[rt][0]), zero, 0, 0, 0);
+      z[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cq[0][1]), __builtin_bit_cast(half8, xf[rt][0]), zero, 0, 0, 0);
+      if constexpr (kPasses == 2) {  // inputs 8..15 onto the same accumulators
+        asm volatile("" : "+v"(cq[0][kCReads - 2]), "+v"(cq[0][kCReads - 1]));
+        z[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cq[0][kCReads - 2]), __builtin_bit_cast(half8, xf[rt][kPasses - 1]), z[0], 0, 0, 0);
+        z[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cq[0][kCReads - 1]), __builtin_bit_cast(half8, xf[rt][kPasses - 1]), z[1], 0, 0, 0);
+      }
     }
   };
   auto l1_bias = [&](int rt, const f32x4 (&z)[2], float (&h)[8]) {
@@ -441,6 +465,7 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_forward_kernel(
         : allowed == 4 ? wait_lds<4>(bh[set], bl[set])
         : allowed == 5 ? wait_lds<5>(bh[set], bl[set])
         : allowed == 6 ? wait_lds<6>(bh[set], bl[set])
+        : allowed == 8 ? wait_lds<8>(bh[set], bl[set])
                        : wait_lds<0>(bh[set], bl[set]);
       }
       if constexpr (kProduce && kMma1) {  // the two small products of this half-step's k block, ahead of the slot's six
@@ -2112,7 +2137,7 @@ static int launch_rows_forward_save(hipStream_t s, const float *x, int64_t m, co
 }
 
 // Width classes (round 5): the smallest compiled class that holds the run-time width.
-int rows_in_class(int d_in) { return d_in <= 3 ? d_in : d_in <= 8 ? 8 : 0; }
+int rows_in_class(int d_in) { return d_in <= 3 ? d_in : d_in <= 8 ? 8 : d_in <= 16 ? 16 : 0; }
 int rows_out_class(int n_out) { return n_out >= 1 && n_out <= 8 ? pad_out(n_out) : 0; }
 
 // The forward behind rl8_mlp_tower_forward_f16_f32 (mlp_f16_kernels.hip checks the arguments and dispatches here).
@@ -2126,6 +2151,7 @@ int mlp_rows_forward_dispatch(hipStream_t s, const float *x, int64_t m, int d_in
   RL8_ROWS(2, 1) RL8_ROWS(2, 2) RL8_ROWS(2, 4) RL8_ROWS(2, 8)
   RL8_ROWS(3, 1) RL8_ROWS(3, 2) RL8_ROWS(3, 4) RL8_ROWS(3, 8)
   RL8_ROWS(8, 1) RL8_ROWS(8, 2) RL8_ROWS(8, 4) RL8_ROWS(8, 8)
+  RL8_ROWS(16, 1) RL8_ROWS(16, 2) RL8_ROWS(16, 4)  // (sixteen inputs x eight outputs: no room for the h2 scratch at two workgroups per CU)
 #undef RL8_ROWS
   return RL8_ESIZE;
 }

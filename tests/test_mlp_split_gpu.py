@@ -61,9 +61,11 @@ def test_forward_row_scale_sees_the_largest_layer_one_entry_wherever_it_sits(d_i
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (127, 1, 1), (128, 1, 2), (129, 2, 3), (1000, 5, 3), (4097, 1, 3),
                                           (5000, 3, 2), (70_001, 1, 2), (33_333, 5, 1), (20_000, 2, 2),
-                                          # round 5: run-time widths inside the compiled classes (d_in <= 8, n_out <= 8)
+                                          # round 5: run-time widths inside the compiled classes (d_in <= 8, n_out <= 8; d_in <= 16, n_out <= 4 below)
                                           (1000, 4, 4), (5000, 4, 1), (3001, 6, 5), (777, 7, 3), (2000, 8, 8), (129, 8, 2),
-                                          (4100, 2, 7), (33_000, 5, 6), (1, 8, 8)])
+                                          (4100, 2, 7), (33_000, 5, 6), (1, 8, 8),
+                                          # class 16 (two chained layer-1 products): d_in 9..16, n_out <= 4
+                                          (1000, 9, 1), (4097, 12, 2), (33_000, 16, 4), (129, 13, 3), (1, 16, 1), (70_001, 10, 2)])
 @pytest.mark.parametrize("scheme", ["f16x2"])
 def test_forward_split_is_fp32_accurate(m, d_in, n_out, scheme):
     """Both generations of the plane-product forward against the SAME bars: six
@@ -575,10 +577,11 @@ def test_unsupported_widths_are_refused_not_miscomputed():
     (tests/test_kernel_resources.py); anything else must fail loudly."""
     assert not hip.mlp_backward_f16_supports(7, 2) and not hip.mlp_backward_f16_supports(1, 5)
     assert hip.mlp_backward_f16_supports(4, 4) and hip.mlp_forward_f16_supports(8, 8)  # round 5
-    assert not hip.mlp_forward_f16_supports(9, 1) and not hip.mlp_forward_f16_supports(1, 9)
-    x = torch.zeros(256, 9, device=DEV)
+    assert hip.mlp_forward_f16_supports(9, 1) and hip.mlp_forward_f16_supports(16, 4)  # round 5: class 16
+    assert not hip.mlp_forward_f16_supports(17, 1) and not hip.mlp_forward_f16_supports(1, 9) and not hip.mlp_forward_f16_supports(12, 6)
+    x = torch.zeros(256, 17, device=DEV)
     h = torch.zeros(256, 256, device=DEV)
-    w7, b = torch.zeros(256, 9, device=DEV), torch.zeros(256, device=DEV)
+    w7, b = torch.zeros(256, 17, device=DEV), torch.zeros(256, device=DEV)
     w3, b3 = torch.zeros(3, 256, device=DEV), torch.zeros(3, device=DEV)
     w2 = torch.zeros(256, 256, device=DEV)
     with pytest.raises(ValueError):
@@ -590,11 +593,12 @@ def test_unsupported_widths_are_refused_not_miscomputed():
 def test_wider_towers_mix_fp32_and_split_kernels():
     """CartPole's tower (5 -> 256 -> 256 -> 3) and a 4 -> 4 one through the fused autograd function (plane kernels
     throughout) -- and widths whose backward has no plane kernel (7 -> 2, 8 -> 5: fp16-plane forward with h1 and h2
-    stored, fp32-MFMA data gradient, bf16-plane weight gradient; 12 -> 2: fp32-MFMA forward too); all must match eager."""
+    stored, fp32-MFMA data gradient, bf16-plane weight gradient; 12 -> 2, 16 -> 4 the same through class 16; 12 -> 6:
+    fp32-MFMA forward too); all must match eager."""
     from rl8_amd.nn import fused_mlp
 
     torch.manual_seed(6)
-    for d_in, n_out in ((5, 3), (4, 4), (7, 2), (8, 5), (3, 6), (12, 2)):
+    for d_in, n_out in ((5, 3), (4, 4), (7, 2), (8, 5), (3, 6), (12, 2), (16, 4), (12, 6)):
         mlp = torch.nn.Sequential(torch.nn.Linear(d_in, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
         trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
         head = torch.nn.Linear(256, n_out).to(DEV)
@@ -1051,7 +1055,7 @@ def test_wide_data_gradients_follow_the_forwards_gates(m, d_in, n_out, pair, mon
 
 
 @pytest.mark.parametrize("x_scale", [1e-12, 1e-3, 1.0, 3e5])
-@pytest.mark.parametrize("d_in,n_out", [(5, 3), (4, 1), (8, 2)])
+@pytest.mark.parametrize("d_in,n_out", [(5, 3), (4, 1), (8, 2), (11, 2), (16, 4)])
 def test_class8_scales_over_observation_magnitudes(d_in, n_out, x_scale):
     """Class 8 carries three powers of two per row (x for z1, h1 for layer 2, dZ1 / x~ for dW1): observations from 1e-12
     to 3e5, rows of exact zeros and rows a million times the others beside each other, forward against fp64 and (where the
