@@ -18,7 +18,7 @@ from rl8_amd import hip
 p = argparse.ArgumentParser()
 p.add_argument("--rows", type=int, default=1 << 20)
 p.add_argument("--reps", type=int, default=10)
-p.add_argument("--widths", default="1x1,1x2,2x2,3x1,4x1,4x4,5x1,5x3,6x2,8x1,8x4,8x8,3x8")
+p.add_argument("--widths", default="1x1,1x2,2x2,3x1,4x1,4x4,5x1,5x3,6x2,8x1,8x4,8x8,3x8,9x1,12x2,16x4")
 args = p.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
