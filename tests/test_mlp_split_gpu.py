@@ -1089,3 +1089,41 @@ def test_class8_scales_over_observation_magnitudes(d_in, n_out, x_scale):
         assert bool(torch.isfinite(got[k]).all()), k
         floor = size[k].max() * 1e-30 + 1e-300
         assert float(((got[k].double() - want_g[k]).abs() / (size[k] + floor)).max()) < 2e-6, k
+
+
+@pytest.mark.parametrize("d_in,n_out", [(5, 3), (5, 1), (4, 2)])
+def test_class8_data_gradient_over_many_tiles(d_in, n_out):
+    """2^20 + 77 rows: every workgroup runs 16-17 tiles, so the waves' chain of running-sums updates (one array per
+    workgroup, a counter per wave that only grows) is exercised across tiles, with a ragged last tile.  dW1 / db1 against fp64
+    on the forward's activations; twice, bit for bit."""
+    m = (1 << 20) + 77
+    g = torch.Generator(device=DEV).manual_seed(d_in * 10 + n_out)
+    x = torch.randn(m, d_in, device=DEV, generator=g) * 2
+    p = _params(g, d_in, n_out)
+    dout = torch.randn(m, n_out, device=DEV, generator=g) / m
+    _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                                  save=True, save_gate=True)
+    w2t = hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+    gate_pack = (lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])) if n_out == 1 else None
+    got = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack,
+                                 assume_general=n_out == 2)
+    again = hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack,
+                                   assume_general=n_out == 2)
+    for k in got:
+        assert torch.equal(got[k], again[k]), k
+    want = {"w1": torch.zeros(256, d_in, dtype=torch.float64, device=DEV), "b1": torch.zeros(256, dtype=torch.float64, device=DEV)}
+    size = {"w1": torch.zeros(256, d_in, dtype=torch.float64, device=DEV), "b1": torch.zeros(256, dtype=torch.float64, device=DEV)}
+    w2d, w3d = p["w2"].double(), p["w3"].double()
+    for lo in range(0, m, 1 << 18):  # (fp64 in slices: the whole dZ1 would be 2 GiB)
+        sl = slice(lo, min(m, lo + (1 << 18)))
+        dz2 = (dout[sl].double() @ w3d) * (h2[sl] > 0)
+        open1 = h1[sl] > 0
+        dz1 = (dz2 @ w2d) * open1
+        inner = (dz2.abs() @ w2d.abs()) * open1
+        xd = x[sl].double()
+        want["w1"] += dz1.T @ xd
+        want["b1"] += dz1.sum(0)
+        size["w1"] += inner.T @ xd.abs()
+        size["b1"] += inner.sum(0)
+    for k in ("w1", "b1"):
+        assert float(((got[k].double() - want[k]).abs() / (size[k] + 1e-300)).max()) < 2e-6, k
