@@ -774,3 +774,30 @@ def test_recurrent_step_with_wide_observations():
     for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
         assert math.isfinite(s0[k]) and s0[k] == s1[k], k
     assert torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("d,a", [(12, 3), (7, 4), (16, 2)])
+def test_walk_env_with_wide_observations_trains(d, a, monkeypatch):
+    """Observations of 7, 12 and 16 floats (the tests' walk environment): rollouts on the plane forward's classes 8 / 16,
+    training through the mixed path (plane forward with h1 / h2 stored, fp32-MFMA data gradient, bf16-plane weight
+    gradient) -- three collect() + step() rounds against the SAME seeded run on the fp32-MFMA towers: rollouts' returns to
+    1e-4, losses to 2e-3, and the return improves."""
+    from rl8_amd import AlgorithmConfig, hip
+    from rl8_amd.nn import fused_mlp
+
+    from ._envs import walk_env
+
+    def run(gemm):
+        monkeypatch.setattr(fused_mlp, "FORWARD_GEMM", gemm)
+        monkeypatch.setattr(fused_mlp, "BACKWARD_GEMM", gemm)
+        torch.manual_seed(11)
+        algo = AlgorithmConfig(num_envs=2048, horizon=16).build(walk_env(d, a))
+        return [(algo.collect(), algo.step()) for _ in range(3)]
+
+    assert hip.mlp_forward_f16_supports(d, a) and not hip.mlp_backward_f16_supports(d, a)
+    planes, f32 = run("f16"), run("f32")
+    for (c0, s0), (c1, s1) in zip(f32, planes):
+        assert c1["returns/mean"] == pytest.approx(c0["returns/mean"], rel=1e-4)
+        for k in ("losses/policy", "losses/vf", "losses/total"):
+            assert s1[k] == pytest.approx(s0[k], rel=2e-3, abs=2e-6), k
+    assert planes[-1][0]["returns/mean"] > planes[0][0]["returns/mean"]
