@@ -254,25 +254,34 @@ constexpr int kF16Top = 14;                                // scaled operands st
 
 // (x0, x1) -> packed fp16 pairs hi, lo (element 0 in the low half); scalar arithmetic, as
 // split_pair(): no packed fp32 ops beside the MFMAs.
+// (Round 5, tools/probes/valu_cost_probe.hip: on gfx950 v_fma_mix{lo,hi}_f16 issue at HALF rate -- 7.5 cycles per
+// instruction and SIMD where v_fma_f32 / v_fma_mix_f32 take 3.8 and v_mul_f32 2.2 -- while v_cvt_pk_f16_f32 rounds TWO
+// floats into a packed pair in 4.1.  So the planes are formed as  t = x s (exact: two muls), hi = cvt_pk(t0, t1), the
+// residuals by v_fma_mix_f32 against the halves of hi (exact), lo = cvt_pk(r0, r1): the SAME bits as the four mix
+// instructions gave for a power-of-two s, 20.6 cycles per pair instead of 30.2; the wide forms 25 instead of 38.)
 __device__ __forceinline__ void f16_pair(float x0, float x1, uint32_t &hi, uint32_t &lo) {
-  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-  const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
-  const half2v hp = {h0, h1}, lp = {(_Float16)r0, (_Float16)r1};
-  hi = __builtin_bit_cast(uint32_t, hp);
-  lo = __builtin_bit_cast(uint32_t, lp);
+  float r0, r1;
+  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_fma_mix_f32 %2, %4, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %3, %5, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_cvt_pk_f16_f32 %1, %2, %3"
+      : "=&v"(hi), "=&v"(lo), "=&v"(r0), "=&v"(r1)
+      : "v"(x0), "v"(x1));
 }
 
 // (x0, x1) * s -> packed fp16 pairs hi = fp16(x * s), lo = fp16(x * s - hi), s a power of two (x * s exact),
-// element 0 in the low half.  v_fma_mix{lo,hi}_f16 compute fma(a, b, c) in fp32 from fp32 or fp16 sources
-// (op_sel_hi: which sources are fp16, op_sel: their half) and round ONCE to fp16 into one half of the
-// destination, keeping the other: four instructions per pair where cvt / cvt back / sub / cvt takes eight.
-// (The compiler itself pairs mixlo + mixhi on one register like this -- no wait state between them.)
+// element 0 in the low half.  v_fma_mix_f32 computes fma(a, b, c) in fp32 from fp32 or fp16 sources (op_sel_hi: which
+// sources are fp16, op_sel: their half): the residual against a half of the packed hi without converting it back.
+// (Rounds 3-4 formed both planes with v_fma_mix{lo,hi}_f16, four instructions per pair; see the note above f16_pair.)
 __device__ __forceinline__ void f16_pair_scaled(float x0, float x1, float s, uint32_t &hi, uint32_t &lo) {
-  asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-      "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-      "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-      : "=&v"(hi), "=&v"(lo)
+  float t0, t1;
+  asm("v_mul_f32 %2, %4, %6\n\t"
+      "v_mul_f32 %3, %5, %6\n\t"
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %3, %5, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_cvt_pk_f16_f32 %1, %2, %3"
+      : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1)
       : "v"(x0), "v"(x1), "v"(s));
 }
 
@@ -282,16 +291,20 @@ __device__ __forceinline__ void f16_pair_scaled(float x0, float x1, float s, uin
 // is rounded, so that it stays a normal fp16 number for |t * d| down to 2^-13 instead of 2^-3 -- 27 binades below the
 // top (2^14) with all 22 bits, not 17 -- and its absolute resolution is 2^-35, not 2^-24.  The matrix instruction undoes
 // the factor: its other operand is the ReLU gate, 1.0 for the hi product and 2^-11 = fp16 0x1000 for this one (one
-// v_and on the gate fragment: 0x3c00 & 0x1000).  k2048: a scalar register holding 2048.0f.  Six instructions per pair.
+// v_and on the gate fragment: 0x3c00 & 0x1000).  k2048: a scalar register holding 2048.0f.  Eight instructions per pair, 25 cycles.
 __device__ __forceinline__ void f16_pair_product_wide(float t0, float t1, float d0, float d1, float k2048, uint32_t &hi,
                                                       uint32_t &lo) {
+  // (hi = fp16 of the fp32-rounded product -- a double rounding where the mix instruction had one -- and the residual
+  // against THAT hi from the exact product: hi + 2^-11 lo is as close to t d as before)
   float r0, r1;
-  asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
-      "v_fma_mixhi_f16 %0, %5, %7, 0\n\t"
+  asm("v_mul_f32 %2, %6, %4\n\t"
+      "v_mul_f32 %3, %7, %5\n\t"
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
       "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
       "v_fma_mix_f32 %3, %5, %7, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixlo_f16 %1, %2, %8, 0\n\t"
-      "v_fma_mixhi_f16 %1, %3, %8, 0"
+      "v_mul_f32 %2, %8, %2\n\t"
+      "v_mul_f32 %3, %8, %3\n\t"
+      "v_cvt_pk_f16_f32 %1, %2, %3"
       : "=&v"(hi), "=&v"(lo), "=&v"(r0), "=&v"(r1)
       : "v"(t0), "v"(t1), "s"(d0), "s"(d1), "s"(k2048));
 }
@@ -302,12 +315,14 @@ constexpr uint32_t kF16GateLowMask = 0x10001000u;  // fp16 1.0 (0x3c00) -> 2^-11
 // operand's hi plane times 2^-11, formed on the fragment registers (f16_pair_times) once their own product is issued.
 __device__ __forceinline__ void f16_pair_scaled_wide(float x0, float x1, float s, float k2048, uint32_t &hi, uint32_t &lo) {
   float r0, r1;
-  asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
-      "v_fma_mixhi_f16 %0, %5, %6, 0\n\t"
+  asm("v_mul_f32 %2, %4, %6\n\t"
+      "v_mul_f32 %3, %5, %6\n\t"
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
       "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
       "v_fma_mix_f32 %3, %5, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixlo_f16 %1, %2, %7, 0\n\t"
-      "v_fma_mixhi_f16 %1, %3, %7, 0"
+      "v_mul_f32 %2, %7, %2\n\t"
+      "v_mul_f32 %3, %7, %3\n\t"
+      "v_cvt_pk_f16_f32 %1, %2, %3"
       : "=&v"(hi), "=&v"(lo), "=&v"(r0), "=&v"(r1)
       : "v"(x0), "v"(x1), "v"(s), "s"(k2048));
 }
@@ -316,12 +331,14 @@ __device__ __forceinline__ void f16_pair_scaled_wide(float x0, float x1, float s
 // a pair are two ROWS with their own factors.
 __device__ __forceinline__ void f16_pair_scaled2_wide(float x0, float x1, float s0, float s1, float k2048, uint32_t &hi, uint32_t &lo) {
   float r0, r1;
-  asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
-      "v_fma_mixhi_f16 %0, %5, %7, 0\n\t"
+  asm("v_mul_f32 %2, %4, %6\n\t"
+      "v_mul_f32 %3, %5, %7\n\t"
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
       "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
       "v_fma_mix_f32 %3, %5, %7, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixlo_f16 %1, %2, %8, 0\n\t"
-      "v_fma_mixhi_f16 %1, %3, %8, 0"
+      "v_mul_f32 %2, %8, %2\n\t"
+      "v_mul_f32 %3, %8, %3\n\t"
+      "v_cvt_pk_f16_f32 %1, %2, %3"
       : "=&v"(hi), "=&v"(lo), "=&v"(r0), "=&v"(r1)
       : "v"(x0), "v"(x1), "v"(s0), "v"(s1), "s"(k2048));
 }
