@@ -44,6 +44,10 @@ __global__ __launch_bounds__(1024) void probe(float *out, int iters) {
         if (OP == 22) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
         if (OP == 23) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(v[i]) : "v"(u[(i + 1) & 15]));
         if (OP == 24) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(m), "v"(c));
+        if (OP == 25) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(*reinterpret_cast<double *>(&v[(2 * i) & 15])) : "v"(*reinterpret_cast<double *>(&v[(2 * i + 4) & 15])), "v"(*reinterpret_cast<double *>(&v[(2 * i + 8) & 15])));
+        if (OP == 26) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*reinterpret_cast<double *>(&v[(2 * i) & 15])) : "v"(*reinterpret_cast<double *>(&v[(2 * i + 4) & 15])));
+        if (OP == 27) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+        if (OP == 28) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[i]));
         if (OP == 15) asm volatile("v_cmp_lt_f32 s[20:21], 0, %0\n\tv_cndmask_b32 %1, 0, %1, s[20:21]" : : "v"(v[i]), "v"(u[i]) : "s20", "s21");
       }
   }
@@ -101,5 +105,9 @@ int main() {
   run<22>("v_sub_f32", 1, out);
   run<23>("v_ldexp_f32", 1, out);
   run<24>("v_fmac_f32 (vop2)", 1, out);
+  run<25>("v_pk_fma_f32 (two fmas)", 1, out);
+  run<26>("v_pk_mul_f32 (two muls)", 1, out);
+  run<27>("v_exp_f32", 1, out);
+  run<28>("v_rcp_f32", 1, out);
   return 0;
 }
