@@ -101,7 +101,7 @@ ALGORITHMIC_BYTES = {
 
 # Fabric traffic of the recurrent bench's kernels (rocprofv3 --pmc TCC_EA0_* per launch at 8 192 envs x 256 steps,
 # tools/diag/recurrent_bench_pmc.sh -> profiles/r03_cfg5_fabric_traffic.txt): bytes per unit of the launch that was profiled
-FABRIC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_cfg5_fabric_traffic.txt") for r in (5, 4, 3))
+FABRIC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_cfg5_fabric_traffic.txt") for r in (6, 5, 4, 3))
                        if os.path.exists(p)), "")
 FABRIC_KERNEL = {  # bench name -> (substring of the profiled kernel's name, units of that launch)
     "lstm_rows_backward": ("lstm_rows_backward_heads_kernel", 1 << 21),
@@ -132,7 +132,7 @@ def fabric_traffic(name: str, units_per_launch: float):
 # passes over tools/kernel_microbench.py at config-2 shapes; corrected as
 # MI355X_MICROARCH.md prescribes; summary committed under profiles/). Scaled by
 # units to the launch size bench.py uses.
-PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_microbench.json") for r in (5, 4, 3, 2, 1))
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_microbench.json") for r in (6, 5, 4, 3, 2, 1))
                     if os.path.exists(p)), os.path.join(ROOT, "profiles", "r05_pmc_traffic_microbench.json"))
 PMC_KERNEL = {  # bench name -> (substring of the profiled kernel name, units in that profiled launch)
     "ppo_loss_categorical": ("ppo_loss_categorical_kernel", 1 << 22),
@@ -163,8 +163,10 @@ PMC_KERNEL_F16 = {  # the fp16-plane kernels (forward, data gradient), same prof
     "mlp_wgrad": ("mlp_wgrad_fused16_kernel<1, 2>", 1 << 20),
 }
 PMC_KERNEL_SPLIT = {  # the six-product bf16-plane weight gradient (RL8_WGRAD_PLANES=bf16), same profiled shape
-    "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2, false, false>", 1 << 20),
+    # (round 5 dropped the F16 template parameter: "<1, 2, false, false>" in the r04 and older summaries)
+    "mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2, false>", 1 << 20),
 }
+PMC_KERNEL_SPLIT_OLD = {"mlp_wgrad": ("mlp_wgrad_split_kernel<1, 2, false, false>", 1 << 20)}
 PMC_KERNEL_GATE = {  # gate-mode kernels (heads whose dZ2 is gate * d * w3e)
     # (template <d_in, PAIR, BITS, F16>: the value tower's kernel, gate bits, two fp16 planes)
     # (round 4: the sixteen-wave kernel, template <d_in, PAIR>; the eight-wave one <d_in, PAIR, BITS, F16> in older summaries)
@@ -191,6 +193,8 @@ def pmc_traffic(name: str, units_per_launch: float, gemm: str = "f32"):
     table = {"f16x2-split": PMC_KERNEL_F16, "bf16x3-split": PMC_KERNEL_SPLIT, "bf16-gate-x3": PMC_KERNEL_GATE,
              "f16-gate-x2": PMC_KERNEL_GATE, "f16-gatebits-x2": PMC_KERNEL_GATE}.get(gemm, PMC_KERNEL)
     needle, units = table.get(name, (None, 1))
+    if table is PMC_KERNEL_SPLIT and needle and not any(needle in kernel for kernel in summary):
+        needle, units = PMC_KERNEL_SPLIT_OLD.get(name, (None, 1))
     for kernel, rec in summary.items():
         if needle and needle in kernel:
             fixed = min(PMC_FIXED_BYTES.get(name, 0.0), rec["traffic_bytes_per_launch"])
@@ -233,6 +237,12 @@ def parse_args(argv: None | list[str] = None) -> argparse.Namespace:
     p.add_argument("--cpu-baseline-seconds", type=float, default=120.0,
                    help="cap on the CPU baseline's wall time (3 sweep points + 10 timed iterations take ~65 s on the GPU hosts)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--secondary", dest="secondary", action="store_true", default=None,
+                   help="after the headline (N = 1): BASELINE configs[2..4] on this one device, a few steps each, under the"
+                        " line's `secondary` key (default: on when the run IS the headline configuration)")
+    p.add_argument("--no-secondary", dest="secondary", action="store_false")
+    p.add_argument("--secondary-steps", type=int, default=3)
+    p.add_argument("--secondary-warmup", type=int, default=1)
     return p.parse_args(argv)
 
 
@@ -516,6 +526,33 @@ def run(args: argparse.Namespace) -> None:
               f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
     # no HIP device / no librl8_amd.so: AlgorithmConfig.build() raises HipExtensionError below
 
+    if args.secondary is None:  # default: with the headline configuration itself, on one device
+        args.secondary = (world == 1 and args.env == "discrete" and args.distribution == "default" and not args.recurrent
+                          and args.num_envs == 1 << 20 and args.horizon == 32 and args.minibatches == 1
+                          and args.towers == "matrix")
+    m = measure(args, world, backend)
+    if rank == 0:
+        line = headline(args, m, world, backend)
+        if world == 1 and args.secondary:
+            line["secondary"] = secondary_lines(args, world, backend)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure(args: argparse.Namespace, world: int, backend: None | str) -> dict:
+    """Build the algorithm ``args`` names, run ``args.warmup`` untimed and exactly ``args.steps`` timed
+    ``collect(); step()`` pairs between barriers (per-kernel HIP-event timers on), then ``args.uninstrumented_steps``
+    more with the timers off; returns the times and the per-kernel table.  Nothing of the algorithm survives the call
+    (buffers, records and caches are released), so several configurations can be measured in one process."""
+    import gc
+
+    import torch
+    import torch.distributed as dist
+
     from rl8_amd import AlgorithmConfig, RecurrentAlgorithmConfig, hip
     from rl8_amd.distributions import SquashedNormal
     from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv
@@ -702,160 +739,250 @@ def run(args: argparse.Namespace) -> None:
                                              else fabric_traffic(name, rec["units_per_launch"])),
         }
 
-    if rank == 0:
-        hbm_dominant = "ppo_loss_categorical" if "ppo_loss_categorical" in kernels else "ppo_loss_normal"
-        if args.towers == "piecewise":
-            line_extra = {"piecewise": dict(piecewise_mlp.stats)}
-        else:
-            line_extra = {}
-        variant = ("Recurrent" if args.recurrent else "") + (" SquashedNormal" if args.distribution == "squashed" else "")
-        dom = kernels[hbm_dominant]
-        # The kernel the timed region spends most of its time in.
-        dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
-        top = kernels[dominant]
-        if top["bound"] == "mfma" and top["gemm"] != "f32":
-            # bf16-plane kernel: priced in the bf16 multiply-adds the matrix pipe executes
-            # (6 per fp32 multiply-add of the algorithm) against the dense bf16 peak
-            roofline = {
-                "kernel": {"mlp_wgrad": "rl8_mlp_wgrad_fused_split_f32", "mlp_wgrad_gate": "rl8_mlp_wgrad_gate_bits_f32 (rank-one heads: one output, or a pair of opposite gradients)",
-                           "mlp_tower_backward_gate": "rl8_mlp_tower_backward_gate_f16_f32",
-                           "lstm_rows_backward": "rl8_lstm_rows_backward_heads_f32 (backward through time of the recurrent models' LSTM)",
-                           "lstm_wgrad": "rl8_lstm_wgrad_f16_f32", "lstm_step_save": "rl8_lstm_step_split_f32"}.get(
-                    dominant, f"rl8_{dominant}_{'f16' if top['gemm'] == 'f16x2-split' else 'split'}_f32"),
-                "bound": "mfma",
-                # ALGORITHMIC FLOP of the launch (one fp32 product per multiply-add of the reference's
-                # arithmetic) / HIP-event time, against the dense 16-bit MFMA peak the kernel's products run on
-                "achieved": top["achieved_TFLOPs"],
-                "peak": MFMA_BF16_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(top["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, 4),
-                # what the matrix pipe EXECUTES: plane_products 16-bit products per fp32 product (fp32 accuracy on a
-                # 16-bit pipe), against the same peak -- the ceiling of this scheme is 1 / plane_products
-                "executed_TFLOPs": top["executed_bf16_TFLOPs"],
-                "executed_frac": top["frac_of_bf16_mfma_peak"],
-                "plane_products": top["plane_products"],
-                "executed_flop_per_launch": top["executed_bf16_flop_per_launch"],
-                "flop_definition": (f"{top['plane_products']} 16-bit plane products x 2*1024*256 per row-step (the recurrent product of"
-                                    " the LSTM: fp32 operands as 3 exact bf16 planes / 2 scaled fp16 planes, fp32 accumulate)"
-                                    if dominant.startswith("lstm_") else
-                                    "3 bf16 plane products x 2*256*256 per row (ReLU gate as one exact bf16 plane x the three"
-                                    " planes of dOut*h1, fp32 accumulate)" if top["gemm"] == "bf16-gate-x3" else
-                                    "2 fp16 plane products x 2*256*256 per row (ReLU gate as one exact fp16 plane x the two"
-                                    " planes of dOut*h1 scaled per column, fp32 accumulate)" if top["gemm"] == "f16-gatebits-x2" else
-                                    "2 fp16 plane products x 2*256*256 per row (ReLU gate as one exact fp16 plane x the two"
-                                    " planes of w3e*W2, fp32 accumulate)" if top["gemm"] == "f16-gate-x2" else
-                                    "3 fp16 plane products x 2*256*256 per row (fp32 operands scaled by powers of two and"
-                                    " split into 2 fp16 planes, fp32 accumulate)" if top["gemm"] == "f16x2-split" else
-                                    "6 bf16 plane products x 2*256*256 per row (fp32 operands split exactly into"
-                                    " 3 bf16 planes, fp32 accumulate)"),
-                "f32_equivalent_TFLOPs": top["achieved_TFLOPs"],   # the algorithm's fp32 FLOP / time
-                "f32_mfma_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
-                "f32_equivalent_frac_of_f32_mfma_peak": top["frac_of_f32_mfma_peak"],  # > 1: beyond the fp32 matrix roofline
-                "sustained_TFLOPs_measured": MFMA_16BIT_SUSTAINED_TFLOPS,  # tools/probes/mfma_shape_probe.hip (power-limited)
-                "frac_of_sustained": round(top["executed_bf16_TFLOPs"] / MFMA_16BIT_SUSTAINED_TFLOPS, 4),
-                "algorithmic_flop_per_launch": top["algorithmic_flop_per_launch"],
-                "avg_launch_ms": top["avg_ms"],
-                "launches": top["launches"],
-                "share_of_step_ms": round(top["total_ms"] / args.steps, 2),
-                "traffic": top["pmc_traffic_bytes_per_launch"],
-            }
-        elif top["bound"] == "mfma":
-            roofline = {
-                "kernel": f"rl8_{dominant}_f32",
-                "bound": "mfma",
-                "achieved": top["achieved_TFLOPs"],
-                "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": top["frac_of_f32_mfma_peak"],
-                "algorithmic_flop_per_launch": top["algorithmic_flop_per_launch"],
-                "avg_launch_ms": top["avg_ms"],
-                "launches": top["launches"],
-                "share_of_step_ms": round(top["total_ms"] / args.steps, 2),
-                "traffic": top["pmc_traffic_bytes_per_launch"],
-            }
-        else:
-            roofline = None
-        transitions = global_envs * horizon * args.steps
-        line = {
-            "metric": "env transitions/sec + policy updates/sec, DiscreteDummyEnv num_envs=2^20 h=32",
-            "value": transitions / elapsed,
-            "unit": "env transitions/sec",
-            "policy_updates_per_sec": args.steps / elapsed,
-            "optimizer_steps_per_sec": args.steps * algo.hparams.num_sgd_iters * algo.hparams.num_minibatches / elapsed,
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "value_uninstrumented": (global_envs * horizon * args.uninstrumented_steps / plain_elapsed
-                                     if plain_elapsed else None),
-            "ms_per_step_uninstrumented": plain_elapsed / args.uninstrumented_steps * 1e3 if plain_elapsed else None,
-            "uninstrumented_steps": args.uninstrumented_steps if plain_elapsed else 0,
-            "rank_ms_per_step": {"min": min(rank_elapsed) / args.steps * 1e3, "max": max(rank_elapsed) / args.steps * 1e3,
-                                 "per_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed]},
-            "collect_ms_per_step": collect_ms / args.steps,
-            "update_ms_per_step": step_ms / args.steps,
-            "higher_is_better": True,
-            "scaling": args.scaling,
-            "world_size": world,
-            "backend": backend,
-            "collectives_per_step": algo.shards.collectives / max(args.steps + args.warmup
-                                                                   + (args.uninstrumented_steps if plain_elapsed else 0), 1),
-            "vs_baseline": None,
-            "dtype": "f32",
-            "gemm": sorted({k["gemm"] for k in kernels.values() if k["bound"] == "mfma"}),
-            "data": "synthetic (Philox-reset DiscreteDummyEnv states, random-init default MLP)",
-            "config": {
-                "workload": f"{env_cls.__name__}{variant} collect()+step(), num_envs={envs_per_gpu} per GPU"
-                            f" ({global_envs} total), horizon={horizon}, AlgorithmConfig defaults"
-                            + (" (4 SGD iters, one full-buffer minibatch, Adam 1e-3)" if args.minibatches == 1 else
-                               f" except sgd_minibatch_size = buffer / {args.minibatches} (4 SGD iters x {args.minibatches}"
-                               " shuffled minibatches, Adam 1e-3)"),
-                "num_envs_per_gpu": envs_per_gpu,
-                "num_envs_global": global_envs,
-                "horizon": horizon,
-                "parallelism": f"env-sharded x{world}",
-            },
-            "roofline": roofline if roofline is not None else {
-                "kernel": f"rl8_{hbm_dominant}_fwd_bwd_f32",
-                "bound": "hbm",
-                "achieved": dom["achieved_GBps"],
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(dom["achieved_GBps"] / HBM_PEAK_GBS, 4),
-                "frac_of_measured_copy_ceiling": round(dom["achieved_GBps"] / HBM_COPY_CEILING_GBS, 4),
-                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                "avg_launch_ms": dom["avg_ms"],
-                "launches": dom["launches"],
-                "traffic": dom["pmc_traffic_bytes_per_launch"],
-            },
-            "roofline_hbm": {
-                "kernel": f"rl8_{hbm_dominant}_fwd_bwd_f32",
-                "bound": "hbm",
-                "achieved": dom["achieved_GBps"],
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(dom["achieved_GBps"] / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                "avg_launch_ms": dom["avg_ms"],
-                "launches": dom["launches"],
-                "traffic": dom["pmc_traffic_bytes_per_launch"],
-            },
-            "kernels": kernels,
-            "kernels_note": "HIP-event times of ABI calls inside the timed region; the recurrent rollout's per-timestep"
-                            " launches are sampled (every 16th timestep), so their `launches` / `total_ms` are of the sample",
-            "hand_kernel_ms_per_step": round(sum(k["total_ms"] for k in kernels.values()) / args.steps, 3),
-            "fused_towers": True,
-            "towers": ("matrix kernels (the product path)" if args.towers == "matrix" else
-                       "OPT-IN PROTOTYPE: exact piecewise-linear tables of a scalar observation (rl8_amd/nn/piecewise_mlp.py);"
-                       " table build and gradient algebra still torch fp64 ops; not the headline"),
+    out = {
+        "kernels": kernels, "elapsed": elapsed, "plain_elapsed": plain_elapsed, "rank_elapsed": rank_elapsed,
+        "collect_ms": collect_ms, "step_ms": step_ms, "global_envs": global_envs, "envs_per_gpu": envs_per_gpu,
+        "horizon": horizon, "env_name": env_cls.__name__, "num_sgd_iters": algo.hparams.num_sgd_iters,
+        "num_minibatches": algo.hparams.num_minibatches, "collectives": algo.shards.collectives,
+        "piecewise": dict(piecewise_mlp.stats) if args.towers == "piecewise" else None,
+        "max_memory_allocated_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+    }
+    # release everything the configuration held on the device (the next one may need most of it)
+    algo._release_step_caches()
+    del algo, model
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    return out
+
+
+def roofline_of(kernels: dict, steps: int) -> tuple[None | dict, str, str]:
+    """The ``roofline`` object of a bench line: the kernel the timed region spent most time in (None when that kernel
+    is HBM-bound: the caller then prices the fused loss kernel), its bench name, and the name of the HBM kernel."""
+    hbm_dominant = "ppo_loss_categorical" if "ppo_loss_categorical" in kernels else "ppo_loss_normal"
+    dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
+    top = kernels[dominant]
+    if top["bound"] == "mfma" and top["gemm"] != "f32":
+        # bf16-plane kernel: priced in the bf16 multiply-adds the matrix pipe executes
+        # (6 per fp32 multiply-add of the algorithm) against the dense bf16 peak
+        roofline = {
+            "kernel": {"mlp_wgrad": "rl8_mlp_wgrad_fused_split_f32", "mlp_wgrad_gate": "rl8_mlp_wgrad_gate_bits_f32 (rank-one heads: one output, or a pair of opposite gradients)",
+                       "mlp_tower_backward_gate": "rl8_mlp_tower_backward_gate_f16_f32",
+                       "lstm_rows_backward": "rl8_lstm_rows_backward_heads_f32 (backward through time of the recurrent models' LSTM)",
+                       "lstm_wgrad": "rl8_lstm_wgrad_f16_f32", "lstm_step_save": "rl8_lstm_step_split_f32"}.get(
+                dominant, f"rl8_{dominant}_{'f16' if top['gemm'] == 'f16x2-split' else 'split'}_f32"),
+            "bound": "mfma",
+            # ALGORITHMIC FLOP of the launch (SURVEY 8d: one fp32 product per multiply-add of the reference's
+            # arithmetic) / HIP-event time, against the dense 16-bit MFMA peak the kernel's products run on
+            "achieved": top["achieved_TFLOPs"],
+            "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(top["achieved_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, 4),
+            # what the matrix pipe EXECUTES: plane_products 16-bit products per fp32 product (fp32 accuracy on a
+            # 16-bit pipe), against the same peak -- the ceiling of this scheme is 1 / plane_products
+            "executed_TFLOPs": top["executed_bf16_TFLOPs"],
+            "executed_frac": top["frac_of_bf16_mfma_peak"],
+            "plane_products": top["plane_products"],
+            "executed_flop_per_launch": top["executed_bf16_flop_per_launch"],
+            "flop_definition": (f"{top['plane_products']} 16-bit plane products x 2*1024*256 per row-step (the recurrent product of"
+                                " the LSTM: fp32 operands as 3 exact bf16 planes / 2 scaled fp16 planes, fp32 accumulate)"
+                                if dominant.startswith("lstm_") else
+                                "3 bf16 plane products x 2*256*256 per row (ReLU gate as one exact bf16 plane x the three"
+                                " planes of dOut*h1, fp32 accumulate)" if top["gemm"] == "bf16-gate-x3" else
+                                "2 fp16 plane products x 2*256*256 per row (ReLU gate as one exact fp16 plane x the two"
+                                " planes of dOut*h1 scaled per column, fp32 accumulate)" if top["gemm"] == "f16-gatebits-x2" else
+                                "2 fp16 plane products x 2*256*256 per row (ReLU gate as one exact fp16 plane x the two"
+                                " planes of w3e*W2, fp32 accumulate)" if top["gemm"] == "f16-gate-x2" else
+                                "3 fp16 plane products x 2*256*256 per row (fp32 operands scaled by powers of two and"
+                                " split into 2 fp16 planes, fp32 accumulate)" if top["gemm"] == "f16x2-split" else
+                                "6 bf16 plane products x 2*256*256 per row (fp32 operands split exactly into"
+                                " 3 bf16 planes, fp32 accumulate)"),
+            "f32_equivalent_TFLOPs": top["achieved_TFLOPs"],   # the algorithm's fp32 FLOP / time
+            "f32_mfma_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+            "f32_equivalent_frac_of_f32_mfma_peak": top["frac_of_f32_mfma_peak"],  # > 1: beyond the fp32 matrix roofline
+            "sustained_TFLOPs_measured": MFMA_16BIT_SUSTAINED_TFLOPS,  # tools/probes/mfma_shape_probe.hip (power-limited)
+            "frac_of_sustained": round(top["executed_bf16_TFLOPs"] / MFMA_16BIT_SUSTAINED_TFLOPS, 4),
+            "algorithmic_flop_per_launch": top["algorithmic_flop_per_launch"],
+            "avg_launch_ms": top["avg_ms"],
+            "launches": top["launches"],
+            "share_of_step_ms": round(top["total_ms"] / steps, 2),
+            "traffic": top["pmc_traffic_bytes_per_launch"],
         }
-        line.update(line_extra)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    elif top["bound"] == "mfma":
+        roofline = {
+            "kernel": f"rl8_{dominant}_f32",
+            "bound": "mfma",
+            "achieved": top["achieved_TFLOPs"],
+            "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": top["frac_of_f32_mfma_peak"],
+            "algorithmic_flop_per_launch": top["algorithmic_flop_per_launch"],
+            "avg_launch_ms": top["avg_ms"],
+            "launches": top["launches"],
+            "share_of_step_ms": round(top["total_ms"] / steps, 2),
+            "traffic": top["pmc_traffic_bytes_per_launch"],
+        }
+    else:
+        roofline = None
+    return roofline, dominant, hbm_dominant
+
+
+def hbm_roofline(kernels: dict, hbm_dominant: str) -> dict:
+    dom = kernels[hbm_dominant]
+    return {
+        "kernel": f"rl8_{hbm_dominant}_fwd_bwd_f32",
+        "bound": "hbm",
+        "achieved": dom["achieved_GBps"],
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(dom["achieved_GBps"] / HBM_PEAK_GBS, 4),
+        "frac_of_measured_copy_ceiling": round(dom["achieved_GBps"] / HBM_COPY_CEILING_GBS, 4),
+        "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+        "avg_launch_ms": dom["avg_ms"],
+        "launches": dom["launches"],
+        "traffic": dom["pmc_traffic_bytes_per_launch"],
+    }
+
+
+def workload_text(args: argparse.Namespace, m: dict) -> str:
+    variant = ("Recurrent" if args.recurrent else "") + (" SquashedNormal" if args.distribution == "squashed" else "")
+    return (f"{m['env_name']}{variant} collect()+step(), num_envs={m['envs_per_gpu']} per GPU"
+            f" ({m['global_envs']} total), horizon={m['horizon']}, AlgorithmConfig defaults"
+            + (" (4 SGD iters, one full-buffer minibatch, Adam 1e-3)" if args.minibatches == 1 else
+               f" except sgd_minibatch_size = buffer / {args.minibatches} (4 SGD iters x {args.minibatches}"
+               " shuffled minibatches, Adam 1e-3)"))
+
+
+def headline(args: argparse.Namespace, m: dict, world: int, backend: None | str) -> dict:
+    """The one JSON line of the contract from a :func:`measure` result."""
+    kernels, elapsed, plain_elapsed, rank_elapsed = m["kernels"], m["elapsed"], m["plain_elapsed"], m["rank_elapsed"]
+    global_envs, horizon = m["global_envs"], m["horizon"]
+    roofline, _, hbm_dominant = roofline_of(kernels, args.steps)
+    hbm = hbm_roofline(kernels, hbm_dominant)
+    transitions = global_envs * horizon * args.steps
+    line = {
+        "metric": "env transitions/sec + policy updates/sec, DiscreteDummyEnv num_envs=2^20 h=32",
+        "value": transitions / elapsed,
+        "unit": "env transitions/sec",
+        "policy_updates_per_sec": args.steps / elapsed,
+        "optimizer_steps_per_sec": args.steps * m["num_sgd_iters"] * m["num_minibatches"] / elapsed,
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "value_uninstrumented": (global_envs * horizon * args.uninstrumented_steps / plain_elapsed
+                                 if plain_elapsed else None),
+        "ms_per_step_uninstrumented": plain_elapsed / args.uninstrumented_steps * 1e3 if plain_elapsed else None,
+        "uninstrumented_steps": args.uninstrumented_steps if plain_elapsed else 0,
+        "rank_ms_per_step": {"min": min(rank_elapsed) / args.steps * 1e3, "max": max(rank_elapsed) / args.steps * 1e3,
+                             "per_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed]},
+        "collect_ms_per_step": m["collect_ms"] / args.steps,
+        "update_ms_per_step": m["step_ms"] / args.steps,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "world_size": world,
+        "backend": backend,
+        "collectives_per_step": m["collectives"] / max(args.steps + args.warmup
+                                                       + (args.uninstrumented_steps if plain_elapsed else 0), 1),
+        "vs_baseline": None,
+        "dtype": "f32",
+        "gemm": sorted({k["gemm"] for k in kernels.values() if k["bound"] == "mfma"}),
+        "data": "synthetic (Philox-reset DiscreteDummyEnv states, random-init default MLP)",
+        "config": {
+            "workload": workload_text(args, m),
+            "num_envs_per_gpu": m["envs_per_gpu"],
+            "num_envs_global": global_envs,
+            "horizon": horizon,
+            "parallelism": f"env-sharded x{world}",
+            # north_star quotes ONE problem (num_envs = 2^20 in total) at 1/2/4/8 GPUs: that table is
+            # `--scaling strong --num-envs 1048576 --gpus N`; this line's convention is `scaling` above
+            "scaling_conventions": {
+                "this_line": {"scaling": args.scaling, "num_envs_global": global_envs, "num_envs_per_gpu": m["envs_per_gpu"]},
+                "weak": {"num_envs_global": args.num_envs * world, "num_envs_per_gpu": args.num_envs},
+                "strong": ({"num_envs_global": args.num_envs, "num_envs_per_gpu": args.num_envs // world}
+                           if args.num_envs % world == 0 else None),
+                "north_star_table": "--scaling strong --num-envs 1048576 (2^20 environments in total at every N)",
+            },
+        },
+        "roofline": roofline if roofline is not None else hbm,
+        "roofline_hbm": {k: v for k, v in hbm.items() if k != "frac_of_measured_copy_ceiling"},
+        "kernels": kernels,
+        "kernels_note": "HIP-event times of ABI calls inside the timed region; the recurrent rollout's per-timestep"
+                        " launches are sampled (every 16th timestep), so their `launches` / `total_ms` are of the sample",
+        "hand_kernel_ms_per_step": round(sum(k["total_ms"] for k in kernels.values()) / args.steps, 3),
+        "max_memory_allocated_GB": m["max_memory_allocated_GB"],
+        "fused_towers": True,
+        "towers": ("matrix kernels (the product path)" if args.towers == "matrix" else
+                   "OPT-IN PROTOTYPE: exact piecewise-linear tables of a scalar observation (rl8_amd/nn/piecewise_mlp.py);"
+                   " table build and gradient algebra still torch fp64 ops; not the headline"),
+    }
+    if m["piecewise"] is not None:
+        line["piecewise"] = m["piecewise"]
+    return line
+
+
+#: BASELINE.json configs[2..4] on ONE device, measured after the headline in the same process (VERDICT r5 next #1b):
+#: (key, what BASELINE calls it, argument overrides).  configs[3] / [4] are quoted on 8 GPUs: here the whole stated
+#: problem runs on one.
+SECONDARY = (
+    ("cfg3", "configs[2]: CartPole, num_envs=2^18, horizon=128",
+     {"env": "cartpole", "num_envs": 1 << 18, "horizon": 128}),
+    ("cfg4", "configs[3]: ContinuousDummyEnv + SquashedNormal, num_envs=2^20, horizon=32 (whole problem on one device)",
+     {"env": "continuous", "distribution": "squashed", "num_envs": 1 << 20, "horizon": 32}),
+    ("cfg5", "configs[4]: RecurrentAlgorithmConfig on DiscreteDummyEnv, num_envs=2^16, horizon=256 (whole problem on one device)",
+     {"env": "discrete", "recurrent": True, "num_envs": 1 << 16, "horizon": 256}),
+)
+
+
+def secondary_lines(args: argparse.Namespace, world: int, backend: None | str) -> dict:
+    """The other single-device configurations of BASELINE.json, a few steps each, same timing rules as the headline
+    (warm-up, barrier + synchronize on both sides, HIP-event timers on, then the same steps with the timers off)."""
+    out: dict = {"note": "same process, after the headline's timed region; each: --secondary-warmup untimed +"
+                         " --secondary-steps timed collect()+step() with the kernel timers on, then as many without"}
+    for key, title, overrides in SECONDARY:
+        a = argparse.Namespace(**{**vars(args), "env": "discrete", "distribution": "default", "recurrent": False,
+                                  "minibatches": 1, "towers": "matrix", "scaling": "weak",
+                                  "steps": args.secondary_steps, "warmup": args.secondary_warmup,
+                                  "uninstrumented_steps": args.secondary_steps, **overrides})
+        t0 = time.perf_counter()
+        try:
+            m = measure(a, world, backend)
+        except Exception as exc:  # noqa: BLE001  (the headline must still be printed)
+            out[key] = {"config": title, "error": f"{exc.__class__.__name__}: {exc}"}
+            print(f"bench.py: secondary {key} failed: {exc!r}", file=sys.stderr, flush=True)
+            continue
+        kernels = m["kernels"]
+        roofline, dominant, hbm_dominant = roofline_of(kernels, a.steps)
+        if roofline is None:
+            roofline = hbm_roofline(kernels, hbm_dominant)
+        transitions = m["global_envs"] * m["horizon"]
+        top = sorted(kernels, key=lambda k: -kernels[k]["total_ms"])[:6]
+        out[key] = {
+            "config": title,
+            "workload": workload_text(a, m),
+            "value": transitions * a.steps / m["elapsed"],
+            "unit": "env transitions/sec",
+            "ms_per_step": m["elapsed"] / a.steps * 1e3,
+            "value_uninstrumented": transitions * a.uninstrumented_steps / m["plain_elapsed"] if m["plain_elapsed"] else None,
+            "collect_ms_per_step": m["collect_ms"] / a.steps,
+            "update_ms_per_step": m["step_ms"] / a.steps,
+            "steps": a.steps, "warmup": a.warmup,
+            "dominant_kernel": dominant,
+            "frac": roofline["frac"],
+            "executed_frac": roofline.get("executed_frac"),
+            "roofline": {k: roofline.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "executed_frac",
+                                                      "plane_products", "avg_launch_ms", "launches", "share_of_step_ms",
+                                                      "traffic")},
+            "kernels_ms_per_step": {k: {"ms_per_step": round(kernels[k]["total_ms"] / a.steps, 3),
+                                        "avg_ms": kernels[k]["avg_ms"], "launches": kernels[k]["launches"],
+                                        "frac": kernels[k].get("frac_of_bf16_mfma_peak", kernels[k].get("frac_of_8TBps"))}
+                                    for k in top},
+            "max_memory_allocated_GB": m["max_memory_allocated_GB"],
+            "wall_s": round(time.perf_counter() - t0, 1),
+        }
+        print(f"bench.py: secondary {key}: {out[key]['value'] / 1e6:.1f} M/s, {out[key]['ms_per_step']:.1f} ms/step,"
+              f" {out[key]['wall_s']} s", file=sys.stderr, flush=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -490,8 +490,7 @@ class Algorithm:
                 self.buffer[DataKeys.REWARDS],
                 self.buffer[DataKeys.REVERSED_DISCOUNTED_RETURNS] if rdr is not None else None,
             )
-            raw = self.shards.combine_rollout_stats(raw)
-            collect_stats, reward_scale = _collect_stats_from_raw(raw.tolist())
+            collect_stats, reward_scale = _collect_stats_from_raw(self.shards.combine_rollout_stats(raw))
             self.state.horizons += 1
             self.state.buffered = True
             self.state.reward_scale = reward_scale if hp.normalize_rewards else 1.0

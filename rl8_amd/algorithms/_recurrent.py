@@ -369,8 +369,7 @@ class RecurrentAlgorithm(Algorithm):
                 raw_rdr = hip.rollout_stats(rewards, self.buffer[DataKeys.REVERSED_DISCOUNTED_RETURNS])
                 raw = torch.cat([raw[:10], raw_rdr[10:]])
                 rdr_count = float(N * H)
-            raw = self.shards.combine_rollout_stats(raw)
-            values = raw.tolist()
+            values = self.shards.combine_rollout_stats(raw)
             collect_stats, _ = _collect_stats_from_raw(values)
             if rdr is not None:
                 world = self.shards.world_size
@@ -444,11 +443,10 @@ class RecurrentAlgorithm(Algorithm):
         L = hp.seq_len
         num_seqs = batch["_num_seqs"]
         dist_cls = self.policy.distribution_cls
-        if not has_fused_loss(dist_cls):
-            raise NotImplementedError(
-                "RecurrentAlgorithm trains with the built-in distributions"
-                " (Categorical, Normal, SquashedNormal)."
-            )
+        # A user's Distribution: the loss is composed from its own logp / entropy with device tensor ops, as the
+        # reference does with whatever class it was given (src/rl8/algorithms/_recurrent.py:560-585) -- the
+        # feed-forward algorithm's rule (Algorithm._composed_loss_backward), here per pass of sequences.
+        fused = has_fused_loss(dist_cls)
         seqs_per_pass = max(1, min(self.max_rows_per_pass, RECURRENT_MAX_ROWS_PER_PASS) // L)
         total_sums: None | torch.Tensor = None
         scale = None
@@ -468,15 +466,21 @@ class RecurrentAlgorithm(Algorithm):
                     inplace=False, requires_grad=True, return_actions=False, return_logp=False,
                     return_values=True,
                 )
-            sums, inputs, grads = fused_ppo_loss(
-                dist_cls, sample[DataKeys.FEATURES], sample[DataKeys.VALUES], batch[DataKeys.ACTIONS][rows],
-                batch[DataKeys.LOGP][rows], batch[DataKeys.ADVANTAGES][rows], batch[DataKeys.RETURNS][rows],
-                clip_param=hp.clip_param, dual_clip_param=hp.dual_clip_param, entropy_coeff=entropy_coeff,
-                vf_clip_param=hp.vf_clip_param, vf_coeff=hp.vf_coeff, grad_scale=grad_scale,
-            )
-            if scale is not None:
-                grads = [g * scale.to(g.dtype) for g in grads]
-            torch.autograd.backward(inputs, grads)
+            if fused:
+                sums, inputs, grads = fused_ppo_loss(
+                    dist_cls, sample[DataKeys.FEATURES], sample[DataKeys.VALUES], batch[DataKeys.ACTIONS][rows],
+                    batch[DataKeys.LOGP][rows], batch[DataKeys.ADVANTAGES][rows], batch[DataKeys.RETURNS][rows],
+                    clip_param=hp.clip_param, dual_clip_param=hp.dual_clip_param, entropy_coeff=entropy_coeff,
+                    vf_clip_param=hp.vf_clip_param, vf_coeff=hp.vf_coeff, grad_scale=grad_scale,
+                )
+                if scale is not None:
+                    grads = [g * scale.to(g.dtype) for g in grads]
+                torch.autograd.backward(inputs, grads)
+            else:
+                chunk = {k: batch[k][rows] for k in (DataKeys.ACTIONS, DataKeys.LOGP, DataKeys.ADVANTAGES,
+                                                     DataKeys.RETURNS)}
+                sums = self._composed_loss_backward(sample[DataKeys.FEATURES], sample[DataKeys.VALUES], chunk,
+                                                    entropy_coeff, grad_scale, scale)
             total_sums = sums if total_sums is None else total_sums + sums
         assert total_sums is not None
         return total_sums

@@ -1320,6 +1320,12 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_gate_kernel(
 
   int stage = 0;
   auto next_stage = [&]() { stage = stage + 1 == RING ? 0 : stage + 1; };
+  // INVARIANT (class 8, rows8_epilogue): the trip count of this loop is uniform over the workgroup (it depends on
+  // blockIdx.x alone) and EVERY one of the four waves runs rows8_epilogue exactly once per tile, publishing sixteen
+  // counters -- waves whose rows lie past m included (their rows carry zero factors).  Wave w's poll of wave w - 1's
+  // counter is unbounded: a wave-conditional tile loop or epilogue (skipping empty tail waves, say) turns it into a hang,
+  // not a wrong number.  tests/test_mlp_split_gpu.py::test_class8_chain_with_empty_waves_and_one_workgroup runs m < 32,
+  // m % 128 != 0 and a one-workgroup grid (RL8_MLP_GRID_CAP=1: the counters reach 16 x tiles).
   for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
     // ---- open the tile: this tile's gate block has landed (requested two half-steps and an epilogue ago: only the
     // eight pieces behind it may still be in flight); block 0's gate fragments; factors and observations of the wave's
@@ -1835,6 +1841,8 @@ __global__ __launch_bounds__(kBlock, 2) void mlp_rows_backward_general_kernel(
 
   int stage = 0;
   auto next_stage = [&]() { stage = stage + 1 == RING ? 0 : stage + 1; };
+  // (INVARIANT of rows8_epilogue's chain: uniform trip count, every wave runs the epilogue once per tile -- see the
+  // gate-mode kernel's tile loop)
   for (int64_t tile = blockIdx.x; tile < tiles; tile += stride) {
     // ---- open the tile (see the gate-mode kernel): the gate block has landed; the next tile's rows requested; row
     // scales; factors and observations to the exchange; block 0's fragments of both row tiles; the first requests

@@ -219,7 +219,15 @@ def _tower_backward(ctx, dout):
 # --------------------------------------------------------------------------- #
 #: Absolute cap on the h2 slabs a rollout record may hold (1 KiB per row and general-head tower: 34 GB at 2^25 rows),
 #: besides "a third of what is free when the slab is made" (ADVICE r4).  ``RL8_AMD_RECORD_H2_GIB`` overrides; 0: never.
-RECORD_H2_BUDGET_BYTES = int(float(os.environ.get("RL8_AMD_RECORD_H2_GIB", "48")) * (1 << 30))
+def _record_h2_budget_bytes() -> int:
+    try:  # (a malformed value must not abort importing the package: ADVICE r5)
+        gib = float(os.environ.get("RL8_AMD_RECORD_H2_GIB", "48"))
+    except ValueError:
+        gib = 48.0
+    return int(max(gib, 0.0) * (1 << 30))
+
+
+RECORD_H2_BUDGET_BYTES = _record_h2_budget_bytes()
 #: ... and the slabs are given back when, at the end of a step(), less than this is free on the device.
 RECORD_H2_KEEP_FREE_BYTES = 8 << 30
 

@@ -82,11 +82,11 @@ class EnvShards:
                 t.copy_(buf)
         return t
 
-    def combine_rollout_stats(self, raw: torch.Tensor):
-        """12 raw stats of this shard -> 12 raw stats of the global rollout (the input itself when not sharded, else a
-        host array: both answer ``.tolist()``)."""
+    def combine_rollout_stats(self, raw: torch.Tensor) -> list[float]:
+        """12 raw stats of this shard -> 12 raw stats of the global rollout, on the host as a plain list of floats in
+        either case (this read is the one host sync of ``collect()``)."""
         if not self.active:
-            return raw
+            return raw.reshape(-1).tolist()
         src, staged = self._staged(raw.contiguous().reshape(-1))
         flat = torch.empty(self.world_size * raw.numel(), dtype=raw.dtype, device=src.device)
         dist.all_gather_into_tensor(flat, src, group=self.group)
@@ -103,7 +103,7 @@ class EnvShards:
         out = gathered.sum(0)
         out[list(STAT_MIN)] = gathered[:, list(STAT_MIN)].min(0)
         out[list(STAT_MAX)] = gathered[:, list(STAT_MAX)].max(0)
-        return out  # (a numpy array: ``.tolist()`` as the tensor it replaces)
+        return out.tolist()
 
     def sum_gradients_(self, params: Iterable[torch.nn.Parameter], sums: Sequence[torch.Tensor] = ()) -> None:
         """ONE SUM all-reduce per optimizer step: the flattened gradient of ``params``

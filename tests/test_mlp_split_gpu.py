@@ -1091,6 +1091,64 @@ def test_class8_scales_over_observation_magnitudes(d_in, n_out, x_scale):
         assert float(((got[k].double() - want_g[k]).abs() / (size[k] + floor)).max()) < 2e-6, k
 
 
+_CHAIN_CHILD = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from rl8_amd import hip
+DEV = "cuda"
+def params(g, d_in, n_out):
+    r = lambda *s, k=1.0: (torch.rand(*s, device=DEV, generator=g) * 2 - 1) * k
+    return dict(w1=r(256, d_in, k=1.0), b1=r(256, k=0.5), w2=r(256, 256, k=0.0625), b2=r(256, k=0.0625),
+                w3=r(n_out, 256, k=0.0625), b3=r(n_out, k=0.0625))
+worst = 0.0
+for d_in, n_out in ((5, 3), (5, 1), (4, 2), (4, 1)):
+    for m in (1, 17, 31, 33, 100, 128 * 37 + 5):
+        g = torch.Generator(device=DEV).manual_seed(m * 7 + d_in + n_out)
+        x = torch.randn(m, d_in, device=DEV, generator=g) * 2
+        p = params(g, d_in, n_out)
+        dout = torch.randn(m, n_out, device=DEV, generator=g)
+        _, h1, h2, gate = hip.mlp_tower_forward_split(x, p["w1"], p["b1"], hip.mlp_pack_w2_f16(p["w2"]), p["b2"], p["w3"], p["b3"],
+                                                      save=True, save_gate=True)
+        w2t = hip.mlp_pack_w2_f16(p["w2"], transposed=True)
+        gate_pack = (lambda: hip.mlp_pack_w2_f16_gate(p["w2"], p["w3"])) if n_out == 1 else None
+        runs = [hip.mlp_tower_backward(x, None, h2, dout, w2t, p["w3"], p["w1"], p["b1"], gate2=gate, gate_pack=gate_pack,
+                                       assume_general=n_out == 2) for _ in range(2)]
+        torch.cuda.synchronize()
+        for k in runs[0]:
+            assert torch.equal(runs[0][k], runs[1][k]), (d_in, n_out, m, k)
+        dz2 = (dout.double() @ p["w3"].double()) * (h2 > 0)
+        open1 = h1 > 0
+        dz1 = (dz2 @ p["w2"].double()) * open1
+        inner = (dz2.abs() @ p["w2"].double().abs()) * open1
+        want = dict(w1=dz1.T @ x.double(), b1=dz1.sum(0))
+        size = dict(w1=inner.T @ x.double().abs(), b1=inner.sum(0))
+        for k in ("w1", "b1"):
+            err = float(((runs[0][k].double() - want[k]).abs() / (size[k] + 1e-300 + 1e-30 * float(size[k].max()))).max())
+            assert err < 2e-6, (d_in, n_out, m, k, err)
+            worst = max(worst, err)
+print("class8 chain ok", worst)
+"""
+
+
+def test_class8_chain_with_empty_waves_and_one_workgroup():
+    """the class-8 data gradients order the four waves' dW1 / db1 updates with an unbounded LDS poll of the
+    predecessor wave's counter (mlp_rows_kernels.hip, rows8_epilogue) -- correct only while every wave runs the epilogue
+    once per tile.  Exercised where that is most at risk: fewer rows than one wave's 32 (three EMPTY waves), m not a
+    multiple of 128 (ragged last tile), and ONE workgroup for the whole launch (``RL8_MLP_GRID_CAP=1``, read once per
+    process, hence a child interpreter: 38 tiles, counters up to 608) -- dW1 / db1 against fp64 on the forward's own
+    activations, twice, bit for bit.  A broken invariant shows as the child's timeout, not as a wrong number."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RL8_MLP_GRID_CAP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", _CHAIN_CHILD.format(root=root)], capture_output=True, text=True, timeout=240,
+                         env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "class8 chain ok" in out.stdout
+
+
 @pytest.mark.parametrize("d_in,n_out", [(5, 3), (5, 1), (4, 2)])
 def test_class8_data_gradient_over_many_tiles(d_in, n_out):
     """2^20 + 77 rows: every workgroup runs 16-17 tiles, so the waves' chain of running-sums updates (one array per

@@ -60,7 +60,8 @@ def worker(rank: int, port: int, results, WORLD: int = WORLD) -> None:  # noqa: 
 
         # 1. collect statistics
         combined = shards.combine_rollout_stats(raw_stats(rewards[local], rdr[local]))
-        stats, scale = _collect_stats_from_raw(combined.tolist())
+        assert isinstance(combined, list) and len(combined) == 12
+        stats, scale = _collect_stats_from_raw(combined)
         want = oracle.rollout_stats(rewards, rdr)
         for k, v in stats.items():
             assert v == pytest.approx(want[k], rel=1e-6), k
@@ -181,4 +182,4 @@ def test_single_process_is_identity():
     shards = EnvShards()
     assert not shards.active and shards.world_size == 1 and shards.env_offset(100) == 0
     t = torch.arange(12, dtype=torch.float64)
-    assert shards.combine_rollout_stats(t) is t and shards.sum_(t) is t
+    assert shards.combine_rollout_stats(t) == t.tolist() and shards.sum_(t) is t  # (a list of floats either way: ADVICE r5)

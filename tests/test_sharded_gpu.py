@@ -45,12 +45,16 @@ def run_algo(kind: str, **kw):
     return out, params, algo.local_num_envs
 
 
-def worker(rank: int, world: int, port: int, kind: str, kw: dict, results) -> None:
+def worker(rank: int, world: int, port: int, kind: str, kw: dict, results, backend: str = "gloo") -> None:
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":  # production: one device per rank, collectives through RCCL (tests/test_nccl_multi_gpu.py)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         out, params, local_envs = run_algo(kind, **kw)
         assert local_envs == GLOBAL_ENVS // world
@@ -63,11 +67,11 @@ def worker(rank: int, world: int, port: int, kind: str, kw: dict, results) -> No
         dist.destroy_process_group()
 
 
-def sharded(kind: str, world: int = 2, **kw):
+def sharded(kind: str, world: int = 2, backend: str = "gloo", **kw):
     ctx = mp.get_context("spawn")
     results = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, kind, kw, results)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, kind, kw, results, backend)) for r in range(world)]
     for p in procs:
         p.start()
     got = [results.get(timeout=300) for _ in procs]
@@ -100,8 +104,12 @@ def test_sharded_minibatches_keep_ranks_in_step():
     ("recurrent", {}),
 ])
 def test_two_ranks_match_one_process(kind, kw):
+    check_two_ranks_match_one_process(kind, kw, "gloo")
+
+
+def check_two_ranks_match_one_process(kind: str, kw: dict, backend: str) -> None:
     single, single_params, _ = run_algo(kind, **kw)
-    got = sharded(kind, **kw)
+    got = sharded(kind, backend=backend, **kw)
     (_, out0, params0), (_, out1, params1) = got
     # both ranks agree with each other exactly (same reduced numbers, same update)
     assert torch.equal(params0, params1)

@@ -4,7 +4,8 @@
 #   gpurun -- 'bash tools/diag/pmc_sq_counters.sh [tag script args...]'
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 TAG=${1:-mb}
-shift
+[ $# -gt 0 ] && shift
+mkdir -p "$R/gpurun_out"
 if [ $# -eq 0 ]; then set -- "$R/tools/kernel_microbench.py" --rounds 1; fi
 cd /tmp && export TMPDIR=/tmp
 pass() {

@@ -6,7 +6,7 @@
 # be judged are copied into profiles/ by hand afterwards.
 #   gpurun --timeout 1200 -- 'tools/final_measurements.sh r02'
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$R"
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gputests.log 2>&1; tail -2 gpurun_out/${TAG}_gputests.log
