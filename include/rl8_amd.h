@@ -21,6 +21,29 @@
  *   "env-major"  buffer leaf: [N][H+1] contiguous  (the reference's [N, H+1, 1])
  *   "time-major" buffer leaf: [H+1][N] contiguous  (rl8_amd's own rollout
  *                buffer; exposed to Python as a transposed [N, H+1, 1] view)
+ *
+ * Which entry runs where (round 6; every entry is exported, declared here and called by rl8_amd/hip.py --
+ * tests/test_host_logic.py checks the three lists against each other; none is dead):
+ *   PRODUCT, default path (AlgorithmConfig / RecurrentAlgorithmConfig defaults, built-in envs, default models):
+ *     rollout    rl8_rollout_step_{dummy,cartpole,mountain_car,pendulum}_f32, rl8_rollout_step_dummy_heads_f32,
+ *                rl8_rollout_scatter_f32 (user envs), rl8_rollout_stats_f32, rl8_*_reset_f32, rl8_*_step_f32 (Env.step()
+ *                called by the user), rl8_categorical_sample_logp_f32, rl8_normal_sample_logp_f32 (Distribution.sample())
+ *     update     rl8_gae_scan_f32, rl8_advantage_normalise_f32, rl8_ppo_loss_{categorical,normal}_fwd_bwd_f32,
+ *                rl8_pack_samples, rl8_gather_packed, rl8_gather_minibatch
+ *     towers     rl8_mlp_tower_forward_f16_f32, rl8_mlp_tower_backward_gate_f16_f32, rl8_mlp_tower_backward_f16_f32,
+ *                rl8_mlp_wgrad_gate_bits_f32, rl8_mlp_wgrad_fused_split_f32, rl8_mlp_wgrad_fused_pair_f32,
+ *                rl8_mlp_pack_w2_f16, rl8_mlp_pack_w2_f16_gate, rl8_mlp_dout_pair_check, the *_supports / *_bytes /
+ *                *_floats / *_max_rows queries
+ *     recurrent  rl8_lstm_pack_split, rl8_lstm_split_state[_bound], rl8_lstm_step_split_f32,
+ *                rl8_lstm_rows_backward_pack, rl8_lstm_rows_backward[_heads]_f32, rl8_lstm_wgrad_f16_f32,
+ *                rl8_linear_heads_{forward,forward_pair,backward}_f32
+ *   PRODUCT, fallback (shapes outside the plane kernels' envelope -- d_in > 16, n_out > 8, hidden != 256 go to eager --
+ *   or a switch: RL8_AMD_TOWER_GEMM=f32, RL8_AMD_LSTM_GEMM=f32, RL8_WGRAD_PLANES=bf16, RL8_AMD_LSTM_WGRAD_PLANES=bf16,
+ *   RL8_AMD_LSTM_BACKWARD_ROWS=0), and THE YARDSTICK the parity tests hold the plane kernels against beside fp64:
+ *     rl8_mlp_tower_forward_f32, rl8_mlp_tower_backward_f32, rl8_mlp_wgrad_f32, rl8_mlp_wgrad_split_f32,
+ *     rl8_mlp_pack_w2_f32, rl8_lstm_pack_f32, rl8_lstm_forward_f32, rl8_lstm_backward_f32,
+ *     rl8_mlp_wgrad_strided_f32, rl8_mlp_wgrad_split_strided_f32, rl8_mlp_wgrad_f16_strided_f32 (one gate per launch)
+ *   OPT-IN prototype (RL8_AMD_TOWERS=piecewise; never the default, never the headline): rl8_pw_*
  */
 #ifndef RL8_AMD_H
 #define RL8_AMD_H

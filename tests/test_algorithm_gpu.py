@@ -10,7 +10,9 @@ reference, so logits differ in the last ulps; everything downstream is compared
 with tolerances that reflect fp32 GEMM reordering, not kernel error.
 """
 
+import json
 import math
+import os
 from unittest.mock import patch
 
 import numpy as np
@@ -75,21 +77,51 @@ def compare_collect(algo, g, it, *, discrete, loose=None):
     if discrete:
         assert np.array_equal(got_actions, want["actions"][:, :HORIZON])
     else:
-        np.testing.assert_allclose(got_actions, want["actions"][:, :HORIZON], rtol=1e-5, atol=1e-5)
+        close_arrays(f"it{it} buffer actions", got_actions, want["actions"][:, :HORIZON], rtol=1e-5, atol=1e-5)
     for key in ("obs", "rewards", "reversed_discounted_returns"):
-        np.testing.assert_allclose(buf[key].cpu().numpy(), want[key], rtol=1e-5, atol=1e-4, err_msg=key)
-    np.testing.assert_allclose(buf[DataKeys.LOGP].cpu().numpy()[:, :HORIZON], want["logp"][:, :HORIZON],
-                               rtol=1e-5 * loose, atol=(2e-5 if discrete else 5e-4) * loose)
-    np.testing.assert_allclose(buf[DataKeys.VALUES].cpu().numpy(), want["values"], rtol=1e-4 * loose,
-                               atol=2e-5 * loose)
+        close_arrays(f"it{it} buffer {key}", buf[key].cpu().numpy(), want[key], rtol=1e-5, atol=1e-4, err_msg=key)
+    close_arrays(f"it{it} buffer logp", buf[DataKeys.LOGP].cpu().numpy()[:, :HORIZON], want["logp"][:, :HORIZON],
+                 rtol=1e-5 * loose, atol=(2e-5 if discrete else 5e-4) * loose)
+    close_arrays(f"it{it} buffer values", buf[DataKeys.VALUES].cpu().numpy(), want["values"], rtol=1e-4 * loose,
+                 atol=2e-5 * loose)
 
 
-def compare_stats(got, keys, want, rel, abs_tol=1e-7):
+# Drift monitor: with RL8_TRACE_DRIFT_JSON=<path> every comparison of the free-running traces
+# also records error / allowed (1.0 = at the band) under the running test's name; the file is rewritten after each
+# comparison.  profiles/r06_trace_drift.json is that file from this round's kernels.
+_DRIFT: dict = {}
+
+
+def _record_drift(label: str, err: float, allowed: float) -> None:
+    path = os.environ.get("RL8_TRACE_DRIFT_JSON")
+    if not path:
+        return
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
+    slot = _DRIFT.setdefault(test, {})
+    ratio = err / allowed if allowed > 0 else (0.0 if err == 0 else float("inf"))
+    if label not in slot or ratio > slot[label]["used"]:
+        slot[label] = {"err": float(err), "allowed": float(allowed), "used": round(float(ratio), 4)}
+    with open(path, "w") as f:
+        json.dump(_DRIFT, f, indent=1, sort_keys=True)
+
+
+def close_arrays(label, actual, desired, rtol, atol, err_msg=""):
+    """np.testing.assert_allclose that also reports how much of its band the worst element used."""
+    a, d = np.asarray(actual, dtype=np.float64), np.asarray(desired, dtype=np.float64)
+    if a.shape == d.shape and a.size:
+        used = np.abs(a - d) / (atol + rtol * np.abs(d))
+        i = int(np.nanargmax(used))
+        _record_drift(label, float(np.abs(a - d).reshape(-1)[i]), float((atol + rtol * np.abs(d)).reshape(-1)[i]))
+    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=atol, err_msg=err_msg or label)
+
+
+def compare_stats(got, keys, want, rel, abs_tol=1e-7, label=""):
     for k, w in zip(keys, want):
+        _record_drift(f"{label}{k}", abs(got[k] - w), max(rel * abs(w), abs_tol))
         assert got[k] == pytest.approx(w, rel=rel, abs=abs_tol), (k, got[k], w)
 
 
-def run_trace(golden, name, env_cls, *, discrete, step_rel, drift=(10.0, 2e-4), **config):
+def run_trace(golden, name, env_cls, *, discrete, step_rel, drift=(10.0, 2e-4), weights_atol=(2e-4, 1e-3), **config):
     g = golden(name)
     algo = build_from_trace(g, env_cls, **config)
     for it in range(2):
@@ -98,7 +130,7 @@ def run_trace(golden, name, env_cls, *, discrete, step_rel, drift=(10.0, 2e-4), 
         compare_collect(algo, g, it, discrete=discrete)
         # absolute band: rewards/max is -min|state| of states that are O(100) sums of
         # actions, so one fp32 ulp of a state (7.6e-6) is the floor for it.
-        compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5, abs_tol=1e-5)
+        compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5, abs_tol=1e-5, label=f"it{it} collect ")
         assert algo.state.reward_scale == pytest.approx(float(g[f"it{it}_reward_scale"]), rel=1e-5)
         step_stats = algo.step()
         # The 1e-5 bar against the reference's own numbers is held where weights are
@@ -112,9 +144,9 @@ def run_trace(golden, name, env_cls, *, discrete, step_rel, drift=(10.0, 2e-4), 
         # iteration-1 KL by 7e-4 relative on the minibatched config:
         # profiles/r02_reference_drift.json.)
         compare_stats(step_stats, g["step_stat_keys"], g[f"it{it}_step_stats"], step_rel * (1 if it == 0 else drift[0]),
-                      1e-7 if it == 0 else drift[1])
+                      1e-7 if it == 0 else drift[1], label=f"it{it} step ")
         final_obs = algo.buffer[DataKeys.OBS][:, -1].cpu().numpy()
-        np.testing.assert_allclose(final_obs, g[f"it{it}_final_obs"], rtol=1e-5, atol=1e-4)
+        close_arrays(f"it{it} final_obs", final_obs, g[f"it{it}_final_obs"], rtol=1e-5, atol=1e-4)
         # the rest of the buffer was zeroed (reference re-allocates it, :603-609)
         assert float(algo.buffer[DataKeys.REWARDS].abs().sum()) == 0.0
         assert float(algo.buffer[DataKeys.OBS][:, :-1].abs().sum()) == 0.0
@@ -123,8 +155,8 @@ def run_trace(golden, name, env_cls, *, discrete, step_rel, drift=(10.0, 2e-4), 
             # Adam moves each weight by <= lr (1e-3) per step whatever the gradient's
             # size, so rounding-level gradient differences show up at the 1e-4 level
             # after tens of optimizer steps.
-            np.testing.assert_allclose(v.cpu().numpy(), g[f"it{it}_final_{k}"], rtol=2e-3,
-                                       atol=2e-4 if it == 0 else 1e-3, err_msg=f"it{it} {k}")
+            close_arrays(f"it{it} weights {k}", v.cpu().numpy(), g[f"it{it}_final_{k}"], rtol=2e-3,
+                         atol=weights_atol[0] if it == 0 else weights_atol[1], err_msg=f"it{it} {k}")
 
 
 def test_trace_feedforward_discrete_full_batch(golden):
@@ -394,19 +426,19 @@ def run_recurrent_trace(golden, name, env_cls, *, discrete, **config):
         if discrete:
             assert np.array_equal(got_actions, g[f"it{it}_collect_actions"][:, :HORIZON])
         else:
-            np.testing.assert_allclose(got_actions, g[f"it{it}_collect_actions"][:, :HORIZON], rtol=1e-4, atol=1e-4 * loose)
+            close_arrays(f"it{it} buffer actions", got_actions, g[f"it{it}_collect_actions"][:, :HORIZON], rtol=1e-4, atol=1e-4 * loose)
         for key in ("obs", "rewards", "reversed_discounted_returns"):
-            np.testing.assert_allclose(buf[key].cpu().numpy(), g[f"it{it}_collect_{key}"], rtol=1e-5, atol=2e-4 * loose, err_msg=key)
-        np.testing.assert_allclose(buf[DataKeys.VALUES].cpu().numpy(), g[f"it{it}_collect_values"], rtol=1e-4 * loose, atol=5e-5 * loose)
+            close_arrays(f"it{it} buffer {key}", buf[key].cpu().numpy(), g[f"it{it}_collect_{key}"], rtol=1e-5, atol=2e-4 * loose, err_msg=key)
+        close_arrays(f"it{it} buffer values", buf[DataKeys.VALUES].cpu().numpy(), g[f"it{it}_collect_values"], rtol=1e-4 * loose, atol=5e-5 * loose)
         for sk in ("hidden_states", "cell_states"):
             leaf = buf[DataKeys.STATES][sk].cpu().numpy()
-            np.testing.assert_allclose(leaf[:, -1], g[f"it{it}_collect_states_{sk}_last"], rtol=1e-4 * loose, atol=2e-5 * loose)
-            np.testing.assert_allclose(leaf[:, 6], g[f"it{it}_collect_states_{sk}_col6"], rtol=1e-4 * loose, atol=2e-5 * loose)
-        compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5 * loose, 1e-7)
+            close_arrays(f"it{it} {sk} last", leaf[:, -1], g[f"it{it}_collect_states_{sk}_last"], rtol=1e-4 * loose, atol=2e-5 * loose)
+            close_arrays(f"it{it} {sk} col6", leaf[:, 6], g[f"it{it}_collect_states_{sk}_col6"], rtol=1e-4 * loose, atol=2e-5 * loose)
+        compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5 * loose, 1e-7, label=f"it{it} collect ")
         assert algo.state.reward_scale == pytest.approx(float(g[f"it{it}_reward_scale"]), rel=1e-5 * loose)
         step_stats = algo.step()
         compare_stats(step_stats, g["step_stat_keys"], g[f"it{it}_step_stats"], 1e-3 * (1 if it == 0 else 10),
-                      2e-6 if it == 0 else 1e-4)
+                      2e-6 if it == 0 else 1e-4, label=f"it{it} step ")
         # final states survive the buffer reset (:645-646)
         for sk in ("hidden_states", "cell_states"):
             leaf = algo.buffer[DataKeys.STATES][sk]

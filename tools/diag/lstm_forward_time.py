@@ -9,7 +9,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from rl8_amd import hip  # noqa: E402
 
-b, l, d = 1 << 19, int(sys.argv[1]) if len(sys.argv) > 1 else 4, 1
+b, l, d = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 19, int(sys.argv[1]) if len(sys.argv) > 1 else 4, 1
+save = (sys.argv[3] if len(sys.argv) > 3 else "save") == "save"  # "rollout": no gates stored (the rollout's launches)
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(3)
 lstm = torch.nn.LSTM(d, 256, batch_first=True).to(dev)
@@ -21,16 +22,17 @@ planes = hip.lstm_state_planes(b, dev, copies=2)
 
 
 def run():
-    return hip.lstm_forward_split(x, h0, c0, packed, wb, save=True, planes=planes)
+    return hip.lstm_forward_split(x, h0, c0, packed, wb, save=save, planes=planes)
 
 
 run()
 torch.cuda.synchronize()
 a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
-for _ in range(5):
+reps = 5 if b * l >= 1 << 20 else 50
+for _ in range(reps):
     out = run()
     del out
 e.record()
 torch.cuda.synchronize()
-print(f"{a.elapsed_time(e) / 5:.3f} ms per forward of {b} x {l} row-steps ({a.elapsed_time(e) / 5 / l:.3f} ms per step launch incl. allocation)")
+print(f"{a.elapsed_time(e) / reps:.3f} ms per forward of {b} x {l} row-steps ({a.elapsed_time(e) / reps / l * 1e3:.1f} us per step launch incl. allocation), save={save}")
