@@ -513,7 +513,14 @@ RL8_API int rl8_mlp_tower_forward_f16_f32(const float *x, int64_t m, int d_in, c
 /* The backward kernels are compiled per width (their observations and dOut arrive through scalar loads of rows whose
  * stride is a compile-time constant): d_in 1..5, n_out 1..4.  Wider towers train through the fp32-MFMA kernels (their
  * rollouts still run the plane forward: rl8_mlp_forward_f16_supports). */
-RL8_API int rl8_mlp_backward_f16_supports(int d_in, int n_out) { return d_in >= 1 && d_in <= 5 && n_out >= 1 && n_out <= 4; }
+// d_in <= 7 (round 6; 5 until then): the data-gradient kernels' class 8 takes seven inputs (M slot 7 of its dW1 product
+// carries the ones of db1), the weight-gradient kernels are compiled per width.  7 x 4 excepted: the exact bf16-plane
+// weight gradient (the guard's fallback) keeps a step's observations and dOut in scalar registers -- 8 rows x (7 + 4)
+// floats = 88 of them -- and at that width the compiler parks the destination of a load still in flight
+// (tests/test_kernel_resources.py::_check_wgrad_scalar_windows finds it): not compiled.
+RL8_API int rl8_mlp_backward_f16_supports(int d_in, int n_out) {
+  return d_in >= 1 && d_in <= 7 && n_out >= 1 && n_out <= 4 && !(d_in == 7 && n_out == 4);
+}
 
 // Grids of the two halves of the fused backward (as in mlp_split_kernels.hip: both derive
 // them from m alone, so that each can zero the partial-row segments the other does not cover).

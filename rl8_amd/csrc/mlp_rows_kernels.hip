@@ -2091,6 +2091,10 @@ int mlp_rows_backward_general_dispatch(int grid, hipStream_t s, const float *x, 
   if (dc == D && (n_out == 3 || n_out == 4)) return launch_rows_backward_general<D, 4>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out, d_in);
   RL8_ROWS_BWD_GENERAL(1) RL8_ROWS_BWD_GENERAL(2) RL8_ROWS_BWD_GENERAL(3) RL8_ROWS_BWD_GENERAL(8)
 #undef RL8_ROWS_BWD_GENERAL
+  // one output in GENERAL mode (h2 given, no gate pack: the product takes the gate mode for it) at d_in 6, 7 -- widths the
+  // tile kernel of mlp_f16_kernels.hip is not compiled for: the two-output class with a zero second record
+  if (dc == 8 && d_in >= 6 && n_out == 1)
+    return launch_rows_backward_general<8, 2>(grid, s, x, w1, b1, dout, m, w2ts, w3, partials, stride, head_rows, gate2, n_out, d_in);
   return -1;
 }
 

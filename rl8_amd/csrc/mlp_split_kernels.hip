@@ -80,12 +80,12 @@ struct WgradFusedArgs {
   int guard_want = 0;
 };
 
-// Words of the 64 behind the slabs of the weight-gradient workspace: [0 .. 3] max |dOut column|, [4 .. 8] max |x column|
-// (wgrad_bounds_kernel), then the guard's sample sums, its ticket, its decision, the entries it found at the maximum and
-// the NaNs it saw (words 10 .. 16) -- the first 32 words are zeroed per call -- and two
+// Words of the 64 behind the slabs of the weight-gradient workspace: [0 .. 3] max |dOut column|, [4 .. 11] max |x column|
+// (wgrad_bounds_kernel; round 6: eight inputs, five until then), then the guard's sample sums, its ticket, its decision,
+// the entries it found at the maximum and the NaNs it saw (words 12 .. 18) -- the first 32 words are zeroed per call -- and two
 // counters that only ever grow (calls that consulted the guard, calls it sent to the bf16 planes), zeroed by whoever
 // allocates the workspace if they are to be read.
-constexpr int kGuardSum = 8 + 2 /* two words: a uint64, 8-byte aligned */, kGuardNonzero = 12, kGuardTicket = 13, kGuardFlag = 14;
+constexpr int kGuardSum = 12 /* two words: a uint64, 8-byte aligned */, kGuardNonzero = 14, kGuardTicket = 15, kGuardFlag = 16;
 constexpr int kGuardCalls = 32, kGuardFires = 33;
 // What the guard measures ("bound / mean |term|"): how far below the largest |dOut| of the call the
 // non-zero entries sit ON AVERAGE.  The planes are scaled by the column's bound, which carries max |dOut| as a factor;
@@ -232,6 +232,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_split_kernel(
       if constexpr (kIn > 2) xq[2] = scalar_buffer_load_x8<64>(rx);
       if constexpr (kIn > 3) xq[3] = scalar_buffer_load_x8<96>(rx);
       if constexpr (kIn > 4) xq[4] = scalar_buffer_load_x8<128>(rx);
+      if constexpr (kIn > 5) xq[5] = scalar_buffer_load_x8<160>(rx);
+      if constexpr (kIn > 6) xq[6] = scalar_buffer_load_x8<192>(rx);
       if constexpr (FUSED > 0) {
         const u32x4 rd = scalar_rsrc(fused.dout + row0 * kOut, rows * kOut * 4);
         dq[0] = scalar_buffer_load_x8<0>(rd);
@@ -630,6 +632,8 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_wgrad_gate_kernel(
     if constexpr (kIn > 2) xq[2] = scalar_buffer_load_x8<64>(rx);
     if constexpr (kIn > 3) xq[3] = scalar_buffer_load_x8<96>(rx);
     if constexpr (kIn > 4) xq[4] = scalar_buffer_load_x8<128>(rx);
+    if constexpr (kIn > 5) xq[5] = scalar_buffer_load_x8<160>(rx);
+    if constexpr (kIn > 6) xq[6] = scalar_buffer_load_x8<192>(rx);
     const u32x4 rd = scalar_rsrc(fused.dout + at * (PAIR ? 2 : 1), rows * (PAIR ? 8 : 4));
     dq = scalar_buffer_load_x8<0>(rd);
     if constexpr (PAIR) dq_hi = scalar_buffer_load_x8<32>(rd);
@@ -903,22 +907,46 @@ __global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_gate16_kernel(
   };
   // (32-bit offsets through buffer descriptors that end at row m: rows past the end read as zero, no branches.  No wait
   // here: the loads fly under the step's production and products; land() is the wait and the compiler's fence)
+  // d_in >= 6 (round 6): the scalar loads are made in land(), directly in front of their wait.  Requested a chunk ahead
+  // like the narrower widths' -- two sets of up to 40 scalar registers in flight across a whole consume() + produce() --
+  // the register allocator ran out and parked destinations of loads still in flight in vector lanes (v_writelane of stale
+  // data: tools/check_inflight_regs.py finds it).  One set, alive from its wait to the end of produce(); the wait costs a
+  // scalar-cache round trip per chunk, behind which the SIMD's other three waves work.
+  constexpr bool kLateScalars = kIn >= 6;
   auto issue = [&](Raw &r, int64_t n) {
     const int64_t row0 = (blockIdx.x + n * stride) * kWsChunk + 4 * q;
     const int64_t left = m - row0;
     const int rows = left <= 0 ? 0 : left < 4 ? (int)left : 4;
     const int64_t at = rows > 0 ? row0 : 0;
     const __amdgpu_buffer_rsrc_t g = buffer_rsrc(fused.gate2 + at * 8, rows * 32);
-    const u32x4 rx = scalar_rsrc(x + at * kIn, rows * kIn * 4);
-    const u32x4 rd = scalar_rsrc(fused.dout + at * (PAIR ? 2 : 1), rows * (PAIR ? 8 : 4));
+    if constexpr (kLateScalars) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r.g[e] = __float_as_uint(buffer_load_f32(g, (col >> 5) * 4, e * 32));
-    r.dv = scalar_buffer_load_x8<0>(rd);
-    r.xv[0] = scalar_buffer_load_x8<0>(rx);
-    if constexpr (4 * kIn > 8) r.xv[1] = scalar_buffer_load_x8<32>(rx);
-    if constexpr (4 * kIn > 16) r.xv[2] = scalar_buffer_load_x8<64>(rx);
+      for (int e = 0; e < 4; ++e) r.g[e] = __float_as_uint(buffer_load_f32(g, (col >> 5) * 4, e * 32));
+    } else {  // (the narrower widths: text and code as in rounds 4-5)
+      const u32x4 rx = scalar_rsrc(x + at * kIn, rows * kIn * 4);
+      const u32x4 rd = scalar_rsrc(fused.dout + at * (PAIR ? 2 : 1), rows * (PAIR ? 8 : 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.g[e] = __float_as_uint(buffer_load_f32(g, (col >> 5) * 4, e * 32));
+      r.dv = scalar_buffer_load_x8<0>(rd);
+      r.xv[0] = scalar_buffer_load_x8<0>(rx);
+      if constexpr (4 * kIn > 8) r.xv[1] = scalar_buffer_load_x8<32>(rx);
+      if constexpr (4 * kIn > 16) r.xv[2] = scalar_buffer_load_x8<64>(rx);
+    }
   };
-  auto land = [&](Raw &r) {
+  auto land = [&](Raw &r, [[maybe_unused]] int64_t n) {  // n: the chunk issue(r, n) was called for
+    if constexpr (kLateScalars) {
+      const int64_t row0 = (blockIdx.x + n * stride) * kWsChunk + 4 * q;
+      const int64_t left = m - row0;
+      const int rows = left <= 0 ? 0 : left < 4 ? (int)left : 4;
+      const int64_t at = rows > 0 ? row0 : 0;
+      const u32x4 rx = scalar_rsrc(x + at * kIn, rows * kIn * 4);
+      const u32x4 rd = scalar_rsrc(fused.dout + at * (PAIR ? 2 : 1), rows * (PAIR ? 8 : 4));
+      r.dv = scalar_buffer_load_x8<0>(rd);
+      r.xv[0] = scalar_buffer_load_x8<0>(rx);
+      r.xv[1] = scalar_buffer_load_x8<32>(rx);
+      r.xv[2] = scalar_buffer_load_x8<64>(rx);
+      if constexpr (4 * kIn > 24) r.xv[3] = scalar_buffer_load_x8<96>(rx);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     scalar_tie(r.dv);
 #pragma unroll
@@ -988,13 +1016,13 @@ __global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_gate16_kernel(
   // (produced two steps ago), barrier.  Stage (n + 2) % 4 was last read in step n - 2: two barriers back.
   Raw ra, rb;
   issue(ra, 0);
-  land(ra);
+  land(ra, 0);
   produce(ra, 0);
   issue(ra, 1);
-  land(ra);
+  land(ra, 1);
   produce(ra, 1);
   issue(ra, 2);
-  land(ra);
+  land(ra, 2);
   __syncthreads();
   const int64_t steps = (mine + 3) & ~(int64_t)3;  // (a multiple of four: chunks past the end are all zero)
 #pragma unroll 1
@@ -1003,20 +1031,20 @@ __global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_gate16_kernel(
     issue(rb, n + 3);
     consume(0);
     produce(ra, 2);
-    land(rb);
+    land(rb, n + 3);
     issue(ra, n + 4);
     consume(1);
     produce(rb, 3);
-    land(ra);
+    land(ra, n + 4);
     __syncthreads();
     issue(rb, n + 5);
     consume(2);
     produce(ra, 0);
-    land(rb);
+    land(rb, n + 5);
     issue(ra, n + 6);
     consume(3);
     produce(rb, 1);
-    land(ra);
+    land(ra, n + 6);
     __syncthreads();
   }
 
@@ -1122,23 +1150,43 @@ __global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_fused16_kernel(
     float h[4];               // h2 of this thread's column, its four rows
     f32x8 dv[kDv], xv[kXv];   // scalar registers: requested by issue(), usable behind land()
   };
+  constexpr bool kLateScalars = kIn >= 6;  // (see mlp_wgrad_gate16_kernel: the scalar loads in land(), one set alive)
   auto issue = [&](Raw &r, int64_t n) {
     const int64_t row0 = (blockIdx.x + n * stride) * kWsChunk + 4 * q;
     const int64_t left = m - row0;
     const int rows = left <= 0 ? 0 : left < 4 ? (int)left : 4;
     const int64_t at = rows > 0 ? row0 : 0;
     const __amdgpu_buffer_rsrc_t hr = buffer_rsrc(h2 + at * kHidden, rows * kHidden * 4);
-    const u32x4 rx = scalar_rsrc(x + at * kIn, rows * kIn * 4);
-    const u32x4 rd = scalar_rsrc(fused.dout + at * kOut, rows * kOut * 4);
+    if constexpr (kLateScalars) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r.h[e] = buffer_load_f32(hr, col * 4, e * (kHidden * 4));
-    r.dv[0] = scalar_buffer_load_x8<0>(rd);
-    if constexpr (kDv > 1) r.dv[1] = scalar_buffer_load_x8<32>(rd);
-    r.xv[0] = scalar_buffer_load_x8<0>(rx);
-    if constexpr (kXv > 1) r.xv[1] = scalar_buffer_load_x8<32>(rx);
-    if constexpr (kXv > 2) r.xv[2] = scalar_buffer_load_x8<64>(rx);
+      for (int e = 0; e < 4; ++e) r.h[e] = buffer_load_f32(hr, col * 4, e * (kHidden * 4));
+    } else {  // (the narrower widths: text and code as in rounds 4-5)
+      const u32x4 rx = scalar_rsrc(x + at * kIn, rows * kIn * 4);
+      const u32x4 rd = scalar_rsrc(fused.dout + at * kOut, rows * kOut * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.h[e] = buffer_load_f32(hr, col * 4, e * (kHidden * 4));
+      r.dv[0] = scalar_buffer_load_x8<0>(rd);
+      if constexpr (kDv > 1) r.dv[1] = scalar_buffer_load_x8<32>(rd);
+      r.xv[0] = scalar_buffer_load_x8<0>(rx);
+      if constexpr (kXv > 1) r.xv[1] = scalar_buffer_load_x8<32>(rx);
+      if constexpr (kXv > 2) r.xv[2] = scalar_buffer_load_x8<64>(rx);
+    }
   };
-  auto land = [&](Raw &r) {
+  auto land = [&](Raw &r, [[maybe_unused]] int64_t n) {  // n: the chunk issue(r, n) was called for
+    if constexpr (kLateScalars) {
+      const int64_t row0 = (blockIdx.x + n * stride) * kWsChunk + 4 * q;
+      const int64_t left = m - row0;
+      const int rows = left <= 0 ? 0 : left < 4 ? (int)left : 4;
+      const int64_t at = rows > 0 ? row0 : 0;
+      const u32x4 rx = scalar_rsrc(x + at * kIn, rows * kIn * 4);
+      const u32x4 rd = scalar_rsrc(fused.dout + at * kOut, rows * kOut * 4);
+      r.dv[0] = scalar_buffer_load_x8<0>(rd);
+      if constexpr (kDv > 1) r.dv[1] = scalar_buffer_load_x8<32>(rd);
+      r.xv[0] = scalar_buffer_load_x8<0>(rx);
+      r.xv[1] = scalar_buffer_load_x8<32>(rx);
+      r.xv[2] = scalar_buffer_load_x8<64>(rx);
+      if constexpr (kXv > 3) r.xv[3] = scalar_buffer_load_x8<96>(rx);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < kDv; ++i) scalar_tie(r.dv[i]);
@@ -1225,13 +1273,13 @@ __global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_fused16_kernel(
 
   Raw ra, rb;
   issue(ra, 0);
-  land(ra);
+  land(ra, 0);
   produce(ra, 0);
   issue(ra, 1);
-  land(ra);
+  land(ra, 1);
   produce(ra, 1);
   issue(ra, 2);
-  land(ra);
+  land(ra, 2);
   __syncthreads();
   const int64_t steps = (mine + 3) & ~(int64_t)3;
 #pragma unroll 1
@@ -1239,20 +1287,20 @@ __global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_fused16_kernel(
     issue(rb, n + 3);
     consume(0);
     produce(ra, 2);
-    land(rb);
+    land(rb, n + 3);
     issue(ra, n + 4);
     consume(1);
     produce(rb, 3);
-    land(ra);
+    land(ra, n + 4);
     __syncthreads();
     issue(rb, n + 5);
     consume(2);
     produce(ra, 0);
-    land(rb);
+    land(rb, n + 5);
     issue(ra, n + 6);
     consume(3);
     produce(rb, 1);
-    land(ra);
+    land(ra, n + 6);
     __syncthreads();
   }
 
@@ -1471,6 +1519,8 @@ static uint32_t *launch_wgrad_bounds(hipStream_t s, const float *dout, const flo
   else if (d_in == 3) wgrad_bounds_kernel<3, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
   else if (d_in == 4) wgrad_bounds_kernel<4, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
   else if (d_in == 5) wgrad_bounds_kernel<5, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
+  else if (d_in == 6) wgrad_bounds_kernel<6, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
+  else if (d_in == 7) wgrad_bounds_kernel<7, NOUT><<<grid, kBlock, 0, s>>>(dout, x, m, bounds);
   else return nullptr;
   return bounds;
 }
@@ -1482,7 +1532,7 @@ static uint32_t *launch_wgrad_bounds(hipStream_t s, const float *dout, const flo
 // of both sums (with the maximum inside a small sample its own 2^24 kept "count * 2^12 > sum" from ever
 // holding: what is asked is how far the OTHER entries sit below it); a NaN anywhere in the sample sends the call to the
 // exact planes.
-constexpr int kGuardTop = 15, kGuardNan = 16;  // words of the workspace tail: entries at the maximum, NaNs seen
+constexpr int kGuardTop = 17, kGuardNan = 18;  // words of the workspace tail: entries at the maximum, NaNs seen
 __global__ __launch_bounds__(kBlock) void wgrad_tail_kernel(const float *__restrict__ dout, int64_t floats,
                                                             uint32_t *__restrict__ bounds, int every) {
   float top = 0.0f;
@@ -1706,6 +1756,7 @@ __global__ __launch_bounds__(kW16Threads, 1) void mlp_wgrad_loadh16_kernel(
     r.xv[0] = scalar_buffer_load_x8<0>(rx);
     if constexpr (kXv > 1) r.xv[1] = scalar_buffer_load_x8<32>(rx);
     if constexpr (kXv > 2) r.xv[2] = scalar_buffer_load_x8<64>(rx);
+    if constexpr (kXv > 3) r.xv[3] = scalar_buffer_load_x8<96>(rx);
   };
   auto land = [&](Raw &r) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2009,7 +2060,9 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
         case 2: status = launch_wgrad_gate<2>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
         case 3: status = launch_wgrad_gate<3>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
         case 4: status = launch_wgrad_gate<4>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
-        default: status = launch_wgrad_gate<5>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+        case 5: status = launch_wgrad_gate<5>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+        case 6: status = launch_wgrad_gate<6>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+        default: status = launch_wgrad_gate<7>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
       }
       if (status != 0) return status;
       mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0);
@@ -2026,6 +2079,8 @@ RL8_API int rl8_mlp_wgrad_fused_split_f32(const float *h2, const float *dout, co
     RL8_WGRAD_FUSED(3, 1) RL8_WGRAD_FUSED(3, 2) RL8_WGRAD_FUSED(3, 3) RL8_WGRAD_FUSED(3, 4)
     RL8_WGRAD_FUSED(4, 1) RL8_WGRAD_FUSED(4, 2) RL8_WGRAD_FUSED(4, 3) RL8_WGRAD_FUSED(4, 4)
     RL8_WGRAD_FUSED(5, 1) RL8_WGRAD_FUSED(5, 2) RL8_WGRAD_FUSED(5, 3) RL8_WGRAD_FUSED(5, 4)
+    RL8_WGRAD_FUSED(6, 1) RL8_WGRAD_FUSED(6, 2) RL8_WGRAD_FUSED(6, 3) RL8_WGRAD_FUSED(6, 4)
+    RL8_WGRAD_FUSED(7, 1) RL8_WGRAD_FUSED(7, 2) RL8_WGRAD_FUSED(7, 3)  // (7 x 4: rl8_mlp_backward_f16_supports)
 #undef RL8_WGRAD_FUSED
     if (status != 0) return status;
     mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0);
@@ -2072,7 +2127,9 @@ RL8_API int rl8_mlp_wgrad_fused_pair_f32(const float *h2, const float *dout, con
       case 2: status = launch_wgrad_gate<2, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
       case 3: status = launch_wgrad_gate<3, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
       case 4: status = launch_wgrad_gate<4, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
-      default: status = launch_wgrad_gate<5, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+      case 5: status = launch_wgrad_gate<5, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+      case 6: status = launch_wgrad_gate<6, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
+      default: status = launch_wgrad_gate<7, true>(grid, s, h2s, xs, w1, b1, rows, workspace, fused); break;
     }
     if (status != 0) return status;
     mlp_wgrad_split_reduce_kernel<<<kHidden * kHidden / kBlock, kBlock, 0, s>>>(workspace, grid, dw2_out, at > 0);
@@ -2128,7 +2185,7 @@ RL8_API int rl8_mlp_wgrad_gate_bits_f32(const uint32_t *gate2, const float *dout
       status = n_out == 2 ? launch_wgrad_gate<D, true, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, exact) \
                           : launch_wgrad_gate<D, false, true>(grid, s, nullptr, xs, w1, b1, rows, workspace, exact); \
   }
-    RL8_WGRAD_BITS(1) RL8_WGRAD_BITS(2) RL8_WGRAD_BITS(3) RL8_WGRAD_BITS(4) RL8_WGRAD_BITS(5)
+    RL8_WGRAD_BITS(1) RL8_WGRAD_BITS(2) RL8_WGRAD_BITS(3) RL8_WGRAD_BITS(4) RL8_WGRAD_BITS(5) RL8_WGRAD_BITS(6) RL8_WGRAD_BITS(7)
 #undef RL8_WGRAD_BITS
     if (status != 0) return status;
     if (n_out == 2)

@@ -70,7 +70,7 @@ def compare_collect(algo, g, it, *, discrete, loose=None):
     # num_sgd_iters x num_minibatches Adam steps computed with a different GEMM
     # reduction order, so per-sample floats drift by a few 1e-5.
     if loose is None:
-        loose = 1.0 if it == 0 else 25.0
+        loose = 1.0 if it == 0 else 5.0   # (round 6: 25 until the drift was re-measured -- profiles/r06_trace_drift.json)
     buf = algo.buffer
     want = {k[len(f"it{it}_collect_"):]: g[k] for k in g if k.startswith(f"it{it}_collect_") and not k.endswith("stats")}
     got_actions = buf[DataKeys.ACTIONS][:, :HORIZON].cpu().numpy()
@@ -121,7 +121,13 @@ def compare_stats(got, keys, want, rel, abs_tol=1e-7, label=""):
         assert got[k] == pytest.approx(w, rel=rel, abs=abs_tol), (k, got[k], w)
 
 
-def run_trace(golden, name, env_cls, *, discrete, step_rel, drift=(10.0, 2e-4), weights_atol=(2e-4, 1e-3), **config):
+def run_trace(golden, name, env_cls, *, discrete, step_rel, drift=(10.0, 2e-5), weights_atol=(2e-5, 1e-4), **config):
+    # Bands re-taken in round 6.  profiles/r06_trace_drift.json holds, per comparison, how much of its
+    # ROUND-2 band this round's kernels used: <= 0.3 % of every iteration-1 StepStats band and <= 1 % of every weight band
+    # on the three full-batch traces (the towers now follow the reference's fp32 arithmetic to 1e-7..1e-6 through eight
+    # Adam steps), 30 % / 79 % on the 64-Adam-step minibatch trace.  Bands beaten by more than 3x were cut by 10x
+    # (StepStats: step_rel, the absolute floor of iteration 1, the weights' atol; the buffer's `loose` 25 -> 5), which
+    # still leaves the full-batch traces a factor >= 20; the minibatch trace keeps its own bands.
     g = golden(name)
     algo = build_from_trace(g, env_cls, **config)
     for it in range(2):
@@ -160,7 +166,7 @@ def run_trace(golden, name, env_cls, *, discrete, step_rel, drift=(10.0, 2e-4), 
 
 
 def test_trace_feedforward_discrete_full_batch(golden):
-    run_trace(golden, "trace_ff_discrete.npz", DiscreteDummyEnv, discrete=True, step_rel=1e-4)
+    run_trace(golden, "trace_ff_discrete.npz", DiscreteDummyEnv, discrete=True, step_rel=1e-5)
 
 
 def test_trace_feedforward_discrete_minibatches(golden):
@@ -172,16 +178,16 @@ def test_trace_feedforward_discrete_minibatches(golden):
     # config differs by 5-18 % between ANY two of the four by iteration 1, eager vs fp32 MFMA
     # included (profiles/r02_gemm_mode_drift.json).  Iteration 0 is held to 1e-4 as before.
     run_trace(golden, "trace_ff_discrete_minibatch.npz", DiscreteDummyEnv, discrete=True, step_rel=1e-4,
-              drift=(50.0, 5e-4), sgd_minibatch_size=256, entropy_coeff=1e-2, dual_clip_param=5.0, horizons_per_env_reset=2)
+              drift=(50.0, 5e-4), weights_atol=(2e-5, 1e-3), sgd_minibatch_size=256, entropy_coeff=1e-2, dual_clip_param=5.0, horizons_per_env_reset=2)
 
 
 def test_trace_feedforward_continuous_squashed(golden):
-    run_trace(golden, "trace_ff_continuous_squashed.npz", ContinuousDummyEnv, discrete=False, step_rel=1e-3,
+    run_trace(golden, "trace_ff_continuous_squashed.npz", ContinuousDummyEnv, discrete=False, step_rel=1e-4,
               distribution_cls=SquashedNormal)
 
 
 def test_trace_feedforward_continuous_normal_entropy(golden):
-    run_trace(golden, "trace_ff_continuous_normal.npz", ContinuousDummyEnv, discrete=False, step_rel=1e-3,
+    run_trace(golden, "trace_ff_continuous_normal.npz", ContinuousDummyEnv, discrete=False, step_rel=1e-4,
               entropy_coeff=1e-2)
 
 
@@ -420,7 +426,7 @@ def run_recurrent_trace(golden, name, env_cls, *, discrete, **config):
     for it in range(2):
         inject(algo, g, it)
         collect_stats = algo.collect()
-        loose = 1.0 if it == 0 else 25.0
+        loose = 1.0 if it == 0 else 5.0   # (25 until round 6: the recurrent traces used <= 2 % of those bands)
         buf = algo.buffer
         got_actions = buf[DataKeys.ACTIONS][:, :HORIZON].cpu().numpy()
         if discrete:
@@ -437,8 +443,9 @@ def run_recurrent_trace(golden, name, env_cls, *, discrete, **config):
         compare_stats(collect_stats, g["collect_stat_keys"], g[f"it{it}_collect_stats"], 1e-5 * loose, 1e-7, label=f"it{it} collect ")
         assert algo.state.reward_scale == pytest.approx(float(g[f"it{it}_reward_scale"]), rel=1e-5 * loose)
         step_stats = algo.step()
-        compare_stats(step_stats, g["step_stat_keys"], g[f"it{it}_step_stats"], 1e-3 * (1 if it == 0 else 10),
-                      2e-6 if it == 0 else 1e-4, label=f"it{it} step ")
+        # (round 6: 1e-3 / 1e-2 relative with floors 2e-6 / 1e-4 until the drift was re-measured: <= 0.4 % of those used)
+        compare_stats(step_stats, g["step_stat_keys"], g[f"it{it}_step_stats"], 1e-4 * (1 if it == 0 else 10),
+                      1e-6 if it == 0 else 1e-5, label=f"it{it} step ")
         # final states survive the buffer reset (:645-646)
         for sk in ("hidden_states", "cell_states"):
             leaf = algo.buffer[DataKeys.STATES][sk]
@@ -863,6 +870,45 @@ def test_recurrent_algorithm_with_a_users_distribution(env_cls):
     lstm_keys = [k for k in m2 if "lstm" in k]
     assert lstm_keys and all(m2[k] > 0 for k in lstm_keys), m2
     assert not torch.equal(p0, p2)
+
+
+@pytest.mark.parametrize("d,a", [(7, 3), (6, 4), (7, 2)])
+def test_walk_env_with_six_and_seven_observations_trains_on_the_plane_kernels(d, a, monkeypatch):
+    """Round 6 (VERDICT r5 missing #3, in part): d_in 6 and 7 (n_out <= 4; 7 x 4 excepted) train on the plane kernels end to
+    end -- class-8 data gradients, weight gradients compiled per width with their scalar loads made in front of the wait
+    -- like the 4- and 5-wide towers: three collect() + step() rounds against the SAME seeded run on the fp32-MFMA towers
+    (returns to 1e-4, losses to 2e-3, the return improves), and every backward call carried the gate bits of h2, which
+    only the plane path takes."""
+    from rl8_amd import AlgorithmConfig, hip
+    from rl8_amd.nn import fused_mlp
+
+    from ._envs import walk_env
+
+    assert hip.mlp_forward_f16_supports(d, a) and hip.mlp_backward_f16_supports(d, a) and hip.mlp_backward_f16_supports(d, 1)
+    calls = []
+    real = hip.mlp_tower_backward
+
+    def spy(*args, **kw):
+        calls.append(kw.get("gate2") is not None)
+        return real(*args, **kw)
+
+    def run(gemm):
+        monkeypatch.setattr(fused_mlp, "FORWARD_GEMM", gemm)
+        monkeypatch.setattr(fused_mlp, "BACKWARD_GEMM", gemm)
+        torch.manual_seed(11)
+        algo = AlgorithmConfig(num_envs=2048, horizon=16).build(walk_env(d, a))
+        return [(algo.collect(), algo.step()) for _ in range(3)]
+
+    monkeypatch.setattr(hip, "mlp_tower_backward", spy)
+    planes = run("f16")
+    assert calls and all(calls), calls
+    monkeypatch.setattr(hip, "mlp_tower_backward", real)
+    f32 = run("f32")
+    for (c0, s0), (c1, s1) in zip(f32, planes):
+        assert c1["returns/mean"] == pytest.approx(c0["returns/mean"], rel=1e-4)
+        for k in ("losses/policy", "losses/vf", "losses/total"):
+            assert s1[k] == pytest.approx(s0[k], rel=2e-3, abs=2e-6), k
+    assert planes[-1][0]["returns/mean"] > planes[0][0]["returns/mean"]
 
 
 @pytest.mark.parametrize("d,a", [(12, 3), (7, 4), (16, 2)])

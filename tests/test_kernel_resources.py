@@ -118,7 +118,15 @@ def test_compiled_split_kernels_resources(tmp_path):
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         assert not re.search(r"mlp_tower_(forward|backward)_split_kernel", name)
         if re.search(r"mlp_wgrad_(gate16|fused16|loadh16)_kernel", name):  # (round 4) sixteen waves: four per SIMD, 128 registers each
-            assert scratch == 0 and vgprs <= 128, (name, scratch, vgprs)
+            # (round 6: d_in 6 and 7.  The widest variants -- gate16 at d_in 7, fused16 at 6 x 4 -- keep two or three
+            # registers of the prologue / epilogue in scratch; none of it inside the chunk loop, checked below)
+            wide16 = re.search(r"gate16_kernelILi[67]E|fused16_kernelILi[67]ELi[34]E", name) is not None
+            assert (scratch == 0 or (wide16 and scratch <= 16)) and vgprs <= 128, (name, scratch, vgprs)
+            if scratch:
+                code = text[text.index("\n" + name + ":"):]
+                code = code[:code.index(".Lfunc_end")]
+                loop = re.search(r"\.LBB\d+_\d+:\s*; =>This Inner Loop Header.*?s_cbranch_\w+ \.LBB\d+_\d+", code, re.S)
+                assert loop is not None and "v_mfma" in loop.group(0) and "scratch_" not in loop.group(0), name
             checked += 1
         if re.search(r"mlp_wgrad_split_kernel|mlp_wgrad_gate_kernel", name):
             # every compiled (= dispatched) variant: no scratch at all -- these kernels read
@@ -127,8 +135,9 @@ def test_compiled_split_kernels_resources(tmp_path):
             # (round 5: the widest fused variant on the exact bf16 planes, d_in 5 x n_out 4 -- 72 scalar registers of
             # observations and dOut per step -- keeps three registers in scratch; the walkers below hold for it as for
             # the others: no hand-issued load's destination, vector or scalar, is touched before its wait)
-            widest = "mlp_wgrad_split_kernelILi5ELi4ELb0EE" in name
-            assert scratch == 0 or (widest and scratch <= 16), (name, scratch)
+            # (round 6: d_in 6 and 7 x n_out 3 and 4 -- up to 88 scalar registers per step -- keep up to ten)
+            widest = re.search(r"mlp_wgrad_split_kernelILi[567]ELi[34]ELb0EE", name) is not None
+            assert scratch == 0 or (widest and scratch <= 48), (name, scratch)
             assert vgprs <= 256, (name, vgprs)
             checked += 1
     # general (5 run-time/compiled widths from memory + 12 fused, bf16 and fp16 planes), two-operand (4 + 4), gate-plane kernels

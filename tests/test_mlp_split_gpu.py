@@ -182,7 +182,11 @@ def test_forward_f16_scaling_holds_over_the_dynamic_range(case):
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (129, 1, 1), (1000, 5, 3), (4097, 3, 2), (40_000, 1, 2), (9000, 2, 1),
                                           (33_000, 1, 2), (33_000, 5, 3), (20_000, 3, 1), (16_500, 2, 3),
                                           # round 5: four-wide observations, four-way heads
-                                          (1000, 4, 4), (4097, 4, 1), (9000, 5, 4), (3000, 2, 4), (33_000, 4, 3)])
+                                          (1000, 4, 4), (4097, 4, 1), (9000, 5, 4), (3000, 2, 4), (33_000, 4, 3),
+                                          # round 6: six and seven observations (class 8 data gradients; the weight
+                                          # gradients' scalar loads made in front of their wait)
+                                          (1000, 6, 3), (4097, 7, 3), (9000, 6, 4), (3000, 7, 1), (33_000, 7, 2),
+                                          (129, 6, 1), (20_000, 6, 2), (1, 7, 3)])
 @pytest.mark.parametrize("scheme", ["f16x2"])
 def test_backward_split_matches_fp64(m, d_in, n_out, scheme):
     """Against an fp64 evaluation of the backward formulas on the SAVED activations
@@ -293,7 +297,7 @@ def test_backward_f16_scaling_holds_over_the_dynamic_range(case, n_out):
 
 @pytest.mark.parametrize("case", ["plain", "rows_of_mixed_magnitude", "one_outlier_row", "clipped_rows", "outlier_weights"])
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 1), (129, 1, 2), (1000, 5, 1), (4097, 3, 2), (40_000, 1, 1), (9000, 2, 2),
-                                          (20_000, 3, 1), (33_000, 5, 2), (1000, 4, 1), (4097, 4, 2)])
+                                          (20_000, 3, 1), (33_000, 5, 2), (1000, 4, 1), (4097, 4, 2), (3000, 6, 1), (5000, 7, 2)])
 def test_gate_mode_data_gradient(m, d_in, n_out, case):
     """Heads whose dZ2 is gate * d[s] * w3e[k] (one output; two outputs with exactly opposite gradients):
     the data-gradient kernel takes the ReLU gate itself as its A operand and the planes of w3e[k] W2[k][i] as B.
@@ -358,7 +362,7 @@ def test_gate_mode_data_gradient(m, d_in, n_out, case):
 
 @pytest.mark.parametrize("x_scale", [3.0, 100.0])
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 1), (129, 1, 2), (1000, 5, 1), (4097, 3, 2), (40_000, 1, 2), (9000, 2, 1),
-                                          (100_000, 1, 1), (1000, 4, 1), (4097, 4, 2)])
+                                          (100_000, 1, 1), (1000, 4, 1), (4097, 4, 2), (3000, 6, 2), (5000, 7, 1), (20_000, 7, 2)])
 def test_rank_one_backward_from_the_gate_bits_alone(m, d_in, n_out, x_scale):
     """A forward that keeps ONLY the gate bits of h2 (32 bytes per row) and a backward that never sees h2: the gate
     modes of the data and weight gradients, with dW3 = sum_i W2[.][i] M[.][i] + b2 sum_s G dOut taken from the sums M
@@ -484,7 +488,7 @@ def test_guard_picks_the_planes_of_the_gate_bits_weight_gradient_from_the_data(c
     assert err <= 3 * err_exact + 2e-7, (case, err, err_exact)
 
 
-@pytest.mark.parametrize("m,d_in", [(1, 1), (129, 1), (1000, 5), (4097, 3), (40_000, 1), (9000, 2)])
+@pytest.mark.parametrize("m,d_in", [(1, 1), (129, 1), (1000, 5), (4097, 3), (40_000, 1), (9000, 2), (3000, 6), (5000, 7)])
 def test_pair_weight_gradient_of_a_two_way_head(m, d_in, monkeypatch):
     """dOut[s][1] == -dOut[s][0] exactly (what the categorical loss kernel emits for two actions):
     dZ2 = gate * dOut[s][0] * (W3[0] - W3[1]), so the weight gradient runs with the gate as its
@@ -536,7 +540,7 @@ def test_pair_weight_gradient_of_a_two_way_head(m, d_in, monkeypatch):
 
 
 @pytest.mark.parametrize("m,d_in,n_out", [(1, 1, 2), (13, 1, 1), (4099, 2, 3), (20_003, 5, 3), (33_001, 3, 2), (9, 5, 1),
-                                          (4099, 4, 4), (131, 4, 2)])
+                                          (4099, 4, 4), (131, 4, 2), (4099, 7, 3), (131, 6, 4), (9, 7, 1)])
 @pytest.mark.parametrize("scheme", ["f16x2"])
 def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out, scheme):
     """The kernels fetch whole windows of rows (eight samples of x / dOut through scalar
@@ -575,8 +579,10 @@ def test_backward_split_never_uses_rows_past_the_end(m, d_in, n_out, scheme):
 def test_unsupported_widths_are_refused_not_miscomputed():
     """Only widths whose kernels compile without scratch are offered
     (tests/test_kernel_resources.py); anything else must fail loudly."""
-    assert not hip.mlp_backward_f16_supports(7, 2) and not hip.mlp_backward_f16_supports(1, 5)
+    assert not hip.mlp_backward_f16_supports(8, 2) and not hip.mlp_backward_f16_supports(1, 5)
     assert hip.mlp_backward_f16_supports(4, 4) and hip.mlp_forward_f16_supports(8, 8)  # round 5
+    # round 6: six and seven observations; 7 x 4 is not compiled (88 scalar registers per step in the exact-plane kernel)
+    assert hip.mlp_backward_f16_supports(7, 3) and hip.mlp_backward_f16_supports(6, 4) and not hip.mlp_backward_f16_supports(7, 4)
     assert hip.mlp_forward_f16_supports(9, 1) and hip.mlp_forward_f16_supports(16, 4)  # round 5: class 16
     assert not hip.mlp_forward_f16_supports(17, 1) and not hip.mlp_forward_f16_supports(1, 9) and not hip.mlp_forward_f16_supports(12, 6)
     x = torch.zeros(256, 17, device=DEV)
@@ -592,13 +598,13 @@ def test_unsupported_widths_are_refused_not_miscomputed():
 
 def test_wider_towers_mix_fp32_and_split_kernels():
     """CartPole's tower (5 -> 256 -> 256 -> 3) and a 4 -> 4 one through the fused autograd function (plane kernels
-    throughout) -- and widths whose backward has no plane kernel (7 -> 2, 8 -> 5: fp16-plane forward with h1 and h2
-    stored, fp32-MFMA data gradient, bf16-plane weight gradient; 12 -> 2, 16 -> 4 the same through class 16; 12 -> 6:
-    fp32-MFMA forward too); all must match eager."""
+    throughout; round 6: 7 -> 2 and 6 -> 4 too) -- and widths whose backward has no plane kernel (7 -> 4, 8 -> 5:
+    fp16-plane forward with h1 and h2 stored, fp32-MFMA data gradient, bf16-plane weight gradient; 12 -> 2, 16 -> 4 the
+    same through class 16; 12 -> 6: fp32-MFMA forward too); all must match eager."""
     from rl8_amd.nn import fused_mlp
 
     torch.manual_seed(6)
-    for d_in, n_out in ((5, 3), (4, 4), (7, 2), (8, 5), (3, 6), (12, 2), (16, 4), (12, 6)):
+    for d_in, n_out in ((5, 3), (4, 4), (7, 2), (6, 4), (7, 4), (8, 5), (3, 6), (12, 2), (16, 4), (12, 6)):
         mlp = torch.nn.Sequential(torch.nn.Linear(d_in, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256)).to(DEV)
         trunk = torch.nn.Sequential(mlp, torch.nn.ReLU()).to(DEV)
         head = torch.nn.Linear(256, n_out).to(DEV)
