@@ -18,12 +18,27 @@ process touches no GPU: it starts N children of this same script with
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, waits,
 and prints rank 0's JSON line (``launch_ranks``).
 
-Scaling. ``--scaling weak`` (default): every rank owns ``--num-envs``
-environments. ``--scaling strong``: ``--num-envs`` is the GLOBAL count, split
-over the ranks (BASELINE configs[3]: ``--env continuous --distribution squashed
---num-envs 1048576``; configs[4]: ``--recurrent --num-envs 65536 --horizon 256``).
-Either way the environments are sharded and the only traffic between ranks is
-the RCCL all-reduce of moments and of [gradient | loss sums] per optimizer step.
+Scaling. ``--scaling weak`` (default, what the driver's ``bench.py --gpus N``
+runs): every rank owns ``--num-envs`` environments -- 2^20 per GPU, 2^23 in
+total at N = 8.  ``--scaling strong``: ``--num-envs`` is the GLOBAL count, split
+over the ranks.  BASELINE.json's ``north_star`` quotes ONE problem (num_envs =
+2^20 in total) at 1 / 2 / 4 / 8 GPUs: THAT table is
+
+    python bench.py --gpus N --scaling strong --num-envs 1048576
+
+(configs[3]: add ``--env continuous --distribution squashed``; configs[4]:
+``--recurrent --num-envs 65536 --horizon 256``).  Every line names both
+conventions under ``config.scaling_conventions``.  Either way the environments
+are sharded and the only traffic between ranks is the RCCL all-reduce of moments
+and of [gradient | loss sums] per optimizer step.
+
+Secondary configurations. With the headline configuration on one GPU (the
+defaults) the line also carries ``secondary``: BASELINE configs[2..4] --
+CartPole 2^18 x 128, ContinuousDummyEnv + SquashedNormal 2^20 x 32, the
+recurrent algorithm at 2^16 x 256 -- measured after the headline's timed region
+in the same process, a few steps each under the same timing rules (value,
+ms_per_step, dominant kernel, frac / executed_frac per configuration;
+``--no-secondary`` skips them, ``--secondary-steps`` sets their length).
 
 Besides the contract's fields, the JSON line carries
   roofline      the kernel the timed region spends most time in (whichever it is

@@ -70,7 +70,7 @@ def compare_collect(algo, g, it, *, discrete, loose=None):
     # num_sgd_iters x num_minibatches Adam steps computed with a different GEMM
     # reduction order, so per-sample floats drift by a few 1e-5.
     if loose is None:
-        loose = 1.0 if it == 0 else 5.0   # (round 6: 25 until the drift was re-measured -- profiles/r06_trace_drift.json)
+        loose = 1.0 if it == 0 else 5.0   # (round 6: 25 until the drift was re-measured -- profiles/r06_trace_drift_vs_round2_bands.json)
     buf = algo.buffer
     want = {k[len(f"it{it}_collect_"):]: g[k] for k in g if k.startswith(f"it{it}_collect_") and not k.endswith("stats")}
     got_actions = buf[DataKeys.ACTIONS][:, :HORIZON].cpu().numpy()
@@ -88,7 +88,7 @@ def compare_collect(algo, g, it, *, discrete, loose=None):
 
 # Drift monitor: with RL8_TRACE_DRIFT_JSON=<path> every comparison of the free-running traces
 # also records error / allowed (1.0 = at the band) under the running test's name; the file is rewritten after each
-# comparison.  profiles/r06_trace_drift.json is that file from this round's kernels.
+# comparison.  profiles/r06_trace_drift*.json are that file from this round's kernels.
 _DRIFT: dict = {}
 
 
@@ -122,7 +122,7 @@ def compare_stats(got, keys, want, rel, abs_tol=1e-7, label=""):
 
 
 def run_trace(golden, name, env_cls, *, discrete, step_rel, drift=(10.0, 2e-5), weights_atol=(2e-5, 1e-4), **config):
-    # Bands re-taken in round 6.  profiles/r06_trace_drift.json holds, per comparison, how much of its
+    # Bands re-taken in round 6.  profiles/r06_trace_drift_vs_round2_bands.json holds, per comparison, how much of its
     # ROUND-2 band this round's kernels used: <= 0.3 % of every iteration-1 StepStats band and <= 1 % of every weight band
     # on the three full-batch traces (the towers now follow the reference's fp32 arithmetic to 1e-7..1e-6 through eight
     # Adam steps), 30 % / 79 % on the 64-Adam-step minibatch trace.  Bands beaten by more than 3x were cut by 10x

@@ -185,8 +185,9 @@ def test_six_updates_from_tables_track_the_matrix_towers(env_name, monkeypatch):
     from rl8_amd.distributions import SquashedNormal
     from rl8_amd.env import ContinuousDummyEnv, DiscreteDummyEnv
 
-    def run(tables):
+    def run(tables, tile="0"):
         monkeypatch.setattr(piecewise_mlp, "ENABLED", tables)
+        monkeypatch.setenv("RL8_MLP_DGRAD_TILE", tile)  # (read per call by rl8_mlp_tower_backward_f16_f32)
         torch.manual_seed(5)
         if env_name == "discrete":
             algo = AlgorithmConfig(num_envs=4096, horizon=16).build(DiscreteDummyEnv)
@@ -195,15 +196,22 @@ def test_six_updates_from_tables_track_the_matrix_towers(env_name, monkeypatch):
         out = [(algo.collect(), algo.step()) for _ in range(6)]
         return out, torch.cat([p.detach().flatten() for p in algo.policy.model.parameters()])
 
+    def compare(a, b, loose_from, what):
+        for update, ((c0, s0), (c1, s1)) in enumerate(zip(a, b)):
+            loose = 1.0 if update < loose_from else 5.0
+            for k in ("returns/mean", "rewards/mean", "returns/std"):
+                assert c1[k] == pytest.approx(c0[k], rel=1e-4 * loose), (what, update, k)
+            for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
+                assert s1[k] == pytest.approx(s0[k], rel=2e-3 * loose * (4.0 if update >= loose_from else 1.0), abs=2e-6), (what, update, k)
+
     before = dict(piecewise_mlp.stats)
-    (matrix, w_matrix), (tables, w_tables) = run(False), run(True)
+    #  The ORIGINAL bars for all six updates against the matrix towers pinned to the data-gradient kernel they were
+    # set with (RL8_MLP_DGRAD_TILE=1: the tile kernel of rounds 2-4, general heads only -- the discrete variant's
+    # rank-one heads never ran it); the five-times bars from the third update on only between the tables and the
+    # PRODUCT's rows-shape data gradient, where the flipped unit was traced.
+    (pinned, w_pinned), (matrix, w_matrix), (tables, w_tables) = run(False, "1"), run(False), run(True)
     assert piecewise_mlp.stats["forwards"] > before["forwards"] and piecewise_mlp.stats["backwards"] > before["backwards"]
-    for update, ((c0, s0), (c1, s1)) in enumerate(zip(matrix, tables)):
-        # the first two updates to the original bars; once such a unit has opened in one run (update 3 at this seed) the
-        # two runs are two nearby trajectories of the same algorithm: five times the bars
-        loose = 1.0 if update < 2 else 5.0
-        for k in ("returns/mean", "rewards/mean", "returns/std"):
-            assert c1[k] == pytest.approx(c0[k], rel=1e-4 * loose), (update, k)
-        for k in ("losses/policy", "losses/vf", "losses/total", "monitors/kl_div"):
-            assert s1[k] == pytest.approx(s0[k], rel=2e-3 * loose * (4.0 if update >= 2 else 1.0), abs=2e-6), (update, k)
+    compare(pinned, tables, 6, "tile-pinned matrix towers vs tables")
+    compare(matrix, tables, 2, "product matrix towers vs tables")
+    assert float((w_tables - w_pinned).abs().max()) <= 2e-3 * float(w_pinned.abs().max())
     assert float((w_tables - w_matrix).abs().max()) <= 2e-3 * float(w_matrix.abs().max())

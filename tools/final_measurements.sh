@@ -4,30 +4,46 @@
 # separate runs, kernel-trace only) over the microbench, then the bench lines of every
 # BASELINE config's single-GPU share.  Summaries land in gpurun_out/ (scratch); the ones to
 # be judged are copied into profiles/ by hand afterwards.
-#   gpurun --timeout 1200 -- 'tools/final_measurements.sh r02'
+#   gpurun --timeout 1200 -- 'tools/final_measurements.sh r06 a'   then   ... r06 b'
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r06}
+PART=${2:-all}   # a: tests, microbench, rocprofv3 stats, PMC passes; b: the bench lines; all: both (may not fit one 20-minute call)
 cd "$R"
 mkdir -p gpurun_out
+if [ "$PART" != b ]; then
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gputests.log 2>&1; tail -2 gpurun_out/${TAG}_gputests.log
 timeout -k 10 400 python tools/kernel_microbench.py --rounds 20 > gpurun_out/${TAG}_kernel_microbench.txt 2>&1 || { echo microbench failed; tail -5 gpurun_out/${TAG}_kernel_microbench.txt; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_${TAG}" -o bench --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof_bench.log" 2>&1 || { echo "rocprof stats failed"; exit 1; }
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_${TAG}" -o bench --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$R/gpurun_out/prof_bench.log" 2>&1 || { echo "rocprof stats failed"; exit 1; }
+# the secondary block's configurations, one stats run each (VERDICT r5 next #1b: kernel stats matching the secondary lines)
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_${TAG}_cfg3" -o bench --output-format csv -- python3 "$R/bench.py" --env cartpole --num-envs 262144 --horizon 128 --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof_cfg3.log" 2>&1 || echo "rocprof stats (cfg3) failed"
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_${TAG}_cfg4" -o bench --output-format csv -- python3 "$R/bench.py" --env continuous --distribution squashed --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof_cfg4.log" 2>&1 || echo "rocprof stats (cfg4) failed"
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_${TAG}_cfg5_full" -o bench --output-format csv -- python3 "$R/bench.py" --recurrent --num-envs 65536 --horizon 256 --steps 1 --warmup 1 --uninstrumented-steps 0 --no-cpu-baseline > "$R/gpurun_out/prof_cfg5_full.log" 2>&1 || echo "rocprof stats (cfg5 full) failed"
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_${TAG}_cfg5" -o bench --output-format csv -- python3 "$R/bench.py" --recurrent --num-envs 8192 --horizon 256 --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/prof_cfg5.log" 2>&1 || echo "rocprof stats (recurrent) failed"
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$R/gpurun_out/pmc_fetch" -o mb --output-format csv -- python3 "$R/tools/kernel_microbench.py" --rounds 1 > "$R/gpurun_out/pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; exit 1; }
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$R/gpurun_out/pmc_write" -o mb --output-format csv -- python3 "$R/tools/kernel_microbench.py" --rounds 1 > "$R/gpurun_out/pmc_write.log" 2>&1 || { echo "pmc write failed"; exit 1; }
 cd "$R"
 python tools/summarize_profiles.py stats "$(find gpurun_out/prof_${TAG} -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_bench_kernel_stats.csv || exit 1
 python tools/summarize_profiles.py stats "$(find gpurun_out/prof_${TAG}_cfg5 -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_cfg5_kernel_stats.csv || echo "no recurrent kernel stats"
+for c in cfg3 cfg4 cfg5_full; do python tools/summarize_profiles.py stats "$(find gpurun_out/prof_${TAG}_$c -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_${c}_kernel_stats.csv || echo "no $c kernel stats"; done
 python tools/summarize_profiles.py pmc "$(find gpurun_out/pmc_fetch -name '*counter_collection.csv' | head -1)" "$(find gpurun_out/pmc_write -name '*counter_collection.csv' | head -1)" gpurun_out/${TAG}_pmc_traffic_microbench.json || exit 1
 cp gpurun_out/${TAG}_pmc_traffic_microbench.json profiles/${TAG}_pmc_traffic_microbench.json   # the bench lines below carry this build's traffic
+fi
+if [ "$PART" = a ]; then echo "part a done"; exit 0; fi
+cd "$R"
 timeout -k 10 500 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err || { echo bench failed; tail -5 gpurun_out/${TAG}_bench_n1.err; exit 1; }
 timeout -k 10 300 python bench.py --env cartpole --num-envs 262144 --horizon 128 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg3.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --env continuous --distribution squashed --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg4.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --recurrent --num-envs 8192 --horizon 256 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg5.json 2>/dev/null || exit 1
 # configs[4] at its stated size on ONE device (2 x 17.2 GB of LSTM states in the buffer)
 timeout -k 10 400 python bench.py --recurrent --num-envs 65536 --horizon 256 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg5_full.json 2>/dev/null || echo "full-size recurrent line failed"
-timeout -k 10 300 python tools/diag/tower_width_sweep.py --reps 20 > gpurun_out/${TAG}_tower_width_sweep.txt 2>&1 || echo "width sweep failed"
+timeout -k 10 300 python tools/diag/tower_width_sweep.py --reps 20 --widths 1x1,1x2,2x2,3x1,4x1,4x4,5x1,5x3,6x1,6x2,6x4,7x1,7x2,7x3,8x1,8x4,8x8,3x8,9x1,12x2,16x4 > gpurun_out/${TAG}_tower_width_sweep.txt 2>&1 || echo "width sweep failed"
+# the 8-GPU shards of the stated problems on one device (VERDICT r5 next #6a): 2^20 / 8 environments (configs 2, 4), 2^18 / 8 (config 3)
+timeout -k 10 300 python bench.py --num-envs 131072 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_b_shard8_headline.json 2>/dev/null || echo "shard line (headline) failed"
+timeout -k 10 300 python bench.py --env continuous --distribution squashed --num-envs 131072 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_b_shard8_cfg4.json 2>/dev/null || echo "shard line (cfg4) failed"
+timeout -k 10 300 python bench.py --env cartpole --num-envs 32768 --horizon 128 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_b_shard8_cfg3.json 2>/dev/null || echo "shard line (cfg3) failed"
+RL8_TRACE_DRIFT_JSON=$R/gpurun_out/${TAG}_trace_drift.json timeout -k 10 300 python -m pytest tests/test_algorithm_gpu.py -q -k trace > gpurun_out/${TAG}_trace_drift.log 2>&1 || echo "trace drift run failed"
+bash tools/diag/recurrent_bench_pmc.sh > gpurun_out/${TAG}_cfg5_fabric_traffic.txt 2>&1 || echo "fabric traffic run failed"
 timeout -k 10 300 python bench.py --env mountain_car --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_mountain_car.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --env pendulum --num-envs 262144 --horizon 128 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_pendulum.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --minibatches 8 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_b_minibatches8.json 2>/dev/null || echo "minibatch bench failed"
@@ -40,7 +56,7 @@ timeout -k 10 300 python bench.py --gpus 4 --backend gloo --single-device --num-
 # opt-in prototype lines (never the headline): towers of a scalar observation from piecewise-linear tables
 timeout -k 10 300 python bench.py --towers piecewise --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_b_piecewise_optin.json 2>/dev/null || echo "piecewise line failed"
 timeout -k 10 300 python bench.py --towers piecewise --env continuous --distribution squashed --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_b_cfg4_piecewise_optin.json 2>/dev/null || echo "piecewise cfg4 line failed"
-for f in bench_n1 b_cfg3 b_cfg4 b_cfg5 b_cfg5_full b_cfg5_minibatches4 b_mountain_car b_pendulum b_minibatches8 b_2rank_rehearsal b_4rank_rehearsal b_piecewise_optin b_cfg4_piecewise_optin; do python -c "
+for f in bench_n1 b_shard8_headline b_shard8_cfg4 b_shard8_cfg3 b_cfg3 b_cfg4 b_cfg5 b_cfg5_full b_cfg5_minibatches4 b_mountain_car b_pendulum b_minibatches8 b_2rank_rehearsal b_4rank_rehearsal b_piecewise_optin b_cfg4_piecewise_optin; do python -c "
 import json; d=json.loads(open('gpurun_out/${TAG}_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value']), round(d['ms_per_step'],1), round(d['collect_ms_per_step'],1), round(d['update_ms_per_step'],1))"; done
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 echo done
