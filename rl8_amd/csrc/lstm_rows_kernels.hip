@@ -51,12 +51,25 @@ namespace rl8 {
 constexpr int kLrRows = 128;                 // sequences per workgroup (32 per wave)
 constexpr int kLrChunks = 8;                 // unit chunks (out tiles) per step
 constexpr int kLrGateSteps = 8 * kLrChunks;  // k-chunks of 16 per step
-constexpr int kLrSlotBytes = 3 * 8 * 1024;   // one gate-step of W_hh^T: [plane][out tile] x 1 KiB
+// Two plane schemes (round 6).  bf16: three exact planes of both operands, six products -- any dG.  F16 (the HEADS form
+// only): two fp16 planes, THREE products.  dG has fp32's range, but lane = sequence in the B operand AND in the result, so
+// a power of two per SEQUENCE and step commutes with the sum over gate rows: dG~ = dG 2^(kLrTop - e), e from a bound on the
+// step's |dG| of that sequence that is known before its first chunk -- |dh| <= sum_q |dOut_q| max|W_q| + max|carried dh|,
+// |dc| <= |dh| + max|carried dc|, |do|, |di| <= a quarter of those, |dg| <= |dc|, |df| <= |dc| |c_{t-1}| / 4 -- with the
+// bound placed at 2^kLrTop = 2^6 instead of fp16's 2^14: |c_{t-1}| up to 4 094 before a plane overflows (to inf: loudly).
+// Values down to 2^-9 of the bound keep hi + lo = 22 bits, below that the absolute resolution is 2^-31 of the bound.
+constexpr int lr_slot_bytes(bool f16) { return (f16 ? 2 : 3) * 8 * 1024; }  // one gate-step of W_hh^T: [plane][out tile] x 1 KiB
+constexpr int lr_dma(bool f16) { return f16 ? 4 : 6; }                       // 1-KiB direct-to-LDS loads per wave and gate-step
+constexpr int kLrSlotBytes = lr_slot_bytes(false);
 constexpr int kLrRing = 4;
-constexpr int kLrPackedBytes = kLrGateSteps * kLrSlotBytes;  // 1.5 MiB
+constexpr int kLrPackedBytes = kLrGateSteps * kLrSlotBytes;          // 1.5 MiB: the bf16 planes
+constexpr int kLrPacked16Bytes = kLrGateSteps * lr_slot_bytes(true);  // 1 MiB: the fp16 planes behind them, then {2^k, 2^-k, 0, 0}
+constexpr int kLrPackTotalBytes = kLrPackedBytes + kLrPacked16Bytes + 16;
 constexpr int kLrStageBytes = 4 * 8 * 1024;  // one park of two arrays: [wave][array][instruction] x 1 KiB; two parks
-constexpr int kLrLdsBytes = kLrRing * kLrSlotBytes + 2 * kLrStageBytes;  // 160 KiB: the whole CU
-constexpr int kLrDma = 6;                    // 1-KiB direct-to-LDS loads per wave and gate-step
+constexpr int lr_lds_bytes(bool f16) { return kLrRing * lr_slot_bytes(f16) + 2 * kLrStageBytes; }
+constexpr int kLrLdsBytes = lr_lds_bytes(false);  // 160 KiB: the whole CU (F16: 128 KiB)
+constexpr int kLrDma = lr_dma(false);
+constexpr int kLrTop = 6;
 // 16-byte row operations a lane issues in gate-step k of a chunk (k = 2 pos + half): loads in front of the step's
 // request, stores behind its matrix work
 // HEADS (the kernel's second form): dL/dh_t of the output heads is not read as a [b][l][256] array but formed from the
@@ -67,9 +80,9 @@ constexpr int lr_loads_at(int k, bool heads) {  // B of this chunk | C of this c
 }
 constexpr int kLrStoresAt[8] = {0, 8, 0, 0, 0, 8, 0, 4};   // dG_i, dG_g | dG_f, dc | dG_o of the next chunk
 // operations a wave has issued behind its request for gate-step k's chunk of W_hh^T (made in step k - 3)
-constexpr int lr_behind(int k, bool heads) {
-  return kLrStoresAt[(k + 5) & 7] + lr_loads_at((k + 6) & 7, heads) + kLrDma + kLrStoresAt[(k + 6) & 7] +
-         lr_loads_at((k + 7) & 7, heads) + kLrDma + kLrStoresAt[(k + 7) & 7];
+constexpr int lr_behind(int k, bool heads, int dma = kLrDma) {
+  return kLrStoresAt[(k + 5) & 7] + lr_loads_at((k + 6) & 7, heads) + dma + kLrStoresAt[(k + 6) & 7] +
+         lr_loads_at((k + 7) & 7, heads) + dma + kLrStoresAt[(k + 7) & 7];
 }
 static_assert(lr_behind(0, false) == 40 && lr_behind(3, false) == 28 && lr_behind(5, false) == 12 && lr_behind(7, false) == 36,
               "see the table in open_step");
@@ -77,10 +90,10 @@ static_assert(lr_behind(0, true) == 38 && lr_behind(1, true) == 24 && lr_behind(
               "see the table in open_step");
 // ... and behind the parked loads of a phase, from the step that makes them to the end of the matrix work of the step that
 // reads them: B 0 -> 1, C 2 -> 5, A 6 -> 7 (vmcnt has six bits: all but the 63 youngest covers anything further back)
-constexpr int lr_behind_loads(int from, int to, bool heads) {  // from the loads of step `from` to the end of step `to`'s matrix work
-  int n = kLrDma;
+constexpr int lr_behind_loads(int from, int to, bool heads, int dma = kLrDma) {  // from the loads of step `from` to the end of step `to`'s matrix work
+  int n = dma;
   for (int k = (from + 1) & 7;; k = (k + 1) & 7) {
-    n += kLrStoresAt[(k + 7) & 7] + lr_loads_at(k, heads) + kLrDma;
+    n += kLrStoresAt[(k + 7) & 7] + lr_loads_at(k, heads) + dma;
     if (k == to) break;
   }
   return n < 63 ? n : 63;
@@ -93,6 +106,12 @@ static_assert(kLrBehindB == 12 && kLrBehindC == 24 && kLrBehindA == 12, "see the
 static_assert(kLrBehindB == lr_behind_loads(0, 1, true) && kLrBehindC == lr_behind_loads(2, 5, true) &&
                   kLrBehindA == lr_behind_loads(6, 7, true),
               "the spans do not contain gate-step 6");
+// F16 (four direct-to-LDS pieces per gate-step instead of six): K 0..7 -> 34 20 28 24 24 8 16 30; B 8, C 16, A 8
+static_assert(lr_behind(0, true, 4) == 34 && lr_behind(1, true, 4) == 20 && lr_behind(2, true, 4) == 28 && lr_behind(5, true, 4) == 8 &&
+                  lr_behind(6, true, 4) == 16 && lr_behind(7, true, 4) == 30,
+              "see the table in open_step");
+static_assert(lr_behind_loads(0, 1, true, 4) == 8 && lr_behind_loads(2, 5, true, 4) == 16 && lr_behind_loads(6, 7, true, 4) == 8,
+              "see the table in open_step");
 constexpr int kLrHeads = 4;  // outputs of the heads the HEADS form takes (their gradient padded to four floats per row-step)
 #ifndef RL8_LR_DIAG
 #define RL8_LR_DIAG 0  // tuning builds (tools/diag_mlp.sh lr<bits>): 1 no stores reach memory, 2 no row loads do, 4 one plane
@@ -161,24 +180,45 @@ struct LrStoreDesc {
   __amdgpu_buffer_rsrc_t dgates, dcout;
 };
 
-template <bool HEADS>
+template <bool HEADS, bool F16 = false>
 __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const void *__restrict__ w_planes) {
+  static_assert(HEADS || !F16, "the fp16 planes need the step's bound on |dh| before its first chunk: the HEADS form only");
+  constexpr int kSlot = lr_slot_bytes(F16), kDma = lr_dma(F16);  // (shadow the bf16 shape's names below)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = lds_offset(smem);
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = a.l;
-  const __amdgpu_buffer_rsrc_t wrsrc = buffer_rsrc(w_planes, (kLrDiag & 8) ? 0 : kLrPackedBytes);
+  const __amdgpu_buffer_rsrc_t wrsrc = buffer_rsrc(static_cast<const unsigned char *>(w_planes) + (F16 ? kLrPackedBytes : 0),
+                                                   (kLrDiag & 8) ? 0 : (F16 ? kLrPacked16Bytes : kLrPackedBytes));
   const unsigned a_read = lds0 + lane * 16;
+  // F16: 1 / (W_hh's power of two) from behind the planes; max |W_heads[q]| per head (wave-uniform, scalar registers)
+  [[maybe_unused]] float inv_sw = 1.0f, wmax[kLrHeads] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (F16) {
+    inv_sw = reinterpret_cast<const float *>(static_cast<const unsigned char *>(w_planes) + kLrPackedBytes + kLrPacked16Bytes)[1];
+#pragma unroll
+    for (int q = 0; q < kLrHeads; ++q) {
+      const f32x4 v = reinterpret_cast<const f32x4 *>(a.heads_w + q * kHidden)[lane];
+      float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
+                                __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+      wmax[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(m)));
+    }
+    // (all of it landed and reduced before the first counted wait: the prologue below drains with vmcnt(0))
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  // F16: this sequence's power of two for the step being computed, its inverse times W_hh's; what bounds the next step's
+  [[maybe_unused]] float s_n = 1.0f, inv_n = 1.0f, cmax = 0.0f, emax = 0.0f, emax_prev = 0.0f;
 
   // gate-step k of chunk c -> ring slot: the packed order is [16-unit chunk 2 c + half][gate position]
-  auto request = [&](int c, int k, int slot, int u0 = 0, int u1 = kLrDma) {  // pieces u0 .. u1 - 1 of the wave's six
+  auto request = [&](int c, int k, int slot, int u0 = 0, int u1 = lr_dma(F16)) {  // pieces u0 .. u1 - 1 of the wave's six (F16: four)
     const int src = (4 * (2 * c + (k & 1)) + (k >> 1)) & (kLrGateSteps - 1);
 #pragma unroll
     for (int u = u0; u < u1; ++u) {
-      const int block = wave * kLrDma + u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, smem + slot * kLrSlotBytes + block * 1024, 16, lane * 16,
-                                               src * kLrSlotBytes + block * 1024, 0, 0);
+      const int block = wave * kDma + u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, smem + slot * kSlot + block * 1024, 16, lane * 16,
+                                               src * kSlot + block * 1024, 0, 0);
     }
   };
 
@@ -231,7 +271,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   // Parks: PARK 0 / 1, array AR (0 / 1) of this wave = four 1-KiB blocks; instruction k moves rows 8 k .. 8 k + 7.
   // Lane i of instruction k: row 8 k + (i >> 3), LDS slot i & 7 <-> piece (i & 7) ^ ((4 k + (i >> 4)) & 7) of the row.
   const int park_piece = (lane & 7) ^ (lane >> 4);  // k even; k odd: ^ 4
-  auto park_lds = [&](int park, int ar, int k) { return kLrRing * kLrSlotBytes + park * kLrStageBytes + ((wave * 2 + ar) * 4 + k) * 1024; };
+  auto park_lds = [&](int park, int ar, int k) { return kLrRing * kSlot + park * kLrStageBytes + ((wave * 2 + ar) * 4 + k) * 1024; };
   auto park4 = [&](int park, int ar, const __amdgpu_buffer_rsrc_t &r, int pitch_bytes, int soff, int k0 = 0, int k1 = 4) {
     const int v_row = (lane >> 3) * pitch_bytes;
 #pragma unroll
@@ -243,8 +283,8 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   unsigned park_at[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    park_at[j] = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + n * 128 + (((2 * j + hh) ^ ((n >> 1) & 7)) * 16);
-  const unsigned park_line = lds0 + kLrRing * kLrSlotBytes + wave * (8 * 1024) + lane * 16;  // the instruction view
+    park_at[j] = lds0 + kLrRing * kSlot + wave * (8 * 1024) + n * 128 + (((2 * j + hh) ^ ((n >> 1) & 7)) * 16);
+  const unsigned park_line = lds0 + kLrRing * kSlot + wave * (8 * 1024) + lane * 16;  // the instruction view
   const int pitch_gates = l * (4 * kHidden * 4), pitch_seq = l * (kHidden * 4), pitch_state = kHidden * 4;
   // (each in parts, so that a gate-step can spread them between its MFMA groups: a direct-to-LDS load costs the wave
   // ~75 cycles at issue, and issued in one run at the head of a step those were 19 % of its time with the pipe idle)
@@ -334,11 +374,11 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
 
   auto math_a = [&](const LrStoreDesc &sd, int c) {  // -> dg[0] (o), dcv
     u32x4 la_o[4], la_ct[4], la_dh[4], la_dc[4];
-    loads_landed(std::integral_constant<int, kLrBehindA>{}, 8);
+    loads_landed(std::integral_constant<int, lr_behind_loads(6, 7, HEADS, kDma)>{}, 8);
     if constexpr (HEADS) {
       // dL/dh_t of the heads for this lane's sixteen units: sum_q dOut[n][q] W[q][unit], the weights broadcast from the
       // park (two addresses per instruction: the lane halves), head by head
-      const unsigned pk = lds0 + kLrRing * kLrSlotBytes + kLrStageBytes + (wave * 2) * 4096;
+      const unsigned pk = lds0 + kLrRing * kSlot + kLrStageBytes + (wave * 2) * 4096;
       u32x4 dv = lds_read_b128<1024>(pk + n * 16);
       u32x4 wq[4];
 #pragma unroll
@@ -351,6 +391,20 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
                            : lds_read_b128<384>(pk + (8 * j + 4 * hh) * 4);
         if (q == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(dv));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]));
+        if constexpr (F16) {
+          if (q == 0 && c == 0) {
+            // a new step of this sequence: the power of two its dG planes carry (see the head of the file)
+            float bound = cmax + emax_prev;
+#pragma unroll
+            for (int qq = 0; qq < kLrHeads; ++qq) bound = __builtin_fmaf(__builtin_fabsf(__uint_as_float(dv[qq])), wmax[qq], bound);
+            // (down to 2^-118: the whole of fp32's normal range -- f16_bound_exponent stops at 2^-80, good for
+            // operands that are weights or activations, not for the gradient of a mean over 2^25 samples times 1e-20)
+            int e = __builtin_amdgcn_frexp_expf(bound * 1.0001f);
+            e = e < -118 ? -118 : e;
+            s_n = __builtin_amdgcn_ldexpf(1.0f, kLrTop - e);
+            inv_n = __builtin_amdgcn_ldexpf(1.0f, e - kLrTop);  // (W_hh's 2^-k is applied apart: their product can underflow)
+          }
+        }
         const float d = __uint_as_float(dv[q]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -384,7 +438,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   };
   auto math_b = [&](const LrStoreDesc &sd, int c) {  // -> dg[1] (i), dg[2] (g)
     u32x4 lb_i[4], lb_g[4];
-    loads_landed(std::integral_constant<int, kLrBehindB>{}, 8);
+    loads_landed(std::integral_constant<int, lr_behind_loads(0, 1, HEADS, kDma)>{}, 8);
     unpark(Z0{}, Z0{}, lb_i);
     unpark(Z0{}, Z1{}, lb_g);
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -405,7 +459,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   };
   auto math_c = [&](const LrStoreDesc &sd, int c) {  // -> dg[3] (f), dc out
     u32x4 lc_f[4], lc_cp[4];
-    loads_landed(std::integral_constant<int, kLrBehindC>{}, 9);
+    loads_landed(std::integral_constant<int, lr_behind_loads(2, 5, HEADS, kDma)>{}, 9);
     unpark(Z1{}, Z0{}, lc_f);
     unpark(Z1{}, Z1{}, lc_cp);
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -418,6 +472,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
       dg[3][e] = dcv[e] * cp * (gf * (1.0f - gf));
       dc_out[e] = dcv[e] * gf;
       lmax = __builtin_fmaxf(lmax, __builtin_fabsf(dg[3][e]));
+      if constexpr (F16) emax = __builtin_fmaxf(emax, __builtin_fabsf(dc_out[e]));
     }
     fold_max(lmax);
     repark(Z1{}, Z0{}, dg[3]);
@@ -431,6 +486,51 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   auto matrix_step = [&](auto k_tag, auto &&side) {  // side(mp): what the step issues behind the MFMAs of tile pair mp
     constexpr int K = decltype(k_tag)::value;
     constexpr int POS = K >> 1, E0 = 8 * (K & 1);
+    if constexpr (F16) {
+      // two fp16 planes of this sequence's dG times its power of two; W_hh^T's two planes from the slot: hi x lo, lo x hi,
+      // hi x hi (smallest terms first), out tiles in pairs as below
+      u32x4 bh, bl;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        uint32_t hi, lo;
+        f16_pair_scaled(dg[POS][E0 + e], dg[POS][E0 + e + 1], s_n, hi, lo);
+        bh[e >> 1] = hi;
+        bl[e >> 1] = lo;
+      }
+      const unsigned ar = a_read + (K & 3) * kSlot;
+      u32x4 ah[2][2], al[2][2];  // [buffer][tile of the pair]
+      auto fetch = [&](int mp, int s) {
+        ah[s][0] = mp == 0 ? lds_read_b128<0 * 1024>(ar) : mp == 1 ? lds_read_b128<2 * 1024>(ar) : mp == 2 ? lds_read_b128<4 * 1024>(ar) : lds_read_b128<6 * 1024>(ar);
+        ah[s][1] = mp == 0 ? lds_read_b128<1 * 1024>(ar) : mp == 1 ? lds_read_b128<3 * 1024>(ar) : mp == 2 ? lds_read_b128<5 * 1024>(ar) : lds_read_b128<7 * 1024>(ar);
+        al[s][0] = mp == 0 ? lds_read_b128<8 * 1024>(ar) : mp == 1 ? lds_read_b128<10 * 1024>(ar) : mp == 2 ? lds_read_b128<12 * 1024>(ar) : lds_read_b128<14 * 1024>(ar);
+        al[s][1] = mp == 0 ? lds_read_b128<9 * 1024>(ar) : mp == 1 ? lds_read_b128<11 * 1024>(ar) : mp == 2 ? lds_read_b128<13 * 1024>(ar) : lds_read_b128<15 * 1024>(ar);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int mp = 0; mp < 4; ++mp) {
+        const int s = mp & 1;
+        {
+          RL8_LR_T0;
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[s][0]), "+v"(ah[s][1]), "+v"(al[s][0]), "+v"(al[s][1]));
+          RL8_LR_T1(12);
+        }
+        if (mp < 3) fetch(mp + 1, s ^ 1);
+        f32x16 d0 = acc[2 * mp], d1 = acc[2 * mp + 1];
+#define RL8_LR_MMA16(A, B)                                                                                              \
+  d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A[s][0]), __builtin_bit_cast(half8, B), d0, 0, 0, 0); \
+  d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A[s][1]), __builtin_bit_cast(half8, B), d1, 0, 0, 0)
+        if constexpr ((kLrDiag & 4) == 0) {
+          RL8_LR_MMA16(ah, bl);
+          RL8_LR_MMA16(al, bh);
+        }
+        RL8_LR_MMA16(ah, bh);
+#undef RL8_LR_MMA16
+        acc[2 * mp] = d0;
+        acc[2 * mp + 1] = d1;
+        side(mp);
+      }
+      return;
+    }
     u32x4 bh, bm, bl;
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
@@ -440,7 +540,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
       bm[e >> 1] = mid;
       bl[e >> 1] = lo;
     }
-    const unsigned ar = a_read + (K & 3) * kLrSlotBytes;
+    const unsigned ar = a_read + (K & 3) * kSlot;
     u32x4 ah[2][2], am[2][2], al[2][2];  // [buffer][tile of the pair]
     auto fetch = [&](int mp, int s) {
       ah[s][0] = mp == 0 ? lds_read_b128<0 * 1024>(ar) : mp == 1 ? lds_read_b128<2 * 1024>(ar) : mp == 2 ? lds_read_b128<4 * 1024>(ar) : lds_read_b128<6 * 1024>(ar);
@@ -492,7 +592,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   //   N       40  24  32  28  28  12  20  36
   auto open_step = [&](auto k_tag) {
     constexpr int K = decltype(k_tag)::value;
-    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : lr_behind(K, HEADS);
+    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : lr_behind(K, HEADS, kDma);
 #ifdef RL8_LR_STAMP
     {
       RL8_LR_T0;
@@ -550,7 +650,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
       const LrLoadDesc &ad = wrap ? after : nd;
       auto only_request = [&](int cc, int k, int slot) {
         return [&, cc, k, slot](int mp) {
-          if (mp < 3) request(cc, k, slot, 2 * mp, 2 * mp + 2);
+          if (2 * mp < kDma) request(cc, k, slot, 2 * mp, 2 * mp + 2);
         };
       };
       open_step(K0{});
@@ -561,8 +661,8 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
       matrix_step(K0{}, [&](int mp) {
         if (mp == 0) issue_b(nd, c, 0);
         else if (mp == 1) issue_b(nd, c, 1);
-        else if (mp == 2) request(c, 3, 3, 0, 3);
-        else request(c, 3, 3, 3, 6);
+        else if (mp == 2) request(c, 3, 3, 0, kDma / 2);
+        else request(c, 3, 3, kDma / 2, kDma);
       });
       open_step(K1{});
       matrix_step(K1{}, only_request(c, 4, 0));
@@ -571,8 +671,8 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
       matrix_step(K2{}, [&](int mp) {
         if (mp == 0) issue_c(nd, c, 0);
         else if (mp == 1) issue_c(nd, c, 1);
-        else if (mp == 2) request(c, 5, 1, 0, 3);
-        else request(c, 5, 1, 3, 6);
+        else if (mp == 2) request(c, 5, 1, 0, kDma / 2);
+        else request(c, 5, 1, kDma / 2, kDma);
       });
       open_step(K3{});
       matrix_step(K3{}, only_request(c, 6, 2));
@@ -589,16 +689,35 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
           issue_a(ad, cn, 2);
           asm volatile("" ::: "memory");
           request(cn, 1, 1, 0, 2);
-        } else request(cn, 1, 1, 2, 6);
+        } else request(cn, 1, 1, 2, kDma);
       });
       open_step(K7{});
       matrix_step(K7{}, only_request(cn, 2, 2));
       if (wrap) {
         // the step's dh is complete: it becomes the carry of the step the next arithmetic belongs to (zero for a new tile)
+        if constexpr (F16) {
+          // the accumulators carry this step's power of two times W_hh's; what the carries bound in the step that follows:
+          // max |dh| over the sequence's 256 units (the other 128 sit in lane ^ 32), max |dc| of this step's chunks
+          float m = 0.0f;
 #pragma unroll
-        for (int cc = 0; cc < kLrChunks; ++cc)
+          for (int cc = 0; cc < kLrChunks; ++cc)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) dhe[e][cc] = last_step ? 0.0f : acc[cc][e];
+            for (int e = 0; e < 16; ++e) {
+              const float v = last_step ? 0.0f : (acc[cc][e] * inv_sw) * inv_n;
+              dhe[e][cc] = v;
+              m = __builtin_fmaxf(m, __builtin_fabsf(v));
+            }
+          const auto sm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+          cmax = __builtin_fmaxf(__uint_as_float(sm[0]), __uint_as_float(sm[1]));
+          const auto se = __builtin_amdgcn_permlane32_swap(__float_as_uint(emax), __float_as_uint(emax), false, false);
+          emax_prev = last_step ? 0.0f : __builtin_fmaxf(__uint_as_float(se[0]), __uint_as_float(se[1]));
+          emax = 0.0f;
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < kLrChunks; ++cc)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dhe[e][cc] = last_step ? 0.0f : acc[cc][e];
+        }
         sd = store_desc(ntile, nt);
       }
       { RL8_LR_T0; math_a(sd, cn); RL8_LR_T1(14); }
@@ -632,17 +751,75 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_kernel(LrArgs a,
 __global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_heads_kernel(LrArgs a, const void *__restrict__ w_planes) {
   lstm_rows_backward_body<true>(a, w_planes);
 }
+__global__ __launch_bounds__(kBlock, 1) void lstm_rows_backward_heads16_kernel(LrArgs a, const void *__restrict__ w_planes) {
+  lstm_rows_backward_body<true, true>(a, w_planes);
+}
+
+// max |W_hh| -> {2^k, 2^-k} with max * 2^k < 2^14 behind the fp16 planes (one workgroup; as lstm_whh_scale_kernel of
+// lstm_split_kernels.hip)
+__global__ __launch_bounds__(1024) void lstm_rows_scale_kernel(const float *__restrict__ w_hh, float *__restrict__ tail) {
+  __shared__ float red[1024];
+  const int tid = threadIdx.x;
+  float mx = 0.0f;
+  const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w_hh);
+#pragma unroll 8
+  for (int i = tid; i < kHidden * kHidden; i += 1024) {
+    const f32x4 v = w4[i];
+    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))),
+                         __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+  }
+  red[tid] = mx;
+  __syncthreads();
+  for (int half = 512; half > 0; half >>= 1) {
+    if (tid < half) red[tid] = __builtin_fmaxf(red[tid], red[tid + half]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int e = f16_bound_exponent(red[0]);
+    tail[0] = __builtin_amdgcn_ldexpf(1.0f, kF16Top - e);
+    tail[1] = __builtin_amdgcn_ldexpf(1.0f, e - kF16Top);
+    tail[2] = tail[3] = 0.0f;
+  }
+}
+
+// ... and the fp16 planes of W_hh^T times that power of two, same fragment order, two planes per gate-step
+__global__ __launch_bounds__(kBlock) void lstm_rows_pack16_kernel(const float *__restrict__ w_hh, unsigned char *__restrict__ packed16,
+                                                                  const float *__restrict__ tail) {
+  const int idx = blockIdx.x * kBlock + threadIdx.x;  // (gs, mo, lane)
+  if (idx >= kLrGateSteps * 8 * 64) return;
+  const int lane = idx & 63, mo = (idx >> 6) & 7, gs = idx >> 9;
+  const int q = lr_gate(gs & 3), c = gs >> 2;
+  const int out = 32 * mo + (lane & 31);
+  const float *src = w_hh + (int64_t)(kHidden * q) * kHidden + out;
+  const float scale = tail[0];
+  u32x4 planes[2];
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    uint32_t hi, lo;
+    f16_pair_scaled(src[lr_in_unit(c, lane >> 5, e) * kHidden], src[lr_in_unit(c, lane >> 5, e + 1) * kHidden], scale, hi, lo);
+    planes[0][e >> 1] = hi;
+    planes[1][e >> 1] = lo;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+    *reinterpret_cast<u32x4 *>(packed16 + (int64_t)gs * lr_slot_bytes(true) + (p * 8 + mo) * 1024 + lane * 16) = planes[p];
+}
 
 }  // namespace rl8
 
 using namespace rl8;
 
-RL8_API int64_t rl8_lstm_rows_backward_pack_bytes(void) { return kLrPackedBytes; }
+RL8_API int64_t rl8_lstm_rows_backward_pack_bytes(void) { return kLrPackTotalBytes; }
 
 RL8_API int rl8_lstm_rows_backward_pack(const float *w_hh, void *packed, void *stream) {
   if (!w_hh || !packed) return RL8_ENULL;
   if (!aligned16(packed)) return RL8_EALIGN;
   lstm_rows_pack_kernel<<<kLrGateSteps * 8 * 64 / kBlock, kBlock, 0, (hipStream_t)stream>>>(w_hh, static_cast<uint32_t *>(packed));
+  // (round 6) behind the bf16 planes: the fp16 planes of the HEADS form and W_hh's power of two
+  unsigned char *p16 = static_cast<unsigned char *>(packed) + kLrPackedBytes;
+  float *tail = reinterpret_cast<float *>(p16 + kLrPacked16Bytes);
+  lstm_rows_scale_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(w_hh, tail);
+  lstm_rows_pack16_kernel<<<kLrGateSteps * 8 * 64 / kBlock, kBlock, 0, (hipStream_t)stream>>>(w_hh, p16, tail);
   return launch_status();
 }
 
@@ -668,7 +845,14 @@ static int rows_backward(int64_t b, int l, const float *c0, const float *gates, 
 #endif
   if (dg_bound_out && hipMemsetAsync(dg_bound_out, 0, 4, (hipStream_t)stream) != hipSuccess) return launch_status();
   const LrArgs args = {c0, gates, cs, dhs, heads_w, dgates, dc_scratch, b, l, stamps, dg_bound_out};
-  if (heads_w) lstm_rows_backward_heads_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
+  // the HEADS form on fp16 planes (three plane products) unless RL8_AMD_LSTM_BACKWARD_PLANES=bf16 (six; read per call)
+  const char *planes = getenv("RL8_AMD_LSTM_BACKWARD_PLANES");
+  const bool f16 = heads_w != nullptr && !(planes && planes[0] == 'b');
+  if (f16) {
+    static LdsOptIn lds_attr_set_2;
+    if (const int e = allow_dynamic_lds(lds_attr_set_2, reinterpret_cast<const void *>(&lstm_rows_backward_heads16_kernel), lr_lds_bytes(true))) return e;
+    lstm_rows_backward_heads16_kernel<<<grid, kBlock, lr_lds_bytes(true), (hipStream_t)stream>>>(args, packed);
+  } else if (heads_w) lstm_rows_backward_heads_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
   else lstm_rows_backward_kernel<<<grid, kBlock, kLrLdsBytes, (hipStream_t)stream>>>(args, packed);
   return launch_status();
 }

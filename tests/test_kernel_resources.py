@@ -385,18 +385,21 @@ def test_compiled_lstm_rows_backward_kernel_resources(tmp_path):
     assert not re.search(r"\bv_pk_(fma|add|mul)_f32\b", text)
     # both forms: dL/dh_t read as an array, or formed from the heads' gradient and weights (_heads_kernel: phase A of
     # gate-step 6 is fourteen direct-to-LDS loads instead of sixteen, and the barriers that look back over it count two less)
+    # (round 6) ... and the HEADS form on fp16 planes: FOUR direct-to-LDS pieces of W_hh^T per gate-step instead of six
     forms = {
-        "lstm_rows_backward_kernel": (["B40", "B24", "B32", "B28", "B28", "B12", "B20", "B36"], 22),
-        "lstm_rows_backward_heads_kernel": (["B38", "B24", "B32", "B28", "B28", "B12", "B20", "B34"], 20),
+        "lstm_rows_backward_kernel": (["B40", "B24", "B32", "B28", "B28", "B12", "B20", "B36"], 22, 6),
+        "lstm_rows_backward_heads_kernel": (["B38", "B24", "B32", "B28", "B28", "B12", "B20", "B34"], 20, 6),
+        "lstm_rows_backward_heads16_kernel": (["B34", "B20", "B28", "B24", "B24", "B8", "B16", "B30"], 18, 4),
     }
     bodies = dict(re.findall(r"\.amdhsa_kernel (\S*lstm_rows_backward\w*_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S))
-    assert len(bodies) == 2
-    for form, (want, step6) in forms.items():
-        body = next(b for n, b in bodies.items() if form in n)
+    assert len(bodies) == 3
+    for form, (want, step6, dma) in forms.items():
+        body = next(b for n, b in bodies.items() if form + "E" in n or n.endswith(form))
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 512
-        code = next(b for n, b in inflight.kernels_of(text) if form in n)
-        assert "v_mfma_f32_32x32x16_bf16" in code and "scratch_" not in code
+        code = next(b for n, b in inflight.kernels_of(text) if form + "E" in n)
+        assert ("v_mfma_f32_32x32x16_f16" if dma == 4 else "v_mfma_f32_32x32x16_bf16") in code and "scratch_" not in code
+        assert ("v_mfma_f32_32x32x16_bf16" in code) == (dma == 6)
         # the chunk loop: the eight counted barriers in order, and what the wave issues between them
         ops = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)\n\ts_barrier|(buffer_load_dwordx4[^\n]* lds)|(buffer_load_dwordx4)|(buffer_store_dwordx4)", code)
         seq = ["B" + w if w else "D" if d else "L" if ld else "S" for w, d, ld, st in ops]
@@ -408,5 +411,5 @@ def test_compiled_lstm_rows_backward_kernel_resources(tmp_path):
         # [row loads, direct-to-LDS loads (parked row loads + 6 of W_hh^T), stores] per gate-step; the four stores of the
         # next chunk's dG_o follow step 7 on the loop's back edge
         # (every row load is parked: direct-to-LDS, eight per two-array phase, sixteen / fourteen for phase A)
-        assert counts[:7] == [(0, 14, 0), (0, 6, 8), (0, 14, 0), (0, 6, 0), (0, 6, 0), (0, 6, 8), (0, step6, 0)], (form, counts)
-        assert counts[7][:2] == (0, 6), (form, counts)
+        assert counts[:7] == [(0, 8 + dma, 0), (0, dma, 8), (0, 8 + dma, 0), (0, dma, 0), (0, dma, 0), (0, dma, 8), (0, step6, 0)], (form, counts)
+        assert counts[7][:2] == (0, dma), (form, counts)

@@ -304,6 +304,51 @@ def test_lstm_rows_backward_with_the_heads_gradient_formed_inside(b, l, n):
         hip.lstm_rows_backward(c0, gates, cs, array_form[:, :, 0], packed, heads=(dout, w))
 
 
+@pytest.mark.parametrize("case", ["plain", "large_cell_states", "zero_and_tiny_rows", "huge_gradients"])
+@pytest.mark.parametrize("b,l,n", [(129, 4, 3), (4101, 3, 2), (1000, 7, 1)])
+def test_lstm_rows_backward_heads_form_on_fp16_and_bf16_planes(b, l, n, case, monkeypatch):
+    """Round 6: the HEADS form runs the recurrent product dG x W_hh on TWO fp16 planes per operand (three plane products)
+    with dG scaled by a power of two per sequence and step from a bound known before the step's first chunk (|dOut| x
+    max|W_heads| + the carried max|dh| + max|dc|, placed at 2^6 so that |c_{t-1}| up to 4 094 cannot overflow a plane)
+    -- against the same kernel on the three exact bf16 planes (RL8_AMD_LSTM_BACKWARD_PLANES=bf16, read per call) and the
+    fp64 recurrences, at the bars of the bf16 form: 2e-6 of each sequence's largest gate gradient.  Cases: cell states up
+    to +-60 (the f gate's gradient carries |c_{t-1}|), sequences whose gradient is zero or ~1e-30, gradients of 1e+20."""
+    c0, gates, cs, _, w_hh = _rows_backward_inputs(b, l, 31 * b + l + n)
+    g = torch.Generator(device=DEV).manual_seed(b + 5 * n)
+    rowscale = torch.exp(-12 * torch.rand(b, 1, device=DEV, generator=g)).repeat_interleave(l, 0) * 1e-3
+    dout = (torch.rand(b * l, n, device=DEV, generator=g) * 2 - 1) * rowscale
+    if case == "large_cell_states":
+        cs, c0 = cs * 40.0, c0 * 40.0
+    elif case == "zero_and_tiny_rows":
+        dout = dout.view(b, l, n)
+        dout[::3] = 0.0
+        dout[1::3] *= 1e-20   # (|dG| down to ~1e-30: fp32 still normal, far below 2^-80)
+        dout = dout.view(b * l, n).contiguous()
+    elif case == "huge_gradients":
+        dout = dout * 1e23
+    w = (torch.rand(n, 256, device=DEV, generator=g) * 2 - 1) / 16
+    packed = hip.lstm_rows_backward_pack(w_hh)
+    monkeypatch.delenv("RL8_AMD_LSTM_BACKWARD_PLANES", raising=False)
+    f16, f16_bound = hip.lstm_rows_backward(c0, gates, cs, None, packed, with_bound=True, heads=(dout, w))
+    monkeypatch.setenv("RL8_AMD_LSTM_BACKWARD_PLANES", "bf16")
+    bf16 = hip.lstm_rows_backward(c0, gates, cs, None, packed, heads=(dout, w))
+    monkeypatch.delenv("RL8_AMD_LSTM_BACKWARD_PLANES")
+    want = _backward_through_time_fp64(c0, gates, cs, (dout.double() @ w.double()).view(b, l, 256), w_hh)
+    assert bool(torch.isfinite(f16).all()) and bool(torch.isfinite(bf16).all())
+    scale = want.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-300)
+    err16 = float(((f16.double() - want).abs() / scale).max())
+    err_bf = float(((bf16.double() - want).abs() / scale).max())
+    # (cell states of +-60: 1 - tanh^2 c cancels in fp32 in BOTH schemes' gate arithmetic -- the same code -- so the bar
+    # of that case is the exact planes' own error)
+    bar = 2e-5 if case == "large_cell_states" else 2e-6
+    assert err16 < bar and err_bf < bar, (err16, err_bf)
+    assert err16 <= 3 * err_bf + 2e-7, (err16, err_bf)   # as accurate as the exact planes
+    assert float(f16_bound) == float(f16.abs().max())
+    # the last step of every sequence has no carried gradient: both plane schemes form the same dG there, bit for bit
+    assert torch.equal(f16[:, l - 1], bf16[:, l - 1])
+    assert torch.equal(f16, hip.lstm_rows_backward(c0, gates, cs, None, packed, heads=(dout, w)))  # repeatable
+
+
 def test_recurrent_model_with_and_without_the_fused_heads_node():
     """A training pass of the default recurrent models as one LSTM + heads node (fused_lstm.lstm_heads_forward) and as
     the two nodes it replaces: same outputs bit for bit (the same forward kernels), parameter gradients to 2e-6 of each

@@ -105,6 +105,16 @@ def main() -> None:
 
         prev = timed(old)
         print(f"2^19 sequences x 4 steps: rows kernel {new:.2f} ms, fp32-MFMA kernel {prev:.2f} ms")
+        # the HEADS form (the product's: dL/dh_t from four floats per row-step), fp16 planes (round 6) and bf16 planes
+        import os
+        gen = torch.Generator(device=dev).manual_seed(3)
+        dout = (torch.rand(b * l, 3, device=dev, generator=gen) * 2 - 1) * 1e-3
+        w = (torch.rand(3, H, device=dev, generator=gen) * 2 - 1) / 16
+        for planes in ("f16", "bf16", "f16", "bf16"):
+            os.environ["RL8_AMD_LSTM_BACKWARD_PLANES"] = planes
+            t = timed(lambda: hip.lstm_rows_backward(c0, gates, cs, None, packed, heads=(dout, w)))
+            print(f"heads form, {planes} planes: {t:.2f} ms per 2^21 row-steps", flush=True)
+        os.environ.pop("RL8_AMD_LSTM_BACKWARD_PLANES", None)
     sys.exit(1 if failures else 0)
 
 
