@@ -66,8 +66,8 @@ constexpr int kLrPackedBytes = kLrGateSteps * kLrSlotBytes;          // 1.5 MiB:
 constexpr int kLrPacked16Bytes = kLrGateSteps * lr_slot_bytes(true);  // 1 MiB: the fp16 planes behind them, then {2^k, 2^-k, 0, 0}
 constexpr int kLrPackTotalBytes = kLrPackedBytes + kLrPacked16Bytes + 16;
 constexpr int kLrStageBytes = 4 * 8 * 1024;  // one park of two arrays: [wave][array][instruction] x 1 KiB; two parks
-constexpr int lr_lds_bytes(bool f16) { return kLrRing * lr_slot_bytes(f16) + 2 * kLrStageBytes; }
-constexpr int kLrLdsBytes = lr_lds_bytes(false);  // 160 KiB: the whole CU (F16: 128 KiB)
+constexpr int lr_lds_bytes(bool f16) { return kLrRing * lr_slot_bytes(f16) + (f16 ? 3 : 2) * kLrStageBytes; }  // (F16: a third park)
+constexpr int kLrLdsBytes = lr_lds_bytes(false);  // 160 KiB: the whole CU, either way
 constexpr int kLrDma = lr_dma(false);
 constexpr int kLrTop = 6;
 // 16-byte row operations a lane issues in gate-step k of a chunk (k = 2 pos + half): loads in front of the step's
@@ -75,14 +75,21 @@ constexpr int kLrTop = 6;
 // HEADS (the kernel's second form): dL/dh_t of the output heads is not read as a [b][l][256] array but formed from the
 // heads' own gradient, four floats per row-step, and their weights: phase A then brings the chunk's rows of the heads'
 // weights and the rows' four floats (one instruction each) instead of the four of dh_t.
-constexpr int lr_loads_at(int k, bool heads) {  // B of this chunk | C of this chunk | A of the next
+constexpr int lr_loads_at(int k, bool heads, bool f16 = false) {  // B of this chunk | C of this chunk | A of the next
+  // F16 (round 6, three parks: the ring's 16-KiB slots leave room for one more): every phase but the last third of A is
+  // requested most of a chunk ahead of its arithmetic -- C of this chunk in step 0 (its park fell free with the arithmetic
+  // that closed the chunk before), {o, c_t} of the NEXT chunk in step 1, {i, g} of the NEXT chunk in step 2 (the third
+  // park: free since this chunk's dG_i / dG_g left it behind step 1), the heads' rows and the carried dc of the next chunk
+  // in step 6 as before (their park is C's until step 5)
+  if (f16) return k == 0 || k == 1 || k == 2 ? 8 : k == 6 ? 6 : 0;
   return k == 0 || k == 2 ? 8 : k == 6 ? (heads ? 14 : 16) : 0;
 }
 constexpr int kLrStoresAt[8] = {0, 8, 0, 0, 0, 8, 0, 4};   // dG_i, dG_g | dG_f, dc | dG_o of the next chunk
 // operations a wave has issued behind its request for gate-step k's chunk of W_hh^T (made in step k - 3)
-constexpr int lr_behind(int k, bool heads, int dma = kLrDma) {
-  return kLrStoresAt[(k + 5) & 7] + lr_loads_at((k + 6) & 7, heads) + dma + kLrStoresAt[(k + 6) & 7] +
-         lr_loads_at((k + 7) & 7, heads) + dma + kLrStoresAt[(k + 7) & 7];
+constexpr int lr_behind(int k, bool heads, bool f16 = false) {
+  const int dma = lr_dma(f16);
+  return kLrStoresAt[(k + 5) & 7] + lr_loads_at((k + 6) & 7, heads, f16) + dma + kLrStoresAt[(k + 6) & 7] +
+         lr_loads_at((k + 7) & 7, heads, f16) + dma + kLrStoresAt[(k + 7) & 7];
 }
 static_assert(lr_behind(0, false) == 40 && lr_behind(3, false) == 28 && lr_behind(5, false) == 12 && lr_behind(7, false) == 36,
               "see the table in open_step");
@@ -90,10 +97,11 @@ static_assert(lr_behind(0, true) == 38 && lr_behind(1, true) == 24 && lr_behind(
               "see the table in open_step");
 // ... and behind the parked loads of a phase, from the step that makes them to the end of the matrix work of the step that
 // reads them: B 0 -> 1, C 2 -> 5, A 6 -> 7 (vmcnt has six bits: all but the 63 youngest covers anything further back)
-constexpr int lr_behind_loads(int from, int to, bool heads, int dma = kLrDma) {  // from the loads of step `from` to the end of step `to`'s matrix work
+constexpr int lr_behind_loads(int from, int to, bool heads, bool f16 = false) {  // from the loads of step `from` to the end of step `to`'s matrix work
+  const int dma = lr_dma(f16);
   int n = dma;
   for (int k = (from + 1) & 7;; k = (k + 1) & 7) {
-    n += kLrStoresAt[(k + 7) & 7] + lr_loads_at(k, heads) + dma;
+    n += kLrStoresAt[(k + 7) & 7] + lr_loads_at(k, heads, f16) + dma;
     if (k == to) break;
   }
   return n < 63 ? n : 63;
@@ -106,11 +114,14 @@ static_assert(kLrBehindB == 12 && kLrBehindC == 24 && kLrBehindA == 12, "see the
 static_assert(kLrBehindB == lr_behind_loads(0, 1, true) && kLrBehindC == lr_behind_loads(2, 5, true) &&
                   kLrBehindA == lr_behind_loads(6, 7, true),
               "the spans do not contain gate-step 6");
-// F16 (four direct-to-LDS pieces per gate-step instead of six): K 0..7 -> 34 20 28 24 24 8 16 30; B 8, C 16, A 8
-static_assert(lr_behind(0, true, 4) == 34 && lr_behind(1, true, 4) == 20 && lr_behind(2, true, 4) == 28 && lr_behind(5, true, 4) == 8 &&
-                  lr_behind(6, true, 4) == 16 && lr_behind(7, true, 4) == 30,
+// F16 (four direct-to-LDS pieces per gate-step instead of six, the three-park schedule): K 0..7 -> 26 20 36 32 24 8 16 22;
+// the phases' spans: {i, g} from step 2 to step 1 of the next chunk (66 operations: all but the 63 youngest covers it),
+// {f, c_{t-1}} from step 0 to step 5 (48), the last part of A from step 6 to step 7 (8)
+static_assert(lr_behind(0, true, true) == 26 && lr_behind(1, true, true) == 20 && lr_behind(2, true, true) == 36 &&
+                  lr_behind(3, true, true) == 32 && lr_behind(4, true, true) == 24 && lr_behind(5, true, true) == 8 &&
+                  lr_behind(6, true, true) == 16 && lr_behind(7, true, true) == 22,
               "see the table in open_step");
-static_assert(lr_behind_loads(0, 1, true, 4) == 8 && lr_behind_loads(2, 5, true, 4) == 16 && lr_behind_loads(6, 7, true, 4) == 8,
+static_assert(lr_behind_loads(2, 1, true, true) == 63 && lr_behind_loads(0, 5, true, true) == 48 && lr_behind_loads(6, 7, true, true) == 8,
               "see the table in open_step");
 constexpr int kLrHeads = 4;  // outputs of the heads the HEADS form takes (their gradient padded to four floats per row-step)
 #ifndef RL8_LR_DIAG
@@ -285,12 +296,17 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   for (int j = 0; j < 4; ++j)
     park_at[j] = lds0 + kLrRing * kSlot + wave * (8 * 1024) + n * 128 + (((2 * j + hh) ^ ((n >> 1) & 7)) * 16);
   const unsigned park_line = lds0 + kLrRing * kSlot + wave * (8 * 1024) + lane * 16;  // the instruction view
+  // (a DS instruction's offset field has sixteen bits: the third park, 64 KiB up, gets address registers of its own)
+  [[maybe_unused]] unsigned park2_at[4], park2_line = park_line + 2 * kLrStageBytes;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) park2_at[j] = park_at[j] + 2 * kLrStageBytes;
   const int pitch_gates = l * (4 * kHidden * 4), pitch_seq = l * (kHidden * 4), pitch_state = kHidden * 4;
   // (each in parts, so that a gate-step can spread them between its MFMA groups: a direct-to-LDS load costs the wave
   // ~75 cycles at issue, and issued in one run at the head of a step those were 19 % of its time with the pipe idle)
+  constexpr int kParkB = F16 ? 2 : 0;  // (F16: {i, g} and their dG live in the third park)
   auto issue_b = [&](const LrLoadDesc &d, int c, int part = -1) {
-    if (part != 1) park4(0, 0, d.gates, pitch_gates, c * 128);
-    if (part != 0) park4(0, 1, d.gates, pitch_gates, c * 128 + 2 * (kHidden * 4));
+    if (part != 1) park4(kParkB, 0, d.gates, pitch_gates, c * 128);
+    if (part != 0) park4(kParkB, 1, d.gates, pitch_gates, c * 128 + 2 * (kHidden * 4));
   };
   auto issue_c = [&](const LrLoadDesc &d, int c, int part = -1) {
     if (part != 1) park4(1, 0, d.gates, pitch_gates, c * 128 + 1 * (kHidden * 4));
@@ -320,9 +336,10 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   };
   // array AR of park PARK into this lane's registers (its sixteen units); the wait for the loads is the caller's
   auto unpark = [&](auto park_tag, auto ar_tag, u32x4 (&x)[4]) {
-    constexpr int OFF = decltype(park_tag)::value * kLrStageBytes + decltype(ar_tag)::value * 4096;
+    constexpr bool THIRD = decltype(park_tag)::value == 2;
+    constexpr int OFF = (THIRD ? 0 : decltype(park_tag)::value * kLrStageBytes) + decltype(ar_tag)::value * 4096;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = lds_read_b128<OFF>(park_at[j]);
+    for (int j = 0; j < 4; ++j) x[j] = lds_read_b128<OFF>(THIRD ? park2_at[j] : park_at[j]);
   };
   auto loads_landed = [&](auto n_tag, int stamp) {  // N = operations the wave has issued behind the phase's loads
     constexpr int N = RL8_LR_SAFE_WAITS ? 0 : decltype(n_tag)::value;
@@ -333,17 +350,20 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   };
   // sixteen values per lane -> array AR of park PARK (lane = sequence view), then out of it eight lanes per row
   auto repark = [&](auto park_tag, auto ar_tag, const float (&v)[16]) {
-    constexpr int OFF = decltype(park_tag)::value * kLrStageBytes + decltype(ar_tag)::value * 4096;
+    constexpr bool THIRD = decltype(park_tag)::value == 2;
+    constexpr int OFF = (THIRD ? 0 : decltype(park_tag)::value * kLrStageBytes) + decltype(ar_tag)::value * 4096;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      lds_write_b128<OFF>(park_at[j], u32x4{__float_as_uint(v[4 * j]), __float_as_uint(v[4 * j + 1]), __float_as_uint(v[4 * j + 2]),
+      lds_write_b128<OFF>(THIRD ? park2_at[j] : park_at[j], u32x4{__float_as_uint(v[4 * j]), __float_as_uint(v[4 * j + 1]), __float_as_uint(v[4 * j + 2]),
                                             __float_as_uint(v[4 * j + 3])});
   };
   auto store_park = [&](auto park_tag, auto ar_tag, const __amdgpu_buffer_rsrc_t &r, int pitch_bytes, int soff) {
-    constexpr int OFF = decltype(park_tag)::value * kLrStageBytes + decltype(ar_tag)::value * 4096;
+    constexpr bool THIRD = decltype(park_tag)::value == 2;
+    constexpr int OFF = (THIRD ? 0 : decltype(park_tag)::value * kLrStageBytes) + decltype(ar_tag)::value * 4096;
+    const unsigned line = THIRD ? park2_line : park_line;
     u32x4 v[4];
-    v[0] = lds_read_b128<OFF>(park_line), v[1] = lds_read_b128<OFF + 1024>(park_line);
-    v[2] = lds_read_b128<OFF + 2048>(park_line), v[3] = lds_read_b128<OFF + 3072>(park_line);
+    v[0] = lds_read_b128<OFF>(line), v[1] = lds_read_b128<OFF + 1024>(line);
+    v[2] = lds_read_b128<OFF + 2048>(line), v[3] = lds_read_b128<OFF + 3072>(line);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
     const int v_row = (lane >> 3) * pitch_bytes;
 #pragma unroll
@@ -374,7 +394,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
 
   auto math_a = [&](const LrStoreDesc &sd, int c) {  // -> dg[0] (o), dcv
     u32x4 la_o[4], la_ct[4], la_dh[4], la_dc[4];
-    loads_landed(std::integral_constant<int, lr_behind_loads(6, 7, HEADS, kDma)>{}, 8);
+    loads_landed(std::integral_constant<int, lr_behind_loads(6, 7, HEADS, F16)>{}, 8);
     if constexpr (HEADS) {
       // dL/dh_t of the heads for this lane's sixteen units: sum_q dOut[n][q] W[q][unit], the weights broadcast from the
       // park (two addresses per instruction: the lane halves), head by head
@@ -438,9 +458,10 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   };
   auto math_b = [&](const LrStoreDesc &sd, int c) {  // -> dg[1] (i), dg[2] (g)
     u32x4 lb_i[4], lb_g[4];
-    loads_landed(std::integral_constant<int, lr_behind_loads(0, 1, HEADS, kDma)>{}, 8);
-    unpark(Z0{}, Z0{}, lb_i);
-    unpark(Z0{}, Z1{}, lb_g);
+    loads_landed(std::integral_constant<int, F16 ? lr_behind_loads(2, 1, HEADS, true) : lr_behind_loads(0, 1, HEADS, false)>{}, 8);
+    using ZB = std::integral_constant<int, kParkB>;
+    unpark(ZB{}, Z0{}, lb_i);
+    unpark(ZB{}, Z1{}, lb_g);
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(lb_i[0]), "+v"(lb_i[1]), "+v"(lb_i[2]), "+v"(lb_i[3]), "+v"(lb_g[0]), "+v"(lb_g[1]), "+v"(lb_g[2]), "+v"(lb_g[3]));
     float lmax = 0.0f;
@@ -452,14 +473,14 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
       lmax = __builtin_fmaxf(lmax, __builtin_fmaxf(__builtin_fabsf(dg[1][e]), __builtin_fabsf(dg[2][e])));
     }
     fold_max(lmax);
-    repark(Z0{}, Z0{}, dg[1]);
-    repark(Z0{}, Z1{}, dg[2]);
-    store_park(Z0{}, Z0{}, sd.dgates, pitch_gates, c * 128);
-    store_park(Z0{}, Z1{}, sd.dgates, pitch_gates, c * 128 + 2 * (kHidden * 4));
+    repark(ZB{}, Z0{}, dg[1]);
+    repark(ZB{}, Z1{}, dg[2]);
+    store_park(ZB{}, Z0{}, sd.dgates, pitch_gates, c * 128);
+    store_park(ZB{}, Z1{}, sd.dgates, pitch_gates, c * 128 + 2 * (kHidden * 4));
   };
   auto math_c = [&](const LrStoreDesc &sd, int c) {  // -> dg[3] (f), dc out
     u32x4 lc_f[4], lc_cp[4];
-    loads_landed(std::integral_constant<int, lr_behind_loads(2, 5, HEADS, kDma)>{}, 9);
+    loads_landed(std::integral_constant<int, F16 ? lr_behind_loads(0, 5, HEADS, true) : lr_behind_loads(2, 5, HEADS, false)>{}, 9);
     unpark(Z1{}, Z0{}, lc_f);
     unpark(Z1{}, Z1{}, lc_cp);
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -592,7 +613,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   //   N       40  24  32  28  28  12  20  36
   auto open_step = [&](auto k_tag) {
     constexpr int K = decltype(k_tag)::value;
-    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : lr_behind(K, HEADS, kDma);
+    constexpr int N = RL8_LR_SAFE_WAITS ? 0 : lr_behind(K, HEADS, F16);
 #ifdef RL8_LR_STAMP
     {
       RL8_LR_T0;
@@ -627,6 +648,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
   for (int e = 0; e < 16; ++e) dhe[e] = f32x8v{0, 0, 0, 0, 0, 0, 0, 0};
   LrLoadDesc nd = load_desc(tile, t);  // where the loads of the current step come from
   issue_a(nd, 0);
+  if constexpr (F16) issue_b(nd, 0);  // (the three-park schedule requests {i, g} a chunk ahead: the first chunk's here)
   request(0, 0, 0);
   request(0, 1, 1);
   request(0, 2, 2);
@@ -653,6 +675,55 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
           if (2 * mp < kDma) request(cc, k, slot, 2 * mp, 2 * mp + 2);
         };
       };
+      if constexpr (F16) {
+        // The three-park schedule (lr_loads_at): [row loads | request | matrix work | stores] within a gate-step, as the
+        // wait tables assume; a descriptor of the NEXT chunk is `ad` (the next step's, or tile's, at the wrap).
+        auto loads_then_request = [&](auto &&first, auto &&second, int cc, int k, int slot) {
+          return [&, cc, k, slot](int mp) {
+            if (mp == 0) first();
+            else if (mp == 1) second();
+            else if (mp == 2) request(cc, k, slot, 0, kDma / 2);
+            else request(cc, k, slot, kDma / 2, kDma);
+          };
+        };
+        open_step(K0{});
+        if (c == 0) {
+#pragma unroll
+          for (int mo = 0; mo < 8; ++mo) acc[mo] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        matrix_step(K0{}, loads_then_request([&]() { issue_c(nd, c, 0); }, [&]() { issue_c(nd, c, 1); }, c, 3, 3));
+        open_step(K1{});
+        matrix_step(K1{}, loads_then_request([&]() { park4(0, 0, ad.gates, pitch_gates, cn * 128 + 3 * (kHidden * 4)); },
+                                             [&]() { park4(0, 1, ad.cs, pitch_seq, cn * 128); }, c, 4, 0));
+        { RL8_LR_T0; math_b(sd, c); RL8_LR_T1(14); }
+        open_step(K2{});
+        matrix_step(K2{}, loads_then_request([&]() { issue_b(ad, cn, 0); }, [&]() { issue_b(ad, cn, 1); }, c, 5, 1));
+        open_step(K3{});
+        matrix_step(K3{}, only_request(c, 6, 2));
+        open_step(K4{});
+        matrix_step(K4{}, only_request(c, 7, 3));
+        open_step(K5{});
+        matrix_step(K5{}, only_request(cn, 0, 0));
+        { RL8_LR_T0; math_c(sd, c); RL8_LR_T1(14); }
+        open_step(K6{});
+        matrix_step(K6{}, [&](int mp) {  // the last third of A: the heads' rows and dOut (two loads), the carried dc (four)
+          if (mp == 0) {
+            const int far = 0x7fffff00;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(hwrsrc, smem + park_lds(1, 0, 0), 16,
+                                                     lane < 32 ? (lane >> 3) * (kHidden * 4) + (lane & 7) * 16 : far, cn * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.dhs, smem + park_lds(1, 0, 1), 16, lane < 32 ? lane * (l * kLrHeads * 4) : far,
+                                                     0, 0, 0);
+          } else if (mp == 1) {
+            park4(1, 1, ad.dcin, pitch_state, cn * 128);
+            asm volatile("" ::: "memory");
+            request(cn, 1, 1, 0, 2);
+          } else if (mp == 2) {
+            request(cn, 1, 1, 2, kDma);
+          }
+        });
+        open_step(K7{});
+        matrix_step(K7{}, only_request(cn, 2, 2));
+      } else {
       open_step(K0{});
       if (c == 0) {
 #pragma unroll
@@ -693,6 +764,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
       });
       open_step(K7{});
       matrix_step(K7{}, only_request(cn, 2, 2));
+      }  // (the schedules)
       if (wrap) {
         // the step's dh is complete: it becomes the carry of the step the next arithmetic belongs to (zero for a new tile)
         if constexpr (F16) {

@@ -389,7 +389,7 @@ def test_compiled_lstm_rows_backward_kernel_resources(tmp_path):
     forms = {
         "lstm_rows_backward_kernel": (["B40", "B24", "B32", "B28", "B28", "B12", "B20", "B36"], 22, 6),
         "lstm_rows_backward_heads_kernel": (["B38", "B24", "B32", "B28", "B28", "B12", "B20", "B34"], 20, 6),
-        "lstm_rows_backward_heads16_kernel": (["B34", "B20", "B28", "B24", "B24", "B8", "B16", "B30"], 18, 4),
+        "lstm_rows_backward_heads16_kernel": (["B26", "B20", "B36", "B32", "B24", "B8", "B16", "B22"], 10, 4),
     }
     bodies = dict(re.findall(r"\.amdhsa_kernel (\S*lstm_rows_backward\w*_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S))
     assert len(bodies) == 3
@@ -411,5 +411,8 @@ def test_compiled_lstm_rows_backward_kernel_resources(tmp_path):
         # [row loads, direct-to-LDS loads (parked row loads + 6 of W_hh^T), stores] per gate-step; the four stores of the
         # next chunk's dG_o follow step 7 on the loop's back edge
         # (every row load is parked: direct-to-LDS, eight per two-array phase, sixteen / fourteen for phase A)
-        assert counts[:7] == [(0, 8 + dma, 0), (0, dma, 8), (0, 8 + dma, 0), (0, dma, 0), (0, dma, 0), (0, dma, 8), (0, step6, 0)], (form, counts)
+        # (the fp16 form's three-park schedule requests {f, c_prev} in step 0, the next chunk's {o, c_t} in step 1 and its
+        # {i, g} in step 2 -- eight parked loads each -- and the rest of phase A, six loads, in step 6)
+        step1 = (0, 8 + dma, 8) if dma == 4 else (0, dma, 8)
+        assert counts[:7] == [(0, 8 + dma, 0), step1, (0, 8 + dma, 0), (0, dma, 0), (0, dma, 0), (0, dma, 8), (0, step6, 0)], (form, counts)
         assert counts[7][:2] == (0, dma), (form, counts)
