@@ -683,8 +683,10 @@ def measure(args: argparse.Namespace, world: int, backend: None | str) -> dict:
         "lstm_step": (2.0 * 256 * 1024, "f16x2-split"), "lstm_step_save": (2.0 * 256 * 1024, "f16x2-split"),
         "lstm_forward": (2.0 * 264 * 1024, "f32"), "lstm_forward_save": (2.0 * 264 * 1024, "f32"),
         "lstm_backward": (2.0 * 1024 * 256, "f32"),
-        # backward through time on bf16 planes (six products): the recurrent product dG x W_hh of a row-step
-        "lstm_rows_backward": (2.0 * 1024 * 256, "bf16x3-split"),
+        # backward through time: the recurrent product dG x W_hh of a row-step on two fp16 planes scaled per sequence
+        # (three products; round 6, the heads form the default models run) or on three exact bf16 planes (six)
+        "lstm_rows_backward": (2.0 * 1024 * 256,
+                               "bf16x3-split" if os.environ.get("RL8_AMD_LSTM_BACKWARD_PLANES", "f16").startswith("b") else "f16x2-split"),
         # weight gradient: fp16 planes (three products) behind the rows kernel's bound on |dG|, bf16 planes (six) else
         "lstm_wgrad": (2.0 * 1024 * 256,
                        "f32" if os.environ.get("RL8_AMD_LSTM_GEMM", "split") != "split" else
