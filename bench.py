@@ -119,9 +119,9 @@ ALGORITHMIC_BYTES = {
 FABRIC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_cfg5_fabric_traffic.txt") for r in (6, 5, 4, 3))
                        if os.path.exists(p)), "")
 FABRIC_KERNEL = {  # bench name -> (substring of the profiled kernel's name, units of that launch)
-    "lstm_rows_backward": ("lstm_rows_backward_heads_kernel", 1 << 21),
+    "lstm_rows_backward": ("lstm_rows_backward_heads", 1 << 21),   # (heads16_kernel since round 6, heads_kernel before)
     "lstm_step_save": ("lstm_step_split_kernel<1, true>", 1 << 19),
-    "lstm_wgrad": ("mlp_wgrad_split_kernel<1, 0, true, true>", 1 << 19),
+    "lstm_wgrad": ("mlp_wgrad_loadh16_kernel<1>", 1 << 19),        # (four gates per launch; mlp_wgrad_split_kernel<1, 0, true, true> in r03)
     "linear_heads_forward": ("linear_heads_forward_kernel<3>", 1 << 21),
     "linear_heads_backward": ("linear_heads_backward_kernel<3>", 1 << 21),
 }
