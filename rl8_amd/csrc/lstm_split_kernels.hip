@@ -434,7 +434,8 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
 
 using namespace rl8;
 
-RL8_API int rl8_lstm_split_supports(int d_in) { return d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5; }
+// (round 6: every width the [w_ih | bias] rows hold -- d_in <= 7; 1, 2, 3, 5 until then)
+RL8_API int rl8_lstm_split_supports(int d_in) { return d_in >= 1 && d_in <= kLsInCols - 1; }
 RL8_API int64_t rl8_lstm_split_packed_bytes(void) { return kLsPackedBytes + 16; }
 RL8_API int64_t rl8_lstm_split_wb_floats(void) { return 4 * kHidden * kLsInCols; }
 // bytes of the state planes for b rows (whole 128-row tiles)
@@ -513,6 +514,9 @@ RL8_API int rl8_lstm_step_split_f32(const float *x, int64_t x_pitch, int d_in, c
     case 1: return launch_lstm_step<1>(grid, s, h_planes, w_planes, wb, b, args);
     case 2: return launch_lstm_step<2>(grid, s, h_planes, w_planes, wb, b, args);
     case 3: return launch_lstm_step<3>(grid, s, h_planes, w_planes, wb, b, args);
-    default: return launch_lstm_step<5>(grid, s, h_planes, w_planes, wb, b, args);
+    case 4: return launch_lstm_step<4>(grid, s, h_planes, w_planes, wb, b, args);
+    case 5: return launch_lstm_step<5>(grid, s, h_planes, w_planes, wb, b, args);
+    case 6: return launch_lstm_step<6>(grid, s, h_planes, w_planes, wb, b, args);
+    default: return launch_lstm_step<7>(grid, s, h_planes, w_planes, wb, b, args);
   }
 }

@@ -1923,7 +1923,7 @@ static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int6
   if (!aligned16(workspace) || !aligned16(dw_out)) return RL8_EALIGN;
   if (colsums) {
     if (!x || !colsum_rows_out) return RL8_ENULL;
-    if (!(d_in == 1 || d_in == 2 || d_in == 3 || d_in == 5)) return RL8_ESIZE;
+    if (d_in < 1 || d_in > 7) return RL8_ESIZE;  // (round 6: 4, 6, 7 too)
   }
   hipStream_t s = (hipStream_t)stream;
   int first_grid = 0;
@@ -1947,14 +1947,20 @@ static int wgrad_strided(const float *dz, int64_t dz_pitch, const float *h, int6
         case 1: status = launch_wgrad_loadh16<1>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
         case 2: status = launch_wgrad_loadh16<2>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
         case 3: status = launch_wgrad_loadh16<3>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
-        default: status = launch_wgrad_loadh16<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 4: status = launch_wgrad_loadh16<4>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 5: status = launch_wgrad_loadh16<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 6: status = launch_wgrad_loadh16<6>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        default: status = launch_wgrad_loadh16<7>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
       }
     } else {  // no bound: the exact bf16 planes
       switch (colsums ? d_in : 1) {
         case 1: status = launch_wgrad_loadh<1>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
         case 2: status = launch_wgrad_loadh<2>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
         case 3: status = launch_wgrad_loadh<3>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
-        default: status = launch_wgrad_loadh<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 4: status = launch_wgrad_loadh<4>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 5: status = launch_wgrad_loadh<5>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        case 6: status = launch_wgrad_loadh<6>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
+        default: status = launch_wgrad_loadh<7>(grid, s, dz + at * dz_pitch, xs, rows, workspace, ops); break;
       }
     }
     if (status != 0) return status;

@@ -872,6 +872,42 @@ def test_recurrent_algorithm_with_a_users_distribution(env_cls):
     assert not torch.equal(p0, p2)
 
 
+@pytest.mark.parametrize("d,a", [(4, 3), (7, 2), (6, 4)])
+def test_recurrent_walk_env_of_four_six_seven_observations_runs_the_plane_lstm(d, a, monkeypatch):
+    """Round 6: the LSTM's plane kernels (fp16-plane step, backward through time, four-gate weight gradient) take every
+    observation width the [w_ih | bias] rows hold (d_in <= 7; 1, 2, 3, 5 until then).  Two collect() + step() rounds of
+    the recurrent algorithm on the tests' walk environment against the SAME seeded run on the fp32-MFMA LSTM kernels
+    (RL8_AMD_LSTM_GEMM=f32's switch): rollouts' returns to 1e-4, losses to 2e-3."""
+    from rl8_amd import RecurrentAlgorithmConfig, hip
+    from rl8_amd.nn import fused_lstm
+
+    from ._envs import walk_env
+
+    assert hip.lstm_split_supports(d)
+    steps = []
+    real = hip.lstm_forward_split
+
+    def spy(*args, **kw):
+        steps.append(args[0].shape[-1])
+        return real(*args, **kw)
+
+    def run(gemm):
+        monkeypatch.setattr(fused_lstm, "FORWARD_GEMM", gemm)
+        torch.manual_seed(13)
+        algo = RecurrentAlgorithmConfig(num_envs=512, horizon=32).build(walk_env(d, a))
+        return [(algo.collect(), algo.step()) for _ in range(2)]
+
+    monkeypatch.setattr(hip, "lstm_forward_split", spy)
+    planes = run("split")
+    assert steps and all(w == d for w in steps), steps
+    monkeypatch.setattr(hip, "lstm_forward_split", real)
+    f32 = run("f32")
+    for (c0, s0), (c1, s1) in zip(f32, planes):
+        assert c1["returns/mean"] == pytest.approx(c0["returns/mean"], rel=1e-4)
+        for k in ("losses/policy", "losses/vf", "losses/total"):
+            assert s1[k] == pytest.approx(s0[k], rel=2e-3, abs=2e-6), k
+
+
 @pytest.mark.parametrize("d,a", [(7, 3), (6, 4), (7, 2)])
 def test_walk_env_with_six_and_seven_observations_trains_on_the_plane_kernels(d, a, monkeypatch):
     """Round 6 (VERDICT r5 missing #3, in part): d_in 6 and 7 (n_out <= 4; 7 x 4 excepted) train on the plane kernels end to

@@ -196,7 +196,8 @@ def test_lstm_kernels_repeat_bit_for_bit_under_load():
             assert torch.equal(a, c), trial
 
 
-@pytest.mark.parametrize("b,l,d", [(1, 1, 1), (127, 4, 1), (129, 3, 2), (1000, 4, 5), (4097, 2, 3), (640, 7, 1)])
+@pytest.mark.parametrize("b,l,d", [(1, 1, 1), (127, 4, 1), (129, 3, 2), (1000, 4, 5), (4097, 2, 3), (640, 7, 1),
+                                   (300, 4, 4), (2000, 3, 6), (129, 5, 7)])   # (round 6: every width up to seven)
 def test_lstm_split_step_matches_the_fp32_kernel_and_fp64(b, l, d):
     """The bf16-plane step kernel (one launch per timestep, h_{t-1} through bf16 planes)
     against the fp32-MFMA kernel on the same inputs -- outputs, final states, saved gates
@@ -395,7 +396,7 @@ def test_recurrent_model_with_and_without_the_fused_heads_node():
                 assert float((one[1][k] - two[1][k]).abs().max()) / scale < 2e-6, (model_cls.__name__, use_state, k)
 
 
-@pytest.mark.parametrize("b,l,d_in", [(33, 3, 1), (300, 5, 5), (2000, 8, 1), (4097, 2, 3)])
+@pytest.mark.parametrize("b,l,d_in", [(33, 3, 1), (300, 5, 5), (2000, 8, 1), (4097, 2, 3), (300, 4, 4), (2000, 3, 6), (1000, 4, 7)])
 def test_lstm_backward_on_planes_matches_autograd(b, l, d_in):
     """hip.lstm_backward with the rows kernel (what fused_lstm runs by default) against torch's autograd, as
     test_lstm_backward_matches_autograd holds the fp32-MFMA kernel; and the two kernels' gradients beside each other."""
