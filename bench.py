@@ -693,6 +693,9 @@ def measure(args: argparse.Namespace, world: int, backend: None | str) -> dict:
                        "f16x2-split" if (os.environ.get("RL8_AMD_LSTM_BACKWARD_ROWS", "1") != "0"
                                          and os.environ.get("RL8_AMD_LSTM_WGRAD_PLANES", "f16") != "bf16") else "bf16x3-split"),
     }
+    # ... and what the same kernels move per row-step: since the backward through time went to fp16
+    # planes (round 6) it is the HBM roofline that binds it, not the matrix pipe
+    lstm_bytes = {"lstm_rows_backward": 12.0 * 1024, "lstm_step_save": 9.0 * 1024, "lstm_step": 5.0 * 1024, "lstm_wgrad": 5.0 * 1024}
     for name, rec in hip.timer.summary().items():
         if name in lstm_gemm:
             per_row, gemm = lstm_gemm[name]
@@ -704,6 +707,11 @@ def measure(args: argparse.Namespace, world: int, backend: None | str) -> dict:
                 "achieved_TFLOPs": round(tflops, 2), "frac_of_f32_mfma_peak": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
                 "pmc_traffic_bytes_per_launch": fabric_traffic(name, rec["units_per_launch"]),
             }
+            if name in lstm_bytes:
+                moved = lstm_bytes[name] * rec["units_per_launch"]
+                gbs = moved / (rec["avg_ms"] * 1e-3) / 1e9 if rec["avg_ms"] > 0 else 0.0
+                kernels[name].update({"algorithmic_bytes_per_launch": moved, "achieved_GBps": round(gbs, 1),
+                                      "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4)})
             if gemm != "f32":
                 executed = PLANE_PRODUCTS[gemm] * flops_per_launch
                 kernels[name].update({
@@ -779,7 +787,26 @@ def roofline_of(kernels: dict, steps: int) -> tuple[None | dict, str, str]:
     hbm_dominant = "ppo_loss_categorical" if "ppo_loss_categorical" in kernels else "ppo_loss_normal"
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
     top = kernels[dominant]
-    if top["bound"] == "mfma" and top["gemm"] != "f32":
+    if top["bound"] == "mfma" and top.get("frac_of_8TBps", 0.0) > top.get("frac_of_bf16_mfma_peak", 1.0):
+        # a plane kernel that sits closer to the HBM roofline than to the matrix pipe's (the LSTM's backward through time
+        # on fp16 planes: 12 KiB per row-step at 4.5+ TB/s against 0.24 executed of the 16-bit MFMA peak)
+        roofline = {
+            "kernel": {"lstm_rows_backward": "rl8_lstm_rows_backward_heads_f32 (backward through time of the recurrent models' LSTM)",
+                       "lstm_wgrad": "rl8_lstm_wgrad_f16_f32", "lstm_step_save": "rl8_lstm_step_split_f32"}.get(dominant, f"rl8_{dominant}_f32"),
+            "bound": "hbm",
+            "achieved": top["achieved_GBps"],
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": top["frac_of_8TBps"],
+            "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
+            "executed_frac": top.get("frac_of_bf16_mfma_peak"),   # (of the 16-bit MFMA peak, for comparison)
+            "plane_products": top.get("plane_products"),
+            "avg_launch_ms": top["avg_ms"],
+            "launches": top["launches"],
+            "share_of_step_ms": round(top["total_ms"] / steps, 2),
+            "traffic": top["pmc_traffic_bytes_per_launch"],
+        }
+    elif top["bound"] == "mfma" and top["gemm"] != "f32":
         # bf16-plane kernel: priced in the bf16 multiply-adds the matrix pipe executes
         # (6 per fp32 multiply-add of the algorithm) against the dense bf16 peak
         roofline = {
