@@ -128,6 +128,9 @@ constexpr int kLrHeads = 4;  // outputs of the heads the HEADS form takes (their
 #define RL8_LR_DIAG 0  // tuning builds (tools/diag_mlp.sh lr<bits>): 1 no stores reach memory, 2 no row loads do, 4 one plane
 #endif                 // product of six, 8 no W_hh^T traffic (wrong results, same instruction stream)
 constexpr int kLrDiag = RL8_LR_DIAG;
+#ifndef RL8_LR_STORE_AUX
+#define RL8_LR_STORE_AUX 0                   // cache policy of the kernel's stores (tuning builds: 18 = sc1 | nt, streaming)
+#endif
 #ifndef RL8_LR_SAFE_WAITS
 #define RL8_LR_SAFE_WAITS 0                  // tuning builds: 1 = every barrier behind vmcnt(0)
 #endif
@@ -369,7 +372,7 @@ __device__ __forceinline__ void lstm_rows_backward_body(const LrArgs &a, const v
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       __builtin_amdgcn_raw_buffer_store_b128(v[k], r, v_row + ((k & 1) ? (park_piece ^ 4) : park_piece) * 16,
-                                             soff + 8 * k * pitch_bytes, 0);
+                                             soff + 8 * k * pitch_bytes, RL8_LR_STORE_AUX);
   };
   using Z0 = std::integral_constant<int, 0>;
   using Z1 = std::integral_constant<int, 1>;

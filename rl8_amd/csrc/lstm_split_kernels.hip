@@ -390,10 +390,11 @@ __global__ __launch_bounds__(kBlock, 2) void lstm_step_split_kernel(
           buffer_store_f32(h, hrsrc, v_h, srow * hp4);
           buffer_store_f32(c, cors, v_co, srow * co4);
           if constexpr (SAVE) {
-            buffer_store_f32(gi, grsrc, v_g, srow * gp4);
-            buffer_store_f32(gf, grsrc, v_g + kHidden * 4, srow * gp4);
-            buffer_store_f32(gg, grsrc, v_g + 2 * kHidden * 4, srow * gp4);
-            buffer_store_f32(go, grsrc, v_g + 3 * kHidden * 4, srow * gp4);
+            // (the saved gates are read once, by the backward pass, gigabytes later: streaming stores -- sc1 | nt; 0.5-1 %)
+            buffer_store_f32_streaming(gi, grsrc, v_g, srow * gp4);
+            buffer_store_f32_streaming(gf, grsrc, v_g + kHidden * 4, srow * gp4);
+            buffer_store_f32_streaming(gg, grsrc, v_g + 2 * kHidden * 4, srow * gp4);
+            buffer_store_f32_streaming(go, grsrc, v_g + 3 * kHidden * 4, srow * gp4);
           }
         }
       }
