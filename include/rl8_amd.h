@@ -68,8 +68,11 @@ extern "C" {
  * mismatch).  History: 100 rounds 1-2; 103 round 3 (bf16-plane forward / data-gradient entries removed, reduction
  * scratch doubled with two-level tickets -- bump owed since then); 104 round 4 (weight-gradient
  * workspace: guard words and lifetime counters behind the slabs; caller-owned outputs of the forward unchanged);
- * 105 round 4 (rl8_gather_minibatch takes index = NULL: all samples in order). */
-#define RL8_ABI_VERSION 105
+ * 105 round 4 (rl8_gather_minibatch takes index = NULL: all samples in order); 106 round 6 (no signature changed:
+ * rl8_lstm_rows_backward_pack writes the fp16 planes of W_hh^T behind the bf16 ones -- rl8_lstm_rows_backward_pack_bytes
+ * grew by 1 MiB + 16, and rl8_lstm_rows_backward_heads_f32 reads them; rl8_mlp_backward_f16_supports and
+ * rl8_lstm_split_supports report wider envelopes; the weight-gradient workspace's tail words moved). */
+#define RL8_ABI_VERSION 106
 int rl8_abi_version(char *arch, int arch_len);
 
 /* Scratch the reductions need (bytes); the caller allocates it once per stream

@@ -177,7 +177,7 @@ SIGNATURES: dict[str, list[Any]] = {
 
 
 #: RL8_ABI_VERSION of include/rl8_amd.h this binding is written against (checked against the library in ``load``).
-ABI_VERSION = 105
+ABI_VERSION = 106
 
 
 def library_path() -> str:

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"librl8_amd.so lacks {name}"
     assert sorted(hip.SIGNATURES) == names, "rl8_amd/hip.py bindings out of sync with include/rl8_amd.h"
-    assert hip.abi_version() == (hip.ABI_VERSION, "gfx950") and hip.ABI_VERSION == 105
+    assert hip.abi_version() == (hip.ABI_VERSION, "gfx950") and hip.ABI_VERSION == 106
     assert lib.rl8_scratch_bytes() >= 2048 * 16 * 8
 
 
