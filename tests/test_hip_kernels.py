@@ -35,7 +35,7 @@ def host(t):
 
 def test_abi_loads_on_device():
     version, arch = hip.abi_version()
-    assert version == hip.ABI_VERSION == 105 and arch == "gfx950"
+    assert version == hip.ABI_VERSION == 106 and arch == "gfx950"
     assert torch.cuda.get_device_properties(0).gcnArchName.startswith("gfx950")
 
 
