@@ -8,7 +8,8 @@
 // and the pre-activation gate gradients dG [b][l][4][256] stored for the weight-gradient kernels -- with the recurrent
 // product as an fp32-accurate product of bf16 planes (three per operand, six plane products: split_tile.hip.h; bf16
 // because dG has fp32's range and no bound that is known before it is computed) instead of fp32 MFMAs on 32-row tiles
-// (11.65 ms per 2^21 row-steps, 60 % of the fp32 matrix peak, W_hh^T re-read from L2 per 32 rows).
+// (11.65 ms per 2^21 row-steps, 60 % of the fp32 matrix peak, W_hh^T re-read from L2 per 32 rows).  Round 6: the HEADS
+// form -- where such a bound DOES exist, per sequence and step -- on two fp16 planes, three products (see lr_slot_bytes).
 //
 // Shape: rows per wave, as mlp_rows_kernels.hip.  A wave owns 32 sequences for all l steps; a workgroup is four waves
 // (128 sequences), one per SIMD, one workgroup per CU.  The product is taken TRANSPOSED, dh_{t-1}^T = W_hh^T x dG^T:
